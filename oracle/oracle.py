@@ -1,0 +1,383 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (troy-nova_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtroy_oracle.so")
+
+u64 = C.c_uint64
+sz = C.c_size_t
+p64 = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class Modulus(C.Structure):
+    _fields_ = [("value", u64), ("const_ratio", u64 * 3), ("bit_count", u64),
+                ("is_prime", C.c_int32), ("pad_", C.c_int32)]
+
+
+class MulOp(C.Structure):
+    _fields_ = [("operand", u64), ("quotient", u64)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "troy_oracle.c")
+    hdr = os.path.join(_HERE, "troy_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    MP = C.POINTER(Modulus)
+    OP = C.POINTER(MulOp)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("orc_modulus_init", C.c_int, MP, u64)
+    sig("orc_barrett_reduce64", u64, u64, MP)
+    sig("orc_barrett_reduce128", u64, u64, u64, MP)
+    sig("orc_multiply_mod", u64, u64, u64, MP)
+    sig("orc_add_mod", u64, u64, u64, MP)
+    sig("orc_sub_mod", u64, u64, u64, MP)
+    sig("orc_negate_mod", u64, u64, MP)
+    sig("orc_mulop_init", None, OP, u64, MP)
+    sig("orc_mulop_mod", u64, u64, OP, MP)
+    sig("orc_mulop_mod_lazy", u64, u64, OP, MP)
+    sig("orc_exponentiate_mod", u64, u64, u64, MP)
+    sig("orc_try_invert_mod", C.c_int, u64, MP, p64)
+    sig("orc_dot_product_mod", u64, p64, p64, sz, MP)
+    sig("orc_is_prime", C.c_int, u64)
+    sig("orc_get_primes", C.c_int, u64, sz, sz, p64)
+    sig("orc_coeff_modulus_create", C.c_int, sz, C.POINTER(sz), sz, p64)
+    sig("orc_try_minimal_primitive_root", C.c_int, u64, MP, p64)
+    sig("orc_ntt_tables_create", vp, sz, u64)
+    sig("orc_ntt_tables_destroy", None, vp)
+    sig("orc_ntt_tables_root", u64, vp)
+    sig("orc_ntt_tables_root_power", u64, vp, sz, C.c_int, C.c_int)
+    sig("orc_ntt_tables_inv_degree", u64, vp, C.c_int)
+    sig("orc_ntt_forward", None, p64, sz, sz, sz, C.POINTER(vp), sz, C.c_int, sz)
+    sig("orc_ntt_inverse", None, p64, sz, sz, sz, C.POINTER(vp), sz, C.c_int, sz)
+    for nm in ("orc_add_ps", "orc_sub_ps", "orc_dyadic_product_ps"):
+        sig(nm, None, p64, p64, sz, sz, MP, sz, p64)
+    for nm in ("orc_negate_ps", "orc_modulo_ps"):
+        sig(nm, None, p64, sz, sz, MP, sz, p64)
+    sig("orc_multiply_scalar_ps", None, p64, u64, sz, sz, MP, sz, p64)
+    sig("orc_dyadic_convolute", None, p64, p64, sz, sz, MP, sz, sz, p64)
+    sig("orc_dyadic_square", None, p64, MP, sz, sz, p64)
+    sig("orc_rns_tool_create", vp, sz, p64, sz, u64)
+    sig("orc_rns_tool_destroy", None, vp)
+    sig("orc_rns_tool_base_B_size", sz, vp)
+    sig("orc_rns_tool_base_Bsk_size", sz, vp)
+    sig("orc_rns_tool_m_sk", u64, vp)
+    sig("orc_rns_tool_gamma", u64, vp)
+    sig("orc_rns_tool_m_tilde", u64, vp)
+    sig("orc_rns_tool_base_Bsk", None, vp, p64)
+    sig("orc_rns_tool_inv_q_last_mod_q", u64, vp, sz, C.c_int)
+    sig("orc_fast_convert_array", None, p64, sz, p64, sz, p64, sz, p64)
+    for nm in ("orc_rns_fast_b_conv_m_tilde", "orc_rns_sm_mrq", "orc_rns_fast_floor", "orc_rns_fast_b_conv_sk",
+               "orc_rns_fast_b_conv_m_tilde_sm_mrq"):
+        sig(nm, None, vp, p64, p64)
+    sig("orc_rns_fast_floor_fast_b_conv_sk", None, vp, p64, p64, sz, p64)
+    sig("orc_rns_divide_and_round_q_last", None, vp, p64, sz, p64)
+    sig("orc_rns_divide_and_round_q_last_ntt", None, vp, p64, sz, p64, C.POINTER(vp))
+    sig("orc_context_create", vp, C.c_int, sz, p64, sz, u64)
+    sig("orc_context_destroy", None, vp)
+    sig("orc_context_key_modulus_size", sz, vp)
+    sig("orc_context_ntt_table", vp, vp, sz)
+    sig("orc_context_rns_tool", vp, vp, sz)
+    sig("orc_context_moduli", MP, vp)
+    sig("orc_transform_to_ntt", None, vp, p64, sz, sz)
+    sig("orc_transform_from_ntt", None, vp, p64, sz, sz)
+    sig("orc_switch_key", None, vp, sz, C.c_int, p64, C.POINTER(p64), C.c_int, p64)
+    sig("orc_relinearize", None, vp, sz, C.c_int, p64, C.POINTER(p64), p64)
+    sig("orc_ckks_multiply", None, vp, sz, p64, sz, p64, sz, p64)
+    sig("orc_bfv_multiply", None, vp, sz, p64, sz, p64, sz, p64)
+    sig("orc_mod_switch_scale_to_next", None, vp, sz, p64, sz, p64)
+    sig("orc_mod_switch_drop_to_next", None, vp, sz, p64, sz, p64)
+    sig("orc_fill_uniform", None, u64, u64, p64, sz)
+    sig("orc_fnv1a64", u64, p64, sz)
+    _lib = L
+    return L
+
+
+# ---- numpy helpers -------------------------------------------------------------------
+
+def ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(p64)
+
+
+def arr(x):
+    return np.ascontiguousarray(np.array(x, dtype=np.uint64))
+
+
+def modulus(value):
+    m = Modulus()
+    if lib().orc_modulus_init(C.byref(m), value) != 0:
+        raise ValueError("invalid modulus %d" % value)
+    return m
+
+
+def moduli_array(values):
+    ms = (Modulus * len(values))()
+    for i, v in enumerate(values):
+        if lib().orc_modulus_init(C.byref(ms[i]), int(v)) != 0:
+            raise ValueError("invalid modulus %d" % v)
+    return ms
+
+
+def get_primes(factor, bit_size, count):
+    out = np.zeros(count, dtype=np.uint64)
+    if lib().orc_get_primes(factor, bit_size, count, ptr(out)) < 0:
+        raise ValueError("not enough primes")
+    return [int(x) for x in out]
+
+
+def coeff_modulus_create(n, bit_sizes):
+    bs = (sz * len(bit_sizes))(*bit_sizes)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    if lib().orc_coeff_modulus_create(n, bs, len(bit_sizes), ptr(out)) != 0:
+        raise ValueError("coeff_modulus_create failed")
+    return [int(x) for x in out]
+
+
+def fill_uniform(seed, bound, n):
+    out = np.empty(n, dtype=np.uint64)
+    lib().orc_fill_uniform(seed, bound, ptr(out), n)
+    return out
+
+
+def fnv1a64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+    return int(lib().orc_fnv1a64(ptr(a), a.size))
+
+
+class NTTTables:
+    def __init__(self, log_n, q):
+        self.h = lib().orc_ntt_tables_create(log_n, q)
+        if not self.h:
+            raise ValueError("cannot create NTT tables for q=%d logN=%d" % (q, log_n))
+        self.log_n, self.q = log_n, q
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ntt_tables_destroy(self.h)
+            self.h = None
+
+    @property
+    def root(self):
+        return int(lib().orc_ntt_tables_root(self.h))
+
+    def root_power(self, i, inverse=False, quotient=False):
+        return int(lib().orc_ntt_tables_root_power(self.h, i, int(inverse), int(quotient)))
+
+    def inv_degree(self, quotient=False):
+        return int(lib().orc_ntt_tables_inv_degree(self.h, int(quotient)))
+
+
+def _table_handles(tables):
+    hs = (vp * len(tables))(*[t.h if isinstance(t, NTTTables) else t for t in tables])
+    return hs
+
+
+def ntt_forward(data, pcount, ncomp, log_n, tables, mode=0, decomp=0):
+    """in-place on a flat uint64 numpy array"""
+    lib().orc_ntt_forward(ptr(data), pcount, ncomp, log_n, _table_handles(tables), len(tables), mode, decomp)
+    return data
+
+
+def ntt_inverse(data, pcount, ncomp, log_n, tables, mode=0, decomp=0):
+    lib().orc_ntt_inverse(ptr(data), pcount, ncomp, log_n, _table_handles(tables), len(tables), mode, decomp)
+    return data
+
+
+class RNSTool:
+    def __init__(self, n, q, t):
+        qa = arr(q)
+        self.h = lib().orc_rns_tool_create(n, ptr(qa), len(q), t)
+        if not self.h:
+            raise ValueError("cannot create RNSTool")
+        self.n, self.q, self.t = n, list(q), t
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rns_tool_destroy(self.h)
+            self.h = None
+
+    @property
+    def base_B_size(self):
+        return int(lib().orc_rns_tool_base_B_size(self.h))
+
+    @property
+    def base_Bsk_size(self):
+        return int(lib().orc_rns_tool_base_Bsk_size(self.h))
+
+    @property
+    def m_sk(self):
+        return int(lib().orc_rns_tool_m_sk(self.h))
+
+    @property
+    def gamma(self):
+        return int(lib().orc_rns_tool_gamma(self.h))
+
+    @property
+    def m_tilde(self):
+        return int(lib().orc_rns_tool_m_tilde(self.h))
+
+    @property
+    def base_Bsk(self):
+        out = np.zeros(self.base_Bsk_size, dtype=np.uint64)
+        lib().orc_rns_tool_base_Bsk(self.h, ptr(out))
+        return [int(x) for x in out]
+
+    def _call(self, name, inp, out_len):
+        inp = arr(inp)
+        out = np.zeros(out_len, dtype=np.uint64)
+        getattr(lib(), name)(self.h, ptr(inp), ptr(out))
+        return out
+
+    def fast_b_conv_m_tilde(self, inp):
+        return self._call("orc_rns_fast_b_conv_m_tilde", inp, (self.base_Bsk_size + 1) * self.n)
+
+    def sm_mrq(self, inp):
+        return self._call("orc_rns_sm_mrq", inp, self.base_Bsk_size * self.n)
+
+    def fast_floor(self, inp):
+        return self._call("orc_rns_fast_floor", inp, self.base_Bsk_size * self.n)
+
+    def fast_b_conv_sk(self, inp):
+        return self._call("orc_rns_fast_b_conv_sk", inp, len(self.q) * self.n)
+
+
+class Context:
+    """orc_context: key-level chain (K primes) + per-level RNS tools."""
+
+    def __init__(self, scheme, n, coeff_modulus, plain_modulus=0):
+        self.scheme = {"bfv": 1, "ckks": 2, "bgv": 3}[scheme] if isinstance(scheme, str) else scheme
+        self.n = n
+        self.log_n = n.bit_length() - 1
+        self.q = [int(x) for x in coeff_modulus]
+        self.K = len(self.q)
+        self.t = plain_modulus
+        qa = arr(self.q)
+        self.h = lib().orc_context_create(self.scheme, n, ptr(qa), self.K, plain_modulus)
+        if not self.h:
+            raise ValueError("cannot create oracle context")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_context_destroy(self.h)
+            self.h = None
+
+    def moduli(self):
+        return lib().orc_context_moduli(self.h)
+
+    def table(self, i):
+        return lib().orc_context_ntt_table(self.h, i)
+
+    def rns_tool(self, nlimbs):
+        return lib().orc_context_rns_tool(self.h, nlimbs)
+
+    # all functions take / return flat or shaped uint64 numpy arrays (copied)
+    def to_ntt(self, ct, pcount, L):
+        out = np.ascontiguousarray(ct, dtype=np.uint64).copy()
+        lib().orc_transform_to_ntt(self.h, ptr(out.reshape(-1)), pcount, L)
+        return out
+
+    def from_ntt(self, ct, pcount, L):
+        out = np.ascontiguousarray(ct, dtype=np.uint64).copy()
+        lib().orc_transform_from_ntt(self.h, ptr(out.reshape(-1)), pcount, L)
+        return out
+
+    def _keys(self, keys):
+        ks = [np.ascontiguousarray(k, dtype=np.uint64).reshape(-1) for k in keys]
+        arrp = (p64 * len(ks))(*[ptr(k) for k in ks])
+        return ks, arrp
+
+    def switch_key(self, L, is_ntt, target, keys, assign=1, dest=None):
+        target = np.ascontiguousarray(target, dtype=np.uint64).reshape(-1)
+        ks, arrp = self._keys(keys)
+        if dest is None:
+            dest = np.zeros(2 * L * self.n, dtype=np.uint64)
+        else:
+            dest = np.ascontiguousarray(dest, dtype=np.uint64).reshape(-1).copy()
+        lib().orc_switch_key(self.h, L, int(is_ntt), ptr(target), arrp, assign, ptr(dest))
+        return dest.reshape(2, L, self.n)
+
+    def relinearize(self, L, is_ntt, ct3, keys):
+        ct3 = np.ascontiguousarray(ct3, dtype=np.uint64).reshape(-1)
+        ks, arrp = self._keys(keys)
+        out = np.zeros(2 * L * self.n, dtype=np.uint64)
+        lib().orc_relinearize(self.h, L, int(is_ntt), ptr(ct3), arrp, ptr(out))
+        return out.reshape(2, L, self.n)
+
+    def ckks_multiply(self, L, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        pa, pb = a.size // (L * self.n), b.size // (L * self.n)
+        out = np.zeros((pa + pb - 1) * L * self.n, dtype=np.uint64)
+        lib().orc_ckks_multiply(self.h, L, ptr(a.reshape(-1)), pa, ptr(b.reshape(-1)), pb, ptr(out))
+        return out.reshape(pa + pb - 1, L, self.n)
+
+    def bfv_multiply(self, L, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        pa, pb = a.size // (L * self.n), b.size // (L * self.n)
+        out = np.zeros((pa + pb - 1) * L * self.n, dtype=np.uint64)
+        lib().orc_bfv_multiply(self.h, L, ptr(a.reshape(-1)), pa, ptr(b.reshape(-1)), pb, ptr(out))
+        return out.reshape(pa + pb - 1, L, self.n)
+
+    def mod_switch_scale_to_next(self, L, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        p = ct.size // (L * self.n)
+        out = np.zeros(p * (L - 1) * self.n, dtype=np.uint64)
+        lib().orc_mod_switch_scale_to_next(self.h, L, ptr(ct.reshape(-1)), p, ptr(out))
+        return out.reshape(p, L - 1, self.n)
+
+    def mod_switch_drop_to_next(self, L, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        p = ct.size // (L * self.n)
+        out = np.zeros(p * (L - 1) * self.n, dtype=np.uint64)
+        lib().orc_mod_switch_drop_to_next(self.h, L, ptr(ct.reshape(-1)), p, ptr(out))
+        return out.reshape(p, L - 1, self.n)
+
+    def random_ct(self, seed, pcount, L):
+        """uniform residues x[p][l][i] in [0, q_l) from the shared splitmix generator"""
+        out = np.empty((pcount, L, self.n), dtype=np.uint64)
+        for p in range(pcount):
+            for l in range(L):
+                out[p, l] = fill_uniform(seed * 1000003 + p * 101 + l, self.q[l], self.n)
+        return out
+
+    def random_keys(self, seed, L):
+        """L key-switching keys, each u64[2][K][N] of uniform residues (NTT form)"""
+        keys = []
+        for j in range(L):
+            k = np.empty((2, self.K, self.n), dtype=np.uint64)
+            for c in range(2):
+                for l in range(self.K):
+                    k[c, l] = fill_uniform(seed * 7919 + j * 257 + c * 31 + l, self.q[l], self.n)
+            keys.append(k)
+        return keys

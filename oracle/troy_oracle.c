@@ -1,0 +1,1165 @@
+/*
+ * troy_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see troy_oracle.h).
+ *
+ * Plain C11 (+ unsigned __int128) restatement of the reference's HOST code paths.  Each
+ * function names the reference file:line (relative to src/) whose algorithm it follows.
+ * Single-threaded, scalar, deliberately unoptimised: it mirrors the reference loop
+ * structure so that it can also serve as the "port" CPU baseline in bench.py.
+ *
+ * PARITY: the reference cannot be built in this image (CUDA toolchain absent), so this
+ * file is pinned by the reference's own known-answer tests (tests/golden/ref_kats.json,
+ * checked by tests/test_oracle_kats.py).
+ */
+#include "troy_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ====================================================================================== */
+/* scalar helpers (utils/basics.h)                                                         */
+/* ====================================================================================== */
+
+static inline uint64_t mul_hi64(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) >> 64); }
+
+/* utils/basics.h add_uint64: returns carry */
+static inline unsigned add_u64(uint64_t a, uint64_t b, uint64_t* r) {
+    *r = a + b;
+    return *r < a;
+}
+
+static inline size_t significant_bits(uint64_t v) {
+    size_t c = 0;
+    while (v) { c++; v >>= 1; }
+    return c;
+}
+
+static inline uint64_t reverse_bits(uint64_t x, size_t bit_count) {
+    /* utils/basics.h:130-147 */
+    if (bit_count == 0) return 0;
+    uint64_t r = 0;
+    for (size_t i = 0; i < 64; i++) { r = (r << 1) | ((x >> i) & 1); }
+    return r >> (64 - bit_count);
+}
+
+/* ====================================================================================== */
+/* Modulus (modulus.h / modulus.cu)                                                        */
+/* ====================================================================================== */
+
+int orc_modulus_init(orc_modulus* m, uint64_t value) {
+    /* modulus.cu:7-32 Modulus::set_value */
+    memset(m, 0, sizeof(*m));
+    if (value == 0) return 0;
+    if ((value >> 61) != 0 || value == 1) return -1;
+    m->value = value;
+    m->bit_count = significant_bits(value);
+    /* floor(2^128 / value) via two 128/64 divisions (divide_uint192_uint64_inplace) */
+    u128 two64 = (u128)1 << 64;
+    u128 hi = two64 / value;
+    u128 r = two64 % value;
+    u128 lo = (r << 64) / value;
+    u128 rem = (r << 64) % value;
+    m->const_ratio[0] = (uint64_t)lo;
+    m->const_ratio[1] = (uint64_t)hi;
+    m->const_ratio[2] = (uint64_t)rem;
+    m->is_prime = orc_is_prime(value);
+    return 0;
+}
+
+uint64_t orc_barrett_reduce64(uint64_t input, const orc_modulus* m) {
+    /* modulus.h:22-42 Modulus::reduce */
+    uint64_t tmp1 = mul_hi64(input, m->const_ratio[1]);
+    uint64_t tmp0 = input - tmp1 * m->value;
+    return tmp0 >= m->value ? tmp0 - m->value : tmp0;
+}
+
+uint64_t orc_barrett_reduce128(uint64_t in0, uint64_t in1, const orc_modulus* m) {
+    /* modulus.h:44-78 Modulus::reduce_uint128_limbs */
+    uint64_t tmp1, tmp3, carry;
+    const uint64_t* cr = m->const_ratio;
+    /* Round 1 */
+    carry = mul_hi64(in0, cr[0]);
+    u128 t2 = (u128)in0 * cr[1];
+    uint64_t t2lo = (uint64_t)t2, t2hi = (uint64_t)(t2 >> 64);
+    tmp3 = t2hi + add_u64(t2lo, carry, &tmp1);
+    /* Round 2 */
+    t2 = (u128)in1 * cr[0];
+    t2lo = (uint64_t)t2; t2hi = (uint64_t)(t2 >> 64);
+    carry = t2hi + add_u64(tmp1, t2lo, &tmp1);
+    /* This is all we care about */
+    tmp1 = in1 * cr[1] + tmp3 + carry;
+    /* Barrett subtraction */
+    tmp3 = in0 - tmp1 * m->value;
+    return tmp3 >= m->value ? tmp3 - m->value : tmp3;
+}
+
+uint64_t orc_multiply_mod(uint64_t a, uint64_t b, const orc_modulus* m) {
+    /* uint_small_mod.h:85-90 multiply_uint64_mod */
+    u128 p = (u128)a * b;
+    return orc_barrett_reduce128((uint64_t)p, (uint64_t)(p >> 64), m);
+}
+
+uint64_t orc_add_mod(uint64_t a, uint64_t b, const orc_modulus* m) {
+    /* uint_small_mod.h:54-61 (single correction) */
+    a += b;
+    return a >= m->value ? a - m->value : a;
+}
+
+uint64_t orc_sub_mod(uint64_t a, uint64_t b, const orc_modulus* m) {
+    /* uint_small_mod.h:64-72 */
+    uint64_t t = a - b;
+    return (a < b) ? t + m->value : t;
+}
+
+uint64_t orc_negate_mod(uint64_t a, const orc_modulus* m) {
+    /* uint_small_mod.h:30-36 */
+    return a == 0 ? 0 : m->value - a;
+}
+
+void orc_mulop_init(orc_mulop* o, uint64_t operand, const orc_modulus* m) {
+    /* uint_small_mod.h:97-113: quotient = floor(operand * 2^64 / modulus) (low word) */
+    o->operand = operand;
+    o->quotient = (uint64_t)((((u128)operand) << 64) / m->value);
+}
+
+uint64_t orc_mulop_mod(uint64_t x, const orc_mulop* y, const orc_modulus* m) {
+    /* uint_small_mod.h:130-139 */
+    uint64_t p = m->value;
+    uint64_t tmp1 = mul_hi64(x, y->quotient);
+    uint64_t tmp2 = y->operand * x - tmp1 * p;
+    return tmp2 >= p ? tmp2 - p : tmp2;
+}
+
+uint64_t orc_mulop_mod_lazy(uint64_t x, const orc_mulop* y, const orc_modulus* m) {
+    /* uint_small_mod.h:142-148 */
+    uint64_t tmp1 = mul_hi64(x, y->quotient);
+    return y->operand * x - tmp1 * m->value;
+}
+
+uint64_t orc_exponentiate_mod(uint64_t operand, uint64_t exponent, const orc_modulus* m) {
+    /* uint_small_mod.h:215-231 */
+    if (exponent == 0) return 1;
+    if (exponent == 1) return operand;
+    uint64_t power = operand, intermediate = 1;
+    for (;;) {
+        if (exponent & 1) intermediate = orc_multiply_mod(power, intermediate, m);
+        exponent >>= 1;
+        if (exponent == 0) break;
+        power = orc_multiply_mod(power, power, m);
+    }
+    return intermediate;
+}
+
+int orc_try_invert_mod(uint64_t value, const orc_modulus* m, uint64_t* out) {
+    /* utils/number_theory.h:30-68 xgcd + try_invert_uint64_mod_uint64 */
+    if (value == 0) return 0;
+    int64_t a = (int64_t)value, b = (int64_t)m->value;
+    int64_t x0 = 1, x1 = 0;
+    while (b != 0) {
+        int64_t q = a / b, r = a % b;
+        a = b; b = r;
+        int64_t x2 = x0 - q * x1;
+        x0 = x1; x1 = x2;
+    }
+    if (a != 1) return 0;
+    *out = (x0 < 0) ? (uint64_t)((int64_t)m->value + x0) : (uint64_t)x0;
+    return 1;
+}
+
+uint64_t orc_dot_product_mod(const uint64_t* a, const uint64_t* b, size_t n, const orc_modulus* m) {
+    /* uint_small_mod.h:251-261: 128-bit lazy accumulation then one Barrett-128 */
+    u128 acc = 0;
+    for (size_t i = 0; i < n; i++) acc += (u128)a[i] * b[i];
+    return orc_barrett_reduce128((uint64_t)acc, (uint64_t)(acc >> 64), m);
+}
+
+static uint64_t mulmod_plain(uint64_t a, uint64_t b, uint64_t n) { return (uint64_t)(((u128)a * b) % n); }
+static uint64_t powmod_plain(uint64_t a, uint64_t e, uint64_t n) {
+    uint64_t r = 1;
+    a %= n;
+    while (e) { if (e & 1) r = mulmod_plain(r, a, n); a = mulmod_plain(a, a, n); e >>= 1; }
+    return r;
+}
+
+int orc_is_prime(uint64_t value) {
+    /* uint_small_mod.h:264-301.  The reference runs 40 Miller-Rabin rounds with base 2 and
+     * rand() bases; the verdict for a true prime / true composite does not depend on the
+     * bases (up to a 4^-40 error), so the oracle uses the deterministic base set that is
+     * exact for all 64-bit inputs. */
+    if (value < 2) return 0;
+    static const uint64_t small[] = {2, 3, 5, 7, 11, 13};
+    for (size_t i = 0; i < 6; i++) {
+        if (value == small[i]) return 1;
+        if (value % small[i] == 0) return 0;
+    }
+    uint64_t d = value - 1, r = 0;
+    while ((d & 1) == 0) { d >>= 1; r++; }
+    static const uint64_t bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (size_t i = 0; i < 12; i++) {
+        uint64_t a = bases[i] % value;
+        if (a == 0) continue;
+        uint64_t x = powmod_plain(a, d, value);
+        if (x == 1 || x == value - 1) continue;
+        int composite = 1;
+        for (uint64_t k = 1; k < r; k++) {
+            x = mulmod_plain(x, x, value);
+            if (x == value - 1) { composite = 0; break; }
+        }
+        if (composite) return 0;
+    }
+    return 1;
+}
+
+int orc_get_primes(uint64_t factor, size_t bit_size, size_t count, uint64_t* out) {
+    /* utils/number_theory.cu:22-39: descending search from the largest value = 1 (mod factor) */
+    uint64_t value = ((((uint64_t)1) << bit_size) - 1) / factor * factor + 1;
+    uint64_t lower_bound = ((uint64_t)1) << (bit_size - 1);
+    size_t found = 0;
+    while (found < count && value > lower_bound) {
+        if (orc_is_prime(value)) out[found++] = value;
+        value -= factor;
+    }
+    return found == count ? (int)found : -1;
+}
+
+int orc_coeff_modulus_create(size_t poly_modulus_degree, const size_t* bit_sizes, size_t n, uint64_t* out) {
+    /* coeff_modulus.cu:65-108.  For every distinct bit size s occurring c_s times the c_s
+     * largest primes = 1 mod 2N are found (descending); the result takes them from the BACK
+     * of that list, i.e. smallest first (:103-104). */
+    if (n == 0 || n > 64) return -1;
+    uint64_t factor = 2 * (uint64_t)poly_modulus_degree;
+    size_t used[65];
+    memset(used, 0, sizeof(used));
+    for (size_t i = 0; i < n; i++) {
+        size_t s = bit_sizes[i];
+        if (s > 60 || s < 2) return -1;
+        size_t total = 0;
+        for (size_t k = 0; k < n; k++) total += (bit_sizes[k] == s);
+        uint64_t primes[64];
+        if (orc_get_primes(factor, s, total, primes) < 0) return -1;
+        /* pop_back order: the u-th request of size s receives primes[total-1-u] */
+        out[i] = primes[total - 1 - used[s]];
+        used[s]++;
+    }
+    return 0;
+}
+
+int orc_try_minimal_primitive_root(uint64_t degree, const orc_modulus* m, uint64_t* out) {
+    /* utils/number_theory.cu:41-87.  try_primitive_root draws random candidates; the
+     * minimal root found afterwards (:68-87) is independent of the starting root, so the
+     * oracle starts from the first deterministic candidate 2,3,4,... */
+    uint64_t size_entire_group = m->value - 1;
+    uint64_t size_quotient_group = size_entire_group / degree;
+    if (size_entire_group - size_quotient_group * degree != 0) return 0;
+    uint64_t root = 0;
+    int ok = 0;
+    for (uint64_t cand = 2; cand < 2 + 4096 && cand < m->value; cand++) {
+        uint64_t r = orc_exponentiate_mod(cand, size_quotient_group, m);
+        /* is_primitive_root, number_theory.h:85-92 */
+        if (r != 0 && orc_exponentiate_mod(r, degree >> 1, m) == m->value - 1) { root = r; ok = 1; break; }
+    }
+    if (!ok) return 0;
+    uint64_t current_generator = root;
+    uint64_t generator_sq = orc_multiply_mod(root, root, m);
+    for (uint64_t i = 0; i < (degree + 1) / 2; i++) {
+        if (current_generator < root) root = current_generator;
+        current_generator = orc_multiply_mod(current_generator, generator_sq, m);
+    }
+    *out = root;
+    return 1;
+}
+
+/* ====================================================================================== */
+/* NTT tables + transforms                                                                 */
+/* ====================================================================================== */
+
+orc_ntt_tables* orc_ntt_tables_create(size_t coeff_count_power, uint64_t modulus_value) {
+    /* utils/ntt.cu:14-76 NTTTables::NTTTables */
+    orc_ntt_tables* t = (orc_ntt_tables*)calloc(1, sizeof(*t));
+    if (!t) return NULL;
+    if (orc_modulus_init(&t->modulus, modulus_value) != 0) { free(t); return NULL; }
+    size_t n = (size_t)1 << coeff_count_power;
+    const orc_modulus* m = &t->modulus;
+    uint64_t root = 0, inv_root = 0;
+    if (!orc_try_minimal_primitive_root(2 * (uint64_t)n, m, &root)) { free(t); return NULL; }
+    if (!orc_try_invert_mod(root, m, &inv_root)) { free(t); return NULL; }
+    t->root_powers = (orc_mulop*)malloc(n * sizeof(orc_mulop));
+    t->inv_root_powers = (orc_mulop*)malloc(n * sizeof(orc_mulop));
+    orc_mulop root_operand;
+    orc_mulop_init(&root_operand, root, m);
+    uint64_t power = root;
+    for (size_t i = 1; i < n; i++) {
+        orc_mulop_init(&t->root_powers[reverse_bits(i, coeff_count_power)], power, m);
+        power = orc_mulop_mod(power, &root_operand, m);
+    }
+    orc_mulop_init(&t->root_powers[0], 1, m);
+    orc_mulop_init(&root_operand, inv_root, m);
+    power = inv_root;
+    for (size_t i = 1; i < n; i++) {
+        orc_mulop_init(&t->inv_root_powers[reverse_bits(i - 1, coeff_count_power) + 1], power, m);
+        power = orc_mulop_mod(power, &root_operand, m);
+    }
+    orc_mulop_init(&t->inv_root_powers[0], 1, m);
+    uint64_t inv_degree = 0;
+    if (!orc_try_invert_mod((uint64_t)n, m, &inv_degree)) { orc_ntt_tables_destroy(t); return NULL; }
+    orc_mulop_init(&t->inv_degree_modulo, inv_degree, m);
+    t->root = root;
+    t->coeff_count = n;
+    t->coeff_count_power = coeff_count_power;
+    return t;
+}
+
+void orc_ntt_tables_destroy(orc_ntt_tables* t) {
+    if (!t) return;
+    free(t->root_powers);
+    free(t->inv_root_powers);
+    free(t);
+}
+
+uint64_t orc_ntt_tables_root(const orc_ntt_tables* t) { return t->root; }
+uint64_t orc_ntt_tables_root_power(const orc_ntt_tables* t, size_t i, int inverse, int want_quotient) {
+    const orc_mulop* o = inverse ? &t->inv_root_powers[i] : &t->root_powers[i];
+    return want_quotient ? o->quotient : o->operand;
+}
+uint64_t orc_ntt_tables_inv_degree(const orc_ntt_tables* t, int want_quotient) {
+    return want_quotient ? t->inv_degree_modulo.quotient : t->inv_degree_modulo.operand;
+}
+
+static inline const orc_ntt_tables* indexer_get(const orc_ntt_tables* const* tables, size_t n_tables, int mode,
+                                                size_t decomp, size_t poly_index, size_t component_index) {
+    /* utils/ntt.h:105-124 NTTTableIndexer::get */
+    switch (mode) {
+        case ORC_IDX_KS_SET_PRODUCTS:
+            return (poly_index == decomp) ? tables[n_tables - 1] : tables[poly_index];
+        case ORC_IDX_KS_SKIP_FINALS:
+            return (component_index == decomp) ? tables[n_tables - 1] : tables[component_index];
+        default:
+            return tables[component_index];
+    }
+}
+
+void orc_ntt_forward(uint64_t* data, size_t pcount, size_t component_count, size_t log_degree,
+                     const orc_ntt_tables* const* tables, size_t n_tables, int mode, size_t decomp) {
+    /* fgk/ntt_grouped.cu:258-270 host branch: one host_ntt_transfer_to_rev_layer (:11-56) per layer */
+    for (size_t layer = 0; layer < log_degree; layer++) {
+        size_t m = (size_t)1 << layer;
+        size_t gap_power = log_degree - layer - 1;
+        size_t gap = (size_t)1 << gap_power;
+        size_t i_upperbound = (size_t)1 << (log_degree - 1);
+        for (size_t j = 0; j < component_count; j++) {
+            for (size_t k = 0; k < pcount; k++) {
+                const orc_ntt_tables* table = indexer_get(tables, n_tables, mode, decomp, k, j);
+                const orc_modulus* modulus = &table->modulus;
+                uint64_t two_times_modulus = modulus->value << 1;
+                uint64_t* base = data + ((k * component_count + j) << log_degree);
+                for (size_t i = 0; i < i_upperbound; i++) {
+                    size_t rid = m + (i >> gap_power);
+                    size_t coeff_index = ((i >> gap_power) << (gap_power + 1)) + (i & (gap - 1));
+                    const orc_mulop* r = &table->root_powers[rid];
+                    uint64_t x = base[coeff_index];
+                    uint64_t y = base[coeff_index + gap];
+                    uint64_t u = (x >= two_times_modulus) ? (x - two_times_modulus) : x;
+                    uint64_t v = orc_mulop_mod_lazy(y, r, modulus);
+                    base[coeff_index] = u + v;
+                    base[coeff_index + gap] = u + two_times_modulus - v;
+                }
+            }
+        }
+        if (layer == log_degree - 1) {
+            size_t n = (size_t)1 << log_degree;
+            for (size_t j = 0; j < component_count; j++) {
+                for (size_t k = 0; k < pcount; k++) {
+                    const orc_modulus* modulus = &indexer_get(tables, n_tables, mode, decomp, k, j)->modulus;
+                    uint64_t mv = modulus->value, tmv = modulus->value << 1;
+                    uint64_t* base = data + ((k * component_count + j) << log_degree);
+                    for (size_t i = 0; i < n; i++) {
+                        if (base[i] >= tmv) base[i] -= tmv;
+                        if (base[i] >= mv) base[i] -= mv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+void orc_ntt_inverse(uint64_t* data, size_t pcount, size_t component_count, size_t log_degree,
+                     const orc_ntt_tables* const* tables, size_t n_tables, int mode, size_t decomp) {
+    /* fgk/ntt_grouped.cu:597-610 host branch: one host_ntt_transfer_from_rev_layer (:346-391) per layer */
+    for (size_t layer = 0; layer < log_degree; layer++) {
+        size_t m = (size_t)1 << (log_degree - layer - 1);
+        size_t gap_power = layer;
+        size_t gap = (size_t)1 << gap_power;
+        size_t i_upperbound = (size_t)1 << (log_degree - 1);
+        for (size_t j = 0; j < component_count; j++) {
+            for (size_t k = 0; k < pcount; k++) {
+                const orc_ntt_tables* table = indexer_get(tables, n_tables, mode, decomp, k, j);
+                const orc_modulus* modulus = &table->modulus;
+                uint64_t two_times_modulus = modulus->value << 1;
+                uint64_t* base = data + ((k * component_count + j) << log_degree);
+                for (size_t i = 0; i < i_upperbound; i++) {
+                    size_t rid = ((size_t)1 << log_degree) - (m << 1) + 1 + (i >> gap_power);
+                    size_t coeff_index = ((i >> gap_power) << (gap_power + 1)) + (i & (gap - 1));
+                    const orc_mulop* r = &table->inv_root_powers[rid];
+                    uint64_t u = base[coeff_index];
+                    uint64_t v = base[coeff_index + gap];
+                    base[coeff_index] = (u + v > two_times_modulus) ? (u + v - two_times_modulus) : (u + v);
+                    base[coeff_index + gap] = orc_mulop_mod_lazy(u + two_times_modulus - v, r, modulus);
+                }
+            }
+        }
+        if (layer == log_degree - 1) {
+            size_t n = (size_t)1 << log_degree;
+            for (size_t j = 0; j < component_count; j++) {
+                for (size_t k = 0; k < pcount; k++) {
+                    const orc_ntt_tables* table = indexer_get(tables, n_tables, mode, decomp, k, j);
+                    const orc_modulus* modulus = &table->modulus;
+                    uint64_t mv = modulus->value, tmv = modulus->value << 1;
+                    uint64_t* base = data + ((k * component_count + j) << log_degree);
+                    for (size_t i = 0; i < n; i++) {
+                        uint64_t x = base[i];
+                        if (x >= tmv) x -= tmv;
+                        if (x >= mv) x -= mv;
+                        base[i] = orc_mulop_mod_lazy(x, &table->inv_degree_modulo, modulus);
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ====================================================================================== */
+/* element-wise ops (utils/poly_small_mod.cu host loops)                                   */
+/* ====================================================================================== */
+
+#define FOR_PS(body)                                                        \
+    for (size_t i = 0; i < pcount; i++)                                     \
+        for (size_t j = 0; j < nmod; j++) {                                 \
+            const orc_modulus* mod = &moduli[j];                            \
+            (void)mod;                                                      \
+            for (size_t k = 0; k < degree; k++) {                           \
+                size_t idx = (i * nmod + j) * degree + k;                   \
+                body;                                                       \
+            }                                                               \
+        }
+
+void orc_add_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:243-256 host_add_ps */
+    FOR_PS(out[idx] = orc_add_mod(a[idx], b[idx], mod))
+}
+void orc_sub_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:306-318 host_sub_ps */
+    FOR_PS(out[idx] = orc_sub_mod(a[idx], b[idx], mod))
+}
+void orc_negate_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:182-194 host_negate_ps */
+    FOR_PS(out[idx] = orc_negate_mod(a[idx], mod))
+}
+void orc_modulo_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:119-128 host_modulo_ps */
+    FOR_PS(out[idx] = orc_barrett_reduce64(a[idx], mod))
+}
+void orc_multiply_scalar_ps(const uint64_t* a, uint64_t scalar, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:653-662 host_multiply_scalar_ps */
+    FOR_PS(out[idx] = orc_multiply_mod(a[idx], scalar, mod))
+}
+void orc_dyadic_product_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:816-855 host_dyadic_product_ps */
+    FOR_PS(out[idx] = orc_multiply_mod(a[idx], b[idx], mod))
+}
+
+void orc_dyadic_convolute(const uint64_t* a, const uint64_t* b, size_t pa, size_t pb, const orc_modulus* moduli, size_t nmod, size_t degree, uint64_t* out) {
+    /* fgk/dyadic_convolute.cu:43-80 host branch: zero, then pa*pb (product + add) passes */
+    size_t pc = nmod * degree;
+    uint64_t* temp = (uint64_t*)malloc(pc * sizeof(uint64_t));
+    memset(out, 0, (pa + pb - 1) * pc * sizeof(uint64_t));
+    for (size_t i = 0; i < pa; i++) {
+        for (size_t j = 0; j < pb; j++) {
+            size_t k = i + j;
+            orc_dyadic_product_ps(a + pc * i, b + pc * j, 1, degree, moduli, nmod, temp);
+            orc_add_ps(out + pc * k, temp, 1, degree, moduli, nmod, out + pc * k);
+        }
+    }
+    free(temp);
+}
+
+void orc_dyadic_square(const uint64_t* a, const orc_modulus* moduli, size_t nmod, size_t degree, uint64_t* out) {
+    /* fgk/dyadic_convolute.cu:116-140 host branch */
+    size_t pc = nmod * degree;
+    const uint64_t *c0 = a, *c1 = a + pc;
+    uint64_t *r0 = out, *r1 = out + pc, *r2 = out + 2 * pc;
+    orc_dyadic_product_ps(c0, c0, 1, degree, moduli, nmod, r0);
+    orc_dyadic_product_ps(c0, c1, 1, degree, moduli, nmod, r1);
+    orc_add_ps(r1, r1, 1, degree, moduli, nmod, r1);
+    orc_dyadic_product_ps(c1, c1, 1, degree, moduli, nmod, r2);
+}
+
+/* ====================================================================================== */
+/* RNS base / base converter / RNS tool                                                    */
+/* ====================================================================================== */
+
+/* utils/rns_base.h RNSBase: moduli + inv_punctured_product_mod_base (rns_base.cu:56-105).
+ * The multi-precision punctured products are only ever consumed reduced modulo a word-size
+ * modulus (modulo_uint), so the oracle keeps them as residues: prod_{k!=i} q_k mod p. */
+typedef struct {
+    size_t size;
+    orc_modulus* base;
+    orc_mulop* inv_punctured_product_mod_base;
+} rns_base;
+
+static uint64_t punctured_product_mod(const rns_base* b, size_t except, const orc_modulus* p) {
+    /* = modulo_uint(punctured_product(except), p)  (uint_small_mod.h:170-186) */
+    uint64_t acc = 1 % p->value;
+    if (p->value == 1) return 0;
+    for (size_t k = 0; k < b->size; k++) {
+        if (k == except) continue;
+        acc = orc_multiply_mod(acc, orc_barrett_reduce64(b->base[k].value, p), p);
+    }
+    return acc;
+}
+
+static uint64_t base_product_mod(const rns_base* b, const orc_modulus* p) {
+    uint64_t acc = 1;
+    for (size_t k = 0; k < b->size; k++) acc = orc_multiply_mod(acc, orc_barrett_reduce64(b->base[k].value, p), p);
+    return acc;
+}
+
+static int rns_base_init(rns_base* b, const uint64_t* values, size_t n) {
+    b->size = n;
+    b->base = (orc_modulus*)calloc(n, sizeof(orc_modulus));
+    b->inv_punctured_product_mod_base = (orc_mulop*)calloc(n, sizeof(orc_mulop));
+    for (size_t i = 0; i < n; i++) {
+        if (orc_modulus_init(&b->base[i], values[i]) != 0 || values[i] == 0) return -1;
+    }
+    for (size_t i = 0; i < n; i++) {
+        uint64_t temp = (n == 1) ? 1 : punctured_product_mod(b, i, &b->base[i]);
+        uint64_t inv = 0;
+        if (n == 1) inv = 1;
+        else if (!orc_try_invert_mod(temp, &b->base[i], &inv)) return -1;
+        orc_mulop_init(&b->inv_punctured_product_mod_base[i], inv, &b->base[i]);
+    }
+    return 0;
+}
+
+static void rns_base_free(rns_base* b) {
+    free(b->base);
+    free(b->inv_punctured_product_mod_base);
+    b->base = NULL; b->inv_punctured_product_mod_base = NULL;
+}
+
+/* utils/rns_base.h:165-205 BaseConverter */
+typedef struct {
+    rns_base ibase, obase;
+    uint64_t* base_change_matrix; /* [obase.size][ibase.size] */
+} base_converter;
+
+static int base_converter_init(base_converter* c, const uint64_t* iv, size_t ni, const uint64_t* ov, size_t no) {
+    if (rns_base_init(&c->ibase, iv, ni) != 0) return -1;
+    /* the output base does not need invertible punctured products (e.g. {m_tilde}) */
+    c->obase.size = no;
+    c->obase.base = (orc_modulus*)calloc(no, sizeof(orc_modulus));
+    c->obase.inv_punctured_product_mod_base = NULL;
+    for (size_t i = 0; i < no; i++) if (orc_modulus_init(&c->obase.base[i], ov[i]) != 0) return -1;
+    c->base_change_matrix = (uint64_t*)malloc(ni * no * sizeof(uint64_t));
+    for (size_t i = 0; i < no; i++)
+        for (size_t j = 0; j < ni; j++)
+            c->base_change_matrix[i * ni + j] = punctured_product_mod(&c->ibase, j, &c->obase.base[i]);
+    return 0;
+}
+
+static void base_converter_free(base_converter* c) {
+    rns_base_free(&c->ibase);
+    rns_base_free(&c->obase);
+    free(c->base_change_matrix);
+    c->base_change_matrix = NULL;
+}
+
+static void fast_convert_array(const base_converter* c, const uint64_t* input, size_t count, uint64_t* output) {
+    /* utils/rns_base.cu:350-380 host_fast_convert_array */
+    size_t ni = c->ibase.size, no = c->obase.size;
+    uint64_t* temp = (uint64_t*)malloc(ni * count * sizeof(uint64_t));
+    for (size_t i = 0; i < ni; i++) {
+        const orc_mulop* op = &c->ibase.inv_punctured_product_mod_base[i];
+        const orc_modulus* base = &c->ibase.base[i];
+        if (op->operand == 1) {
+            for (size_t j = 0; j < count; j++) temp[j * ni + i] = orc_barrett_reduce64(input[i * count + j], base);
+        } else {
+            for (size_t j = 0; j < count; j++) temp[j * ni + i] = orc_mulop_mod(input[i * count + j], op, base);
+        }
+    }
+    for (size_t i = 0; i < no; i++)
+        for (size_t j = 0; j < count; j++)
+            output[i * count + j] = orc_dot_product_mod(temp + j * ni, c->base_change_matrix + i * ni, ni, &c->obase.base[i]);
+    free(temp);
+}
+
+void orc_fast_convert_array(const uint64_t* ibase, size_t ni, const uint64_t* obase, size_t no,
+                            const uint64_t* input, size_t count, uint64_t* output) {
+    base_converter c;
+    memset(&c, 0, sizeof(c));
+    if (base_converter_init(&c, ibase, ni, obase, no) == 0) fast_convert_array(&c, input, count, output);
+    base_converter_free(&c);
+}
+
+struct orc_rns_tool {
+    /* utils/rns_tool.h members, utils/rns_tool.cu:29-275 */
+    size_t coeff_count;
+    size_t q_size, B_size, Bsk_size;
+    rns_base base_q, base_B, base_Bsk;
+    orc_modulus m_tilde, m_sk, t, gamma;
+    base_converter q_to_Bsk, q_to_m_tilde, B_to_q, B_to_m_sk;
+    uint64_t* prod_B_mod_q;           /* [q] */
+    orc_mulop* inv_prod_q_mod_Bsk;    /* [Bsk] */
+    orc_mulop inv_prod_B_mod_m_sk;
+    orc_mulop* inv_m_tilde_mod_Bsk;   /* [Bsk] */
+    orc_mulop neg_inv_prod_q_mod_m_tilde;
+    uint64_t* prod_q_mod_Bsk;         /* [Bsk] */
+    orc_mulop* inv_q_last_mod_q;      /* [q-1] */
+    uint64_t q_last_half;
+    orc_ntt_tables** Bsk_ntt_tables;  /* [Bsk] (NULL when the ring degree is not NTT-friendly) */
+};
+
+static size_t bigmul_bits(const uint64_t* v, size_t n) {
+    /* get_significant_bit_count_uint(base_product) -- schoolbook product of n words */
+    uint64_t acc[130];
+    size_t len = 1;
+    memset(acc, 0, sizeof(acc));
+    acc[0] = 1;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t carry = 0;
+        for (size_t k = 0; k < len; k++) {
+            u128 p = (u128)acc[k] * v[i] + carry;
+            acc[k] = (uint64_t)p;
+            carry = (uint64_t)(p >> 64);
+        }
+        if (carry) acc[len++] = carry;
+    }
+    return significant_bits(acc[len - 1]) + (len - 1) * 64;
+}
+
+orc_rns_tool* orc_rns_tool_create(size_t poly_modulus_degree, const uint64_t* q, size_t q_size, uint64_t t_value) {
+    /* utils/rns_tool.cu:29-275 */
+    if (q_size < 1 || q_size > 64) return NULL;
+    size_t coeff_count_power = 0;
+    while (((size_t)1 << coeff_count_power) < poly_modulus_degree) coeff_count_power++;
+    if (((size_t)1 << coeff_count_power) != poly_modulus_degree) return NULL;
+    orc_rns_tool* r = (orc_rns_tool*)calloc(1, sizeof(*r));
+    r->coeff_count = poly_modulus_degree;
+    r->q_size = q_size;
+    if (orc_modulus_init(&r->t, t_value) != 0) { free(r); return NULL; }
+    size_t total_coeff_bit_count = bigmul_bits(q, q_size);
+    size_t base_B_size = q_size;
+    if (32 + r->t.bit_count + total_coeff_bit_count >= 61 * q_size + 61) base_B_size++;
+    size_t base_Bsk_size = base_B_size + 1;
+    size_t base_Bsk_m_tilde_size = base_Bsk_size + 1;
+    r->B_size = base_B_size;
+    r->Bsk_size = base_Bsk_size;
+    uint64_t primes[70];
+    if (orc_get_primes(2 * (uint64_t)poly_modulus_degree, 61, base_Bsk_m_tilde_size, primes) < 0) { free(r); return NULL; }
+    orc_modulus_init(&r->m_sk, primes[0]);
+    orc_modulus_init(&r->gamma, primes[1]);
+    uint64_t Bsk_values[70];
+    for (size_t i = 0; i < base_B_size; i++) Bsk_values[i] = primes[2 + i];
+    Bsk_values[base_B_size] = r->m_sk.value;
+    orc_modulus_init(&r->m_tilde, (uint64_t)1 << 32);
+    uint64_t m_tilde_value = r->m_tilde.value;
+
+    int ok = 1;
+    ok &= rns_base_init(&r->base_q, q, q_size) == 0;
+    ok &= rns_base_init(&r->base_B, Bsk_values, base_B_size) == 0;
+    ok &= rns_base_init(&r->base_Bsk, Bsk_values, base_Bsk_size) == 0;
+    ok &= base_converter_init(&r->q_to_Bsk, q, q_size, Bsk_values, base_Bsk_size) == 0;
+    ok &= base_converter_init(&r->q_to_m_tilde, q, q_size, &m_tilde_value, 1) == 0;
+    ok &= base_converter_init(&r->B_to_q, Bsk_values, base_B_size, q, q_size) == 0;
+    ok &= base_converter_init(&r->B_to_m_sk, Bsk_values, base_B_size, &r->m_sk.value, 1) == 0;
+    if (!ok) { orc_rns_tool_destroy(r); return NULL; }
+
+    r->prod_B_mod_q = (uint64_t*)malloc(q_size * sizeof(uint64_t));
+    for (size_t i = 0; i < q_size; i++) r->prod_B_mod_q[i] = base_product_mod(&r->base_B, &r->base_q.base[i]);
+
+    r->inv_prod_q_mod_Bsk = (orc_mulop*)malloc(base_Bsk_size * sizeof(orc_mulop));
+    r->inv_m_tilde_mod_Bsk = (orc_mulop*)malloc(base_Bsk_size * sizeof(orc_mulop));
+    r->prod_q_mod_Bsk = (uint64_t*)malloc(base_Bsk_size * sizeof(uint64_t));
+    for (size_t i = 0; i < base_Bsk_size; i++) {
+        const orc_modulus* modulus = &r->base_Bsk.base[i];
+        uint64_t temp = base_product_mod(&r->base_q, modulus), inv = 0;
+        r->prod_q_mod_Bsk[i] = temp;
+        if (!orc_try_invert_mod(temp, modulus, &inv)) { orc_rns_tool_destroy(r); return NULL; }
+        orc_mulop_init(&r->inv_prod_q_mod_Bsk[i], inv, modulus);
+        if (!orc_try_invert_mod(orc_barrett_reduce64(m_tilde_value, modulus), modulus, &inv)) { orc_rns_tool_destroy(r); return NULL; }
+        orc_mulop_init(&r->inv_m_tilde_mod_Bsk[i], inv, modulus);
+    }
+    {
+        uint64_t temp = base_product_mod(&r->base_B, &r->m_sk), inv = 0;
+        if (!orc_try_invert_mod(temp, &r->m_sk, &inv)) { orc_rns_tool_destroy(r); return NULL; }
+        orc_mulop_init(&r->inv_prod_B_mod_m_sk, inv, &r->m_sk);
+        temp = base_product_mod(&r->base_q, &r->m_tilde);
+        if (!orc_try_invert_mod(temp, &r->m_tilde, &inv)) { orc_rns_tool_destroy(r); return NULL; }
+        orc_mulop_init(&r->neg_inv_prod_q_mod_m_tilde, orc_negate_mod(inv, &r->m_tilde), &r->m_tilde);
+    }
+    /* q[last]^-1 mod q[i], :225-236 */
+    if (q_size > 1) {
+        r->inv_q_last_mod_q = (orc_mulop*)malloc((q_size - 1) * sizeof(orc_mulop));
+        uint64_t last_q = q[q_size - 1];
+        for (size_t i = 0; i + 1 < q_size; i++) {
+            uint64_t inv = 0;
+            if (!orc_try_invert_mod(last_q, &r->base_q.base[i], &inv)) { orc_rns_tool_destroy(r); return NULL; }
+            orc_mulop_init(&r->inv_q_last_mod_q[i], inv, &r->base_q.base[i]);
+        }
+    }
+    r->q_last_half = q[q_size - 1] >> 1;
+    /* Bsk NTT tables :97-101 (all Bsk primes are = 1 mod 2N by construction) */
+    r->Bsk_ntt_tables = (orc_ntt_tables**)calloc(base_Bsk_size, sizeof(orc_ntt_tables*));
+    for (size_t i = 0; i < base_Bsk_size; i++) {
+        r->Bsk_ntt_tables[i] = orc_ntt_tables_create(coeff_count_power, Bsk_values[i]);
+        if (!r->Bsk_ntt_tables[i]) { orc_rns_tool_destroy(r); return NULL; }
+    }
+    return r;
+}
+
+void orc_rns_tool_destroy(orc_rns_tool* r) {
+    if (!r) return;
+    rns_base_free(&r->base_q); rns_base_free(&r->base_B); rns_base_free(&r->base_Bsk);
+    base_converter_free(&r->q_to_Bsk); base_converter_free(&r->q_to_m_tilde);
+    base_converter_free(&r->B_to_q); base_converter_free(&r->B_to_m_sk);
+    free(r->prod_B_mod_q); free(r->inv_prod_q_mod_Bsk); free(r->inv_m_tilde_mod_Bsk);
+    free(r->prod_q_mod_Bsk); free(r->inv_q_last_mod_q);
+    if (r->Bsk_ntt_tables) {
+        for (size_t i = 0; i < r->Bsk_size; i++) orc_ntt_tables_destroy(r->Bsk_ntt_tables[i]);
+        free(r->Bsk_ntt_tables);
+    }
+    free(r);
+}
+
+size_t orc_rns_tool_base_B_size(const orc_rns_tool* r) { return r->B_size; }
+size_t orc_rns_tool_base_Bsk_size(const orc_rns_tool* r) { return r->Bsk_size; }
+uint64_t orc_rns_tool_m_sk(const orc_rns_tool* r) { return r->m_sk.value; }
+uint64_t orc_rns_tool_gamma(const orc_rns_tool* r) { return r->gamma.value; }
+uint64_t orc_rns_tool_m_tilde(const orc_rns_tool* r) { return r->m_tilde.value; }
+void orc_rns_tool_base_Bsk(const orc_rns_tool* r, uint64_t* out) {
+    for (size_t i = 0; i < r->Bsk_size; i++) out[i] = r->base_Bsk.base[i].value;
+}
+uint64_t orc_rns_tool_inv_q_last_mod_q(const orc_rns_tool* r, size_t i, int want_quotient) {
+    return want_quotient ? r->inv_q_last_mod_q[i].quotient : r->inv_q_last_mod_q[i].operand;
+}
+
+void orc_rns_fast_b_conv_m_tilde(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest) {
+    /* utils/rns_tool.cu:1083-1094 */
+    size_t n = r->coeff_count;
+    uint64_t* temp = (uint64_t*)malloc(r->q_size * n * sizeof(uint64_t));
+    orc_multiply_scalar_ps(input, r->m_tilde.value, 1, n, r->base_q.base, r->q_size, temp);
+    fast_convert_array(&r->q_to_Bsk, temp, n, dest);
+    fast_convert_array(&r->q_to_m_tilde, temp, n, dest + r->Bsk_size * n);
+    free(temp);
+}
+
+void orc_rns_sm_mrq(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest) {
+    /* utils/rns_tool.cu:870-905 host_sm_mrq */
+    size_t n = r->coeff_count, bsk = r->Bsk_size;
+    const uint64_t* input_m_tilde = input + bsk * n;
+    uint64_t m_tilde_div_2 = r->m_tilde.value >> 1;
+    for (size_t j = 0; j < n; j++) {
+        uint64_t r_m_tilde = orc_mulop_mod(input_m_tilde[j], &r->neg_inv_prod_q_mod_m_tilde, &r->m_tilde);
+        for (size_t i = 0; i < bsk; i++) {
+            const orc_modulus* modulus = &r->base_Bsk.base[i];
+            orc_mulop prod_q_mod_Bsk_elt;
+            orc_mulop_init(&prod_q_mod_Bsk_elt, r->prod_q_mod_Bsk[i], modulus);
+            uint64_t temp = r_m_tilde;
+            if (temp >= m_tilde_div_2) temp += modulus->value - r->m_tilde.value;
+            /* multiply_uint64operand_add_uint64_mod, uint_small_mod.h:199-210 */
+            uint64_t mad = orc_add_mod(orc_mulop_mod(temp, &prod_q_mod_Bsk_elt, modulus),
+                                       orc_barrett_reduce64(input[i * n + j], modulus), modulus);
+            dest[i * n + j] = orc_mulop_mod(mad, &r->inv_m_tilde_mod_Bsk[i], modulus);
+        }
+    }
+}
+
+void orc_rns_fast_floor(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest) {
+    /* utils/rns_tool.cu:1010-1036 + host_fast_floor :973-988 */
+    size_t n = r->coeff_count, qs = r->q_size, bsk = r->Bsk_size;
+    fast_convert_array(&r->q_to_Bsk, input, n, dest);
+    const uint64_t* in_bsk = input + qs * n;
+    for (size_t i = 0; i < bsk; i++) {
+        const orc_modulus* modulus = &r->base_Bsk.base[i];
+        for (size_t j = 0; j < n; j++) {
+            size_t index = i * n + j;
+            dest[index] = orc_mulop_mod(in_bsk[index] + modulus->value - dest[index], &r->inv_prod_q_mod_Bsk[i], modulus);
+        }
+    }
+}
+
+void orc_rns_fast_b_conv_sk(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest) {
+    /* utils/rns_tool.cu:831-868 + host_fast_b_conv_sk_step1 :762-790 */
+    size_t n = r->coeff_count, bs = r->B_size, qs = r->q_size;
+    fast_convert_array(&r->B_to_q, input, n, dest);
+    uint64_t* temp = (uint64_t*)malloc(n * sizeof(uint64_t));
+    fast_convert_array(&r->B_to_m_sk, input, n, temp);
+    uint64_t m_sk_value = r->m_sk.value, m_sk_div_2 = m_sk_value >> 1;
+    for (size_t j = 0; j < n; j++) {
+        uint64_t alpha_sk = orc_mulop_mod(temp[j] + (m_sk_value - input[bs * n + j]), &r->inv_prod_B_mod_m_sk, &r->m_sk);
+        for (size_t i = 0; i < qs; i++) {
+            const orc_modulus* modulus = &r->base_q.base[i];
+            orc_mulop prod_elt, neg_prod_elt;
+            orc_mulop_init(&prod_elt, r->prod_B_mod_q[i], modulus);
+            orc_mulop_init(&neg_prod_elt, modulus->value - r->prod_B_mod_q[i], modulus);
+            uint64_t* d = &dest[i * n + j];
+            if (alpha_sk > m_sk_div_2) {
+                *d = orc_add_mod(orc_mulop_mod(orc_negate_mod(alpha_sk, &r->m_sk), &prod_elt, modulus),
+                                 orc_barrett_reduce64(*d, modulus), modulus);
+            } else {
+                *d = orc_add_mod(orc_mulop_mod(alpha_sk, &neg_prod_elt, modulus),
+                                 orc_barrett_reduce64(*d, modulus), modulus);
+            }
+        }
+    }
+    free(temp);
+}
+
+void orc_rns_fast_b_conv_m_tilde_sm_mrq(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest) {
+    /* utils/rns_tool.cu:1096-1104 host branch */
+    size_t n = r->coeff_count;
+    uint64_t* temp = (uint64_t*)malloc((r->Bsk_size + 1) * n * sizeof(uint64_t));
+    orc_rns_fast_b_conv_m_tilde(r, input, temp);
+    orc_rns_sm_mrq(r, temp, dest);
+    free(temp);
+}
+
+void orc_rns_fast_floor_fast_b_conv_sk(const orc_rns_tool* r, const uint64_t* in_q, const uint64_t* in_Bsk, size_t dest_size, uint64_t* dest) {
+    /* utils/rns_tool.cu:1038-1075 host branch */
+    size_t n = r->coeff_count, qs = r->q_size, bsk = r->Bsk_size;
+    uint64_t* temp_q_Bsk = (uint64_t*)malloc((qs + bsk) * n * sizeof(uint64_t));
+    uint64_t* temp_Bsk = (uint64_t*)malloc(bsk * n * sizeof(uint64_t));
+    uint64_t t = r->t.value;
+    for (size_t i = 0; i < dest_size; i++) {
+        orc_multiply_scalar_ps(in_q + i * n * qs, t, 1, n, r->base_q.base, qs, temp_q_Bsk);
+        orc_multiply_scalar_ps(in_Bsk + i * n * bsk, t, 1, n, r->base_Bsk.base, bsk, temp_q_Bsk + qs * n);
+        orc_rns_fast_floor(r, temp_q_Bsk, temp_Bsk);
+        orc_rns_fast_b_conv_sk(r, temp_Bsk, dest + i * n * qs);
+    }
+    free(temp_q_Bsk);
+    free(temp_Bsk);
+}
+
+void orc_rns_divide_and_round_q_last(const orc_rns_tool* r, const uint64_t* input, size_t pcount, uint64_t* dest) {
+    /* utils/rns_tool.cu:421-466 host branch */
+    size_t n = r->coeff_count, qs = r->q_size;
+    uint64_t half = r->q_last_half;
+    const orc_modulus* last = &r->base_q.base[qs - 1];
+    for (size_t p = 0; p < pcount; p++) {
+        size_t poffset = p * n * qs, doffset = p * n * (qs - 1);
+        const uint64_t* input_last = input + poffset + (qs - 1) * n;
+        for (size_t i = 0; i + 1 < qs; i++) {
+            const orc_modulus* modulus = &r->base_q.base[i];
+            uint64_t half_mod = orc_barrett_reduce64(half, modulus);
+            for (size_t j = 0; j < n; j++) {
+                uint64_t translated = orc_add_mod(input_last[j], half, last);          /* add_scalar */
+                uint64_t temp = orc_barrett_reduce64(translated, modulus);             /* modulo */
+                temp = orc_sub_mod(temp, half_mod, modulus);                           /* sub_scalar_inplace */
+                uint64_t d = orc_sub_mod(input[poffset + i * n + j], temp, modulus);   /* sub */
+                dest[doffset + i * n + j] = orc_mulop_mod(d, &r->inv_q_last_mod_q[i], modulus);
+            }
+        }
+    }
+}
+
+void orc_rns_divide_and_round_q_last_ntt(const orc_rns_tool* r, const uint64_t* input, size_t pcount, uint64_t* dest,
+                                          const orc_ntt_tables* const* tables) {
+    /* utils/rns_tool.cu:664-694 host branch (INTT of the last limb only) + step1 :499-521 + step2 :586-605 */
+    size_t n = r->coeff_count, qs = r->q_size;
+    size_t log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    const orc_modulus* last_modulus = &r->base_q.base[qs - 1];
+    uint64_t* input_last = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint64_t* temp = (uint64_t*)malloc((qs - 1) * n * sizeof(uint64_t));
+    for (size_t p = 0; p < pcount; p++) {
+        size_t poffset = p * n * qs, offset = p * n * (qs - 1);
+        memcpy(input_last, input + poffset + (qs - 1) * n, n * sizeof(uint64_t));
+        orc_ntt_inverse(input_last, 1, 1, log_n, &tables[qs - 1], 1, ORC_IDX_COMPONENTWISE, 0);
+        /* step1 */
+        for (size_t j = 0; j < n; j++) input_last[j] = orc_add_mod(input_last[j], r->q_last_half, last_modulus);
+        for (size_t i = 0; i + 1 < qs; i++) {
+            const orc_modulus* modulus = &r->base_q.base[i];
+            uint64_t* temp_i = temp + i * n;
+            uint64_t half_mod = orc_barrett_reduce64(r->q_last_half, modulus);
+            for (size_t j = 0; j < n; j++) {
+                uint64_t v = (modulus->value < last_modulus->value) ? orc_barrett_reduce64(input_last[j], modulus) : input_last[j];
+                temp_i[j] = orc_sub_mod(v, half_mod, modulus);
+            }
+        }
+        orc_ntt_forward(temp, 1, qs - 1, log_n, tables, qs - 1, ORC_IDX_COMPONENTWISE, 0);
+        /* step2 */
+        for (size_t i = 0; i + 1 < qs; i++) {
+            const orc_modulus* modulus = &r->base_q.base[i];
+            uint64_t qi_lazy = modulus->value << 2;
+            for (size_t j = 0; j < n; j++) {
+                uint64_t d = orc_add_mod(input[poffset + i * n + j], qi_lazy, modulus);
+                d = orc_sub_mod(d, temp[i * n + j], modulus);
+                dest[offset + i * n + j] = orc_mulop_mod(d, &r->inv_q_last_mod_q[i], modulus);
+            }
+        }
+    }
+    free(input_last);
+    free(temp);
+}
+
+/* ====================================================================================== */
+/* context                                                                                 */
+/* ====================================================================================== */
+
+struct orc_context {
+    int scheme;
+    size_t n, log_n, K;
+    uint64_t plain_modulus;
+    orc_modulus* key_modulus;      /* [K] */
+    orc_ntt_tables** ntt_tables;   /* [K] key-level small_ntt_tables */
+    orc_rns_tool** rns_tools;      /* index = nlimbs (1..K) */
+};
+
+orc_context* orc_context_create(int scheme, size_t n, const uint64_t* coeff_modulus, size_t K, uint64_t plain_modulus) {
+    /* he_context.cu:46-123: key level (K limbs), then the chain obtained by dropping the last
+     * prime repeatedly; every level owns an RNSTool (context_data.cu:322) built from ITS primes. */
+    orc_context* c = (orc_context*)calloc(1, sizeof(*c));
+    c->scheme = scheme; c->n = n; c->K = K; c->plain_modulus = plain_modulus;
+    while (((size_t)1 << c->log_n) < n) c->log_n++;
+    c->key_modulus = (orc_modulus*)calloc(K, sizeof(orc_modulus));
+    c->ntt_tables = (orc_ntt_tables**)calloc(K, sizeof(void*));
+    c->rns_tools = (orc_rns_tool**)calloc(K + 1, sizeof(void*));
+    for (size_t i = 0; i < K; i++) {
+        if (orc_modulus_init(&c->key_modulus[i], coeff_modulus[i]) != 0) { orc_context_destroy(c); return NULL; }
+        c->ntt_tables[i] = orc_ntt_tables_create(c->log_n, coeff_modulus[i]);
+        if (!c->ntt_tables[i]) { orc_context_destroy(c); return NULL; }
+    }
+    uint64_t t = (scheme == ORC_SCHEME_CKKS) ? 0 : plain_modulus;
+    for (size_t nl = 1; nl <= K; nl++) {
+        c->rns_tools[nl] = orc_rns_tool_create(n, coeff_modulus, nl, t);
+        if (!c->rns_tools[nl]) { orc_context_destroy(c); return NULL; }
+    }
+    return c;
+}
+
+void orc_context_destroy(orc_context* c) {
+    if (!c) return;
+    if (c->ntt_tables) for (size_t i = 0; i < c->K; i++) orc_ntt_tables_destroy(c->ntt_tables[i]);
+    if (c->rns_tools) for (size_t i = 0; i <= c->K; i++) orc_rns_tool_destroy(c->rns_tools[i]);
+    free(c->ntt_tables); free(c->rns_tools); free(c->key_modulus);
+    free(c);
+}
+
+size_t orc_context_key_modulus_size(const orc_context* c) { return c->K; }
+const orc_ntt_tables* orc_context_ntt_table(const orc_context* c, size_t i) { return c->ntt_tables[i]; }
+const orc_rns_tool* orc_context_rns_tool(const orc_context* c, size_t nlimbs) { return c->rns_tools[nlimbs]; }
+const orc_modulus* orc_context_moduli(const orc_context* c) { return c->key_modulus; }
+
+void orc_transform_to_ntt(const orc_context* c, uint64_t* ct, size_t pcount, size_t L) {
+    /* evaluator_transform_ntt.cu:525-538 -> utils::ntt_inplace_ps */
+    orc_ntt_forward(ct, pcount, L, c->log_n, (const orc_ntt_tables* const*)c->ntt_tables, L, ORC_IDX_COMPONENTWISE, 0);
+}
+
+void orc_transform_from_ntt(const orc_context* c, uint64_t* ct, size_t pcount, size_t L) {
+    /* evaluator_transform_ntt.cu:621-634 -> utils::intt_inplace_ps */
+    orc_ntt_inverse(ct, pcount, L, c->log_n, (const orc_ntt_tables* const*)c->ntt_tables, L, ORC_IDX_COMPONENTWISE, 0);
+}
+
+void orc_switch_key(const orc_context* c, size_t L, int is_ntt_form, const uint64_t* target,
+                    const uint64_t* const* keys, int assign_method, uint64_t* destination) {
+    /* evaluator_keyswitching_core.cu:757-1052, HOST branches (:833-902 and :923-985);
+     * BGV (ski_util5) is not restated. */
+    const size_t coeff_count = c->n, log_n = c->log_n;
+    const size_t decomp_modulus_size = L;
+    const orc_modulus* key_modulus = c->key_modulus;
+    const size_t key_modulus_size = c->K;
+    const size_t rns_modulus_size = decomp_modulus_size + 1;
+    const orc_ntt_tables* const* key_ntt_tables = (const orc_ntt_tables* const*)c->ntt_tables;
+    const orc_mulop* modswitch_factors = c->rns_tools[c->K]->inv_q_last_mod_q; /* key level rns_tool, :788 */
+    const size_t key_component_count = 2;
+    const int is_ckks = (c->scheme == ORC_SCHEME_CKKS);
+
+    uint64_t* target_copied_buf = (uint64_t*)malloc(decomp_modulus_size * coeff_count * sizeof(uint64_t));
+    const uint64_t* target_copied;
+    if (is_ntt_form) {
+        /* :817-821 intt_p over the first L key tables */
+        memcpy(target_copied_buf, target, decomp_modulus_size * coeff_count * sizeof(uint64_t));
+        orc_ntt_inverse(target_copied_buf, 1, decomp_modulus_size, log_n, key_ntt_tables, decomp_modulus_size, ORC_IDX_COMPONENTWISE, 0);
+        target_copied = target_copied_buf;
+    } else {
+        target_copied = target;
+    }
+
+    uint64_t* poly_prod = (uint64_t*)malloc(key_component_count * rns_modulus_size * coeff_count * sizeof(uint64_t));
+    u128* poly_lazy = (u128*)malloc(key_component_count * coeff_count * sizeof(u128));
+    uint64_t* temp_ntt = (uint64_t*)malloc((decomp_modulus_size > 0 ? decomp_modulus_size : 1) * coeff_count * sizeof(uint64_t));
+
+    for (size_t i = 0; i < rns_modulus_size; i++) {
+        size_t key_index = (i == decomp_modulus_size ? key_modulus_size - 1 : i);
+        const orc_modulus* km = &key_modulus[key_index];
+        size_t lazy_reduction_summand_bound = 256; /* HE_MULTIPLY_ACCUMULATE_USER_MOD_MAX, constants.h:27 */
+        size_t lazy_reduction_counter = lazy_reduction_summand_bound;
+        memset(poly_lazy, 0, key_component_count * coeff_count * sizeof(u128));
+        for (size_t j = 0; j < decomp_modulus_size; j++) {
+            const uint64_t* temp_operand;
+            if (is_ntt_form && (i == j)) {
+                temp_operand = target + j * coeff_count;
+            } else {
+                if (key_modulus[j].value <= km->value) {
+                    memcpy(temp_ntt, target_copied + j * coeff_count, coeff_count * sizeof(uint64_t));
+                } else {
+                    for (size_t x = 0; x < coeff_count; x++) temp_ntt[x] = orc_barrett_reduce64(target_copied[j * coeff_count + x], km);
+                }
+                orc_ntt_forward(temp_ntt, 1, 1, log_n, &key_ntt_tables[key_index], 1, ORC_IDX_COMPONENTWISE, 0);
+                temp_operand = temp_ntt;
+            }
+            size_t key_poly_coeff_size = key_modulus_size * coeff_count;
+            const uint64_t* key_vector_j = keys[j];
+            for (size_t x = 0; x < coeff_count; x++) {
+                for (size_t k = 0; k < key_component_count; k++) {
+                    u128 qword = (u128)temp_operand[x] * key_vector_j[k * key_poly_coeff_size + key_index * coeff_count + x];
+                    qword += poly_lazy[k * coeff_count + x];
+                    if (!lazy_reduction_counter) {
+                        /* ski_util1 :42-60 */
+                        poly_lazy[k * coeff_count + x] = orc_barrett_reduce128((uint64_t)qword, (uint64_t)(qword >> 64), km);
+                    } else {
+                        /* ski_util2 :98-115 */
+                        poly_lazy[k * coeff_count + x] = qword;
+                    }
+                }
+            }
+            lazy_reduction_counter -= 1;
+            if (lazy_reduction_counter == 0) lazy_reduction_counter = lazy_reduction_summand_bound;
+        }
+        uint64_t* t_poly_prod_iter = poly_prod + i * coeff_count;
+        for (size_t x = 0; x < coeff_count; x++) {
+            for (size_t k = 0; k < key_component_count; k++) {
+                u128 acc = poly_lazy[k * coeff_count + x];
+                if (lazy_reduction_counter == lazy_reduction_summand_bound) {
+                    /* ski_util3 :146-160 */
+                    t_poly_prod_iter[k * coeff_count * rns_modulus_size + x] = (uint64_t)acc;
+                } else {
+                    /* ski_util4 :190-205 */
+                    t_poly_prod_iter[k * coeff_count * rns_modulus_size + x] = orc_barrett_reduce128((uint64_t)acc, (uint64_t)(acc >> 64), km);
+                }
+            }
+        }
+    }
+
+    /* :923-985 host tail (non-BGV) */
+    uint64_t* t_ntt = (uint64_t*)malloc(decomp_modulus_size * coeff_count * sizeof(uint64_t));
+    const orc_modulus* qk = &key_modulus[key_modulus_size - 1];
+    for (size_t i = 0; i < key_component_count; i++) {
+        int add_inplace = (assign_method == ORC_ASSIGN_ADD_INPLACE) || (i == 0 && assign_method == ORC_ASSIGN_OVERWRITE_EXCEPT_FIRST);
+        uint64_t* t_last = poly_prod + coeff_count * rns_modulus_size * i + decomp_modulus_size * coeff_count;
+        orc_ntt_inverse(t_last, 1, 1, log_n, &key_ntt_tables[key_modulus_size - 1], 1, ORC_IDX_COMPONENTWISE, 0);
+        /* ski_util6 :367-385 */
+        uint64_t qk_half = qk->value >> 1;
+        for (size_t x = 0; x < coeff_count; x++) {
+            t_last[x] = orc_barrett_reduce64(t_last[x] + qk_half, qk);
+            for (size_t j = 0; j < decomp_modulus_size; j++) {
+                const orc_modulus* qi = &key_modulus[j];
+                uint64_t v = (qk->value > qi->value) ? orc_barrett_reduce64(t_last[x], qi) : t_last[x];
+                uint64_t fix = qi->value - orc_barrett_reduce64(qk_half, qi);
+                t_ntt[j * coeff_count + x] = v + fix;
+            }
+        }
+        uint64_t* t_poly_prod_i = poly_prod + i * coeff_count * rns_modulus_size;
+        if (is_ntt_form) {
+            orc_ntt_forward(t_ntt, 1, decomp_modulus_size, log_n, key_ntt_tables, decomp_modulus_size, ORC_IDX_COMPONENTWISE, 0);
+        } else {
+            orc_ntt_inverse(t_poly_prod_i, 1, decomp_modulus_size, log_n, key_ntt_tables, decomp_modulus_size, ORC_IDX_COMPONENTWISE, 0);
+        }
+        /* ski_util7 :718-740 */
+        uint64_t* destination_i = destination + i * decomp_modulus_size * coeff_count;
+        for (size_t x = 0; x < coeff_count; x++) {
+            for (size_t j = 0; j < decomp_modulus_size; j++) {
+                uint64_t qi = key_modulus[j].value;
+                uint64_t d = t_poly_prod_i[j * coeff_count + x];
+                d += (is_ckks ? (qi << 2) : (qi << 1)) - t_ntt[j * coeff_count + x];
+                d = orc_mulop_mod(d, &modswitch_factors[j], &key_modulus[j]);
+                if (add_inplace) destination_i[j * coeff_count + x] = orc_add_mod(destination_i[j * coeff_count + x], d, &key_modulus[j]);
+                else destination_i[j * coeff_count + x] = d;
+            }
+        }
+    }
+    free(t_ntt); free(temp_ntt); free(poly_lazy); free(poly_prod); free(target_copied_buf);
+}
+
+void orc_relinearize(const orc_context* c, size_t L, int is_ntt_form, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2) {
+    /* evaluator_keyswitching.cu:119-144 relinearize_internal (P=3 -> 2): destination is a zeroed
+     * 2-poly ciphertext, switch_key(target = poly 2, Overwrite), then add c0,c1 (:143). */
+    size_t pc = L * c->n;
+    orc_switch_key(c, L, is_ntt_form, ct3 + 2 * pc, keys, ORC_ASSIGN_OVERWRITE, out2);
+    orc_add_ps(out2, ct3, 2, c->n, c->key_modulus, L, out2);
+}
+
+void orc_ckks_multiply(const orc_context* c, size_t L, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out) {
+    /* evaluator.cu:118-144 */
+    orc_dyadic_convolute(a, b, pa, pb, c->key_modulus, L, c->n, out);
+}
+
+void orc_bfv_multiply(const orc_context* c, size_t L, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out) {
+    /* evaluator.cu:29-116 (BEHZ) */
+    const orc_rns_tool* rt = c->rns_tools[L];
+    size_t n = c->n, log_n = c->log_n, bsk = rt->Bsk_size;
+    size_t dest_size = pa + pb - 1;
+    const orc_ntt_tables* const* q_tables = (const orc_ntt_tables* const*)c->ntt_tables;
+    const orc_ntt_tables* const* bsk_tables = (const orc_ntt_tables* const*)rt->Bsk_ntt_tables;
+    uint64_t* a_q = (uint64_t*)malloc(pa * L * n * 8);
+    uint64_t* a_Bsk = (uint64_t*)malloc(pa * bsk * n * 8);
+    uint64_t* b_q = (uint64_t*)malloc(pb * L * n * 8);
+    uint64_t* b_Bsk = (uint64_t*)malloc(pb * bsk * n * 8);
+    memcpy(a_q, a, pa * L * n * 8);
+    orc_ntt_forward(a_q, pa, L, log_n, q_tables, L, ORC_IDX_COMPONENTWISE, 0);
+    for (size_t i = 0; i < pa; i++) orc_rns_fast_b_conv_m_tilde_sm_mrq(rt, a + i * L * n, a_Bsk + i * bsk * n);
+    orc_ntt_forward(a_Bsk, pa, bsk, log_n, bsk_tables, bsk, ORC_IDX_COMPONENTWISE, 0);
+    memcpy(b_q, b, pb * L * n * 8);
+    orc_ntt_forward(b_q, pb, L, log_n, q_tables, L, ORC_IDX_COMPONENTWISE, 0);
+    for (size_t i = 0; i < pb; i++) orc_rns_fast_b_conv_m_tilde_sm_mrq(rt, b + i * L * n, b_Bsk + i * bsk * n);
+    orc_ntt_forward(b_Bsk, pb, bsk, log_n, bsk_tables, bsk, ORC_IDX_COMPONENTWISE, 0);
+
+    uint64_t* d_q = (uint64_t*)malloc(dest_size * L * n * 8);
+    uint64_t* d_Bsk = (uint64_t*)malloc(dest_size * bsk * n * 8);
+    orc_dyadic_convolute(a_q, b_q, pa, pb, rt->base_q.base, L, n, d_q);
+    orc_dyadic_convolute(a_Bsk, b_Bsk, pa, pb, rt->base_Bsk.base, bsk, n, d_Bsk);
+    orc_ntt_inverse(d_q, dest_size, L, log_n, q_tables, L, ORC_IDX_COMPONENTWISE, 0);
+    orc_ntt_inverse(d_Bsk, dest_size, bsk, log_n, bsk_tables, bsk, ORC_IDX_COMPONENTWISE, 0);
+    orc_rns_fast_floor_fast_b_conv_sk(rt, d_q, d_Bsk, dest_size, out);
+    free(a_q); free(a_Bsk); free(b_q); free(b_Bsk); free(d_q); free(d_Bsk);
+}
+
+void orc_mod_switch_scale_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out) {
+    /* evaluator_modswitch.cu:14-74 */
+    const orc_rns_tool* rt = c->rns_tools[L];
+    if (c->scheme == ORC_SCHEME_CKKS) {
+        orc_rns_divide_and_round_q_last_ntt(rt, in, pcount, out, (const orc_ntt_tables* const*)c->ntt_tables);
+    } else {
+        orc_rns_divide_and_round_q_last(rt, in, pcount, out);
+    }
+}
+
+void orc_mod_switch_drop_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out) {
+    /* evaluator_modswitch.cu:164-220: copy the first L-1 limbs of every polynomial */
+    size_t n = c->n;
+    for (size_t p = 0; p < pcount; p++)
+        memcpy(out + p * (L - 1) * n, in + p * L * n, (L - 1) * n * sizeof(uint64_t));
+}
+
+/* ====================================================================================== */
+/* test utilities                                                                          */
+/* ====================================================================================== */
+
+void orc_fill_uniform(uint64_t seed, uint64_t bound, uint64_t* out, size_t n) {
+    uint64_t s = seed;
+    for (size_t i = 0; i < n; i++) {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[i] = bound ? (uint64_t)(((u128)z * bound) >> 64) : z;
+    }
+}
+
+uint64_t orc_fnv1a64(const uint64_t* data, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n * 8; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}

@@ -1,0 +1,179 @@
+/*
+ * troy_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY).
+ *
+ * A plain-C restatement of the *host* (CPU) algorithms of lightbulb128/troy-nova's
+ * RNS-RLWE hot path: modular arithmetic, NTT tables, negacyclic NTT/INTT, RNS dyadic
+ * products, key switching, modulus switching / CKKS rescale and the BEHZ BFV multiply.
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference checkout's src/ directory).
+ *
+ * This library is the CHECKER.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (troy-nova_amd/) never links, imports or
+ * calls anything in this directory; it fails loudly when its HIP library is missing.
+ *
+ * Parity pinning: the reference is CUDA (.cu sources that need nvcc + libcudart, neither
+ * of which exists in this image), so it is UNBUILDABLE here and oracle/_ref is not
+ * provided.  The oracle is pinned against the reference's own known-answer tests
+ * (test/utils/ntt.cu, test/modulus.cu, test/utils/uint_small_mod.cu,
+ * test/utils/rns_base.cu, test/utils/rns_tool.cu) re-typed as data in tests/golden/, and
+ * against the values recorded in SURVEY.md (prime chains, BEHZ auxiliary primes).
+ */
+#ifndef TROY_ORACLE_H
+#define TROY_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar layer ------------------------------------------------------------------ */
+
+/* modulus.h:8-124 (class Modulus) */
+typedef struct {
+    uint64_t value;
+    uint64_t const_ratio[3]; /* floor(2^128/value) lo, hi ; 2^128 mod value */
+    uint64_t bit_count;
+    int32_t is_prime;
+    int32_t pad_;
+} orc_modulus;
+
+/* utils/uint_small_mod.h:92-122 (struct MultiplyUint64Operand) */
+typedef struct {
+    uint64_t operand;
+    uint64_t quotient;
+} orc_mulop;
+
+int orc_modulus_init(orc_modulus* m, uint64_t value); /* modulus.cu:7-32; -1 on invalid */
+uint64_t orc_barrett_reduce64(uint64_t x, const orc_modulus* m);             /* modulus.h:22-42 */
+uint64_t orc_barrett_reduce128(uint64_t lo, uint64_t hi, const orc_modulus* m); /* modulus.h:44-78 */
+uint64_t orc_multiply_mod(uint64_t a, uint64_t b, const orc_modulus* m);    /* uint_small_mod.h:85-90 */
+uint64_t orc_add_mod(uint64_t a, uint64_t b, const orc_modulus* m);         /* uint_small_mod.h:54-61 */
+uint64_t orc_sub_mod(uint64_t a, uint64_t b, const orc_modulus* m);         /* uint_small_mod.h:64-72 */
+uint64_t orc_negate_mod(uint64_t a, const orc_modulus* m);                  /* uint_small_mod.h:30-36 */
+void orc_mulop_init(orc_mulop* o, uint64_t operand, const orc_modulus* m);   /* uint_small_mod.h:97-113 */
+uint64_t orc_mulop_mod(uint64_t x, const orc_mulop* y, const orc_modulus* m);      /* :130-139 */
+uint64_t orc_mulop_mod_lazy(uint64_t x, const orc_mulop* y, const orc_modulus* m); /* :142-148 */
+uint64_t orc_exponentiate_mod(uint64_t a, uint64_t e, const orc_modulus* m);       /* :215-231 */
+int orc_try_invert_mod(uint64_t a, const orc_modulus* m, uint64_t* out);           /* basics.h try_invert_uint64_mod */
+uint64_t orc_dot_product_mod(const uint64_t* a, const uint64_t* b, size_t n, const orc_modulus* m); /* :251-261 */
+int orc_is_prime(uint64_t value);                                             /* uint_small_mod.h:264-301 */
+
+/* utils/number_theory.cu:22-39 ; returns number of primes written (== count) or -1 */
+int orc_get_primes(uint64_t factor, size_t bit_size, size_t count, uint64_t* out);
+/* coeff_modulus.cu:65-108 */
+int orc_coeff_modulus_create(size_t poly_modulus_degree, const size_t* bit_sizes, size_t n, uint64_t* out);
+/* utils/number_theory.cu:68-87 */
+int orc_try_minimal_primitive_root(uint64_t degree, const orc_modulus* m, uint64_t* out);
+
+/* ---- NTT --------------------------------------------------------------------------- */
+
+/* utils/ntt.h:12-87, utils/ntt.cu:14-76 */
+typedef struct {
+    uint64_t root;
+    size_t coeff_count_power;
+    size_t coeff_count;
+    orc_modulus modulus;
+    orc_mulop inv_degree_modulo;
+    orc_mulop* root_powers;     /* [coeff_count], bit-reversed order */
+    orc_mulop* inv_root_powers; /* [coeff_count], scrambled order */
+} orc_ntt_tables;
+
+orc_ntt_tables* orc_ntt_tables_create(size_t coeff_count_power, uint64_t modulus);
+void orc_ntt_tables_destroy(orc_ntt_tables* t);
+uint64_t orc_ntt_tables_root(const orc_ntt_tables* t);
+uint64_t orc_ntt_tables_root_power(const orc_ntt_tables* t, size_t i, int inverse, int want_quotient);
+uint64_t orc_ntt_tables_inv_degree(const orc_ntt_tables* t, int want_quotient);
+
+/* utils/ntt.h:89-130 NTTTableIndexer modes */
+enum { ORC_IDX_COMPONENTWISE = 0, ORC_IDX_KS_SET_PRODUCTS = 1, ORC_IDX_KS_SKIP_FINALS = 2 };
+
+/* fgk/ntt_grouped.cu:11-56 + :258-270 (host branch): in-place forward negacyclic NTT over
+ * data[pcount][component_count][N]; tables = array of `n_tables` pointers. */
+void orc_ntt_forward(uint64_t* data, size_t pcount, size_t component_count, size_t log_degree,
+                     const orc_ntt_tables* const* tables, size_t n_tables, int indexer_mode, size_t decomp_size);
+/* fgk/ntt_grouped.cu:346-391 + :597-610 (host branch) */
+void orc_ntt_inverse(uint64_t* data, size_t pcount, size_t component_count, size_t log_degree,
+                     const orc_ntt_tables* const* tables, size_t n_tables, int indexer_mode, size_t decomp_size);
+
+/* ---- element-wise RNS polynomial ops (utils/poly_small_mod.cu host_* loops) ---------- */
+void orc_add_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_sub_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_negate_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_modulo_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_multiply_scalar_ps(const uint64_t* a, uint64_t scalar, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_dyadic_product_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+/* fgk/dyadic_convolute.cu:43-80 (host branch) / :116-140 */
+void orc_dyadic_convolute(const uint64_t* a, const uint64_t* b, size_t pa, size_t pb, const orc_modulus* moduli, size_t nmod, size_t degree, uint64_t* out);
+void orc_dyadic_square(const uint64_t* a, const orc_modulus* moduli, size_t nmod, size_t degree, uint64_t* out);
+
+/* ---- RNS tool (utils/rns_base.cu, utils/rns_tool.cu) -------------------------------- */
+typedef struct orc_rns_tool orc_rns_tool;
+orc_rns_tool* orc_rns_tool_create(size_t poly_modulus_degree, const uint64_t* q, size_t q_size, uint64_t t);
+void orc_rns_tool_destroy(orc_rns_tool* r);
+size_t orc_rns_tool_base_B_size(const orc_rns_tool* r);
+size_t orc_rns_tool_base_Bsk_size(const orc_rns_tool* r);
+uint64_t orc_rns_tool_m_sk(const orc_rns_tool* r);
+uint64_t orc_rns_tool_gamma(const orc_rns_tool* r);
+uint64_t orc_rns_tool_m_tilde(const orc_rns_tool* r);
+void orc_rns_tool_base_Bsk(const orc_rns_tool* r, uint64_t* out);
+uint64_t orc_rns_tool_inv_q_last_mod_q(const orc_rns_tool* r, size_t i, int want_quotient);
+/* generic BaseConverter::fast_convert_array, utils/rns_base.cu:350-380, exposed for KATs */
+void orc_fast_convert_array(const uint64_t* ibase, size_t ni, const uint64_t* obase, size_t no,
+                            const uint64_t* input, size_t count, uint64_t* output);
+void orc_rns_fast_b_conv_m_tilde(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest); /* rns_tool.cu:1083-1094 */
+void orc_rns_sm_mrq(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest);              /* :870-905 */
+void orc_rns_fast_floor(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest);          /* :973-988,:1010-1036 */
+void orc_rns_fast_b_conv_sk(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest);      /* :762-790,:831-868 */
+void orc_rns_fast_b_conv_m_tilde_sm_mrq(const orc_rns_tool* r, const uint64_t* input, uint64_t* dest); /* :1096-1104 */
+void orc_rns_fast_floor_fast_b_conv_sk(const orc_rns_tool* r, const uint64_t* in_q, const uint64_t* in_Bsk, size_t dest_size, uint64_t* dest); /* :1038-1075 */
+/* rns_tool.cu:421-466 (host branch): in [pcount][L][N] -> out [pcount][L-1][N] */
+void orc_rns_divide_and_round_q_last(const orc_rns_tool* r, const uint64_t* input, size_t pcount, uint64_t* dest);
+/* rns_tool.cu:664-694 (host branch); tables = the level's L tables */
+void orc_rns_divide_and_round_q_last_ntt(const orc_rns_tool* r, const uint64_t* input, size_t pcount, uint64_t* dest,
+                                          const orc_ntt_tables* const* tables);
+
+/* ---- context: modulus chain (he_context.cu:46-123, context_data.cu:71-345) ------------ */
+enum { ORC_SCHEME_BFV = 1, ORC_SCHEME_CKKS = 2, ORC_SCHEME_BGV = 3 };
+typedef struct orc_context orc_context;
+/* coeff_modulus = full key-level chain (K primes, last = special prime when K > 1). */
+orc_context* orc_context_create(int scheme, size_t poly_modulus_degree, const uint64_t* coeff_modulus, size_t K, uint64_t plain_modulus);
+void orc_context_destroy(orc_context* c);
+size_t orc_context_key_modulus_size(const orc_context* c);
+const orc_ntt_tables* orc_context_ntt_table(const orc_context* c, size_t i);
+/* level is addressed by its number of limbs `nlimbs` (K for the key level, K-1 for the first data level, ...) */
+const orc_rns_tool* orc_context_rns_tool(const orc_context* c, size_t nlimbs);
+const orc_modulus* orc_context_moduli(const orc_context* c);
+
+/* evaluator_transform_ntt.cu:525-538 / :621-634 : ct[pcount][L][N] in place */
+void orc_transform_to_ntt(const orc_context* c, uint64_t* ct, size_t pcount, size_t L);
+void orc_transform_from_ntt(const orc_context* c, uint64_t* ct, size_t pcount, size_t L);
+
+/* SwitchKeyDestinationAssignMethod, evaluator.h */
+enum { ORC_ASSIGN_ADD_INPLACE = 0, ORC_ASSIGN_OVERWRITE = 1, ORC_ASSIGN_OVERWRITE_EXCEPT_FIRST = 2 };
+/* evaluator_keyswitching_core.cu:757-1052 (host branches :833-902, :923-985).
+ * target[L][N]; keys[j] (j < L) -> u64[2][K][N] NTT form; destination[2][L][N]. */
+void orc_switch_key(const orc_context* c, size_t L, int is_ntt_form, const uint64_t* target,
+                    const uint64_t* const* keys, int assign_method, uint64_t* destination);
+/* evaluator_keyswitching.cu:96-144: ct[3][L][N] -> out[2][L][N] (relinearize_new) */
+void orc_relinearize(const orc_context* c, size_t L, int is_ntt_form, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2);
+/* evaluator.cu:118-144 ckks_multiply : a[pa][L][N] x b[pb][L][N] -> out[pa+pb-1][L][N] */
+void orc_ckks_multiply(const orc_context* c, size_t L, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out);
+/* evaluator.cu:29-116 bfv_multiply (BEHZ) */
+void orc_bfv_multiply(const orc_context* c, size_t L, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out);
+/* evaluator_modswitch.cu:14-74 : BFV -> divide_and_round_q_last ; CKKS -> _ntt ; in[p][L][N] -> out[p][L-1][N] */
+void orc_mod_switch_scale_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out);
+/* evaluator_modswitch.cu:164-220 mod_switch_drop_to_next (CKKS mod_switch_to_next): drop last limb */
+void orc_mod_switch_drop_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out);
+
+/* deterministic 64-bit generator used by tests/bench to make identical inputs on both sides
+ * (splitmix64; NOT the reference's AES PRNG) ; fills out[i] uniformly in [0, bound) */
+void orc_fill_uniform(uint64_t seed, uint64_t bound, uint64_t* out, size_t n);
+/* FNV-1a-64 over the little-endian bytes of a u64 stream (SURVEY.md Appendix C digest) */
+uint64_t orc_fnv1a64(const uint64_t* data, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
