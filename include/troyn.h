@@ -1,0 +1,176 @@
+/*
+ * troyn.h -- C-ABI of the MI355X-native RNS-RLWE hot path (libtroyn.so).
+ *
+ * This is the drop-in boundary for the data-parallel hot path of lightbulb128/troy-nova:
+ * negacyclic NTT/INTT, RNS dyadic multiply/add, key switching (relinearize), modulus
+ * switching / CKKS rescale, and the BEHZ BFV multiply.  The reference has no FFI layer for
+ * this path (its device code is reached by `if (on_device()) kernel<<<>>>` branches inside
+ * C++ functions), so every entry point below names the reference C++
+ * function (file:line under the reference's src/) whose *device branch* it replaces.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes only.  All polynomial data are DEVICE pointers to uint64_t in
+ *    the reference layout data[(p*L + l)*N + i] (ciphertext.h:211-247), canonical residues.
+ *  - every op takes `batch` independent items laid out contiguously ([batch][...]) unless a
+ *    stride is given explicitly; batch = 1 reproduces the reference's single-object calls,
+ *    batch > 1 replaces its `*_batched` pointer-table variants (box_batch.h:231-257).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue
+ *    work; they never synchronise and never allocate device memory.  Temporaries come from a
+ *    caller-supplied workspace (size from the matching *_workspace_bytes query), which is how
+ *    the reference's MemoryPool plugs in.
+ *  - return value: 0 = success; > 0 = hipError_t from the runtime; < 0 = TROYN_E_* below.
+ *    troyn_last_error() returns a thread-local message (the C++ mirror turns negative codes
+ *    into std::invalid_argument and positive codes into std::runtime_error, matching
+ *    kernel_provider.h:11-16 and the reference's "[Class::method] ..." messages).
+ */
+#ifndef TROYN_H
+#define TROYN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TROYN_VERSION 1
+
+enum {
+    TROYN_OK = 0,
+    TROYN_E_INVALID = -1,     /* bad argument (sizes, null pointers, unsupported N) */
+    TROYN_E_MODULUS = -2,     /* modulus not usable (not < 2^61, no 2N-th root, not coprime) */
+    TROYN_E_WORKSPACE = -3,   /* workspace too small */
+    TROYN_E_UNSUPPORTED = -4  /* scheme / shape not implemented */
+};
+
+typedef void* troyn_stream_t;
+typedef struct troyn_plan troyn_plan;
+typedef struct troyn_behz troyn_behz;
+
+const char* troyn_last_error(void);
+int troyn_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Plan = device-resident mirror of one modulus chain: for each of the `n_moduli` primes
+ * (key level order, special prime last) the Modulus constants (modulus.h:8-124), the
+ * NTTTables (utils/ntt.h:12-87, built exactly as utils/ntt.cu:14-76 does: minimal primitive
+ * 2N-th root, bit-reversed psi powers, scrambled inverse powers, N^-1) and, for every level
+ * L <= n_moduli, q_{L-1}^-1 mod q_i (RNSTool::inv_q_last_mod_q, utils/rns_tool.cu:225-236).
+ * Replaces ContextData::to_device_inplace (context_data.cu:34-69).
+ * `roots` may be NULL (roots are then searched as number_theory.cu:68-87 does) or hold the
+ * reference's NTTTables::root() per modulus.
+ * ------------------------------------------------------------------------------------- */
+int troyn_plan_create(troyn_plan** plan, int device, uint32_t log_n, uint32_t n_moduli,
+                      const uint64_t* moduli, const uint64_t* roots);
+int troyn_plan_destroy(troyn_plan* plan);
+uint32_t troyn_plan_log_n(const troyn_plan* plan);
+uint32_t troyn_plan_n_moduli(const troyn_plan* plan);
+/* host copies of table contents, for known-answer checks: out[2*i] = operand, out[2*i+1] = quotient */
+int troyn_plan_get_root(const troyn_plan* plan, uint32_t modulus_index, uint64_t* root);
+int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t modulus_index, int inverse, uint64_t* out);
+
+/* NTTTableIndexer modes (utils/ntt.h:89-130) */
+enum { TROYN_IDX_COMPONENTWISE = 0, TROYN_IDX_KS_SET_PRODUCTS = 1, TROYN_IDX_KS_SKIP_FINALS = 2 };
+
+/* ---------------------------------------------------------------------------------------
+ * troyn_ntt: negacyclic NTT (inverse = 0; natural -> bit-reversed, canonical output) or INTT
+ * (inverse = 1; includes the N^-1 scaling) of batch*pcount*ncomp limb-polynomials.
+ * Replaces the device branches of fgk::ntt_grouped::ntt / intt (fgk/ntt_grouped.cu:258-295,
+ * :597-640) and their _batched forms, i.e. utils::ntt_ps / intt_ps / *_inplace_* /
+ * *_b* (utils/ntt.h:164-391).  in == out is allowed.  Component j of polynomial k uses table
+ * `table_start + get(k, j)` where get() is NTTTableIndexer::get over a slice of
+ * `table_count` tables (utils/ntt.h:105-124).
+ * ------------------------------------------------------------------------------------- */
+int troyn_ntt(const troyn_plan* plan, int inverse, const uint64_t* in, uint64_t* out,
+              size_t batch, size_t pcount, size_t ncomp,
+              uint32_t table_start, uint32_t table_count, int indexer_mode, uint32_t decomp_size,
+              troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Element-wise RNS polynomial ops over count*nmod limb-polynomials ([count][nmod][N]); limb l
+ * uses modulus mod_start + l.  Replace the device branches of utils::add_ps / sub_ps /
+ * negate_ps / multiply_scalar_ps / dyadic_product_ps (utils/poly_small_mod.cu:243-304,
+ * :306-365, :182-241, :653-714, :816-900).
+ * ------------------------------------------------------------------------------------- */
+int troyn_add(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
+              uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_sub(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
+              uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_negate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a,
+                 uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_multiply_scalar(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, uint64_t scalar,
+                          uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_dyadic_product(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
+                         uint64_t* out, size_t count, troyn_stream_t stream);
+
+/* fgk::dyadic_convolute::dyadic_convolute (fgk/dyadic_convolute.cu:43-90): a[pa][nmod][N] x
+ * b[pb][nmod][N] -> out[pa+pb-1][nmod][N], per batch item.  CKKS/BGV multiply is exactly this
+ * (evaluator.cu:118-173). */
+int troyn_dyadic_convolute(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod,
+                           const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out,
+                           size_t batch, troyn_stream_t stream);
+/* fgk::dyadic_convolute::dyadic_square (fgk/dyadic_convolute.cu:116-150) */
+int troyn_dyadic_square(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod,
+                        const uint64_t* a, uint64_t* out, size_t batch, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Key switching core: Evaluator::switch_key_internal(_batched)
+ * (evaluator_keyswitching_core.cu:757-1052, :1055-1267), device branch, BFV/CKKS.
+ *   L            decomposition size = limbs of the data level (L <= n_moduli - 1)
+ *   target       [batch][L][N]   polynomial to switch (NTT form iff is_ntt_form)
+ *   keys         host array of L DEVICE pointers, keys[j] -> u64[2][K][N] in NTT form
+ *                (KSwitchKeys::get_data_ptrs, kswitch_keys.h:34-54); shared by the batch
+ *   destination  [batch][2][L][N], written or accumulated per `assign_method`
+ *                (SwitchKeyDestinationAssignMethod, evaluator.h)
+ * ------------------------------------------------------------------------------------- */
+enum { TROYN_ASSIGN_ADD_INPLACE = 0, TROYN_ASSIGN_OVERWRITE = 1, TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST = 2 };
+size_t troyn_switch_key_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch);
+int troyn_switch_key(const troyn_plan* plan, uint32_t L, int is_ckks, int is_ntt_form,
+                     const uint64_t* target, const uint64_t* const* keys, int assign_method,
+                     uint64_t* destination, void* workspace, size_t workspace_bytes,
+                     size_t batch, troyn_stream_t stream);
+
+/* Evaluator::relinearize_internal for a 3-polynomial ciphertext (evaluator_keyswitching.cu:
+ * 119-144): ct[batch][3][L][N] -> out[batch][2][L][N] = switch_key(ct[2], Overwrite) + ct[0..2). */
+size_t troyn_relinearize_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch);
+int troyn_relinearize(const troyn_plan* plan, uint32_t L, int is_ckks, int is_ntt_form,
+                      const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2,
+                      void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Modulus switching.
+ * troyn_divide_and_round_q_last      RNSTool::divide_and_round_q_last (utils/rns_tool.cu:374-466),
+ *                                    BFV mod_switch_to_next, coefficient form.
+ * troyn_divide_and_round_q_last_ntt  RNSTool::divide_and_round_q_last_ntt (utils/rns_tool.cu:499-694),
+ *                                    CKKS rescale_to_next, NTT form.
+ * troyn_mod_switch_drop              kernel_mod_switch_drop_to (evaluator_modswitch.cu:164-171).
+ * in [batch][pcount][L][N] -> out [batch][pcount][L-1][N] (drop: [L_out]).
+ * ------------------------------------------------------------------------------------- */
+int troyn_divide_and_round_q_last(const troyn_plan* plan, uint32_t L, const uint64_t* in, size_t pcount,
+                                  uint64_t* out, size_t batch, troyn_stream_t stream);
+size_t troyn_divide_and_round_q_last_ntt_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t pcount, size_t batch);
+int troyn_divide_and_round_q_last_ntt(const troyn_plan* plan, uint32_t L, const uint64_t* in, size_t pcount,
+                                      uint64_t* out, void* workspace, size_t workspace_bytes,
+                                      size_t batch, troyn_stream_t stream);
+int troyn_mod_switch_drop(const troyn_plan* plan, uint32_t L_in, uint32_t L_out, const uint64_t* in, size_t pcount,
+                          uint64_t* out, size_t batch, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BEHZ BFV multiply: Evaluator::bfv_multiply (evaluator.cu:29-116) with the RNSTool of the level
+ * holding the first L plan moduli and plain modulus t (RNSTool ctor utils/rns_tool.cu:29-275;
+ * fused device kernels fgk/rns_tool.cu:7-100, :147-286).  a[batch][pa][L][N] x b[batch][pb][L][N]
+ * (coefficient form) -> out[batch][pa+pb-1][L][N].
+ * ------------------------------------------------------------------------------------- */
+int troyn_behz_create(troyn_behz** behz, const troyn_plan* plan, uint32_t L, uint64_t plain_modulus);
+int troyn_behz_destroy(troyn_behz* behz);
+uint32_t troyn_behz_base_Bsk_size(const troyn_behz* behz);
+int troyn_behz_get_base_Bsk(const troyn_behz* behz, uint64_t* out); /* host copy, KAT hook */
+size_t troyn_bfv_multiply_workspace_bytes(const troyn_behz* behz, size_t pa, size_t pb, size_t batch);
+int troyn_bfv_multiply(const troyn_behz* behz, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb,
+                       uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TROYN_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libtroyn.so (the C-ABI in include/troyn.h).
+
+PyTorch is used only as plumbing: device buffers (int64 storage reinterpreted as uint64),
+streams and torch.distributed.  Nothing here computes on the CPU, and there is no fallback:
+if the HIP library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtroyn.so")
+
+u64 = C.c_uint64
+u32 = C.c_uint32
+sz = C.c_size_t
+vp = C.c_void_p
+p64 = C.POINTER(C.c_uint64)
+
+# every symbol include/troyn.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "troyn_last_error": (C.c_char_p, []),
+    "troyn_version": (C.c_int, []),
+    "troyn_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, u32, u32, p64, p64]),
+    "troyn_plan_destroy": (C.c_int, [vp]),
+    "troyn_plan_log_n": (u32, [vp]),
+    "troyn_plan_n_moduli": (u32, [vp]),
+    "troyn_plan_get_root": (C.c_int, [vp, u32, p64]),
+    "troyn_plan_get_root_powers": (C.c_int, [vp, u32, C.c_int, p64]),
+    "troyn_ntt": (C.c_int, [vp, C.c_int, vp, vp, sz, sz, sz, u32, u32, C.c_int, u32, vp]),
+    "troyn_add": (C.c_int, [vp, u32, u32, vp, vp, vp, sz, vp]),
+    "troyn_sub": (C.c_int, [vp, u32, u32, vp, vp, vp, sz, vp]),
+    "troyn_negate": (C.c_int, [vp, u32, u32, vp, vp, sz, vp]),
+    "troyn_multiply_scalar": (C.c_int, [vp, u32, u32, vp, u64, vp, sz, vp]),
+    "troyn_dyadic_product": (C.c_int, [vp, u32, u32, vp, vp, vp, sz, vp]),
+    "troyn_dyadic_convolute": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp, sz, vp]),
+    "troyn_dyadic_square": (C.c_int, [vp, u32, u32, vp, vp, sz, vp]),
+    "troyn_switch_key_workspace_bytes": (sz, [vp, u32, sz]),
+    "troyn_switch_key": (C.c_int, [vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), C.c_int, vp, vp, sz, sz, vp]),
+    "troyn_relinearize_workspace_bytes": (sz, [vp, u32, sz]),
+    "troyn_relinearize": (C.c_int, [vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), vp, vp, sz, sz, vp]),
+    "troyn_divide_and_round_q_last": (C.c_int, [vp, u32, vp, sz, vp, sz, vp]),
+    "troyn_divide_and_round_q_last_ntt_workspace_bytes": (sz, [vp, u32, sz, sz]),
+    "troyn_divide_and_round_q_last_ntt": (C.c_int, [vp, u32, vp, sz, vp, vp, sz, sz, vp]),
+    "troyn_mod_switch_drop": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp]),
+    "troyn_behz_create": (C.c_int, [C.POINTER(vp), vp, u32, u64]),
+    "troyn_behz_destroy": (C.c_int, [vp]),
+    "troyn_behz_base_Bsk_size": (u32, [vp]),
+    "troyn_behz_get_base_Bsk": (C.c_int, [vp, p64]),
+    "troyn_bfv_multiply_workspace_bytes": (sz, [vp, sz, sz, sz]),
+    "troyn_bfv_multiply": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, sz, sz, vp]),
+}
+
+_lib = None
+
+
+class TroynError(RuntimeError):
+    """Runtime (HIP) failure -- the reference throws std::runtime_error (kernel_provider.h:11-16)."""
+
+
+class TroynInvalidArgument(ValueError):
+    """API misuse -- the reference throws std::invalid_argument("[Class::method] ...")."""
+
+
+def lib():
+    """Load libtroyn.so; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TroynError(
+            "libtroyn.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().troyn_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise TroynInvalidArgument("%s (troyn code %d)" % (msg, rc))
+    raise TroynError("%s (hipError %d)" % (msg, rc))

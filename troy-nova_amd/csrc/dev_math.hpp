@@ -1,0 +1,72 @@
+// dev_math.hpp -- 64-bit modular arithmetic for gfx950 integer ALUs (no MFMA: this is not a
+// dense FP contraction).  Value semantics follow the reference's scalar layer:
+//   Barrett-64 / Barrett-128   modulus.h:22-78
+//   Shoup multiply (lazy/full) utils/uint_small_mod.h:130-148
+//   add/sub with ONE correction utils/uint_small_mod.h:54-72
+// so every canonical result is bit-identical to the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace troyn {
+
+typedef unsigned long long u64;  // matches ulonglong2 element type
+typedef unsigned __int128 u128;
+
+// Per-modulus constants resident in HBM (read through the scalar/vector caches).
+struct DevModulus {
+    u64 q;
+    u64 ratio_lo;   // floor(2^128/q) low word   (const_ratio[0])
+    u64 ratio_hi;   // floor(2^128/q) high word  (const_ratio[1])
+    u64 inv_n_op;   // N^-1 mod q                (NTTTables::inv_degree_modulo().operand)
+    u64 inv_n_quo;  //                            (.quotient)
+    u64 pad_[3];
+};
+
+__device__ __forceinline__ u64 mul_hi(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// multiply_uint64operand_mod_lazy: result in [0, 2q) for any 64-bit x
+__device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 wq, u64 q) { return w * x - mul_hi(x, wq) * q; }
+
+// multiply_uint64operand_mod: canonical
+__device__ __forceinline__ u64 shoup_mul(u64 x, u64 w, u64 wq, u64 q) {
+    u64 r = shoup_lazy(x, w, wq, q);
+    return r >= q ? r - q : r;
+}
+
+// Modulus::reduce (Barrett-64 with const_ratio[1])
+__device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 ratio_hi) {
+    u64 r = x - mul_hi(x, ratio_hi) * q;
+    return r >= q ? r - q : r;
+}
+
+// Modulus::reduce_uint128_limbs, same word-level sequence as modulus.h:44-78
+__device__ __forceinline__ u64 barrett128(u64 in0, u64 in1, u64 q, u64 r0, u64 r1) {
+    u64 carry = mul_hi(in0, r0);
+    u64 t2lo = in0 * r1, t2hi = mul_hi(in0, r1);
+    u64 tmp1 = t2lo + carry;
+    u64 tmp3 = t2hi + (tmp1 < t2lo ? 1ull : 0ull);
+    t2lo = in1 * r0; t2hi = mul_hi(in1, r0);
+    u64 tmp1b = tmp1 + t2lo;
+    carry = t2hi + (tmp1b < tmp1 ? 1ull : 0ull);
+    u64 quot = in1 * r1 + tmp3 + carry;
+    u64 r = in0 - quot * q;
+    return r >= q ? r - q : r;
+}
+
+__device__ __forceinline__ u64 mul_mod(u64 a, u64 b, const DevModulus& m) {
+    return barrett128(a * b, mul_hi(a, b), m.q, m.ratio_lo, m.ratio_hi);
+}
+
+__device__ __forceinline__ u64 add_mod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+__device__ __forceinline__ u64 sub_mod(u64 a, u64 b, u64 q) { u64 d = a - b; return a < b ? d + q : d; }
+__device__ __forceinline__ u64 neg_mod(u64 a, u64 q) { return a == 0 ? 0 : q - a; }
+
+// 128-bit accumulate helper for lazy dot products
+__device__ __forceinline__ void mac128(u64& lo, u64& hi, u64 a, u64 b) {
+    u64 pl = a * b, ph = mul_hi(a, b);
+    lo += pl;
+    hi += ph + (lo < pl ? 1ull : 0ull);
+}
+
+}  // namespace troyn

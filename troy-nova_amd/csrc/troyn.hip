@@ -1,0 +1,770 @@
+// troyn.hip -- libtroyn.so: plan management, launch logic and the extern "C" boundary
+// declared in include/troyn.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/troyn.h"
+#include "behz_kernels.hpp"
+#include "host_math.hpp"
+#include "ntt_kernels.hpp"
+#include "poly_kernels.hpp"
+
+using namespace troyn;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail((int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) return fail((int)e_, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* troyn_last_error(void) { return g_last_error.c_str(); }
+extern "C" int troyn_version(void) { return TROYN_VERSION; }
+
+// ---------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------
+struct troyn_plan {
+    int device = 0;
+    unsigned log_n = 0, n = 0, K = 0;
+    std::vector<u64> moduli;
+    std::vector<host::NttTable> tables;   // host copies (KAT hooks, BEHZ construction)
+    DevModulus* d_mods = nullptr;         // [K]
+    ulonglong2* d_fwd = nullptr;          // [K][N]
+    ulonglong2* d_inv = nullptr;          // [K][N]
+    ulonglong2* d_inv_last = nullptr;     // [(K+1)][K]: row L holds q_{L-1}^-1 mod q_i, i < L-1
+};
+
+static DevModulus make_dev_modulus(u64 q, unsigned log_n, bool with_inv_n) {
+    DevModulus m;
+    std::memset(&m, 0, sizeof(m));
+    m.q = q;
+    host::BarrettRatio r = host::barrett_ratio(q);
+    m.ratio_lo = r.lo; m.ratio_hi = r.hi;
+    if (with_inv_n) {
+        u64 ninv = 0;
+        if (host::invmod(((u64)1 << log_n) % q, q, ninv)) {
+            host::Shoup s = host::shoup(ninv, q);
+            m.inv_n_op = s.operand; m.inv_n_quo = s.quotient;
+        }
+    }
+    return m;
+}
+
+static int plan_upload(troyn_plan* p) {
+    const size_t K = p->K, n = p->n;
+    std::vector<DevModulus> mods(K);
+    for (size_t i = 0; i < K; i++) {
+        mods[i] = make_dev_modulus(p->moduli[i], p->log_n, true);
+        mods[i].inv_n_op = p->tables[i].inv_degree.operand;
+        mods[i].inv_n_quo = p->tables[i].inv_degree.quotient;
+    }
+    std::vector<ulonglong2> inv_last((K + 1) * K, make_ulonglong2(0, 0));
+    for (size_t L = 2; L <= K; L++) {
+        for (size_t i = 0; i + 1 < L; i++) {
+            u64 inv = 0;
+            if (!host::invmod(p->moduli[L - 1] % p->moduli[i], p->moduli[i], inv))
+                return fail(TROYN_E_MODULUS, "[troyn_plan_create] Unable to invert q[last] mod q[i].");
+            host::Shoup s = host::shoup(inv, p->moduli[i]);
+            inv_last[L * K + i] = make_ulonglong2(s.operand, s.quotient);
+        }
+    }
+    HIP_TRY(hipMalloc(&p->d_mods, K * sizeof(DevModulus)));
+    HIP_TRY(hipMalloc(&p->d_fwd, K * n * sizeof(ulonglong2)));
+    HIP_TRY(hipMalloc(&p->d_inv, K * n * sizeof(ulonglong2)));
+    HIP_TRY(hipMalloc(&p->d_inv_last, inv_last.size() * sizeof(ulonglong2)));
+    HIP_TRY(hipMemcpy(p->d_mods, mods.data(), K * sizeof(DevModulus), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < K; i++) {
+        static_assert(sizeof(host::Shoup) == sizeof(ulonglong2), "Shoup layout");
+        HIP_TRY(hipMemcpy(p->d_fwd + i * n, p->tables[i].fwd.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_inv + i * n, p->tables[i].inv.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(p->d_inv_last, inv_last.data(), inv_last.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
+    return TROYN_OK;
+}
+
+static void plan_free(troyn_plan* p) {
+    if (!p) return;
+    if (p->d_mods) (void)hipFree(p->d_mods);
+    if (p->d_fwd) (void)hipFree(p->d_fwd);
+    if (p->d_inv) (void)hipFree(p->d_inv);
+    if (p->d_inv_last) (void)hipFree(p->d_inv_last);
+    delete p;
+}
+
+extern "C" int troyn_plan_create(troyn_plan** plan, int device, uint32_t log_n, uint32_t n_moduli,
+                                 const uint64_t* moduli, const uint64_t* roots) {
+    if (!plan || !moduli) return fail(TROYN_E_INVALID, "[troyn_plan_create] null argument");
+    *plan = nullptr;
+    if (log_n < 1 || log_n > 17) return fail(TROYN_E_INVALID, "[troyn_plan_create] Invalid poly_modulus_degree.");
+    if (n_moduli < 1 || n_moduli > 64) return fail(TROYN_E_INVALID, "[troyn_plan_create] Invalid coeff modulus count.");
+    std::unique_ptr<troyn_plan, void (*)(troyn_plan*)> p(new troyn_plan, plan_free);
+    p->device = device; p->log_n = log_n; p->n = 1u << log_n; p->K = n_moduli;
+    p->moduli.assign(moduli, moduli + n_moduli);
+    for (uint32_t i = 0; i < n_moduli; i++) {
+        u64 q = moduli[i];
+        if ((q >> 61) != 0 || q < 2) return fail(TROYN_E_MODULUS, "[Modulus::set_value] Value can be at most 61-bit and cannot be 1.");
+        for (uint32_t j = 0; j < i; j++)
+            if (moduli[j] == q) return fail(TROYN_E_MODULUS, "[troyn_plan_create] coeff_modulus must be pairwise coprime.");
+        try {
+            p->tables.push_back(host::make_ntt_table(log_n, q, roots ? roots[i] : 0));
+        } catch (const std::exception& e) {
+            return fail(TROYN_E_MODULUS, e.what());
+        }
+    }
+    HIP_TRY(hipSetDevice(device));
+    int rc = plan_upload(p.get());
+    if (rc != TROYN_OK) return rc;
+    *plan = p.release();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_plan_destroy(troyn_plan* plan) {
+    plan_free(plan);
+    return TROYN_OK;
+}
+
+extern "C" uint32_t troyn_plan_log_n(const troyn_plan* plan) { return plan ? plan->log_n : 0; }
+extern "C" uint32_t troyn_plan_n_moduli(const troyn_plan* plan) { return plan ? plan->K : 0; }
+
+extern "C" int troyn_plan_get_root(const troyn_plan* plan, uint32_t mi, uint64_t* root) {
+    if (!plan || !root || mi >= plan->K) return fail(TROYN_E_INVALID, "[troyn_plan_get_root] bad argument");
+    *root = plan->tables[mi].root;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, int inverse, uint64_t* out) {
+    if (!plan || !out || mi >= plan->K) return fail(TROYN_E_INVALID, "[troyn_plan_get_root_powers] bad argument");
+    const auto& v = inverse ? plan->tables[mi].inv : plan->tables[mi].fwd;
+    for (size_t i = 0; i < v.size(); i++) { out[2 * i] = v[i].operand; out[2 * i + 1] = v[i].quotient; }
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// NTT launch
+// ---------------------------------------------------------------------------------------
+template <int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
+    const unsigned tiles = 1u << (LOGN - TB);
+    dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
+    hipLaunchKernelGGL((ntt_pass_kernel<LOGN, LO, G, TB, EB, INV, FIRST, LAST>), grid, block, 0, s, a);
+}
+
+// single pass: whole limb in one tile
+template <int LOGN, int EB>
+static void launch_single(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
+    if (inv) launch_pass<LOGN, 0, LOGN, LOGN, EB, true, true, true>(a, lp, s);
+    else launch_pass<LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
+}
+
+// two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks
+template <int LOGN, int TB, int EB>
+static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
+    constexpr int G1 = LOGN - TB;
+    NttArgs second = a;   // the second pass works in place on `out`
+    second.in = a.out;
+    second.in_bstride = a.out_bstride; second.in_pstride = a.out_pstride; second.in_cstride = a.out_cstride;
+    second.reduce_input = 0;
+    if (!inv) {
+        launch_pass<LOGN, 0, G1, TB, EB, false, true, false>(a, lp, s);
+        launch_pass<LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
+    } else {
+        launch_pass<LOGN, G1, TB, TB, EB, true, true, false>(a, lp, s);
+        launch_pass<LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
+    }
+}
+
+static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s) {
+    a.mods = p->d_mods;
+    a.tw = inverse ? p->d_inv : p->d_fwd;
+    const size_t lp = batch * a.pcount * a.ncomp;
+    if (lp == 0) return TROYN_OK;
+    if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
+        return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
+    switch (p->log_n) {
+        case 10: launch_single<10, 4>(a, lp, inverse, s); break;
+        case 11: launch_single<11, 4>(a, lp, inverse, s); break;
+        case 12: launch_single<12, 4>(a, lp, inverse, s); break;
+        case 13: launch_single<13, 4>(a, lp, inverse, s); break;
+        case 14: launch_single<14, 4>(a, lp, inverse, s); break;
+        case 15: launch_two_pass<15, 12, 4>(a, lp, inverse, s); break;
+        case 16: launch_two_pass<16, 12, 4>(a, lp, inverse, s); break;
+        case 17: launch_two_pass<17, 12, 4>(a, lp, inverse, s); break;
+        default:
+            hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)lp), dim3(256), 0, s, a, p->log_n, inverse ? 1 : 0);
+    }
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+static NttArgs contiguous_args(const troyn_plan* p, const u64* in, u64* out, size_t pcount, size_t ncomp,
+                               unsigned table_start, unsigned table_count, int mode, unsigned decomp) {
+    NttArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out;
+    a.in_cstride = a.out_cstride = p->n;
+    a.in_pstride = a.out_pstride = (long long)ncomp * p->n;
+    a.in_bstride = a.out_bstride = (long long)pcount * ncomp * p->n;
+    a.pcount = (unsigned)pcount; a.ncomp = (unsigned)ncomp;
+    a.table_start = table_start; a.table_count = table_count; a.mode = (unsigned)mode; a.decomp = decomp;
+    return a;
+}
+
+extern "C" int troyn_ntt(const troyn_plan* plan, int inverse, const uint64_t* in, uint64_t* out,
+                         size_t batch, size_t pcount, size_t ncomp,
+                         uint32_t table_start, uint32_t table_count, int indexer_mode, uint32_t decomp_size,
+                         troyn_stream_t stream) {
+    if (!plan || !in || !out) return fail(TROYN_E_INVALID, "[troyn_ntt] null argument");
+    if (table_count == 0 || table_start + table_count > plan->K)
+        return fail(TROYN_E_INVALID, "[troyn_ntt] table slice out of range");
+    if (indexer_mode == TROYN_IDX_COMPONENTWISE && ncomp > table_count)
+        return fail(TROYN_E_INVALID, "[troyn_ntt] more components than tables");
+    if (indexer_mode == TROYN_IDX_KS_SET_PRODUCTS && (pcount > decomp_size + 1 || decomp_size >= table_count + 0u + 1u))
+        return fail(TROYN_E_INVALID, "[troyn_ntt] bad KeySwitchingSetProducts shape");
+    if (indexer_mode == TROYN_IDX_KS_SKIP_FINALS && (ncomp > decomp_size + 1 || decomp_size > table_count))
+        return fail(TROYN_E_INVALID, "[troyn_ntt] bad KeySwitchingSkipFinals shape");
+    NttArgs a = contiguous_args(plan, (const u64*)in, (u64*)out, pcount, ncomp, table_start, table_count, indexer_mode, decomp_size);
+    return launch_ntt(plan, a, batch, inverse != 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// streaming ops
+// ---------------------------------------------------------------------------------------
+static inline unsigned chunks_pairs(unsigned n) { unsigned c = (n / 2 + POLY_BLOCK - 1) / POLY_BLOCK; return c ? c : 1; }
+static inline unsigned chunks_single(unsigned n) { unsigned c = (n + 255) / 256; return c ? c : 1; }
+
+static int check_rows(size_t rows, unsigned chunks) {
+    if (rows * chunks > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn] batch too large for one launch");
+    return TROYN_OK;
+}
+
+template <int OP>
+static int launch_elementwise(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
+                              uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t stream) {
+    if (!p || !a || !out || (OP != EW_NEG && OP != EW_MULS && !b)) return fail(TROYN_E_INVALID, "[troyn elementwise] null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[troyn elementwise] modulus slice out of range");
+    const size_t rows = count * nmod;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_pairs(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL((elementwise_kernel<OP>), dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->n, (const u64*)a, (const u64*)b, (u64)scalar, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_add(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    return launch_elementwise<EW_ADD>(p, ms, nm, a, b, 0, out, count, s);
+}
+extern "C" int troyn_sub(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    return launch_elementwise<EW_SUB>(p, ms, nm, a, b, 0, out, count, s);
+}
+extern "C" int troyn_negate(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, uint64_t* out, size_t count, troyn_stream_t s) {
+    return launch_elementwise<EW_NEG>(p, ms, nm, a, nullptr, 0, out, count, s);
+}
+extern "C" int troyn_multiply_scalar(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t s) {
+    return launch_elementwise<EW_MULS>(p, ms, nm, a, nullptr, scalar, out, count, s);
+}
+extern "C" int troyn_dyadic_product(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    return launch_elementwise<EW_MUL>(p, ms, nm, a, b, 0, out, count, s);
+}
+
+static int launch_convolute(const DevModulus* mods, unsigned n, uint32_t mod_start, uint32_t nmod,
+                            const u64* a, size_t pa, const u64* b, size_t pb, u64* out, size_t batch, hipStream_t s) {
+    const size_t rows = batch * nmod;
+    if (rows == 0) return TROYN_OK;
+    if (pa == 2 && pb == 2) {
+        const unsigned ch = chunks_pairs(n);
+        if (int rc = check_rows(rows, ch)) return rc;
+        hipLaunchKernelGGL((dyadic_convolute_kernel<2, 2>), dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, mods, mod_start, nmod, n, a, b, out);
+    } else if (pa == 3 && pb == 2) {
+        const unsigned ch = chunks_pairs(n);
+        if (int rc = check_rows(rows, ch)) return rc;
+        hipLaunchKernelGGL((dyadic_convolute_kernel<3, 2>), dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, mods, mod_start, nmod, n, a, b, out);
+    } else if (pa == 2 && pb == 3) {
+        const unsigned ch = chunks_pairs(n);
+        if (int rc = check_rows(rows, ch)) return rc;
+        hipLaunchKernelGGL((dyadic_convolute_kernel<2, 3>), dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, mods, mod_start, nmod, n, a, b, out);
+    } else {
+        const unsigned ch = chunks_single(n);
+        if (int rc = check_rows(rows, ch)) return rc;
+        hipLaunchKernelGGL(dyadic_convolute_generic_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, mods, mod_start, nmod, n,
+                           a, (unsigned)pa, b, (unsigned)pb, out);
+    }
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_dyadic_convolute(const troyn_plan* p, uint32_t mod_start, uint32_t nmod,
+                                      const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out,
+                                      size_t batch, troyn_stream_t stream) {
+    if (!p || !a || !b || !out) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] modulus slice out of range");
+    if (pa < 1 || pb < 1 || pa > 16 || pb > 16) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] Result size mismatch");
+    return launch_convolute(p->d_mods, p->n, mod_start, nmod, (const u64*)a, pa, (const u64*)b, pb, (u64*)out, batch, (hipStream_t)stream);
+}
+
+extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint32_t nmod,
+                                   const uint64_t* a, uint64_t* out, size_t batch, troyn_stream_t stream) {
+    if (!p || !a || !out) return fail(TROYN_E_INVALID, "[fgk::dyadic_square] null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[fgk::dyadic_square] modulus slice out of range");
+    const size_t rows = batch * nmod;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_pairs(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(dyadic_square_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->n, (const u64*)a, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// key switching
+// ---------------------------------------------------------------------------------------
+struct KsLayout {
+    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, total;  // element offsets
+};
+
+static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
+    const size_t n = p->n;
+    KsLayout w;
+    size_t off = 0;
+    w.target_intt = off; off += batch * L * n;
+    w.temp_ntt = off;    off += batch * (size_t)(L + 1) * L * n;
+    w.poly_prod = off;   off += batch * 2 * (size_t)(L + 1) * n;
+    w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
+    w.temp_last = off;   off += batch * 2 * (size_t)L * n;
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t troyn_switch_key_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch) {
+    if (!plan) return 0;
+    return ks_layout(plan, L, batch).total * sizeof(u64);
+}
+extern "C" size_t troyn_relinearize_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch) {
+    return troyn_switch_key_workspace_bytes(plan, L, batch);
+}
+
+// target: [batch] items of L limbs, `target_bstride` elements apart.
+static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_ntt_form,
+                           const u64* target, size_t target_bstride, const uint64_t* const* keys, int assign_method,
+                           u64* dest, const u64* addend, size_t addend_bstride,
+                           void* workspace, size_t workspace_bytes, size_t batch, hipStream_t s) {
+    const unsigned K = p->K, n = p->n;
+    if (K < 2) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
+    if (L < 1 || L > K - 1) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] Invalid target size.");
+    if (!target || !keys || !dest || !workspace) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null argument");
+    if (assign_method < 0 || assign_method > 2) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] bad assign method");
+    const KsLayout w = ks_layout(p, L, batch);
+    if (workspace_bytes < w.total * sizeof(u64)) return fail(TROYN_E_WORKSPACE, "[troyn_switch_key] workspace too small");
+    if (batch == 0) return TROYN_OK;
+    u64* ws = (u64*)workspace;
+    KeyPtrs kp;
+    std::memset(&kp, 0, sizeof(kp));
+    for (unsigned j = 0; j < L; j++) {
+        if (!keys[j]) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null key pointer");
+        kp.p[j] = (const u64*)keys[j];
+    }
+    int rc;
+    const u64* digits_src = target;
+    size_t digits_bstride = target_bstride;
+
+    // (1) NTT form: bring the target back to coefficient form (evaluator_keyswitching_core.cu:817-821)
+    if (is_ntt_form) {
+        NttArgs a = contiguous_args(p, target, ws + w.target_intt, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = (long long)target_bstride;
+        if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
+        digits_src = ws + w.target_intt;
+        digits_bstride = (size_t)L * n;
+    }
+    // (2) digit decomposition fused into the forward NTT (replaces kernel_set_accumulate, fgk/switch_key.cu:6-54,
+    //     + ntt_inplace_ps with key_switching_set_products, :907-908): row i = digits reduced mod q_key(i)
+    {
+        NttArgs a = contiguous_args(p, digits_src, ws + w.temp_ntt, L + 1, L, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
+        a.in_bstride = (long long)digits_bstride;
+        a.in_pstride = 0;            // every row re-reads the same L digits
+        a.reduce_input = 1;
+        if ((rc = launch_ntt(p, a, batch, false, s))) return rc;
+    }
+    // (3) <digits, key> inner product (fgk/switch_key.cu:83-154)
+    {
+        const unsigned ch = chunks_pairs(n);
+        const size_t rows = batch * (L + 1);
+        if ((rc = check_rows(rows, ch))) return rc;
+        hipLaunchKernelGGL(ks_accumulate_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, K, L, n, ws + w.temp_ntt, kp, ws + w.poly_prod);
+        LAUNCH_CHECK();
+    }
+    // (4) INTT: only the special-prime rows when the result stays in NTT form; all rows otherwise (:991-996)
+    const u64* last_src;
+    size_t last_stride;
+    const u64* prod_for_util7;
+    if (is_ntt_form) {
+        NttArgs a = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.prod_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_pstride = (long long)(L + 1) * n;
+        a.in_bstride = 2ll * (L + 1) * n;
+        if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
+        last_src = ws + w.prod_intt; last_stride = n;
+        prod_for_util7 = ws + w.poly_prod;
+    } else {
+        NttArgs a = contiguous_args(p, ws + w.poly_prod, ws + w.prod_intt, 2, L + 1, 0, K, TROYN_IDX_KS_SKIP_FINALS, L);
+        if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
+        last_src = ws + w.prod_intt + (size_t)L * n; last_stride = (size_t)(L + 1) * n;
+        prod_for_util7 = ws + w.prod_intt;
+    }
+    // (5) rounding fix of the special-prime component, per data limb (:570-598)
+    {
+        const unsigned ch = chunks_pairs(n);
+        const size_t rows = batch * 2 * L;
+        if ((rc = check_rows(rows, ch))) return rc;
+        hipLaunchKernelGGL(ks_util6_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, K, L, n, last_src, last_stride, ws + w.temp_last);
+        LAUNCH_CHECK();
+    }
+    // (6) back to NTT form when needed (:1033-1036)
+    if (is_ntt_form) {
+        NttArgs a = contiguous_args(p, ws + w.temp_last, ws + w.temp_last, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        if ((rc = launch_ntt(p, a, batch, false, s))) return rc;
+    }
+    // (7) divide by the special prime and assign (:625-658)
+    {
+        const unsigned ch = chunks_pairs(n);
+        const size_t rows = batch * 2 * L;
+        hipLaunchKernelGGL(ks_util7_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, L, L + 1, n, prod_for_util7, ws + w.temp_last,
+                           p->d_inv_last + (size_t)K * K, is_ckks, assign_method, dest, addend, addend_bstride);
+        LAUNCH_CHECK();
+    }
+    return TROYN_OK;
+}
+
+extern "C" int troyn_switch_key(const troyn_plan* plan, uint32_t L, int is_ckks, int is_ntt_form,
+                                const uint64_t* target, const uint64_t* const* keys, int assign_method,
+                                uint64_t* destination, void* workspace, size_t workspace_bytes,
+                                size_t batch, troyn_stream_t stream) {
+    if (!plan) return fail(TROYN_E_INVALID, "[troyn_switch_key] null plan");
+    return switch_key_impl(plan, L, is_ckks, is_ntt_form, (const u64*)target, (size_t)L * plan->n, keys, assign_method,
+                           (u64*)destination, nullptr, 0, workspace, workspace_bytes, batch, (hipStream_t)stream);
+}
+
+extern "C" int troyn_relinearize(const troyn_plan* plan, uint32_t L, int is_ckks, int is_ntt_form,
+                                 const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2,
+                                 void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    if (!plan || !ct3) return fail(TROYN_E_INVALID, "[Evaluator::relinearize_inplace_internal] null argument");
+    const size_t pc = (size_t)L * plan->n;
+    // relinearize_internal (evaluator_keyswitching.cu:119-144): switch_key(target = c2, Overwrite) then += (c0, c1)
+    return switch_key_impl(plan, L, is_ckks, is_ntt_form, (const u64*)ct3 + 2 * pc, 3 * pc, keys, TROYN_ASSIGN_OVERWRITE,
+                           (u64*)out2, (const u64*)ct3, 3 * pc, workspace, workspace_bytes, batch, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// modulus switching
+// ---------------------------------------------------------------------------------------
+extern "C" int troyn_divide_and_round_q_last(const troyn_plan* p, uint32_t L, const uint64_t* in, size_t pcount,
+                                             uint64_t* out, size_t batch, troyn_stream_t stream) {
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, "[RNSTool::divide_and_round_q_last] null argument");
+    if (L < 2 || L > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
+    const size_t items = batch * pcount, rows = items * (L - 1);
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_pairs(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(divide_round_q_last_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, L, p->n, (const u64*)in, p->d_inv_last + (size_t)L * p->K, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" size_t troyn_divide_and_round_q_last_ntt_workspace_bytes(const troyn_plan* p, uint32_t L, size_t pcount, size_t batch) {
+    if (!p || L < 1) return 0;
+    return batch * pcount * (size_t)L * p->n * sizeof(u64);   // last_intt [items][N] + temp [items][L-1][N]
+}
+
+extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L, const uint64_t* in, size_t pcount,
+                                                 uint64_t* out, void* workspace, size_t workspace_bytes,
+                                                 size_t batch, troyn_stream_t stream) {
+    if (!p || !in || !out || !workspace) return fail(TROYN_E_INVALID, "[RNSTool::divide_and_round_q_last_ntt] null argument");
+    if (L < 2 || L > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
+    if (workspace_bytes < troyn_divide_and_round_q_last_ntt_workspace_bytes(p, L, pcount, batch))
+        return fail(TROYN_E_WORKSPACE, "[troyn_divide_and_round_q_last_ntt] workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t items = batch * pcount, n = p->n;
+    if (items == 0) return TROYN_OK;
+    u64* last_intt = (u64*)workspace;
+    u64* temp = last_intt + items * n;
+    int rc;
+    // INTT of the last limb only (the reference's device branch transforms all L limbs, utils/rns_tool.cu:675)
+    {
+        NttArgs a = contiguous_args(p, (const u64*)in + (size_t)(L - 1) * n, last_intt, 1, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = (long long)L * n;
+        if ((rc = launch_ntt(p, a, items, true, s))) return rc;
+    }
+    const unsigned ch = chunks_pairs(p->n);
+    const size_t rows = items * (L - 1);
+    if ((rc = check_rows(rows, ch))) return rc;
+    hipLaunchKernelGGL(rescale_step1_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n, last_intt, temp);
+    LAUNCH_CHECK();
+    {
+        NttArgs a = contiguous_args(p, temp, temp, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+        if ((rc = launch_ntt(p, a, items, false, s))) return rc;
+    }
+    hipLaunchKernelGGL(rescale_step2_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n,
+                       (const u64*)in, temp, p->d_inv_last + (size_t)L * p->K, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_mod_switch_drop(const troyn_plan* p, uint32_t L_in, uint32_t L_out, const uint64_t* in, size_t pcount,
+                                     uint64_t* out, size_t batch, troyn_stream_t stream) {
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_drop_to_internal] null argument");
+    if (L_out < 1 || L_out > L_in || L_in > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_drop_to_next_internal] Next context data is not set.");
+    const size_t items = batch * pcount, rows = items * L_out;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_pairs(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(copy_limbs_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->n, (const u64*)in, (size_t)L_in * p->n, 0u, (u64*)out, (size_t)L_out * p->n, L_out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BEHZ
+// ---------------------------------------------------------------------------------------
+struct troyn_behz {
+    const troyn_plan* plan = nullptr;   // base q (first L moduli)
+    troyn_plan* aux = nullptr;          // Bsk primes (NTT tables for base Bsk, rns_tool.cu:97-101)
+    unsigned L = 0, Bn = 0, Bsk = 0;
+    u64 t = 0;
+    std::vector<u64> bsk_values;
+    u64* d_consts = nullptr;
+    BehzDev dev;
+};
+
+extern "C" int troyn_behz_destroy(troyn_behz* b) {
+    if (!b) return TROYN_OK;
+    if (b->aux) plan_free(b->aux);
+    if (b->d_consts) (void)hipFree(b->d_consts);
+    delete b;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint32_t L, uint64_t t) {
+    if (!out || !plan) return fail(TROYN_E_INVALID, "[troyn_behz_create] null argument");
+    *out = nullptr;
+    if (L < 1 || L > plan->K) return fail(TROYN_E_INVALID, "[RNSTool::RNSTool] RNSBase length is invalid.");
+    if (t == 0 || (t >> 61) != 0 || t == 1) return fail(TROYN_E_MODULUS, "[troyn_behz_create] BFV needs a plain modulus in [2, 2^61).");
+    std::unique_ptr<troyn_behz, int (*)(troyn_behz*)> b(new troyn_behz, troyn_behz_destroy);
+    b->plan = plan; b->L = L; b->t = t;
+    const unsigned n = plan->n;
+    std::vector<u64> q(plan->moduli.begin(), plan->moduli.begin() + L);
+    // auxiliary base sizes and primes: utils/rns_tool.cu:52-80
+    size_t total_bits = host::product_bit_count(q);
+    size_t Bn = L;
+    if (32 + host::bit_count(t) + total_bits >= 61 * (size_t)L + 61) Bn++;
+    const size_t Bsk = Bn + 1;
+    std::vector<u64> primes;
+    try {
+        primes = host::get_primes(2 * (u64)n, 61, Bsk + 1);
+    } catch (const std::exception& e) {
+        return fail(TROYN_E_MODULUS, e.what());
+    }
+    const u64 m_sk = primes[0];   // primes[1] = gamma (decrypt side only)
+    std::vector<u64> B(primes.begin() + 2, primes.begin() + 2 + Bn);
+    std::vector<u64> bsk = B; bsk.push_back(m_sk);
+    const u64 mt = (u64)1 << 32;
+    b->Bn = (unsigned)Bn; b->Bsk = (unsigned)Bsk; b->bsk_values = bsk;
+
+    int rc = troyn_plan_create(&b->aux, plan->device, plan->log_n, (uint32_t)Bsk, reinterpret_cast<const uint64_t*>(bsk.data()), nullptr);
+    if (rc != TROYN_OK) return rc;
+
+    // constant block: all tables in one allocation
+    std::vector<u64> blob;
+    auto push_shoup = [&](u64 w, u64 m) { host::Shoup s = host::shoup(w % m, m); blob.push_back(s.operand); blob.push_back(s.quotient); };
+    auto need_inv = [&](u64 a, u64 m, u64& o) { return host::invmod(a % m, m, o); };
+    size_t off_q_inv_punc = blob.size();
+    for (size_t i = 0; i < L; i++) {
+        u64 inv = 1;
+        if (L > 1 && !need_inv(host::product_mod(q, i, q[i]), q[i], inv)) return fail(TROYN_E_MODULUS, "[RNSBase::initialize] RNSBase product is not invertible.");
+        push_shoup(inv, q[i]);
+    }
+    size_t off_q_to_bsk = blob.size();
+    for (size_t bi = 0; bi < Bsk; bi++) for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, bsk[bi]));
+    size_t off_q_to_mt = blob.size();
+    for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, mt));
+    if (blob.size() & 1) blob.push_back(0);
+    size_t off_prod_q_mod_bsk = blob.size();
+    for (size_t bi = 0; bi < Bsk; bi++) push_shoup(host::product_mod(q, SIZE_MAX, bsk[bi]), bsk[bi]);
+    size_t off_inv_mt_mod_bsk = blob.size();
+    for (size_t bi = 0; bi < Bsk; bi++) {
+        u64 inv;
+        if (!need_inv(mt, bsk[bi], inv)) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert m_tilde.");
+        push_shoup(inv, bsk[bi]);
+    }
+    size_t off_inv_prod_q_mod_bsk = blob.size();
+    for (size_t bi = 0; bi < Bsk; bi++) {
+        u64 inv;
+        if (!need_inv(host::product_mod(q, SIZE_MAX, bsk[bi]), bsk[bi], inv)) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert base_q product.");
+        push_shoup(inv, bsk[bi]);
+    }
+    size_t off_B_inv_punc = blob.size();
+    for (size_t bi = 0; bi < Bn; bi++) {
+        u64 inv = 1;
+        if (Bn > 1 && !need_inv(host::product_mod(B, bi, B[bi]), B[bi], inv)) return fail(TROYN_E_MODULUS, "[RNSBase::initialize] RNSBase product is not invertible.");
+        push_shoup(inv, B[bi]);
+    }
+    size_t off_B_to_q = blob.size();
+    for (size_t i = 0; i < L; i++) for (size_t bi = 0; bi < Bn; bi++) blob.push_back(host::product_mod(B, bi, q[i]));
+    size_t off_B_to_msk = blob.size();
+    for (size_t bi = 0; bi < Bn; bi++) blob.push_back(host::product_mod(B, bi, m_sk));
+    if (blob.size() & 1) blob.push_back(0);
+    size_t off_prod_B_mod_q = blob.size();
+    for (size_t i = 0; i < L; i++) push_shoup(host::product_mod(B, SIZE_MAX, q[i]), q[i]);
+    size_t off_neg_prod_B_mod_q = blob.size();
+    for (size_t i = 0; i < L; i++) { u64 v = host::product_mod(B, SIZE_MAX, q[i]); push_shoup(q[i] - v, q[i]); }
+
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipMalloc(&b->d_consts, blob.size() * sizeof(u64)));
+    HIP_TRY(hipMemcpy(b->d_consts, blob.data(), blob.size() * sizeof(u64), hipMemcpyHostToDevice));
+
+    BehzDev& d = b->dev;
+    std::memset(&d, 0, sizeof(d));
+    d.L = L; d.Bn = (unsigned)Bn; d.Bsk = (unsigned)Bsk; d.n = n; d.t = t;
+    d.q_mods = plan->d_mods;
+    d.bsk_mods = b->aux->d_mods;
+    d.m_tilde = make_dev_modulus(mt, plan->log_n, false);
+    auto P2 = [&](size_t off) { return reinterpret_cast<const ulonglong2*>(b->d_consts + off); };
+    d.q_inv_punc = P2(off_q_inv_punc);
+    d.q_to_bsk = b->d_consts + off_q_to_bsk;
+    d.q_to_mt = b->d_consts + off_q_to_mt;
+    {
+        u64 inv;
+        if (!need_inv(host::product_mod(q, SIZE_MAX, mt), mt, inv)) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert base_q product.");
+        host::Shoup s = host::shoup((mt - inv) % mt, mt);
+        d.neg_inv_prod_q_mod_mt = make_ulonglong2(s.operand, s.quotient);
+        if (!need_inv(host::product_mod(B, SIZE_MAX, m_sk), m_sk, inv)) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert base_B product.");
+        s = host::shoup(inv, m_sk);
+        d.inv_prod_B_mod_msk = make_ulonglong2(s.operand, s.quotient);
+    }
+    d.prod_q_mod_bsk = P2(off_prod_q_mod_bsk);
+    d.inv_mt_mod_bsk = P2(off_inv_mt_mod_bsk);
+    d.inv_prod_q_mod_bsk = P2(off_inv_prod_q_mod_bsk);
+    d.B_inv_punc = P2(off_B_inv_punc);
+    d.B_to_q = b->d_consts + off_B_to_q;
+    d.B_to_msk = b->d_consts + off_B_to_msk;
+    d.prod_B_mod_q = P2(off_prod_B_mod_q);
+    d.neg_prod_B_mod_q = P2(off_neg_prod_B_mod_q);
+    *out = b.release();
+    return TROYN_OK;
+}
+
+extern "C" uint32_t troyn_behz_base_Bsk_size(const troyn_behz* b) { return b ? b->Bsk : 0; }
+extern "C" int troyn_behz_get_base_Bsk(const troyn_behz* b, uint64_t* out) {
+    if (!b || !out) return fail(TROYN_E_INVALID, "[troyn_behz_get_base_Bsk] null argument");
+    for (size_t i = 0; i < b->bsk_values.size(); i++) out[i] = b->bsk_values[i];
+    return TROYN_OK;
+}
+
+struct BehzLayout { size_t a_q, a_bsk, b_q, b_bsk, d_q, d_bsk, total; };
+static BehzLayout behz_layout(const troyn_behz* b, size_t pa, size_t pb, size_t batch) {
+    const size_t n = b->plan->n, L = b->L, S = b->Bsk, po = pa + pb - 1;
+    BehzLayout w; size_t off = 0;
+    w.a_q = off;   off += batch * pa * L * n;
+    w.a_bsk = off; off += batch * pa * S * n;
+    w.b_q = off;   off += batch * pb * L * n;
+    w.b_bsk = off; off += batch * pb * S * n;
+    w.d_q = off;   off += batch * po * L * n;
+    w.d_bsk = off; off += batch * po * S * n;
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t troyn_bfv_multiply_workspace_bytes(const troyn_behz* b, size_t pa, size_t pb, size_t batch) {
+    if (!b || pa < 1 || pb < 1) return 0;
+    return behz_layout(b, pa, pb, batch).total * sizeof(u64);
+}
+
+template <typename F4, typename F8, typename F16, typename F64>
+static void dispatch_bound(unsigned v, F4 f4, F8 f8, F16 f16, F64 f64) {
+    if (v <= 4) f4(); else if (v <= 8) f8(); else if (v <= 16) f16(); else f64();
+}
+
+extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_t pa, const uint64_t* b_, size_t pb,
+                                  uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    if (!b || !a_ || !b_ || !out || !workspace) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] null argument");
+    if (pa < 1 || pb < 1 || pa > 16 || pb > 16) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] invalid ciphertext size");
+    const BehzLayout w = behz_layout(b, pa, pb, batch);
+    if (workspace_bytes < w.total * sizeof(u64)) return fail(TROYN_E_WORKSPACE, "[troyn_bfv_multiply] workspace too small");
+    if (batch == 0) return TROYN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const troyn_plan* pq = b->plan;
+    const troyn_plan* px = b->aux;
+    const unsigned n = pq->n, L = b->L, S = b->Bsk;
+    const size_t po = pa + pb - 1;
+    u64* ws = (u64*)workspace;
+    int rc;
+    const unsigned ch1 = chunks_single(n);
+    auto lift = [&](const u64* src, size_t pcount, u64* dst_q, u64* dst_bsk) -> int {
+        // steps (1)-(3) of evaluator.cu:50-60 for one operand
+        NttArgs a = contiguous_args(pq, src, dst_q, pcount, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        int r = launch_ntt(pq, a, batch, false, s);
+        if (r) return r;
+        const size_t items = batch * pcount;
+        if ((r = check_rows(items, ch1))) return r;
+        dim3 grid((unsigned)(items * ch1)), block(256);
+        dispatch_bound(L,
+            [&] { hipLaunchKernelGGL((behz_lift_kernel<4>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
+            [&] { hipLaunchKernelGGL((behz_lift_kernel<8>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
+            [&] { hipLaunchKernelGGL((behz_lift_kernel<16>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
+            [&] { hipLaunchKernelGGL((behz_lift_kernel<64>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); });
+        LAUNCH_CHECK();
+        NttArgs ab = contiguous_args(px, dst_bsk, dst_bsk, pcount, S, 0, S, TROYN_IDX_COMPONENTWISE, 0);
+        return launch_ntt(px, ab, batch, false, s);
+    };
+    if ((rc = lift((const u64*)a_, pa, ws + w.a_q, ws + w.a_bsk))) return rc;
+    if ((rc = lift((const u64*)b_, pb, ws + w.b_q, ws + w.b_bsk))) return rc;
+    // step (4)
+    if ((rc = launch_convolute(pq->d_mods, n, 0, L, ws + w.a_q, pa, ws + w.b_q, pb, ws + w.d_q, batch, s))) return rc;
+    if ((rc = launch_convolute(px->d_mods, n, 0, S, ws + w.a_bsk, pa, ws + w.b_bsk, pb, ws + w.d_bsk, batch, s))) return rc;
+    // step (5)
+    {
+        NttArgs a = contiguous_args(pq, ws + w.d_q, ws + w.d_q, po, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        if ((rc = launch_ntt(pq, a, batch, true, s))) return rc;
+        NttArgs ab = contiguous_args(px, ws + w.d_bsk, ws + w.d_bsk, po, S, 0, S, TROYN_IDX_COMPONENTWISE, 0);
+        if ((rc = launch_ntt(px, ab, batch, true, s))) return rc;
+    }
+    // steps (6)-(8)
+    {
+        const size_t items = batch * po;
+        if ((rc = check_rows(items, ch1))) return rc;
+        dim3 grid((unsigned)(items * ch1)), block(256);
+        dispatch_bound(S,
+            [&] { hipLaunchKernelGGL((behz_floor_kernel<4>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
+            [&] { hipLaunchKernelGGL((behz_floor_kernel<8>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
+            [&] { hipLaunchKernelGGL((behz_floor_kernel<16>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
+            [&] { hipLaunchKernelGGL((behz_floor_kernel<66>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); });
+        LAUNCH_CHECK();
+    }
+    return TROYN_OK;
+}

@@ -1,0 +1,236 @@
+"""Host-side handle objects over the C-ABI: Plan (one modulus chain on one GPU) and Behz.
+
+Ciphertext payloads are torch int64 CUDA tensors whose bits are the reference's uint64 words,
+layout [batch][poly][limb][N] (ciphertext.h:211-247).  Every method only enqueues work on the
+current torch stream; nothing is computed on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+IDX_COMPONENTWISE, IDX_KS_SET_PRODUCTS, IDX_KS_SKIP_FINALS = 0, 1, 2
+ASSIGN_ADD_INPLACE, ASSIGN_OVERWRITE, ASSIGN_OVERWRITE_EXCEPT_FIRST = 0, 1, 2
+
+
+def to_device(a, device):
+    """numpy uint64 array -> int64 CUDA tensor holding the same bits"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    """int64 tensor -> numpy uint64 array (same bits)"""
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def _ptr(t):
+    if t.dtype != torch.int64 or not t.is_contiguous() or not t.is_cuda:
+        raise capi.TroynInvalidArgument("[troyn] operands must be contiguous int64 CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """troyn_plan: device tables for the key-level modulus chain q_0..q_{K-1} (special prime last).
+
+    Mirrors what ContextData::to_device_inplace (context_data.cu:34-69) uploads for every level.
+    """
+
+    def __init__(self, device, log_n, moduli, roots=None):
+        self.lib = capi.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise capi.TroynError("[troyn] the hot path runs on an MI355X only; there is no CPU path")
+        self.log_n, self.n = int(log_n), 1 << int(log_n)
+        self.moduli = [int(q) for q in moduli]
+        self.K = len(self.moduli)
+        h = C.c_void_p()
+        m = (C.c_uint64 * self.K)(*self.moduli)
+        r = (C.c_uint64 * self.K)(*[int(x) for x in roots]) if roots is not None else None
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        capi.check(self.lib.troyn_plan_create(C.byref(h), index, self.log_n, self.K, m, r))
+        self.h = h
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.troyn_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- table inspection (known-answer hooks) --------------------------------------------
+    def root(self, i):
+        out = C.c_uint64()
+        capi.check(self.lib.troyn_plan_get_root(self.h, i, C.byref(out)))
+        return int(out.value)
+
+    def root_powers(self, i, inverse=False):
+        out = np.zeros(2 * self.n, dtype=np.uint64)
+        capi.check(self.lib.troyn_plan_get_root_powers(self.h, i, int(inverse), out.ctypes.data_as(capi.p64)))
+        return out.reshape(self.n, 2)
+
+    # -- workspace (stands in for the reference's MemoryPool) -------------------------------
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- NTT ---------------------------------------------------------------------------------
+    def ntt(self, x, pcount, ncomp, inverse=False, out=None, table_start=0, table_count=None,
+            mode=IDX_COMPONENTWISE, decomp=0):
+        """x: [batch][pcount][ncomp][N] (any leading shape with that many elements)"""
+        if table_count is None:
+            table_count = ncomp if mode == IDX_COMPONENTWISE else self.K
+        out = x if out is None else out
+        batch = x.numel() // (pcount * ncomp * self.n)
+        capi.check(self.lib.troyn_ntt(self.h, int(inverse), _ptr(x), _ptr(out), batch, pcount, ncomp,
+                                      table_start, table_count, mode, decomp, _stream()))
+        return out
+
+    # -- element-wise ---------------------------------------------------------------------------
+    def _ew(self, fn, a, b, nmod, mod_start, out):
+        out = torch.empty_like(a) if out is None else out
+        count = a.numel() // (nmod * self.n)
+        if b is None:
+            capi.check(fn(self.h, mod_start, nmod, _ptr(a), _ptr(out), count, _stream()))
+        else:
+            capi.check(fn(self.h, mod_start, nmod, _ptr(a), _ptr(b), _ptr(out), count, _stream()))
+        return out
+
+    def add(self, a, b, nmod, mod_start=0, out=None):
+        return self._ew(self.lib.troyn_add, a, b, nmod, mod_start, out)
+
+    def sub(self, a, b, nmod, mod_start=0, out=None):
+        return self._ew(self.lib.troyn_sub, a, b, nmod, mod_start, out)
+
+    def negate(self, a, nmod, mod_start=0, out=None):
+        return self._ew(self.lib.troyn_negate, a, None, nmod, mod_start, out)
+
+    def dyadic_product(self, a, b, nmod, mod_start=0, out=None):
+        return self._ew(self.lib.troyn_dyadic_product, a, b, nmod, mod_start, out)
+
+    def multiply_scalar(self, a, scalar, nmod, mod_start=0, out=None):
+        out = torch.empty_like(a) if out is None else out
+        count = a.numel() // (nmod * self.n)
+        capi.check(self.lib.troyn_multiply_scalar(self.h, mod_start, nmod, _ptr(a), int(scalar), _ptr(out), count, _stream()))
+        return out
+
+    def dyadic_convolute(self, a, pa, b, pb, nmod, mod_start=0, out=None):
+        batch = a.numel() // (pa * nmod * self.n)
+        if out is None:
+            out = torch.empty((batch, pa + pb - 1, nmod, self.n), dtype=torch.int64, device=a.device)
+        capi.check(self.lib.troyn_dyadic_convolute(self.h, mod_start, nmod, _ptr(a), pa, _ptr(b), pb, _ptr(out), batch, _stream()))
+        return out
+
+    def dyadic_square(self, a, nmod, mod_start=0, out=None):
+        batch = a.numel() // (2 * nmod * self.n)
+        if out is None:
+            out = torch.empty((batch, 3, nmod, self.n), dtype=torch.int64, device=a.device)
+        capi.check(self.lib.troyn_dyadic_square(self.h, mod_start, nmod, _ptr(a), _ptr(out), batch, _stream()))
+        return out
+
+    # -- key switching -----------------------------------------------------------------------------
+    def _key_ptrs(self, keys, L):
+        if len(keys) < L:
+            raise capi.TroynInvalidArgument("[Evaluator::switch_key_inplace_internal] Key switch keys index out of range.")
+        arr = (C.c_void_p * L)(*[k.data_ptr() for k in keys[:L]])
+        return arr
+
+    def switch_key(self, L, target, keys, dest=None, assign=ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True):
+        """target [batch][L][N]; keys: list of L tensors [2][K][N]; dest [batch][2][L][N]"""
+        batch = target.numel() // (L * self.n)
+        if dest is None:
+            dest = torch.zeros((batch, 2, L, self.n), dtype=torch.int64, device=target.device)
+        nbytes = self.lib.troyn_switch_key_workspace_bytes(self.h, L, batch)
+        ws = self.workspace(nbytes)
+        capi.check(self.lib.troyn_switch_key(self.h, L, int(is_ckks), int(is_ntt_form), _ptr(target), self._key_ptrs(keys, L),
+                                             assign, _ptr(dest), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return dest
+
+    def relinearize(self, L, ct3, keys, out=None, is_ckks=True, is_ntt_form=True):
+        """ct3 [batch][3][L][N] -> [batch][2][L][N]"""
+        batch = ct3.numel() // (3 * L * self.n)
+        if out is None:
+            out = torch.empty((batch, 2, L, self.n), dtype=torch.int64, device=ct3.device)
+        nbytes = self.lib.troyn_relinearize_workspace_bytes(self.h, L, batch)
+        ws = self.workspace(nbytes)
+        capi.check(self.lib.troyn_relinearize(self.h, L, int(is_ckks), int(is_ntt_form), _ptr(ct3), self._key_ptrs(keys, L),
+                                              _ptr(out), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
+
+    # -- modulus switching -------------------------------------------------------------------------
+    def divide_and_round_q_last(self, L, x, pcount, out=None):
+        batch = x.numel() // (pcount * L * self.n)
+        if out is None:
+            out = torch.empty((batch, pcount, L - 1, self.n), dtype=torch.int64, device=x.device)
+        capi.check(self.lib.troyn_divide_and_round_q_last(self.h, L, _ptr(x), pcount, _ptr(out), batch, _stream()))
+        return out
+
+    def divide_and_round_q_last_ntt(self, L, x, pcount, out=None):
+        batch = x.numel() // (pcount * L * self.n)
+        if out is None:
+            out = torch.empty((batch, pcount, L - 1, self.n), dtype=torch.int64, device=x.device)
+        nbytes = self.lib.troyn_divide_and_round_q_last_ntt_workspace_bytes(self.h, L, pcount, batch)
+        ws = self.workspace(nbytes)
+        capi.check(self.lib.troyn_divide_and_round_q_last_ntt(self.h, L, _ptr(x), pcount, _ptr(out),
+                                                              C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
+
+    def mod_switch_drop(self, L_in, L_out, x, pcount, out=None):
+        batch = x.numel() // (pcount * L_in * self.n)
+        if out is None:
+            out = torch.empty((batch, pcount, L_out, self.n), dtype=torch.int64, device=x.device)
+        capi.check(self.lib.troyn_mod_switch_drop(self.h, L_in, L_out, _ptr(x), pcount, _ptr(out), batch, _stream()))
+        return out
+
+
+class Behz:
+    """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""
+
+    def __init__(self, plan, L, plain_modulus):
+        self.plan, self.L, self.t = plan, int(L), int(plain_modulus)
+        h = C.c_void_p()
+        capi.check(plan.lib.troyn_behz_create(C.byref(h), plan.h, self.L, self.t))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.plan.lib.troyn_behz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def base_Bsk(self):
+        n = self.plan.lib.troyn_behz_base_Bsk_size(self.h)
+        out = np.zeros(n, dtype=np.uint64)
+        capi.check(self.plan.lib.troyn_behz_get_base_Bsk(self.h, out.ctypes.data_as(capi.p64)))
+        return [int(x) for x in out]
+
+    def multiply(self, a, pa, b, pb, out=None):
+        """a [batch][pa][L][N] x b [batch][pb][L][N] (coefficient form) -> [batch][pa+pb-1][L][N]"""
+        n, L = self.plan.n, self.L
+        batch = a.numel() // (pa * L * n)
+        if out is None:
+            out = torch.empty((batch, pa + pb - 1, L, n), dtype=torch.int64, device=a.device)
+        nbytes = self.plan.lib.troyn_bfv_multiply_workspace_bytes(self.h, pa, pb, batch)
+        ws = self.plan.workspace(nbytes)
+        capi.check(self.plan.lib.troyn_bfv_multiply(self.h, _ptr(a), pa, _ptr(b), pb, _ptr(out),
+                                                    C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
