@@ -1,0 +1,142 @@
+"""GPU parity: key switching / relinearize / modulus switching / BEHZ multiply vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(O, pkg, dev, scheme, n, bits, t=0):
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context(scheme, n, q, t)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    return ctx, plan, q
+
+
+@pytest.mark.parametrize("scheme,ntt_form,n,bits,L", [
+    ("ckks", True, 32, [40, 40, 40], 2),
+    ("ckks", True, 32, [60, 40, 40, 60], 3),      # the reference's test moduli (test/evaluator.cu)
+    ("ckks", True, 1024, [30, 30, 30, 30], 2),     # lower level: L < K-1
+    ("ckks", True, 8192, [40, 40, 40, 40], 3),
+    ("ckks", True, 16384, [50] * 6, 5),            # BASELINE config 3
+    ("bfv", False, 32, [40, 40, 40], 2),
+    ("bfv", False, 4096, [36, 36, 37], 2),
+    ("bfv", False, 8192, [40, 40, 40], 2),         # BASELINE config 2 shape
+    ("bfv", False, 32768, [50] * 4, 3),
+    ("bfv", True, 2048, [54], 1) if False else ("bfv", False, 2048, [27, 27], 1),
+])
+def test_switch_key(O, pkg, dev, scheme, ntt_form, n, bits, L):
+    t = 1032193 if scheme == "bfv" else 0
+    ctx, plan, q = _setup(O, pkg, dev, scheme, n, bits, t)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    batch = 2
+    tg = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(batch)])
+    dt = pkg.to_device(tg, dev)
+    is_ckks = scheme == "ckks"
+    for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE, pkg.ASSIGN_OVERWRITE_EXCEPT_FIRST):
+        d0 = np.stack([ctx.random_ct(40 + i, 2, L) for i in range(batch)])
+        dd = pkg.to_device(d0, dev)
+        plan.switch_key(L, dt, dkeys, dest=dd, assign=assign, is_ckks=is_ckks, is_ntt_form=ntt_form)
+        got = pkg.to_host(dd)
+        for i in range(batch):
+            exp = ctx.switch_key(L, ntt_form, tg[i], keys, assign=assign, dest=d0[i])
+            assert np.array_equal(got[i], exp), "switch_key mismatch (assign=%d, item %d)" % (assign, i)
+    # the target must be left untouched
+    assert np.array_equal(pkg.to_host(dt), tg)
+
+
+@pytest.mark.parametrize("scheme,ntt_form,n,bits,L", [
+    ("ckks", True, 64, [40, 40, 40], 2),
+    ("ckks", True, 16384, [50] * 6, 5),
+    ("bfv", False, 8192, [40, 40, 40], 2),
+])
+def test_relinearize(O, pkg, dev, scheme, ntt_form, n, bits, L):
+    t = 1032193 if scheme == "bfv" else 0
+    ctx, plan, q = _setup(O, pkg, dev, scheme, n, bits, t)
+    keys = ctx.random_keys(9, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    batch = 3
+    ct3 = np.stack([ctx.random_ct(70 + i, 3, L) for i in range(batch)])
+    got = pkg.to_host(plan.relinearize(L, pkg.to_device(ct3, dev), dkeys, is_ckks=(scheme == "ckks"), is_ntt_form=ntt_form))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.relinearize(L, ntt_form, ct3[i], keys))
+
+
+@pytest.mark.parametrize("n,bits,L", [(32, [40, 40, 40], 3), (32, [30, 40, 50, 60], 4), (32, [60, 50, 40, 30], 4),
+                                      (8192, [40, 40, 40], 2), (16384, [50] * 6, 5), (32768, [50] * 3, 3)])
+def test_ckks_rescale(O, pkg, dev, n, bits, L):
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, bits)
+    batch, p = 2, 2
+    x = np.stack([ctx.random_ct(13 + i, p, L) for i in range(batch)])
+    got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(x, dev), p))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i]))
+    # 3-polynomial ciphertext (rescale before relinearize)
+    x3 = ctx.random_ct(77, 3, L)
+    got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(x3, dev), 3))
+    assert np.array_equal(got[0], ctx.mod_switch_scale_to_next(L, x3))
+
+
+@pytest.mark.parametrize("n,bits,L", [(32, [40, 40, 40], 3), (32, [30, 40, 50, 60], 4), (32, [60, 50, 40, 30], 2),
+                                      (8192, [40, 40, 40], 2), (32768, [50] * 4, 4)])
+def test_bfv_mod_switch(O, pkg, dev, n, bits, L):
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, 1032193)
+    batch, p = 2, 2
+    x = np.stack([ctx.random_ct(21 + i, p, L) for i in range(batch)])
+    got = pkg.to_host(plan.divide_and_round_q_last(L, pkg.to_device(x, dev), p))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i]))
+
+
+def test_mod_switch_drop(O, pkg, dev):
+    n, L = 1024, 4
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, [40] * 5)
+    x = np.stack([ctx.random_ct(3 + i, 2, L) for i in range(2)])
+    got = pkg.to_host(plan.mod_switch_drop(L, L - 1, pkg.to_device(x, dev), 2))
+    for i in range(2):
+        assert np.array_equal(got[i], ctx.mod_switch_drop_to_next(L, x[i]))
+    got = pkg.to_host(plan.mod_switch_drop(L, 1, pkg.to_device(x, dev), 2))
+    assert np.array_equal(got, x[:, :, :1, :])
+
+
+@pytest.mark.parametrize("n,bits,L,t,pa,pb", [
+    (32, [40, 40, 40], 2, 1032193 % (1 << 20) | 1, 2, 2),
+    (32, [60, 60, 60], 3, 65537, 2, 2),
+    (32, [30], 1, 97, 2, 2),
+    (1024, [27, 27, 27], 2, 12289, 2, 3),
+    (8192, [40, 40, 40], 2, 1032193, 2, 2),       # BASELINE config 2
+    (8192, [60, 40, 40, 60], 3, 1 << 21, 2, 2),   # matmul app parameters (non-prime t)
+    (16384, [50] * 6, 5, 1032193, 2, 2),
+    (32768, [50] * 11, 10, 1032193, 2, 2),        # BASELINE config 4
+])
+def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb):
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
+    behz = pkg.Behz(plan, L, t)
+    rt = O.lib().orc_context_rns_tool(ctx.h, L)
+    bsk = np.zeros(O.lib().orc_rns_tool_base_Bsk_size(rt), dtype=np.uint64)
+    O.lib().orc_rns_tool_base_Bsk(rt, O.ptr(bsk))
+    assert behz.base_Bsk == [int(v) for v in bsk]
+    batch = 2
+    a = np.stack([ctx.random_ct(31 + i, pa, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(47 + i, pb, L) for i in range(batch)])
+    got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), pa, pkg.to_device(b, dev), pb))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i]))
+
+
+def test_error_behaviour(O, pkg, dev):
+    # misuse -> invalid_argument-style errors, mirroring the reference's checks
+    n = 1024
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, [40, 40, 40])
+    x = pkg.to_device(ctx.random_ct(1, 2, 2), dev)
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.divide_and_round_q_last_ntt(1, x[:, :, :1].contiguous(), 2)     # no next level
+    keys = [pkg.to_device(k, dev) for k in ctx.random_keys(1, 2)]
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.switch_key(3, x, keys)                                          # L > K-1
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.switch_key(2, x[0, 0].contiguous(), keys[:1])                   # key index out of range
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        pkg.Plan(dev, 10, [1 << 61])                                         # modulus too large
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        pkg.Plan(dev, 10, [97])                                              # no 2N-th root of unity
