@@ -51,6 +51,12 @@ typedef struct troyn_behz troyn_behz;
 const char* troyn_last_error(void);
 int troyn_version(void);
 
+/* Host-only helpers (no GPU touched) so that a host can build the same parameter sets as the
+ * reference: CoeffModulus::create (coeff_modulus.cu:65-108: for every bit size the k largest primes
+ * = 1 mod 2N, handed out smallest-first) and utils::get_primes (utils/number_theory.cu:22-39). */
+int troyn_coeff_modulus_create(size_t poly_modulus_degree, const size_t* bit_sizes, size_t n, uint64_t* out);
+int troyn_get_primes(uint64_t factor, size_t bit_size, size_t count, uint64_t* out);
+
 /* ---------------------------------------------------------------------------------------
  * Plan = device-resident mirror of one modulus chain: for each of the `n_moduli` primes
  * (key level order, special prime last) the Modulus constants (modulus.h:8-124), the

@@ -20,6 +20,8 @@ p64 = C.POINTER(C.c_uint64)
 SYMBOLS = {
     "troyn_last_error": (C.c_char_p, []),
     "troyn_version": (C.c_int, []),
+    "troyn_coeff_modulus_create": (C.c_int, [sz, C.POINTER(sz), sz, p64]),
+    "troyn_get_primes": (C.c_int, [u64, sz, sz, p64]),
     "troyn_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, u32, u32, p64, p64]),
     "troyn_plan_destroy": (C.c_int, [vp]),
     "troyn_plan_log_n": (u32, [vp]),
@@ -86,3 +88,19 @@ def check(rc):
     if rc < 0:
         raise TroynInvalidArgument("%s (troyn code %d)" % (msg, rc))
     raise TroynError("%s (hipError %d)" % (msg, rc))
+
+
+def coeff_modulus_create(poly_modulus_degree, bit_sizes):
+    """CoeffModulus::create (coeff_modulus.cu:65-108) -- host only"""
+    n = len(bit_sizes)
+    bs = (sz * n)(*bit_sizes)
+    out = (u64 * n)()
+    check(lib().troyn_coeff_modulus_create(poly_modulus_degree, bs, n, out))
+    return [int(x) for x in out]
+
+
+def get_primes(factor, bit_size, count):
+    """utils::get_primes (utils/number_theory.cu:22-39) -- host only"""
+    out = (u64 * count)()
+    check(lib().troyn_get_primes(factor, bit_size, count, out))
+    return [int(x) for x in out]

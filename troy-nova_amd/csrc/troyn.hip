@@ -42,6 +42,39 @@ static int fail(int code, const std::string& msg) {
 extern "C" const char* troyn_last_error(void) { return g_last_error.c_str(); }
 extern "C" int troyn_version(void) { return TROYN_VERSION; }
 
+extern "C" int troyn_get_primes(uint64_t factor, size_t bit_size, size_t count, uint64_t* out) {
+    if (!out || factor == 0 || bit_size < 2 || bit_size > 62) return fail(TROYN_E_INVALID, "[get_primes] bad argument");
+    try {
+        std::vector<u64> v = host::get_primes(factor, bit_size, count);
+        for (size_t i = 0; i < count; i++) out[i] = v[i];
+    } catch (const std::exception& e) {
+        return fail(TROYN_E_MODULUS, e.what());
+    }
+    return TROYN_OK;
+}
+
+extern "C" int troyn_coeff_modulus_create(size_t poly_modulus_degree, const size_t* bit_sizes, size_t n, uint64_t* out) {
+    // coeff_modulus.cu:65-108
+    if (!bit_sizes || !out) return fail(TROYN_E_INVALID, "[CoeffModulus::create] null argument");
+    if (poly_modulus_degree > 131072 || poly_modulus_degree < 2) return fail(TROYN_E_INVALID, "[CoeffModulus::create] Invalid poly_modulus_degree.");
+    if (n > 64 || n < 1) return fail(TROYN_E_INVALID, "[CoeffModulus::create] Invalid bit_sizes length.");
+    for (size_t i = 0; i < n; i++)
+        if (bit_sizes[i] > 60 || bit_sizes[i] < 2) return fail(TROYN_E_INVALID, "[CoeffModulus::create] Invalid max_bit_size.");
+    std::vector<size_t> handed(61, 0);
+    try {
+        for (size_t i = 0; i < n; i++) {
+            const size_t s = bit_sizes[i];
+            size_t total = 0;
+            for (size_t k = 0; k < n; k++) total += (bit_sizes[k] == s);
+            std::vector<u64> primes = host::get_primes(2 * (u64)poly_modulus_degree, s, total);
+            out[i] = primes[total - 1 - handed[s]++];   // prime_table[size].back(); pop_back()
+        }
+    } catch (const std::exception& e) {
+        return fail(TROYN_E_MODULUS, e.what());
+    }
+    return TROYN_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------
