@@ -1,0 +1,183 @@
+"""Pin the CPU oracle against the reference's own known-answer tests (tests/golden/ref_kats.json,
+re-typed as data from the reference's test/ directory) and the values recorded in SURVEY.md.
+Runs without a GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "ref_kats.json")))
+MT = 1 << 32
+
+
+def _val(x):
+    if isinstance(x, int):
+        return x
+    return int(eval(x.replace("2MT", "(2*MT)").replace("4MT", "(4*MT)"), {"MT": MT}))
+
+
+def test_modulus_create_and_reduce(O):
+    for c in KATS["modulus"]["create"]:
+        m = O.modulus(c["value"])
+        assert m.bit_count == c["bit_count"]
+        assert list(m.const_ratio) == c["const_ratio"]
+        assert bool(m.is_prime) == c["is_prime"]
+    z = O.Modulus()
+    assert O.lib().orc_modulus_init(C.byref(z), 0) == 0 and z.value == 0 and z.bit_count == 0 and list(z.const_ratio) == [0, 0, 0]
+    assert O.lib().orc_modulus_init(C.byref(z), 1) != 0          # "cannot be 1"
+    assert O.lib().orc_modulus_init(C.byref(z), 1 << 61) != 0    # "at most 61-bit"
+    for blk in KATS["modulus"]["reduce"]:
+        m = O.modulus(blk["modulus"])
+        for x, exp in blk["cases"]:
+            assert O.lib().orc_barrett_reduce64(x, C.byref(m)) == exp
+
+
+@pytest.mark.parametrize("op,fn", [("add", "orc_add_mod"), ("sub", "orc_sub_mod"), ("multiply", "orc_multiply_mod"),
+                                   ("exponentiate", "orc_exponentiate_mod")])
+def test_uint_small_mod_binary(O, op, fn):
+    for blk in KATS["uint_small_mod"][op]:
+        m = O.modulus(blk["modulus"])
+        for a, b, exp in blk["cases"]:
+            assert getattr(O.lib(), fn)(a, b, C.byref(m)) == exp, (op, blk["modulus"], a, b)
+
+
+def test_barrett128(O):
+    for blk in KATS["uint_small_mod"]["barrett128"]:
+        m = O.modulus(blk["modulus"])
+        for lo, hi, exp in blk["cases"]:
+            assert O.lib().orc_barrett_reduce128(lo, hi, C.byref(m)) == exp
+
+
+def test_shoup_multiply_matches_barrett(O):
+    # multiply_uint64operand_mod == multiply_uint64_mod on canonical inputs (uint_small_mod.h:130-139)
+    for q in (2305843009211596801, 1099510824961, 1032193):
+        m = O.modulus(q)
+        xs = O.fill_uniform(q & 0xffff, q, 64)
+        ws = O.fill_uniform(q & 0xfff, q, 64)
+        for x, w in zip(xs, ws):
+            op = O.MulOp()
+            O.lib().orc_mulop_init(C.byref(op), int(w), C.byref(m))
+            assert O.lib().orc_mulop_mod(int(x), C.byref(op), C.byref(m)) == (int(x) * int(w)) % q
+            lazy = O.lib().orc_mulop_mod_lazy(int(x), C.byref(op), C.byref(m))
+            assert lazy < 2 * q and lazy % q == (int(x) * int(w)) % q
+
+
+def test_ntt_kats(O):
+    k = KATS["ntt"]
+    q = k["modulus"]
+    t1, t2 = O.NTTTables(1, q), O.NTTTables(2, q)
+    assert [t1.root_power(i) for i in range(2)] == k["root_powers_logn1"]
+    assert [t2.root_power(i) for i in range(4)] == k["root_powers_logn2"]
+    m = O.modulus(q)
+    inv = C.c_uint64()
+    assert O.lib().orc_try_invert_mod(k["root_powers_logn1"][1], C.byref(m), C.byref(inv))
+    assert t1.root_power(1, inverse=True) == inv.value
+    for inp, exp in k["forward_logn1"]:
+        d = O.arr(inp)
+        O.ntt_forward(d, 1, 1, 1, [t1])
+        assert [int(v) for v in d] == exp
+    ln = k["roundtrip_logn"]
+    t = O.NTTTables(ln, q)
+    z = np.zeros(1 << ln, dtype=np.uint64)
+    O.ntt_inverse(z, 1, 1, ln, [t])
+    assert not z.any()
+    x0 = np.arange(1 << ln, dtype=np.uint64)
+    x = x0.copy()
+    O.ntt_forward(x, 1, 1, ln, [t])
+    O.ntt_inverse(x, 1, 1, ln, [t])
+    assert np.array_equal(x, x0)
+
+
+def test_ntt_table_sizes(O):
+    # test/utils/ntt.cu:12-31 (Basics): get_prime(2N, bits) + table creation for logN = 1, 2, 10
+    for ln, bits in ((1, 60), (2, 50), (10, 40)):
+        q = O.get_primes(2 << ln, bits, 1)[0]
+        t = O.NTTTables(ln, q)
+        assert pow(t.root, 1 << ln, q) == q - 1
+        assert t.inv_degree() == pow(1 << ln, -1, q)
+
+
+def test_fast_convert_array(O):
+    for c in KATS["rns_base"]["fast_convert_array"]:
+        ib, ob, inp = O.arr(c["ibase"]), O.arr(c["obase"]), O.arr(c["input"])
+        count = len(c["input"]) // len(c["ibase"])
+        out = np.zeros(count * len(c["obase"]), dtype=np.uint64)
+        O.lib().orc_fast_convert_array(O.ptr(ib), len(ib), O.ptr(ob), len(ob), O.ptr(inp), count, O.ptr(out))
+        assert [int(v) for v in out] == c["output"]
+
+
+def test_rns_tool_kats(O):
+    k = KATS["rns_tool"]
+    for c in k["fast_b_conv_sk"]:
+        r = O.RNSTool(2, c["q"], 0)
+        assert [int(v) for v in r.fast_b_conv_sk(c["input"])] == c["output"]
+    for c in k["sm_mrq"]:
+        r = O.RNSTool(2, c["q"], 0)
+        assert r.m_tilde == MT
+        assert [int(v) for v in r.sm_mrq([_val(x) for x in c["input"]])] == c["output"]
+    for c in k["fast_floor"]:
+        r = O.RNSTool(2, c["q"], 0)
+        got = [int(v) for v in r.fast_floor(c["input"])]
+        assert all(abs(g - e) <= c["tolerance"] for g, e in zip(got, c["output"]))
+    for c in k["fast_b_conv_m_tilde"]:
+        r = O.RNSTool(2, c["q"], 0)
+        got = [int(v) for v in r.fast_b_conv_m_tilde(c["input"])]
+        base = r.base_Bsk + [MT]
+        vals = [_val(x) for x in c["expect_values"]]
+        for bi, p in enumerate(base):
+            for j in range(2):
+                assert got[bi * 2 + j] == vals[j] % p
+
+
+def test_survey_recorded_values(O):
+    s = KATS["survey_values"]
+    for c in s["coeff_modulus"]:
+        assert O.coeff_modulus_create(c["n"], c["bits"]) == c["primes"]
+    assert O.get_primes(2 * 8192, 20, 1)[0] == s["plain_modulus_batching_8192_20"]   # PlainModulus::batching(8192, 20)
+    for c in s["behz"]:
+        q = O.coeff_modulus_create(c["n"], c["q_bits"])[:c["L"]]
+        r = O.RNSTool(c["n"], q, c["t"])
+        assert r.base_Bsk_size == c["base_Bsk_size"]
+        if "m_sk" in c:
+            assert r.m_sk == c["m_sk"] and r.gamma == c["gamma"]
+
+
+def test_oracle_self_consistency(O):
+    """decrypt-free structural checks of the restated pipelines on a tiny ring (N = 32)."""
+    n = 32
+    q = O.coeff_modulus_create(n, [40, 40, 40])
+    ctx = O.Context("ckks", n, q)
+    L = 2
+    a, b = ctx.random_ct(1, 2, L), ctx.random_ct(2, 2, L)
+    # NTT is a ring homomorphism: INTT(NTT(a) (*) NTT(b)) = negacyclic product (schoolbook check)
+    fa, fb = ctx.to_ntt(a, 2, L), ctx.to_ntt(b, 2, L)
+    prod = ctx.from_ntt(ctx.ckks_multiply(L, fa, fb), 3, L)
+    for l in range(L):
+        ql = q[l]
+        def negacyclic(x, y):
+            out = [0] * n
+            for i in range(n):
+                for j in range(n):
+                    k = i + j
+                    v = int(x[i]) * int(y[j])
+                    if k >= n:
+                        out[k - n] = (out[k - n] - v) % ql
+                    else:
+                        out[k] = (out[k] + v) % ql
+            return out
+        assert [int(v) for v in prod[0, l]] == negacyclic(a[0, l], b[0, l])
+        c1 = [(x + y) % ql for x, y in zip(negacyclic(a[0, l], b[1, l]), negacyclic(a[1, l], b[0, l]))]
+        assert [int(v) for v in prod[1, l]] == c1
+    # rescale: (c - [c]_{q_last} rounded) / q_last, exact integer check per coefficient in coefficient domain
+    x = ctx.random_ct(5, 1, 3)
+    out = ctx.mod_switch_scale_to_next(3, ctx.to_ntt(x, 1, 3))
+    out_c = ctx.from_ntt(out, 1, 2)
+    ql = q[2]
+    for l in range(2):
+        for i in range(n):
+            r = (int(x[0, 2, i]) + ql // 2) % ql
+            exp = ((int(x[0, l, i]) - (r - ql // 2)) * pow(ql, -1, q[l])) % q[l]
+            assert int(out_c[0, l, i]) == exp

@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: batch sharding + key broadcast + max-over-ranks with gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, ret):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    shard = importlib.import_module("troy_nova_amd.shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # keys are produced on rank 0 only and broadcast once
+    keys = [torch.full((2, 3, 8), 100 + j if rank == 0 else -1, dtype=torch.int64) for j in range(2)]
+    shard.broadcast_tensors(keys, src=0)
+    ok_keys = all(int(k[0, 0, 0]) == 100 + j for j, k in enumerate(keys))
+    lo, hi = shard.shard_range(total, rank, world)
+    # stand-in "evaluation": every rank handles its own slice of the batch with no exchange
+    mine = torch.arange(lo, hi, dtype=torch.int64) * 2
+    t = shard.max_over_ranks(1.0 + rank)
+    n = shard.sum_over_ranks(hi - lo)
+    shard.barrier()
+    ret[rank] = (lo, hi, ok_keys, t, n, mine.tolist())
+    dist.destroy_process_group()
+
+
+def test_shard_range_partition():
+    sys.path.insert(0, ROOT)
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    shard = importlib.import_module("troy_nova_amd.shard")
+    for total in (0, 1, 7, 8, 1024, 1025):
+        for world in (1, 2, 4, 8):
+            parts = [shard.shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard.max_over_ranks(3.5) == 3.5 and not shard.is_distributed()
+
+
+def test_two_rank_gloo():
+    world, total = 2, 11
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, total, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        r0, r1 = ret[0], ret[1]
+    assert (r0[0], r0[1]) == (0, 6) and (r1[0], r1[1]) == (6, 11)
+    assert r0[2] and r1[2], "keys must be identical on every rank after the broadcast"
+    assert r0[3] == 2.0 and r1[3] == 2.0, "timing is the max over ranks"
+    assert r0[4] == total and r1[4] == total
+    assert r0[5] + r1[5] == [2 * i for i in range(total)]
