@@ -45,6 +45,14 @@ DEFINE_KERNEL(k_fma_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u]
               asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(x[u]) : "v"((double)b0)))
 DEFINE_KERNEL(k_mul_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (double)(a0 + u + threadIdx.x),
               asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x[u]) : "v"((double)b0)))
+DEFINE_KERNEL(k_add_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (double)(a0 + u + threadIdx.x),
+              asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[u]) : "v"((double)b0)))
+DEFINE_KERNEL(k_rndne_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (double)(a0 + u + threadIdx.x),
+              asm volatile("v_rndne_f64 %0, %0" : "+v"(x[u])))
+DEFINE_KERNEL(k_floor_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (double)(a0 + u + threadIdx.x),
+              asm volatile("v_floor_f64 %0, %0" : "+v"(x[u])))
+DEFINE_KERNEL(k_cmp_f64, double x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (double)(a0 + u + threadIdx.x),
+              asm volatile("v_cmp_lt_f64 vcc, %0, %1" : "+v"(x[u]) : "v"((double)b0) : "vcc"))
 DEFINE_KERNEL(k_fma_f32, float x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = (float)(a0 + u + threadIdx.x),
               asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[u]) : "v"((float)b0)))
 DEFINE_KERNEL(k_cndmask, unsigned x[UNROLL]; for (int u = 0; u < UNROLL; ++u) x[u] = a0 + u + threadIdx.x,
@@ -110,5 +118,9 @@ int main() {
     run("v_fma_f32", k_fma_f32, d_out);
     run("v_fma_f64", k_fma_f64, d_out);
     run("v_mul_f64", k_mul_f64, d_out);
+    run("v_add_f64", k_add_f64, d_out);
+    run("v_rndne_f64", k_rndne_f64, d_out);
+    run("v_floor_f64", k_floor_f64, d_out);
+    run("v_cmp_lt_f64", k_cmp_f64, d_out);
     return 0;
 }

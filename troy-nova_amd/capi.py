@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtroyn.so")
+LIB_PATH = os.environ.get("TROYN_LIB", os.path.join(_HERE, "libtroyn.so"))   # TROYN_LIB: profiling builds only
 
 u64 = C.c_uint64
 u32 = C.c_uint32

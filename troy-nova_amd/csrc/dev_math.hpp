@@ -20,8 +20,14 @@ struct DevModulus {
     u64 ratio_hi;   // floor(2^128/q) high word  (const_ratio[1])
     u64 inv_n_op;   // N^-1 mod q                (NTTTables::inv_degree_modulo().operand)
     u64 inv_n_quo;  //                            (.quotient)
+    // FP64 fast path (valid when q < 2^50, see dev_math_f64.hpp)
+    double pd;        // (double) q
+    double inv_pd;    // fl(1 / q)
+    double inv_n_d;   // (double) N^-1 mod q
+    double inv_n_pd;  // fl(inv_n_d / q)
     u64 pad_[3];
 };
+static_assert(sizeof(DevModulus) == 96, "DevModulus layout");
 
 __device__ __forceinline__ u64 mul_hi(u64 a, u64 b) { return __umul64hi(a, b); }
 

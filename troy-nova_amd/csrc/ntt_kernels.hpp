@@ -17,6 +17,7 @@
 //     the same banks.
 #pragma once
 #include "dev_math.hpp"
+#include "dev_math_f64.hpp"
 #include <type_traits>
 
 namespace troyn {
@@ -25,7 +26,7 @@ struct NttArgs {
     const u64* in;
     u64* out;
     const DevModulus* mods;   // [n_moduli]
-    const ulonglong2* tw;     // [n_moduli][N] forward or inverse table (operand, quotient)
+    const void* tw;           // [n_moduli][N] forward or inverse table: (operand, quotient) u64 pairs, or (w, w/p) double pairs
     long long in_bstride, in_pstride, in_cstride;     // element strides: batch, polynomial, component
     long long out_bstride, out_pstride, out_cstride;
     unsigned pcount, ncomp;
@@ -54,6 +55,80 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// ---- arithmetic policies -------------------------------------------------------------------
+// ArithU64: 64-bit Harvey/Shoup butterflies in the integer ALU, any modulus < 2^61 (the reference's
+//           lazy ranges: [0,4q) forward, [0,2q) inverse; fgk/ntt_grouped.cu:204-233, :540-572).
+// ArithF64: the same butterflies on integer-valued doubles for moduli < 2^50 (dev_math_f64.hpp).
+struct ArithU64 {
+    using elem = u64;
+    using tw_t = ulonglong2;
+    static constexpr bool MID_FIX = false;
+    struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo; };
+    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo}; }
+    static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
+    static __device__ __forceinline__ elem load_mid(u64 raw, const Mod&) { return raw; }
+    static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return x; }
+    static __device__ __forceinline__ elem from_lds(u64 raw) { return raw; }
+    static __device__ __forceinline__ u64 to_lds(elem x, const Mod&) { return x; }
+    static __device__ __forceinline__ elem mid_fix(elem x, const Mod&) { return x; }
+    static __device__ __forceinline__ void fwd(elem& a, elem& b, const tw_t w, const Mod& m) {
+        u64 u = a;
+        u = u >= m.two_q ? u - m.two_q : u;
+        const u64 v = shoup_lazy(b, w.x, w.y, m.q);
+        a = u + v;
+        b = u + m.two_q - v;
+    }
+    static __device__ __forceinline__ void inv(elem& a, elem& b, const tw_t w, const Mod& m) {
+        const u64 u = a, v = b;
+        const u64 s = u + v;
+        a = s >= m.two_q ? s - m.two_q : s;
+        b = shoup_lazy(u + m.two_q - v, w.x, w.y, m.q);
+    }
+    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {
+        v = v >= m.two_q ? v - m.two_q : v;
+        return v >= m.q ? v - m.q : v;
+    }
+    static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) {
+        return shoup_lazy(final_fwd(v, m), m.ninv_op, m.ninv_quo, m.q);   // the reference's lazy N^-1 multiply
+    }
+};
+
+struct ArithF64 {
+    using elem = double;
+    using tw_t = double2;
+    static constexpr bool MID_FIX = true;   // inverse blocks of 4 layers re-centre their sums after 2
+    struct Mod { F64Mod m; double ninv, ninv_p; };
+    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd}; }
+    static __device__ __forceinline__ elem load_first(u64 raw, bool, const Mod& m) { return f64_corr(f64_from_u64(raw), m.m); }
+    static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
+    static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
+    static __device__ __forceinline__ elem from_lds(u64 raw) { return f64_bits_to_double(raw); }
+    static __device__ __forceinline__ u64 to_lds(elem x, const Mod& m) { return f64_double_to_bits(f64_corr(x, m.m)); }
+    static __device__ __forceinline__ elem mid_fix(elem x, const Mod& m) { return f64_corr(x, m.m); }
+    static __device__ __forceinline__ void fwd(elem& a, elem& b, const tw_t w, const Mod& m) {
+        const double r = f64_mulc(b, w.x, w.y, m.m.p);
+        const double u = a;
+        a = u + r;
+        b = u - r;
+    }
+    static __device__ __forceinline__ void inv(elem& a, elem& b, const tw_t w, const Mod& m) {
+        const double u = a, v = b;
+        a = u + v;
+        b = f64_mulc(u - v, w.x, w.y, m.m.p);
+    }
+    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) { return f64_canon(v, m.m); }
+    static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) { return f64_canon(f64_mulc(v, m.ninv, m.ninv_p, m.m.p), m.m); }
+};
+
+// Which local index bits identify the wave (thread bits >= 6) when the register window starts at bit S.
+// If two consecutive rounds have the same set, a wave reads back exactly the LDS words it wrote itself
+// (register <-> lane transpose), so that exchange needs no workgroup barrier at all.
+__host__ __device__ constexpr unsigned ntt_wave_bits(int S, int EB, int TB) {
+    unsigned m = 0;
+    for (int p = 6; p < TB - EB; ++p) m |= 1u << (p < S ? p : p + EB);
+    return m;
+}
+
 // One pass over the transform bits [LOGN-LO-G, LOGN-LO) of a 2^LOGN-point transform.
 //   tile = all 2^G values of those bits x 2^C consecutive low indices, C = TB - G;
 //   local index = (mid << C) | low, transform bits = local bits [C, TB).
@@ -62,7 +137,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Round r keeps local bits [S, S+EB) in registers and runs the butterflies of the transform
 // bits [BLO, BHI] that fall inside that window.
 // FIRST/LAST mark the first/last pass of the whole transform (prologue / final correction).
-template <int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
 __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     constexpr int C = TB - G;
     constexpr int E = 1 << EB;
@@ -71,6 +146,8 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     constexpr int NLB = LOGN - LO - G - C;             // low-block bits in the tile id
     static_assert(G >= 1 && C >= 0 && NLB >= 0 && TB >= EB, "bad NTT pass shape");
     constexpr int ROUNDS = (G + EB - 1) / EB;
+    using elem = typename A::elem;
+    using tw_t = typename A::tw_t;
 
     __shared__ u64 lds[ROUNDS > 1 ? ntt_lds_words(TB) : 1];
 
@@ -84,9 +161,14 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     const unsigned lb = tile & ((1u << NLB) - 1);
 
     const unsigned mi = ntt_table_index(a, k, j);
-    const DevModulus md = a.mods[mi];
-    const u64 q = md.q, two_q = md.q << 1;
-    const ulonglong2* __restrict__ tw = a.tw + (size_t)mi * N;
+    const typename A::Mod md = A::make(a.mods[mi]);
+    // twiddle tables are never written by a kernel: read them through the constant address space so that
+    // wave-uniform fetches become scalar loads and stay out of the vector-memory queue
+    typedef decltype(tw_t{}.x) tw_scalar;
+    typedef tw_scalar tw_raw __attribute__((ext_vector_type(2)));
+    typedef const tw_raw __attribute__((address_space(4)))* ctw_ptr;
+    const ctw_ptr twc = (ctw_ptr)(unsigned long long)(reinterpret_cast<const tw_t*>(a.tw) + (size_t)mi * N);
+    auto tw_load = [&](unsigned idx) -> tw_t { const tw_raw v = twc[idx]; tw_t w; w.x = v.x; w.y = v.y; return w; };
     const u64* __restrict__ gin = a.in + (long long)b * a.in_bstride + (long long)k * a.in_pstride + (long long)j * a.in_cstride;
     u64* __restrict__ gout = a.out + (long long)b * a.out_bstride + (long long)k * a.out_pstride + (long long)j * a.out_cstride;
 
@@ -94,7 +176,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
         return (top << (LOGN - LO)) | ((loc >> C) << (LOGN - LO - G)) | (lb << C) | (loc & ((1u << C) - 1));
     };
 
-    u64 x[E];
+    elem x[E];
 
     static_for<0, ROUNDS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
@@ -105,70 +187,105 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
         static_assert(S >= 0 && S + EB <= TB && BLO >= S && BHI < S + EB && BLO <= BHI, "bad round window");
         const unsigned tlow = t & ((1u << S) - 1);
         const unsigned locbase = tlow | ((t >> S) << (S + EB));
+        // the twiddle index only sees bits above the butterfly bit; when S >= 6 those are wave-uniform
+        const unsigned twbase = (S >= 6) ? ((unsigned)__builtin_amdgcn_readfirstlane((int)(t >> S)) << (S + EB)) : locbase;
+
+        // window of the previous / next round (for the wave-private exchange test)
+        constexpr int S_PREV = (r == 0) ? S : (INV ? ((C + (r - 1) * EB < TB - EB) ? C + (r - 1) * EB : TB - EB)
+                                                   : ((TB - r * EB > 0) ? TB - r * EB : 0));
+        constexpr int S_NEXT = (r == ROUNDS - 1) ? S : (INV ? ((C + (r + 1) * EB < TB - EB) ? C + (r + 1) * EB : TB - EB)
+                                                            : ((TB - (r + 2) * EB > 0) ? TB - (r + 2) * EB : 0));
+        constexpr bool PRIVATE_IN = (r > 0) && ntt_wave_bits(S_PREV, EB, TB) == ntt_wave_bits(S, EB, TB);
+        constexpr bool PRIVATE_OUT = (r < ROUNDS - 1) && ntt_wave_bits(S, EB, TB) == ntt_wave_bits(S_NEXT, EB, TB);
+        (void)PRIVATE_IN;
 
         if constexpr (r == 0) {
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                u64 v = gin[gindex(locbase | ((unsigned)R << S))];
-                if (FIRST && a.reduce_input) v = barrett64(v, q, md.ratio_hi);
-                x[R] = v;
+#ifdef TROYN_ABLATE_NO_GLOAD
+                const u64 raw = (u64)(t * 16 + R + blockIdx.x);
+#else
+                const u64 raw = gin[gindex(locbase | ((unsigned)R << S))];
+#endif
+                if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
+                else x[R] = A::load_mid(raw, md);
             });
         } else {
+#ifndef TROYN_ABLATE_NO_LDS
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                x[R] = lds[lds_phys(locbase | ((unsigned)R << S))];
+                x[R] = A::from_lds(lds[lds_phys(locbase | ((unsigned)R << S))]);
             });
+#endif
         }
 
         constexpr int NLAYERS = BHI - BLO + 1;
         static_for<0, NLAYERS>([&](auto lc) {
             // forward: highest bit first; inverse: lowest bit first
-            constexpr int bit = INV ? BLO + decltype(lc)::value : BHI - decltype(lc)::value;
+            constexpr int li = decltype(lc)::value;
+            constexpr int bit = INV ? BLO + li : BHI - li;
             constexpr int rb = bit - S;            // register bit
             constexpr int kk = TB - 1 - bit;       // layer inside the tile
             constexpr int l = LO + kk;             // global (forward-numbered) layer of this bit
             static_for<0, (E >> (rb + 1))>([&](auto hc) {
                 constexpr int hi = decltype(hc)::value;
-                const unsigned loc0 = locbase | ((unsigned)(hi << (rb + 1)) << S);
+                const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
                 const unsigned grp = (top << kk) + (loc0 >> (bit + 1));
-                const ulonglong2 w = INV ? tw[N - (2u << l) + 1 + grp] : tw[(1u << l) + grp];
+                const tw_t w = tw_load(INV ? N - (2u << l) + 1 + grp : (1u << l) + grp);
                 static_for<0, (1 << rb)>([&](auto oc) {
                     constexpr int R0 = (hi << (rb + 1)) | decltype(oc)::value;
                     constexpr int R1 = R0 | (1 << rb);
-                    if constexpr (!INV) {
-                        u64 u = x[R0];
-                        u = u >= two_q ? u - two_q : u;
-                        const u64 v = shoup_lazy(x[R1], w.x, w.y, q);
-                        x[R0] = u + v;
-                        x[R1] = u + two_q - v;
-                    } else {
-                        const u64 u = x[R0], v = x[R1];
-                        const u64 s = u + v;
-                        x[R0] = s >= two_q ? s - two_q : s;
-                        x[R1] = shoup_lazy(u + two_q - v, w.x, w.y, q);
+#ifdef TROYN_ABLATE_NO_BUTTERFLY
+                    x[R0] = x[R0] + x[R1]; (void)w;
+#else
+                    if constexpr (!INV) A::fwd(x[R0], x[R1], w, md);
+                    else {
+                        A::inv(x[R0], x[R1], w, md);
+                        if constexpr (A::MID_FIX && NLAYERS == 4 && li == 1) x[R0] = A::mid_fix(x[R0], md);
                     }
+#endif
                 });
             });
         });
 
-        if constexpr (r == ROUNDS - 1) {
+        if constexpr (r == ROUNDS - 1 && !INV && LAST && S == 0 && C == 0 && ROUNDS > 1) {
+            // A thread ends with E consecutive coefficients, a wave with 64*E.  Transpose them inside the wave's own
+            // LDS slice (exactly the words this wave read in the last exchange, so no other wave is disturbed)
+            // and store 16 bytes per lane to consecutive addresses: every store instruction writes 1 KiB of
+            // consecutive bytes instead of touching 64 different 128-byte lines.
+            const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                u64 v = x[R];
-                if constexpr (LAST) {
-                    v = v >= two_q ? v - two_q : v;
-                    v = v >= q ? v - q : v;
-                    if constexpr (INV) v = shoup_lazy(v, md.inv_n_op, md.inv_n_quo, q);
-                }
+                lds[lds_phys(wbase + lane * E + R)] = A::final_fwd(x[R], md);
+            });
+            __builtin_amdgcn_wave_barrier();
+            const unsigned gbase = gindex(wbase);
+            static_for<0, E / 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned idx = m * 128u + lane * 2u;
+                const u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
+                *reinterpret_cast<ulonglong2*>(gout + gbase + idx) = make_ulonglong2(v0, v1);
+            });
+        } else if constexpr (r == ROUNDS - 1) {
+            static_for<0, E>([&](auto Rc) {
+                constexpr int R = decltype(Rc)::value;
+                u64 v;
+                if constexpr (LAST) v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
+                else v = A::store_mid(x[R], md);
                 gout[gindex(locbase | ((unsigned)R << S))] = v;
             });
         } else {
-            if constexpr (r > 0) __syncthreads();   // all reads of the previous exchange are done
+#ifndef TROYN_ABLATE_NO_LDS
+            // WAR: a thread overwrites exactly the words it read itself at the start of this round (same window S),
+            // so no barrier is needed before the writes.
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[lds_phys(locbase | ((unsigned)R << S))] = x[R];
+                lds[lds_phys(locbase | ((unsigned)R << S))] = A::to_lds(x[R], md);
             });
-            __syncthreads();
+            // RAW: readers are the writer's own wave (LDS executes a wave's accesses in order) or other waves
+            if constexpr (PRIVATE_OUT) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();
+#endif
         }
     });
 }
@@ -186,7 +303,7 @@ __global__ __launch_bounds__(256) void ntt_generic_kernel(NttArgs a, unsigned lo
     const unsigned mi = ntt_table_index(a, k, j);
     const DevModulus md = a.mods[mi];
     const u64 q = md.q, two_q = md.q << 1;
-    const ulonglong2* __restrict__ tw = a.tw + (size_t)mi * n;
+    const ulonglong2* __restrict__ tw = reinterpret_cast<const ulonglong2*>(a.tw) + (size_t)mi * n;
     const u64* gin = a.in + (long long)b * a.in_bstride + (long long)k * a.in_pstride + (long long)j * a.in_cstride;
     u64* gout = a.out + (long long)b * a.out_bstride + (long long)k * a.out_pstride + (long long)j * a.out_cstride;
     const bool use_lds = n <= 4096;

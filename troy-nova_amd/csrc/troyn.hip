@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -86,6 +87,9 @@ struct troyn_plan {
     DevModulus* d_mods = nullptr;         // [K]
     ulonglong2* d_fwd = nullptr;          // [K][N]
     ulonglong2* d_inv = nullptr;          // [K][N]
+    double2* d_fwd_f64 = nullptr;         // [K][N] (w, w/q) for moduli < 2^50 (zeros otherwise)
+    double2* d_inv_f64 = nullptr;         // [K][N]
+    std::vector<char> small_modulus;      // [K] 1 iff q < 2^50 (FP64 fast path usable)
     ulonglong2* d_inv_last = nullptr;     // [(K+1)][K]: row L holds q_{L-1}^-1 mod q_i, i < L-1
 };
 
@@ -100,8 +104,10 @@ static DevModulus make_dev_modulus(u64 q, unsigned log_n, bool with_inv_n) {
         if (host::invmod(((u64)1 << log_n) % q, q, ninv)) {
             host::Shoup s = host::shoup(ninv, q);
             m.inv_n_op = s.operand; m.inv_n_quo = s.quotient;
+            if (q < F64_MODULUS_LIMIT) { m.inv_n_d = (double)ninv; m.inv_n_pd = (double)ninv / (double)q; }
         }
     }
+    if (q < F64_MODULUS_LIMIT) { m.pd = (double)q; m.inv_pd = 1.0 / (double)q; }
     return m;
 }
 
@@ -134,6 +140,23 @@ static int plan_upload(troyn_plan* p) {
         HIP_TRY(hipMemcpy(p->d_inv + i * n, p->tables[i].inv.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(p->d_inv_last, inv_last.data(), inv_last.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
+    // FP64 twiddles (w, fl(w/q)) for the moduli below 2^50
+    p->small_modulus.assign(K, 0);
+    HIP_TRY(hipMalloc(&p->d_fwd_f64, K * n * sizeof(double2)));
+    HIP_TRY(hipMalloc(&p->d_inv_f64, K * n * sizeof(double2)));
+    HIP_TRY(hipMemset(p->d_fwd_f64, 0, K * n * sizeof(double2)));
+    HIP_TRY(hipMemset(p->d_inv_f64, 0, K * n * sizeof(double2)));
+    std::vector<double2> tmp(n);
+    for (size_t i = 0; i < K; i++) {
+        const u64 q = p->moduli[i];
+        if (q >= F64_MODULUS_LIMIT) continue;
+        p->small_modulus[i] = 1;
+        const double qd = (double)q;
+        for (size_t x = 0; x < n; x++) { const double w = (double)p->tables[i].fwd[x].operand; tmp[x] = make_double2(w, w / qd); }
+        HIP_TRY(hipMemcpy(p->d_fwd_f64 + i * n, tmp.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+        for (size_t x = 0; x < n; x++) { const double w = (double)p->tables[i].inv[x].operand; tmp[x] = make_double2(w, w / qd); }
+        HIP_TRY(hipMemcpy(p->d_inv_f64 + i * n, tmp.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+    }
     return TROYN_OK;
 }
 
@@ -143,6 +166,8 @@ static void plan_free(troyn_plan* p) {
     if (p->d_fwd) (void)hipFree(p->d_fwd);
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_inv_last) (void)hipFree(p->d_inv_last);
+    if (p->d_fwd_f64) (void)hipFree(p->d_fwd_f64);
+    if (p->d_inv_f64) (void)hipFree(p->d_inv_f64);
     delete p;
 }
 
@@ -197,22 +222,22 @@ extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, i
 // ---------------------------------------------------------------------------------------
 // NTT launch
 // ---------------------------------------------------------------------------------------
-template <int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
 static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     const unsigned tiles = 1u << (LOGN - TB);
     dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
-    hipLaunchKernelGGL((ntt_pass_kernel<LOGN, LO, G, TB, EB, INV, FIRST, LAST>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST>), grid, block, 0, s, a);
 }
 
 // single pass: whole limb in one tile
-template <int LOGN, int EB>
+template <class A, int LOGN, int EB>
 static void launch_single(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
-    if (inv) launch_pass<LOGN, 0, LOGN, LOGN, EB, true, true, true>(a, lp, s);
-    else launch_pass<LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
+    if (inv) launch_pass<A, LOGN, 0, LOGN, LOGN, EB, true, true, true>(a, lp, s);
+    else launch_pass<A, LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
 }
 
 // two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks
-template <int LOGN, int TB, int EB>
+template <class A, int LOGN, int TB, int EB>
 static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
     constexpr int G1 = LOGN - TB;
     NttArgs second = a;   // the second pass works in place on `out`
@@ -220,32 +245,55 @@ static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s
     second.in_bstride = a.out_bstride; second.in_pstride = a.out_pstride; second.in_cstride = a.out_cstride;
     second.reduce_input = 0;
     if (!inv) {
-        launch_pass<LOGN, 0, G1, TB, EB, false, true, false>(a, lp, s);
-        launch_pass<LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
+        launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, lp, s);
+        launch_pass<A, LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
     } else {
-        launch_pass<LOGN, G1, TB, TB, EB, true, true, false>(a, lp, s);
-        launch_pass<LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
+        launch_pass<A, LOGN, G1, TB, TB, EB, true, true, false>(a, lp, s);
+        launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
     }
 }
 
+template <class A>
+static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s) {
+    switch (log_n) {
+        case 10: launch_single<A, 10, 4>(a, lp, inverse, s); return true;
+        case 11: launch_single<A, 11, 4>(a, lp, inverse, s); return true;
+        case 12: launch_single<A, 12, 4>(a, lp, inverse, s); return true;
+        case 13: launch_single<A, 13, 4>(a, lp, inverse, s); return true;
+        case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
+        case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s); return true;
+        case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s); return true;
+        case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s); return true;
+        default: return false;
+    }
+}
+
+static int g_force_integer_ntt = -1;   // TROYN_NTT_ARITH=u64 forces the integer butterflies (A/B testing)
+
 static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s) {
     a.mods = p->d_mods;
-    a.tw = inverse ? p->d_inv : p->d_fwd;
     const size_t lp = batch * a.pcount * a.ncomp;
     if (lp == 0) return TROYN_OK;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
-    switch (p->log_n) {
-        case 10: launch_single<10, 4>(a, lp, inverse, s); break;
-        case 11: launch_single<11, 4>(a, lp, inverse, s); break;
-        case 12: launch_single<12, 4>(a, lp, inverse, s); break;
-        case 13: launch_single<13, 4>(a, lp, inverse, s); break;
-        case 14: launch_single<14, 4>(a, lp, inverse, s); break;
-        case 15: launch_two_pass<15, 12, 4>(a, lp, inverse, s); break;
-        case 16: launch_two_pass<16, 12, 4>(a, lp, inverse, s); break;
-        case 17: launch_two_pass<17, 12, 4>(a, lp, inverse, s); break;
-        default:
-            hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)lp), dim3(256), 0, s, a, p->log_n, inverse ? 1 : 0);
+    if (g_force_integer_ntt < 0) {
+        const char* e = getenv("TROYN_NTT_ARITH");
+        g_force_integer_ntt = (e && std::strcmp(e, "u64") == 0) ? 1 : 0;
+    }
+    // FP64 butterflies when every modulus this launch can touch is below 2^50
+    bool f64 = !g_force_integer_ntt && p->log_n >= 10;
+    for (unsigned i = 0; f64 && i < a.table_count; i++) f64 = p->small_modulus[a.table_start + i] != 0;
+    bool done;
+    if (f64) {
+        a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
+        done = launch_ntt_optimised<ArithF64>(p->log_n, a, lp, inverse, s);
+    } else {
+        a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
+        done = launch_ntt_optimised<ArithU64>(p->log_n, a, lp, inverse, s);
+    }
+    if (!done) {
+        a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
+        hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)lp), dim3(256), 0, s, a, p->log_n, inverse ? 1 : 0);
     }
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -467,18 +515,20 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         last_src = ws + w.prod_intt + (size_t)L * n; last_stride = (size_t)(L + 1) * n;
         prod_for_util7 = ws + w.prod_intt;
     }
-    // (5) rounding fix of the special-prime component, per data limb (:570-598)
+    // (5) rounding fix of the special-prime component, per data limb (:570-598).  In NTT form the result goes to
+    //     the unused tail of the prod_intt region so that step (6) can transform out of place.
+    u64* util6_out = is_ntt_form ? ws + w.prod_intt + batch * 2 * (size_t)n : ws + w.temp_last;
     {
         const unsigned ch = chunks_pairs(n);
         const size_t rows = batch * 2 * L;
         if ((rc = check_rows(rows, ch))) return rc;
         hipLaunchKernelGGL(ks_util6_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
-                           ch, p->d_mods, K, L, n, last_src, last_stride, ws + w.temp_last);
+                           ch, p->d_mods, K, L, n, last_src, last_stride, util6_out);
         LAUNCH_CHECK();
     }
     // (6) back to NTT form when needed (:1033-1036)
     if (is_ntt_form) {
-        NttArgs a = contiguous_args(p, ws + w.temp_last, ws + w.temp_last, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        NttArgs a = contiguous_args(p, util6_out, ws + w.temp_last, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
         if ((rc = launch_ntt(p, a, batch, false, s))) return rc;
     }
     // (7) divide by the special prime and assign (:625-658)
@@ -531,7 +581,7 @@ extern "C" int troyn_divide_and_round_q_last(const troyn_plan* p, uint32_t L, co
 
 extern "C" size_t troyn_divide_and_round_q_last_ntt_workspace_bytes(const troyn_plan* p, uint32_t L, size_t pcount, size_t batch) {
     if (!p || L < 1) return 0;
-    return batch * pcount * (size_t)L * p->n * sizeof(u64);   // last_intt [items][N] + temp [items][L-1][N]
+    return batch * pcount * (size_t)(2 * L - 1) * p->n * sizeof(u64);   // last_intt [items][N] + 2 x temp [items][L-1][N]
 }
 
 extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L, const uint64_t* in, size_t pcount,
@@ -545,7 +595,8 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
     const size_t items = batch * pcount, n = p->n;
     if (items == 0) return TROYN_OK;
     u64* last_intt = (u64*)workspace;
-    u64* temp = last_intt + items * n;
+    u64* temp0 = last_intt + items * n;               // step1 output (coefficient form)
+    u64* temp = temp0 + items * (size_t)(L - 1) * n;  // its NTT (out of place: lets the NTT use half-limb workgroups)
     int rc;
     // INTT of the last limb only (the reference's device branch transforms all L limbs, utils/rns_tool.cu:675)
     {
@@ -556,10 +607,10 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
     const unsigned ch = chunks_pairs(p->n);
     const size_t rows = items * (L - 1);
     if ((rc = check_rows(rows, ch))) return rc;
-    hipLaunchKernelGGL(rescale_step1_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n, last_intt, temp);
+    hipLaunchKernelGGL(rescale_step1_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n, last_intt, temp0);
     LAUNCH_CHECK();
     {
-        NttArgs a = contiguous_args(p, temp, temp, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+        NttArgs a = contiguous_args(p, temp0, temp, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
         if ((rc = launch_ntt(p, a, items, false, s))) return rc;
     }
     hipLaunchKernelGGL(rescale_step2_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n,
