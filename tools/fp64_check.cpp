@@ -45,7 +45,7 @@ static int check(unsigned log_n, u64 q, unsigned seed, int adversarial) {
     for (unsigned layer = 0; layer < log_n; layer++) {
         const size_t mm = (size_t)1 << layer, gap = n >> (layer + 1);
         for (size_t g = 0; g < mm; g++) {
-            const double w = (double)t->root_powers[mm + g].operand, wp = w / p;
+            const double w = (double)t->root_powers[mm + g].operand, wp = w * m.inv_p;
             for (size_t j = 0; j < gap; j++) {
                 const size_t a = 2 * g * gap + j, b = a + gap;
                 const double r = f64_mulc(x[b], w, wp, p);
@@ -68,7 +68,7 @@ static int check(unsigned log_n, u64 q, unsigned seed, int adversarial) {
     for (unsigned layer = 0; layer < log_n; layer++) {
         const size_t gap = (size_t)1 << layer, mm = n >> (layer + 1);
         for (size_t g = 0; g < mm; g++) {
-            const double w = (double)t->inv_root_powers[n - 2 * mm + 1 + g].operand, wp = w / p;
+            const double w = (double)t->inv_root_powers[n - 2 * mm + 1 + g].operand, wp = w * m.inv_p;
             for (size_t j = 0; j < gap; j++) {
                 const size_t a = 2 * g * gap + j, b = a + gap;
                 const double u = x[a], v = x[b];
@@ -83,7 +83,7 @@ static int check(unsigned log_n, u64 q, unsigned seed, int adversarial) {
         }
         if ((layer + 1) % 4 == 0) for (size_t i = 0; i < n; i++) x[i] = f64_corr(x[i], m);
     }
-    const double ninv = (double)t->inv_degree_modulo.operand, ninv_p = ninv / p;
+    const double ninv = (double)t->inv_degree_modulo.operand, ninv_p = ninv * m.inv_p;
     for (size_t i = 0; i < n; i++) {
         const double r = f64_mulc(x[i], ninv, ninv_p, p);
         if (f64_canon(r, m) != inv_ref[i]) { if (bad2 < 3) printf("inv mismatch i=%zu\n", i); bad2++; }

@@ -8,13 +8,14 @@
 // bit-identical to the reference's Barrett/Shoup results:
 //   * all values are integers of magnitude < 2^53, hence exactly representable;
 //   * mulc(): h = fl(y*w), l = fma(y,w,-h) is the error-free product (y*w = h + l exactly);
-//     q = rint(fl(y*wp)) with wp = fl(w/p) is within 0.5 + |y|*2^-52 of y*w/p; h - q*p is an integer
-//     below 2^53 so fma(-q,p,h) is exact, and r = (h - q*p) + l = y*w - q*p exactly,
-//     |r| <= (0.5 + |y|*2^-52) * p.
+//     q = rint(fl(y*wp)) with wp = fl(w * fl(1/p)) (relative error <= 1.5 * 2^-52) is within
+//     0.5 + 1.5*|y|*2^-52 of y*w/p; h - q*p is an integer below 2^53 so fma(-q,p,h) is exact, and
+//     r = (h - q*p) + l = y*w - q*p exactly, |r| <= (0.5 + 1.5*|y|*2^-52) * p.
 //   * corr(): x - rint(x/p)*p, exact for |x| < 2^53, result |x| <= 0.5p + 1.
 // Bounds used by the NTT kernels (p < 2^50): forward blocks of 4 Cooley-Tukey layers start with
-// |x| <= 0.5p+1 and stay below 4.2p; inverse blocks of 4 Gentleman-Sande layers re-centre the sums
-// after 2 layers and stay below 4.1p; both are < 2^53 = 8 * 2^50.
+// |x| <= 0.5p+1 and stay below 5.2p; inverse blocks of 4 Gentleman-Sande layers re-centre the sums
+// after 2 layers and stay below 4.5p; both are < 2^53 = 8 * 2^50 (tools/fp64_check.cpp prints the
+// maxima actually reached).
 #pragma once
 #include "dev_math.hpp"
 

@@ -26,7 +26,7 @@ struct NttArgs {
     const u64* in;
     u64* out;
     const DevModulus* mods;   // [n_moduli]
-    const void* tw;           // [n_moduli][N] forward or inverse table: (operand, quotient) u64 pairs, or (w, w/p) double pairs
+    const void* tw;           // [n_moduli][N] forward or inverse table: (operand, quotient) u64 pairs, or w as double
     long long in_bstride, in_pstride, in_cstride;     // element strides: batch, polynomial, component
     long long out_bstride, out_pstride, out_cstride;
     unsigned pcount, ncomp;
@@ -46,6 +46,27 @@ constexpr int NTT_PAD_SHIFT = 5;
 __host__ __device__ constexpr unsigned ntt_lds_words(int tb) { return (1u << tb) + ((1u << tb) >> NTT_PAD_SHIFT); }
 __device__ __forceinline__ unsigned lds_phys(unsigned loc) { return loc + (loc >> NTT_PAD_SHIFT); }
 
+// Streaming (non-temporal) accesses for the polynomial data: every word is touched once per kernel, while the
+// twiddle tables (same size as one limb, shared by every workgroup of that modulus) should stay in the XCD's L2.
+#ifdef TROYN_NO_NT
+__device__ __forceinline__ u64 nt_load(const u64* p) { return *p; }
+__device__ __forceinline__ ulonglong2 nt_load2(const u64* p) { return *reinterpret_cast<const ulonglong2*>(p); }
+__device__ __forceinline__ void nt_store(u64* p, u64 v) { *p = v; }
+__device__ __forceinline__ void nt_store2(u64* p, u64 a, u64 b) { *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(a, b); }
+#else
+typedef u64 u64x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64 nt_load(const u64* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ ulonglong2 nt_load2(const u64* p) {
+    const u64x2_native v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_native*>(p));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store(u64* p, u64 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store2(u64* p, u64 a, u64 b) {
+    u64x2_native v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<u64x2_native*>(p));
+}
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E_, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -59,12 +80,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ArithU64: 64-bit Harvey/Shoup butterflies in the integer ALU, any modulus < 2^61 (the reference's
 //           lazy ranges: [0,4q) forward, [0,2q) inverse; fgk/ntt_grouped.cu:204-233, :540-572).
 // ArithF64: the same butterflies on integer-valued doubles for moduli < 2^50 (dev_math_f64.hpp).
+typedef u64 u64x2_mem __attribute__((ext_vector_type(2)));
 struct ArithU64 {
     using elem = u64;
     using tw_t = ulonglong2;
+    using tw_mem = u64x2_mem;     // (operand, quotient) as stored in the table
+
     static constexpr bool MID_FIX = false;
     struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo; };
     static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo}; }
+    static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem v, const Mod&) { return make_ulonglong2(v.x, v.y); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod&) { return raw; }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return x; }
@@ -96,9 +121,11 @@ struct ArithU64 {
 struct ArithF64 {
     using elem = double;
     using tw_t = double2;
+    using tw_mem = double;        // only w is stored (8 bytes per twiddle); w/p is rebuilt as w * fl(1/p)
     static constexpr bool MID_FIX = true;   // inverse blocks of 4 layers re-centre their sums after 2
     struct Mod { F64Mod m; double ninv, ninv_p; };
     static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd}; }
+    static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem w, const Mod& m) { return make_double2(w, w * m.m.inv_p); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool, const Mod& m) { return f64_corr(f64_from_u64(raw), m.m); }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
@@ -164,11 +191,10 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     const typename A::Mod md = A::make(a.mods[mi]);
     // twiddle tables are never written by a kernel: read them through the constant address space so that
     // wave-uniform fetches become scalar loads and stay out of the vector-memory queue
-    typedef decltype(tw_t{}.x) tw_scalar;
-    typedef tw_scalar tw_raw __attribute__((ext_vector_type(2)));
-    typedef const tw_raw __attribute__((address_space(4)))* ctw_ptr;
-    const ctw_ptr twc = (ctw_ptr)(unsigned long long)(reinterpret_cast<const tw_t*>(a.tw) + (size_t)mi * N);
-    auto tw_load = [&](unsigned idx) -> tw_t { const tw_raw v = twc[idx]; tw_t w; w.x = v.x; w.y = v.y; return w; };
+    typedef typename A::tw_mem tw_mem;
+    typedef const tw_mem __attribute__((address_space(4)))* ctw_ptr;
+    const ctw_ptr twc = (ctw_ptr)(unsigned long long)(reinterpret_cast<const tw_mem*>(a.tw) + (size_t)mi * N);
+    auto tw_load = [&](unsigned idx) -> tw_t { const tw_mem v = twc[idx]; return A::tw_from_mem(v, md); };
     const u64* __restrict__ gin = a.in + (long long)b * a.in_bstride + (long long)k * a.in_pstride + (long long)j * a.in_cstride;
     u64* __restrict__ gout = a.out + (long long)b * a.out_bstride + (long long)k * a.out_pstride + (long long)j * a.out_cstride;
 
@@ -199,13 +225,34 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
         constexpr bool PRIVATE_OUT = (r < ROUNDS - 1) && ntt_wave_bits(S, EB, TB) == ntt_wave_bits(S_NEXT, EB, TB);
         (void)PRIVATE_IN;
 
-        if constexpr (r == 0) {
+        if constexpr (r == 0 && INV && S == 0 && C == 0 && ROUNDS > 1) {
+            // Mirror image of the forward store transpose: a thread starts with E consecutive coefficients.  Loading
+            // them directly makes every load instruction touch 64 different 128-byte lines; instead the wave loads
+            // its 64*E consecutive words with 16 bytes per lane, parks them in its own LDS slice (the words it will
+            // overwrite itself in the first exchange) and picks its coefficients from there.
+            const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            const unsigned gbase = gindex(wbase);
+            static_for<0, E / 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned idx = m * 128u + lane * 2u;
+                const ulonglong2 v = nt_load2(gin + gbase + idx);
+                lds[lds_phys(wbase + idx)] = v.x;
+                lds[lds_phys(wbase + idx + 1)] = v.y;
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, E>([&](auto Rc) {
+                constexpr int R = decltype(Rc)::value;
+                const u64 raw = lds[lds_phys(wbase + lane * E + R)];
+                if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
+                else x[R] = A::load_mid(raw, md);
+            });
+        } else if constexpr (r == 0) {
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
 #ifdef TROYN_ABLATE_NO_GLOAD
                 const u64 raw = (u64)(t * 16 + R + blockIdx.x);
 #else
-                const u64 raw = gin[gindex(locbase | ((unsigned)R << S))];
+                const u64 raw = nt_load(gin + gindex(locbase | ((unsigned)R << S)));
 #endif
                 if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
@@ -231,7 +278,11 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
                 constexpr int hi = decltype(hc)::value;
                 const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
                 const unsigned grp = (top << kk) + (loc0 >> (bit + 1));
+#ifdef TROYN_ABLATE_NO_TWIDDLE
+                const tw_t w = tw_load(1u + (grp & 1u));
+#else
                 const tw_t w = tw_load(INV ? N - (2u << l) + 1 + grp : (1u << l) + grp);
+#endif
                 static_for<0, (1 << rb)>([&](auto oc) {
                     constexpr int R0 = (hi << (rb + 1)) | decltype(oc)::value;
                     constexpr int R1 = R0 | (1 << rb);
@@ -264,7 +315,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 const u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
-                *reinterpret_cast<ulonglong2*>(gout + gbase + idx) = make_ulonglong2(v0, v1);
+                nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
             static_for<0, E>([&](auto Rc) {
@@ -272,7 +323,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
                 u64 v;
                 if constexpr (LAST) v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
                 else v = A::store_mid(x[R], md);
-                gout[gindex(locbase | ((unsigned)R << S))] = v;
+                nt_store(gout + gindex(locbase | ((unsigned)R << S)), v);
             });
         } else {
 #ifndef TROYN_ABLATE_NO_LDS

@@ -87,8 +87,8 @@ struct troyn_plan {
     DevModulus* d_mods = nullptr;         // [K]
     ulonglong2* d_fwd = nullptr;          // [K][N]
     ulonglong2* d_inv = nullptr;          // [K][N]
-    double2* d_fwd_f64 = nullptr;         // [K][N] (w, w/q) for moduli < 2^50 (zeros otherwise)
-    double2* d_inv_f64 = nullptr;         // [K][N]
+    double* d_fwd_f64 = nullptr;          // [K][N] w as double for moduli < 2^50 (zeros otherwise)
+    double* d_inv_f64 = nullptr;          // [K][N]
     std::vector<char> small_modulus;      // [K] 1 iff q < 2^50 (FP64 fast path usable)
     ulonglong2* d_inv_last = nullptr;     // [(K+1)][K]: row L holds q_{L-1}^-1 mod q_i, i < L-1
 };
@@ -104,7 +104,7 @@ static DevModulus make_dev_modulus(u64 q, unsigned log_n, bool with_inv_n) {
         if (host::invmod(((u64)1 << log_n) % q, q, ninv)) {
             host::Shoup s = host::shoup(ninv, q);
             m.inv_n_op = s.operand; m.inv_n_quo = s.quotient;
-            if (q < F64_MODULUS_LIMIT) { m.inv_n_d = (double)ninv; m.inv_n_pd = (double)ninv / (double)q; }
+            if (q < F64_MODULUS_LIMIT) { m.inv_n_d = (double)ninv; m.inv_n_pd = (double)ninv * (1.0 / (double)q); }
         }
     }
     if (q < F64_MODULUS_LIMIT) { m.pd = (double)q; m.inv_pd = 1.0 / (double)q; }
@@ -140,22 +140,21 @@ static int plan_upload(troyn_plan* p) {
         HIP_TRY(hipMemcpy(p->d_inv + i * n, p->tables[i].inv.data(), n * sizeof(ulonglong2), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(p->d_inv_last, inv_last.data(), inv_last.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
-    // FP64 twiddles (w, fl(w/q)) for the moduli below 2^50
+    // FP64 twiddles (w as an exact double) for the moduli below 2^50
     p->small_modulus.assign(K, 0);
-    HIP_TRY(hipMalloc(&p->d_fwd_f64, K * n * sizeof(double2)));
-    HIP_TRY(hipMalloc(&p->d_inv_f64, K * n * sizeof(double2)));
-    HIP_TRY(hipMemset(p->d_fwd_f64, 0, K * n * sizeof(double2)));
-    HIP_TRY(hipMemset(p->d_inv_f64, 0, K * n * sizeof(double2)));
-    std::vector<double2> tmp(n);
+    HIP_TRY(hipMalloc(&p->d_fwd_f64, K * n * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->d_inv_f64, K * n * sizeof(double)));
+    HIP_TRY(hipMemset(p->d_fwd_f64, 0, K * n * sizeof(double)));
+    HIP_TRY(hipMemset(p->d_inv_f64, 0, K * n * sizeof(double)));
+    std::vector<double> tmp(n);
     for (size_t i = 0; i < K; i++) {
         const u64 q = p->moduli[i];
         if (q >= F64_MODULUS_LIMIT) continue;
         p->small_modulus[i] = 1;
-        const double qd = (double)q;
-        for (size_t x = 0; x < n; x++) { const double w = (double)p->tables[i].fwd[x].operand; tmp[x] = make_double2(w, w / qd); }
-        HIP_TRY(hipMemcpy(p->d_fwd_f64 + i * n, tmp.data(), n * sizeof(double2), hipMemcpyHostToDevice));
-        for (size_t x = 0; x < n; x++) { const double w = (double)p->tables[i].inv[x].operand; tmp[x] = make_double2(w, w / qd); }
-        HIP_TRY(hipMemcpy(p->d_inv_f64 + i * n, tmp.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+        for (size_t x = 0; x < n; x++) tmp[x] = (double)p->tables[i].fwd[x].operand;
+        HIP_TRY(hipMemcpy(p->d_fwd_f64 + i * n, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        for (size_t x = 0; x < n; x++) tmp[x] = (double)p->tables[i].inv[x].operand;
+        HIP_TRY(hipMemcpy(p->d_inv_f64 + i * n, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
     return TROYN_OK;
 }
@@ -226,7 +225,9 @@ template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST
 static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     const unsigned tiles = 1u << (LOGN - TB);
     dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
-    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST>), grid, block, 0, s, a);
+    static int extra_lds = -1;   // TROYN_NTT_EXTRA_LDS=<bytes>: occupancy experiments only
+    if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST>), grid, block, (size_t)extra_lds, s, a);
 }
 
 // single pass: whole limb in one tile
