@@ -117,9 +117,17 @@ def main():
     limb_polys = B * (L + 1) * L
     alg_bytes = 16.0 * n * limb_polys
     achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel<14,fwd> (key-switch digits, %d limb-polys/launch)" % limb_polys,
+    # HBM traffic of that launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_ntt_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("grid_x") == limb_polys * 1024:
+            traffic = tj["traffic_bytes_per_launch"]
+    roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel<ArithF64,14,fwd> (forward NTT of the key-switch digits, %d limb-polys/launch)" % limb_polys,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launch_ms": round(ntt_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
     result = {

@@ -32,7 +32,106 @@ struct NttArgs {
     unsigned pcount, ncomp;
     unsigned table_start, table_count, mode, decomp;  // NTTTableIndexer (utils/ntt.h:105-124)
     unsigned reduce_input;   // 1: Barrett-reduce inputs mod the limb's modulus while loading
+    unsigned stream_loads;   // 1: inputs are read exactly once (non-temporal loads); 0: several blocks re-read them (keep in L2)
+    // ---- fused element-wise prologue / epilogue (see NttLoad / NttStore below) ----
+    unsigned load_mode, store_mode;
+    unsigned aux_mod;          // modulus index of the "other" prime (special prime / dropped prime)
+    unsigned skip_diag;        // 1: blocks with k == j < decomp produce nothing (the consumer reads the untouched input limb)
+    unsigned flags;            // bit0: CKKS lift (4q instead of 2q); bits 1-2: SwitchKeyDestinationAssignMethod
+    const u64* ext0;           // store: key-switch products / rescale input
+    long long ext0_bstride, ext0_pstride, ext0_cstride;
+    const u64* ext1;           // store: optional addend (relinearize's c0, c1)
+    long long ext1_bstride, ext1_pstride, ext1_cstride;
+    const ulonglong2* inv_table;   // store: Shoup pair of (dropped prime)^-1 mod q_j, indexed by component j
 };
+
+// Fused prologues: what a coefficient looks like when it enters the transform.
+enum NttLoad {
+    NTT_LOAD_PLAIN = 0,
+    // evaluator_keyswitching_core.cu:570-598 (ski_util6_merged): input = INTT of the special-prime row (same for
+    // every component j); value = ((x + qk/2) mod qk) mod q_j + (q_j - (qk/2 mod q_j))
+    NTT_LOAD_KS_ROUND = 1,
+    // utils/rns_tool.cu:523-550 (divide_and_round_q_last_ntt step 1): input = INTT of the last limb;
+    // value = ((x + ql/2) mod ql) mod q_i - (ql/2 mod q_i)
+    NTT_LOAD_RESCALE = 2,
+};
+// Fused epilogues: what happens to a canonical NTT output y before it is stored.
+enum NttStore {
+    NTT_STORE_PLAIN = 0,
+    // evaluator_keyswitching_core.cu:625-658 (ski_util7_merged): out = (prod + lift - y) * qk^-1 mod q_j, then
+    // overwrite / accumulate into the destination, plus relinearize's trailing add (evaluator_keyswitching.cu:143)
+    NTT_STORE_KS_FINISH = 1,
+    // utils/rns_tool.cu:607-627 (divide_and_round_q_last_ntt step 2): out = (in + 4q - y) * ql^-1 mod q_i
+    NTT_STORE_RESCALE = 2,
+};
+
+struct NttIo {
+    unsigned load_mode, store_mode;
+    // loader constants
+    u64 aux_q, aux_ratio_hi, aux_half;   // the other prime, its Barrett word, floor(aux/2)
+    u64 q, ratio_hi, fix;                // this limb's prime; fix = q - (aux_half mod q)  (KS)  or  (aux_half mod q) (rescale)
+    bool aux_bigger;
+    // storer
+    const u64* ext0; const u64* ext1; u64* dest;
+    ulonglong2 inv; u64 lift; bool add_inplace;
+};
+
+__device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi, u64* gout) {
+    NttIo io;
+    io.load_mode = a.load_mode; io.store_mode = a.store_mode;
+    const DevModulus md = a.mods[mi];
+    io.q = md.q; io.ratio_hi = md.ratio_hi;
+    io.aux_q = 0; io.aux_ratio_hi = 0; io.aux_half = 0; io.fix = 0; io.aux_bigger = false;
+    if (a.load_mode != NTT_LOAD_PLAIN) {
+        const DevModulus ax = a.mods[a.aux_mod];
+        io.aux_q = ax.q; io.aux_ratio_hi = ax.ratio_hi; io.aux_half = ax.q >> 1;
+        const u64 half_mod = barrett64(io.aux_half, md.q, md.ratio_hi);
+        io.fix = (a.load_mode == NTT_LOAD_KS_ROUND) ? md.q - half_mod : half_mod;
+        io.aux_bigger = ax.q > md.q;
+    }
+    io.ext0 = nullptr; io.ext1 = nullptr; io.dest = gout; io.inv = make_ulonglong2(0, 0); io.lift = 0; io.add_inplace = false;
+    if (a.store_mode != NTT_STORE_PLAIN) {
+        io.ext0 = a.ext0 + (long long)b * a.ext0_bstride + (long long)k * a.ext0_pstride + (long long)j * a.ext0_cstride;
+        if (a.ext1) io.ext1 = a.ext1 + (long long)b * a.ext1_bstride + (long long)k * a.ext1_pstride + (long long)j * a.ext1_cstride;
+        io.inv = a.inv_table[j];
+        io.lift = (a.store_mode == NTT_STORE_RESCALE || (a.flags & 1u)) ? (md.q << 2) : (md.q << 1);
+        const unsigned assign = (a.flags >> 1) & 3u;
+        io.add_inplace = (a.store_mode == NTT_STORE_KS_FINISH) && (assign == 0u || (k == 0u && assign == 2u));
+    }
+    return io;
+}
+
+// raw input word -> the word the transform should see (still subject to A::load_first)
+__device__ __forceinline__ u64 ntt_io_load(const NttIo& io, u64 raw) {
+    if (io.load_mode == NTT_LOAD_KS_ROUND) {
+        u64 t = barrett64(raw + io.aux_half, io.aux_q, io.aux_ratio_hi);
+        if (io.aux_bigger) t = barrett64(t, io.q, io.ratio_hi);
+        return t + io.fix;
+    }
+    if (io.load_mode == NTT_LOAD_RESCALE) {
+        u64 t = add_mod(raw, io.aux_half, io.aux_q);
+        if (io.aux_bigger) t = barrett64(t, io.q, io.ratio_hi);   // q_i < q_last
+        return sub_mod(t, io.fix, io.q);
+    }
+    return raw;
+}
+
+// canonical transform output y at limb-local index idx -> stored word
+__device__ __forceinline__ u64 ntt_io_store(const NttIo& io, u64 y, unsigned idx) {
+    if (io.store_mode == NTT_STORE_KS_FINISH) {
+        u64 d = shoup_mul(io.ext0[idx] + io.lift - y, io.inv.x, io.inv.y, io.q);
+        if (io.add_inplace) d = add_mod(io.dest[idx], d, io.q);
+        if (io.ext1) d = add_mod(d, io.ext1[idx], io.q);
+        return d;
+    }
+    if (io.store_mode == NTT_STORE_RESCALE) {
+        u64 d = add_mod(io.ext0[idx], io.lift, io.q);    // add_uint64_mod(x, 4q): x + 3q
+        d = sub_mod(d, y, io.q);
+        return shoup_mul(d, io.inv.x, io.inv.y, io.q);
+    }
+    return y;
+}
+
 
 __device__ __forceinline__ unsigned ntt_table_index(const NttArgs& a, unsigned k, unsigned j) {
     unsigned idx;
@@ -187,6 +286,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     const unsigned top = tile >> NLB;
     const unsigned lb = tile & ((1u << NLB) - 1);
 
+    if (a.skip_diag && k == j && k < a.decomp) return;   // consumer reads the original limb (see ks_accumulate_kernel)
     const unsigned mi = ntt_table_index(a, k, j);
     const typename A::Mod md = A::make(a.mods[mi]);
     // twiddle tables are never written by a kernel: read them through the constant address space so that
@@ -201,6 +301,10 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     auto gindex = [&](unsigned loc) -> unsigned {
         return (top << (LOGN - LO)) | ((loc >> C) << (LOGN - LO - G)) | (lb << C) | (loc & ((1u << C) - 1));
     };
+    const bool fused_io = (FIRST && a.load_mode != NTT_LOAD_PLAIN) || (LAST && a.store_mode != NTT_STORE_PLAIN);
+    NttIo io;
+    if (fused_io) io = ntt_io_make(a, b, k, j, mi, gout);
+    else { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; }
 
     elem x[E];
 
@@ -235,9 +339,9 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
-                const ulonglong2 v = nt_load2(gin + gbase + idx);
-                lds[lds_phys(wbase + idx)] = v.x;
-                lds[lds_phys(wbase + idx + 1)] = v.y;
+                const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
+                lds[lds_phys(wbase + idx)] = FIRST ? ntt_io_load(io, v.x) : v.x;
+                lds[lds_phys(wbase + idx + 1)] = FIRST ? ntt_io_load(io, v.y) : v.y;
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, E>([&](auto Rc) {
@@ -252,9 +356,9 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
 #ifdef TROYN_ABLATE_NO_GLOAD
                 const u64 raw = (u64)(t * 16 + R + blockIdx.x);
 #else
-                const u64 raw = nt_load(gin + gindex(locbase | ((unsigned)R << S)));
+                const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
-                if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
+                if constexpr (FIRST) x[R] = A::load_first(ntt_io_load(io, raw), a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
         } else {
@@ -314,16 +418,20 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
-                const u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
+                u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
+                if (io.store_mode != NTT_STORE_PLAIN) { v0 = ntt_io_store(io, v0, gbase + idx); v1 = ntt_io_store(io, v1, gbase + idx + 1); }
                 nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 u64 v;
-                if constexpr (LAST) v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
-                else v = A::store_mid(x[R], md);
-                nt_store(gout + gindex(locbase | ((unsigned)R << S)), v);
+                const unsigned gi = gindex(locbase | ((unsigned)R << S));
+                if constexpr (LAST) {
+                    v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
+                    if (io.store_mode != NTT_STORE_PLAIN) v = ntt_io_store(io, v, gi);
+                } else v = A::store_mid(x[R], md);
+                nt_store(gout + gi, v);
             });
         } else {
 #ifndef TROYN_ABLATE_NO_LDS

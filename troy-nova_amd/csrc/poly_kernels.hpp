@@ -134,8 +134,11 @@ struct KeyPtrs { const u64* p[KS_MAX_KEYS]; };
 // components from a single pass over its L digits; the <digit, key> sum is accumulated in
 // 128 bits and reduced once (a sum of L <= 64 products of 61-bit residues is < 2^128, and the
 // reference's per-term Barrett reduction yields the same canonical value).
+// diag != nullptr: the digit of row i under its own modulus (j == i < L) is the untouched NTT-form input limb
+// (the reference's host path does the same, evaluator_keyswitching_core.cu:851-852), read from diag[item][j].
 __global__ __launch_bounds__(POLY_BLOCK) void ks_accumulate_kernel(unsigned chunks, const DevModulus* mods, unsigned K, unsigned L, unsigned n,
-                                                                   const u64* temp_ntt, KeyPtrs keys, u64* poly_prod) {
+                                                                   const u64* temp_ntt, KeyPtrs keys, u64* poly_prod,
+                                                                   const u64* diag, size_t diag_bstride) {
     const unsigned i = blk_row(chunks) % (L + 1);
     const size_t item = blk_row(chunks) / (L + 1);
     const unsigned key_index = (i == L) ? K - 1 : i;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(POLY_BLOCK) void ks_accumulate_kernel(unsigned chun
     for (unsigned x = blk_col(chunks) * 2; x < n; x += chunks * blockDim.x * 2) {
         u64 lo00 = 0, hi00 = 0, lo01 = 0, hi01 = 0, lo10 = 0, hi10 = 0, lo11 = 0, hi11 = 0;
         for (unsigned j = 0; j < L; ++j) {
-            const u64x2 d = ld2(tp + (size_t)j * n + x);
+            const u64x2 d = (diag && j == i) ? ld2(diag + item * diag_bstride + (size_t)j * n + x) : ld2(tp + (size_t)j * n + x);
             const u64* kj = keys.p[j] + (size_t)key_index * n + x;
             const u64x2 k0 = ld2(kj), k1 = ld2(kj + key_poly);
             mac128(lo00, hi00, d.a, k0.a); mac128(lo01, hi01, d.b, k0.b);

@@ -273,6 +273,8 @@ static int g_force_integer_ntt = -1;   // TROYN_NTT_ARITH=u64 forces the integer
 
 static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s) {
     a.mods = p->d_mods;
+    // inputs shared by several limb-polynomials of the launch (stride 0) should stay cached
+    a.stream_loads = ((a.pcount <= 1 || a.in_pstride != 0) && (a.ncomp <= 1 || a.in_cstride != 0)) ? 1u : 0u;
     const size_t lp = batch * a.pcount * a.ncomp;
     if (lp == 0) return TROYN_OK;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
@@ -472,6 +474,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     int rc;
     const u64* digits_src = target;
     size_t digits_bstride = target_bstride;
+    // the optimised NTT kernels carry fused prologues / epilogues; tiny rings (generic kernel) use the unfused chain
+    const bool fused = is_ntt_form && p->log_n >= 10;
 
     // (1) NTT form: bring the target back to coefficient form (evaluator_keyswitching_core.cu:817-821)
     if (is_ntt_form) {
@@ -488,6 +492,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.in_bstride = (long long)digits_bstride;
         a.in_pstride = 0;            // every row re-reads the same L digits
         a.reduce_input = 1;
+        a.skip_diag = fused ? 1 : 0; // row i, digit i is the NTT-form input itself: not recomputed
         if ((rc = launch_ntt(p, a, batch, false, s))) return rc;
     }
     // (3) <digits, key> inner product (fgk/switch_key.cu:83-154)
@@ -496,7 +501,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         const size_t rows = batch * (L + 1);
         if ((rc = check_rows(rows, ch))) return rc;
         hipLaunchKernelGGL(ks_accumulate_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
-                           ch, p->d_mods, K, L, n, ws + w.temp_ntt, kp, ws + w.poly_prod);
+                           ch, p->d_mods, K, L, n, ws + w.temp_ntt, kp, ws + w.poly_prod,
+                           fused ? target : (const u64*)nullptr, target_bstride);
         LAUNCH_CHECK();
     }
     // (4) INTT: only the special-prime rows when the result stays in NTT form; all rows otherwise (:991-996)
@@ -515,6 +521,19 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
         last_src = ws + w.prod_intt + (size_t)L * n; last_stride = (size_t)(L + 1) * n;
         prod_for_util7 = ws + w.prod_intt;
+    }
+    if (fused) {
+        // (5)-(7) in ONE launch: the forward NTT reads the INTT'd special rows through the rounding-fix prologue
+        // (ski_util6_merged) and finishes with the divide-by-special-prime / assign epilogue (ski_util7_merged)
+        NttArgs a = contiguous_args(p, last_src, dest, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = 2ll * n; a.in_pstride = n; a.in_cstride = 0;
+        a.load_mode = NTT_LOAD_KS_ROUND; a.aux_mod = K - 1;
+        a.store_mode = NTT_STORE_KS_FINISH;
+        a.flags = (is_ckks ? 1u : 0u) | ((unsigned)assign_method << 1);
+        a.ext0 = ws + w.poly_prod; a.ext0_bstride = 2ll * (L + 1) * n; a.ext0_pstride = (long long)(L + 1) * n; a.ext0_cstride = n;
+        a.ext1 = addend; a.ext1_bstride = (long long)addend_bstride; a.ext1_pstride = (long long)L * n; a.ext1_cstride = n;
+        a.inv_table = p->d_inv_last + (size_t)K * K;
+        return launch_ntt(p, a, batch, false, s);
     }
     // (5) rounding fix of the special-prime component, per data limb (:570-598).  In NTT form the result goes to
     //     the unused tail of the prod_intt region so that step (6) can transform out of place.
@@ -604,6 +623,16 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
         NttArgs a = contiguous_args(p, (const u64*)in + (size_t)(L - 1) * n, last_intt, 1, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         a.in_bstride = (long long)L * n;
         if ((rc = launch_ntt(p, a, items, true, s))) return rc;
+    }
+    if (p->log_n >= 10) {
+        // step1 -> NTT -> step2 in one launch (prologue / epilogue of the forward transform)
+        NttArgs a = contiguous_args(p, last_intt, (u64*)out, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = (long long)n; a.in_pstride = 0; a.in_cstride = 0;
+        a.load_mode = NTT_LOAD_RESCALE; a.aux_mod = L - 1;
+        a.store_mode = NTT_STORE_RESCALE;
+        a.ext0 = (const u64*)in; a.ext0_bstride = (long long)L * n; a.ext0_pstride = 0; a.ext0_cstride = n;
+        a.inv_table = p->d_inv_last + (size_t)L * p->K;
+        return launch_ntt(p, a, items, false, s);
     }
     const unsigned ch = chunks_pairs(p->n);
     const size_t rows = items * (L - 1);
