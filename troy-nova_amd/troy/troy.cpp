@@ -1,0 +1,892 @@
+// troy.cpp -- bodies of the host-side mirror declared in troy.h.  Host logic only; every device
+// operation goes through the C-ABI (include/troyn.h).  Reference file:line citations name the
+// function whose behaviour (checks, metadata updates, error text) is mirrored.
+#include "troy.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace troy {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static void hip_check(hipError_t e, const char* what) {
+    // kernel_provider.h:11-16: runtime failures are std::runtime_error with the runtime's message
+    if (e != hipSuccess) throw std::runtime_error(std::string("[kernel_provider::") + what + "] " + hipGetErrorString(e));
+}
+
+static void troyn_check(int rc) {
+    if (rc == 0) return;
+    if (rc < 0) throw std::invalid_argument(troyn_last_error());
+    throw std::runtime_error(troyn_last_error());
+}
+
+static inline hipStream_t current_stream() { return hipStreamPerThread; }
+
+namespace utils {
+
+size_t device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;   // memory_pool.h:14-33: no usable device -> 0
+    return n < 0 ? 0 : static_cast<size_t>(n);
+}
+
+static std::mutex g_global_pool_mutex;
+static MemoryPoolHandle g_global_pool;
+
+MemoryPool::MemoryPool(size_t device) : device_(device) {
+    if (device >= device_count()) throw std::runtime_error("[MemoryPool::MemoryPool] No such device.");
+}
+
+MemoryPool::~MemoryPool() {
+    for (auto& kv : free_) (void)hipFree(kv.second);
+    for (auto& kv : live_) (void)hipFree(kv.first);
+}
+
+MemoryPoolHandle MemoryPool::GlobalPool() {
+    std::lock_guard<std::mutex> lock(g_global_pool_mutex);
+    if (!g_global_pool) g_global_pool = std::make_shared<MemoryPool>(0);
+    return g_global_pool;
+}
+
+void MemoryPool::Destroy() {
+    std::lock_guard<std::mutex> lock(g_global_pool_mutex);
+    g_global_pool.reset();
+}
+
+void* MemoryPool::allocate(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~size_t(255);
+    std::lock_guard<std::mutex> lock(mutex_);
+    auto it = free_.lower_bound(bytes);
+    if (it != free_.end() && it->first <= bytes * 2) {   // at most 2x slack, as memory_pool_safe.in:119-148
+        void* p = it->second;
+        size_t sz = it->first;
+        free_.erase(it);
+        live_[p] = sz;
+        return p;
+    }
+    hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {   // give cached blocks back and retry once
+        for (auto& kv : free_) (void)hipFree(kv.second);
+        free_.clear();
+        hip_check(hipMalloc(&p, bytes), "malloc");
+    }
+    live_[p] = bytes;
+    return p;
+}
+
+void MemoryPool::release(void* ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(mutex_);
+    auto it = live_.find(ptr);
+    if (it == live_.end()) return;
+    free_.emplace(it->second, ptr);
+    live_.erase(it);
+}
+
+void MemoryPool::release_unused() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (auto& kv : free_) (void)hipFree(kv.second);
+    free_.clear();
+}
+
+DynamicArray::DynamicArray(size_t count, bool device, MemoryPoolHandle pool) : size_(count), device_(device) {
+    if (device) {
+        pool_ = pool ? pool : MemoryPool::GlobalPool();
+        data_ = static_cast<uint64_t*>(pool_->allocate(count * sizeof(uint64_t)));
+    } else {
+        data_ = count ? static_cast<uint64_t*>(std::malloc(count * sizeof(uint64_t))) : nullptr;
+        if (count && !data_) throw std::bad_alloc();
+    }
+}
+
+void DynamicArray::free_() {
+    if (!data_) return;
+    if (device_) {
+        // the pool hands the block to the next allocation, which is ordered on the same per-thread stream
+        pool_->release(data_);
+    } else {
+        std::free(data_);
+    }
+    data_ = nullptr; size_ = 0;
+}
+
+DynamicArray::~DynamicArray() { free_(); }
+
+DynamicArray::DynamicArray(const DynamicArray& o) : DynamicArray(o.size_, o.device_, o.pool_) {
+    if (size_) copy_from(o.data_, size_, o.device_);
+}
+
+DynamicArray::DynamicArray(DynamicArray&& o) noexcept : data_(o.data_), size_(o.size_), device_(o.device_), pool_(std::move(o.pool_)) {
+    o.data_ = nullptr; o.size_ = 0;
+}
+
+DynamicArray& DynamicArray::operator=(const DynamicArray& o) {
+    if (this == &o) return *this;
+    DynamicArray tmp(o);
+    *this = std::move(tmp);
+    return *this;
+}
+
+DynamicArray& DynamicArray::operator=(DynamicArray&& o) noexcept {
+    if (this == &o) return *this;
+    free_();
+    data_ = o.data_; size_ = o.size_; device_ = o.device_; pool_ = std::move(o.pool_);
+    o.data_ = nullptr; o.size_ = 0;
+    return *this;
+}
+
+DynamicArray DynamicArray::from_vector(const std::vector<uint64_t>& v) {
+    DynamicArray a(v.size(), false);
+    if (!v.empty()) std::memcpy(a.data_, v.data(), v.size() * sizeof(uint64_t));
+    return a;
+}
+
+std::vector<uint64_t> DynamicArray::to_vector() const {
+    std::vector<uint64_t> v(size_);
+    if (!size_) return v;
+    if (device_) {
+        hip_check(hipSetDevice(static_cast<int>(device_index())), "copy_device_to_host");
+        hip_check(hipMemcpyAsync(v.data(), data_, size_ * sizeof(uint64_t), hipMemcpyDeviceToHost, current_stream()), "copy_device_to_host");
+        hip_check(hipStreamSynchronize(current_stream()), "copy_device_to_host");
+    } else {
+        std::memcpy(v.data(), data_, size_ * sizeof(uint64_t));
+    }
+    return v;
+}
+
+DynamicArray DynamicArray::clone(MemoryPoolHandle pool) const {
+    DynamicArray a(size_, device_, pool ? pool : pool_);
+    if (size_) a.copy_from(data_, size_, device_);
+    return a;
+}
+
+void DynamicArray::copy_from(const uint64_t* src, size_t count, bool src_on_device) {
+    if (count > size_) throw std::invalid_argument("[DynamicArray::copy_from] source is larger than the array");
+    if (!count) return;
+    const size_t bytes = count * sizeof(uint64_t);
+    if (!device_ && !src_on_device) { std::memcpy(data_, src, bytes); return; }
+    hipMemcpyKind kind = device_ ? (src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : hipMemcpyDeviceToHost;
+    hip_check(hipMemcpyAsync(data_, src, bytes, kind, current_stream()), "copy");
+    // host buffers may be freed or reused by the caller right away: finish the transfer (reference: D2H is synchronous)
+    if (kind != hipMemcpyDeviceToDevice) hip_check(hipStreamSynchronize(current_stream()), "copy");
+}
+
+void DynamicArray::set_zero() {
+    if (!size_) return;
+    if (device_) hip_check(hipMemsetAsync(data_, 0, size_ * sizeof(uint64_t), current_stream()), "memset");
+    else std::memset(data_, 0, size_ * sizeof(uint64_t));
+}
+
+void DynamicArray::resize(size_t count, bool keep) {
+    if (count == size_) return;
+    DynamicArray n(count, device_, pool_);
+    if (keep && size_ && count) {
+        n.copy_from(data_, std::min(count, size_), device_);
+        if (count > size_) {
+            if (device_) hip_check(hipMemsetAsync(n.data_ + size_, 0, (count - size_) * sizeof(uint64_t), current_stream()), "memset");
+            else std::memset(n.data_ + size_, 0, (count - size_) * sizeof(uint64_t));
+        }
+    } else {
+        n.set_zero();
+    }
+    *this = std::move(n);
+}
+
+void DynamicArray::to_device_inplace(MemoryPoolHandle pool) {
+    if (device_) return;
+    DynamicArray d(size_, true, pool ? pool : MemoryPool::GlobalPool());
+    if (size_) d.copy_from(data_, size_, false);
+    *this = std::move(d);
+}
+
+void DynamicArray::to_host_inplace() {
+    if (!device_) return;
+    DynamicArray h(size_, false);
+    if (size_) h.copy_from(data_, size_, true);
+    *this = std::move(h);
+}
+
+}  // namespace utils
+
+// ------------------------------------------------------------------------------------------------
+// Modulus / CoeffModulus / PlainModulus
+// ------------------------------------------------------------------------------------------------
+static bool is_prime_u64(uint64_t n) {
+    if (n < 2) return false;
+    auto mulmod = [](uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)(((unsigned __int128)a * b) % m); };
+    auto powmod = [&](uint64_t a, uint64_t e, uint64_t m) { uint64_t r = 1; a %= m; while (e) { if (e & 1) r = mulmod(r, a, m); a = mulmod(a, a, m); e >>= 1; } return r; };
+    for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) { if (n == p) return true; if (n % p == 0) return false; }
+    uint64_t d = n - 1; int r = 0;
+    while ((d & 1) == 0) { d >>= 1; r++; }
+    for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        uint64_t x = powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < r; i++) { x = mulmod(x, x, n); if (x == n - 1) { comp = false; break; } }
+        if (comp) return false;
+    }
+    return true;
+}
+
+Modulus::Modulus(uint64_t value) {
+    // modulus.cu:7-32
+    if (value == 0) return;
+    if ((value >> 61) != 0 || value == 1) throw std::invalid_argument("[Modulus::set_value] Value can be at most 61-bit and cannot be 1.");
+    value_ = value;
+    for (uint64_t v = value; v; v >>= 1) bit_count_++;
+    unsigned __int128 two64 = (unsigned __int128)1 << 64;
+    unsigned __int128 hi = two64 / value, r = two64 % value;
+    const_ratio_[0] = (uint64_t)((r << 64) / value);
+    const_ratio_[1] = (uint64_t)hi;
+    const_ratio_[2] = (uint64_t)((r << 64) % value);
+    is_prime_ = is_prime_u64(value);
+}
+
+uint64_t Modulus::reduce(uint64_t input) const {
+    uint64_t t = input - (uint64_t)(((unsigned __int128)input * const_ratio_[1]) >> 64) * value_;
+    return t >= value_ ? t - value_ : t;
+}
+
+size_t CoeffModulus::max_bit_count(size_t n, SecurityLevel sec) {
+    // utils/he_standard_params.h (HomomorphicEncryption.org tables)
+    static const std::map<size_t, std::vector<size_t>> table = {
+        {1024, {27, 19, 14}}, {2048, {54, 37, 29}}, {4096, {109, 75, 58}}, {8192, {218, 152, 118}}, {16384, {438, 305, 237}}, {32768, {881, 611, 476}}};
+    if (sec == SecurityLevel::Nil) return static_cast<size_t>(-1) >> 1;
+    auto it = table.find(n);
+    if (it == table.end()) return 0;
+    return it->second[static_cast<size_t>(sec) - 1];
+}
+
+std::vector<Modulus> CoeffModulus::create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
+    // coeff_modulus.cu:65-108 -- prime search lives in libtroyn's host helpers
+    std::vector<uint64_t> out(bit_sizes.size());
+    int rc = troyn_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), bit_sizes.size(), out.data());
+    if (rc != 0) throw std::invalid_argument(troyn_last_error());
+    std::vector<Modulus> res;
+    for (uint64_t q : out) res.emplace_back(q);
+    return res;
+}
+
+Modulus PlainModulus::batching(size_t poly_modulus_degree, size_t bit_size) {
+    return CoeffModulus::create(poly_modulus_degree, {bit_size})[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// EncryptionParameters
+// ------------------------------------------------------------------------------------------------
+const ParmsID parms_id_zero{};
+
+void EncryptionParameters::compute_parms_id() {
+    // encryption_parameters.cu:8-32 hashes [scheme, N, q_0..q_{K-1}, t]; here four FNV-1a lanes
+    std::vector<uint64_t> words{static_cast<uint64_t>(scheme_), static_cast<uint64_t>(poly_modulus_degree_)};
+    for (const Modulus& m : coeff_modulus_) words.push_back(m.value());
+    words.push_back(plain_modulus_.value());
+    for (int lane = 0; lane < 4; lane++) {
+        uint64_t h = 0xcbf29ce484222325ull ^ (0x9E3779B97F4A7C15ull * (lane + 1));
+        for (uint64_t w : words)
+            for (int b = 0; b < 8; b++) { h ^= (w >> (8 * b)) & 0xff; h *= 0x100000001b3ull; }
+        parms_id_.v[lane] = h ? h : 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HeContext
+// ------------------------------------------------------------------------------------------------
+static bool validate_parms(const EncryptionParameters& p, SecurityLevel sec) {
+    // the subset of ContextData::validate (context_data.cu:71-345) that decides parameters_set()
+    const size_t n = p.poly_modulus_degree();
+    if (p.scheme() == SchemeType::Nil) return false;
+    if (n < 2 || n > 131072 || (n & (n - 1)) != 0) return false;
+    const auto& q = p.coeff_modulus();
+    if (q.empty() || q.size() > 64) return false;
+    size_t total_bits = 0;
+    for (size_t i = 0; i < q.size(); i++) {
+        if (q[i].is_zero() || q[i].bit_count() > 60 || q[i].bit_count() < 2) return false;
+        if ((q[i].value() - 1) % (2 * n) != 0 || !q[i].is_prime()) return false;   // NTT tables must exist
+        for (size_t j = 0; j < i; j++) if (q[j].value() == q[i].value()) return false;
+        total_bits += q[i].bit_count();
+    }
+    if (sec != SecurityLevel::Nil) {
+        size_t maxb = CoeffModulus::max_bit_count(n, sec);
+        if (maxb == 0 || total_bits > maxb) return false;
+    }
+    if (p.scheme() == SchemeType::BFV || p.scheme() == SchemeType::BGV) {
+        const Modulus& t = p.plain_modulus();
+        if (t.is_zero() || t.bit_count() > 60) return false;
+        for (const auto& qi : q) if (qi.value() <= t.value() && qi.value() == t.value()) return false;
+    } else if (!p.plain_modulus().is_zero()) {
+        return false;   // CKKS must not set a plain modulus
+    }
+    return true;
+}
+
+HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_chain, SecurityLevel sec_level, uint64_t random_seed) {
+    // he_context.cu:46-132
+    HeContextPointer he(new HeContext());
+    he->security_level_ = sec_level;
+    auto add = [&](const EncryptionParameters& p) {
+        auto cd = std::make_shared<ContextData>();
+        cd->parms_ = p;
+        he->map_[p.parms_id()] = cd;
+        return cd;
+    };
+    auto key_cd = add(parms);
+    he->key_parms_id_ = parms.parms_id();
+    he->parameters_set_ = validate_parms(parms, sec_level);
+    auto drop_last = [](const EncryptionParameters& p) {
+        EncryptionParameters nx = p;
+        std::vector<Modulus> q(p.coeff_modulus().begin(), p.coeff_modulus().end() - 1);
+        nx.set_coeff_modulus(q);
+        return nx;
+    };
+    std::shared_ptr<ContextData> first_cd = key_cd;
+    if (he->parameters_set_ && parms.coeff_modulus().size() > 1 && !parms.use_special_prime_for_encryption()) {
+        EncryptionParameters nx = drop_last(parms);
+        if (validate_parms(nx, sec_level)) {
+            first_cd = add(nx);
+            key_cd->next_ = first_cd;
+            first_cd->prev_ = key_cd;
+        }
+    }
+    he->first_parms_id_ = first_cd->parms_id();
+    he->using_keyswitching_ = he->first_parms_id_ != he->key_parms_id_;
+    std::shared_ptr<ContextData> last_cd = first_cd;
+    if (expand_mod_chain && he->parameters_set_) {
+        while (last_cd->parms().coeff_modulus().size() > 1) {
+            EncryptionParameters nx = drop_last(last_cd->parms());
+            if (!validate_parms(nx, sec_level)) break;
+            auto cd = add(nx);
+            last_cd->next_ = cd;
+            cd->prev_ = last_cd;
+            last_cd = cd;
+        }
+    }
+    he->last_parms_id_ = last_cd->parms_id();
+    // chain_index: key level highest, last level 0 (he_context.cu:111-123)
+    size_t count = he->map_.size();
+    for (std::shared_ptr<const ContextData> c = key_cd; c; c = c->next_) {
+        std::const_pointer_cast<ContextData>(c)->chain_index_ = --count;
+    }
+    he->random_seed_ = random_seed;
+    return he;
+}
+
+HeContext::~HeContext() {
+    for (auto& kv : behz_) troyn_behz_destroy(kv.second);
+    if (plan_) troyn_plan_destroy(plan_);
+}
+
+void HeContext::to_device_inplace(MemoryPoolHandle pool) {
+    if (plan_) return;
+    if (!parameters_set_) throw std::invalid_argument("[HeContext::to_device_inplace] Encryption parameters are not valid.");
+    pool_ = pool ? pool : MemoryPool::GlobalPool();
+    const EncryptionParameters& kp = key_context_data().value()->parms();
+    std::vector<uint64_t> q;
+    for (const Modulus& m : kp.coeff_modulus()) q.push_back(m.value());
+    uint32_t log_n = 0;
+    while ((size_t(1) << log_n) < kp.poly_modulus_degree()) log_n++;
+    troyn_check(troyn_plan_create(&plan_, static_cast<int>(pool_->get_device()), log_n, static_cast<uint32_t>(q.size()), q.data(), nullptr));
+}
+
+const troyn_behz* HeContext::behz(size_t L) const {
+    std::lock_guard<std::mutex> lock(behz_mutex_);
+    auto it = behz_.find(L);
+    if (it != behz_.end()) return it->second;
+    troyn_behz* b = nullptr;
+    const EncryptionParameters& kp = key_context_data().value()->parms();
+    troyn_check(troyn_behz_create(&b, plan_, static_cast<uint32_t>(L), kp.plain_modulus().value()));
+    behz_[L] = b;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ciphertext
+// ------------------------------------------------------------------------------------------------
+Ciphertext Ciphertext::from_members(size_t polynomial_count, size_t coeff_modulus_size, size_t poly_modulus_degree, const ParmsID& parms_id,
+                                    double scale, bool is_ntt_form, uint64_t correction_factor, uint64_t seed, utils::DynamicArray&& data) {
+    if (data.size() != polynomial_count * coeff_modulus_size * poly_modulus_degree)
+        throw std::invalid_argument("[Ciphertext::from_members] data size does not match the shape");
+    Ciphertext c;
+    c.polynomial_count_ = polynomial_count; c.coeff_modulus_size_ = coeff_modulus_size; c.poly_modulus_degree_ = poly_modulus_degree;
+    c.parms_id_ = parms_id; c.scale_ = scale; c.is_ntt_form_ = is_ntt_form; c.correction_factor_ = correction_factor; c.seed_ = seed;
+    c.data_ = std::move(data);
+    return c;
+}
+
+Ciphertext Ciphertext::like(const Ciphertext& o, size_t polynomial_count, size_t coeff_modulus_size, bool fill_zeros, MemoryPoolHandle pool) {
+    // ciphertext.cu:5-24
+    Ciphertext c;
+    c.polynomial_count_ = polynomial_count; c.coeff_modulus_size_ = coeff_modulus_size; c.poly_modulus_degree_ = o.poly_modulus_degree_;
+    c.parms_id_ = o.parms_id_; c.scale_ = o.scale_; c.is_ntt_form_ = o.is_ntt_form_; c.correction_factor_ = o.correction_factor_; c.seed_ = 0;
+    c.data_ = utils::DynamicArray(polynomial_count * coeff_modulus_size * o.poly_modulus_degree_, o.on_device(), pool);
+    if (fill_zeros) c.data_.set_zero();
+    return c;
+}
+
+Ciphertext Ciphertext::clone(MemoryPoolHandle pool) const {
+    Ciphertext c = *this;   // deep copy through DynamicArray's copy constructor
+    (void)pool;
+    return c;
+}
+
+void Ciphertext::resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep) {
+    auto cd = context->get_context_data(parms_id);
+    if (!cd.has_value()) throw std::invalid_argument("[Ciphertext::resize] ParmsID is not valid for the current context.");
+    const EncryptionParameters& p = cd.value()->parms();
+    parms_id_ = parms_id;
+    polynomial_count_ = polynomial_count;
+    coeff_modulus_size_ = p.coeff_modulus().size();
+    poly_modulus_degree_ = p.poly_modulus_degree();
+    data_.resize(polynomial_count_ * coeff_modulus_size_ * poly_modulus_degree_, keep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// KSwitchKeys
+// ------------------------------------------------------------------------------------------------
+bool KSwitchKeys::on_device() const {
+    for (const auto& v : keys_) for (const auto& k : v) return k.on_device();
+    return false;
+}
+void KSwitchKeys::to_device_inplace(MemoryPoolHandle pool) { for (auto& v : keys_) for (auto& k : v) k.to_device_inplace(pool); }
+void KSwitchKeys::to_host_inplace() { for (auto& v : keys_) for (auto& k : v) k.to_host_inplace(); }
+std::vector<const uint64_t*> KSwitchKeys::get_data_ptrs(size_t index) const {
+    std::vector<const uint64_t*> p;
+    for (const auto& k : keys_.at(index)) p.push_back(k.as_ciphertext().data().raw_pointer());
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Evaluator
+// ------------------------------------------------------------------------------------------------
+static void check_no_seed(const char* prompt, const Ciphertext& c) {
+    if (c.contains_seed()) throw std::invalid_argument(std::string(prompt) + " Argument contains seed.");
+}
+static void check_same_parms_id(const char* prompt, const Ciphertext& a, const Ciphertext& b) {
+    if (a.parms_id() != b.parms_id()) throw std::invalid_argument(std::string(prompt) + " Arguments have different parms ID.");
+}
+static bool are_close_double(double a, double b) {
+    double s = std::max(std::max(a, b), 1.0);
+    return std::fabs(a - b) < s * 2.220446049250313e-16;   // basics.h:150-160
+}
+static void check_same_scale(const char* prompt, const Ciphertext& a, const Ciphertext& b) {
+    if (!are_close_double(a.scale(), b.scale())) throw std::invalid_argument(std::string(prompt) + " Arguments have different scales.");
+}
+static void check_same_ntt_form(const char* prompt, const Ciphertext& a, const Ciphertext& b) {
+    if (a.is_ntt_form() != b.is_ntt_form()) throw std::invalid_argument(std::string(prompt) + " Arguments have different NTT form.");
+}
+static void check_is_ntt_form(const char* prompt, const Ciphertext& a) {
+    if (!a.is_ntt_form()) throw std::invalid_argument(std::string(prompt) + " Argument is not in NTT form.");
+}
+static void check_is_not_ntt_form(const char* prompt, const Ciphertext& a) {
+    if (a.is_ntt_form()) throw std::invalid_argument(std::string(prompt) + " Argument is in NTT form.");
+}
+static void check_on_device(const char* prompt, const HeContextPointer& ctx, const Ciphertext& a) {
+    // the reference dispatches host operands to its CPU branch; this build has no CPU path for the hot path
+    if (!ctx->on_device()) throw std::invalid_argument(std::string(prompt) + " HeContext is not on device (call to_device_inplace).");
+    if (!a.on_device()) throw std::invalid_argument(std::string(prompt) + " Operand is on host; the evaluator runs on the GPU only.");
+}
+
+static uint32_t scheme_is_ckks(const ContextDataPointer& cd) { return cd->parms().scheme() == SchemeType::CKKS ? 1u : 0u; }
+
+ContextDataPointer Evaluator::get_context_data(const char* prompt, const ParmsID& id) const {
+    auto cd = context_->get_context_data(id);
+    if (!cd.has_value()) throw std::invalid_argument(std::string(prompt) + " Context data not found parms id.");
+    return cd.value();
+}
+
+// -- negate ------------------------------------------------------------------------------------
+void Evaluator::negate(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    check_no_seed("[Evaluator::negate]", encrypted);
+    check_on_device("[Evaluator::negate]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::negate]", encrypted.parms_id());
+    destination = Ciphertext::like(encrypted, false, pool);
+    const size_t L = cd->parms().coeff_modulus().size();
+    troyn_check(troyn_negate(context_->plan(), 0, static_cast<uint32_t>(L), encrypted.data().raw_pointer(), destination.data().raw_pointer(),
+                             encrypted.polynomial_count(), current_stream()));
+}
+
+void Evaluator::negate_inplace(Ciphertext& encrypted) const {
+    check_no_seed("[Evaluator::negate_inplace]", encrypted);
+    check_on_device("[Evaluator::negate_inplace]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::negate_inplace]", encrypted.parms_id());
+    const size_t L = cd->parms().coeff_modulus().size();
+    troyn_check(troyn_negate(context_->plan(), 0, static_cast<uint32_t>(L), encrypted.data().raw_pointer(), encrypted.data().raw_pointer(),
+                             encrypted.polynomial_count(), current_stream()));
+}
+
+void Evaluator::negate_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
+    for (Ciphertext* c : encrypted) negate_inplace(*c);
+}
+void Evaluator::negate_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::negate_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < encrypted.size(); i++) negate(*encrypted[i], *destination[i], pool);
+}
+
+// -- add / sub (evaluator_translate.cu:12-118) ------------------------------------------------------
+void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, bool subtract, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::translate_inplace]";
+    check_no_seed(P, e1); check_no_seed(P, e2);
+    check_same_parms_id(P, e1, e2);
+    check_same_scale(P, e1, e2);
+    check_same_ntt_form(P, e1, e2);
+    check_on_device(P, context_, e1); check_on_device(P, context_, e2);
+    auto cd = get_context_data(P, e1.parms_id());
+    if (e1.correction_factor() != e2.correction_factor())
+        throw std::logic_error("[Evaluator::translate] BGV correction-factor balancing is not part of this build.");
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t n = cd->parms().poly_modulus_degree();
+    const size_t s1 = e1.polynomial_count(), s2 = e2.polynomial_count();
+    const size_t mx = std::max(s1, s2), mn = std::min(s1, s2);
+    Ciphertext out = Ciphertext::like(e1, mx, false, pool);
+    const troyn_plan* plan = context_->plan();
+    if (!subtract) troyn_check(troyn_add(plan, 0, L, e1.data().raw_pointer(), e2.data().raw_pointer(), out.data().raw_pointer(), mn, current_stream()));
+    else troyn_check(troyn_sub(plan, 0, L, e1.data().raw_pointer(), e2.data().raw_pointer(), out.data().raw_pointer(), mn, current_stream()));
+    const size_t pc = static_cast<size_t>(L) * n;
+    if (s1 < s2) {
+        if (!subtract) hip_check(hipMemcpyAsync(out.poly(s1), e2.poly(s1), (s2 - s1) * pc * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+        else troyn_check(troyn_negate(plan, 0, L, e2.poly(s1), out.poly(s1), s2 - s1, current_stream()));
+    } else if (s1 > s2) {
+        hip_check(hipMemcpyAsync(out.poly(s2), e1.poly(s2), (s1 - s2) * pc * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+    }
+    destination = std::move(out);
+}
+
+void Evaluator::translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool subtract, MemoryPoolHandle pool) const {
+    Ciphertext d;
+    translate(e1, e2, d, subtract, pool);
+    e1 = std::move(d);
+}
+
+void Evaluator::add_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < e1.size(); i++) translate(*e1[i], *e2[i], *d[i], false, pool);
+}
+void Evaluator::sub_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < e1.size(); i++) translate(*e1[i], *e2[i], *d[i], true, pool);
+}
+
+// -- multiply / square (evaluator.cu:29-343) ------------------------------------------------------------
+void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, MemoryPoolHandle pool) const {
+    check_no_seed("[Evaluator::multiply]", e1); check_no_seed("[Evaluator::multiply]", e2);
+    check_same_parms_id("[Evaluator::multiply]", e1, e2);
+    check_on_device("[Evaluator::multiply]", context_, e1); check_on_device("[Evaluator::multiply]", context_, e2);
+    SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    auto cd = get_context_data("[Evaluator::multiply]", e1.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t p1 = e1.polynomial_count(), p2 = e2.polynomial_count();
+    Ciphertext out = Ciphertext::like(e1, p1 + p2 - 1, false, pool);
+    switch (scheme) {
+        case SchemeType::BFV: {
+            check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e1); check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e2);
+            const troyn_behz* bz = context_->behz(L);
+            size_t bytes = troyn_bfv_multiply_workspace_bytes(bz, p1, p2, 1);
+            utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+            troyn_check(troyn_bfv_multiply(bz, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(),
+                                           ws.raw_pointer(), bytes, 1, current_stream()));
+            break;
+        }
+        case SchemeType::CKKS: case SchemeType::BGV: {
+            const char* P = scheme == SchemeType::CKKS ? "[Evaluator::ckks_multiply_inplace]" : "[Evaluator::bgv_multiply]";
+            check_is_ntt_form(P, e1); check_is_ntt_form(P, e2);
+            troyn_check(troyn_dyadic_convolute(context_->plan(), 0, L, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2,
+                                               out.data().raw_pointer(), 1, current_stream()));
+            if (scheme == SchemeType::CKKS) out.scale() = e1.scale() * e2.scale();
+            else {
+                const Modulus& t = cd->parms().plain_modulus();
+                out.correction_factor() = (uint64_t)(((unsigned __int128)e1.correction_factor() * e2.correction_factor()) % t.value());
+            }
+            break;
+        }
+        default: throw std::logic_error("[Evaluator::multiply] Scheme not implemented.");
+    }
+    destination = std::move(out);
+}
+
+void Evaluator::square(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    check_no_seed("[Evaluator::square]", encrypted);
+    check_on_device("[Evaluator::square]", context_, encrypted);
+    SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme == SchemeType::BFV || encrypted.polynomial_count() != 2) { multiply(encrypted, encrypted, destination, pool); return; }
+    auto cd = get_context_data("[Evaluator::square]", encrypted.parms_id());
+    check_is_ntt_form("[Evaluator::ckks_square_inplace]", encrypted);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    Ciphertext out = Ciphertext::like(encrypted, 3, false, pool);
+    troyn_check(troyn_dyadic_square(context_->plan(), 0, L, encrypted.data().raw_pointer(), out.data().raw_pointer(), 1, current_stream()));
+    if (scheme == SchemeType::CKKS) out.scale() = encrypted.scale() * encrypted.scale();
+    else {
+        const Modulus& t = cd->parms().plain_modulus();
+        out.correction_factor() = (uint64_t)(((unsigned __int128)encrypted.correction_factor() * encrypted.correction_factor()) % t.value());
+    }
+    destination = std::move(out);
+}
+
+void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::multiply_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < e1.size(); i++) multiply(*e1[i], *e2[i], *d[i], pool);
+}
+
+// -- key switching (evaluator_keyswitching_core.cu:757-1052, evaluator_keyswitching.cu:11-144) ---------------
+void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
+                                    SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::switch_key_inplace_internal]";
+    check_no_seed(P, encrypted);
+    if (!context_->using_keyswitching()) throw std::invalid_argument(std::string(P) + " Keyswitching is not supported.");
+    if (kswitch_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Keyswitching key has incorrect parms id.");
+    if (kswitch_keys_index >= kswitch_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
+    auto cd = get_context_data(P, encrypted.parms_id());
+    SchemeType scheme = cd->parms().scheme();
+    if (scheme == SchemeType::BGV) throw std::logic_error(std::string(P) + " BGV key switching is not part of this build.");
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const auto& key_vector = kswitch_keys.data()[kswitch_keys_index];
+    if (key_vector.size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
+    if (destination.polynomial_count() < 2) throw std::invalid_argument(std::string(P) + " Destination should have at least same amount of polys as the key switching key.");
+    if (destination.parms_id() != encrypted.parms_id()) throw std::invalid_argument(std::string(P) + " Destination parms_id should match the input parms_id.");
+    for (const auto& k : key_vector) {
+        check_no_seed(P, k.as_ciphertext());
+        if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
+    }
+    check_on_device(P, context_, encrypted); check_on_device(P, context_, destination);
+    const size_t n = cd->parms().poly_modulus_degree();
+    if (destination.polynomial_count() > 2 && assign_method != SwitchKeyDestinationAssignMethod::AddInplace)
+        hip_check(hipMemsetAsync(destination.poly(2), 0, (destination.polynomial_count() - 2) * L * n * 8, current_stream()), "memset");
+    std::vector<const uint64_t*> ptrs = kswitch_keys.get_data_ptrs(kswitch_keys_index);
+    size_t bytes = troyn_switch_key_workspace_bytes(context_->plan(), L, 1);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    troyn_check(troyn_switch_key(context_->plan(), L, scheme == SchemeType::CKKS, encrypted.is_ntt_form(), target, ptrs.data(),
+                                 static_cast<int>(assign_method), destination.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+}
+
+void Evaluator::apply_keyswitching(const Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_keyswitching.cu:11-50
+    if (kswitch_keys.data().size() != 1) throw std::invalid_argument("[Evaluator::apply_keyswitching_inplace] Key switch keys size must be 1.");
+    if (encrypted.polynomial_count() != 2) throw std::invalid_argument("[Evaluator::apply_keyswitching_inplace] Ciphertext polynomial count must be 2.");
+    auto cd = get_context_data("[Evaluator::apply_keyswitching_inplace]", encrypted.parms_id());
+    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    switch_key_internal(encrypted, encrypted.poly(1), kswitch_keys, 0, SwitchKeyDestinationAssignMethod::Overwrite, out, pool);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    // c0' = c0 + ks0
+    troyn_check(troyn_add(context_->plan(), 0, L, out.poly(0), encrypted.poly(0), out.poly(0), 1, current_stream()));
+    destination = std::move(out);
+}
+
+void Evaluator::apply_keyswitching_inplace(Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, MemoryPoolHandle pool) const {
+    Ciphertext d;
+    apply_keyswitching(encrypted, kswitch_keys, d, pool);
+    encrypted = std::move(d);
+}
+
+void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_keyswitching.cu:119-144
+    const char* P = "[Evaluator::relinearize_inplace_internal]";
+    check_no_seed(P, encrypted);
+    if (relin_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Relin keys has incorrect parms id.");
+    auto cd = get_context_data(P, encrypted.parms_id());
+    size_t encrypted_size = encrypted.polynomial_count();
+    if (encrypted_size < 2 || destination_size > encrypted_size)
+        throw std::invalid_argument(std::string(P) + " Destination size must be at least 2 and less/equal to the size of the encrypted polynomial.");
+    if (destination_size == encrypted_size) { destination = encrypted; return; }
+    check_on_device(P, context_, encrypted);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    if (encrypted_size == 3 && destination_size == 2) {
+        // one call: switch_key(c2, Overwrite) + (c0, c1), the trailing add fused into the key-switch epilogue
+        size_t idx = RelinKeys::get_index(2);
+        if (idx >= relin_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
+        SchemeType scheme = cd->parms().scheme();
+        if (scheme == SchemeType::BGV) throw std::logic_error(std::string(P) + " BGV key switching is not part of this build.");
+        if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
+        if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
+        for (const auto& k : relin_keys.data()[idx]) if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
+        Ciphertext out = Ciphertext::like(encrypted, 2, false, pool);
+        std::vector<const uint64_t*> ptrs = relin_keys.get_data_ptrs(idx);
+        size_t bytes = troyn_relinearize_workspace_bytes(context_->plan(), L, 1);
+        utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        troyn_check(troyn_relinearize(context_->plan(), L, scheme == SchemeType::CKKS, encrypted.is_ntt_form(), encrypted.data().raw_pointer(), ptrs.data(),
+                                      out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+        destination = std::move(out);
+        return;
+    }
+    Ciphertext out = Ciphertext::like(encrypted, destination_size, false, pool);
+    size_t relins_needed = encrypted_size - destination_size;
+    for (size_t i = 0; i < relins_needed; i++) {
+        switch_key_internal(encrypted, encrypted.poly(encrypted_size - 1), relin_keys.as_kswitch_keys(), RelinKeys::get_index(encrypted_size - 1),
+                            i == 0 ? SwitchKeyDestinationAssignMethod::Overwrite : SwitchKeyDestinationAssignMethod::AddInplace, out, pool);
+        encrypted_size -= 1;
+    }
+    troyn_check(troyn_add(context_->plan(), 0, L, out.data().raw_pointer(), encrypted.data().raw_pointer(), out.data().raw_pointer(), destination_size, current_stream()));
+    destination = std::move(out);
+}
+
+void Evaluator::relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const {
+    Ciphertext d;
+    relinearize_internal(encrypted, relin_keys, destination_size, d, pool);
+    encrypted = std::move(d);
+}
+
+void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (encrypted.size() != d.size()) throw std::invalid_argument("[Evaluator::relinearize_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < encrypted.size(); i++) relinearize_internal(*encrypted[i], relin_keys, 2, *d[i], pool);
+}
+
+// -- modulus switching (evaluator_modswitch.cu) --------------------------------------------------------------
+void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:14-74
+    const char* P = "[Evaluator::mod_switch_scale_to_next_internal]";
+    auto cd = get_context_data(P, encrypted.parms_id());
+    SchemeType scheme = cd->parms().scheme();
+    if (scheme == SchemeType::BFV) check_is_not_ntt_form(P, encrypted);
+    else if (scheme == SchemeType::CKKS) check_is_ntt_form(P, encrypted);
+    else throw std::logic_error(std::string(P) + " Scheme not implemented.");
+    if (!cd->next_context_data().has_value()) throw std::invalid_argument(std::string(P) + " Next context data is not set.");
+    check_on_device(P, context_, encrypted);
+    ContextDataPointer next = cd->next_context_data().value();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t pc = encrypted.polynomial_count();
+    Ciphertext out = Ciphertext::like(encrypted, pc, L - 1, false, pool);
+    out.parms_id() = next->parms_id();
+    if (scheme == SchemeType::BFV) {
+        troyn_check(troyn_divide_and_round_q_last(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), 1, current_stream()));
+    } else {
+        size_t bytes = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), L, pc, 1);
+        utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        troyn_check(troyn_divide_and_round_q_last_ntt(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(),
+                                                      ws.raw_pointer(), bytes, 1, current_stream()));
+        out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
+    }
+    out.is_ntt_form() = encrypted.is_ntt_form();
+    destination = std::move(out);
+}
+
+void Evaluator::mod_switch_drop_to_internal(const Ciphertext& encrypted, Ciphertext& destination, const ParmsID& target, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:173-220
+    const char* P = "[Evaluator::mod_switch_drop_to_internal]";
+    auto cd = get_context_data(P, encrypted.parms_id());
+    if (cd->parms().scheme() == SchemeType::CKKS) check_is_ntt_form(P, encrypted);
+    if (!cd->next_context_data().has_value()) throw std::invalid_argument("[Evaluator::mod_switch_drop_to_next_internal] Next context data is not set.");
+    auto tcd = get_context_data("[Evaluator::mod_switch_drop_to_next_internal]", target);
+    check_on_device(P, context_, encrypted);
+    const uint32_t L_in = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const uint32_t L_out = static_cast<uint32_t>(tcd->parms().coeff_modulus().size());
+    const size_t pc = encrypted.polynomial_count();
+    Ciphertext out = Ciphertext::like(encrypted, pc, L_out, false, pool);
+    out.parms_id() = target;
+    troyn_check(troyn_mod_switch_drop(context_->plan(), L_in, L_out, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), 1, current_stream()));
+    destination = std::move(out);
+}
+
+void Evaluator::mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:275-300
+    check_no_seed("[Evaluator::mod_switch_to_next]", encrypted);
+    if (context_->last_parms_id() == encrypted.parms_id()) throw std::invalid_argument("[Evaluator::mod_switch_to_next] End of modulus switching chain reached.");
+    SchemeType scheme = context_->first_context_data().value()->parms().scheme();
+    switch (scheme) {
+        case SchemeType::BFV: mod_switch_scale_to_next_internal(encrypted, destination, pool); break;
+        case SchemeType::CKKS: {
+            auto cd = get_context_data("[Evaluator::mod_switch_to_next]", encrypted.parms_id());
+            mod_switch_drop_to_internal(encrypted, destination, cd->next_context_data().value()->parms_id(), pool);
+            break;
+        }
+        default: throw std::logic_error("[Evaluator::mod_switch_to_next] Scheme not implemented.");
+    }
+}
+
+void Evaluator::mod_switch_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::mod_switch_to_next_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < encrypted.size(); i++) mod_switch_to_next(*encrypted[i], *destination[i], pool);
+}
+
+void Evaluator::mod_switch_to(const Ciphertext& encrypted, const ParmsID& parms_id, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:330-360
+    auto cd = get_context_data("[Evaluator::mod_switch_to]", encrypted.parms_id());
+    auto tcd = get_context_data("[Evaluator::mod_switch_to]", parms_id);
+    if (cd->chain_index() < tcd->chain_index()) throw std::invalid_argument("[Evaluator::mod_switch_to] Cannot switch to a higher level.");
+    if (encrypted.parms_id() == parms_id) { destination = encrypted; return; }
+    SchemeType scheme = cd->parms().scheme();
+    if (scheme == SchemeType::CKKS) { mod_switch_drop_to_internal(encrypted, destination, parms_id, pool); return; }
+    Ciphertext cur = encrypted;
+    while (cur.parms_id() != parms_id) { Ciphertext nx; mod_switch_to_next(cur, nx, pool); cur = std::move(nx); }
+    destination = std::move(cur);
+}
+
+void Evaluator::rescale_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:445-461
+    check_no_seed("[Evaluator::rescale_to_next]", encrypted);
+    if (context_->last_parms_id() == encrypted.parms_id()) throw std::invalid_argument("[Evaluator::rescale_to_next] End of modulus switching chain reached.");
+    SchemeType scheme = context_->first_context_data().value()->parms().scheme();
+    switch (scheme) {
+        case SchemeType::BFV: case SchemeType::BGV: throw std::invalid_argument("[Evaluator::rescale_to_next] Cannot rescale BFV/BGV ciphertext.");
+        case SchemeType::CKKS: mod_switch_scale_to_next_internal(encrypted, destination, pool); break;
+        default: throw std::logic_error("[Evaluator::rescale_to_next] Scheme not implemented.");
+    }
+}
+
+void Evaluator::rescale_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::rescale_to_next_batched] Input and destination have different sizes.");
+    for (size_t i = 0; i < encrypted.size(); i++) rescale_to_next(*encrypted[i], *destination[i], pool);
+}
+
+// -- NTT (evaluator_transform_ntt.cu:469-652) ----------------------------------------------------------------
+void Evaluator::transform_to_ntt_inplace(Ciphertext& encrypted) const {
+    check_no_seed("[Evaluator::transform_to_ntt_inplace]", encrypted);
+    check_is_not_ntt_form("[Evaluator::transform_to_ntt_inplace]", encrypted);
+    check_on_device("[Evaluator::transform_to_ntt_inplace]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::transform_to_ntt_inplace]", encrypted.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    troyn_check(troyn_ntt(context_->plan(), 0, encrypted.data().raw_pointer(), encrypted.data().raw_pointer(), 1, encrypted.polynomial_count(), L,
+                          0, L, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    encrypted.is_ntt_form() = true;
+}
+
+void Evaluator::transform_to_ntt(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    check_no_seed("[Evaluator::transform_to_ntt]", encrypted);
+    check_is_not_ntt_form("[Evaluator::transform_to_ntt]", encrypted);
+    check_on_device("[Evaluator::transform_to_ntt]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::transform_to_ntt]", encrypted.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    troyn_check(troyn_ntt(context_->plan(), 0, encrypted.data().raw_pointer(), out.data().raw_pointer(), 1, encrypted.polynomial_count(), L,
+                          0, L, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    out.is_ntt_form() = true;
+    destination = std::move(out);
+}
+
+void Evaluator::transform_from_ntt_inplace(Ciphertext& encrypted) const {
+    check_no_seed("[Evaluator::transform_from_ntt_inplace]", encrypted);
+    check_is_ntt_form("[Evaluator::transform_from_ntt_inplace]", encrypted);
+    check_on_device("[Evaluator::transform_from_ntt_inplace]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::transform_from_ntt_inplace]", encrypted.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    troyn_check(troyn_ntt(context_->plan(), 1, encrypted.data().raw_pointer(), encrypted.data().raw_pointer(), 1, encrypted.polynomial_count(), L,
+                          0, L, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    encrypted.is_ntt_form() = false;
+}
+
+void Evaluator::transform_from_ntt(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    check_no_seed("[Evaluator::transform_from_ntt]", encrypted);
+    check_is_ntt_form("[Evaluator::transform_from_ntt]", encrypted);
+    check_on_device("[Evaluator::transform_from_ntt]", context_, encrypted);
+    auto cd = get_context_data("[Evaluator::transform_from_ntt]", encrypted.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    troyn_check(troyn_ntt(context_->plan(), 1, encrypted.data().raw_pointer(), out.data().raw_pointer(), 1, encrypted.polynomial_count(), L,
+                          0, L, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    out.is_ntt_form() = false;
+    destination = std::move(out);
+}
+
+void Evaluator::transform_to_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
+    for (Ciphertext* c : encrypted) transform_to_ntt_inplace(*c);
+}
+void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
+    for (Ciphertext* c : encrypted) transform_from_ntt_inplace(*c);
+}
+
+}  // namespace troy

@@ -1,0 +1,461 @@
+// troy.h -- host-side C++ mirror of troy-nova's public API for the hot path, on top of the
+// C-ABI in include/troyn.h (libtroyn.so).  Same namespace, class and method names, argument
+// meaning and error behaviour as the reference (src/troy.h and the headers it includes), so code
+// written against `#include "troy/troy.h"` for the operations below compiles unchanged:
+//
+//   EncryptionParameters / CoeffModulus / PlainModulus   src/encryption_parameters.h, coeff_modulus.h
+//   HeContext::create / to_device_inplace, ContextData     src/he_context.h, context_data.h
+//   MemoryPool / MemoryPoolHandle                           src/utils/memory_pool.h
+//   Ciphertext / Plaintext / KSwitchKeys / RelinKeys        src/ciphertext.h, plaintext.h, kswitch_keys.h
+//   Evaluator (negate, add, sub, multiply, square, relinearize, apply_keyswitching,
+//              mod_switch_to_next, mod_switch_to, rescale_to_next, transform_to/from_ntt,
+//              x / x_inplace / x_new / x_batched)           src/evaluator.h:113-700
+//
+// Differences that are deliberate:
+//   * the Evaluator runs on the GPU only.  Operands must be on the device; a host-resident operand
+//     raises std::invalid_argument instead of silently taking a CPU path (there is none).
+//   * ParmsID is a 256-bit FNV digest of (scheme, N, moduli, t) rather than BLAKE2b (out of scope);
+//     it is only ever compared for equality.
+//   * multiply / relinearize / rescale also exist as *_batched (the reference lists them as
+//     "not implemented yet", test/bench/he_operations.cpp:119-135).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/troyn.h"
+
+namespace troy {
+
+enum class SchemeType : uint8_t { Nil = 0, BFV = 1, CKKS = 2, BGV = 3 };
+enum class SecurityLevel : uint8_t { Nil = 0, Classical128 = 1, Classical192 = 2, Classical256 = 3 };
+
+// ----------------------------------------------------------------------------------------------
+// utils: device runtime shim + memory pool (src/kernel_provider.h, src/utils/memory_pool.h)
+// ----------------------------------------------------------------------------------------------
+namespace utils {
+
+size_t device_count();
+
+class MemoryPool;
+using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
+
+// Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
+// uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.
+class MemoryPool {
+public:
+    explicit MemoryPool(size_t device = 0);
+    ~MemoryPool();
+    static MemoryPoolHandle create(size_t device = 0) { return std::make_shared<MemoryPool>(device); }
+    static MemoryPoolHandle GlobalPool();
+    static void Destroy();   // releases the global pool; call before exit (reference readme.md:129)
+    size_t get_device() const { return device_; }
+    void* allocate(size_t bytes);
+    void release(void* ptr);
+    void release_unused();
+private:
+    size_t device_;
+    std::mutex mutex_;
+    std::unordered_map<void*, size_t> live_;
+    std::multimap<size_t, void*> free_;
+};
+
+// Owning array of uint64_t on the host (malloc) or on a device (pool) -- src/utils/dynamic_array.h
+class DynamicArray {
+public:
+    DynamicArray() = default;
+    DynamicArray(size_t count, bool device, MemoryPoolHandle pool = nullptr);
+    DynamicArray(const DynamicArray& other);
+    DynamicArray(DynamicArray&& other) noexcept;
+    DynamicArray& operator=(const DynamicArray& other);
+    DynamicArray& operator=(DynamicArray&& other) noexcept;
+    ~DynamicArray();
+
+    static DynamicArray from_vector(const std::vector<uint64_t>& v);
+    std::vector<uint64_t> to_vector() const;
+    DynamicArray clone(MemoryPoolHandle pool = nullptr) const;
+
+    size_t size() const noexcept { return size_; }
+    bool on_device() const noexcept { return device_; }
+    MemoryPoolHandle pool() const { return pool_; }
+    size_t device_index() const { return pool_ ? pool_->get_device() : 0; }
+    uint64_t* raw_pointer() noexcept { return data_; }
+    const uint64_t* raw_pointer() const noexcept { return data_; }
+    uint64_t& operator[](size_t i) { return data_[i]; }             // host only
+    const uint64_t& operator[](size_t i) const { return data_[i]; } // host only
+    void set_zero();
+    void resize(size_t count, bool keep = true);
+    void to_device_inplace(MemoryPoolHandle pool);
+    void to_host_inplace();
+    void copy_from(const uint64_t* src, size_t count, bool src_on_device);
+private:
+    void free_();
+    uint64_t* data_ = nullptr;
+    size_t size_ = 0;
+    bool device_ = false;
+    MemoryPoolHandle pool_;
+};
+
+}  // namespace utils
+
+using MemoryPool = utils::MemoryPool;
+using MemoryPoolHandle = utils::MemoryPoolHandle;
+
+// ----------------------------------------------------------------------------------------------
+// Modulus, CoeffModulus, PlainModulus  (src/modulus.h, coeff_modulus.h)
+// ----------------------------------------------------------------------------------------------
+class Modulus {
+public:
+    explicit Modulus(uint64_t value = 0);
+    uint64_t value() const { return value_; }
+    size_t bit_count() const { return bit_count_; }
+    bool is_prime() const { return is_prime_; }
+    bool is_zero() const { return value_ == 0; }
+    const uint64_t* const_ratio() const { return const_ratio_; }
+    uint64_t reduce(uint64_t input) const;
+private:
+    uint64_t value_ = 0;
+    uint64_t const_ratio_[3] = {0, 0, 0};
+    size_t bit_count_ = 0;
+    bool is_prime_ = false;
+};
+
+class CoeffModulus {
+public:
+    static size_t max_bit_count(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
+    static std::vector<Modulus> create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes);
+};
+
+class PlainModulus {
+public:
+    static Modulus batching(size_t poly_modulus_degree, size_t bit_size);
+    static std::vector<Modulus> batching_multiple(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
+        return CoeffModulus::create(poly_modulus_degree, std::move(bit_sizes));
+    }
+};
+
+// ----------------------------------------------------------------------------------------------
+// EncryptionParameters, ParmsID  (src/encryption_parameters.h)
+// ----------------------------------------------------------------------------------------------
+struct ParmsID {
+    uint64_t v[4] = {0, 0, 0, 0};
+    bool operator==(const ParmsID& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+    bool operator!=(const ParmsID& o) const { return !(*this == o); }
+    bool is_zero() const { return v[0] == 0 && v[1] == 0 && v[2] == 0 && v[3] == 0; }
+};
+extern const ParmsID parms_id_zero;
+struct ParmsIDHash { size_t operator()(const ParmsID& p) const { return static_cast<size_t>(p.v[0] ^ p.v[3]); } };
+
+class EncryptionParameters {
+public:
+    explicit EncryptionParameters(SchemeType scheme = SchemeType::Nil) : scheme_(scheme) { compute_parms_id(); }
+    void set_poly_modulus_degree(size_t n) { poly_modulus_degree_ = n; compute_parms_id(); }
+    void set_coeff_modulus(const std::vector<Modulus>& q) { coeff_modulus_ = q; compute_parms_id(); }
+    void set_plain_modulus(const Modulus& t) { plain_modulus_ = t; compute_parms_id(); }
+    void set_plain_modulus(uint64_t t) { set_plain_modulus(Modulus(t)); }
+    void set_use_special_prime_for_encryption(bool f) { use_special_prime_for_encryption_ = f; }
+    SchemeType scheme() const { return scheme_; }
+    size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    const std::vector<Modulus>& coeff_modulus() const { return coeff_modulus_; }
+    const Modulus& plain_modulus() const { return plain_modulus_; }
+    bool use_special_prime_for_encryption() const { return use_special_prime_for_encryption_; }
+    const ParmsID& parms_id() const { return parms_id_; }
+private:
+    void compute_parms_id();
+    SchemeType scheme_;
+    size_t poly_modulus_degree_ = 0;
+    std::vector<Modulus> coeff_modulus_;
+    Modulus plain_modulus_;
+    bool use_special_prime_for_encryption_ = false;
+    ParmsID parms_id_;
+};
+
+// ----------------------------------------------------------------------------------------------
+// ContextData, HeContext  (src/context_data.h, he_context.h)
+// ----------------------------------------------------------------------------------------------
+class HeContext;
+class ContextData;
+using ContextDataPointer = std::shared_ptr<const ContextData>;
+using HeContextPointer = std::shared_ptr<HeContext>;
+
+class ContextData {
+public:
+    const EncryptionParameters& parms() const { return parms_; }
+    const ParmsID& parms_id() const { return parms_.parms_id(); }
+    size_t chain_index() const { return chain_index_; }
+    std::optional<ContextDataPointer> next_context_data() const { return next_ ? std::optional<ContextDataPointer>(next_) : std::nullopt; }
+    std::optional<ContextDataPointer> prev_context_data() const {
+        auto p = prev_.lock();
+        return p ? std::optional<ContextDataPointer>(p) : std::nullopt;
+    }
+    bool is_ckks() const { return parms_.scheme() == SchemeType::CKKS; }
+    bool is_bfv() const { return parms_.scheme() == SchemeType::BFV; }
+    bool is_bgv() const { return parms_.scheme() == SchemeType::BGV; }
+private:
+    friend class HeContext;
+    EncryptionParameters parms_;
+    size_t chain_index_ = 0;
+    std::shared_ptr<const ContextData> next_;
+    std::weak_ptr<const ContextData> prev_;
+};
+
+class HeContext {
+public:
+    // src/he_context.cu:46-132
+    static HeContextPointer create(EncryptionParameters parms, bool expand_mod_chain, SecurityLevel sec_level = SecurityLevel::Classical128,
+                                   uint64_t random_seed = 0);
+    ~HeContext();
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool());   // src/he_context.cu:134
+    bool on_device() const noexcept { return plan_ != nullptr; }
+    MemoryPoolHandle pool() const { return pool_; }
+    size_t device_index() const { return pool_ ? pool_->get_device() : 0; }
+    ParmsID key_parms_id() const noexcept { return key_parms_id_; }
+    ParmsID first_parms_id() const noexcept { return first_parms_id_; }
+    ParmsID last_parms_id() const noexcept { return last_parms_id_; }
+    std::optional<ContextDataPointer> get_context_data(const ParmsID& id) const noexcept {
+        auto it = map_.find(id);
+        return it == map_.end() ? std::nullopt : std::optional<ContextDataPointer>(it->second);
+    }
+    std::optional<ContextDataPointer> key_context_data() const noexcept { return get_context_data(key_parms_id_); }
+    std::optional<ContextDataPointer> first_context_data() const noexcept { return get_context_data(first_parms_id_); }
+    std::optional<ContextDataPointer> last_context_data() const noexcept { return get_context_data(last_parms_id_); }
+    SecurityLevel security_level() const noexcept { return security_level_; }
+    bool using_keyswitching() const noexcept { return using_keyswitching_; }
+    bool parameters_set() const { return parameters_set_; }
+    uint64_t random_seed() const { return random_seed_; }
+
+    // C-ABI handles (boundary objects)
+    const troyn_plan* plan() const { return plan_; }
+    const troyn_behz* behz(size_t coeff_modulus_size) const;   // created on first use
+private:
+    HeContext() = default;
+    std::unordered_map<ParmsID, std::shared_ptr<ContextData>, ParmsIDHash> map_;
+    ParmsID key_parms_id_, first_parms_id_, last_parms_id_;
+    SecurityLevel security_level_ = SecurityLevel::Nil;
+    bool using_keyswitching_ = false, parameters_set_ = false;
+    uint64_t random_seed_ = 0;
+    MemoryPoolHandle pool_;
+    troyn_plan* plan_ = nullptr;
+    mutable std::mutex behz_mutex_;
+    mutable std::map<size_t, troyn_behz*> behz_;
+};
+
+// ----------------------------------------------------------------------------------------------
+// Ciphertext, Plaintext  (src/ciphertext.h, plaintext.h): data[(p*L + l)*N + i]
+// ----------------------------------------------------------------------------------------------
+class Ciphertext {
+public:
+    Ciphertext() = default;
+    static Ciphertext from_members(size_t polynomial_count, size_t coeff_modulus_size, size_t poly_modulus_degree, const ParmsID& parms_id,
+                                   double scale, bool is_ntt_form, uint64_t correction_factor, uint64_t seed, utils::DynamicArray&& data);
+    static Ciphertext like(const Ciphertext& other, size_t polynomial_count, size_t coeff_modulus_size, bool fill_zeros,
+                           MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Ciphertext like(const Ciphertext& other, size_t polynomial_count, bool fill_zeros, MemoryPoolHandle pool = MemoryPool::GlobalPool()) {
+        return like(other, polynomial_count, other.coeff_modulus_size(), fill_zeros, pool);
+    }
+    static Ciphertext like(const Ciphertext& other, bool fill_zeros, MemoryPoolHandle pool = MemoryPool::GlobalPool()) {
+        return like(other, other.polynomial_count(), other.coeff_modulus_size(), fill_zeros, pool);
+    }
+    Ciphertext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
+    const ParmsID& parms_id() const noexcept { return parms_id_; }
+    ParmsID& parms_id() noexcept { return parms_id_; }
+    size_t polynomial_count() const noexcept { return polynomial_count_; }
+    size_t coeff_modulus_size() const noexcept { return coeff_modulus_size_; }
+    size_t poly_modulus_degree() const noexcept { return poly_modulus_degree_; }
+    double scale() const noexcept { return scale_; }
+    double& scale() noexcept { return scale_; }
+    bool is_ntt_form() const noexcept { return is_ntt_form_; }
+    bool& is_ntt_form() noexcept { return is_ntt_form_; }
+    uint64_t correction_factor() const noexcept { return correction_factor_; }
+    uint64_t& correction_factor() noexcept { return correction_factor_; }
+    uint64_t seed() const noexcept { return seed_; }
+    uint64_t& seed() noexcept { return seed_; }
+    bool contains_seed() const noexcept { return seed_ != 0; }
+    bool on_device() const noexcept { return data_.on_device(); }
+    MemoryPoolHandle pool() const { return data_.pool(); }
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
+    void to_host_inplace() { data_.to_host_inplace(); }
+    Ciphertext to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext c = clone(pool); c.to_device_inplace(pool); return c; }
+    Ciphertext to_host() const { Ciphertext c = *this; c.to_host_inplace(); return c; }
+    const utils::DynamicArray& data() const noexcept { return data_; }
+    utils::DynamicArray& data() noexcept { return data_; }
+    uint64_t* poly(size_t p) { return data_.raw_pointer() + p * coeff_modulus_size_ * poly_modulus_degree_; }
+    const uint64_t* poly(size_t p) const { return data_.raw_pointer() + p * coeff_modulus_size_ * poly_modulus_degree_; }
+    // resize(context, parms_id, polynomial_count) -- src/ciphertext.cu:26-60
+    void resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep = true);
+private:
+    size_t polynomial_count_ = 0, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
+    ParmsID parms_id_;
+    double scale_ = 1.0;
+    bool is_ntt_form_ = false;
+    uint64_t correction_factor_ = 1, seed_ = 0;
+    utils::DynamicArray data_;
+};
+
+class Plaintext {
+public:
+    Plaintext() = default;
+    const ParmsID& parms_id() const noexcept { return parms_id_; }
+    ParmsID& parms_id() noexcept { return parms_id_; }
+    double scale() const noexcept { return scale_; }
+    double& scale() noexcept { return scale_; }
+    size_t coeff_count() const noexcept { return coeff_count_; }
+    size_t& coeff_count() noexcept { return coeff_count_; }
+    bool is_ntt_form() const noexcept { return is_ntt_form_; }
+    bool& is_ntt_form() noexcept { return is_ntt_form_; }
+    bool on_device() const noexcept { return data_.on_device(); }
+    const utils::DynamicArray& data() const noexcept { return data_; }
+    utils::DynamicArray& data() noexcept { return data_; }
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
+    void to_host_inplace() { data_.to_host_inplace(); }
+private:
+    size_t coeff_count_ = 0;
+    ParmsID parms_id_;
+    double scale_ = 1.0;
+    bool is_ntt_form_ = false;
+    utils::DynamicArray data_;
+};
+
+// ----------------------------------------------------------------------------------------------
+// Keys  (src/key.h, kswitch_keys.h)
+// ----------------------------------------------------------------------------------------------
+class PublicKey {
+public:
+    PublicKey() = default;
+    explicit PublicKey(Ciphertext&& c) : data_(std::move(c)) {}
+    const Ciphertext& as_ciphertext() const { return data_; }
+    Ciphertext& as_ciphertext() { return data_; }
+    const ParmsID& parms_id() const { return data_.parms_id(); }
+    bool on_device() const { return data_.on_device(); }
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
+    void to_host_inplace() { data_.to_host_inplace(); }
+private:
+    Ciphertext data_;
+};
+
+class KSwitchKeys {
+public:
+    KSwitchKeys() = default;
+    KSwitchKeys(const ParmsID& parms_id, std::vector<std::vector<PublicKey>>&& keys) : parms_id_(parms_id), keys_(std::move(keys)) {}
+    const ParmsID& parms_id() const { return parms_id_; }
+    ParmsID& parms_id() { return parms_id_; }
+    const std::vector<std::vector<PublicKey>>& data() const { return keys_; }
+    std::vector<std::vector<PublicKey>>& data() { return keys_; }
+    const std::vector<PublicKey>& operator[](size_t i) const { return keys_[i]; }
+    bool on_device() const;
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    void to_host_inplace();
+    // device pointers of key_vector[index][j] (kswitch_keys.h:34-54), as a host array for the C-ABI
+    std::vector<const uint64_t*> get_data_ptrs(size_t index) const;
+    const KSwitchKeys& as_kswitch_keys() const { return *this; }
+private:
+    ParmsID parms_id_;
+    std::vector<std::vector<PublicKey>> keys_;
+};
+
+class RelinKeys : public KSwitchKeys {
+public:
+    RelinKeys() = default;
+    explicit RelinKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    static size_t get_index(size_t key_power) {
+        if (key_power < 2) throw std::invalid_argument("[RelinKeys::get_index] key_power must be at least 2.");
+        return key_power - 2;
+    }
+    bool has_key(size_t key_power) const { size_t i = get_index(key_power); return i < data().size() && !data()[i].empty(); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Evaluator  (src/evaluator.h)
+// ----------------------------------------------------------------------------------------------
+class Evaluator {
+public:
+    enum class SwitchKeyDestinationAssignMethod { AddInplace = 0, Overwrite = 1, OverwriteExceptFirst = 2 };
+
+    explicit Evaluator(HeContextPointer context) : context_(std::move(context)) {}
+    HeContextPointer context() const { return context_; }
+    bool on_device() const { return context_->on_device(); }
+
+    // negate -- evaluator.h:113-133
+    void negate_inplace(Ciphertext& encrypted) const;
+    void negate(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext negate_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; negate(encrypted, d, pool); return d; }
+    void negate_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void negate_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
+    // add / sub -- evaluator.h:138-220 (translate, evaluator_translate.cu:64-118)
+    void add_inplace(Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_inplace(e1, e2, false, pool); }
+    void add(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate(e1, e2, d, false, pool); }
+    Ciphertext add_new(const Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; add(e1, e2, d, pool); return d; }
+    void sub_inplace(Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_inplace(e1, e2, true, pool); }
+    void sub(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate(e1, e2, d, true, pool); }
+    Ciphertext sub_new(const Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; sub(e1, e2, d, pool); return d; }
+    void add_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d,
+                     MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void sub_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d,
+                     MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
+    // multiply / square -- evaluator.h:225-262 (evaluator.cu:29-343)
+    void multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void multiply_inplace(Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; multiply(e1, e2, d, pool); e1 = std::move(d); }
+    Ciphertext multiply_new(const Ciphertext& e1, const Ciphertext& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; multiply(e1, e2, d, pool); return d; }
+    void square(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void square_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; square(encrypted, d, pool); encrypted = std::move(d); }
+    Ciphertext square_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; square(encrypted, d, pool); return d; }
+    void multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d,
+                          MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition (see header comment)
+
+    // key switching -- evaluator.h:267-303 (evaluator_keyswitching.cu)
+    void apply_keyswitching_inplace(Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void apply_keyswitching(const Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext apply_keyswitching_new(const Ciphertext& encrypted, const KSwitchKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_keyswitching(encrypted, k, d, pool); return d; }
+    void relinearize_inplace(Ciphertext& encrypted, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { relinearize_inplace_internal(encrypted, relin_keys, 2, pool); }
+    void relinearize(const Ciphertext& encrypted, const RelinKeys& relin_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { relinearize_internal(encrypted, relin_keys, 2, destination, pool); }
+    Ciphertext relinearize_new(const Ciphertext& encrypted, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; relinearize(encrypted, relin_keys, d, pool); return d; }
+    void relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d,
+                             MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition
+
+    // modulus switching -- evaluator.h:308-420 (evaluator_modswitch.cu)
+    void mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_to_next_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to_next(encrypted, d, pool); encrypted = std::move(d); }
+    Ciphertext mod_switch_to_next_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to_next(encrypted, d, pool); return d; }
+    void mod_switch_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_to(const Ciphertext& encrypted, const ParmsID& parms_id, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_to_inplace(Ciphertext& encrypted, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to(encrypted, parms_id, d, pool); encrypted = std::move(d); }
+    Ciphertext mod_switch_to_new(const Ciphertext& encrypted, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to(encrypted, parms_id, d, pool); return d; }
+    void rescale_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rescale_to_next_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to_next(encrypted, d, pool); encrypted = std::move(d); }
+    Ciphertext rescale_to_next_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to_next(encrypted, d, pool); return d; }
+    void rescale_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition
+
+    // NTT -- evaluator.h:655-700 (evaluator_transform_ntt.cu:469-652)
+    void transform_to_ntt_inplace(Ciphertext& encrypted) const;
+    void transform_to_ntt(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext transform_to_ntt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; transform_to_ntt(encrypted, d, pool); return d; }
+    void transform_from_ntt_inplace(Ciphertext& encrypted) const;
+    void transform_from_ntt(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext transform_from_ntt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; transform_from_ntt(encrypted, d, pool); return d; }
+    void transform_to_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void transform_from_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
+private:
+    ContextDataPointer get_context_data(const char* prompt, const ParmsID& id) const;
+    void translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool subtract, MemoryPoolHandle pool) const;
+    void translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& d, bool subtract, MemoryPoolHandle pool) const;
+    void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
+                             SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
+    void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
+    void relinearize_internal(const Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, Ciphertext& destination, MemoryPoolHandle pool) const;
+    void mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const;
+    void mod_switch_drop_to_internal(const Ciphertext& encrypted, Ciphertext& destination, const ParmsID& target, MemoryPoolHandle pool) const;
+    HeContextPointer context_;
+};
+
+}  // namespace troy
