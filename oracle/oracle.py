@@ -118,6 +118,18 @@ def lib():
     sig("orc_mod_switch_drop_to_next", None, vp, sz, p64, sz, p64)
     sig("orc_fill_uniform", None, u64, u64, p64, sz)
     sig("orc_fnv1a64", u64, p64, sz)
+    sig("orc_aes128_encrypt_block", None, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8))
+    sig("orc_rng_create", vp, u64, u64)
+    sig("orc_rng_destroy", None, vp)
+    sig("orc_rng_sample_uint64", u64, vp)
+    sig("orc_rng_fill_uint64s", None, vp, p64, sz)
+    for nm in ("orc_sample_poly_ternary", "orc_sample_poly_centered_binomial", "orc_sample_poly_uniform"):
+        sig(nm, None, vp, p64, sz, MP, sz)
+    sig("orc_keygen_secret_key", None, vp, vp, p64)
+    sig("orc_keygen_public_key", None, vp, vp, p64, p64)
+    sig("orc_batch_encode", C.c_int, vp, p64, sz, p64)
+    sig("orc_encrypt_asymmetric_bfv", None, vp, vp, p64, p64, sz, p64)
+    sig("orc_fnv_words", u64, p64, sz)
     _lib = L
     return L
 
@@ -172,6 +184,48 @@ def fill_uniform(seed, bound, n):
 def fnv1a64(a):
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
     return int(lib().orc_fnv1a64(ptr(a), a.size))
+
+
+def fnv_words(a):
+    """The survey probe's digest: FNV-1a step per 64-bit word."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+    return int(lib().orc_fnv_words(ptr(a), a.size))
+
+
+def aes128_encrypt_block(block, key):
+    b = (C.c_uint8 * 16)(*block)
+    k = (C.c_uint8 * 16)(*key)
+    lib().orc_aes128_encrypt_block(b, k)
+    return bytes(b)
+
+
+class Rng:
+    """AES-128-CTR generator of the reference's HeContext (utils/random_generator.cu)."""
+
+    def __init__(self, seed_low, seed_high=0):
+        self.h = lib().orc_rng_create(seed_low, seed_high)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rng_destroy(self.h)
+            self.h = None
+
+    def sample_uint64(self):
+        return int(lib().orc_rng_sample_uint64(self.h))
+
+    def _sample(self, fn, n, q):
+        out = np.zeros(len(q) * n, dtype=np.uint64)
+        getattr(lib(), fn)(self.h, ptr(out), n, moduli_array(q), len(q))
+        return out.reshape(len(q), n)
+
+    def ternary(self, n, q):
+        return self._sample("orc_sample_poly_ternary", n, q)
+
+    def centered_binomial(self, n, q):
+        return self._sample("orc_sample_poly_centered_binomial", n, q)
+
+    def uniform(self, n, q):
+        return self._sample("orc_sample_poly_uniform", n, q)
 
 
 class NTTTables:
@@ -362,6 +416,29 @@ class Context:
         out = np.zeros(p * (L - 1) * self.n, dtype=np.uint64)
         lib().orc_mod_switch_drop_to_next(self.h, L, ptr(ct.reshape(-1)), p, ptr(out))
         return out.reshape(p, L - 1, self.n)
+
+    # ---- BASELINE config 1 host path (keygen / encode / encrypt), used to pin the oracle ----
+    def secret_key(self, rng):
+        sk = np.zeros(self.K * self.n, dtype=np.uint64)
+        lib().orc_keygen_secret_key(self.h, rng.h, ptr(sk))
+        return sk.reshape(self.K, self.n)
+
+    def public_key(self, rng, sk):
+        pk = np.zeros(2 * self.K * self.n, dtype=np.uint64)
+        lib().orc_keygen_public_key(self.h, rng.h, ptr(np.ascontiguousarray(sk).reshape(-1)), ptr(pk))
+        return pk.reshape(2, self.K, self.n)
+
+    def batch_encode(self, values):
+        v = arr(values)
+        plain = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_batch_encode(self.h, ptr(v), v.size, ptr(plain)) != 0:
+            raise ValueError("batch_encode failed")
+        return plain
+
+    def encrypt_asymmetric_bfv(self, rng, pk, plain):
+        out = np.zeros(2 * (self.K - 1) * self.n, dtype=np.uint64)
+        lib().orc_encrypt_asymmetric_bfv(self.h, rng.h, ptr(np.ascontiguousarray(pk).reshape(-1)), ptr(plain), plain.size, ptr(out))
+        return out.reshape(2, self.K - 1, self.n)
 
     def random_ct(self, seed, pcount, L):
         """uniform residues x[p][l][i] in [0, q_l) from the shared splitmix generator"""

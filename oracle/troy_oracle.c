@@ -1163,3 +1163,242 @@ uint64_t orc_fnv1a64(const uint64_t* data, size_t n) {
     for (size_t i = 0; i < n * 8; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
     return h;
 }
+
+/* ====================================================================================== */
+/* BASELINE config 1 host path: AES-CTR PRNG, samplers, keygen, batch encode, encrypt      */
+/* ====================================================================================== */
+
+/* AES-128 (FIPS-197).  The reference vendors tiny-AES-c (utils/aes_impl.inc); this is the published algorithm. */
+static uint8_t aes_sbox[256];
+static int aes_sbox_ready = 0;
+static uint8_t gf_mul(uint8_t a, uint8_t b) {
+    uint8_t p = 0;
+    for (int i = 0; i < 8; i++) { if (b & 1) p ^= a; uint8_t hi = a & 0x80; a <<= 1; if (hi) a ^= 0x1b; b >>= 1; }
+    return p;
+}
+static void aes_init_sbox(void) {
+    /* multiplicative inverse in GF(2^8) followed by the affine map */
+    for (int x = 0; x < 256; x++) {
+        uint8_t inv = 0;
+        if (x) for (int y = 1; y < 256; y++) if (gf_mul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        uint8_t s = inv, r = inv;
+        for (int i = 0; i < 4; i++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
+        aes_sbox[x] = s ^ 0x63;
+    }
+    aes_sbox_ready = 1;
+}
+
+void orc_aes128_encrypt_block(uint8_t st[16], const uint8_t key[16]) {
+    if (!aes_sbox_ready) aes_init_sbox();
+    uint8_t rk[176];
+    memcpy(rk, key, 16);
+    uint8_t rcon = 1;
+    for (int i = 16; i < 176; i += 4) {
+        uint8_t t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+        if (i % 16 == 0) {
+            uint8_t tmp = t[0];
+            t[0] = aes_sbox[t[1]] ^ rcon; t[1] = aes_sbox[t[2]]; t[2] = aes_sbox[t[3]]; t[3] = aes_sbox[tmp];
+            rcon = gf_mul(rcon, 2);
+        }
+        for (int k = 0; k < 4; k++) rk[i + k] = rk[i - 16 + k] ^ t[k];
+    }
+    for (int k = 0; k < 16; k++) st[k] ^= rk[k];
+    for (int round = 1; round <= 10; round++) {
+        uint8_t t[16];
+        for (int k = 0; k < 16; k++) t[k] = aes_sbox[st[k]];
+        /* ShiftRows: state is column-major (st[4*c + r]) */
+        for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) st[4 * c + r] = t[4 * ((c + r) & 3) + r];
+        if (round < 10) {
+            for (int c = 0; c < 4; c++) {
+                uint8_t a0 = st[4 * c], a1 = st[4 * c + 1], a2 = st[4 * c + 2], a3 = st[4 * c + 3];
+                st[4 * c] = gf_mul(a0, 2) ^ gf_mul(a1, 3) ^ a2 ^ a3;
+                st[4 * c + 1] = a0 ^ gf_mul(a1, 2) ^ gf_mul(a2, 3) ^ a3;
+                st[4 * c + 2] = a0 ^ a1 ^ gf_mul(a2, 2) ^ gf_mul(a3, 3);
+                st[4 * c + 3] = gf_mul(a0, 3) ^ a1 ^ a2 ^ gf_mul(a3, 2);
+            }
+        }
+        for (int k = 0; k < 16; k++) st[k] ^= rk[16 * round + k];
+    }
+}
+
+struct orc_rng { uint64_t seed[2]; uint64_t counter[2]; };   /* utils/random_generator.h:9-46: {low, high} little endian */
+
+orc_rng* orc_rng_create(uint64_t seed_low, uint64_t seed_high) {
+    orc_rng* r = (orc_rng*)calloc(1, sizeof(*r));
+    r->seed[0] = seed_low; r->seed[1] = seed_high;
+    return r;
+}
+void orc_rng_destroy(orc_rng* r) { free(r); }
+
+static void rng_next_block(orc_rng* r, uint64_t out[2]) {
+    /* host_generate_uint128, random_generator.cu:112-117 */
+    uint8_t block[16];
+    memcpy(block, r->counter, 16);
+    orc_aes128_encrypt_block(block, (const uint8_t*)r->seed);
+    memcpy(out, block, 16);
+    r->counter[0]++;
+    if (r->counter[0] == 0) r->counter[1]++;
+}
+
+uint64_t orc_rng_sample_uint64(orc_rng* r) { uint64_t b[2]; rng_next_block(r, b); return b[0]; }
+
+void orc_rng_fill_uint64s(orc_rng* r, uint64_t* out, size_t n) {
+    /* fill_bytes :124-137 over n*8 bytes */
+    size_t i = 0;
+    for (; i + 2 <= n; i += 2) rng_next_block(r, out + i);
+    if (i < n) { uint64_t b[2]; rng_next_block(r, b); out[i] = b[0]; }
+}
+
+void orc_sample_poly_ternary(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod) {
+    /* random_generator.cu:318-336 host branch */
+    size_t byte_at = 0;
+    uint64_t w[2] = {0, 0};
+    for (size_t j = 0; j < degree; j++) {
+        if (byte_at == 0) rng_next_block(r, w);
+        uint8_t byte = (byte_at < 8) ? (uint8_t)(w[0] >> (byte_at * 8)) : (uint8_t)(w[1] >> ((byte_at - 8) * 8));
+        uint8_t v = byte % 3;
+        byte_at = (byte_at + 1) & 15;
+        for (size_t i = 0; i < nmod; i++) dest[i * degree + j] = (v == 2) ? moduli[i].value - 1 : v;
+    }
+}
+
+static int popcount8(uint8_t x) { int c = 0; while (x) { c += x & 1; x >>= 1; } return c; }
+static int uint64_to_cbd(uint64_t v) {
+    /* random_generator.cu:374-385 */
+    uint8_t x[8];
+    memcpy(x, &v, 8);
+    x[2] &= 0x1f; x[5] &= 0x1f;
+    return popcount8(x[0]) + popcount8(x[1]) + popcount8(x[2]) - popcount8(x[3]) - popcount8(x[4]) - popcount8(x[5]);
+}
+
+void orc_sample_poly_centered_binomial(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod) {
+    /* random_generator.cu:421-440 host branch */
+    uint64_t w[2] = {0, 0};
+    for (size_t j = 0; j < degree; j++) {
+        if (!(j & 1)) rng_next_block(r, w);
+        int v = uint64_to_cbd((j & 1) ? w[1] : w[0]);
+        for (size_t i = 0; i < nmod; i++) dest[i * degree + j] = (v >= 0) ? (uint64_t)v : moduli[i].value - (uint64_t)(-v);
+    }
+}
+
+void orc_sample_poly_uniform(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod) {
+    /* random_generator.cu:475-481: fill_uint64s then modulo_inplace_p (Barrett-64) */
+    orc_rng_fill_uint64s(r, dest, degree * nmod);
+    for (size_t i = 0; i < nmod; i++)
+        for (size_t j = 0; j < degree; j++) dest[i * degree + j] = orc_barrett_reduce64(dest[i * degree + j], &moduli[i]);
+}
+
+void orc_keygen_secret_key(const orc_context* c, orc_rng* rng, uint64_t* sk) {
+    /* key_generator.cu:31-58: ternary over the K key-level limbs, then NTT */
+    orc_sample_poly_ternary(rng, sk, c->n, c->key_modulus, c->K);
+    orc_ntt_forward(sk, 1, c->K, c->log_n, (const orc_ntt_tables* const*)c->ntt_tables, c->K, ORC_IDX_COMPONENTWISE, 0);
+}
+
+void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* pk) {
+    /* key_generator.cu:65-84 -> rlwe::symmetric at the key level, NTT form, no saved seed (utils/rlwe.cu:218-317) */
+    const size_t n = c->n, K = c->K;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t seed = 0;
+    while (seed == 0) seed = orc_rng_sample_uint64(rng);
+    orc_rng* c1_prng = orc_rng_create(seed, 0);
+    uint64_t* c0 = pk, *c1 = pk + K * n;
+    orc_sample_poly_uniform(c1_prng, c1, n, c->key_modulus, K);        /* directly sampled in NTT form */
+    orc_rng_destroy(c1_prng);
+    uint64_t* noise = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    orc_sample_poly_centered_binomial(rng, noise, n, c->key_modulus, K);
+    orc_dyadic_product_ps(sk, c1, 1, n, c->key_modulus, K, c0);
+    orc_ntt_forward(noise, 1, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+    orc_add_ps(c0, noise, 1, n, c->key_modulus, K, c0);
+    orc_negate_ps(c0, 1, n, c->key_modulus, K, c0);
+    free(noise);
+}
+
+int orc_batch_encode(const orc_context* c, const uint64_t* values, size_t count, uint64_t* plain) {
+    /* batch_encoder.cu:14-64 (index map, generator 3) and :169-226 (scatter + INTT over t) */
+    const size_t n = c->n, logn = c->log_n;
+    if (count > n) return -1;
+    orc_ntt_tables* pt = orc_ntt_tables_create(logn, c->plain_modulus);
+    if (!pt) return -1;
+    size_t* map = (size_t*)malloc(n * sizeof(size_t));
+    size_t row = n >> 1, m = n << 1, pos = 1;
+    for (size_t i = 0; i < row; i++) {
+        map[i] = reverse_bits((pos - 1) >> 1, logn);
+        map[i + row] = reverse_bits((m - pos - 1) >> 1, logn);
+        pos = (pos * 3) & (m - 1);
+    }
+    memset(plain, 0, n * sizeof(uint64_t));
+    for (size_t i = 0; i < count; i++) plain[map[i]] = values[i];
+    const orc_ntt_tables* tt = pt;
+    orc_ntt_inverse(plain, 1, 1, logn, &tt, 1, ORC_IDX_COMPONENTWISE, 0);
+    free(map);
+    orc_ntt_tables_destroy(pt);
+    return 0;
+}
+
+/* multi-limb q / small t helpers for the BFV Delta constants (context_data.cu:226-247) */
+static size_t big_product(const uint64_t* v, size_t n, uint64_t* out /* n words */) {
+    size_t len = 1;
+    memset(out, 0, n * sizeof(uint64_t));
+    out[0] = 1;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t carry = 0;
+        for (size_t k = 0; k < len; k++) { u128 p = (u128)out[k] * v[i] + carry; out[k] = (uint64_t)p; carry = (uint64_t)(p >> 64); }
+        if (carry) out[len++] = carry;
+    }
+    return len;
+}
+static uint64_t big_divmod_small(uint64_t* a, size_t len, uint64_t d) {   /* a /= d, returns remainder */
+    u128 rem = 0;
+    for (size_t k = len; k-- > 0;) { u128 cur = (rem << 64) | a[k]; a[k] = (uint64_t)(cur / d); rem = cur % d; }
+    return (uint64_t)rem;
+}
+static uint64_t big_mod_small(const uint64_t* a, size_t len, uint64_t d) {
+    u128 rem = 0;
+    for (size_t k = len; k-- > 0;) rem = ((rem << 64) | a[k]) % d;
+    return (uint64_t)rem;
+}
+
+void orc_encrypt_asymmetric_bfv(const orc_context* c, orc_rng* rng, const uint64_t* pk, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out) {
+    /* encryptor.cu:259-268: encrypt zero at the first data level -- which, having a previous (key) level, means an
+     * encryption of zero with all K limbs (utils/rlwe.cu:11-91, coefficient form) followed by divide_and_round_q_last
+     * (encryptor.cu:44-75) -- then c0 += round(q*m/t) (fgk/translate_plain.cu:28-38). */
+    const size_t n = c->n, K = c->K, L = K - 1;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t* temp = (uint64_t*)malloc(2 * K * n * sizeof(uint64_t));
+    uint64_t* u = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    orc_sample_poly_ternary(rng, u, n, c->key_modulus, K);
+    orc_ntt_forward(u, 1, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+    for (size_t j = 0; j < 2; j++) orc_dyadic_product_ps(u, pk + j * K * n, 1, n, c->key_modulus, K, temp + j * K * n);
+    orc_ntt_inverse(temp, 2, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+    for (size_t j = 0; j < 2; j++) {
+        orc_sample_poly_centered_binomial(rng, u, n, c->key_modulus, K);   /* u reused as e_j */
+        orc_add_ps(temp + j * K * n, u, 1, n, c->key_modulus, K, temp + j * K * n);
+    }
+    orc_rns_divide_and_round_q_last(c->rns_tools[K], temp, 2, out);
+    /* Delta scaling at the first data level (L limbs) */
+    uint64_t qv[64], big[65], quot[65];
+    for (size_t i = 0; i < L; i++) qv[i] = c->key_modulus[i].value;
+    size_t len = big_product(qv, L, big);
+    memcpy(quot, big, len * sizeof(uint64_t));
+    const uint64_t t = c->plain_modulus;
+    const uint64_t q_mod_t = big_divmod_small(quot, len, t);          /* quot = floor(q/t) */
+    const uint64_t threshold = (t + 1) >> 1;                           /* plain_upper_half_threshold */
+    for (size_t j = 0; j < L; j++) {
+        const orc_modulus* mod = &c->key_modulus[j];
+        orc_mulop delta;
+        orc_mulop_init(&delta, big_mod_small(quot, len, mod->value), mod);   /* coeff_div_plain_modulus[j] */
+        for (size_t i = 0; i < plain_coeff_count && i < n; i++) {
+            u128 numerator = (u128)plain[i] * q_mod_t + threshold;
+            uint64_t fix = (uint64_t)(numerator / t);
+            uint64_t scaled = orc_add_mod(orc_mulop_mod(plain[i], &delta, mod), orc_barrett_reduce64(fix, mod), mod);
+            out[j * n + i] = orc_add_mod(out[j * n + i], scaled, mod);
+        }
+    }
+    free(u); free(temp);
+}
+
+uint64_t orc_fnv_words(const uint64_t* data, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= data[i]; h *= 1099511628211ull; }
+    return h;
+}

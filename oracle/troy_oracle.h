@@ -16,7 +16,10 @@
  * provided.  The oracle is pinned against the reference's own known-answer tests
  * (test/utils/ntt.cu, test/modulus.cu, test/utils/uint_small_mod.cu,
  * test/utils/rns_base.cu, test/utils/rns_tool.cu) re-typed as data in tests/golden/, and
- * against the values recorded in SURVEY.md (prime chains, BEHZ auxiliary primes).
+ * against the values recorded in SURVEY.md (prime chains, BEHZ auxiliary primes), and
+ * against OUTPUT of the reference itself: the digests of the BASELINE config-1 ciphertext
+ * and of its BEHZ product that the reference's CPU branch produced for seed 0x123
+ * (tests/golden/config1_digests.json, tests/test_oracle_config1.py).
  */
 #ifndef TROY_ORACLE_H
 #define TROY_ORACLE_H
@@ -166,6 +169,30 @@ void orc_bfv_multiply(const orc_context* c, size_t L, const uint64_t* a, size_t 
 void orc_mod_switch_scale_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out);
 /* evaluator_modswitch.cu:164-220 mod_switch_drop_to_next (CKKS mod_switch_to_next): drop last limb */
 void orc_mod_switch_drop_to_next(const orc_context* c, size_t L, const uint64_t* in, size_t pcount, uint64_t* out);
+
+/* ---- BASELINE config 1 host path (encode -> keygen -> encrypt), for pinning against the reference's digests ----
+ * utils/random_generator.cu (AES-128-CTR PRNG :37-58,:238-247,:277-280; ternary :318-336; centered binomial :374-385,
+ * :421-440; uniform :475-481), key_generator.cu:31-58 (secret key), :65-84 + utils/rlwe.cu:218-317 (public key),
+ * batch_encoder.cu:14-64,:169-226 (encode), encryptor.cu:12-110,:259-268 + utils/rlwe.cu:11-91 (asymmetric encryption
+ * with modulus switch from the key level), fgk/translate_plain.cu:28-38 (Delta scaling).  BFV only. */
+typedef struct orc_rng orc_rng;
+void orc_aes128_encrypt_block(uint8_t block[16], const uint8_t key[16]);
+orc_rng* orc_rng_create(uint64_t seed_low, uint64_t seed_high);
+void orc_rng_destroy(orc_rng* r);
+uint64_t orc_rng_sample_uint64(orc_rng* r);
+void orc_rng_fill_uint64s(orc_rng* r, uint64_t* out, size_t n);
+void orc_sample_poly_ternary(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod);
+void orc_sample_poly_centered_binomial(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod);
+void orc_sample_poly_uniform(orc_rng* r, uint64_t* dest, size_t degree, const orc_modulus* moduli, size_t nmod);
+/* secret key [K][N] (NTT form) and public key [2][K][N] (NTT form) drawn from `rng` in the reference's call order */
+void orc_keygen_secret_key(const orc_context* c, orc_rng* rng, uint64_t* sk);
+void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* pk);
+/* BatchEncoder::encode: values[count] -> plain[N] mod t */
+int orc_batch_encode(const orc_context* c, const uint64_t* values, size_t count, uint64_t* plain);
+/* Encryptor::encrypt_asymmetric (BFV, plain at parms_id_zero): out [2][K-1][N], coefficient form */
+void orc_encrypt_asymmetric_bfv(const orc_context* c, orc_rng* rng, const uint64_t* pk, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out);
+/* the survey's digest: h = FNV offset; for each 64-bit WORD: h ^= word; h *= FNV prime */
+uint64_t orc_fnv_words(const uint64_t* data, size_t n);
 
 /* deterministic 64-bit generator used by tests/bench to make identical inputs on both sides
  * (splitmix64; NOT the reference's AES PRNG) ; fills out[i] uniformly in [0, bound) */

@@ -1,0 +1,60 @@
+"""Pin the oracle against real reference OUTPUT: BASELINE config 1 (examples/99_quickstart.cu parameters) run through
+the reference's CPU branch with seed 0x123 produced the two digests in tests/golden/config1_digests.json (SURVEY.md
+Appendix C).  Reproducing them needs every hot-path piece bit-exact: NTT/INTT over q and t, dyadic products, the
+modulus switch used inside encryption (divide_and_round_q_last) and the whole BEHZ multiply.  Runs without a GPU."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "config1_digests.json")))
+
+
+def config1_ciphertext(O):
+    n = G["poly_modulus_degree"]
+    q = O.coeff_modulus_create(n, G["coeff_modulus_bits"])
+    assert [int(v) for v in q] == G["coeff_modulus"]
+    t = int(O.get_primes(2 * n, 20, 1)[0])           # PlainModulus::batching(8192, 20)
+    assert t == G["plain_modulus"]
+    ctx = O.Context("bfv", n, q, t)
+    rng = O.Rng(G["seed"])
+    sk = ctx.secret_key(rng)
+    pk = ctx.public_key(rng, sk)
+    plain = ctx.batch_encode(G["message"])
+    ct = ctx.encrypt_asymmetric_bfv(rng, pk, plain)
+    return ctx, sk, ct
+
+
+def test_aes128_known_answer(O):
+    k = G["aes128_fips197"]
+    got = O.aes128_encrypt_block(bytes.fromhex(k["plaintext"]), bytes.fromhex(k["key"]))
+    assert got.hex() == k["ciphertext"]
+
+
+def test_samplers_shape(O):
+    q = G["coeff_modulus"]
+    r = O.Rng(7)
+    tern = r.ternary(64, q)
+    for i, qi in enumerate(q):
+        assert set(int(v) for v in tern[i]) <= {0, 1, qi - 1}
+    assert np.array_equal(tern[0] == 1, tern[1] == 1)            # same small value in every limb
+    cbd = r.centered_binomial(64, q)
+    small = np.where(cbd[0] > q[0] // 2, cbd[0].astype(np.int64) - q[0], cbd[0].astype(np.int64))
+    assert np.abs(small).max() <= 21
+    uni = r.uniform(64, q)
+    assert all((uni[i] < q[i]).all() for i in range(len(q)))
+    # determinism: same seed -> same stream
+    assert O.Rng(7).sample_uint64() == O.Rng(7).sample_uint64()
+
+
+def test_config1_ciphertext_digest(O):
+    _, _, ct = config1_ciphertext(O)
+    assert "%016x" % O.fnv_words(ct) == G["ciphertext_digest"]
+
+
+def test_config1_multiply_digest(O):
+    ctx, _, ct = config1_ciphertext(O)
+    prod = ctx.bfv_multiply(2, ct, ct)
+    assert prod.shape == (3, 2, G["poly_modulus_degree"])
+    assert "%016x" % O.fnv_words(prod) == G["multiply_digest"]
