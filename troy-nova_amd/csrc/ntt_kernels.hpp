@@ -22,6 +22,9 @@
 
 namespace troyn {
 
+constexpr int KS_MAX_KEYS = 64;  // HE_COEFF_MOD_COUNT_MAX (utils/constants.h:9)
+struct KeyPtrs { const u64* p[KS_MAX_KEYS]; };
+
 struct NttArgs {
     const u64* in;
     u64* out;
@@ -43,6 +46,8 @@ struct NttArgs {
     const u64* ext1;           // store: optional addend (relinearize's c0, c1)
     long long ext1_bstride, ext1_pstride, ext1_cstride;
     const ulonglong2* inv_table;   // store: Shoup pair of (dropped prime)^-1 mod q_j, indexed by component j
+    unsigned batch;                // ks_mac_kernel: number of items (workgroup -> (row, item) mapping)
+    long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
 };
 
 // Fused prologues: what a coefficient looks like when it enters the transform.
@@ -186,8 +191,20 @@ struct ArithU64 {
     using tw_mem = u64x2_mem;     // (operand, quotient) as stored in the table
 
     static constexpr bool MID_FIX = false;
-    struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo; };
-    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo}; }
+    struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo, ratio_lo; };
+    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo, d.ratio_lo}; }
+    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {
+        v = v >= m.two_q ? v - m.two_q : v;
+        return v >= m.q ? v - m.q : v;
+    }
+    // <digit, key> accumulation of the fused key switch (ks_mac_kernel): canonical in, canonical accumulator
+    static __device__ __forceinline__ elem mac_zero() { return 0; }
+    static __device__ __forceinline__ elem mac_in(u64 canonical, const Mod&) { return canonical; }
+    static __device__ __forceinline__ u64 mac_to_lds(elem x, const Mod& m) { return final_fwd(x, m); }
+    static __device__ __forceinline__ void mac(elem& acc, elem v, u64 key, const Mod& m) {
+        acc = add_mod(acc, barrett128(v * key, mul_hi(v, key), m.q, m.ratio_lo, m.ratio_hi), m.q);
+    }
+    static __device__ __forceinline__ u64 mac_final(elem acc, const Mod&) { return acc; }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem v, const Mod&) { return make_ulonglong2(v.x, v.y); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod&) { return raw; }
@@ -208,10 +225,6 @@ struct ArithU64 {
         a = s >= m.two_q ? s - m.two_q : s;
         b = shoup_lazy(u + m.two_q - v, w.x, w.y, m.q);
     }
-    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {
-        v = v >= m.two_q ? v - m.two_q : v;
-        return v >= m.q ? v - m.q : v;
-    }
     static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) {
         return shoup_lazy(final_fwd(v, m), m.ninv_op, m.ninv_quo, m.q);   // the reference's lazy N^-1 multiply
     }
@@ -224,6 +237,16 @@ struct ArithF64 {
     static constexpr bool MID_FIX = true;   // inverse blocks of 4 layers re-centre their sums after 2
     struct Mod { F64Mod m; double ninv, ninv_p; };
     static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd}; }
+    // <digit, key> accumulation: |v| <= 0.5p+1, key in [0,p): the product term is |r| <= 0.69p (dev_math_f64.hpp),
+    // the accumulator is re-centred after every term, so everything stays far below 2^53 and exact.
+    static __device__ __forceinline__ elem mac_zero() { return 0.0; }
+    static __device__ __forceinline__ elem mac_in(u64 canonical, const Mod& m) { return f64_corr(f64_from_u64(canonical), m.m); }
+    static __device__ __forceinline__ u64 mac_to_lds(elem x, const Mod& m) { return f64_double_to_bits(f64_corr(x, m.m)); }
+    static __device__ __forceinline__ void mac(elem& acc, elem v, u64 key, const Mod& m) {
+        const double y = f64_from_u64(key);
+        acc = f64_corr(acc + f64_mulc(v, y, y * m.m.inv_p, m.m.p), m.m);
+    }
+    static __device__ __forceinline__ u64 mac_final(elem acc, const Mod& m) { return f64_canon(acc, m.m); }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem w, const Mod& m) { return make_double2(w, w * m.m.inv_p); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool, const Mod& m) { return f64_corr(f64_from_u64(raw), m.m); }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
@@ -263,8 +286,13 @@ __host__ __device__ constexpr unsigned ntt_wave_bits(int S, int EB, int TB) {
 // Round r keeps local bits [S, S+EB) in registers and runs the butterflies of the transform
 // bits [BLO, BHI] that fall inside that window.
 // FIRST/LAST mark the first/last pass of the whole transform (prologue / final correction).
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
-__global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
+//
+// KSMAC (ks_mac_kernel): the workgroup owns output row k of one item of the key switch and loops over the L digits:
+// digit j is reduced mod q_key(k) while loading, transformed, and multiplied into two register accumulators with
+// the matching limbs of key j (fgk/switch_key.cu:6-54 + :83-154 in one pass); the (L+1)*L transformed digits never
+// reach HBM.  Digit k of row k < L is the untouched NTT-form input limb (evaluator_keyswitching_core.cu:851-852).
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC>
+__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds) {
     constexpr int C = TB - G;
     constexpr int E = 1 << EB;
     constexpr unsigned N = 1u << LOGN;
@@ -272,42 +300,84 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     constexpr int NLB = LOGN - LO - G - C;             // low-block bits in the tile id
     static_assert(G >= 1 && C >= 0 && NLB >= 0 && TB >= EB, "bad NTT pass shape");
     constexpr int ROUNDS = (G + EB - 1) / EB;
+    static_assert(!KSMAC || (!INV && FIRST && LAST && C == 0 && LO == 0 && ROUNDS > 1), "KSMAC needs a whole-limb forward tile");
     using elem = typename A::elem;
     using tw_t = typename A::tw_t;
 
-    __shared__ u64 lds[ROUNDS > 1 ? ntt_lds_words(TB) : 1];
-
-    const unsigned t = threadIdx.x;
+    unsigned t = threadIdx.x;
     unsigned bid = blockIdx.x;
-    const unsigned tile = bid & ((1u << TILE_BITS) - 1); bid >>= TILE_BITS;
-    const unsigned j = bid % a.ncomp; bid /= a.ncomp;
-    const unsigned k = bid % a.pcount;
-    const unsigned b = bid / a.pcount;
+    unsigned tile, j, k, b;
+    if constexpr (KSMAC) {
+        // row-major over the launch: consecutive workgroups (dealt round-robin to the 8 XCDs) work on the same
+        // output row, so that row's 2*L key limbs (L2-sized) stay hot in every XCD while the digits stream through
+        tile = 0; j = 0;
+        b = bid % a.batch; k = bid / a.batch;
+    } else {
+        tile = bid & ((1u << TILE_BITS) - 1); bid >>= TILE_BITS;
+        j = bid % a.ncomp; bid /= a.ncomp;
+        k = bid % a.pcount;
+        b = bid / a.pcount;
+    }
     const unsigned top = tile >> NLB;
     const unsigned lb = tile & ((1u << NLB) - 1);
 
-    if (a.skip_diag && k == j && k < a.decomp) return;   // consumer reads the original limb (see ks_accumulate_kernel)
-    const unsigned mi = ntt_table_index(a, k, j);
+    if (!KSMAC && a.skip_diag && k == j && k < a.decomp) return;   // consumer reads the original limb (see ks_accumulate_kernel)
+    const unsigned mi = KSMAC ? a.table_start + ((k == a.decomp) ? a.table_count - 1 : k) : ntt_table_index(a, k, j);
     const typename A::Mod md = A::make(a.mods[mi]);
     // twiddle tables are never written by a kernel: read them through the constant address space so that
     // wave-uniform fetches become scalar loads and stay out of the vector-memory queue
     typedef typename A::tw_mem tw_mem;
     typedef const tw_mem __attribute__((address_space(4)))* ctw_ptr;
-    const ctw_ptr twc = (ctw_ptr)(unsigned long long)(reinterpret_cast<const tw_mem*>(a.tw) + (size_t)mi * N);
+    unsigned long long tw_addr = (unsigned long long)(reinterpret_cast<const tw_mem*>(a.tw) + (size_t)mi * N);
+    ctw_ptr twc = (ctw_ptr)tw_addr;
     auto tw_load = [&](unsigned idx) -> tw_t { const tw_mem v = twc[idx]; return A::tw_from_mem(v, md); };
-    const u64* __restrict__ gin = a.in + (long long)b * a.in_bstride + (long long)k * a.in_pstride + (long long)j * a.in_cstride;
-    u64* __restrict__ gout = a.out + (long long)b * a.out_bstride + (long long)k * a.out_pstride + (long long)j * a.out_cstride;
+    const u64* __restrict__ gin = a.in + (long long)b * a.in_bstride + (KSMAC ? 0ll : (long long)k * a.in_pstride + (long long)j * a.in_cstride);
+    u64* __restrict__ gout = a.out + (long long)b * a.out_bstride + (KSMAC ? (long long)k * a.out_cstride : (long long)k * a.out_pstride + (long long)j * a.out_cstride);
 
     auto gindex = [&](unsigned loc) -> unsigned {
         return (top << (LOGN - LO)) | ((loc >> C) << (LOGN - LO - G)) | (lb << C) | (loc & ((1u << C) - 1));
     };
-    const bool fused_io = (FIRST && a.load_mode != NTT_LOAD_PLAIN) || (LAST && a.store_mode != NTT_STORE_PLAIN);
+    const bool fused_io = !KSMAC && ((FIRST && a.load_mode != NTT_LOAD_PLAIN) || (LAST && a.store_mode != NTT_STORE_PLAIN));
     NttIo io;
     if (fused_io) io = ntt_io_make(a, b, k, j, mi, gout);
     else { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; }
 
     elem x[E];
-
+    elem acc0[KSMAC ? E : 1], acc1[KSMAC ? E : 1];
+    const u64* __restrict__ key0 = nullptr;   // this iteration's key, component 0, limb mi
+    if constexpr (KSMAC) {
+        static_for<0, E>([&](auto Rc) { acc0[decltype(Rc)::value] = A::mac_zero(); acc1[decltype(Rc)::value] = A::mac_zero(); });
+    }
+    const u64* const gin0 = gin;
+    auto one_digit = [&](unsigned it) {
+    if constexpr (KSMAC) {
+        // neither the twiddles nor the LDS addresses depend on the digit: without these the compiler hoists every
+        // twiddle load (with its w/p product) and every index computation out of the digit loop and spills them
+        asm volatile("" : "+v"(t));
+        unsigned tw_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tw_addr);
+        unsigned tw_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tw_addr >> 32));
+        asm volatile("" : "+s"(tw_lo), "+s"(tw_hi));
+        twc = (ctw_ptr)(((unsigned long long)tw_hi << 32) | tw_lo);
+        gin = gin0 + (long long)it * a.in_cstride;
+        key0 = keys->p[it] + (size_t)(mi - a.table_start) * N;
+        if (a.skip_diag && it == k) {
+            // own digit: already in NTT form under this modulus; read it in the accumulators' (transposed) layout
+            const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            const u64* dg = a.ext0 + (long long)b * a.ext0_bstride + (long long)k * a.ext0_cstride;
+            static_for<0, E / 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned idx = wbase + m * 128u + lane * 2u;
+                const ulonglong2 v = nt_load2(dg + idx);
+                const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(key0 + idx);
+                const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(key0 + a.key_pstride + idx);
+                const elem v0 = A::mac_in(v.x, md), v1 = A::mac_in(v.y, md);
+                A::mac(acc0[2 * m], v0, k0.x, md); A::mac(acc0[2 * m + 1], v1, k0.y, md);
+                A::mac(acc1[2 * m], v0, k1.x, md); A::mac(acc1[2 * m + 1], v1, k1.y, md);
+                __builtin_amdgcn_sched_barrier(0);   // keep the key loads of later pairs from piling up in registers
+            });
+            return;
+        }
+    }
     static_for<0, ROUNDS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         // transform bits handled this round, and the register window [S, S+EB)
@@ -358,7 +428,8 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
 #else
                 const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
-                if constexpr (FIRST) x[R] = A::load_first(ntt_io_load(io, raw), a.reduce_input != 0, md);
+                if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
+                else if constexpr (FIRST) x[R] = A::load_first(ntt_io_load(io, raw), a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
         } else {
@@ -378,6 +449,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
             constexpr int rb = bit - S;            // register bit
             constexpr int kk = TB - 1 - bit;       // layer inside the tile
             constexpr int l = LO + kk;             // global (forward-numbered) layer of this bit
+            if constexpr (KSMAC) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
             static_for<0, (E >> (rb + 1))>([&](auto hc) {
                 constexpr int hi = decltype(hc)::value;
                 const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
@@ -403,7 +475,28 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
             });
         });
 
-        if constexpr (r == ROUNDS - 1 && !INV && LAST && S == 0 && C == 0 && ROUNDS > 1) {
+        if constexpr (KSMAC && r == ROUNDS - 1) {
+            // transpose inside the wave's own LDS slice (see the store path below), then multiply-accumulate with
+            // 16-byte coalesced key loads
+            const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            static_for<0, E>([&](auto Rc) {
+                constexpr int R = decltype(Rc)::value;
+                lds[lds_phys(wbase + lane * E + R)] = A::mac_to_lds(x[R], md);
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, E / 2>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned idx = wbase + m * 128u + lane * 2u;
+                const elem v0 = A::from_lds(lds[lds_phys(idx)]), v1 = A::from_lds(lds[lds_phys(idx + 1)]);
+                const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(key0 + idx);
+                const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(key0 + a.key_pstride + idx);
+                A::mac(acc0[2 * m], v0, k0.x, md); A::mac(acc0[2 * m + 1], v1, k0.y, md);
+                A::mac(acc1[2 * m], v0, k1.x, md); A::mac(acc1[2 * m + 1], v1, k1.y, md);
+                __builtin_amdgcn_sched_barrier(0);   // keep the key loads of later pairs from piling up in registers
+            });
+            // the next digit's first exchange overwrites every wave's slice
+            __syncthreads();
+        } else if constexpr (r == ROUNDS - 1 && !INV && LAST && S == 0 && C == 0 && ROUNDS > 1) {
             // A thread ends with E consecutive coefficients, a wave with 64*E.  Transpose them inside the wave's own
             // LDS slice (exactly the words this wave read in the last exchange, so no other wave is disturbed)
             // and store 16 bytes per lane to consecutive addresses: every store instruction writes 1 KiB of
@@ -447,6 +540,33 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
 #endif
         }
     });
+    };   // one_digit
+    if constexpr (KSMAC) { for (unsigned it = 0; it < a.decomp; ++it) one_digit(it); }
+    else one_digit(0u);
+    if constexpr (KSMAC) {
+        const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+        static_for<0, E / 2>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const unsigned idx = wbase + m * 128u + lane * 2u;
+            nt_store2(gout + idx, A::mac_final(acc0[2 * m], md), A::mac_final(acc0[2 * m + 1], md));
+            nt_store2(gout + a.out_pstride + idx, A::mac_final(acc1[2 * m], md), A::mac_final(acc1[2 * m + 1], md));
+        });
+    }
+}
+
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+__global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
+    __shared__ u64 lds[(G + EB - 1) / EB > 1 ? ntt_lds_words(TB) : 1];
+    ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false>(a, nullptr, lds);
+}
+
+// Fused key-switch inner product: grid = (L+1) rows x batch items, one whole-limb workgroup each.
+//   a.in   digits in coefficient form [item][j][N] (in_bstride, in_cstride), a.ext0 the NTT-form input (diagonal)
+//   keys   L pointers to u64[2][K][N];  a.out poly_prod [item][2][L+1][N] (out_bstride, out_pstride = poly, out_cstride = row)
+template <class A, int LOGN, int EB>
+__global__ __launch_bounds__(1 << (LOGN - EB)) void ks_mac_kernel(NttArgs a, KeyPtrs keys) {
+    __shared__ u64 lds[ntt_lds_words(LOGN)];
+    ntt_pass_body<A, LOGN, 0, LOGN, LOGN, EB, false, true, true, true>(a, &keys, lds);
 }
 
 // Generic fallback for any 2 <= N: one workgroup per limb-polynomial, radix-2 layer by layer.

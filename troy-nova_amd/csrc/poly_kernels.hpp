@@ -123,8 +123,7 @@ __global__ __launch_bounds__(POLY_BLOCK) void dyadic_square_kernel(unsigned chun
 
 // ---- key switching ---------------------------------------------------------------------
 
-constexpr int KS_MAX_KEYS = 64;  // HE_COEFF_MOD_COUNT_MAX (utils/constants.h:9)
-struct KeyPtrs { const u64* p[KS_MAX_KEYS]; };
+// KeyPtrs / KS_MAX_KEYS: ntt_kernels.hpp
 
 // fgk/switch_key.cu:83-136 kernel_accumulate_products.
 //   temp_ntt [batch][L+1][L][N]   decomposed digits in NTT form (row i under q_key(i))

@@ -270,6 +270,30 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
 }
 
 static int g_force_integer_ntt = -1;   // TROYN_NTT_ARITH=u64 forces the integer butterflies (A/B testing)
+static int g_ks_unfused_mac = -1;      // TROYN_KS_MAC=split keeps decomposition NTT and inner product in two launches (A/B testing)
+
+static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_count) {
+    if (g_force_integer_ntt < 0) {
+        const char* e = getenv("TROYN_NTT_ARITH");
+        g_force_integer_ntt = (e && std::strcmp(e, "u64") == 0) ? 1 : 0;
+    }
+    // FP64 butterflies when every modulus this launch can touch is below 2^50
+    bool f64 = !g_force_integer_ntt && p->log_n >= 10;
+    for (unsigned i = 0; f64 && i < table_count; i++) f64 = p->small_modulus[table_start + i] != 0;
+    return f64;
+}
+
+template <class A>
+static bool launch_ks_mac_t(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
+    switch (log_n) {
+        case 10: hipLaunchKernelGGL((ks_mac_kernel<A, 10, 4>), dim3((unsigned)blocks), dim3(1u << 6), 0, s, a, kp); return true;
+        case 11: hipLaunchKernelGGL((ks_mac_kernel<A, 11, 4>), dim3((unsigned)blocks), dim3(1u << 7), 0, s, a, kp); return true;
+        case 12: hipLaunchKernelGGL((ks_mac_kernel<A, 12, 4>), dim3((unsigned)blocks), dim3(1u << 8), 0, s, a, kp); return true;
+        case 13: hipLaunchKernelGGL((ks_mac_kernel<A, 13, 4>), dim3((unsigned)blocks), dim3(1u << 9), 0, s, a, kp); return true;
+        case 14: hipLaunchKernelGGL((ks_mac_kernel<A, 14, 4>), dim3((unsigned)blocks), dim3(1u << 10), 0, s, a, kp); return true;
+        default: return false;
+    }
+}
 
 static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s) {
     a.mods = p->d_mods;
@@ -279,13 +303,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     if (lp == 0) return TROYN_OK;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
-    if (g_force_integer_ntt < 0) {
-        const char* e = getenv("TROYN_NTT_ARITH");
-        g_force_integer_ntt = (e && std::strcmp(e, "u64") == 0) ? 1 : 0;
-    }
-    // FP64 butterflies when every modulus this launch can touch is below 2^50
-    bool f64 = !g_force_integer_ntt && p->log_n >= 10;
-    for (unsigned i = 0; f64 && i < a.table_count; i++) f64 = p->small_modulus[a.table_start + i] != 0;
+    const bool f64 = use_f64(p, a.table_start, a.table_count);
     bool done;
     if (f64) {
         a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
@@ -485,6 +503,31 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         digits_src = ws + w.target_intt;
         digits_bstride = (size_t)L * n;
     }
+    if (g_ks_unfused_mac < 0) {
+        const char* e = getenv("TROYN_KS_MAC");
+        g_ks_unfused_mac = (e && std::strcmp(e, "split") == 0) ? 1 : 0;
+    }
+    // (2)+(3) in ONE launch for whole-limb rings (N <= 16384): every workgroup owns one output row of one item,
+    //     transforms that row's L digits one after the other and multiplies them into register accumulators with
+    //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
+    //     (L+1)*L transformed digits never reach HBM.
+    const bool mac_fused = !g_ks_unfused_mac && p->log_n >= 10 && p->log_n <= 14 && batch * (size_t)(L + 1) <= 0x7fffffffull;
+    if (mac_fused) {
+        NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
+        a.in_bstride = (long long)digits_bstride; a.in_pstride = 0; a.in_cstride = n;
+        a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
+        a.reduce_input = 1;
+        a.stream_loads = 0;                      // the L+1 rows of an item re-read the same digits
+        a.skip_diag = is_ntt_form ? 1 : 0;       // digit k of row k is the NTT-form input limb itself
+        a.ext0 = target; a.ext0_bstride = (long long)target_bstride; a.ext0_cstride = n;
+        a.batch = (unsigned)batch; a.key_pstride = (long long)K * n;
+        a.mods = p->d_mods;
+        const bool f64 = use_f64(p, 0, K);
+        a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
+        if (f64) launch_ks_mac_t<ArithF64>(p->log_n, a, kp, batch * (L + 1), s);
+        else launch_ks_mac_t<ArithU64>(p->log_n, a, kp, batch * (L + 1), s);
+        LAUNCH_CHECK();
+    } else {
     // (2) digit decomposition fused into the forward NTT (replaces kernel_set_accumulate, fgk/switch_key.cu:6-54,
     //     + ntt_inplace_ps with key_switching_set_products, :907-908): row i = digits reduced mod q_key(i)
     {
@@ -504,6 +547,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
                            ch, p->d_mods, K, L, n, ws + w.temp_ntt, kp, ws + w.poly_prod,
                            fused ? target : (const u64*)nullptr, target_bstride);
         LAUNCH_CHECK();
+    }
     }
     // (4) INTT: only the special-prime rows when the result stays in NTT form; all rows otherwise (:991-996)
     const u64* last_src;
