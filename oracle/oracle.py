@@ -130,6 +130,10 @@ def lib():
     sig("orc_batch_encode", C.c_int, vp, p64, sz, p64)
     sig("orc_encrypt_asymmetric_bfv", None, vp, vp, p64, p64, sz, p64)
     sig("orc_fnv_words", u64, p64, sz)
+    sig("orc_keygen_relin_keys", None, vp, vp, p64, p64)
+    sig("orc_rns_decrypt_scale_and_round", C.c_int, vp, p64, p64)
+    sig("orc_decrypt_bfv", C.c_int, vp, p64, p64, sz, sz, p64)
+    sig("orc_batch_decode", C.c_int, vp, p64, p64)
     _lib = L
     return L
 
@@ -439,6 +443,34 @@ class Context:
         out = np.zeros(2 * (self.K - 1) * self.n, dtype=np.uint64)
         lib().orc_encrypt_asymmetric_bfv(self.h, rng.h, ptr(np.ascontiguousarray(pk).reshape(-1)), ptr(plain), plain.size, ptr(out))
         return out.reshape(2, self.K - 1, self.n)
+
+    def relin_keys(self, rng, sk):
+        """list of K-1 keys u64[2][K][N] (KeyGenerator::create_relin_keys)"""
+        L = self.K - 1
+        out = np.zeros(L * 2 * self.K * self.n, dtype=np.uint64)
+        lib().orc_keygen_relin_keys(self.h, rng.h, ptr(np.ascontiguousarray(sk).reshape(-1)), ptr(out))
+        return [k.copy() for k in out.reshape(L, 2, self.K, self.n)]
+
+    def decrypt_bfv(self, sk, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        pcount, L = ct.shape[0], ct.shape[1]
+        plain = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_decrypt_bfv(self.h, ptr(np.ascontiguousarray(sk).reshape(-1)), ptr(ct.reshape(-1)), pcount, L, ptr(plain)) != 0:
+            raise ValueError("decrypt failed")
+        return plain
+
+    def decrypt_scale_and_round(self, L, phase):
+        phase = np.ascontiguousarray(phase, dtype=np.uint64)
+        out = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_rns_decrypt_scale_and_round(self.rns_tool(L), ptr(phase.reshape(-1)), ptr(out)) != 0:
+            raise ValueError("decrypt_scale_and_round failed")
+        return out
+
+    def batch_decode(self, plain):
+        out = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_batch_decode(self.h, ptr(np.ascontiguousarray(plain, dtype=np.uint64)), ptr(out)) != 0:
+            raise ValueError("batch_decode failed")
+        return out
 
     def random_ct(self, seed, pcount, L):
         """uniform residues x[p][l][i] in [0, q_l) from the shared splitmix generator"""

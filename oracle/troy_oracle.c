@@ -1294,14 +1294,14 @@ void orc_keygen_secret_key(const orc_context* c, orc_rng* rng, uint64_t* sk) {
     orc_ntt_forward(sk, 1, c->K, c->log_n, (const orc_ntt_tables* const*)c->ntt_tables, c->K, ORC_IDX_COMPONENTWISE, 0);
 }
 
-void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* pk) {
-    /* key_generator.cu:65-84 -> rlwe::symmetric at the key level, NTT form, no saved seed (utils/rlwe.cu:218-317) */
+static void symmetric_zero_ntt(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* out) {
+    /* rlwe::symmetric at the key level, NTT form, no saved seed (utils/rlwe.cu:218-317): out [2][K][N] */
     const size_t n = c->n, K = c->K;
     const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
     uint64_t seed = 0;
     while (seed == 0) seed = orc_rng_sample_uint64(rng);
     orc_rng* c1_prng = orc_rng_create(seed, 0);
-    uint64_t* c0 = pk, *c1 = pk + K * n;
+    uint64_t* c0 = out, *c1 = out + K * n;
     orc_sample_poly_uniform(c1_prng, c1, n, c->key_modulus, K);        /* directly sampled in NTT form */
     orc_rng_destroy(c1_prng);
     uint64_t* noise = (uint64_t*)malloc(K * n * sizeof(uint64_t));
@@ -1313,6 +1313,124 @@ void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* s
     free(noise);
 }
 
+void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* pk) {
+    /* key_generator.cu:65-84 */
+    symmetric_zero_ntt(c, rng, sk, pk);
+}
+
+void orc_keygen_relin_keys(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* out) {
+    /* generate_rlk(1): new key = s^2 (compute_secret_key_powers, key_generator.cu:86-109); generate_one_kswitch_key
+     * (:136-153): key i = symmetric encryption of zero, then (q_special mod q_i) * s^2 added to limb i of c0 */
+    const size_t n = c->n, K = c->K, L = K - 1;
+    uint64_t* sk2 = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    orc_dyadic_product_ps(sk, sk, 1, n, c->key_modulus, K, sk2);
+    for (size_t i = 0; i < L; i++) {
+        uint64_t* key = out + i * 2 * K * n;
+        symmetric_zero_ntt(c, rng, sk, key);
+        const orc_modulus* qi = &c->key_modulus[i];
+        uint64_t factor = orc_barrett_reduce64(c->key_modulus[K - 1].value, qi);
+        for (size_t x = 0; x < n; x++) {
+            uint64_t v = orc_multiply_mod(sk2[i * n + x], factor, qi);     /* utils::multiply_scalar */
+            key[i * n + x] = orc_add_mod(key[i * n + x], v, qi);
+        }
+    }
+    free(sk2);
+}
+
+static void batch_index_map(size_t n, size_t logn, size_t* map) {
+    /* batch_encoder.cu:14-64 */
+    size_t row = n >> 1, m = n << 1, pos = 1;
+    for (size_t i = 0; i < row; i++) {
+        map[i] = reverse_bits((pos - 1) >> 1, logn);
+        map[i + row] = reverse_bits((m - pos - 1) >> 1, logn);
+        pos = (pos * 3) & (m - 1);
+    }
+}
+
+int orc_batch_decode(const orc_context* c, const uint64_t* plain, uint64_t* values) {
+    /* batch_encoder.cu decode: copy, NTT over t, gather through the index map */
+    const size_t n = c->n, logn = c->log_n;
+    orc_ntt_tables* pt = orc_ntt_tables_create(logn, c->plain_modulus);
+    if (!pt) return -1;
+    uint64_t* tmp = (uint64_t*)malloc(n * sizeof(uint64_t));
+    memcpy(tmp, plain, n * sizeof(uint64_t));
+    const orc_ntt_tables* tt = pt;
+    orc_ntt_forward(tmp, 1, 1, logn, &tt, 1, ORC_IDX_COMPONENTWISE, 0);
+    size_t* map = (size_t*)malloc(n * sizeof(size_t));
+    batch_index_map(n, logn, map);
+    for (size_t i = 0; i < n; i++) values[i] = tmp[map[i]];
+    free(map); free(tmp);
+    orc_ntt_tables_destroy(pt);
+    return 0;
+}
+
+int orc_rns_decrypt_scale_and_round(const orc_rns_tool* r, const uint64_t* phase, uint64_t* dest) {
+    /* constants: utils/rns_tool.cu:93-97,:111-114,:168-211; algorithm: :1344-1369 + :1118-1136 */
+    const size_t n = r->coeff_count, qs = r->q_size;
+    if (r->t.value == 0) return -1;
+    uint64_t qv[64], tg[2] = {r->t.value, r->gamma.value};
+    for (size_t i = 0; i < qs; i++) qv[i] = r->base_q.base[i].value;
+    base_converter conv;
+    memset(&conv, 0, sizeof(conv));
+    if (base_converter_init(&conv, qv, qs, tg, 2) != 0) { base_converter_free(&conv); return -1; }
+    uint64_t inv = 0;
+    if (!orc_try_invert_mod(orc_barrett_reduce64(r->gamma.value, &r->t), &r->t, &inv)) { base_converter_free(&conv); return -1; }
+    orc_mulop inv_gamma_mod_t;
+    orc_mulop_init(&inv_gamma_mod_t, inv, &r->t);
+    orc_mulop neg_inv_q[2];
+    const orc_modulus* tgm[2] = {&r->t, &r->gamma};
+    for (int i = 0; i < 2; i++) {
+        uint64_t temp = base_product_mod(&r->base_q, tgm[i]);
+        if (!orc_try_invert_mod(temp, tgm[i], &temp)) { base_converter_free(&conv); return -1; }
+        orc_mulop_init(&neg_inv_q[i], orc_negate_mod(temp, tgm[i]), tgm[i]);
+    }
+    uint64_t* temp = (uint64_t*)malloc(qs * n * sizeof(uint64_t));
+    uint64_t* ttg = (uint64_t*)malloc(2 * n * sizeof(uint64_t));
+    for (size_t i = 0; i < qs; i++) {
+        const orc_modulus* m = &r->base_q.base[i];
+        orc_mulop prod;
+        orc_mulop_init(&prod, orc_multiply_mod(orc_barrett_reduce64(r->t.value, m), orc_barrett_reduce64(r->gamma.value, m), m), m);
+        for (size_t x = 0; x < n; x++) temp[i * n + x] = orc_mulop_mod(phase[i * n + x], &prod, m);
+    }
+    fast_convert_array(&conv, temp, n, ttg);
+    for (int i = 0; i < 2; i++)
+        for (size_t x = 0; x < n; x++) ttg[i * n + x] = orc_mulop_mod(ttg[i * n + x], &neg_inv_q[i], tgm[i]);
+    const uint64_t gamma = r->gamma.value, gamma_div_2 = gamma >> 1;
+    for (size_t x = 0; x < n; x++) {
+        uint64_t d;
+        if (ttg[n + x] > gamma_div_2) d = orc_add_mod(ttg[x], orc_barrett_reduce64(gamma - ttg[n + x], &r->t), &r->t);
+        else d = orc_sub_mod(ttg[x], orc_barrett_reduce64(ttg[n + x], &r->t), &r->t);
+        dest[x] = d ? orc_mulop_mod(d, &inv_gamma_mod_t, &r->t) : 0;
+    }
+    free(temp); free(ttg);
+    base_converter_free(&conv);
+    return 0;
+}
+
+int orc_decrypt_bfv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t* plain) {
+    /* dot_product_ct_sk_array, coefficient-form input (decryptor.cu:27-105): NTT(c_1..), multiply by s, s^2, ..,
+     * sum, INTT, add c_0; then decrypt_scale_and_round (:331-362) */
+    const size_t n = c->n, K = c->K;
+    if (pcount < 2 || L < 1 || L > K) return -1;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t* spow = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    uint64_t* term = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    uint64_t* acc = (uint64_t*)calloc(L * n, sizeof(uint64_t));
+    memcpy(spow, sk, K * n * sizeof(uint64_t));
+    for (size_t i = 1; i < pcount; i++) {
+        memcpy(term, ct + i * L * n, L * n * sizeof(uint64_t));
+        orc_ntt_forward(term, 1, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+        orc_dyadic_product_ps(term, spow, 1, n, c->key_modulus, L, term);        /* first L limbs of s^i */
+        orc_add_ps(acc, term, 1, n, c->key_modulus, L, acc);
+        if (i + 1 < pcount) orc_dyadic_product_ps(spow, sk, 1, n, c->key_modulus, K, spow);
+    }
+    orc_ntt_inverse(acc, 1, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+    orc_add_ps(acc, ct, 1, n, c->key_modulus, L, acc);
+    int rc = orc_rns_decrypt_scale_and_round(c->rns_tools[L], acc, plain);
+    free(spow); free(term); free(acc);
+    return rc;
+}
+
 int orc_batch_encode(const orc_context* c, const uint64_t* values, size_t count, uint64_t* plain) {
     /* batch_encoder.cu:14-64 (index map, generator 3) and :169-226 (scatter + INTT over t) */
     const size_t n = c->n, logn = c->log_n;
@@ -1320,12 +1438,7 @@ int orc_batch_encode(const orc_context* c, const uint64_t* values, size_t count,
     orc_ntt_tables* pt = orc_ntt_tables_create(logn, c->plain_modulus);
     if (!pt) return -1;
     size_t* map = (size_t*)malloc(n * sizeof(size_t));
-    size_t row = n >> 1, m = n << 1, pos = 1;
-    for (size_t i = 0; i < row; i++) {
-        map[i] = reverse_bits((pos - 1) >> 1, logn);
-        map[i + row] = reverse_bits((m - pos - 1) >> 1, logn);
-        pos = (pos * 3) & (m - 1);
-    }
+    batch_index_map(n, logn, map);
     memset(plain, 0, n * sizeof(uint64_t));
     for (size_t i = 0; i < count; i++) plain[map[i]] = values[i];
     const orc_ntt_tables* tt = pt;

@@ -191,6 +191,14 @@ void orc_keygen_public_key(const orc_context* c, orc_rng* rng, const uint64_t* s
 int orc_batch_encode(const orc_context* c, const uint64_t* values, size_t count, uint64_t* plain);
 /* Encryptor::encrypt_asymmetric (BFV, plain at parms_id_zero): out [2][K-1][N], coefficient form */
 void orc_encrypt_asymmetric_bfv(const orc_context* c, orc_rng* rng, const uint64_t* pk, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out);
+/* KeyGenerator::generate_rlk(1) (key_generator.cu:136-153,:206-237): L = K-1 keys, out [L][2][K][N] */
+void orc_keygen_relin_keys(const orc_context* c, orc_rng* rng, const uint64_t* sk, uint64_t* out);
+/* RNSTool::decrypt_scale_and_round, host branch (utils/rns_tool.cu:1118-1136,:1334-1370): phase [q_size][N] -> dest [N] mod t */
+int orc_rns_decrypt_scale_and_round(const orc_rns_tool* r, const uint64_t* phase, uint64_t* dest);
+/* Decryptor::bfv_decrypt (decryptor.cu:27-105,:268-362): ct [pcount][L][N] coefficient form, sk [K][N] NTT form -> plain [N] */
+int orc_decrypt_bfv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t* plain);
+/* BatchEncoder::decode (batch_encoder.cu): plain [N] mod t -> values [N] */
+int orc_batch_decode(const orc_context* c, const uint64_t* plain, uint64_t* values);
 /* the survey's digest: h = FNV offset; for each 64-bit WORD: h ^= word; h *= FNV prime */
 uint64_t orc_fnv_words(const uint64_t* data, size_t n);
 

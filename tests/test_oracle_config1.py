@@ -58,3 +58,26 @@ def test_config1_multiply_digest(O):
     prod = ctx.bfv_multiply(2, ct, ct)
     assert prod.shape == (3, 2, G["poly_modulus_degree"])
     assert "%016x" % O.fnv_words(prod) == G["multiply_digest"]
+
+
+def test_config1_end_to_end_semantics(O):
+    """examples/99_quickstart.cu flow with genuine keys: the oracle's BEHZ multiply, key switching (relinearize with
+    real relinearization keys) and modulus switch must DECRYPT to the right slots -- a first-principles check of those
+    paths that does not depend on any restated constant."""
+    ctx, sk, ct = config1_ciphertext(O)
+    plain = ctx.batch_encode(G["message"])
+    dec = ctx.decrypt_bfv(sk, ct)
+    assert np.array_equal(dec, plain)
+    assert [int(v) for v in ctx.batch_decode(dec)[:6]] == [1, 2, 3, 4, 0, 0]
+    rng = O.Rng(99)
+    prod = ctx.bfv_multiply(2, ct, ct)
+    want = [1, 4, 9, 16, 0, 0]
+    d3 = ctx.decrypt_bfv(sk, prod)
+    assert [int(v) for v in ctx.batch_decode(d3)[:6]] == want
+    rel = ctx.relinearize(2, False, prod, ctx.relin_keys(rng, sk))
+    assert np.array_equal(ctx.decrypt_bfv(sk, rel), d3)
+    low = ctx.mod_switch_scale_to_next(2, rel)
+    assert np.array_equal(ctx.decrypt_bfv(sk, low), d3)
+    # add: (m + m) decrypts to 2m
+    two = np.stack([(ct[p].astype(object) * 2 % np.array(ctx.q[:2], dtype=object)[:, None]).astype(np.uint64) for p in range(2)])
+    assert [int(v) for v in ctx.batch_decode(ctx.decrypt_bfv(sk, two))[:4]] == [2, 4, 6, 8]
