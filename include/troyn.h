@@ -163,6 +163,26 @@ int troyn_mod_switch_drop(const troyn_plan* plan, uint32_t L_in, uint32_t L_out,
                           uint64_t* out, size_t batch, troyn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Callers either side of the evaluator path, kept on the device:
+ *
+ * Context PRNG = AES-128 in counter mode (utils/random_generator.cu:37-58,:112-117): key = seed[2]
+ * (low, high), block i = AES(counter + i).  The samplers write `nmod` limbs (the first nmod plan
+ * moduli) of one polynomial and report how many blocks they consumed so the caller can advance its
+ * counter exactly like RandomGenerator does:
+ *   troyn_sample_ternary            RandomGenerator::sample_poly_ternary            (:318-336)  ceil(N/16) blocks
+ *   troyn_sample_centered_binomial  RandomGenerator::sample_poly_centered_binomial  (:421-440)  ceil(N/2)  blocks
+ *   troyn_sample_uniform            RandomGenerator::sample_poly_uniform            (:475-481)  ceil(nmod*N/2) blocks
+ *   troyn_prng_block                host_generate_uint128 (:112-117), host only: sample_uint64() = out[0]
+ * ------------------------------------------------------------------------------------- */
+int troyn_prng_block(const uint64_t seed[2], uint64_t counter, uint64_t out[2]);
+int troyn_sample_ternary(const troyn_plan* plan, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                         uint64_t* blocks_used, troyn_stream_t stream);
+int troyn_sample_centered_binomial(const troyn_plan* plan, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                                   uint64_t* blocks_used, troyn_stream_t stream);
+int troyn_sample_uniform(const troyn_plan* plan, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                         uint64_t* blocks_used, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * BEHZ BFV multiply: Evaluator::bfv_multiply (evaluator.cu:29-116) with the RNSTool of the level
  * holding the first L plan moduli and plain modulus t (RNSTool ctor utils/rns_tool.cu:29-275;
  * fused device kernels fgk/rns_tool.cu:7-100, :147-286).  a[batch][pa][L][N] x b[batch][pb][L][N]
@@ -172,6 +192,16 @@ int troyn_behz_create(troyn_behz** behz, const troyn_plan* plan, uint32_t L, uin
 int troyn_behz_destroy(troyn_behz* behz);
 uint32_t troyn_behz_base_Bsk_size(const troyn_behz* behz);
 int troyn_behz_get_base_Bsk(const troyn_behz* behz, uint64_t* out); /* host copy, KAT hook */
+uint64_t troyn_behz_gamma(const troyn_behz* behz);
+/* scaling_variant::scale_up / multiply_add_plain / multiply_sub_plain (utils/scaling_variant.cu:17-90,
+ * fgk/translate_plain.cu:6-75): dest[item][L][N] = (from[item][L][N] or 0) +/- round(q/t * plain[item][i]);
+ * coefficients i >= plain_coeff_count copy `from` (or 0).  Strides in elements; `from` may be NULL or == dest. */
+int troyn_bfv_scale_up(const troyn_behz* behz, const uint64_t* plain, size_t plain_coeff_count, size_t plain_bstride,
+                       const uint64_t* from, size_t from_bstride, uint64_t* dest, size_t dest_bstride,
+                       int subtract, size_t batch, troyn_stream_t stream);
+/* RNSTool::decrypt_scale_and_round (utils/rns_tool.cu:1189-1391): phase[batch][L][N] (c0 + c1*s + ..., coefficient
+ * form) -> dest[batch][N] mod t. */
+int troyn_bfv_decrypt_scale_and_round(const troyn_behz* behz, const uint64_t* phase, uint64_t* dest, size_t batch, troyn_stream_t stream);
 size_t troyn_bfv_multiply_workspace_bytes(const troyn_behz* behz, size_t pa, size_t pb, size_t batch);
 int troyn_bfv_multiply(const troyn_behz* behz, const uint64_t* a, size_t pa, const uint64_t* b, size_t pb,
                        uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream);

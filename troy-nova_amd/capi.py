@@ -48,6 +48,13 @@ SYMBOLS = {
     "troyn_behz_destroy": (C.c_int, [vp]),
     "troyn_behz_base_Bsk_size": (u32, [vp]),
     "troyn_behz_get_base_Bsk": (C.c_int, [vp, p64]),
+    "troyn_behz_gamma": (u64, [vp]),
+    "troyn_bfv_scale_up": (C.c_int, [vp, vp, sz, sz, vp, sz, vp, sz, C.c_int, sz, vp]),
+    "troyn_bfv_decrypt_scale_and_round": (C.c_int, [vp, vp, vp, sz, vp]),
+    "troyn_prng_block": (C.c_int, [p64, u64, p64]),
+    "troyn_sample_ternary": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
+    "troyn_sample_centered_binomial": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
+    "troyn_sample_uniform": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
     "troyn_bfv_multiply_workspace_bytes": (sz, [vp, sz, sz, sz]),
     "troyn_bfv_multiply": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, sz, sz, vp]),
 }

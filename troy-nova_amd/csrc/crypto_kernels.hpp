@@ -1,0 +1,158 @@
+// crypto_kernels.hpp -- the callers either side of the evaluator hot path: the context PRNG's
+// samplers, BFV plaintext scaling (encrypt side) and BEHZ decrypt_scale_and_round (decrypt side).
+//
+// These are small launches (N or L*N coefficients); they exist so that key generation, encryption and decryption
+// stay on the GPU next to the evaluator kernels and reproduce the reference's results word for word:
+//   * samplers: utils/random_generator.cu (ternary :318-336, centered binomial :374-385,:421-440, uniform
+//     :475-481); one AES-128-CTR block per thread, blocks numbered from the generator's counter.
+//   * bfv_scale_up_kernel: fgk/translate_plain.cu:6-75 (multiply_translate_plain).
+//   * bfv_decrypt_round_kernel: utils/rns_tool.cu:1189-1268 (decrypt_scale_and_round, fused device form), with the
+//     per-coefficient scratch of the reference (temp / fast_convert_temp in global memory) kept in registers.
+#pragma once
+#include "aes128.hpp"
+#include "poly_kernels.hpp"
+
+namespace troyn {
+
+// out [nmod][n]; thread = one AES block = 16 coefficients (one byte each, byte % 3; 2 -> q-1)
+__global__ __launch_bounds__(256) void sample_ternary_kernel(AesRoundKeys key, u64 counter, const DevModulus* mods, unsigned nmod, unsigned n, u64* out) {
+    const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((size_t)blk * 16 >= n) return;
+    u64 w[2];
+    aes128_encrypt_counter(key, counter + blk, (counter + blk < counter) ? 1ull : 0ull, w[0], w[1]);
+    for (unsigned k = 0; k < 16 && blk * 16 + k < n; k++) {
+        const unsigned byte = (unsigned)((w[k >> 3] >> ((k & 7) * 8)) & 0xff);
+        const unsigned v = byte % 3;
+        const unsigned j = blk * 16 + k;
+        for (unsigned i = 0; i < nmod; i++) out[(size_t)i * n + j] = (v == 2) ? mods[i].q - 1 : (u64)v;
+    }
+}
+
+__device__ __forceinline__ int cbd_from_u64(u64 v) {
+    // utils/random_generator.cu:374-385: 21 bits minus 21 bits
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned pos = lo & 0x1fffffu;                                     // bytes 0,1 and the low 5 bits of byte 2
+    const unsigned neg = ((lo >> 24) & 0xffu) | ((hi & 0xffu) << 8) | (((hi >> 8) & 0x1fu) << 16);   // bytes 3,4, 5 bits of byte 5
+    return __popc(pos) - __popc(neg);
+}
+
+// out [nmod][n]; thread = one AES block = 2 coefficients
+__global__ __launch_bounds__(256) void sample_cbd_kernel(AesRoundKeys key, u64 counter, const DevModulus* mods, unsigned nmod, unsigned n, u64* out) {
+    const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((size_t)blk * 2 >= n) return;
+    u64 w[2];
+    aes128_encrypt_counter(key, counter + blk, (counter + blk < counter) ? 1ull : 0ull, w[0], w[1]);
+    for (unsigned k = 0; k < 2 && blk * 2 + k < n; k++) {
+        const int v = cbd_from_u64(w[k]);
+        const unsigned j = blk * 2 + k;
+        for (unsigned i = 0; i < nmod; i++) out[(size_t)i * n + j] = (v >= 0) ? (u64)v : mods[i].q - (u64)(-v);
+    }
+}
+
+// out [nmod][n] = the AES-CTR word stream reduced per limb (fill_uint64s + modulo_inplace_p); thread = 2 words
+__global__ __launch_bounds__(256) void sample_uniform_kernel(AesRoundKeys key, u64 counter, const DevModulus* mods, unsigned nmod, unsigned n, u64* out) {
+    const size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)nmod * n;
+    if (blk * 2 >= total) return;
+    u64 w[2];
+    aes128_encrypt_counter(key, counter + blk, (counter + blk < counter) ? 1ull : 0ull, w[0], w[1]);
+    for (unsigned k = 0; k < 2 && blk * 2 + k < total; k++) {
+        const size_t pos = blk * 2 + k;
+        const DevModulus md = mods[pos / n];
+        out[pos] = barrett64(w[k], md.q, md.ratio_hi);
+    }
+}
+
+struct ScaleUpArgs {
+    unsigned L, n, plain_coeff_count, subtract;
+    const DevModulus* mods;
+    const ulonglong2* delta;       // [L] Shoup pair of floor(q/t) mod q_j   (coeff_div_plain_modulus)
+    DevModulus t;                  // plain modulus with its Barrett ratio
+    u64 q_mod_t, threshold;        // q mod t, (t+1)/2
+    const u64* plain; long long plain_bstride;
+    const u64* from;  long long from_bstride;     // nullable
+    u64* dest;        long long dest_bstride;
+};
+
+// floor(((hi:lo)) / t) for a numerator below t*t (quotient < 2^64): Barrett-128 quotient + one correction
+__device__ __forceinline__ u64 div128_small_quotient(u64 in0, u64 in1, const DevModulus& t) {
+    u64 carry = mul_hi(in0, t.ratio_lo);
+    u64 t2lo = in0 * t.ratio_hi, t2hi = mul_hi(in0, t.ratio_hi);
+    u64 tmp1 = t2lo + carry;
+    u64 tmp3 = t2hi + (tmp1 < t2lo ? 1ull : 0ull);
+    t2lo = in1 * t.ratio_lo; t2hi = mul_hi(in1, t.ratio_lo);
+    u64 tmp1b = tmp1 + t2lo;
+    carry = t2hi + (tmp1b < tmp1 ? 1ull : 0ull);
+    u64 quot = in1 * t.ratio_hi + tmp3 + carry;
+    const u64 r = in0 - quot * t.q;
+    return r >= t.q ? quot + 1 : quot;
+}
+
+// one polynomial [L][n] per item: dest = (from or 0) +/- round(q/t * m); grid = items * L rows
+__global__ __launch_bounds__(POLY_BLOCK) void bfv_scale_up_kernel(unsigned chunks, ScaleUpArgs a) {
+    const unsigned j = blk_row(chunks) % a.L;
+    const size_t item = blk_row(chunks) / a.L;
+    const DevModulus md = a.mods[j];
+    const ulonglong2 delta = a.delta[j];
+    const u64* pl = a.plain + item * a.plain_bstride;
+    const u64* fr = a.from ? a.from + item * a.from_bstride + (size_t)j * a.n : nullptr;
+    u64* de = a.dest + item * a.dest_bstride + (size_t)j * a.n;
+    for (unsigned i = blk_col(chunks); i < a.n; i += chunks * blockDim.x) {
+        u64 v;
+        if (i < a.plain_coeff_count) {
+            const u64 m = pl[i];
+            u64 lo = m * a.q_mod_t, hi = mul_hi(m, a.q_mod_t);
+            const u64 lo2 = lo + a.threshold;
+            hi += (lo2 < lo) ? 1ull : 0ull;
+            const u64 fix = div128_small_quotient(lo2, hi, a.t);
+            const u64 scaled = add_mod(shoup_mul(m, delta.x, delta.y, md.q), barrett64(fix, md.q, md.ratio_hi), md.q);
+            if (fr) v = a.subtract ? sub_mod(fr[i], scaled, md.q) : add_mod(fr[i], scaled, md.q);
+            else v = a.subtract ? neg_mod(scaled, md.q) : scaled;
+        } else {
+            v = fr ? fr[i] : 0;
+        }
+        de[i] = v;
+    }
+}
+
+struct DecryptArgs {
+    unsigned L, n;
+    const DevModulus* mods;                 // base q
+    DevModulus t, gamma;
+    const ulonglong2* prod_t_gamma_mod_q;   // [L]
+    const ulonglong2* q_inv_punc;           // [L]
+    const u64* q_to_t;                      // [L] (q/q_i) mod t
+    const u64* q_to_gamma;                  // [L] (q/q_i) mod gamma
+    ulonglong2 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t;
+};
+
+// phase [items][L][n] -> dest [items][n]; one thread per coefficient
+__global__ __launch_bounds__(256) void bfv_decrypt_round_kernel(unsigned chunks, DecryptArgs c, const u64* phase, u64* dest) {
+    const size_t item = blockIdx.x / chunks;
+    const u64* ph = phase + item * (size_t)c.L * c.n;
+    u64* de = dest + item * (size_t)c.n;
+    for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < c.n; x += chunks * blockDim.x) {
+        u64 lo_t = 0, hi_t = 0, lo_g = 0, hi_g = 0;
+#pragma unroll 4
+        for (unsigned i = 0; i < c.L; ++i) {
+            const DevModulus md = c.mods[i];
+            const ulonglong2 ptg = c.prod_t_gamma_mod_q[i];
+            u64 y = shoup_mul(ph[(size_t)i * c.n + x], ptg.x, ptg.y, md.q);          // |gamma*t|_qi * ct(s)
+            const ulonglong2 ip = c.q_inv_punc[i];
+            y = (ip.x == 1) ? barrett64(y, md.q, md.ratio_hi) : shoup_mul(y, ip.x, ip.y, md.q);
+            mac128(lo_t, hi_t, y, c.q_to_t[i]);
+            mac128(lo_g, hi_g, y, c.q_to_gamma[i]);
+        }
+        u64 vt = barrett128(lo_t, hi_t, c.t.q, c.t.ratio_lo, c.t.ratio_hi);
+        u64 vg = barrett128(lo_g, hi_g, c.gamma.q, c.gamma.ratio_lo, c.gamma.ratio_hi);
+        vt = shoup_mul(vt, c.neg_inv_q_mod_t.x, c.neg_inv_q_mod_t.y, c.t.q);
+        vg = shoup_mul(vg, c.neg_inv_q_mod_gamma.x, c.neg_inv_q_mod_gamma.y, c.gamma.q);
+        const u64 gamma_div_2 = c.gamma.q >> 1;
+        u64 d;
+        if (vg > gamma_div_2) d = add_mod(vt, barrett64(c.gamma.q - vg, c.t.q, c.t.ratio_hi), c.t.q);
+        else d = sub_mod(vt, barrett64(vg, c.t.q, c.t.ratio_hi), c.t.q);
+        de[x] = d ? shoup_mul(d, c.inv_gamma_mod_t.x, c.inv_gamma_mod_t.y, c.t.q) : 0;
+    }
+}
+
+}  // namespace troyn

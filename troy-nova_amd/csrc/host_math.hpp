@@ -183,4 +183,34 @@ inline u64 product_mod(const std::vector<u64>& base, size_t except, u64 p) {
     return acc;
 }
 
+// ---- multi-word helpers for the BFV Delta constants (context_data.cu:226-247: floor(q/t), q mod t) ----
+inline std::vector<u64> big_product(const std::vector<u64>& values) {
+    std::vector<u64> acc{1};
+    for (u64 v : values) {
+        u64 carry = 0;
+        for (size_t k = 0; k < acc.size(); k++) {
+            const u128 p = static_cast<u128>(acc[k]) * v + carry;
+            acc[k] = static_cast<u64>(p);
+            carry = static_cast<u64>(p >> 64);
+        }
+        if (carry) acc.push_back(carry);
+    }
+    return acc;
+}
+// a <- floor(a / d); returns a mod d
+inline u64 big_divmod_small(std::vector<u64>& a, u64 d) {
+    u128 rem = 0;
+    for (size_t k = a.size(); k-- > 0;) {
+        const u128 cur = (rem << 64) | a[k];
+        a[k] = static_cast<u64>(cur / d);
+        rem = cur % d;
+    }
+    return static_cast<u64>(rem);
+}
+inline u64 big_mod_small(const std::vector<u64>& a, u64 d) {
+    u128 rem = 0;
+    for (size_t k = a.size(); k-- > 0;) rem = ((rem << 64) | a[k]) % d;
+    return static_cast<u64>(rem);
+}
+
 }}  // namespace troyn::host

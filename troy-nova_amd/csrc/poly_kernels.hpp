@@ -7,6 +7,7 @@
 // (>> 256 workgroups for any batch worth timing).
 #pragma once
 #include "dev_math.hpp"
+#include "ntt_kernels.hpp"   // KeyPtrs
 
 namespace troyn {
 

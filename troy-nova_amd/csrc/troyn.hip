@@ -12,6 +12,7 @@
 
 #include "../../include/troyn.h"
 #include "behz_kernels.hpp"
+#include "crypto_kernels.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
 #include "poly_kernels.hpp"
@@ -718,6 +719,15 @@ struct troyn_behz {
     std::vector<u64> bsk_values;
     u64* d_consts = nullptr;
     BehzDev dev;
+    // encrypt / decrypt side constants of the same RNSTool / ContextData (context_data.cu:226-247, rns_tool.cu:168-211)
+    u64 gamma = 0, q_mod_t = 0;
+    DevModulus t_mod, gamma_mod;
+    const ulonglong2* d_delta = nullptr;               // [L] floor(q/t) mod q_j
+    const ulonglong2* d_prod_t_gamma_mod_q = nullptr;  // [L]
+    const u64* d_q_to_t = nullptr;                     // [L]
+    const u64* d_q_to_gamma = nullptr;                 // [L]
+    ulonglong2 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t;
+    bool decrypt_ready = false;
 };
 
 extern "C" int troyn_behz_destroy(troyn_behz* b) {
@@ -802,6 +812,37 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     size_t off_neg_prod_B_mod_q = blob.size();
     for (size_t i = 0; i < L; i++) { u64 v = host::product_mod(B, SIZE_MAX, q[i]); push_shoup(q[i] - v, q[i]); }
 
+    // ---- encrypt / decrypt side ----
+    const u64 gamma = primes[1];
+    b->gamma = gamma;
+    std::vector<u64> q_over_t;                       // floor(q / t) as a multi-word integer
+    {
+        std::vector<u64> big = host::big_product(q);
+        b->q_mod_t = host::big_divmod_small(big, t);  // big <- floor(q/t)
+        q_over_t = big;
+    }
+    if (blob.size() & 1) blob.push_back(0);
+    size_t off_delta = blob.size();
+    for (size_t i = 0; i < L; i++) push_shoup(host::big_mod_small(q_over_t, q[i]), q[i]);
+    size_t off_ptg = blob.size();
+    for (size_t i = 0; i < L; i++) push_shoup(host::mulmod(t % q[i], gamma % q[i], q[i]), q[i]);
+    size_t off_q_to_t = blob.size();
+    for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, t));
+    size_t off_q_to_gamma = blob.size();
+    for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, gamma));
+    {
+        u64 inv;
+        b->decrypt_ready = true;
+        if (need_inv(gamma % t, t, inv)) { host::Shoup s = host::shoup(inv, t); b->inv_gamma_mod_t = make_ulonglong2(s.operand, s.quotient); }
+        else b->decrypt_ready = false;                // "[RNSTool::RNSTool] Unable to invert gamma mod t."
+        if (need_inv(host::product_mod(q, SIZE_MAX, t), t, inv)) { host::Shoup s = host::shoup((t - inv) % t, t); b->neg_inv_q_mod_t = make_ulonglong2(s.operand, s.quotient); }
+        else b->decrypt_ready = false;
+        if (need_inv(host::product_mod(q, SIZE_MAX, gamma), gamma, inv)) { host::Shoup s = host::shoup((gamma - inv) % gamma, gamma); b->neg_inv_q_mod_gamma = make_ulonglong2(s.operand, s.quotient); }
+        else b->decrypt_ready = false;
+    }
+    b->t_mod = make_dev_modulus(t, plan->log_n, false);
+    b->gamma_mod = make_dev_modulus(gamma, plan->log_n, false);
+
     HIP_TRY(hipSetDevice(plan->device));
     HIP_TRY(hipMalloc(&b->d_consts, blob.size() * sizeof(u64)));
     HIP_TRY(hipMemcpy(b->d_consts, blob.data(), blob.size() * sizeof(u64), hipMemcpyHostToDevice));
@@ -833,6 +874,10 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     d.B_to_msk = b->d_consts + off_B_to_msk;
     d.prod_B_mod_q = P2(off_prod_B_mod_q);
     d.neg_prod_B_mod_q = P2(off_neg_prod_B_mod_q);
+    b->d_delta = P2(off_delta);
+    b->d_prod_t_gamma_mod_q = P2(off_ptg);
+    b->d_q_to_t = b->d_consts + off_q_to_t;
+    b->d_q_to_gamma = b->d_consts + off_q_to_gamma;
     *out = b.release();
     return TROYN_OK;
 }
@@ -926,3 +971,85 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     }
     return TROYN_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// context PRNG samplers, BFV plaintext scaling, BFV decryption rounding
+// ---------------------------------------------------------------------------------------
+extern "C" int troyn_prng_block(const uint64_t seed[2], uint64_t counter, uint64_t out[2]) {
+    if (!seed || !out) return fail(TROYN_E_INVALID, "[troyn_prng_block] null argument");
+    const AesRoundKeys k = aes128_expand(seed[0], seed[1]);
+    u64 lo, hi;
+    aes128_encrypt_counter(k, counter, 0, lo, hi);
+    out[0] = lo; out[1] = hi;
+    return TROYN_OK;
+}
+
+template <typename K>
+static int launch_sampler(K kernel, const char* who, const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter,
+                          uint64_t* out, size_t blocks, uint64_t* blocks_used, troyn_stream_t stream) {
+    if (!p || !seed || !out) return fail(TROYN_E_INVALID, std::string(who) + " null argument");
+    if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(who) + " modulus count out of range");
+    const AesRoundKeys k = aes128_expand(seed[0], seed[1]);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       k, (u64)counter, p->d_mods, (unsigned)nmod, p->n, (u64*)out);
+    LAUNCH_CHECK();
+    if (blocks_used) *blocks_used = blocks;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_sample_ternary(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                                    uint64_t* blocks_used, troyn_stream_t stream) {
+    return launch_sampler(sample_ternary_kernel, "[RandomGenerator::sample_poly_ternary]", p, nmod, seed, counter, out,
+                          p ? ((size_t)p->n + 15) / 16 : 0, blocks_used, stream);
+}
+extern "C" int troyn_sample_centered_binomial(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                                              uint64_t* blocks_used, troyn_stream_t stream) {
+    return launch_sampler(sample_cbd_kernel, "[RandomGenerator::sample_poly_centered_binomial]", p, nmod, seed, counter, out,
+                          p ? ((size_t)p->n + 1) / 2 : 0, blocks_used, stream);
+}
+extern "C" int troyn_sample_uniform(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
+                                    uint64_t* blocks_used, troyn_stream_t stream) {
+    return launch_sampler(sample_uniform_kernel, "[RandomGenerator::sample_poly_uniform]", p, nmod, seed, counter, out,
+                          p ? ((size_t)p->n * nmod + 1) / 2 : 0, blocks_used, stream);
+}
+
+extern "C" int troyn_bfv_scale_up(const troyn_behz* b, const uint64_t* plain, size_t plain_coeff_count, size_t plain_bstride,
+                                  const uint64_t* from, size_t from_bstride, uint64_t* dest, size_t dest_bstride,
+                                  int subtract, size_t batch, troyn_stream_t stream) {
+    if (!b || !plain || !dest) return fail(TROYN_E_INVALID, "[scaling_variant::scale_up] null argument");
+    const unsigned n = b->plan->n;
+    if (plain_coeff_count > n) return fail(TROYN_E_INVALID, "[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+    if (batch == 0) return TROYN_OK;
+    ScaleUpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.L = b->L; a.n = n; a.plain_coeff_count = (unsigned)plain_coeff_count; a.subtract = subtract ? 1u : 0u;
+    a.mods = b->plan->d_mods; a.delta = b->d_delta; a.t = b->t_mod; a.q_mod_t = b->q_mod_t; a.threshold = (b->t + 1) >> 1;
+    a.plain = (const u64*)plain; a.plain_bstride = (long long)plain_bstride;
+    a.from = (const u64*)from; a.from_bstride = (long long)from_bstride;
+    a.dest = (u64*)dest; a.dest_bstride = (long long)dest_bstride;
+    const unsigned ch = chunks_single(n);
+    const size_t rows = batch * b->L;
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(bfv_scale_up_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream, ch, a);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_bfv_decrypt_scale_and_round(const troyn_behz* b, const uint64_t* phase, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    if (!b || !phase || !dest) return fail(TROYN_E_INVALID, "[RNSTool::decrypt_scale_and_round] null argument");
+    if (!b->decrypt_ready) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert gamma mod t.");
+    if (batch == 0) return TROYN_OK;
+    DecryptArgs c;
+    std::memset(&c, 0, sizeof(c));
+    c.L = b->L; c.n = b->plan->n; c.mods = b->plan->d_mods; c.t = b->t_mod; c.gamma = b->gamma_mod;
+    c.prod_t_gamma_mod_q = b->d_prod_t_gamma_mod_q; c.q_inv_punc = b->dev.q_inv_punc;
+    c.q_to_t = b->d_q_to_t; c.q_to_gamma = b->d_q_to_gamma;
+    c.neg_inv_q_mod_t = b->neg_inv_q_mod_t; c.neg_inv_q_mod_gamma = b->neg_inv_q_mod_gamma; c.inv_gamma_mod_t = b->inv_gamma_mod_t;
+    const unsigned ch = chunks_single(c.n);
+    if (int rc = check_rows(batch, ch)) return rc;
+    hipLaunchKernelGGL(bfv_decrypt_round_kernel, dim3((unsigned)(batch * ch)), dim3(256), 0, (hipStream_t)stream, ch, c, (const u64*)phase, (u64*)dest);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" uint64_t troyn_behz_gamma(const troyn_behz* b) { return b ? b->gamma : 0; }

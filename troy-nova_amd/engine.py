@@ -196,6 +196,39 @@ class Plan:
         return out
 
 
+class Prng:
+    """The context generator (AES-128-CTR, utils/random_generator.cu): seed + block counter on the host, sampling
+    kernels on the device."""
+
+    def __init__(self, plan, seed_low, seed_high=0):
+        self.plan = plan
+        self.seed = np.array([seed_low, seed_high], dtype=np.uint64)
+        self.counter = 0
+
+    def sample_uint64(self):
+        out = np.zeros(2, dtype=np.uint64)
+        capi.check(self.plan.lib.troyn_prng_block(self.seed.ctypes.data_as(capi.p64), self.counter, out.ctypes.data_as(capi.p64)))
+        self.counter += 1
+        return int(out[0])
+
+    def _sample(self, fn, nmod):
+        out = torch.empty((nmod, self.plan.n), dtype=torch.int64, device=self.plan.device)
+        used = np.zeros(1, dtype=np.uint64)
+        capi.check(getattr(self.plan.lib, fn)(self.plan.h, nmod, self.seed.ctypes.data_as(capi.p64), self.counter, _ptr(out),
+                                              used.ctypes.data_as(capi.p64), _stream()))
+        self.counter += int(used[0])
+        return out
+
+    def ternary(self, nmod):
+        return self._sample("troyn_sample_ternary", nmod)
+
+    def centered_binomial(self, nmod):
+        return self._sample("troyn_sample_centered_binomial", nmod)
+
+    def uniform(self, nmod):
+        return self._sample("troyn_sample_uniform", nmod)
+
+
 class Behz:
     """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""
 
@@ -222,6 +255,29 @@ class Behz:
         out = np.zeros(n, dtype=np.uint64)
         capi.check(self.plan.lib.troyn_behz_get_base_Bsk(self.h, out.ctypes.data_as(capi.p64)))
         return [int(x) for x in out]
+
+    @property
+    def gamma(self):
+        return int(self.plan.lib.troyn_behz_gamma(self.h))
+
+    def scale_up(self, plain, src=None, subtract=False, out=None):
+        """plain [batch][N] mod t -> out [batch][L][N] = (src or 0) +/- round(q/t * plain)   (scaling_variant::scale_up)"""
+        n, L = self.plan.n, self.L
+        batch = plain.numel() // n
+        if out is None:
+            out = torch.empty((batch, L, n), dtype=torch.int64, device=plain.device)
+        capi.check(self.plan.lib.troyn_bfv_scale_up(self.h, _ptr(plain), n, n, _ptr(src) if src is not None else None, L * n,
+                                                    _ptr(out), L * n, int(subtract), batch, _stream()))
+        return out
+
+    def decrypt_scale_and_round(self, phase, out=None):
+        """phase [batch][L][N] -> [batch][N] mod t   (RNSTool::decrypt_scale_and_round)"""
+        n, L = self.plan.n, self.L
+        batch = phase.numel() // (L * n)
+        if out is None:
+            out = torch.empty((batch, n), dtype=torch.int64, device=phase.device)
+        capi.check(self.plan.lib.troyn_bfv_decrypt_scale_and_round(self.h, _ptr(phase), _ptr(out), batch, _stream()))
+        return out
 
     def multiply(self, a, pa, b, pb, out=None):
         """a [batch][pa][L][N] x b [batch][pb][L][N] (coefficient form) -> [batch][pa+pb-1][L][N]"""
