@@ -64,3 +64,30 @@ def test_evaluator_cpp_api(O, dev, tmp_path, scheme, n, t, bits):
     neg = np.empty(L * n, dtype=np.uint64)
     O.lib().orc_negate_ps(O.ptr(np.ascontiguousarray(prod[2].reshape(-1))), 1, n, mods, L, O.ptr(neg))
     assert np.array_equal(d[9][0][:2].reshape(-1), tmp) and np.array_equal(d[9][0][2].reshape(-1), neg)
+
+
+def test_quickstart_cpp_api(dev):
+    """BASELINE config 1 through the C++ mirror (keygen, encoder, encryptor, evaluator, decryptor on the GPU): the
+    digests must equal the ones the reference itself produced for seed 0x123 (tests/golden/config1_digests.json)."""
+    import json
+    drv = os.path.join(ROOT, "tests", "cpp", "quickstart_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/quickstart_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_digests.json")))
+    r = subprocess.run([drv, hex(G["seed"])], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert kv["ct_digest"] == [G["ciphertext_digest"]]
+    assert kv["mul_digest"] == [G["multiply_digest"]]
+    assert kv["decrypt"] == ["1", "2", "3", "4", "0", "0"]
+    assert kv["add"] == ["2", "4", "6", "8", "0", "0"]
+    for k in ("mul", "relin", "modswitch"):
+        assert kv[k] == ["1", "4", "9", "16", "0", "0"], k
+    assert kv["relin_polys"] == ["2"] and kv["low_limbs"] == ["1"]
+    assert kv["mul2"] == ["5", "12", "21", "32", "0", "0"]
+    assert kv["sub"] == ["4", "4", "4", "4", "0", "0"]
+    assert kv["host_plain_rejected"] == ["1"]
+    # a different seed gives a different ciphertext but the same plaintext results
+    r2 = subprocess.run([drv, "0x456"], capture_output=True, text=True, timeout=600)
+    kv2 = {ln.split()[0]: ln.split()[1:] for ln in r2.stdout.splitlines() if ln.strip()}
+    assert kv2["ct_digest"] != kv["ct_digest"] and kv2["mul"] == kv["mul"]

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -375,13 +376,33 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
     for (std::shared_ptr<const ContextData> c = key_cd; c; c = c->next_) {
         std::const_pointer_cast<ContextData>(c)->chain_index_ = --count;
     }
+    // he_context.cu:126-131: seed 0 means "seed from the clock"
+    if (random_seed == 0) {
+        random_seed = static_cast<uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
+        if (random_seed == 0) random_seed = 1;
+    }
     he->random_seed_ = random_seed;
+    he->random_generator_.reset_seed(random_seed, 0);
     return he;
 }
 
 HeContext::~HeContext() {
     for (auto& kv : behz_) troyn_behz_destroy(kv.second);
+    if (plain_plan_) troyn_plan_destroy(plain_plan_);
     if (plan_) troyn_plan_destroy(plan_);
+}
+
+const troyn_plan* HeContext::plain_plan() const {
+    // ContextData::plain_ntt_tables (context_data.cu:189-203): one table set modulo t
+    std::lock_guard<std::mutex> lock(behz_mutex_);
+    if (plain_plan_) return plain_plan_;
+    if (!plan_) throw std::invalid_argument("[HeContext::plain_plan] HeContext is not on device (call to_device_inplace).");
+    const EncryptionParameters& kp = key_context_data().value()->parms();
+    uint32_t log_n = 0;
+    while ((size_t(1) << log_n) < kp.poly_modulus_degree()) log_n++;
+    const uint64_t t = kp.plain_modulus().value();
+    troyn_check(troyn_plan_create(&plain_plan_, static_cast<int>(pool_->get_device()), log_n, 1, &t, nullptr));
+    return plain_plan_;
 }
 
 void HeContext::to_device_inplace(MemoryPoolHandle pool) {
@@ -887,6 +908,513 @@ void Evaluator::transform_to_ntt_inplace_batched(const std::vector<Ciphertext*>&
 }
 void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
     for (Ciphertext* c : encrypted) transform_from_ntt_inplace(*c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// utils::RandomGenerator  (utils/random_generator.cu)
+// ------------------------------------------------------------------------------------------------
+namespace utils {
+
+uint64_t RandomGenerator::sample_uint64() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    uint64_t out[2];
+    troyn_check(troyn_prng_block(seed_, counter_, out));
+    counter_ += 1;
+    return out[0];
+}
+
+void RandomGenerator::sample_poly_ternary(const troyn_plan* plan, size_t nmod, uint64_t* destination) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    uint64_t used = 0;
+    troyn_check(troyn_sample_ternary(plan, static_cast<uint32_t>(nmod), seed_, counter_, destination, &used, current_stream()));
+    counter_ += used;
+}
+
+void RandomGenerator::sample_poly_centered_binomial(const troyn_plan* plan, size_t nmod, uint64_t* destination) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    uint64_t used = 0;
+    troyn_check(troyn_sample_centered_binomial(plan, static_cast<uint32_t>(nmod), seed_, counter_, destination, &used, current_stream()));
+    counter_ += used;
+}
+
+void RandomGenerator::sample_poly_uniform(const troyn_plan* plan, size_t nmod, uint64_t* destination) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    uint64_t used = 0;
+    troyn_check(troyn_sample_uniform(plan, static_cast<uint32_t>(nmod), seed_, counter_, destination, &used, current_stream()));
+    counter_ += used;
+}
+
+}  // namespace utils
+
+void Plaintext::resize_rns(const HeContext& context, const ParmsID& parms_id) {
+    // plaintext.cu resize_rns: a full RNS polynomial of the level's shape
+    auto cd = context.get_context_data(parms_id);
+    if (!cd.has_value()) throw std::invalid_argument("[Plaintext::resize_rns] ParmsID is not valid for the current context.");
+    const EncryptionParameters& p = cd.value()->parms();
+    parms_id_ = parms_id;
+    coeff_modulus_size_ = p.coeff_modulus().size();
+    poly_modulus_degree_ = p.poly_modulus_degree();
+    coeff_count_ = poly_modulus_degree_;
+    data_.resize(coeff_modulus_size_ * poly_modulus_degree_, false);
+}
+
+static void require_device_context(const char* prompt, const HeContextPointer& ctx) {
+    if (!ctx->on_device()) throw std::invalid_argument(std::string(prompt) + " HeContext is not on device (call to_device_inplace).");
+}
+
+// ------------------------------------------------------------------------------------------------
+// rlwe  (utils/rlwe.cu)
+// ------------------------------------------------------------------------------------------------
+namespace rlwe {
+
+static ContextDataPointer level(const char* prompt, const HeContextPointer& context, const ParmsID& parms_id) {
+    auto cd = context->get_context_data(parms_id);
+    if (!cd.has_value()) throw std::invalid_argument(std::string(prompt) + " parms_id is not valid for the current context.");
+    return cd.value();
+}
+
+void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form, bool save_seed,
+               Ciphertext& destination, MemoryPoolHandle pool) {
+    // utils/rlwe.cu:218-317 (symmetric_with_c1_prng with the context generator as c1 generator)
+    const char* P = "[rlwe::symmetric]";
+    require_device_context(P, context);
+    if (!sk.on_device()) throw std::invalid_argument(std::string(P) + " context_data and secret_key is not on the same device.");
+    ContextDataPointer cd = level(P, context, parms_id);
+    const EncryptionParameters& parms = cd->parms();
+    if (parms.scheme() == SchemeType::BGV) throw std::logic_error("[rlwe::symmetric] BGV is not part of this build.");
+    const uint32_t L = static_cast<uint32_t>(parms.coeff_modulus().size());
+    const size_t n = parms.poly_modulus_degree();
+    const troyn_plan* plan = context->plan();
+    hipStream_t s = current_stream();
+    destination = Ciphertext();
+    destination.data() = utils::DynamicArray(0, true, pool);
+    destination.resize(context, parms_id, 2, false);
+    destination.is_ntt_form() = is_ntt_form;
+    destination.scale() = 1.0;
+    destination.correction_factor() = 1;
+    destination.seed() = 0;
+    utils::RandomGenerator& prng = context->random_generator();
+    uint64_t seed = 0;
+    while (seed == 0) seed = prng.sample_uint64();
+    utils::RandomGenerator c1_prng(seed);
+    c1_prng.sample_poly_uniform(plan, L, destination.poly(1));
+    if (!is_ntt_form && save_seed) {
+        // the seed reproduces c1 in coefficient form; the computation below needs it in NTT form
+        troyn_check(troyn_ntt(plan, 0, destination.poly(1), destination.poly(1), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    }
+    if (save_seed) destination.seed() = seed;
+    utils::DynamicArray noise(static_cast<size_t>(L) * n, true, pool);
+    prng.sample_poly_centered_binomial(plan, L, noise.raw_pointer());
+    troyn_check(troyn_dyadic_product(plan, 0, L, sk.data().raw_pointer(), destination.poly(1), destination.poly(0), 1, s));
+    if (is_ntt_form) troyn_check(troyn_ntt(plan, 0, noise.raw_pointer(), noise.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    else troyn_check(troyn_ntt(plan, 1, destination.poly(0), destination.poly(0), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_add(plan, 0, L, destination.poly(0), noise.raw_pointer(), destination.poly(0), 1, s));
+    troyn_check(troyn_negate(plan, 0, L, destination.poly(0), destination.poly(0), 1, s));
+    if (!is_ntt_form && !save_seed)
+        troyn_check(troyn_ntt(plan, 1, destination.poly(1), destination.poly(1), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    hip_check(hipStreamSynchronize(s), "stream_sync");   // `noise` returns to the pool
+}
+
+void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form,
+                Ciphertext& destination, MemoryPoolHandle pool) {
+    // utils/rlwe.cu:11-91 (asymmetric_with_u_prng with the context generator as u generator)
+    const char* P = "[rlwe::asymmetric]";
+    require_device_context(P, context);
+    if (!pk.on_device()) throw std::invalid_argument(std::string(P) + " context_data and public_key is not on the same device.");
+    ContextDataPointer cd = level(P, context, parms_id);
+    const EncryptionParameters& parms = cd->parms();
+    if (parms.scheme() == SchemeType::BGV) throw std::logic_error("[rlwe::asymmetric] BGV is not part of this build.");
+    const uint32_t L = static_cast<uint32_t>(parms.coeff_modulus().size());
+    const size_t n = parms.poly_modulus_degree();
+    const troyn_plan* plan = context->plan();
+    hipStream_t s = current_stream();
+    const Ciphertext& public_key = pk.as_ciphertext();
+    const size_t encrypted_size = public_key.polynomial_count();
+    destination = Ciphertext();
+    destination.data() = utils::DynamicArray(0, true, pool);
+    destination.resize(context, parms_id, encrypted_size, false);
+    destination.is_ntt_form() = is_ntt_form;
+    destination.scale() = 1.0;
+    destination.correction_factor() = 1;
+    destination.seed() = 0;
+    utils::RandomGenerator& prng = context->random_generator();
+    utils::DynamicArray u(static_cast<size_t>(L) * n, true, pool);
+    prng.sample_poly_ternary(plan, L, u.raw_pointer());
+    troyn_check(troyn_ntt(plan, 0, u.raw_pointer(), u.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    for (size_t j = 0; j < encrypted_size; j++)     // the key's first L limbs of polynomial j
+        troyn_check(troyn_dyadic_product(plan, 0, L, u.raw_pointer(), public_key.poly(j), destination.poly(j), 1, s));
+    if (!is_ntt_form)
+        troyn_check(troyn_ntt(plan, 1, destination.poly(0), destination.poly(0), 1, encrypted_size, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    for (size_t j = 0; j < encrypted_size; j++) {
+        prng.sample_poly_centered_binomial(plan, L, u.raw_pointer());   // u reused as e_j
+        if (is_ntt_form) troyn_check(troyn_ntt(plan, 0, u.raw_pointer(), u.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        troyn_check(troyn_add(plan, 0, L, destination.poly(j), u.raw_pointer(), destination.poly(j), 1, s));
+    }
+    hip_check(hipStreamSynchronize(s), "stream_sync");
+}
+
+}  // namespace rlwe
+
+// ------------------------------------------------------------------------------------------------
+// KeyGenerator  (key_generator.cu)
+// ------------------------------------------------------------------------------------------------
+static Plaintext key_level_plaintext(const HeContextPointer& context, MemoryPoolHandle pool) {
+    ContextDataPointer kcd = context->key_context_data().value();
+    Plaintext p;
+    p.data() = utils::DynamicArray(0, true, pool);
+    p.resize_rns(*context, kcd->parms_id());
+    p.is_ntt_form() = true;
+    return p;
+}
+
+KeyGenerator::KeyGenerator(HeContextPointer context, MemoryPoolHandle pool) : context_(std::move(context)) {
+    // key_generator.cu:31-58: s <- R_3 under every key-level modulus, stored in NTT form
+    require_device_context("[KeyGenerator::KeyGenerator]", context_);
+    ContextDataPointer kcd = context_->key_context_data().value();
+    const uint32_t K = static_cast<uint32_t>(kcd->parms().coeff_modulus().size());
+    Plaintext sk = key_level_plaintext(context_, pool);
+    context_->random_generator().sample_poly_ternary(context_->plan(), K, sk.poly());
+    troyn_check(troyn_ntt(context_->plan(), 0, sk.poly(), sk.poly(), 1, 1, K, 0, K, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    secret_key_ = SecretKey(std::move(sk));
+    secret_key_array_ = secret_key_.data().clone(pool);
+}
+
+KeyGenerator::KeyGenerator(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool) : context_(std::move(context)) {
+    require_device_context("[KeyGenerator::KeyGenerator]", context_);
+    secret_key_ = secret_key.clone(pool);
+    if (!secret_key_.on_device()) secret_key_.to_device_inplace(pool);
+    secret_key_array_ = secret_key_.data().clone(pool);
+}
+
+PublicKey KeyGenerator::create_public_key(bool save_seed, MemoryPoolHandle pool) const {
+    // key_generator.cu:65-84
+    Ciphertext c;
+    rlwe::symmetric(secret_key_, context_, context_->key_parms_id(), true, save_seed, c, pool);
+    return PublicKey(std::move(c));
+}
+
+void KeyGenerator::compute_secret_key_powers(HeContextPointer context, size_t max_power, utils::DynamicArray& secret_key_array) {
+    // key_generator.cu:86-109
+    ContextDataPointer kcd = context->key_context_data().value();
+    const uint32_t K = static_cast<uint32_t>(kcd->parms().coeff_modulus().size());
+    const size_t poly_size = static_cast<size_t>(K) * kcd->parms().poly_modulus_degree();
+    if (secret_key_array.size() % poly_size != 0 || secret_key_array.size() == 0)
+        throw std::invalid_argument("[static KeyGenerator::compute_secret_key_powers] secret_key_array size must be a positive multiple of (coeff_count * coeff_modulus_size)");
+    const size_t old_size = secret_key_array.size() / poly_size;
+    const size_t new_size = std::max(old_size, max_power);
+    if (old_size == new_size) return;
+    secret_key_array.resize(new_size * poly_size, true);
+    uint64_t* base = secret_key_array.raw_pointer();
+    for (size_t i = old_size; i < new_size; i++)
+        troyn_check(troyn_dyadic_product(context->plan(), 0, K, base + (i - 1) * poly_size, base, base + i * poly_size, 1, current_stream()));
+}
+
+void KeyGenerator::generate_one_kswitch_key(const uint64_t* new_key, std::vector<PublicKey>& destination, bool save_seed, MemoryPoolHandle pool) const {
+    // key_generator.cu:136-153
+    if (!context_->using_keyswitching()) throw std::logic_error("[KeyGenerator::generate_one_kswitch_key] Keyswitching is not enabled.");
+    ContextDataPointer kcd = context_->key_context_data().value();
+    const auto& key_modulus = kcd->parms().coeff_modulus();
+    const size_t n = kcd->parms().poly_modulus_degree(), K = key_modulus.size();
+    const size_t decomp_mod_count = context_->first_context_data().value()->parms().coeff_modulus().size();
+    const troyn_plan* plan = context_->plan();
+    hipStream_t s = current_stream();
+    utils::DynamicArray temp(n, true, pool);
+    destination.clear();
+    for (size_t i = 0; i < decomp_mod_count; i++) {
+        Ciphertext c;
+        rlwe::symmetric(secret_key_, context_, kcd->parms_id(), true, save_seed, c, pool);
+        const uint64_t factor = key_modulus[i].reduce(key_modulus[K - 1].value());
+        troyn_check(troyn_multiply_scalar(plan, static_cast<uint32_t>(i), 1, new_key + i * n, factor, temp.raw_pointer(), 1, s));
+        uint64_t* component = c.poly(0) + i * n;
+        troyn_check(troyn_add(plan, static_cast<uint32_t>(i), 1, component, temp.raw_pointer(), component, 1, s));
+        destination.emplace_back(std::move(c));
+    }
+    hip_check(hipStreamSynchronize(s), "stream_sync");
+}
+
+KSwitchKeys KeyGenerator::create_keyswitching_key(const SecretKey& new_key, bool save_seed, MemoryPoolHandle pool) const {
+    std::vector<std::vector<PublicKey>> keys(1);
+    generate_one_kswitch_key(new_key.data().raw_pointer(), keys[0], save_seed, pool);
+    return KSwitchKeys(context_->key_parms_id(), std::move(keys));
+}
+
+RelinKeys KeyGenerator::create_relin_keys(bool save_seed, size_t max_power, MemoryPoolHandle pool) const {
+    // key_generator.h:72-77, key_generator.cu:206-237 (generate_rlk)
+    if (max_power < 2) throw std::invalid_argument("[KeyGenerator::create_relin_keys] max_power must be at least 2");
+    const size_t count = max_power - 1;
+    ContextDataPointer kcd = context_->key_context_data().value();
+    const size_t d = kcd->parms().coeff_modulus().size() * kcd->parms().poly_modulus_degree();
+    std::lock_guard<std::mutex> lock(secret_key_array_mutex_);
+    compute_secret_key_powers(context_, count + 1, secret_key_array_);
+    std::vector<std::vector<PublicKey>> keys(count);
+    for (size_t i = 0; i < count; i++)
+        generate_one_kswitch_key(secret_key_array_.raw_pointer() + (i + 1) * d, keys[i], save_seed, pool);
+    return RelinKeys(KSwitchKeys(kcd->parms_id(), std::move(keys)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encryptor  (encryptor.cu)
+// ------------------------------------------------------------------------------------------------
+const PublicKey& Encryptor::public_key() const {
+    if (!public_key_.has_value()) throw std::runtime_error("[Encryptor::public_key] Encryptor has no public key");
+    return public_key_.value();
+}
+const SecretKey& Encryptor::secret_key() const {
+    if (!secret_key_.has_value()) throw std::runtime_error("[Encryptor::secret_key] Encryptor has no secret key");
+    return secret_key_.value();
+}
+
+void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form, bool is_asymmetric, bool save_seed,
+                                      Ciphertext& destination, MemoryPoolHandle pool) const {
+    // encryptor.cu:12-110
+    const char* P = "[Encryptor::encrypt_zero_internal]";
+    if (is_asymmetric && !public_key_.has_value()) throw std::invalid_argument(std::string(P) + " Public key not set for asymmetric encryption.");
+    if (!is_asymmetric && !secret_key_.has_value()) throw std::invalid_argument(std::string(P) + " Secret key not set for symmetric encryption.");
+    if (save_seed && is_asymmetric) throw std::invalid_argument(std::string(P) + " Cannot save seed when using asymmetric encryption.");
+    auto cdo = context_->get_context_data(parms_id);
+    if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " parms_id is not valid for encryption parameters.");
+    ContextDataPointer cd = cdo.value();
+    if (!is_asymmetric) {
+        rlwe::symmetric(secret_key(), context_, parms_id, is_ntt_form, save_seed, destination, pool);
+        return;
+    }
+    auto prev = cd->prev_context_data();
+    if (!prev.has_value()) {
+        rlwe::asymmetric(public_key(), context_, parms_id, is_ntt_form, destination, pool);
+        return;
+    }
+    // encrypt one level up, then switch the extra prime away (encryptor.cu:44-75)
+    ContextDataPointer pcd = prev.value();
+    Ciphertext temp;
+    rlwe::asymmetric(public_key(), context_, pcd->parms_id(), is_ntt_form, temp, pool);
+    const uint32_t Lp = static_cast<uint32_t>(pcd->parms().coeff_modulus().size());
+    const size_t n = pcd->parms().poly_modulus_degree();
+    const size_t pc = temp.polynomial_count();
+    Ciphertext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize(context_, parms_id, pc, false);
+    hipStream_t s = current_stream();
+    if (is_ntt_form) {
+        const size_t wsb = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), Lp, pc, 1);
+        utils::DynamicArray ws((wsb + 7) / 8, true, pool);
+        troyn_check(troyn_divide_and_round_q_last_ntt(context_->plan(), Lp, temp.data().raw_pointer(), pc, out.data().raw_pointer(),
+                                                      ws.raw_pointer(), wsb, 1, s));
+        hip_check(hipStreamSynchronize(s), "stream_sync");
+    } else {
+        troyn_check(troyn_divide_and_round_q_last(context_->plan(), Lp, temp.data().raw_pointer(), pc, out.data().raw_pointer(), 1, s));
+    }
+    (void)n;
+    out.is_ntt_form() = is_ntt_form;
+    out.scale() = temp.scale();
+    out.correction_factor() = temp.correction_factor();
+    out.seed() = 0;
+    hip_check(hipStreamSynchronize(s), "stream_sync");   // `temp` returns to the pool
+    destination = std::move(out);
+}
+
+void Encryptor::encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const {
+    const bool ntt = context_->first_context_data().value()->parms().scheme() == SchemeType::CKKS;
+    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), ntt, true, false, destination, pool);
+}
+void Encryptor::encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const {
+    const bool ntt = context_->first_context_data().value()->parms().scheme() == SchemeType::CKKS;
+    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), ntt, false, save_seed, destination, pool);
+}
+
+void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // encryptor.cu:245-330
+    const char* P = "[Encryptor::encrypt_internal]";
+    require_device_context(P, context_);
+    if (!plain.on_device()) throw std::invalid_argument(std::string(P) + " The arguments are not on the same device.");
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    hipStream_t s = current_stream();
+    switch (scheme) {
+        case SchemeType::BFV: {
+            if (plain.parms_id() == parms_id_zero) {
+                if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BFV - Plaintext is in NTT form.");
+                encrypt_zero_internal(context_->first_parms_id(), false, is_asymmetric, save_seed, destination, pool);
+                // scaling_variant::multiply_add_plain_inplace: c0 += round(q/t * m)
+                const size_t L = destination.coeff_modulus_size(), n = destination.poly_modulus_degree();
+                if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+                troyn_check(troyn_bfv_scale_up(context_->behz(L), plain.poly(), plain.coeff_count(), n, destination.poly(0), L * n,
+                                               destination.poly(0), L * n, 0, 1, s));
+            } else {
+                auto cdo = context_->get_context_data(plain.parms_id());
+                if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " BFV - Plaintext parms_id is not valid.");
+                const uint32_t L = static_cast<uint32_t>(cdo.value()->parms().coeff_modulus().size());
+                encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool);
+                if (plain.coeff_count() != cdo.value()->parms().poly_modulus_degree())
+                    throw std::logic_error("[Encryptor::encrypt_internal] partial RNS plaintexts are not part of this build.");
+                troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
+            }
+            break;
+        }
+        case SchemeType::CKKS: {
+            auto cdo = context_->get_context_data(plain.parms_id());
+            if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " CKKS - Plaintext parms_id is not valid.");
+            const uint32_t L = static_cast<uint32_t>(cdo.value()->parms().coeff_modulus().size());
+            encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool);
+            troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
+            destination.scale() = plain.scale();
+            break;
+        }
+        default:
+            throw std::logic_error("[Encryptor::encrypt_internal] BGV is not part of this build.");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decryptor  (decryptor.cu)
+// ------------------------------------------------------------------------------------------------
+Decryptor::Decryptor(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool) : context_(std::move(context)) {
+    // decryptor.cu:14-25
+    require_device_context("[Decryptor::Decryptor]", context_);
+    const EncryptionParameters& kp = context_->key_context_data().value()->parms();
+    if (secret_key.data().size() != kp.poly_modulus_degree() * kp.coeff_modulus().size())
+        throw std::invalid_argument("[Decryptor::Decryptor] secret_key is not valid for encryption parameters");
+    secret_key_array_ = secret_key.data().clone(pool);
+    if (!secret_key_array_.on_device()) secret_key_array_.to_device_inplace(pool);
+}
+
+void Decryptor::dot_product_ct_sk_array(const Ciphertext& encrypted, uint64_t* destination, MemoryPoolHandle pool) const {
+    // decryptor.cu:27-105: c_0 + <(c_1, .., c_k), (s, .., s^k)>, in the form of the ciphertext
+    ContextDataPointer cd = context_->get_context_data(encrypted.parms_id()).value();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t n = cd->parms().poly_modulus_degree();
+    const size_t K = context_->key_context_data().value()->parms().coeff_modulus().size();
+    const size_t size = encrypted.polynomial_count();
+    const size_t pc = static_cast<size_t>(L) * n, kpc = K * n;
+    const troyn_plan* plan = context_->plan();
+    hipStream_t s = current_stream();
+    std::lock_guard<std::mutex> lock(secret_key_array_mutex_);
+    KeyGenerator::compute_secret_key_powers(context_, size - 1, secret_key_array_);
+    const bool ntt = encrypted.is_ntt_form();
+    utils::DynamicArray copy((size - 1) * pc, true, pool);
+    if (!ntt) troyn_check(troyn_ntt(plan, 0, encrypted.poly(1), copy.raw_pointer(), 1, size - 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    for (size_t i = 0; i + 1 < size; i++) {
+        const uint64_t* ci = ntt ? encrypted.poly(i + 1) : copy.raw_pointer() + i * pc;
+        troyn_check(troyn_dyadic_product(plan, 0, L, ci, secret_key_array_.raw_pointer() + i * kpc, copy.raw_pointer() + i * pc, 1, s));
+    }
+    hip_check(hipMemcpyAsync(destination, copy.raw_pointer(), pc * 8, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+    for (size_t i = 1; i + 1 < size; i++) troyn_check(troyn_add(plan, 0, L, destination, copy.raw_pointer() + i * pc, destination, 1, s));
+    if (!ntt) troyn_check(troyn_ntt(plan, 1, destination, destination, 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_add(plan, 0, L, destination, encrypted.poly(0), destination, 1, s));
+    hip_check(hipStreamSynchronize(s), "stream_sync");
+}
+
+void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool) const {
+    // decryptor.cu:227-244, :268-362 (BFV), :419-450 (CKKS)
+    const char* P = "[Decryptor::decrypt]";
+    require_device_context(P, context_);
+    if (!encrypted.on_device()) throw std::invalid_argument(std::string(P) + " Operand is on host; the decryptor runs on the GPU only.");
+    if (encrypted.contains_seed()) throw std::invalid_argument(std::string(P) + " Seed should be expanded first.");
+    if (encrypted.polynomial_count() < 2) throw std::invalid_argument(std::string(P) + " Ciphertext is invalid.");
+    auto cdo = context_->get_context_data(encrypted.parms_id());
+    if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " Ciphertext parms_id is not valid.");
+    ContextDataPointer cd = cdo.value();
+    const size_t L = cd->parms().coeff_modulus().size(), n = cd->parms().poly_modulus_degree();
+    switch (cd->parms().scheme()) {
+        case SchemeType::BFV: {
+            if (encrypted.is_ntt_form()) throw std::invalid_argument("[Decryptor::bfv_decrypt] Ciphertext is in NTT form.");
+            utils::DynamicArray phase(L * n, true, pool);
+            dot_product_ct_sk_array(encrypted, phase.raw_pointer(), pool);
+            Plaintext out;
+            out.data() = utils::DynamicArray(0, true, pool);
+            out.parms_id() = parms_id_zero;
+            out.resize(n);
+            troyn_check(troyn_bfv_decrypt_scale_and_round(context_->behz(L), phase.raw_pointer(), out.poly(), 1, current_stream()));
+            hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+            out.is_ntt_form() = false;
+            out.coeff_modulus_size() = L;
+            out.poly_modulus_degree() = n;
+            destination = std::move(out);
+            break;
+        }
+        case SchemeType::CKKS: {
+            if (!encrypted.is_ntt_form()) throw std::invalid_argument("[Decryptor::ckks_decrypt] Ciphertext is not in NTT form.");
+            Plaintext out;
+            out.data() = utils::DynamicArray(0, true, pool);
+            out.resize_rns(*context_, encrypted.parms_id());
+            dot_product_ct_sk_array(encrypted, out.poly(), pool);
+            out.is_ntt_form() = true;
+            out.scale() = encrypted.scale();
+            destination = std::move(out);
+            break;
+        }
+        default:
+            throw std::logic_error("[Decryptor::decrypt] BGV is not part of this build.");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchEncoder  (batch_encoder.cu)
+// ------------------------------------------------------------------------------------------------
+static size_t reverse_bits_sz(size_t x, size_t bits) {
+    size_t r = 0;
+    for (size_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+BatchEncoder::BatchEncoder(HeContextPointer context) : context_(std::move(context)) {
+    // batch_encoder.cu:14-64
+    ContextDataPointer cd = context_->first_context_data().value();
+    const EncryptionParameters& parms = cd->parms();
+    if (parms.scheme() != SchemeType::BFV && parms.scheme() != SchemeType::BGV)
+        throw std::invalid_argument("[BatchEncoder::BatchEncoder] Unsupported scheme");
+    slots_ = parms.poly_modulus_degree();
+    const uint64_t t = parms.plain_modulus().value();
+    if (!parms.plain_modulus().is_prime() || (t - 1) % (2 * slots_) != 0)
+        throw std::invalid_argument("[BatchEncoder::BatchEncoder] Encryption parameters are not valid for batching");
+    size_t logn = 0;
+    while ((size_t(1) << logn) < slots_) logn++;
+    matrix_reps_index_map_.resize(slots_);
+    const size_t row = slots_ >> 1, m = slots_ << 1;
+    size_t pos = 1;
+    for (size_t i = 0; i < row; i++) {
+        matrix_reps_index_map_[i] = reverse_bits_sz((pos - 1) >> 1, logn);
+        matrix_reps_index_map_[i + row] = reverse_bits_sz((m - pos - 1) >> 1, logn);
+        pos = (pos * 3) & (m - 1);     // GALOIS_GENERATOR = 3
+    }
+}
+
+void BatchEncoder::encode(const std::vector<uint64_t>& values, Plaintext& destination, MemoryPoolHandle pool) const {
+    // batch_encoder.cu:169-226: scatter through the index map, inverse NTT modulo t
+    const char* P = "[BatchEncoder::encode]";
+    require_device_context(P, context_);
+    if (values.size() > slots_) throw std::invalid_argument(std::string(P) + " Values has size larger than the number of slots");
+    const uint64_t t = context_->first_context_data().value()->parms().plain_modulus().value();
+    std::vector<uint64_t> buf(slots_, 0);
+    for (size_t i = 0; i < values.size(); i++) {
+        if (values[i] >= t) throw std::invalid_argument(std::string(P) + " Value is larger than plain modulus");
+        buf[matrix_reps_index_map_[i]] = values[i];
+    }
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.parms_id() = parms_id_zero;
+    out.resize(slots_);
+    out.data().copy_from(buf.data(), slots_, false);
+    troyn_check(troyn_ntt(context_->plain_plan(), 1, out.poly(), out.poly(), 1, 1, 1, 0, 1, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    out.is_ntt_form() = false;
+    out.poly_modulus_degree() = slots_;
+    out.coeff_modulus_size() = context_->first_context_data().value()->parms().coeff_modulus().size();
+    destination = std::move(out);
+}
+
+void BatchEncoder::decode(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool) const {
+    // batch_encoder.cu decode: forward NTT modulo t of a copy, gather through the index map
+    const char* P = "[BatchEncoder::decode]";
+    require_device_context(P, context_);
+    if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is in NTT form");
+    if (plain.coeff_count() > slots_) throw std::invalid_argument(std::string(P) + " Plaintext is not valid");
+    utils::DynamicArray tmp(slots_, true, pool);
+    tmp.set_zero();
+    hip_check(hipMemcpyAsync(tmp.raw_pointer(), plain.poly(), plain.coeff_count() * 8,
+                             plain.on_device() ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, current_stream()), "copy");
+    troyn_check(troyn_ntt(context_->plain_plan(), 0, tmp.raw_pointer(), tmp.raw_pointer(), 1, 1, 1, 0, 1, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    std::vector<uint64_t> host = tmp.to_vector();
+    destination.assign(slots_, 0);
+    for (size_t i = 0; i < slots_; i++) destination[i] = host[matrix_reps_index_map_[i]];
 }
 
 }  // namespace troy

@@ -7,6 +7,9 @@
 //   HeContext::create / to_device_inplace, ContextData     src/he_context.h, context_data.h
 //   MemoryPool / MemoryPoolHandle                           src/utils/memory_pool.h
 //   Ciphertext / Plaintext / KSwitchKeys / RelinKeys        src/ciphertext.h, plaintext.h, kswitch_keys.h
+//   utils::RandomGenerator, SecretKey, KeyGenerator, Encryptor, Decryptor, BatchEncoder
+//                                                          src/utils/random_generator.h, key_generator.h, encryptor.h,
+//                                                          decryptor.h, batch_encoder.h   (BFV and CKKS; GPU only)
 //   Evaluator (negate, add, sub, multiply, square, relinearize, apply_keyswitching,
 //              mod_switch_to_next, mod_switch_to, rescale_to_next, transform_to/from_ntt,
 //              x / x_inplace / x_new / x_batched)           src/evaluator.h:113-700
@@ -101,6 +104,23 @@ private:
     size_t size_ = 0;
     bool device_ = false;
     MemoryPoolHandle pool_;
+};
+
+// utils/random_generator.h: AES-128-CTR generator; the seed/counter state lives on the host, the polynomial
+// samplers run on the device through the C-ABI (troyn_sample_*).
+class RandomGenerator {
+public:
+    explicit RandomGenerator(uint64_t seed_low = 0, uint64_t seed_high = 0) { reset_seed(seed_low, seed_high); }
+    void reset_seed(uint64_t seed_low, uint64_t seed_high = 0) { seed_[0] = seed_low; seed_[1] = seed_high; counter_ = 0; }
+    uint64_t sample_uint64();
+    // destination: device buffer of nmod*N words (the first nmod moduli of the plan's chain)
+    void sample_poly_ternary(const troyn_plan* plan, size_t nmod, uint64_t* destination);
+    void sample_poly_centered_binomial(const troyn_plan* plan, size_t nmod, uint64_t* destination);
+    void sample_poly_uniform(const troyn_plan* plan, size_t nmod, uint64_t* destination);
+private:
+    uint64_t seed_[2] = {0, 0};
+    uint64_t counter_ = 0;
+    std::mutex mutex_;
 };
 
 }  // namespace utils
@@ -231,9 +251,12 @@ public:
     bool parameters_set() const { return parameters_set_; }
     uint64_t random_seed() const { return random_seed_; }
 
+    utils::RandomGenerator& random_generator() const { return random_generator_; }   // he_context.h:16 (mutable shared state)
+
     // C-ABI handles (boundary objects)
     const troyn_plan* plan() const { return plan_; }
     const troyn_behz* behz(size_t coeff_modulus_size) const;   // created on first use
+    const troyn_plan* plain_plan() const;                      // NTT tables mod t (ContextData::plain_ntt_tables), first use
 private:
     HeContext() = default;
     std::unordered_map<ParmsID, std::shared_ptr<ContextData>, ParmsIDHash> map_;
@@ -245,7 +268,11 @@ private:
     troyn_plan* plan_ = nullptr;
     mutable std::mutex behz_mutex_;
     mutable std::map<size_t, troyn_behz*> behz_;
+    mutable troyn_plan* plain_plan_ = nullptr;
+    mutable utils::RandomGenerator random_generator_;
 };
+
+
 
 // ----------------------------------------------------------------------------------------------
 // Ciphertext, Plaintext  (src/ciphertext.h, plaintext.h): data[(p*L + l)*N + i]
@@ -314,6 +341,15 @@ public:
     bool on_device() const noexcept { return data_.on_device(); }
     const utils::DynamicArray& data() const noexcept { return data_; }
     utils::DynamicArray& data() noexcept { return data_; }
+    size_t coeff_modulus_size() const noexcept { return coeff_modulus_size_; }
+    size_t& coeff_modulus_size() noexcept { return coeff_modulus_size_; }
+    size_t poly_modulus_degree() const noexcept { return poly_modulus_degree_; }
+    size_t& poly_modulus_degree() noexcept { return poly_modulus_degree_; }
+    uint64_t* poly() { return data_.raw_pointer(); }
+    const uint64_t* poly() const { return data_.raw_pointer(); }
+    void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
+    void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
+    Plaintext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
 private:
@@ -321,7 +357,25 @@ private:
     ParmsID parms_id_;
     double scale_ = 1.0;
     bool is_ntt_form_ = false;
+    size_t coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
     utils::DynamicArray data_;
+};
+
+// src/key.h: the secret key is a plaintext-shaped object holding s in NTT form under the key-level moduli
+class SecretKey {
+public:
+    SecretKey() = default;
+    explicit SecretKey(Plaintext&& p) : data_(std::move(p)) {}
+    const Plaintext& as_plaintext() const { return data_; }
+    Plaintext& as_plaintext() { return data_; }
+    const utils::DynamicArray& data() const { return data_.data(); }
+    utils::DynamicArray& data() { return data_.data(); }
+    bool on_device() const { return data_.on_device(); }
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
+    void to_host_inplace() { data_.to_host_inplace(); }
+    SecretKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+private:
+    Plaintext data_;
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -334,6 +388,7 @@ public:
     const Ciphertext& as_ciphertext() const { return data_; }
     Ciphertext& as_ciphertext() { return data_; }
     const ParmsID& parms_id() const { return data_.parms_id(); }
+    PublicKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
     bool on_device() const { return data_.on_device(); }
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
@@ -370,6 +425,96 @@ public:
         return key_power - 2;
     }
     bool has_key(size_t key_power) const { size_t i = get_index(key_power); return i < data().size() && !data()[i].empty(); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// KeyGenerator  (src/key_generator.h, key_generator.cu)
+// ----------------------------------------------------------------------------------------------
+class KeyGenerator {
+public:
+    explicit KeyGenerator(HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());                 // samples s
+    KeyGenerator(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    HeContextPointer context() const { return context_; }
+    bool on_device() const { return secret_key_.on_device(); }
+    const SecretKey& secret_key() const { return secret_key_; }
+    PublicKey create_public_key(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    KSwitchKeys create_keyswitching_key(const SecretKey& new_key, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    RelinKeys create_relin_keys(bool save_seed, size_t max_power = 2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    static void compute_secret_key_powers(HeContextPointer context, size_t max_power, utils::DynamicArray& secret_key_array);
+private:
+    void generate_one_kswitch_key(const uint64_t* new_key, std::vector<PublicKey>& destination, bool save_seed, MemoryPoolHandle pool) const;
+    HeContextPointer context_;
+    SecretKey secret_key_;
+    mutable std::mutex secret_key_array_mutex_;
+    mutable utils::DynamicArray secret_key_array_;   // s, s^2, ... each [K][N], NTT form
+};
+
+namespace rlwe {
+// utils/rlwe.h: encryptions of zero.  `parms_id` selects the level whose moduli are used.
+void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form, bool save_seed,
+               Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form,
+                Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+}  // namespace rlwe
+
+// ----------------------------------------------------------------------------------------------
+// Encryptor / Decryptor  (src/encryptor.h, decryptor.h)
+// ----------------------------------------------------------------------------------------------
+class Encryptor {
+public:
+    explicit Encryptor(HeContextPointer context) : context_(std::move(context)) {}
+    HeContextPointer context() const { return context_; }
+    void set_public_key(const PublicKey& public_key, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { public_key_ = public_key.clone(pool); }
+    void set_secret_key(const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { secret_key_ = secret_key.clone(pool); }
+    const PublicKey& public_key() const;
+    const SecretKey& secret_key() const;
+    void encrypt_asymmetric(const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encrypt_internal(plain, true, false, destination, pool); }
+    Ciphertext encrypt_asymmetric_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_asymmetric(plain, d, pool); return d; }
+    void encrypt_symmetric(const Plaintext& plain, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encrypt_internal(plain, false, save_seed, destination, pool); }
+    Ciphertext encrypt_symmetric_new(const Plaintext& plain, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_symmetric(plain, save_seed, d, pool); return d; }
+    void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_asymmetric(d, parms_id, pool); return d; }
+    void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext encrypt_zero_symmetric_new(bool save_seed, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_symmetric(save_seed, d, parms_id, pool); return d; }
+private:
+    void encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const;
+    void encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const;
+    HeContextPointer context_;
+    std::optional<PublicKey> public_key_;
+    std::optional<SecretKey> secret_key_;
+};
+
+class Decryptor {
+public:
+    Decryptor(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    HeContextPointer context() const { return context_; }
+    bool on_device() const { return secret_key_array_.on_device(); }
+    void decrypt(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext decrypt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; decrypt(encrypted, d, pool); return d; }
+private:
+    void dot_product_ct_sk_array(const Ciphertext& encrypted, uint64_t* destination, MemoryPoolHandle pool) const;
+    HeContextPointer context_;
+    mutable std::mutex secret_key_array_mutex_;
+    mutable utils::DynamicArray secret_key_array_;
+};
+
+// ----------------------------------------------------------------------------------------------
+// BatchEncoder  (src/batch_encoder.h, batch_encoder.cu)
+// ----------------------------------------------------------------------------------------------
+class BatchEncoder {
+public:
+    explicit BatchEncoder(HeContextPointer context);
+    HeContextPointer context() const { return context_; }
+    size_t slot_count() const { return slots_; }
+    bool on_device() const { return context_->on_device(); }
+    void encode(const std::vector<uint64_t>& values, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext encode_new(const std::vector<uint64_t>& values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode(values, p, pool); return p; }
+    void decode(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<uint64_t> decode_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<uint64_t> v; decode(plain, v, pool); return v; }
+private:
+    HeContextPointer context_;
+    size_t slots_ = 0;
+    std::vector<size_t> matrix_reps_index_map_;
 };
 
 // ----------------------------------------------------------------------------------------------
