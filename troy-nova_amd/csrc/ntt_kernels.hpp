@@ -107,13 +107,14 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
 }
 
 // raw input word -> the word the transform should see (still subject to A::load_first)
+template <int LM>
 __device__ __forceinline__ u64 ntt_io_load(const NttIo& io, u64 raw) {
-    if (io.load_mode == NTT_LOAD_KS_ROUND) {
+    if constexpr (LM == NTT_LOAD_KS_ROUND) {
         u64 t = barrett64(raw + io.aux_half, io.aux_q, io.aux_ratio_hi);
         if (io.aux_bigger) t = barrett64(t, io.q, io.ratio_hi);
         return t + io.fix;
     }
-    if (io.load_mode == NTT_LOAD_RESCALE) {
+    if constexpr (LM == NTT_LOAD_RESCALE) {
         u64 t = add_mod(raw, io.aux_half, io.aux_q);
         if (io.aux_bigger) t = barrett64(t, io.q, io.ratio_hi);   // q_i < q_last
         return sub_mod(t, io.fix, io.q);
@@ -122,14 +123,15 @@ __device__ __forceinline__ u64 ntt_io_load(const NttIo& io, u64 raw) {
 }
 
 // canonical transform output y at limb-local index idx -> stored word
+template <int SM>
 __device__ __forceinline__ u64 ntt_io_store(const NttIo& io, u64 y, unsigned idx) {
-    if (io.store_mode == NTT_STORE_KS_FINISH) {
+    if constexpr (SM == NTT_STORE_KS_FINISH) {
         u64 d = shoup_mul(io.ext0[idx] + io.lift - y, io.inv.x, io.inv.y, io.q);
         if (io.add_inplace) d = add_mod(io.dest[idx], d, io.q);
         if (io.ext1) d = add_mod(d, io.ext1[idx], io.q);
         return d;
     }
-    if (io.store_mode == NTT_STORE_RESCALE) {
+    if constexpr (SM == NTT_STORE_RESCALE) {
         u64 d = add_mod(io.ext0[idx], io.lift, io.q);    // add_uint64_mod(x, 4q): x + 3q
         d = sub_mod(d, y, io.q);
         return shoup_mul(d, io.inv.x, io.inv.y, io.q);
@@ -291,8 +293,10 @@ __host__ __device__ constexpr unsigned ntt_wave_bits(int S, int EB, int TB) {
 // digit j is reduced mod q_key(k) while loading, transformed, and multiplied into two register accumulators with
 // the matching limbs of key j (fgk/switch_key.cu:6-54 + :83-154 in one pass); the (L+1)*L transformed digits never
 // reach HBM.  Digit k of row k < L is the untouched NTT-form input limb (evaluator_keyswitching_core.cu:851-852).
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC>
-__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds) {
+// IOM selects the fused element-wise prologue / epilogue at compile time: 0 plain, 1 key-switch tail
+// (NTT_LOAD_KS_ROUND on the first pass, NTT_STORE_KS_FINISH on the last), 2 rescale.
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM>
+__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t) {
     constexpr int C = TB - G;
     constexpr int E = 1 << EB;
     constexpr unsigned N = 1u << LOGN;
@@ -304,8 +308,6 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     using elem = typename A::elem;
     using tw_t = typename A::tw_t;
 
-    unsigned t = threadIdx.x;
-    unsigned bid = blockIdx.x;
     unsigned tile, j, k, b;
     if constexpr (KSMAC) {
         // row-major over the launch: consecutive workgroups (dealt round-robin to the 8 XCDs) work on the same
@@ -337,9 +339,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     auto gindex = [&](unsigned loc) -> unsigned {
         return (top << (LOGN - LO)) | ((loc >> C) << (LOGN - LO - G)) | (lb << C) | (loc & ((1u << C) - 1));
     };
-    const bool fused_io = !KSMAC && ((FIRST && a.load_mode != NTT_LOAD_PLAIN) || (LAST && a.store_mode != NTT_STORE_PLAIN));
+    constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
+    constexpr int SM = (LAST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_STORE_KS_FINISH : IOM == 2 ? (int)NTT_STORE_RESCALE : (int)NTT_STORE_PLAIN) : (int)NTT_STORE_PLAIN;
     NttIo io;
-    if (fused_io) io = ntt_io_make(a, b, k, j, mi, gout);
+    if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
     else { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; }
 
     elem x[E];
@@ -410,8 +413,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
-                lds[lds_phys(wbase + idx)] = FIRST ? ntt_io_load(io, v.x) : v.x;
-                lds[lds_phys(wbase + idx + 1)] = FIRST ? ntt_io_load(io, v.y) : v.y;
+                lds[lds_phys(wbase + idx)] = ntt_io_load<LM>(io, v.x);
+                lds[lds_phys(wbase + idx + 1)] = ntt_io_load<LM>(io, v.y);
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, E>([&](auto Rc) {
@@ -429,7 +432,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
-                else if constexpr (FIRST) x[R] = A::load_first(ntt_io_load(io, raw), a.reduce_input != 0, md);
+                else if constexpr (FIRST) x[R] = A::load_first(ntt_io_load<LM>(io, raw), a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
         } else {
@@ -512,7 +515,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
-                if (io.store_mode != NTT_STORE_PLAIN) { v0 = ntt_io_store(io, v0, gbase + idx); v1 = ntt_io_store(io, v1, gbase + idx + 1); }
+                v0 = ntt_io_store<SM>(io, v0, gbase + idx); v1 = ntt_io_store<SM>(io, v1, gbase + idx + 1);
                 nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
@@ -522,7 +525,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned gi = gindex(locbase | ((unsigned)R << S));
                 if constexpr (LAST) {
                     v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
-                    if (io.store_mode != NTT_STORE_PLAIN) v = ntt_io_store(io, v, gi);
+                    v = ntt_io_store<SM>(io, v, gi);
                 } else v = A::store_mid(x[R], md);
                 nt_store(gout + gi, v);
             });
@@ -554,10 +557,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     }
 }
 
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     __shared__ u64 lds[(G + EB - 1) / EB > 1 ? ntt_lds_words(TB) : 1];
-    ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false>(a, nullptr, lds);
+    ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false, IOM>(a, nullptr, lds, blockIdx.x, threadIdx.x);
 }
 
 // Fused key-switch inner product: grid = (L+1) rows x batch items, one whole-limb workgroup each.
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
 template <class A, int LOGN, int EB>
 __global__ __launch_bounds__(1 << (LOGN - EB)) void ks_mac_kernel(NttArgs a, KeyPtrs keys) {
     __shared__ u64 lds[ntt_lds_words(LOGN)];
-    ntt_pass_body<A, LOGN, 0, LOGN, LOGN, EB, false, true, true, true>(a, &keys, lds);
+    ntt_pass_body<A, LOGN, 0, LOGN, LOGN, EB, false, true, true, true, 0>(a, &keys, lds, blockIdx.x, threadIdx.x);
 }
 
 // Generic fallback for any 2 <= N: one workgroup per limb-polynomial, radix-2 layer by layer.
