@@ -79,6 +79,9 @@ struct NttIo {
     // storer
     const u64* ext0; const u64* ext1; u64* dest;
     ulonglong2 inv; u64 lift; bool add_inplace;
+    // the same constants as doubles, for the FP64 policy (all moduli < 2^50, exact integers)
+    double aux_qd, aux_half_d, hm_d;     // other prime, floor(aux/2), (aux_half mod q)
+    double inv_d, inv_pd;                // (dropped prime)^-1 mod q and fl(inv/q)
 };
 
 __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi, u64* gout) {
@@ -87,18 +90,22 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
     const DevModulus md = a.mods[mi];
     io.q = md.q; io.ratio_hi = md.ratio_hi;
     io.aux_q = 0; io.aux_ratio_hi = 0; io.aux_half = 0; io.fix = 0; io.aux_bigger = false;
+    io.aux_qd = 0.0; io.aux_half_d = 0.0; io.hm_d = 0.0;
     if (a.load_mode != NTT_LOAD_PLAIN) {
         const DevModulus ax = a.mods[a.aux_mod];
         io.aux_q = ax.q; io.aux_ratio_hi = ax.ratio_hi; io.aux_half = ax.q >> 1;
         const u64 half_mod = barrett64(io.aux_half, md.q, md.ratio_hi);
         io.fix = (a.load_mode == NTT_LOAD_KS_ROUND) ? md.q - half_mod : half_mod;
         io.aux_bigger = ax.q > md.q;
+        io.aux_qd = ax.pd; io.aux_half_d = (double)io.aux_half; io.hm_d = (double)half_mod;
     }
     io.ext0 = nullptr; io.ext1 = nullptr; io.dest = gout; io.inv = make_ulonglong2(0, 0); io.lift = 0; io.add_inplace = false;
+    io.inv_d = 0.0; io.inv_pd = 0.0;
     if (a.store_mode != NTT_STORE_PLAIN) {
         io.ext0 = a.ext0 + (long long)b * a.ext0_bstride + (long long)k * a.ext0_pstride + (long long)j * a.ext0_cstride;
         if (a.ext1) io.ext1 = a.ext1 + (long long)b * a.ext1_bstride + (long long)k * a.ext1_pstride + (long long)j * a.ext1_cstride;
         io.inv = a.inv_table[j];
+        io.inv_d = (double)io.inv.x; io.inv_pd = io.inv_d * md.inv_pd;
         io.lift = (a.store_mode == NTT_STORE_RESCALE || (a.flags & 1u)) ? (md.q << 2) : (md.q << 1);
         const unsigned assign = (a.flags >> 1) & 3u;
         io.add_inplace = (a.store_mode == NTT_STORE_KS_FINISH) && (assign == 0u || (k == 0u && assign == 2u));
@@ -209,6 +216,14 @@ struct ArithU64 {
     static __device__ __forceinline__ u64 mac_final(elem acc, const Mod&) { return acc; }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem v, const Mod&) { return make_ulonglong2(v.x, v.y); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
+    // fused prologue / epilogue (NttLoad / NttStore): integer forms of the reference kernels
+    template <int LM> static __device__ __forceinline__ elem load_io(const NttIo& io, u64 raw, bool reduce, const Mod& m) {
+        return load_first(ntt_io_load<LM>(io, raw), reduce, m);
+    }
+    template <int SM> static __device__ __forceinline__ u64 store_prep(elem x, const Mod& m) { return final_fwd(x, m); }
+    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, unsigned idx, const Mod&) {
+        return ntt_io_store<SM>(io, word, idx);
+    }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod&) { return raw; }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return x; }
     static __device__ __forceinline__ elem from_lds(u64 raw) { return raw; }
@@ -251,6 +266,33 @@ struct ArithF64 {
     static __device__ __forceinline__ u64 mac_final(elem acc, const Mod& m) { return f64_canon(acc, m.m); }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem w, const Mod& m) { return make_double2(w, w * m.m.inv_p); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool, const Mod& m) { return f64_corr(f64_from_u64(raw), m.m); }
+    // fused prologue: T = (x + aux/2) mod aux, value = T - (aux/2 mod p)  (KS_ROUND adds p - (..), the same residue)
+    template <int LM> static __device__ __forceinline__ elem load_io(const NttIo& io, u64 raw, bool, const Mod& m) {
+        if constexpr (LM == NTT_LOAD_PLAIN) return f64_corr(f64_from_u64(raw), m.m);
+        else {
+            double t = f64_from_u64(raw) + io.aux_half_d;          // x < aux: t < 1.5 aux < 2^51, exact
+            t = (t >= io.aux_qd) ? t - io.aux_qd : t;
+            return f64_corr(t - io.hm_d, m.m);
+        }
+    }
+    // fused epilogue: the transform output stays a centred double through the wave transpose
+    template <int SM> static __device__ __forceinline__ u64 store_prep(elem x, const Mod& m) {
+        if constexpr (SM == NTT_STORE_PLAIN) return final_fwd(x, m);
+        else return f64_double_to_bits(f64_corr(x, m.m));
+    }
+    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, unsigned idx, const Mod& m) {
+        if constexpr (SM == NTT_STORE_PLAIN) return word;
+        else {
+            // (prod - y) * inv mod p  [+ dest] [+ addend]; |prod - y| <= 1.5p + 1, every term an exact integer
+            const double y = f64_bits_to_double(word);
+            double d = f64_mulc(f64_from_u64(io.ext0[idx]) - y, io.inv_d, io.inv_pd, m.m.p);
+            if constexpr (SM == NTT_STORE_KS_FINISH) {
+                if (io.add_inplace) d += f64_from_u64(io.dest[idx]);
+                if (io.ext1) d += f64_from_u64(io.ext1[idx]);
+            }
+            return f64_canon(d, m.m);
+        }
+    }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
     static __device__ __forceinline__ elem from_lds(u64 raw) { return f64_bits_to_double(raw); }
@@ -432,7 +474,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
-                else if constexpr (FIRST) x[R] = A::load_first(ntt_io_load<LM>(io, raw), a.reduce_input != 0, md);
+                else if constexpr (FIRST) x[R] = A::template load_io<LM>(io, raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
         } else {
@@ -507,7 +549,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[lds_phys(wbase + lane * E + R)] = A::final_fwd(x[R], md);
+                lds[lds_phys(wbase + lane * E + R)] = A::template store_prep<SM>(x[R], md);
             });
             __builtin_amdgcn_wave_barrier();
             const unsigned gbase = gindex(wbase);
@@ -515,7 +557,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
-                v0 = ntt_io_store<SM>(io, v0, gbase + idx); v1 = ntt_io_store<SM>(io, v1, gbase + idx + 1);
+                v0 = A::template store_io<SM>(io, v0, gbase + idx, md); v1 = A::template store_io<SM>(io, v1, gbase + idx + 1, md);
                 nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
@@ -524,8 +566,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 u64 v;
                 const unsigned gi = gindex(locbase | ((unsigned)R << S));
                 if constexpr (LAST) {
-                    v = INV ? A::final_inv(x[R], md) : A::final_fwd(x[R], md);
-                    v = ntt_io_store<SM>(io, v, gi);
+                    if constexpr (INV) v = A::final_inv(x[R], md);
+                    else v = A::template store_io<SM>(io, A::template store_prep<SM>(x[R], md), gi, md);
                 } else v = A::store_mid(x[R], md);
                 nt_store(gout + gi, v);
             });
