@@ -18,6 +18,9 @@ def _setup(O, pkg, dev, scheme, n, bits, t=0):
     ("ckks", True, 1024, [30, 30, 30, 30], 2),     # lower level: L < K-1
     ("ckks", True, 8192, [40, 40, 40, 40], 3),
     ("ckks", True, 16384, [50] * 6, 5),            # BASELINE config 3
+    ("ckks", True, 4096, [36] * 10, 9),            # fused inner product with > 8 digits (accumulator re-centring)
+    ("ckks", True, 2048, [55, 55, 56], 2),         # moduli >= 2^50: integer butterflies in the fused kernels
+    ("bfv", False, 2048, [54, 54, 55], 2),
     ("bfv", False, 32, [40, 40, 40], 2),
     ("bfv", False, 4096, [36, 36, 37], 2),
     ("bfv", False, 8192, [40, 40, 40], 2),         # BASELINE config 2 shape

@@ -213,6 +213,7 @@ struct ArithU64 {
     static __device__ __forceinline__ void mac(elem& acc, elem v, u64 key, const Mod& m) {
         acc = add_mod(acc, barrett128(v * key, mul_hi(v, key), m.q, m.ratio_lo, m.ratio_hi), m.q);
     }
+    static __device__ __forceinline__ void mac_fix(elem&, const Mod&) {}
     static __device__ __forceinline__ u64 mac_final(elem acc, const Mod&) { return acc; }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem v, const Mod&) { return make_ulonglong2(v.x, v.y); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
@@ -254,15 +255,20 @@ struct ArithF64 {
     static constexpr bool MID_FIX = true;   // inverse blocks of 4 layers re-centre their sums after 2
     struct Mod { F64Mod m; double ninv, ninv_p; };
     static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd}; }
-    // <digit, key> accumulation: |v| <= 0.5p+1, key in [0,p): the product term is |r| <= 0.69p (dev_math_f64.hpp),
-    // the accumulator is re-centred after every term, so everything stays far below 2^53 and exact.
+    // <digit, key> accumulation: |v| <= 0.5p+1, key in [0,p).  The quotient is estimated from the product itself
+    // (q = rint(fl(v*y) * fl(1/p)), off by < 0.2 from v*y/p), so each term is an exact integer of magnitude <= 0.69p;
+    // the accumulator is re-centred every 8 terms (mac_fix), i.e. it stays below 6.1p < 2^53.
     static __device__ __forceinline__ elem mac_zero() { return 0.0; }
     static __device__ __forceinline__ elem mac_in(u64 canonical, const Mod& m) { return f64_corr(f64_from_u64(canonical), m.m); }
     static __device__ __forceinline__ u64 mac_to_lds(elem x, const Mod& m) { return f64_double_to_bits(f64_corr(x, m.m)); }
     static __device__ __forceinline__ void mac(elem& acc, elem v, u64 key, const Mod& m) {
         const double y = f64_from_u64(key);
-        acc = f64_corr(acc + f64_mulc(v, y, y * m.m.inv_p, m.m.p), m.m);
+        const double h = v * y;
+        const double l = __builtin_fma(v, y, -h);
+        const double q = __builtin_rint(h * m.m.inv_p);
+        acc += __builtin_fma(-q, m.m.p, h) + l;
     }
+    static __device__ __forceinline__ void mac_fix(elem& acc, const Mod& m) { acc = f64_corr(acc, m.m); }
     static __device__ __forceinline__ u64 mac_final(elem acc, const Mod& m) { return f64_canon(acc, m.m); }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem w, const Mod& m) { return make_double2(w, w * m.m.inv_p); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool, const Mod& m) { return f64_corr(f64_from_u64(raw), m.m); }
@@ -586,7 +592,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         }
     });
     };   // one_digit
-    if constexpr (KSMAC) { for (unsigned it = 0; it < a.decomp; ++it) one_digit(it); }
+    if constexpr (KSMAC) {
+        for (unsigned it = 0; it < a.decomp; ++it) {
+            one_digit(it);
+            if ((it & 7u) == 7u) static_for<0, E>([&](auto Rc) { A::mac_fix(acc0[decltype(Rc)::value], md); A::mac_fix(acc1[decltype(Rc)::value], md); });
+        }
+    }
     else one_digit(0u);
     if constexpr (KSMAC) {
         const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
