@@ -158,6 +158,10 @@ __device__ __forceinline__ unsigned ntt_table_index(const NttArgs& a, unsigned k
 constexpr int NTT_PAD_SHIFT = 5;
 __host__ __device__ constexpr unsigned ntt_lds_words(int tb) { return (1u << tb) + ((1u << tb) >> NTT_PAD_SHIFT); }
 __device__ __forceinline__ unsigned lds_phys(unsigned loc) { return loc + (loc >> NTT_PAD_SHIFT); }
+// lds_phys(base | X) == lds_phys(base) + lds_off(X) whenever base has zeros in every bit position X can set (the
+// low-5-bit parts are then disjoint, so the padding term splits without a carry).  All LDS accesses of a round are
+// therefore one per-thread base plus compile-time offsets (immediate operands of ds_read / ds_write).
+__host__ __device__ constexpr unsigned lds_off(unsigned x) { return x + (x >> NTT_PAD_SHIFT); }
 
 // Streaming (non-temporal) accesses for the polynomial data: every word is touched once per kernel, while the
 // twiddle tables (same size as one limb, shared by every workgroup of that modulus) should stay in the XCD's L2.
@@ -438,6 +442,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         static_assert(S >= 0 && S + EB <= TB && BLO >= S && BHI < S + EB && BLO <= BHI, "bad round window");
         const unsigned tlow = t & ((1u << S) - 1);
         const unsigned locbase = tlow | ((t >> S) << (S + EB));
+        const unsigned pbase = lds_phys(locbase);
         // the twiddle index only sees bits above the butterfly bit; when S >= 6 those are wave-uniform
         const unsigned twbase = (S >= 6) ? ((unsigned)__builtin_amdgcn_readfirstlane((int)(t >> S)) << (S + EB)) : locbase;
 
@@ -456,18 +461,19 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // its 64*E consecutive words with 16 bytes per lane, parks them in its own LDS slice (the words it will
             // overwrite itself in the first exchange) and picks its coefficients from there.
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             const unsigned gbase = gindex(wbase);
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
-                lds[lds_phys(wbase + idx)] = ntt_io_load<LM>(io, v.x);
-                lds[lds_phys(wbase + idx + 1)] = ntt_io_load<LM>(io, v.y);
+                lds[pidx + lds_off(m * 128u)] = ntt_io_load<LM>(io, v.x);
+                lds[pidx + lds_off(m * 128u) + 1] = ntt_io_load<LM>(io, v.y);
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                const u64 raw = lds[lds_phys(wbase + lane * E + R)];
+                const u64 raw = lds[pown + R];
                 if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
@@ -487,7 +493,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
 #ifndef TROYN_ABLATE_NO_LDS
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                x[R] = A::from_lds(lds[lds_phys(locbase | ((unsigned)R << S))]);
+                x[R] = A::from_lds(lds[pbase + lds_off((unsigned)R << S)]);
             });
 #endif
         }
@@ -530,15 +536,16 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // transpose inside the wave's own LDS slice (see the store path below), then multiply-accumulate with
             // 16-byte coalesced key loads
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[lds_phys(wbase + lane * E + R)] = A::mac_to_lds(x[R], md);
+                lds[pown + R] = A::mac_to_lds(x[R], md);
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = wbase + m * 128u + lane * 2u;
-                const elem v0 = A::from_lds(lds[lds_phys(idx)]), v1 = A::from_lds(lds[lds_phys(idx + 1)]);
+                const elem v0 = A::from_lds(lds[pidx + lds_off(m * 128u)]), v1 = A::from_lds(lds[pidx + lds_off(m * 128u) + 1]);
                 const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(key0 + idx);
                 const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(key0 + a.key_pstride + idx);
                 A::mac(acc0[2 * m], v0, k0.x, md); A::mac(acc0[2 * m + 1], v1, k0.y, md);
@@ -553,16 +560,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // and store 16 bytes per lane to consecutive addresses: every store instruction writes 1 KiB of
             // consecutive bytes instead of touching 64 different 128-byte lines.
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
+            const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[lds_phys(wbase + lane * E + R)] = A::template store_prep<SM>(x[R], md);
+                lds[pown + R] = A::template store_prep<SM>(x[R], md);
             });
             __builtin_amdgcn_wave_barrier();
             const unsigned gbase = gindex(wbase);
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
-                u64 v0 = lds[lds_phys(wbase + idx)], v1 = lds[lds_phys(wbase + idx + 1)];
+                u64 v0 = lds[pidx + lds_off(m * 128u)], v1 = lds[pidx + lds_off(m * 128u) + 1];
                 v0 = A::template store_io<SM>(io, v0, gbase + idx, md); v1 = A::template store_io<SM>(io, v1, gbase + idx + 1, md);
                 nt_store2(gout + gbase + idx, v0, v1);
             });
@@ -583,7 +591,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // so no barrier is needed before the writes.
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[lds_phys(locbase | ((unsigned)R << S))] = A::to_lds(x[R], md);
+                lds[pbase + lds_off((unsigned)R << S)] = A::to_lds(x[R], md);
             });
             // RAW: readers are the writer's own wave (LDS executes a wave's accesses in order) or other waves
             if constexpr (PRIVATE_OUT) __builtin_amdgcn_wave_barrier();
