@@ -25,7 +25,9 @@ struct DevModulus {
     double inv_pd;    // fl(1 / q)
     double inv_n_d;   // (double) N^-1 mod q
     double inv_n_pd;  // fl(inv_n_d / q)
-    u64 pad_[3];
+    double inv_n_w_d;   // (N^-1 * w_last) mod q, w_last = the single twiddle of the final inverse layer
+    double inv_n_w_pd;  // fl(inv_n_w_d / q)
+    u64 pad_;
 };
 static_assert(sizeof(DevModulus) == 96, "DevModulus layout");
 

@@ -204,6 +204,7 @@ struct ArithU64 {
     using tw_mem = u64x2_mem;     // (operand, quotient) as stored in the table
 
     static constexpr bool MID_FIX = false;
+    static constexpr bool FOLD_NINV = false;
     struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo, ratio_lo; };
     static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo, d.ratio_lo}; }
     static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {
@@ -250,6 +251,7 @@ struct ArithU64 {
     static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) {
         return shoup_lazy(final_fwd(v, m), m.ninv_op, m.ninv_quo, m.q);   // the reference's lazy N^-1 multiply
     }
+    static __device__ __forceinline__ void inv_fold(elem&, elem&, const Mod&) {}   // FOLD_NINV is false: never used
 };
 
 struct ArithF64 {
@@ -257,8 +259,16 @@ struct ArithF64 {
     using tw_t = double2;
     using tw_mem = double;        // only w is stored (8 bytes per twiddle); w/p is rebuilt as w * fl(1/p)
     static constexpr bool MID_FIX = true;   // inverse blocks of 4 layers re-centre their sums after 2
-    struct Mod { F64Mod m; double ninv, ninv_p; };
-    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd}; }
+    // the final inverse layer multiplies its difference output by (w * N^-1) directly, so only the sum outputs
+    // still need the N^-1 multiply at the end (8 of 16 per thread)
+    static constexpr bool FOLD_NINV = true;
+    struct Mod { F64Mod m; double ninv, ninv_p, nw, nw_p; };
+    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{F64Mod{d.pd, d.inv_pd}, d.inv_n_d, d.inv_n_pd, d.inv_n_w_d, d.inv_n_w_pd}; }
+    static __device__ __forceinline__ void inv_fold(elem& a, elem& b, const Mod& m) {
+        const double u = a, v = b;
+        a = u + v;
+        b = f64_mulc(u - v, m.nw, m.nw_p, m.m.p);
+    }
     // <digit, key> accumulation: |v| <= 0.5p+1, key in [0,p).  The quotient is estimated from the product itself
     // (q = rint(fl(v*y) * fl(1/p)), off by < 0.2 from v*y/p), so each term is an exact integer of magnitude <= 0.69p;
     // the accumulator is re-centred every 8 terms (mac_fix), i.e. it stays below 6.1p < 2^53.
@@ -524,7 +534,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
 #else
                     if constexpr (!INV) A::fwd(x[R0], x[R1], w, md);
                     else {
-                        A::inv(x[R0], x[R1], w, md);
+                        if constexpr (A::FOLD_NINV && LAST && l == 0) { A::inv_fold(x[R0], x[R1], md); (void)w; }
+                        else A::inv(x[R0], x[R1], w, md);
                         if constexpr (A::MID_FIX && NLAYERS == 4 && li == 1) x[R0] = A::mid_fix(x[R0], md);
                     }
 #endif
@@ -580,7 +591,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 u64 v;
                 const unsigned gi = gindex(locbase | ((unsigned)R << S));
                 if constexpr (LAST) {
-                    if constexpr (INV) v = A::final_inv(x[R], md);
+                    if constexpr (INV && A::FOLD_NINV && ((R >> (EB - 1)) & 1)) v = A::final_fwd(x[R], md);   // already scaled
+                    else if constexpr (INV) v = A::final_inv(x[R], md);
                     else v = A::template store_io<SM>(io, A::template store_prep<SM>(x[R], md), gi, md);
                 } else v = A::store_mid(x[R], md);
                 nt_store(gout + gi, v);

@@ -119,6 +119,12 @@ static int plan_upload(troyn_plan* p) {
         mods[i] = make_dev_modulus(p->moduli[i], p->log_n, true);
         mods[i].inv_n_op = p->tables[i].inv_degree.operand;
         mods[i].inv_n_quo = p->tables[i].inv_degree.quotient;
+        if (p->moduli[i] < F64_MODULUS_LIMIT && n >= 2) {
+            // the final Gentleman-Sande layer has one twiddle (table index N-1); N^-1 is folded into it
+            const u64 nw = host::mulmod(p->tables[i].inv[n - 1].operand, p->tables[i].inv_degree.operand, p->moduli[i]);
+            mods[i].inv_n_w_d = (double)nw;
+            mods[i].inv_n_w_pd = (double)nw * (1.0 / (double)p->moduli[i]);
+        }
     }
     std::vector<ulonglong2> inv_last((K + 1) * K, make_ulonglong2(0, 0));
     for (size_t L = 2; L <= K; L++) {
