@@ -183,6 +183,26 @@ int troyn_sample_uniform(const troyn_plan* plan, uint32_t nmod, const uint64_t s
                          uint64_t* blocks_used, troyn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Ciphertext x plaintext (the BASELINE config 5 matmul path):
+ *   troyn_plain_centralize        scaling_variant::centralize (utils/scaling_variant.cu:326-357, fast-plain-lift case):
+ *                                 plain[batch][count] mod t -> dest[batch][L][N], ready for the forward NTT
+ *                                 (Evaluator::transform_plain_to_ntt, evaluator_transform_ntt.cu:35-70)
+ *   troyn_dyadic_broadcast_product fgk::dyadic_convolute::dyadic_broadcast_product_ps (fgk/dyadic_convolute.cu:173-195):
+ *                                 out[b][p][l] = ct[b][p][l] (.) pt[b][l]; pt_bstride = 0 shares one plaintext
+ *   troyn_multiply_plain_accumulate Evaluator::multiply_plain_ntt_accumulate (evaluator_multiply_plain.cu:258-307):
+ *                                 dst[k] (+)= ct[k] (.) pt[k] over `count` triples of device pointers (host arrays);
+ *                                 equal dst pointers accumulate; set_zero != 0 overwrites instead of adding to dst.
+ * ------------------------------------------------------------------------------------- */
+int troyn_plain_centralize(const troyn_plan* plan, uint32_t L, uint64_t plain_modulus, const uint64_t* plain, size_t plain_coeff_count,
+                           size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream);
+int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
+                                   const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream);
+size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count);
+int troyn_multiply_plain_accumulate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, size_t pcount,
+                                    const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,
+                                    int set_zero, void* workspace, size_t workspace_bytes, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * BEHZ BFV multiply: Evaluator::bfv_multiply (evaluator.cu:29-116) with the RNSTool of the level
  * holding the first L plan moduli and plain modulus t (RNSTool ctor utils/rns_tool.cu:29-275;
  * fused device kernels fgk/rns_tool.cu:7-100, :147-286).  a[batch][pa][L][N] x b[batch][pb][L][N]

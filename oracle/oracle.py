@@ -130,6 +130,9 @@ def lib():
     sig("orc_batch_encode", C.c_int, vp, p64, sz, p64)
     sig("orc_encrypt_asymmetric_bfv", None, vp, vp, p64, p64, sz, p64)
     sig("orc_fnv_words", u64, p64, sz)
+    sig("orc_plain_centralize", C.c_int, vp, sz, p64, sz, p64)
+    sig("orc_multiply_plain_normal", C.c_int, vp, sz, p64, sz, p64, sz, p64)
+    sig("orc_multiply_plain_ntt", None, vp, sz, p64, sz, p64, p64)
     sig("orc_keygen_relin_keys", None, vp, vp, p64, p64)
     sig("orc_rns_decrypt_scale_and_round", C.c_int, vp, p64, p64)
     sig("orc_decrypt_bfv", C.c_int, vp, p64, p64, sz, sz, p64)
@@ -471,6 +474,30 @@ class Context:
         if lib().orc_batch_decode(self.h, ptr(np.ascontiguousarray(plain, dtype=np.uint64)), ptr(out)) != 0:
             raise ValueError("batch_decode failed")
         return out
+
+    def plain_centralize(self, L, plain):
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros(L * self.n, dtype=np.uint64)
+        if lib().orc_plain_centralize(self.h, L, ptr(plain), plain.size, ptr(out)) != 0:
+            raise ValueError("no fast plain lift")
+        return out.reshape(L, self.n)
+
+    def multiply_plain_normal(self, L, ct, plain):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        p = ct.size // (L * self.n)
+        out = np.zeros(ct.size, dtype=np.uint64)
+        if lib().orc_multiply_plain_normal(self.h, L, ptr(ct.reshape(-1)), p, ptr(plain), plain.size, ptr(out)) != 0:
+            raise ValueError("multiply_plain failed")
+        return out.reshape(p, L, self.n)
+
+    def multiply_plain_ntt(self, L, ct, plain_ntt):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        plain_ntt = np.ascontiguousarray(plain_ntt, dtype=np.uint64)
+        p = ct.size // (L * self.n)
+        out = np.zeros(ct.size, dtype=np.uint64)
+        lib().orc_multiply_plain_ntt(self.h, L, ptr(ct.reshape(-1)), p, ptr(plain_ntt.reshape(-1)), ptr(out))
+        return out.reshape(p, L, self.n)
 
     def random_ct(self, seed, pcount, L):
         """uniform residues x[p][l][i] in [0, q_l) from the shared splitmix generator"""

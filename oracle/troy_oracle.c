@@ -1510,6 +1510,39 @@ void orc_encrypt_asymmetric_bfv(const orc_context* c, orc_rng* rng, const uint64
     free(u); free(temp);
 }
 
+int orc_plain_centralize(const orc_context* c, size_t L, const uint64_t* plain, size_t plain_coeff_count, uint64_t* dest) {
+    /* context_data.cu:215-258: using_fast_plain_lift iff t < every q_i; increment_i = q_i - t, threshold = (t+1)/2 */
+    const size_t n = c->n;
+    const uint64_t t = c->plain_modulus, threshold = (t + 1) >> 1;
+    for (size_t i = 0; i < L; i++) if (c->key_modulus[i].value <= t) return -1;
+    for (size_t i = 0; i < L; i++) {
+        const uint64_t inc = c->key_modulus[i].value - t;
+        for (size_t j = 0; j < n; j++)
+            dest[i * n + j] = (j < plain_coeff_count) ? ((plain[j] >= threshold) ? plain[j] + inc : plain[j]) : 0;
+    }
+    return 0;
+}
+
+void orc_multiply_plain_ntt(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain_ntt, uint64_t* out) {
+    /* dyadic_broadcast_product_ps, host branch (fgk/dyadic_convolute.cu:183-194) */
+    const size_t pc = L * c->n;
+    for (size_t p = 0; p < pcount; p++) orc_dyadic_product_ps(ct + p * pc, plain_ntt, 1, c->n, c->key_modulus, L, out + p * pc);
+}
+
+int orc_multiply_plain_normal(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out) {
+    const size_t n = c->n;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t* temp = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    if (orc_plain_centralize(c, L, plain, plain_coeff_count, temp) != 0) { free(temp); return -1; }
+    orc_ntt_forward(temp, 1, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+    memcpy(out, ct, pcount * L * n * sizeof(uint64_t));
+    orc_ntt_forward(out, pcount, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+    orc_multiply_plain_ntt(c, L, out, pcount, temp, out);
+    orc_ntt_inverse(out, pcount, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+    free(temp);
+    return 0;
+}
+
 uint64_t orc_fnv_words(const uint64_t* data, size_t n) {
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < n; i++) { h ^= data[i]; h *= 1099511628211ull; }

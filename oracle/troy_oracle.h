@@ -199,6 +199,15 @@ int orc_rns_decrypt_scale_and_round(const orc_rns_tool* r, const uint64_t* phase
 int orc_decrypt_bfv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t* plain);
 /* BatchEncoder::decode (batch_encoder.cu): plain [N] mod t -> values [N] */
 int orc_batch_decode(const orc_context* c, const uint64_t* plain, uint64_t* values);
+/* ---- ciphertext x plaintext (BASELINE config 5 path) ----
+ * scaling_variant::centralize, fast-plain-lift case (utils/scaling_variant.cu:258-275,:326-357): plain [count] mod t ->
+ * dest [L][N] (coefficient form); returns -1 when some q_i <= t (no fast plain lift). */
+int orc_plain_centralize(const orc_context* c, size_t L, const uint64_t* plain, size_t plain_coeff_count, uint64_t* dest);
+/* Evaluator::multiply_plain_normal (evaluator_multiply_plain.cu:13-68): ct [pcount][L][N] coefficient form x plain (mod t,
+ * parms_id_zero) -> out [pcount][L][N] coefficient form */
+int orc_multiply_plain_normal(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out);
+/* Evaluator::multiply_plain_ntt (:196-218): NTT-form ct x NTT-form RNS plaintext [L][N] */
+void orc_multiply_plain_ntt(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain_ntt, uint64_t* out);
 /* the survey's digest: h = FNV offset; for each 64-bit WORD: h ^= word; h *= FNV prime */
 uint64_t orc_fnv_words(const uint64_t* data, size_t n);
 

@@ -1,0 +1,72 @@
+"""GPU parity of the ciphertext x plaintext path (BASELINE config 5): centralize,
+transform_plain_to_ntt, multiply_plain (both forms) and the batched multiply-accumulate of the matmul application."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,bits,t", [(8192, [60, 40, 40, 60], 1 << 21),     # examples/10_bfv_matmul.cu parameters
+                                      (8192, [40, 40, 40], 1032193), (64, [40, 40, 40], 769)])
+def test_centralize_and_multiply_plain(O, pkg, dev, n, bits, t):
+    q = [int(v) for v in O.coeff_modulus_create(n, bits)]
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    L = len(q) - 1
+    m = O.fill_uniform(77, t, 3 * n).reshape(3, n)
+    m[0, :4] = [0, 1, t - 1, (t + 1) // 2]
+    cen = plan.plain_centralize(L, t, pkg.to_device(m, dev))
+    cen_h = pkg.to_host(cen)
+    for i in range(3):
+        assert np.array_equal(cen_h[i], ctx.plain_centralize(L, m[i]))
+    # multiply_plain_normal: centralize -> NTT(plain), NTT(ct), broadcast product, INTT
+    ct = np.stack([ctx.random_ct(5 + i, 2, L) for i in range(3)])
+    pt_ntt = plan.ntt(cen, 1, L)
+    dct = plan.ntt(pkg.to_device(ct, dev), 2, L)
+    prod = plan.ntt(plan.dyadic_broadcast_product(dct, 2, pt_ntt, L), 2, L, inverse=True)
+    got = pkg.to_host(prod)
+    for i in range(3):
+        assert np.array_equal(got[i], ctx.multiply_plain_normal(L, ct[i], m[i])), i
+    # shared plaintext (pt_bstride = 0) and NTT-form product against the oracle's multiply_plain_ntt
+    shared = plan.dyadic_broadcast_product(dct, 2, pt_ntt[0].contiguous(), L, shared_plain=True)
+    dct_h, ptn_h = pkg.to_host(dct), pkg.to_host(pt_ntt)
+    for i in range(3):
+        assert np.array_equal(pkg.to_host(shared)[i], ctx.multiply_plain_ntt(L, dct_h[i], ptn_h[0]))
+
+
+@pytest.mark.parametrize("n,bits,B,I,J", [(4096, [36, 36, 37], 2, 5, 3), (8192, [60, 40, 40, 60], 1, 40, 2), (32, [40, 40, 40], 3, 2, 2)])
+def test_multiply_plain_accumulate_matmul_pattern(O, pkg, dev, n, bits, B, I, J):
+    """ret[b][j] = sum_i a[b][i] (.) w[i][j]  (MatmulHelper::matmul, app/matmul.cu:352-370) in ONE launch"""
+    q = [int(v) for v in O.coeff_modulus_create(n, bits)]
+    ctx = O.Context("bfv", n, q, 1 << 16)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    L = len(q) - 1
+    a = np.stack([np.stack([ctx.random_ct(100 + b * 31 + i, 2, L) for i in range(I)]) for b in range(B)])        # [B][I][2][L][N]
+    w = np.stack([np.stack([ctx.random_ct(900 + i * 17 + j, 1, L)[0] for j in range(J)]) for i in range(I)])     # [I][J][L][N]
+    da, dw = pkg.to_device(a, dev), pkg.to_device(w, dev)
+    out = torch.empty((B, J, 2, L, n), dtype=torch.int64, device=dev)
+    cts, pts, dsts = [], [], []
+    for i in range(I):
+        for j in range(J):
+            for b in range(B):
+                cts.append(da[b, i]); pts.append(dw[i, j]); dsts.append(out[b, j])
+    plan.multiply_plain_accumulate(cts, pts, dsts, 2, L, set_zero=True)
+    got = pkg.to_host(out)
+    qv = [int(x) for x in q[:L]]
+    for b in range(B):
+        for j in range(J):
+            acc = np.zeros((2, L, n), dtype=np.uint64)
+            for i in range(I):
+                term = ctx.multiply_plain_ntt(L, a[b, i], w[i, j])
+                for l in range(L):
+                    acc[:, l] = (acc[:, l] + term[:, l]) % np.uint64(qv[l])
+            assert np.array_equal(got[b, j], acc), (b, j)
+    # accumulate on top of existing destinations (set_zero = False)
+    plan.multiply_plain_accumulate(cts[:B * J], pts[:B * J], dsts[:B * J], 2, L, set_zero=False)
+    got2 = pkg.to_host(out)
+    for b in range(B):
+        for j in range(J):
+            term = ctx.multiply_plain_ntt(L, a[b, 0], w[0, j])
+            exp = np.stack([(got[b, j][:, l] + term[:, l]) % np.uint64(qv[l]) for l in range(L)], axis=1)
+            assert np.array_equal(got2[b, j], exp), (b, j)

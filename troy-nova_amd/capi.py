@@ -48,6 +48,10 @@ SYMBOLS = {
     "troyn_behz_destroy": (C.c_int, [vp]),
     "troyn_behz_base_Bsk_size": (u32, [vp]),
     "troyn_behz_get_base_Bsk": (C.c_int, [vp, p64]),
+    "troyn_plain_centralize": (C.c_int, [vp, u32, u64, vp, sz, sz, vp, sz, vp]),
+    "troyn_dyadic_broadcast_product": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp, sz, vp]),
+    "troyn_multiply_plain_accumulate_workspace_bytes": (sz, [sz]),
+    "troyn_multiply_plain_accumulate": (C.c_int, [vp, u32, u32, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.c_int, vp, sz, vp]),
     "troyn_behz_gamma": (u64, [vp]),
     "troyn_bfv_scale_up": (C.c_int, [vp, vp, sz, sz, vp, sz, vp, sz, C.c_int, sz, vp]),
     "troyn_bfv_decrypt_scale_and_round": (C.c_int, [vp, vp, vp, sz, vp]),

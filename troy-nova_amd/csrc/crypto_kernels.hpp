@@ -155,4 +155,79 @@ __global__ __launch_bounds__(256) void bfv_decrypt_round_kernel(unsigned chunks,
     }
 }
 
+// ---- ciphertext x plaintext -------------------------------------------------------------
+
+// scaling_variant::centralize, fast-plain-lift case (utils/scaling_variant.cu:226-275): plain [items][count] mod t ->
+// dest [items][L][n]: m >= (t+1)/2 ? m + (q_l - t) : m, zero beyond plain_coeff_count
+__global__ __launch_bounds__(POLY_BLOCK) void plain_centralize_kernel(unsigned chunks, const DevModulus* mods, unsigned L, unsigned n, u64 t,
+                                                                      const u64* plain, unsigned plain_coeff_count, long long plain_bstride, u64* dest) {
+    const unsigned l = blk_row(chunks) % L;
+    const size_t item = blk_row(chunks) / L;
+    const u64 inc = mods[l].q - t, threshold = (t + 1) >> 1;
+    const u64* pl = plain + item * plain_bstride;
+    u64* de = dest + (item * L + l) * (size_t)n;
+    for (unsigned i = blk_col(chunks); i < n; i += chunks * blockDim.x) {
+        u64 v = 0;
+        if (i < plain_coeff_count) { const u64 m = pl[i]; v = (m >= threshold) ? m + inc : m; }
+        de[i] = v;
+    }
+}
+
+// fgk/dyadic_convolute.cu:152-195 kernel_dyadic_broadcast_product_ps: out[item][p][l] = ct[item][p][l] (.) pt[item][l]
+__global__ __launch_bounds__(POLY_BLOCK) void dyadic_broadcast_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
+                                                                      unsigned pcount, const u64* ct, const u64* pt, long long pt_bstride, u64* out) {
+    const unsigned l = blk_row(chunks) % nmod;
+    const size_t item = blk_row(chunks) / nmod;
+    const DevModulus md = mods[mod_start + l];
+    const size_t pc = (size_t)nmod * n;
+    const u64* cp = ct + item * pcount * pc + (size_t)l * n;
+    const u64* pp = pt + item * pt_bstride + (size_t)l * n;
+    u64* op = out + item * pcount * pc + (size_t)l * n;
+    for (unsigned i = blk_col(chunks) * 2; i < n; i += chunks * blockDim.x * 2) {
+        const u64x2 w = ld2(pp + i);
+        for (unsigned p = 0; p < pcount; ++p) {
+            const u64x2 c = ld2(cp + p * pc + i);
+            st2(op + p * pc + i, mul_mod(c.a, w.a, md), mul_mod(c.b, w.b, md));
+        }
+    }
+}
+
+// Evaluator::multiply_plain_ntt_accumulate (evaluator_multiply_plain.cu:258-307; the reference kernel
+// kernel_dyadic_broadcast_product_accumulate_bps makes every thread walk the whole batch).  Here the (ct, pt, dst)
+// triples are grouped by destination on the host; one thread owns two coefficients of one (destination, poly, limb)
+// and walks that destination's terms with a 128-bit lazy sum, so every destination word is written exactly once
+// and every ct / pt word of the group is read exactly once.
+//   tab: [ct_ptr x count][pt_ptr x count][dst_ptr x groups][start x (groups+1)]
+__global__ __launch_bounds__(POLY_BLOCK) void plain_mac_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
+                                                               unsigned pcount, const u64* tab, unsigned count, unsigned groups, int set_zero) {
+    const unsigned row = blk_row(chunks);
+    const unsigned l = row % nmod;
+    const unsigned p = (row / nmod) % pcount;
+    const unsigned g = row / (nmod * pcount);
+    const DevModulus md = mods[mod_start + l];
+    const u64* const* cts = reinterpret_cast<const u64* const*>(tab);
+    const u64* const* pts = reinterpret_cast<const u64* const*>(tab + count);
+    u64* dst = reinterpret_cast<u64* const*>(tab + 2 * (size_t)count)[g];
+    const u64* starts = tab + 2 * (size_t)count + groups;
+    const unsigned k0 = (unsigned)starts[g], k1 = (unsigned)starts[g + 1];
+    const size_t coff = ((size_t)p * nmod + l) * n, poff = (size_t)l * n;
+    for (unsigned i = blk_col(chunks) * 2; i < n; i += chunks * blockDim.x * 2) {
+        u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, r0 = 0, r1 = 0;
+        unsigned pending = 0;
+        for (unsigned k = k0; k < k1; ++k) {
+            const u64x2 c = ld2(cts[k] + coff + i), w = ld2(pts[k] + poff + i);
+            mac128(lo0, hi0, c.a, w.a); mac128(lo1, hi1, c.b, w.b);
+            if (++pending == 32) {      // 32 products of 61-bit residues stay below 2^128
+                r0 = add_mod(r0, barrett128(lo0, hi0, md.q, md.ratio_lo, md.ratio_hi), md.q);
+                r1 = add_mod(r1, barrett128(lo1, hi1, md.q, md.ratio_lo, md.ratio_hi), md.q);
+                lo0 = hi0 = lo1 = hi1 = 0; pending = 0;
+            }
+        }
+        r0 = add_mod(r0, barrett128(lo0, hi0, md.q, md.ratio_lo, md.ratio_hi), md.q);
+        r1 = add_mod(r1, barrett128(lo1, hi1, md.q, md.ratio_lo, md.ratio_hi), md.q);
+        if (!set_zero) { const u64x2 d = ld2(dst + coff + i); r0 = add_mod(r0, d.a, md.q); r1 = add_mod(r1, d.b, md.q); }
+        st2(dst + coff + i, r0, r1);
+    }
+}
+
 }  // namespace troyn

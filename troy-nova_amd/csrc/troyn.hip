@@ -2,6 +2,7 @@
 // declared in include/troyn.h.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1074,3 +1075,79 @@ extern "C" int troyn_bfv_decrypt_scale_and_round(const troyn_behz* b, const uint
 }
 
 extern "C" uint64_t troyn_behz_gamma(const troyn_behz* b) { return b ? b->gamma : 0; }
+
+// ---------------------------------------------------------------------------------------
+// ciphertext x plaintext
+// ---------------------------------------------------------------------------------------
+extern "C" int troyn_plain_centralize(const troyn_plan* p, uint32_t L, uint64_t t, const uint64_t* plain, size_t plain_coeff_count,
+                                      size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    if (!p || !plain || !dest) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] null argument");
+    if (L < 1 || L > p->K) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] Destination has incorrect size.");
+    if (plain_coeff_count > p->n) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] destination_coeff_count should no less than plain_coeff_count.");
+    for (unsigned i = 0; i < L; i++)
+        if (p->moduli[i] <= t) return fail(TROYN_E_MODULUS, "[scaling_variant::centralize] plain modulus is not below every coefficient modulus (no fast plain lift).");
+    if (batch == 0) return TROYN_OK;
+    const unsigned ch = chunks_single(p->n);
+    const size_t rows = batch * L;
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(plain_centralize_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, (unsigned)L, p->n, (u64)t, (const u64*)plain, (unsigned)plain_coeff_count, (long long)plain_bstride, (u64*)dest);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_dyadic_broadcast_product(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
+                                              const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream) {
+    if (!p || !ct || !pt || !out) return fail(TROYN_E_INVALID, "[dyadic_product_ps] null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[dyadic_product_ps] modulus slice out of range");
+    if (batch == 0 || pcount == 0) return TROYN_OK;
+    const unsigned ch = chunks_pairs(p->n);
+    const size_t rows = batch * nmod;
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(dyadic_broadcast_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->n, (unsigned)pcount, (const u64*)ct, (const u64*)pt, (long long)pt_bstride, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count) { return (4 * count + 2) * sizeof(u64); }
+
+extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, size_t pcount,
+                                               const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,
+                                               int set_zero, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    const char* P = "[Evaluator::multiply_plain_ntt_batched]";
+    if (!p || !ct || !pt || !dst || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
+    if (count == 0 || pcount == 0) return TROYN_OK;
+    if (workspace_bytes < troyn_multiply_plain_accumulate_workspace_bytes(count)) return fail(TROYN_E_WORKSPACE, "[troyn_multiply_plain_accumulate] workspace too small");
+    if (count > 0x7fffffffull) return fail(TROYN_E_INVALID, std::string(P) + " too many terms");
+    // group the terms by destination (stable), so that each destination is produced by one pass over its terms
+    std::vector<size_t> order(count);
+    for (size_t i = 0; i < count; i++) {
+        if (!ct[i] || !pt[i] || !dst[i]) return fail(TROYN_E_INVALID, std::string(P) + " null pointer in the batch");
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return (uintptr_t)dst[a] < (uintptr_t)dst[b]; });
+    std::vector<u64> tab(2 * count);
+    std::vector<u64> gdst, gstart;
+    for (size_t i = 0; i < count; i++) {
+        const size_t k = order[i];
+        tab[i] = (u64)(uintptr_t)ct[k];
+        tab[count + i] = (u64)(uintptr_t)pt[k];
+        if (i == 0 || dst[k] != dst[order[i - 1]]) { gdst.push_back((u64)(uintptr_t)dst[k]); gstart.push_back((u64)i); }
+    }
+    gstart.push_back((u64)count);
+    const size_t groups = gdst.size();
+    tab.insert(tab.end(), gdst.begin(), gdst.end());
+    tab.insert(tab.end(), gstart.begin(), gstart.end());
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // `tab` is a host temporary
+    const unsigned ch = chunks_pairs(p->n);
+    const size_t rows = groups * pcount * nmod;
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(plain_mac_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                       ch, p->d_mods, mod_start, nmod, p->n, (unsigned)pcount, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}

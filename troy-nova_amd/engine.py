@@ -141,6 +141,35 @@ class Plan:
         capi.check(self.lib.troyn_dyadic_square(self.h, mod_start, nmod, _ptr(a), _ptr(out), batch, _stream()))
         return out
 
+    # -- ciphertext x plaintext ------------------------------------------------------------------
+    def plain_centralize(self, L, t, plain, out=None):
+        """plain [batch][N] mod t -> [batch][L][N] (scaling_variant::centralize)"""
+        batch = plain.numel() // self.n
+        if out is None:
+            out = torch.empty((batch, L, self.n), dtype=torch.int64, device=plain.device)
+        capi.check(self.lib.troyn_plain_centralize(self.h, L, int(t), _ptr(plain), self.n, self.n, _ptr(out), batch, _stream()))
+        return out
+
+    def dyadic_broadcast_product(self, ct, pcount, pt, nmod, shared_plain=False, mod_start=0, out=None):
+        """ct [batch][pcount][nmod][N] (.) pt [batch][nmod][N] (or one shared [nmod][N])"""
+        batch = ct.numel() // (pcount * nmod * self.n)
+        out = torch.empty_like(ct) if out is None else out
+        capi.check(self.lib.troyn_dyadic_broadcast_product(self.h, mod_start, nmod, _ptr(ct), pcount, _ptr(pt),
+                                                           0 if shared_plain else nmod * self.n, _ptr(out), batch, _stream()))
+        return out
+
+    def multiply_plain_accumulate(self, cts, pts, dsts, pcount, nmod, set_zero=True, mod_start=0):
+        """dsts[k] (+)= cts[k] (.) pts[k]; equal destination tensors accumulate (multiply_plain_ntt_accumulate)"""
+        count = len(cts)
+        arr = lambda ts: (C.c_void_p * count)(*[t.data_ptr() for t in ts])
+        for t in list(cts) + list(pts) + list(dsts):
+            _ptr(t)
+        nbytes = self.lib.troyn_multiply_plain_accumulate_workspace_bytes(count)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+        capi.check(self.lib.troyn_multiply_plain_accumulate(self.h, mod_start, nmod, pcount, arr(cts), arr(pts), arr(dsts), count,
+                                                            int(set_zero), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+        return dsts
+
     # -- key switching -----------------------------------------------------------------------------
     def _key_ptrs(self, keys, L):
         if len(keys) < L:
