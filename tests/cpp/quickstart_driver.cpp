@@ -69,6 +69,17 @@ int main(int argc, char** argv) {
         Ciphertext diff = evaluator.sub_new(d, c);
         print_slots("sub", encoder.decode_new(decryptor.decrypt_new(diff)));
 
+        // ciphertext x plaintext: multiply_plain (coefficient-form ciphertext, plaintext at parms_id_zero) and the
+        // matmul-style accumulate out = c (.) w0 + d (.) w1 in NTT form
+        Plaintext w0 = encoder.encode_new({3, 5, 7, 11}), w1 = encoder.encode_new({2, 2, 2, 2});
+        print_slots("mulplain", encoder.decode_new(decryptor.decrypt_new(evaluator.multiply_plain_new(c, w0))));
+        Ciphertext cn = evaluator.transform_to_ntt_new(c), dn = evaluator.transform_to_ntt_new(d);
+        Plaintext w0n = evaluator.transform_plain_to_ntt_new(w0, c.parms_id()), w1n = evaluator.transform_plain_to_ntt_new(w1, c.parms_id());
+        Ciphertext acc;
+        evaluator.multiply_plain_accumulate({&cn, &dn}, {&w0n, &w1n}, {&acc, &acc}, true);
+        evaluator.transform_from_ntt_inplace(acc);
+        print_slots("macc", encoder.decode_new(decryptor.decrypt_new(acc)));
+
         // misuse: host-resident plaintext / ciphertext
         bool threw = false;
         try { Plaintext p = encoder.encode_new({1}); p.to_host_inplace(); encryptor.encrypt_asymmetric_new(p); } catch (const std::invalid_argument&) { threw = true; }

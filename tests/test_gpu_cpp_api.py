@@ -86,6 +86,8 @@ def test_quickstart_cpp_api(dev):
     assert kv["relin_polys"] == ["2"] and kv["low_limbs"] == ["1"]
     assert kv["mul2"] == ["5", "12", "21", "32", "0", "0"]
     assert kv["sub"] == ["4", "4", "4", "4", "0", "0"]
+    assert kv["mulplain"] == ["3", "10", "21", "44", "0", "0"]
+    assert kv["macc"] == ["13", "22", "35", "60", "0", "0"]       # {1,2,3,4}*{3,5,7,11} + {5,6,7,8}*2
     assert kv["host_plain_rejected"] == ["1"]
     # a different seed gives a different ciphertext but the same plaintext results
     r2 = subprocess.run([drv, "0x456"], capture_output=True, text=True, timeout=600)

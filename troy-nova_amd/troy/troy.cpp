@@ -911,6 +911,108 @@ void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Evaluator: ciphertext x plaintext  (evaluator_multiply_plain.cu, evaluator_transform_ntt.cu:35-70)
+// ------------------------------------------------------------------------------------------------
+void Evaluator::transform_plain_to_ntt(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::transform_plain_to_ntt]";
+    if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is already in NTT form.");
+    if (!context_->on_device() || !plain.on_device()) throw std::invalid_argument(std::string(P) + " Operand is on host; the evaluator runs on the GPU only.");
+    auto cd = get_context_data("[Evaluator::transform_plain_to_ntt_inplace]", parms_id);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t n = cd->parms().poly_modulus_degree();
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, parms_id);
+    out.scale() = plain.scale();
+    hipStream_t s = current_stream();
+    if (plain.parms_id() == parms_id_zero) {
+        troyn_check(troyn_plain_centralize(context_->plan(), L, cd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n,
+                                           out.poly(), 1, s));
+        troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    } else {
+        if (plain.parms_id() != parms_id) throw std::invalid_argument(std::string(P) + " Plaintext parameters do not match.");
+        if (plain.coeff_count() != n) throw std::logic_error("[Evaluator::transform_plain_to_ntt] partial RNS plaintexts are not part of this build.");
+        troyn_check(troyn_ntt(context_->plan(), 0, plain.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    }
+    out.is_ntt_form() = true;
+    destination = std::move(out);
+}
+
+void Evaluator::multiply_plain(const Ciphertext& encrypted, const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_multiply_plain.cu:309-326 dispatch; :13-68 (normal), :196-218 (ntt)
+    const char* P = "[Evaluator::multiply_plain]";
+    check_no_seed(P, encrypted);
+    check_on_device(P, context_, encrypted);
+    auto cd = get_context_data(P, encrypted.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t pc = encrypted.polynomial_count();
+    hipStream_t s = current_stream();
+    Plaintext plain_ntt_storage;
+    const Plaintext* pn = &plain;
+    if (!plain.is_ntt_form()) {
+        transform_plain_to_ntt(plain, encrypted.parms_id(), plain_ntt_storage, pool);
+        pn = &plain_ntt_storage;
+    } else if (plain.parms_id() != encrypted.parms_id()) {
+        throw std::invalid_argument("[Evaluator::multiply_plain_ntt] Plaintext and ciphertext parameters do not match.");
+    }
+    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    const uint64_t* src = encrypted.data().raw_pointer();
+    if (!encrypted.is_ntt_form()) {
+        troyn_check(troyn_ntt(context_->plan(), 0, src, out.data().raw_pointer(), 1, pc, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        src = out.data().raw_pointer();
+    }
+    troyn_check(troyn_dyadic_broadcast_product(context_->plan(), 0, L, src, pc, pn->poly(), 0, out.data().raw_pointer(), 1, s));
+    if (!encrypted.is_ntt_form())
+        troyn_check(troyn_ntt(context_->plan(), 1, out.data().raw_pointer(), out.data().raw_pointer(), 1, pc, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    if (cd->parms().scheme() == SchemeType::CKKS) out.scale() = encrypted.scale() * plain.scale();
+    hip_check(hipStreamSynchronize(s), "stream_sync");   // the temporary NTT plaintext returns to the pool
+    destination = std::move(out);
+}
+
+void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
+                                          const std::vector<Ciphertext*>& destination, bool set_zero, MemoryPoolHandle pool) const {
+    // evaluator_multiply_plain.cu:258-307 (multiply_plain_ntt_accumulate): all operands in NTT form, same parms_id
+    const char* P = "[Evaluator::multiply_plain_ntt_batched]";
+    if (encrypted.size() != plain.size() || encrypted.size() != destination.size()) throw std::invalid_argument(std::string(P) + " Input vectors have different sizes.");
+    if (encrypted.empty()) return;
+    const ParmsID pid = encrypted[0]->parms_id();
+    const size_t pc = encrypted[0]->polynomial_count();
+    auto cd = get_context_data("[Evaluator::multiply_plain_ntt]", pid);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    for (size_t i = 0; i < encrypted.size(); i++) {
+        check_no_seed(P, *encrypted[i]);
+        check_on_device(P, context_, *encrypted[i]);
+        if (encrypted[i]->parms_id() != pid || encrypted[i]->polynomial_count() != pc || !encrypted[i]->is_ntt_form())
+            throw std::invalid_argument(std::string(P) + " Ciphertexts must share parms_id, size and NTT form.");
+        if (!plain[i]->is_ntt_form() || plain[i]->parms_id() != pid || !plain[i]->on_device())
+            throw std::invalid_argument("[Evaluator::multiply_plain_ntt] Plaintext and ciphertext parameters do not match.");
+    }
+    if (set_zero) {
+        for (size_t i = 0; i < destination.size(); i++) {
+            bool seen = false;
+            for (size_t k = 0; k < i && !seen; k++) seen = destination[k] == destination[i];
+            if (!seen) *destination[i] = Ciphertext::like(*encrypted[i], false, pool);
+        }
+    } else {
+        for (size_t i = 0; i < destination.size(); i++)
+            if (destination[i]->parms_id() != pid || !destination[i]->is_ntt_form() || destination[i]->polynomial_count() != pc)
+                throw std::invalid_argument("[Evaluator::multiply_plain_normal_accumulate] Destination parameters do not match.");
+    }
+    std::vector<const uint64_t*> cts(encrypted.size()), pts(encrypted.size());
+    std::vector<uint64_t*> dsts(encrypted.size());
+    for (size_t i = 0; i < encrypted.size(); i++) {
+        cts[i] = encrypted[i]->data().raw_pointer(); pts[i] = plain[i]->poly(); dsts[i] = destination[i]->data().raw_pointer();
+    }
+    const size_t wsb = troyn_multiply_plain_accumulate_workspace_bytes(cts.size());
+    utils::DynamicArray ws((wsb + 7) / 8, true, pool);
+    troyn_check(troyn_multiply_plain_accumulate(context_->plan(), 0, L, pc, cts.data(), pts.data(), dsts.data(), cts.size(), set_zero ? 1 : 0,
+                                                ws.raw_pointer(), wsb, current_stream()));
+    if (cd->parms().scheme() == SchemeType::CKKS)
+        for (size_t i = 0; i < encrypted.size(); i++) destination[i]->scale() = encrypted[i]->scale() * plain[i]->scale();
+    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+}
+
+// ------------------------------------------------------------------------------------------------
 // utils::RandomGenerator  (utils/random_generator.cu)
 // ------------------------------------------------------------------------------------------------
 namespace utils {

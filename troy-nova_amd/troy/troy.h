@@ -557,6 +557,18 @@ public:
     void multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d,
                           MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition (see header comment)
 
+    // ciphertext x plaintext -- evaluator.h (multiply_plain*, transform_plain_to_ntt*); evaluator_multiply_plain.cu,
+    // evaluator_transform_ntt.cu:35-70
+    void transform_plain_to_ntt(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext transform_plain_to_ntt_new(const Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; transform_plain_to_ntt(plain, parms_id, d, pool); return d; }
+    void transform_plain_to_ntt_inplace(Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; transform_plain_to_ntt(plain, parms_id, d, pool); plain = std::move(d); }
+    void multiply_plain(const Ciphertext& encrypted, const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void multiply_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; multiply_plain(encrypted, plain, d, pool); encrypted = std::move(d); }
+    Ciphertext multiply_plain_new(const Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; multiply_plain(encrypted, plain, d, pool); return d; }
+    // destination[i] (+)= encrypted[i] * plain[i]; equal destination pointers accumulate (MatmulHelper::matmul's call)
+    void multiply_plain_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
+                                   const std::vector<Ciphertext*>& destination, bool set_zero, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
     // key switching -- evaluator.h:267-303 (evaluator_keyswitching.cu)
     void apply_keyswitching_inplace(Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void apply_keyswitching(const Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
