@@ -197,6 +197,12 @@ int troyn_plain_centralize(const troyn_plan* plan, uint32_t L, uint64_t plain_mo
                            size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream);
 int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
                                    const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream);
+/* Galois automorphism X -> X^g of `count` polynomials of nmod limbs each:
+ * GaloisTool::apply_ps (coefficient form, utils/galois.cu:168-206) / apply_ntt_ps (NTT form, :24-41,:250-343).
+ * Out of place (in != out).  Evaluator::apply_galois = this permutation of (c0, c1) followed by troyn_switch_key on
+ * the permuted c1 with TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST (evaluator_keyswitching.cu:147-179). */
+int troyn_apply_galois(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
+                       const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream);
 size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count);
 int troyn_multiply_plain_accumulate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, size_t pcount,
                                     const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,

@@ -130,6 +130,10 @@ def lib():
     sig("orc_batch_encode", C.c_int, vp, p64, sz, p64)
     sig("orc_encrypt_asymmetric_bfv", None, vp, vp, p64, p64, sz, p64)
     sig("orc_fnv_words", u64, p64, sz)
+    sig("orc_apply_galois", None, vp, sz, C.c_int, sz, p64, sz, p64)
+    sig("orc_apply_galois_ct", None, vp, sz, C.c_int, sz, p64, C.POINTER(p64), p64)
+    sig("orc_keygen_galois_key", None, vp, vp, p64, sz, p64)
+    sig("orc_galois_element_from_step", sz, sz, C.c_int)
     sig("orc_plain_centralize", C.c_int, vp, sz, p64, sz, p64)
     sig("orc_multiply_plain_normal", C.c_int, vp, sz, p64, sz, p64, sz, p64)
     sig("orc_multiply_plain_ntt", None, vp, sz, p64, sz, p64, p64)
@@ -474,6 +478,29 @@ class Context:
         if lib().orc_batch_decode(self.h, ptr(np.ascontiguousarray(plain, dtype=np.uint64)), ptr(out)) != 0:
             raise ValueError("batch_decode failed")
         return out
+
+    def galois_element_from_step(self, step):
+        return int(lib().orc_galois_element_from_step(self.n, step))
+
+    def apply_galois(self, nmod, is_ntt_form, element, data):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        p = data.size // (nmod * self.n)
+        out = np.zeros(data.size, dtype=np.uint64)
+        lib().orc_apply_galois(self.h, nmod, int(is_ntt_form), element, ptr(data.reshape(-1)), p, ptr(out))
+        return out.reshape(data.shape)
+
+    def apply_galois_ct(self, L, is_ntt_form, element, ct, keys):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        keep, karr = self._keys(keys)
+        out = np.zeros(ct.size, dtype=np.uint64)
+        lib().orc_apply_galois_ct(self.h, L, int(is_ntt_form), element, ptr(ct.reshape(-1)), karr, ptr(out))
+        return out.reshape(2, L, self.n)
+
+    def galois_key(self, rng, sk, element):
+        L = self.K - 1
+        out = np.zeros(L * 2 * self.K * self.n, dtype=np.uint64)
+        lib().orc_keygen_galois_key(self.h, rng.h, ptr(np.ascontiguousarray(sk).reshape(-1)), element, ptr(out))
+        return [k.copy() for k in out.reshape(L, 2, self.K, self.n)]
 
     def plain_centralize(self, L, plain):
         plain = np.ascontiguousarray(plain, dtype=np.uint64)

@@ -1543,6 +1543,63 @@ int orc_multiply_plain_normal(const orc_context* c, size_t L, const uint64_t* ct
     return 0;
 }
 
+size_t orc_galois_element_from_step(size_t n, int step) {
+    size_t m = n * 2;
+    if (step == 0) return m - 1;
+    int sign = step < 0;
+    size_t pos_step = (size_t)(step < 0 ? -step : step);
+    size_t true_step = sign ? ((n >> 1) - pos_step) : pos_step;
+    size_t e = 1;
+    for (size_t i = 0; i < true_step; i++) e = (e * 3) & (m - 1);
+    return e;
+}
+
+void orc_apply_galois(const orc_context* c, size_t nmod, int is_ntt_form, size_t g, const uint64_t* in, size_t pcount, uint64_t* out) {
+    const size_t n = c->n, logn = c->log_n, mask = n - 1;
+    if (!is_ntt_form) {
+        /* host_apply_ps, utils/galois.cu:147-166 */
+        for (size_t k = 0; k < pcount; k++)
+            for (size_t j = 0; j < nmod; j++)
+                for (size_t i = 0; i < n; i++) {
+                    size_t index_raw = i * g, index = index_raw & mask;
+                    uint64_t v = in[(k * nmod + j) * n + i];
+                    out[(k * nmod + j) * n + index] = ((index_raw >> logn) & 1) ? orc_negate_mod(v, &c->key_modulus[j]) : v;
+                }
+    } else {
+        /* generate_table_ntt :24-41 + host_apply_ntt_ps (result[i] = poly[table[i]]) */
+        for (size_t i = 0; i < n; i++) {
+            size_t reversed = reverse_bits(i + n, logn + 1);
+            size_t index_raw = ((g * reversed) >> 1) & mask;
+            size_t src = reverse_bits(index_raw, logn);
+            for (size_t k = 0; k < pcount * nmod; k++) out[k * n + i] = in[k * n + src];
+        }
+    }
+}
+
+void orc_apply_galois_ct(const orc_context* c, size_t L, int is_ntt_form, size_t g, const uint64_t* ct, const uint64_t* const* keys, uint64_t* out) {
+    const size_t n = c->n;
+    orc_apply_galois(c, L, is_ntt_form, g, ct, 2, out);
+    uint64_t* target = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    memcpy(target, out + L * n, L * n * sizeof(uint64_t));
+    orc_switch_key(c, L, is_ntt_form, target, keys, 2 /* OverwriteExceptFirst */, out);
+    free(target);
+}
+
+void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, size_t g, uint64_t* out) {
+    const size_t n = c->n, K = c->K, L = K - 1;
+    uint64_t* rot = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    orc_apply_galois(c, K, 1, g, sk, 1, rot);      /* galois_tool.apply_ntt_p on the NTT-form secret key */
+    for (size_t i = 0; i < L; i++) {
+        uint64_t* key = out + i * 2 * K * n;
+        symmetric_zero_ntt(c, rng, sk, key);
+        const orc_modulus* qi = &c->key_modulus[i];
+        uint64_t factor = orc_barrett_reduce64(c->key_modulus[K - 1].value, qi);
+        for (size_t x = 0; x < n; x++)
+            key[i * n + x] = orc_add_mod(key[i * n + x], orc_multiply_mod(rot[i * n + x], factor, qi), qi);
+    }
+    free(rot);
+}
+
 uint64_t orc_fnv_words(const uint64_t* data, size_t n) {
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < n; i++) { h ^= data[i]; h *= 1099511628211ull; }

@@ -208,6 +208,16 @@ int orc_plain_centralize(const orc_context* c, size_t L, const uint64_t* plain, 
 int orc_multiply_plain_normal(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out);
 /* Evaluator::multiply_plain_ntt (:196-218): NTT-form ct x NTT-form RNS plaintext [L][N] */
 void orc_multiply_plain_ntt(const orc_context* c, size_t L, const uint64_t* ct, size_t pcount, const uint64_t* plain_ntt, uint64_t* out);
+/* ---- Galois automorphisms ----
+ * GaloisTool::apply_ps / apply_ntt_ps, host branches (utils/galois.cu:24-41,:147-166,:250-270): data [pcount][nmod][N] */
+void orc_apply_galois(const orc_context* c, size_t nmod, int is_ntt_form, size_t galois_element, const uint64_t* in, size_t pcount, uint64_t* out);
+/* Evaluator::apply_galois (evaluator_keyswitching.cu:147-179): ct [2][L][N]; keys = the L key-switching keys of the element */
+void orc_apply_galois_ct(const orc_context* c, size_t L, int is_ntt_form, size_t galois_element, const uint64_t* ct,
+                         const uint64_t* const* keys, uint64_t* out);
+/* KeyGenerator::generate_galois_keys for ONE element (key_generator.cu:239-260): out [L][2][K][N] */
+void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, size_t galois_element, uint64_t* out);
+/* GaloisTool::get_element_from_step (utils/galois.cu:43-63) */
+size_t orc_galois_element_from_step(size_t n, int step);
 /* the survey's digest: h = FNV offset; for each 64-bit WORD: h ^= word; h *= FNV prime */
 uint64_t orc_fnv_words(const uint64_t* data, size_t n);
 

@@ -70,3 +70,53 @@ def test_multiply_plain_accumulate_matmul_pattern(O, pkg, dev, n, bits, B, I, J)
             term = ctx.multiply_plain_ntt(L, a[b, 0], w[0, j])
             exp = np.stack([(got[b, j][:, l] + term[:, l]) % np.uint64(qv[l]) for l in range(L)], axis=1)
             assert np.array_equal(got2[b, j], exp), (b, j)
+
+
+@pytest.mark.parametrize("scheme,ntt,n,bits", [("bfv", False, 8192, [40, 40, 40]), ("ckks", True, 16384, [50] * 6),
+                                               ("ckks", True, 32, [40, 40, 40]), ("bfv", False, 64, [40, 40, 40])])
+def test_apply_galois(O, pkg, dev, scheme, ntt, n, bits):
+    """GaloisTool permutations (both forms) and Evaluator::apply_galois = permutation + key switch"""
+    q = [int(v) for v in O.coeff_modulus_create(n, bits)]
+    ctx = O.Context(scheme, n, q, 1032193 if scheme == "bfv" else 0)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    L = len(q) - 1
+    ct = np.stack([ctx.random_ct(3 + i, 2, L) for i in range(2)])
+    dct = pkg.to_device(ct, dev)
+    keys = ctx.random_keys(13, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    for step in (1, -3, 0):
+        g = ctx.galois_element_from_step(step)
+        for form in (False, True):
+            got = pkg.to_host(plan.apply_galois_poly(dct, L, g, form))
+            for i in range(2):
+                assert np.array_equal(got[i], ctx.apply_galois(L, form, g, ct[i])), (step, form)
+        rot = pkg.to_host(plan.apply_galois(L, dct, g, dkeys, is_ckks=(scheme == "ckks"), is_ntt_form=ntt))
+        for i in range(2):
+            assert np.array_equal(rot[i], ctx.apply_galois_ct(L, ntt, g, ct[i], keys)), step
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.apply_galois_poly(dct, L, 4, False)         # even element
+
+
+def test_rotation_decrypts(O, pkg, dev):
+    """rotate_rows / rotate_columns with genuine Galois keys: device result == oracle, and it decrypts to the rotated slots"""
+    n, t = 8192, 1032193
+    q = [int(v) for v in O.coeff_modulus_create(n, [40, 40, 40])]
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, 13, q)
+    rng = O.Rng(5)
+    sk = ctx.secret_key(rng)
+    pk = ctx.public_key(rng, sk)
+    ct = ctx.encrypt_asymmetric_bfv(rng, pk, ctx.batch_encode(list(range(1, n + 1))))
+    dct = pkg.to_device(ct[None], dev)
+    row = n // 2
+    for step in (1, -2, 0):
+        g = ctx.galois_element_from_step(step)
+        gk = ctx.galois_key(rng, sk, g)
+        got = pkg.to_host(plan.apply_galois(2, dct, g, [pkg.to_device(k, dev) for k in gk], is_ckks=False, is_ntt_form=False))[0]
+        assert np.array_equal(got, ctx.apply_galois_ct(2, False, g, ct, gk))
+        dec = [int(v) for v in ctx.batch_decode(ctx.decrypt_bfv(sk, got))]
+        if step == 0:
+            assert dec[:3] == [row + 1, row + 2, row + 3] and dec[row:row + 3] == [1, 2, 3]
+        else:
+            want = [((i + step) % row) + 1 for i in range(4)]
+            assert dec[:4] == want and dec[row:row + 4] == [w + row for w in want]

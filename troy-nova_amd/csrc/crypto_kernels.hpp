@@ -230,4 +230,30 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac_kernel(unsigned chunks, 
     }
 }
 
+// ---- Galois automorphisms ---------------------------------------------------------------
+// GaloisTool::apply_ps (utils/galois.cu:168-185): coefficient form, X -> X^g: out[i*g mod N] = +/- in[i]
+// GaloisTool::apply_ntt_ps (:24-41 table + gather): NTT form, out[i] = in[table(i)],
+//   table(i) = bitrev_logN(((g * bitrev_{logN+1}(i + N)) >> 1) mod N) -- computed on the fly, no table upload.
+// data [rows][n], one limb-polynomial per row; row % nmod selects the modulus (negation in coefficient form).
+__global__ __launch_bounds__(POLY_BLOCK) void galois_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned log_n,
+                                                            unsigned g, int is_ntt_form, const u64* in, u64* out) {
+    const unsigned n = 1u << log_n, mask = n - 1;
+    const size_t row = blk_row(chunks);
+    const u64 q = mods[mod_start + row % nmod].q;
+    const u64* ip = in + row * n;
+    u64* op = out + row * n;
+    for (unsigned i = blk_col(chunks); i < n; i += chunks * blockDim.x) {
+        if (is_ntt_form) {
+            const unsigned reversed = __brev(i + n) >> (31 - log_n);               // (log_n + 1)-bit reversal
+            const unsigned index_raw = (unsigned)(((u64)g * reversed) >> 1) & mask;
+            const unsigned src = __brev(index_raw) >> (32 - log_n);
+            op[i] = ip[src];
+        } else {
+            const u64 index_raw = (u64)i * g;
+            const u64 v = ip[i];
+            op[index_raw & mask] = ((index_raw >> log_n) & 1) ? neg_mod(v, q) : v;
+        }
+    }
+}
+
 }  // namespace troyn

@@ -1110,6 +1110,23 @@ extern "C" int troyn_dyadic_broadcast_product(const troyn_plan* p, uint32_t mod_
     return TROYN_OK;
 }
 
+extern "C" int troyn_apply_galois(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
+                                  const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream) {
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] null argument");
+    if (in == out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] the permutation cannot run in place");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[GaloisTool::apply] modulus slice out of range");
+    if ((galois_element & 1) == 0 || galois_element >= 2ull * p->n) return fail(TROYN_E_INVALID, "[Evaluator::apply_galois_inplace] Galois element is not valid.");
+    if (p->log_n < 1) return fail(TROYN_E_INVALID, "[GaloisTool::GaloisTool] coeff_count_power is invalid");
+    const size_t rows = count * nmod;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(galois_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->log_n, (unsigned)galois_element, is_ntt_form ? 1 : 0, (const u64*)in, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
 extern "C" size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count) { return (4 * count + 2) * sizeof(u64); }
 
 extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, size_t pcount,

@@ -170,6 +170,23 @@ class Plan:
                                                             int(set_zero), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
         return dsts
 
+    # -- Galois automorphisms -----------------------------------------------------------------------
+    def apply_galois_poly(self, x, nmod, element, is_ntt_form, mod_start=0, out=None):
+        """X -> X^element on every polynomial of x [count][nmod][N] (GaloisTool::apply_ps / apply_ntt_ps)"""
+        count = x.numel() // (nmod * self.n)
+        out = torch.empty_like(x) if out is None else out
+        capi.check(self.lib.troyn_apply_galois(self.h, mod_start, nmod, int(is_ntt_form), int(element), _ptr(x), _ptr(out), count, _stream()))
+        return out
+
+    def apply_galois(self, L, ct, element, keys, is_ckks=True, is_ntt_form=True):
+        """ct [batch][2][L][N] -> Evaluator::apply_galois: permute both polynomials, key-switch the second"""
+        out = self.apply_galois_poly(ct, L, element, is_ntt_form)
+        batch = ct.numel() // (2 * L * self.n)
+        target = out.view(batch, 2, L, self.n)[:, 1].contiguous()
+        self.switch_key(L, target, keys, dest=out.view(batch, 2, L, self.n), assign=ASSIGN_OVERWRITE_EXCEPT_FIRST,
+                        is_ckks=is_ckks, is_ntt_form=is_ntt_form)
+        return out
+
     # -- key switching -----------------------------------------------------------------------------
     def _key_ptrs(self, keys, L):
         if len(keys) < L:
