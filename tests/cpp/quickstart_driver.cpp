@@ -80,6 +80,16 @@ int main(int argc, char** argv) {
         evaluator.transform_from_ntt_inplace(acc);
         print_slots("macc", encoder.decode_new(decryptor.decrypt_new(acc)));
 
+        // rotations with genuine Galois keys (only the power-of-two steps are generated: 3 = 4 - 1 goes through NAF)
+        GaloisKeys galois_keys = keygen.create_galois_keys(false);
+        std::vector<uint64_t> ramp(8192);
+        for (size_t i = 0; i < ramp.size(); i++) ramp[i] = i + 1;
+        Ciphertext r = encryptor.encrypt_asymmetric_new(encoder.encode_new(ramp));
+        print_slots("rot1", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_rows_new(r, 1, galois_keys))));
+        print_slots("rot3", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_rows_new(r, 3, galois_keys))));
+        print_slots("rotm2", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_rows_new(r, -2, galois_keys))));
+        print_slots("rotcol", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_columns_new(r, galois_keys))));
+
         // misuse: host-resident plaintext / ciphertext
         bool threw = false;
         try { Plaintext p = encoder.encode_new({1}); p.to_host_inplace(); encryptor.encrypt_asymmetric_new(p); } catch (const std::invalid_argument&) { threw = true; }

@@ -88,6 +88,10 @@ def test_quickstart_cpp_api(dev):
     assert kv["sub"] == ["4", "4", "4", "4", "0", "0"]
     assert kv["mulplain"] == ["3", "10", "21", "44", "0", "0"]
     assert kv["macc"] == ["13", "22", "35", "60", "0", "0"]       # {1,2,3,4}*{3,5,7,11} + {5,6,7,8}*2
+    assert kv["rot1"] == ["2", "3", "4", "5", "6", "7"]
+    assert kv["rot3"] == ["4", "5", "6", "7", "8", "9"]
+    assert kv["rotm2"] == ["4095", "4096", "1", "2", "3", "4"]
+    assert kv["rotcol"] == ["4097", "4098", "4099", "4100", "4101", "4102"]
     assert kv["host_plain_rejected"] == ["1"]
     # a different seed gives a different ciphertext but the same plaintext results
     r2 = subprocess.run([drv, "0x456"], capture_output=True, text=True, timeout=600)

@@ -1013,6 +1013,141 @@ void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Galois automorphisms  (utils/galois.cu, evaluator_keyswitching.cu:147-361, key_generator.cu:239-260)
+// ------------------------------------------------------------------------------------------------
+namespace utils {
+
+size_t galois_element_from_step(size_t n, int step) {
+    // utils/galois.cu:43-63
+    const size_t m = n * 2;
+    if (step == 0) return m - 1;
+    const bool sign = step < 0;
+    const size_t pos_step = static_cast<size_t>(step < 0 ? -step : step);
+    if (pos_step >= (n >> 1)) throw std::invalid_argument("[GaloisTool::get_element_from_step] Step count too large");
+    const size_t true_step = sign ? ((n >> 1) - pos_step) : pos_step;
+    size_t e = 1;
+    for (size_t i = 0; i < true_step; i++) e = (e * 3) & (m - 1);   // GALOIS_GENERATOR = 3
+    return e;
+}
+
+std::vector<size_t> galois_elements_all(size_t n) {
+    // utils/galois.cu:65-89
+    const size_t m = n * 2;
+    std::vector<size_t> out{m - 1};
+    size_t logn = 0;
+    while ((size_t(1) << logn) < n) logn++;
+    size_t pos = 3, neg = 1;
+    for (size_t x = 1; x < m; x += 2) if (((x * 3) & (m - 1)) == 1) { neg = x; break; }   // 3^-1 mod m
+    for (size_t i = 0; i + 1 < logn; i++) {
+        out.push_back(pos);
+        out.push_back(neg);
+        pos = (pos * pos) & (m - 1);
+        neg = (neg * neg) & (m - 1);
+    }
+    return out;
+}
+
+std::vector<int> naf(int value) {
+    std::vector<int> res;
+    const bool sign = value < 0;
+    value = std::abs(value);
+    int i = 0;
+    while (value > 0) {
+        const int zi = ((value & 1) != 0) ? (2 - (value & 3)) : 0;
+        value = (value - zi) >> 1;
+        if (zi != 0) res.push_back((sign ? -zi : zi) << i);
+        i++;
+    }
+    return res;
+}
+
+}  // namespace utils
+
+GaloisKeys KeyGenerator::create_galois_keys_from_elements(const std::vector<size_t>& galois_elements, bool save_seed, MemoryPoolHandle pool) const {
+    // key_generator.cu:239-260: key for element g encrypts the secret key rotated by g
+    ContextDataPointer kcd = context_->key_context_data().value();
+    const size_t n = kcd->parms().poly_modulus_degree();
+    const uint32_t K = static_cast<uint32_t>(kcd->parms().coeff_modulus().size());
+    std::vector<std::vector<PublicKey>> keys(n);
+    utils::DynamicArray rotated(static_cast<size_t>(K) * n, true, pool);
+    for (size_t g : galois_elements) {
+        if (g % 2 == 0 || g >= (n << 1)) throw std::invalid_argument("[KeyGenerator::generate_galois_keys] Galois element is not valid.");
+        const size_t index = GaloisKeys::get_index(g);
+        if (!keys[index].empty()) continue;
+        troyn_check(troyn_apply_galois(context_->plan(), 0, K, 1, g, secret_key_.data().raw_pointer(), rotated.raw_pointer(), 1, current_stream()));
+        generate_one_kswitch_key(rotated.raw_pointer(), keys[index], save_seed, pool);
+    }
+    return GaloisKeys(KSwitchKeys(kcd->parms_id(), std::move(keys)));
+}
+
+GaloisKeys KeyGenerator::create_galois_keys_from_steps(const std::vector<int>& steps, bool save_seed, MemoryPoolHandle pool) const {
+    const size_t n = context_->key_context_data().value()->parms().poly_modulus_degree();
+    std::vector<size_t> elements;
+    for (int st : steps) elements.push_back(utils::galois_element_from_step(n, st));
+    return create_galois_keys_from_elements(elements, save_seed, pool);
+}
+
+GaloisKeys KeyGenerator::create_galois_keys(bool save_seed, MemoryPoolHandle pool) const {
+    const size_t n = context_->key_context_data().value()->parms().poly_modulus_degree();
+    return create_galois_keys_from_elements(utils::galois_elements_all(n), save_seed, pool);
+}
+
+void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_keyswitching.cu:147-179
+    const char* P = "[Evaluator::apply_galois_inplace]";
+    check_no_seed(P, encrypted);
+    check_on_device(P, context_, encrypted);
+    if (galois_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Galois keys has incorrect parms id.");
+    auto cd = get_context_data(P, encrypted.parms_id());
+    const size_t n = cd->parms().poly_modulus_degree();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    if ((galois_element & 1) == 0 || galois_element > 2 * n) throw std::invalid_argument(std::string(P) + " Galois element is not valid.");
+    if (!galois_keys.has_key(galois_element)) throw std::invalid_argument(std::string(P) + " Galois key not present.");
+    if (encrypted.polynomial_count() > 2) throw std::invalid_argument(std::string(P) + " Ciphertext size must be 2.");
+    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    troyn_check(troyn_apply_galois(context_->plan(), 0, L, encrypted.is_ntt_form() ? 1 : 0, galois_element,
+                                   encrypted.data().raw_pointer(), out.data().raw_pointer(), 2, current_stream()));
+    // the permuted c1 is the key-switch target; the result overwrites it (c0 += ks0, c1 = ks1)
+    utils::DynamicArray target(static_cast<size_t>(L) * n, true, pool);
+    hip_check(hipMemcpyAsync(target.raw_pointer(), out.poly(1), static_cast<size_t>(L) * n * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+    switch_key_internal(encrypted, target.raw_pointer(), galois_keys, GaloisKeys::get_index(galois_element),
+                        SwitchKeyDestinationAssignMethod::OverwriteExceptFirst, out, pool);
+    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    destination = std::move(out);
+}
+
+void Evaluator::rotate_internal(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_keyswitching.cu:263-294
+    const char* P = "[Evaluator::rotate_inplace_internal]";
+    auto cd = get_context_data(P, encrypted.parms_id());
+    if (galois_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Galois keys has incorrect parms id.");
+    if (steps == 0) { destination = encrypted; return; }
+    const size_t n = cd->parms().poly_modulus_degree();
+    const size_t element = utils::galois_element_from_step(n, steps);
+    if (galois_keys.has_key(element)) { apply_galois(encrypted, element, galois_keys, destination, pool); return; }
+    std::vector<int> naf_steps = utils::naf(steps);
+    if (naf_steps.size() == 1) throw std::invalid_argument(std::string(P) + " Galois key not present.");
+    bool first = true;
+    for (int st : naf_steps) {
+        if (first) { rotate_internal(encrypted, st, galois_keys, destination, pool); first = false; }
+        else { Ciphertext temp; rotate_internal(destination, st, galois_keys, temp, pool); destination = std::move(temp); }
+    }
+}
+
+void Evaluator::rotate_rows(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument("[Evaluator::rotate_rows_inplace] Rotate rows only applies for BFV or BGV");
+    rotate_internal(encrypted, steps, galois_keys, destination, pool);
+}
+
+void Evaluator::rotate_columns(const Ciphertext& encrypted, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument("[Evaluator::rotate_columns_inplace] Rotate columns only applies for BFV or BGV");
+    auto cd = get_context_data("[Evaluator::conjugate_inplace_internal]", encrypted.parms_id());
+    apply_galois(encrypted, utils::galois_element_from_step(cd->parms().poly_modulus_degree(), 0), galois_keys, destination, pool);
+}
+
+// ------------------------------------------------------------------------------------------------
 // utils::RandomGenerator  (utils/random_generator.cu)
 // ------------------------------------------------------------------------------------------------
 namespace utils {

@@ -427,6 +427,25 @@ public:
     bool has_key(size_t key_power) const { size_t i = get_index(key_power); return i < data().size() && !data()[i].empty(); }
 };
 
+// kswitch_keys.h:300-370: key-switching keys indexed by Galois element, index = (element - 1) / 2
+class GaloisKeys : public KSwitchKeys {
+public:
+    GaloisKeys() = default;
+    explicit GaloisKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    static size_t get_index(size_t galois_element) {
+        if ((galois_element & 1) == 0) throw std::invalid_argument("[GaloisTool::get_index_from_element] galois_element must be odd");
+        return (galois_element - 1) >> 1;
+    }
+    bool has_key(size_t galois_element) const { size_t i = get_index(galois_element); return i < data().size() && !data()[i].empty(); }
+};
+
+namespace utils {
+// utils/galois.cu:43-96 (the permutation itself runs on the device: troyn_apply_galois)
+size_t galois_element_from_step(size_t poly_modulus_degree, int step);
+std::vector<size_t> galois_elements_all(size_t poly_modulus_degree);
+std::vector<int> naf(int value);   // utils/number_theory.cu:6-20
+}  // namespace utils
+
 // ----------------------------------------------------------------------------------------------
 // KeyGenerator  (src/key_generator.h, key_generator.cu)
 // ----------------------------------------------------------------------------------------------
@@ -440,6 +459,9 @@ public:
     PublicKey create_public_key(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     KSwitchKeys create_keyswitching_key(const SecretKey& new_key, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     RelinKeys create_relin_keys(bool save_seed, size_t max_power = 2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    GaloisKeys create_galois_keys_from_elements(const std::vector<size_t>& galois_elements, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    GaloisKeys create_galois_keys_from_steps(const std::vector<int>& steps, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    GaloisKeys create_galois_keys(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // all power-of-two rotations + row swap
     static void compute_secret_key_powers(HeContextPointer context, size_t max_power, utils::DynamicArray& secret_key_array);
 private:
     void generate_one_kswitch_key(const uint64_t* new_key, std::vector<PublicKey>& destination, bool save_seed, MemoryPoolHandle pool) const;
@@ -579,6 +601,17 @@ public:
     void relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d,
                              MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition
 
+    // Galois automorphisms / rotations -- evaluator.h:700-850 (evaluator_keyswitching.cu:147-361)
+    void apply_galois(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void apply_galois_inplace(Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); encrypted = std::move(d); }
+    Ciphertext apply_galois_new(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); return d; }
+    void rotate_rows(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rotate_rows_inplace(Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_rows(encrypted, steps, galois_keys, d, pool); encrypted = std::move(d); }
+    Ciphertext rotate_rows_new(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_rows(encrypted, steps, galois_keys, d, pool); return d; }
+    void rotate_columns(const Ciphertext& encrypted, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rotate_columns_inplace(Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); encrypted = std::move(d); }
+    Ciphertext rotate_columns_new(const Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); return d; }
+
     // modulus switching -- evaluator.h:308-420 (evaluator_modswitch.cu)
     void mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void mod_switch_to_next_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to_next(encrypted, d, pool); encrypted = std::move(d); }
@@ -609,6 +642,7 @@ private:
     void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
                              SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
+    void rotate_internal(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_internal(const Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, Ciphertext& destination, MemoryPoolHandle pool) const;
     void mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const;
     void mod_switch_drop_to_internal(const Ciphertext& encrypted, Ciphertext& destination, const ParmsID& target, MemoryPoolHandle pool) const;
