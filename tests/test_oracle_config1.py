@@ -81,3 +81,29 @@ def test_config1_end_to_end_semantics(O):
     # add: (m + m) decrypts to 2m
     two = np.stack([(ct[p].astype(object) * 2 % np.array(ctx.q[:2], dtype=object)[:, None]).astype(np.uint64) for p in range(2)])
     assert [int(v) for v in ctx.batch_decode(ctx.decrypt_bfv(sk, two))[:4]] == [2, 4, 6, 8]
+
+
+def test_rotations_and_plain_multiply_semantics(O):
+    """Galois automorphisms (with genuine Galois keys) and ciphertext x plaintext products decrypt to the expected
+    slots: first-principles validation of the oracle's apply_galois / key switch / centralize paths."""
+    n = G["poly_modulus_degree"]
+    ctx, sk, ct = config1_ciphertext(O)
+    rng = O.Rng(4242)
+    w = ctx.batch_encode([3, 5, 7, 11])
+    assert [int(v) for v in ctx.batch_decode(ctx.decrypt_bfv(sk, ctx.multiply_plain_normal(2, ct, w)))[:5]] == [3, 10, 21, 44, 0]
+    pk = ctx.public_key(rng, sk)
+    ramp = ctx.encrypt_asymmetric_bfv(rng, pk, ctx.batch_encode(list(range(1, n + 1))))
+    row = n // 2
+    for step in (1, -2, 0):
+        g = ctx.galois_element_from_step(step)
+        rot = ctx.apply_galois_ct(2, False, g, ramp, ctx.galois_key(rng, sk, g))
+        dec = [int(v) for v in ctx.batch_decode(ctx.decrypt_bfv(sk, rot))]
+        if step == 0:
+            assert dec[:3] == [row + 1, row + 2, row + 3] and dec[row:row + 3] == [1, 2, 3]
+        else:
+            assert dec[:4] == [((i + step) % row) + 1 for i in range(4)]
+    # NTT-form permutation == coefficient-form permutation conjugated by the transform
+    a = ctx.random_ct(9, 1, 2)
+    g = ctx.galois_element_from_step(5)
+    via_ntt = ctx.from_ntt(ctx.apply_galois(2, True, g, ctx.to_ntt(a, 1, 2)), 1, 2)
+    assert np.array_equal(via_ntt, ctx.apply_galois(2, False, g, a))
