@@ -548,6 +548,11 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // 16-byte coalesced key loads
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
             const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
+            // key loads are software-pipelined one pair ahead: the first pair is requested before the transpose, pair
+            // m+1 before the arithmetic of pair m (two pairs = 16 VGPRs in flight; more would spill)
+            const u64* kp0 = key0 + wbase + lane * 2u;
+            const u64* kp1 = kp0 + a.key_pstride;
+            ulonglong2 kc0 = *reinterpret_cast<const ulonglong2*>(kp0), kc1 = *reinterpret_cast<const ulonglong2*>(kp1);
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 lds[pown + R] = A::mac_to_lds(x[R], md);
@@ -555,12 +560,15 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             __builtin_amdgcn_wave_barrier();
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                const unsigned idx = wbase + m * 128u + lane * 2u;
+                ulonglong2 kn0 = kc0, kn1 = kc1;
+                if constexpr (m + 1 < E / 2) {
+                    kn0 = *reinterpret_cast<const ulonglong2*>(kp0 + (m + 1) * 128u);
+                    kn1 = *reinterpret_cast<const ulonglong2*>(kp1 + (m + 1) * 128u);
+                }
                 const elem v0 = A::from_lds(lds[pidx + lds_off(m * 128u)]), v1 = A::from_lds(lds[pidx + lds_off(m * 128u) + 1]);
-                const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(key0 + idx);
-                const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(key0 + a.key_pstride + idx);
-                A::mac(acc0[2 * m], v0, k0.x, md); A::mac(acc0[2 * m + 1], v1, k0.y, md);
-                A::mac(acc1[2 * m], v0, k1.x, md); A::mac(acc1[2 * m + 1], v1, k1.y, md);
+                A::mac(acc0[2 * m], v0, kc0.x, md); A::mac(acc0[2 * m + 1], v1, kc0.y, md);
+                A::mac(acc1[2 * m], v0, kc1.x, md); A::mac(acc1[2 * m + 1], v1, kc1.y, md);
+                kc0 = kn0; kc1 = kn1;
                 __builtin_amdgcn_sched_barrier(0);   // keep the key loads of later pairs from piling up in registers
             });
             // the next digit's first exchange overwrites every wave's slice
