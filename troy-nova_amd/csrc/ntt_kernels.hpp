@@ -130,16 +130,18 @@ __device__ __forceinline__ u64 ntt_io_load(const NttIo& io, u64 raw) {
 }
 
 // canonical transform output y at limb-local index idx -> stored word
+// Operands of the epilogue are passed by value (prod = ext0 word, addend = ext1 word, destv = old destination word)
+// so that the caller can request all of them before any arithmetic starts.
 template <int SM>
-__device__ __forceinline__ u64 ntt_io_store(const NttIo& io, u64 y, unsigned idx) {
+__device__ __forceinline__ u64 ntt_io_store(const NttIo& io, u64 y, u64 prod, u64 addend, u64 destv) {
     if constexpr (SM == NTT_STORE_KS_FINISH) {
-        u64 d = shoup_mul(io.ext0[idx] + io.lift - y, io.inv.x, io.inv.y, io.q);
-        if (io.add_inplace) d = add_mod(io.dest[idx], d, io.q);
-        if (io.ext1) d = add_mod(d, io.ext1[idx], io.q);
+        u64 d = shoup_mul(prod + io.lift - y, io.inv.x, io.inv.y, io.q);
+        if (io.add_inplace) d = add_mod(destv, d, io.q);
+        if (io.ext1) d = add_mod(d, addend, io.q);
         return d;
     }
     if constexpr (SM == NTT_STORE_RESCALE) {
-        u64 d = add_mod(io.ext0[idx], io.lift, io.q);    // add_uint64_mod(x, 4q): x + 3q
+        u64 d = add_mod(prod, io.lift, io.q);    // add_uint64_mod(x, 4q): x + 3q
         d = sub_mod(d, y, io.q);
         return shoup_mul(d, io.inv.x, io.inv.y, io.q);
     }
@@ -227,8 +229,8 @@ struct ArithU64 {
         return load_first(ntt_io_load<LM>(io, raw), reduce, m);
     }
     template <int SM> static __device__ __forceinline__ u64 store_prep(elem x, const Mod& m) { return final_fwd(x, m); }
-    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, unsigned idx, const Mod&) {
-        return ntt_io_store<SM>(io, word, idx);
+    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, u64 prod, u64 addend, u64 destv, const Mod&) {
+        return ntt_io_store<SM>(io, word, prod, addend, destv);
     }
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod&) { return raw; }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return x; }
@@ -300,15 +302,15 @@ struct ArithF64 {
         if constexpr (SM == NTT_STORE_PLAIN) return final_fwd(x, m);
         else return f64_double_to_bits(f64_corr(x, m.m));
     }
-    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, unsigned idx, const Mod& m) {
+    template <int SM> static __device__ __forceinline__ u64 store_io(const NttIo& io, u64 word, u64 prod, u64 addend, u64 destv, const Mod& m) {
         if constexpr (SM == NTT_STORE_PLAIN) return word;
         else {
             // (prod - y) * inv mod p  [+ dest] [+ addend]; |prod - y| <= 1.5p + 1, every term an exact integer
             const double y = f64_bits_to_double(word);
-            double d = f64_mulc(f64_from_u64(io.ext0[idx]) - y, io.inv_d, io.inv_pd, m.m.p);
+            double d = f64_mulc(f64_from_u64(prod) - y, io.inv_d, io.inv_pd, m.m.p);
             if constexpr (SM == NTT_STORE_KS_FINISH) {
-                if (io.add_inplace) d += f64_from_u64(io.dest[idx]);
-                if (io.ext1) d += f64_from_u64(io.ext1[idx]);
+                if (io.add_inplace) d += f64_from_u64(destv);
+                if (io.ext1) d += f64_from_u64(addend);
             }
             return f64_canon(d, m.m);
         }
@@ -584,13 +586,36 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int R = decltype(Rc)::value;
                 lds[pown + R] = A::template store_prep<SM>(x[R], md);
             });
-            __builtin_amdgcn_wave_barrier();
             const unsigned gbase = gindex(wbase);
+            // epilogue operands: request every word first (16 bytes per lane, all in flight together), then compute
+            ulonglong2 e0[SM != NTT_STORE_PLAIN ? E / 2 : 1], e1[SM == NTT_STORE_KS_FINISH ? E / 2 : 1], ed[SM == NTT_STORE_KS_FINISH ? E / 2 : 1];
+            if constexpr (SM != NTT_STORE_PLAIN) {
+                static_for<0, E / 2>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    e0[m] = *reinterpret_cast<const ulonglong2*>(io.ext0 + gbase + m * 128u + lane * 2u);
+                });
+                if constexpr (SM == NTT_STORE_KS_FINISH) {
+                    static_for<0, E / 2>([&](auto mc) { e1[decltype(mc)::value] = make_ulonglong2(0, 0); ed[decltype(mc)::value] = make_ulonglong2(0, 0); });
+                    if (io.ext1) static_for<0, E / 2>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        e1[m] = *reinterpret_cast<const ulonglong2*>(io.ext1 + gbase + m * 128u + lane * 2u);
+                    });
+                    if (io.add_inplace) static_for<0, E / 2>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value;
+                        ed[m] = *reinterpret_cast<const ulonglong2*>(io.dest + gbase + m * 128u + lane * 2u);
+                    });
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = lds[pidx + lds_off(m * 128u)], v1 = lds[pidx + lds_off(m * 128u) + 1];
-                v0 = A::template store_io<SM>(io, v0, gbase + idx, md); v1 = A::template store_io<SM>(io, v1, gbase + idx + 1, md);
+                if constexpr (SM != NTT_STORE_PLAIN) {
+                    constexpr int mk = (SM == NTT_STORE_KS_FINISH) ? m : 0;
+                    v0 = A::template store_io<SM>(io, v0, e0[m].x, e1[mk].x, ed[mk].x, md);
+                    v1 = A::template store_io<SM>(io, v1, e0[m].y, e1[mk].y, ed[mk].y, md);
+                }
                 nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
@@ -601,7 +626,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 if constexpr (LAST) {
                     if constexpr (INV && A::FOLD_NINV && ((R >> (EB - 1)) & 1)) v = A::final_fwd(x[R], md);   // already scaled
                     else if constexpr (INV) v = A::final_inv(x[R], md);
-                    else v = A::template store_io<SM>(io, A::template store_prep<SM>(x[R], md), gi, md);
+                    else if constexpr (SM == NTT_STORE_PLAIN) v = A::final_fwd(x[R], md);
+                    else v = A::template store_io<SM>(io, A::template store_prep<SM>(x[R], md), io.ext0[gi],
+                                                      (SM == NTT_STORE_KS_FINISH && io.ext1) ? io.ext1[gi] : 0,
+                                                      (SM == NTT_STORE_KS_FINISH && io.add_inplace) ? io.dest[gi] : 0, md);
                 } else v = A::store_mid(x[R], md);
                 nt_store(gout + gi, v);
             });
