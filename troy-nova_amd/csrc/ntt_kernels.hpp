@@ -47,6 +47,7 @@ struct NttArgs {
     long long ext1_bstride, ext1_pstride, ext1_cstride;
     const ulonglong2* inv_table;   // store: Shoup pair of (dropped prime)^-1 mod q_j, indexed by component j
     unsigned batch;                // ks_mac_kernel: number of items (workgroup -> (row, item) mapping)
+    unsigned xcd_groups;           // fused tail / rescale launches: batch * pcount groups whose ncomp limbs share one input row (0: off)
     long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
 };
 
@@ -380,9 +381,19 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         b = bid % a.batch; k = bid / a.batch;
     } else {
         tile = bid & ((1u << TILE_BITS) - 1); bid >>= TILE_BITS;
-        j = bid % a.ncomp; bid /= a.ncomp;
-        k = bid % a.pcount;
-        b = bid / a.pcount;
+        unsigned g;   // (batch, poly) group
+        if (IOM != 0 && TILE_BITS == 0 && a.xcd_groups) {
+            // The ncomp limbs of a group read the SAME input row (fused key-switch tail / rescale).  Workgroups are
+            // dealt round-robin to the 8 XCDs, so place a group's limbs 8 apart: they land on one XCD, back to back,
+            // and the shared row is fetched from HBM once instead of ncomp times.
+            const unsigned per = 8u * a.ncomp, full = (a.xcd_groups / 8u) * per;
+            if (bid < full) { const unsigned r = bid % per; j = r / 8u; g = (bid / per) * 8u + (r % 8u); }
+            else { const unsigned r = bid - full; j = r % a.ncomp; g = (a.xcd_groups / 8u) * 8u + r / a.ncomp; }
+        } else {
+            j = bid % a.ncomp; g = bid / a.ncomp;
+        }
+        k = g % a.pcount;
+        b = g / a.pcount;
     }
     const unsigned top = tile >> NLB;
     const unsigned lb = tile & ((1u << NLB) - 1);

@@ -324,6 +324,8 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     a.stream_loads = ((a.pcount <= 1 || a.in_pstride != 0) && (a.ncomp <= 1 || a.in_cstride != 0)) ? 1u : 0u;
     const size_t lp = batch * a.pcount * a.ncomp;
     if (lp == 0) return TROYN_OK;
+    // limbs that share one input row (component stride 0) are co-located on an XCD by the fused forward kernels
+    a.xcd_groups = (a.load_mode != NTT_LOAD_PLAIN && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     const bool f64 = use_f64(p, a.table_start, a.table_count);
