@@ -1,0 +1,95 @@
+"""The reference's Python surface (pytroy / pytroy_raw) over the C++ mirror: parameter objects work without a GPU;
+the evaluation flow (written like pybind/tests/test_basics.py and test_he_operations.py) runs on the GPU."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "troy-nova_amd")
+
+
+@pytest.fixture(scope="module")
+def pytroy():
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    try:
+        import pytroy as m
+    except ImportError as e:
+        pytest.fail("pytroy_raw is not built (python -c 'import __graft_entry__ as g; g.build()'): %s" % e)
+    return m
+
+
+def _params(pytroy, scheme, n, bits, t_bits=20):
+    p = pytroy.EncryptionParameters(scheme)
+    p.set_poly_modulus_degree(n)
+    p.set_coeff_modulus(pytroy.CoeffModulus.create(n, bits))
+    if scheme != pytroy.SchemeType.CKKS:
+        p.set_plain_modulus(pytroy.PlainModulus.batching(n, t_bits))
+    return p
+
+
+def test_parameter_objects(pytroy):
+    assert pytroy.it_works() == 42
+    assert pytroy.Modulus(1234).value() == 1234
+    bits = [60, 40, 40, 60]
+    moduli = pytroy.CoeffModulus.create(8192, bits)
+    assert [m.bit_count() for m in moduli] == bits
+    p = _params(pytroy, pytroy.SchemeType.BFV, 8192, bits)
+    assert p.scheme() == pytroy.SchemeType.BFV and p.poly_modulus_degree() == 8192
+    assert [m.value() for m in p.coeff_modulus()] == [m.value() for m in moduli]
+    assert p.plain_modulus().value() == 1032193
+    ctx = pytroy.HeContext(p)
+    assert not ctx.on_device() and ctx.using_keyswitching()
+    chain, cd = [], ctx.key_context_data()
+    while cd is not None:
+        chain.append(len(cd.parms().coeff_modulus()))
+        cd = cd.next_context_data()
+    assert chain == [4, 3, 2, 1]
+    assert ctx.first_parms_id() == ctx.key_context_data().next_context_data().parms_id()
+    assert pytroy.parms_id_zero.is_zero()
+
+
+@pytest.mark.gpu
+def test_quickstart_flow_in_python(pytroy, dev):
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_digests.json")))
+    p = _params(pytroy, pytroy.SchemeType.BFV, 8192, [40, 40, 40])
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Classical128, G["seed"])
+    ctx.to_device_inplace()
+    assert ctx.pool() == pytroy.MemoryPool.global_pool()
+    encoder = pytroy.BatchEncoder(ctx)
+    encoder.to_device_inplace()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_public_key(keygen.create_public_key(False))
+    decryptor = pytroy.Decryptor(ctx, keygen.secret_key())
+    evaluator = pytroy.Evaluator(ctx)
+    c = encryptor.encrypt_asymmetric_new(encoder.encode_simd_new([1, 2, 3, 4]))
+
+    def digest(words):
+        h = 1469598103934665603
+        for w in words:
+            h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+    assert digest(c.data()) == G["ciphertext_digest"]                 # the reference's own output for this seed
+    dec = lambda ct: encoder.decode_simd_new(decryptor.decrypt_new(ct))
+    assert dec(c)[:5] == [1, 2, 3, 4, 0]
+    assert dec(evaluator.add_new(c, c))[:4] == [2, 4, 6, 8]
+    prod = evaluator.multiply_new(c, c)
+    assert digest(prod.data()) == G["multiply_digest"] and prod.polynomial_count() == 3
+    relin = evaluator.relinearize_new(prod, keygen.create_relin_keys(False))
+    assert relin.polynomial_count() == 2 and dec(relin)[:4] == [1, 4, 9, 16]
+    low = evaluator.mod_switch_to_next_new(relin)
+    assert low.coeff_modulus_size() == 1 and dec(low)[:4] == [1, 4, 9, 16]
+    w = encoder.encode_simd_new([3, 5, 7, 11])
+    assert dec(evaluator.multiply_plain_new(c, w))[:4] == [3, 10, 21, 44]
+    gk = keygen.create_galois_keys(False)
+    r = encryptor.encrypt_asymmetric_new(encoder.encode_simd_new(list(range(1, 8193))))
+    assert dec(evaluator.rotate_rows_new(r, 3, gk))[:3] == [4, 5, 6]
+    assert dec(evaluator.rotate_columns_new(r, gk))[:2] == [4097, 4098]
+    host = c.clone()
+    host.to_host_inplace()
+    with pytest.raises(ValueError):
+        evaluator.add_new(host, c)                                      # std::invalid_argument -> ValueError
+    pytroy.MemoryPool.destroy_global_pool()

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations (bench.py covers configs[2], the headline):
+  cfg2  BFV  N=8192  L=2      NTT(a), NTT(b) + dyadic 2x2->3 + INTT (the "NTT+dyadic-mul+INTT" pipeline), ciphertexts/s
+  cfg3  CKKS N=16384 L=5 K=6  relinearize alone, ops/s
+  cfg4  BFV  N=32768 L=10     BEHZ multiply (+ relinearize) of independent ciphertext pairs, ops/s
+  cfg5  BFV  N=8192 {60,40,40,60}  ct x pt multiply-accumulate of the matmul application, weight plaintexts/s
+Synthetic uniform residues.  usage: python tools/bench_configs.py [--only cfg4]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+
+
+def residues(pkg, shape_prefix, q, n, dev, gen):
+    out = torch.empty(tuple(shape_prefix) + (len(q), n), dtype=torch.int64, device=dev)
+    for l, m in enumerate(q):
+        out[..., l, :] = torch.randint(0, m, tuple(shape_prefix) + (n,), dtype=torch.int64, device=dev, generator=gen)
+    return out
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    pkg = entry.load_package()
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    res = {}
+
+    if a.only in ("", "cfg2"):
+        n, B = 8192, 2048
+        q = pkg.capi.coeff_modulus_create(n, [40, 40, 40])
+        L = 2
+        plan = pkg.Plan(dev, 13, q)
+        x, y = residues(pkg, (B, 2), q[:L], n, dev, gen), residues(pkg, (B, 2), q[:L], n, dev, gen)
+        xn, yn = torch.empty_like(x), torch.empty_like(y)
+        prod = torch.empty((B, 3, L, n), dtype=torch.int64, device=dev)
+
+        def step():
+            plan.ntt(x, 2, L, out=xn); plan.ntt(y, 2, L, out=yn)
+            plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod)
+            plan.ntt(prod, 3, L, inverse=True)
+        t = timed(step, a.reps)
+        alg = (4 * 16 + 56 + 3 * 16) * n * L * B          # 168*N*L bytes per product, unfused
+        res["cfg2"] = {"what": "BFV N=8192 L=2: 4 NTT + dyadic 2x2->3 + 3 INTT per ciphertext pair", "batch": B,
+                       "ciphertext_products_per_s": round(B / t, 1), "algorithmic_GBps": round(alg / t / 1e9, 1)}
+
+    if a.only in ("", "cfg3"):
+        n, B = 16384, 256
+        q = pkg.capi.coeff_modulus_create(n, [50] * 6)
+        K, L = 6, 5
+        plan = pkg.Plan(dev, 14, q)
+        ct3 = residues(pkg, (B, 3), q[:L], n, dev, gen)
+        keys = [residues(pkg, (2,), q, n, dev, gen) for _ in range(L)]
+        out = torch.empty((B, 2, L, n), dtype=torch.int64, device=dev)
+        t = timed(lambda: plan.relinearize(L, ct3, keys, out=out, is_ckks=True, is_ntt_form=True), a.reps)
+        res["cfg3_relinearize"] = {"what": "CKKS N=16384 L=5 K=6 relinearize (3 -> 2 polynomials)", "batch": B, "ops_per_s": round(B / t, 1)}
+
+    if a.only in ("", "cfg4"):
+        n, B = 32768, 64
+        q = pkg.capi.coeff_modulus_create(n, [50] * 11)
+        K, L, t_plain = 11, 10, 1032193
+        plan = pkg.Plan(dev, 15, q)
+        behz = pkg.Behz(plan, L, t_plain)
+        x, y = residues(pkg, (B, 2), q[:L], n, dev, gen), residues(pkg, (B, 2), q[:L], n, dev, gen)
+        prod = torch.empty((B, 3, L, n), dtype=torch.int64, device=dev)
+        keys = [residues(pkg, (2,), q, n, dev, gen) for _ in range(L)]
+        out = torch.empty((B, 2, L, n), dtype=torch.int64, device=dev)
+        tm = timed(lambda: behz.multiply(x, 2, y, 2, out=prod), max(3, a.reps // 2))
+        tr = timed(lambda: plan.relinearize(L, prod, keys, out=out, is_ckks=False, is_ntt_form=False), max(3, a.reps // 2))
+        res["cfg4"] = {"what": "BFV N=32768 L=10: BEHZ multiply, then relinearize", "batch": B,
+                       "multiply_ops_per_s": round(B / tm, 1), "relinearize_ops_per_s": round(B / tr, 1),
+                       "multiply_relinearize_ops_per_s": round(B / (tm + tr), 1)}
+
+    if a.only in ("", "cfg5"):
+        # 512x512x512 matmul packed into N=8192 slots: the kernel is ret[b][j] = sum_i a[b][i] (.) w[i][j]
+        import ctypes as C
+        n, I, J, Bt = 8192, 256, 64, 1                      # 16 384 weight plaintexts
+        q = pkg.capi.coeff_modulus_create(n, [60, 40, 40, 60])
+        L = 3
+        plan = pkg.Plan(dev, 13, q)
+        av = residues(pkg, (Bt, I, 2), q[:L], n, dev, gen)
+        w = torch.empty((I, J, L, n), dtype=torch.int64, device=dev)
+        for l, m in enumerate(q[:L]):
+            w[:, :, l, :].random_(0, m, generator=gen)
+        out = torch.empty((Bt, J, 2, L, n), dtype=torch.int64, device=dev)
+        cts, pts, dsts = [], [], []
+        for i in range(I):
+            for j in range(J):
+                for b in range(Bt):
+                    cts.append(av[b, i].data_ptr()); pts.append(w[i, j].data_ptr()); dsts.append(out[b, j].data_ptr())
+        terms = len(cts)
+        arr = lambda v: (C.c_void_p * terms)(*v)
+        ca, pa, da = arr(cts), arr(pts), arr(dsts)          # pointer tables built once, as a matmul call would
+        nbytes = plan.lib.troyn_multiply_plain_accumulate_workspace_bytes(terms)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def mac():
+            pkg.capi.check(plan.lib.troyn_multiply_plain_accumulate(plan.h, 0, L, 2, ca, pa, da, terms, 1, C.c_void_p(ws.data_ptr()), ws.numel(), stream))
+        t = timed(mac, a.reps)
+        alg = terms * (2 + 1) * L * n * 8 + J * Bt * 2 * L * n * 8        # every ct and pt word of a term read once, outputs written once
+        res["cfg5_mac"] = {"what": "ct x pt multiply-accumulate, N=8192 L=3: %d x %d weight plaintexts, %d input block(s)" % (I, J, Bt),
+                           "terms_per_s": round(terms / t, 1), "algorithmic_GBps": round(alg / t / 1e9, 1), "ms": round(t * 1e3, 3),
+                           "weight_GBps": round(terms * L * n * 8 / t / 1e9, 1)}
+
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

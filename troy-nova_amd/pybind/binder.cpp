@@ -1,0 +1,240 @@
+// binder.cpp -- `pytroy_raw`: the Python surface of the reference (pybind/src/*.cu registers the same class and method
+// names) over the host-side mirror troy/troy.h.  Only what the mirror implements is exposed; everything runs on the GPU
+// (call context.to_device_inplace() first), and host-resident operands raise ValueError / RuntimeError exactly as the
+// C++ exceptions map (std::invalid_argument -> ValueError).
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <optional>
+
+#include "../troy/troy.h"
+
+namespace py = pybind11;
+using namespace troy;
+
+using PoolArg = std::optional<MemoryPoolHandle>;
+static MemoryPoolHandle P(const PoolArg& p) { return p.has_value() ? p.value() : MemoryPool::GlobalPool(); }
+#define POOL py::arg("pool") = std::nullopt
+
+// unary / binary / keyed evaluator operations come in (x, x_inplace, x_new) triples with identical shapes
+#define EV_UNARY(cls, name)                                                                                                  \
+    cls.def(#name, [](const Evaluator& s, const Ciphertext& a, Ciphertext& d, PoolArg p) { s.name(a, d, P(p)); },            \
+            py::arg("encrypted"), py::arg("destination"), POOL);                                                             \
+    cls.def(#name "_new", [](const Evaluator& s, const Ciphertext& a, PoolArg p) { return s.name##_new(a, P(p)); },          \
+            py::arg("encrypted"), POOL)
+#define EV_UNARY_INPLACE_POOL(cls, name)                                                                                     \
+    cls.def(#name "_inplace", [](const Evaluator& s, Ciphertext& a, PoolArg p) { s.name##_inplace(a, P(p)); }, py::arg("encrypted"), POOL)
+#define EV_BINARY(cls, name)                                                                                                 \
+    cls.def(#name, [](const Evaluator& s, const Ciphertext& a, const Ciphertext& b, Ciphertext& d, PoolArg p) { s.name(a, b, d, P(p)); }, \
+            py::arg("encrypted1"), py::arg("encrypted2"), py::arg("destination"), POOL);                                     \
+    cls.def(#name "_inplace", [](const Evaluator& s, Ciphertext& a, const Ciphertext& b, PoolArg p) { s.name##_inplace(a, b, P(p)); },   \
+            py::arg("encrypted1"), py::arg("encrypted2"), POOL);                                                             \
+    cls.def(#name "_new", [](const Evaluator& s, const Ciphertext& a, const Ciphertext& b, PoolArg p) { return s.name##_new(a, b, P(p)); }, \
+            py::arg("encrypted1"), py::arg("encrypted2"), POOL)
+#define EV_KEYED(cls, name, KeyT, keyarg)                                                                                    \
+    cls.def(#name, [](const Evaluator& s, const Ciphertext& a, const KeyT& k, Ciphertext& d, PoolArg p) { s.name(a, k, d, P(p)); }, \
+            py::arg("encrypted"), py::arg(keyarg), py::arg("destination"), POOL);                                            \
+    cls.def(#name "_inplace", [](const Evaluator& s, Ciphertext& a, const KeyT& k, PoolArg p) { s.name##_inplace(a, k, P(p)); },   \
+            py::arg("encrypted"), py::arg(keyarg), POOL);                                                                    \
+    cls.def(#name "_new", [](const Evaluator& s, const Ciphertext& a, const KeyT& k, PoolArg p) { return s.name##_new(a, k, P(p)); }, \
+            py::arg("encrypted"), py::arg(keyarg), POOL)
+
+template <typename T>
+static std::vector<const T*> const_ptrs(const std::vector<T*>& v) { return std::vector<const T*>(v.begin(), v.end()); }
+
+PYBIND11_MODULE(pytroy_raw, m) {
+    m.doc() = "MI355X-native troy-nova hot path: Python surface (subset of the reference's pytroy_raw)";
+    m.def("it_works", []() { return 42; });
+    m.def("device_count", &utils::device_count);
+
+    py::enum_<SchemeType>(m, "SchemeType").value("Nil", SchemeType::Nil).value("BFV", SchemeType::BFV).value("CKKS", SchemeType::CKKS).value("BGV", SchemeType::BGV);
+    py::enum_<SecurityLevel>(m, "SecurityLevel").value("Nil", SecurityLevel::Nil).value("Classical128", SecurityLevel::Classical128)
+        .value("Classical192", SecurityLevel::Classical192).value("Classical256", SecurityLevel::Classical256);
+
+    py::class_<MemoryPool, MemoryPoolHandle>(m, "MemoryPool")
+        .def(py::init([](size_t device) { return MemoryPool::create(device); }), py::arg("device") = 0)
+        .def_static("global_pool", &MemoryPool::GlobalPool)
+        .def_static("destroy_global_pool", &MemoryPool::Destroy)
+        .def("get_device", &MemoryPool::get_device)
+        .def("release_unused", &MemoryPool::release_unused);
+
+    py::class_<Modulus>(m, "Modulus")
+        .def(py::init<uint64_t>(), py::arg("value") = 0)
+        .def("value", &Modulus::value).def("bit_count", &Modulus::bit_count).def("is_prime", &Modulus::is_prime)
+        .def("is_zero", &Modulus::is_zero).def("reduce", &Modulus::reduce)
+        .def("__repr__", [](const Modulus& s) { return "Modulus(" + std::to_string(s.value()) + ")"; });
+    py::class_<CoeffModulus>(m, "CoeffModulus")
+        .def_static("max_bit_count", &CoeffModulus::max_bit_count, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128)
+        .def_static("create", &CoeffModulus::create, py::arg("poly_modulus_degree"), py::arg("bit_sizes"));
+    py::class_<PlainModulus>(m, "PlainModulus").def_static("batching", &PlainModulus::batching, py::arg("poly_modulus_degree"), py::arg("bit_size"));
+
+    py::class_<ParmsID>(m, "ParmsID")
+        .def("is_zero", &ParmsID::is_zero)
+        .def("__eq__", [](const ParmsID& a, const ParmsID& b) { return a == b; })
+        .def("__hash__", [](const ParmsID& a) { return ParmsIDHash{}(a); })
+        .def("to_vector", [](const ParmsID& a) { return std::vector<uint64_t>(a.v, a.v + 4); });
+    m.attr("parms_id_zero") = parms_id_zero;
+
+    py::class_<EncryptionParameters>(m, "EncryptionParameters")
+        .def(py::init<SchemeType>(), py::arg("scheme"))
+        .def("set_poly_modulus_degree", &EncryptionParameters::set_poly_modulus_degree)
+        .def("set_coeff_modulus", &EncryptionParameters::set_coeff_modulus)
+        .def("set_plain_modulus", py::overload_cast<const Modulus&>(&EncryptionParameters::set_plain_modulus))
+        .def("set_plain_modulus", py::overload_cast<uint64_t>(&EncryptionParameters::set_plain_modulus))
+        .def("scheme", &EncryptionParameters::scheme).def("poly_modulus_degree", &EncryptionParameters::poly_modulus_degree)
+        .def("coeff_modulus", &EncryptionParameters::coeff_modulus).def("plain_modulus", &EncryptionParameters::plain_modulus)
+        .def("parms_id", &EncryptionParameters::parms_id);
+
+    using CDP = std::shared_ptr<ContextData>;
+    auto unconst = [](const std::optional<ContextDataPointer>& c) -> std::optional<CDP> {
+        return c.has_value() ? std::optional<CDP>(std::const_pointer_cast<ContextData>(c.value())) : std::nullopt;
+    };
+    py::class_<ContextData, CDP>(m, "ContextData")
+        .def("parms", &ContextData::parms).def("parms_id", &ContextData::parms_id).def("chain_index", &ContextData::chain_index)
+        .def("next_context_data", [unconst](const ContextData& s) { return unconst(s.next_context_data()); })
+        .def("prev_context_data", [unconst](const ContextData& s) { return unconst(s.prev_context_data()); });
+
+    py::class_<HeContext, HeContextPointer>(m, "HeContext")
+        .def(py::init([](const EncryptionParameters& parms, bool expand, SecurityLevel sec, uint64_t seed) { return HeContext::create(parms, expand, sec, seed); }),
+             py::arg("parms"), py::arg("expand_mod_chain") = true, py::arg("sec_level") = SecurityLevel::Classical128, py::arg("random_seed") = 0)
+        .def("to_device_inplace", [](HeContext& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL)
+        .def("on_device", &HeContext::on_device).def("pool", &HeContext::pool)
+        .def("key_parms_id", &HeContext::key_parms_id).def("first_parms_id", &HeContext::first_parms_id).def("last_parms_id", &HeContext::last_parms_id)
+        .def("get_context_data", [unconst](const HeContext& s, const ParmsID& id) { return unconst(s.get_context_data(id)); })
+        .def("key_context_data", [unconst](const HeContext& s) { return unconst(s.key_context_data()); })
+        .def("first_context_data", [unconst](const HeContext& s) { return unconst(s.first_context_data()); })
+        .def("last_context_data", [unconst](const HeContext& s) { return unconst(s.last_context_data()); })
+        .def("using_keyswitching", &HeContext::using_keyswitching).def("parameters_set", &HeContext::parameters_set);
+
+    py::class_<Plaintext>(m, "Plaintext")
+        .def(py::init<>())
+        .def("clone", [](const Plaintext& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("on_device", &Plaintext::on_device)
+        .def("to_device_inplace", [](Plaintext& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL)
+        .def("to_host_inplace", &Plaintext::to_host_inplace)
+        .def("parms_id", [](const Plaintext& s) { return s.parms_id(); }).def("scale", [](const Plaintext& s) { return s.scale(); })
+        .def("set_scale", [](Plaintext& s, double v) { s.scale() = v; })
+        .def("coeff_count", [](const Plaintext& s) { return s.coeff_count(); }).def("is_ntt_form", [](const Plaintext& s) { return s.is_ntt_form(); })
+        .def("data", [](const Plaintext& s) { return s.data().to_vector(); });
+
+    py::class_<Ciphertext>(m, "Ciphertext")
+        .def(py::init<>())
+        .def("clone", [](const Ciphertext& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("on_device", &Ciphertext::on_device)
+        .def("to_device_inplace", [](Ciphertext& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL)
+        .def("to_host_inplace", &Ciphertext::to_host_inplace)
+        .def("parms_id", [](const Ciphertext& s) { return s.parms_id(); }).def("scale", [](const Ciphertext& s) { return s.scale(); })
+        .def("set_scale", [](Ciphertext& s, double v) { s.scale() = v; })
+        .def("polynomial_count", &Ciphertext::polynomial_count).def("coeff_modulus_size", &Ciphertext::coeff_modulus_size)
+        .def("poly_modulus_degree", &Ciphertext::poly_modulus_degree)
+        .def("is_ntt_form", [](const Ciphertext& s) { return s.is_ntt_form(); }).def("contains_seed", &Ciphertext::contains_seed)
+        .def("data", [](const Ciphertext& s) { return s.data().to_vector(); });
+
+    py::class_<SecretKey>(m, "SecretKey").def(py::init<>()).def("on_device", &SecretKey::on_device)
+        .def("clone", [](const SecretKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("data", [](const SecretKey& s) { return s.data().to_vector(); });
+    py::class_<PublicKey>(m, "PublicKey").def(py::init<>()).def("on_device", &PublicKey::on_device)
+        .def("clone", [](const PublicKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("as_ciphertext", [](const PublicKey& s) { return s.as_ciphertext(); });
+    py::class_<KSwitchKeys>(m, "KSwitchKeys").def(py::init<>()).def("on_device", &KSwitchKeys::on_device).def("parms_id", [](const KSwitchKeys& s) { return s.parms_id(); });
+    py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key);
+    py::class_<GaloisKeys, KSwitchKeys>(m, "GaloisKeys").def(py::init<>()).def("has_key", &GaloisKeys::has_key);
+
+    py::class_<KeyGenerator>(m, "KeyGenerator")
+        .def(py::init([](HeContextPointer c, PoolArg p) { return new KeyGenerator(c, P(p)); }), py::arg("context"), POOL)
+        .def(py::init([](HeContextPointer c, const SecretKey& sk, PoolArg p) { return new KeyGenerator(c, sk, P(p)); }), py::arg("context"), py::arg("secret_key"), POOL)
+        .def("on_device", &KeyGenerator::on_device).def("context", &KeyGenerator::context)
+        .def("secret_key", [](const KeyGenerator& s) { return s.secret_key().clone(); })
+        .def("create_public_key", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_public_key(save_seed, P(p)); }, py::arg("save_seed"), POOL)
+        .def("create_relin_keys", [](const KeyGenerator& s, bool save_seed, size_t max_power, PoolArg p) { return s.create_relin_keys(save_seed, max_power, P(p)); },
+             py::arg("save_seed"), py::arg("max_power") = 2, POOL)
+        .def("create_keyswitching_key", [](const KeyGenerator& s, const SecretKey& nk, bool save_seed, PoolArg p) { return s.create_keyswitching_key(nk, save_seed, P(p)); },
+             py::arg("new_key"), py::arg("save_seed"), POOL)
+        .def("create_galois_keys", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_galois_keys(save_seed, P(p)); }, py::arg("save_seed"), POOL)
+        .def("create_galois_keys_from_steps", [](const KeyGenerator& s, const std::vector<int>& st, bool save_seed, PoolArg p) { return s.create_galois_keys_from_steps(st, save_seed, P(p)); },
+             py::arg("steps"), py::arg("save_seed"), POOL)
+        .def("create_galois_keys_from_elements", [](const KeyGenerator& s, const std::vector<size_t>& el, bool save_seed, PoolArg p) { return s.create_galois_keys_from_elements(el, save_seed, P(p)); },
+             py::arg("galois_elements"), py::arg("save_seed"), POOL);
+
+    py::class_<Encryptor>(m, "Encryptor")
+        .def(py::init<HeContextPointer>()).def("context", &Encryptor::context)
+        .def("to_device_inplace", [](Encryptor&, PoolArg) {}, POOL)
+        .def("set_public_key", [](Encryptor& s, const PublicKey& k, PoolArg p) { s.set_public_key(k, P(p)); }, py::arg("public_key"), POOL)
+        .def("set_secret_key", [](Encryptor& s, const SecretKey& k, PoolArg p) { s.set_secret_key(k, P(p)); }, py::arg("secret_key"), POOL)
+        .def("encrypt_asymmetric", [](const Encryptor& s, const Plaintext& pl, Ciphertext& d, PoolArg p) { s.encrypt_asymmetric(pl, d, P(p)); }, py::arg("plain"), py::arg("destination"), POOL)
+        .def("encrypt_asymmetric_new", [](const Encryptor& s, const Plaintext& pl, PoolArg p) { return s.encrypt_asymmetric_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("encrypt_symmetric", [](const Encryptor& s, const Plaintext& pl, bool seed, Ciphertext& d, PoolArg p) { s.encrypt_symmetric(pl, seed, d, P(p)); },
+             py::arg("plain"), py::arg("save_seed"), py::arg("destination"), POOL)
+        .def("encrypt_symmetric_new", [](const Encryptor& s, const Plaintext& pl, bool seed, PoolArg p) { return s.encrypt_symmetric_new(pl, seed, P(p)); },
+             py::arg("plain"), py::arg("save_seed"), POOL)
+        .def("encrypt_zero_asymmetric_new", [](const Encryptor& s, std::optional<ParmsID> id, PoolArg p) { return s.encrypt_zero_asymmetric_new(id, P(p)); },
+             py::arg("parms_id") = std::nullopt, POOL)
+        .def("encrypt_zero_symmetric_new", [](const Encryptor& s, bool seed, std::optional<ParmsID> id, PoolArg p) { return s.encrypt_zero_symmetric_new(seed, id, P(p)); },
+             py::arg("save_seed"), py::arg("parms_id") = std::nullopt, POOL);
+
+    py::class_<Decryptor>(m, "Decryptor")
+        .def(py::init([](HeContextPointer c, const SecretKey& sk, PoolArg p) { return new Decryptor(c, sk, P(p)); }), py::arg("context"), py::arg("secret_key"), POOL)
+        .def("to_device_inplace", [](Decryptor&, PoolArg) {}, POOL).def("on_device", &Decryptor::on_device)
+        .def("decrypt", [](const Decryptor& s, const Ciphertext& c, Plaintext& d, PoolArg p) { s.decrypt(c, d, P(p)); }, py::arg("encrypted"), py::arg("destination"), POOL)
+        .def("decrypt_new", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.decrypt_new(c, P(p)); }, py::arg("encrypted"), POOL);
+
+    py::class_<BatchEncoder>(m, "BatchEncoder")
+        .def(py::init<HeContextPointer>()).def("context", &BatchEncoder::context).def("slot_count", &BatchEncoder::slot_count)
+        .def("on_device", &BatchEncoder::on_device).def("to_device_inplace", [](BatchEncoder&, PoolArg) {}, POOL)
+        .def("encode_simd", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
+        .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
+        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL);
+
+    py::class_<Evaluator> ev(m, "Evaluator");
+    ev.def(py::init<HeContextPointer>()).def("context", &Evaluator::context).def("on_device", &Evaluator::on_device);
+    EV_UNARY(ev, negate);
+    ev.def("negate_inplace", [](const Evaluator& s, Ciphertext& a) { s.negate_inplace(a); }, py::arg("encrypted"));
+    EV_BINARY(ev, add);
+    EV_BINARY(ev, sub);
+    EV_BINARY(ev, multiply);
+    EV_UNARY(ev, square);
+    EV_UNARY_INPLACE_POOL(ev, square);
+    EV_KEYED(ev, relinearize, RelinKeys, "relin_keys");
+    EV_KEYED(ev, apply_keyswitching, KSwitchKeys, "kswitch_keys");
+    EV_UNARY(ev, mod_switch_to_next);
+    EV_UNARY_INPLACE_POOL(ev, mod_switch_to_next);
+    EV_UNARY(ev, rescale_to_next);
+    EV_UNARY_INPLACE_POOL(ev, rescale_to_next);
+    EV_UNARY(ev, transform_to_ntt);
+    EV_UNARY(ev, transform_from_ntt);
+    ev.def("transform_to_ntt_inplace", [](const Evaluator& s, Ciphertext& a) { s.transform_to_ntt_inplace(a); }, py::arg("encrypted"));
+    ev.def("transform_from_ntt_inplace", [](const Evaluator& s, Ciphertext& a) { s.transform_from_ntt_inplace(a); }, py::arg("encrypted"));
+    ev.def("mod_switch_to", [](const Evaluator& s, const Ciphertext& a, const ParmsID& id, Ciphertext& d, PoolArg p) { s.mod_switch_to(a, id, d, P(p)); },
+           py::arg("encrypted"), py::arg("parms_id"), py::arg("destination"), POOL);
+    ev.def("mod_switch_to_inplace", [](const Evaluator& s, Ciphertext& a, const ParmsID& id, PoolArg p) { s.mod_switch_to_inplace(a, id, P(p)); }, py::arg("encrypted"), py::arg("parms_id"), POOL);
+    ev.def("mod_switch_to_new", [](const Evaluator& s, const Ciphertext& a, const ParmsID& id, PoolArg p) { return s.mod_switch_to_new(a, id, P(p)); }, py::arg("encrypted"), py::arg("parms_id"), POOL);
+    // ciphertext x plaintext
+    ev.def("multiply_plain", [](const Evaluator& s, const Ciphertext& a, const Plaintext& w, Ciphertext& d, PoolArg p) { s.multiply_plain(a, w, d, P(p)); },
+           py::arg("encrypted"), py::arg("plain"), py::arg("destination"), POOL);
+    ev.def("multiply_plain_inplace", [](const Evaluator& s, Ciphertext& a, const Plaintext& w, PoolArg p) { s.multiply_plain_inplace(a, w, P(p)); }, py::arg("encrypted"), py::arg("plain"), POOL);
+    ev.def("multiply_plain_new", [](const Evaluator& s, const Ciphertext& a, const Plaintext& w, PoolArg p) { return s.multiply_plain_new(a, w, P(p)); }, py::arg("encrypted"), py::arg("plain"), POOL);
+    ev.def("transform_plain_to_ntt_new", [](const Evaluator& s, const Plaintext& w, const ParmsID& id, PoolArg p) { return s.transform_plain_to_ntt_new(w, id, P(p)); },
+           py::arg("plain"), py::arg("parms_id"), POOL);
+    ev.def("multiply_plain_accumulate", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Plaintext*>& w, const std::vector<Ciphertext*>& d, bool set_zero, PoolArg p) {
+        s.multiply_plain_accumulate(const_ptrs(a), const_ptrs(w), d, set_zero, P(p));
+    }, py::arg("encrypted"), py::arg("plain"), py::arg("destination"), py::arg("set_zero"), POOL);
+    // batched forms (lists of objects)
+    ev.def("add_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Ciphertext*>& b, const std::vector<Ciphertext*>& d, PoolArg p) {
+        s.add_batched(const_ptrs(a), const_ptrs(b), d, P(p)); }, py::arg("encrypted1"), py::arg("encrypted2"), py::arg("destination"), POOL);
+    ev.def("multiply_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Ciphertext*>& b, const std::vector<Ciphertext*>& d, PoolArg p) {
+        s.multiply_batched(const_ptrs(a), const_ptrs(b), d, P(p)); }, py::arg("encrypted1"), py::arg("encrypted2"), py::arg("destination"), POOL);
+    ev.def("relinearize_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const RelinKeys& k, const std::vector<Ciphertext*>& d, PoolArg p) {
+        s.relinearize_batched(const_ptrs(a), k, d, P(p)); }, py::arg("encrypted"), py::arg("relin_keys"), py::arg("destination"), POOL);
+    ev.def("rescale_to_next_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Ciphertext*>& d, PoolArg p) {
+        s.rescale_to_next_batched(const_ptrs(a), d, P(p)); }, py::arg("encrypted"), py::arg("destination"), POOL);
+    // Galois
+    ev.def("apply_galois", [](const Evaluator& s, const Ciphertext& a, size_t g, const GaloisKeys& k, Ciphertext& d, PoolArg p) { s.apply_galois(a, g, k, d, P(p)); },
+           py::arg("encrypted"), py::arg("galois_element"), py::arg("galois_keys"), py::arg("destination"), POOL);
+    ev.def("apply_galois_new", [](const Evaluator& s, const Ciphertext& a, size_t g, const GaloisKeys& k, PoolArg p) { return s.apply_galois_new(a, g, k, P(p)); },
+           py::arg("encrypted"), py::arg("galois_element"), py::arg("galois_keys"), POOL);
+    ev.def("rotate_rows", [](const Evaluator& s, const Ciphertext& a, int st, const GaloisKeys& k, Ciphertext& d, PoolArg p) { s.rotate_rows(a, st, k, d, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), py::arg("destination"), POOL);
+    ev.def("rotate_rows_inplace", [](const Evaluator& s, Ciphertext& a, int st, const GaloisKeys& k, PoolArg p) { s.rotate_rows_inplace(a, st, k, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
+    ev.def("rotate_rows_new", [](const Evaluator& s, const Ciphertext& a, int st, const GaloisKeys& k, PoolArg p) { return s.rotate_rows_new(a, st, k, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
+    EV_KEYED(ev, rotate_columns, GaloisKeys, "galois_keys");
+}
