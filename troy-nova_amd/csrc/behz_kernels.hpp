@@ -35,6 +35,23 @@ struct BehzDev {
     const ulonglong2* neg_prod_B_mod_q;     // [L]   -B mod q_i                     (Shoup)
 };
 
+// The conversion matrices and per-modulus constants are never written by a kernel and every access has a
+// wave-uniform index: reading them through the constant address space turns ~300 dependent vector loads per
+// coefficient into scalar loads (SGPR operands of the multiplies).
+typedef const u64 __attribute__((address_space(4)))* cu64p;
+typedef u64 u64x2c __attribute__((ext_vector_type(2)));
+typedef const u64x2c __attribute__((address_space(4)))* cu64x2p;
+typedef const DevModulus __attribute__((address_space(4)))* cmodp;
+template <typename T> __device__ __forceinline__ cu64p as_c64(const T* p) { return (cu64p)(unsigned long long)p; }
+template <typename T> __device__ __forceinline__ cu64x2p as_c128(const T* p) { return (cu64x2p)(unsigned long long)p; }
+__device__ __forceinline__ cmodp as_cmod(const DevModulus* p) { return (cmodp)(unsigned long long)p; }
+__device__ __forceinline__ ulonglong2 ld_pair(cu64x2p p, unsigned i) { const u64x2c v = p[i]; return make_ulonglong2(v.x, v.y); }
+__device__ __forceinline__ DevModulus ld_mod(cmodp p, unsigned i) {
+    DevModulus m;
+    m.q = p[i].q; m.ratio_lo = p[i].ratio_lo; m.ratio_hi = p[i].ratio_hi;
+    return m;
+}
+
 // BaseConverter::fast_convert_array step 1: x * inv_punc mod q (barrett when the operand is 1,
 // utils/rns_base.cu:358-366)
 __device__ __forceinline__ u64 conv_scale(u64 x, const ulonglong2 op, const DevModulus& m) {
@@ -50,33 +67,36 @@ __global__ __launch_bounds__(256) void behz_lift_kernel(unsigned chunks, BehzDev
     const u64* ip = in + item * (size_t)L * n;
     u64* op = out + item * (size_t)Bsk * n;
     const u64 mt = c.m_tilde.q;
+    const cmodp q_mods = as_cmod(c.q_mods), bsk_mods = as_cmod(c.bsk_mods);
+    const cu64x2p q_inv_punc = as_c128(c.q_inv_punc), prod_q_mod_bsk = as_c128(c.prod_q_mod_bsk), inv_mt_mod_bsk = as_c128(c.inv_mt_mod_bsk);
+    const cu64p q_to_mt = as_c64(c.q_to_mt), q_to_bsk = as_c64(c.q_to_bsk);
     for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
         u64 y[MAXL];
 #pragma unroll
         for (int i = 0; i < MAXL; ++i) {
             if (i < (int)L) {
-                const DevModulus md = c.q_mods[i];
+                const DevModulus md = ld_mod(q_mods, i);
                 const u64 v = mul_mod(ip[(size_t)i * n + x], mt, md);      // multiply_scalar_p by m_tilde
-                y[i] = conv_scale(v, c.q_inv_punc[i], md);
+                y[i] = conv_scale(v, ld_pair(q_inv_punc, i), md);
             } else y[i] = 0;
         }
         // q -> {m_tilde}
         u64 lo = 0, hi = 0;
 #pragma unroll
-        for (int i = 0; i < MAXL; ++i) if (i < (int)L) mac128(lo, hi, y[i], c.q_to_mt[i]);
+        for (int i = 0; i < MAXL; ++i) if (i < (int)L) mac128(lo, hi, y[i], q_to_mt[i]);
         const u64 in_mt = barrett128(lo, hi, mt, c.m_tilde.ratio_lo, c.m_tilde.ratio_hi);
         const u64 r_mt = shoup_mul(in_mt, c.neg_inv_prod_q_mod_mt.x, c.neg_inv_prod_q_mod_mt.y, mt);
         const u64 mt_half = mt >> 1;
         for (unsigned b = 0; b < Bsk; ++b) {
-            const DevModulus mb = c.bsk_mods[b];
+            const DevModulus mb = ld_mod(bsk_mods, b);
             lo = 0; hi = 0;
-            const u64* row = c.q_to_bsk + (size_t)b * L;
+            const cu64p row = q_to_bsk + (size_t)b * L;
 #pragma unroll
             for (int i = 0; i < MAXL; ++i) if (i < (int)L) mac128(lo, hi, y[i], row[i]);
             const u64 in_b = barrett128(lo, hi, mb.q, mb.ratio_lo, mb.ratio_hi);
             u64 temp = r_mt;
             if (temp >= mt_half) temp += mb.q - mt;
-            const ulonglong2 pq = c.prod_q_mod_bsk[b], im = c.inv_mt_mod_bsk[b];
+            const ulonglong2 pq = ld_pair(prod_q_mod_bsk, b), im = ld_pair(inv_mt_mod_bsk, b);
             const u64 mad = add_mod(shoup_mul(temp, pq.x, pq.y, mb.q), barrett64(in_b, mb.q, mb.ratio_hi), mb.q);
             op[(size_t)b * n + x] = shoup_mul(mad, im.x, im.y, mb.q);
         }
@@ -91,14 +111,18 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
     const u64* qp = in_q + item * (size_t)L * n;
     const u64* bp = in_bsk + item * (size_t)Bsk * n;
     u64* op = out + item * (size_t)L * n;
+    const cmodp q_mods = as_cmod(c.q_mods), bsk_mods = as_cmod(c.bsk_mods);
+    const cu64x2p q_inv_punc = as_c128(c.q_inv_punc), inv_prod_q_mod_bsk = as_c128(c.inv_prod_q_mod_bsk), B_inv_punc = as_c128(c.B_inv_punc),
+                  prod_B_mod_q = as_c128(c.prod_B_mod_q), neg_prod_B_mod_q = as_c128(c.neg_prod_B_mod_q);
+    const cu64p q_to_bsk = as_c64(c.q_to_bsk), B_to_q = as_c64(c.B_to_q), B_to_msk = as_c64(c.B_to_msk);
     for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
         u64 y[MAXB];   // first the scaled q residues (L <= MAXB), later the scaled B residues
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
             if (i < (int)L) {
-                const DevModulus md = c.q_mods[i];
+                const DevModulus md = ld_mod(q_mods, i);
                 const u64 v = mul_mod(qp[(size_t)i * n + x], c.t, md);       // step (6): times t
-                y[i] = conv_scale(v, c.q_inv_punc[i], md);
+                y[i] = conv_scale(v, ld_pair(q_inv_punc, i), md);
             } else y[i] = 0;
         }
         // step (7) fast_floor into Bsk
@@ -106,40 +130,40 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             if (b < (int)Bsk) {
-                const DevModulus mb = c.bsk_mods[b];
+                const DevModulus mb = ld_mod(bsk_mods, b);
                 u64 lo = 0, hi = 0;
-                const u64* row = c.q_to_bsk + (size_t)b * L;
+                const cu64p row = q_to_bsk + (size_t)b * L;
 #pragma unroll
                 for (int i = 0; i < MAXB; ++i) if (i < (int)L) mac128(lo, hi, y[i], row[i]);
                 const u64 f = barrett128(lo, hi, mb.q, mb.ratio_lo, mb.ratio_hi);
                 const u64 tb = mul_mod(bp[(size_t)b * n + x], c.t, mb);
-                const ulonglong2 iq = c.inv_prod_q_mod_bsk[b];
+                const ulonglong2 iq = ld_pair(inv_prod_q_mod_bsk, b);
                 r[b] = shoup_mul(tb + mb.q - f, iq.x, iq.y, mb.q);
             } else r[b] = 0;
         }
         // step (8) fast_b_conv_sk: B -> q and B -> {m_sk}
-        const DevModulus msk = c.bsk_mods[Bn];
+        const DevModulus msk = ld_mod(bsk_mods, Bn);
         u64 r_sk = 0;
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
             if (b == (int)Bn) r_sk = r[b];
-            if (b < (int)Bn) y[b] = conv_scale(r[b], c.B_inv_punc[b], c.bsk_mods[b]);
+            if (b < (int)Bn) y[b] = conv_scale(r[b], ld_pair(B_inv_punc, b), ld_mod(bsk_mods, b));
         }
         u64 lo = 0, hi = 0;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < (int)Bn) mac128(lo, hi, y[b], c.B_to_msk[b]);
+        for (int b = 0; b < MAXB; ++b) if (b < (int)Bn) mac128(lo, hi, y[b], B_to_msk[b]);
         const u64 h = barrett128(lo, hi, msk.q, msk.ratio_lo, msk.ratio_hi);
         const u64 alpha_sk = shoup_mul(h + (msk.q - r_sk), c.inv_prod_B_mod_msk.x, c.inv_prod_B_mod_msk.y, msk.q);
         const bool neg = alpha_sk > (msk.q >> 1);
         const u64 alpha_use = neg ? neg_mod(alpha_sk, msk.q) : alpha_sk;
         for (unsigned i = 0; i < L; ++i) {
-            const DevModulus md = c.q_mods[i];
+            const DevModulus md = ld_mod(q_mods, i);
             lo = 0; hi = 0;
-            const u64* row = c.B_to_q + (size_t)i * Bn;
+            const cu64p row = B_to_q + (size_t)i * Bn;
 #pragma unroll
             for (int b = 0; b < MAXB; ++b) if (b < (int)Bn) mac128(lo, hi, y[b], row[b]);
             const u64 g = barrett128(lo, hi, md.q, md.ratio_lo, md.ratio_hi);
-            const ulonglong2 f = neg ? c.prod_B_mod_q[i] : c.neg_prod_B_mod_q[i];
+            const ulonglong2 f = neg ? ld_pair(prod_B_mod_q, i) : ld_pair(neg_prod_B_mod_q, i);
             op[(size_t)i * n + x] = add_mod(shoup_mul(alpha_use, f.x, f.y, md.q), barrett64(g, md.q, md.ratio_hi), md.q);
         }
     }
