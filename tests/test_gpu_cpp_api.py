@@ -97,3 +97,21 @@ def test_quickstart_cpp_api(dev):
     r2 = subprocess.run([drv, "0x456"], capture_output=True, text=True, timeout=600)
     kv2 = {ln.split()[0]: ln.split()[1:] for ln in r2.stdout.splitlines() if ln.strip()}
     assert kv2["ct_digest"] != kv["ct_digest"] and kv2["mul"] == kv["mul"]
+
+
+def test_ckks_cpp_api(dev):
+    """BASELINE config 3's parameters through the C++ mirror with the CKKS encoder: every result must decode to the
+    expected slots (tolerances: fresh 1e-6, after one multiplication + rescale at scale 2^30 1e-3)."""
+    drv = os.path.join(ROOT, "tests", "cpp", "ckks_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/ckks_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert float(kv["encode_roundtrip"][0]) < 1e-8
+    assert float(kv["decrypt"][0]) < 1e-6 and float(kv["add"][0]) < 1e-6
+    assert kv["levels"][0] == "4" and abs(float(kv["levels"][2]) - 30.0) < 0.01
+    for k in ("mul_relin_rescale", "multiply_plain"):
+        assert float(kv[k][0]) < 1e-3, k
+    for k in ("rotate1", "rotate-3", "conjugate"):
+        assert float(kv[k][0]) < 1e-4, k

@@ -93,3 +93,32 @@ def test_quickstart_flow_in_python(pytroy, dev):
     with pytest.raises(ValueError):
         evaluator.add_new(host, c)                                      # std::invalid_argument -> ValueError
     pytroy.MemoryPool.destroy_global_pool()
+
+
+@pytest.mark.gpu
+def test_ckks_flow_in_python(pytroy, dev):
+    import cmath
+    import random
+    p = _params(pytroy, pytroy.SchemeType.CKKS, 8192, [40, 40, 40, 40])
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Classical128, 99)
+    ctx.to_device_inplace()
+    enc = pytroy.CKKSEncoder(ctx)
+    kg = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_public_key(kg.create_public_key(False))
+    dec = pytroy.Decryptor(ctx, kg.secret_key())
+    ev = pytroy.Evaluator(ctx)
+    rnd = random.Random(3)
+    z1 = [complex(rnd.uniform(-1, 1), rnd.uniform(-1, 1)) for _ in range(enc.slot_count())]
+    z2 = [complex(rnd.uniform(-1, 1), rnd.uniform(-1, 1)) for _ in range(enc.slot_count())]
+    scale = float(1 << 30)
+    c1 = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z1, None, scale))
+    c2 = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z2, None, scale))
+    m = ev.relinearize_new(ev.multiply_new(c1, c2), kg.create_relin_keys(False))
+    ev.rescale_to_next_inplace(m)
+    got = enc.decode_complex64_simd_new(dec.decrypt_new(m))
+    assert max(abs(g - a * b) for g, a, b in zip(got, z1, z2)) < 1e-2
+    gk = kg.create_galois_keys_from_steps([2], False)
+    rot = enc.decode_complex64_simd_new(dec.decrypt_new(ev.rotate_vector_new(c1, 2, gk)))
+    assert max(abs(rot[i] - z1[(i + 2) % len(z1)]) for i in range(len(z1))) < 2e-2   # scale 2^30: key-switch noise ~2^-10
+    pytroy.MemoryPool.destroy_global_pool()

@@ -3,6 +3,7 @@
 // (call context.to_device_inplace() first), and host-resident operands raise ValueError / RuntimeError exactly as the
 // C++ exceptions map (std::invalid_argument -> ValueError).
 #include <pybind11/pybind11.h>
+#include <pybind11/complex.h>
 #include <pybind11/stl.h>
 
 #include <optional>
@@ -183,6 +184,19 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
         .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL);
 
+    py::class_<CKKSEncoder>(m, "CKKSEncoder")
+        .def(py::init<HeContextPointer>()).def("context", &CKKSEncoder::context).def("slot_count", &CKKSEncoder::slot_count)
+        .def("polynomial_modulus_degree", &CKKSEncoder::polynomial_modulus_degree).def("on_device", &CKKSEncoder::on_device)
+        .def("to_device_inplace", [](CKKSEncoder&, PoolArg) {}, POOL)
+        .def("encode_complex64_simd_new", [](const CKKSEncoder& s, const std::vector<std::complex<double>>& v, std::optional<ParmsID> id, double scale, PoolArg p) {
+            return s.encode_complex64_simd_new(v, id, scale, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), POOL)
+        .def("encode_float64_polynomial_new", [](const CKKSEncoder& s, const std::vector<double>& v, std::optional<ParmsID> id, double scale, PoolArg p) {
+            return s.encode_float64_polynomial_new(v, id, scale, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), POOL)
+        .def("encode_float64_single_new", [](const CKKSEncoder& s, double v, std::optional<ParmsID> id, double scale, PoolArg p) {
+            return s.encode_float64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
+        .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL);
+
     py::class_<Evaluator> ev(m, "Evaluator");
     ev.def(py::init<HeContextPointer>()).def("context", &Evaluator::context).def("on_device", &Evaluator::on_device);
     EV_UNARY(ev, negate);
@@ -237,4 +251,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
     ev.def("rotate_rows_new", [](const Evaluator& s, const Ciphertext& a, int st, const GaloisKeys& k, PoolArg p) { return s.rotate_rows_new(a, st, k, P(p)); },
            py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
     EV_KEYED(ev, rotate_columns, GaloisKeys, "galois_keys");
+    ev.def("rotate_vector_new", [](const Evaluator& s, const Ciphertext& a, int st, const GaloisKeys& k, PoolArg p) { return s.rotate_vector_new(a, st, k, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
+    ev.def("rotate_vector_inplace", [](const Evaluator& s, Ciphertext& a, int st, const GaloisKeys& k, PoolArg p) { s.rotate_vector_inplace(a, st, k, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
+    ev.def("complex_conjugate_new", [](const Evaluator& s, const Ciphertext& a, const GaloisKeys& k, PoolArg p) { return s.complex_conjugate_new(a, k, P(p)); },
+           py::arg("encrypted"), py::arg("galois_keys"), POOL);
 }

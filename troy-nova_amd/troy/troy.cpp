@@ -1654,4 +1654,202 @@ void BatchEncoder::decode(const Plaintext& plain, std::vector<uint64_t>& destina
     for (size_t i = 0; i < slots_; i++) destination[i] = host[matrix_reps_index_map_[i]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// CKKSEncoder  (ckks_encoder.cu)
+// ------------------------------------------------------------------------------------------------
+void Evaluator::rotate_vector(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    if (context_->key_context_data().value()->parms().scheme() != SchemeType::CKKS)
+        throw std::invalid_argument("[Evaluator::rotate_vector_inplace] Rotate vector only applies for CKKS");
+    rotate_internal(encrypted, steps, galois_keys, destination, pool);
+}
+
+void Evaluator::complex_conjugate(const Ciphertext& encrypted, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    if (context_->key_context_data().value()->parms().scheme() != SchemeType::CKKS)
+        throw std::invalid_argument("[Evaluator::complex_conjugate_inplace] Complex conjugate only applies for CKKS");
+    auto cd = get_context_data("[Evaluator::conjugate_inplace_internal]", encrypted.parms_id());
+    apply_galois(encrypted, utils::galois_element_from_step(cd->parms().poly_modulus_degree(), 0), galois_keys, destination, pool);
+}
+
+CKKSEncoder::CKKSEncoder(HeContextPointer context) : context_(std::move(context)) {
+    // ckks_encoder.cu:121-183 (the reference wants a host context here and moves the encoder later; this build is
+    // device-only, so either order is accepted)
+    if (!context_->parameters_set()) throw std::invalid_argument("[CKKSEncoder::CKKSEncoder] Encryption parameters are not set correctly.");
+    const EncryptionParameters& parms = context_->first_context_data().value()->parms();
+    if (parms.scheme() != SchemeType::CKKS) throw std::invalid_argument("[CKKSEncoder::CKKSEncoder] Unsupported scheme.");
+    const size_t n = parms.poly_modulus_degree();
+    if (n < 4) throw std::invalid_argument("[CKKSEncoder::CKKSEncoder] Poly modulus degree is too small.");
+    slots_ = n / 2;
+    size_t logn = 0;
+    while ((size_t(1) << logn) < n) logn++;
+    matrix_reps_index_map_.resize(n);
+    const size_t m = n << 1;
+    size_t pos = 1;
+    for (size_t i = 0; i < slots_; i++) {
+        matrix_reps_index_map_[i] = reverse_bits_sz((pos - 1) >> 1, logn);
+        matrix_reps_index_map_[i + slots_] = reverse_bits_sz((m - pos - 1) >> 1, logn);
+        pos = (pos * 3) & (m - 1);
+    }
+    // psi = exp(2 pi i / m); root_powers[i] = psi^bitrev(i), inv_root_powers[i] = conj(psi^(bitrev(i-1)+1))
+    const double pi = 3.14159265358979323846264338327950288;
+    auto root = [&](size_t k) { const double ang = 2.0 * pi * static_cast<double>(k % m) / static_cast<double>(m); return std::complex<double>(std::cos(ang), std::sin(ang)); };
+    root_powers_.assign(n, {0, 0});
+    inv_root_powers_.assign(n, {0, 0});
+    for (size_t i = 1; i < n; i++) {
+        root_powers_[i] = root(reverse_bits_sz(i, logn));
+        inv_root_powers_[i] = std::conj(root(reverse_bits_sz(i - 1, logn) + 1));
+    }
+}
+
+void CKKSEncoder::set_plaintext(const std::vector<double>& coeffs, const ParmsID& parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool) const {
+    // set_plaintext_value_array (ckks_encoder.cu:454-690): scaled real coefficients -> residues, then NTT
+    const char* P = "[CKKSEncoder::encode_internal]";
+    if (!context_->on_device()) throw std::invalid_argument(std::string(P) + " HeContext is not on device (call to_device_inplace).");
+    auto cdo = context_->get_context_data(parms_id);
+    if (!cdo.has_value()) throw std::invalid_argument("[CKKSEncoder::encode_internal_complex_array] parms_id not valid for context.");
+    const EncryptionParameters& parms = cdo.value()->parms();
+    const auto& q = parms.coeff_modulus();
+    const size_t n = parms.poly_modulus_degree(), L = q.size();
+    size_t total_bits = 0;
+    for (const Modulus& mdl : q) total_bits += mdl.bit_count();
+    if (scale <= 0 || std::log2(scale) + 1.0 >= static_cast<double>(total_bits))
+        throw std::invalid_argument("[CKKSEncoder::encode_internal_complex_array] scale out of bounds.");
+    std::vector<uint64_t> host(L * n, 0);
+    const double two64 = 18446744073709551616.0;
+    for (size_t j = 0; j < n && j < coeffs.size(); j++) {
+        const double v = std::nearbyint(coeffs[j]);
+        const bool neg = v < 0;
+        double a = std::fabs(v);
+        if (a >= two64 * two64) throw std::invalid_argument("[CKKSEncoder::encode_internal_complex_array] encoded values are too large.");
+        const uint64_t hi = static_cast<uint64_t>(a / two64);
+        const uint64_t lo = static_cast<uint64_t>(a - static_cast<double>(hi) * two64);
+        for (size_t i = 0; i < L; i++) {
+            const uint64_t qi = q[i].value();
+            uint64_t r = static_cast<uint64_t>(((static_cast<unsigned __int128>(hi) << 64) | lo) % qi);
+            host[i * n + j] = (neg && r) ? qi - r : r;
+        }
+    }
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, parms_id);
+    out.data().copy_from(host.data(), host.size(), false);
+    troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    out.scale() = scale;
+    out.is_ntt_form() = true;
+    destination = std::move(out);
+}
+
+void CKKSEncoder::encode_complex64_simd(const std::vector<std::complex<double>>& values, std::optional<ParmsID> parms_id, double scale,
+                                        Plaintext& destination, MemoryPoolHandle pool) const {
+    // ckks_encoder.cu:693-776
+    if (values.size() > slots_) throw std::invalid_argument("[CKKSEncoder::encode_internal_complex_array] Too many input values.");
+    const size_t n = slots_ * 2;
+    std::vector<std::complex<double>> a(n, {0, 0});
+    for (size_t i = 0; i < values.size(); i++) {                      // set_conjugate_values
+        a[matrix_reps_index_map_[i]] = values[i];
+        a[matrix_reps_index_map_[i + slots_]] = std::conj(values[i]);
+    }
+    // fft_transform_from_rev: Gentleman-Sande layers with the inverse root powers, then scale / n
+    size_t root_index = 1;
+    for (size_t mm = n >> 1, gap = 1; mm >= 1; mm >>= 1, gap <<= 1) {
+        size_t offset = 0;
+        for (size_t i = 0; i < mm; i++) {
+            const std::complex<double> r = inv_root_powers_[root_index++];
+            for (size_t j = offset; j < offset + gap; j++) {
+                const std::complex<double> u = a[j], v = a[j + gap];
+                a[j] = u + v;
+                a[j + gap] = (u - v) * r;
+            }
+            offset += gap << 1;
+        }
+        if (mm == 1) break;
+    }
+    const double fix = scale / static_cast<double>(n);
+    std::vector<double> coeffs(n);
+    for (size_t i = 0; i < n; i++) coeffs[i] = a[i].real() * fix;
+    set_plaintext(coeffs, parms_id.value_or(context_->first_parms_id()), scale, destination, pool);
+}
+
+void CKKSEncoder::encode_float64_polynomial(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
+                                            MemoryPoolHandle pool) const {
+    // ckks_encoder.cu:777-848: coefficients directly
+    if (values.size() > slots_ * 2) throw std::invalid_argument("[CKKSEncoder::encode_internal_double_polynomial] Too many input values.");
+    std::vector<double> coeffs(values.size());
+    for (size_t i = 0; i < values.size(); i++) coeffs[i] = values[i] * scale;
+    set_plaintext(coeffs, parms_id.value_or(context_->first_parms_id()), scale, destination, pool);
+}
+
+std::vector<double> CKKSEncoder::plaintext_coefficients(const Plaintext& plain, MemoryPoolHandle pool) const {
+    // decode_internal (ckks_encoder.cu:947-1290): INTT, CRT-compose, centre.  Mixed-radix (Garner) digits instead of the
+    // reference's multi-word compose: x = d_0 + q_0 (d_1 + q_1 (d_2 + ...)), evaluated in long double from the top.
+    const char* P = "[CKKSEncoder::decode_internal]";
+    if (!plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is not in NTT form.");
+    auto cdo = context_->get_context_data(plain.parms_id());
+    if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " Plaintext parms_id is not valid.");
+    const auto& q = cdo.value()->parms().coeff_modulus();
+    const size_t n = cdo.value()->parms().poly_modulus_degree(), L = q.size();
+    utils::DynamicArray tmp(L * n, true, pool);
+    troyn_check(troyn_ntt(context_->plan(), 1, plain.poly(), tmp.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    std::vector<uint64_t> h = tmp.to_vector();
+    auto mulmod = [](uint64_t a, uint64_t b, uint64_t m) { return static_cast<uint64_t>(static_cast<unsigned __int128>(a) * b % m); };
+    auto invmod = [&](uint64_t a, uint64_t m) {   // m prime
+        uint64_t r = 1, e = m - 2, b = a % m;
+        while (e) { if (e & 1) r = mulmod(r, b, m); b = mulmod(b, b, m); e >>= 1; }
+        return r;
+    };
+    // inv[i][j] = q_j^-1 mod q_i (j < i)
+    std::vector<std::vector<uint64_t>> inv(L);
+    for (size_t i = 0; i < L; i++) for (size_t j = 0; j < i; j++) inv[i].push_back(invmod(q[j].value() % q[i].value(), q[i].value()));
+    std::vector<double> out(n);
+    std::vector<uint64_t> d(L);
+    for (size_t x = 0; x < n; x++) {
+        for (size_t i = 0; i < L; i++) {
+            const uint64_t qi = q[i].value();
+            uint64_t v = h[i * n + x] % qi;
+            for (size_t j = 0; j < i; j++) {
+                const uint64_t dj = d[j] % qi;
+                v = mulmod(v >= dj ? v - dj : v + qi - dj, inv[i][j], qi);
+            }
+            d[i] = v;
+        }
+        // x > Q/2  <=>  the top digit decides (ties resolved by lower digits; a tie is measure-zero for real data)
+        bool negative = 2 * static_cast<unsigned __int128>(d[L - 1]) >= q[L - 1].value();
+        if (negative) {                      // Q - x: complement the digits, add one
+            for (size_t i = 0; i < L; i++) d[i] = q[i].value() - 1 - d[i];
+            for (size_t i = 0; i < L; i++) { if (++d[i] < q[i].value()) break; d[i] = 0; }
+        }
+        long double acc = 0;
+        for (size_t i = L; i-- > 0;) acc = acc * static_cast<long double>(q[i].value()) + static_cast<long double>(d[i]);
+        out[x] = static_cast<double>(negative ? -acc : acc);
+    }
+    return out;
+}
+
+void CKKSEncoder::decode_float64_polynomial(const Plaintext& plain, std::vector<double>& destination, MemoryPoolHandle pool) const {
+    destination = plaintext_coefficients(plain, pool);
+    for (double& v : destination) v /= plain.scale();
+}
+
+void CKKSEncoder::decode_complex64_simd(const Plaintext& plain, std::vector<std::complex<double>>& destination, MemoryPoolHandle pool) const {
+    const std::vector<double> c = plaintext_coefficients(plain, pool);
+    const size_t n = slots_ * 2;
+    std::vector<std::complex<double>> a(n);
+    for (size_t i = 0; i < n; i++) a[i] = std::complex<double>(c[i] / plain.scale(), 0.0);
+    // fft_transform_to_rev: Cooley-Tukey layers with the root powers (natural -> bit-reversed)
+    size_t root_index = 1;
+    for (size_t mm = 1, gap = n >> 1; mm < n; mm <<= 1, gap >>= 1) {
+        size_t offset = 0;
+        for (size_t i = 0; i < mm; i++) {
+            const std::complex<double> r = root_powers_[root_index++];
+            for (size_t j = offset; j < offset + gap; j++) {
+                const std::complex<double> u = a[j], v = a[j + gap] * r;
+                a[j] = u + v;
+                a[j + gap] = u - v;
+            }
+            offset += gap << 1;
+        }
+    }
+    destination.resize(slots_);
+    for (size_t i = 0; i < slots_; i++) destination[i] = a[matrix_reps_index_map_[i]];
+}
+
 }  // namespace troy

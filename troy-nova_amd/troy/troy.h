@@ -22,6 +22,7 @@
 //   * multiply / relinearize / rescale also exist as *_batched (the reference lists them as
 //     "not implemented yet", test/bench/he_operations.cpp:119-135).
 #pragma once
+#include <complex>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -540,6 +541,47 @@ private:
 };
 
 // ----------------------------------------------------------------------------------------------
+// CKKSEncoder  (src/ckks_encoder.h, ckks_encoder.cu).  The canonical-embedding FFT and the RNS conversion of the
+// scaled coefficients are floating-point / host work outside the integer hot path: they run on the host in double
+// precision (same slot order as the reference: Galois generator 3, bit-reversed), the NTT on the device.
+// ----------------------------------------------------------------------------------------------
+class CKKSEncoder {
+public:
+    explicit CKKSEncoder(HeContextPointer context);
+    HeContextPointer context() const { return context_; }
+    size_t slot_count() const { return slots_; }
+    size_t polynomial_modulus_degree() const { return slots_ * 2; }
+    bool on_device() const { return context_->on_device(); }
+    void to_device_inplace(MemoryPoolHandle = MemoryPool::GlobalPool()) {}
+    void encode_complex64_simd(const std::vector<std::complex<double>>& values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
+                               MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext encode_complex64_simd_new(const std::vector<std::complex<double>>& values, std::optional<ParmsID> parms_id, double scale,
+                                        MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_complex64_simd(values, parms_id, scale, p, pool); return p; }
+    void encode_float64_polynomial(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
+                                   MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext encode_float64_polynomial_new(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale,
+                                            MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_float64_polynomial(values, parms_id, scale, p, pool); return p; }
+    Plaintext encode_float64_single_new(double value, std::optional<ParmsID> parms_id, double scale, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        return encode_float64_polynomial_new({value}, parms_id, scale, pool);   // a constant polynomial = the value in every slot
+    }
+    void decode_complex64_simd(const Plaintext& plain, std::vector<std::complex<double>>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<std::complex<double>> decode_complex64_simd_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<std::complex<double>> v; decode_complex64_simd(plain, v, pool); return v;
+    }
+    void decode_float64_polynomial(const Plaintext& plain, std::vector<double>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<double> decode_float64_polynomial_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<double> v; decode_float64_polynomial(plain, v, pool); return v;
+    }
+private:
+    void set_plaintext(const std::vector<double>& coeffs, const ParmsID& parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool) const;
+    std::vector<double> plaintext_coefficients(const Plaintext& plain, MemoryPoolHandle pool) const;   // centred, as doubles (not yet / scale)
+    HeContextPointer context_;
+    size_t slots_ = 0;
+    std::vector<size_t> matrix_reps_index_map_;
+    std::vector<std::complex<double>> root_powers_, inv_root_powers_;   // bit-reversed order, as NTTTables
+};
+
+// ----------------------------------------------------------------------------------------------
 // Evaluator  (src/evaluator.h)
 // ----------------------------------------------------------------------------------------------
 class Evaluator {
@@ -608,6 +650,12 @@ public:
     void rotate_rows(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void rotate_rows_inplace(Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_rows(encrypted, steps, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext rotate_rows_new(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_rows(encrypted, steps, galois_keys, d, pool); return d; }
+    // CKKS: rotate_vector / complex_conjugate (evaluator.h:850-940)
+    void rotate_vector(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext rotate_vector_new(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_vector(encrypted, steps, galois_keys, d, pool); return d; }
+    void rotate_vector_inplace(Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_vector(encrypted, steps, galois_keys, d, pool); encrypted = std::move(d); }
+    void complex_conjugate(const Ciphertext& encrypted, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext complex_conjugate_new(const Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; complex_conjugate(encrypted, galois_keys, d, pool); return d; }
     void rotate_columns(const Ciphertext& encrypted, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void rotate_columns_inplace(Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext rotate_columns_new(const Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); return d; }
