@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="ciphertext pairs per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -101,9 +101,10 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: the forward NTT of the key-switch digits -------------------
-    # one launch transforms B*(L+1)*L limb-polynomials; algorithmic bytes = 16*N per limb-polynomial
+    # one launch transforms RB*(L+1)*L limb-polynomials; algorithmic bytes = 16*N per limb-polynomial
     # (8 read + 8 written).  Timed with events on the stream the kernel is launched on.
-    digits = uniform_residues((B, L + 1), q[:L], n, device, gen)
+    RB = 256    # the roofline launch is a fixed shape (the one profiles/r01_ntt_traffic.json was collected on)
+    digits = uniform_residues((RB, L + 1), q[:L], n, device, gen)
     reps = max(5, args.steps)
     plan.ntt(digits, L + 1, L, mode=pkg.IDX_KS_SET_PRODUCTS, decomp=L, table_count=K)
     torch.cuda.synchronize()
@@ -114,7 +115,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ntt_ms = e0.elapsed_time(e1) / reps
-    limb_polys = B * (L + 1) * L
+    limb_polys = RB * (L + 1) * L
     alg_bytes = 16.0 * n * limb_polys
     achieved = alg_bytes / (ntt_ms * 1e-3) / 1e9
     # HBM traffic of that launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
