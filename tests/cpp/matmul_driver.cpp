@@ -1,0 +1,75 @@
+// C++ driver for tests/test_gpu_cpp_api.py::test_matmul_cpp_api and tools/bench_configs.py (cfg5): BASELINE config 5, the BFV
+// matrix product of examples/10_bfv_matmul.cu (N=8192, {60,40,40,60}, t=2^21) through troy::linear::MatmulHelper:
+// encode weights, encrypt inputs, matmul, decrypt, compare with the plain product mod t; prints phase times.
+// usage: matmul_driver <batch> <input_dims> <output_dims> [repeat]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../troy-nova_amd/troy/matmul.h"
+
+using namespace troy;
+using namespace troy::linear;
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+    try {
+        const size_t M = argc > 1 ? std::strtoull(argv[1], nullptr, 0) : 25, R = argc > 2 ? std::strtoull(argv[2], nullptr, 0) : 30,
+                     Nn = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 35;
+        const int repeat = argc > 4 ? std::atoi(argv[4]) : 1;
+        const size_t n = 8192;
+        const uint64_t t = 1ull << 21;
+        EncryptionParameters params(SchemeType::BFV);
+        params.set_poly_modulus_degree(n);
+        params.set_coeff_modulus(CoeffModulus::create(n, {60, 40, 40, 60}));
+        params.set_plain_modulus(t);
+        HeContextPointer context = HeContext::create(params, true, SecurityLevel::Classical128, 0x77);
+        context->to_device_inplace();
+        BatchEncoder encoder(context);
+        KeyGenerator keygen(context);
+        Encryptor encryptor(context);
+        encryptor.set_secret_key(keygen.secret_key());
+        Decryptor decryptor(context, keygen.secret_key());
+        Evaluator evaluator(context);
+
+        std::mt19937_64 gen(11);
+        std::vector<uint64_t> x(M * R), w(R * Nn), want(M * Nn, 0);
+        for (auto& v : x) v = gen() % t;
+        for (auto& v : w) v = gen() % t;
+        for (size_t i = 0; i < M; i++)
+            for (size_t k = 0; k < R; k++)
+                for (size_t j = 0; j < Nn; j++) want[i * Nn + j] = (want[i * Nn + j] + x[i * R + k] * w[k * Nn + j]) % t;
+
+        MatmulHelper helper(M, R, Nn, n, MatmulObjective::EncryptLeft, false);
+        std::printf("block %zu %zu %zu\n", helper.batch_block, helper.input_block, helper.output_block);
+        double t0 = now();
+        Plain2d we = helper.encode_weights_uint64s(encoder, w.data());
+        double t1 = now();
+        Cipher2d xe = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
+        double t2 = now();
+        Cipher2d ye = helper.matmul(evaluator, xe, we);
+        double t3 = now();
+        for (int r = 1; r < repeat; r++) ye = helper.matmul(evaluator, xe, we);
+        double t4 = now();
+        std::vector<uint64_t> got = helper.decrypt_outputs_uint64s(encoder, decryptor, ye);
+        double t5 = now();
+        size_t weights_n = 0, inputs_n = 0, outputs_n = 0;
+        for (auto& r : we.data()) weights_n += r.size();
+        for (auto& r : xe.data()) inputs_n += r.size();
+        for (auto& r : ye.data()) outputs_n += r.size();
+        std::printf("objects weights %zu inputs %zu outputs %zu\n", weights_n, inputs_n, outputs_n);
+        std::printf("ms encode_weights %.3f encrypt_inputs %.3f matmul_first %.3f matmul_repeat %.3f decrypt %.3f\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                    (t3 - t2) * 1e3, repeat > 1 ? (t4 - t3) * 1e3 / (repeat - 1) : 0.0, (t5 - t4) * 1e3);
+        size_t bad = 0;
+        for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];
+        std::printf("mismatches %zu of %zu\n", bad, got.size());
+        std::printf(bad ? "FAIL\n" : "OK\n");
+        MemoryPool::Destroy();
+        return bad ? 1 : 0;
+    } catch (const std::exception& e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 1;
+    }
+}

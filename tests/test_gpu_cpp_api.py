@@ -115,3 +115,14 @@ def test_ckks_cpp_api(dev):
         assert float(kv[k][0]) < 1e-3, k
     for k in ("rotate1", "rotate-3", "conjugate"):
         assert float(kv[k][0]) < 1e-4, k
+
+
+@pytest.mark.parametrize("dims", [(25, 30, 35), (4, 600, 7), (128, 64, 96)])
+def test_matmul_cpp_api(dev, dims):
+    """BASELINE config 5 path (examples/10_bfv_matmul.cu parameters): encrypted inputs x plaintext weights through
+    troy::linear::MatmulHelper equals the plain matrix product mod t."""
+    drv = os.path.join(ROOT, "tests", "cpp", "matmul_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv] + [str(d) for d in dims], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout and "mismatches 0 of %d" % (dims[0] * dims[2]) in r.stdout, r.stdout + r.stderr

@@ -121,6 +121,32 @@ def main():
                            "terms_per_s": round(terms / t, 1), "algorithmic_GBps": round(alg / t / 1e9, 1), "ms": round(t * 1e3, 3),
                            "weight_GBps": round(terms * L * n * 8 / t / 1e9, 1)}
 
+    if a.only in ("", "cfg5", "cfg5_e2e"):
+        import subprocess
+        drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "matmul_driver")
+        r = subprocess.run([drv, "512", "512", "512", "5"], capture_output=True, text=True, timeout=900)
+        lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+        ms = dict(zip(lines["ms"][0::2], [float(v) for v in lines["ms"][1::2]]))
+        res["cfg5_e2e"] = {"what": "BFV 512x512x512 matmul through MatmulHelper (N=8192, {60,40,40,60}, t=2^21), encrypted inputs x plaintext weights",
+                           "block": lines["block"], "objects": " ".join(lines["objects"]), "ms": ms,
+                           "latency_ms_encrypt_matmul_decrypt": round(ms["encrypt_inputs"] + ms["matmul_repeat"] + ms["decrypt"], 2),
+                           "correct": "OK" in r.stdout}
+        # CPU baseline of the matmul core (the oracle's multiply_plain_ntt + add, one thread), on a bounded sample of terms
+        import numpy as np
+        O = entry.load_oracle()
+        q = [int(v) for v in O.coeff_modulus_create(8192, [60, 40, 40, 60])]
+        ctx = O.Context("bfv", 8192, q, 1 << 21)
+        ct, pt = ctx.random_ct(1, 2, 3), ctx.random_ct(2, 1, 3)[0]
+        acc = np.zeros_like(ct)
+        sample, t0 = 300, time.perf_counter()
+        for _ in range(sample):
+            term = ctx.multiply_plain_ntt(3, ct, pt)
+            for l in range(3):
+                acc[:, l] = (acc[:, l] + term[:, l]) % np.uint64(q[l])
+        per_term = (time.perf_counter() - t0) / sample
+        res["cfg5_e2e"]["cpu_matmul_core_ms_estimate"] = round(per_term * 16384 * 1e3, 1)
+        res["cfg5_e2e"]["cpu_sample"] = "%d of 16384 multiply_plain_ntt+add terms on one host thread (oracle), extrapolated" % sample
+
     print(json.dumps(res, indent=1))
 
 

@@ -1,0 +1,126 @@
+// matmul.cpp -- see matmul.h.  Host logic only; all arithmetic goes through the mirror's Evaluator (GPU).
+#include "matmul.h"
+
+namespace troy { namespace linear {
+
+static size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+MatmulHelper::MatmulHelper(size_t batch_size, size_t input_dims, size_t output_dims, size_t slot_count, MatmulObjective objective, bool pack_lwe,
+                           MemoryPoolHandle pool)
+    : batch_size(batch_size), input_dims(input_dims), output_dims(output_dims), slot_count(slot_count), objective(objective), pack_lwe(pack_lwe),
+      pool(std::move(pool)) {
+    if (pack_lwe) throw std::logic_error("[MatmulHelper::MatmulHelper] LWE output packing is not part of this build.");
+    if (objective != MatmulObjective::EncryptLeft) throw std::logic_error("[MatmulHelper::MatmulHelper] only MatmulObjective::EncryptLeft is part of this build.");
+    determine_block();
+}
+
+void MatmulHelper::determine_block() {
+    // app/matmul.cu:101-127 (no LWE packing): choose (bb, ib, ob), bb*ib*ob <= N, minimising the number of ciphertexts that
+    // travel: encrypted inputs ceil(B/bb)*ceil(I/ib) plus encrypted outputs ceil(B/bb)*ceil(O/ob)
+    size_t best_cost = static_cast<size_t>(-1);
+    for (size_t bb = std::min(batch_size, slot_count - 1); bb >= 1; bb--) {
+        const size_t bc = ceil_div(batch_size, bb);
+        if (2 * bc > best_cost) continue;
+        for (size_t ib = 1; ib <= input_dims && ib < slot_count / bb; ib++) {
+            size_t ob = std::min(slot_count / bb / ib, output_dims);
+            if (ob < 1) continue;
+            const size_t cost = bc * (ceil_div(input_dims, ib) + ceil_div(output_dims, ob));
+            if (cost < best_cost) { best_cost = cost; batch_block = bb; input_block = ib; output_block = ob; }
+        }
+    }
+    if (best_cost == static_cast<size_t>(-1)) throw std::invalid_argument("[MatmulHelper::determine_block] no valid blocking for these dimensions.");
+}
+
+Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const {
+    // app/matmul.cu:160-230: coefficient packing, then centralize + NTT (the weights multiply ciphertexts)
+    Evaluator evaluator(encoder.context());
+    const ParmsID first = encoder.context()->first_parms_id();
+    Plain2d out;
+    for (size_t li = 0; li < input_dims; li += input_block) {
+        const size_t ui = std::min(li + input_block, input_dims);
+        std::vector<Plaintext> row;
+        for (size_t lj = 0; lj < output_dims; lj += output_block) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            std::vector<uint64_t> vec(input_block * output_block, 0);
+            for (size_t j = lj; j < uj; j++)
+                for (size_t i = li; i < ui; i++) vec[(j - lj) * input_block + input_block - (i - li) - 1] = weights[i * output_dims + j];
+            Plaintext p = encoder.encode_polynomial_new(vec, pool);
+            row.push_back(evaluator.transform_plain_to_ntt_new(p, first, pool));
+        }
+        out.data().push_back(std::move(row));
+    }
+    return out;
+}
+
+Plain2d MatmulHelper::encode_inputs_uint64s(const BatchEncoder& encoder, const uint64_t* inputs) const {
+    // app/matmul.cu:245-300
+    Plain2d out;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        std::vector<Plaintext> row;
+        for (size_t lj = 0; lj < input_dims; lj += input_block) {
+            const size_t uj = std::min(lj + input_block, input_dims);
+            std::vector<uint64_t> vec(slot_count, 0);
+            for (size_t j = lj; j < uj; j++)
+                for (size_t i = li; i < ui; i++) vec[(i - li) * input_block * output_block + (j - lj)] = inputs[i * input_dims + j];
+            row.push_back(encoder.encode_polynomial_new(vec, pool));
+        }
+        out.data().push_back(std::move(row));
+    }
+    return out;
+}
+
+Cipher2d MatmulHelper::encrypt_inputs_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* inputs) const {
+    Plain2d plain = encode_inputs_uint64s(encoder, inputs);
+    Evaluator evaluator(encoder.context());
+    Cipher2d out;
+    for (size_t i = 0; i < plain.size(); i++) {
+        std::vector<Ciphertext> row;
+        for (size_t j = 0; j < plain[i].size(); j++) {
+            Ciphertext c = encryptor.encrypt_symmetric_new(plain[i][j], false, pool);
+            evaluator.transform_to_ntt_inplace(c);          // the products are taken in NTT form
+            row.push_back(std::move(c));
+        }
+        out.data().push_back(std::move(row));
+    }
+    return out;
+}
+
+Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, const Plain2d& w) const {
+    // app/matmul.cu:326-374, batched form
+    const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
+    if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
+    if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
+    Cipher2d ret;
+    ret.data().resize(batch_split);
+    for (auto& r : ret.data()) r.resize(output_split);
+    std::vector<const Ciphertext*> a_ptrs;
+    std::vector<const Plaintext*> w_ptrs;
+    std::vector<Ciphertext*> r_ptrs;
+    for (size_t i = 0; i < input_split; i++)
+        for (size_t j = 0; j < output_split; j++)
+            for (size_t b = 0; b < batch_split; b++) { a_ptrs.push_back(&a[b][i]); w_ptrs.push_back(&w[i][j]); r_ptrs.push_back(&ret[b][j]); }
+    evaluator.multiply_plain_accumulate(a_ptrs, w_ptrs, r_ptrs, true, pool);
+    for (auto& r : ret.data()) for (Ciphertext& c : r) evaluator.transform_from_ntt_inplace(c);     // BFV results leave in coefficient form
+    return ret;
+}
+
+std::vector<uint64_t> MatmulHelper::decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
+    // app/matmul.cu:560-640
+    std::vector<uint64_t> out(batch_size * output_dims, 0);
+    size_t bi = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, bi++) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        size_t bj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, bj++) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            const std::vector<uint64_t> coeffs = encoder.decode_polynomial_new(decryptor.decrypt_new(outputs[bi][bj], pool), pool);
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++)
+                    out[i * output_dims + j] = coeffs[(i - li) * input_block * output_block + (j - lj) * input_block + input_block - 1];
+        }
+    }
+    return out;
+}
+
+}}  // namespace troy::linear

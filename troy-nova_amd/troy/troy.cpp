@@ -1600,8 +1600,9 @@ BatchEncoder::BatchEncoder(HeContextPointer context) : context_(std::move(contex
         throw std::invalid_argument("[BatchEncoder::BatchEncoder] Unsupported scheme");
     slots_ = parms.poly_modulus_degree();
     const uint64_t t = parms.plain_modulus().value();
-    if (!parms.plain_modulus().is_prime() || (t - 1) % (2 * slots_) != 0)
-        throw std::invalid_argument("[BatchEncoder::BatchEncoder] Encryption parameters are not valid for batching");
+    // qualifiers().using_batching: t prime and t = 1 mod 2N.  Without it only the polynomial (coefficient) packing is
+    // available (batch_encoder.cu:33: the SIMD tables are built only when batching is possible).
+    if (!parms.plain_modulus().is_prime() || (t - 1) % (2 * slots_) != 0) return;
     size_t logn = 0;
     while ((size_t(1) << logn) < slots_) logn++;
     matrix_reps_index_map_.resize(slots_);
@@ -1618,6 +1619,7 @@ void BatchEncoder::encode(const std::vector<uint64_t>& values, Plaintext& destin
     // batch_encoder.cu:169-226: scatter through the index map, inverse NTT modulo t
     const char* P = "[BatchEncoder::encode]";
     require_device_context(P, context_);
+    if (matrix_reps_index_map_.empty()) throw std::invalid_argument(std::string(P) + " The parameters do not support vector batching.");
     if (values.size() > slots_) throw std::invalid_argument(std::string(P) + " Values has size larger than the number of slots");
     const uint64_t t = context_->first_context_data().value()->parms().plain_modulus().value();
     std::vector<uint64_t> buf(slots_, 0);
@@ -1638,10 +1640,35 @@ void BatchEncoder::encode(const std::vector<uint64_t>& values, Plaintext& destin
     destination = std::move(out);
 }
 
+Plaintext BatchEncoder::encode_polynomial_new(const std::vector<uint64_t>& values, MemoryPoolHandle pool) const {
+    const char* P = "[BatchEncoder::encode_polynomial]";
+    require_device_context(P, context_);
+    if (values.size() > slots_) throw std::invalid_argument(std::string(P) + " Values has size larger than the number of slots");
+    const uint64_t t = context_->first_context_data().value()->parms().plain_modulus().value();
+    for (uint64_t v : values) if (v >= t) throw std::invalid_argument(std::string(P) + " Value is larger than plain modulus");
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.parms_id() = parms_id_zero;
+    out.resize(values.size());
+    if (!values.empty()) out.data().copy_from(values.data(), values.size(), false);
+    out.is_ntt_form() = false;
+    out.poly_modulus_degree() = slots_;
+    out.coeff_modulus_size() = context_->first_context_data().value()->parms().coeff_modulus().size();
+    return out;
+}
+
+std::vector<uint64_t> BatchEncoder::decode_polynomial_new(const Plaintext& plain, MemoryPoolHandle) const {
+    if (plain.is_ntt_form()) throw std::invalid_argument("[BatchEncoder::decode_polynomial] Plaintext is in NTT form");
+    std::vector<uint64_t> v = plain.data().to_vector();
+    v.resize(plain.coeff_count());
+    return v;
+}
+
 void BatchEncoder::decode(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool) const {
     // batch_encoder.cu decode: forward NTT modulo t of a copy, gather through the index map
     const char* P = "[BatchEncoder::decode]";
     require_device_context(P, context_);
+    if (matrix_reps_index_map_.empty()) throw std::invalid_argument(std::string(P) + " The parameters do not support vector batching.");
     if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is in NTT form");
     if (plain.coeff_count() > slots_) throw std::invalid_argument(std::string(P) + " Plaintext is not valid");
     utils::DynamicArray tmp(slots_, true, pool);

@@ -534,6 +534,9 @@ public:
     Plaintext encode_new(const std::vector<uint64_t>& values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode(values, p, pool); return p; }
     void decode(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<uint64_t> decode_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<uint64_t> v; decode(plain, v, pool); return v; }
+    // coefficient ("polynomial") packing: values are the plaintext coefficients themselves (batch_encoder.cu encode_polynomial)
+    Plaintext encode_polynomial_new(const std::vector<uint64_t>& values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<uint64_t> decode_polynomial_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
 private:
     HeContextPointer context_;
     size_t slots_ = 0;
