@@ -32,20 +32,52 @@ void MatmulHelper::determine_block() {
 }
 
 Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const {
-    // app/matmul.cu:160-230: coefficient packing, then centralize + NTT (the weights multiply ciphertexts)
-    Evaluator evaluator(encoder.context());
-    const ParmsID first = encoder.context()->first_parms_id();
-    Plain2d out;
+    // app/matmul.cu:160-230: coefficient packing, then centralize + NTT (the weights multiply ciphertexts).  All blocks are
+    // packed on the host into one buffer and go through ONE copy, ONE centralize launch and ONE NTT launch; the plaintext
+    // objects are windows of the shared result buffer.
+    HeContextPointer context = encoder.context();
+    if (!context->on_device()) throw std::invalid_argument("[MatmulHelper::encode_weights] HeContext is not on device (call to_device_inplace).");
+    ContextDataPointer cd = context->first_context_data().value();
+    const ParmsID first = context->first_parms_id();
+    const size_t n = cd->parms().poly_modulus_degree(), L = cd->parms().coeff_modulus().size();
+    const uint64_t t = cd->parms().plain_modulus().value();
+    const size_t rows = ceil_div(input_dims, input_block), cols = ceil_div(output_dims, output_block), count = rows * cols;
+    const size_t clen = input_block * output_block;
+    std::vector<uint64_t> packed(count * clen, 0);
+    size_t idx = 0;
     for (size_t li = 0; li < input_dims; li += input_block) {
         const size_t ui = std::min(li + input_block, input_dims);
-        std::vector<Plaintext> row;
-        for (size_t lj = 0; lj < output_dims; lj += output_block) {
+        for (size_t lj = 0; lj < output_dims; lj += output_block, idx++) {
             const size_t uj = std::min(lj + output_block, output_dims);
-            std::vector<uint64_t> vec(input_block * output_block, 0);
+            uint64_t* vec = packed.data() + idx * clen;
             for (size_t j = lj; j < uj; j++)
-                for (size_t i = li; i < ui; i++) vec[(j - lj) * input_block + input_block - (i - li) - 1] = weights[i * output_dims + j];
-            Plaintext p = encoder.encode_polynomial_new(vec, pool);
-            row.push_back(evaluator.transform_plain_to_ntt_new(p, first, pool));
+                for (size_t i = li; i < ui; i++) {
+                    const uint64_t v = weights[i * output_dims + j];
+                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
+                    vec[(j - lj) * input_block + input_block - (i - li) - 1] = v;
+                }
+        }
+    }
+    utils::DynamicArray staged(packed.size(), true, pool);
+    staged.copy_from(packed.data(), packed.size(), false);
+    auto shared = std::make_shared<utils::DynamicArray>(count * L * n, true, pool);
+    troyn_check_public(troyn_plain_centralize(context->plan(), static_cast<uint32_t>(L), t, staged.raw_pointer(), clen, clen, shared->raw_pointer(), count, troyn_current_stream()));
+    troyn_check_public(troyn_ntt(context->plan(), 0, shared->raw_pointer(), shared->raw_pointer(), count, 1, L, 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0,
+                                 troyn_current_stream()));
+    troyn_sync_current_stream();     // `staged` returns to the pool
+    Plain2d out;
+    idx = 0;
+    for (size_t r = 0; r < rows; r++) {
+        std::vector<Plaintext> row;
+        for (size_t c = 0; c < cols; c++, idx++) {
+            Plaintext p;
+            p.data() = utils::DynamicArray::device_view(shared->raw_pointer() + idx * L * n, L * n, shared);
+            p.parms_id() = first;
+            p.coeff_count() = n;
+            p.coeff_modulus_size() = L;
+            p.poly_modulus_degree() = n;
+            p.is_ntt_form() = true;
+            row.push_back(std::move(p));
         }
         out.data().push_back(std::move(row));
     }

@@ -28,6 +28,10 @@ static void troyn_check(int rc) {
 
 static inline hipStream_t current_stream() { return hipStreamPerThread; }
 
+void troyn_check_public(int rc) { troyn_check(rc); }
+troyn_stream_t troyn_current_stream() { return (troyn_stream_t)current_stream(); }
+void troyn_sync_current_stream() { hip_check(hipStreamSynchronize(current_stream()), "stream_sync"); }
+
 namespace utils {
 
 size_t device_count() {
@@ -108,8 +112,15 @@ DynamicArray::DynamicArray(size_t count, bool device, MemoryPoolHandle pool) : s
     }
 }
 
+DynamicArray DynamicArray::device_view(uint64_t* ptr, size_t count, std::shared_ptr<DynamicArray> owner) {
+    DynamicArray a;
+    a.data_ = ptr; a.size_ = count; a.device_ = true; a.pool_ = owner->pool_; a.owner_ = std::move(owner);
+    return a;
+}
+
 void DynamicArray::free_() {
     if (!data_) return;
+    if (owner_) { owner_.reset(); data_ = nullptr; size_ = 0; return; }
     if (device_) {
         // the pool hands the block to the next allocation, which is ordered on the same per-thread stream
         pool_->release(data_);
@@ -125,7 +136,8 @@ DynamicArray::DynamicArray(const DynamicArray& o) : DynamicArray(o.size_, o.devi
     if (size_) copy_from(o.data_, size_, o.device_);
 }
 
-DynamicArray::DynamicArray(DynamicArray&& o) noexcept : data_(o.data_), size_(o.size_), device_(o.device_), pool_(std::move(o.pool_)) {
+DynamicArray::DynamicArray(DynamicArray&& o) noexcept
+    : data_(o.data_), size_(o.size_), device_(o.device_), pool_(std::move(o.pool_)), owner_(std::move(o.owner_)) {
     o.data_ = nullptr; o.size_ = 0;
 }
 
@@ -139,7 +151,7 @@ DynamicArray& DynamicArray::operator=(const DynamicArray& o) {
 DynamicArray& DynamicArray::operator=(DynamicArray&& o) noexcept {
     if (this == &o) return *this;
     free_();
-    data_ = o.data_; size_ = o.size_; device_ = o.device_; pool_ = std::move(o.pool_);
+    data_ = o.data_; size_ = o.size_; device_ = o.device_; pool_ = std::move(o.pool_); owner_ = std::move(o.owner_);
     o.data_ = nullptr; o.size_ = 0;
     return *this;
 }

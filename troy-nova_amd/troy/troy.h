@@ -83,6 +83,9 @@ public:
     ~DynamicArray();
 
     static DynamicArray from_vector(const std::vector<uint64_t>& v);
+    // a device array that is a window of a larger allocation kept alive by `owner` (objects produced by one batched
+    // launch share their buffer; copies of the object are ordinary owning arrays)
+    static DynamicArray device_view(uint64_t* ptr, size_t count, std::shared_ptr<DynamicArray> owner);
     std::vector<uint64_t> to_vector() const;
     DynamicArray clone(MemoryPoolHandle pool = nullptr) const;
 
@@ -105,6 +108,7 @@ private:
     size_t size_ = 0;
     bool device_ = false;
     MemoryPoolHandle pool_;
+    std::shared_ptr<DynamicArray> owner_;   // non-null: data_ points into *owner_
 };
 
 // utils/random_generator.h: AES-128-CTR generator; the seed/counter state lives on the host, the polynomial
@@ -125,6 +129,12 @@ private:
 };
 
 }  // namespace utils
+
+// helpers for code layered on the mirror (matmul.cpp): C-ABI status -> the reference's exception types, the calling
+// thread's stream (hipStreamPerThread), and a wait on it
+void troyn_check_public(int rc);
+troyn_stream_t troyn_current_stream();
+void troyn_sync_current_stream();
 
 using MemoryPool = utils::MemoryPool;
 using MemoryPoolHandle = utils::MemoryPoolHandle;
