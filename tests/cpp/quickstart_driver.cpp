@@ -5,7 +5,9 @@
 // usage: quickstart_driver <seed>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 
 #include "../../troy-nova_amd/troy/troy.h"
 
@@ -89,6 +91,33 @@ int main(int argc, char** argv) {
         print_slots("rot3", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_rows_new(r, 3, galois_keys))));
         print_slots("rotm2", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_rows_new(r, -2, galois_keys))));
         print_slots("rotcol", encoder.decode_new(decryptor.decrypt_new(evaluator.rotate_columns_new(r, galois_keys))));
+
+        // serialization in the reference's raw format: round trips, a seed-compressed symmetric ciphertext, key sets
+        {
+            std::stringstream ss;
+            const size_t ct_bytes = c.save(ss, context);
+            Ciphertext c_back = Ciphertext::load_new(ss, context);
+            std::printf("ser_ct %zu %d\n", ct_bytes, (int)(c_back.data().to_vector() == c.data().to_vector() && c_back.parms_id() == c.parms_id()));
+            std::stringstream sk_s, rk_s, pt_s, pr_s, seeded_s;
+            keygen.secret_key().save(sk_s);
+            relin_keys.save(rk_s, context);
+            w0.save(pt_s);
+            params.save(pr_s);
+            SecretKey sk_back = SecretKey::load_new(sk_s);
+            RelinKeys rk_back; rk_back.load(rk_s, context);
+            Plaintext w0_back = Plaintext::load_new(pt_s);
+            EncryptionParameters pr_back; pr_back.load(pr_s);
+            std::printf("ser_params %d\n", (int)(pr_back.parms_id() == params.parms_id()));
+            Decryptor dec2(context, sk_back);
+            print_slots("ser_relin", encoder.decode_new(dec2.decrypt_new(evaluator.relinearize_new(prod, rk_back))));
+            print_slots("ser_plain", encoder.decode_new(w0_back));
+            Ciphertext seeded = encryptor.encrypt_symmetric_new(encoder.encode_new({9, 8, 7}), true);
+            const size_t seeded_bytes = seeded.save(seeded_s, context);
+            std::printf("ser_seeded %zu %d\n", seeded_bytes, (int)seeded.contains_seed());
+            Ciphertext seeded_back = Ciphertext::load_new(seeded_s, context);
+            print_slots("ser_seeded_dec", encoder.decode_new(decryptor.decrypt_new(seeded_back)));
+            if (argc > 2) { std::ofstream f(argv[2], std::ios::binary); c.save(f, context); }
+        }
 
         // misuse: host-resident plaintext / ciphertext
         bool threw = false;

@@ -66,7 +66,7 @@ def test_evaluator_cpp_api(O, dev, tmp_path, scheme, n, t, bits):
     assert np.array_equal(d[9][0][:2].reshape(-1), tmp) and np.array_equal(d[9][0][2].reshape(-1), neg)
 
 
-def test_quickstart_cpp_api(dev):
+def test_quickstart_cpp_api(dev, tmp_path):
     """BASELINE config 1 through the C++ mirror (keygen, encoder, encryptor, evaluator, decryptor on the GPU): the
     digests must equal the ones the reference itself produced for seed 0x123 (tests/golden/config1_digests.json)."""
     import json
@@ -74,9 +74,27 @@ def test_quickstart_cpp_api(dev):
     if not os.path.exists(drv):
         pytest.fail("tests/cpp/quickstart_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_digests.json")))
-    r = subprocess.run([drv, hex(G["seed"])], capture_output=True, text=True, timeout=600)
+    ct_file = str(tmp_path / "ct.bin")
+    r = subprocess.run([drv, hex(G["seed"]), ct_file], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    # serialization: the reference's raw layout (utils/serialize.h, ciphertext.cu:93-140), parsed here field by field
+    import hashlib
+    import struct
+    n, L = 8192, 2
+    body = 2 * L * n * 8
+    assert kv["ser_ct"] == [str(1 + 32 + 24 + 1 + body), "1"] and kv["ser_params"] == ["1"]
+    assert kv["ser_relin"] == ["1", "4", "9", "16", "0", "0"] and kv["ser_plain"] == ["3", "5", "7", "11", "0", "0"]
+    assert kv["ser_seeded"] == [str(1 + 32 + 24 + 1 + 8 + body // 2), "1"] and kv["ser_seeded_dec"] == ["9", "8", "7", "0", "0", "0"]
+    raw = open(ct_file, "rb").read()
+    words = [1, n] + G["coeff_modulus"][:L] + [G["plain_modulus"]]              # scheme BFV = 1, first data level
+    assert raw[0] == 0                                                           # CompressionMode::Nil
+    assert raw[1:33] == hashlib.blake2b(struct.pack("<%dQ" % len(words), *words), digest_size=32).digest()     # ParmsID
+    assert struct.unpack("<3Q", raw[33:57]) == (2, L, n) and raw[57] == 0b100   # not NTT, no seed, on device
+    h = 1469598103934665603
+    for w in struct.unpack("<%dQ" % (2 * L * n), raw[58:]):
+        h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert "%016x" % h == G["ciphertext_digest"]                                 # payload = the reference's ciphertext words
     assert kv["ct_digest"] == [G["ciphertext_digest"]]
     assert kv["mul_digest"] == [G["multiply_digest"]]
     assert kv["decrypt"] == ["1", "2", "3", "4", "0", "0"]

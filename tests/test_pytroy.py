@@ -14,6 +14,7 @@ PKG = os.path.join(ROOT, "troy-nova_amd")
 def pytroy():
     if PKG not in sys.path:
         sys.path.insert(0, PKG)
+    import torch  # noqa: F401  (first: one HIP runtime per process -- torch bundles its own libamdhip64)
     try:
         import pytroy as m
     except ImportError as e:
@@ -88,6 +89,14 @@ def test_quickstart_flow_in_python(pytroy, dev):
     r = encryptor.encrypt_asymmetric_new(encoder.encode_simd_new(list(range(1, 8193))))
     assert dec(evaluator.rotate_rows_new(r, 3, gk))[:3] == [4, 5, 6]
     assert dec(evaluator.rotate_columns_new(r, gk))[:2] == [4097, 4098]
+    # save / load through byte strings (reference layout)
+    blob = c.save(ctx)
+    assert len(blob) == 1 + 32 + 24 + 1 + 2 * 2 * 8192 * 8
+    assert pytroy.Ciphertext.load_new(blob, ctx).data() == c.data()
+    rk = keygen.create_relin_keys(True)                                  # seeded keys: c1 regenerated on load
+    rk2 = pytroy.RelinKeys()
+    rk2.load(rk.save(ctx), ctx)
+    assert dec(evaluator.relinearize_new(prod, rk2))[:4] == [1, 4, 9, 16]
     host = c.clone()
     host.to_host_inplace()
     with pytest.raises(ValueError):

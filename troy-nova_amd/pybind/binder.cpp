@@ -7,6 +7,7 @@
 #include <pybind11/stl.h>
 
 #include <optional>
+#include <sstream>
 
 #include "../troy/troy.h"
 
@@ -39,6 +40,9 @@ static MemoryPoolHandle P(const PoolArg& p) { return p.has_value() ? p.value() :
             py::arg("encrypted"), py::arg(keyarg), POOL);                                                                    \
     cls.def(#name "_new", [](const Evaluator& s, const Ciphertext& a, const KeyT& k, PoolArg p) { return s.name##_new(a, k, P(p)); }, \
             py::arg("encrypted"), py::arg(keyarg), POOL)
+
+// save(...) -> bytes / load(bytes, ...): the reference's pybind exposes the stream API through byte strings
+template <typename F> static py::bytes to_bytes(F&& save) { std::ostringstream os; save(os); return py::bytes(os.str()); }
 
 template <typename T>
 static std::vector<const T*> const_ptrs(const std::vector<T*>& v) { return std::vector<const T*>(v.begin(), v.end()); }
@@ -116,7 +120,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("parms_id", [](const Plaintext& s) { return s.parms_id(); }).def("scale", [](const Plaintext& s) { return s.scale(); })
         .def("set_scale", [](Plaintext& s, double v) { s.scale() = v; })
         .def("coeff_count", [](const Plaintext& s) { return s.coeff_count(); }).def("is_ntt_form", [](const Plaintext& s) { return s.is_ntt_form(); })
-        .def("data", [](const Plaintext& s) { return s.data().to_vector(); });
+        .def("data", [](const Plaintext& s) { return s.data().to_vector(); })
+        .def("save", [](const Plaintext& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
+        .def("load", [](Plaintext& s, const std::string& b, PoolArg p) { std::istringstream is(b); s.load(is, P(p)); }, py::arg("bytes"), POOL)
+        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return Plaintext::load_new(is, P(p)); }, py::arg("bytes"), POOL);
 
     py::class_<Ciphertext>(m, "Ciphertext")
         .def(py::init<>())
@@ -129,13 +136,22 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("polynomial_count", &Ciphertext::polynomial_count).def("coeff_modulus_size", &Ciphertext::coeff_modulus_size)
         .def("poly_modulus_degree", &Ciphertext::poly_modulus_degree)
         .def("is_ntt_form", [](const Ciphertext& s) { return s.is_ntt_form(); }).def("contains_seed", &Ciphertext::contains_seed)
-        .def("data", [](const Ciphertext& s) { return s.data().to_vector(); });
+        .def("data", [](const Ciphertext& s) { return s.data().to_vector(); })
+        .def("expand_seed", &Ciphertext::expand_seed)
+        .def("save", [](const Ciphertext& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
+        .def("load", [](Ciphertext& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL)
+        .def_static("load_new", [](const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); return Ciphertext::load_new(is, c, P(p)); },
+                    py::arg("bytes"), py::arg("context"), POOL);
 
     py::class_<SecretKey>(m, "SecretKey").def(py::init<>()).def("on_device", &SecretKey::on_device)
-        .def("clone", [](const SecretKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("data", [](const SecretKey& s) { return s.data().to_vector(); });
+        .def("clone", [](const SecretKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("data", [](const SecretKey& s) { return s.data().to_vector(); })
+        .def("save", [](const SecretKey& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
+        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return SecretKey::load_new(is, P(p)); }, py::arg("bytes"), POOL);
     py::class_<PublicKey>(m, "PublicKey").def(py::init<>()).def("on_device", &PublicKey::on_device)
         .def("clone", [](const PublicKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("as_ciphertext", [](const PublicKey& s) { return s.as_ciphertext(); });
-    py::class_<KSwitchKeys>(m, "KSwitchKeys").def(py::init<>()).def("on_device", &KSwitchKeys::on_device).def("parms_id", [](const KSwitchKeys& s) { return s.parms_id(); });
+    py::class_<KSwitchKeys>(m, "KSwitchKeys").def(py::init<>()).def("on_device", &KSwitchKeys::on_device).def("parms_id", [](const KSwitchKeys& s) { return s.parms_id(); })
+        .def("save", [](const KSwitchKeys& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
+        .def("load", [](KSwitchKeys& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL);
     py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key);
     py::class_<GaloisKeys, KSwitchKeys>(m, "GaloisKeys").def(py::init<>()).def("has_key", &GaloisKeys::has_key);
 

@@ -9,6 +9,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <istream>
+#include <ostream>
 
 namespace troy {
 
@@ -297,17 +299,66 @@ Modulus PlainModulus::batching(size_t poly_modulus_degree, size_t bit_size) {
 // ------------------------------------------------------------------------------------------------
 const ParmsID parms_id_zero{};
 
+// BLAKE2b (RFC 7693), unkeyed, digest length `outlen` <= 64.  The reference vendors the BLAKE2 reference code
+// (utils/blake2/) and uses its 32-byte digest as ParmsID (utils/hash.h:24-31); this is the published algorithm.
+namespace {
+inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+void blake2b_compress(uint64_t h[8], const uint8_t block[128], uint64_t t0, bool last) {
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                                   0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    static const uint8_t SIGMA[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    uint64_t m[16], v[16];
+    for (int i = 0; i < 16; i++) std::memcpy(&m[i], block + 8 * i, 8);
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+    v[12] ^= t0;                 // message length < 2^64: the high counter word stays 0
+    if (last) v[14] = ~v[14];
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+        v[a] = v[a] + v[b] + x; v[d] = rotr64(v[d] ^ v[a], 32);
+        v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 24);
+        v[a] = v[a] + v[b] + y; v[d] = rotr64(v[d] ^ v[a], 16);
+        v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; r++) {
+        const uint8_t* s = SIGMA[r];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+}  // namespace
+
+void utils::blake2b(void* out, size_t outlen, const void* in, size_t inlen) {
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                                   0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    if (outlen == 0 || outlen > 64) throw std::invalid_argument("[blake2b] invalid digest length");
+    uint64_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010000ull ^ static_cast<uint64_t>(outlen);
+    const uint8_t* p = static_cast<const uint8_t*>(in);
+    uint8_t block[128];
+    size_t done = 0;
+    while (inlen - done > 128) { blake2b_compress(h, p + done, done + 128, false); done += 128; }
+    std::memset(block, 0, 128);
+    std::memcpy(block, p + done, inlen - done);
+    blake2b_compress(h, block, inlen, true);
+    std::memcpy(out, h, outlen);
+}
+
 void EncryptionParameters::compute_parms_id() {
-    // encryption_parameters.cu:8-32 hashes [scheme, N, q_0..q_{K-1}, t]; here four FNV-1a lanes
+    // encryption_parameters.cu:8-32: BLAKE2b-256 of the words [scheme, N, q_0..q_{K-1}, t]
     std::vector<uint64_t> words{static_cast<uint64_t>(scheme_), static_cast<uint64_t>(poly_modulus_degree_)};
     for (const Modulus& m : coeff_modulus_) words.push_back(m.value());
     words.push_back(plain_modulus_.value());
-    for (int lane = 0; lane < 4; lane++) {
-        uint64_t h = 0xcbf29ce484222325ull ^ (0x9E3779B97F4A7C15ull * (lane + 1));
-        for (uint64_t w : words)
-            for (int b = 0; b < 8; b++) { h ^= (w >> (8 * b)) & 0xff; h *= 0x100000001b3ull; }
-        parms_id_.v[lane] = h ? h : 1;
-    }
+    utils::blake2b(parms_id_.v, sizeof(parms_id_.v), words.data(), words.size() * 8);
+    if (parms_id_.is_zero()) throw std::logic_error("[EncryptionParameters::compute_parms_id] Computed parms_id is zero");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1157,6 +1208,200 @@ void Evaluator::rotate_columns(const Ciphertext& encrypted, const GaloisKeys& ga
     if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument("[Evaluator::rotate_columns_inplace] Rotate columns only applies for BFV or BGV");
     auto cd = get_context_data("[Evaluator::conjugate_inplace_internal]", encrypted.parms_id());
     apply_galois(encrypted, utils::galois_element_from_step(cd->parms().poly_modulus_degree(), 0), galois_keys, destination, pool);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Serialization  (utils/serialize.h, ciphertext.cu:93-210, plaintext.cu:20-70, kswitch_keys.cu:5-55,
+// encryption_parameters.cu:53-112): raw little-endian fields in the reference's order, so files are interchangeable.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <typename T> void put(std::ostream& os, const T& v) { os.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+template <typename T> void get(std::istream& is, T& v) {
+    is.read(reinterpret_cast<char*>(&v), sizeof(T));
+    if (!is) throw std::runtime_error("[serialize::load_object] unexpected end of stream");
+}
+void put_words(std::ostream& os, const std::vector<uint64_t>& v, size_t count) { os.write(reinterpret_cast<const char*>(v.data()), count * 8); }
+void put_mode(std::ostream& os, CompressionMode mode) {
+    if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::compress] Zstd is not available in this build.");
+    put(os, mode);
+}
+void get_mode(std::istream& is) {
+    CompressionMode mode;
+    get(is, mode);
+    if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::decompress] Zstd is not available in this build.");
+}
+bool get_bool(std::istream& is) {
+    unsigned char c;
+    get(is, c);
+    if (c > 1) throw std::runtime_error("Invalid bool value");
+    return c != 0;
+}
+}  // namespace
+
+size_t EncryptionParameters::save(std::ostream& stream) const {
+    put(stream, scheme_);
+    put(stream, poly_modulus_degree_);
+    put(stream, coeff_modulus_.size());
+    for (const Modulus& m : coeff_modulus_) put(stream, m.value());
+    size_t bytes = sizeof(SchemeType) + 2 * sizeof(size_t) + coeff_modulus_.size() * 8 + sizeof(bool);
+    if (scheme_ == SchemeType::BFV || scheme_ == SchemeType::BGV) { put(stream, plain_modulus_.value()); bytes += 8; }
+    put(stream, use_special_prime_for_encryption_);
+    return bytes;
+}
+
+void EncryptionParameters::load(std::istream& stream) {
+    get(stream, scheme_);
+    size_t n, k;
+    get(stream, n); get(stream, k);
+    if (k > 64) throw std::runtime_error("[EncryptionParameters::load] invalid coefficient modulus count");
+    poly_modulus_degree_ = n;
+    coeff_modulus_.clear();
+    for (size_t i = 0; i < k; i++) { uint64_t v; get(stream, v); coeff_modulus_.push_back(Modulus(v)); }
+    if (scheme_ == SchemeType::BFV || scheme_ == SchemeType::BGV) { uint64_t v; get(stream, v); plain_modulus_ = Modulus(v); }
+    use_special_prime_for_encryption_ = get_bool(stream);
+    compute_parms_id();
+}
+
+size_t Plaintext::serialized_size_upperbound(CompressionMode) const {
+    return sizeof(CompressionMode) + sizeof(ParmsID) + sizeof(double) + 2 * sizeof(size_t) + 2 * sizeof(bool) + data_.size() * 8 + 2 * sizeof(size_t);
+}
+
+size_t Plaintext::save(std::ostream& stream, CompressionMode mode) const {
+    put_mode(stream, mode);
+    put(stream, parms_id_);
+    put(stream, scale_);
+    put(stream, coeff_count_);
+    put(stream, static_cast<unsigned char>(on_device()));
+    put(stream, data_.size());
+    put_words(stream, data_.to_vector(), data_.size());
+    put(stream, static_cast<unsigned char>(is_ntt_form_));
+    put(stream, poly_modulus_degree_);
+    put(stream, coeff_modulus_size_);
+    return serialized_size_upperbound(mode);
+}
+
+void Plaintext::load(std::istream& stream, MemoryPoolHandle pool) {
+    get_mode(stream);
+    get(stream, parms_id_);
+    get(stream, scale_);
+    get(stream, coeff_count_);
+    const bool device = get_bool(stream);
+    size_t size;
+    get(stream, size);
+    std::vector<uint64_t> words(size);
+    stream.read(reinterpret_cast<char*>(words.data()), size * 8);
+    if (!stream) throw std::runtime_error("[Plaintext::load] unexpected end of stream");
+    data_ = utils::DynamicArray::from_vector(words);
+    if (device) data_.to_device_inplace(pool);
+    is_ntt_form_ = get_bool(stream);
+    get(stream, poly_modulus_degree_);
+    get(stream, coeff_modulus_size_);
+}
+
+static SchemeType context_scheme(const HeContextPointer& context) { return context->key_context_data().value()->parms().scheme(); }
+
+size_t Ciphertext::serialized_size_upperbound(HeContextPointer context, CompressionMode) const {
+    size_t bytes = sizeof(CompressionMode) + sizeof(ParmsID) + 3 * sizeof(size_t) + 1;
+    const SchemeType scheme = context_scheme(context);
+    if (scheme == SchemeType::CKKS) bytes += sizeof(double);
+    if (scheme == SchemeType::BGV) bytes += sizeof(uint64_t);
+    const size_t poly = poly_modulus_degree_ * coeff_modulus_size_;
+    bytes += contains_seed() ? 8 + poly * 8 : poly * polynomial_count_ * 8;
+    return bytes;
+}
+
+size_t Ciphertext::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
+    put_mode(stream, mode);
+    put(stream, parms_id_);
+    put(stream, polynomial_count_);
+    put(stream, coeff_modulus_size_);
+    put(stream, poly_modulus_degree_);
+    unsigned char flags = static_cast<unsigned char>(is_ntt_form_) | static_cast<unsigned char>(contains_seed() << 1) | static_cast<unsigned char>(on_device() << 2);
+    put(stream, flags);
+    const SchemeType scheme = context_scheme(context);
+    if (scheme == SchemeType::CKKS) put(stream, scale_);
+    if (scheme == SchemeType::BGV) put(stream, correction_factor_);
+    const std::vector<uint64_t> words = data_.to_vector();
+    if (contains_seed()) {
+        if (polynomial_count_ != 2) throw std::logic_error("[Ciphertext::save] Ciphertext contains seed but polynomial count is not 2.");
+        put(stream, seed_);
+        put_words(stream, words, poly_modulus_degree_ * coeff_modulus_size_);     // c0 only; c1 is regenerated from the seed
+    } else {
+        put_words(stream, words, words.size());
+    }
+    return serialized_size_upperbound(context, mode);
+}
+
+void Ciphertext::load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool) {
+    get_mode(stream);
+    get(stream, parms_id_);
+    get(stream, polynomial_count_);
+    get(stream, coeff_modulus_size_);
+    get(stream, poly_modulus_degree_);
+    unsigned char flags;
+    get(stream, flags);
+    is_ntt_form_ = flags & 1;
+    const bool seeded = flags & 2, device = flags & 4;
+    if (flags & 8) throw std::logic_error("[Ciphertext::load] Trying to call load with ciphertext with only terms saved.");
+    const SchemeType scheme = context_scheme(context);
+    scale_ = 1.0; correction_factor_ = 1;
+    if (scheme == SchemeType::CKKS) get(stream, scale_);
+    if (scheme == SchemeType::BGV) get(stream, correction_factor_);
+    const size_t poly = poly_modulus_degree_ * coeff_modulus_size_;
+    if (poly_modulus_degree_ > 131072 || coeff_modulus_size_ > 64 || polynomial_count_ > 64) throw std::runtime_error("[Ciphertext::load] invalid shape");
+    std::vector<uint64_t> words(poly * (seeded ? 2 : polynomial_count_), 0);
+    seed_ = 0;
+    if (seeded) get(stream, seed_);
+    stream.read(reinterpret_cast<char*>(words.data()), (seeded ? poly : words.size()) * 8);
+    if (!stream) throw std::runtime_error("[Ciphertext::load] unexpected end of stream");
+    data_ = utils::DynamicArray::from_vector(words);
+    if (device || seeded) data_.to_device_inplace(pool);     // seed expansion runs on the device
+    if (seeded) expand_seed(context);
+}
+
+void Ciphertext::expand_seed(HeContextPointer context) {
+    // ciphertext.cu:79-91: c1 <- uniform(RandomGenerator(seed)) under the ciphertext's moduli
+    if (!contains_seed()) throw std::invalid_argument("[Ciphertext::expand_seed] Ciphertext does not contain seed.");
+    auto cd = context->get_context_data(parms_id_);
+    if (!cd.has_value()) throw std::invalid_argument("[Ciphertext::expand_seed] ParmsID is not valid.");
+    if (!context->on_device() || !on_device()) throw std::invalid_argument("[Ciphertext::expand_seed] the seed is expanded on the GPU: context and ciphertext must be on the device.");
+    utils::RandomGenerator c1_prng(seed_);
+    c1_prng.sample_poly_uniform(context->plan(), coeff_modulus_size_, poly(1));
+    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    seed_ = 0;
+}
+
+size_t KSwitchKeys::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
+    size_t total = sizeof(ParmsID) + 2 * sizeof(size_t);
+    put(stream, parms_id_);
+    put(stream, keys_.size());
+    size_t valid = 0;
+    for (const auto& v : keys_) valid += !v.empty();
+    put(stream, valid);
+    for (size_t i = 0; i < keys_.size(); i++) {
+        if (keys_[i].empty()) continue;
+        put(stream, i);
+        put(stream, keys_[i].size());
+        total += 2 * sizeof(size_t);
+        for (const PublicKey& k : keys_[i]) total += k.save(stream, context, mode);
+    }
+    return total;
+}
+
+void KSwitchKeys::load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool) {
+    get(stream, parms_id_);
+    size_t size1d, valid;
+    get(stream, size1d); get(stream, valid);
+    if (size1d > (size_t(1) << 20) || valid > size1d) throw std::runtime_error("[KSwitchKeys::load] invalid sizes");
+    keys_.clear();
+    keys_.resize(size1d);
+    for (size_t v = 0; v < valid; v++) {
+        size_t id, size2d;
+        get(stream, id); get(stream, size2d);
+        if (id >= size1d || size2d > 64) throw std::runtime_error("[KSwitchKeys::load] invalid key index");
+        keys_[id].resize(size2d);
+        for (size_t j = 0; j < size2d; j++) keys_[id][j].load(stream, context, pool);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,14 +17,13 @@
 // Differences that are deliberate:
 //   * the Evaluator runs on the GPU only.  Operands must be on the device; a host-resident operand
 //     raises std::invalid_argument instead of silently taking a CPU path (there is none).
-//   * ParmsID is a 256-bit FNV digest of (scheme, N, moduli, t) rather than BLAKE2b (out of scope);
-//     it is only ever compared for equality.
 //   * multiply / relinearize / rescale also exist as *_batched (the reference lists them as
 //     "not implemented yet", test/bench/he_operations.cpp:119-135).
 #pragma once
 #include <complex>
 #include <cstdint>
 #include <cstring>
+#include <iosfwd>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -39,6 +38,8 @@
 namespace troy {
 
 enum class SchemeType : uint8_t { Nil = 0, BFV = 1, CKKS = 2, BGV = 3 };
+// utils/compression.h:15-18.  Only Nil is available (the reference's zstd submodule is not vendored either).
+enum class CompressionMode : uint8_t { Nil = 0, Zstd = 1 };
 enum class SecurityLevel : uint8_t { Nil = 0, Classical128 = 1, Classical192 = 2, Classical256 = 3 };
 
 // ----------------------------------------------------------------------------------------------
@@ -130,6 +131,8 @@ private:
 
 }  // namespace utils
 
+namespace utils { void blake2b(void* out, size_t outlen, const void* in, size_t inlen); }   // RFC 7693, unkeyed
+
 // helpers for code layered on the mirror (matmul.cpp): C-ABI status -> the reference's exception types, the calling
 // thread's stream (hipStreamPerThread), and a wait on it
 void troyn_check_public(int rc);
@@ -198,6 +201,9 @@ public:
     const Modulus& plain_modulus() const { return plain_modulus_; }
     bool use_special_prime_for_encryption() const { return use_special_prime_for_encryption_; }
     const ParmsID& parms_id() const { return parms_id_; }
+    // encryption_parameters.cu:53-112 (raw little-endian fields, no compression header)
+    size_t save(std::ostream& stream) const;
+    void load(std::istream& stream);
 private:
     void compute_parms_id();
     SchemeType scheme_;
@@ -329,6 +335,12 @@ public:
     const uint64_t* poly(size_t p) const { return data_.raw_pointer() + p * coeff_modulus_size_ * poly_modulus_degree_; }
     // resize(context, parms_id, polynomial_count) -- src/ciphertext.cu:26-60
     void resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep = true);
+    // ciphertext.cu:79-210, ciphertext.h:257-270: [CompressionMode][raw fields]; a seeded ciphertext stores c0 + seed only
+    size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
+    void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Ciphertext load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Ciphertext c; c.load(stream, context, pool); return c; }
+    size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
+    void expand_seed(HeContextPointer context);
 private:
     size_t polynomial_count_ = 0, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
     ParmsID parms_id_;
@@ -361,6 +373,11 @@ public:
     void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
     void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
     Plaintext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    // plaintext.cu:20-70, plaintext.h save/load: [CompressionMode][raw fields]; byte-compatible with the reference
+    size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
+    void load(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Plaintext load_new(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Plaintext p; p.load(stream, pool); return p; }
+    size_t serialized_size_upperbound(CompressionMode mode = CompressionMode::Nil) const;
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
 private:
@@ -385,6 +402,9 @@ public:
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
     SecretKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const { return data_.save(stream, mode); }
+    void load(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.load(stream, pool); }
+    static SecretKey load_new(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { SecretKey k; k.load(stream, pool); return k; }
 private:
     Plaintext data_;
 };
@@ -400,6 +420,11 @@ public:
     Ciphertext& as_ciphertext() { return data_; }
     const ParmsID& parms_id() const { return data_.parms_id(); }
     PublicKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const { return data_.save(stream, context, mode); }
+    void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.load(stream, context, pool); }
+    static PublicKey load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { PublicKey k; k.load(stream, context, pool); return k; }
+    bool contains_seed() const { return data_.contains_seed(); }
+    void expand_seed(HeContextPointer context) { data_.expand_seed(context); }
     bool on_device() const { return data_.on_device(); }
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
@@ -422,6 +447,9 @@ public:
     // device pointers of key_vector[index][j] (kswitch_keys.h:34-54), as a host array for the C-ABI
     std::vector<const uint64_t*> get_data_ptrs(size_t index) const;
     const KSwitchKeys& as_kswitch_keys() const { return *this; }
+    // kswitch_keys.cu:5-55
+    size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
+    void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
 private:
     ParmsID parms_id_;
     std::vector<std::vector<PublicKey>> keys_;
