@@ -181,6 +181,14 @@ int troyn_sample_centered_binomial(const troyn_plan* plan, uint32_t nmod, const 
                                    uint64_t* blocks_used, troyn_stream_t stream);
 int troyn_sample_uniform(const troyn_plan* plan, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
                          uint64_t* blocks_used, troyn_stream_t stream);
+/* batched forms (one launch for `count` polynomials, out[count][nmod][N]):
+ *   _strided: polynomial i continues the SAME generator at counter + i*counter_stride -- the positions `count`
+ *             sequential encryptions would have used (each consumes ceil(N/2) blocks here plus whatever else it draws);
+ *   _multi:   polynomial i comes from its own generator seeds[2i], seeds[2i+1] at counter 0 (the per-ciphertext
+ *             c1 generators of rlwe::symmetric, utils/rlwe.cu:262-266). */
+int troyn_sample_centered_binomial_strided(const troyn_plan* plan, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t counter_stride,
+                                           uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_sample_uniform_multi(const troyn_plan* plan, uint32_t nmod, const uint64_t* seeds, uint64_t* out, size_t count, troyn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Ciphertext x plaintext (the BASELINE config 5 matmul path):

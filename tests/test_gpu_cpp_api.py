@@ -144,3 +144,15 @@ def test_matmul_cpp_api(dev, dims):
         pytest.fail("tests/cpp/matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv] + [str(d) for d in dims], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout and "mismatches 0 of %d" % (dims[0] * dims[2]) in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n,count", [(8192, 19), (4096, 3)])
+def test_batched_encrypt_decrypt_cpp_api(dev, n, count):
+    """encryptor.h encrypt_symmetric_batched / decryptor.h decrypt_batched: bit-identical to the per-object calls on an
+    identically seeded context (the generator positions are reproduced), generators left at the same position."""
+    drv = os.path.join(ROOT, "tests", "cpp", "batched_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/batched_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, str(n), str(count)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "encrypt_mismatches 0 of" in r.stdout and "decrypt_mismatches 0 of" in r.stdout and "ntt_form_rejected 1" in r.stdout

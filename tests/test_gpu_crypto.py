@@ -28,6 +28,32 @@ def test_prng_block_and_samplers(O, pkg, dev):
     assert ref.sample_uint64() == gpu.sample_uint64()          # counters advanced identically
 
 
+def test_batched_samplers_reproduce_sequential_positions(O, pkg, dev):
+    """troyn_sample_centered_binomial_strided / troyn_sample_uniform_multi (batched encryption): item i equals what the
+    oracle's generator yields at the position a sequential encryption would use (seed block, then N/2 noise blocks)."""
+    ctx, plan, q, t, n = _ctx(O, pkg, dev)
+    count, nmod, per_ct = 19, 2, 1 + n // 2                    # 19 crosses the 16-generator launch chunk
+    ref, gpu = O.Rng(0x1234, 0x99), pkg.Prng(plan, 0x1234, 0x99)
+    for _ in range(3):
+        assert ref.sample_uint64() == gpu.sample_uint64()
+    base = gpu.counter
+    want_seed, want_noise, want_c1 = [], [], []
+    for i in range(count):
+        sd = ref.sample_uint64()
+        want_seed.append(sd)
+        want_c1.append(O.Rng(sd, 0).uniform(n, q[:nmod]))
+        want_noise.append(ref.centered_binomial(n, q[:nmod]))
+    seeds = []
+    for i in range(count):
+        gpu.counter = base + i * per_ct
+        seeds.append((gpu.sample_uint64(), 0))
+    assert [s[0] for s in seeds] == want_seed
+    gpu.counter = base + 1
+    noise = pkg.to_host(gpu.centered_binomial_strided(nmod, count, per_ct))
+    c1 = pkg.to_host(pkg.sample_uniform_multi(plan, nmod, seeds))
+    assert np.array_equal(noise, np.stack(want_noise)) and np.array_equal(c1, np.stack(want_c1))
+
+
 @pytest.mark.parametrize("n,bits,t", [(8192, [40, 40, 40], 1032193), (4096, [36, 36, 37], 1 << 21), (1024, [50, 50], 65537)])
 def test_scale_up_and_decrypt_round(O, pkg, dev, n, bits, t):
     q = [int(v) for v in O.coeff_modulus_create(n, bits)]

@@ -130,6 +130,7 @@ def main():
         res["cfg5_e2e"] = {"what": "BFV 512x512x512 matmul through MatmulHelper (N=8192, {60,40,40,60}, t=2^21), encrypted inputs x plaintext weights",
                            "block": lines["block"], "objects": " ".join(lines["objects"]), "ms": ms,
                            "latency_ms_encrypt_matmul_decrypt": round(ms["encrypt_inputs"] + ms["matmul_repeat"] + ms["decrypt"], 2),
+                           "ms_repeat": dict(zip(lines["ms_repeat"][0::2], [float(v) for v in lines["ms_repeat"][1::2]])),
                            "correct": "OK" in r.stdout}
         # CPU baseline of the matmul core (the oracle's multiply_plain_ntt + add, one thread), on a bounded sample of terms
         import numpy as np

@@ -60,6 +60,8 @@ SYMBOLS = {
     "troyn_sample_ternary": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
     "troyn_sample_centered_binomial": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
     "troyn_sample_uniform": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
+    "troyn_sample_centered_binomial_strided": (C.c_int, [vp, u32, p64, u64, u64, vp, sz, vp]),
+    "troyn_sample_uniform_multi": (C.c_int, [vp, u32, p64, vp, sz, vp]),
     "troyn_bfv_multiply_workspace_bytes": (sz, [vp, sz, sz, sz]),
     "troyn_bfv_multiply": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, sz, sz, vp]),
 }

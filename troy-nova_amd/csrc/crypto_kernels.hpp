@@ -63,6 +63,43 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(AesRoundKeys key, u
     }
 }
 
+// batched forms for many independent ciphertexts in one launch (grid.y = item):
+//   centered binomial: item i draws from the SAME generator at counter + i * counter_stride (what i sequential
+//   encryptions would have consumed); uniform: item i has its own generator (key i), counter 0
+constexpr int SAMPLE_MULTI_KEYS = 16;     // 16 x 176 B of round keys fit the kernel-argument block
+struct AesRoundKeysMulti { AesRoundKeys k[SAMPLE_MULTI_KEYS]; };
+
+__global__ __launch_bounds__(256) void sample_cbd_strided_kernel(AesRoundKeys key, u64 counter, u64 counter_stride, const DevModulus* mods, unsigned nmod,
+                                                                unsigned n, u64* out) {
+    const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned item = blockIdx.y;
+    if ((size_t)blk * 2 >= n) return;
+    u64 w[2];
+    const u64 ctr = counter + (u64)item * counter_stride + blk;
+    aes128_encrypt_counter(key, ctr, 0ull, w[0], w[1]);
+    u64* op = out + (size_t)item * nmod * n;
+    for (unsigned k = 0; k < 2 && blk * 2 + k < n; k++) {
+        const int v = cbd_from_u64(w[k]);
+        const unsigned j = blk * 2 + k;
+        for (unsigned i = 0; i < nmod; i++) op[(size_t)i * n + j] = (v >= 0) ? (u64)v : mods[i].q - (u64)(-v);
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_uniform_multi_kernel(AesRoundKeysMulti keys, const DevModulus* mods, unsigned nmod, unsigned n, u64* out) {
+    const size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned item = blockIdx.y;
+    const size_t total = (size_t)nmod * n;
+    if (blk * 2 >= total) return;
+    u64 w[2];
+    aes128_encrypt_counter(keys.k[item], (u64)blk, 0ull, w[0], w[1]);
+    u64* op = out + (size_t)item * total;
+    for (unsigned k = 0; k < 2 && blk * 2 + k < total; k++) {
+        const size_t pos = blk * 2 + k;
+        const DevModulus md = mods[pos / n];
+        op[pos] = barrett64(w[k], md.q, md.ratio_hi);
+    }
+}
+
 struct ScaleUpArgs {
     unsigned L, n, plain_coeff_count, subtract;
     const DevModulus* mods;

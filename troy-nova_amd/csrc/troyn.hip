@@ -1037,6 +1037,39 @@ extern "C" int troyn_sample_uniform(const troyn_plan* p, uint32_t nmod, const ui
                           p ? ((size_t)p->n * nmod + 1) / 2 : 0, blocks_used, stream);
 }
 
+extern "C" int troyn_sample_centered_binomial_strided(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t counter_stride,
+                                                      uint64_t* out, size_t count, troyn_stream_t stream) {
+    const char* P = "[RandomGenerator::sample_poly_centered_binomial]";
+    if (!p || !seed || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    if (count == 0) return TROYN_OK;
+    if (count > 65535) return fail(TROYN_E_INVALID, std::string(P) + " batch too large for one launch");
+    const AesRoundKeys k = aes128_expand(seed[0], seed[1]);
+    const unsigned blocks = (unsigned)((((size_t)p->n + 1) / 2 + 255) / 256);
+    hipLaunchKernelGGL(sample_cbd_strided_kernel, dim3(blocks, (unsigned)count), dim3(256), 0, (hipStream_t)stream,
+                       k, (u64)counter, (u64)counter_stride, p->d_mods, (unsigned)nmod, p->n, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_sample_uniform_multi(const troyn_plan* p, uint32_t nmod, const uint64_t* seeds, uint64_t* out, size_t count, troyn_stream_t stream) {
+    const char* P = "[RandomGenerator::sample_poly_uniform]";
+    if (!p || !seeds || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    const size_t per_item = (size_t)nmod * p->n;
+    const unsigned blocks = (unsigned)(((per_item + 1) / 2 + 255) / 256);
+    for (size_t base = 0; base < count; base += SAMPLE_MULTI_KEYS) {
+        const size_t m = std::min<size_t>(SAMPLE_MULTI_KEYS, count - base);
+        AesRoundKeysMulti keys;
+        std::memset(&keys, 0, sizeof(keys));
+        for (size_t i = 0; i < m; i++) keys.k[i] = aes128_expand(seeds[2 * (base + i)], seeds[2 * (base + i) + 1]);
+        hipLaunchKernelGGL(sample_uniform_multi_kernel, dim3(blocks, (unsigned)m), dim3(256), 0, (hipStream_t)stream,
+                           keys, p->d_mods, (unsigned)nmod, p->n, (u64*)out + base * per_item);
+        LAUNCH_CHECK();
+    }
+    return TROYN_OK;
+}
+
 extern "C" int troyn_bfv_scale_up(const troyn_behz* b, const uint64_t* plain, size_t plain_coeff_count, size_t plain_bstride,
                                   const uint64_t* from, size_t from_bstride, uint64_t* dest, size_t dest_bstride,
                                   int subtract, size_t batch, troyn_stream_t stream) {

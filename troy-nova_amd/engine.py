@@ -274,6 +274,23 @@ class Prng:
     def uniform(self, nmod):
         return self._sample("troyn_sample_uniform", nmod)
 
+    def centered_binomial_strided(self, nmod, count, counter_stride):
+        """`count` noise polynomials; item i reads the blocks from counter + i*counter_stride (the positions `count`
+        sequential encryptions would use).  The counter is not advanced: the caller owns the block range."""
+        out = torch.empty((count, nmod, self.plan.n), dtype=torch.int64, device=self.plan.device)
+        capi.check(self.plan.lib.troyn_sample_centered_binomial_strided(self.plan.h, nmod, self.seed.ctypes.data_as(capi.p64), self.counter,
+                                                                        int(counter_stride), _ptr(out), count, _stream()))
+        return out
+
+
+def sample_uniform_multi(plan, nmod, seeds):
+    """One uniform RNS polynomial per seed pair (low, high), each from block 0 of its own generator (the c1 generators
+    of `len(seeds)` symmetric encryptions, utils/rlwe.cu:252-262)."""
+    sd = np.ascontiguousarray(np.array(seeds, dtype=np.uint64).reshape(-1, 2))
+    out = torch.empty((sd.shape[0], nmod, plan.n), dtype=torch.int64, device=plan.device)
+    capi.check(plan.lib.troyn_sample_uniform_multi(plan.h, nmod, sd.ctypes.data_as(capi.p64), _ptr(out), sd.shape[0], _stream()))
+    return out
+
 
 class Behz:
     """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""

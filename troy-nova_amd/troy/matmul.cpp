@@ -103,16 +103,41 @@ Plain2d MatmulHelper::encode_inputs_uint64s(const BatchEncoder& encoder, const u
 }
 
 Cipher2d MatmulHelper::encrypt_inputs_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* inputs) const {
-    Plain2d plain = encode_inputs_uint64s(encoder, inputs);
-    Evaluator evaluator(encoder.context());
-    Cipher2d out;
-    for (size_t i = 0; i < plain.size(); i++) {
-        std::vector<Ciphertext> row;
-        for (size_t j = 0; j < plain[i].size(); j++) {
-            Ciphertext c = encryptor.encrypt_symmetric_new(plain[i][j], false, pool);
-            evaluator.transform_to_ntt_inplace(c);          // the products are taken in NTT form
-            row.push_back(std::move(c));
+    // every block packed on the host, one copy, one batched symmetric encryption, one batched NTT (the same ciphertexts
+    // as encode_inputs_uint64s + encrypt_symmetric per block, see Encryptor::encrypt_symmetric_packed)
+    HeContextPointer context = encoder.context();
+    const size_t n = slot_count;
+    const uint64_t t = context->first_context_data().value()->parms().plain_modulus().value();
+    const size_t rows = ceil_div(batch_size, batch_block), cols = ceil_div(input_dims, input_block), count = rows * cols;
+    std::vector<uint64_t> packed(count * n, 0);
+    size_t idx = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        for (size_t lj = 0; lj < input_dims; lj += input_block, idx++) {
+            const size_t uj = std::min(lj + input_block, input_dims);
+            uint64_t* vec = packed.data() + idx * n;
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) {
+                    const uint64_t v = inputs[i * input_dims + j];
+                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
+                    vec[(i - li) * input_block * output_block + (j - lj)] = v;
+                }
         }
+    }
+    utils::DynamicArray staged(packed.size(), true, pool);
+    staged.copy_from(packed.data(), packed.size(), false);
+    std::vector<Ciphertext> cts = encryptor.encrypt_symmetric_packed(staged.raw_pointer(), n, n, count, pool);
+    // the products are taken in NTT form: the ciphertexts are windows of one buffer, transformed in one launch
+    const uint32_t L = static_cast<uint32_t>(cts[0].coeff_modulus_size());
+    troyn_check_public(troyn_ntt(context->plan(), 0, cts[0].data().raw_pointer(), cts[0].data().raw_pointer(), count, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0,
+                                 troyn_current_stream()));
+    for (Ciphertext& c : cts) c.is_ntt_form() = true;
+    troyn_sync_current_stream();
+    Cipher2d out;
+    idx = 0;
+    for (size_t r = 0; r < rows; r++) {
+        std::vector<Ciphertext> row;
+        for (size_t c = 0; c < cols; c++, idx++) row.push_back(std::move(cts[idx]));
         out.data().push_back(std::move(row));
     }
     return out;
@@ -123,33 +148,48 @@ Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, con
     const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
     if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
     if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
+    // the results are windows of one zeroed buffer, so the trailing inverse NTT is one launch
+    const Ciphertext& a0 = a[0][0];
+    const size_t pcnt = a0.polynomial_count(), L = a0.coeff_modulus_size(), n = a0.poly_modulus_degree(), words = pcnt * L * n;
+    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, pool);
+    shared->set_zero();
     Cipher2d ret;
     ret.data().resize(batch_split);
-    for (auto& r : ret.data()) r.resize(output_split);
+    for (size_t b = 0; b < batch_split; b++)
+        for (size_t j = 0; j < output_split; j++)
+            ret[b].push_back(Ciphertext::from_members(pcnt, L, n, a0.parms_id(), a0.scale(), true, a0.correction_factor(), 0,
+                                                      utils::DynamicArray::device_view(shared->raw_pointer() + (b * output_split + j) * words, words, shared)));
     std::vector<const Ciphertext*> a_ptrs;
     std::vector<const Plaintext*> w_ptrs;
     std::vector<Ciphertext*> r_ptrs;
     for (size_t i = 0; i < input_split; i++)
         for (size_t j = 0; j < output_split; j++)
             for (size_t b = 0; b < batch_split; b++) { a_ptrs.push_back(&a[b][i]); w_ptrs.push_back(&w[i][j]); r_ptrs.push_back(&ret[b][j]); }
-    evaluator.multiply_plain_accumulate(a_ptrs, w_ptrs, r_ptrs, true, pool);
-    for (auto& r : ret.data()) for (Ciphertext& c : r) evaluator.transform_from_ntt_inplace(c);     // BFV results leave in coefficient form
+    evaluator.multiply_plain_accumulate(a_ptrs, w_ptrs, r_ptrs, false, pool);
+    // BFV results leave in coefficient form
+    troyn_check_public(troyn_ntt(evaluator.context()->plan(), 1, shared->raw_pointer(), shared->raw_pointer(), batch_split * output_split, pcnt,
+                                 static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
+    troyn_sync_current_stream();
+    for (auto& r : ret.data()) for (Ciphertext& c : r) c.is_ntt_form() = false;
     return ret;
 }
 
 std::vector<uint64_t> MatmulHelper::decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
-    // app/matmul.cu:560-640
+    // app/matmul.cu:560-640; all output ciphertexts decrypted as one batch and read back with one copy
+    (void)encoder;
+    std::vector<const Ciphertext*> all;
+    for (const auto& r : outputs.data()) for (const Ciphertext& c : r) all.push_back(&c);
+    const std::vector<uint64_t> coeffs = decryptor.bfv_decrypt_to_host(all, pool);
+    const size_t n = slot_count;
     std::vector<uint64_t> out(batch_size * output_dims, 0);
-    size_t bi = 0;
-    for (size_t li = 0; li < batch_size; li += batch_block, bi++) {
+    size_t idx = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
         const size_t ui = std::min(li + batch_block, batch_size);
-        size_t bj = 0;
-        for (size_t lj = 0; lj < output_dims; lj += output_block, bj++) {
+        for (size_t lj = 0; lj < output_dims; lj += output_block, idx++) {
             const size_t uj = std::min(lj + output_block, output_dims);
-            const std::vector<uint64_t> coeffs = encoder.decode_polynomial_new(decryptor.decrypt_new(outputs[bi][bj], pool), pool);
+            const uint64_t* cf = coeffs.data() + idx * n;
             for (size_t i = li; i < ui; i++)
-                for (size_t j = lj; j < uj; j++)
-                    out[i * output_dims + j] = coeffs[(i - li) * input_block * output_block + (j - lj) * input_block + input_block - 1];
+                for (size_t j = lj; j < uj; j++) out[i * output_dims + j] = cf[(i - li) * input_block * output_block + (j - lj) * input_block + input_block - 1];
         }
     }
     return out;

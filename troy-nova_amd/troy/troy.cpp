@@ -1417,6 +1417,13 @@ uint64_t RandomGenerator::sample_uint64() {
     return out[0];
 }
 
+uint64_t RandomGenerator::reserve_blocks(uint64_t blocks) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    const uint64_t first = counter_;
+    counter_ += blocks;
+    return first;
+}
+
 void RandomGenerator::sample_poly_ternary(const troyn_plan* plan, size_t nmod, uint64_t* destination) {
     std::lock_guard<std::mutex> lock(mutex_);
     uint64_t used = 0;
@@ -1757,6 +1764,73 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
     }
 }
 
+std::vector<Ciphertext> Encryptor::encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count, MemoryPoolHandle pool) const {
+    // rlwe::symmetric (utils/rlwe.cu:218-317) + multiply_add_plain for `count` BFV plaintexts, batched.  Ciphertext i uses
+    // exactly the generator blocks a sequential call would: block base + i*(1 + N/2) for its c1 seed, the next N/2 blocks
+    // for its noise.
+    const char* P = "[Encryptor::encrypt_symmetric_batched]";
+    require_device_context(P, context_);
+    if (!secret_key_.has_value()) throw std::invalid_argument("[Encryptor::encrypt_zero_internal] Secret key not set for symmetric encryption.");
+    ContextDataPointer cd = context_->first_context_data().value();
+    if (cd->parms().scheme() != SchemeType::BFV) throw std::logic_error(std::string(P) + " the packed path is BFV only.");
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t n = cd->parms().poly_modulus_degree(), pc = static_cast<size_t>(L) * n;
+    if (coeff_count > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+    std::vector<Ciphertext> out;
+    if (count == 0) return out;
+    const troyn_plan* plan = context_->plan();
+    hipStream_t s = current_stream();
+    utils::RandomGenerator& prng = context_->random_generator();
+    const uint64_t per_ct = 1 + (n + 1) / 2;
+    const uint64_t base = prng.reserve_blocks(per_ct * count);
+    std::vector<uint64_t> seeds(2 * count, 0);
+    for (size_t i = 0; i < count; i++) {
+        uint64_t blk[2];
+        troyn_check(troyn_prng_block(prng.seed(), base + i * per_ct, blk));
+        // the sequential path redraws a zero seed, which would shift every later position; probability 2^-64 per draw
+        if (blk[0] == 0) throw std::runtime_error(std::string(P) + " a zero c1 seed was drawn; encrypt again.");
+        seeds[2 * i] = blk[0];
+    }
+    utils::DynamicArray c0(count * pc, true, pool), c1(count * pc, true, pool), noise(count * pc, true, pool);
+    troyn_check(troyn_sample_uniform_multi(plan, L, seeds.data(), c1.raw_pointer(), count, s));
+    troyn_check(troyn_sample_centered_binomial_strided(plan, L, prng.seed(), base + 1, per_ct, noise.raw_pointer(), count, s));
+    // c0 = -(INTT(c1 (.) s) + e) + round(q/t * m); c1 is sampled as an NTT-form polynomial and leaves in coefficient form
+    troyn_check(troyn_dyadic_broadcast_product(plan, 0, L, c1.raw_pointer(), 1, secret_key_.value().data().raw_pointer(), 0, c0.raw_pointer(), count, s));
+    troyn_check(troyn_ntt(plan, 1, c0.raw_pointer(), c0.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_add(plan, 0, L, c0.raw_pointer(), noise.raw_pointer(), c0.raw_pointer(), count, s));
+    troyn_check(troyn_negate(plan, 0, L, c0.raw_pointer(), c0.raw_pointer(), count, s));
+    troyn_check(troyn_ntt(plan, 1, c1.raw_pointer(), c1.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_bfv_scale_up(context_->behz(L), plains, coeff_count, stride, c0.raw_pointer(), pc, c0.raw_pointer(), pc, 0, count, s));
+    auto shared = std::make_shared<utils::DynamicArray>(count * 2 * pc, true, pool);
+    hip_check(hipMemcpy2DAsync(shared->raw_pointer(), 2 * pc * 8, c0.raw_pointer(), pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+    hip_check(hipMemcpy2DAsync(shared->raw_pointer() + pc, 2 * pc * 8, c1.raw_pointer(), pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+    hip_check(hipStreamSynchronize(s), "stream_sync");
+    out.reserve(count);
+    for (size_t i = 0; i < count; i++)
+        out.push_back(Ciphertext::from_members(2, L, n, cd->parms_id(), 1.0, false, 1, 0, utils::DynamicArray::device_view(shared->raw_pointer() + i * 2 * pc, 2 * pc, shared)));
+    return out;
+}
+
+void Encryptor::encrypt_symmetric_batched(const std::vector<const Plaintext*>& plain, bool save_seed, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    if (plain.size() != destination.size()) throw std::invalid_argument("[Encryptor::encrypt_symmetric_batched] plain and destination are not the same size.");
+    if (plain.empty()) return;
+    bool packable = !save_seed && context_->on_device() && context_->key_context_data().value()->parms().scheme() == SchemeType::BFV;
+    for (const Plaintext* p : plain) packable = packable && p->parms_id() == parms_id_zero && !p->is_ntt_form() && p->on_device();
+    if (!packable) {
+        for (size_t i = 0; i < plain.size(); i++) encrypt_symmetric(*plain[i], save_seed, *destination[i], pool);
+        return;
+    }
+    const size_t n = context_->first_context_data().value()->parms().poly_modulus_degree();
+    utils::DynamicArray staged(plain.size() * n, true, pool);
+    staged.set_zero();
+    for (size_t i = 0; i < plain.size(); i++) {
+        if (plain[i]->coeff_count() > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+        hip_check(hipMemcpyAsync(staged.raw_pointer() + i * n, plain[i]->poly(), plain[i]->coeff_count() * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+    }
+    std::vector<Ciphertext> out = encrypt_symmetric_packed(staged.raw_pointer(), n, n, plain.size(), pool);
+    for (size_t i = 0; i < plain.size(); i++) *destination[i] = std::move(out[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decryptor  (decryptor.cu)
 // ------------------------------------------------------------------------------------------------
@@ -1837,6 +1911,83 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
         }
         default:
             throw std::logic_error("[Decryptor::decrypt] BGV is not part of this build.");
+    }
+}
+
+bool Decryptor::bfv_batchable(const std::vector<const Ciphertext*>& encrypted) const {
+    if (encrypted.empty() || !context_->on_device()) return false;
+    auto cd = context_->get_context_data(encrypted[0]->parms_id());
+    if (!cd.has_value() || cd.value()->parms().scheme() != SchemeType::BFV) return false;
+    for (const Ciphertext* c : encrypted)
+        if (c->parms_id() != encrypted[0]->parms_id() || c->polynomial_count() != 2 || c->is_ntt_form() || c->contains_seed() || !c->on_device()) return false;
+    return true;
+}
+
+std::shared_ptr<utils::DynamicArray> Decryptor::bfv_decrypt_batch_device(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool) const {
+    // decryptor.cu:107-225 (dot_product_ct_sk_array_batched) + decrypt_scale_and_round for two-polynomial BFV ciphertexts:
+    // gather, then a constant number of launches
+    ContextDataPointer cd = context_->get_context_data(encrypted[0]->parms_id()).value();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t n = cd->parms().poly_modulus_degree(), pc = static_cast<size_t>(L) * n, count = encrypted.size();
+    const troyn_plan* plan = context_->plan();
+    hipStream_t s = current_stream();
+    utils::DynamicArray c0(count * pc, true, pool), c1(count * pc, true, pool);
+    // ciphertexts that are equally spaced windows of one buffer (what the batched producers return) gather in two copies
+    const uint64_t* first = encrypted[0]->poly(0);
+    const ptrdiff_t step = count > 1 ? encrypted[1]->poly(0) - first : static_cast<ptrdiff_t>(2 * pc);
+    bool strided = step >= static_cast<ptrdiff_t>(2 * pc);
+    for (size_t i = 0; i < count && strided; i++) strided = encrypted[i]->poly(0) == first + static_cast<ptrdiff_t>(i) * step;
+    if (strided) {
+        hip_check(hipMemcpy2DAsync(c0.raw_pointer(), pc * 8, first, static_cast<size_t>(step) * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+        hip_check(hipMemcpy2DAsync(c1.raw_pointer(), pc * 8, first + pc, static_cast<size_t>(step) * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+    } else {
+        for (size_t i = 0; i < count; i++) {
+            hip_check(hipMemcpyAsync(c0.raw_pointer() + i * pc, encrypted[i]->poly(0), pc * 8, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+            hip_check(hipMemcpyAsync(c1.raw_pointer() + i * pc, encrypted[i]->poly(1), pc * 8, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+        }
+    }
+    std::lock_guard<std::mutex> lock(secret_key_array_mutex_);
+    troyn_check(troyn_ntt(plan, 0, c1.raw_pointer(), c1.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_dyadic_broadcast_product(plan, 0, L, c1.raw_pointer(), 1, secret_key_array_.raw_pointer(), 0, c1.raw_pointer(), count, s));
+    troyn_check(troyn_ntt(plan, 1, c1.raw_pointer(), c1.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    troyn_check(troyn_add(plan, 0, L, c1.raw_pointer(), c0.raw_pointer(), c1.raw_pointer(), count, s));
+    auto out = std::make_shared<utils::DynamicArray>(count * n, true, pool);
+    troyn_check(troyn_bfv_decrypt_scale_and_round(context_->behz(L), c1.raw_pointer(), out->raw_pointer(), count, s));
+    hip_check(hipStreamSynchronize(s), "stream_sync");
+    return out;
+}
+
+std::vector<uint64_t> Decryptor::bfv_decrypt_to_host(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool) const {
+    require_device_context("[Decryptor::decrypt_batched]", context_);
+    if (!bfv_batchable(encrypted)) {
+        std::vector<uint64_t> all;
+        for (const Ciphertext* c : encrypted) {
+            const std::vector<uint64_t> v = decrypt_new(*c, pool).data().to_vector();
+            all.insert(all.end(), v.begin(), v.end());
+        }
+        return all;
+    }
+    return bfv_decrypt_batch_device(encrypted, pool)->to_vector();
+}
+
+void Decryptor::decrypt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool) const {
+    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Decryptor::decrypt_batched] encrypted and destination are not the same size.");
+    if (!bfv_batchable(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) decrypt(*encrypted[i], *destination[i], pool);
+        return;
+    }
+    ContextDataPointer cd = context_->get_context_data(encrypted[0]->parms_id()).value();
+    const size_t n = cd->parms().poly_modulus_degree(), L = cd->parms().coeff_modulus().size();
+    std::shared_ptr<utils::DynamicArray> shared = bfv_decrypt_batch_device(encrypted, pool);
+    for (size_t i = 0; i < encrypted.size(); i++) {
+        Plaintext out;
+        out.data() = utils::DynamicArray::device_view(shared->raw_pointer() + i * n, n, shared);
+        out.parms_id() = parms_id_zero;
+        out.coeff_count() = n;
+        out.is_ntt_form() = false;
+        out.coeff_modulus_size() = L;
+        out.poly_modulus_degree() = n;
+        *destination[i] = std::move(out);
     }
 }
 

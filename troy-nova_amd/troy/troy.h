@@ -123,6 +123,9 @@ public:
     void sample_poly_ternary(const troyn_plan* plan, size_t nmod, uint64_t* destination);
     void sample_poly_centered_binomial(const troyn_plan* plan, size_t nmod, uint64_t* destination);
     void sample_poly_uniform(const troyn_plan* plan, size_t nmod, uint64_t* destination);
+    // batched encryption: take `blocks` consecutive counter values at once (returns the first); read the seed
+    uint64_t reserve_blocks(uint64_t blocks);
+    const uint64_t* seed() const { return seed_; }
 private:
     uint64_t seed_[2] = {0, 0};
     uint64_t counter_ = 0;
@@ -533,6 +536,13 @@ public:
     Ciphertext encrypt_asymmetric_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_asymmetric(plain, d, pool); return d; }
     void encrypt_symmetric(const Plaintext& plain, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encrypt_internal(plain, false, save_seed, destination, pool); }
     Ciphertext encrypt_symmetric_new(const Plaintext& plain, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_symmetric(plain, save_seed, d, pool); return d; }
+    // encryptor.h encrypt_symmetric_batched: the same ciphertexts, bit for bit, as encrypt_symmetric called once per plaintext
+    // in order (the generator positions are reproduced), in a constant number of launches; the results share one buffer
+    void encrypt_symmetric_batched(const std::vector<const Plaintext*>& plain, bool save_seed, const std::vector<Ciphertext*>& destination,
+                                   MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    // the same for `count` BFV plaintexts (parms_id_zero, coefficient form) already on the device, `stride` words apart
+    std::vector<Ciphertext> encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count,
+                                                     MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_asymmetric(d, parms_id, pool); return d; }
     void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
@@ -552,8 +562,14 @@ public:
     bool on_device() const { return secret_key_array_.on_device(); }
     void decrypt(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext decrypt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; decrypt(encrypted, d, pool); return d; }
+    // decryptor.h decrypt_batched (BFV two-polynomial ciphertexts of one level take the batched path; anything else loops)
+    void decrypt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    // the plaintext coefficients of every ciphertext, concatenated on the host ([count][N]); one device-to-host copy
+    std::vector<uint64_t> bfv_decrypt_to_host(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
 private:
     void dot_product_ct_sk_array(const Ciphertext& encrypted, uint64_t* destination, MemoryPoolHandle pool) const;
+    bool bfv_batchable(const std::vector<const Ciphertext*>& encrypted) const;
+    std::shared_ptr<utils::DynamicArray> bfv_decrypt_batch_device(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool) const;   // [count][N] mod t
     HeContextPointer context_;
     mutable std::mutex secret_key_array_mutex_;
     mutable utils::DynamicArray secret_key_array_;
