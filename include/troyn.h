@@ -211,6 +211,33 @@ int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, u
  * the permuted c1 with TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST (evaluator_keyswitching.cu:147-179). */
 int troyn_apply_galois(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
                        const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream);
+/* RLWE / LWE packing (evaluator_lwes.cu):
+ *   troyn_negacyclic_shift     utils::negacyclic_shift_ps (utils/poly_small_mod.cu:927-968): multiply `count` RNS polynomials by
+ *                              X^shift, shift in [0, 2N); out of place
+ *   troyn_multiply_inv_degree  utils::ntt_multiply_inv_degree (utils/ntt.cu:93-134): x * N^-1 * scalar mod q_l
+ *                              (Evaluator::divide_by_poly_modulus_degree_inplace, evaluator_lwes.cu:142-151)
+ *   troyn_pack_prepare         first step of Evaluator::pack_rlwe_ciphertexts_new(_batched) (evaluator_lwes.cu:361-381, :599-640):
+ *                              out[slot] = X^shift * src[slot] * N^-1 * mul, zero where src[slot] == NULL; src = host array of
+ *                              `slots` device pointers to coefficient-form ciphertexts u64[pcount][L][N]
+ *   troyn_pack_layer           one layer of the packing tree (:441-477, :654-697) on adjacent pairs in[2k] (even), in[2k+1] (odd)
+ *                              of two-polynomial ciphertexts:  temp = X^shift*odd, out[k] = even + temp + perm_g(even - temp) with
+ *                              the permuted c1 diverted to target[k]; follow with troyn_switch_key(target -> out, ADD_INPLACE,
+ *                              batch = pairs, Galois key of g) to finish apply_galois.  in u64[2*pairs][2][L][N],
+ *                              out u64[pairs][2][L][N], target u64[pairs][L][N]
+ *   troyn_extract_lwe          Evaluator::extract_lwe_new (evaluator_lwes.cu:52-97) for `count` (ciphertext, term) pairs:
+ *                              c0 u64[count][L], c1 u64[count][L][N] */
+int troyn_negacyclic_shift(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, size_t shift,
+                           size_t count, troyn_stream_t stream);
+int troyn_multiply_inv_degree(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, uint64_t scalar,
+                              size_t count, troyn_stream_t stream);
+size_t troyn_pack_prepare_workspace_bytes(size_t slots);
+int troyn_pack_prepare(const troyn_plan* plan, uint32_t L, size_t pcount, const uint64_t* const* src, size_t slots, uint64_t mul, size_t shift,
+                       uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream);
+int troyn_pack_layer(const troyn_plan* plan, uint32_t L, uint64_t galois_element, size_t shift, const uint64_t* in, uint64_t* out,
+                     uint64_t* target, size_t pairs, troyn_stream_t stream);
+size_t troyn_extract_lwe_workspace_bytes(size_t count);
+int troyn_extract_lwe(const troyn_plan* plan, uint32_t L, const uint64_t* const* ct, const size_t* terms, uint64_t* c0, uint64_t* c1, size_t count,
+                      void* workspace, size_t workspace_bytes, troyn_stream_t stream);
 size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count);
 int troyn_multiply_plain_accumulate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, size_t pcount,
                                     const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,

@@ -132,6 +132,9 @@ def lib():
     sig("orc_fnv_words", u64, p64, sz)
     sig("orc_apply_galois", None, vp, sz, C.c_int, sz, p64, sz, p64)
     sig("orc_apply_galois_ct", None, vp, sz, C.c_int, sz, p64, C.POINTER(p64), p64)
+    sig("orc_negacyclic_shift", None, vp, sz, p64, sz, sz, p64)
+    sig("orc_multiply_inv_degree", None, vp, sz, p64, sz, u64)
+    sig("orc_extract_lwe", None, vp, sz, p64, sz, p64, p64)
     sig("orc_keygen_galois_key", None, vp, vp, p64, sz, p64)
     sig("orc_galois_element_from_step", sz, sz, C.c_int)
     sig("orc_plain_centralize", C.c_int, vp, sz, p64, sz, p64)
@@ -495,6 +498,85 @@ class Context:
         out = np.zeros(ct.size, dtype=np.uint64)
         lib().orc_apply_galois_ct(self.h, L, int(is_ntt_form), element, ptr(ct.reshape(-1)), karr, ptr(out))
         return out.reshape(2, L, self.n)
+
+    def negacyclic_shift(self, nmod, data, shift):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros(data.size, dtype=np.uint64)
+        lib().orc_negacyclic_shift(self.h, nmod, ptr(data.reshape(-1)), data.size // (nmod * self.n), shift, ptr(out))
+        return out.reshape(data.shape)
+
+    def multiply_inv_degree(self, nmod, data, scalar):
+        out = np.array(data, dtype=np.uint64, copy=True, order="C")
+        lib().orc_multiply_inv_degree(self.h, nmod, ptr(out.reshape(-1)), out.size // (nmod * self.n), scalar)
+        return out
+
+    def extract_lwe(self, L, ct, term):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        c0, c1 = np.zeros(L, dtype=np.uint64), np.zeros(L * self.n, dtype=np.uint64)
+        lib().orc_extract_lwe(self.h, L, ptr(ct.reshape(-1)), term, ptr(c0), ptr(c1))
+        return c0, c1.reshape(L, self.n)
+
+    def assemble_lwe(self, L, c0, c1):
+        """LWECiphertext::assemble_lwe (lwe_ciphertext.cu:9-60): c0 becomes the constant coefficient, c1 is kept"""
+        ct = np.zeros((2, L, self.n), dtype=np.uint64)
+        ct[0, :, 0] = c0
+        ct[1] = c1
+        return ct
+
+    def _ct_add(self, L, a, b, subtract=False):
+        q = np.array(self.q[:L], dtype=np.uint64).reshape(1, L, 1)
+        return (a + (q - b if subtract else b)) % q          # q < 2^61: no wrap
+
+    def pack_rlwe_ciphertexts(self, L, cts, keys_by_element, shift, input_interval, output_interval, is_ntt_form=False, apply_field_trace=True):
+        """Evaluator::pack_rlwe_ciphertexts_new, host branch (evaluator_lwes.cu:315-439, :479-489), for BFV (results stay in
+        coefficient form).  cts: list of [2][L][N]; keys_by_element: {galois element: the L keys of that element}."""
+        n = self.n
+        maxc = input_interval // output_interval
+        layers = maxc.bit_length() - 1
+        assert 1 <= len(cts) <= maxc and (1 << layers) == maxc
+        rl = [None] * maxc
+        for i in range(maxc):
+            index = int("{:0{w}b}".format(i, w=layers)[::-1], 2) if layers else 0
+            if index < len(cts):
+                c = np.array(cts[index], dtype=np.uint64, copy=True)
+                if is_ntt_form:
+                    c = self.from_ntt(c, 2, L)
+                c = self.multiply_inv_degree(L, c, n // input_interval)
+                if shift:
+                    c = self.negacyclic_shift(L, c, shift)
+                rl[i] = c
+        for layer in range(layers):
+            gap, sh = 1 << layer, input_interval >> (layer + 1)
+            g = (n // input_interval) * (1 << (layer + 1)) + 1
+            for offset in range(0, maxc, gap * 2):
+                even, odd = rl[offset], rl[offset + gap]
+                if even is None and odd is None:
+                    continue
+                temp = self.negacyclic_shift(L, odd, sh) if odd is not None else None
+                if even is not None:
+                    if odd is not None:
+                        odd2 = self._ct_add(L, even, temp, subtract=True)
+                        even = self._ct_add(L, even, temp)
+                        even = self._ct_add(L, even, self.apply_galois_ct(L, False, g, odd2, keys_by_element[g]))
+                    else:
+                        even = self._ct_add(L, even, self.apply_galois_ct(L, False, g, even, keys_by_element[g]))
+                else:
+                    neg = self._ct_add(L, np.zeros_like(temp), temp, subtract=True)
+                    even = self._ct_add(L, self.apply_galois_ct(L, False, g, neg, keys_by_element[g]), temp)
+                rl[offset] = even
+        ret = rl[0]
+        if output_interval != 1 and apply_field_trace:
+            logn = (n // output_interval).bit_length() - 1
+            ret = self.field_trace(L, ret, keys_by_element, logn)
+        return ret
+
+    def field_trace(self, L, ct, keys_by_element, logn):
+        """Evaluator::field_trace_inplace (evaluator_lwes.cu:100-109), coefficient form"""
+        d = self.n
+        while d > (1 << logn):
+            ct = self._ct_add(L, ct, self.apply_galois_ct(L, False, d + 1, ct, keys_by_element[d + 1]))
+            d >>= 1
+        return ct
 
     def galois_key(self, rng, sk, element):
         L = self.K - 1

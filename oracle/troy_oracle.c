@@ -1600,6 +1600,45 @@ void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* s
     free(rot);
 }
 
+/* ---- RLWE / LWE packing primitives (evaluator_lwes.cu) ---- */
+void orc_negacyclic_shift(const orc_context* c, size_t nmod, const uint64_t* in, size_t pcount, size_t shift, uint64_t* out) {
+    /* host_negacyclic_shift_ps, utils/poly_small_mod.cu:902-925 */
+    const size_t n = c->n, mask = n - 1;
+    if (shift == 0) { memcpy(out, in, pcount * nmod * n * sizeof(uint64_t)); return; }
+    for (size_t i = 0; i < pcount; i++)
+        for (size_t j = 0; j < nmod; j++) {
+            size_t index_raw = shift;
+            uint64_t q = c->key_modulus[j].value;
+            for (size_t k = 0; k < n; k++) {
+                size_t index = index_raw & mask, idx = (i * nmod + j) * n + k, ridx = (i * nmod + j) * n + index;
+                if (in[idx] == 0 || (index_raw & n) == 0) out[ridx] = in[idx];
+                else out[ridx] = q - in[idx];
+                index_raw += 1;
+            }
+        }
+}
+
+void orc_multiply_inv_degree(const orc_context* c, size_t nmod, uint64_t* data, size_t pcount, uint64_t scalar) {
+    /* host_ntt_multiply_inv_degree, utils/ntt.cu:78-91 (Evaluator::divide_by_poly_modulus_degree_inplace) */
+    const size_t n = c->n;
+    for (size_t j = 0; j < nmod; j++)
+        for (size_t k = 0; k < pcount; k++) {
+            const orc_modulus* m = &c->key_modulus[j];
+            const orc_mulop* invd = &c->ntt_tables[j]->inv_degree_modulo;
+            for (size_t i = 0; i < n; i++) {
+                size_t x = (k * nmod + j) * n + i;
+                data[x] = orc_multiply_mod(orc_mulop_mod_lazy(data[x], invd, m), scalar, m);
+            }
+        }
+}
+
+void orc_extract_lwe(const orc_context* c, size_t L, const uint64_t* ct, size_t term, uint64_t* c0, uint64_t* c1) {
+    /* Evaluator::extract_lwe_new, evaluator_lwes.cu:52-97 (coefficient-form two-polynomial ciphertext) */
+    const size_t n = c->n;
+    orc_negacyclic_shift(c, L, ct + L * n, 1, term == 0 ? 0 : 2 * n - term, c1);
+    for (size_t i = 0; i < L; i++) c0[i] = ct[n * i + term];
+}
+
 uint64_t orc_fnv_words(const uint64_t* data, size_t n) {
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < n; i++) { h ^= data[i]; h *= 1099511628211ull; }

@@ -218,6 +218,13 @@ void orc_apply_galois_ct(const orc_context* c, size_t L, int is_ntt_form, size_t
 void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, size_t galois_element, uint64_t* out);
 /* GaloisTool::get_element_from_step (utils/galois.cu:43-63) */
 size_t orc_galois_element_from_step(size_t n, int step);
+/* ---- RLWE / LWE packing primitives (evaluator_lwes.cu) ----
+ * utils::negacyclic_shift_ps host branch (utils/poly_small_mod.cu:902-925): data [pcount][nmod][N], shift in [0, 2N) */
+void orc_negacyclic_shift(const orc_context* c, size_t nmod, const uint64_t* in, size_t pcount, size_t shift, uint64_t* out);
+/* utils::ntt_multiply_inv_degree host branch (utils/ntt.cu:78-91): data * N^-1 * scalar, in place */
+void orc_multiply_inv_degree(const orc_context* c, size_t nmod, uint64_t* data, size_t pcount, uint64_t scalar);
+/* Evaluator::extract_lwe_new (evaluator_lwes.cu:52-97): ct [2][L][N] coefficient form -> c0 [L], c1 [L][N] */
+void orc_extract_lwe(const orc_context* c, size_t L, const uint64_t* ct, size_t term, uint64_t* c0, uint64_t* c1);
 /* the survey's digest: h = FNV offset; for each 64-bit WORD: h ^= word; h *= FNV prime */
 uint64_t orc_fnv_words(const uint64_t* data, size_t n);
 

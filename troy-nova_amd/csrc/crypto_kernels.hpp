@@ -293,4 +293,89 @@ __global__ __launch_bounds__(POLY_BLOCK) void galois_kernel(unsigned chunks, con
     }
 }
 
+// ---- RLWE packing (Evaluator::pack_rlwe_ciphertexts, evaluator_lwes.cu:315-681) ------------------------
+// negacyclic_shift_ps (utils/poly_small_mod.cu:927-944): out[(shift + k) mod N] = ((shift + k) & N) ? -in[k] : in[k], shift in [0, 2N).
+// Written as a gather so stores stay coalesced: the source of output index k is j = (k - shift) mod N.
+__device__ __forceinline__ u64 shifted_coeff(const u64* poly, unsigned k, unsigned shift, unsigned log_n, u64 q) {
+    const unsigned mask = (1u << log_n) - 1;
+    const unsigned j = (k - shift) & mask;
+    const u64 v = poly[j];
+    return (((shift + j) >> log_n) & 1) ? neg_mod(v, q) : v;
+}
+
+__global__ __launch_bounds__(POLY_BLOCK) void negacyclic_shift_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned log_n,
+                                                                      unsigned shift, const u64* in, u64* out) {
+    const unsigned n = 1u << log_n;
+    const size_t row = blk_row(chunks);
+    const u64 q = mods[mod_start + row % nmod].q;
+    for (unsigned k = blk_col(chunks); k < n; k += chunks * blockDim.x) out[row * n + k] = shifted_coeff(in + row * n, k, shift, log_n, q);
+}
+
+// ntt_multiply_inv_degree (utils/ntt.cu:93-107): x * N^-1 * scalar mod q (lazy Shoup by N^-1, then a Barrett product: canonical)
+__global__ __launch_bounds__(POLY_BLOCK) void multiply_inv_degree_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
+                                                                         u64 scalar, const u64* in, u64* out) {
+    const size_t row = blk_row(chunks);
+    const DevModulus m = mods[mod_start + row % nmod];
+    for (unsigned k = blk_col(chunks); k < n; k += chunks * blockDim.x)
+        out[row * n + k] = mul_mod(shoup_lazy(in[row * n + k], m.inv_n_op, m.inv_n_quo, m.q), scalar, m);
+}
+
+// The first step of pack_rlwe_ciphertexts (:361-381 / :599-640): slot s of the working set takes source ciphertext src[s]
+// (device pointer, polynomial count pcount, coefficient form) scaled by N^-1 * mul and shifted by `shift`; absent slots are zero.
+__global__ __launch_bounds__(POLY_BLOCK) void pack_prepare_kernel(unsigned chunks, const DevModulus* mods, unsigned L, unsigned log_n, unsigned pcount,
+                                                                  u64 mul, unsigned shift, const u64* const* src, u64* out) {
+    const unsigned n = 1u << log_n, mask = n - 1;
+    const size_t row = blk_row(chunks);                       // (slot, poly, limb)
+    const size_t slot = row / ((size_t)pcount * L);
+    const DevModulus m = mods[row % L];
+    const u64* sp = src[slot];
+    u64* op = out + row * n;
+    if (!sp) {
+        for (unsigned k = blk_col(chunks); k < n; k += chunks * blockDim.x) op[k] = 0;
+        return;
+    }
+    sp += (row % ((size_t)pcount * L)) * n;
+    for (unsigned k = blk_col(chunks); k < n; k += chunks * blockDim.x) {
+        const unsigned j = (k - shift) & mask;
+        const u64 v = mul_mod(shoup_lazy(sp[j], m.inv_n_op, m.inv_n_quo, m.q), mul, m);
+        op[k] = (((shift + j) >> log_n) & 1) ? neg_mod(v, m.q) : v;
+    }
+}
+
+// One layer of the packing tree (:441-477 / :654-697), everything except the key switch, for adjacent (even, odd) pairs:
+//   temp = negacyclic_shift(odd, shift);  odd' = even - temp;  even' = even + temp;  result = even' + apply_galois(odd', g)
+// apply_galois = coefficient permutation X -> X^g of (c0, c1) followed by a key switch of the permuted c1 whose output is
+// added to (perm c0, 0).  This kernel writes out[pair] = (even'.c0 + perm(odd'.c0), even'.c1) and target[pair] = perm(odd'.c1);
+// troyn_switch_key(target -> out, AddInplace) completes the layer.  The permutation is taken as a gather (g_inv = g^-1 mod 2N):
+// output coefficient k of perm(x) is +/- x[i], i = k * g_inv mod 2N folded into [0, N).
+__global__ __launch_bounds__(POLY_BLOCK) void pack_layer_kernel(unsigned chunks, const DevModulus* mods, unsigned L, unsigned log_n, unsigned shift,
+                                                                unsigned g_inv, const u64* in, u64* out, u64* target) {
+    const unsigned n = 1u << log_n, mask2 = 2 * n - 1;
+    const size_t row = blk_row(chunks);                       // (pair, poly, limb)
+    const size_t pair = row / (2 * (size_t)L);
+    const unsigned c = (unsigned)((row / L) % 2), l = (unsigned)(row % L);
+    const u64 q = mods[l].q;
+    const u64* even = in + ((2 * pair) * 2 * L + (size_t)c * L + l) * n;
+    const u64* odd = in + ((2 * pair + 1) * 2 * L + (size_t)c * L + l) * n;
+    u64* op = out + row * n;
+    u64* tp = target + (pair * L + l) * n;
+    for (unsigned k = blk_col(chunks); k < n; k += chunks * blockDim.x) {
+        const u64 sum = add_mod(even[k], shifted_coeff(odd, k, shift, log_n, q), q);
+        const unsigned raw = (unsigned)(((u64)k * g_inv) & mask2);
+        const unsigned i = raw & (n - 1);
+        u64 diff = sub_mod(even[i], shifted_coeff(odd, i, shift, log_n, q), q);
+        if (raw >> log_n) diff = neg_mod(diff, q);            // i*g = k + N (mod 2N): the coefficient arrives negated
+        if (c == 0) op[k] = add_mod(sum, diff, q);
+        else { op[k] = sum; tp[k] = diff; }
+    }
+}
+
+// extract_lwe (evaluator_lwes.cu:15-22): c0[l] = rlwe_c0[l][term] for `count` (ciphertext, term) pairs given as device arrays
+__global__ void extract_lwe_c0_kernel(unsigned L, unsigned n, const u64* const* c0_polys, const unsigned* terms, u64* out, unsigned count) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * L) return;
+    const unsigned item = idx / L, l = idx % L;
+    out[idx] = c0_polys[item][(size_t)l * n + terms[item]];
+}
+
 }  // namespace troyn

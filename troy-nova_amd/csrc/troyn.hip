@@ -1162,6 +1162,117 @@ extern "C" int troyn_apply_galois(const troyn_plan* p, uint32_t mod_start, uint3
     return TROYN_OK;
 }
 
+extern "C" int troyn_negacyclic_shift(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, size_t shift,
+                                      size_t count, troyn_stream_t stream) {
+    const char* P = "[negacyclic_shift_ps]";
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (in == out) return fail(TROYN_E_INVALID, std::string(P) + " the shift cannot run in place");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
+    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    const size_t rows = count * nmod;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(negacyclic_shift_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->log_n, (unsigned)shift, (const u64*)in, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_multiply_inv_degree(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, uint64_t scalar,
+                                         size_t count, troyn_stream_t stream) {
+    const char* P = "[ntt_multiply_inv_degree]";
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
+    const size_t rows = count * nmod;
+    if (rows == 0) return TROYN_OK;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(multiply_inv_degree_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, mod_start, nmod, p->n, (u64)scalar, (const u64*)in, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" size_t troyn_pack_prepare_workspace_bytes(size_t slots) { return (slots + 1) * sizeof(u64); }
+
+extern "C" int troyn_pack_prepare(const troyn_plan* p, uint32_t L, size_t pcount, const uint64_t* const* src, size_t slots, uint64_t mul, size_t shift,
+                                  uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    const char* P = "[Evaluator::pack_rlwe_ciphertexts_new]";
+    if (!p || !src || !out || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    if (slots == 0 || pcount == 0) return TROYN_OK;
+    if (workspace_bytes < troyn_pack_prepare_workspace_bytes(slots)) return fail(TROYN_E_WORKSPACE, "[troyn_pack_prepare] workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(workspace, src, slots * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // `src` belongs to the caller
+    const size_t rows = slots * pcount * L;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(pack_prepare_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                       ch, p->d_mods, (unsigned)L, p->log_n, (unsigned)pcount, (u64)mul, (unsigned)shift, (const u64* const*)workspace, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_pack_layer(const troyn_plan* p, uint32_t L, uint64_t galois_element, size_t shift, const uint64_t* in, uint64_t* out,
+                                uint64_t* target, size_t pairs, troyn_stream_t stream) {
+    const char* P = "[Evaluator::pack_rlwe_ciphertexts_new]";
+    if (!p || !in || !out || !target) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    if ((galois_element & 1) == 0 || galois_element >= 2ull * p->n) return fail(TROYN_E_INVALID, "[Evaluator::apply_galois_inplace] Galois element is not valid.");
+    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    if (pairs == 0) return TROYN_OK;
+    // g^-1 mod 2N (g odd): Newton iteration on the 2-adic inverse
+    const u64 two_n = 2ull * p->n;
+    u64 inv = galois_element;
+    for (int it = 0; it < 6; it++) inv = inv * (2 - galois_element * inv);
+    inv &= two_n - 1;
+    const size_t rows = pairs * 2 * L;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(rows, ch)) return rc;
+    hipLaunchKernelGGL(pack_layer_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, (unsigned)L, p->log_n, (unsigned)shift, (unsigned)inv, (const u64*)in, (u64*)out, (u64*)target);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" size_t troyn_extract_lwe_workspace_bytes(size_t count) { return (count + (count + 1) / 2 + 1) * sizeof(u64); }
+
+extern "C" int troyn_extract_lwe(const troyn_plan* p, uint32_t L, const uint64_t* const* ct, const size_t* terms, uint64_t* c0, uint64_t* c1, size_t count,
+                                 void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    const char* P = "[Evaluator::extract_lwe_new]";
+    if (!p || !ct || !terms || !c0 || !c1 || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    if (count == 0) return TROYN_OK;
+    if (count * L > 0x7fffffffull) return fail(TROYN_E_INVALID, std::string(P) + " batch too large for one launch");
+    if (workspace_bytes < troyn_extract_lwe_workspace_bytes(count)) return fail(TROYN_E_WORKSPACE, "[troyn_extract_lwe] workspace too small");
+    const size_t n = p->n, pc = (size_t)L * n;
+    std::vector<u64> tab(count + (count + 1) / 2, 0);
+    unsigned* t32 = reinterpret_cast<unsigned*>(tab.data() + count);
+    for (size_t i = 0; i < count; i++) {
+        if (!ct[i]) return fail(TROYN_E_INVALID, std::string(P) + " null pointer in the batch");
+        if (terms[i] >= n) return fail(TROYN_E_INVALID, std::string(P) + " term out of range");
+        tab[i] = (u64)(uintptr_t)ct[i];
+        t32[i] = (unsigned)terms[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // c1 of the LWE = c1 of the RLWE shifted by 2N - term (term 0: unshifted), evaluator_lwes.cu:72-79
+    const unsigned ch = chunks_single(p->n);
+    for (size_t i = 0; i < count; i++) {
+        const size_t shift = terms[i] == 0 ? 0 : 2 * n - terms[i];
+        hipLaunchKernelGGL(negacyclic_shift_kernel, dim3((unsigned)(L * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, 0u, (unsigned)L, p->log_n, (unsigned)shift, (const u64*)ct[i] + pc, (u64*)c1 + i * pc);
+    }
+    hipLaunchKernelGGL(extract_lwe_c0_kernel, dim3((unsigned)((count * L + 255) / 256)), dim3(256), 0, s,
+                       (unsigned)L, (unsigned)n, (const u64* const*)workspace, (const unsigned*)((const u64*)workspace + count), (u64*)c0, (unsigned)count);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
 extern "C" size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count) { return (4 * count + 2) * sizeof(u64); }
 
 extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, size_t pcount,

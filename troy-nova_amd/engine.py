@@ -187,6 +187,65 @@ class Plan:
                         is_ckks=is_ckks, is_ntt_form=is_ntt_form)
         return out
 
+    # -- RLWE / LWE packing (evaluator_lwes.cu) -----------------------------------------------------
+    def negacyclic_shift(self, x, nmod, shift, mod_start=0):
+        """x [count][nmod][N] * X^shift (utils::negacyclic_shift_ps), shift in [0, 2N)"""
+        out = torch.empty_like(x)
+        capi.check(self.lib.troyn_negacyclic_shift(self.h, mod_start, nmod, _ptr(x), _ptr(out), int(shift), x.numel() // (nmod * self.n), _stream()))
+        return out
+
+    def multiply_inv_degree(self, x, nmod, scalar, mod_start=0, out=None):
+        """x * N^-1 * scalar (utils::ntt_multiply_inv_degree); in place when out is x"""
+        out = torch.empty_like(x) if out is None else out
+        capi.check(self.lib.troyn_multiply_inv_degree(self.h, mod_start, nmod, _ptr(x), _ptr(out), int(scalar), x.numel() // (nmod * self.n), _stream()))
+        return out
+
+    def extract_lwe(self, L, cts, terms):
+        """Evaluator::extract_lwe_new for (cts[i], terms[i]); cts: coefficient-form tensors [2][L][N] -> c0 [count][L], c1 [count][L][N]"""
+        count = len(cts)
+        c0 = torch.empty((count, L), dtype=torch.int64, device=self.device)
+        c1 = torch.empty((count, L, self.n), dtype=torch.int64, device=self.device)
+        ptrs = (C.c_void_p * count)(*[c.data_ptr() for c in cts])
+        tarr = (C.c_size_t * count)(*[int(t) for t in terms])
+        ws = self.workspace(self.lib.troyn_extract_lwe_workspace_bytes(count))
+        capi.check(self.lib.troyn_extract_lwe(self.h, L, ptrs, tarr, _ptr(c0), _ptr(c1), count, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+        return c0, c1
+
+    def pack_rlwe_ciphertexts(self, L, groups, keys_by_element, shift, input_interval, output_interval, is_ckks=False, apply_field_trace=True):
+        """Evaluator::pack_rlwe_ciphertexts_new_batched (evaluator_lwes.cu:491-681) for coefficient-form two-polynomial
+        ciphertexts: groups = list of lists of tensors [2][L][N]; returns [len(groups)][2][L][N] (coefficient form).
+        One working buffer holds every group's slots in bit-reversed order; each layer is troyn_pack_layer + one batched
+        troyn_switch_key and halves the buffer."""
+        n, G = self.n, len(groups)
+        maxc = input_interval // output_interval
+        layers = maxc.bit_length() - 1
+        slots = G * maxc
+        src = (C.c_void_p * slots)()
+        for g, cts in enumerate(groups):
+            if not 1 <= len(cts) <= maxc:
+                raise capi.TroynInvalidArgument("[Evaluator::pack_rlwe_ciphertexts_new] ciphers count must be less than input_interval / output_interval.")
+            for i in range(maxc):
+                index = int("{:0{w}b}".format(i, w=layers)[::-1], 2) if layers else 0
+                src[g * maxc + i] = cts[index].data_ptr() if index < len(cts) else None
+        cur = torch.empty((slots, 2, L, n), dtype=torch.int64, device=self.device)
+        ws = self.workspace(self.lib.troyn_pack_prepare_workspace_bytes(slots))
+        capi.check(self.lib.troyn_pack_prepare(self.h, L, 2, src, slots, n // input_interval, int(shift), _ptr(cur),
+                                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+        for layer in range(layers):
+            pairs = cur.shape[0] // 2
+            g = (n // input_interval) * (1 << (layer + 1)) + 1
+            nxt = torch.empty((pairs, 2, L, n), dtype=torch.int64, device=self.device)
+            target = torch.empty((pairs, L, n), dtype=torch.int64, device=self.device)
+            capi.check(self.lib.troyn_pack_layer(self.h, L, g, input_interval >> (layer + 1), _ptr(cur), _ptr(nxt), _ptr(target), pairs, _stream()))
+            self.switch_key(L, target, keys_by_element[g], dest=nxt, assign=ASSIGN_ADD_INPLACE, is_ckks=is_ckks, is_ntt_form=False)
+            cur = nxt
+        if output_interval != 1 and apply_field_trace:
+            d = n
+            while d > n // output_interval:
+                cur = self.add(cur, self.apply_galois(L, cur, d + 1, keys_by_element[d + 1], is_ckks=is_ckks, is_ntt_form=False), L)
+                d >>= 1
+        return cur
+
     # -- key switching -----------------------------------------------------------------------------
     def _key_ptrs(self, keys, L):
         if len(keys) < L:
