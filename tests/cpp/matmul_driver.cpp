@@ -1,11 +1,13 @@
 // C++ driver for tests/test_gpu_cpp_api.py::test_matmul_cpp_api and tools/bench_configs.py (cfg5): BASELINE config 5, the BFV
-// matrix product of examples/10_bfv_matmul.cu (N=8192, {60,40,40,60}, t=2^21) through troy::linear::MatmulHelper:
-// encode weights, encrypt inputs, matmul, decrypt, compare with the plain product mod t; prints phase times.
-// usage: matmul_driver <batch> <input_dims> <output_dims> [repeat]
+// matrix product y = x * w + s of examples/10_bfv_matmul.cu (N=8192, {60,40,40,60}, t=2^21) through troy::linear::MatmulHelper,
+// with the example's steps: encode weights and bias, encrypt inputs, serialize / load the inputs, matmul, optional mod-switch,
+// optional output packing, add the bias, serialize / load the outputs, decrypt, compare with the plain result mod t.
+// usage: matmul_driver <batch> <input_dims> <output_dims> [repeat] [pack_lwe 0|1] [mod_switch 0|1]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <sstream>
 
 #include "../../troy-nova_amd/troy/matmul.h"
 
@@ -19,6 +21,7 @@ int main(int argc, char** argv) {
         const size_t M = argc > 1 ? std::strtoull(argv[1], nullptr, 0) : 25, R = argc > 2 ? std::strtoull(argv[2], nullptr, 0) : 30,
                      Nn = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 35;
         const int repeat = argc > 4 ? std::atoi(argv[4]) : 1;
+        const bool pack_lwe = argc > 5 && std::atoi(argv[5]) != 0, mod_switch = argc > 6 && std::atoi(argv[6]) != 0;
         const size_t n = 8192;
         const uint64_t t = 1ull << 21;
         EncryptionParameters params(SchemeType::BFV);
@@ -33,27 +36,49 @@ int main(int argc, char** argv) {
         encryptor.set_secret_key(keygen.secret_key());
         Decryptor decryptor(context, keygen.secret_key());
         Evaluator evaluator(context);
+        GaloisKeys automorphism_key;
+        if (pack_lwe) automorphism_key = keygen.create_automorphism_keys(false);
 
         std::mt19937_64 gen(11);
-        std::vector<uint64_t> x(M * R), w(R * Nn), want(M * Nn, 0);
+        std::vector<uint64_t> x(M * R), w(R * Nn), sbias(M * Nn), want(M * Nn, 0);
         for (auto& v : x) v = gen() % t;
         for (auto& v : w) v = gen() % t;
+        for (auto& v : sbias) v = gen() % t;
         for (size_t i = 0; i < M; i++)
             for (size_t k = 0; k < R; k++)
                 for (size_t j = 0; j < Nn; j++) want[i * Nn + j] = (want[i * Nn + j] + x[i * R + k] * w[k * Nn + j]) % t;
+        for (size_t i = 0; i < M * Nn; i++) want[i] = (want[i] + sbias[i]) % t;
 
-        MatmulHelper helper(M, R, Nn, n, MatmulObjective::EncryptLeft, false);
-        std::printf("block %zu %zu %zu\n", helper.batch_block, helper.input_block, helper.output_block);
+        MatmulHelper helper(M, R, Nn, n, MatmulObjective::EncryptLeft, pack_lwe);
+        std::printf("block %zu %zu %zu pack_lwe %d mod_switch %d\n", helper.batch_block, helper.input_block, helper.output_block, pack_lwe ? 1 : 0, mod_switch ? 1 : 0);
         double t0 = now();
         Plain2d we = helper.encode_weights_uint64s(encoder, w.data());
         double t1 = now();
+        Plain2d se = helper.encode_outputs_uint64s(encoder, sbias.data());
+        double t1b = now();
         Cipher2d xe = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
         double t2 = now();
+        std::stringstream x_serialized;
+        xe.save(x_serialized, context);
+        const size_t x_bytes = x_serialized.str().size();
+        xe = Cipher2d::load_new(x_serialized, context);
+        double t2b = now();
         Cipher2d ye = helper.matmul(evaluator, xe, we);
         double t3 = now();
         for (int r = 1; r < repeat; r++) ye = helper.matmul(evaluator, xe, we);
         double t4 = now();
-        std::vector<uint64_t> got = helper.decrypt_outputs_uint64s(encoder, decryptor, ye);
+        if (mod_switch) ye.mod_switch_to_next_inplace(evaluator);
+        double t4a = now();
+        if (pack_lwe) ye = helper.pack_outputs(evaluator, automorphism_key, ye);
+        double t4b = now();
+        ye.add_plain_inplace(evaluator, se);
+        double t4c = now();
+        std::stringstream y_serialized;
+        helper.serialize_outputs(evaluator, ye, y_serialized);
+        const size_t y_bytes = y_serialized.str().size();
+        Cipher2d yl = helper.deserialize_outputs(evaluator, y_serialized);
+        double t4d = now();
+        std::vector<uint64_t> got = helper.decrypt_outputs_uint64s(encoder, decryptor, yl);
         double t5 = now();
         // steady state of the two client-side phases (buffers already in the pool)
         double enc_rep = 0, dec_rep = 0;
@@ -72,8 +97,11 @@ int main(int argc, char** argv) {
         for (auto& r : xe.data()) inputs_n += r.size();
         for (auto& r : ye.data()) outputs_n += r.size();
         std::printf("objects weights %zu inputs %zu outputs %zu\n", weights_n, inputs_n, outputs_n);
-        std::printf("ms encode_weights %.3f encrypt_inputs %.3f matmul_first %.3f matmul_repeat %.3f decrypt %.3f\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
-                    (t3 - t2) * 1e3, repeat > 1 ? (t4 - t3) * 1e3 / (repeat - 1) : 0.0, (t5 - t4) * 1e3);
+        std::printf("bytes inputs %zu outputs %zu\n", x_bytes, y_bytes);
+        std::printf("ms encode_weights %.3f encode_bias %.3f encrypt_inputs %.3f inputs_wire %.3f matmul_first %.3f matmul_repeat %.3f mod_switch %.3f pack %.3f add_bias %.3f "
+                    "outputs_wire %.3f decrypt %.3f\n",
+                    (t1 - t0) * 1e3, (t1b - t1) * 1e3, (t2 - t1b) * 1e3, (t2b - t2) * 1e3, (t3 - t2b) * 1e3, repeat > 1 ? (t4 - t3) * 1e3 / (repeat - 1) : 0.0,
+                    (t4a - t4) * 1e3, (t4b - t4a) * 1e3, (t4c - t4b) * 1e3, (t4d - t4c) * 1e3, (t5 - t4d) * 1e3);
         std::printf("ms_repeat encrypt_inputs %.3f decrypt %.3f\n", enc_rep, dec_rep);
         size_t bad = 0;
         for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];

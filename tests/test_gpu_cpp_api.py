@@ -135,15 +135,26 @@ def test_ckks_cpp_api(dev):
         assert float(kv[k][0]) < 1e-4, k
 
 
-@pytest.mark.parametrize("dims", [(25, 30, 35), (4, 600, 7), (128, 64, 96)])
-def test_matmul_cpp_api(dev, dims):
-    """BASELINE config 5 path (examples/10_bfv_matmul.cu parameters): encrypted inputs x plaintext weights through
-    troy::linear::MatmulHelper equals the plain matrix product mod t."""
+@pytest.mark.parametrize("dims,pack_lwe,mod_switch", [((25, 30, 35), 0, 1), ((25, 30, 35), 1, 1),      # the example's two runs
+                                                      ((4, 600, 7), 0, 0), ((128, 64, 96), 1, 0), ((3, 5, 70), 1, 1), ((128, 64, 96), 0, 1)])
+def test_matmul_cpp_api(dev, dims, pack_lwe, mod_switch):
+    """BASELINE config 5 path, the whole flow of examples/10_bfv_matmul.cu: y = x * w + s with encrypted x through
+    troy::linear::MatmulHelper (inputs and outputs through their wire formats, optional mod-switch and output packing)
+    equals the plain result mod t."""
     drv = os.path.join(ROOT, "tests", "cpp", "matmul_driver")
     if not os.path.exists(drv):
         pytest.fail("tests/cpp/matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    r = subprocess.run([drv] + [str(d) for d in dims], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([drv] + [str(d) for d in dims] + ["1", str(pack_lwe), str(mod_switch)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout and "mismatches 0 of %d" % (dims[0] * dims[2]) in r.stdout, r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    sizes = dict(zip(kv["bytes"][0::2], [int(v) for v in kv["bytes"][1::2]]))
+    objs = dict(zip(kv["objects"][0::2], [int(v) for v in kv["objects"][1::2]]))
+    L = 2 if mod_switch else 3
+    full = 1 + 32 + 3 * 8 + 1 + 2 * L * 8192 * 8                          # one whole ciphertext on the wire (ciphertext.cu:98-139)
+    if pack_lwe:
+        assert sizes["outputs"] == objs["outputs"] * full
+    else:
+        assert sizes["outputs"] < objs["outputs"] * full                 # save_terms: c0 cut down to the result coefficients
 
 
 @pytest.mark.parametrize("n,count", [(8192, 19), (4096, 3)])

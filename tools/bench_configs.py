@@ -124,14 +124,17 @@ def main():
     if a.only in ("", "cfg5", "cfg5_e2e"):
         import subprocess
         drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cpp", "matmul_driver")
-        r = subprocess.run([drv, "512", "512", "512", "5"], capture_output=True, text=True, timeout=900)
-        lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
-        ms = dict(zip(lines["ms"][0::2], [float(v) for v in lines["ms"][1::2]]))
-        res["cfg5_e2e"] = {"what": "BFV 512x512x512 matmul through MatmulHelper (N=8192, {60,40,40,60}, t=2^21), encrypted inputs x plaintext weights",
-                           "block": lines["block"], "objects": " ".join(lines["objects"]), "ms": ms,
-                           "latency_ms_encrypt_matmul_decrypt": round(ms["encrypt_inputs"] + ms["matmul_repeat"] + ms["decrypt"], 2),
-                           "ms_repeat": dict(zip(lines["ms_repeat"][0::2], [float(v) for v in lines["ms_repeat"][1::2]])),
-                           "correct": "OK" in r.stdout}
+        res["cfg5_e2e"] = {"what": "BFV 512x512x512 y = x*w + s through MatmulHelper (N=8192, {60,40,40,60}, t=2^21), the flow of examples/10_bfv_matmul.cu: "
+                                   "encrypted inputs x plaintext weights, inputs/outputs through their wire formats"}
+        for tag, flags in (("plain_outputs", ["0", "0"]), ("mod_switched_outputs", ["0", "1"]), ("packed_outputs", ["1", "1"])):
+            r = subprocess.run([drv, "512", "512", "512", "5"] + flags, capture_output=True, text=True, timeout=900)
+            lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+            ms = dict(zip(lines["ms"][0::2], [float(v) for v in lines["ms"][1::2]]))
+            compute = ms["encrypt_inputs"] + ms["matmul_repeat"] + ms["mod_switch"] + ms["pack"] + ms["add_bias"] + ms["decrypt"]
+            res["cfg5_e2e"][tag] = {"block": lines["block"][:3], "objects": " ".join(lines["objects"]), "wire_bytes": " ".join(lines["bytes"]), "ms": ms,
+                                    "latency_ms_encrypt_to_decrypt_without_wire": round(compute, 2),
+                                    "ms_repeat": dict(zip(lines["ms_repeat"][0::2], [float(v) for v in lines["ms_repeat"][1::2]])),
+                                    "correct": "OK" in r.stdout}
         # CPU baseline of the matmul core (the oracle's multiply_plain_ntt + add, one thread), on a bounded sample of terms
         import numpy as np
         O = entry.load_oracle()

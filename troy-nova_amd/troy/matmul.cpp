@@ -1,30 +1,155 @@
 // matmul.cpp -- see matmul.h.  Host logic only; all arithmetic goes through the mirror's Evaluator (GPU).
 #include "matmul.h"
 
+#include <cmath>
+
 namespace troy { namespace linear {
 
 static size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// ------------------------------------------------------------------------------------------------
+// Plain2d / Cipher2d  (app/cipher2d.h, cipher2d.cu)
+// ------------------------------------------------------------------------------------------------
+namespace {
+void put_size(std::ostream& os, size_t v) { os.write(reinterpret_cast<const char*>(&v), sizeof(v)); }
+size_t get_size(std::istream& is) {
+    size_t v = 0;
+    is.read(reinterpret_cast<char*>(&v), sizeof(v));
+    if (!is) throw std::runtime_error("[serialize::load_object] unexpected end of stream");
+    return v;
+}
+}  // namespace
+
+size_t Plain2d::save(std::ostream& stream, CompressionMode mode) const {
+    size_t bytes = sizeof(size_t);
+    put_size(stream, rows());
+    for (const auto& row : inner) {
+        put_size(stream, row.size());
+        bytes += sizeof(size_t);
+        for (const Plaintext& p : row) bytes += p.save(stream, mode);
+    }
+    return bytes;
+}
+
+void Plain2d::load(std::istream& stream, MemoryPoolHandle pool) {
+    inner.clear();
+    const size_t rows = get_size(stream);
+    for (size_t i = 0; i < rows; i++) {
+        const size_t count = get_size(stream);
+        std::vector<Plaintext>& row = new_row();
+        for (size_t j = 0; j < count; j++) row.push_back(Plaintext::load_new(stream, pool));
+    }
+}
+
+Cipher2d Cipher2d::clone(MemoryPoolHandle pool) const {
+    Cipher2d out;
+    for (const auto& row : inner) {
+        std::vector<Ciphertext>& r = out.new_row();
+        for (const Ciphertext& c : row) r.push_back(c.clone(pool));
+    }
+    return out;
+}
+
+void Cipher2d::expand_seed(HeContextPointer context) {
+    for (auto& row : inner) for (Ciphertext& c : row) if (c.contains_seed()) c.expand_seed(context);
+}
+
+size_t Cipher2d::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
+    put_size(stream, rows());
+    for (const auto& row : inner) {
+        put_size(stream, row.size());
+        for (const Ciphertext& c : row) c.save(stream, context, mode);
+    }
+    return serialized_size_upperbound(context, mode);
+}
+
+void Cipher2d::load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool) {
+    inner.clear();
+    const size_t rows = get_size(stream);
+    for (size_t i = 0; i < rows; i++) {
+        const size_t count = get_size(stream);
+        std::vector<Ciphertext>& row = new_row();
+        for (size_t j = 0; j < count; j++) { Ciphertext c; c.load(stream, context, pool); row.push_back(std::move(c)); }
+    }
+}
+
+size_t Cipher2d::serialized_size_upperbound(HeContextPointer context, CompressionMode mode) const {
+    size_t bytes = sizeof(size_t);
+    for (const auto& row : inner) {
+        bytes += sizeof(size_t);
+        for (const Ciphertext& c : row) bytes += c.serialized_size_upperbound(context, mode);
+    }
+    return bytes;
+}
+
+void Cipher2d::mod_switch_to_next_inplace(const Evaluator& evaluator, MemoryPoolHandle pool) {
+    std::vector<const Ciphertext*> src;
+    std::vector<Ciphertext*> dst;
+    for (auto& row : inner) for (Ciphertext& c : row) { src.push_back(&c); dst.push_back(&c); }
+    evaluator.mod_switch_to_next_batched(src, dst, pool);
+}
+
+void Cipher2d::translate_inplace(const Evaluator& evaluator, const Cipher2d& other, bool subtract, MemoryPoolHandle pool) {
+    if (size() != other.size()) throw std::runtime_error("[Cipher2d::translate_inplace] Row size mismatch.");
+    for (size_t i = 0; i < rows(); i++) {
+        if (inner[i].size() != other[i].size()) throw std::runtime_error("[Cipher2d::translate_inplace] Column size mismatch.");
+        for (size_t j = 0; j < inner[i].size(); j++) {
+            if (subtract) evaluator.sub_inplace(inner[i][j], other[i][j], pool);
+            else evaluator.add_inplace(inner[i][j], other[i][j], pool);
+        }
+    }
+}
+
+void Cipher2d::translate_plain_inplace(const Evaluator& evaluator, const Plain2d& other, bool subtract, MemoryPoolHandle pool) {
+    if (size() != other.size()) throw std::runtime_error("[Cipher2d::translate_plain_inplace] Row size mismatch.");
+    for (size_t i = 0; i < rows(); i++) {
+        if (inner[i].size() != other[i].size()) throw std::runtime_error("[Cipher2d::translate_plain_inplace] Column size mismatch.");
+        for (size_t j = 0; j < inner[i].size(); j++) {
+            if (subtract) evaluator.sub_plain_inplace(inner[i][j], other[i][j], pool);
+            else evaluator.add_plain_inplace(inner[i][j], other[i][j], pool);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MatmulHelper  (app/matmul.h, matmul.cu)
+// ------------------------------------------------------------------------------------------------
 MatmulHelper::MatmulHelper(size_t batch_size, size_t input_dims, size_t output_dims, size_t slot_count, MatmulObjective objective, bool pack_lwe,
                            MemoryPoolHandle pool)
     : batch_size(batch_size), input_dims(input_dims), output_dims(output_dims), slot_count(slot_count), objective(objective), pack_lwe(pack_lwe),
       pool(std::move(pool)) {
-    if (pack_lwe) throw std::logic_error("[MatmulHelper::MatmulHelper] LWE output packing is not part of this build.");
     if (objective != MatmulObjective::EncryptLeft) throw std::logic_error("[MatmulHelper::MatmulHelper] only MatmulObjective::EncryptLeft is part of this build.");
     determine_block();
 }
 
 void MatmulHelper::determine_block() {
-    // app/matmul.cu:101-127 (no LWE packing): choose (bb, ib, ob), bb*ib*ob <= N, minimising the number of ciphertexts that
-    // travel: encrypted inputs ceil(B/bb)*ceil(I/ib) plus encrypted outputs ceil(B/bb)*ceil(O/ob)
     size_t best_cost = static_cast<size_t>(-1);
-    for (size_t bb = std::min(batch_size, slot_count - 1); bb >= 1; bb--) {
-        const size_t bc = ceil_div(batch_size, bb);
-        if (2 * bc > best_cost) continue;
-        for (size_t ib = 1; ib <= input_dims && ib < slot_count / bb; ib++) {
+    if (!pack_lwe) {
+        // app/matmul.cu:103-127: choose (bb, ib, ob), bb*ib*ob <= N, minimising the number of ciphertexts that travel:
+        // encrypted inputs ceil(B/bb)*ceil(I/ib) plus encrypted outputs ceil(B/bb)*ceil(O/ob)
+        for (size_t bb = std::min(batch_size, slot_count - 1); bb >= 1; bb--) {
+            const size_t bc = ceil_div(batch_size, bb);
+            if (2 * bc > best_cost) continue;
+            for (size_t ib = 1; ib <= input_dims && ib < slot_count / bb; ib++) {
+                size_t ob = std::min(slot_count / bb / ib, output_dims);
+                if (ob < 1) continue;
+                const size_t cost = bc * (ceil_div(input_dims, ib) + ceil_div(output_dims, ob));
+                if (cost < best_cost) { best_cost = cost; batch_block = bb; input_block = ib; output_block = ob; }
+            }
+        }
+    } else {
+        // app/matmul.cu:128-158: the input block is a power of two near N^(1/3) (the packing tree merges input_block
+        // outputs into one ciphertext); the outputs then cost ceil(#outputs / ib) ciphertexts
+        const double cube = std::pow(static_cast<double>(slot_count), 0.33);
+        size_t ib = 1;
+        while (static_cast<double>(ib * 2) < cube) ib *= 2;
+        if (ib > input_dims) { ib = 1; while (ib < input_dims) ib *= 2; }
+        for (size_t bb = 1; bb <= batch_size; bb++) {
+            const size_t bc = ceil_div(batch_size, bb);
+            if (bb > slot_count) continue;
             size_t ob = std::min(slot_count / bb / ib, output_dims);
             if (ob < 1) continue;
-            const size_t cost = bc * (ceil_div(input_dims, ib) + ceil_div(output_dims, ob));
+            const size_t cost = bc * ceil_div(input_dims, ib) + ceil_div(bc * ceil_div(output_dims, ob), ib);
             if (cost < best_cost) { best_cost = cost; batch_block = bb; input_block = ib; output_block = ob; }
         }
     }
@@ -175,24 +300,149 @@ Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, con
 }
 
 std::vector<uint64_t> MatmulHelper::decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
-    // app/matmul.cu:560-640; all output ciphertexts decrypted as one batch and read back with one copy
+    // app/matmul.cu:519-566; every output ciphertext is decrypted in one batch and read back with one copy
     (void)encoder;
     std::vector<const Ciphertext*> all;
     for (const auto& r : outputs.data()) for (const Ciphertext& c : r) all.push_back(&c);
     const std::vector<uint64_t> coeffs = decryptor.bfv_decrypt_to_host(all, pool);
-    const size_t n = slot_count;
+    const size_t n = slot_count, ocols = ceil_div(output_dims, output_block);
+    if (all.size() != (pack_lwe ? ceil_div(ceil_div(batch_size, batch_block) * ocols, input_block) : ceil_div(batch_size, batch_block) * ocols))
+        throw std::invalid_argument("[MatmulHelper::decrypt_outputs] Output ciphertext count incorrect");
     std::vector<uint64_t> out(batch_size * output_dims, 0);
-    size_t idx = 0;
-    for (size_t li = 0; li < batch_size; li += batch_block) {
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
         const size_t ui = std::min(li + batch_block, batch_size);
-        for (size_t lj = 0; lj < output_dims; lj += output_block, idx++) {
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
             const size_t uj = std::min(lj + output_block, output_dims);
-            const uint64_t* cf = coeffs.data() + idx * n;
+            const size_t cipher_id = di * ocols + dj;
+            // unpacked: output k of the block sits on coefficient ..*ib + ib-1; packed: ciphertext cipher_id % ib of its group
+            // was moved to offset cipher_id % ib
+            const uint64_t* cf = coeffs.data() + (pack_lwe ? cipher_id / input_block : cipher_id) * n;
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
             for (size_t i = li; i < ui; i++)
-                for (size_t j = lj; j < uj; j++) out[i * output_dims + j] = cf[(i - li) * input_block * output_block + (j - lj) * input_block + input_block - 1];
+                for (size_t j = lj; j < uj; j++) out[i * output_dims + j] = cf[(i - li) * input_block * output_block + (j - lj) * input_block + offset];
         }
     }
     return out;
+}
+
+Plain2d MatmulHelper::encode_outputs_uint64s(const BatchEncoder& encoder, const uint64_t* outputs) const {
+    // app/matmul.cu:452-512: the same coefficient positions decrypt_outputs reads
+    const size_t n = slot_count, ocols = ceil_div(output_dims, output_block), brows = ceil_div(batch_size, batch_block);
+    const size_t count = pack_lwe ? ceil_div(brows * ocols, input_block) : brows * ocols;
+    std::vector<std::vector<uint64_t>> buffers(count, std::vector<uint64_t>(n, 0));
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            const size_t cipher_id = di * ocols + dj;
+            std::vector<uint64_t>& buf = buffers[pack_lwe ? cipher_id / input_block : cipher_id];
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) buf[(i - li) * input_block * output_block + (j - lj) * input_block + offset] = outputs[i * output_dims + j];
+        }
+    }
+    Plain2d out;
+    if (pack_lwe) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (const auto& buf : buffers) row.push_back(encoder.encode_polynomial_new(buf, pool));
+    } else {
+        for (size_t r = 0; r < brows; r++) {
+            std::vector<Plaintext>& row = out.new_row();
+            for (size_t c = 0; c < ocols; c++) row.push_back(encoder.encode_polynomial_new(buffers[r * ocols + c], pool));
+        }
+    }
+    return out;
+}
+
+Cipher2d MatmulHelper::pack_outputs(const Evaluator& evaluator, const GaloisKeys& auto_key, const Cipher2d& cipher) const {
+    // app/matmul.cu:572-619: consecutive runs of input_block outputs are packed into one ciphertext.  Output k of a group has
+    // its results on coefficients = ib-1 (mod ib); the shift 2N - (ib-1) moves them to multiples of ib and the packing tree
+    // interleaves the members, member k landing on offset k.  All groups run through the tree together.
+    if (!pack_lwe) throw std::invalid_argument("[MatmulHelper::packOutputs] PackLwe not enabled");
+    Cipher2d ret;
+    ret.new_row();
+    if (cipher.data().empty() || cipher.data()[0].empty()) return ret;
+    const size_t pack_slots = input_block;
+    const size_t inherent_shift = pack_slots == 1 ? 0 : 2 * slot_count - (pack_slots - 1);
+    std::vector<std::vector<const Ciphertext*>> to_pack;
+    for (const auto& row : cipher.data())
+        for (const Ciphertext& c : row) {
+            if (to_pack.empty() || to_pack.back().size() == pack_slots) to_pack.emplace_back();
+            to_pack.back().push_back(&c);
+        }
+    ret[0] = evaluator.pack_rlwe_ciphertexts_new_batched(to_pack, auto_key, inherent_shift, input_block, 1, pool);
+    return ret;
+}
+
+void MatmulHelper::serialize_encoded_weights(const Plain2d& w, std::ostream& stream, CompressionMode mode) const {
+    // app/matmul.cu:621-636
+    const size_t rows = w.rows();
+    if (rows == 0) throw std::invalid_argument("[MatmulHelper::serialize_encoded_weights] No rows in weight matrix.");
+    const size_t cols = w[0].size();
+    if (cols == 0) throw std::invalid_argument("[MatmulHelper::serialize_encoded_weights] No columns in weight matrix.");
+    for (size_t i = 0; i < rows; i++)
+        if (w[i].size() != cols) throw std::invalid_argument("[MatmulHelper::serialize_encoded_weights] Weight matrix is not rectangular.");
+    put_size(stream, rows);
+    put_size(stream, cols);
+    for (size_t i = 0; i < rows; i++) for (size_t j = 0; j < cols; j++) w[i][j].save(stream, mode);
+}
+
+Plain2d MatmulHelper::deserialize_encoded_weights(std::istream& stream) const {
+    const size_t rows = get_size(stream), cols = get_size(stream);
+    Plain2d ret;
+    for (size_t i = 0; i < rows; i++) {
+        std::vector<Plaintext>& row = ret.new_row();
+        for (size_t j = 0; j < cols; j++) row.push_back(Plaintext::load_new(stream, pool));
+    }
+    return ret;
+}
+
+static std::vector<size_t> output_terms(const MatmulHelper& h, size_t li, size_t ui, size_t lj, size_t uj) {
+    std::vector<size_t> required;
+    for (size_t i = li; i < ui; i++)
+        for (size_t j = lj; j < uj; j++) required.push_back((i - li) * h.input_block * h.output_block + (j - lj) * h.input_block + h.input_block - 1);
+    return required;
+}
+
+void MatmulHelper::serialize_outputs(const Evaluator& evaluator, const Cipher2d& x, std::ostream& stream, CompressionMode mode) const {
+    // app/matmul.cu:655-688: unpacked outputs carry results on (ui-li)*(uj-lj) coefficients only, so c0 is cut down to those
+    HeContextPointer context = evaluator.context();
+    if (!pack_lwe) {
+        size_t di = 0;
+        for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+            const size_t ui = std::min(li + batch_block, batch_size);
+            size_t dj = 0;
+            for (size_t lj = 0; lj < output_dims; lj += output_block, dj++)
+                x[di][dj].save_terms(stream, context, output_terms(*this, li, ui, lj, std::min(lj + output_block, output_dims)), pool, mode);
+        }
+    } else {
+        const size_t count = ceil_div(ceil_div(batch_size, batch_block) * ceil_div(output_dims, output_block), input_block);
+        if (x.data().empty() || count != x.data()[0].size()) throw std::invalid_argument("[MatmulHelper::serialize_outputs] Output ciphertext count incorrect");
+        for (const Ciphertext& c : x.data()[0]) c.save(stream, context, mode);
+    }
+}
+
+Cipher2d MatmulHelper::deserialize_outputs(const Evaluator& evaluator, std::istream& stream) const {
+    // app/matmul.cu:690-720
+    HeContextPointer context = evaluator.context();
+    Cipher2d ret;
+    if (!pack_lwe) {
+        for (size_t li = 0; li < batch_size; li += batch_block) {
+            const size_t ui = std::min(li + batch_block, batch_size);
+            std::vector<Ciphertext>& row = ret.new_row();
+            for (size_t lj = 0; lj < output_dims; lj += output_block)
+                row.push_back(Ciphertext::load_terms_new(stream, context, output_terms(*this, li, ui, lj, std::min(lj + output_block, output_dims)), pool));
+        }
+    } else {
+        const size_t count = ceil_div(ceil_div(batch_size, batch_block) * ceil_div(output_dims, output_block), input_block);
+        std::vector<Ciphertext>& row = ret.new_row();
+        for (size_t i = 0; i < count; i++) { Ciphertext c; c.load(stream, context, pool); row.push_back(std::move(c)); }
+    }
+    return ret;
 }
 
 }}  // namespace troy::linear

@@ -2,7 +2,8 @@
 // (src/app/matmul.h, matmul.cu; BASELINE config 5 = examples/10_bfv_matmul.cu at 512x512x512) on top of the mirror API.
 //
 // Supported here: BFV with BatchEncoder polynomial (coefficient) packing, encrypted inputs x plaintext weights
-// (MatmulObjective::EncryptLeft, the example's configuration), without LWE output packing.  Layout, as the reference:
+// (MatmulObjective::EncryptLeft, the example's configuration), with and without packing of the outputs (pack_lwe),
+// output mod-switch, bias addition and the outputs' partial wire format.  Layout, as the reference:
 //   input block  (batch rows li..ui, input columns lj..uj):   coefficient (i-li)*ib*ob + (j-lj)              = x[i][j]
 //   weight block (input rows li..ui, output columns lj..uj):  coefficient (j-lj)*ib + ib - (i-li) - 1         = w[i][j]
 //   output block: y[i][j] is coefficient (i-li)*ib*ob + (j-lj)*ib + ib - 1 of sum_k input[b][k] * weight[k][j-block]
@@ -19,8 +20,16 @@ public:
     std::vector<std::vector<Plaintext>>& data() { return inner; }
     const std::vector<std::vector<Plaintext>>& data() const { return inner; }
     size_t size() const { return inner.size(); }
+    size_t rows() const { return inner.size(); }
+    size_t columns() const { return inner.empty() ? 0 : inner[0].size(); }
     std::vector<Plaintext>& operator[](size_t i) { return inner[i]; }
     const std::vector<Plaintext>& operator[](size_t i) const { return inner[i]; }
+    std::vector<Plaintext>& new_row() { inner.emplace_back(); return inner.back(); }
+    void resize(size_t rows, size_t columns) { inner.resize(rows); for (auto& r : inner) r.resize(columns); }
+    // app/cipher2d.cu: [rows][row size, plaintexts...] in the Plaintext wire format
+    size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
+    void load(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Plain2d load_new(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Plain2d p; p.load(stream, pool); return p; }
 private:
     std::vector<std::vector<Plaintext>> inner;
 };
@@ -30,9 +39,33 @@ public:
     std::vector<std::vector<Ciphertext>>& data() { return inner; }
     const std::vector<std::vector<Ciphertext>>& data() const { return inner; }
     size_t size() const { return inner.size(); }
+    size_t rows() const { return inner.size(); }
+    size_t columns() const { return inner.empty() ? 0 : inner[0].size(); }
     std::vector<Ciphertext>& operator[](size_t i) { return inner[i]; }
     const std::vector<Ciphertext>& operator[](size_t i) const { return inner[i]; }
+    std::vector<Ciphertext>& new_row() { inner.emplace_back(); return inner.back(); }
+    void resize(size_t rows, size_t columns) { inner.resize(rows); for (auto& r : inner) r.resize(columns); }
+    Cipher2d clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void expand_seed(HeContextPointer context);
+    // app/cipher2d.cu:29-67: [rows][row size, ciphertexts...] in the Ciphertext wire format
+    size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
+    void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Cipher2d load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Cipher2d c; c.load(stream, context, pool); return c; }
+    size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
+    // app/cipher2d.h:164-230
+    void mod_switch_to_next_inplace(const Evaluator& evaluator, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    Cipher2d mod_switch_to_next(const Evaluator& evaluator, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.mod_switch_to_next_inplace(evaluator, pool); return c; }
+    void add_inplace(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_inplace(evaluator, other, false, pool); }
+    void sub_inplace(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_inplace(evaluator, other, true, pool); }
+    Cipher2d add(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.add_inplace(evaluator, other, pool); return c; }
+    Cipher2d sub(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.sub_inplace(evaluator, other, pool); return c; }
+    void add_plain_inplace(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_plain_inplace(evaluator, other, false, pool); }
+    void sub_plain_inplace(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_plain_inplace(evaluator, other, true, pool); }
+    Cipher2d add_plain(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.add_plain_inplace(evaluator, other, pool); return c; }
+    Cipher2d sub_plain(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.sub_plain_inplace(evaluator, other, pool); return c; }
 private:
+    void translate_inplace(const Evaluator& evaluator, const Cipher2d& other, bool subtract, MemoryPoolHandle pool);
+    void translate_plain_inplace(const Evaluator& evaluator, const Plain2d& other, bool subtract, MemoryPoolHandle pool);
     std::vector<std::vector<Ciphertext>> inner;
 };
 
@@ -45,7 +78,7 @@ public:
     MemoryPoolHandle pool;
 
     MatmulHelper(size_t batch_size, size_t input_dims, size_t output_dims, size_t slot_count,
-                 MatmulObjective objective = MatmulObjective::EncryptLeft, bool pack_lwe = false, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+                 MatmulObjective objective = MatmulObjective::EncryptLeft, bool pack_lwe = true, MemoryPoolHandle pool = MemoryPool::GlobalPool());
 
     // weights [input_dims][output_dims] row-major -> NTT-form plaintexts [ceil(in/ib)][ceil(out/ob)]
     Plain2d encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const;
@@ -56,6 +89,17 @@ public:
     Cipher2d matmul(const Evaluator& evaluator, const Cipher2d& a, const Plain2d& w) const;
     // outputs [batch_size][output_dims] row-major, values mod t
     std::vector<uint64_t> decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
+    // a bias / share [batch_size][output_dims] laid out like the (packed or unpacked) outputs, for Cipher2d::add_plain_inplace
+    Plain2d encode_outputs_uint64s(const BatchEncoder& encoder, const uint64_t* outputs) const;
+    // pack_lwe: input_block output ciphertexts are merged into one (Evaluator::pack_rlwe_ciphertexts, all groups batched);
+    // the result is one row of ceil(#outputs / input_block) ciphertexts.  Needs the Galois keys of
+    // (N / input_block) * 2^k + 1, k = 1..log2(input_block)
+    Cipher2d pack_outputs(const Evaluator& evaluator, const GaloisKeys& auto_key, const Cipher2d& cipher) const;
+    // app/matmul.cu:621-720: the weights in full; of the unpacked outputs only the coefficients that carry results
+    void serialize_encoded_weights(const Plain2d& w, std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
+    Plain2d deserialize_encoded_weights(std::istream& stream) const;
+    void serialize_outputs(const Evaluator& evaluator, const Cipher2d& x, std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
+    Cipher2d deserialize_outputs(const Evaluator& evaluator, std::istream& stream) const;
 
 private:
     void determine_block();

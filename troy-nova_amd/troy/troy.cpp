@@ -1359,6 +1359,97 @@ void Ciphertext::load(std::istream& stream, HeContextPointer context, MemoryPool
     if (seeded) expand_seed(context);
 }
 
+size_t Ciphertext::serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode) const {
+    // ciphertext.cu:341-365
+    size_t bytes = sizeof(CompressionMode) + sizeof(ParmsID) + 3 * sizeof(size_t) + 1;
+    const SchemeType scheme = context_scheme(context);
+    if (scheme == SchemeType::CKKS) bytes += sizeof(double);
+    if (scheme == SchemeType::BGV) bytes += sizeof(uint64_t);
+    const size_t poly = poly_modulus_degree_ * coeff_modulus_size_;
+    if (contains_seed()) bytes += 8;
+    bytes += terms_count * coeff_modulus_size_ * 8;
+    bytes += contains_seed() ? 0 : poly * (polynomial_count_ - 1) * 8;
+    return bytes;
+}
+
+size_t Ciphertext::save_terms(std::ostream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool, CompressionMode mode) const {
+    // ciphertext.cu:213-280: as save(), flag bit 3 set, and of c0 only the coefficients `terms` (taken in coefficient form)
+    put_mode(stream, mode);
+    put(stream, parms_id_);
+    put(stream, polynomial_count_);
+    put(stream, coeff_modulus_size_);
+    put(stream, poly_modulus_degree_);
+    unsigned char flags = static_cast<unsigned char>(is_ntt_form_) | static_cast<unsigned char>(contains_seed() << 1) | static_cast<unsigned char>(on_device() << 2) | 8;
+    put(stream, flags);
+    const SchemeType scheme = context_scheme(context);
+    if (scheme == SchemeType::CKKS) put(stream, scale_);
+    if (scheme == SchemeType::BGV) put(stream, correction_factor_);
+    const size_t n = poly_modulus_degree_, L = coeff_modulus_size_, poly = n * L;
+    if (contains_seed()) {
+        if (polynomial_count_ != 2) throw std::logic_error("[Ciphertext::save] Ciphertext contains seed but polynomial count is not 2.");
+        put(stream, seed_);
+    }
+    for (size_t t : terms) if (t >= n) throw std::invalid_argument("[Ciphertext::save_terms] term out of range");
+    std::vector<uint64_t> c0;
+    if (is_ntt_form_) {
+        if (!on_device() || !context->on_device()) throw std::invalid_argument("[Ciphertext::save_terms] an NTT-form ciphertext is transformed on the GPU: context and ciphertext must be on the device.");
+        utils::DynamicArray tmp(poly, true, pool);
+        troyn_check(troyn_ntt(context->plan(), 1, data_.raw_pointer(), tmp.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+        c0 = tmp.to_vector();
+    } else {
+        utils::DynamicArray view = data_.clone(pool);
+        c0 = view.to_vector();
+        c0.resize(poly);
+    }
+    for (size_t j = 0; j < L; j++)
+        for (size_t t : terms) put(stream, c0[j * n + t]);
+    const size_t start = contains_seed() ? 2 : 1;
+    if (polynomial_count_ > start) {
+        const std::vector<uint64_t> words = data_.to_vector();
+        stream.write(reinterpret_cast<const char*>(words.data() + start * poly), (polynomial_count_ - start) * poly * 8);
+    }
+    return serialized_terms_size_upperbound(context, terms.size(), mode);
+}
+
+void Ciphertext::load_terms(std::istream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool) {
+    // ciphertext.cu:282-339: the coefficients of c0 that were not saved are zero
+    get_mode(stream);
+    get(stream, parms_id_);
+    get(stream, polynomial_count_);
+    get(stream, coeff_modulus_size_);
+    get(stream, poly_modulus_degree_);
+    unsigned char flags;
+    get(stream, flags);
+    is_ntt_form_ = flags & 1;
+    const bool seeded = flags & 2, device = flags & 4;
+    if (!(flags & 8)) throw std::logic_error("[Ciphertext::load_terms] Trying to call load_terms with ciphertext with all terms saved.");
+    const SchemeType scheme = context_scheme(context);
+    scale_ = 1.0; correction_factor_ = 1;
+    if (scheme == SchemeType::CKKS) get(stream, scale_);
+    if (scheme == SchemeType::BGV) get(stream, correction_factor_);
+    const size_t n = poly_modulus_degree_, L = coeff_modulus_size_, poly = n * L;
+    if (n > 131072 || L > 64 || polynomial_count_ > 64 || polynomial_count_ < 2) throw std::runtime_error("[Ciphertext::load] invalid shape");
+    std::vector<uint64_t> words(poly * (seeded ? 2 : polynomial_count_), 0);
+    seed_ = 0;
+    if (seeded) get(stream, seed_);
+    for (size_t t : terms) if (t >= n) throw std::invalid_argument("[Ciphertext::load_terms] term out of range");
+    for (size_t j = 0; j < L; j++)
+        for (size_t t : terms) get(stream, words[j * n + t]);
+    const size_t start = seeded ? 2 : 1;
+    if (polynomial_count_ > start) {
+        stream.read(reinterpret_cast<char*>(words.data() + start * poly), (polynomial_count_ - start) * poly * 8);
+        if (!stream) throw std::runtime_error("[Ciphertext::load] unexpected end of stream");
+    }
+    data_ = utils::DynamicArray::from_vector(words);
+    if (device || seeded || is_ntt_form_) data_.to_device_inplace(pool);
+    if (is_ntt_form_) {
+        if (!context->on_device()) throw std::invalid_argument("[Ciphertext::load_terms] an NTT-form ciphertext is transformed on the GPU: the context must be on the device.");
+        troyn_check(troyn_ntt(context->plan(), 0, data_.raw_pointer(), data_.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    }
+    if (seeded) expand_seed(context);
+}
+
 void Ciphertext::expand_seed(HeContextPointer context) {
     // ciphertext.cu:79-91: c1 <- uniform(RandomGenerator(seed)) under the ciphertext's moduli
     if (!contains_seed()) throw std::invalid_argument("[Ciphertext::expand_seed] Ciphertext does not contain seed.");
@@ -1932,11 +2023,13 @@ std::shared_ptr<utils::DynamicArray> Decryptor::bfv_decrypt_batch_device(const s
     const troyn_plan* plan = context_->plan();
     hipStream_t s = current_stream();
     utils::DynamicArray c0(count * pc, true, pool), c1(count * pc, true, pool);
-    // ciphertexts that are equally spaced windows of one buffer (what the batched producers return) gather in two copies
+    // ciphertexts that are adjacent windows of one buffer (what the batched producers return) gather in two copies
     const uint64_t* first = encrypted[0]->poly(0);
     const ptrdiff_t step = count > 1 ? encrypted[1]->poly(0) - first : static_cast<ptrdiff_t>(2 * pc);
-    bool strided = step >= static_cast<ptrdiff_t>(2 * pc);
-    for (size_t i = 0; i < count && strided; i++) strided = encrypted[i]->poly(0) == first + static_cast<ptrdiff_t>(i) * step;
+    bool strided = step == static_cast<ptrdiff_t>(2 * pc);   // adjacent windows; anything else (unrelated allocations) is copied one by one
+    const utils::DynamicArray* owner = encrypted[0]->data().view_owner();   // a 2D copy must stay inside ONE allocation
+    for (size_t i = 0; i < count && strided; i++)
+        strided = owner && encrypted[i]->data().view_owner() == owner && encrypted[i]->poly(0) == first + static_cast<ptrdiff_t>(i) * step;
     if (strided) {
         hip_check(hipMemcpy2DAsync(c0.raw_pointer(), pc * 8, first, static_cast<size_t>(step) * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
         hip_check(hipMemcpy2DAsync(c1.raw_pointer(), pc * 8, first + pc, static_cast<size_t>(step) * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");

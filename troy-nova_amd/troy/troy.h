@@ -87,6 +87,7 @@ public:
     // a device array that is a window of a larger allocation kept alive by `owner` (objects produced by one batched
     // launch share their buffer; copies of the object are ordinary owning arrays)
     static DynamicArray device_view(uint64_t* ptr, size_t count, std::shared_ptr<DynamicArray> owner);
+    const DynamicArray* view_owner() const noexcept { return owner_.get(); }   // the shared buffer a view points into, or null
     std::vector<uint64_t> to_vector() const;
     DynamicArray clone(MemoryPoolHandle pool = nullptr) const;
 
@@ -344,6 +345,14 @@ public:
     static Ciphertext load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Ciphertext c; c.load(stream, context, pool); return c; }
     size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void expand_seed(HeContextPointer context);
+    // ciphertext.cu:213-339: only the listed coefficients of c0 are written (flag bit 3); the other polynomials in full
+    size_t save_terms(std::ostream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
+                      CompressionMode mode = CompressionMode::Nil) const;
+    void load_terms(std::istream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static Ciphertext load_terms_new(std::istream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool = MemoryPool::GlobalPool()) {
+        Ciphertext c; c.load_terms(stream, context, terms, pool); return c;
+    }
+    size_t serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode mode = CompressionMode::Nil) const;
 private:
     size_t polynomial_count_ = 0, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
     ParmsID parms_id_;
@@ -504,6 +513,13 @@ public:
     GaloisKeys create_galois_keys_from_elements(const std::vector<size_t>& galois_elements, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     GaloisKeys create_galois_keys_from_steps(const std::vector<int>& steps, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     GaloisKeys create_galois_keys(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // all power-of-two rotations + row swap
+    // key_generator.h:101-109: the elements N/2^k + 1 used by field traces and the RLWE packing tree
+    GaloisKeys create_automorphism_keys(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        size_t poly_degree = context_->key_context_data().value()->parms().poly_modulus_degree();
+        std::vector<size_t> galois_elements;
+        while (poly_degree >= 2) { galois_elements.push_back(poly_degree + 1); poly_degree >>= 1; }
+        return create_galois_keys_from_elements(galois_elements, save_seed, pool);
+    }
     static void compute_secret_key_powers(HeContextPointer context, size_t max_power, utils::DynamicArray& secret_key_array);
 private:
     void generate_one_kswitch_key(const uint64_t* new_key, std::vector<PublicKey>& destination, bool save_seed, MemoryPoolHandle pool) const;
@@ -639,6 +655,45 @@ private:
 };
 
 // ----------------------------------------------------------------------------------------------
+// LWECiphertext  (src/lwe_ciphertext.h, lwe_ciphertext.cu): c0 u64[L], c1 u64[L][N]
+// ----------------------------------------------------------------------------------------------
+class LWECiphertext {
+public:
+    LWECiphertext() = default;
+    LWECiphertext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    bool on_device() const;
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { c0_.to_device_inplace(pool); c1_.to_device_inplace(pool); }
+    void to_host_inplace() { c0_.to_host_inplace(); c1_.to_host_inplace(); }
+    LWECiphertext to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { LWECiphertext r = clone(pool); r.to_device_inplace(pool); return r; }
+    LWECiphertext to_host() const { LWECiphertext r = clone(); r.to_host_inplace(); return r; }
+    size_t coeff_modulus_size() const noexcept { return coeff_modulus_size_; }
+    size_t& coeff_modulus_size() noexcept { return coeff_modulus_size_; }
+    size_t poly_modulus_degree() const noexcept { return poly_modulus_degree_; }
+    size_t& poly_modulus_degree() noexcept { return poly_modulus_degree_; }
+    const utils::DynamicArray& c0_dyn() const { return c0_; }
+    utils::DynamicArray& c0_dyn() { return c0_; }
+    const utils::DynamicArray& c1_dyn() const { return c1_; }
+    utils::DynamicArray& c1_dyn() { return c1_; }
+    const uint64_t* c0() const { return c0_.raw_pointer(); }
+    const uint64_t* c1() const { return c1_.raw_pointer(); }
+    const ParmsID& parms_id() const noexcept { return parms_id_; }
+    ParmsID& parms_id() noexcept { return parms_id_; }
+    double scale() const noexcept { return scale_; }
+    double& scale() noexcept { return scale_; }
+    uint64_t correction_factor() const noexcept { return correction_factor_; }
+    uint64_t& correction_factor() noexcept { return correction_factor_; }
+    // lwe_ciphertext.cu:9-60: the RLWE ciphertext (c0 as constant coefficient, c1) -- coefficient form
+    Ciphertext assemble_lwe(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    static std::vector<Ciphertext> assemble_lwe_batched_new(const std::vector<const LWECiphertext*>& lwes, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+private:
+    size_t coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
+    utils::DynamicArray c0_, c1_;
+    ParmsID parms_id_ = parms_id_zero;
+    double scale_ = 1.0;
+    uint64_t correction_factor_ = 1;
+};
+
+// ----------------------------------------------------------------------------------------------
 // Evaluator  (src/evaluator.h)
 // ----------------------------------------------------------------------------------------------
 class Evaluator {
@@ -717,6 +772,41 @@ public:
     void rotate_columns_inplace(Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext rotate_columns_new(const Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); return d; }
 
+    // ciphertext +/- plaintext -- evaluator.h (add_plain*, sub_plain*); evaluator_translate_plain.cu:13-170
+    void add_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_plain_inplace(encrypted, plain, false, pool); }
+    void add_plain(const Ciphertext& encrypted, const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encrypted.clone(pool); translate_plain_inplace(destination, plain, false, pool); }
+    Ciphertext add_plain_new(const Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; add_plain(encrypted, plain, d, pool); return d; }
+    void sub_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_plain_inplace(encrypted, plain, true, pool); }
+    void sub_plain(const Ciphertext& encrypted, const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encrypted.clone(pool); translate_plain_inplace(destination, plain, true, pool); }
+    Ciphertext sub_plain_new(const Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; sub_plain(encrypted, plain, d, pool); return d; }
+
+    // LWE extraction and RLWE packing -- evaluator.h:940-1041 (evaluator_lwes.cu)
+    LWECiphertext extract_lwe_new(const Ciphertext& encrypted, size_t term, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext assemble_lwe_new(const LWECiphertext& lwe, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return lwe.assemble_lwe(pool); }
+    void field_trace_inplace(Ciphertext& encrypted, const GaloisKeys& automorphism_keys, size_t logn, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void field_trace_inplace_batched(const std::vector<Ciphertext*>& encrypted, const GaloisKeys& automorphism_keys, size_t logn, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void divide_by_poly_modulus_degree_inplace(Ciphertext& encrypted, uint64_t mul = 1) const;
+    void negacyclic_shift(const Ciphertext& encrypted, size_t shift, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext negacyclic_shift_new(const Ciphertext& encrypted, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; negacyclic_shift(encrypted, shift, d, pool); return d; }
+    void negacyclic_shift_inplace(Ciphertext& encrypted, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; negacyclic_shift(encrypted, shift, d, pool); encrypted = std::move(d); }
+    Ciphertext pack_lwe_ciphertexts_new(const std::vector<const LWECiphertext*>& lwes, const GaloisKeys& automorphism_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
+                                        bool apply_field_trace = true) const;
+    Ciphertext pack_rlwe_ciphertexts_new(const std::vector<const Ciphertext*>& ciphers, const GaloisKeys& automorphism_keys, size_t shift, size_t input_interval,
+                                         size_t output_interval, MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const;
+    // every group's packing tree advances together: one fused layer kernel and one batched key switch per layer
+    void pack_rlwe_ciphertexts_batched(const std::vector<std::vector<const Ciphertext*>>& cipher_groups, const GaloisKeys& automorphism_keys, size_t shift,
+                                       size_t input_interval, size_t output_interval, const std::vector<Ciphertext*>& outputs,
+                                       MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const;
+    std::vector<Ciphertext> pack_rlwe_ciphertexts_new_batched(const std::vector<std::vector<const Ciphertext*>>& cipher_groups, const GaloisKeys& automorphism_keys,
+                                                              size_t shift, size_t input_interval, size_t output_interval,
+                                                              MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const {
+        std::vector<Ciphertext> out(cipher_groups.size());
+        std::vector<Ciphertext*> ptrs;
+        for (Ciphertext& c : out) ptrs.push_back(&c);
+        pack_rlwe_ciphertexts_batched(cipher_groups, automorphism_keys, shift, input_interval, output_interval, ptrs, pool, apply_field_trace);
+        return out;
+    }
+
     // modulus switching -- evaluator.h:308-420 (evaluator_modswitch.cu)
     void mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void mod_switch_to_next_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; mod_switch_to_next(encrypted, d, pool); encrypted = std::move(d); }
@@ -744,6 +834,7 @@ private:
     ContextDataPointer get_context_data(const char* prompt, const ParmsID& id) const;
     void translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool subtract, MemoryPoolHandle pool) const;
     void translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& d, bool subtract, MemoryPoolHandle pool) const;
+    void translate_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, bool subtract, MemoryPoolHandle pool) const;
     void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
                              SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
