@@ -238,6 +238,10 @@ int troyn_pack_layer(const troyn_plan* plan, uint32_t L, uint64_t galois_element
 size_t troyn_extract_lwe_workspace_bytes(size_t count);
 int troyn_extract_lwe(const troyn_plan* plan, uint32_t L, const uint64_t* const* ct, const size_t* terms, uint64_t* c0, uint64_t* c1, size_t count,
                       void* workspace, size_t workspace_bytes, troyn_stream_t stream);
+/* Staging for the reference's x_batched(vector<const T*>, ...) forms (batch_utils.h construct_batch + per-item loops inside
+ * the kernels): `count` scattered device buffers of `words` words (16-byte aligned) -> one contiguous block, one launch. */
+size_t troyn_gather_workspace_bytes(size_t count);
+int troyn_gather(const uint64_t* const* src, size_t count, size_t words, uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream);
 size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count);
 int troyn_multiply_plain_accumulate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, size_t pcount,
                                     const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,

@@ -167,3 +167,16 @@ def test_batched_encrypt_decrypt_cpp_api(dev, n, count):
     r = subprocess.run([drv, str(n), str(count)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "encrypt_mismatches 0 of" in r.stdout and "decrypt_mismatches 0 of" in r.stdout and "ntt_form_rejected 1" in r.stdout
+
+
+@pytest.mark.parametrize("scheme,count", [("bfv", 6), ("ckks", 5), ("bfv", 2)])
+def test_batched_ops_cpp_api(dev, scheme, count):
+    """every Evaluator x_batched form equals the per-object call bit for bit (scattered operands, adjacent windows, in place,
+    mixed batches, below the batching threshold)"""
+    drv = os.path.join(ROOT, "tests", "cpp", "batched_ops_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/batched_ops_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme, str(count)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln and ln not in ("OK",)]
+    assert len(lines) >= 17 and all(ln.endswith(" 0") or ln == "size_mismatch_rejected 1" for ln in lines), r.stdout

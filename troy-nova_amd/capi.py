@@ -62,6 +62,8 @@ SYMBOLS = {
     "troyn_sample_uniform": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
     "troyn_sample_centered_binomial_strided": (C.c_int, [vp, u32, p64, u64, u64, vp, sz, vp]),
     "troyn_sample_uniform_multi": (C.c_int, [vp, u32, p64, vp, sz, vp]),
+    "troyn_gather_workspace_bytes": (sz, [sz]),
+    "troyn_gather": (C.c_int, [vp, sz, sz, vp, vp, sz, vp]),
     "troyn_negacyclic_shift": (C.c_int, [vp, u32, u32, vp, vp, sz, sz, vp]),
     "troyn_multiply_inv_degree": (C.c_int, [vp, u32, u32, vp, vp, u64, sz, vp]),
     "troyn_pack_prepare_workspace_bytes": (sz, [sz]),

@@ -378,4 +378,15 @@ __global__ void extract_lwe_c0_kernel(unsigned L, unsigned n, const u64* const* 
     out[idx] = c0_polys[item][(size_t)l * n + terms[item]];
 }
 
+// Collect `count` device buffers of `words` words each into one contiguous block (the batched host API stages scattered
+// operands with ONE launch instead of `count` copies).  src = device array of pointers; 16-byte accesses.
+__global__ __launch_bounds__(256) void gather_kernel(const u64* const* src, size_t words, u64* out) {
+    const u64* sp = src[blockIdx.y];
+    u64* op = out + (size_t)blockIdx.y * words;
+    const size_t pairs = words / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2*>(op)[i] = reinterpret_cast<const ulonglong2*>(sp)[i];
+    if ((words & 1) && blockIdx.x == 0 && threadIdx.x == 0) op[words - 1] = sp[words - 1];
+}
+
 }  // namespace troyn

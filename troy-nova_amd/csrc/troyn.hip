@@ -1273,6 +1273,25 @@ extern "C" int troyn_extract_lwe(const troyn_plan* p, uint32_t L, const uint64_t
     return TROYN_OK;
 }
 
+extern "C" size_t troyn_gather_workspace_bytes(size_t count) { return (count + 1) * sizeof(u64); }
+
+extern "C" int troyn_gather(const uint64_t* const* src, size_t count, size_t words, uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    if (!src || !out || !workspace) return fail(TROYN_E_INVALID, "[troyn_gather] null argument");
+    if (count == 0 || words == 0) return TROYN_OK;
+    if (count > 65535) return fail(TROYN_E_INVALID, "[troyn_gather] batch too large for one launch");
+    if (workspace_bytes < troyn_gather_workspace_bytes(count)) return fail(TROYN_E_WORKSPACE, "[troyn_gather] workspace too small");
+    for (size_t i = 0; i < count; i++)
+        if (!src[i] || ((uintptr_t)src[i] & 15)) return fail(TROYN_E_INVALID, "[troyn_gather] null or misaligned pointer in the batch");
+    if ((uintptr_t)out & 15) return fail(TROYN_E_INVALID, "[troyn_gather] misaligned destination");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(workspace, src, count * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // `src` belongs to the caller
+    const unsigned bx = (unsigned)std::min<size_t>((words / 2 + 255) / 256 + 1, 64);
+    hipLaunchKernelGGL(gather_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64* const*)workspace, words, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
 extern "C" size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count) { return (4 * count + 2) * sizeof(u64); }
 
 extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, size_t pcount,

@@ -1,0 +1,329 @@
+// The Evaluator's x_batched(vector<const T*>, vector<T*>, pool) forms (evaluator.h; batch_utils.h in the reference).
+//
+// The reference builds device arrays of slice pointers per call and lets every kernel thread loop over the batch.  Here a
+// uniform batch is ONE contiguous block [count][polys][limbs][N]: scattered operands are staged by a single gather launch
+// (operands that are already adjacent windows of one buffer -- which is what these functions return -- are used in place),
+// the C-ABI entry runs once with batch = count, and the results are windows of one shared buffer.  Item 0 goes through the
+// per-object function first: it performs every argument check of the reference and fixes the result's shape and metadata.
+#include <hip/hip_runtime.h>
+
+#include "troy.h"
+
+namespace troy {
+
+namespace {
+
+hipStream_t stream() { return static_cast<hipStream_t>(troyn_current_stream()); }
+
+void hip_ok(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("[kernel_provider::") + what + "] " + hipGetErrorString(e));
+}
+
+// same level, shape, form and scale as item 0, on the device, no seed
+bool uniform(const std::vector<const Ciphertext*>& v) {
+    if (v.empty()) return false;
+    const Ciphertext& a = *v[0];
+    for (const Ciphertext* c : v)
+        if (!c->on_device() || c->contains_seed() || c->parms_id() != a.parms_id() || c->polynomial_count() != a.polynomial_count() ||
+            c->coeff_modulus_size() != a.coeff_modulus_size() || c->is_ntt_form() != a.is_ntt_form() || c->scale() != a.scale() ||
+            c->correction_factor() != a.correction_factor() || c->data().size() != a.data().size())
+            return false;
+    return true;
+}
+
+// [count][words] contiguous: the operands themselves when they are adjacent windows of one buffer, else a staged copy
+const uint64_t* contiguous(const std::vector<const Ciphertext*>& v, utils::DynamicArray& staged, MemoryPoolHandle pool) {
+    const size_t count = v.size(), words = v[0]->data().size();
+    const utils::DynamicArray* owner = v[0]->data().view_owner();
+    const uint64_t* base = v[0]->data().raw_pointer();
+    bool adjacent = owner != nullptr;
+    for (size_t i = 0; i < count && adjacent; i++) adjacent = v[i]->data().view_owner() == owner && v[i]->data().raw_pointer() == base + i * words;
+    if (adjacent) return base;
+    staged = utils::DynamicArray(count * words, true, pool);
+    std::vector<const uint64_t*> src(count);
+    for (size_t i = 0; i < count; i++) src[i] = v[i]->data().raw_pointer();
+    const size_t bytes = troyn_gather_workspace_bytes(count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    troyn_check_public(troyn_gather(src.data(), count, words, staged.raw_pointer(), ws.raw_pointer(), bytes, stream()));
+    troyn_sync_current_stream();   // `ws` returns to the pool
+    return staged.raw_pointer();
+}
+
+// the results: windows of one buffer shaped like `proto` (the per-object result of item 0)
+std::shared_ptr<utils::DynamicArray> result_block(const Ciphertext& proto, size_t count, MemoryPoolHandle pool) {
+    return std::make_shared<utils::DynamicArray>(count * proto.data().size(), true, pool);
+}
+
+void assign_views(const Ciphertext& proto, const std::shared_ptr<utils::DynamicArray>& block, const std::vector<Ciphertext*>& destination) {
+    troyn_sync_current_stream();
+    const size_t words = proto.data().size();
+    for (size_t i = 0; i < destination.size(); i++)
+        *destination[i] = Ciphertext::from_members(proto.polynomial_count(), proto.coeff_modulus_size(), proto.poly_modulus_degree(), proto.parms_id(), proto.scale(),
+                                                   proto.is_ntt_form(), proto.correction_factor(), 0,
+                                                   utils::DynamicArray::device_view(block->raw_pointer() + i * words, words, block));
+}
+
+std::vector<const Ciphertext*> as_const(const std::vector<Ciphertext*>& v) { return std::vector<const Ciphertext*>(v.begin(), v.end()); }
+
+void same_size(const char* prompt, size_t a, size_t b) {
+    if (a != b) throw std::invalid_argument(std::string(prompt) + " Input and destination have different sizes.");
+}
+
+}  // namespace
+
+// -- negate ------------------------------------------------------------------------------------------------------------
+void Evaluator::negate_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::negate_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext d; negate(*encrypted[i], d, pool); *destination[i] = std::move(d); }
+        return;
+    }
+    Ciphertext proto;
+    negate(*encrypted[0], proto, pool);
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, encrypted.size(), pool);
+    troyn_check_public(troyn_negate(context_->plan(), 0, static_cast<uint32_t>(proto.coeff_modulus_size()), in, block->raw_pointer(),
+                                    encrypted.size() * proto.polynomial_count(), stream()));
+    assign_views(proto, block, destination);
+}
+
+void Evaluator::negate_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool) const { negate_batched(as_const(encrypted), encrypted, pool); }
+
+// -- add / sub ---------------------------------------------------------------------------------------------------------
+void Evaluator::translate_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, bool subtract,
+                                  MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
+    const bool batched = e1.size() >= BATCH_OP_THRESHOLD && uniform(e1) && uniform(e2) && e1[0]->polynomial_count() == e2[0]->polynomial_count();
+    if (!batched) {
+        for (size_t i = 0; i < e1.size(); i++) { Ciphertext out; translate(*e1[i], *e2[i], out, subtract, pool); *d[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    translate(*e1[0], *e2[0], proto, subtract, pool);
+    utils::DynamicArray s1(0, true, pool), s2(0, true, pool);
+    const uint64_t* a = contiguous(e1, s1, pool);
+    const uint64_t* b = contiguous(e2, s2, pool);
+    auto block = result_block(proto, e1.size(), pool);
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, a, b, block->raw_pointer(), e1.size() * proto.polynomial_count(), stream()));
+    assign_views(proto, block, d);
+}
+
+void Evaluator::add_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    translate_batched(e1, e2, d, false, pool);
+}
+void Evaluator::sub_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    translate_batched(e1, e2, d, true, pool);
+}
+
+// -- multiply ----------------------------------------------------------------------------------------------------------
+void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::multiply_batched] Input and destination have different sizes.");
+    if (e1.size() < BATCH_OP_THRESHOLD || !uniform(e1) || !uniform(e2)) {
+        for (size_t i = 0; i < e1.size(); i++) { Ciphertext out; multiply(*e1[i], *e2[i], out, pool); *d[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    multiply(*e1[0], *e2[0], proto, pool);
+    const size_t count = e1.size(), p1 = e1[0]->polynomial_count(), p2 = e2[0]->polynomial_count();
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    utils::DynamicArray s1(0, true, pool), s2(0, true, pool);
+    const uint64_t* a = contiguous(e1, s1, pool);
+    const uint64_t* b = contiguous(e2, s2, pool);
+    auto block = result_block(proto, count, pool);
+    if (context_->key_context_data().value()->parms().scheme() == SchemeType::BFV) {
+        const troyn_behz* bz = context_->behz(L);
+        const size_t bytes = troyn_bfv_multiply_workspace_bytes(bz, p1, p2, count);
+        utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        troyn_check_public(troyn_bfv_multiply(bz, a, p1, b, p2, block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
+        troyn_sync_current_stream();
+    } else {
+        troyn_check_public(troyn_dyadic_convolute(context_->plan(), 0, L, a, p1, b, p2, block->raw_pointer(), count, stream()));
+    }
+    assign_views(proto, block, d);
+}
+
+// -- relinearize -------------------------------------------------------------------------------------------------------
+void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::relinearize_batched]", encrypted.size(), d.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted) || encrypted[0]->polynomial_count() != 3) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; relinearize_internal(*encrypted[i], relin_keys, 2, out, pool); *d[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    relinearize_internal(*encrypted[0], relin_keys, 2, proto, pool);
+    const size_t count = encrypted.size();
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    const std::vector<const uint64_t*> keys = relin_keys.get_data_ptrs(RelinKeys::get_index(2));
+    const size_t bytes = troyn_relinearize_workspace_bytes(context_->plan(), L, count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    const bool ckks = context_->key_context_data().value()->parms().scheme() == SchemeType::CKKS;
+    troyn_check_public(troyn_relinearize(context_->plan(), L, ckks, proto.is_ntt_form(), in, keys.data(), block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
+    assign_views(proto, block, d);
+}
+
+// -- modulus switching -------------------------------------------------------------------------------------------------
+void Evaluator::mod_switch_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::mod_switch_to_next_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; mod_switch_to_next(*encrypted[i], out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    mod_switch_to_next(*encrypted[0], proto, pool);
+    const size_t count = encrypted.size(), pc = proto.polynomial_count();
+    const uint32_t L = static_cast<uint32_t>(encrypted[0]->coeff_modulus_size());
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    if (context_->first_context_data().value()->parms().scheme() == SchemeType::BFV)
+        troyn_check_public(troyn_divide_and_round_q_last(context_->plan(), L, in, pc, block->raw_pointer(), count, stream()));
+    else
+        troyn_check_public(troyn_mod_switch_drop(context_->plan(), L, static_cast<uint32_t>(proto.coeff_modulus_size()), in, pc, block->raw_pointer(), count, stream()));
+    assign_views(proto, block, destination);
+}
+
+void Evaluator::rescale_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::rescale_to_next_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; rescale_to_next(*encrypted[i], out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    rescale_to_next(*encrypted[0], proto, pool);
+    const size_t count = encrypted.size(), pc = proto.polynomial_count();
+    const uint32_t L = static_cast<uint32_t>(encrypted[0]->coeff_modulus_size());
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    const size_t bytes = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), L, pc, count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    troyn_check_public(troyn_divide_and_round_q_last_ntt(context_->plan(), L, in, pc, block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
+    assign_views(proto, block, destination);
+}
+
+// -- NTT ---------------------------------------------------------------------------------------------------------------
+static void ntt_batched(const Evaluator& ev, const HeContextPointer& context, bool inverse, const std::vector<const Ciphertext*>& encrypted,
+                        const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) {
+    same_size(inverse ? "[Evaluator::transform_from_ntt_batched]" : "[Evaluator::transform_to_ntt_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < Evaluator::BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) {
+            Ciphertext out;
+            if (inverse) ev.transform_from_ntt(*encrypted[i], out, pool); else ev.transform_to_ntt(*encrypted[i], out, pool);
+            *destination[i] = std::move(out);
+        }
+        return;
+    }
+    Ciphertext proto;
+    if (inverse) ev.transform_from_ntt(*encrypted[0], proto, pool); else ev.transform_to_ntt(*encrypted[0], proto, pool);
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, encrypted.size(), pool);
+    troyn_check_public(troyn_ntt(context->plan(), inverse ? 1 : 0, in, block->raw_pointer(), encrypted.size(), proto.polynomial_count(), L, 0, L, TROYN_IDX_COMPONENTWISE, 0,
+                                 stream()));
+    assign_views(proto, block, destination);
+}
+
+void Evaluator::transform_to_ntt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    ntt_batched(*this, context_, false, encrypted, destination, pool);
+}
+void Evaluator::transform_from_ntt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    ntt_batched(*this, context_, true, encrypted, destination, pool);
+}
+void Evaluator::transform_to_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool) const {
+    ntt_batched(*this, context_, false, as_const(encrypted), encrypted, pool);
+}
+void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle pool) const {
+    ntt_batched(*this, context_, true, as_const(encrypted), encrypted, pool);
+}
+
+// -- Galois automorphism -----------------------------------------------------------------------------------------------
+void Evaluator::apply_galois_batched(const std::vector<const Ciphertext*>& encrypted, size_t galois_element, const GaloisKeys& galois_keys,
+                                     const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::apply_galois_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; apply_galois(*encrypted[i], galois_element, galois_keys, out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    apply_galois(*encrypted[0], galois_element, galois_keys, proto, pool);
+    const size_t count = encrypted.size(), n = proto.poly_modulus_degree();
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    const size_t pc = static_cast<size_t>(L) * n;
+    const troyn_plan* plan = context_->plan();
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    // permute (c0, c1) of every item, take the permuted c1s as key-switch targets, overwrite them with the switched result
+    troyn_check_public(troyn_apply_galois(plan, 0, L, proto.is_ntt_form() ? 1 : 0, galois_element, in, block->raw_pointer(), count * 2, stream()));
+    utils::DynamicArray target(count * pc, true, pool);
+    hip_ok(hipMemcpy2DAsync(target.raw_pointer(), pc * 8, block->raw_pointer() + pc, 2 * pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+    const std::vector<const uint64_t*> keys = galois_keys.get_data_ptrs(GaloisKeys::get_index(galois_element));
+    const size_t bytes = troyn_switch_key_workspace_bytes(plan, L, count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    const bool ckks = context_->key_context_data().value()->parms().scheme() == SchemeType::CKKS;
+    troyn_check_public(troyn_switch_key(plan, L, ckks, proto.is_ntt_form(), target.raw_pointer(), keys.data(), TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST, block->raw_pointer(),
+                                        ws.raw_pointer(), bytes, count, stream()));
+    assign_views(proto, block, destination);
+}
+
+// -- ciphertext +/- plaintext, ciphertext x plaintext ----------------------------------------------------------------------
+void Evaluator::translate_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                                        bool subtract, MemoryPoolHandle pool) const {
+    if (encrypted.size() != plain.size() || encrypted.size() != destination.size())
+        throw std::invalid_argument("[Evaluator::translate_plain_batched] Input and destination have different sizes.");
+    bool batched = encrypted.size() >= BATCH_OP_THRESHOLD && uniform(encrypted) && context_->key_context_data().value()->parms().scheme() == SchemeType::BFV;
+    for (const Plaintext* p : plain) batched = batched && p->parms_id() == parms_id_zero && !p->is_ntt_form() && p->on_device();
+    if (!batched) {
+        for (size_t i = 0; i < encrypted.size(); i++) {
+            Ciphertext out = encrypted[i]->clone(pool);
+            translate_plain_inplace(out, *plain[i], subtract, pool);
+            *destination[i] = std::move(out);
+        }
+        return;
+    }
+    // BFV, plaintexts mod t: c0 +/- round(q/t * m) for the whole batch (scaling_variant::multiply_add_plain_inplace)
+    Ciphertext proto = encrypted[0]->clone(pool);
+    translate_plain_inplace(proto, *plain[0], subtract, pool);
+    const size_t count = encrypted.size(), n = proto.poly_modulus_degree(), L = proto.coeff_modulus_size(), words = proto.data().size();
+    utils::DynamicArray staged(0, true, pool), plains(count * n, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    plains.set_zero();
+    for (size_t i = 0; i < count; i++) {
+        if (plain[i]->coeff_count() > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+        hip_ok(hipMemcpyAsync(plains.raw_pointer() + i * n, plain[i]->poly(), plain[i]->coeff_count() * 8, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+    }
+    auto block = result_block(proto, count, pool);
+    hip_ok(hipMemcpyAsync(block->raw_pointer(), in, count * words * 8, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+    troyn_check_public(troyn_bfv_scale_up(context_->behz(L), plains.raw_pointer(), n, n, in, words, block->raw_pointer(), words, subtract ? 1 : 0, count, stream()));
+    assign_views(proto, block, destination);
+}
+
+void Evaluator::multiply_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                                       MemoryPoolHandle pool) const {
+    if (encrypted.size() != plain.size() || encrypted.size() != destination.size())
+        throw std::invalid_argument("[Evaluator::multiply_plain_batched] Input and destination have different sizes.");
+    bool ntt = !encrypted.empty();
+    for (size_t i = 0; i < encrypted.size() && ntt; i++) ntt = encrypted[i]->is_ntt_form() && plain[i]->is_ntt_form();
+    bool distinct = true;
+    for (size_t i = 0; i < destination.size() && distinct; i++)
+        for (size_t k = 0; k < i && distinct; k++) distinct = destination[k] != destination[i];
+    if (ntt && distinct && uniform(encrypted)) {
+        // evaluator_multiply_plain.cu:356-385 (multiply_plain_ntt_batched): one launch over all (ciphertext, plaintext) pairs;
+        // an in-place call (destination[i] == encrypted[i]) goes through temporaries
+        std::vector<Ciphertext> tmp(encrypted.size());
+        std::vector<Ciphertext*> tp;
+        for (Ciphertext& c : tmp) tp.push_back(&c);
+        multiply_plain_accumulate(encrypted, plain, tp, true, pool);
+        for (size_t i = 0; i < tmp.size(); i++) *destination[i] = std::move(tmp[i]);
+        return;
+    }
+    for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; multiply_plain(*encrypted[i], *plain[i], out, pool); *destination[i] = std::move(out); }
+}
+
+}  // namespace troy

@@ -218,7 +218,20 @@ void Evaluator::field_trace_inplace(Ciphertext& encrypted, const GaloisKeys& aut
 }
 
 void Evaluator::field_trace_inplace_batched(const std::vector<Ciphertext*>& encrypted, const GaloisKeys& automorphism_keys, size_t logn, MemoryPoolHandle pool) const {
-    for (Ciphertext* c : encrypted) field_trace_inplace(*c, automorphism_keys, logn, pool);
+    // evaluator_lwes.cu:111-139
+    if (encrypted.empty()) return;
+    size_t poly_degree = encrypted[0]->poly_modulus_degree();
+    for (Ciphertext* c : encrypted)
+        if (c->poly_modulus_degree() != poly_degree) throw std::invalid_argument("[Evaluator::field_trace_inplace_batched] Mismatched poly_modulus_degree.");
+    std::vector<Ciphertext> temp(encrypted.size());
+    std::vector<Ciphertext*> temp_ptrs;
+    std::vector<const Ciphertext*> temp_const, enc_const(encrypted.begin(), encrypted.end());
+    for (Ciphertext& t : temp) { temp_ptrs.push_back(&t); temp_const.push_back(&t); }
+    while (poly_degree > (static_cast<size_t>(1) << logn)) {
+        apply_galois_batched(enc_const, poly_degree + 1, automorphism_keys, temp_ptrs, pool);
+        add_batched(enc_const, temp_const, encrypted, pool);
+        poly_degree >>= 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,24 +91,25 @@ void Cipher2d::mod_switch_to_next_inplace(const Evaluator& evaluator, MemoryPool
 
 void Cipher2d::translate_inplace(const Evaluator& evaluator, const Cipher2d& other, bool subtract, MemoryPoolHandle pool) {
     if (size() != other.size()) throw std::runtime_error("[Cipher2d::translate_inplace] Row size mismatch.");
+    std::vector<const Ciphertext*> a, b;
+    std::vector<Ciphertext*> d;
     for (size_t i = 0; i < rows(); i++) {
         if (inner[i].size() != other[i].size()) throw std::runtime_error("[Cipher2d::translate_inplace] Column size mismatch.");
-        for (size_t j = 0; j < inner[i].size(); j++) {
-            if (subtract) evaluator.sub_inplace(inner[i][j], other[i][j], pool);
-            else evaluator.add_inplace(inner[i][j], other[i][j], pool);
-        }
+        for (size_t j = 0; j < inner[i].size(); j++) { a.push_back(&inner[i][j]); b.push_back(&other[i][j]); d.push_back(&inner[i][j]); }
     }
+    if (subtract) evaluator.sub_batched(a, b, d, pool); else evaluator.add_batched(a, b, d, pool);
 }
 
 void Cipher2d::translate_plain_inplace(const Evaluator& evaluator, const Plain2d& other, bool subtract, MemoryPoolHandle pool) {
     if (size() != other.size()) throw std::runtime_error("[Cipher2d::translate_plain_inplace] Row size mismatch.");
+    std::vector<const Ciphertext*> a;
+    std::vector<const Plaintext*> b;
+    std::vector<Ciphertext*> d;
     for (size_t i = 0; i < rows(); i++) {
         if (inner[i].size() != other[i].size()) throw std::runtime_error("[Cipher2d::translate_plain_inplace] Column size mismatch.");
-        for (size_t j = 0; j < inner[i].size(); j++) {
-            if (subtract) evaluator.sub_plain_inplace(inner[i][j], other[i][j], pool);
-            else evaluator.add_plain_inplace(inner[i][j], other[i][j], pool);
-        }
+        for (size_t j = 0; j < inner[i].size(); j++) { a.push_back(&inner[i][j]); b.push_back(&other[i][j]); d.push_back(&inner[i][j]); }
     }
+    if (subtract) evaluator.sub_plain_batched(a, b, d, pool); else evaluator.add_plain_batched(a, b, d, pool);
 }
 
 // ------------------------------------------------------------------------------------------------

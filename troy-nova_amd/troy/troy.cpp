@@ -606,13 +606,6 @@ void Evaluator::negate_inplace(Ciphertext& encrypted) const {
                              encrypted.polynomial_count(), current_stream()));
 }
 
-void Evaluator::negate_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
-    for (Ciphertext* c : encrypted) negate_inplace(*c);
-}
-void Evaluator::negate_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
-    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::negate_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < encrypted.size(); i++) negate(*encrypted[i], *destination[i], pool);
-}
 
 // -- add / sub (evaluator_translate.cu:12-118) ------------------------------------------------------
 void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, bool subtract, MemoryPoolHandle pool) const {
@@ -649,14 +642,6 @@ void Evaluator::translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool sub
     e1 = std::move(d);
 }
 
-void Evaluator::add_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
-    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < e1.size(); i++) translate(*e1[i], *e2[i], *d[i], false, pool);
-}
-void Evaluator::sub_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
-    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < e1.size(); i++) translate(*e1[i], *e2[i], *d[i], true, pool);
-}
 
 // -- multiply / square (evaluator.cu:29-343) ------------------------------------------------------------
 void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, MemoryPoolHandle pool) const {
@@ -713,10 +698,6 @@ void Evaluator::square(const Ciphertext& encrypted, Ciphertext& destination, Mem
     destination = std::move(out);
 }
 
-void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
-    if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::multiply_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < e1.size(); i++) multiply(*e1[i], *e2[i], *d[i], pool);
-}
 
 // -- key switching (evaluator_keyswitching_core.cu:757-1052, evaluator_keyswitching.cu:11-144) ---------------
 void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
@@ -815,10 +796,6 @@ void Evaluator::relinearize_inplace_internal(Ciphertext& encrypted, const RelinK
     encrypted = std::move(d);
 }
 
-void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
-    if (encrypted.size() != d.size()) throw std::invalid_argument("[Evaluator::relinearize_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < encrypted.size(); i++) relinearize_internal(*encrypted[i], relin_keys, 2, *d[i], pool);
-}
 
 // -- modulus switching (evaluator_modswitch.cu) --------------------------------------------------------------
 void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
@@ -882,10 +859,6 @@ void Evaluator::mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& dest
     }
 }
 
-void Evaluator::mod_switch_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
-    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::mod_switch_to_next_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < encrypted.size(); i++) mod_switch_to_next(*encrypted[i], *destination[i], pool);
-}
 
 void Evaluator::mod_switch_to(const Ciphertext& encrypted, const ParmsID& parms_id, Ciphertext& destination, MemoryPoolHandle pool) const {
     // evaluator_modswitch.cu:330-360
@@ -912,10 +885,6 @@ void Evaluator::rescale_to_next(const Ciphertext& encrypted, Ciphertext& destina
     }
 }
 
-void Evaluator::rescale_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
-    if (encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::rescale_to_next_batched] Input and destination have different sizes.");
-    for (size_t i = 0; i < encrypted.size(); i++) rescale_to_next(*encrypted[i], *destination[i], pool);
-}
 
 // -- NTT (evaluator_transform_ntt.cu:469-652) ----------------------------------------------------------------
 void Evaluator::transform_to_ntt_inplace(Ciphertext& encrypted) const {
@@ -966,12 +935,6 @@ void Evaluator::transform_from_ntt(const Ciphertext& encrypted, Ciphertext& dest
     destination = std::move(out);
 }
 
-void Evaluator::transform_to_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
-    for (Ciphertext* c : encrypted) transform_to_ntt_inplace(*c);
-}
-void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*>& encrypted, MemoryPoolHandle) const {
-    for (Ciphertext* c : encrypted) transform_from_ntt_inplace(*c);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Evaluator: ciphertext x plaintext  (evaluator_multiply_plain.cu, evaluator_transform_ntt.cu:35-70)

@@ -772,6 +772,22 @@ public:
     void rotate_columns_inplace(Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext rotate_columns_new(const Ciphertext& encrypted, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rotate_columns(encrypted, galois_keys, d, pool); return d; }
 
+    // The x_batched forms below run ONE launch per step over the whole batch when the operands are uniform (same level, size,
+    // form, scale): scattered operands are staged into a contiguous block by one gather launch (adjacent windows of one buffer --
+    // what these functions themselves return -- are used in place), and the results are windows of one shared buffer.  Mixed
+    // batches and batches below BATCH_OP_THRESHOLD take the per-object path (utils/constants.h BATCH_OP_THRESHOLD).
+    static constexpr size_t BATCH_OP_THRESHOLD = 4;
+    void transform_to_ntt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void transform_from_ntt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void apply_galois_batched(const std::vector<const Ciphertext*>& encrypted, size_t galois_element, const GaloisKeys& galois_keys, const std::vector<Ciphertext*>& destination,
+                              MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void add_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                           MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_plain_batched(encrypted, plain, destination, false, pool); }
+    void sub_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                           MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_plain_batched(encrypted, plain, destination, true, pool); }
+    void multiply_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                                MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
     // ciphertext +/- plaintext -- evaluator.h (add_plain*, sub_plain*); evaluator_translate_plain.cu:13-170
     void add_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_plain_inplace(encrypted, plain, false, pool); }
     void add_plain(const Ciphertext& encrypted, const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encrypted.clone(pool); translate_plain_inplace(destination, plain, false, pool); }
@@ -835,6 +851,10 @@ private:
     void translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool subtract, MemoryPoolHandle pool) const;
     void translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& d, bool subtract, MemoryPoolHandle pool) const;
     void translate_plain_inplace(Ciphertext& encrypted, const Plaintext& plain, bool subtract, MemoryPoolHandle pool) const;
+    void translate_plain_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination,
+                                 bool subtract, MemoryPoolHandle pool) const;
+    void translate_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, bool subtract,
+                           MemoryPoolHandle pool) const;
     void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
                              SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
