@@ -131,3 +131,55 @@ def test_ckks_flow_in_python(pytroy, dev):
     rot = enc.decode_complex64_simd_new(dec.decrypt_new(ev.rotate_vector_new(c1, 2, gk)))
     assert max(abs(rot[i] - z1[(i + 2) % len(z1)]) for i in range(len(z1))) < 2e-2   # scale 2^30: key-switch noise ~2^-10
     pytroy.MemoryPool.destroy_global_pool()
+
+
+@pytest.mark.gpu
+def test_lwe_packing_flow_in_python(pytroy, dev):
+    """pybind/tests-style use of the LWE / packing defs of pybind/src/evaluator.cu: extract_lwe_new, assemble_lwe_new,
+    pack_lwe_ciphertexts_new(_batched), pack_rlwe_ciphertexts_new, negacyclic_shift_new, add_plain_new, field traces"""
+    n = 4096
+    p = _params(pytroy, pytroy.SchemeType.BFV, n, [40, 40, 40, 40])
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Nil, 0x99)
+    ctx.to_device_inplace()
+    t = p.plain_modulus().value()
+    encoder = pytroy.BatchEncoder(ctx)
+    encoder.to_device_inplace()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_secret_key(keygen.secret_key())
+    decryptor = pytroy.Decryptor(ctx, keygen.secret_key())
+    evaluator = pytroy.Evaluator(ctx)
+    auto = keygen.create_automorphism_keys(False)
+    msg = [(7 * i + 3) % t for i in range(n)]
+    dec = lambda ct: encoder.decode_polynomial_new(decryptor.decrypt_new(ct))
+    c = encryptor.encrypt_symmetric_new(encoder.encode_polynomial_new(msg), False)
+    assert dec(c) == msg
+    # X^5 * m: coefficients move up by 5, the wrapped ones change sign
+    sh = dec(evaluator.negacyclic_shift_new(c, 5))
+    assert sh[5:] == msg[:n - 5] and sh[:5] == [(t - v) % t for v in msg[n - 5:]]
+    bias = [(11 * i + 1) % t for i in range(n)]
+    assert dec(evaluator.add_plain_new(c, encoder.encode_polynomial_new(bias))) == [(a + b) % t for a, b in zip(msg, bias)]
+    assert dec(evaluator.sub_plain_new(c, encoder.encode_polynomial_new(bias))) == [(a - b) % t for a, b in zip(msg, bias)]
+    terms = [0, 9, n - 1, 1234, 77]
+    lwes = [evaluator.extract_lwe_new(c, term) for term in terms]
+    assert lwes[0].poly_modulus_degree() == n and lwes[0].coeff_modulus_size() == 3
+    for lwe, term in zip(lwes, terms):
+        assert dec(evaluator.assemble_lwe_new(lwe))[0] == msg[term]
+    packed = dec(evaluator.pack_lwe_ciphertexts_new(lwes, auto))
+    stride = n // 8                                                       # 5 LWEs -> 8 slots
+    want = [0] * n
+    for i, term in enumerate(terms):
+        want[i * stride] = msg[term]
+    assert packed == want
+    both = evaluator.pack_lwe_ciphertexts_new_batched([lwes, lwes[:2]], auto)
+    assert dec(both[0]) == want
+    w2 = [0] * n
+    w2[0], w2[n // 8] = msg[terms[0]], msg[terms[1]]                      # the tree depth follows the largest group
+    assert dec(both[1]) == w2
+    # MatmulHelper::pack_outputs's call: members carry results on coefficients = 3 (mod 4); member k lands on offset k
+    others = [encryptor.encrypt_symmetric_new(encoder.encode_polynomial_new([(msg[i] * (k + 2)) % t for i in range(n)]), False) for k in range(3)]
+    merged = dec(evaluator.pack_rlwe_ciphertexts_new([c] + others, auto, 2 * n - 3, 4, 1))
+    for k in range(4):
+        src = msg if k == 0 else [(v * (k + 1)) % t for v in msg]
+        assert merged[k::4] == src[3::4], k
+    pytroy.MemoryPool.destroy_global_pool()

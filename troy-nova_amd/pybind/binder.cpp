@@ -166,6 +166,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("create_keyswitching_key", [](const KeyGenerator& s, const SecretKey& nk, bool save_seed, PoolArg p) { return s.create_keyswitching_key(nk, save_seed, P(p)); },
              py::arg("new_key"), py::arg("save_seed"), POOL)
         .def("create_galois_keys", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_galois_keys(save_seed, P(p)); }, py::arg("save_seed"), POOL)
+        .def("create_automorphism_keys", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_automorphism_keys(save_seed, P(p)); }, py::arg("save_seed"), POOL)
         .def("create_galois_keys_from_steps", [](const KeyGenerator& s, const std::vector<int>& st, bool save_seed, PoolArg p) { return s.create_galois_keys_from_steps(st, save_seed, P(p)); },
              py::arg("steps"), py::arg("save_seed"), POOL)
         .def("create_galois_keys_from_elements", [](const KeyGenerator& s, const std::vector<size_t>& el, bool save_seed, PoolArg p) { return s.create_galois_keys_from_elements(el, save_seed, P(p)); },
@@ -198,7 +199,9 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("on_device", &BatchEncoder::on_device).def("to_device_inplace", [](BatchEncoder&, PoolArg) {}, POOL)
         .def("encode_simd", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
         .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL);
+        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("encode_polynomial_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_polynomial_new(v, P(p)); }, py::arg("values"), POOL)
+        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL);
 
     py::class_<CKKSEncoder>(m, "CKKSEncoder")
         .def(py::init<HeContextPointer>()).def("context", &CKKSEncoder::context).def("slot_count", &CKKSEncoder::slot_count)
@@ -212,6 +215,16 @@ PYBIND11_MODULE(pytroy_raw, m) {
             return s.encode_float64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
         .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("plain"), POOL)
         .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL);
+
+    py::class_<LWECiphertext>(m, "LWECiphertext")
+        .def(py::init<>())
+        .def("clone", [](const LWECiphertext& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("on_device", &LWECiphertext::on_device)
+        .def("parms_id", [](const LWECiphertext& s) { return s.parms_id(); })
+        .def("coeff_modulus_size", [](const LWECiphertext& s) { return s.coeff_modulus_size(); })
+        .def("poly_modulus_degree", [](const LWECiphertext& s) { return s.poly_modulus_degree(); })
+        .def("scale", [](const LWECiphertext& s) { return s.scale(); })
+        .def("assemble_lwe", [](const LWECiphertext& s, PoolArg p) { return s.assemble_lwe(P(p)); }, POOL);
 
     py::class_<Evaluator> ev(m, "Evaluator");
     ev.def(py::init<HeContextPointer>()).def("context", &Evaluator::context).def("on_device", &Evaluator::on_device);
@@ -273,4 +286,73 @@ PYBIND11_MODULE(pytroy_raw, m) {
            py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), POOL);
     ev.def("complex_conjugate_new", [](const Evaluator& s, const Ciphertext& a, const GaloisKeys& k, PoolArg p) { return s.complex_conjugate_new(a, k, P(p)); },
            py::arg("encrypted"), py::arg("galois_keys"), POOL);
+    // ciphertext +/- plaintext
+#define EV_PLAIN(name)                                                                                                           \
+    ev.def(#name, [](const Evaluator& s, const Ciphertext& a, const Plaintext& w, Ciphertext& d, PoolArg p) { s.name(a, w, d, P(p)); },  \
+           py::arg("encrypted"), py::arg("plain"), py::arg("destination"), POOL);                                               \
+    ev.def(#name "_inplace", [](const Evaluator& s, Ciphertext& a, const Plaintext& w, PoolArg p) { s.name##_inplace(a, w, P(p)); }, \
+           py::arg("encrypted"), py::arg("plain"), POOL);                                                                       \
+    ev.def(#name "_new", [](const Evaluator& s, const Ciphertext& a, const Plaintext& w, PoolArg p) { return s.name##_new(a, w, P(p)); }, \
+           py::arg("encrypted"), py::arg("plain"), POOL)
+    EV_PLAIN(add_plain);
+    EV_PLAIN(sub_plain);
+#undef EV_PLAIN
+    ev.def("transform_plain_to_ntt", [](const Evaluator& s, const Plaintext& w, const ParmsID& id, Plaintext& d, PoolArg p) { s.transform_plain_to_ntt(w, id, d, P(p)); },
+           py::arg("plain"), py::arg("parms_id"), py::arg("destination"), POOL);
+    ev.def("transform_plain_to_ntt_inplace", [](const Evaluator& s, Plaintext& w, const ParmsID& id, PoolArg p) { s.transform_plain_to_ntt_inplace(w, id, P(p)); },
+           py::arg("plain"), py::arg("parms_id"), POOL);
+    ev.def("multiply_plain_new_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Plaintext*>& w, PoolArg p) {
+        std::vector<Ciphertext> out(a.size());
+        std::vector<Ciphertext*> op;
+        for (Ciphertext& c : out) op.push_back(&c);
+        s.multiply_plain_batched(const_ptrs(a), const_ptrs(w), op, P(p));
+        return out;
+    }, py::arg("encrypted"), py::arg("plain"), POOL);
+    // rescale / plaintext modulus switching
+    ev.def("rescale_to", [](const Evaluator& s, const Ciphertext& a, const ParmsID& id, Ciphertext& d, PoolArg p) { s.rescale_to(a, id, d, P(p)); },
+           py::arg("encrypted"), py::arg("parms_id"), py::arg("destination"), POOL);
+    ev.def("rescale_to_inplace", [](const Evaluator& s, Ciphertext& a, const ParmsID& id, PoolArg p) { s.rescale_to_inplace(a, id, P(p)); }, py::arg("encrypted"), py::arg("parms_id"), POOL);
+    ev.def("rescale_to_new", [](const Evaluator& s, const Ciphertext& a, const ParmsID& id, PoolArg p) { return s.rescale_to_new(a, id, P(p)); }, py::arg("encrypted"), py::arg("parms_id"), POOL);
+    ev.def("mod_switch_plain_to", [](const Evaluator& s, const Plaintext& a, const ParmsID& id, Plaintext& d, PoolArg p) { s.mod_switch_plain_to(a, id, d, P(p)); },
+           py::arg("plain"), py::arg("parms_id"), py::arg("destination"), POOL);
+    ev.def("mod_switch_plain_to_inplace", [](const Evaluator& s, Plaintext& a, const ParmsID& id, PoolArg p) { s.mod_switch_plain_to_inplace(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id"), POOL);
+    ev.def("mod_switch_plain_to_new", [](const Evaluator& s, const Plaintext& a, const ParmsID& id, PoolArg p) { return s.mod_switch_plain_to_new(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id"), POOL);
+    ev.def("mod_switch_plain_to_next", [](const Evaluator& s, const Plaintext& a, Plaintext& d, PoolArg p) { s.mod_switch_plain_to_next(a, d, P(p)); }, py::arg("plain"), py::arg("destination"), POOL);
+    ev.def("mod_switch_plain_to_next_inplace", [](const Evaluator& s, Plaintext& a, PoolArg p) { s.mod_switch_plain_to_next_inplace(a, P(p)); }, py::arg("plain"), POOL);
+    ev.def("mod_switch_plain_to_next_new", [](const Evaluator& s, const Plaintext& a, PoolArg p) { return s.mod_switch_plain_to_next_new(a, P(p)); }, py::arg("plain"), POOL);
+    // Galois, remaining spellings
+    ev.def("apply_galois_inplace", [](const Evaluator& s, Ciphertext& a, size_t g, const GaloisKeys& k, PoolArg p) { s.apply_galois_inplace(a, g, k, P(p)); },
+           py::arg("encrypted"), py::arg("galois_element"), py::arg("galois_keys"), POOL);
+    ev.def("rotate_vector", [](const Evaluator& s, const Ciphertext& a, int st, const GaloisKeys& k, Ciphertext& d, PoolArg p) { s.rotate_vector(a, st, k, d, P(p)); },
+           py::arg("encrypted"), py::arg("steps"), py::arg("galois_keys"), py::arg("destination"), POOL);
+    ev.def("complex_conjugate", [](const Evaluator& s, const Ciphertext& a, const GaloisKeys& k, Ciphertext& d, PoolArg p) { s.complex_conjugate(a, k, d, P(p)); },
+           py::arg("encrypted"), py::arg("galois_keys"), py::arg("destination"), POOL);
+    ev.def("complex_conjugate_inplace", [](const Evaluator& s, Ciphertext& a, const GaloisKeys& k, PoolArg p) { Ciphertext d; s.complex_conjugate(a, k, d, P(p)); a = std::move(d); },
+           py::arg("encrypted"), py::arg("galois_keys"), POOL);
+    // LWE extraction and RLWE packing
+    ev.def("extract_lwe_new", [](const Evaluator& s, const Ciphertext& a, size_t term, PoolArg p) { return s.extract_lwe_new(a, term, P(p)); }, py::arg("encrypted"), py::arg("term"), POOL);
+    ev.def("assemble_lwe_new", [](const Evaluator& s, const LWECiphertext& l, PoolArg p) { return s.assemble_lwe_new(l, P(p)); }, py::arg("lwe_encrypted"), POOL);
+    ev.def("field_trace_inplace", [](const Evaluator& s, Ciphertext& a, const GaloisKeys& k, size_t logn, PoolArg p) { s.field_trace_inplace(a, k, logn, P(p)); },
+           py::arg("encrypted"), py::arg("automorphism_keys"), py::arg("logn"), POOL);
+    ev.def("divide_by_poly_modulus_degree_inplace", [](const Evaluator& s, Ciphertext& a, uint64_t mul) { s.divide_by_poly_modulus_degree_inplace(a, mul); },
+           py::arg("encrypted"), py::arg("mul") = 1);
+    ev.def("negacyclic_shift", [](const Evaluator& s, const Ciphertext& a, size_t shift, Ciphertext& d, PoolArg p) { s.negacyclic_shift(a, shift, d, P(p)); },
+           py::arg("encrypted"), py::arg("shift"), py::arg("destination"), POOL);
+    ev.def("negacyclic_shift_inplace", [](const Evaluator& s, Ciphertext& a, size_t shift, PoolArg p) { s.negacyclic_shift_inplace(a, shift, P(p)); }, py::arg("encrypted"), py::arg("shift"), POOL);
+    ev.def("negacyclic_shift_new", [](const Evaluator& s, const Ciphertext& a, size_t shift, PoolArg p) { return s.negacyclic_shift_new(a, shift, P(p)); }, py::arg("encrypted"), py::arg("shift"), POOL);
+    ev.def("pack_lwe_ciphertexts_new", [](const Evaluator& s, const std::vector<LWECiphertext*>& l, const GaloisKeys& k, PoolArg p, bool trace) {
+        return s.pack_lwe_ciphertexts_new(const_ptrs(l), k, P(p), trace); }, py::arg("lwe_encrypted"), py::arg("automorphism_keys"), POOL, py::arg("apply_field_trace") = true);
+    ev.def("pack_lwe_ciphertexts_new_batched", [](const Evaluator& s, const std::vector<std::vector<LWECiphertext*>>& groups, const GaloisKeys& k, PoolArg p, bool trace) {
+        std::vector<std::vector<const LWECiphertext*>> g;
+        for (const auto& grp : groups) g.push_back(const_ptrs(grp));
+        return s.pack_lwe_ciphertexts_new_batched(g, k, P(p), trace); }, py::arg("lwe_groups"), py::arg("automorphism_keys"), POOL, py::arg("apply_field_trace") = true);
+    ev.def("pack_rlwe_ciphertexts_new", [](const Evaluator& s, const std::vector<Ciphertext*>& c, const GaloisKeys& k, size_t shift, size_t in_iv, size_t out_iv, PoolArg p, bool trace) {
+        return s.pack_rlwe_ciphertexts_new(const_ptrs(c), k, shift, in_iv, out_iv, P(p), trace); },
+        py::arg("ciphers"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
+    ev.def("pack_rlwe_ciphertexts_new_batched", [](const Evaluator& s, const std::vector<std::vector<Ciphertext*>>& groups, const GaloisKeys& k, size_t shift, size_t in_iv, size_t out_iv,
+                                                   PoolArg p, bool trace) {
+        std::vector<std::vector<const Ciphertext*>> g;
+        for (const auto& grp : groups) g.push_back(const_ptrs(grp));
+        return s.pack_rlwe_ciphertexts_new_batched(g, k, shift, in_iv, out_iv, P(p), trace); },
+        py::arg("cipher_groups"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
 }

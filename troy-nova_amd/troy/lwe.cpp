@@ -235,6 +235,46 @@ void Evaluator::field_trace_inplace_batched(const std::vector<Ciphertext*>& encr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Evaluator: rescale_to, plaintext modulus switching  (evaluator_modswitch.cu:279-316, :402-443, :463-472)
+// ------------------------------------------------------------------------------------------------
+void Evaluator::rescale_to(const Ciphertext& encrypted, const ParmsID& parms_id, Ciphertext& destination, MemoryPoolHandle pool) const {
+    ContextDataPointer cd = level("[Evaluator::rescale_to]", context_, encrypted.parms_id());
+    ContextDataPointer target = level("[Evaluator::rescale_to]", context_, parms_id);
+    if (cd->chain_index() < target->chain_index()) throw std::invalid_argument("[Evaluator::rescale_to] Cannot rescale to a higher level.");
+    Ciphertext cur = encrypted.clone(pool);
+    while (cur.parms_id() != parms_id) { Ciphertext next; rescale_to_next(cur, next, pool); cur = std::move(next); }
+    destination = std::move(cur);
+}
+
+void Evaluator::mod_switch_plain_to(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::mod_switch_plain_to_inplace]";
+    if (!plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is not in NTT form.");
+    if (!plain.on_device() || !context_->on_device()) throw std::invalid_argument(std::string(P) + " Operands must be on the device (the evaluator runs on the GPU only).");
+    ContextDataPointer cd = level(P, context_, plain.parms_id());
+    ContextDataPointer target = level(P, context_, parms_id);
+    if (cd->chain_index() < target->chain_index()) throw std::invalid_argument(std::string(P) + " Cannot switch to a higher level.");
+    if (plain.parms_id() == parms_id) { destination = plain.clone(pool); return; }
+    // kernel_mod_switch_drop_to with one polynomial: the first L_out limbs are kept
+    const uint32_t L_in = static_cast<uint32_t>(cd->parms().coeff_modulus().size()), L_out = static_cast<uint32_t>(target->parms().coeff_modulus().size());
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, parms_id);
+    troyn_check_public(troyn_mod_switch_drop(context_->plan(), L_in, L_out, plain.poly(), 1, out.poly(), 1, stream()));
+    troyn_sync_current_stream();
+    out.is_ntt_form() = true;
+    out.scale() = plain.scale();
+    destination = std::move(out);
+}
+
+void Evaluator::mod_switch_plain_to_next(const Plaintext& plain, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::mod_switch_plain_to_next]";
+    if (context_->last_parms_id() == plain.parms_id()) throw std::invalid_argument(std::string(P) + " End of modulus switching chain reached.");
+    ContextDataPointer cd = level(P, context_, plain.parms_id());
+    if (!cd->next_context_data().has_value()) throw std::invalid_argument("[Evaluator::mod_switch_drop_to_plain_internal] Next context data is not set.");
+    mod_switch_plain_to(plain, cd->next_context_data().value()->parms_id(), destination, pool);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Evaluator: RLWE packing  (evaluator_lwes.cu:200-681)
 // ------------------------------------------------------------------------------------------------
 Ciphertext Evaluator::pack_lwe_ciphertexts_new(const std::vector<const LWECiphertext*>& lwes, const GaloisKeys& automorphism_keys, MemoryPoolHandle pool,
@@ -252,6 +292,38 @@ Ciphertext Evaluator::pack_lwe_ciphertexts_new(const std::vector<const LWECipher
     std::vector<const Ciphertext*> ptrs;
     for (const Ciphertext& c : rlwes) ptrs.push_back(&c);
     return pack_rlwe_ciphertexts_new(ptrs, automorphism_keys, 0, n, n >> l, pool, apply_field_trace);
+}
+
+std::vector<Ciphertext> Evaluator::pack_lwe_ciphertexts_new_batched(const std::vector<std::vector<const LWECiphertext*>>& lwe_groups, const GaloisKeys& automorphism_keys,
+                                                                    MemoryPoolHandle pool, bool apply_field_trace) const {
+    // evaluator_lwes.cu:232-300: every group goes through the packing tree together; the tree depth is set by the largest group
+    const char* P = "[Evaluator::pack_lwe_ciphertexts_new]";
+    std::vector<Ciphertext> out(lwe_groups.size());
+    if (lwe_groups.empty()) return out;
+    size_t max_count = 0;
+    std::vector<const LWECiphertext*> flat;
+    for (const auto& group : lwe_groups) {
+        if (group.empty()) throw std::invalid_argument(std::string(P) + " LWE ciphertexts must not be empty.");
+        max_count = std::max(max_count, group.size());
+        for (const LWECiphertext* l : group) {
+            if (l->parms_id() != lwe_groups[0][0]->parms_id()) throw std::invalid_argument(std::string(P) + " LWE ciphertexts must have same parms id.");
+            flat.push_back(l);
+        }
+    }
+    ContextDataPointer cd = level(P, context_, lwe_groups[0][0]->parms_id());
+    const size_t n = cd->parms().poly_modulus_degree();
+    if (max_count > n) throw std::invalid_argument(std::string(P) + " LWE ciphertexts count must be less than poly_modulus_degree.");
+    size_t l = 0;
+    while ((static_cast<size_t>(1) << l) < max_count) l++;
+    std::vector<Ciphertext> rlwes = LWECiphertext::assemble_lwe_batched_new(flat, pool);
+    std::vector<std::vector<const Ciphertext*>> groups(lwe_groups.size());
+    size_t k = 0;
+    for (size_t i = 0; i < lwe_groups.size(); i++)
+        for (size_t j = 0; j < lwe_groups[i].size(); j++) groups[i].push_back(&rlwes[k++]);
+    std::vector<Ciphertext*> ptrs;
+    for (Ciphertext& c : out) ptrs.push_back(&c);
+    pack_rlwe_ciphertexts_batched(groups, automorphism_keys, 0, n, n >> l, ptrs, pool, apply_field_trace);
+    return out;
 }
 
 Ciphertext Evaluator::pack_rlwe_ciphertexts_new(const std::vector<const Ciphertext*>& ciphers, const GaloisKeys& automorphism_keys, size_t shift, size_t input_interval,

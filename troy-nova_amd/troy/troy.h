@@ -807,6 +807,8 @@ public:
     void negacyclic_shift_inplace(Ciphertext& encrypted, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; negacyclic_shift(encrypted, shift, d, pool); encrypted = std::move(d); }
     Ciphertext pack_lwe_ciphertexts_new(const std::vector<const LWECiphertext*>& lwes, const GaloisKeys& automorphism_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
                                         bool apply_field_trace = true) const;
+    std::vector<Ciphertext> pack_lwe_ciphertexts_new_batched(const std::vector<std::vector<const LWECiphertext*>>& lwe_groups, const GaloisKeys& automorphism_keys,
+                                                             MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const;
     Ciphertext pack_rlwe_ciphertexts_new(const std::vector<const Ciphertext*>& ciphers, const GaloisKeys& automorphism_keys, size_t shift, size_t input_interval,
                                          size_t output_interval, MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const;
     // every group's packing tree advances together: one fused layer kernel and one batched key switch per layer
@@ -834,6 +836,16 @@ public:
     void rescale_to_next(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void rescale_to_next_inplace(Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to_next(encrypted, d, pool); encrypted = std::move(d); }
     Ciphertext rescale_to_next_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to_next(encrypted, d, pool); return d; }
+    void rescale_to(const Ciphertext& encrypted, const ParmsID& parms_id, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rescale_to_inplace(Ciphertext& encrypted, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to(encrypted, parms_id, d, pool); encrypted = std::move(d); }
+    Ciphertext rescale_to_new(const Ciphertext& encrypted, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; rescale_to(encrypted, parms_id, d, pool); return d; }
+    // NTT-form (CKKS) plaintexts follow the ciphertexts down the chain -- evaluator_modswitch.cu:279-316,:402-443
+    void mod_switch_plain_to(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_plain_to_inplace(Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; mod_switch_plain_to(plain, parms_id, d, pool); plain = std::move(d); }
+    Plaintext mod_switch_plain_to_new(const Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; mod_switch_plain_to(plain, parms_id, d, pool); return d; }
+    void mod_switch_plain_to_next(const Plaintext& plain, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_plain_to_next_inplace(Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; mod_switch_plain_to_next(plain, d, pool); plain = std::move(d); }
+    Plaintext mod_switch_plain_to_next_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; mod_switch_plain_to_next(plain, d, pool); return d; }
     void rescale_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition
 
     // NTT -- evaluator.h:655-700 (evaluator_transform_ntt.cu:469-652)
