@@ -211,6 +211,37 @@ int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, u
  * the permuted c1 with TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST (evaluator_keyswitching.cu:147-179). */
 int troyn_apply_galois(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
                        const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream);
+/* ---------------------------------------------------------------------------------------
+ * BGV.  BGV ciphertexts live in NTT form and reuse troyn_ntt, troyn_dyadic_convolute (bgv_multiply,
+ * evaluator.cu:150-173), troyn_add/sub/negate/multiply_scalar, troyn_apply_galois and troyn_plain_centralize unchanged; the
+ * entries below are the steps where BGV differs.  troyn_bgv holds the constants of ONE level's RNSTool that only BGV reads
+ * (utils/rns_tool.cu:205-232): the converter q -> {t}, q_last^-1 mod t.
+ *   troyn_bgv_mod_t_and_divide_q_last_ntt  RNSTool::mod_t_and_divide_q_last_ntt (utils/rns_tool.cu:1540-1772):
+ *                                   in [batch][pcount][L][N] NTT -> out [batch][pcount][L-1][N] NTT; the caller multiplies
+ *                                   the correction factor by troyn_bgv_inv_q_last_mod_t (evaluator_modswitch.cu:70-72)
+ *   troyn_bgv_decrypt_mod_t         scaling_variant::decentralize (utils/scaling_variant.cu:415-431) = BaseConverter::
+ *                                   exact_convey_array (utils/rns_base.cu:445-598, double-precision vote summed in limb
+ *                                   order) then * correction_factor^-1 mod t: phase [batch][L][N] coefficient form -> [batch][N]
+ *   troyn_bgv_multiply_scalar_mod_t utils::multiply_scalar on mod-t plaintext words (evaluator_translate_plain.cu:80-82)
+ *   troyn_bgv_switch_key / _relinearize  switch_key_internal / relinearize_internal with the ski_util5 tail
+ *                                   (evaluator_keyswitching_core.cu:436-538, :998-1030); `key_level` must be created with
+ *                                   L = the plan's modulus count (its last prime is the special prime).  Shapes and
+ *                                   workspace as troyn_switch_key / troyn_relinearize, NTT-form operands.
+ * ------------------------------------------------------------------------------------- */
+typedef struct troyn_bgv troyn_bgv;
+int troyn_bgv_create(troyn_bgv** out, const troyn_plan* plan, uint32_t L, uint64_t plain_modulus);
+int troyn_bgv_destroy(troyn_bgv* bgv);
+uint64_t troyn_bgv_inv_q_last_mod_t(const troyn_bgv* bgv);
+size_t troyn_bgv_mod_switch_workspace_bytes(const troyn_bgv* bgv, size_t pcount, size_t batch);
+int troyn_bgv_mod_t_and_divide_q_last_ntt(const troyn_bgv* bgv, const uint64_t* in, size_t pcount, uint64_t* out, void* workspace, size_t workspace_bytes,
+                                          size_t batch, troyn_stream_t stream);
+int troyn_bgv_decrypt_mod_t(const troyn_bgv* bgv, const uint64_t* phase, uint64_t correction_factor, uint64_t* dest, size_t batch, troyn_stream_t stream);
+int troyn_bgv_multiply_scalar_mod_t(const troyn_bgv* bgv, const uint64_t* in, uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_bgv_switch_key(const troyn_bgv* key_level, uint32_t L, const uint64_t* target, const uint64_t* const* keys, int assign_method,
+                         uint64_t* destination, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream);
+int troyn_bgv_relinearize(const troyn_bgv* key_level, uint32_t L, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2, void* workspace,
+                          size_t workspace_bytes, size_t batch, troyn_stream_t stream);
+
 /* RLWE / LWE packing (evaluator_lwes.cu):
  *   troyn_negacyclic_shift     utils::negacyclic_shift_ps (utils/poly_small_mod.cu:927-968): multiply `count` RNS polynomials by
  *                              X^shift, shift in [0, 2N); out of place

@@ -132,6 +132,11 @@ def lib():
     sig("orc_fnv_words", u64, p64, sz)
     sig("orc_apply_galois", None, vp, sz, C.c_int, sz, p64, sz, p64)
     sig("orc_apply_galois_ct", None, vp, sz, C.c_int, sz, p64, C.POINTER(p64), p64)
+    sig("orc_rns_mod_t_and_divide_q_last_ntt", None, vp, sz, p64, sz, p64)
+    sig("orc_bgv_inv_q_last_mod_t", u64, vp, sz)
+    sig("orc_rns_decrypt_mod_t", C.c_int, vp, sz, p64, p64)
+    sig("orc_decrypt_bgv", C.c_int, vp, p64, p64, sz, sz, u64, p64)
+    sig("orc_encrypt_asymmetric_bgv", C.c_int, vp, vp, p64, p64, sz, p64)
     sig("orc_negacyclic_shift", None, vp, sz, p64, sz, sz, p64)
     sig("orc_multiply_inv_degree", None, vp, sz, p64, sz, u64)
     sig("orc_extract_lwe", None, vp, sz, p64, sz, p64, p64)
@@ -453,6 +458,39 @@ class Context:
         out = np.zeros(2 * (self.K - 1) * self.n, dtype=np.uint64)
         lib().orc_encrypt_asymmetric_bfv(self.h, rng.h, ptr(np.ascontiguousarray(pk).reshape(-1)), ptr(plain), plain.size, ptr(out))
         return out.reshape(2, self.K - 1, self.n)
+
+    # -- BGV (NTT-form ciphertexts; the correction factor is carried by the caller) ----------------------
+    def encrypt_asymmetric_bgv(self, rng, pk, plain):
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros(2 * (self.K - 1) * self.n, dtype=np.uint64)
+        if lib().orc_encrypt_asymmetric_bgv(self.h, rng.h, ptr(np.ascontiguousarray(pk).reshape(-1)), ptr(plain), plain.size, ptr(out)) != 0:
+            raise ValueError("encrypt failed")
+        return out.reshape(2, self.K - 1, self.n)
+
+    def decrypt_bgv(self, sk, ct, correction_factor=1):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        pcount, L = ct.shape[0], ct.shape[1]
+        plain = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_decrypt_bgv(self.h, ptr(np.ascontiguousarray(sk).reshape(-1)), ptr(ct.reshape(-1)), pcount, L, int(correction_factor), ptr(plain)) != 0:
+            raise ValueError("decrypt failed")
+        return plain
+
+    def decrypt_mod_t(self, L, phase):
+        phase = np.ascontiguousarray(phase, dtype=np.uint64)
+        out = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_rns_decrypt_mod_t(self.h, L, ptr(phase.reshape(-1)), ptr(out)) != 0:
+            raise ValueError("no plain modulus")
+        return out
+
+    def mod_t_and_divide_q_last_ntt(self, L, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        p = ct.size // (L * self.n)
+        out = np.zeros(p * (L - 1) * self.n, dtype=np.uint64)
+        lib().orc_rns_mod_t_and_divide_q_last_ntt(self.h, L, ptr(ct.reshape(-1)), p, ptr(out))
+        return out.reshape(p, L - 1, self.n)
+
+    def bgv_inv_q_last_mod_t(self, L):
+        return int(lib().orc_bgv_inv_q_last_mod_t(self.h, L))
 
     def relin_keys(self, rng, sk):
         """list of K-1 keys u64[2][K][N] (KeyGenerator::create_relin_keys)"""

@@ -12,6 +12,7 @@
  */
 #include "troy_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -617,6 +618,10 @@ struct orc_rns_tool {
     orc_mulop* inv_q_last_mod_q;      /* [q-1] */
     uint64_t q_last_half;
     orc_ntt_tables** Bsk_ntt_tables;  /* [Bsk] (NULL when the ring degree is not NTT-friendly) */
+    /* BGV (utils/rns_tool.cu:205-232): base converter q -> {t}, q_last^-1 mod t, q_last mod t; valid when t != 0 */
+    int has_t;
+    base_converter q_to_t;
+    uint64_t inv_q_last_mod_t, q_last_mod_t;
 };
 
 static size_t bigmul_bits(const uint64_t* v, size_t n) {
@@ -708,6 +713,16 @@ orc_rns_tool* orc_rns_tool_create(size_t poly_modulus_degree, const uint64_t* q,
         }
     }
     r->q_last_half = q[q_size - 1] >> 1;
+    r->inv_q_last_mod_t = 1; r->q_last_mod_t = 1;
+    if (t_value != 0) {
+        /* :205-232 */
+        if (base_converter_init(&r->q_to_t, q, q_size, &t_value, 1) != 0) { orc_rns_tool_destroy(r); return NULL; }
+        r->has_t = 1;
+        uint64_t inv = 0;
+        /* a plain modulus that shares a factor with q_last has no BGV mod-switch; BFV contexts never read these */
+        if (orc_try_invert_mod(orc_barrett_reduce64(q[q_size - 1], &r->t), &r->t, &inv)) r->inv_q_last_mod_t = inv;
+        r->q_last_mod_t = orc_barrett_reduce64(q[q_size - 1], &r->t);
+    }
     /* Bsk NTT tables :97-101 (all Bsk primes are = 1 mod 2N by construction) */
     r->Bsk_ntt_tables = (orc_ntt_tables**)calloc(base_Bsk_size, sizeof(orc_ntt_tables*));
     for (size_t i = 0; i < base_Bsk_size; i++) {
@@ -722,6 +737,7 @@ void orc_rns_tool_destroy(orc_rns_tool* r) {
     rns_base_free(&r->base_q); rns_base_free(&r->base_B); rns_base_free(&r->base_Bsk);
     base_converter_free(&r->q_to_Bsk); base_converter_free(&r->q_to_m_tilde);
     base_converter_free(&r->B_to_q); base_converter_free(&r->B_to_m_sk);
+    if (r->has_t) base_converter_free(&r->q_to_t);
     free(r->prod_B_mod_q); free(r->inv_prod_q_mod_Bsk); free(r->inv_m_tilde_mod_Bsk);
     free(r->prod_q_mod_Bsk); free(r->inv_q_last_mod_q);
     if (r->Bsk_ntt_tables) {
@@ -963,7 +979,7 @@ void orc_transform_from_ntt(const orc_context* c, uint64_t* ct, size_t pcount, s
 void orc_switch_key(const orc_context* c, size_t L, int is_ntt_form, const uint64_t* target,
                     const uint64_t* const* keys, int assign_method, uint64_t* destination) {
     /* evaluator_keyswitching_core.cu:757-1052, HOST branches (:833-902 and :923-985);
-     * BGV (ski_util5) is not restated. */
+     * BGV ciphertexts are always in NTT form (ski_util5 tail below). */
     const size_t coeff_count = c->n, log_n = c->log_n;
     const size_t decomp_modulus_size = L;
     const orc_modulus* key_modulus = c->key_modulus;
@@ -1048,6 +1064,35 @@ void orc_switch_key(const orc_context* c, size_t L, int is_ntt_form, const uint6
         int add_inplace = (assign_method == ORC_ASSIGN_ADD_INPLACE) || (i == 0 && assign_method == ORC_ASSIGN_OVERWRITE_EXCEPT_FIRST);
         uint64_t* t_last = poly_prod + coeff_count * rns_modulus_size * i + decomp_modulus_size * coeff_count;
         orc_ntt_inverse(t_last, 1, 1, log_n, &key_ntt_tables[key_modulus_size - 1], 1, ORC_IDX_COMPONENTWISE, 0);
+        if (c->scheme == ORC_SCHEME_BGV) {
+            /* ski_util5 host branch :286-318: k = -t_last * qk^-1 mod t; delta_j = (k mod q_j) * qk + t_last mod q_j; NTT;
+             * (prod_j - delta_j) * qk^-1 mod q_j */
+            const orc_modulus* pm = &c->rns_tools[c->K]->t;
+            const uint64_t qk_inv_qp = c->rns_tools[c->K]->inv_q_last_mod_t;
+            uint64_t* kk = (uint64_t*)malloc(coeff_count * sizeof(uint64_t));
+            uint64_t* delta = (uint64_t*)malloc(coeff_count * sizeof(uint64_t));
+            for (size_t x = 0; x < coeff_count; x++) {
+                uint64_t v = orc_negate_mod(orc_barrett_reduce64(t_last[x], pm), pm);
+                kk[x] = (qk_inv_qp != 1) ? orc_multiply_mod(v, qk_inv_qp, pm) : v;
+            }
+            uint64_t* prod_i = poly_prod + i * coeff_count * rns_modulus_size;
+            uint64_t* dest_i = destination + i * decomp_modulus_size * coeff_count;
+            for (size_t j = 0; j < decomp_modulus_size; j++) {
+                const orc_modulus* qj = &key_modulus[j];
+                for (size_t x = 0; x < coeff_count; x++) {
+                    uint64_t d = orc_multiply_mod(orc_barrett_reduce64(kk[x], qj), qk->value, qj);
+                    delta[x] = orc_add_mod(d, orc_barrett_reduce64(t_last[x], qj), qj);
+                }
+                orc_ntt_forward(delta, 1, 1, log_n, &key_ntt_tables[j], 1, ORC_IDX_COMPONENTWISE, 0);
+                for (size_t x = 0; x < coeff_count; x++) {
+                    uint64_t v = orc_sub_mod(prod_i[j * coeff_count + x], delta[x], qj);
+                    v = orc_mulop_mod(v, &modswitch_factors[j], qj);
+                    dest_i[j * coeff_count + x] = add_inplace ? orc_add_mod(dest_i[j * coeff_count + x], v, qj) : v;
+                }
+            }
+            free(kk); free(delta);
+            continue;
+        }
         /* ski_util6 :367-385 */
         uint64_t qk_half = qk->value >> 1;
         for (size_t x = 0; x < coeff_count; x++) {
@@ -1129,6 +1174,8 @@ void orc_mod_switch_scale_to_next(const orc_context* c, size_t L, const uint64_t
     const orc_rns_tool* rt = c->rns_tools[L];
     if (c->scheme == ORC_SCHEME_CKKS) {
         orc_rns_divide_and_round_q_last_ntt(rt, in, pcount, out, (const orc_ntt_tables* const*)c->ntt_tables);
+    } else if (c->scheme == ORC_SCHEME_BGV) {
+        orc_rns_mod_t_and_divide_q_last_ntt(c, L, in, pcount, out);
     } else {
         orc_rns_divide_and_round_q_last(rt, in, pcount, out);
     }
@@ -1308,6 +1355,7 @@ static void symmetric_zero_ntt(const orc_context* c, orc_rng* rng, const uint64_
     orc_sample_poly_centered_binomial(rng, noise, n, c->key_modulus, K);
     orc_dyadic_product_ps(sk, c1, 1, n, c->key_modulus, K, c0);
     orc_ntt_forward(noise, 1, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+    if (c->scheme == ORC_SCHEME_BGV) orc_multiply_scalar_ps(noise, c->plain_modulus, 1, n, c->key_modulus, K, noise);   /* -(as + t e), rlwe.cu:300-304 */
     orc_add_ps(c0, noise, 1, n, c->key_modulus, K, c0);
     orc_negate_ps(c0, 1, n, c->key_modulus, K, c0);
     free(noise);
@@ -1598,6 +1646,127 @@ void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* s
             key[i * n + x] = orc_add_mod(key[i * n + x], orc_multiply_mod(rot[i * n + x], factor, qi), qi);
     }
     free(rot);
+}
+
+/* ---- BGV ---- */
+void orc_rns_mod_t_and_divide_q_last_ntt(const orc_context* c, size_t nl, const uint64_t* input, size_t pcount, uint64_t* dest) {
+    /* RNSTool::mod_t_and_divide_q_last_ntt, host branch (utils/rns_tool.cu:1540-1590, :1746-1772): input [pcount][nl][N]
+     * NTT form at the level with nl limbs -> dest [pcount][nl-1][N] NTT form */
+    const orc_rns_tool* r = c->rns_tools[nl];
+    const size_t n = c->n;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    const orc_modulus* pm = &r->t;
+    const uint64_t last_q = c->key_modulus[nl - 1].value;
+    uint64_t* c_last = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint64_t* neg = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint64_t* delta = (uint64_t*)malloc(n * sizeof(uint64_t));
+    for (size_t p = 0; p < pcount; p++) {
+        memcpy(c_last, input + (p * nl + nl - 1) * n, n * sizeof(uint64_t));
+        orc_ntt_inverse(c_last, 1, 1, c->log_n, &tb[nl - 1], 1, ORC_IDX_COMPONENTWISE, 0);
+        for (size_t x = 0; x < n; x++) {
+            uint64_t v = orc_negate_mod(orc_barrett_reduce64(c_last[x], pm), pm);
+            neg[x] = (r->inv_q_last_mod_t != 1) ? orc_multiply_mod(v, r->inv_q_last_mod_t, pm) : v;
+        }
+        for (size_t i = 0; i + 1 < nl; i++) {
+            const orc_modulus* qi = &c->key_modulus[i];
+            for (size_t x = 0; x < n; x++) {
+                uint64_t d = orc_multiply_mod(orc_barrett_reduce64(neg[x], qi), last_q, qi);
+                delta[x] = orc_add_mod(d, orc_barrett_reduce64(c_last[x], qi), qi);
+            }
+            orc_ntt_forward(delta, 1, 1, c->log_n, &tb[i], 1, ORC_IDX_COMPONENTWISE, 0);
+            for (size_t x = 0; x < n; x++) {
+                uint64_t v = orc_sub_mod(input[(p * nl + i) * n + x], delta[x], qi);
+                dest[(p * (nl - 1) + i) * n + x] = orc_mulop_mod(v, &r->inv_q_last_mod_q[i], qi);
+            }
+        }
+    }
+    free(c_last); free(neg); free(delta);
+}
+
+uint64_t orc_bgv_inv_q_last_mod_t(const orc_context* c, size_t nl) { return c->rns_tools[nl]->inv_q_last_mod_t; }
+
+int orc_rns_decrypt_mod_t(const orc_context* c, size_t nl, const uint64_t* phase, uint64_t* dest) {
+    /* BaseConverter::exact_convey_array q -> {t} (utils/rns_base.cu:445-465, :510-529): phase [nl][N] coefficient form */
+    const orc_rns_tool* r = c->rns_tools[nl];
+    if (!r->has_t) return -1;
+    const size_t n = c->n, ni = nl;
+    const rns_base* ib = &r->q_to_t.ibase;
+    const orc_modulus* pm = &r->q_to_t.obase.base[0];
+    uint64_t qv[64];
+    for (size_t i = 0; i < ni; i++) qv[i] = ib->base[i].value;
+    uint64_t big[65];
+    size_t len = big_product(qv, ni, big);
+    const uint64_t q_mod_p = big_mod_small(big, len, pm->value);
+    uint64_t* temp = (uint64_t*)malloc(ni * sizeof(uint64_t));
+    for (size_t j = 0; j < n; j++) {
+        double aggregated_v = 0;
+        for (size_t i = 0; i < ni; i++) {
+            const orc_mulop* op = &ib->inv_punctured_product_mod_base[i];
+            temp[i] = (op->operand == 1) ? orc_barrett_reduce64(phase[i * n + j], &ib->base[i]) : orc_mulop_mod(phase[i * n + j], op, &ib->base[i]);
+            aggregated_v += (double)temp[i] / (double)ib->base[i].value;
+        }
+        uint64_t rounded = (uint64_t)round(aggregated_v);
+        uint64_t sum = orc_dot_product_mod(temp, r->q_to_t.base_change_matrix, ni, pm);
+        dest[j] = orc_sub_mod(sum, orc_multiply_mod(rounded, q_mod_p, pm), pm);
+    }
+    free(temp);
+    return 0;
+}
+
+int orc_decrypt_bgv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t correction_factor, uint64_t* plain) {
+    /* Decryptor::bgv_decrypt (decryptor.cu:509-539): NTT-form dot product with the powers of s, INTT, decrypt_mod_t,
+     * times correction_factor^-1 mod t (scaling_variant::decentralize, utils/scaling_variant.cu:415-431) */
+    const size_t n = c->n, K = c->K;
+    if (pcount < 2 || L < 1 || L > K) return -1;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t* spow = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    uint64_t* term = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    uint64_t* acc = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    memcpy(acc, ct, L * n * sizeof(uint64_t));
+    memcpy(spow, sk, K * n * sizeof(uint64_t));
+    for (size_t i = 1; i < pcount; i++) {
+        orc_dyadic_product_ps(ct + i * L * n, spow, 1, n, c->key_modulus, L, term);
+        orc_add_ps(acc, term, 1, n, c->key_modulus, L, acc);
+        if (i + 1 < pcount) orc_dyadic_product_ps(spow, sk, 1, n, c->key_modulus, K, spow);
+    }
+    orc_ntt_inverse(acc, 1, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+    int rc = orc_rns_decrypt_mod_t(c, L, acc, plain);
+    if (rc == 0 && correction_factor != 1) {
+        const orc_modulus* pm = &c->rns_tools[L]->t;
+        uint64_t fix = 1;
+        if (!orc_try_invert_mod(correction_factor, pm, &fix)) rc = -2;
+        else for (size_t x = 0; x < n; x++) plain[x] = orc_multiply_mod(plain[x], fix, pm);
+    }
+    free(spow); free(term); free(acc);
+    return rc;
+}
+
+int orc_encrypt_asymmetric_bgv(const orc_context* c, orc_rng* rng, const uint64_t* pk, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out) {
+    /* Encryptor::encrypt_internal BGV (encryptor.cu:300-333): zero encryption in NTT form at the key level (utils/rlwe.cu:
+     * 11-91, noise times t), mod_t_and_divide_q_last_ntt down to the first data level (encryptor.cu:79-84), then the
+     * centralized plaintext in NTT form is added to c0.  out [2][L][N] NTT form, correction factor 1. */
+    const size_t n = c->n, K = c->K, L = K - 1;
+    const orc_ntt_tables* const* tb = (const orc_ntt_tables* const*)c->ntt_tables;
+    uint64_t* temp = (uint64_t*)malloc(2 * K * n * sizeof(uint64_t));
+    uint64_t* u = (uint64_t*)malloc(K * n * sizeof(uint64_t));
+    orc_sample_poly_ternary(rng, u, n, c->key_modulus, K);
+    orc_ntt_forward(u, 1, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+    for (size_t j = 0; j < 2; j++) orc_dyadic_product_ps(u, pk + j * K * n, 1, n, c->key_modulus, K, temp + j * K * n);
+    for (size_t j = 0; j < 2; j++) {
+        orc_sample_poly_centered_binomial(rng, u, n, c->key_modulus, K);
+        orc_ntt_forward(u, 1, K, c->log_n, tb, K, ORC_IDX_COMPONENTWISE, 0);
+        orc_multiply_scalar_ps(u, c->plain_modulus, 1, n, c->key_modulus, K, u);
+        orc_add_ps(temp + j * K * n, u, 1, n, c->key_modulus, K, temp + j * K * n);
+    }
+    orc_rns_mod_t_and_divide_q_last_ntt(c, K, temp, 2, out);
+    uint64_t* m = (uint64_t*)malloc(L * n * sizeof(uint64_t));
+    int rc = orc_plain_centralize(c, L, plain, plain_coeff_count, m);
+    if (rc == 0) {
+        orc_ntt_forward(m, 1, L, c->log_n, tb, L, ORC_IDX_COMPONENTWISE, 0);
+        orc_add_ps(out, m, 1, n, c->key_modulus, L, out);
+    }
+    free(m); free(u); free(temp);
+    return rc;
 }
 
 /* ---- RLWE / LWE packing primitives (evaluator_lwes.cu) ---- */

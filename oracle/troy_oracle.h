@@ -218,6 +218,20 @@ void orc_apply_galois_ct(const orc_context* c, size_t L, int is_ntt_form, size_t
 void orc_keygen_galois_key(const orc_context* c, orc_rng* rng, const uint64_t* sk, size_t galois_element, uint64_t* out);
 /* GaloisTool::get_element_from_step (utils/galois.cu:43-63) */
 size_t orc_galois_element_from_step(size_t n, int step);
+/* ---- BGV.  A context created with ORC_SCHEME_BGV multiplies the key-generation and encryption
+ * noise by t (utils/rlwe.cu:82-86,:300-304) and finishes orc_switch_key with the ski_util5 tail
+ * (evaluator_keyswitching_core.cu:272-318).  BGV ciphertexts are NTT form; multiply = the dyadic product of
+ * orc_ckks_multiply with correction factors multiplied mod t (evaluator.cu:150-173). ----
+ * RNSTool::mod_t_and_divide_q_last_ntt (utils/rns_tool.cu:1540-1590): [pcount][nl][N] -> [pcount][nl-1][N]; the
+ * ciphertext's correction factor is multiplied by orc_bgv_inv_q_last_mod_t (evaluator_modswitch.cu:70-72) */
+void orc_rns_mod_t_and_divide_q_last_ntt(const orc_context* c, size_t nl, const uint64_t* input, size_t pcount, uint64_t* dest);
+uint64_t orc_bgv_inv_q_last_mod_t(const orc_context* c, size_t nl);
+/* RNSTool::decrypt_mod_t = BaseConverter::exact_convey_array (utils/rns_base.cu:445-529): phase [nl][N] -> [N] mod t */
+int orc_rns_decrypt_mod_t(const orc_context* c, size_t nl, const uint64_t* phase, uint64_t* dest);
+/* Decryptor::bgv_decrypt (decryptor.cu:509-539) */
+int orc_decrypt_bgv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t correction_factor, uint64_t* plain);
+/* Encryptor::encrypt_asymmetric for BGV, plaintext mod t (encryptor.cu:300-333): out [2][K-1][N] NTT form */
+int orc_encrypt_asymmetric_bgv(const orc_context* c, orc_rng* rng, const uint64_t* pk, const uint64_t* plain, size_t plain_coeff_count, uint64_t* out);
 /* ---- RLWE / LWE packing primitives (evaluator_lwes.cu) ----
  * utils::negacyclic_shift_ps host branch (utils/poly_small_mod.cu:902-925): data [pcount][nmod][N], shift in [0, 2N) */
 void orc_negacyclic_shift(const orc_context* c, size_t nmod, const uint64_t* in, size_t pcount, size_t shift, uint64_t* out);

@@ -62,6 +62,15 @@ SYMBOLS = {
     "troyn_sample_uniform": (C.c_int, [vp, u32, p64, u64, vp, p64, vp]),
     "troyn_sample_centered_binomial_strided": (C.c_int, [vp, u32, p64, u64, u64, vp, sz, vp]),
     "troyn_sample_uniform_multi": (C.c_int, [vp, u32, p64, vp, sz, vp]),
+    "troyn_bgv_create": (C.c_int, [C.POINTER(vp), vp, u32, u64]),
+    "troyn_bgv_destroy": (C.c_int, [vp]),
+    "troyn_bgv_inv_q_last_mod_t": (u64, [vp]),
+    "troyn_bgv_mod_switch_workspace_bytes": (sz, [vp, sz, sz]),
+    "troyn_bgv_mod_t_and_divide_q_last_ntt": (C.c_int, [vp, vp, sz, vp, vp, sz, sz, vp]),
+    "troyn_bgv_decrypt_mod_t": (C.c_int, [vp, vp, u64, vp, sz, vp]),
+    "troyn_bgv_multiply_scalar_mod_t": (C.c_int, [vp, vp, u64, vp, sz, vp]),
+    "troyn_bgv_switch_key": (C.c_int, [vp, u32, vp, vp, C.c_int, vp, vp, sz, sz, vp]),
+    "troyn_bgv_relinearize": (C.c_int, [vp, u32, vp, vp, vp, vp, sz, sz, vp]),
     "troyn_gather_workspace_bytes": (sz, [sz]),
     "troyn_gather": (C.c_int, [vp, sz, sz, vp, vp, sz, vp]),
     "troyn_negacyclic_shift": (C.c_int, [vp, u32, u32, vp, vp, sz, sz, vp]),

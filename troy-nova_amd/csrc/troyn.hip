@@ -14,6 +14,7 @@
 #include "../../include/troyn.h"
 #include "behz_kernels.hpp"
 #include "crypto_kernels.hpp"
+#include "bgv_kernels.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
 #include "poly_kernels.hpp"
@@ -494,11 +495,14 @@ extern "C" size_t troyn_relinearize_workspace_bytes(const troyn_plan* plan, uint
     return troyn_switch_key_workspace_bytes(plan, L, batch);
 }
 
+// BGV divides by the special prime with a correction computed mod t (ski_util5); everything before the tail is shared.
+struct BgvTail { DevModulus t; u64 inv_special_mod_t; };
+
 // target: [batch] items of L limbs, `target_bstride` elements apart.
 static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_ntt_form,
                            const u64* target, size_t target_bstride, const uint64_t* const* keys, int assign_method,
                            u64* dest, const u64* addend, size_t addend_bstride,
-                           void* workspace, size_t workspace_bytes, size_t batch, hipStream_t s) {
+                           void* workspace, size_t workspace_bytes, size_t batch, hipStream_t s, const BgvTail* bgv = nullptr) {
     const unsigned K = p->K, n = p->n;
     if (K < 2) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
     if (L < 1 || L > K - 1) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] Invalid target size.");
@@ -518,7 +522,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     const u64* digits_src = target;
     size_t digits_bstride = target_bstride;
     // the optimised NTT kernels carry fused prologues / epilogues; tiny rings (generic kernel) use the unfused chain
-    const bool fused = is_ntt_form && p->log_n >= 10;
+    const bool fused = is_ntt_form && p->log_n >= 10 && !bgv;
 
     // (1) NTT form: bring the target back to coefficient form (evaluator_keyswitching_core.cu:817-821)
     if (is_ntt_form) {
@@ -607,7 +611,15 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     // (5) rounding fix of the special-prime component, per data limb (:570-598).  In NTT form the result goes to
     //     the unused tail of the prod_intt region so that step (6) can transform out of place.
     u64* util6_out = is_ntt_form ? ws + w.prod_intt + batch * 2 * (size_t)n : ws + w.temp_last;
-    {
+    if (bgv) {
+        // kernel_ski_util5_merged_step1 (:436-476): delta_j = (k mod q_j) * q_special + c mod q_j, k = -c * q_special^-1 mod t
+        const unsigned ch = chunks_single(n);
+        const size_t rows = batch * 2 * L;
+        if ((rc = check_rows(rows, ch))) return rc;
+        hipLaunchKernelGGL(bgv_delta_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, L, n, bgv->t, bgv->inv_special_mod_t, p->moduli[K - 1], last_src, last_stride, util6_out);
+        LAUNCH_CHECK();
+    } else {
         const unsigned ch = chunks_pairs(n);
         const size_t rows = batch * 2 * L;
         if ((rc = check_rows(rows, ch))) return rc;
@@ -620,8 +632,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         NttArgs a = contiguous_args(p, util6_out, ws + w.temp_last, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
         if ((rc = launch_ntt(p, a, batch, false, s))) return rc;
     }
-    // (7) divide by the special prime and assign (:625-658)
-    {
+    // (7) divide by the special prime and assign (:625-658; BGV: kernel_ski_util5_merged_step2 :506-538)
+    if (bgv) {
+        const unsigned ch = chunks_single(n);
+        const size_t rows = batch * 2 * L;
+        hipLaunchKernelGGL(bgv_finish_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, L, L + 1, n, prod_for_util7, ws + w.temp_last, p->d_inv_last + (size_t)K * K, assign_method, dest, addend, addend_bstride);
+        LAUNCH_CHECK();
+    } else {
         const unsigned ch = chunks_pairs(n);
         const size_t rows = batch * 2 * L;
         hipLaunchKernelGGL(ks_util7_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
@@ -730,6 +748,150 @@ extern "C" int troyn_mod_switch_drop(const troyn_plan* p, uint32_t L_in, uint32_
                        ch, p->n, (const u64*)in, (size_t)L_in * p->n, 0u, (u64*)out, (size_t)L_out * p->n, L_out);
     LAUNCH_CHECK();
     return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BGV: constants of one level's RNSTool that only BGV reads (utils/rns_tool.cu:205-232)
+// ---------------------------------------------------------------------------------------
+struct troyn_bgv {
+    const troyn_plan* plan = nullptr;
+    unsigned L = 0;
+    u64 t = 0, inv_q_last_mod_t = 1, q_mod_t = 0;
+    DevModulus t_mod;
+    u64* d_consts = nullptr;            // [L] Shoup pairs (q/q_i)^-1 mod q_i, then [L] (q/q_i) mod t
+    bool can_divide = false;            // q_last invertible mod t
+};
+
+extern "C" int troyn_bgv_destroy(troyn_bgv* b) {
+    if (!b) return TROYN_OK;
+    if (b->d_consts) (void)hipFree(b->d_consts);
+    delete b;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_bgv_create(troyn_bgv** out, const troyn_plan* plan, uint32_t L, uint64_t t) {
+    if (!out || !plan) return fail(TROYN_E_INVALID, "[troyn_bgv_create] null argument");
+    *out = nullptr;
+    if (L < 1 || L > plan->K) return fail(TROYN_E_INVALID, "[RNSTool::RNSTool] RNSBase length is invalid.");
+    if (t < 2 || (t >> 61) != 0) return fail(TROYN_E_MODULUS, "[troyn_bgv_create] BGV needs a plain modulus in [2, 2^61).");
+    std::unique_ptr<troyn_bgv, int (*)(troyn_bgv*)> b(new troyn_bgv, troyn_bgv_destroy);
+    b->plan = plan; b->L = L; b->t = t;
+    std::vector<u64> q(plan->moduli.begin(), plan->moduli.begin() + L);
+    std::vector<u64> blob;
+    for (size_t i = 0; i < L; i++) {
+        u64 inv = 1;
+        if (L > 1 && !host::invmod(host::product_mod(q, i, q[i]) % q[i], q[i], inv)) return fail(TROYN_E_MODULUS, "[RNSBase::initialize] RNSBase product is not invertible.");
+        host::Shoup sh = host::shoup(inv % q[i], q[i]);
+        blob.push_back(sh.operand); blob.push_back(sh.quotient);
+    }
+    for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, t));
+    b->q_mod_t = host::product_mod(q, SIZE_MAX, t);
+    u64 inv = 1;
+    b->can_divide = host::invmod(q[L - 1] % t, t, inv);       // "[RNSTool::RNSTool] Unable to invert q[last] mod t."
+    b->inv_q_last_mod_t = b->can_divide ? inv : 1;
+    b->t_mod = make_dev_modulus(t, plan->log_n, false);
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipMalloc(&b->d_consts, blob.size() * sizeof(u64)));
+    HIP_TRY(hipMemcpy(b->d_consts, blob.data(), blob.size() * sizeof(u64), hipMemcpyHostToDevice));
+    *out = b.release();
+    return TROYN_OK;
+}
+
+extern "C" uint64_t troyn_bgv_inv_q_last_mod_t(const troyn_bgv* b) { return b ? b->inv_q_last_mod_t : 0; }
+
+extern "C" size_t troyn_bgv_mod_switch_workspace_bytes(const troyn_bgv* b, size_t pcount, size_t batch) {
+    return b ? troyn_divide_and_round_q_last_ntt_workspace_bytes(b->plan, b->L, pcount, batch) : 0;
+}
+
+extern "C" int troyn_bgv_mod_t_and_divide_q_last_ntt(const troyn_bgv* b, const uint64_t* in, size_t pcount, uint64_t* out, void* workspace, size_t workspace_bytes,
+                                                     size_t batch, troyn_stream_t stream) {
+    const char* P = "[RNSTool::mod_t_and_divide_q_last_ntt]";
+    if (!b || !in || !out || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    const troyn_plan* p = b->plan;
+    const unsigned L = b->L;
+    if (L < 2) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
+    if (!b->can_divide) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert q[last] mod t.");
+    if (workspace_bytes < troyn_bgv_mod_switch_workspace_bytes(b, pcount, batch)) return fail(TROYN_E_WORKSPACE, "[troyn_bgv_mod_t_and_divide_q_last_ntt] workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t items = batch * pcount, n = p->n;
+    if (items == 0) return TROYN_OK;
+    u64* last_intt = (u64*)workspace;
+    u64* delta = last_intt + items * n;
+    u64* delta_ntt = delta + items * (size_t)(L - 1) * n;
+    int rc;
+    {   // INTT of the last limb only (the reference's device branch transforms all of them, utils/rns_tool.cu:1757)
+        NttArgs a = contiguous_args(p, (const u64*)in + (size_t)(L - 1) * n, last_intt, 1, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = (long long)L * n;
+        if ((rc = launch_ntt(p, a, items, true, s))) return rc;
+    }
+    const unsigned ch = chunks_single(p->n);
+    const size_t rows = items * (L - 1);
+    if ((rc = check_rows(rows, ch))) return rc;
+    hipLaunchKernelGGL(bgv_delta_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                       ch, p->d_mods, L - 1, p->n, b->t_mod, b->inv_q_last_mod_t, p->moduli[L - 1], last_intt, n, delta);
+    LAUNCH_CHECK();
+    {
+        NttArgs a = contiguous_args(p, delta, delta_ntt, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+        if ((rc = launch_ntt(p, a, items, false, s))) return rc;
+    }
+    hipLaunchKernelGGL(bgv_finish_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
+                       ch, p->d_mods, L - 1, L, p->n, (const u64*)in, delta_ntt, p->d_inv_last + (size_t)L * p->K, -1, (u64*)out, (const u64*)nullptr, (size_t)0);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_bgv_decrypt_mod_t(const troyn_bgv* b, const uint64_t* phase, uint64_t correction_factor, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    const char* P = "[scaling_variant::decentralize]";
+    if (!b || !phase || !dest) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (batch == 0) return TROYN_OK;
+    if (batch > 65535) return fail(TROYN_E_INVALID, std::string(P) + " batch too large for one launch");
+    u64 fix = 1;
+    if (correction_factor != 1 && !host::invmod(correction_factor % b->t, b->t, fix)) return fail(TROYN_E_INVALID, std::string(P) + " Correction factor is not invertible.");
+    BgvDecryptArgs a;
+    a.mods = b->plan->d_mods;
+    a.inv_punctured = reinterpret_cast<const ulonglong2*>(b->d_consts);
+    a.punctured_mod_t = b->d_consts + 2 * (size_t)b->L;
+    a.t = b->t_mod; a.q_mod_t = b->q_mod_t; a.fix = fix; a.L = b->L; a.n = b->plan->n;
+    hipLaunchKernelGGL(bgv_decrypt_mod_t_kernel, dim3((b->plan->n + 255) / 256, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a, (const u64*)phase, (u64*)dest);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_bgv_multiply_scalar_mod_t(const troyn_bgv* b, const uint64_t* in, uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t stream) {
+    if (!b || !in || !out) return fail(TROYN_E_INVALID, "[utils::multiply_scalar] null argument");
+    if (count == 0) return TROYN_OK;
+    hipLaunchKernelGGL(scalar_mod_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->t_mod, (u64)(scalar % b->t), (const u64*)in, (u64*)out, count);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// Key switching for BGV: `key_level` = troyn_bgv_create(plan, n_moduli, t), whose last prime is the special prime
+static int bgv_tail_from(const troyn_bgv* key_level, BgvTail& tail) {
+    if (!key_level) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null BGV constants");
+    if (key_level->L != key_level->plan->K) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] BGV key switching needs the key level's constants");
+    if (!key_level->can_divide) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert q[last] mod t.");
+    tail.t = key_level->t_mod; tail.inv_special_mod_t = key_level->inv_q_last_mod_t;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_bgv_switch_key(const troyn_bgv* key_level, uint32_t L, const uint64_t* target, const uint64_t* const* keys, int assign_method,
+                                    uint64_t* destination, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    BgvTail tail;
+    if (int rc = bgv_tail_from(key_level, tail)) return rc;
+    const troyn_plan* plan = key_level->plan;
+    return switch_key_impl(plan, L, 0, 1, (const u64*)target, (size_t)L * plan->n, keys, assign_method, (u64*)destination, nullptr, 0, workspace, workspace_bytes, batch,
+                           (hipStream_t)stream, &tail);
+}
+
+extern "C" int troyn_bgv_relinearize(const troyn_bgv* key_level, uint32_t L, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2, void* workspace,
+                                     size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    BgvTail tail;
+    if (int rc = bgv_tail_from(key_level, tail)) return rc;
+    if (!ct3) return fail(TROYN_E_INVALID, "[Evaluator::relinearize_inplace_internal] null argument");
+    const troyn_plan* plan = key_level->plan;
+    const size_t pc = (size_t)L * plan->n;
+    return switch_key_impl(plan, L, 0, 1, (const u64*)ct3 + 2 * pc, 3 * pc, keys, TROYN_ASSIGN_OVERWRITE, (u64*)out2, (const u64*)ct3, 3 * pc, workspace, workspace_bytes,
+                           batch, (hipStream_t)stream, &tail);
 }
 
 // ---------------------------------------------------------------------------------------

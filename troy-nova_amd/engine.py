@@ -351,6 +351,71 @@ def sample_uniform_multi(plan, nmod, seeds):
     return out
 
 
+class Bgv:
+    """troyn_bgv: the BGV-only constants of one level (RNSTool, utils/rns_tool.cu:205-232) and the steps that use them."""
+
+    def __init__(self, plan, L, plain_modulus):
+        self.plan, self.L, self.t = plan, int(L), int(plain_modulus)
+        h = C.c_void_p()
+        capi.check(plan.lib.troyn_bgv_create(C.byref(h), plan.h, self.L, self.t))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.plan.lib.troyn_bgv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def inv_q_last_mod_t(self):
+        return int(self.plan.lib.troyn_bgv_inv_q_last_mod_t(self.h))
+
+    def mod_t_and_divide_q_last_ntt(self, x, pcount):
+        """x [batch][pcount][L][N] NTT form -> [batch][pcount][L-1][N]"""
+        n, L = self.plan.n, self.L
+        batch = x.numel() // (pcount * L * n)
+        out = torch.empty((batch, pcount, L - 1, n), dtype=torch.int64, device=x.device)
+        ws = self.plan.workspace(self.plan.lib.troyn_bgv_mod_switch_workspace_bytes(self.h, pcount, batch))
+        capi.check(self.plan.lib.troyn_bgv_mod_t_and_divide_q_last_ntt(self.h, _ptr(x), pcount, _ptr(out), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
+
+    def decrypt_mod_t(self, phase, correction_factor=1):
+        """phase [batch][L][N] coefficient form -> [batch][N] mod t (times correction_factor^-1)"""
+        n = self.plan.n
+        batch = phase.numel() // (self.L * n)
+        out = torch.empty((batch, n), dtype=torch.int64, device=phase.device)
+        capi.check(self.plan.lib.troyn_bgv_decrypt_mod_t(self.h, _ptr(phase), int(correction_factor), _ptr(out), batch, _stream()))
+        return out
+
+    def multiply_scalar_mod_t(self, x, scalar):
+        out = torch.empty_like(x)
+        capi.check(self.plan.lib.troyn_bgv_multiply_scalar_mod_t(self.h, _ptr(x), int(scalar), _ptr(out), x.numel(), _stream()))
+        return out
+
+    def switch_key(self, L, target, keys, dest=None, assign=ASSIGN_OVERWRITE):
+        """self must be the key level (L = plan.K); target [batch][L][N] NTT form"""
+        plan = self.plan
+        batch = target.numel() // (L * plan.n)
+        if dest is None:
+            dest = torch.zeros((batch, 2, L, plan.n), dtype=torch.int64, device=target.device)
+        ws = plan.workspace(plan.lib.troyn_switch_key_workspace_bytes(plan.h, L, batch))
+        capi.check(plan.lib.troyn_bgv_switch_key(self.h, L, _ptr(target), plan._key_ptrs(keys, L), assign, _ptr(dest), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return dest
+
+    def relinearize(self, L, ct3, keys):
+        plan = self.plan
+        batch = ct3.numel() // (3 * L * plan.n)
+        out = torch.empty((batch, 2, L, plan.n), dtype=torch.int64, device=ct3.device)
+        ws = plan.workspace(plan.lib.troyn_relinearize_workspace_bytes(plan.h, L, batch))
+        capi.check(plan.lib.troyn_bgv_relinearize(self.h, L, _ptr(ct3), plan._key_ptrs(keys, L), _ptr(out), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
+
+
 class Behz:
     """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""
 
