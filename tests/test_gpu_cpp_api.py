@@ -180,3 +180,15 @@ def test_batched_ops_cpp_api(dev, scheme, count):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln and ln not in ("OK",)]
     assert len(lines) >= 17 and all(ln.endswith(" 0") or ln == "size_mismatch_rejected 1" for ln in lines), r.stdout
+
+
+def test_bgv_cpp_api(dev):
+    """the BGV scheme through the mirror: every evaluator result decrypts to the plain computation on the slots"""
+    drv = os.path.join(ROOT, "tests", "cpp", "bgv_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/bgv_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert "form ntt=1 cf=1 L=3" in r.stdout and "serialized_cf_equal 1" in r.stdout
+    checks = [ln for ln in r.stdout.splitlines() if ln.split()[-1].isdigit() and not ln.startswith(("form", "mod_switch L", "correction", "serialized"))]
+    assert len(checks) >= 13 and all(ln.endswith(" 0") for ln in checks), r.stdout

@@ -94,7 +94,8 @@ void Evaluator::negate_inplace_batched(const std::vector<Ciphertext*>& encrypted
 void Evaluator::translate_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, bool subtract,
                                   MemoryPoolHandle pool) const {
     if (e1.size() != e2.size() || e1.size() != d.size()) throw std::invalid_argument("[Evaluator::translate_batched] Input and destination have different sizes.");
-    const bool batched = e1.size() >= BATCH_OP_THRESHOLD && uniform(e1) && uniform(e2) && e1[0]->polynomial_count() == e2[0]->polynomial_count();
+    const bool batched = e1.size() >= BATCH_OP_THRESHOLD && uniform(e1) && uniform(e2) && e1[0]->polynomial_count() == e2[0]->polynomial_count() &&
+                         e1[0]->correction_factor() == e2[0]->correction_factor();   // BGV operands with different factors are balanced one by one
     if (!batched) {
         for (size_t i = 0; i < e1.size(); i++) { Ciphertext out; translate(*e1[i], *e2[i], out, subtract, pool); *d[i] = std::move(out); }
         return;
@@ -147,7 +148,8 @@ void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const
 // -- relinearize -------------------------------------------------------------------------------------------------------
 void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
     same_size("[Evaluator::relinearize_batched]", encrypted.size(), d.size());
-    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted) || encrypted[0]->polynomial_count() != 3) {
+    const bool bgv = context_->key_context_data().value()->parms().scheme() == SchemeType::BGV;   // ski_util5 tail: per-object path
+    if (bgv || encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted) || encrypted[0]->polynomial_count() != 3) {
         for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; relinearize_internal(*encrypted[i], relin_keys, 2, out, pool); *d[i] = std::move(out); }
         return;
     }
@@ -169,7 +171,8 @@ void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encryp
 // -- modulus switching -------------------------------------------------------------------------------------------------
 void Evaluator::mod_switch_to_next_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
     same_size("[Evaluator::mod_switch_to_next_batched]", encrypted.size(), destination.size());
-    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+    const bool bgv = context_->key_context_data().value()->parms().scheme() == SchemeType::BGV;
+    if (bgv || encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
         for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; mod_switch_to_next(*encrypted[i], out, pool); *destination[i] = std::move(out); }
         return;
     }
@@ -246,7 +249,8 @@ void Evaluator::transform_from_ntt_inplace_batched(const std::vector<Ciphertext*
 void Evaluator::apply_galois_batched(const std::vector<const Ciphertext*>& encrypted, size_t galois_element, const GaloisKeys& galois_keys,
                                      const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
     same_size("[Evaluator::apply_galois_batched]", encrypted.size(), destination.size());
-    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+    const bool bgv = context_->key_context_data().value()->parms().scheme() == SchemeType::BGV;
+    if (bgv || encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
         for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; apply_galois(*encrypted[i], galois_element, galois_keys, out, pool); *destination[i] = std::move(out); }
         return;
     }

@@ -144,8 +144,21 @@ void Evaluator::translate_plain_inplace(Ciphertext& encrypted, const Plaintext& 
             troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), plain.poly(), encrypted.poly(0), 1, stream()));
             break;
         }
+        case SchemeType::BGV: {
+            // evaluator_translate_plain.cu:78-88: the plaintext (mod t) takes the ciphertext's correction factor, is lifted
+            // centrally, transformed and added
+            if (!encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Ciphertext is not in NTT form.");
+            if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is in NTT form.");
+            if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::centralize] plain_coeff_count exceeds the polynomial degree.");
+            utils::DynamicArray scaled(plain.coeff_count(), true, pool), lifted(static_cast<size_t>(L) * n, true, pool);
+            troyn_check_public(troyn_bgv_multiply_scalar_mod_t(context_->bgv(L), plain.poly(), encrypted.correction_factor(), scaled.raw_pointer(), plain.coeff_count(), stream()));
+            troyn_check_public(troyn_plain_centralize(context_->plan(), L, parms.plain_modulus().value(), scaled.raw_pointer(), plain.coeff_count(), n, lifted.raw_pointer(), 1, stream()));
+            troyn_check_public(troyn_ntt(context_->plan(), 0, lifted.raw_pointer(), lifted.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
+            troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), lifted.raw_pointer(), encrypted.poly(0), 1, stream()));
+            break;
+        }
         default:
-            throw std::logic_error(std::string(P) + " BGV is not part of this build.");
+            throw std::logic_error(std::string(P) + " Scheme not implemented.");
     }
     troyn_sync_current_stream();
 }

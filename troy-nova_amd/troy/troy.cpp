@@ -451,6 +451,7 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
 
 HeContext::~HeContext() {
     for (auto& kv : behz_) troyn_behz_destroy(kv.second);
+    for (auto& kv : bgv_) troyn_bgv_destroy(kv.second);
     if (plain_plan_) troyn_plan_destroy(plain_plan_);
     if (plan_) troyn_plan_destroy(plan_);
 }
@@ -488,6 +489,18 @@ const troyn_behz* HeContext::behz(size_t L) const {
     const EncryptionParameters& kp = key_context_data().value()->parms();
     troyn_check(troyn_behz_create(&b, plan_, static_cast<uint32_t>(L), kp.plain_modulus().value()));
     behz_[L] = b;
+    return b;
+}
+
+const troyn_bgv* HeContext::bgv(size_t L) const {
+    std::lock_guard<std::mutex> lock(behz_mutex_);
+    auto it = bgv_.find(L);
+    if (it != bgv_.end()) return it->second;
+    if (!plan_) throw std::invalid_argument("[HeContext::bgv] HeContext is not on device (call to_device_inplace).");
+    troyn_bgv* b = nullptr;
+    const EncryptionParameters& kp = key_context_data().value()->parms();
+    troyn_check(troyn_bgv_create(&b, plan_, static_cast<uint32_t>(L), kp.plain_modulus().value()));
+    bgv_[L] = b;
     return b;
 }
 
@@ -607,6 +620,42 @@ void Evaluator::negate_inplace(Ciphertext& encrypted) const {
 }
 
 
+// evaluator_utils.h:254-305: e1, e2 with e1 * factor1 = e2 * factor2 = prod (mod t), chosen small (extended Euclid on the ratio)
+static void balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t, uint64_t& prod, uint64_t& e1, uint64_t& e2) {
+    auto mulmod = [t](uint64_t a, uint64_t b) { return static_cast<uint64_t>((static_cast<unsigned __int128>(a) * b) % t); };
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { uint64_t r = a % b; a = b; b = r; } return a; };
+    const uint64_t half_t = t >> 1;
+    auto sum_abs = [half_t, t](uint64_t x, uint64_t y) -> uint64_t {
+        const int64_t xb = x > half_t ? static_cast<int64_t>(x - t) : static_cast<int64_t>(x);
+        const int64_t yb = y > half_t ? static_cast<int64_t>(y - t) : static_cast<int64_t>(y);
+        return static_cast<uint64_t>(std::llabs(xb) + std::llabs(yb));
+    };
+    // factor1^-1 mod t (extended Euclid)
+    int64_t r0 = static_cast<int64_t>(t), r1 = static_cast<int64_t>(factor1 % t), s0 = 0, s1 = 1;
+    while (r1 != 0) { const int64_t qq = r0 / r1; int64_t tmp = r0 - qq * r1; r0 = r1; r1 = tmp; tmp = s0 - qq * s1; s0 = s1; s1 = tmp; }
+    if (r0 != 1) throw std::logic_error("[balance_correction_factors] Failed to invert factor1.");
+    uint64_t ratio = mulmod(static_cast<uint64_t>(s0 < 0 ? s0 + static_cast<int64_t>(t) : s0), factor2 % t);
+    e1 = ratio; e2 = 1;
+    uint64_t sum = sum_abs(factor1, factor2);
+    int64_t prev_a = static_cast<int64_t>(t), prev_b = 0, a = static_cast<int64_t>(ratio), b = 1;
+    while (a != 0) {
+        const int64_t qq = prev_a / a;
+        int64_t temp = prev_a % a;
+        prev_a = a; a = temp;
+        temp = prev_b - qq * b;
+        prev_b = b; b = temp;
+        uint64_t a_mod = static_cast<uint64_t>(std::llabs(a)) % t;
+        if (a < 0 && a_mod != 0) a_mod = t - a_mod;
+        uint64_t b_mod = static_cast<uint64_t>(std::llabs(b)) % t;
+        if (b < 0 && b_mod != 0) b_mod = t - b_mod;
+        if (a_mod != 0 && gcd(a_mod, t) == 1) {
+            const uint64_t new_sum = sum_abs(a_mod, b_mod);
+            if (new_sum < sum) { e1 = a_mod; e2 = b_mod; sum = new_sum; }
+        }
+    }
+    prod = mulmod(e1, factor1 % t);
+}
+
 // -- add / sub (evaluator_translate.cu:12-118) ------------------------------------------------------
 void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, bool subtract, MemoryPoolHandle pool) const {
     const char* P = "[Evaluator::translate_inplace]";
@@ -616,8 +665,21 @@ void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext
     check_same_ntt_form(P, e1, e2);
     check_on_device(P, context_, e1); check_on_device(P, context_, e2);
     auto cd = get_context_data(P, e1.parms_id());
-    if (e1.correction_factor() != e2.correction_factor())
-        throw std::logic_error("[Evaluator::translate] BGV correction-factor balancing is not part of this build.");
+    if (e1.correction_factor() != e2.correction_factor()) {
+        // evaluator_translate.cu:84-98: bring both operands to a common correction factor first
+        if (cd->parms().scheme() != SchemeType::BGV) throw std::invalid_argument(std::string(P) + " Correction factors differ outside BGV.");
+        uint64_t f0 = 1, f1 = 1, f2 = 1;
+        balance_correction_factors(e1.correction_factor(), e2.correction_factor(), cd->parms().plain_modulus().value(), f0, f1, f2);
+        const uint32_t Lb = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+        Ciphertext a = Ciphertext::like(e1, false, pool), b = Ciphertext::like(e2, false, pool);
+        troyn_check(troyn_multiply_scalar(context_->plan(), 0, Lb, e1.data().raw_pointer(), f1, a.data().raw_pointer(), e1.polynomial_count(), current_stream()));
+        troyn_check(troyn_multiply_scalar(context_->plan(), 0, Lb, e2.data().raw_pointer(), f2, b.data().raw_pointer(), e2.polynomial_count(), current_stream()));
+        a.correction_factor() = f0;
+        b.correction_factor() = f0;
+        translate(a, b, destination, subtract, pool);
+        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+        return;
+    }
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const size_t n = cd->parms().poly_modulus_degree();
     const size_t s1 = e1.polynomial_count(), s2 = e2.polynomial_count();
@@ -709,7 +771,7 @@ void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t*
     if (kswitch_keys_index >= kswitch_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
     auto cd = get_context_data(P, encrypted.parms_id());
     SchemeType scheme = cd->parms().scheme();
-    if (scheme == SchemeType::BGV) throw std::logic_error(std::string(P) + " BGV key switching is not part of this build.");
+    if (scheme == SchemeType::BGV && !encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BGV ciphertexts are in NTT form.");
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const auto& key_vector = kswitch_keys.data()[kswitch_keys_index];
     if (key_vector.size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
@@ -726,6 +788,12 @@ void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t*
     std::vector<const uint64_t*> ptrs = kswitch_keys.get_data_ptrs(kswitch_keys_index);
     size_t bytes = troyn_switch_key_workspace_bytes(context_->plan(), L, 1);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    if (scheme == SchemeType::BGV) {
+        // the ski_util5 tail needs the key level's q_special^-1 mod t (evaluator_keyswitching_core.cu:930-932)
+        const size_t K = context_->key_context_data().value()->parms().coeff_modulus().size();
+        troyn_check(troyn_bgv_switch_key(context_->bgv(K), L, target, ptrs.data(), static_cast<int>(assign_method), destination.data().raw_pointer(), ws.raw_pointer(), bytes, 1,
+                                         current_stream()));
+    } else
     troyn_check(troyn_switch_key(context_->plan(), L, scheme == SchemeType::CKKS, encrypted.is_ntt_form(), target, ptrs.data(),
                                  static_cast<int>(assign_method), destination.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
 }
@@ -766,7 +834,7 @@ void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKey
         size_t idx = RelinKeys::get_index(2);
         if (idx >= relin_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
         SchemeType scheme = cd->parms().scheme();
-        if (scheme == SchemeType::BGV) throw std::logic_error(std::string(P) + " BGV key switching is not part of this build.");
+        if (scheme == SchemeType::BGV && !encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BGV ciphertexts are in NTT form.");
         if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
         if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
         for (const auto& k : relin_keys.data()[idx]) if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
@@ -774,6 +842,10 @@ void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKey
         std::vector<const uint64_t*> ptrs = relin_keys.get_data_ptrs(idx);
         size_t bytes = troyn_relinearize_workspace_bytes(context_->plan(), L, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        if (scheme == SchemeType::BGV) {
+            const size_t K = context_->key_context_data().value()->parms().coeff_modulus().size();
+            troyn_check(troyn_bgv_relinearize(context_->bgv(K), L, encrypted.data().raw_pointer(), ptrs.data(), out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+        } else
         troyn_check(troyn_relinearize(context_->plan(), L, scheme == SchemeType::CKKS, encrypted.is_ntt_form(), encrypted.data().raw_pointer(), ptrs.data(),
                                       out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
         destination = std::move(out);
@@ -804,7 +876,7 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
     auto cd = get_context_data(P, encrypted.parms_id());
     SchemeType scheme = cd->parms().scheme();
     if (scheme == SchemeType::BFV) check_is_not_ntt_form(P, encrypted);
-    else if (scheme == SchemeType::CKKS) check_is_ntt_form(P, encrypted);
+    else if (scheme == SchemeType::CKKS || scheme == SchemeType::BGV) check_is_ntt_form(P, encrypted);
     else throw std::logic_error(std::string(P) + " Scheme not implemented.");
     if (!cd->next_context_data().has_value()) throw std::invalid_argument(std::string(P) + " Next context data is not set.");
     check_on_device(P, context_, encrypted);
@@ -815,6 +887,15 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
     out.parms_id() = next->parms_id();
     if (scheme == SchemeType::BFV) {
         troyn_check(troyn_divide_and_round_q_last(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), 1, current_stream()));
+    } else if (scheme == SchemeType::BGV) {
+        // RNSTool::mod_t_and_divide_q_last_ntt; the plaintext is multiplied by q_last^-1 mod t (evaluator_modswitch.cu:62-72)
+        const troyn_bgv* bg = context_->bgv(L);
+        const size_t bytes = troyn_bgv_mod_switch_workspace_bytes(bg, pc, 1);
+        utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        troyn_check(troyn_bgv_mod_t_and_divide_q_last_ntt(bg, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+        const uint64_t t = next->parms().plain_modulus().value();
+        out.correction_factor() = static_cast<uint64_t>((static_cast<unsigned __int128>(encrypted.correction_factor()) * troyn_bgv_inv_q_last_mod_t(bg)) % t);
     } else {
         size_t bytes = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), L, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
@@ -849,7 +930,7 @@ void Evaluator::mod_switch_to_next(const Ciphertext& encrypted, Ciphertext& dest
     if (context_->last_parms_id() == encrypted.parms_id()) throw std::invalid_argument("[Evaluator::mod_switch_to_next] End of modulus switching chain reached.");
     SchemeType scheme = context_->first_context_data().value()->parms().scheme();
     switch (scheme) {
-        case SchemeType::BFV: mod_switch_scale_to_next_internal(encrypted, destination, pool); break;
+        case SchemeType::BFV: case SchemeType::BGV: mod_switch_scale_to_next_internal(encrypted, destination, pool); break;
         case SchemeType::CKKS: {
             auto cd = get_context_data("[Evaluator::mod_switch_to_next]", encrypted.parms_id());
             mod_switch_drop_to_internal(encrypted, destination, cd->next_context_data().value()->parms_id(), pool);
@@ -1536,7 +1617,6 @@ void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& par
     if (!sk.on_device()) throw std::invalid_argument(std::string(P) + " context_data and secret_key is not on the same device.");
     ContextDataPointer cd = level(P, context, parms_id);
     const EncryptionParameters& parms = cd->parms();
-    if (parms.scheme() == SchemeType::BGV) throw std::logic_error("[rlwe::symmetric] BGV is not part of this build.");
     const uint32_t L = static_cast<uint32_t>(parms.coeff_modulus().size());
     const size_t n = parms.poly_modulus_degree();
     const troyn_plan* plan = context->plan();
@@ -1563,6 +1643,8 @@ void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& par
     troyn_check(troyn_dyadic_product(plan, 0, L, sk.data().raw_pointer(), destination.poly(1), destination.poly(0), 1, s));
     if (is_ntt_form) troyn_check(troyn_ntt(plan, 0, noise.raw_pointer(), noise.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
     else troyn_check(troyn_ntt(plan, 1, destination.poly(0), destination.poly(0), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+    if (parms.scheme() == SchemeType::BGV)      // -(a s + t e), utils/rlwe.cu:300-304
+        troyn_check(troyn_multiply_scalar(plan, 0, L, noise.raw_pointer(), parms.plain_modulus().value(), noise.raw_pointer(), 1, s));
     troyn_check(troyn_add(plan, 0, L, destination.poly(0), noise.raw_pointer(), destination.poly(0), 1, s));
     troyn_check(troyn_negate(plan, 0, L, destination.poly(0), destination.poly(0), 1, s));
     if (!is_ntt_form && !save_seed)
@@ -1578,7 +1660,6 @@ void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& pa
     if (!pk.on_device()) throw std::invalid_argument(std::string(P) + " context_data and public_key is not on the same device.");
     ContextDataPointer cd = level(P, context, parms_id);
     const EncryptionParameters& parms = cd->parms();
-    if (parms.scheme() == SchemeType::BGV) throw std::logic_error("[rlwe::asymmetric] BGV is not part of this build.");
     const uint32_t L = static_cast<uint32_t>(parms.coeff_modulus().size());
     const size_t n = parms.poly_modulus_degree();
     const troyn_plan* plan = context->plan();
@@ -1603,6 +1684,8 @@ void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& pa
     for (size_t j = 0; j < encrypted_size; j++) {
         prng.sample_poly_centered_binomial(plan, L, u.raw_pointer());   // u reused as e_j
         if (is_ntt_form) troyn_check(troyn_ntt(plan, 0, u.raw_pointer(), u.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        if (parms.scheme() == SchemeType::BGV)   // pk_j u + t e_j, utils/rlwe.cu:82-86
+            troyn_check(troyn_multiply_scalar(plan, 0, L, u.raw_pointer(), parms.plain_modulus().value(), u.raw_pointer(), 1, s));
         troyn_check(troyn_add(plan, 0, L, destination.poly(j), u.raw_pointer(), destination.poly(j), 1, s));
     }
     hip_check(hipStreamSynchronize(s), "stream_sync");
@@ -1749,7 +1832,15 @@ void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form,
     out.data() = utils::DynamicArray(0, true, pool);
     out.resize(context_, parms_id, pc, false);
     hipStream_t s = current_stream();
-    if (is_ntt_form) {
+    if (cd->parms().scheme() == SchemeType::BGV) {
+        // encryptor.cu:65-84
+        if (!is_ntt_form) throw std::invalid_argument(std::string(P) + " BGV - Plaintext is not in NTT form.");
+        const troyn_bgv* bg = context_->bgv(Lp);
+        const size_t wsb = troyn_bgv_mod_switch_workspace_bytes(bg, pc, 1);
+        utils::DynamicArray ws((wsb + 7) / 8, true, pool);
+        troyn_check(troyn_bgv_mod_t_and_divide_q_last_ntt(bg, temp.data().raw_pointer(), pc, out.data().raw_pointer(), ws.raw_pointer(), wsb, 1, s));
+        hip_check(hipStreamSynchronize(s), "stream_sync");
+    } else if (is_ntt_form) {
         const size_t wsb = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), Lp, pc, 1);
         utils::DynamicArray ws((wsb + 7) / 8, true, pool);
         troyn_check(troyn_divide_and_round_q_last_ntt(context_->plan(), Lp, temp.data().raw_pointer(), pc, out.data().raw_pointer(),
@@ -1813,8 +1904,27 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
             destination.scale() = plain.scale();
             break;
         }
+        case SchemeType::BGV: {
+            // encryptor.cu:300-333: zero encryption in NTT form at the first level, plus the (centralized, NTT) plaintext
+            encrypt_zero_internal(context_->first_parms_id(), true, is_asymmetric, save_seed, destination, pool);
+            ContextDataPointer fcd = context_->first_context_data().value();
+            const uint32_t L = static_cast<uint32_t>(fcd->parms().coeff_modulus().size());
+            const size_t n = fcd->parms().poly_modulus_degree();
+            if (!plain.is_ntt_form()) {
+                if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::centralize] plain_coeff_count exceeds the polynomial degree.");
+                utils::DynamicArray lifted(static_cast<size_t>(L) * n, true, pool);
+                troyn_check(troyn_plain_centralize(context_->plan(), L, fcd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n, lifted.raw_pointer(), 1, s));
+                troyn_check(troyn_ntt(context_->plan(), 0, lifted.raw_pointer(), lifted.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+                troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), lifted.raw_pointer(), destination.poly(0), 1, s));
+                hip_check(hipStreamSynchronize(s), "stream_sync");
+            } else {
+                if (plain.parms_id() != context_->first_parms_id()) throw std::invalid_argument(std::string(P) + " BGV - Plaintext parms_id is not valid.");
+                troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
+            }
+            break;
+        }
         default:
-            throw std::logic_error("[Encryptor::encrypt_internal] BGV is not part of this build.");
+            throw std::logic_error("[Encryptor::encrypt_internal] Scheme not implemented.");
     }
 }
 
@@ -1963,8 +2073,27 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
             destination = std::move(out);
             break;
         }
+        case SchemeType::BGV: {
+            // decryptor.cu:509-539: NTT-form dot product, INTT, decrypt_mod_t with the correction factor (decentralize)
+            if (!encrypted.is_ntt_form()) throw std::invalid_argument("[Decryptor::bgv_decrypt] Ciphertext is not in NTT form.");
+            utils::DynamicArray phase(L * n, true, pool);
+            dot_product_ct_sk_array(encrypted, phase.raw_pointer(), pool);
+            troyn_check(troyn_ntt(context_->plan(), 1, phase.raw_pointer(), phase.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0,
+                                  current_stream()));
+            Plaintext out;
+            out.data() = utils::DynamicArray(0, true, pool);
+            out.parms_id() = parms_id_zero;
+            out.resize(n);
+            troyn_check(troyn_bgv_decrypt_mod_t(context_->bgv(L), phase.raw_pointer(), encrypted.correction_factor(), out.poly(), 1, current_stream()));
+            hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+            out.is_ntt_form() = false;
+            out.coeff_modulus_size() = L;
+            out.poly_modulus_degree() = n;
+            destination = std::move(out);
+            break;
+        }
         default:
-            throw std::logic_error("[Decryptor::decrypt] BGV is not part of this build.");
+            throw std::logic_error("[Decryptor::decrypt] Scheme not implemented.");
     }
 }
 

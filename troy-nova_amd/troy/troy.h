@@ -277,6 +277,7 @@ public:
     // C-ABI handles (boundary objects)
     const troyn_plan* plan() const { return plan_; }
     const troyn_behz* behz(size_t coeff_modulus_size) const;   // created on first use
+    const troyn_bgv* bgv(size_t coeff_modulus_size) const;     // BGV-only constants of the level with that many primes
     const troyn_plan* plain_plan() const;                      // NTT tables mod t (ContextData::plain_ntt_tables), first use
 private:
     HeContext() = default;
@@ -289,6 +290,7 @@ private:
     troyn_plan* plan_ = nullptr;
     mutable std::mutex behz_mutex_;
     mutable std::map<size_t, troyn_behz*> behz_;
+    mutable std::map<size_t, troyn_bgv*> bgv_;
     mutable troyn_plan* plain_plan_ = nullptr;
     mutable utils::RandomGenerator random_generator_;
 };
