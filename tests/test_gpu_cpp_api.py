@@ -192,3 +192,13 @@ def test_bgv_cpp_api(dev):
     assert "form ntt=1 cf=1 L=3" in r.stdout and "serialized_cf_equal 1" in r.stdout
     checks = [ln for ln in r.stdout.splitlines() if ln.split()[-1].isdigit() and not ln.startswith(("form", "mod_switch L", "correction", "serialized"))]
     assert len(checks) >= 13 and all(ln.endswith(" 0") for ln in checks), r.stdout
+
+
+def test_multithread_cpp_api(dev):
+    """test/test_multithread.cu's scenario: host threads sharing one context, keys and the global pool, each on its own
+    per-thread stream; the Evaluator methods are const and re-entrant, the context generator is the only shared mutable state"""
+    drv = os.path.join(ROOT, "tests", "cpp", "multithread_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/multithread_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "4", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "completed 32 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -3,6 +3,8 @@
 // function whose behaviour (checks, metadata updates, error text) is mirrored.
 #include "troy.h"
 
+#include <atomic>
+
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -49,8 +51,14 @@ MemoryPool::MemoryPool(size_t device) : device_(device) {
     if (device >= device_count()) throw std::runtime_error("[MemoryPool::MemoryPool] No such device.");
 }
 
+static uint64_t this_thread_tag() {
+    static std::atomic<uint64_t> next{1};
+    thread_local uint64_t tag = next.fetch_add(1);
+    return tag;
+}
+
 MemoryPool::~MemoryPool() {
-    for (auto& kv : free_) (void)hipFree(kv.second);
+    for (auto& kv : free_) for (auto& blk : kv.second) (void)hipFree(blk.ptr);
     for (auto& kv : live_) (void)hipFree(kv.first);
 }
 
@@ -68,40 +76,67 @@ void MemoryPool::Destroy() {
 void* MemoryPool::allocate(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
-    std::lock_guard<std::mutex> lock(mutex_);
-    auto it = free_.lower_bound(bytes);
-    if (it != free_.end() && it->first <= bytes * 2) {   // at most 2x slack, as memory_pool_safe.in:119-148
-        void* p = it->second;
-        size_t sz = it->first;
-        free_.erase(it);
-        live_[p] = sz;
-        return p;
+    const uint64_t me = this_thread_tag();
+    void* found = nullptr;
+    bool foreign = false;
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        // best fit with at most 2x slack (memory_pool_safe.in:119-148); among the fitting blocks prefer one this thread released
+        auto first = free_.lower_bound(bytes);
+        auto pick = free_.end();
+        size_t pick_index = 0;
+        for (auto it = first; it != free_.end() && it->first <= bytes * 2 && !found; ++it) {
+            for (size_t i = it->second.size(); i-- > 0;)
+                if (it->second[i].owner == me) { pick = it; pick_index = i; found = it->second[i].ptr; break; }
+        }
+        if (!found && first != free_.end() && first->first <= bytes * 2) {
+            pick = first; pick_index = first->second.size() - 1; found = first->second[pick_index].ptr; foreign = true;
+        }
+        if (found) {
+            const size_t sz = pick->first;
+            pick->second.erase(pick->second.begin() + static_cast<std::ptrdiff_t>(pick_index));
+            if (pick->second.empty()) free_.erase(pick);
+            live_[found] = sz;
+        }
+    }
+    if (found) {
+        if (foreign) {   // kernels of the releasing thread's stream may still be using the block
+            hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
+            hip_check(hipDeviceSynchronize(), "device_synchronize");
+        }
+        return found;
     }
     hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {   // give cached blocks back and retry once
-        for (auto& kv : free_) (void)hipFree(kv.second);
-        free_.clear();
+        release_unused();
         hip_check(hipMalloc(&p, bytes), "malloc");
     }
+    std::lock_guard<std::mutex> lock(mutex_);
     live_[p] = bytes;
     return p;
 }
 
 void MemoryPool::release(void* ptr) {
     if (!ptr) return;
+    const uint64_t me = this_thread_tag();
     std::lock_guard<std::mutex> lock(mutex_);
     auto it = live_.find(ptr);
     if (it == live_.end()) return;
-    free_.emplace(it->second, ptr);
+    free_[it->second].push_back(FreeBlock{ptr, me});
     live_.erase(it);
 }
 
 void MemoryPool::release_unused() {
-    std::lock_guard<std::mutex> lock(mutex_);
-    for (auto& kv : free_) (void)hipFree(kv.second);
-    free_.clear();
+    std::map<size_t, std::vector<FreeBlock>> drop;
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        drop.swap(free_);
+    }
+    if (drop.empty()) return;
+    (void)hipDeviceSynchronize();   // queued kernels may still read blocks released a moment ago
+    for (auto& kv : drop) for (auto& blk : kv.second) (void)hipFree(blk.ptr);
 }
 
 DynamicArray::DynamicArray(size_t count, bool device, MemoryPoolHandle pool) : size_(count), device_(device) {

@@ -53,7 +53,10 @@ class MemoryPool;
 using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 
 // Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
-// uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.
+// uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on its own
+// stream (hipStreamPerThread), and a block may be released while kernels that use it are still queued: a thread that
+// takes back one of ITS OWN blocks is safe by stream order; a block last released by another thread is handed out only
+// after a device-wide synchronisation (memory_pool_safe.in:133-143 does the same with cudaDeviceSynchronize).
 class MemoryPool {
 public:
     explicit MemoryPool(size_t device = 0);
@@ -68,8 +71,9 @@ public:
 private:
     size_t device_;
     std::mutex mutex_;
+    struct FreeBlock { void* ptr; uint64_t owner; };   // owner = tag of the thread that released it
     std::unordered_map<void*, size_t> live_;
-    std::multimap<size_t, void*> free_;
+    std::map<size_t, std::vector<FreeBlock>> free_;
 };
 
 // Owning array of uint64_t on the host (malloc) or on a device (pool) -- src/utils/dynamic_array.h
