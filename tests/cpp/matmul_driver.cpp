@@ -2,7 +2,8 @@
 // matrix product y = x * w + s of examples/10_bfv_matmul.cu (N=8192, {60,40,40,60}, t=2^21) through troy::linear::MatmulHelper,
 // with the example's steps: encode weights and bias, encrypt inputs, serialize / load the inputs, matmul, optional mod-switch,
 // optional output packing, add the bias, serialize / load the outputs, decrypt, compare with the plain result mod t.
-// usage: matmul_driver <batch> <input_dims> <output_dims> [repeat] [pack_lwe 0|1] [mod_switch 0|1]
+// usage: matmul_driver <batch> <input_dims> <output_dims> [repeat] [pack_lwe 0|1] [mod_switch 0|1] [objective: left|right|crossed]
+// (right: plaintext inputs x encrypted weights; crossed: both encrypted, BGV -- the reference's BFV ciphertexts cannot be multiplied in NTT form)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,9 +23,11 @@ int main(int argc, char** argv) {
                      Nn = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 35;
         const int repeat = argc > 4 ? std::atoi(argv[4]) : 1;
         const bool pack_lwe = argc > 5 && std::atoi(argv[5]) != 0, mod_switch = argc > 6 && std::atoi(argv[6]) != 0;
+        const std::string obj = argc > 7 ? argv[7] : "left";
+        const MatmulObjective objective = obj == "right" ? MatmulObjective::EncryptRight : obj == "crossed" ? MatmulObjective::Crossed : MatmulObjective::EncryptLeft;
         const size_t n = 8192;
-        const uint64_t t = 1ull << 21;
-        EncryptionParameters params(SchemeType::BFV);
+        const uint64_t t = objective == MatmulObjective::Crossed ? 1032193ull : 1ull << 21;   // BGV needs t coprime to the q_i
+        EncryptionParameters params(objective == MatmulObjective::Crossed ? SchemeType::BGV : SchemeType::BFV);
         params.set_poly_modulus_degree(n);
         params.set_coeff_modulus(CoeffModulus::create(n, {60, 40, 40, 60}));
         params.set_plain_modulus(t);
@@ -49,23 +52,41 @@ int main(int argc, char** argv) {
                 for (size_t j = 0; j < Nn; j++) want[i * Nn + j] = (want[i * Nn + j] + x[i * R + k] * w[k * Nn + j]) % t;
         for (size_t i = 0; i < M * Nn; i++) want[i] = (want[i] + sbias[i]) % t;
 
-        MatmulHelper helper(M, R, Nn, n, MatmulObjective::EncryptLeft, pack_lwe);
-        std::printf("block %zu %zu %zu pack_lwe %d mod_switch %d\n", helper.batch_block, helper.input_block, helper.output_block, pack_lwe ? 1 : 0, mod_switch ? 1 : 0);
+        MatmulHelper helper(M, R, Nn, n, objective, pack_lwe);
+        RelinKeys relin_keys;
+        if (objective == MatmulObjective::Crossed) relin_keys = keygen.create_relin_keys(false);
+        std::printf("block %zu %zu %zu pack_lwe %d mod_switch %d objective %s\n", helper.batch_block, helper.input_block, helper.output_block, pack_lwe ? 1 : 0, mod_switch ? 1 : 0,
+                    obj.c_str());
         double t0 = now();
-        Plain2d we = helper.encode_weights_uint64s(encoder, w.data());
+        Plain2d we, xp;
+        Cipher2d wc;
+        if (objective == MatmulObjective::EncryptLeft) we = helper.encode_weights_uint64s(encoder, w.data());
+        else wc = helper.encrypt_weights_uint64s(encryptor, encoder, w.data());
         double t1 = now();
         Plain2d se = helper.encode_outputs_uint64s(encoder, sbias.data());
         double t1b = now();
-        Cipher2d xe = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
+        Cipher2d xe;
+        if (objective == MatmulObjective::EncryptRight) xp = helper.encode_inputs_uint64s(encoder, x.data());
+        else xe = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
         double t2 = now();
+        // the encrypted operand travels: seed-compressed on the wire, expanded by load
         std::stringstream x_serialized;
-        xe.save(x_serialized, context);
+        Cipher2d& sent = objective == MatmulObjective::EncryptRight ? wc : xe;
+        sent.save(x_serialized, context);
         const size_t x_bytes = x_serialized.str().size();
-        xe = Cipher2d::load_new(x_serialized, context);
+        sent = Cipher2d::load_new(x_serialized, context);
+        if (objective == MatmulObjective::Crossed) wc.expand_seed(context);
         double t2b = now();
-        Cipher2d ye = helper.matmul(evaluator, xe, we);
+        auto product = [&]() {
+            if (objective == MatmulObjective::EncryptLeft) return helper.matmul(evaluator, xe, we);
+            if (objective == MatmulObjective::EncryptRight) return helper.matmul_reverse(evaluator, xp, wc);
+            Cipher2d p = helper.matmul_cipher(evaluator, xe, wc);
+            for (auto& row : p.data()) for (Ciphertext& c : row) evaluator.relinearize_inplace(c, relin_keys);
+            return p;
+        };
+        Cipher2d ye = product();
         double t3 = now();
-        for (int r = 1; r < repeat; r++) ye = helper.matmul(evaluator, xe, we);
+        for (int r = 1; r < repeat; r++) ye = product();
         double t4 = now();
         if (mod_switch) ye.mod_switch_to_next_inplace(evaluator);
         double t4a = now();
@@ -84,7 +105,7 @@ int main(int argc, char** argv) {
         double enc_rep = 0, dec_rep = 0;
         for (int r = 1; r < repeat; r++) {
             double a0 = now();
-            Cipher2d xr = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
+            Cipher2d xr = objective == MatmulObjective::EncryptRight ? Cipher2d() : helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
             double a1 = now();
             std::vector<uint64_t> gr = helper.decrypt_outputs_uint64s(encoder, decryptor, ye);
             double a2 = now();
@@ -94,6 +115,8 @@ int main(int argc, char** argv) {
         }
         size_t weights_n = 0, inputs_n = 0, outputs_n = 0;
         for (auto& r : we.data()) weights_n += r.size();
+        for (auto& r : wc.data()) weights_n += r.size();
+        for (auto& r : xp.data()) inputs_n += r.size();
         for (auto& r : xe.data()) inputs_n += r.size();
         for (auto& r : ye.data()) outputs_n += r.size();
         std::printf("objects weights %zu inputs %zu outputs %zu\n", weights_n, inputs_n, outputs_n);

@@ -135,22 +135,30 @@ def test_ckks_cpp_api(dev):
         assert float(kv[k][0]) < 1e-4, k
 
 
-@pytest.mark.parametrize("dims,pack_lwe,mod_switch", [((25, 30, 35), 0, 1), ((25, 30, 35), 1, 1),      # the example's two runs
-                                                      ((4, 600, 7), 0, 0), ((128, 64, 96), 1, 0), ((3, 5, 70), 1, 1), ((128, 64, 96), 0, 1)])
-def test_matmul_cpp_api(dev, dims, pack_lwe, mod_switch):
+@pytest.mark.parametrize("dims,pack_lwe,mod_switch,objective", [
+    ((25, 30, 35), 0, 1, "left"), ((25, 30, 35), 1, 1, "left"),                       # the example's two runs
+    ((4, 600, 7), 0, 0, "left"), ((128, 64, 96), 1, 0, "left"), ((3, 5, 70), 1, 1, "left"), ((128, 64, 96), 0, 1, "left"),
+    ((25, 30, 35), 0, 1, "right"), ((128, 64, 96), 1, 1, "right"),                     # plaintext inputs x encrypted weights
+    ((25, 30, 35), 0, 1, "crossed"), ((6, 40, 9), 0, 0, "crossed")])                   # both encrypted (BGV)
+def test_matmul_cpp_api(dev, dims, pack_lwe, mod_switch, objective):
     """BASELINE config 5 path, the whole flow of examples/10_bfv_matmul.cu: y = x * w + s with encrypted x through
     troy::linear::MatmulHelper (inputs and outputs through their wire formats, optional mod-switch and output packing)
     equals the plain result mod t."""
     drv = os.path.join(ROOT, "tests", "cpp", "matmul_driver")
     if not os.path.exists(drv):
         pytest.fail("tests/cpp/matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    r = subprocess.run([drv] + [str(d) for d in dims] + ["1", str(pack_lwe), str(mod_switch)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([drv] + [str(d) for d in dims] + ["1", str(pack_lwe), str(mod_switch), objective], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout and "mismatches 0 of %d" % (dims[0] * dims[2]) in r.stdout, r.stdout + r.stderr
     kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
     sizes = dict(zip(kv["bytes"][0::2], [int(v) for v in kv["bytes"][1::2]]))
     objs = dict(zip(kv["objects"][0::2], [int(v) for v in kv["objects"][1::2]]))
     L = 2 if mod_switch else 3
     full = 1 + 32 + 3 * 8 + 1 + 2 * L * 8192 * 8                          # one whole ciphertext on the wire (ciphertext.cu:98-139)
+    if objective == "crossed":
+        return                                                              # BGV: correction factor on the wire, unseeded operands
+    sent = objs["weights"] if objective == "right" else objs["inputs"]
+    framing = sizes["inputs"] - sent * (1 + 32 + 3 * 8 + 1 + 8 + 3 * 8192 * 8)  # seed-compressed: c0 + the 8-byte seed of c1
+    assert 16 <= framing <= 8 + 8 * sent and framing % 8 == 0                  # Cipher2d framing: row count + one size per row
     if pack_lwe:
         assert sizes["outputs"] == objs["outputs"] * full
     else:

@@ -119,22 +119,24 @@ MatmulHelper::MatmulHelper(size_t batch_size, size_t input_dims, size_t output_d
                            MemoryPoolHandle pool)
     : batch_size(batch_size), input_dims(input_dims), output_dims(output_dims), slot_count(slot_count), objective(objective), pack_lwe(pack_lwe),
       pool(std::move(pool)) {
-    if (objective != MatmulObjective::EncryptLeft) throw std::logic_error("[MatmulHelper::MatmulHelper] only MatmulObjective::EncryptLeft is part of this build.");
     determine_block();
 }
 
 void MatmulHelper::determine_block() {
     size_t best_cost = static_cast<size_t>(-1);
     if (!pack_lwe) {
-        // app/matmul.cu:103-127: choose (bb, ib, ob), bb*ib*ob <= N, minimising the number of ciphertexts that travel:
-        // encrypted inputs ceil(B/bb)*ceil(I/ib) plus encrypted outputs ceil(B/bb)*ceil(O/ob)
+        // app/matmul.cu:103-127: choose (bb, ib, ob), bb*ib*ob <= N, minimising the number of ciphertexts that travel (which
+        // operands are encrypted depends on the objective; the outputs always are)
         for (size_t bb = std::min(batch_size, slot_count - 1); bb >= 1; bb--) {
             const size_t bc = ceil_div(batch_size, bb);
             if (2 * bc > best_cost) continue;
             for (size_t ib = 1; ib <= input_dims && ib < slot_count / bb; ib++) {
                 size_t ob = std::min(slot_count / bb / ib, output_dims);
                 if (ob < 1) continue;
-                const size_t cost = bc * (ceil_div(input_dims, ib) + ceil_div(output_dims, ob));
+                size_t cost;
+                if (objective == MatmulObjective::EncryptLeft) cost = bc * (ceil_div(input_dims, ib) + ceil_div(output_dims, ob));
+                else if (objective == MatmulObjective::EncryptRight) cost = (bc + ceil_div(input_dims, ib)) * ceil_div(output_dims, ob);
+                else cost = bc * input_dims + (bc + ceil_div(input_dims, ib)) * ceil_div(output_dims, ob);
                 if (cost < best_cost) { best_cost = cost; batch_block = bb; input_block = ib; output_block = ob; }
             }
         }
@@ -150,32 +152,27 @@ void MatmulHelper::determine_block() {
             if (bb > slot_count) continue;
             size_t ob = std::min(slot_count / bb / ib, output_dims);
             if (ob < 1) continue;
-            const size_t cost = bc * ceil_div(input_dims, ib) + ceil_div(bc * ceil_div(output_dims, ob), ib);
+            const size_t packed_out = ceil_div(bc * ceil_div(output_dims, ob), ib);
+            size_t cost;
+            if (objective == MatmulObjective::EncryptLeft) cost = bc * ceil_div(input_dims, ib) + packed_out;
+            else if (objective == MatmulObjective::EncryptRight) cost = ceil_div(output_dims, ob) * ceil_div(input_dims, ib) + packed_out;
+            else cost = bc * ceil_div(input_dims, ib) + ceil_div(output_dims, ob) * ceil_div(input_dims, ib) + packed_out;
             if (cost < best_cost) { best_cost = cost; batch_block = bb; input_block = ib; output_block = ob; }
         }
     }
     if (best_cost == static_cast<size_t>(-1)) throw std::invalid_argument("[MatmulHelper::determine_block] no valid blocking for these dimensions.");
 }
 
-Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const {
-    // app/matmul.cu:160-230: coefficient packing, then centralize + NTT (the weights multiply ciphertexts).  All blocks are
-    // packed on the host into one buffer and go through ONE copy, ONE centralize launch and ONE NTT launch; the plaintext
-    // objects are windows of the shared result buffer.
-    HeContextPointer context = encoder.context();
-    if (!context->on_device()) throw std::invalid_argument("[MatmulHelper::encode_weights] HeContext is not on device (call to_device_inplace).");
-    ContextDataPointer cd = context->first_context_data().value();
-    const ParmsID first = context->first_parms_id();
-    const size_t n = cd->parms().poly_modulus_degree(), L = cd->parms().coeff_modulus().size();
-    const uint64_t t = cd->parms().plain_modulus().value();
-    const size_t rows = ceil_div(input_dims, input_block), cols = ceil_div(output_dims, output_block), count = rows * cols;
-    const size_t clen = input_block * output_block;
-    std::vector<uint64_t> packed(count * clen, 0);
+std::vector<uint64_t> MatmulHelper::pack_weight_blocks(uint64_t t, const uint64_t* weights, size_t& rows, size_t& cols, size_t& len) const {
+    // app/matmul.cu:160-175 (encode_weights_small): coefficient (j-lj)*ib + ib - (i-li) - 1 = w[i][j]
+    rows = ceil_div(input_dims, input_block); cols = ceil_div(output_dims, output_block); len = input_block * output_block;
+    std::vector<uint64_t> packed(rows * cols * len, 0);
     size_t idx = 0;
     for (size_t li = 0; li < input_dims; li += input_block) {
         const size_t ui = std::min(li + input_block, input_dims);
         for (size_t lj = 0; lj < output_dims; lj += output_block, idx++) {
             const size_t uj = std::min(lj + output_block, output_dims);
-            uint64_t* vec = packed.data() + idx * clen;
+            uint64_t* vec = packed.data() + idx * len;
             for (size_t j = lj; j < uj; j++)
                 for (size_t i = li; i < ui; i++) {
                     const uint64_t v = weights[i * output_dims + j];
@@ -184,17 +181,50 @@ Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const 
                 }
         }
     }
+    return packed;
+}
+
+std::vector<uint64_t> MatmulHelper::pack_input_blocks(uint64_t t, const uint64_t* inputs, size_t& rows, size_t& cols, size_t& len) const {
+    // app/matmul.cu:245-258 (encode_inputs_small): coefficient (i-li)*ib*ob + (j-lj) = x[i][j]
+    rows = ceil_div(batch_size, batch_block); cols = ceil_div(input_dims, input_block); len = slot_count;
+    std::vector<uint64_t> packed(rows * cols * len, 0);
+    size_t idx = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        for (size_t lj = 0; lj < input_dims; lj += input_block, idx++) {
+            const size_t uj = std::min(lj + input_block, input_dims);
+            uint64_t* vec = packed.data() + idx * len;
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) {
+                    const uint64_t v = inputs[i * input_dims + j];
+                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
+                    vec[(i - li) * input_block * output_block + (j - lj)] = v;
+                }
+        }
+    }
+    return packed;
+}
+
+Plain2d MatmulHelper::encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const {
+    // encode_for_plain + ensure_ntt_form(centralize = true) (app/matmul.cu:14-70,:200-203): all blocks go through ONE copy, ONE
+    // centralize launch and ONE NTT launch; the plaintext objects are windows of the shared result buffer
+    HeContextPointer context = encoder.context();
+    if (!context->on_device()) throw std::invalid_argument("[MatmulHelper::encode_weights] HeContext is not on device (call to_device_inplace).");
+    ContextDataPointer cd = context->first_context_data().value();
+    const ParmsID first = context->first_parms_id();
+    const size_t n = cd->parms().poly_modulus_degree(), L = cd->parms().coeff_modulus().size(), count = rows * cols;
+    const uint64_t t = cd->parms().plain_modulus().value();
     utils::DynamicArray staged(packed.size(), true, pool);
     staged.copy_from(packed.data(), packed.size(), false);
     auto shared = std::make_shared<utils::DynamicArray>(count * L * n, true, pool);
-    troyn_check_public(troyn_plain_centralize(context->plan(), static_cast<uint32_t>(L), t, staged.raw_pointer(), clen, clen, shared->raw_pointer(), count, troyn_current_stream()));
+    troyn_check_public(troyn_plain_centralize(context->plan(), static_cast<uint32_t>(L), t, staged.raw_pointer(), len, len, shared->raw_pointer(), count, troyn_current_stream()));
     troyn_check_public(troyn_ntt(context->plan(), 0, shared->raw_pointer(), shared->raw_pointer(), count, 1, L, 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0,
                                  troyn_current_stream()));
     troyn_sync_current_stream();     // `staged` returns to the pool
     Plain2d out;
-    idx = 0;
+    size_t idx = 0;
     for (size_t r = 0; r < rows; r++) {
-        std::vector<Plaintext> row;
+        std::vector<Plaintext>& row = out.new_row();
         for (size_t c = 0; c < cols; c++, idx++) {
             Plaintext p;
             p.data() = utils::DynamicArray::device_view(shared->raw_pointer() + idx * L * n, L * n, shared);
@@ -205,68 +235,86 @@ Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const 
             p.is_ntt_form() = true;
             row.push_back(std::move(p));
         }
-        out.data().push_back(std::move(row));
     }
     return out;
+}
+
+Cipher2d MatmulHelper::encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const {
+    // encode_for_cipher + ensure_ntt_form(centralize = false) + encrypt_symmetric_batched(save_seed = true) (app/matmul.cu:200-216,
+    // :296-311): one copy and one batched encryption that stays in NTT form; the ciphertexts carry the seed of c1
+    std::vector<Ciphertext> cts;
+    if (encoder.context()->first_context_data().value()->parms().scheme() == SchemeType::BFV) {
+        utils::DynamicArray staged(packed.size(), true, pool);
+        staged.copy_from(packed.data(), packed.size(), false);
+        cts = encryptor.encrypt_symmetric_packed(staged.raw_pointer(), len, len, rows * cols, pool, true);
+    } else {
+        // BGV: block by block through the encoder and Encryptor::encrypt_symmetric (NTT-form ciphertexts, no seed)
+        for (size_t k = 0; k < rows * cols; k++) {
+            const std::vector<uint64_t> block(packed.begin() + static_cast<std::ptrdiff_t>(k * len), packed.begin() + static_cast<std::ptrdiff_t>((k + 1) * len));
+            cts.push_back(encryptor.encrypt_symmetric_new(encoder.encode_polynomial_new(block, pool), false, pool));
+        }
+    }
+    Cipher2d out;
+    size_t idx = 0;
+    for (size_t r = 0; r < rows; r++) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (size_t c = 0; c < cols; c++, idx++) row.push_back(std::move(cts[idx]));
+    }
+    return out;
+}
+
+Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const {
+    size_t rows, cols, len;
+    const std::vector<uint64_t> packed = pack_weight_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), weights, rows, cols, len);
+    return encode_blocks_for_plain(encoder, packed, rows, cols, len);
+}
+
+Cipher2d MatmulHelper::encrypt_weights_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* weights) const {
+    size_t rows, cols, len;
+    const std::vector<uint64_t> packed = pack_weight_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), weights, rows, cols, len);
+    return encrypt_blocks(encryptor, encoder, packed, rows, cols, len);
 }
 
 Plain2d MatmulHelper::encode_inputs_uint64s(const BatchEncoder& encoder, const uint64_t* inputs) const {
-    // app/matmul.cu:245-300
-    Plain2d out;
-    for (size_t li = 0; li < batch_size; li += batch_block) {
-        const size_t ui = std::min(li + batch_block, batch_size);
-        std::vector<Plaintext> row;
-        for (size_t lj = 0; lj < input_dims; lj += input_block) {
-            const size_t uj = std::min(lj + input_block, input_dims);
-            std::vector<uint64_t> vec(slot_count, 0);
-            for (size_t j = lj; j < uj; j++)
-                for (size_t i = li; i < ui; i++) vec[(i - li) * input_block * output_block + (j - lj)] = inputs[i * input_dims + j];
-            row.push_back(encoder.encode_polynomial_new(vec, pool));
-        }
-        out.data().push_back(std::move(row));
-    }
-    return out;
+    size_t rows, cols, len;
+    const std::vector<uint64_t> packed = pack_input_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), inputs, rows, cols, len);
+    return encode_blocks_for_plain(encoder, packed, rows, cols, len);
 }
 
 Cipher2d MatmulHelper::encrypt_inputs_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* inputs) const {
-    // every block packed on the host, one copy, one batched symmetric encryption, one batched NTT (the same ciphertexts
-    // as encode_inputs_uint64s + encrypt_symmetric per block, see Encryptor::encrypt_symmetric_packed)
-    HeContextPointer context = encoder.context();
-    const size_t n = slot_count;
-    const uint64_t t = context->first_context_data().value()->parms().plain_modulus().value();
-    const size_t rows = ceil_div(batch_size, batch_block), cols = ceil_div(input_dims, input_block), count = rows * cols;
-    std::vector<uint64_t> packed(count * n, 0);
-    size_t idx = 0;
-    for (size_t li = 0; li < batch_size; li += batch_block) {
-        const size_t ui = std::min(li + batch_block, batch_size);
-        for (size_t lj = 0; lj < input_dims; lj += input_block, idx++) {
-            const size_t uj = std::min(lj + input_block, input_dims);
-            uint64_t* vec = packed.data() + idx * n;
-            for (size_t i = li; i < ui; i++)
-                for (size_t j = lj; j < uj; j++) {
-                    const uint64_t v = inputs[i * input_dims + j];
-                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
-                    vec[(i - li) * input_block * output_block + (j - lj)] = v;
-                }
-        }
+    size_t rows, cols, len;
+    const std::vector<uint64_t> packed = pack_input_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), inputs, rows, cols, len);
+    return encrypt_blocks(encryptor, encoder, packed, rows, cols, len);
+}
+
+// ret[b][j] = sum_i ct(b, i, j) (.) pt(b, i, j) in one multiply_plain_accumulate launch; the results are windows of one zeroed
+// buffer, so the trailing inverse NTT (BFV results leave in coefficient form) is one launch too
+template <typename CtAt, typename PtAt>
+static Cipher2d accumulate_products(const MatmulHelper& h, const Evaluator& evaluator, const Ciphertext& like, size_t batch_split, size_t input_split, size_t output_split,
+                                    CtAt ct_at, PtAt pt_at) {
+    const size_t pcnt = like.polynomial_count(), L = like.coeff_modulus_size(), n = like.poly_modulus_degree(), words = pcnt * L * n;
+    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, h.pool);
+    shared->set_zero();
+    Cipher2d ret;
+    ret.data().resize(batch_split);
+    for (size_t b = 0; b < batch_split; b++)
+        for (size_t j = 0; j < output_split; j++)
+            ret[b].push_back(Ciphertext::from_members(pcnt, L, n, like.parms_id(), like.scale(), true, like.correction_factor(), 0,
+                                                      utils::DynamicArray::device_view(shared->raw_pointer() + (b * output_split + j) * words, words, shared)));
+    std::vector<const Ciphertext*> c_ptrs;
+    std::vector<const Plaintext*> p_ptrs;
+    std::vector<Ciphertext*> r_ptrs;
+    for (size_t i = 0; i < input_split; i++)
+        for (size_t j = 0; j < output_split; j++)
+            for (size_t b = 0; b < batch_split; b++) { c_ptrs.push_back(ct_at(b, i, j)); p_ptrs.push_back(pt_at(b, i, j)); r_ptrs.push_back(&ret[b][j]); }
+    evaluator.multiply_plain_accumulate(c_ptrs, p_ptrs, r_ptrs, false, h.pool);
+    if (evaluator.context()->first_context_data().value()->parms().scheme() == SchemeType::BFV) {
+        troyn_check_public(troyn_ntt(evaluator.context()->plan(), 1, shared->raw_pointer(), shared->raw_pointer(), batch_split * output_split, pcnt,
+                                     static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
+        troyn_sync_current_stream();
+        for (auto& r : ret.data()) for (Ciphertext& c : r) c.is_ntt_form() = false;
     }
-    utils::DynamicArray staged(packed.size(), true, pool);
-    staged.copy_from(packed.data(), packed.size(), false);
-    std::vector<Ciphertext> cts = encryptor.encrypt_symmetric_packed(staged.raw_pointer(), n, n, count, pool);
-    // the products are taken in NTT form: the ciphertexts are windows of one buffer, transformed in one launch
-    const uint32_t L = static_cast<uint32_t>(cts[0].coeff_modulus_size());
-    troyn_check_public(troyn_ntt(context->plan(), 0, cts[0].data().raw_pointer(), cts[0].data().raw_pointer(), count, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0,
-                                 troyn_current_stream()));
-    for (Ciphertext& c : cts) c.is_ntt_form() = true;
-    troyn_sync_current_stream();
-    Cipher2d out;
-    idx = 0;
-    for (size_t r = 0; r < rows; r++) {
-        std::vector<Ciphertext> row;
-        for (size_t c = 0; c < cols; c++, idx++) row.push_back(std::move(cts[idx]));
-        out.data().push_back(std::move(row));
-    }
-    return out;
+    return ret;
 }
 
 Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, const Plain2d& w) const {
@@ -274,29 +322,39 @@ Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, con
     const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
     if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
     if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
-    // the results are windows of one zeroed buffer, so the trailing inverse NTT is one launch
-    const Ciphertext& a0 = a[0][0];
-    const size_t pcnt = a0.polynomial_count(), L = a0.coeff_modulus_size(), n = a0.poly_modulus_degree(), words = pcnt * L * n;
-    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, pool);
-    shared->set_zero();
+    return accumulate_products(*this, evaluator, a[0][0], batch_split, input_split, output_split,
+                               [&](size_t b, size_t i, size_t) { return &a[b][i]; }, [&](size_t, size_t i, size_t j) { return &w[i][j]; });
+}
+
+Cipher2d MatmulHelper::matmul_reverse(const Evaluator& evaluator, const Plain2d& a, const Cipher2d& w) const {
+    // app/matmul.cu:406-454: the weights are the encrypted side
+    const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
+    if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
+    if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
+    return accumulate_products(*this, evaluator, w[0][0], batch_split, input_split, output_split,
+                               [&](size_t, size_t i, size_t j) { return &w[i][j]; }, [&](size_t b, size_t i, size_t) { return &a[b][i]; });
+}
+
+Cipher2d MatmulHelper::matmul_cipher(const Evaluator& evaluator, const Cipher2d& a, const Cipher2d& w) const {
+    // app/matmul.cu:376-404
+    const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
+    if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul_cipher] Input batch_size incorrect.");
+    if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul_cipher] Weight input dimension incorrect.");
     Cipher2d ret;
-    ret.data().resize(batch_split);
-    for (size_t b = 0; b < batch_split; b++)
-        for (size_t j = 0; j < output_split; j++)
-            ret[b].push_back(Ciphertext::from_members(pcnt, L, n, a0.parms_id(), a0.scale(), true, a0.correction_factor(), 0,
-                                                      utils::DynamicArray::device_view(shared->raw_pointer() + (b * output_split + j) * words, words, shared)));
-    std::vector<const Ciphertext*> a_ptrs;
-    std::vector<const Plaintext*> w_ptrs;
-    std::vector<Ciphertext*> r_ptrs;
-    for (size_t i = 0; i < input_split; i++)
-        for (size_t j = 0; j < output_split; j++)
-            for (size_t b = 0; b < batch_split; b++) { a_ptrs.push_back(&a[b][i]); w_ptrs.push_back(&w[i][j]); r_ptrs.push_back(&ret[b][j]); }
-    evaluator.multiply_plain_accumulate(a_ptrs, w_ptrs, r_ptrs, false, pool);
-    // BFV results leave in coefficient form
-    troyn_check_public(troyn_ntt(evaluator.context()->plan(), 1, shared->raw_pointer(), shared->raw_pointer(), batch_split * output_split, pcnt,
-                                 static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
-    troyn_sync_current_stream();
-    for (auto& r : ret.data()) for (Ciphertext& c : r) c.is_ntt_form() = false;
+    for (size_t b = 0; b < batch_split; b++) {
+        std::vector<Ciphertext>& row = ret.new_row();
+        row.resize(output_split);
+        for (size_t j = 0; j < output_split; j++) {
+            std::vector<const Ciphertext*> lhs, rhs;
+            for (size_t i = 0; i < input_split; i++) { lhs.push_back(&a[b][i]); rhs.push_back(&w[i][j]); }
+            std::vector<Ciphertext> prods(input_split);
+            std::vector<Ciphertext*> pp;
+            for (Ciphertext& c : prods) pp.push_back(&c);
+            evaluator.multiply_batched(lhs, rhs, pp, pool);
+            row[j] = std::move(prods[0]);
+            for (size_t i = 1; i < input_split; i++) evaluator.add_inplace(row[j], prods[i], pool);
+        }
+    }
     return ret;
 }
 

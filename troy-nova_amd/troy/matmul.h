@@ -1,9 +1,10 @@
 // matmul.h -- troy::linear::MatmulHelper, the BFV matrix product of the reference's matmul application
 // (src/app/matmul.h, matmul.cu; BASELINE config 5 = examples/10_bfv_matmul.cu at 512x512x512) on top of the mirror API.
 //
-// Supported here: BFV with BatchEncoder polynomial (coefficient) packing, encrypted inputs x plaintext weights
-// (MatmulObjective::EncryptLeft, the example's configuration), with and without packing of the outputs (pack_lwe),
-// output mod-switch, bias addition and the outputs' partial wire format.  Layout, as the reference:
+// Supported here: BFV (and BGV for the ciphertext x ciphertext product) with BatchEncoder polynomial (coefficient) packing; the three
+// objectives -- encrypted inputs x plaintext weights (EncryptLeft, the example's configuration), plaintext inputs x encrypted
+// weights (EncryptRight), both encrypted (Crossed) -- with and without packing of the outputs (pack_lwe), output mod-switch,
+// bias addition and the outputs' partial wire format.  Layout, as the reference:
 //   input block  (batch rows li..ui, input columns lj..uj):   coefficient (i-li)*ib*ob + (j-lj)              = x[i][j]
 //   weight block (input rows li..ui, output columns lj..uj):  coefficient (j-lj)*ib + ib - (i-li) - 1         = w[i][j]
 //   output block: y[i][j] is coefficient (i-li)*ib*ob + (j-lj)*ib + ib - 1 of sum_k input[b][k] * weight[k][j-block]
@@ -80,13 +81,20 @@ public:
     MatmulHelper(size_t batch_size, size_t input_dims, size_t output_dims, size_t slot_count,
                  MatmulObjective objective = MatmulObjective::EncryptLeft, bool pack_lwe = true, MemoryPoolHandle pool = MemoryPool::GlobalPool());
 
-    // weights [input_dims][output_dims] row-major -> NTT-form plaintexts [ceil(in/ib)][ceil(out/ob)]
+    // weights [input_dims][output_dims] row-major -> [ceil(in/ib)][ceil(out/ob)] NTT-form plaintexts (centred lift: they multiply
+    // ciphertexts) or NTT-form ciphertexts carrying their c1 seed (scaled up by q/t; expand_seed / load before use)
     Plain2d encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const;
-    // inputs [batch_size][input_dims] row-major -> plaintexts / ciphertexts [ceil(batch/bb)][ceil(in/ib)]
+    Cipher2d encrypt_weights_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* weights) const;
+    // inputs [batch_size][input_dims] row-major -> [ceil(batch/bb)][ceil(in/ib)], the same two forms
     Plain2d encode_inputs_uint64s(const BatchEncoder& encoder, const uint64_t* inputs) const;
     Cipher2d encrypt_inputs_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* inputs) const;
     // ret[b][j] = sum_i a[b][i] * w[i][j]: ONE multiply_plain_accumulate launch over all (i, j, b) terms
     Cipher2d matmul(const Evaluator& evaluator, const Cipher2d& a, const Plain2d& w) const;
+    // the same product with the roles exchanged (MatmulObjective::EncryptRight): plaintext inputs x encrypted weights
+    Cipher2d matmul_reverse(const Evaluator& evaluator, const Plain2d& a, const Cipher2d& w) const;
+    // both operands encrypted (MatmulObjective::Crossed): ciphertext products; as in the reference this needs a scheme whose
+    // ciphertexts multiply in NTT form (CKKS / BGV) -- BFV operands in NTT form are refused by Evaluator::multiply
+    Cipher2d matmul_cipher(const Evaluator& evaluator, const Cipher2d& a, const Cipher2d& w) const;
     // outputs [batch_size][output_dims] row-major, values mod t
     std::vector<uint64_t> decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
     // a bias / share [batch_size][output_dims] laid out like the (packed or unpacked) outputs, for Cipher2d::add_plain_inplace
@@ -103,6 +111,11 @@ public:
 
 private:
     void determine_block();
+    // the blocks of a [rows][cols] matrix as coefficient vectors of length `len`, back to back, packed by `place(i, j)`
+    Plain2d encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const;
+    Cipher2d encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const;
+    std::vector<uint64_t> pack_weight_blocks(uint64_t t, const uint64_t* weights, size_t& rows, size_t& cols, size_t& len) const;
+    std::vector<uint64_t> pack_input_blocks(uint64_t t, const uint64_t* inputs, size_t& rows, size_t& cols, size_t& len) const;
 };
 
 }}  // namespace troy::linear

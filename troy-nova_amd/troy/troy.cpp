@@ -1963,7 +1963,8 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
     }
 }
 
-std::vector<Ciphertext> Encryptor::encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count, MemoryPoolHandle pool) const {
+std::vector<Ciphertext> Encryptor::encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count, MemoryPoolHandle pool,
+                                                            bool ntt_seeded) const {
     // rlwe::symmetric (utils/rlwe.cu:218-317) + multiply_add_plain for `count` BFV plaintexts, batched.  Ciphertext i uses
     // exactly the generator blocks a sequential call would: block base + i*(1 + N/2) for its c1 seed, the next N/2 blocks
     // for its noise.
@@ -1993,8 +1994,28 @@ std::vector<Ciphertext> Encryptor::encrypt_symmetric_packed(const uint64_t* plai
     utils::DynamicArray c0(count * pc, true, pool), c1(count * pc, true, pool), noise(count * pc, true, pool);
     troyn_check(troyn_sample_uniform_multi(plan, L, seeds.data(), c1.raw_pointer(), count, s));
     troyn_check(troyn_sample_centered_binomial_strided(plan, L, prng.seed(), base + 1, per_ct, noise.raw_pointer(), count, s));
-    // c0 = -(INTT(c1 (.) s) + e) + round(q/t * m); c1 is sampled as an NTT-form polynomial and leaves in coefficient form
     troyn_check(troyn_dyadic_broadcast_product(plan, 0, L, c1.raw_pointer(), 1, secret_key_.value().data().raw_pointer(), 0, c0.raw_pointer(), count, s));
+    if (ntt_seeded) {
+        // everything stays in NTT form: c0 = -(c1 (.) s + NTT(e)) + NTT(round(q/t * m)); c1 is the sampled polynomial itself and
+        // is reproduced from its seed by expand_seed (rlwe::symmetric with is_ntt_form && save_seed, then the NTT-form plaintext
+        // is added, encryptor.cu:269-284)
+        utils::DynamicArray dm(count * pc, true, pool);
+        troyn_check(troyn_bfv_scale_up(context_->behz(L), plains, coeff_count, stride, nullptr, 0, dm.raw_pointer(), pc, 0, count, s));
+        troyn_check(troyn_ntt(plan, 0, dm.raw_pointer(), dm.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        troyn_check(troyn_ntt(plan, 0, noise.raw_pointer(), noise.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        troyn_check(troyn_add(plan, 0, L, c0.raw_pointer(), noise.raw_pointer(), c0.raw_pointer(), count, s));
+        troyn_check(troyn_negate(plan, 0, L, c0.raw_pointer(), c0.raw_pointer(), count, s));
+        troyn_check(troyn_add(plan, 0, L, c0.raw_pointer(), dm.raw_pointer(), c0.raw_pointer(), count, s));
+        auto block = std::make_shared<utils::DynamicArray>(count * 2 * pc, true, pool);
+        hip_check(hipMemcpy2DAsync(block->raw_pointer(), 2 * pc * 8, c0.raw_pointer(), pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+        hip_check(hipMemcpy2DAsync(block->raw_pointer() + pc, 2 * pc * 8, c1.raw_pointer(), pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, s), "copy_device_to_device");
+        hip_check(hipStreamSynchronize(s), "stream_sync");
+        out.reserve(count);
+        for (size_t i = 0; i < count; i++)
+            out.push_back(Ciphertext::from_members(2, L, n, cd->parms_id(), 1.0, true, 1, seeds[2 * i], utils::DynamicArray::device_view(block->raw_pointer() + i * 2 * pc, 2 * pc, block)));
+        return out;
+    }
+    // c0 = -(INTT(c1 (.) s) + e) + round(q/t * m); c1 is sampled as an NTT-form polynomial and leaves in coefficient form
     troyn_check(troyn_ntt(plan, 1, c0.raw_pointer(), c0.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
     troyn_check(troyn_add(plan, 0, L, c0.raw_pointer(), noise.raw_pointer(), c0.raw_pointer(), count, s));
     troyn_check(troyn_negate(plan, 0, L, c0.raw_pointer(), c0.raw_pointer(), count, s));

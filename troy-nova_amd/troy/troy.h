@@ -563,8 +563,10 @@ public:
     void encrypt_symmetric_batched(const std::vector<const Plaintext*>& plain, bool save_seed, const std::vector<Ciphertext*>& destination,
                                    MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     // the same for `count` BFV plaintexts (parms_id_zero, coefficient form) already on the device, `stride` words apart
+    // ntt_seeded: the form MatmulHelper sends (app/matmul.cu:300-311, encrypt_symmetric_batched(.., save_seed = true) of scaled-up
+    // NTT-form plaintexts): NTT-form ciphertexts that carry the seed of c1 (half the wire size; expand_seed before use)
     std::vector<Ciphertext> encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count,
-                                                     MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+                                                     MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool ntt_seeded = false) const;
     void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_asymmetric(d, parms_id, pool); return d; }
     void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
