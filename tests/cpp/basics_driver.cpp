@@ -1,0 +1,77 @@
+// C++ driver for tests/test_gpu_cpp_api.py::test_basics_cpp_api, in the spirit of examples/1_bfv_basics.cu and 3_levels.cu:
+// SEAL's default parameters (CoeffModulus::bfv_default), context qualifiers, the invariant noise budget along a computation
+// (fresh > after a multiplication > ... > 0, at which point decryption stops being correct), modulus switching down the chain.
+#include <cstdio>
+#include <random>
+
+#include "../../troy-nova_amd/troy/troy.h"
+
+using namespace troy;
+
+int main() {
+    try {
+        const size_t n = 4096;
+        const uint64_t t = 1024;                                     // the example's non-batching plain modulus
+        EncryptionParameters params(SchemeType::BFV);
+        params.set_poly_modulus_degree(n);
+        params.set_coeff_modulus(CoeffModulus::bfv_default(n));
+        params.set_plain_modulus(t);
+        HeContextPointer context = HeContext::create(params, true, SecurityLevel::Classical128, 0x1b);
+        ContextDataPointer key = context->key_context_data().value(), first = context->first_context_data().value();
+        std::printf("chain %zu primes, key level %zu bits, first level %zu bits\n", key->parms().coeff_modulus().size(), key->total_coeff_modulus_bit_count(),
+                    first->total_coeff_modulus_bit_count());
+        std::printf("qualifiers batching %d fast_plain_lift %d descending %d security %d\n", first->qualifiers().using_batching ? 1 : 0,
+                    first->qualifiers().using_fast_plain_lift ? 1 : 0, first->qualifiers().using_descending_modulus_chain ? 1 : 0,
+                    static_cast<int>(first->qualifiers().security_level));
+        context->to_device_inplace();
+        BatchEncoder encoder(context);
+        KeyGenerator keygen(context);
+        Encryptor encryptor(context);
+        encryptor.set_public_key(keygen.create_public_key(false));
+        Decryptor decryptor(context, keygen.secret_key());
+        Evaluator ev(context);
+        RelinKeys rk = keygen.create_relin_keys(false);
+
+        // x = 6 as the constant polynomial; evaluate (x^2 + 1) and (x + 1)^2, then their product 4x^4 + 8x^3 + 8x^2 + 8x + 4 = 4 (x^2+1)(x+1)^2
+        const uint64_t x = 6;
+        Ciphertext cx = encryptor.encrypt_asymmetric_new(encoder.encode_polynomial_new({x}));
+        const size_t fresh = decryptor.invariant_noise_budget(cx);
+        Plaintext one = encoder.encode_polynomial_new({1}), four = encoder.encode_polynomial_new({4});
+        Ciphertext a = ev.add_plain_new(ev.square_new(cx), one);      // x^2 + 1, three polynomials
+        const size_t after_square = decryptor.invariant_noise_budget(a);
+        ev.relinearize_inplace(a, rk);
+        const size_t after_relin = decryptor.invariant_noise_budget(a);
+        Ciphertext b = ev.add_plain_new(cx, one);
+        ev.square_inplace(b);
+        ev.relinearize_inplace(b, rk);
+        Ciphertext r = ev.multiply_new(a, b);
+        ev.relinearize_inplace(r, rk);
+        ev.multiply_plain_inplace(r, four);
+        const size_t final_budget = decryptor.invariant_noise_budget(r);
+        const uint64_t want = (4 * x * x * x * x + 8 * x * x * x + 8 * x * x + 8 * x + 4) % t;
+        const uint64_t got = encoder.decode_polynomial_new(decryptor.decrypt_new(r))[0];
+        std::printf("noise budget fresh %zu after_square %zu after_relinearize %zu final %zu\n", fresh, after_square, after_relin, final_budget);
+        std::printf("polynomial got %llu want %llu\n", (unsigned long long)got, (unsigned long long)want);
+        bool ok = got == want && fresh > after_square && after_square >= after_relin && after_relin > final_budget && final_budget > 0;
+
+        // 3_levels: the budget shrinks with the modulus, the value survives
+        Ciphertext low = ev.mod_switch_to_next_new(cx);
+        const size_t low_budget = decryptor.invariant_noise_budget(low);
+        std::printf("mod_switch level %zu budget %zu value %llu\n", context->get_context_data(low.parms_id()).value()->chain_index(), low_budget,
+                    (unsigned long long)encoder.decode_polynomial_new(decryptor.decrypt_new(low))[0]);
+        ok = ok && low_budget < fresh && low_budget > 0 && encoder.decode_polynomial_new(decryptor.decrypt_new(low))[0] == x;
+
+        // exhaust the budget: repeated squaring ends at 0 bits and a wrong decryption
+        Ciphertext s = cx;
+        size_t budget = fresh, steps = 0;
+        while (budget > 0 && steps < 12) { ev.square_inplace(s); ev.relinearize_inplace(s, rk); budget = decryptor.invariant_noise_budget(s); steps++; }
+        std::printf("budget exhausted after %zu squarings (budget %zu)\n", steps, budget);
+        ok = ok && budget == 0 && steps >= 2 && steps < 12;
+        std::printf(ok ? "OK\n" : "FAIL\n");
+        MemoryPool::Destroy();
+        return ok ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 1;
+    }
+}

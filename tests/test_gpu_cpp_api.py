@@ -210,3 +210,15 @@ def test_multithread_cpp_api(dev):
         pytest.fail("tests/cpp/multithread_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv, "4", "8"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "completed 32 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_basics_cpp_api(dev):
+    """examples/1_bfv_basics.cu and 3_levels.cu in spirit: SEAL's default chain, qualifiers, the invariant noise budget shrinking
+    along a computation and with the modulus, until it reaches zero and decryption stops being correct"""
+    drv = os.path.join(ROOT, "tests", "cpp", "basics_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/basics_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert "chain 3 primes, key level 109 bits, first level 72 bits" in r.stdout          # bfv_default(4096): 36 + 36 + 37 bits
+    assert "qualifiers batching 0 fast_plain_lift 1 descending 1 security 1" in r.stdout

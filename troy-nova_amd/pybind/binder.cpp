@@ -70,7 +70,8 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("__repr__", [](const Modulus& s) { return "Modulus(" + std::to_string(s.value()) + ")"; });
     py::class_<CoeffModulus>(m, "CoeffModulus")
         .def_static("max_bit_count", &CoeffModulus::max_bit_count, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128)
-        .def_static("create", &CoeffModulus::create, py::arg("poly_modulus_degree"), py::arg("bit_sizes"));
+        .def_static("create", &CoeffModulus::create, py::arg("poly_modulus_degree"), py::arg("bit_sizes"))
+        .def_static("bfv_default", [](size_t n, SecurityLevel sec) { return CoeffModulus::bfv_default(n, sec); }, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128);
     py::class_<PlainModulus>(m, "PlainModulus").def_static("batching", &PlainModulus::batching, py::arg("poly_modulus_degree"), py::arg("bit_size"));
 
     py::class_<ParmsID>(m, "ParmsID")
@@ -192,6 +193,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def(py::init([](HeContextPointer c, const SecretKey& sk, PoolArg p) { return new Decryptor(c, sk, P(p)); }), py::arg("context"), py::arg("secret_key"), POOL)
         .def("to_device_inplace", [](Decryptor&, PoolArg) {}, POOL).def("on_device", &Decryptor::on_device)
         .def("decrypt", [](const Decryptor& s, const Ciphertext& c, Plaintext& d, PoolArg p) { s.decrypt(c, d, P(p)); }, py::arg("encrypted"), py::arg("destination"), POOL)
+        .def("invariant_noise_budget", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.invariant_noise_budget(c, P(p)); }, py::arg("encrypted"), POOL)
         .def("decrypt_new", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.decrypt_new(c, P(p)); }, py::arg("encrypted"), POOL);
 
     py::class_<BatchEncoder>(m, "BatchEncoder")

@@ -315,6 +315,44 @@ size_t CoeffModulus::max_bit_count(size_t n, SecurityLevel sec) {
     return it->second[static_cast<size_t>(sec) - 1];
 }
 
+std::vector<Modulus> CoeffModulus::bfv_default(size_t poly_modulus_degree, SecurityLevel sec_level) {
+    // coeff_modulus.cu:6-63.  The chains are SEAL's published defaults (data, not logic): rows = (security level, degree).
+    struct Row { SecurityLevel sec; size_t n; std::vector<uint64_t> q; };
+    static const std::vector<Row> table = {
+        {SecurityLevel::Classical128, 1024, {0x7e00001}},
+        {SecurityLevel::Classical128, 2048, {0x3fffffff000001}},
+        {SecurityLevel::Classical128, 4096, {0xffffee001, 0xffffc4001, 0x1ffffe0001}},
+        {SecurityLevel::Classical128, 8192, {0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001}},
+        {SecurityLevel::Classical128, 16384, {0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001, 0x1ffffffee8001, 0x1ffffffea0001,
+                                              0x1ffffffe88001, 0x1ffffffe48001}},
+        {SecurityLevel::Classical128, 32768, {0x7fffffffe90001, 0x7fffffffbf0001, 0x7fffffffbd0001, 0x7fffffffba0001, 0x7fffffffaa0001, 0x7fffffffa50001,
+                                              0x7fffffff9f0001, 0x7fffffff7e0001, 0x7fffffff770001, 0x7fffffff380001, 0x7fffffff330001, 0x7fffffff2d0001,
+                                              0x7fffffff170001, 0x7fffffff150001, 0x7ffffffef00001, 0xfffffffff70001}},
+        {SecurityLevel::Classical192, 1024, {0x7f001}},
+        {SecurityLevel::Classical192, 2048, {0x1ffffc0001}},
+        {SecurityLevel::Classical192, 4096, {0x1ffc001, 0x1fce001, 0x1fc0001}},
+        {SecurityLevel::Classical192, 8192, {0x3ffffac001, 0x3ffff54001, 0x3ffff48001, 0x3ffff28001}},
+        {SecurityLevel::Classical192, 16384, {0x3ffffffdf0001, 0x3ffffffd48001, 0x3ffffffd20001, 0x3ffffffd18001, 0x3ffffffcd0001, 0x3ffffffc70001}},
+        {SecurityLevel::Classical192, 32768, {0x3fffffffd60001, 0x3fffffffca0001, 0x3fffffff6d0001, 0x3fffffff5d0001, 0x3fffffff550001, 0x7fffffffe90001,
+                                              0x7fffffffbf0001, 0x7fffffffbd0001, 0x7fffffffba0001, 0x7fffffffaa0001, 0x7fffffffa50001}},
+        {SecurityLevel::Classical256, 1024, {0x3001}},
+        {SecurityLevel::Classical256, 2048, {0x1ffc0001}},
+        {SecurityLevel::Classical256, 4096, {0x3ffffffff040001}},
+        {SecurityLevel::Classical256, 8192, {0x7ffffec001, 0x7ffffb0001, 0xfffffdc001}},
+        {SecurityLevel::Classical256, 16384, {0x7ffffffc8001, 0x7ffffff00001, 0x7fffffe70001, 0xfffffffd8001, 0xfffffffa0001}},
+        {SecurityLevel::Classical256, 32768, {0xffffffff00001, 0x1fffffffe30001, 0x1fffffffd80001, 0x1fffffffd10001, 0x1fffffffc50001, 0x1fffffffbf0001,
+                                              0x1fffffffb90001, 0x1fffffffb60001, 0x1fffffffa50001}},
+    };
+    if (sec_level == SecurityLevel::Nil) throw std::invalid_argument("[CoeffModulus::bfv_default_vector] No default for Nil security.");
+    for (const Row& r : table)
+        if (r.sec == sec_level && r.n == poly_modulus_degree) {
+            std::vector<Modulus> out;
+            for (uint64_t v : r.q) out.emplace_back(v);
+            return out;
+        }
+    throw std::invalid_argument("[CoeffModulus::bfv_default_vector] Invalid poly_modulus_degree or sec_level.");
+}
+
 std::vector<Modulus> CoeffModulus::create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
     // coeff_modulus.cu:65-108 -- prime search lives in libtroyn's host helpers
     std::vector<uint64_t> out(bit_sizes.size());
@@ -434,12 +472,36 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
     auto add = [&](const EncryptionParameters& p) {
         auto cd = std::make_shared<ContextData>();
         cd->parms_ = p;
+        // context_data.cu:137-218,:330-336
+        EncryptionParameterQualifiers& ql = cd->qualifiers_;
+        ql.security_level = sec_level;
+        const auto& q = p.coeff_modulus();
+        ql.using_descending_modulus_chain = true;
+        for (size_t i = 1; i < q.size(); i++) if (q[i - 1].value() <= q[i].value()) ql.using_descending_modulus_chain = false;
+        {
+            std::vector<uint64_t> prod{1};
+            for (const Modulus& m : q) {
+                uint64_t carry = 0;
+                for (uint64_t& w : prod) { const unsigned __int128 v = static_cast<unsigned __int128>(w) * m.value() + carry; w = static_cast<uint64_t>(v); carry = static_cast<uint64_t>(v >> 64); }
+                if (carry) prod.push_back(carry);
+            }
+            size_t bits = (prod.size() - 1) * 64;
+            for (uint64_t top = prod.back(); top; top >>= 1) bits++;
+            cd->total_coeff_modulus_bit_count_ = bits;
+        }
+        if (p.scheme() == SchemeType::BFV || p.scheme() == SchemeType::BGV) {
+            const uint64_t t = p.plain_modulus().value();
+            ql.using_batching = t > 1 && p.plain_modulus().is_prime() && (t - 1) % (2 * p.poly_modulus_degree()) == 0;
+            ql.using_fast_plain_lift = true;
+            for (const Modulus& m : q) if (m.value() <= t) ql.using_fast_plain_lift = false;
+        }
         he->map_[p.parms_id()] = cd;
         return cd;
     };
     auto key_cd = add(parms);
     he->key_parms_id_ = parms.parms_id();
     he->parameters_set_ = validate_parms(parms, sec_level);
+    key_cd->qualifiers_.parameters_set = he->parameters_set_;
     auto drop_last = [](const EncryptionParameters& p) {
         EncryptionParameters nx = p;
         std::vector<Modulus> q(p.coeff_modulus().begin(), p.coeff_modulus().end() - 1);
@@ -2230,6 +2292,65 @@ void Decryptor::decrypt_batched(const std::vector<const Ciphertext*>& encrypted,
         out.poly_modulus_degree() = n;
         *destination[i] = std::move(out);
     }
+}
+
+size_t Decryptor::invariant_noise_budget(const Ciphertext& encrypted, MemoryPoolHandle pool) const {
+    // decryptor.cu:581-640
+    const char* P = "[Decryptor::invariant_noise_budget]";
+    require_device_context(P, context_);
+    if (encrypted.polynomial_count() < 2) throw std::invalid_argument(std::string(P) + " Ciphertext is invalid.");
+    const SchemeType scheme = context_->first_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument(std::string(P) + " Unsupported scheme.");
+    if (!encrypted.on_device()) throw std::invalid_argument(std::string(P) + " Operand is on host; the decryptor runs on the GPU only.");
+    auto cdo = context_->get_context_data(encrypted.parms_id());
+    if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " Ciphertext parms_id is not valid.");
+    ContextDataPointer cd = cdo.value();
+    const auto& q = cd->parms().coeff_modulus();
+    const size_t L = q.size(), n = cd->parms().poly_modulus_degree();
+    // c(s) = Delta m + v: the phase in coefficient form, times t for BFV (so that the message term vanishes mod q)
+    utils::DynamicArray noise(L * n, true, pool);
+    dot_product_ct_sk_array(encrypted, noise.raw_pointer(), pool);
+    if (encrypted.is_ntt_form())
+        troyn_check(troyn_ntt(context_->plan(), 1, noise.raw_pointer(), noise.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    if (scheme == SchemeType::BFV)
+        troyn_check(troyn_multiply_scalar(context_->plan(), 0, static_cast<uint32_t>(L), noise.raw_pointer(), cd->parms().plain_modulus().value(), noise.raw_pointer(), 1, current_stream()));
+    const std::vector<uint64_t> h = noise.to_vector();
+    // CRT composition as mixed-radix digits x = d_0 + q_0 (d_1 + q_1 (...)); the centred magnitude min(x, Q - x) of every
+    // coefficient, the largest one as a multi-word integer, its bit length
+    auto mulmod = [](uint64_t a, uint64_t b, uint64_t m) { return static_cast<uint64_t>(static_cast<unsigned __int128>(a) * b % m); };
+    auto invmod = [&](uint64_t a, uint64_t m) { uint64_t r = 1, e = m - 2, b = a % m; while (e) { if (e & 1) r = mulmod(r, b, m); b = mulmod(b, b, m); e >>= 1; } return r; };
+    std::vector<std::vector<uint64_t>> inv(L);
+    for (size_t i = 0; i < L; i++) for (size_t j = 0; j < i; j++) inv[i].push_back(invmod(q[j].value() % q[i].value(), q[i].value()));
+    std::vector<uint64_t> d(L), best(L, 0);
+    for (size_t x = 0; x < n; x++) {
+        for (size_t i = 0; i < L; i++) {
+            const uint64_t qi = q[i].value();
+            uint64_t v = h[i * n + x] % qi;
+            for (size_t j = 0; j < i; j++) { const uint64_t dj = d[j] % qi; v = mulmod(v >= dj ? v - dj : v + qi - dj, inv[i][j], qi); }
+            d[i] = v;
+        }
+        // x > Q/2  <=>  2x > Q: compare 2x with Q digit-wise from the top (Q = all digits q_i - 1, plus one)
+        std::vector<uint64_t> c(L);                         // Q - x
+        for (size_t i = 0; i < L; i++) c[i] = q[i].value() - 1 - d[i];
+        for (size_t i = 0; i < L; i++) { if (++c[i] < q[i].value()) break; c[i] = 0; }
+        bool x_is_smaller = true;                           // lexicographic compare of (d) and (c) from the most significant digit
+        for (size_t i = L; i-- > 0;) { if (d[i] != c[i]) { x_is_smaller = d[i] < c[i]; break; } }
+        const std::vector<uint64_t>& mag = x_is_smaller ? d : c;
+        bool larger = false;
+        for (size_t i = L; i-- > 0;) { if (mag[i] != best[i]) { larger = mag[i] > best[i]; break; } }
+        if (larger) best = mag;
+    }
+    std::vector<uint64_t> words{0};
+    for (size_t i = L; i-- > 0;) {                          // words = words * q_i + best_i
+        uint64_t carry = best[i];
+        for (uint64_t& w : words) { const unsigned __int128 v = static_cast<unsigned __int128>(w) * q[i].value() + carry; w = static_cast<uint64_t>(v); carry = static_cast<uint64_t>(v >> 64); }
+        if (carry) words.push_back(carry);
+    }
+    while (words.size() > 1 && words.back() == 0) words.pop_back();
+    size_t norm_bits = (words.size() - 1) * 64;
+    for (uint64_t top = words.back(); top; top >>= 1) norm_bits++;
+    const int64_t diff = static_cast<int64_t>(cd->total_coeff_modulus_bit_count()) - static_cast<int64_t>(norm_bits) - 1;
+    return diff < 0 ? 0 : static_cast<size_t>(diff);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -173,6 +173,8 @@ class CoeffModulus {
 public:
     static size_t max_bit_count(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
     static std::vector<Modulus> create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes);
+    // coeff_modulus.cu:6-63: SEAL's default BFV chains per degree and security level
+    static std::vector<Modulus> bfv_default(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
 };
 
 class PlainModulus {
@@ -230,9 +232,21 @@ class ContextData;
 using ContextDataPointer = std::shared_ptr<const ContextData>;
 using HeContextPointer = std::shared_ptr<HeContext>;
 
+// encryption_parameters.h:277-289
+struct EncryptionParameterQualifiers {
+    bool parameters_set = false;
+    bool using_fft = true, using_ntt = true;
+    bool using_batching = false;                 // t is an NTT prime for this degree (BFV / BGV)
+    bool using_fast_plain_lift = false;          // every q_i > t
+    bool using_descending_modulus_chain = false;
+    SecurityLevel security_level = SecurityLevel::Nil;
+};
+
 class ContextData {
 public:
     const EncryptionParameters& parms() const { return parms_; }
+    const EncryptionParameterQualifiers& qualifiers() const { return qualifiers_; }
+    size_t total_coeff_modulus_bit_count() const { return total_coeff_modulus_bit_count_; }
     const ParmsID& parms_id() const { return parms_.parms_id(); }
     size_t chain_index() const { return chain_index_; }
     std::optional<ContextDataPointer> next_context_data() const { return next_ ? std::optional<ContextDataPointer>(next_) : std::nullopt; }
@@ -246,6 +260,8 @@ public:
 private:
     friend class HeContext;
     EncryptionParameters parms_;
+    EncryptionParameterQualifiers qualifiers_;
+    size_t total_coeff_modulus_bit_count_ = 0;
     size_t chain_index_ = 0;
     std::shared_ptr<const ContextData> next_;
     std::weak_ptr<const ContextData> prev_;
@@ -586,6 +602,9 @@ public:
     bool on_device() const { return secret_key_array_.on_device(); }
     void decrypt(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext decrypt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; decrypt(encrypted, d, pool); return d; }
+    // decryptor.cu:581-640 (BFV / BGV): bits of room left before decryption fails; the phase is formed on the device, the
+    // centred infinity norm of its CRT composition (a diagnostic, outside the hot path) on the host
+    size_t invariant_noise_budget(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     // decryptor.h decrypt_batched (BFV two-polynomial ciphertexts of one level take the batched path; anything else loops)
     void decrypt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     // the plaintext coefficients of every ciphertext, concatenated on the host ([count][N]); one device-to-host copy
@@ -638,13 +657,17 @@ public:
                                MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext encode_complex64_simd_new(const std::vector<std::complex<double>>& values, std::optional<ParmsID> parms_id, double scale,
                                         MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_complex64_simd(values, parms_id, scale, p, pool); return p; }
+    // the same value in every slot = a constant polynomial (ckks_encoder.h:120-135)
+    void encode_float64_single(double value, std::optional<ParmsID> parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        set_plaintext(std::vector<double>{value * scale}, parms_id.value_or(context_->first_parms_id()), scale, destination, pool);
+    }
+    Plaintext encode_float64_single_new(double value, std::optional<ParmsID> parms_id, double scale, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext p; encode_float64_single(value, parms_id, scale, p, pool); return p;
+    }
     void encode_float64_polynomial(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
                                    MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext encode_float64_polynomial_new(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale,
                                             MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_float64_polynomial(values, parms_id, scale, p, pool); return p; }
-    Plaintext encode_float64_single_new(double value, std::optional<ParmsID> parms_id, double scale, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        return encode_float64_polynomial_new({value}, parms_id, scale, pool);   // a constant polynomial = the value in every slot
-    }
     void decode_complex64_simd(const Plaintext& plain, std::vector<std::complex<double>>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<std::complex<double>> decode_complex64_simd_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
         std::vector<std::complex<double>> v; decode_complex64_simd(plain, v, pool); return v;
