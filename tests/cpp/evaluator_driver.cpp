@@ -65,13 +65,14 @@ static bool throws_invalid_argument(F&& f) {
 
 int main(int argc, char** argv) {
     if (argc < 6) { std::cerr << "usage: evaluator_driver <ckks|bfv> <N> <t> <out.bin> <bits...>\n"; return 2; }
-    const bool ckks = std::strcmp(argv[1], "ckks") == 0;
+    const bool ckks = std::strcmp(argv[1], "ckks") == 0, bgv = std::strcmp(argv[1], "bgv") == 0;
+    const bool ntt = ckks || bgv;            // CKKS and BGV ciphertexts live in NTT form
     const size_t n = std::strtoull(argv[2], nullptr, 10);
     const uint64_t t = std::strtoull(argv[3], nullptr, 10);
     std::vector<size_t> bits;
     for (int i = 5; i < argc; i++) bits.push_back(std::strtoull(argv[i], nullptr, 10));
 
-    EncryptionParameters parms(ckks ? SchemeType::CKKS : SchemeType::BFV);
+    EncryptionParameters parms(ckks ? SchemeType::CKKS : bgv ? SchemeType::BGV : SchemeType::BFV);
     parms.set_poly_modulus_degree(n);
     parms.set_coeff_modulus(CoeffModulus::create(n, bits));
     if (!ckks) parms.set_plain_modulus(t);
@@ -82,8 +83,8 @@ int main(int argc, char** argv) {
     const double scale = 1099511627776.0;   // 2^40
 
     int failures = 0;
-    Ciphertext a = random_ct(context, first, 11, 2, ckks, scale);
-    Ciphertext b = random_ct(context, first, 29, 2, ckks, scale);
+    Ciphertext a = random_ct(context, first, 11, 2, ntt, ckks ? scale : 1.0);
+    Ciphertext b = random_ct(context, first, 29, 2, ntt, ckks ? scale : 1.0);
     RelinKeys rk = random_relin_keys(context, 7);
 
     // device / host duality: the evaluator refuses host operands and an un-moved context
@@ -102,7 +103,7 @@ int main(int argc, char** argv) {
     dump(f, evaluator.add_new(a, b));
     dump(f, evaluator.sub_new(a, b));
     dump(f, evaluator.negate_new(a));
-    dump(f, ckks ? evaluator.transform_from_ntt_new(a) : evaluator.transform_to_ntt_new(a));
+    dump(f, ntt ? evaluator.transform_from_ntt_new(a) : evaluator.transform_to_ntt_new(a));
     // in-place flavours must agree with the _new flavours
     Ciphertext p2 = a;
     evaluator.multiply_inplace(p2, b);
@@ -123,12 +124,14 @@ int main(int argc, char** argv) {
     }
     // error behaviour mirrored from the reference
     if (!throws_invalid_argument([&] { evaluator.multiply_new(a, next); })) { std::cerr << "FAIL: parms mismatch accepted\n"; failures++; }
-    if (ckks) {
-        if (!throws_invalid_argument([&] { Ciphertext c = evaluator.transform_from_ntt_new(a); evaluator.multiply_new(c, c); })) { std::cerr << "FAIL: non-NTT CKKS multiply accepted\n"; failures++; }
+    if (ntt) {
+        if (!throws_invalid_argument([&] { Ciphertext c = evaluator.transform_from_ntt_new(a); evaluator.multiply_new(c, c); })) { std::cerr << "FAIL: non-NTT CKKS/BGV multiply accepted\n"; failures++; }
         if (!throws_invalid_argument([&] { evaluator.transform_to_ntt_new(a); })) { std::cerr << "FAIL: double NTT accepted\n"; failures++; }
-    } else {
-        if (!throws_invalid_argument([&] { evaluator.rescale_to_next_new(a); })) { std::cerr << "FAIL: BFV rescale accepted\n"; failures++; }
     }
+    if (!ckks) {
+        if (!throws_invalid_argument([&] { evaluator.rescale_to_next_new(a); })) { std::cerr << "FAIL: BFV/BGV rescale accepted\n"; failures++; }
+    }
+    if (bgv && (next.correction_factor() == 1 || relin.correction_factor() != 1)) { std::cerr << "FAIL: BGV correction factor bookkeeping\n"; failures++; }
     {
         Ciphertext last = a;
         while (last.parms_id() != context->last_parms_id()) evaluator.mod_switch_to_next_inplace(last);

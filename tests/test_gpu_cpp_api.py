@@ -25,7 +25,8 @@ def _read_dump(path):
 
 @pytest.mark.parametrize("scheme,n,t,bits", [("ckks", 32, 0, [40, 40, 40, 40]), ("ckks", 8192, 0, [40, 40, 40, 40]),
                                              ("ckks", 16384, 0, [50] * 6), ("bfv", 32, 65537, [40, 40, 40]),
-                                             ("bfv", 8192, 1032193, [40, 40, 40])])
+                                             ("bfv", 8192, 1032193, [40, 40, 40]),
+                                             ("bgv", 32, 65537, [40, 40, 40]), ("bgv", 8192, 1032193, [40, 40, 40]), ("bgv", 16384, 65537, [50] * 5)])
 def test_evaluator_cpp_api(O, dev, tmp_path, scheme, n, t, bits):
     if not os.path.exists(DRIVER):
         pytest.fail("tests/cpp/evaluator_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
@@ -35,7 +36,7 @@ def test_evaluator_cpp_api(O, dev, tmp_path, scheme, n, t, bits):
     q = O.coeff_modulus_create(n, bits)
     ctx = O.Context(scheme, n, q, t)
     L = len(q) - 1
-    ntt = scheme == "ckks"
+    ntt = scheme != "bfv"                                    # CKKS and BGV ciphertexts live in NTT form
     a, b = ctx.random_ct(11, 2, L), ctx.random_ct(29, 2, L)
     keys = ctx.random_keys(7, L)
     d = _read_dump(out)
