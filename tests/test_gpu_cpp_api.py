@@ -223,3 +223,14 @@ def test_basics_cpp_api(dev):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert "chain 3 primes, key level 109 bits, first level 72 bits" in r.stdout          # bfv_default(4096): 36 + 36 + 37 bits
     assert "qualifiers batching 0 fast_plain_lift 1 descending 1 security 1" in r.stdout
+
+
+@pytest.mark.parametrize("dims,pack_lwe,mod_switch", [((25, 30, 35), 0, 1), ((25, 30, 35), 1, 1), ((64, 48, 40), 1, 0), ((7, 100, 9), 0, 0)])
+def test_ckks_matmul_cpp_api(dev, dims, pack_lwe, mod_switch):
+    """examples/11_ckks_matmul.cu: y = x * w + s on real matrices through MatmulHelper and the CKKS encoder (its two configurations
+    and two more), every output within the scale-2^20 tolerance of the plain result"""
+    drv = os.path.join(ROOT, "tests", "cpp", "ckks_matmul_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/ckks_matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv] + [str(d) for d in dims] + [str(pack_lwe), str(mod_switch)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -140,7 +140,13 @@ void Evaluator::translate_plain_inplace(Ciphertext& encrypted, const Plaintext& 
             if (!encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Ciphertext is not in NTT form.");
             if (!are_close_double(plain.scale(), encrypted.scale())) throw std::invalid_argument(std::string(P) + " Plaintext scale is not equal to the scale of the ciphertext.");
             if (!plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext and ciphertext are not in the same NTT form.");
-            if (plain.parms_id() != encrypted.parms_id()) throw std::invalid_argument(std::string(P) + " Plaintext and ciphertext parameters do not match.");
+            // the reference adds the first L limbs of the plaintext whatever its level (utils::add_inplace_p over the ciphertext's
+            // moduli, evaluator_translate_plain.cu:71-75): a plaintext encoded higher up the chain is a valid operand
+            if (plain.parms_id() != encrypted.parms_id()) {
+                auto pcd = context_->get_context_data(plain.parms_id());
+                if (!pcd.has_value() || pcd.value()->chain_index() < cd->chain_index() || pcd.value()->parms().poly_modulus_degree() != n)
+                    throw std::invalid_argument(std::string(P) + " Plaintext and ciphertext parameters do not match.");
+            }
             troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), plain.poly(), encrypted.poly(0), 1, stream()));
             break;
         }

@@ -504,4 +504,103 @@ Cipher2d MatmulHelper::deserialize_outputs(const Evaluator& evaluator, std::istr
     return ret;
 }
 
+// ------------------------------------------------------------------------------------------------
+// CKKS forms (encoder_adapter.h:28-46: both operand kinds are encode_float64_polynomial at the given level and scale)
+// ------------------------------------------------------------------------------------------------
+Plain2d MatmulHelper::encode_weights_doubles(const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const {
+    Plain2d out;
+    for (size_t li = 0; li < input_dims; li += input_block) {
+        const size_t ui = std::min(li + input_block, input_dims);
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t lj = 0; lj < output_dims; lj += output_block) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            std::vector<double> vec(input_block * output_block, 0.0);
+            for (size_t j = lj; j < uj; j++)
+                for (size_t i = li; i < ui; i++) vec[(j - lj) * input_block + input_block - (i - li) - 1] = weights[i * output_dims + j];
+            row.push_back(encoder.encode_float64_polynomial_new(vec, parms_id, scale, pool));
+        }
+    }
+    return out;
+}
+
+Plain2d MatmulHelper::encode_inputs_doubles(const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const {
+    Plain2d out;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t lj = 0; lj < input_dims; lj += input_block) {
+            const size_t uj = std::min(lj + input_block, input_dims);
+            std::vector<double> vec(slot_count, 0.0);
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) vec[(i - li) * input_block * output_block + (j - lj)] = inputs[i * input_dims + j];
+            row.push_back(encoder.encode_float64_polynomial_new(vec, parms_id, scale, pool));
+        }
+    }
+    return out;
+}
+
+Cipher2d MatmulHelper::encrypt_inputs_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const {
+    // app/matmul.cu:296-311: symmetric encryption with the c1 seed kept (half the wire size; Cipher2d::load / expand_seed restores c1)
+    const Plain2d plain = encode_inputs_doubles(encoder, inputs, parms_id, scale);
+    Cipher2d out;
+    for (const auto& prow : plain.data()) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (const Plaintext& p : prow) row.push_back(encryptor.encrypt_symmetric_new(p, true, pool));
+    }
+    return out;
+}
+
+Plain2d MatmulHelper::encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const {
+    const size_t n = slot_count, ocols = ceil_div(output_dims, output_block), brows = ceil_div(batch_size, batch_block);
+    const size_t count = pack_lwe ? ceil_div(brows * ocols, input_block) : brows * ocols;
+    std::vector<std::vector<double>> buffers(count, std::vector<double>(n, 0.0));
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            const size_t cipher_id = di * ocols + dj;
+            std::vector<double>& buf = buffers[pack_lwe ? cipher_id / input_block : cipher_id];
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) buf[(i - li) * input_block * output_block + (j - lj) * input_block + offset] = outputs[i * output_dims + j];
+        }
+    }
+    Plain2d out;
+    if (pack_lwe) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (const auto& buf : buffers) row.push_back(encoder.encode_float64_polynomial_new(buf, parms_id, scale, pool));
+    } else {
+        for (size_t r = 0; r < brows; r++) {
+            std::vector<Plaintext>& row = out.new_row();
+            for (size_t c = 0; c < ocols; c++) row.push_back(encoder.encode_float64_polynomial_new(buffers[r * ocols + c], parms_id, scale, pool));
+        }
+    }
+    return out;
+}
+
+std::vector<double> MatmulHelper::decrypt_outputs_doubles(const CKKSEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
+    std::vector<std::vector<double>> coeffs;
+    for (const auto& r : outputs.data()) for (const Ciphertext& c : r) coeffs.push_back(encoder.decode_float64_polynomial_new(decryptor.decrypt_new(c, pool), pool));
+    const size_t ocols = ceil_div(output_dims, output_block);
+    if (coeffs.size() != (pack_lwe ? ceil_div(ceil_div(batch_size, batch_block) * ocols, input_block) : ceil_div(batch_size, batch_block) * ocols))
+        throw std::invalid_argument("[MatmulHelper::decrypt_outputs] Output ciphertext count incorrect");
+    std::vector<double> out(batch_size * output_dims, 0.0);
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+        const size_t ui = std::min(li + batch_block, batch_size);
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
+            const size_t uj = std::min(lj + output_block, output_dims);
+            const size_t cipher_id = di * ocols + dj;
+            const std::vector<double>& cf = coeffs[pack_lwe ? cipher_id / input_block : cipher_id];
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
+            for (size_t i = li; i < ui; i++)
+                for (size_t j = lj; j < uj; j++) out[i * output_dims + j] = cf[(i - li) * input_block * output_block + (j - lj) * input_block + offset];
+        }
+    }
+    return out;
+}
+
 }}  // namespace troy::linear

@@ -99,6 +99,13 @@ public:
     std::vector<uint64_t> decrypt_outputs_uint64s(const BatchEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
     // a bias / share [batch_size][output_dims] laid out like the (packed or unpacked) outputs, for Cipher2d::add_plain_inplace
     Plain2d encode_outputs_uint64s(const BatchEncoder& encoder, const uint64_t* outputs) const;
+    // CKKS (examples/11_ckks_matmul.cu): the same layouts on real coefficients through CKKSEncoder::encode_float64_polynomial; the
+    // product carries scale^2, so a bias is encoded at scale^2 (and at the level of the outputs when they were mod-switched)
+    Plain2d encode_weights_doubles(const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const;
+    Plain2d encode_inputs_doubles(const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const;
+    Cipher2d encrypt_inputs_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const;
+    Plain2d encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const;
+    std::vector<double> decrypt_outputs_doubles(const CKKSEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
     // pack_lwe: input_block output ciphertexts are merged into one (Evaluator::pack_rlwe_ciphertexts, all groups batched);
     // the result is one row of ceil(#outputs / input_block) ciphertexts.  Needs the Galois keys of
     // (N / input_block) * 2^k + 1, k = 1..log2(input_block)
