@@ -234,3 +234,17 @@ def test_ckks_matmul_cpp_api(dev, dims, pack_lwe, mod_switch):
         pytest.fail("tests/cpp/ckks_matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv] + [str(d) for d in dims] + [str(pack_lwe), str(mod_switch)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shape,mod_switch,objective", [((2, 3, 5, 15, 15, 3, 3), 0, "left"),          # the example's run
+                                                        ((2, 3, 5, 15, 15, 3, 3), 1, "left"), ((1, 4, 6, 40, 37, 5, 3), 1, "left"),
+                                                        ((3, 2, 2, 9, 9, 1, 1), 0, "left"), ((2, 3, 5, 15, 15, 3, 3), 1, "right"),
+                                                        ((4, 16, 8, 32, 32, 3, 3), 1, "left"), ((1, 1, 2, 100, 120, 3, 3), 0, "left"), ((2, 2, 1, 70, 130, 4, 2), 1, "left")])  # several overlapping tiles
+def test_conv2d_cpp_api(dev, shape, mod_switch, objective):
+    """examples/14_bfv_conv2d.cu: y = conv2d(x, w) + s with encrypted images (or encrypted kernels) through Conv2dHelper, tiles that
+    overlap by the kernel size, the outputs' partial wire format; equals the plain cross-correlation mod t"""
+    drv = os.path.join(ROOT, "tests", "cpp", "conv2d_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/conv2d_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv] + [str(v) for v in shape] + [str(mod_switch), objective], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "mismatches 0 of" in r.stdout, r.stdout + r.stderr

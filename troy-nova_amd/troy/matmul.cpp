@@ -205,7 +205,7 @@ std::vector<uint64_t> MatmulHelper::pack_input_blocks(uint64_t t, const uint64_t
     return packed;
 }
 
-Plain2d MatmulHelper::encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const {
+Plain2d detail::encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len, MemoryPoolHandle pool) {
     // encode_for_plain + ensure_ntt_form(centralize = true) (app/matmul.cu:14-70,:200-203): all blocks go through ONE copy, ONE
     // centralize launch and ONE NTT launch; the plaintext objects are windows of the shared result buffer
     HeContextPointer context = encoder.context();
@@ -239,7 +239,8 @@ Plain2d MatmulHelper::encode_blocks_for_plain(const BatchEncoder& encoder, const
     return out;
 }
 
-Cipher2d MatmulHelper::encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const {
+Cipher2d detail::encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len,
+                                MemoryPoolHandle pool) {
     // encode_for_cipher + ensure_ntt_form(centralize = false) + encrypt_symmetric_batched(save_seed = true) (app/matmul.cu:200-216,
     // :296-311): one copy and one batched encryption that stays in NTT form; the ciphertexts carry the seed of c1
     std::vector<Ciphertext> cts;
@@ -266,34 +267,34 @@ Cipher2d MatmulHelper::encrypt_blocks(const Encryptor& encryptor, const BatchEnc
 Plain2d MatmulHelper::encode_weights_uint64s(const BatchEncoder& encoder, const uint64_t* weights) const {
     size_t rows, cols, len;
     const std::vector<uint64_t> packed = pack_weight_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), weights, rows, cols, len);
-    return encode_blocks_for_plain(encoder, packed, rows, cols, len);
+    return detail::encode_blocks_for_plain(encoder, packed, rows, cols, len, pool);
 }
 
 Cipher2d MatmulHelper::encrypt_weights_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* weights) const {
     size_t rows, cols, len;
     const std::vector<uint64_t> packed = pack_weight_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), weights, rows, cols, len);
-    return encrypt_blocks(encryptor, encoder, packed, rows, cols, len);
+    return detail::encrypt_blocks(encryptor, encoder, packed, rows, cols, len, pool);
 }
 
 Plain2d MatmulHelper::encode_inputs_uint64s(const BatchEncoder& encoder, const uint64_t* inputs) const {
     size_t rows, cols, len;
     const std::vector<uint64_t> packed = pack_input_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), inputs, rows, cols, len);
-    return encode_blocks_for_plain(encoder, packed, rows, cols, len);
+    return detail::encode_blocks_for_plain(encoder, packed, rows, cols, len, pool);
 }
 
 Cipher2d MatmulHelper::encrypt_inputs_uint64s(const Encryptor& encryptor, const BatchEncoder& encoder, const uint64_t* inputs) const {
     size_t rows, cols, len;
     const std::vector<uint64_t> packed = pack_input_blocks(encoder.context()->first_context_data().value()->parms().plain_modulus().value(), inputs, rows, cols, len);
-    return encrypt_blocks(encryptor, encoder, packed, rows, cols, len);
+    return detail::encrypt_blocks(encryptor, encoder, packed, rows, cols, len, pool);
 }
 
 // ret[b][j] = sum_i ct(b, i, j) (.) pt(b, i, j) in one multiply_plain_accumulate launch; the results are windows of one zeroed
 // buffer, so the trailing inverse NTT (BFV results leave in coefficient form) is one launch too
-template <typename CtAt, typename PtAt>
-static Cipher2d accumulate_products(const MatmulHelper& h, const Evaluator& evaluator, const Ciphertext& like, size_t batch_split, size_t input_split, size_t output_split,
-                                    CtAt ct_at, PtAt pt_at) {
+Cipher2d detail::accumulate_products(const Evaluator& evaluator, const Ciphertext& like, size_t batch_split, size_t input_split, size_t output_split,
+                                     const std::function<const Ciphertext*(size_t, size_t, size_t)>& ct_at,
+                                     const std::function<const Plaintext*(size_t, size_t, size_t)>& pt_at, MemoryPoolHandle pool) {
     const size_t pcnt = like.polynomial_count(), L = like.coeff_modulus_size(), n = like.poly_modulus_degree(), words = pcnt * L * n;
-    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, h.pool);
+    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, pool);
     shared->set_zero();
     Cipher2d ret;
     ret.data().resize(batch_split);
@@ -307,7 +308,7 @@ static Cipher2d accumulate_products(const MatmulHelper& h, const Evaluator& eval
     for (size_t i = 0; i < input_split; i++)
         for (size_t j = 0; j < output_split; j++)
             for (size_t b = 0; b < batch_split; b++) { c_ptrs.push_back(ct_at(b, i, j)); p_ptrs.push_back(pt_at(b, i, j)); r_ptrs.push_back(&ret[b][j]); }
-    evaluator.multiply_plain_accumulate(c_ptrs, p_ptrs, r_ptrs, false, h.pool);
+    evaluator.multiply_plain_accumulate(c_ptrs, p_ptrs, r_ptrs, false, pool);
     if (evaluator.context()->first_context_data().value()->parms().scheme() == SchemeType::BFV) {
         troyn_check_public(troyn_ntt(evaluator.context()->plan(), 1, shared->raw_pointer(), shared->raw_pointer(), batch_split * output_split, pcnt,
                                      static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
@@ -322,8 +323,8 @@ Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, con
     const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
     if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
     if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
-    return accumulate_products(*this, evaluator, a[0][0], batch_split, input_split, output_split,
-                               [&](size_t b, size_t i, size_t) { return &a[b][i]; }, [&](size_t, size_t i, size_t j) { return &w[i][j]; });
+    return detail::accumulate_products(evaluator, a[0][0], batch_split, input_split, output_split,
+                                       [&](size_t b, size_t i, size_t) { return &a[b][i]; }, [&](size_t, size_t i, size_t j) { return &w[i][j]; }, pool);
 }
 
 Cipher2d MatmulHelper::matmul_reverse(const Evaluator& evaluator, const Plain2d& a, const Cipher2d& w) const {
@@ -331,8 +332,8 @@ Cipher2d MatmulHelper::matmul_reverse(const Evaluator& evaluator, const Plain2d&
     const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
     if (a.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
     if (w.size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Weight input dimension incorrect.");
-    return accumulate_products(*this, evaluator, w[0][0], batch_split, input_split, output_split,
-                               [&](size_t, size_t i, size_t j) { return &w[i][j]; }, [&](size_t b, size_t i, size_t) { return &a[b][i]; });
+    return detail::accumulate_products(evaluator, w[0][0], batch_split, input_split, output_split,
+                                       [&](size_t, size_t i, size_t j) { return &w[i][j]; }, [&](size_t b, size_t i, size_t) { return &a[b][i]; }, pool);
 }
 
 Cipher2d MatmulHelper::matmul_cipher(const Evaluator& evaluator, const Cipher2d& a, const Cipher2d& w) const {

@@ -10,6 +10,8 @@
 //   output block: y[i][j] is coefficient (i-li)*ib*ob + (j-lj)*ib + ib - 1 of sum_k input[b][k] * weight[k][j-block]
 // with (bb, ib, ob) = (batch_block, input_block, output_block), bb*ib*ob <= N.
 #pragma once
+#include <functional>
+
 #include "troy.h"
 
 namespace troy { namespace linear {
@@ -70,6 +72,20 @@ private:
     std::vector<std::vector<Ciphertext>> inner;
 };
 
+// Shared by the linear-algebra helpers (matmul, conv2d): `packed` holds rows*cols coefficient vectors of length `len` back to back.
+namespace detail {
+// encode_for_plain + ensure_ntt_form(centralize) (app/matmul.cu:14-70): one copy, one centralize launch, one NTT launch; the
+// plaintexts are windows of one buffer
+Plain2d encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len, MemoryPoolHandle pool);
+// encode_for_cipher + ensure_ntt_form(scale up) + encrypt_symmetric_batched(save_seed = true): NTT-form ciphertexts carrying the c1 seed
+Cipher2d encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len,
+                        MemoryPoolHandle pool);
+// ret[b][j] = sum_i ct(b, i, j) (.) pt(b, i, j): one multiply_plain_accumulate launch, results in one buffer, one trailing INTT (BFV)
+Cipher2d accumulate_products(const Evaluator& evaluator, const Ciphertext& like, size_t batch_split, size_t input_split, size_t output_split,
+                             const std::function<const Ciphertext*(size_t, size_t, size_t)>& ct_at,
+                             const std::function<const Plaintext*(size_t, size_t, size_t)>& pt_at, MemoryPoolHandle pool);
+}  // namespace detail
+
 class MatmulHelper {
 public:
     size_t batch_size, input_dims, output_dims, slot_count;
@@ -118,9 +134,6 @@ public:
 
 private:
     void determine_block();
-    // the blocks of a [rows][cols] matrix as coefficient vectors of length `len`, back to back, packed by `place(i, j)`
-    Plain2d encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const;
-    Cipher2d encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len) const;
     std::vector<uint64_t> pack_weight_blocks(uint64_t t, const uint64_t* weights, size_t& rows, size_t& cols, size_t& len) const;
     std::vector<uint64_t> pack_input_blocks(uint64_t t, const uint64_t* inputs, size_t& rows, size_t& cols, size_t& len) const;
 };
