@@ -183,3 +183,53 @@ def test_lwe_packing_flow_in_python(pytroy, dev):
         src = msg if k == 0 else [(v * (k + 1)) % t for v in msg]
         assert merged[k::4] == src[3::4], k
     pytroy.MemoryPool.destroy_global_pool()
+
+
+@pytest.mark.gpu
+def test_matmul_and_conv2d_helpers_in_python(pytroy, dev):
+    """pybind/src/matmul_helper.cu and conv2d_helper.cu names over numpy arrays: the flows of examples/10_bfv_matmul.cu (packed
+    outputs) and 14_bfv_conv2d.cu from Python"""
+    import numpy as np
+    n, t = 8192, 1 << 21
+    p = pytroy.EncryptionParameters(pytroy.SchemeType.BFV)
+    p.set_poly_modulus_degree(n)
+    p.set_coeff_modulus(pytroy.CoeffModulus.create(n, [60, 40, 40, 60]))
+    p.set_plain_modulus(t)
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Classical128, 0x42)
+    ctx.to_device_inplace()
+    encoder = pytroy.BatchEncoder(ctx)
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_secret_key(keygen.secret_key())
+    decryptor = pytroy.Decryptor(ctx, keygen.secret_key())
+    evaluator = pytroy.Evaluator(ctx)
+    rs = np.random.RandomState(5)
+    m, r, o = 20, 33, 17
+    x, w, s = (rs.randint(0, t, shape).astype(np.uint64) for shape in ((m, r), (r, o), (m, o)))
+    helper = pytroy.MatmulHelper(m, r, o, n, pytroy.MatmulObjective.EncryptLeft, True)
+    assert helper.input_block() == 16 and helper.pack_lwe()
+    w_enc, s_enc = helper.encode_weights(encoder, w), helper.encode_outputs(encoder, s)
+    x_enc = pytroy.Cipher2d.load_new(helper.encrypt_inputs(encryptor, encoder, x).save(ctx), ctx)
+    y = helper.matmul(evaluator, x_enc, w_enc)
+    y.mod_switch_to_next_inplace(evaluator)
+    y = helper.pack_outputs(evaluator, keygen.create_automorphism_keys(False), y)
+    y.add_plain_inplace(evaluator, s_enc)
+    y = helper.deserialize_outputs(evaluator, helper.serialize_outputs(evaluator, y))
+    got = helper.decrypt_outputs(encoder, decryptor, y).reshape(m, o)
+    want = ((x.astype(object) @ w.astype(object) + s.astype(object)) % t).astype(np.uint64)
+    assert np.array_equal(got, want)
+    # conv2d
+    bs, ic, oc, H, W, kh, kw = 2, 3, 4, 12, 11, 3, 2
+    xi = rs.randint(0, t, (bs, ic, H, W)).astype(np.uint64)
+    wk = rs.randint(0, t, (oc, ic, kh, kw)).astype(np.uint64)
+    conv = pytroy.Conv2dHelper(bs, ic, oc, H, W, kh, kw, n)
+    yc = conv.conv2d(evaluator, pytroy.Cipher2d.load_new(conv.encrypt_inputs(encryptor, encoder, xi).save(ctx), ctx), conv.encode_weights(encoder, wk))
+    gotc = conv.decrypt_outputs(encoder, decryptor, yc).reshape(bs, oc, H - kh + 1, W - kw + 1)
+    wantc = np.zeros(gotc.shape, dtype=object)
+    for a in range(kh):
+        for b in range(kw):
+            wantc += np.einsum("bchw,oc->bohw", xi[:, :, a:a + H - kh + 1, b:b + W - kw + 1].astype(object), wk[:, :, a, b].astype(object))
+    assert np.array_equal(gotc, (wantc % t).astype(np.uint64))
+    with pytest.raises(ValueError):
+        helper.encode_weights(encoder, w[:-1])
+    pytroy.MemoryPool.destroy_global_pool()

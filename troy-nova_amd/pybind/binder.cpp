@@ -4,11 +4,14 @@
 // C++ exceptions map (std::invalid_argument -> ValueError).
 #include <pybind11/pybind11.h>
 #include <pybind11/complex.h>
+#include <pybind11/numpy.h>
 #include <pybind11/stl.h>
 
 #include <optional>
 #include <sstream>
 
+#include "../troy/conv2d.h"
+#include "../troy/matmul.h"
 #include "../troy/troy.h"
 
 namespace py = pybind11;
@@ -357,4 +360,116 @@ PYBIND11_MODULE(pytroy_raw, m) {
         for (const auto& grp : groups) g.push_back(const_ptrs(grp));
         return s.pack_rlwe_ciphertexts_new_batched(g, k, shift, in_iv, out_iv, P(p), trace); },
         py::arg("cipher_groups"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
+
+    // ---- linear-algebra applications (pybind/src/matmul_helper.cu, conv2d_helper.cu): numpy arrays in, numpy arrays out ----
+    using linear::Cipher2d; using linear::Conv2dHelper; using linear::MatmulHelper; using linear::MatmulObjective; using linear::Plain2d;
+    auto vec_u64 = [](const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& a) { return std::vector<uint64_t>(a.data(), a.data() + a.size()); };
+    auto vec_f64 = [](const py::array_t<double, py::array::c_style | py::array::forcecast>& a) { return std::vector<double>(a.data(), a.data() + a.size()); };
+    auto arr_u64 = [](const std::vector<uint64_t>& v) { return py::array_t<uint64_t>(v.size(), v.data()); };
+    auto arr_f64 = [](const std::vector<double>& v) { return py::array_t<double>(v.size(), v.data()); };
+    auto need = [](size_t got, size_t want, const char* what) { if (got != want) throw std::invalid_argument(std::string("[") + what + "] array size does not match the helper's dimensions."); };
+
+    py::class_<Plain2d>(m, "Plain2d")
+        .def(py::init<>()).def("size", &Plain2d::size).def("rows", &Plain2d::rows).def("columns", &Plain2d::columns)
+        .def("clone", [](const Plain2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("encrypt_symmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_symmetric(e, P(p)); }, py::arg("encryptor"), POOL)
+        .def("encrypt_asymmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_asymmetric(e, P(p)); }, py::arg("encryptor"), POOL)
+        .def("get", [](const Plain2d& s, size_t i, size_t j) { return s[i].at(j); });
+    py::class_<Cipher2d>(m, "Cipher2d")
+        .def(py::init<>()).def("size", &Cipher2d::size).def("rows", &Cipher2d::rows).def("columns", &Cipher2d::columns)
+        .def("clone", [](const Cipher2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("expand_seed", &Cipher2d::expand_seed)
+        .def("save", [](const Cipher2d& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
+        .def("load", [](Cipher2d& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("data"), py::arg("context"), POOL)
+        .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; return Cipher2d::load_new(is, c, P(p)); },
+                    py::arg("data"), py::arg("context"), POOL)
+        .def("serialized_size_upperbound", [](const Cipher2d& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+        .def("mod_switch_to_next_inplace", [](Cipher2d& s, const Evaluator& e, PoolArg p) { s.mod_switch_to_next_inplace(e, P(p)); }, py::arg("evaluator"), POOL)
+        .def("mod_switch_to_next", [](const Cipher2d& s, const Evaluator& e, PoolArg p) { return s.mod_switch_to_next(e, P(p)); }, py::arg("evaluator"), POOL)
+        .def("relinearize_inplace", [](Cipher2d& s, const Evaluator& e, const RelinKeys& k, PoolArg p) { s.relinearize_inplace(e, k, P(p)); }, py::arg("evaluator"), py::arg("relin_keys"), POOL)
+        .def("relinearize", [](const Cipher2d& s, const Evaluator& e, const RelinKeys& k, PoolArg p) { return s.relinearize(e, k, P(p)); }, py::arg("evaluator"), py::arg("relin_keys"), POOL)
+        .def("add", [](const Cipher2d& s, const Evaluator& e, const Cipher2d& o, PoolArg p) { return s.add(e, o, P(p)); }, py::arg("evaluator"), py::arg("other"), POOL)
+        .def("add_inplace", [](Cipher2d& s, const Evaluator& e, const Cipher2d& o, PoolArg p) { s.add_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("other"), POOL)
+        .def("add_plain", [](const Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { return s.add_plain(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
+        .def("add_plain_inplace", [](Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { s.add_plain_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
+        .def("sub", [](const Cipher2d& s, const Evaluator& e, const Cipher2d& o, PoolArg p) { return s.sub(e, o, P(p)); }, py::arg("evaluator"), py::arg("other"), POOL)
+        .def("sub_inplace", [](Cipher2d& s, const Evaluator& e, const Cipher2d& o, PoolArg p) { s.sub_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("other"), POOL)
+        .def("sub_plain", [](const Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { return s.sub_plain(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
+        .def("sub_plain_inplace", [](Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { s.sub_plain_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
+        .def("decrypt", [](const Cipher2d& s, const Decryptor& d, PoolArg p) { return s.decrypt(d, P(p)); }, py::arg("decryptor"), POOL)
+        .def("get", [](const Cipher2d& s, size_t i, size_t j) { return s[i].at(j); });
+    py::enum_<MatmulObjective>(m, "MatmulObjective").value("EncryptLeft", MatmulObjective::EncryptLeft).value("EncryptRight", MatmulObjective::EncryptRight)
+        .value("Crossed", MatmulObjective::Crossed);
+
+    py::class_<MatmulHelper> mh(m, "MatmulHelper");
+    mh.def(py::init([](size_t b, size_t i, size_t o, size_t n, MatmulObjective obj, bool pack, PoolArg p) { return MatmulHelper(b, i, o, n, obj, pack, P(p)); }),
+           py::arg("batch_size"), py::arg("input_dims"), py::arg("output_dims"), py::arg("slot_count"), py::arg("objective") = MatmulObjective::EncryptLeft,
+           py::arg("pack_lwe") = true, POOL)
+        .def("set_pool", &MatmulHelper::set_pool)
+        .def("batch_size", [](const MatmulHelper& s) { return s.batch_size; }).def("input_dims", [](const MatmulHelper& s) { return s.input_dims; })
+        .def("output_dims", [](const MatmulHelper& s) { return s.output_dims; }).def("slot_count", [](const MatmulHelper& s) { return s.slot_count; })
+        .def("objective", [](const MatmulHelper& s) { return s.objective; }).def("pack_lwe", [](const MatmulHelper& s) { return s.pack_lwe; })
+        .def("batch_block", [](const MatmulHelper& s) { return s.batch_block; }).def("input_block", [](const MatmulHelper& s) { return s.input_block; })
+        .def("output_block", [](const MatmulHelper& s) { return s.output_block; })
+        .def("matmul", &MatmulHelper::matmul).def("matmul_reverse", &MatmulHelper::matmul_reverse).def("matmul_cipher", &MatmulHelper::matmul_cipher)
+        .def("pack_outputs", &MatmulHelper::pack_outputs)
+        .def("serialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const Cipher2d& x) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os); }); })
+        .def("deserialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); });
+    auto mm_enc_w = [=](const MatmulHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
+        need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encode_weights"); return s.encode_weights_uint64s(enc, vec_u64(w).data()); };
+    auto mm_enc_x = [=](const MatmulHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& x) {
+        need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encode_inputs"); return s.encode_inputs_uint64s(enc, vec_u64(x).data()); };
+    auto mm_cry_w = [=](const MatmulHelper& s, const Encryptor& e, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
+        need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encrypt_weights"); return s.encrypt_weights_uint64s(e, enc, vec_u64(w).data()); };
+    auto mm_cry_x = [=](const MatmulHelper& s, const Encryptor& e, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& x) {
+        need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encrypt_inputs"); return s.encrypt_inputs_uint64s(e, enc, vec_u64(x).data()); };
+    auto mm_enc_y = [=](const MatmulHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& y) {
+        need(y.size(), s.batch_size * s.output_dims, "MatmulHelper::encode_outputs"); return s.encode_outputs_uint64s(enc, vec_u64(y).data()); };
+    auto mm_dec_y = [=](const MatmulHelper& s, const BatchEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_u64(s.decrypt_outputs_uint64s(enc, d, y)); };
+    for (const char* suffix : {"", "_uint64s"}) {
+        mh.def((std::string("encode_weights") + suffix).c_str(), mm_enc_w).def((std::string("encode_inputs") + suffix).c_str(), mm_enc_x)
+          .def((std::string("encrypt_weights") + suffix).c_str(), mm_cry_w).def((std::string("encrypt_inputs") + suffix).c_str(), mm_cry_x)
+          .def((std::string("encode_outputs") + suffix).c_str(), mm_enc_y).def((std::string("decrypt_outputs") + suffix).c_str(), mm_dec_y);
+    }
+    mh.def("encode_weights_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& w, std::optional<ParmsID> id, double scale) {
+            need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encode_weights"); return s.encode_weights_doubles(enc, vec_f64(w).data(), id, scale); })
+      .def("encode_inputs_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& x, std::optional<ParmsID> id, double scale) {
+            need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encode_inputs"); return s.encode_inputs_doubles(enc, vec_f64(x).data(), id, scale); })
+      .def("encrypt_inputs_doubles", [=](const MatmulHelper& s, const Encryptor& e, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& x, std::optional<ParmsID> id, double scale) {
+            need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encrypt_inputs"); return s.encrypt_inputs_doubles(e, enc, vec_f64(x).data(), id, scale); })
+      .def("encode_outputs_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& y, std::optional<ParmsID> id, double scale) {
+            need(y.size(), s.batch_size * s.output_dims, "MatmulHelper::encode_outputs"); return s.encode_outputs_doubles(enc, vec_f64(y).data(), id, scale); })
+      .def("decrypt_outputs_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_f64(s.decrypt_outputs_doubles(enc, d, y)); });
+
+    py::class_<Conv2dHelper> ch(m, "Conv2dHelper");
+    ch.def(py::init([](size_t b, size_t ic, size_t oc, size_t h, size_t w, size_t kh, size_t kw, size_t n, MatmulObjective obj, PoolArg p) { return Conv2dHelper(b, ic, oc, h, w, kh, kw, n, obj, P(p)); }),
+           py::arg("batch_size"), py::arg("input_channels"), py::arg("output_channels"), py::arg("image_height"), py::arg("image_width"), py::arg("kernel_height"),
+           py::arg("kernel_width"), py::arg("poly_degree"), py::arg("objective") = MatmulObjective::EncryptLeft, POOL)
+        .def("batch_size", [](const Conv2dHelper& s) { return s.batch_size; }).def("input_channels", [](const Conv2dHelper& s) { return s.input_channels; })
+        .def("output_channels", [](const Conv2dHelper& s) { return s.output_channels; }).def("image_height", [](const Conv2dHelper& s) { return s.image_height; })
+        .def("image_width", [](const Conv2dHelper& s) { return s.image_width; }).def("kernel_height", [](const Conv2dHelper& s) { return s.kernel_height; })
+        .def("kernel_width", [](const Conv2dHelper& s) { return s.kernel_width; }).def("slot_count", [](const Conv2dHelper& s) { return s.slot_count; })
+        .def("objective", [](const Conv2dHelper& s) { return s.objective; }).def("batch_block", [](const Conv2dHelper& s) { return s.batch_block; })
+        .def("input_channel_block", [](const Conv2dHelper& s) { return s.input_channel_block; }).def("output_channel_block", [](const Conv2dHelper& s) { return s.output_channel_block; })
+        .def("image_height_block", [](const Conv2dHelper& s) { return s.image_height_block; }).def("image_width_block", [](const Conv2dHelper& s) { return s.image_width_block; })
+        .def("conv2d", &Conv2dHelper::conv2d).def("conv2d_reverse", &Conv2dHelper::conv2d_reverse).def("conv2d_cipher", &Conv2dHelper::conv2d_cipher)
+        .def("serialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const Cipher2d& x) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os); }); })
+        .def("deserialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); });
+    auto cv_out = [](const Conv2dHelper& s) { return s.batch_size * s.output_channels * (s.image_height - s.kernel_height + 1) * (s.image_width - s.kernel_width + 1); };
+    auto cv_enc_w = [=](const Conv2dHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
+        need(w.size(), s.output_channels * s.input_channels * s.kernel_height * s.kernel_width, "Conv2dHelper::encode_weights"); return s.encode_weights_uint64s(enc, vec_u64(w).data()); };
+    auto cv_enc_x = [=](const Conv2dHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& x) {
+        need(x.size(), s.batch_size * s.input_channels * s.image_height * s.image_width, "Conv2dHelper::encode_inputs"); return s.encode_inputs_uint64s(enc, vec_u64(x).data()); };
+    auto cv_cry_w = [=](const Conv2dHelper& s, const Encryptor& e, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
+        need(w.size(), s.output_channels * s.input_channels * s.kernel_height * s.kernel_width, "Conv2dHelper::encrypt_weights"); return s.encrypt_weights_uint64s(e, enc, vec_u64(w).data()); };
+    auto cv_cry_x = [=](const Conv2dHelper& s, const Encryptor& e, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& x) {
+        need(x.size(), s.batch_size * s.input_channels * s.image_height * s.image_width, "Conv2dHelper::encrypt_inputs"); return s.encrypt_inputs_uint64s(e, enc, vec_u64(x).data()); };
+    auto cv_enc_y = [=](const Conv2dHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& y) {
+        need(y.size(), cv_out(s), "Conv2dHelper::encode_outputs"); return s.encode_outputs_uint64s(enc, vec_u64(y).data()); };
+    auto cv_dec_y = [=](const Conv2dHelper& s, const BatchEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_u64(s.decrypt_outputs_uint64s(enc, d, y)); };
+    for (const char* suffix : {"", "_uint64s"}) {
+        ch.def((std::string("encode_weights") + suffix).c_str(), cv_enc_w).def((std::string("encode_inputs") + suffix).c_str(), cv_enc_x)
+          .def((std::string("encrypt_weights") + suffix).c_str(), cv_cry_w).def((std::string("encrypt_inputs") + suffix).c_str(), cv_cry_x)
+          .def((std::string("encode_outputs") + suffix).c_str(), cv_enc_y).def((std::string("decrypt_outputs") + suffix).c_str(), cv_dec_y);
+    }
 }

@@ -41,6 +41,31 @@ void Plain2d::load(std::istream& stream, MemoryPoolHandle pool) {
     }
 }
 
+Cipher2d Plain2d::encrypt_symmetric(const Encryptor& encryptor, MemoryPoolHandle pool) const {
+    Cipher2d out;
+    for (const auto& row : inner) { auto& r = out.new_row(); for (const Plaintext& p : row) r.push_back(encryptor.encrypt_symmetric_new(p, false, pool)); }
+    return out;
+}
+
+Cipher2d Plain2d::encrypt_asymmetric(const Encryptor& encryptor, MemoryPoolHandle pool) const {
+    Cipher2d out;
+    for (const auto& row : inner) { auto& r = out.new_row(); for (const Plaintext& p : row) r.push_back(encryptor.encrypt_asymmetric_new(p, pool)); }
+    return out;
+}
+
+void Cipher2d::relinearize_inplace(const Evaluator& evaluator, const RelinKeys& relin_keys, MemoryPoolHandle pool) {
+    std::vector<const Ciphertext*> src;
+    std::vector<Ciphertext*> dst;
+    for (auto& row : inner) for (Ciphertext& c : row) { src.push_back(&c); dst.push_back(&c); }
+    evaluator.relinearize_batched(src, relin_keys, dst, pool);
+}
+
+Plain2d Cipher2d::decrypt(const Decryptor& decryptor, MemoryPoolHandle pool) const {
+    Plain2d out;
+    for (const auto& row : inner) { auto& r = out.new_row(); for (const Ciphertext& c : row) r.push_back(decryptor.decrypt_new(c, pool)); }
+    return out;
+}
+
 Cipher2d Cipher2d::clone(MemoryPoolHandle pool) const {
     Cipher2d out;
     for (const auto& row : inner) {

@@ -18,8 +18,14 @@ namespace troy { namespace linear {
 
 enum class MatmulObjective : uint8_t { EncryptLeft = 0, EncryptRight = 1, Crossed = 2 };
 
+class Cipher2d;
+
 class Plain2d {
 public:
+    Plain2d clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plain2d p; for (const auto& r : inner) { auto& row = p.new_row(); for (const Plaintext& x : r) row.push_back(x.clone(pool)); } return p; }
+    // app/cipher2d.h:52-56: element-wise encryption
+    Cipher2d encrypt_symmetric(const Encryptor& encryptor, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Cipher2d encrypt_asymmetric(const Encryptor& encryptor, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<std::vector<Plaintext>>& data() { return inner; }
     const std::vector<std::vector<Plaintext>>& data() const { return inner; }
     size_t size() const { return inner.size(); }
@@ -62,6 +68,9 @@ public:
     void sub_inplace(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_inplace(evaluator, other, true, pool); }
     Cipher2d add(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.add_inplace(evaluator, other, pool); return c; }
     Cipher2d sub(const Evaluator& evaluator, const Cipher2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.sub_inplace(evaluator, other, pool); return c; }
+    void relinearize_inplace(const Evaluator& evaluator, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    Cipher2d relinearize(const Evaluator& evaluator, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.relinearize_inplace(evaluator, relin_keys, pool); return c; }
+    Plain2d decrypt(const Decryptor& decryptor, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void add_plain_inplace(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_plain_inplace(evaluator, other, false, pool); }
     void sub_plain_inplace(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { translate_plain_inplace(evaluator, other, true, pool); }
     Cipher2d add_plain(const Evaluator& evaluator, const Plain2d& other, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Cipher2d c = clone(pool); c.add_plain_inplace(evaluator, other, pool); return c; }
@@ -94,6 +103,7 @@ public:
     bool pack_lwe;
     MemoryPoolHandle pool;
 
+    void set_pool(MemoryPoolHandle p) { pool = std::move(p); }
     MatmulHelper(size_t batch_size, size_t input_dims, size_t output_dims, size_t slot_count,
                  MatmulObjective objective = MatmulObjective::EncryptLeft, bool pack_lwe = true, MemoryPoolHandle pool = MemoryPool::GlobalPool());
 
