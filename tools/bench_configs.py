@@ -150,6 +150,29 @@ def main():
         per_term = (time.perf_counter() - t0) / sample
         res["cfg5_e2e"]["cpu_matmul_core_ms_estimate"] = round(per_term * 16384 * 1e3, 1)
         res["cfg5_e2e"]["cpu_sample"] = "%d of 16384 multiply_plain_ntt+add terms on one host thread (oracle), extrapolated" % sample
+        # the other phases of the packed flow on one host thread, each timed on a few objects and multiplied out:
+        # encryption of the 32 input blocks, the NTTs around the product, the packing of 32 groups of 16, decryption of 32
+        rng = O.Rng(3)
+        sk = ctx.secret_key(rng)
+        pk = ctx.public_key(rng, sk)
+        msg = O.fill_uniform(9, 1 << 21, 8192)
+
+        def cpu_timed(fn, reps):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = fn()
+            return (time.perf_counter() - t0) / reps, out
+        t_enc, c = cpu_timed(lambda: ctx.encrypt_asymmetric_bfv(rng, pk, msg), 3)
+        t_ntt, _ = cpu_timed(lambda: ctx.from_ntt(ctx.to_ntt(c, 2, 3), 2, 3), 3)            # one forward + one inverse transform of a ciphertext
+        t_dec, _ = cpu_timed(lambda: ctx.decrypt_bfv(sk, c), 3)
+        keys = {(8192 // 16) * (1 << (k + 1)) + 1: ctx.random_keys(50 + k, 2) for k in range(4)}
+        low = ctx.mod_switch_scale_to_next(3, c)
+        t_pack, _ = cpu_timed(lambda: ctx.pack_rlwe_ciphertexts(2, [low] * 16, keys, 2 * 8192 - 15, 16, 1), 1)
+        phases = {"encrypt_32_inputs": t_enc * 32, "ntt_32_inputs_intt_512_outputs": t_ntt / 2 * (32 + 512), "matmul_core": per_term * 16384,
+                  "pack_32_groups_of_16": t_pack * 32, "decrypt_32_outputs": t_dec * 32}
+        res["cfg5_e2e"]["cpu_packed_flow_ms_estimate"] = {k: round(v * 1e3, 1) for k, v in phases.items()}
+        res["cfg5_e2e"]["cpu_packed_flow_ms_estimate"]["total"] = round(sum(phases.values()) * 1e3, 1)
+        res["cfg5_e2e"]["cpu_packed_flow_note"] = "oracle (plain C restatement of the reference's host branches), one host thread, per-object timings multiplied out"
 
     print(json.dumps(res, indent=1))
 
