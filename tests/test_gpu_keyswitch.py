@@ -12,6 +12,19 @@ def _setup(O, pkg, dev, scheme, n, bits, t=0):
     return ctx, plan, q
 
 
+@pytest.mark.parametrize("n,bits,L,batch", [(16384, [50] * 6, 5, 16), (8192, [40, 40, 40, 40], 3, 24), (4096, [36] * 5, 2, 8), (8192, [40, 40, 40, 40], 3, 12)])
+def test_switch_key_batches_of_eight(O, pkg, dev, n, bits, L, batch):
+    """batches that are multiples of 8 take the XCD-aware workgroup order of the fused inner product (all L+1 rows of an item
+    on one XCD); every item still equals the oracle (batch 12: the plain row-major order)"""
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, bits)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    tg = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(batch)])
+    got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    for i in sorted({0, 1, 7, batch // 2, batch - 1}):
+        assert np.array_equal(got[i], ctx.switch_key(L, True, tg[i], keys, assign=pkg.ASSIGN_OVERWRITE)), i
+
+
 @pytest.mark.parametrize("scheme,ntt_form,n,bits,L", [
     ("ckks", True, 32, [40, 40, 40], 2),
     ("ckks", True, 32, [60, 40, 40, 60], 3),      # the reference's test moduli (test/evaluator.cu)

@@ -378,7 +378,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         // row-major over the launch: consecutive workgroups (dealt round-robin to the 8 XCDs) work on the same
         // output row, so that row's 2*L key limbs (L2-sized) stay hot in every XCD while the digits stream through
         tile = 0; j = 0;
-        b = bid % a.batch; k = bid / a.batch;
+        const unsigned R = a.xcd_groups;        // rows co-scheduled per XCD (0 / 1: plain row-major)
+        if (R > 1) {
+            // R rows of the same item land on one XCD back to back (workgroup ids 8 apart), so the item's digits are fetched once
+            // for the R rows, while the launch still walks the rows R at a time and those rows' keys (R * 2L limbs) stay in L2
+            const unsigned per = 8u * R, phase = a.batch * R;
+            const unsigned q = bid % phase, r = q % per;
+            k = (bid / phase) * R + r / 8u;
+            b = (q / per) * 8u + (r % 8u);
+        } else {
+            b = bid % a.batch; k = bid / a.batch;
+        }
     } else {
         tile = bid & ((1u << TILE_BITS) - 1); bid >>= TILE_BITS;
         unsigned g;   // (batch, poly) group

@@ -550,6 +550,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.skip_diag = is_ntt_form ? 1 : 0;       // digit k of row k is the NTT-form input limb itself
         a.ext0 = target; a.ext0_bstride = (long long)target_bstride; a.ext0_cstride = n;
         a.batch = (unsigned)batch; a.key_pstride = (long long)K * n;
+        {
+            // rows of an item co-scheduled per XCD: all L+1 by default (the item's digits are then fetched once per XCD instead of
+            // once per row; measured 1265 vs 1310 us per 512-item launch at cfg3), TROYN_KS_ROWS=1 restores plain row-major order
+            static int ks_rows = -1;
+            if (ks_rows < 0) { const char* e = getenv("TROYN_KS_ROWS"); ks_rows = e ? std::atoi(e) : 0; }
+            const unsigned R = ks_rows > 0 ? (unsigned)ks_rows : L + 1;
+            a.xcd_groups = (R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
+        }
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
