@@ -242,6 +242,21 @@ int troyn_bgv_switch_key(const troyn_bgv* key_level, uint32_t L, const uint64_t*
 int troyn_bgv_relinearize(const troyn_bgv* key_level, uint32_t L, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2, void* workspace,
                           size_t workspace_bytes, size_t batch, troyn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Ring-2^k polynomial encoder (src/app/bfv_ring2k.{h,cu}: PolynomialEncoderRNSHelper<T>, T = uint32_t / uint64_t / uint128_t):
+ * plaintext modulus t = 2^k outside the context's own plain modulus.  One handle per level (first L primes), k and element width.
+ *   troyn_ring2k_scale_up     scale_up (:299-360): src elements [count] -> out u64[L][N] = round(Q/t * m), zero beyond `count`
+ *   troyn_ring2k_centralize   centralize (:488-560): centred lift of m
+ *   troyn_ring2k_scale_down   scale_down (:620-735): in u64[L][N] (phase, coefficient form) -> dst elements [N]
+ * ------------------------------------------------------------------------------------- */
+typedef struct troyn_ring2k troyn_ring2k;
+int troyn_ring2k_create(troyn_ring2k** out, const troyn_plan* plan, uint32_t L, uint32_t t_bit_length, uint32_t element_bytes);
+int troyn_ring2k_destroy(troyn_ring2k* h);
+uint64_t troyn_ring2k_gamma(const troyn_ring2k* h);
+int troyn_ring2k_scale_up(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream);
+int troyn_ring2k_centralize(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream);
+int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in, void* dst, troyn_stream_t stream);
+
 /* RLWE / LWE packing (evaluator_lwes.cu):
  *   troyn_negacyclic_shift     utils::negacyclic_shift_ps (utils/poly_small_mod.cu:927-968): multiply `count` RNS polynomials by
  *                              X^shift, shift in [0, 2N); out of place

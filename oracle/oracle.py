@@ -664,3 +664,62 @@ class Context:
                     k[c, l] = fill_uniform(seed * 7919 + j * 257 + c * 31 + l, self.q[l], self.n)
             keys.append(k)
         return keys
+
+
+class Ring2k:
+    """PolynomialEncoderRNSHelper<T> of the reference's ring-2^k application (src/app/bfv_ring2k.cu:96-194 constants, :197-297
+    scale_up, :488-506 centralize, :620-735 scale_down), restated on Python integers (exact multi-precision arithmetic; the
+    wrap-around of the element type T is applied where the reference's code has it).  q: the level's primes, n: ring degree,
+    t_bits: k, elem_bits: 32 / 64 / 128."""
+
+    def __init__(self, n, q, t_bits, elem_bits):
+        assert elem_bits in (32, 64, 128) and elem_bits // 2 < t_bits <= elem_bits
+        self.n, self.q, self.k, self.bits = n, [int(v) for v in q], t_bits, elem_bits
+        self.mask = (1 << t_bits) - 1
+        self.t_half = 1 << (t_bits - 1)
+        self.Q = 1
+        for v in self.q:
+            self.Q *= v
+        self.gamma = int(get_primes(n, 61, 1)[0])                     # utils::get_prime(poly_degree, 61) (:107)
+        self.Q_mod_t = self.Q & self.mask
+        self.Q_div_t = [(self.Q >> t_bits) % v for v in self.q]
+        self.punct = [self.Q // v for v in self.q]
+        self.inv_punct = [pow(p % v, -1, v) if len(self.q) > 1 else 1 for p, v in zip(self.punct, self.q)]
+        self.neg_inv_Q_mod_t = (-pow(self.Q, -1, 1 << t_bits)) & self.mask
+        self.inv_gamma_mod_t = pow(self.gamma, -1, 1 << t_bits)
+        self.neg_inv_Q_mod_gamma = (-pow(self.Q % self.gamma, -1, self.gamma)) % self.gamma
+        self.gamma_t_mod_q = [(self.gamma % v) * ((1 << t_bits) % v) % v for v in self.q]
+
+    def scale_up(self, src):
+        out = np.zeros((len(self.q), self.n), dtype=np.uint64)
+        tmask = (1 << self.bits) - 1
+        for j, x in enumerate(int(v) for v in src):
+            for i, qi in enumerate(self.q):
+                u = (x % qi) * self.Q_div_t[i] % qi
+                if self.bits <= 64:
+                    v = (((self.Q_mod_t * x + self.t_half) & ((1 << 128) - 1)) >> self.k) & tmask     # T v = (...) >> k
+                    out[i, j] = ((u + v) & ((1 << 64) - 1)) % qi                                        # reduce(u + v), 64-bit sum
+                else:
+                    v = ((self.Q_mod_t * x + self.t_half) >> self.k) & ((1 << 128) - 1)
+                    out[i, j] = ((u + v) & ((1 << 128) - 1)) % qi
+        return out
+
+    def centralize(self, src):
+        out = np.zeros((len(self.q), self.n), dtype=np.uint64)
+        for j, x in enumerate(int(v) for v in src):
+            for i, qi in enumerate(self.q):
+                out[i, j] = (qi - ((-x) & self.mask) % qi) % qi if x > self.t_half else x % qi
+        return out
+
+    def scale_down(self, phase):
+        out = []
+        for c in range(self.n):
+            y = [int(phase[l, c]) * self.gamma_t_mod_q[l] % ql * self.inv_punct[l] % ql for l, ql in enumerate(self.q)]
+            on_gamma = sum(yl * (p % self.gamma) for yl, p in zip(y, self.punct)) % self.gamma
+            on_gamma = on_gamma * self.neg_inv_Q_mod_gamma % self.gamma
+            on_t = sum(yl * (p & self.mask) for yl, p in zip(y, self.punct)) * self.neg_inv_Q_mod_t & self.mask
+            if on_gamma > self.gamma >> 1:
+                out.append(((on_t + self.gamma - on_gamma) * self.inv_gamma_mod_t) & self.mask)
+            else:
+                out.append(((on_t - on_gamma) * self.inv_gamma_mod_t) & self.mask)
+        return out

@@ -248,3 +248,14 @@ def test_conv2d_cpp_api(dev, shape, mod_switch, objective):
         pytest.fail("tests/cpp/conv2d_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv] + [str(v) for v in shape] + [str(mod_switch), objective], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "mismatches 0 of" in r.stdout, r.stdout + r.stderr
+
+
+def test_ring2k_cpp_api(dev):
+    """examples/13_ring2k.cu through PolynomialEncoderRing2k<uint32_t / uint64_t / unsigned __int128>: products in Z_{2^k}, also after a
+    modulus switch"""
+    drv = os.path.join(ROOT, "tests", "cpp", "ring2k_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/ring2k_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert r.stdout.count("example 1 random_mismatches 0 after_mod_switch 0") == 5 and "narrow_k_rejected 1" in r.stdout

@@ -6,4 +6,4 @@ loaded under the importable name ``troy_nova_amd`` by ``__graft_entry__.load_pac
 """
 from . import capi  # noqa: F401
 from .engine import (ASSIGN_ADD_INPLACE, ASSIGN_OVERWRITE, ASSIGN_OVERWRITE_EXCEPT_FIRST,  # noqa: F401
-                     IDX_COMPONENTWISE, IDX_KS_SET_PRODUCTS, IDX_KS_SKIP_FINALS, Behz, Bgv, Plan, Prng, sample_uniform_multi, to_device, to_host)
+                     IDX_COMPONENTWISE, IDX_KS_SET_PRODUCTS, IDX_KS_SKIP_FINALS, Behz, Bgv, Plan, Prng, Ring2k, sample_uniform_multi, to_device, to_host)

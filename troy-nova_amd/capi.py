@@ -71,6 +71,12 @@ SYMBOLS = {
     "troyn_bgv_multiply_scalar_mod_t": (C.c_int, [vp, vp, u64, vp, sz, vp]),
     "troyn_bgv_switch_key": (C.c_int, [vp, u32, vp, vp, C.c_int, vp, vp, sz, sz, vp]),
     "troyn_bgv_relinearize": (C.c_int, [vp, u32, vp, vp, vp, vp, sz, sz, vp]),
+    "troyn_ring2k_create": (C.c_int, [C.POINTER(vp), vp, u32, u32, u32]),
+    "troyn_ring2k_destroy": (C.c_int, [vp]),
+    "troyn_ring2k_gamma": (u64, [vp]),
+    "troyn_ring2k_scale_up": (C.c_int, [vp, vp, sz, vp, vp]),
+    "troyn_ring2k_centralize": (C.c_int, [vp, vp, sz, vp, vp]),
+    "troyn_ring2k_scale_down": (C.c_int, [vp, vp, vp, vp]),
     "troyn_gather_workspace_bytes": (sz, [sz]),
     "troyn_gather": (C.c_int, [vp, sz, sz, vp, vp, sz, vp]),
     "troyn_negacyclic_shift": (C.c_int, [vp, u32, u32, vp, vp, sz, sz, vp]),

@@ -15,6 +15,7 @@
 #include "behz_kernels.hpp"
 #include "crypto_kernels.hpp"
 #include "bgv_kernels.hpp"
+#include "ring2k_kernels.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
 #include "poly_kernels.hpp"
@@ -1439,6 +1440,117 @@ extern "C" int troyn_extract_lwe(const troyn_plan* p, uint32_t L, const uint64_t
     }
     hipLaunchKernelGGL(extract_lwe_c0_kernel, dim3((unsigned)((count * L + 255) / 256)), dim3(256), 0, s,
                        (unsigned)L, (unsigned)n, (const u64* const*)workspace, (const unsigned*)((const u64*)workspace + count), (u64*)c0, (unsigned)count);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ring-2^k encoder (src/app/bfv_ring2k.cu): constants of PolynomialEncoderRNSHelper for one level
+// ---------------------------------------------------------------------------------------
+struct troyn_ring2k {
+    const troyn_plan* plan = nullptr;
+    u64* d_consts = nullptr;
+    Ring2kDev dev;
+    u64 gamma = 0;
+};
+
+extern "C" int troyn_ring2k_destroy(troyn_ring2k* h) {
+    if (!h) return TROYN_OK;
+    if (h->d_consts) (void)hipFree(h->d_consts);
+    delete h;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_ring2k_create(troyn_ring2k** out, const troyn_plan* plan, uint32_t L, uint32_t t_bits, uint32_t elem_bytes) {
+    const char* P = "[PolynomialEncoderRNSHelper::PolynomialEncoderRNSHelper]";
+    if (!out || !plan) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    *out = nullptr;
+    if (L < 1 || L > plan->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
+    if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return fail(TROYN_E_INVALID, std::string(P) + " T must be uint32_t, uint64_t or uint128_t");
+    if (t_bits <= elem_bytes * 4 || t_bits > elem_bytes * 8) return fail(TROYN_E_INVALID, std::string(P) + " t_bit_length must be greater than type_bits<T>() / 2");
+    typedef unsigned __int128 u128h;
+    std::unique_ptr<troyn_ring2k, int (*)(troyn_ring2k*)> h(new troyn_ring2k, troyn_ring2k_destroy);
+    h->plan = plan;
+    const std::vector<u64> q(plan->moduli.begin(), plan->moduli.begin() + L);
+    u64 gamma;
+    try { gamma = host::get_primes((u64)plan->n, 61, 1)[0]; } catch (const std::exception& e) { return fail(TROYN_E_MODULUS, e.what()); }
+    for (u64 v : q) if (v == gamma) return fail(TROYN_E_MODULUS, std::string(P) + " gamma is in coeff_modulus");
+    h->gamma = gamma;
+    const u128h mask = t_bits == 128 ? ~(u128h)0 : (((u128h)1 << t_bits) - 1);
+    auto wrap_product = [&](size_t except) { u128h acc = 1; for (size_t k = 0; k < q.size(); k++) if (k != except) acc *= q[k]; return acc; };   // mod 2^128
+    auto inverse_2k = [](u128h x) { u128h inv = x; for (int it = 0; it < 8; it++) inv *= 2 - x * inv; return inv; };                            // x odd
+    const u128h Q128 = wrap_product(SIZE_MAX);
+    const u128h q_mod_t = Q128 & mask, neg_inv_q = (0 - inverse_2k(Q128)) & mask, inv_gamma = inverse_2k((u128h)gamma) & mask, t_half = (u128h)1 << (t_bits - 1);
+    // floor(Q / 2^k) mod q_l from the multi-word product
+    std::vector<u64> big = host::big_product(q), shifted(big.size(), 0);
+    for (size_t w = 0; w < big.size(); w++) {
+        const size_t src = w + t_bits / 64;
+        u64 v = src < big.size() ? big[src] >> (t_bits % 64) : 0;
+        if ((t_bits % 64) && src + 1 < big.size()) v |= big[src + 1] << (64 - t_bits % 64);
+        shifted[w] = v;
+    }
+    std::vector<u64> blob;
+    auto push_shoup = [&](u64 w, u64 m) { host::Shoup s = host::shoup(w % m, m); blob.push_back(s.operand); blob.push_back(s.quotient); };
+    const size_t off_qdt = blob.size();
+    for (size_t l = 0; l < L; l++) push_shoup(host::big_mod_small(shifted, q[l]), q[l]);
+    const size_t off_gt = blob.size();
+    for (size_t l = 0; l < L; l++) {
+        // gamma * 2^k mod q_l, with 2^k split as 2^(k/2) * 2^(k - k/2) (bfv_ring2k.cu:183-191)
+        const u64 t0 = (u64)(((u128h)1 << (t_bits / 2)) % q[l]), t1 = (u64)(((u128h)1 << (t_bits - t_bits / 2)) % q[l]);
+        push_shoup(host::mulmod(gamma % q[l], host::mulmod(t0, t1, q[l]), q[l]), q[l]);
+    }
+    const size_t off_ip = blob.size();
+    for (size_t l = 0; l < L; l++) {
+        u64 inv = 1;
+        if (L > 1 && !host::invmod(host::product_mod(q, l, q[l]), q[l], inv)) return fail(TROYN_E_MODULUS, "[RNSBase::initialize] RNSBase product is not invertible.");
+        push_shoup(inv, q[l]);
+    }
+    const size_t off_pg = blob.size();
+    for (size_t l = 0; l < L; l++) blob.push_back(host::product_mod(q, l, gamma));
+    if (blob.size() & 1) blob.push_back(0);
+    const size_t off_pt = blob.size();
+    for (size_t l = 0; l < L; l++) { const u128h v = wrap_product(l) & mask; blob.push_back((u64)v); blob.push_back((u64)(v >> 64)); }
+    u64 inv_q_gamma = 0;
+    if (!host::invmod(host::product_mod(q, SIZE_MAX, gamma), gamma, inv_q_gamma)) return fail(TROYN_E_MODULUS, std::string(P) + " failed to invert Q_mod_gamma");
+    HIP_TRY(hipSetDevice(plan->device));
+    HIP_TRY(hipMalloc(&h->d_consts, blob.size() * sizeof(u64)));
+    HIP_TRY(hipMemcpy(h->d_consts, blob.data(), blob.size() * sizeof(u64), hipMemcpyHostToDevice));
+    Ring2kDev& d = h->dev;
+    std::memset(&d, 0, sizeof(d));
+    d.mods = plan->d_mods;
+    d.q_div_t_mod_q = reinterpret_cast<const ulonglong2*>(h->d_consts + off_qdt);
+    d.gamma_t_mod_q = reinterpret_cast<const ulonglong2*>(h->d_consts + off_gt);
+    d.inv_punctured = reinterpret_cast<const ulonglong2*>(h->d_consts + off_ip);
+    d.punctured_mod_gamma = h->d_consts + off_pg;
+    d.punctured_mod_t = h->d_consts + off_pt;
+    d.gamma = make_dev_modulus(gamma, plan->log_n, false);
+    { host::Shoup s = host::shoup((gamma - inv_q_gamma) % gamma, gamma); d.neg_inv_q_mod_gamma = make_ulonglong2(s.operand, s.quotient); }
+    auto set2 = [](u64* dst, u128h v) { dst[0] = (u64)v; dst[1] = (u64)(v >> 64); };
+    set2(d.q_mod_t, q_mod_t); set2(d.t_half, t_half); set2(d.mask, mask); set2(d.neg_inv_q_mod_t, neg_inv_q); set2(d.inv_gamma_mod_t, inv_gamma);
+    d.L = L; d.n = plan->n; d.t_bits = t_bits; d.elem_bytes = elem_bytes;
+    *out = h.release();
+    return TROYN_OK;
+}
+
+extern "C" uint64_t troyn_ring2k_gamma(const troyn_ring2k* h) { return h ? h->gamma : 0; }
+
+static int ring2k_encode(const troyn_ring2k* h, bool scale, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) {
+    const char* P = scale ? "[PolynomialEncoderRNSHelper:scale_up]" : "[PolynomialEncoderRNSHelper:centralize]";
+    if (!h || !out || (!src && count)) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    if (count > h->dev.n) return fail(TROYN_E_INVALID, std::string(P) + " source size is larger than poly_modulus_degree");
+    const dim3 grid((h->dev.n + 255) / 256), block(256);
+    if (scale) hipLaunchKernelGGL(ring2k_scale_up_kernel, grid, block, 0, (hipStream_t)stream, h->dev, src, (unsigned)count, (u64*)out);
+    else hipLaunchKernelGGL(ring2k_centralize_kernel, grid, block, 0, (hipStream_t)stream, h->dev, src, (unsigned)count, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_ring2k_scale_up(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) { return ring2k_encode(h, true, src, count, out, stream); }
+extern "C" int troyn_ring2k_centralize(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) { return ring2k_encode(h, false, src, count, out, stream); }
+
+extern "C" int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in, void* dst, troyn_stream_t stream) {
+    if (!h || !in || !dst) return fail(TROYN_E_INVALID, "[PolynomialEncoderRNSHelper::scale_down] null argument");
+    hipLaunchKernelGGL(ring2k_scale_down_kernel, dim3((h->dev.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev, (const u64*)in, dst);
     LAUNCH_CHECK();
     return TROYN_OK;
 }

@@ -416,6 +416,58 @@ class Bgv:
         return out
 
 
+class Ring2k:
+    """troyn_ring2k: PolynomialEncoderRNSHelper<T> (src/app/bfv_ring2k.cu) of the level with the plan's first L primes; elements are
+    numpy arrays of uint32 / uint64, or uint64 pairs (low, high) for 128-bit elements."""
+
+    def __init__(self, plan, L, t_bits, elem_bits):
+        self.plan, self.L, self.t_bits, self.elem_bytes = plan, int(L), int(t_bits), elem_bits // 8
+        h = C.c_void_p()
+        capi.check(plan.lib.troyn_ring2k_create(C.byref(h), plan.h, self.L, self.t_bits, self.elem_bytes))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.plan.lib.troyn_ring2k_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def gamma(self):
+        return int(self.plan.lib.troyn_ring2k_gamma(self.h))
+
+    def _elements(self, values):
+        """list of Python ints -> device byte buffer"""
+        raw = b"".join(int(v).to_bytes(self.elem_bytes, "little") for v in values) or b"\0" * 16
+        host = np.frombuffer(raw + b"\0" * (-len(raw) % 8), dtype=np.int64).copy()
+        return torch.from_numpy(host).to(self.plan.device)
+
+    def _encode(self, fn, values):
+        buf = self._elements(values)
+        out = torch.empty((self.L, self.plan.n), dtype=torch.int64, device=self.plan.device)
+        capi.check(fn(self.h, _ptr(buf), len(values), _ptr(out), _stream()))
+        return out
+
+    def scale_up(self, values):
+        return self._encode(self.plan.lib.troyn_ring2k_scale_up, values)
+
+    def centralize(self, values):
+        return self._encode(self.plan.lib.troyn_ring2k_centralize, values)
+
+    def scale_down(self, phase):
+        """phase [L][N] coefficient form -> list of N Python ints"""
+        words = (self.plan.n * self.elem_bytes + 7) // 8
+        out = torch.empty(words, dtype=torch.int64, device=self.plan.device)
+        capi.check(self.plan.lib.troyn_ring2k_scale_down(self.h, _ptr(phase), _ptr(out), _stream()))
+        raw = out.cpu().numpy().tobytes()
+        return [int.from_bytes(raw[i * self.elem_bytes:(i + 1) * self.elem_bytes], "little") for i in range(self.plan.n)]
+
+
 class Behz:
     """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""
 

@@ -2294,6 +2294,20 @@ void Decryptor::decrypt_batched(const std::vector<const Ciphertext*>& encrypted,
     }
 }
 
+void Decryptor::bfv_decrypt_without_scaling_down(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool) const {
+    require_device_context("[Decryptor::bfv_decrypt]", context_);
+    if (encrypted.is_ntt_form()) throw std::invalid_argument("[Decryptor::bfv_decrypt] Ciphertext is in NTT form.");
+    if (!encrypted.on_device()) throw std::invalid_argument("[Decryptor::bfv_decrypt] Operand is on host; the decryptor runs on the GPU only.");
+    if (encrypted.contains_seed()) throw std::invalid_argument("[Decryptor::bfv_decrypt] Seed should be expanded first.");
+    if (!context_->get_context_data(encrypted.parms_id()).has_value()) throw std::invalid_argument("[Decryptor::bfv_decrypt] Ciphertext parms_id is not valid.");
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, encrypted.parms_id());
+    dot_product_ct_sk_array(encrypted, out.poly(), pool);
+    out.is_ntt_form() = false;
+    destination = std::move(out);
+}
+
 size_t Decryptor::invariant_noise_budget(const Ciphertext& encrypted, MemoryPoolHandle pool) const {
     // decryptor.cu:581-640
     const char* P = "[Decryptor::invariant_noise_budget]";

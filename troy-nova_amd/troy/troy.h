@@ -605,6 +605,12 @@ public:
     // decryptor.cu:581-640 (BFV / BGV): bits of room left before decryption fails; the phase is formed on the device, the
     // centred infinity norm of its CRT composition (a diagnostic, outside the hot path) on the host
     size_t invariant_noise_budget(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    // decryptor.cu:268-289: the phase c(s) = Delta m + v as an RNS polynomial of the ciphertext's level (coefficient form); the
+    // ring-2^k encoder scales it down itself
+    void bfv_decrypt_without_scaling_down(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext bfv_decrypt_without_scaling_down_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext d; bfv_decrypt_without_scaling_down(encrypted, d, pool); return d;
+    }
     // decryptor.h decrypt_batched (BFV two-polynomial ciphertexts of one level take the batched path; anything else loops)
     void decrypt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     // the plaintext coefficients of every ciphertext, concatenated on the host ([count][N]); one device-to-host copy
