@@ -3,7 +3,9 @@
 // scale_down gives the negacyclic product mod 2^k; for T = uint32_t, uint64_t and unsigned __int128 (N=16384, six 60-bit primes).
 #include <cstdio>
 #include <random>
+#include <sstream>
 
+#include "../../troy-nova_amd/troy/matmul.h"
 #include "../../troy-nova_amd/troy/ring2k.h"
 
 using namespace troy;
@@ -42,6 +44,44 @@ static bool run(const HeContextPointer& he, const Encryptor& encryptor, const De
     return ok && bad == 0 && bad_low == 0;
 }
 
+// y = x * w + s over Z_{2^k} through MatmulHelper's ring-2^k forms (tests of app/matmul with the Ring2k adapters), packed or not
+template <typename T>
+static bool run_matmul(const HeContextPointer& he, const KeyGenerator& keygen, const Encryptor& encryptor, const Decryptor& decryptor, const Evaluator& evaluator,
+                       size_t plain_bits, bool pack_lwe, const char* name) {
+    linear::PolynomialEncoderRing2k<T> encoder(he, plain_bits);
+    const T mask = encoder.t_mask();
+    const size_t M = 9, R = 40, Nn = 17, n = encoder.slot_count();
+    std::mt19937_64 gen(sizeof(T) * 7 + plain_bits + (pack_lwe ? 1 : 0));
+    auto rnd = [&]() { T v = static_cast<T>(gen()); if (sizeof(T) == 16) v = (v << 32 << 32) | static_cast<T>(gen()); return static_cast<T>(v & mask); };
+    std::vector<T> x(M * R), w(R * Nn), sb(M * Nn), want(M * Nn, 0);
+    for (auto& v : x) v = rnd();
+    for (auto& v : w) v = rnd();
+    for (auto& v : sb) v = rnd();
+    for (size_t i = 0; i < M; i++) for (size_t k = 0; k < R; k++) for (size_t j = 0; j < Nn; j++) want[i * Nn + j] = static_cast<T>((want[i * Nn + j] + x[i * R + k] * w[k * Nn + j]) & mask);
+    for (size_t i = 0; i < M * Nn; i++) want[i] = static_cast<T>((want[i] + sb[i]) & mask);
+    linear::MatmulHelper helper(M, R, Nn, n, linear::MatmulObjective::EncryptLeft, pack_lwe);
+    linear::Plain2d we = helper.encode_weights_ring2k(encoder, w.data(), std::nullopt);
+    linear::Cipher2d xe = helper.encrypt_inputs_ring2k(encryptor, encoder, x.data(), std::nullopt);
+    std::stringstream wire;
+    xe.save(wire, he);
+    xe = linear::Cipher2d::load_new(wire, he);
+    linear::Cipher2d ye = helper.matmul(evaluator, xe, we);
+    if (pack_lwe) {
+        GaloisKeys autokey = keygen.create_automorphism_keys(false);
+        ye = helper.pack_outputs(evaluator, autokey, ye);
+    }
+    linear::Plain2d se = helper.encode_outputs_ring2k(encoder, sb.data(), ye[0][0].parms_id());
+    ye.add_plain_inplace(evaluator, se);
+    std::stringstream ywire;
+    helper.serialize_outputs(evaluator, ye, ywire);
+    linear::Cipher2d yl = helper.deserialize_outputs(evaluator, ywire);
+    const std::vector<T> got = helper.decrypt_outputs_ring2k(encoder, decryptor, yl);
+    size_t bad = 0;
+    for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];
+    std::printf("matmul %s k=%zu pack_lwe %d mismatches %zu of %zu\n", name, plain_bits, pack_lwe ? 1 : 0, bad, got.size());
+    return bad == 0;
+}
+
 int main() {
     try {
         const size_t n = 16384;
@@ -62,6 +102,10 @@ int main() {
         ok = run<uint32_t>(he, encryptor, decryptor, evaluator, 32, "uint32") && ok;
         ok = run<u128>(he, encryptor, decryptor, evaluator, 128, "uint128") && ok;
         ok = run<u128>(he, encryptor, decryptor, evaluator, 80, "uint128") && ok;
+        ok = run_matmul<uint64_t>(he, keygen, encryptor, decryptor, evaluator, 64, false, "uint64") && ok;
+        ok = run_matmul<uint64_t>(he, keygen, encryptor, decryptor, evaluator, 50, true, "uint64") && ok;
+        ok = run_matmul<uint32_t>(he, keygen, encryptor, decryptor, evaluator, 32, true, "uint32") && ok;
+        ok = run_matmul<u128>(he, keygen, encryptor, decryptor, evaluator, 100, false, "uint128") && ok;
         bool threw = false;
         try { linear::PolynomialEncoderRing2k<uint64_t> bad(he, 32); } catch (const std::invalid_argument&) { threw = true; }
         std::printf("narrow_k_rejected %d\n", threw ? 1 : 0);

@@ -259,3 +259,5 @@ def test_ring2k_cpp_api(dev):
     r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert r.stdout.count("example 1 random_mismatches 0 after_mod_switch 0") == 5 and "narrow_k_rejected 1" in r.stdout
+    # y = x * w + s over Z_{2^k} through MatmulHelper's ring-2^k forms, packed and not
+    assert r.stdout.count("mismatches 0 of 153") == 4, r.stdout

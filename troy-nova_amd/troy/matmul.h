@@ -12,6 +12,7 @@
 #pragma once
 #include <functional>
 
+#include "ring2k.h"
 #include "troy.h"
 
 namespace troy { namespace linear {
@@ -132,6 +133,14 @@ public:
     Cipher2d encrypt_inputs_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const;
     Plain2d encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const;
     std::vector<double> decrypt_outputs_doubles(const CKKSEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
+    // Z_{2^k} matrices through PolynomialEncoderRing2k<T> (encoder_adapter.h:48-67: the encrypted operand is scaled up, the plaintext
+    // operand centralized, outputs are scaled down from the undivided phase); the same block layouts
+    template <typename T> Plain2d encode_weights_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* weights, std::optional<ParmsID> parms_id) const;
+    template <typename T> Plain2d encode_inputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* inputs, std::optional<ParmsID> parms_id) const;
+    template <typename T> Cipher2d encrypt_inputs_ring2k(const Encryptor& encryptor, const PolynomialEncoderRing2k<T>& encoder, const T* inputs, std::optional<ParmsID> parms_id) const;
+    template <typename T> Cipher2d encrypt_weights_ring2k(const Encryptor& encryptor, const PolynomialEncoderRing2k<T>& encoder, const T* weights, std::optional<ParmsID> parms_id) const;
+    template <typename T> Plain2d encode_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* outputs, std::optional<ParmsID> parms_id) const;
+    template <typename T> std::vector<T> decrypt_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
     // pack_lwe: input_block output ciphertexts are merged into one (Evaluator::pack_rlwe_ciphertexts, all groups batched);
     // the result is one row of ceil(#outputs / input_block) ciphertexts.  Needs the Galois keys of
     // (N / input_block) * 2^k + 1, k = 1..log2(input_block)
@@ -144,8 +153,134 @@ public:
 
 private:
     void determine_block();
+    // block (r, c) of the weights / inputs / outputs as a coefficient vector, any element type
+    template <typename T> std::vector<T> weight_block(const T* weights, size_t li, size_t lj) const {
+        std::vector<T> vec(input_block * output_block, 0);
+        for (size_t j = lj; j < std::min(lj + output_block, output_dims); j++)
+            for (size_t i = li; i < std::min(li + input_block, input_dims); i++) vec[(j - lj) * input_block + input_block - (i - li) - 1] = weights[i * output_dims + j];
+        return vec;
+    }
+    template <typename T> std::vector<T> input_block_vector(const T* inputs, size_t li, size_t lj) const {
+        std::vector<T> vec(slot_count, 0);
+        for (size_t i = li; i < std::min(li + batch_block, batch_size); i++)
+            for (size_t j = lj; j < std::min(lj + input_block, input_dims); j++) vec[(i - li) * input_block * output_block + (j - lj)] = inputs[i * input_dims + j];
+        return vec;
+    }
     std::vector<uint64_t> pack_weight_blocks(uint64_t t, const uint64_t* weights, size_t& rows, size_t& cols, size_t& len) const;
     std::vector<uint64_t> pack_input_blocks(uint64_t t, const uint64_t* inputs, size_t& rows, size_t& cols, size_t& len) const;
 };
+
+// ---- ring-2^k forms (templates; the element type is the encoder's) --------------------------------------------------------------
+template <typename T>
+Plain2d MatmulHelper::encode_weights_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* weights, std::optional<ParmsID> parms_id) const {
+    Plain2d out;
+    for (size_t li = 0; li < input_dims; li += input_block) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t lj = 0; lj < output_dims; lj += output_block) {
+            Plaintext p = encoder.centralize_new(weight_block(weights, li, lj), parms_id, pool);
+            Evaluator(encoder.context()).transform_plain_to_ntt_inplace(p, p.parms_id(), pool);
+            row.push_back(std::move(p));
+        }
+    }
+    return out;
+}
+
+template <typename T>
+Plain2d MatmulHelper::encode_inputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* inputs, std::optional<ParmsID> parms_id) const {
+    Plain2d out;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t lj = 0; lj < input_dims; lj += input_block) {
+            Plaintext p = encoder.centralize_new(input_block_vector(inputs, li, lj), parms_id, pool);
+            Evaluator(encoder.context()).transform_plain_to_ntt_inplace(p, p.parms_id(), pool);
+            row.push_back(std::move(p));
+        }
+    }
+    return out;
+}
+
+template <typename T>
+Cipher2d MatmulHelper::encrypt_inputs_ring2k(const Encryptor& encryptor, const PolynomialEncoderRing2k<T>& encoder, const T* inputs, std::optional<ParmsID> parms_id) const {
+    Evaluator evaluator(encoder.context());
+    Cipher2d out;
+    for (size_t li = 0; li < batch_size; li += batch_block) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (size_t lj = 0; lj < input_dims; lj += input_block) {
+            Plaintext p = encoder.scale_up_new(input_block_vector(inputs, li, lj), parms_id, pool);
+            evaluator.transform_plain_to_ntt_inplace(p, p.parms_id(), pool);
+            row.push_back(encryptor.encrypt_symmetric_new(p, true, pool));      // NTT form, c1 kept as its seed (app/matmul.cu:311)
+        }
+    }
+    return out;
+}
+
+template <typename T>
+Cipher2d MatmulHelper::encrypt_weights_ring2k(const Encryptor& encryptor, const PolynomialEncoderRing2k<T>& encoder, const T* weights, std::optional<ParmsID> parms_id) const {
+    Evaluator evaluator(encoder.context());
+    Cipher2d out;
+    for (size_t li = 0; li < input_dims; li += input_block) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (size_t lj = 0; lj < output_dims; lj += output_block) {
+            Plaintext p = encoder.scale_up_new(weight_block(weights, li, lj), parms_id, pool);
+            evaluator.transform_plain_to_ntt_inplace(p, p.parms_id(), pool);
+            row.push_back(encryptor.encrypt_symmetric_new(p, true, pool));
+        }
+    }
+    return out;
+}
+
+template <typename T>
+Plain2d MatmulHelper::encode_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* outputs, std::optional<ParmsID> parms_id) const {
+    const size_t n = slot_count, ocols = (output_dims + output_block - 1) / output_block, brows = (batch_size + batch_block - 1) / batch_block;
+    const size_t count = pack_lwe ? (brows * ocols + input_block - 1) / input_block : brows * ocols;
+    std::vector<std::vector<T>> buffers(count, std::vector<T>(n, 0));
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
+            const size_t cipher_id = di * ocols + dj;
+            std::vector<T>& buf = buffers[pack_lwe ? cipher_id / input_block : cipher_id];
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
+            for (size_t i = li; i < std::min(li + batch_block, batch_size); i++)
+                for (size_t j = lj; j < std::min(lj + output_block, output_dims); j++)
+                    buf[(i - li) * input_block * output_block + (j - lj) * input_block + offset] = outputs[i * output_dims + j];
+        }
+    }
+    Plain2d out;
+    if (pack_lwe) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (const auto& buf : buffers) row.push_back(encoder.scale_up_new(buf, parms_id, pool));
+    } else {
+        for (size_t r = 0; r < brows; r++) {
+            std::vector<Plaintext>& row = out.new_row();
+            for (size_t c = 0; c < ocols; c++) row.push_back(encoder.scale_up_new(buffers[r * ocols + c], parms_id, pool));
+        }
+    }
+    return out;
+}
+
+template <typename T>
+std::vector<T> MatmulHelper::decrypt_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
+    std::vector<std::vector<T>> coeffs;
+    for (const auto& r : outputs.data())
+        for (const Ciphertext& c : r) coeffs.push_back(encoder.scale_down_new(decryptor.bfv_decrypt_without_scaling_down_new(c, pool), pool));
+    const size_t ocols = (output_dims + output_block - 1) / output_block, brows = (batch_size + batch_block - 1) / batch_block;
+    if (coeffs.size() != (pack_lwe ? (brows * ocols + input_block - 1) / input_block : brows * ocols))
+        throw std::invalid_argument("[MatmulHelper::decrypt_outputs] Output ciphertext count incorrect");
+    std::vector<T> out(batch_size * output_dims, 0);
+    size_t di = 0;
+    for (size_t li = 0; li < batch_size; li += batch_block, di++) {
+        size_t dj = 0;
+        for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
+            const size_t cipher_id = di * ocols + dj;
+            const std::vector<T>& cf = coeffs[pack_lwe ? cipher_id / input_block : cipher_id];
+            const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
+            for (size_t i = li; i < std::min(li + batch_block, batch_size); i++)
+                for (size_t j = lj; j < std::min(lj + output_block, output_dims); j++)
+                    out[i * output_dims + j] = cf[(i - li) * input_block * output_block + (j - lj) * input_block + offset];
+        }
+    }
+    return out;
+}
 
 }}  // namespace troy::linear
