@@ -50,14 +50,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X")
+    torch.cuda.set_device(local_rank)             # before the process group: RCCL binds its communicator to the current device
+    device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
 
     pkg = entry.load_package()
     import importlib

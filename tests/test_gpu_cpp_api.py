@@ -261,3 +261,14 @@ def test_ring2k_cpp_api(dev):
     assert r.stdout.count("example 1 random_mismatches 0 after_mod_switch 0") == 5 and "narrow_k_rejected 1" in r.stdout
     # y = x * w + s over Z_{2^k} through MatmulHelper's ring-2^k forms, packed and not
     assert r.stdout.count("mismatches 0 of 153") == 4, r.stdout
+
+
+def test_conv2d_ckks_ring2k_cpp_api(dev):
+    """Conv2dHelper beyond BFV mod t: the CKKS forms (examples/15_ckks_conv2d.cu, both objectives) and the ring-2^k forms through
+    PolynomialEncoderRing2k<uint64_t / uint32_t / unsigned __int128>, with the wire formats in between"""
+    drv = os.path.join(ROOT, "tests", "cpp", "conv2d_ext_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/conv2d_ext_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert r.stdout.count("mismatches 0 of 800") == 3 and "ckks max_error" in r.stdout

@@ -42,60 +42,14 @@ size_t Conv2dHelper::get_total_batch_size() const {
     return ceil_div(batch_size, batch_block) * ceil_div(image_height - kh, image_height_block - kh) * ceil_div(image_width - kw, image_width_block - kw);
 }
 
+static void check_below(uint64_t v, uint64_t t) { if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus"); }
+
 std::vector<uint64_t> Conv2dHelper::pack_weights(uint64_t t, const uint64_t* weights, size_t& rows, size_t& cols, size_t& len) const {
-    // app/conv2d.cu:110-134: per (output block, input block) the flipped kernels, input channels in reverse order
-    const size_t blk = image_height_block * image_width_block;
-    rows = ceil_div(output_channels, output_channel_block); cols = ceil_div(input_channels, input_channel_block);
-    len = input_channel_block * output_channel_block * blk;
-    std::vector<uint64_t> packed(rows * cols * len, 0);
-    size_t idx = 0;
-    for (size_t loc = 0; loc < output_channels; loc += output_channel_block) {
-        const size_t uoc = std::min(loc + output_channel_block, output_channels);
-        for (size_t lic = 0; lic < input_channels; lic += input_channel_block, idx++) {
-            const size_t uic = std::min(lic + input_channel_block, input_channels);
-            uint64_t* spread = packed.data() + idx * len;
-            for (size_t oc = loc; oc < uoc; oc++)
-                for (size_t ic = lic; ic < uic; ic++)
-                    for (size_t ki = 0; ki < kernel_height; ki++)
-                        for (size_t kj = 0; kj < kernel_width; kj++) {
-                            const uint64_t v = weights[((oc * input_channels) + ic) * (kernel_height * kernel_width) + (kernel_height - ki - 1) * kernel_width + (kernel_width - kj - 1)];
-                            if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
-                            spread[(oc - loc) * input_channel_block * blk + (input_channel_block - 1 - (ic - lic)) * blk + ki * image_width_block + kj] = v;
-                        }
-        }
-    }
-    return packed;
+    return pack_weights_of<uint64_t>(weights, rows, cols, len, [t](uint64_t v) { check_below(v, t); });
 }
 
 std::vector<uint64_t> Conv2dHelper::pack_inputs(uint64_t t, const uint64_t* inputs, size_t& rows, size_t& cols, size_t& len) const {
-    // app/conv2d.cu:176-222: overlapping tiles (stride hb - (kh-1), wb - (kw-1)), one row of input-channel blocks per tile
-    const size_t kh = kernel_height - 1, kw = kernel_width - 1;
-    const size_t sh = ceil_div(image_height - kh, image_height_block - kh), sw = ceil_div(image_width - kw, image_width_block - kw);
-    const size_t image_size = image_height * image_width, blk = image_height_block * image_width_block;
-    rows = ceil_div(batch_size, batch_block) * sh * sw; cols = ceil_div(input_channels, input_channel_block); len = slot_count;
-    std::vector<uint64_t> packed(rows * cols * len, 0);
-    size_t idx = 0;
-    for (size_t lb = 0; lb < batch_size; lb += batch_block) {
-        const size_t ub = std::min(lb + batch_block, batch_size);
-        for (size_t ih = 0; ih < sh; ih++)
-            for (size_t iw = 0; iw < sw; iw++) {
-                const size_t si = ih * (image_height_block - kh), sj = iw * (image_width_block - kw);
-                const size_t ui = std::min(si + image_height_block, image_height), uj = std::min(sj + image_width_block, image_width);
-                for (size_t lci = 0; lci < input_channels; lci += input_channel_block, idx++) {
-                    const size_t uci = std::min(lci + input_channel_block, input_channels);
-                    uint64_t* vec = packed.data() + idx * len;
-                    for (size_t b = 0; b < ub - lb; b++)
-                        for (size_t tci = 0; tci < uci - lci; tci++)
-                            for (size_t ti = si; ti < ui; ti++)
-                                for (size_t tj = sj; tj < uj; tj++) {
-                                    const uint64_t v = inputs[(lb + b) * input_channels * image_size + (lci + tci) * image_size + ti * image_width + tj];
-                                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
-                                    vec[b * input_channel_block * output_channel_block * blk + tci * blk + (ti - si) * image_width_block + (tj - sj)] = v;
-                                }
-                }
-            }
-    }
-    return packed;
+    return pack_inputs_of<uint64_t>(inputs, rows, cols, len, [t](uint64_t v) { check_below(v, t); });
 }
 
 static uint64_t plain_modulus_of(const BatchEncoder& encoder) { return encoder.context()->first_context_data().value()->parms().plain_modulus().value(); }
@@ -158,33 +112,6 @@ Cipher2d Conv2dHelper::conv2d_cipher(const Evaluator& evaluator, const Cipher2d&
     return ret;
 }
 
-template <typename F>
-void Conv2dHelper::for_each_output(F&& f) const {
-    // app/conv2d.cu:259-292, :306-345: tile (ob, si, sj), output block lc, then the (b, c, i, j) of the tile that exist in the image
-    const size_t interval = image_width_block * image_height_block;
-    const size_t yh = image_height_block - kernel_height + 1, yw = image_width_block - kernel_width + 1;
-    const size_t oyh = image_height - kernel_height + 1, oyw = image_width - kernel_width + 1;
-    const size_t kh = kernel_height - 1, kw = kernel_width - 1;
-    const size_t sh = ceil_div(image_height - kh, image_height_block - kh), sw = ceil_div(image_width - kw, image_width_block - kw);
-    const size_t tiles = get_total_batch_size();
-    for (size_t eb = 0; eb < tiles; eb++) {
-        const size_t ob = eb / (sh * sw), si = (eb % (sh * sw)) / sw, sj = eb % sw;
-        const size_t lb = ob * batch_block, ub = std::min(lb + batch_block, batch_size);
-        for (size_t lc = 0; lc < output_channels; lc += output_channel_block) {
-            const size_t uc = std::min(lc + output_channel_block, output_channels);
-            for (size_t b = lb; b < ub; b++)
-                for (size_t c = lc; c < uc; c++)
-                    for (size_t i = 0; i < yh; i++)
-                        for (size_t j = 0; j < yw; j++) {
-                            if (si * yh + i >= oyh || sj * yw + j >= oyw) continue;
-                            const size_t coefficient = ((b - lb) * input_channel_block * output_channel_block + (c - lc) * input_channel_block + input_channel_block - 1) * interval +
-                                                       (image_height_block - yh + i) * image_width_block + (image_width_block - yw + j);
-                            f(eb, lc / output_channel_block, coefficient, b * output_channels * oyh * oyw + c * oyh * oyw + (si * yh + i) * oyw + (sj * yw + j));
-                        }
-        }
-    }
-}
-
 Plain2d Conv2dHelper::encode_outputs_uint64s(const BatchEncoder& encoder, const uint64_t* outputs) const {
     const size_t tiles = get_total_batch_size(), groups = ceil_div(output_channels, output_channel_block);
     std::vector<std::vector<uint64_t>> buffers(tiles * groups, std::vector<uint64_t>(slot_count, 0));
@@ -207,6 +134,70 @@ std::vector<uint64_t> Conv2dHelper::decrypt_outputs_uint64s(const BatchEncoder& 
     const size_t oyh = image_height - kernel_height + 1, oyw = image_width - kernel_width + 1;
     std::vector<uint64_t> out(batch_size * output_channels * oyh * oyw, 0);
     for_each_output([&](size_t tile, size_t group, size_t coefficient, size_t index) { out[index] = coeffs[(tile * groups + group) * n + coefficient]; });
+    return out;
+}
+
+// ---- CKKS forms (app/conv2d.cu *_doubles): the same layouts through CKKSEncoder's polynomial encoding ------------------------------
+static Plain2d encode_double_blocks(const CKKSEncoder& encoder, const std::vector<double>& packed, size_t rows, size_t cols, size_t len, std::optional<ParmsID> parms_id,
+                                    double scale, MemoryPoolHandle pool) {
+    Plain2d out;
+    for (size_t r = 0; r < rows; r++) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t k = 0; k < cols; k++) {
+            const auto begin = packed.begin() + static_cast<std::ptrdiff_t>((r * cols + k) * len);
+            row.push_back(encoder.encode_float64_polynomial_new(std::vector<double>(begin, begin + static_cast<std::ptrdiff_t>(len)), parms_id, scale, pool));
+        }
+    }
+    return out;
+}
+
+static Cipher2d encrypt_plain2d(const Encryptor& encryptor, const Plain2d& plain, MemoryPoolHandle pool) {
+    Cipher2d out;
+    for (const auto& prow : plain.data()) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (const Plaintext& p : prow) row.push_back(encryptor.encrypt_symmetric_new(p, true, pool));   // c1 travels as its seed
+    }
+    return out;
+}
+
+Plain2d Conv2dHelper::encode_weights_doubles(const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const {
+    size_t rows, cols, len;
+    const std::vector<double> packed = pack_weights_of<double>(weights, rows, cols, len, [](double) {});
+    return encode_double_blocks(encoder, packed, rows, cols, len, parms_id, scale, pool);
+}
+Plain2d Conv2dHelper::encode_inputs_doubles(const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const {
+    size_t rows, cols, len;
+    const std::vector<double> packed = pack_inputs_of<double>(inputs, rows, cols, len, [](double) {});
+    return encode_double_blocks(encoder, packed, rows, cols, len, parms_id, scale, pool);
+}
+Cipher2d Conv2dHelper::encrypt_weights_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const {
+    return encrypt_plain2d(encryptor, encode_weights_doubles(encoder, weights, parms_id, scale), pool);
+}
+Cipher2d Conv2dHelper::encrypt_inputs_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* inputs, std::optional<ParmsID> parms_id, double scale) const {
+    return encrypt_plain2d(encryptor, encode_inputs_doubles(encoder, inputs, parms_id, scale), pool);
+}
+
+Plain2d Conv2dHelper::encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const {
+    const size_t tiles = get_total_batch_size(), groups = (output_channels + output_channel_block - 1) / output_channel_block;
+    std::vector<std::vector<double>> buffers(tiles * groups, std::vector<double>(slot_count, 0.0));
+    for_each_output([&](size_t tile, size_t group, size_t coefficient, size_t index) { buffers[tile * groups + group][coefficient] = outputs[index]; });
+    Plain2d out;
+    for (size_t tile = 0; tile < tiles; tile++) {
+        std::vector<Plaintext>& row = out.new_row();
+        for (size_t g = 0; g < groups; g++) row.push_back(encoder.encode_float64_polynomial_new(buffers[tile * groups + g], parms_id, scale, pool));
+    }
+    return out;
+}
+
+std::vector<double> Conv2dHelper::decrypt_outputs_doubles(const CKKSEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const {
+    const size_t tiles = get_total_batch_size(), groups = (output_channels + output_channel_block - 1) / output_channel_block;
+    std::vector<std::vector<double>> coeffs;
+    for (const auto& r : outputs.data())
+        for (const Ciphertext& ct : r) coeffs.push_back(encoder.decode_float64_polynomial_new(decryptor.decrypt_new(ct, pool), pool));
+    if (coeffs.size() != tiles * groups) throw std::invalid_argument("[Conv2dHelper::decrypt_outputs] Output ciphertext count incorrect");
+    const size_t oyh = image_height - kernel_height + 1, oyw = image_width - kernel_width + 1;
+    std::vector<double> out(batch_size * output_channels * oyh * oyw, 0.0);
+    for_each_output([&](size_t tile, size_t group, size_t coefficient, size_t index) { out[index] = coeffs[tile * groups + group][coefficient]; });
     return out;
 }
 
