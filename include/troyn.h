@@ -211,6 +211,10 @@ int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, u
  * the permuted c1 with TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST (evaluator_keyswitching.cu:147-179). */
 int troyn_apply_galois(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
                        const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream);
+/* GaloisTool::apply (utils/galois.cu:43-66) on `count` coefficient-form polynomials [N] modulo ONE explicit modulus -- the plain
+ * modulus t of a BFV / BGV plaintext (Evaluator::apply_galois_plain, evaluator_keyswitching.cu:235-261). */
+int troyn_apply_galois_plain(const troyn_plan* plan, uint64_t modulus, uint64_t galois_element, const uint64_t* in, uint64_t* out, size_t count,
+                             troyn_stream_t stream);
 /* ---------------------------------------------------------------------------------------
  * BGV.  BGV ciphertexts live in NTT form and reuse troyn_ntt, troyn_dyadic_convolute (bgv_multiply,
  * evaluator.cu:150-173), troyn_add/sub/negate/multiply_scalar, troyn_apply_galois and troyn_plain_centralize unchanged; the

@@ -272,3 +272,15 @@ def test_conv2d_ckks_ring2k_cpp_api(dev):
     r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert r.stdout.count("mismatches 0 of 800") == 3 and "ckks max_error" in r.stdout
+
+
+def test_plain_ops_cpp_api(dev):
+    """plaintext-side API: BatchEncoder::scale_up / scale_down / centralize / decentralize with partial RNS plaintexts as operands of
+    encrypt / add_plain / multiply_plain, Evaluator::apply_galois_plain against the rotation under encryption (BFV, BGV, CKKS), the
+    integer and single-value CKKS encodings, is_transparent"""
+    drv = os.path.join(ROOT, "tests", "cpp", "plain_ops_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/plain_ops_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "FAIL" not in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count(" ok\n") >= 44, r.stdout

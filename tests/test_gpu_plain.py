@@ -97,6 +97,31 @@ def test_apply_galois(O, pkg, dev, scheme, ntt, n, bits):
         plan.apply_galois_poly(dct, L, 4, False)         # even element
 
 
+@pytest.mark.parametrize("n,t", [(8192, 1032193), (64, 1 << 21), (4096, (1 << 61) - 1)])
+def test_apply_galois_plain(O, pkg, dev, n, t):
+    """GaloisTool::apply on plaintexts modulo the plain modulus (Evaluator::apply_galois_plain, coefficient form): X -> X^g with the
+    negacyclic sign, checked against the index arithmetic of utils/galois.cu:43-66 and, for t among the q_i, against the oracle"""
+    q = [int(v) for v in O.coeff_modulus_create(max(n, 32), [40, 40, 40])]
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, t, size=(3, n), dtype=np.uint64)
+    dx = pkg.to_device(x, dev)
+    for g in (3, 2 * n - 1, n + 1, 5 ** 7 % (2 * n)):
+        got = pkg.to_host(plan.apply_galois_plain(dx, t, g))
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(g)
+        dst = (idx & np.uint64(n - 1)).astype(np.int64)
+        neg = ((idx >> np.uint64(n.bit_length() - 1)) & np.uint64(1)).astype(bool)
+        exp = np.empty_like(x)
+        exp[:, dst] = np.where(neg[None, :], (np.uint64(t) - x) % np.uint64(t), x)
+        assert np.array_equal(got, exp), g
+    # the same kernel with t = q_0 must agree with the plan-modulus form the oracle covers
+    ctx = O.Context("bfv", n, q, 1032193) if n >= 32 else None
+    y = rng.integers(0, q[0], size=(1, 1, n), dtype=np.uint64)
+    assert np.array_equal(pkg.to_host(plan.apply_galois_plain(pkg.to_device(y.reshape(1, n), dev), q[0], 3)).reshape(1, n), ctx.apply_galois(1, False, 3, y).reshape(1, n))
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.apply_galois_plain(dx, t, 2 * n + 1)
+
+
 def test_rotation_decrypts(O, pkg, dev):
     """rotate_rows / rotate_columns with genuine Galois keys: device result == oracle, and it decrypts to the rotated slots"""
     n, t = 8192, 1032193

@@ -53,6 +53,7 @@ SYMBOLS = {
     "troyn_multiply_plain_accumulate_workspace_bytes": (sz, [sz]),
     "troyn_multiply_plain_accumulate": (C.c_int, [vp, u32, u32, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.c_int, vp, sz, vp]),
     "troyn_apply_galois": (C.c_int, [vp, u32, u32, C.c_int, u64, vp, vp, sz, vp]),
+    "troyn_apply_galois_plain": (C.c_int, [vp, u64, u64, vp, vp, sz, vp]),
     "troyn_behz_gamma": (u64, [vp]),
     "troyn_bfv_scale_up": (C.c_int, [vp, vp, sz, sz, vp, sz, vp, sz, C.c_int, sz, vp]),
     "troyn_bfv_decrypt_scale_and_round": (C.c_int, [vp, vp, vp, sz, vp]),

@@ -273,10 +273,10 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac_kernel(unsigned chunks, 
 //   table(i) = bitrev_logN(((g * bitrev_{logN+1}(i + N)) >> 1) mod N) -- computed on the fly, no table upload.
 // data [rows][n], one limb-polynomial per row; row % nmod selects the modulus (negation in coefficient form).
 __global__ __launch_bounds__(POLY_BLOCK) void galois_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned log_n,
-                                                            unsigned g, int is_ntt_form, const u64* in, u64* out) {
+                                                            unsigned g, int is_ntt_form, const u64* in, u64* out, u64 q_single) {
     const unsigned n = 1u << log_n, mask = n - 1;
     const size_t row = blk_row(chunks);
-    const u64 q = mods[mod_start + row % nmod].q;
+    const u64 q = q_single ? q_single : mods[mod_start + row % nmod].q;    // q_single: one polynomial modulo the plain modulus (GaloisTool::apply)
     const u64* ip = in + row * n;
     u64* op = out + row * n;
     for (unsigned i = blk_col(chunks); i < n; i += chunks * blockDim.x) {

@@ -1328,7 +1328,22 @@ extern "C" int troyn_apply_galois(const troyn_plan* p, uint32_t mod_start, uint3
     const unsigned ch = chunks_single(p->n);
     if (int rc = check_rows(rows, ch)) return rc;
     hipLaunchKernelGGL(galois_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
-                       ch, p->d_mods, mod_start, nmod, p->log_n, (unsigned)galois_element, is_ntt_form ? 1 : 0, (const u64*)in, (u64*)out);
+                       ch, p->d_mods, mod_start, nmod, p->log_n, (unsigned)galois_element, is_ntt_form ? 1 : 0, (const u64*)in, (u64*)out, (u64)0);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_apply_galois_plain(const troyn_plan* p, uint64_t modulus, uint64_t galois_element, const uint64_t* in, uint64_t* out, size_t count,
+                                        troyn_stream_t stream) {
+    if (!p || !in || !out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] null argument");
+    if (in == out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] the permutation cannot run in place");
+    if (modulus < 2) return fail(TROYN_E_INVALID, "[GaloisTool::apply] modulus is invalid");
+    if ((galois_element & 1) == 0 || galois_element >= 2ull * p->n) return fail(TROYN_E_INVALID, "[Evaluator::apply_galois_inplace] Galois element is not valid.");
+    if (count == 0) return TROYN_OK;
+    const unsigned ch = chunks_single(p->n);
+    if (int rc = check_rows(count, ch)) return rc;
+    hipLaunchKernelGGL(galois_kernel, dim3((unsigned)(count * ch)), dim3(POLY_BLOCK), 0, (hipStream_t)stream,
+                       ch, p->d_mods, 0u, 1u, p->log_n, (unsigned)galois_element, 0, (const u64*)in, (u64*)out, (u64)modulus);
     LAUNCH_CHECK();
     return TROYN_OK;
 }

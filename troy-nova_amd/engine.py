@@ -178,6 +178,12 @@ class Plan:
         capi.check(self.lib.troyn_apply_galois(self.h, mod_start, nmod, int(is_ntt_form), int(element), _ptr(x), _ptr(out), count, _stream()))
         return out
 
+    def apply_galois_plain(self, x, modulus, element):
+        """X -> X^element on coefficient-form polynomials [count][N] modulo one explicit modulus (GaloisTool::apply with the plain modulus)"""
+        out = torch.empty_like(x)
+        capi.check(self.lib.troyn_apply_galois_plain(self.h, int(modulus), int(element), _ptr(x), _ptr(out), x.numel() // self.n, _stream()))
+        return out
+
     def apply_galois(self, L, ct, element, keys, is_ckks=True, is_ntt_form=True):
         """ct [batch][2][L][N] -> Evaluator::apply_galois: permute both polynomials, key-switch the second"""
         out = self.apply_galois_poly(ct, L, element, is_ntt_form)

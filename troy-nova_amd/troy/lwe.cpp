@@ -131,7 +131,13 @@ void Evaluator::translate_plain_inplace(Ciphertext& encrypted, const Plaintext& 
                                                       encrypted.poly(0), static_cast<size_t>(L) * n, subtract ? 1 : 0, 1, stream()));
             } else {
                 if (plain.parms_id() != encrypted.parms_id()) throw std::invalid_argument(std::string(P) + " Plaintext and ciphertext parameters do not match.");
-                if (plain.coeff_count() != n) throw std::logic_error(std::string(P) + " partial RNS plaintexts are not part of this build.");
+                if (plain.coeff_count() != n) {
+                    // a partial RNS plaintext (BatchEncoder::scale_up of a short polynomial): zero-padded to the full shape first
+                    const utils::DynamicArray full = plain.expanded_rns(L, n, pool);
+                    troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), full.raw_pointer(), encrypted.poly(0), 1, stream()));
+                    troyn_sync_current_stream();
+                    break;
+                }
                 troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), plain.poly(), encrypted.poly(0), 1, stream()));
             }
             break;

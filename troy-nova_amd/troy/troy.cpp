@@ -1135,8 +1135,14 @@ void Evaluator::transform_plain_to_ntt(const Plaintext& plain, const ParmsID& pa
         troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
     } else {
         if (plain.parms_id() != parms_id) throw std::invalid_argument(std::string(P) + " Plaintext parameters do not match.");
-        if (plain.coeff_count() != n) throw std::logic_error("[Evaluator::transform_plain_to_ntt] partial RNS plaintexts are not part of this build.");
-        troyn_check(troyn_ntt(context_->plan(), 0, plain.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        if (plain.coeff_count() != n) {
+            // a partial RNS plaintext: zero-padded to the full shape, then transformed in place
+            utils::DynamicArray full = plain.expanded_rns(L, n, pool);
+            troyn_check(troyn_ntt(context_->plan(), 0, full.raw_pointer(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+            hip_check(hipStreamSynchronize(s), "stream_sync");
+        } else {
+            troyn_check(troyn_ntt(context_->plan(), 0, plain.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        }
     }
     out.is_ntt_form() = true;
     destination = std::move(out);
@@ -1986,9 +1992,14 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
                 if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " BFV - Plaintext parms_id is not valid.");
                 const uint32_t L = static_cast<uint32_t>(cdo.value()->parms().coeff_modulus().size());
                 encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool);
-                if (plain.coeff_count() != cdo.value()->parms().poly_modulus_degree())
-                    throw std::logic_error("[Encryptor::encrypt_internal] partial RNS plaintexts are not part of this build.");
-                troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
+                if (plain.coeff_count() != cdo.value()->parms().poly_modulus_degree()) {
+                    // a partial RNS plaintext (BatchEncoder::scale_up of a short polynomial): zero-padded to the full shape first
+                    const utils::DynamicArray full = plain.expanded_rns(L, cdo.value()->parms().poly_modulus_degree(), pool);
+                    troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), full.raw_pointer(), destination.poly(0), 1, s));
+                    hip_check(hipStreamSynchronize(s), "stream_sync");
+                } else {
+                    troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
+                }
             }
             break;
         }

@@ -162,6 +162,9 @@ public:
     bool is_zero() const { return value_ == 0; }
     const uint64_t* const_ratio() const { return const_ratio_; }
     uint64_t reduce(uint64_t input) const;
+    uint64_t reduce_mul_uint64(uint64_t operand1, uint64_t operand2) const {                 // modulus.h:86-92 (Barrett-128; the canonical residue)
+        return static_cast<uint64_t>((static_cast<unsigned __int128>(operand1) * operand2) % value_);
+    }
 private:
     uint64_t value_ = 0;
     uint64_t const_ratio_[3] = {0, 0, 0};
@@ -349,6 +352,7 @@ public:
     uint64_t seed() const noexcept { return seed_; }
     uint64_t& seed() noexcept { return seed_; }
     bool contains_seed() const noexcept { return seed_ != 0; }
+    bool is_transparent() const;                          // ciphertext.cu:73-77: no data, fewer than two polynomials, or all words zero
     bool on_device() const noexcept { return data_.on_device(); }
     MemoryPoolHandle pool() const { return data_.pool(); }
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
@@ -406,6 +410,8 @@ public:
     const uint64_t* poly() const { return data_.raw_pointer(); }
     void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
     void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
+    // plaintext.cu resize_rns_partial: an RNS polynomial that keeps only its first coeff_count coefficients, data[l * coeff_count + i]
+    void resize_rns_partial(const HeContext& context, const ParmsID& parms_id, size_t coeff_count);
     Plaintext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
     // plaintext.cu:20-70, plaintext.h save/load: [CompressionMode][raw fields]; byte-compatible with the reference
     size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
@@ -414,6 +420,11 @@ public:
     size_t serialized_size_upperbound(CompressionMode mode = CompressionMode::Nil) const;
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
+    Plaintext to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p = *this; p.to_device_inplace(pool); return p; }
+    Plaintext to_host() const { Plaintext p = *this; p.to_host_inplace(); return p; }
+    MemoryPoolHandle pool() const { return data_.pool(); }
+    // a full-size ([L][N], zero-padded) device copy of an RNS plaintext that keeps only coeff_count coefficients per limb
+    utils::DynamicArray expanded_rns(size_t coeff_modulus_size, size_t poly_modulus_degree, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
 private:
     size_t coeff_count_ = 0;
     ParmsID parms_id_;
@@ -436,6 +447,11 @@ public:
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.to_device_inplace(pool); }
     void to_host_inplace() { data_.to_host_inplace(); }
     SecretKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    SecretKey to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { SecretKey k = *this; k.to_device_inplace(pool); return k; }
+    SecretKey to_host() const { SecretKey k = *this; k.to_host_inplace(); return k; }
+    const ParmsID& parms_id() const { return data_.parms_id(); }
+    ParmsID& parms_id() { return data_.parms_id(); }
+    size_t serialized_size_upperbound(CompressionMode mode = CompressionMode::Nil) const { return data_.serialized_size_upperbound(mode); }
     size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const { return data_.save(stream, mode); }
     void load(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.load(stream, pool); }
     static SecretKey load_new(std::istream& stream, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { SecretKey k; k.load(stream, pool); return k; }
@@ -453,7 +469,11 @@ public:
     const Ciphertext& as_ciphertext() const { return data_; }
     Ciphertext& as_ciphertext() { return data_; }
     const ParmsID& parms_id() const { return data_.parms_id(); }
+    ParmsID& parms_id() { return data_.parms_id(); }
     PublicKey clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    PublicKey to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { PublicKey k = *this; k.to_device_inplace(pool); return k; }
+    PublicKey to_host() const { PublicKey k = *this; k.to_host_inplace(); return k; }
+    size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const { return data_.serialized_size_upperbound(context, mode); }
     size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const { return data_.save(stream, context, mode); }
     void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { data_.load(stream, context, pool); }
     static PublicKey load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { PublicKey k; k.load(stream, context, pool); return k; }
@@ -481,6 +501,9 @@ public:
     // device pointers of key_vector[index][j] (kswitch_keys.h:34-54), as a host array for the C-ABI
     std::vector<const uint64_t*> get_data_ptrs(size_t index) const;
     const KSwitchKeys& as_kswitch_keys() const { return *this; }
+    KSwitchKeys clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
+    KSwitchKeys to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { KSwitchKeys k = *this; k.to_device_inplace(pool); return k; }
+    KSwitchKeys to_host() const { KSwitchKeys k = *this; k.to_host_inplace(); return k; }
     // kswitch_keys.cu:5-55
     size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
@@ -640,6 +663,26 @@ public:
     // coefficient ("polynomial") packing: values are the plaintext coefficients themselves (batch_encoder.cu encode_polynomial)
     Plaintext encode_polynomial_new(const std::vector<uint64_t>& values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<uint64_t> decode_polynomial_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void encode_polynomial(const std::vector<uint64_t>& values, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encode_polynomial_new(values, pool); }
+    void decode_polynomial(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = decode_polynomial_new(plain, pool); }
+    constexpr size_t row_count() const noexcept { return 2; }
+    size_t column_count() const noexcept { return slots_ / 2; }
+    bool simd_encoding_supported() const { return !matrix_reps_index_map_.empty(); }
+    // batch_encoder.cu:558-662: a mod-t plaintext to / from its RNS form at a level.  scale_up = round(q/t * m) (what encryption adds to c0),
+    // centralize = the centred lift (what multiply_plain uses); scale_down / decentralize are their inverses (the final steps of BFV /
+    // BGV decryption).  The RNS plaintexts keep only the source's coeff_count coefficients per limb ("partial").
+    Plaintext scale_up_new(const Plaintext& plain, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void scale_up(const Plaintext& plain, Plaintext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = scale_up_new(plain, parms_id, pool); }
+    void scale_up_inplace(Plaintext& plain, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { plain = scale_up_new(plain, parms_id, pool); }
+    Plaintext scale_down_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void scale_down(const Plaintext& plain, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = scale_down_new(plain, pool); }
+    void scale_down_inplace(Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { plain = scale_down_new(plain, pool); }
+    Plaintext centralize_new(const Plaintext& plain, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void centralize(const Plaintext& plain, Plaintext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = centralize_new(plain, parms_id, pool); }
+    void centralize_inplace(Plaintext& plain, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { plain = centralize_new(plain, parms_id, pool); }
+    Plaintext decentralize_new(const Plaintext& plain, uint64_t correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void decentralize(const Plaintext& plain, Plaintext& destination, uint64_t correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = decentralize_new(plain, correction_factor, pool); }
+    void decentralize_inplace(Plaintext& plain, uint64_t correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { plain = decentralize_new(plain, correction_factor, pool); }
 private:
     HeContextPointer context_;
     size_t slots_ = 0;
@@ -674,6 +717,24 @@ public:
                                    MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext encode_float64_polynomial_new(const std::vector<double>& values, std::optional<ParmsID> parms_id, double scale,
                                             MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_float64_polynomial(values, parms_id, scale, p, pool); return p; }
+    // one complex value in every slot (ckks_encoder.h:42-48, :171-186)
+    void encode_complex64_single(std::complex<double> value, std::optional<ParmsID> parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        encode_complex64_simd(std::vector<std::complex<double>>(slots_, value), parms_id, scale, destination, pool);
+    }
+    Plaintext encode_complex64_single_new(std::complex<double> value, std::optional<ParmsID> parms_id, double scale, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext p; encode_complex64_single(value, parms_id, scale, p, pool); return p;
+    }
+    // exact integers, scale 1 (ckks_encoder.cu:983-1090): coefficient j <- values[j] mod q_i (a single value = the constant polynomial)
+    void encode_integer64_polynomial(const std::vector<int64_t>& values, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext encode_integer64_polynomial_new(const std::vector<int64_t>& values, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext p; encode_integer64_polynomial(values, parms_id, p, pool); return p;
+    }
+    void encode_integer64_single(int64_t value, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        encode_integer64_polynomial(std::vector<int64_t>{value}, parms_id, destination, pool);
+    }
+    Plaintext encode_integer64_single_new(int64_t value, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext p; encode_integer64_single(value, parms_id, p, pool); return p;
+    }
     void decode_complex64_simd(const Plaintext& plain, std::vector<std::complex<double>>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<std::complex<double>> decode_complex64_simd_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
         std::vector<std::complex<double>> v; decode_complex64_simd(plain, v, pool); return v;
@@ -794,6 +855,10 @@ public:
 
     // Galois automorphisms / rotations -- evaluator.h:700-850 (evaluator_keyswitching.cu:147-361)
     void apply_galois(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    // evaluator_keyswitching.cu:235-261: the automorphism on a plaintext (mod t in coefficient form, per limb for RNS plaintexts, a gather in NTT form)
+    void apply_galois_plain(const Plaintext& plain, size_t galois_element, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void apply_galois_plain_inplace(Plaintext& plain, size_t galois_element, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; apply_galois_plain(plain, galois_element, d, pool); plain = std::move(d); }
+    Plaintext apply_galois_plain_new(const Plaintext& plain, size_t galois_element, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; apply_galois_plain(plain, galois_element, d, pool); return d; }
     void apply_galois_inplace(Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext apply_galois_new(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); return d; }
     void rotate_rows(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
