@@ -1,0 +1,26 @@
+"""Lists the method names the reference's Python module registers per class (pybind/src/*.cu: every `.def("name"` / `.def_static("name"`)
+into tests/golden/pytroy_surface.json.  Runs in the build container only (/root/reference is not present on the GPU box); the JSON
+is data -- names, no code -- and tests/test_pytroy.py::test_surface_is_complete checks the built module against it."""
+import json
+import os
+import re
+
+REF = "/root/reference/pybind/src"
+CLASSES = {
+    "batch_encoder": ["BatchEncoder"], "ciphertext": ["Ciphertext"], "ckks_encoder": ["CKKSEncoder"], "conv2d_helper": ["Conv2dHelper"],
+    "decryptor": ["Decryptor"], "encryptor": ["Encryptor"], "evaluator": ["Evaluator"], "key_generator": ["KeyGenerator"],
+    "lwe_ciphertext": ["LWECiphertext"], "plaintext": ["Plaintext"], "public_key": ["PublicKey"], "secret_key": ["SecretKey"],
+    "random_generator": ["RandomGenerator"], "polynomial_encoder_ring2k": ["PolynomialEncoderRing2k32", "PolynomialEncoderRing2k64"],
+    "kswitch_keys": ["KSwitchKeys", "RelinKeys", "GaloisKeys"], "matmul_helper": ["MatmulHelper", "Plain2d", "Cipher2d"],
+    "modulus": ["Modulus", "CoeffModulus", "PlainModulus"], "he_context": ["HeContext", "ContextData"],
+    "encryption_parameters": ["EncryptionParameters", "ParmsID"], "basics": ["MemoryPool"], "binder": [],
+}
+
+out = {}
+for f, classes in sorted(CLASSES.items()):
+    src = open(os.path.join(REF, f + ".cu")).read()
+    names = sorted(set(re.findall(r'\.def(?:_static)?\(\s*"([A-Za-z0-9_]+)"', src)))
+    out[f] = {"classes": classes, "names": names}       # a file that registers several classes: every name must exist on one of them
+out["binder"]["classes"] = ["<module>"]
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pytroy_surface.json"), "w"), indent=1, sort_keys=True)
+print(sum(len(v["names"]) for v in out.values()), "names")

@@ -52,6 +52,21 @@ def test_parameter_objects(pytroy):
     assert pytroy.parms_id_zero.is_zero()
 
 
+def test_surface_is_complete(pytroy):
+    """every method name the reference's pybind module registers (tests/golden/pytroy_surface.json, listed from pybind/src/*.cu by
+    tests/golden/make_pytroy_surface.py) exists on the corresponding class of the built module"""
+    import pytroy.pytroy_raw as raw
+    surface = json.load(open(os.path.join(ROOT, "tests", "golden", "pytroy_surface.json")))
+    missing = []
+    for group, entry in surface.items():
+        have = set()
+        for cls in entry["classes"]:
+            have |= set(dir(raw)) if cls == "<module>" else set(dir(getattr(raw, cls)))
+        missing += ["%s.%s" % (group, n) for n in entry["names"] if n not in have]
+    assert not missing, missing
+    assert sum(len(e["names"]) for e in surface.values()) > 400
+
+
 @pytest.mark.gpu
 def test_quickstart_flow_in_python(pytroy, dev):
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_digests.json")))
@@ -233,3 +248,119 @@ def test_matmul_and_conv2d_helpers_in_python(pytroy, dev):
     with pytest.raises(ValueError):
         helper.encode_weights(encoder, w[:-1])
     pytroy.MemoryPool.destroy_global_pool()
+
+
+@pytest.mark.gpu
+def test_wider_surface_in_python(pytroy, dev):
+    """the rest of the reference's Python names: plaintext scaling (BatchEncoder.scale_up / centralize / scale_down), the ring-2^k
+    encoder, apply_galois_plain, accessors and wire formats of keys and parameters, save_terms / load_terms, the CKKS integer
+    encodings and the CKKS forms of Conv2dHelper"""
+    import numpy as np
+    n = 8192
+    p = _params(pytroy, pytroy.SchemeType.BFV, n, [40, 40, 40])
+    t = p.plain_modulus().value()
+    assert pytroy.EncryptionParameters.load_new(p.save()).parms_id() == p.parms_id() and p.serialized_size_upperbound() == len(p.save())
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Classical128, 0x77)
+    ctx.to_device_inplace()
+    encoder = pytroy.BatchEncoder(ctx)
+    assert encoder.row_count() == 2 and encoder.column_count() == n // 2 and encoder.simd_encoding_supported()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_secret_key(keygen.secret_key())
+    pk = keygen.create_public_key(True)
+    assert pk.contains_seed()
+    pk2 = pytroy.PublicKey.load_new(pk.save(ctx), ctx)                       # load expands the seed
+    assert not pk2.contains_seed() and pk2.parms_id() == ctx.key_parms_id() and len(pk.save(ctx)) <= pk.serialized_size_upperbound(ctx)
+    encryptor.set_public_key(pk2)
+    assert encryptor.public_key().parms_id() == pk2.parms_id() and encryptor.secret_key().on_device()
+    decryptor = pytroy.Decryptor(ctx, keygen.secret_key())
+    evaluator = pytroy.Evaluator(ctx)
+    rs = np.random.RandomState(3)
+    msg = [int(v) for v in rs.randint(0, t, 100)]
+    plain = encoder.encode_polynomial_new(msg)
+    # scale_up / scale_down / centralize, partial RNS plaintexts as operands
+    up = encoder.scale_up_new(plain)
+    assert up.coeff_count() == 100 and len(up.obtain_data()) == 200 and not up.parms_id().is_zero() and up.parms_id() == ctx.first_parms_id()
+    assert encoder.decode_polynomial_new(encoder.scale_down_new(up)) == msg
+    c = encryptor.encrypt_symmetric_new(up, False)
+    assert encoder.decode_polynomial_new(decryptor.decrypt_new(c))[:100] == msg
+    ca = encryptor.encrypt_asymmetric_new(plain)
+    assert not ca.is_transparent() and pytroy.Ciphertext().is_transparent() and ca.correction_factor() == 1 and ca.seed() == 0
+    assert ca.data_address() != 0 and ca.device_index() == 0 and ca.to_host().on_device() is False
+    cen = encoder.centralize_new(plain)
+    assert encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, cen))) == \
+        encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, plain)))
+    # save_terms / load_terms: only the listed coefficients of c0 travel
+    terms = [0, 5, 17, 99]
+    blob = ca.save_terms(ctx, terms)
+    assert len(blob) <= ca.serialized_terms_size_upperbound(ctx, len(terms)) and len(blob) < len(ca.save(ctx))
+    back = encoder.decode_polynomial_new(decryptor.decrypt_new(pytroy.Ciphertext.load_terms_new(blob, ctx, terms)))
+    assert [back[i] for i in terms] == [msg[i] for i in terms]
+    # the plaintext automorphism against the one under encryption
+    slots = [int(v) for v in rs.randint(0, t, n)]
+    ps = encoder.encode_simd_new(slots)
+    gk = keygen.create_galois_keys(False)
+    gk2 = pytroy.KSwitchKeys.load_new(gk.save(ctx), ctx)
+    assert gk2.parms_id() == gk.parms_id() and len(gk.save(ctx)) <= gk.serialized_size_upperbound(ctx)
+    rotated = encoder.decode_simd_new(decryptor.decrypt_new(evaluator.rotate_rows_new(encryptor.encrypt_symmetric_new(ps, False), 1, gk)))
+    g = 3                                                                     # rotate_rows by one step = the generator itself
+    assert encoder.decode_simd_new(evaluator.apply_galois_plain_new(ps, g)) == rotated and rotated != slots
+    sk_plain = keygen.secret_key().get_plaintext()
+    assert sk_plain.is_ntt_form() and pytroy.SecretKey(sk_plain).parms_id() == ctx.key_parms_id()
+    gen = pytroy.RandomGenerator(7)
+    a, b = gen.sample_uint64(), gen.sample_uint64()
+    gen.reset_seed(7)
+    assert a != b and gen.sample_uint64() == a
+    assert pytroy.Modulus(97).reduce_mul(96, 96) == 1 and pytroy.ParmsID.zero().is_zero()
+    assert [m.bit_count() for m in pytroy.PlainModulus.batching_multiple(n, [20, 21])] == [20, 21]
+
+    # ring-2^k: products in Z_{2^64} (wider coefficient modulus)
+    p2 = pytroy.EncryptionParameters(pytroy.SchemeType.BFV)
+    p2.set_poly_modulus_degree(n)
+    p2.set_coeff_modulus(pytroy.CoeffModulus.create(n, [60, 60, 60, 60]))
+    p2.set_plain_modulus(1 << 20)
+    ctx2 = pytroy.HeContext(p2, True, pytroy.SecurityLevel.Nil, 0x78)
+    ctx2.to_device_inplace()
+    kg2 = pytroy.KeyGenerator(ctx2)
+    enc2 = pytroy.Encryptor(ctx2)
+    enc2.set_secret_key(kg2.secret_key())
+    dec2 = pytroy.Decryptor(ctx2, kg2.secret_key())
+    ev2 = pytroy.Evaluator(ctx2)
+    ring = pytroy.PolynomialEncoderRing2k64(ctx2, 64)
+    assert ring.t_bit_length() == 64 and ring.on_device()
+    av = rs.randint(0, 2 ** 63, 40, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    bv = rs.randint(0, 2 ** 63, 30, dtype=np.int64).astype(np.uint64)
+    prod = ev2.multiply_plain_new(enc2.encrypt_symmetric_new(ring.scale_up_new(av, None), False), ring.centralize_new(bv, None))
+    got = ring.scale_down_new(dec2.bfv_decrypt_without_scaling_down_new(prod))
+    want = np.zeros(n, dtype=object)
+    for i, x in enumerate(av):
+        for j, y in enumerate(bv):
+            want[i + j] = (want[i + j] + int(x) * int(y)) % (1 << 64)
+    assert [int(v) for v in got] == [int(v) for v in want]
+
+    # CKKS: integer encodings and Conv2dHelper's real-valued forms
+    p3 = _params(pytroy, pytroy.SchemeType.CKKS, n, [60, 40, 40, 60])
+    ctx3 = pytroy.HeContext(p3, True, pytroy.SecurityLevel.Classical128, 0x79)
+    ctx3.to_device_inplace()
+    ck = pytroy.CKKSEncoder(ctx3)
+    assert ck.poly_modulus_degree() == n
+    assert ck.decode_float64_polynomial_new(ck.encode_integer64_polynomial_new([3, -4, 5], None))[:4] == [3.0, -4.0, 5.0, 0.0]
+    assert all(abs(v - (2 - 1j)) < 1e-6 for v in ck.decode_complex64_simd_new(ck.encode_complex64_single_new(2 - 1j, None, 2.0 ** 30)))
+    assert all(abs(v + 9) < 1e-9 for v in ck.decode_complex64_simd_new(ck.encode_integer64_single_new(-9, None)))
+    kg3 = pytroy.KeyGenerator(ctx3)
+    enc3 = pytroy.Encryptor(ctx3)
+    enc3.set_secret_key(kg3.secret_key())
+    dec3 = pytroy.Decryptor(ctx3, kg3.secret_key())
+    ev3 = pytroy.Evaluator(ctx3)
+    bs, ic, oc, H, W, kh, kw = 2, 3, 4, 12, 11, 3, 2
+    xi, wk = rs.uniform(-1, 1, (bs, ic, H, W)), rs.uniform(-1, 1, (oc, ic, kh, kw))
+    conv = pytroy.Conv2dHelper(bs, ic, oc, H, W, kh, kw, n)
+    scale = 2.0 ** 20
+    yc = conv.conv2d(ev3, pytroy.Cipher2d.load_new(conv.encrypt_inputs_doubles(enc3, ck, xi, None, scale).save(ctx3), ctx3), conv.encode_weights_doubles(ck, wk, None, scale))
+    gotc = conv.decrypt_outputs_doubles(ck, dec3, yc).reshape(bs, oc, H - kh + 1, W - kw + 1)
+    wantc = np.zeros(gotc.shape)
+    for a in range(kh):
+        for b in range(kw):
+            wantc += np.einsum("bchw,oc->bohw", xi[:, :, a:a + H - kh + 1, b:b + W - kw + 1], wk[:, :, a, b])
+    assert np.abs(gotc - wantc).max() < 1e-3
+    pytroy.destroy_memory_pool()

@@ -7,11 +7,14 @@
 #include <pybind11/numpy.h>
 #include <pybind11/stl.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include <optional>
 #include <sstream>
 
 #include "../troy/conv2d.h"
 #include "../troy/matmul.h"
+#include "../troy/ring2k.h"
 #include "../troy/troy.h"
 
 namespace py = pybind11;
@@ -54,6 +57,8 @@ PYBIND11_MODULE(pytroy_raw, m) {
     m.doc() = "MI355X-native troy-nova hot path: Python surface (subset of the reference's pytroy_raw)";
     m.def("it_works", []() { return 42; });
     m.def("device_count", &utils::device_count);
+    m.def("initialize_kernel", [](int device) { if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("[kernel_provider::initialize] cannot select the device"); }, py::arg("device") = 0);
+    m.def("destroy_memory_pool", []() { MemoryPool::Destroy(); });
 
     py::enum_<SchemeType>(m, "SchemeType").value("Nil", SchemeType::Nil).value("BFV", SchemeType::BFV).value("CKKS", SchemeType::CKKS).value("BGV", SchemeType::BGV);
     py::enum_<SecurityLevel>(m, "SecurityLevel").value("Nil", SecurityLevel::Nil).value("Classical128", SecurityLevel::Classical128)
@@ -62,23 +67,25 @@ PYBIND11_MODULE(pytroy_raw, m) {
     py::class_<MemoryPool, MemoryPoolHandle>(m, "MemoryPool")
         .def(py::init([](size_t device) { return MemoryPool::create(device); }), py::arg("device") = 0)
         .def_static("global_pool", &MemoryPool::GlobalPool)
-        .def_static("destroy_global_pool", &MemoryPool::Destroy)
+        .def_static("destroy_global_pool", &MemoryPool::Destroy).def_static("destroy", &MemoryPool::Destroy)
         .def("get_device", &MemoryPool::get_device)
         .def("release_unused", &MemoryPool::release_unused);
 
     py::class_<Modulus>(m, "Modulus")
         .def(py::init<uint64_t>(), py::arg("value") = 0)
         .def("value", &Modulus::value).def("bit_count", &Modulus::bit_count).def("is_prime", &Modulus::is_prime)
-        .def("is_zero", &Modulus::is_zero).def("reduce", &Modulus::reduce)
+        .def("is_zero", &Modulus::is_zero).def("reduce", &Modulus::reduce).def("reduce_mul", &Modulus::reduce_mul_uint64)
+        .def("__str__", [](const Modulus& s) { return std::to_string(s.value()); })
         .def("__repr__", [](const Modulus& s) { return "Modulus(" + std::to_string(s.value()) + ")"; });
     py::class_<CoeffModulus>(m, "CoeffModulus")
         .def_static("max_bit_count", &CoeffModulus::max_bit_count, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128)
         .def_static("create", &CoeffModulus::create, py::arg("poly_modulus_degree"), py::arg("bit_sizes"))
         .def_static("bfv_default", [](size_t n, SecurityLevel sec) { return CoeffModulus::bfv_default(n, sec); }, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128);
-    py::class_<PlainModulus>(m, "PlainModulus").def_static("batching", &PlainModulus::batching, py::arg("poly_modulus_degree"), py::arg("bit_size"));
+    py::class_<PlainModulus>(m, "PlainModulus").def_static("batching", &PlainModulus::batching, py::arg("poly_modulus_degree"), py::arg("bit_size"))
+        .def_static("batching_multiple", [](size_t n, const std::vector<size_t>& bits) { return PlainModulus::batching_multiple(n, bits); }, py::arg("poly_modulus_degree"), py::arg("bit_sizes"));
 
     py::class_<ParmsID>(m, "ParmsID")
-        .def("is_zero", &ParmsID::is_zero)
+        .def("is_zero", &ParmsID::is_zero).def_static("zero", []() { return parms_id_zero; })
         .def("__eq__", [](const ParmsID& a, const ParmsID& b) { return a == b; })
         .def("__hash__", [](const ParmsID& a) { return ParmsIDHash{}(a); })
         .def("to_vector", [](const ParmsID& a) { return std::vector<uint64_t>(a.v, a.v + 4); });
@@ -92,7 +99,12 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("set_plain_modulus", py::overload_cast<uint64_t>(&EncryptionParameters::set_plain_modulus))
         .def("scheme", &EncryptionParameters::scheme).def("poly_modulus_degree", &EncryptionParameters::poly_modulus_degree)
         .def("coeff_modulus", &EncryptionParameters::coeff_modulus).def("plain_modulus", &EncryptionParameters::plain_modulus)
-        .def("parms_id", &EncryptionParameters::parms_id);
+        .def("parms_id", &EncryptionParameters::parms_id)
+        .def("pool", [](const EncryptionParameters&) { return MemoryPool::GlobalPool(); }).def("device_index", [](const EncryptionParameters&) { return size_t(0); })
+        .def("save", [](const EncryptionParameters& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
+        .def("load", [](EncryptionParameters& s, const py::bytes& b) { std::istringstream is{std::string(b)}; s.load(is); }, py::arg("data"))
+        .def_static("load_new", [](const py::bytes& b) { std::istringstream is{std::string(b)}; EncryptionParameters e(SchemeType::Nil); e.load(is); return e; }, py::arg("data"))
+        .def("serialized_size_upperbound", [](const EncryptionParameters& s) { std::ostringstream os; return s.save(os); });
 
     using CDP = std::shared_ptr<ContextData>;
     auto unconst = [](const std::optional<ContextDataPointer>& c) -> std::optional<CDP> {
@@ -100,6 +112,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     };
     py::class_<ContextData, CDP>(m, "ContextData")
         .def("parms", &ContextData::parms).def("parms_id", &ContextData::parms_id).def("chain_index", &ContextData::chain_index)
+        .def("device_index", [](const ContextData&) { return size_t(0); })
         .def("next_context_data", [unconst](const ContextData& s) { return unconst(s.next_context_data()); })
         .def("prev_context_data", [unconst](const ContextData& s) { return unconst(s.prev_context_data()); });
 
@@ -107,7 +120,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def(py::init([](const EncryptionParameters& parms, bool expand, SecurityLevel sec, uint64_t seed) { return HeContext::create(parms, expand, sec, seed); }),
              py::arg("parms"), py::arg("expand_mod_chain") = true, py::arg("sec_level") = SecurityLevel::Classical128, py::arg("random_seed") = 0)
         .def("to_device_inplace", [](HeContext& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL)
-        .def("on_device", &HeContext::on_device).def("pool", &HeContext::pool)
+        .def("on_device", &HeContext::on_device).def("pool", &HeContext::pool).def("device_index", &HeContext::device_index)
         .def("key_parms_id", &HeContext::key_parms_id).def("first_parms_id", &HeContext::first_parms_id).def("last_parms_id", &HeContext::last_parms_id)
         .def("get_context_data", [unconst](const HeContext& s, const ParmsID& id) { return unconst(s.get_context_data(id)); })
         .def("key_context_data", [unconst](const HeContext& s) { return unconst(s.key_context_data()); })
@@ -125,6 +138,15 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("set_scale", [](Plaintext& s, double v) { s.scale() = v; })
         .def("coeff_count", [](const Plaintext& s) { return s.coeff_count(); }).def("is_ntt_form", [](const Plaintext& s) { return s.is_ntt_form(); })
         .def("data", [](const Plaintext& s) { return s.data().to_vector(); })
+        .def("obtain_data", [](const Plaintext& s) { const std::vector<uint64_t> v = s.data().to_vector(); return py::array_t<uint64_t>(v.size(), v.data()); })
+        .def("address", [](const Plaintext& s) { return reinterpret_cast<uintptr_t>(&s); })
+        .def("data_address", [](const Plaintext& s) { return reinterpret_cast<uintptr_t>(s.data().raw_pointer()); })
+        .def("pool", &Plaintext::pool).def("device_index", [](const Plaintext& s) { return s.pool() ? s.pool()->get_device() : size_t(0); })
+        .def("to_device", [](const Plaintext& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &Plaintext::to_host)
+        .def("set_parms_id", [](Plaintext& s, const ParmsID& id) { s.parms_id() = id; }).def("set_coeff_count", [](Plaintext& s, size_t c) { s.coeff_count() = c; })
+        .def("set_is_ntt_form", [](Plaintext& s, bool f) { s.is_ntt_form() = f; }).def("resize", &Plaintext::resize)
+        .def("coeff_modulus_size", [](const Plaintext& s) { return s.coeff_modulus_size(); }).def("poly_modulus_degree", [](const Plaintext& s) { return s.poly_modulus_degree(); })
+        .def("serialized_size_upperbound", [](const Plaintext& s) { return s.serialized_size_upperbound(); })
         .def("save", [](const Plaintext& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
         .def("load", [](Plaintext& s, const std::string& b, PoolArg p) { std::istringstream is(b); s.load(is, P(p)); }, py::arg("bytes"), POOL)
         .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return Plaintext::load_new(is, P(p)); }, py::arg("bytes"), POOL);
@@ -142,18 +164,63 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("is_ntt_form", [](const Ciphertext& s) { return s.is_ntt_form(); }).def("contains_seed", &Ciphertext::contains_seed)
         .def("data", [](const Ciphertext& s) { return s.data().to_vector(); })
         .def("expand_seed", &Ciphertext::expand_seed)
+        .def("obtain_data", [](const Ciphertext& s) { const std::vector<uint64_t> v = s.data().to_vector(); return py::array_t<uint64_t>(v.size(), v.data()); })
+        .def("address", [](const Ciphertext& s) { return reinterpret_cast<uintptr_t>(&s); })
+        .def("data_address", [](const Ciphertext& s) { return reinterpret_cast<uintptr_t>(s.data().raw_pointer()); })
+        .def("pool", &Ciphertext::pool).def("device_index", [](const Ciphertext& s) { return s.pool() ? s.pool()->get_device() : size_t(0); })
+        .def("to_device", [](const Ciphertext& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &Ciphertext::to_host)
+        .def("set_parms_id", [](Ciphertext& s, const ParmsID& id) { s.parms_id() = id; }).def("set_is_ntt_form", [](Ciphertext& s, bool f) { s.is_ntt_form() = f; })
+        .def("correction_factor", [](const Ciphertext& s) { return s.correction_factor(); }).def("set_correction_factor", [](Ciphertext& s, uint64_t f) { s.correction_factor() = f; })
+        .def("seed", [](const Ciphertext& s) { return s.seed(); }).def("set_seed", [](Ciphertext& s, uint64_t v) { s.seed() = v; })
+        .def("is_transparent", &Ciphertext::is_transparent)
+        .def("serialized_size_upperbound", [](const Ciphertext& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+        .def("save_terms", [](const Ciphertext& s, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
+            return to_bytes([&](std::ostream& os) { s.save_terms(os, c, terms, P(p)); }); }, py::arg("context"), py::arg("terms"), POOL)
+        .def("load_terms", [](Ciphertext& s, const py::bytes& b, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
+            std::istringstream is{std::string(b)}; s.load_terms(is, c, terms, P(p)); }, py::arg("data"), py::arg("context"), py::arg("terms"), POOL)
+        .def_static("load_terms_new", [](const py::bytes& b, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
+            std::istringstream is{std::string(b)}; return Ciphertext::load_terms_new(is, c, terms, P(p)); }, py::arg("data"), py::arg("context"), py::arg("terms"), POOL)
+        .def("serialized_terms_size_upperbound", [](const Ciphertext& s, HeContextPointer c, size_t terms_count) { return s.serialized_terms_size_upperbound(c, terms_count); },
+             py::arg("context"), py::arg("terms_count"))
         .def("save", [](const Ciphertext& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
         .def("load", [](Ciphertext& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL)
         .def_static("load_new", [](const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); return Ciphertext::load_new(is, c, P(p)); },
                     py::arg("bytes"), py::arg("context"), POOL);
 
-    py::class_<SecretKey>(m, "SecretKey").def(py::init<>()).def("on_device", &SecretKey::on_device)
+    py::class_<SecretKey>(m, "SecretKey").def(py::init<>()).def(py::init([](const Plaintext& p) { return SecretKey(Plaintext(p)); })).def("on_device", &SecretKey::on_device)
+        .def("to_device_inplace", [](SecretKey& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &SecretKey::to_host_inplace)
+        .def("to_device", [](const SecretKey& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &SecretKey::to_host)
+        .def("parms_id", [](const SecretKey& s) { return s.parms_id(); }).def("set_parms_id", [](SecretKey& s, const ParmsID& id) { s.parms_id() = id; })
+        .def("pool", [](const SecretKey& s) { return s.as_plaintext().pool(); }).def("device_index", [](const SecretKey& s) { return s.as_plaintext().pool() ? s.as_plaintext().pool()->get_device() : size_t(0); })
+        .def("as_plaintext", [](const SecretKey& s) { return s.as_plaintext(); }).def("get_plaintext", [](const SecretKey& s, PoolArg p) { return s.as_plaintext().clone(P(p)); }, POOL)
+        .def("load", [](SecretKey& s, const py::bytes& b, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, P(p)); }, py::arg("data"), POOL)
+        .def("serialized_size_upperbound", [](const SecretKey& s) { return s.serialized_size_upperbound(); })
         .def("clone", [](const SecretKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("data", [](const SecretKey& s) { return s.data().to_vector(); })
         .def("save", [](const SecretKey& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
         .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return SecretKey::load_new(is, P(p)); }, py::arg("bytes"), POOL);
     py::class_<PublicKey>(m, "PublicKey").def(py::init<>()).def("on_device", &PublicKey::on_device)
+        .def("to_device_inplace", [](PublicKey& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &PublicKey::to_host_inplace)
+        .def("to_device", [](const PublicKey& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &PublicKey::to_host)
+        .def("parms_id", [](const PublicKey& s) { return s.parms_id(); }).def("set_parms_id", [](PublicKey& s, const ParmsID& id) { s.parms_id() = id; })
+        .def("pool", [](const PublicKey& s) { return s.as_ciphertext().pool(); }).def("device_index", [](const PublicKey& s) { return s.as_ciphertext().pool() ? s.as_ciphertext().pool()->get_device() : size_t(0); })
+        .def("get_ciphertext", [](const PublicKey& s, PoolArg p) { return s.as_ciphertext().clone(P(p)); }, POOL)
+        .def("contains_seed", &PublicKey::contains_seed).def("expand_seed", &PublicKey::expand_seed)
+        .def("save", [](const PublicKey& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
+        .def("load", [](PublicKey& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("data"), py::arg("context"), POOL)
+        .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; return PublicKey::load_new(is, c, P(p)); },
+                    py::arg("data"), py::arg("context"), POOL)
+        .def("serialized_size_upperbound", [](const PublicKey& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
         .def("clone", [](const PublicKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("as_ciphertext", [](const PublicKey& s) { return s.as_ciphertext(); });
     py::class_<KSwitchKeys>(m, "KSwitchKeys").def(py::init<>()).def("on_device", &KSwitchKeys::on_device).def("parms_id", [](const KSwitchKeys& s) { return s.parms_id(); })
+        .def("set_parms_id", [](KSwitchKeys& s, const ParmsID& id) { s.parms_id() = id; })
+        .def("pool", &KSwitchKeys::pool).def("device_index", [](const KSwitchKeys& s) { return s.pool() ? s.pool()->get_device() : size_t(0); })
+        .def("serialized_size_upperbound", [](const KSwitchKeys& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+        .def("clone", [](const KSwitchKeys& s, PoolArg p) { return s.clone(P(p)); }, POOL)
+        .def("to_device_inplace", [](KSwitchKeys& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &KSwitchKeys::to_host_inplace)
+        .def("to_device", [](const KSwitchKeys& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &KSwitchKeys::to_host)
+        .def("as_kswitch_keys", [](const KSwitchKeys& s) { return s.as_kswitch_keys(); }).def("get_kswitch_keys", [](const KSwitchKeys& s, PoolArg p) { return s.as_kswitch_keys().clone(P(p)); }, POOL)
+        .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; KSwitchKeys k; k.load(is, c, P(p)); return k; },
+                    py::arg("data"), py::arg("context"), POOL)
         .def("save", [](const KSwitchKeys& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
         .def("load", [](KSwitchKeys& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL);
     py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key);
@@ -162,7 +229,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     py::class_<KeyGenerator>(m, "KeyGenerator")
         .def(py::init([](HeContextPointer c, PoolArg p) { return new KeyGenerator(c, P(p)); }), py::arg("context"), POOL)
         .def(py::init([](HeContextPointer c, const SecretKey& sk, PoolArg p) { return new KeyGenerator(c, sk, P(p)); }), py::arg("context"), py::arg("secret_key"), POOL)
-        .def("on_device", &KeyGenerator::on_device).def("context", &KeyGenerator::context)
+        .def("on_device", &KeyGenerator::on_device).def("context", &KeyGenerator::context).def("to_device_inplace", [](KeyGenerator&, PoolArg) {}, POOL)
         .def("secret_key", [](const KeyGenerator& s) { return s.secret_key().clone(); })
         .def("create_public_key", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_public_key(save_seed, P(p)); }, py::arg("save_seed"), POOL)
         .def("create_relin_keys", [](const KeyGenerator& s, bool save_seed, size_t max_power, PoolArg p) { return s.create_relin_keys(save_seed, max_power, P(p)); },
@@ -187,6 +254,12 @@ PYBIND11_MODULE(pytroy_raw, m) {
              py::arg("plain"), py::arg("save_seed"), py::arg("destination"), POOL)
         .def("encrypt_symmetric_new", [](const Encryptor& s, const Plaintext& pl, bool seed, PoolArg p) { return s.encrypt_symmetric_new(pl, seed, P(p)); },
              py::arg("plain"), py::arg("save_seed"), POOL)
+        .def("on_device", [](const Encryptor& s) { return s.context()->on_device(); })
+        .def("public_key", [](const Encryptor& s) { return s.public_key(); }).def("secret_key", [](const Encryptor& s) { return s.secret_key(); })
+        .def("encrypt_zero_asymmetric", [](const Encryptor& s, Ciphertext& d, std::optional<ParmsID> id, PoolArg p) { d = s.encrypt_zero_asymmetric_new(id, P(p)); },
+             py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("encrypt_zero_symmetric", [](const Encryptor& s, bool seed, Ciphertext& d, std::optional<ParmsID> id, PoolArg p) { d = s.encrypt_zero_symmetric_new(seed, id, P(p)); },
+             py::arg("save_seed"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
         .def("encrypt_zero_asymmetric_new", [](const Encryptor& s, std::optional<ParmsID> id, PoolArg p) { return s.encrypt_zero_asymmetric_new(id, P(p)); },
              py::arg("parms_id") = std::nullopt, POOL)
         .def("encrypt_zero_symmetric_new", [](const Encryptor& s, bool seed, std::optional<ParmsID> id, PoolArg p) { return s.encrypt_zero_symmetric_new(seed, id, P(p)); },
@@ -197,7 +270,11 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("to_device_inplace", [](Decryptor&, PoolArg) {}, POOL).def("on_device", &Decryptor::on_device)
         .def("decrypt", [](const Decryptor& s, const Ciphertext& c, Plaintext& d, PoolArg p) { s.decrypt(c, d, P(p)); }, py::arg("encrypted"), py::arg("destination"), POOL)
         .def("invariant_noise_budget", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.invariant_noise_budget(c, P(p)); }, py::arg("encrypted"), POOL)
-        .def("decrypt_new", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.decrypt_new(c, P(p)); }, py::arg("encrypted"), POOL);
+        .def("decrypt_new", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.decrypt_new(c, P(p)); }, py::arg("encrypted"), POOL)
+        .def("context", &Decryptor::context)
+        .def("bfv_decrypt_without_scaling_down", [](const Decryptor& s, const Ciphertext& c, Plaintext& d, PoolArg p) { s.bfv_decrypt_without_scaling_down(c, d, P(p)); },
+             py::arg("encrypted"), py::arg("destination"), POOL)
+        .def("bfv_decrypt_without_scaling_down_new", [](const Decryptor& s, const Ciphertext& c, PoolArg p) { return s.bfv_decrypt_without_scaling_down_new(c, P(p)); }, py::arg("encrypted"), POOL);
 
     py::class_<BatchEncoder>(m, "BatchEncoder")
         .def(py::init<HeContextPointer>()).def("context", &BatchEncoder::context).def("slot_count", &BatchEncoder::slot_count)
@@ -206,7 +283,21 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
         .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL)
         .def("encode_polynomial_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_polynomial_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL);
+        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("encode_polynomial", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode_polynomial(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
+        .def("row_count", &BatchEncoder::row_count).def("column_count", &BatchEncoder::column_count).def("simd_encoding_supported", &BatchEncoder::simd_encoding_supported)
+        .def("scale_up", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, std::optional<ParmsID> id, PoolArg p) { s.scale_up(a, d, id, P(p)); },
+             py::arg("plain"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_up_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.scale_up_inplace(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_up_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.scale_up_new(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("centralize", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, std::optional<ParmsID> id, PoolArg p) { s.centralize(a, d, id, P(p)); },
+             py::arg("plain"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("centralize_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.centralize_inplace(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("centralize_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.centralize_new(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_down", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, PoolArg p) { s.scale_down(a, d, P(p)); }, py::arg("plain"), py::arg("destination"), POOL)
+        .def("scale_down_inplace", [](const BatchEncoder& s, Plaintext& a, PoolArg p) { s.scale_down_inplace(a, P(p)); }, py::arg("plain"), POOL)
+        .def("scale_down_new", [](const BatchEncoder& s, const Plaintext& a, PoolArg p) { return s.scale_down_new(a, P(p)); }, py::arg("plain"), POOL)
+        .def("decentralize_new", [](const BatchEncoder& s, const Plaintext& a, uint64_t cf, PoolArg p) { return s.decentralize_new(a, cf, P(p)); }, py::arg("plain"), py::arg("correction_factor") = 1, POOL);
 
     py::class_<CKKSEncoder>(m, "CKKSEncoder")
         .def(py::init<HeContextPointer>()).def("context", &CKKSEncoder::context).def("slot_count", &CKKSEncoder::slot_count)
@@ -219,7 +310,54 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("encode_float64_single_new", [](const CKKSEncoder& s, double v, std::optional<ParmsID> id, double scale, PoolArg p) {
             return s.encode_float64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
         .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("plain"), POOL)
-        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL);
+        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("poly_modulus_degree", &CKKSEncoder::polynomial_modulus_degree)
+        .def("encode_complex64_simd", [](const CKKSEncoder& s, const std::vector<std::complex<double>>& v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
+            s.encode_complex64_simd(v, id, scale, d, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
+        .def("encode_float64_polynomial", [](const CKKSEncoder& s, const std::vector<double>& v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
+            s.encode_float64_polynomial(v, id, scale, d, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
+        .def("encode_float64_single", [](const CKKSEncoder& s, double v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
+            s.encode_float64_single(v, id, scale, d, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
+        .def("encode_complex64_single", [](const CKKSEncoder& s, std::complex<double> v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
+            s.encode_complex64_single(v, id, scale, d, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
+        .def("encode_complex64_single_new", [](const CKKSEncoder& s, std::complex<double> v, std::optional<ParmsID> id, double scale, PoolArg p) {
+            return s.encode_complex64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
+        .def("encode_integer64_single", [](const CKKSEncoder& s, int64_t v, std::optional<ParmsID> id, Plaintext& d, PoolArg p) { s.encode_integer64_single(v, id, d, P(p)); },
+             py::arg("value"), py::arg("parms_id"), py::arg("destination"), POOL)
+        .def("encode_integer64_single_new", [](const CKKSEncoder& s, int64_t v, std::optional<ParmsID> id, PoolArg p) { return s.encode_integer64_single_new(v, id, P(p)); },
+             py::arg("value"), py::arg("parms_id"), POOL)
+        .def("encode_integer64_polynomial", [](const CKKSEncoder& s, const std::vector<int64_t>& v, std::optional<ParmsID> id, Plaintext& d, PoolArg p) { s.encode_integer64_polynomial(v, id, d, P(p)); },
+             py::arg("values"), py::arg("parms_id"), py::arg("destination"), POOL)
+        .def("encode_integer64_polynomial_new", [](const CKKSEncoder& s, const std::vector<int64_t>& v, std::optional<ParmsID> id, PoolArg p) { return s.encode_integer64_polynomial_new(v, id, P(p)); },
+             py::arg("values"), py::arg("parms_id"), POOL);
+
+    // PolynomialEncoderRing2k32 / 64 (pybind/src/polynomial_encoder_ring2k.cu); 128-bit elements have no numpy dtype and stay C++-only
+    auto register_ring2k = [&m](auto tag, const char* name) {
+        using T = decltype(tag);
+        using Encoder = linear::PolynomialEncoderRing2k<T>;
+        using Arr = py::array_t<T, py::array::c_style | py::array::forcecast>;
+        py::class_<Encoder>(m, name)
+            .def(py::init<HeContextPointer, size_t>(), py::arg("context"), py::arg("t_bit_length"))
+            .def("context", &Encoder::context).def("on_device", &Encoder::on_device).def("t_bit_length", &Encoder::t_bit_length).def("slot_count", &Encoder::slot_count)
+            .def("to_device_inplace", [](Encoder& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL)
+            .def("scale_up", [](const Encoder& s, const Arr& v, std::optional<ParmsID> id, Plaintext& d, PoolArg p) { s.scale_up(std::vector<T>(v.data(), v.data() + v.size()), id, d, P(p)); },
+                 py::arg("values"), py::arg("parms_id"), py::arg("destination"), POOL)
+            .def("scale_up_new", [](const Encoder& s, const Arr& v, std::optional<ParmsID> id, PoolArg p) { return s.scale_up_new(std::vector<T>(v.data(), v.data() + v.size()), id, P(p)); },
+                 py::arg("values"), py::arg("parms_id"), POOL)
+            .def("centralize", [](const Encoder& s, const Arr& v, std::optional<ParmsID> id, Plaintext& d, PoolArg p) { s.centralize(std::vector<T>(v.data(), v.data() + v.size()), id, d, P(p)); },
+                 py::arg("values"), py::arg("parms_id"), py::arg("destination"), POOL)
+            .def("centralize_new", [](const Encoder& s, const Arr& v, std::optional<ParmsID> id, PoolArg p) { return s.centralize_new(std::vector<T>(v.data(), v.data() + v.size()), id, P(p)); },
+                 py::arg("values"), py::arg("parms_id"), POOL)
+            .def("scale_down_new", [](const Encoder& s, const Plaintext& pl, PoolArg p) { const std::vector<T> v = s.scale_down_new(pl, P(p)); return py::array_t<T>(v.size(), v.data()); },
+                 py::arg("values"), POOL);
+    };
+    register_ring2k(uint32_t{}, "PolynomialEncoderRing2k32");
+    register_ring2k(uint64_t{}, "PolynomialEncoderRing2k64");
+
+    py::class_<utils::RandomGenerator>(m, "RandomGenerator")
+        .def(py::init([]() { return new utils::RandomGenerator(); })).def(py::init([](uint64_t seed) { return new utils::RandomGenerator(seed); }), py::arg("seed"))
+        .def("reset_seed", [](utils::RandomGenerator& s, uint64_t seed) { s.reset_seed(seed); }, py::arg("seed"))
+        .def("sample_uint64", &utils::RandomGenerator::sample_uint64);
 
     py::class_<LWECiphertext>(m, "LWECiphertext")
         .def(py::init<>())
@@ -229,7 +367,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("coeff_modulus_size", [](const LWECiphertext& s) { return s.coeff_modulus_size(); })
         .def("poly_modulus_degree", [](const LWECiphertext& s) { return s.poly_modulus_degree(); })
         .def("scale", [](const LWECiphertext& s) { return s.scale(); })
-        .def("assemble_lwe", [](const LWECiphertext& s, PoolArg p) { return s.assemble_lwe(P(p)); }, POOL);
+        .def("assemble_lwe", [](const LWECiphertext& s, PoolArg p) { return s.assemble_lwe(P(p)); }, POOL)
+        .def("address", [](const LWECiphertext& s) { return reinterpret_cast<uintptr_t>(&s); })
+        .def("pool", [](const LWECiphertext& s) { return s.c1_dyn().pool(); })
+        .def("device_index", [](const LWECiphertext& s) { return s.c1_dyn().pool() ? s.c1_dyn().pool()->get_device() : size_t(0); });
 
     py::class_<Evaluator> ev(m, "Evaluator");
     ev.def(py::init<HeContextPointer>()).def("context", &Evaluator::context).def("on_device", &Evaluator::on_device);
@@ -334,6 +475,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
            py::arg("encrypted"), py::arg("galois_keys"), py::arg("destination"), POOL);
     ev.def("complex_conjugate_inplace", [](const Evaluator& s, Ciphertext& a, const GaloisKeys& k, PoolArg p) { Ciphertext d; s.complex_conjugate(a, k, d, P(p)); a = std::move(d); },
            py::arg("encrypted"), py::arg("galois_keys"), POOL);
+    ev.def("apply_galois_plain", [](const Evaluator& s, const Plaintext& a, size_t g, Plaintext& d, PoolArg p) { s.apply_galois_plain(a, g, d, P(p)); },
+           py::arg("plain"), py::arg("galois_element"), py::arg("destination"), POOL);
+    ev.def("apply_galois_plain_inplace", [](const Evaluator& s, Plaintext& a, size_t g, PoolArg p) { s.apply_galois_plain_inplace(a, g, P(p)); }, py::arg("plain"), py::arg("galois_element"), POOL);
+    ev.def("apply_galois_plain_new", [](const Evaluator& s, const Plaintext& a, size_t g, PoolArg p) { return s.apply_galois_plain_new(a, g, P(p)); }, py::arg("plain"), py::arg("galois_element"), POOL);
     // LWE extraction and RLWE packing
     ev.def("extract_lwe_new", [](const Evaluator& s, const Ciphertext& a, size_t term, PoolArg p) { return s.extract_lwe_new(a, term, P(p)); }, py::arg("encrypted"), py::arg("term"), POOL);
     ev.def("assemble_lwe_new", [](const Evaluator& s, const LWECiphertext& l, PoolArg p) { return s.assemble_lwe_new(l, P(p)); }, py::arg("lwe_encrypted"), POOL);
@@ -437,6 +582,8 @@ PYBIND11_MODULE(pytroy_raw, m) {
             need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encode_inputs"); return s.encode_inputs_doubles(enc, vec_f64(x).data(), id, scale); })
       .def("encrypt_inputs_doubles", [=](const MatmulHelper& s, const Encryptor& e, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& x, std::optional<ParmsID> id, double scale) {
             need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encrypt_inputs"); return s.encrypt_inputs_doubles(e, enc, vec_f64(x).data(), id, scale); })
+      .def("encrypt_weights_doubles", [=](const MatmulHelper& s, const Encryptor& e, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& w, std::optional<ParmsID> id, double scale) {
+            need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encrypt_weights"); return s.encrypt_weights_doubles(e, enc, vec_f64(w).data(), id, scale); })
       .def("encode_outputs_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const py::array_t<double, py::array::c_style | py::array::forcecast>& y, std::optional<ParmsID> id, double scale) {
             need(y.size(), s.batch_size * s.output_dims, "MatmulHelper::encode_outputs"); return s.encode_outputs_doubles(enc, vec_f64(y).data(), id, scale); })
       .def("decrypt_outputs_doubles", [=](const MatmulHelper& s, const CKKSEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_f64(s.decrypt_outputs_doubles(enc, d, y)); });
@@ -472,4 +619,19 @@ PYBIND11_MODULE(pytroy_raw, m) {
           .def((std::string("encrypt_weights") + suffix).c_str(), cv_cry_w).def((std::string("encrypt_inputs") + suffix).c_str(), cv_cry_x)
           .def((std::string("encode_outputs") + suffix).c_str(), cv_enc_y).def((std::string("decrypt_outputs") + suffix).c_str(), cv_dec_y);
     }
+    using ArrF = py::array_t<double, py::array::c_style | py::array::forcecast>;
+    auto cv_w = [](const Conv2dHelper& s) { return s.output_channels * s.input_channels * s.kernel_height * s.kernel_width; };
+    auto cv_x = [](const Conv2dHelper& s) { return s.batch_size * s.input_channels * s.image_height * s.image_width; };
+    ch.def("set_pool", &Conv2dHelper::set_pool)
+      .def("encode_weights_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const ArrF& w, std::optional<ParmsID> id, double scale) {
+            need(w.size(), cv_w(s), "Conv2dHelper::encode_weights"); return s.encode_weights_doubles(enc, vec_f64(w).data(), id, scale); })
+      .def("encode_inputs_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const ArrF& x, std::optional<ParmsID> id, double scale) {
+            need(x.size(), cv_x(s), "Conv2dHelper::encode_inputs"); return s.encode_inputs_doubles(enc, vec_f64(x).data(), id, scale); })
+      .def("encrypt_weights_doubles", [=](const Conv2dHelper& s, const Encryptor& e, const CKKSEncoder& enc, const ArrF& w, std::optional<ParmsID> id, double scale) {
+            need(w.size(), cv_w(s), "Conv2dHelper::encrypt_weights"); return s.encrypt_weights_doubles(e, enc, vec_f64(w).data(), id, scale); })
+      .def("encrypt_inputs_doubles", [=](const Conv2dHelper& s, const Encryptor& e, const CKKSEncoder& enc, const ArrF& x, std::optional<ParmsID> id, double scale) {
+            need(x.size(), cv_x(s), "Conv2dHelper::encrypt_inputs"); return s.encrypt_inputs_doubles(e, enc, vec_f64(x).data(), id, scale); })
+      .def("encode_outputs_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const ArrF& y, std::optional<ParmsID> id, double scale) {
+            need(y.size(), cv_out(s), "Conv2dHelper::encode_outputs"); return s.encode_outputs_doubles(enc, vec_f64(y).data(), id, scale); })
+      .def("decrypt_outputs_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_f64(s.decrypt_outputs_doubles(enc, d, y)); });
 }

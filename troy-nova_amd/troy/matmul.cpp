@@ -576,6 +576,16 @@ Cipher2d MatmulHelper::encrypt_inputs_doubles(const Encryptor& encryptor, const 
     return out;
 }
 
+Cipher2d MatmulHelper::encrypt_weights_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const {
+    const Plain2d plain = encode_weights_doubles(encoder, weights, parms_id, scale);
+    Cipher2d out;
+    for (const auto& prow : plain.data()) {
+        std::vector<Ciphertext>& row = out.new_row();
+        for (const Plaintext& p : prow) row.push_back(encryptor.encrypt_symmetric_new(p, true, pool));
+    }
+    return out;
+}
+
 Plain2d MatmulHelper::encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const {
     const size_t n = slot_count, ocols = ceil_div(output_dims, output_block), brows = ceil_div(batch_size, batch_block);
     const size_t count = pack_lwe ? ceil_div(brows * ocols, input_block) : brows * ocols;

@@ -501,6 +501,12 @@ public:
     // device pointers of key_vector[index][j] (kswitch_keys.h:34-54), as a host array for the C-ABI
     std::vector<const uint64_t*> get_data_ptrs(size_t index) const;
     const KSwitchKeys& as_kswitch_keys() const { return *this; }
+    size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const {
+        size_t total = sizeof(ParmsID) + 2 * sizeof(size_t);
+        for (const auto& v : keys_) { if (v.empty()) continue; total += 2 * sizeof(size_t); for (const PublicKey& k : v) total += k.serialized_size_upperbound(context, mode); }
+        return total;
+    }
+    MemoryPoolHandle pool() const { for (const auto& v : keys_) for (const PublicKey& k : v) return k.as_ciphertext().pool(); return nullptr; }
     KSwitchKeys clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
     KSwitchKeys to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { KSwitchKeys k = *this; k.to_device_inplace(pool); return k; }
     KSwitchKeys to_host() const { KSwitchKeys k = *this; k.to_host_inplace(); return k; }
