@@ -129,6 +129,72 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < count; i++) w_mp.push_back(ev.multiply_plain_new(an[i], pn[i]));
             ev.multiply_plain_batched(cptr(an), pnp, mptr(g_mp)); report("multiply_plain_batched", g_mp, w_mp);
         }
+        // ---- the remaining spellings: x_new_batched / x_inplace_batched, key switching, rotations, level switching, shifts ----
+        {
+            report("add_new_batched", ev.add_new_batched(cptr(a), cptr(b)), w_add);
+            report("negate_new_batched", ev.negate_new_batched(cptr(a)), w_neg);
+            std::vector<Ciphertext> ip2;
+            for (auto& c : a) ip2.push_back(c.clone());
+            ev.sub_inplace_batched(mptr(ip2), cptr(b)); report("sub_inplace_batched", ip2, w_sub);
+            KeyGenerator other(context);
+            KSwitchKeys ksk = keygen.create_keyswitching_key(other.secret_key(), false);
+            std::vector<Ciphertext> w_ks;
+            for (auto& c : a) w_ks.push_back(ev.apply_keyswitching_new(c, ksk));
+            report("apply_keyswitching_new_batched", ev.apply_keyswitching_new_batched(cptr(a), ksk), w_ks);
+            std::vector<Ciphertext> ip3;
+            for (auto& c : a) ip3.push_back(c.clone());
+            ev.apply_keyswitching_inplace_batched(mptr(ip3), ksk); report("apply_keyswitching_inplace_batched", ip3, w_ks);
+            GaloisKeys gall = keygen.create_galois_keys(false);
+            for (int steps : {1, 3, -5}) {                                   // 3 and -5 go through the NAF decomposition
+                std::vector<Ciphertext> w_rot;
+                for (auto& c : a) w_rot.push_back(ckks ? ev.rotate_vector_new(c, steps, gall) : ev.rotate_rows_new(c, steps, gall));
+                char label[64];
+                std::snprintf(label, sizeof label, "%s(%d)", ckks ? "rotate_vector_new_batched" : "rotate_rows_new_batched", steps);
+                report(label, ckks ? ev.rotate_vector_new_batched(cptr(a), steps, gall) : ev.rotate_rows_new_batched(cptr(a), steps, gall), w_rot);
+            }
+            {
+                std::vector<Ciphertext> w_conj, ip4;
+                for (auto& c : a) { w_conj.push_back(ckks ? ev.complex_conjugate_new(c, gall) : ev.rotate_columns_new(c, gall)); ip4.push_back(c.clone()); }
+                if (ckks) ev.complex_conjugate_inplace_batched(mptr(ip4), gall); else ev.rotate_columns_inplace_batched(mptr(ip4), gall);
+                report(ckks ? "complex_conjugate_inplace_batched" : "rotate_columns_inplace_batched", ip4, w_conj);
+            }
+            const ParmsID last = context->last_parms_id();
+            std::vector<Ciphertext> w_to, w_shift, w_next;
+            for (auto& c : a) { w_to.push_back(ev.mod_switch_to_new(c, last)); w_next.push_back(ev.mod_switch_to_next_new(c)); }
+            report("mod_switch_to_new_batched(last level)", ev.mod_switch_to_new_batched(cptr(a), last), w_to);
+            report("mod_switch_to_next_new_batched", ev.mod_switch_to_next_new_batched(cptr(a)), w_next);
+            if (!ckks) {                                                       // the shift works on coefficient-form ciphertexts
+                for (auto& c : a) w_shift.push_back(ev.negacyclic_shift_new(c, 37));
+                report("negacyclic_shift_new_batched", ev.negacyclic_shift_new_batched(cptr(a), 37), w_shift);
+            }
+            if (!ckks) {
+                std::vector<Ciphertext> w_mpn;
+                for (size_t i = 0; i < count; i++) w_mpn.push_back(ev.multiply_plain_new(a[i], plains[i]));
+                report("multiply_plain_new_batched", ev.multiply_plain_new_batched(cptr(a), pp), w_mpn);
+                // plaintext side: bfv_centralize + NTT == transform_plain_to_ntt; its inverse returns the centred lift; bfv_scale_up == BatchEncoder::scale_up
+                BatchEncoder benc(context);
+                const ParmsID first = context->first_parms_id();
+                size_t bad = 0;
+                std::vector<Plaintext> cen = ev.bfv_centralize_new_batched(pp, first), ntt = ev.transform_plain_to_ntt_new_batched(pp, first);
+                for (size_t i = 0; i < count; i++) {
+                    bad += ev.transform_plain_to_ntt_new(cen[i], first).data().to_vector() != ntt[i].data().to_vector();
+                    bad += ev.transform_plain_from_ntt_new(ntt[i]).data().to_vector() != cen[i].data().to_vector();
+                    Plaintext full = plains[i].clone();
+                    bad += ev.bfv_scale_up_new(full, first).data().to_vector() != benc.scale_up_new(full, first).expanded_rns(3, n).to_vector();
+                }
+                std::printf("plaintext families %zu\n", bad);
+                failures += bad;
+            }
+            // a caller-supplied generator decides the seed of c1: same generator state, same seed and same c1
+            utils::RandomGenerator g1(99), g2(99);
+            Ciphertext e1 = ckks ? encryptor.encrypt_zero_symmetric_new(true, std::nullopt, &g1) : encryptor.encrypt_symmetric_new(plains[0], true, &g1);
+            Ciphertext e2 = ckks ? encryptor.encrypt_zero_symmetric_new(true, std::nullopt, &g2) : encryptor.encrypt_symmetric_new(plains[0], true, &g2);
+            const bool seeded = e1.seed() != 0 && e1.seed() == e2.seed();
+            std::vector<Ciphertext> zs = encryptor.encrypt_zero_symmetric_new_batched(3, true);
+            const bool zeros = zs.size() == 3 && zs[0].seed() != 0 && zs[0].seed() != zs[1].seed() && zs[0].is_ntt_form() == ckks;
+            std::printf("u_prng_seed %d zero_batched %d\n", seeded ? 1 : 0, zeros ? 1 : 0);
+            failures += !seeded + !zeros;
+        }
         // a mixed batch (one three-polynomial member) takes the per-object path
         {
             std::vector<Ciphertext> mix;

@@ -188,7 +188,7 @@ def test_batched_ops_cpp_api(dev, scheme, count):
     r = subprocess.run([drv, scheme, str(count)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln and ln not in ("OK",)]
-    assert len(lines) >= 17 and all(ln.endswith(" 0") or ln == "size_mismatch_rejected 1" for ln in lines), r.stdout
+    assert len(lines) >= 26 and all(ln.endswith(" 0") or ln in ("size_mismatch_rejected 1", "u_prng_seed 1 zero_batched 1") for ln in lines), r.stdout
 
 
 def test_bgv_cpp_api(dev):

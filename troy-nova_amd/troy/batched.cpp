@@ -331,3 +331,136 @@ void Evaluator::multiply_plain_batched(const std::vector<const Ciphertext*>& enc
 }
 
 }  // namespace troy
+
+namespace troy {
+
+// -- key switching of a batch (evaluator_keyswitching.cu:52-93) -------------------------------------------------------------------
+void Evaluator::apply_keyswitching_batched(const std::vector<const Ciphertext*>& encrypted, const KSwitchKeys& kswitch_keys, const std::vector<Ciphertext*>& destination,
+                                           MemoryPoolHandle pool) const {
+    same_size("[Evaluator::apply_keyswitching_batched]", encrypted.size(), destination.size());
+    const bool bgv = context_->key_context_data().value()->parms().scheme() == SchemeType::BGV;
+    if (bgv || encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; apply_keyswitching(*encrypted[i], kswitch_keys, out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    apply_keyswitching(*encrypted[0], kswitch_keys, proto, pool);      // all the checks of the per-object form
+    const size_t count = encrypted.size(), n = proto.poly_modulus_degree();
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    const size_t pc = static_cast<size_t>(L) * n;
+    const troyn_plan* plan = context_->plan();
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    // (c0, c1) -> (c0 + ks0, ks1): the block starts as a copy, the c1s are the key-switch targets
+    hip_ok(hipMemcpyAsync(block->raw_pointer(), in, count * 2 * pc * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+    utils::DynamicArray target(count * pc, true, pool);
+    hip_ok(hipMemcpy2DAsync(target.raw_pointer(), pc * 8, in + pc, 2 * pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+    const std::vector<const uint64_t*> keys = kswitch_keys.get_data_ptrs(0);
+    const size_t bytes = troyn_switch_key_workspace_bytes(plan, L, count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    const bool ckks = context_->key_context_data().value()->parms().scheme() == SchemeType::CKKS;
+    troyn_check_public(troyn_switch_key(plan, L, ckks, proto.is_ntt_form(), target.raw_pointer(), keys.data(), TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST, block->raw_pointer(),
+                                        ws.raw_pointer(), bytes, count, stream()));
+    assign_views(proto, block, destination);
+}
+
+// -- rotations of a batch ------------------------------------------------------------------------------------------------------------
+void Evaluator::rotate_internal_batched(const std::vector<const Ciphertext*>& encrypted, int steps, const GaloisKeys& galois_keys, const std::vector<Ciphertext*>& destination,
+                                        MemoryPoolHandle pool) const {
+    // evaluator_keyswitching.cu:263-294 for every member; the Galois elements depend on the step only, so each NAF term is one apply_galois_batched
+    const char* P = "[Evaluator::rotate_inplace_internal]";
+    same_size(P, encrypted.size(), destination.size());
+    if (encrypted.empty()) return;
+    if (galois_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Galois keys has incorrect parms id.");
+    if (steps == 0) {
+        for (size_t i = 0; i < encrypted.size(); i++) if (destination[i] != encrypted[i]) *destination[i] = encrypted[i]->clone(pool);
+        return;
+    }
+    const size_t n = encrypted[0]->poly_modulus_degree();
+    const size_t element = utils::galois_element_from_step(n, steps);
+    if (galois_keys.has_key(element)) { apply_galois_batched(encrypted, element, galois_keys, destination, pool); return; }
+    const std::vector<int> naf_steps = utils::naf(steps);
+    if (naf_steps.size() == 1) throw std::invalid_argument(std::string(P) + " Galois key not present.");
+    bool first = true;
+    for (int st : naf_steps) {
+        if (first) { rotate_internal_batched(encrypted, st, galois_keys, destination, pool); first = false; }
+        else rotate_internal_batched(as_const(destination), st, galois_keys, destination, pool);
+    }
+}
+
+void Evaluator::rotate_rows_batched(const std::vector<const Ciphertext*>& e, int steps, const GaloisKeys& k, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument("[Evaluator::rotate_rows_inplace] Rotate rows only applies for BFV or BGV");
+    rotate_internal_batched(e, steps, k, d, pool);
+}
+
+void Evaluator::rotate_vector_batched(const std::vector<const Ciphertext*>& e, int steps, const GaloisKeys& k, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (context_->key_context_data().value()->parms().scheme() != SchemeType::CKKS) throw std::invalid_argument("[Evaluator::rotate_vector_inplace] Rotate vector only applies for CKKS");
+    rotate_internal_batched(e, steps, k, d, pool);
+}
+
+void Evaluator::rotate_columns_batched(const std::vector<const Ciphertext*>& e, const GaloisKeys& k, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::BFV && scheme != SchemeType::BGV) throw std::invalid_argument("[Evaluator::rotate_columns_inplace] Rotate columns only applies for BFV or BGV");
+    same_size("[Evaluator::conjugate_internal_batched]", e.size(), d.size());
+    if (e.empty()) return;
+    apply_galois_batched(e, utils::galois_element_from_step(e[0]->poly_modulus_degree(), 0), k, d, pool);
+}
+
+void Evaluator::complex_conjugate_batched(const std::vector<const Ciphertext*>& e, const GaloisKeys& k, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
+    if (context_->key_context_data().value()->parms().scheme() != SchemeType::CKKS)
+        throw std::invalid_argument("[Evaluator::complex_conjugate_inplace] Complex conjugate only applies for CKKS");
+    same_size("[Evaluator::conjugate_internal_batched]", e.size(), d.size());
+    if (e.empty()) return;
+    apply_galois_batched(e, utils::galois_element_from_step(e[0]->poly_modulus_degree(), 0), k, d, pool);
+}
+
+// -- modulus switching down to a level -------------------------------------------------------------------------------------------------
+void Evaluator::mod_switch_to_batched(const std::vector<const Ciphertext*>& encrypted, const ParmsID& parms_id, const std::vector<Ciphertext*>& destination,
+                                      MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:222-260 per member; a uniform batch steps down together through mod_switch_to_next_batched
+    const char* P = "[Evaluator::mod_switch_to_batched]";
+    same_size(P, encrypted.size(), destination.size());
+    if (encrypted.empty()) return;
+    auto target = context_->get_context_data(parms_id);
+    if (!target.has_value()) throw std::invalid_argument("[Evaluator::mod_switch_to] ParmsID is not valid for the current context.");
+    if (!uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; mod_switch_to(*encrypted[i], parms_id, out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    auto cd = context_->get_context_data(encrypted[0]->parms_id());
+    if (!cd.has_value()) throw std::invalid_argument("[Evaluator::mod_switch_to] ParmsID is not valid for the current context.");
+    if (cd.value()->chain_index() < target.value()->chain_index()) throw std::invalid_argument("[Evaluator::mod_switch_to_inplace] Cannot switch to a higher level.");
+    if (encrypted[0]->parms_id() == parms_id) {
+        for (size_t i = 0; i < encrypted.size(); i++) if (destination[i] != encrypted[i]) *destination[i] = encrypted[i]->clone(pool);
+        return;
+    }
+    mod_switch_to_next_batched(encrypted, destination, pool);
+    while (destination[0]->parms_id() != parms_id) mod_switch_to_next_batched(as_const(destination), destination, pool);
+}
+
+// -- shifts and the 1/N factor of the packing tree ----------------------------------------------------------------------------------------
+void Evaluator::negacyclic_shift_batched(const std::vector<const Ciphertext*>& encrypted, size_t shift, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    same_size("[Evaluator::negacyclic_shift_batched]", encrypted.size(), destination.size());
+    if (encrypted.size() < BATCH_OP_THRESHOLD || !uniform(encrypted)) {
+        for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; negacyclic_shift(*encrypted[i], shift, out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    Ciphertext proto;
+    negacyclic_shift(*encrypted[0], shift, proto, pool);
+    const size_t count = encrypted.size();
+    const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+    utils::DynamicArray staged(0, true, pool);
+    const uint64_t* in = contiguous(encrypted, staged, pool);
+    auto block = result_block(proto, count, pool);
+    troyn_check_public(troyn_negacyclic_shift(context_->plan(), 0, L, in, block->raw_pointer(), shift, count * proto.polynomial_count(), stream()));
+    assign_views(proto, block, destination);
+}
+
+void Evaluator::divide_by_poly_modulus_degree_inplace_batched(const std::vector<Ciphertext*>& encrypted, uint64_t mul, MemoryPoolHandle pool) const {
+    (void)pool;
+    for (Ciphertext* c : encrypted) divide_by_poly_modulus_degree_inplace(*c, mul);
+}
+
+}  // namespace troy

@@ -239,3 +239,84 @@ void CKKSEncoder::encode_integer64_polynomial(const std::vector<int64_t>& values
 }
 
 }  // namespace troy
+
+namespace troy {
+
+// ------------------------------------------------------------------------------------------------
+// Evaluator: mod-t plaintexts to full RNS plaintexts, plaintext NTT transforms (evaluator_transform_ntt.cu:131-240, :366-420)
+// ------------------------------------------------------------------------------------------------
+void Evaluator::bfv_centralize(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::bfv_centralize]";
+    if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is in NTT form.");
+    if (plain.parms_id() != parms_id_zero) throw std::invalid_argument(std::string(P) + " Plaintext is not modulo t.");
+    need_device(P, context_, plain);
+    ContextDataPointer cd = level_of("[Evaluator::transform_plain_to_ntt_inplace]", context_, parms_id);
+    const size_t L = cd->parms().coeff_modulus().size(), n = cd->parms().poly_modulus_degree();
+    if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::centralize] plain_coeff_count exceeds the polynomial degree.");
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, parms_id);
+    troyn_check_public(troyn_plain_centralize(context_->plan(), static_cast<uint32_t>(L), cd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n, out.poly(), 1,
+                                              troyn_current_stream()));
+    troyn_sync_current_stream();
+    out.is_ntt_form() = false;
+    out.scale() = plain.scale();
+    destination = std::move(out);
+}
+
+void Evaluator::bfv_scale_up(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::bfv_centralize]";                       // the reference reuses this prompt (evaluator_transform_ntt.cu:186-189)
+    if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is in NTT form.");
+    if (plain.parms_id() != parms_id_zero) throw std::invalid_argument(std::string(P) + " Plaintext is not modulo t.");
+    need_device(P, context_, plain);
+    ContextDataPointer cd = level_of("[Evaluator::transform_plain_to_ntt_inplace]", context_, parms_id);
+    if (cd->parms().scheme() != SchemeType::BFV) throw std::logic_error("[Evaluator::bfv_scale_up] Only BFV scheme is supported.");
+    const size_t L = cd->parms().coeff_modulus().size(), n = cd->parms().poly_modulus_degree();
+    if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
+    Plaintext out;
+    out.data() = utils::DynamicArray(0, true, pool);
+    out.resize_rns(*context_, parms_id);
+    hip_ok(hipMemsetAsync(out.poly(), 0, L * n * sizeof(uint64_t), stream()), "memset");
+    troyn_check_public(troyn_bfv_scale_up(context_->behz(L), plain.poly(), plain.coeff_count(), n, out.poly(), L * n, out.poly(), L * n, 0, 1, troyn_current_stream()));
+    troyn_sync_current_stream();
+    out.is_ntt_form() = false;
+    out.scale() = plain.scale();
+    destination = std::move(out);
+}
+
+void Evaluator::bfv_centralize_batched(const std::vector<const Plaintext*>& plain, const ParmsID& parms_id, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool) const {
+    if (plain.size() != destination.size()) throw std::invalid_argument("[Evaluator::transform_plain_to_ntt_batched] The number of plaintexts does not match the number of destinations.");
+    for (size_t i = 0; i < plain.size(); i++) { Plaintext d; bfv_centralize(*plain[i], parms_id, d, pool); *destination[i] = std::move(d); }
+}
+
+void Evaluator::bfv_scale_up_batched(const std::vector<const Plaintext*>& plain, const ParmsID& parms_id, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool) const {
+    if (plain.size() != destination.size()) throw std::invalid_argument("[Evaluator::transform_plain_to_ntt_batched] The number of plaintexts does not match the number of destinations.");
+    for (size_t i = 0; i < plain.size(); i++) { Plaintext d; bfv_scale_up(*plain[i], parms_id, d, pool); *destination[i] = std::move(d); }
+}
+
+void Evaluator::transform_plain_to_ntt_batched(const std::vector<const Plaintext*>& plain, const ParmsID& parms_id, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool) const {
+    if (plain.size() != destination.size()) throw std::invalid_argument("[Evaluator::transform_plain_to_ntt_batched] The number of plaintexts does not match the number of destinations.");
+    for (size_t i = 0; i < plain.size(); i++) { Plaintext d; transform_plain_to_ntt(*plain[i], parms_id, d, pool); *destination[i] = std::move(d); }
+}
+
+void Evaluator::transform_plain_from_ntt(const Plaintext& plain, Plaintext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::transform_plain_from_ntt_inplace]";
+    if (!plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " Plaintext is already in NTT form.");      // (sic) the reference's wording
+    if (plain.parms_id() == parms_id_zero) throw std::invalid_argument(std::string(P) + " Invalid ParmsID, but this should never be reached.");
+    need_device(P, context_, plain);
+    ContextDataPointer cd = level_of(P, context_, plain.parms_id());
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    Plaintext out = plain;
+    out.data() = utils::DynamicArray(plain.data().size(), true, pool);
+    troyn_check_public(troyn_ntt(context_->plan(), 1, plain.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
+    troyn_sync_current_stream();
+    out.is_ntt_form() = false;
+    destination = std::move(out);
+}
+
+void Evaluator::transform_plain_from_ntt_batched(const std::vector<const Plaintext*>& plain, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool) const {
+    if (plain.size() != destination.size()) throw std::invalid_argument("[Evaluator::transform_plain_from_ntt_batched] The number of plaintexts does not match the number of destinations.");
+    for (size_t i = 0; i < plain.size(); i++) { Plaintext d; transform_plain_from_ntt(*plain[i], d, pool); *destination[i] = std::move(d); }
+}
+
+}  // namespace troy

@@ -1713,7 +1713,7 @@ static ContextDataPointer level(const char* prompt, const HeContextPointer& cont
 }
 
 void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form, bool save_seed,
-               Ciphertext& destination, MemoryPoolHandle pool) {
+               Ciphertext& destination, MemoryPoolHandle pool, utils::RandomGenerator* c1_seed_prng) {
     // utils/rlwe.cu:218-317 (symmetric_with_c1_prng with the context generator as c1 generator)
     const char* P = "[rlwe::symmetric]";
     require_device_context(P, context);
@@ -1732,8 +1732,8 @@ void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& par
     destination.correction_factor() = 1;
     destination.seed() = 0;
     utils::RandomGenerator& prng = context->random_generator();
-    uint64_t seed = 0;
-    while (seed == 0) seed = prng.sample_uint64();
+    uint64_t seed = 0;                                    // symmetric_with_c1_prng (utils/rlwe.cu:218-317): the seed of c1 may come from the caller's generator
+    while (seed == 0) seed = (c1_seed_prng ? *c1_seed_prng : prng).sample_uint64();
     utils::RandomGenerator c1_prng(seed);
     c1_prng.sample_poly_uniform(plan, L, destination.poly(1));
     if (!is_ntt_form && save_seed) {
@@ -1756,7 +1756,7 @@ void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& par
 }
 
 void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form,
-                Ciphertext& destination, MemoryPoolHandle pool) {
+                Ciphertext& destination, MemoryPoolHandle pool, utils::RandomGenerator* u_prng) {
     // utils/rlwe.cu:11-91 (asymmetric_with_u_prng with the context generator as u generator)
     const char* P = "[rlwe::asymmetric]";
     require_device_context(P, context);
@@ -1778,7 +1778,7 @@ void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& pa
     destination.seed() = 0;
     utils::RandomGenerator& prng = context->random_generator();
     utils::DynamicArray u(static_cast<size_t>(L) * n, true, pool);
-    prng.sample_poly_ternary(plan, L, u.raw_pointer());
+    (u_prng ? *u_prng : prng).sample_poly_ternary(plan, L, u.raw_pointer());     // asymmetric_with_u_prng: u from the caller's generator, the noise from the context's
     troyn_check(troyn_ntt(plan, 0, u.raw_pointer(), u.raw_pointer(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
     for (size_t j = 0; j < encrypted_size; j++)     // the key's first L limbs of polynomial j
         troyn_check(troyn_dyadic_product(plan, 0, L, u.raw_pointer(), public_key.poly(j), destination.poly(j), 1, s));
@@ -1906,7 +1906,7 @@ const SecretKey& Encryptor::secret_key() const {
 }
 
 void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form, bool is_asymmetric, bool save_seed,
-                                      Ciphertext& destination, MemoryPoolHandle pool) const {
+                                      Ciphertext& destination, MemoryPoolHandle pool, utils::RandomGenerator* u_prng) const {
     // encryptor.cu:12-110
     const char* P = "[Encryptor::encrypt_zero_internal]";
     if (is_asymmetric && !public_key_.has_value()) throw std::invalid_argument(std::string(P) + " Public key not set for asymmetric encryption.");
@@ -1916,18 +1916,18 @@ void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form,
     if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " parms_id is not valid for encryption parameters.");
     ContextDataPointer cd = cdo.value();
     if (!is_asymmetric) {
-        rlwe::symmetric(secret_key(), context_, parms_id, is_ntt_form, save_seed, destination, pool);
+        rlwe::symmetric(secret_key(), context_, parms_id, is_ntt_form, save_seed, destination, pool, u_prng);
         return;
     }
     auto prev = cd->prev_context_data();
     if (!prev.has_value()) {
-        rlwe::asymmetric(public_key(), context_, parms_id, is_ntt_form, destination, pool);
+        rlwe::asymmetric(public_key(), context_, parms_id, is_ntt_form, destination, pool, u_prng);
         return;
     }
     // encrypt one level up, then switch the extra prime away (encryptor.cu:44-75)
     ContextDataPointer pcd = prev.value();
     Ciphertext temp;
-    rlwe::asymmetric(public_key(), context_, pcd->parms_id(), is_ntt_form, temp, pool);
+    rlwe::asymmetric(public_key(), context_, pcd->parms_id(), is_ntt_form, temp, pool, u_prng);
     const uint32_t Lp = static_cast<uint32_t>(pcd->parms().coeff_modulus().size());
     const size_t n = pcd->parms().poly_modulus_degree();
     const size_t pc = temp.polynomial_count();
@@ -1961,16 +1961,16 @@ void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form,
     destination = std::move(out);
 }
 
-void Encryptor::encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const {
-    const bool ntt = context_->first_context_data().value()->parms().scheme() == SchemeType::CKKS;
-    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), ntt, true, false, destination, pool);
+void Encryptor::encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id, utils::RandomGenerator* u_prng, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->first_context_data().value()->parms().scheme();      // encryptor.h:160-164: CKKS and BGV zeros are in NTT form
+    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), scheme == SchemeType::CKKS || scheme == SchemeType::BGV, true, false, destination, pool, u_prng);
 }
-void Encryptor::encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const {
-    const bool ntt = context_->first_context_data().value()->parms().scheme() == SchemeType::CKKS;
-    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), ntt, false, save_seed, destination, pool);
+void Encryptor::encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id, utils::RandomGenerator* u_prng, MemoryPoolHandle pool) const {
+    const SchemeType scheme = context_->first_context_data().value()->parms().scheme();
+    encrypt_zero_internal(parms_id.value_or(context_->first_parms_id()), scheme == SchemeType::CKKS || scheme == SchemeType::BGV, false, save_seed, destination, pool, u_prng);
 }
 
-void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const {
+void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool, utils::RandomGenerator* u_prng) const {
     // encryptor.cu:245-330
     const char* P = "[Encryptor::encrypt_internal]";
     require_device_context(P, context_);
@@ -1981,7 +1981,7 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
         case SchemeType::BFV: {
             if (plain.parms_id() == parms_id_zero) {
                 if (plain.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BFV - Plaintext is in NTT form.");
-                encrypt_zero_internal(context_->first_parms_id(), false, is_asymmetric, save_seed, destination, pool);
+                encrypt_zero_internal(context_->first_parms_id(), false, is_asymmetric, save_seed, destination, pool, u_prng);
                 // scaling_variant::multiply_add_plain_inplace: c0 += round(q/t * m)
                 const size_t L = destination.coeff_modulus_size(), n = destination.poly_modulus_degree();
                 if (plain.coeff_count() > n) throw std::invalid_argument("[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
@@ -1991,7 +1991,7 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
                 auto cdo = context_->get_context_data(plain.parms_id());
                 if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " BFV - Plaintext parms_id is not valid.");
                 const uint32_t L = static_cast<uint32_t>(cdo.value()->parms().coeff_modulus().size());
-                encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool);
+                encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool, u_prng);
                 if (plain.coeff_count() != cdo.value()->parms().poly_modulus_degree()) {
                     // a partial RNS plaintext (BatchEncoder::scale_up of a short polynomial): zero-padded to the full shape first
                     const utils::DynamicArray full = plain.expanded_rns(L, cdo.value()->parms().poly_modulus_degree(), pool);
@@ -2007,14 +2007,14 @@ void Encryptor::encrypt_internal(const Plaintext& plain, bool is_asymmetric, boo
             auto cdo = context_->get_context_data(plain.parms_id());
             if (!cdo.has_value()) throw std::invalid_argument(std::string(P) + " CKKS - Plaintext parms_id is not valid.");
             const uint32_t L = static_cast<uint32_t>(cdo.value()->parms().coeff_modulus().size());
-            encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool);
+            encrypt_zero_internal(plain.parms_id(), plain.is_ntt_form(), is_asymmetric, save_seed, destination, pool, u_prng);
             troyn_check(troyn_add(context_->plan(), 0, L, destination.poly(0), plain.poly(), destination.poly(0), 1, s));
             destination.scale() = plain.scale();
             break;
         }
         case SchemeType::BGV: {
             // encryptor.cu:300-333: zero encryption in NTT form at the first level, plus the (centralized, NTT) plaintext
-            encrypt_zero_internal(context_->first_parms_id(), true, is_asymmetric, save_seed, destination, pool);
+            encrypt_zero_internal(context_->first_parms_id(), true, is_asymmetric, save_seed, destination, pool, u_prng);
             ContextDataPointer fcd = context_->first_context_data().value();
             const uint32_t L = static_cast<uint32_t>(fcd->parms().coeff_modulus().size());
             const size_t n = fcd->parms().poly_modulus_degree();

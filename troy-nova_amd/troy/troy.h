@@ -188,6 +188,13 @@ public:
     }
 };
 
+// batch_utils.h: pointer collections for the x_batched forms
+namespace batch_utils {
+template <typename T> std::vector<T*> collect_pointer(std::vector<T>& v) { std::vector<T*> r; r.reserve(v.size()); for (T& x : v) r.push_back(&x); return r; }
+template <typename T> std::vector<const T*> collect_const_pointer(const std::vector<T>& v) { std::vector<const T*> r; r.reserve(v.size()); for (const T& x : v) r.push_back(&x); return r; }
+template <typename T> std::vector<const T*> pcollect_const_pointer(const std::vector<T*>& v) { return std::vector<const T*>(v.begin(), v.end()); }
+}  // namespace batch_utils
+
 // ----------------------------------------------------------------------------------------------
 // EncryptionParameters, ParmsID  (src/encryption_parameters.h)
 // ----------------------------------------------------------------------------------------------
@@ -583,9 +590,9 @@ private:
 namespace rlwe {
 // utils/rlwe.h: encryptions of zero.  `parms_id` selects the level whose moduli are used.
 void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form, bool save_seed,
-               Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+               Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool(), utils::RandomGenerator* c1_seed_prng = nullptr);
 void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& parms_id, bool is_ntt_form,
-                Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+                Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool(), utils::RandomGenerator* u_prng = nullptr);
 }  // namespace rlwe
 
 // ----------------------------------------------------------------------------------------------
@@ -599,10 +606,46 @@ public:
     void set_secret_key(const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { secret_key_ = secret_key.clone(pool); }
     const PublicKey& public_key() const;
     const SecretKey& secret_key() const;
-    void encrypt_asymmetric(const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encrypt_internal(plain, true, false, destination, pool); }
-    Ciphertext encrypt_asymmetric_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_asymmetric(plain, d, pool); return d; }
-    void encrypt_symmetric(const Plaintext& plain, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encrypt_internal(plain, false, save_seed, destination, pool); }
-    Ciphertext encrypt_symmetric_new(const Plaintext& plain, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_symmetric(plain, save_seed, d, pool); return d; }
+    // encryptor.h:140-230.  The reference's argument order: (..., u_prng = nullptr, pool = GlobalPool()).  u_prng, when given, supplies the
+    // ternary u of an asymmetric encryption / the seed of c1 of a symmetric one (utils/rlwe.cu asymmetric_with_u_prng,
+    // symmetric_with_c1_prng); the noise always comes from the context's generator.  The (..., pool) overloads keep three-argument
+    // calls with a pool working.
+    void encrypt_asymmetric(const Plaintext& plain, Ciphertext& destination, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        encrypt_internal(plain, true, false, destination, pool, u_prng);
+    }
+    void encrypt_asymmetric(const Plaintext& plain, Ciphertext& destination, MemoryPoolHandle pool) const { encrypt_internal(plain, true, false, destination, pool, nullptr); }
+    Ciphertext encrypt_asymmetric_new(const Plaintext& plain, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; encrypt_internal(plain, true, false, d, pool, u_prng); return d;
+    }
+    Ciphertext encrypt_asymmetric_new(const Plaintext& plain, MemoryPoolHandle pool) const { Ciphertext d; encrypt_internal(plain, true, false, d, pool, nullptr); return d; }
+    void encrypt_symmetric(const Plaintext& plain, bool save_seed, Ciphertext& destination, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        encrypt_internal(plain, false, save_seed, destination, pool, u_prng);
+    }
+    void encrypt_symmetric(const Plaintext& plain, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const { encrypt_internal(plain, false, save_seed, destination, pool, nullptr); }
+    Ciphertext encrypt_symmetric_new(const Plaintext& plain, bool save_seed, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; encrypt_internal(plain, false, save_seed, d, pool, u_prng); return d;
+    }
+    Ciphertext encrypt_symmetric_new(const Plaintext& plain, bool save_seed, MemoryPoolHandle pool) const { Ciphertext d; encrypt_internal(plain, false, save_seed, d, pool, nullptr); return d; }
+    // batched forms: a caller-supplied generator takes the per-object route (its draws interleave with the context's); without one the
+    // BFV symmetric form is the batched kernel sequence below
+    void encrypt_asymmetric_batched(const std::vector<const Plaintext*>& plain, const std::vector<Ciphertext*>& destination, utils::RandomGenerator* u_prng = nullptr,
+                                    MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (plain.size() != destination.size()) throw std::invalid_argument("[Encryptor::encrypt_internal_batched] Input and destination have different sizes.");
+        for (size_t i = 0; i < plain.size(); i++) encrypt_internal(*plain[i], true, false, *destination[i], pool, u_prng);
+    }
+    std::vector<Ciphertext> encrypt_asymmetric_new_batched(const std::vector<const Plaintext*>& plain, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Ciphertext> d(plain.size()); encrypt_asymmetric_batched(plain, batch_utils::collect_pointer(d), u_prng, pool); return d;
+    }
+    void encrypt_symmetric_batched(const std::vector<const Plaintext*>& plain, bool save_seed, const std::vector<Ciphertext*>& destination, utils::RandomGenerator* u_prng,
+                                   MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (u_prng == nullptr) { encrypt_symmetric_batched(plain, save_seed, destination, pool); return; }
+        if (plain.size() != destination.size()) throw std::invalid_argument("[Encryptor::encrypt_internal_batched] Input and destination have different sizes.");
+        for (size_t i = 0; i < plain.size(); i++) encrypt_internal(*plain[i], false, save_seed, *destination[i], pool, u_prng);
+    }
+    std::vector<Ciphertext> encrypt_symmetric_new_batched(const std::vector<const Plaintext*>& plain, bool save_seed, utils::RandomGenerator* u_prng = nullptr,
+                                                          MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Ciphertext> d(plain.size()); encrypt_symmetric_batched(plain, save_seed, batch_utils::collect_pointer(d), u_prng, pool); return d;
+    }
     // encryptor.h encrypt_symmetric_batched: the same ciphertexts, bit for bit, as encrypt_symmetric called once per plaintext
     // in order (the generator positions are reproduced), in a constant number of launches; the results share one buffer
     void encrypt_symmetric_batched(const std::vector<const Plaintext*>& plain, bool save_seed, const std::vector<Ciphertext*>& destination,
@@ -612,13 +655,39 @@ public:
     // NTT-form plaintexts): NTT-form ciphertexts that carry the seed of c1 (half the wire size; expand_seed before use)
     std::vector<Ciphertext> encrypt_symmetric_packed(const uint64_t* plains, size_t coeff_count, size_t stride, size_t count,
                                                      MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool ntt_seeded = false) const;
-    void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
-    Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_asymmetric(d, parms_id, pool); return d; }
-    void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
-    Ciphertext encrypt_zero_symmetric_new(bool save_seed, std::optional<ParmsID> parms_id = std::nullopt, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; encrypt_zero_symmetric(save_seed, d, parms_id, pool); return d; }
+    void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void encrypt_zero_asymmetric(Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const { encrypt_zero_asymmetric(destination, parms_id, nullptr, pool); }
+    Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; encrypt_zero_asymmetric(d, parms_id, u_prng, pool); return d;
+    }
+    Ciphertext encrypt_zero_asymmetric_new(std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const { Ciphertext d; encrypt_zero_asymmetric(d, parms_id, nullptr, pool); return d; }
+    void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr,
+                                MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void encrypt_zero_symmetric(bool save_seed, Ciphertext& destination, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const { encrypt_zero_symmetric(save_seed, destination, parms_id, nullptr, pool); }
+    Ciphertext encrypt_zero_symmetric_new(bool save_seed, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; encrypt_zero_symmetric(save_seed, d, parms_id, u_prng, pool); return d;
+    }
+    Ciphertext encrypt_zero_symmetric_new(bool save_seed, std::optional<ParmsID> parms_id, MemoryPoolHandle pool) const { Ciphertext d; encrypt_zero_symmetric(save_seed, d, parms_id, nullptr, pool); return d; }
+    void encrypt_zero_asymmetric_batched(const std::vector<Ciphertext*>& destination, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr,
+                                         MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        for (Ciphertext* d : destination) encrypt_zero_asymmetric(*d, parms_id, u_prng, pool);
+    }
+    std::vector<Ciphertext> encrypt_zero_asymmetric_new_batched(size_t count, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr,
+                                                                MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Ciphertext> d(count); encrypt_zero_asymmetric_batched(batch_utils::collect_pointer(d), parms_id, u_prng, pool); return d;
+    }
+    void encrypt_zero_symmetric_batched(bool save_seed, const std::vector<Ciphertext*>& destination, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr,
+                                        MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        for (Ciphertext* d : destination) encrypt_zero_symmetric(save_seed, *d, parms_id, u_prng, pool);
+    }
+    std::vector<Ciphertext> encrypt_zero_symmetric_new_batched(size_t count, bool save_seed, std::optional<ParmsID> parms_id = std::nullopt, utils::RandomGenerator* u_prng = nullptr,
+                                                               MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Ciphertext> d(count); encrypt_zero_symmetric_batched(save_seed, batch_utils::collect_pointer(d), parms_id, u_prng, pool); return d;
+    }
 private:
-    void encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const;
-    void encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool) const;
+    void encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool,
+                               utils::RandomGenerator* u_prng = nullptr) const;
+    void encrypt_internal(const Plaintext& plain, bool is_asymmetric, bool save_seed, Ciphertext& destination, MemoryPoolHandle pool, utils::RandomGenerator* u_prng = nullptr) const;
     HeContextPointer context_;
     std::optional<PublicKey> public_key_;
     std::optional<SecretKey> secret_key_;
@@ -642,6 +711,16 @@ public:
     }
     // decryptor.h decrypt_batched (BFV two-polynomial ciphertexts of one level take the batched path; anything else loops)
     void decrypt_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<Plaintext> decrypt_batched_new(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Plaintext> d(encrypted.size()); decrypt_batched(encrypted, batch_utils::collect_pointer(d), pool); return d;
+    }
+    void bfv_decrypt_without_scaling_down_batched(const std::vector<const Ciphertext*>& encrypted, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (encrypted.size() != destination.size()) throw std::invalid_argument("[Decryptor::bfv_decrypt_without_scaling_down_batched] Input and destination have different sizes.");
+        for (size_t i = 0; i < encrypted.size(); i++) bfv_decrypt_without_scaling_down(*encrypted[i], *destination[i], pool);
+    }
+    std::vector<Plaintext> bfv_decrypt_without_scaling_down_batched_new(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Plaintext> d(encrypted.size()); bfv_decrypt_without_scaling_down_batched(encrypted, batch_utils::collect_pointer(d), pool); return d;
+    }
     // the plaintext coefficients of every ciphertext, concatenated on the host ([count][N]); one device-to-host copy
     std::vector<uint64_t> bfv_decrypt_to_host(const std::vector<const Ciphertext*>& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
 private:
@@ -865,6 +944,83 @@ public:
     void apply_galois_plain(const Plaintext& plain, size_t galois_element, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void apply_galois_plain_inplace(Plaintext& plain, size_t galois_element, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; apply_galois_plain(plain, galois_element, d, pool); plain = std::move(d); }
     Plaintext apply_galois_plain_new(const Plaintext& plain, size_t galois_element, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; apply_galois_plain(plain, galois_element, d, pool); return d; }
+    // ---- the remaining spellings of evaluator.h: x_inplace_batched / x_new_batched over the batched cores, and the plaintext-side families ----
+    typedef std::vector<const Ciphertext*> ConstCiphers;
+    typedef std::vector<Ciphertext*> Ciphers;
+    typedef std::vector<const Plaintext*> ConstPlains;
+    typedef std::vector<Plaintext*> Plains;
+    std::vector<Ciphertext> negate_new_batched(const ConstCiphers& e, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); negate_batched(e, batch_utils::collect_pointer(d), pool); return d; }
+    void add_inplace_batched(const Ciphers& e1, const ConstCiphers& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_batched(batch_utils::pcollect_const_pointer(e1), e2, e1, false, pool); }
+    void sub_inplace_batched(const Ciphers& e1, const ConstCiphers& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_batched(batch_utils::pcollect_const_pointer(e1), e2, e1, true, pool); }
+    void translate_inplace_batched(const Ciphers& e1, const ConstCiphers& e2, bool subtract, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { translate_batched(batch_utils::pcollect_const_pointer(e1), e2, e1, subtract, pool); }
+    std::vector<Ciphertext> add_new_batched(const ConstCiphers& e1, const ConstCiphers& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e1.size()); add_batched(e1, e2, batch_utils::collect_pointer(d), pool); return d; }
+    std::vector<Ciphertext> sub_new_batched(const ConstCiphers& e1, const ConstCiphers& e2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e1.size()); sub_batched(e1, e2, batch_utils::collect_pointer(d), pool); return d; }
+    std::vector<Ciphertext> transform_to_ntt_new_batched(const ConstCiphers& e, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); transform_to_ntt_batched(e, batch_utils::collect_pointer(d), pool); return d; }
+    std::vector<Ciphertext> transform_from_ntt_new_batched(const ConstCiphers& e, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); transform_from_ntt_batched(e, batch_utils::collect_pointer(d), pool); return d; }
+    void mod_switch_to_next_inplace_batched(const Ciphers& e, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { mod_switch_to_next_batched(batch_utils::pcollect_const_pointer(e), e, pool); }
+    std::vector<Ciphertext> mod_switch_to_next_new_batched(const ConstCiphers& e, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); mod_switch_to_next_batched(e, batch_utils::collect_pointer(d), pool); return d; }
+    // evaluator_modswitch.cu mod_switch_to_batched: level by level down to parms_id (the batch moves together when it is uniform)
+    void mod_switch_to_batched(const ConstCiphers& encrypted, const ParmsID& parms_id, const Ciphers& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void mod_switch_to_inplace_batched(const Ciphers& e, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { mod_switch_to_batched(batch_utils::pcollect_const_pointer(e), parms_id, e, pool); }
+    std::vector<Ciphertext> mod_switch_to_new_batched(const ConstCiphers& e, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); mod_switch_to_batched(e, parms_id, batch_utils::collect_pointer(d), pool); return d; }
+    void multiply_plain_inplace_batched(const Ciphers& e, const ConstPlains& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { multiply_plain_batched(batch_utils::pcollect_const_pointer(e), plain, e, pool); }
+    std::vector<Ciphertext> multiply_plain_new_batched(const ConstCiphers& e, const ConstPlains& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); multiply_plain_batched(e, plain, batch_utils::collect_pointer(d), pool); return d; }
+    // evaluator_keyswitching.cu:52-93 apply_keyswitching_batched: one gather + one key-switch launch sequence for a uniform batch
+    void apply_keyswitching_batched(const ConstCiphers& encrypted, const KSwitchKeys& kswitch_keys, const Ciphers& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void apply_keyswitching_inplace_batched(const Ciphers& e, const KSwitchKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { apply_keyswitching_batched(batch_utils::pcollect_const_pointer(e), k, e, pool); }
+    std::vector<Ciphertext> apply_keyswitching_new_batched(const ConstCiphers& e, const KSwitchKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); apply_keyswitching_batched(e, k, batch_utils::collect_pointer(d), pool); return d; }
+    void apply_galois_inplace_batched(const Ciphers& e, size_t galois_element, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { apply_galois_batched(batch_utils::pcollect_const_pointer(e), galois_element, k, e, pool); }
+    std::vector<Ciphertext> apply_galois_new_batched(const ConstCiphers& e, size_t galois_element, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); apply_galois_batched(e, galois_element, k, batch_utils::collect_pointer(d), pool); return d; }
+    // rotations of a batch (evaluator_keyswitching.cu rotate_internal_batched): one apply_galois_batched per step of the NAF decomposition
+    void rotate_internal_batched(const ConstCiphers& encrypted, int steps, const GaloisKeys& galois_keys, const Ciphers& destination, MemoryPoolHandle pool) const;
+    void rotate_rows_batched(const ConstCiphers& e, int steps, const GaloisKeys& k, const Ciphers& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rotate_rows_inplace_batched(const Ciphers& e, int steps, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { rotate_rows_batched(batch_utils::pcollect_const_pointer(e), steps, k, e, pool); }
+    std::vector<Ciphertext> rotate_rows_new_batched(const ConstCiphers& e, int steps, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); rotate_rows_batched(e, steps, k, batch_utils::collect_pointer(d), pool); return d; }
+    void rotate_columns_batched(const ConstCiphers& e, const GaloisKeys& k, const Ciphers& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rotate_columns_inplace_batched(const Ciphers& e, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { rotate_columns_batched(batch_utils::pcollect_const_pointer(e), k, e, pool); }
+    std::vector<Ciphertext> rotate_columns_new_batched(const ConstCiphers& e, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); rotate_columns_batched(e, k, batch_utils::collect_pointer(d), pool); return d; }
+    void rotate_vector_batched(const ConstCiphers& e, int steps, const GaloisKeys& k, const Ciphers& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void rotate_vector_inplace_batched(const Ciphers& e, int steps, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { rotate_vector_batched(batch_utils::pcollect_const_pointer(e), steps, k, e, pool); }
+    std::vector<Ciphertext> rotate_vector_new_batched(const ConstCiphers& e, int steps, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); rotate_vector_batched(e, steps, k, batch_utils::collect_pointer(d), pool); return d; }
+    void complex_conjugate_inplace(Ciphertext& encrypted, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; complex_conjugate(encrypted, k, d, pool); encrypted = std::move(d); }
+    void complex_conjugate_batched(const ConstCiphers& e, const GaloisKeys& k, const Ciphers& d, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void complex_conjugate_inplace_batched(const Ciphers& e, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { complex_conjugate_batched(batch_utils::pcollect_const_pointer(e), k, e, pool); }
+    std::vector<Ciphertext> complex_conjugate_new_batched(const ConstCiphers& e, const GaloisKeys& k, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); complex_conjugate_batched(e, k, batch_utils::collect_pointer(d), pool); return d; }
+    void negacyclic_shift_batched(const ConstCiphers& encrypted, size_t shift, const Ciphers& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void negacyclic_shift_inplace_batched(const Ciphers& e, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { negacyclic_shift_batched(batch_utils::pcollect_const_pointer(e), shift, e, pool); }
+    std::vector<Ciphertext> negacyclic_shift_new_batched(const ConstCiphers& e, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); negacyclic_shift_batched(e, shift, batch_utils::collect_pointer(d), pool); return d; }
+    void divide_by_poly_modulus_degree_inplace_batched(const Ciphers& encrypted, uint64_t mul = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void pack_lwe_ciphertexts(const std::vector<const LWECiphertext*>& lwes, const GaloisKeys& automorphism_keys, Ciphertext& output, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
+                              bool apply_field_trace = true) const { output = pack_lwe_ciphertexts_new(lwes, automorphism_keys, pool, apply_field_trace); }
+    void pack_lwe_ciphertexts_batched(const std::vector<std::vector<const LWECiphertext*>>& lwe_groups, const GaloisKeys& automorphism_keys, const Ciphers& output,
+                                      MemoryPoolHandle pool = MemoryPool::GlobalPool(), bool apply_field_trace = true) const {
+        std::vector<Ciphertext> r = pack_lwe_ciphertexts_new_batched(lwe_groups, automorphism_keys, pool, apply_field_trace);
+        if (r.size() != output.size()) throw std::invalid_argument("[Evaluator::pack_lwe_ciphertexts_batched] Input and destination have different sizes.");
+        for (size_t i = 0; i < r.size(); i++) *output[i] = std::move(r[i]);
+    }
+    // evaluator.h:520-590: a mod-t plaintext to its RNS form at a level (what BatchEncoder::centralize / scale_up return, from the evaluator)
+    void bfv_centralize(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext bfv_centralize_new(const Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; bfv_centralize(plain, parms_id, d, pool); return d; }
+    void bfv_centralize_inplace(Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; bfv_centralize(plain, parms_id, d, pool); plain = std::move(d); }
+    void bfv_centralize_batched(const ConstPlains& plain, const ParmsID& parms_id, const Plains& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<Plaintext> bfv_centralize_new_batched(const ConstPlains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Plaintext> d(plain.size()); bfv_centralize_batched(plain, parms_id, batch_utils::collect_pointer(d), pool); return d; }
+    void bfv_centralize_inplace_batched(const Plains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { bfv_centralize_batched(batch_utils::pcollect_const_pointer(plain), parms_id, plain, pool); }
+    void bfv_scale_up(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Plaintext bfv_scale_up_new(const Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; bfv_scale_up(plain, parms_id, d, pool); return d; }
+    void bfv_scale_up_inplace(Plaintext& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; bfv_scale_up(plain, parms_id, d, pool); plain = std::move(d); }
+    void bfv_scale_up_batched(const ConstPlains& plain, const ParmsID& parms_id, const Plains& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    std::vector<Plaintext> bfv_scale_up_new_batched(const ConstPlains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Plaintext> d(plain.size()); bfv_scale_up_batched(plain, parms_id, batch_utils::collect_pointer(d), pool); return d; }
+    void bfv_scale_up_inplace_batched(const Plains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { bfv_scale_up_batched(batch_utils::pcollect_const_pointer(plain), parms_id, plain, pool); }
+    // evaluator.h:596-660: plaintext NTT transforms, batched and inverse
+    void transform_plain_to_ntt_batched(const ConstPlains& plain, const ParmsID& parms_id, const Plains& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void transform_plain_to_ntt_inplace_batched(const Plains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { transform_plain_to_ntt_batched(batch_utils::pcollect_const_pointer(plain), parms_id, plain, pool); }
+    std::vector<Plaintext> transform_plain_to_ntt_new_batched(const ConstPlains& plain, const ParmsID& parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Plaintext> d(plain.size()); transform_plain_to_ntt_batched(plain, parms_id, batch_utils::collect_pointer(d), pool); return d; }
+    void transform_plain_from_ntt(const Plaintext& plain, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void transform_plain_from_ntt_inplace(Plaintext& plain) const { Plaintext d; transform_plain_from_ntt(plain, d); plain = std::move(d); }
+    Plaintext transform_plain_from_ntt_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; transform_plain_from_ntt(plain, d, pool); return d; }
+    void transform_plain_from_ntt_batched(const ConstPlains& plain, const Plains& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void transform_plain_from_ntt_inplace_batched(const Plains& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { transform_plain_from_ntt_batched(batch_utils::pcollect_const_pointer(plain), plain, pool); }
+    std::vector<Plaintext> transform_plain_from_ntt_new_batched(const ConstPlains& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Plaintext> d(plain.size()); transform_plain_from_ntt_batched(plain, batch_utils::collect_pointer(d), pool); return d; }
     void apply_galois_inplace(Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); encrypted = std::move(d); }
     Ciphertext apply_galois_new(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; apply_galois(encrypted, galois_element, galois_keys, d, pool); return d; }
     void rotate_rows(const Ciphertext& encrypted, int steps, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
