@@ -56,6 +56,13 @@ int main(int argc, char** argv) {
         const size_t x_bytes = x_serialized.str().size();
         xe = Cipher2d::load_new(x_serialized, context);
         Cipher2d ye = helper.matmul(evaluator, xe, we);
+        size_t fly_bad = 0;
+        {
+            Cipher2d yf = helper.matmul_fly_doubles(encoder, evaluator, xe, w.data(), std::nullopt, scale);
+            for (size_t r = 0; r < ye.data().size(); r++)
+                for (size_t c = 0; c < ye[r].size(); c++) fly_bad += yf[r][c].data().to_vector() != ye[r][c].data().to_vector() || yf[r][c].scale() != ye[r][c].scale();
+            std::printf("fly_mismatches %zu\n", fly_bad);
+        }
         if (mod_switch) ye.mod_switch_to_next_inplace(evaluator);
         if (pack_lwe) ye = helper.pack_outputs(evaluator, automorphism_key, ye);
         ye.add_plain_inplace(evaluator, se);
@@ -70,7 +77,7 @@ int main(int argc, char** argv) {
         for (auto& r : ye.data()) outputs_n += r.size();
         std::printf("outputs %zu level %zu scale_log2 %.2f bytes inputs %zu outputs %zu\n", outputs_n, ye[0][0].coeff_modulus_size(), std::log2(ye[0][0].scale()), x_bytes, y_bytes);
         std::printf("max_error %.3e\n", err);
-        const bool ok = err < 1e-3;                       // the reference's own check uses an absolute tolerance of this order at scale 2^20
+        const bool ok = err < 1e-3 && fly_bad == 0;                       // the reference's own check uses an absolute tolerance of this order at scale 2^20
         std::printf(ok ? "OK\n" : "FAIL\n");
         MemoryPool::Destroy();
         return ok ? 0 : 1;

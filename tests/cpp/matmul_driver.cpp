@@ -86,6 +86,20 @@ int main(int argc, char** argv) {
         };
         Cipher2d ye = product();
         double t3 = now();
+        size_t fly_bad = 0;
+        if (objective == MatmulObjective::EncryptLeft) {
+            // matmul_fly: the weights encoded block row by block row give the same ciphertexts, word for word; so does the bias added on the fly
+            Cipher2d yf = helper.matmul_fly_uint64s(encoder, evaluator, xe, w.data());
+            for (size_t r = 0; r < ye.data().size(); r++)
+                for (size_t c = 0; c < ye[r].size(); c++) fly_bad += yf[r][c].data().to_vector() != ye[r][c].data().to_vector();
+            if (!pack_lwe) {                                     // (with packing the bias is laid out for the packed outputs and is added after pack_outputs)
+                Cipher2d yb = ye.clone();
+                yb.add_plain_inplace(evaluator, se);
+                helper.add_bias_inplace_fly_uint64s(encoder, evaluator, yf, sbias.data());
+                for (size_t r = 0; r < yb.data().size(); r++)
+                    for (size_t c = 0; c < yb[r].size(); c++) fly_bad += yf[r][c].data().to_vector() != yb[r][c].data().to_vector();
+            }
+        }
         for (int r = 1; r < repeat; r++) ye = product();
         double t4 = now();
         if (mod_switch) ye.mod_switch_to_next_inplace(evaluator);
@@ -129,6 +143,8 @@ int main(int argc, char** argv) {
         size_t bad = 0;
         for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];
         std::printf("mismatches %zu of %zu\n", bad, got.size());
+        std::printf("fly_mismatches %zu\n", fly_bad);
+        bad += fly_bad;
         std::printf(bad ? "FAIL\n" : "OK\n");
         MemoryPool::Destroy();
         return bad ? 1 : 0;

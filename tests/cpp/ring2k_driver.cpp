@@ -66,6 +66,13 @@ static bool run_matmul(const HeContextPointer& he, const KeyGenerator& keygen, c
     xe.save(wire, he);
     xe = linear::Cipher2d::load_new(wire, he);
     linear::Cipher2d ye = helper.matmul(evaluator, xe, we);
+    {
+        linear::Cipher2d yf = helper.matmul_fly_ring2k(encoder, evaluator, xe, w.data(), std::nullopt);
+        size_t fly_bad = 0;
+        for (size_t r = 0; r < ye.data().size(); r++)
+            for (size_t c = 0; c < ye[r].size(); c++) fly_bad += yf[r][c].data().to_vector() != ye[r][c].data().to_vector();
+        if (fly_bad) { std::printf("matmul_fly_ring2k differs from matmul in %zu ciphertexts\n", fly_bad); return false; }
+    }
     if (pack_lwe) {
         GaloisKeys autokey = keygen.create_automorphism_keys(false);
         ye = helper.pack_outputs(evaluator, autokey, ye);

@@ -150,6 +150,7 @@ def test_matmul_cpp_api(dev, dims, pack_lwe, mod_switch, objective):
         pytest.fail("tests/cpp/matmul_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv] + [str(d) for d in dims] + ["1", str(pack_lwe), str(mod_switch), objective], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout and "mismatches 0 of %d" % (dims[0] * dims[2]) in r.stdout, r.stdout + r.stderr
+    assert "fly_mismatches 0" in r.stdout                                   # matmul_fly / add_bias_inplace_fly == the held-weights forms, word for word
     kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
     sizes = dict(zip(kv["bytes"][0::2], [int(v) for v in kv["bytes"][1::2]]))
     objs = dict(zip(kv["objects"][0::2], [int(v) for v in kv["objects"][1::2]]))

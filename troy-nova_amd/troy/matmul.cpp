@@ -343,6 +343,67 @@ Cipher2d detail::accumulate_products(const Evaluator& evaluator, const Ciphertex
     return ret;
 }
 
+Cipher2d detail::accumulate_products_fly(const Evaluator& evaluator, const Cipher2d& inputs, size_t batch_split, size_t input_split, size_t output_split,
+                                         const std::function<std::vector<Plaintext>(size_t)>& row, MemoryPoolHandle pool) {
+    if (inputs.size() != batch_split) throw std::invalid_argument("[MatmulHelper::matmul] Input batch_size incorrect.");
+    const Ciphertext& like = inputs[0][0];
+    const size_t pcnt = like.polynomial_count(), L = like.coeff_modulus_size(), n = like.poly_modulus_degree(), words = pcnt * L * n;
+    auto shared = std::make_shared<utils::DynamicArray>(batch_split * output_split * words, true, pool);
+    shared->set_zero();
+    Cipher2d ret;
+    ret.data().resize(batch_split);
+    for (size_t b = 0; b < batch_split; b++)
+        for (size_t j = 0; j < output_split; j++)
+            ret[b].push_back(Ciphertext::from_members(pcnt, L, n, like.parms_id(), like.scale(), true, like.correction_factor(), 0,
+                                                      utils::DynamicArray::device_view(shared->raw_pointer() + (b * output_split + j) * words, words, shared)));
+    for (size_t i = 0; i < input_split; i++) {
+        const std::vector<Plaintext> w_i = row(i);                      // alive for this input block only
+        if (w_i.size() != output_split) throw std::invalid_argument("[MatmulHelper::matmul_fly] Weight block count incorrect.");
+        std::vector<const Ciphertext*> c_ptrs;
+        std::vector<const Plaintext*> p_ptrs;
+        std::vector<Ciphertext*> r_ptrs;
+        for (size_t j = 0; j < output_split; j++)
+            for (size_t b = 0; b < batch_split; b++) {
+                if (inputs[b].size() != input_split) throw std::invalid_argument("[MatmulHelper::matmul] Input input_dims incorrect.");
+                c_ptrs.push_back(&inputs[b][i]); p_ptrs.push_back(&w_i[j]); r_ptrs.push_back(&ret[b][j]);
+            }
+        evaluator.multiply_plain_accumulate(c_ptrs, p_ptrs, r_ptrs, false, pool);
+    }
+    if (evaluator.context()->first_context_data().value()->parms().scheme() == SchemeType::BFV) {
+        troyn_check_public(troyn_ntt(evaluator.context()->plan(), 1, shared->raw_pointer(), shared->raw_pointer(), batch_split * output_split, pcnt,
+                                     static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
+        troyn_sync_current_stream();
+        for (auto& r : ret.data()) for (Ciphertext& c : r) c.is_ntt_form() = false;
+    }
+    return ret;
+}
+
+Cipher2d MatmulHelper::matmul_fly_uint64s(const BatchEncoder& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const uint64_t* weights) const {
+    const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
+    const uint64_t t = encoder.context()->first_context_data().value()->parms().plain_modulus().value();
+    const size_t len = input_block * output_block;
+    return detail::accumulate_products_fly(evaluator, inputs, batch_split, input_split, output_split, [&](size_t i) {
+        std::vector<uint64_t> packed(output_split * len);
+        for (size_t j = 0; j < output_split; j++) {
+            const std::vector<uint64_t> block = weight_block(weights, i * input_block, j * output_block);
+            for (uint64_t v : block) if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
+            std::copy(block.begin(), block.end(), packed.begin() + static_cast<std::ptrdiff_t>(j * len));
+        }
+        Plain2d encoded = detail::encode_blocks_for_plain(encoder, packed, 1, output_split, len, pool);     // one copy, one centralize, one NTT launch
+        return std::move(encoded[0]);
+    }, pool);
+}
+
+Cipher2d MatmulHelper::matmul_fly_doubles(const CKKSEncoder& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const double* weights, std::optional<ParmsID> parms_id,
+                                          double scale) const {
+    const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);
+    return detail::accumulate_products_fly(evaluator, inputs, batch_split, input_split, output_split, [&](size_t i) {
+        std::vector<Plaintext> row;
+        for (size_t j = 0; j < output_split; j++) row.push_back(encoder.encode_float64_polynomial_new(weight_block(weights, i * input_block, j * output_block), parms_id, scale, pool));
+        return row;
+    }, pool);
+}
+
 Cipher2d MatmulHelper::matmul(const Evaluator& evaluator, const Cipher2d& a, const Plain2d& w) const {
     // app/matmul.cu:326-374, batched form
     const size_t batch_split = ceil_div(batch_size, batch_block), input_split = ceil_div(input_dims, input_block), output_split = ceil_div(output_dims, output_block);

@@ -94,6 +94,10 @@ Cipher2d encrypt_blocks(const Encryptor& encryptor, const BatchEncoder& encoder,
 Cipher2d accumulate_products(const Evaluator& evaluator, const Ciphertext& like, size_t batch_split, size_t input_split, size_t output_split,
                              const std::function<const Ciphertext*(size_t, size_t, size_t)>& ct_at,
                              const std::function<const Plaintext*(size_t, size_t, size_t)>& pt_at, MemoryPoolHandle pool);
+// the same sum with the plaintext operand produced one input block at a time: row(i) returns the output_split NTT-form plaintexts of
+// input block i, which are multiplied into the running sums and dropped (app/matmul.cu:725-748 matmul_fly)
+Cipher2d accumulate_products_fly(const Evaluator& evaluator, const Cipher2d& inputs, size_t batch_split, size_t input_split, size_t output_split,
+                                 const std::function<std::vector<Plaintext>(size_t)>& row, MemoryPoolHandle pool);
 }  // namespace detail
 
 class MatmulHelper {
@@ -102,6 +106,7 @@ public:
     size_t batch_block = 0, input_block = 0, output_block = 0;
     MatmulObjective objective;
     bool pack_lwe;
+    bool batched_mul = true;          // matmul.h:60-65: the products of a call are formed by batched kernels (always the case here)
     MemoryPoolHandle pool;
 
     void set_pool(MemoryPoolHandle p) { pool = std::move(p); }
@@ -134,6 +139,20 @@ public:
     Cipher2d encrypt_weights_doubles(const Encryptor& encryptor, const CKKSEncoder& encoder, const double* weights, std::optional<ParmsID> parms_id, double scale) const;
     Plain2d encode_outputs_doubles(const CKKSEncoder& encoder, const double* outputs, std::optional<ParmsID> parms_id, double scale) const;
     std::vector<double> decrypt_outputs_doubles(const CKKSEncoder& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
+    // matmul.h:40-51, :120-128: the weights (and the bias) encoded on the fly instead of being held as a Plain2d -- one input block of weight
+    // plaintexts is alive at a time
+    Cipher2d matmul_fly_uint64s(const BatchEncoder& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const uint64_t* weights) const;
+    Cipher2d matmul_fly_doubles(const CKKSEncoder& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const double* weights, std::optional<ParmsID> parms_id, double scale) const;
+    template <typename T> Cipher2d matmul_fly_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const T* weights, std::optional<ParmsID> parms_id) const;
+    void add_bias_inplace_fly_uint64s(const BatchEncoder& encoder, const Evaluator& evaluator, Cipher2d& multiplied, const uint64_t* bias) const {
+        multiplied.add_plain_inplace(evaluator, encode_outputs_uint64s(encoder, bias), pool);
+    }
+    void add_bias_inplace_fly_doubles(const CKKSEncoder& encoder, const Evaluator& evaluator, Cipher2d& multiplied, const double* bias, std::optional<ParmsID> parms_id, double scale) const {
+        multiplied.add_plain_inplace(evaluator, encode_outputs_doubles(encoder, bias, parms_id, scale), pool);
+    }
+    template <typename T> void add_bias_inplace_fly_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Evaluator& evaluator, Cipher2d& multiplied, const T* bias, std::optional<ParmsID> parms_id) const {
+        multiplied.add_plain_inplace(evaluator, encode_outputs_ring2k(encoder, bias, parms_id), pool);
+    }
     // Z_{2^k} matrices through PolynomialEncoderRing2k<T> (encoder_adapter.h:48-67: the encrypted operand is scaled up, the plaintext
     // operand centralized, outputs are scaled down from the undivided phase); the same block layouts
     template <typename T> Plain2d encode_weights_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* weights, std::optional<ParmsID> parms_id) const;
@@ -282,6 +301,20 @@ std::vector<T> MatmulHelper::decrypt_outputs_ring2k(const PolynomialEncoderRing2
         }
     }
     return out;
+}
+
+template <typename T>
+Cipher2d MatmulHelper::matmul_fly_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Evaluator& evaluator, const Cipher2d& inputs, const T* weights, std::optional<ParmsID> parms_id) const {
+    const size_t batch_split = (batch_size + batch_block - 1) / batch_block, input_split = (input_dims + input_block - 1) / input_block, output_split = (output_dims + output_block - 1) / output_block;
+    return detail::accumulate_products_fly(evaluator, inputs, batch_split, input_split, output_split, [&](size_t i) {
+        std::vector<Plaintext> row;
+        for (size_t j = 0; j < output_split; j++) {
+            Plaintext p = encoder.centralize_new(weight_block(weights, i * input_block, j * output_block), parms_id, pool);
+            evaluator.transform_plain_to_ntt_inplace(p, p.parms_id(), pool);
+            row.push_back(std::move(p));
+        }
+        return row;
+    }, pool);
 }
 
 }}  // namespace troy::linear
