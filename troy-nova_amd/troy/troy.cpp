@@ -1834,6 +1834,12 @@ PublicKey KeyGenerator::create_public_key(bool save_seed, MemoryPoolHandle pool)
     return PublicKey(std::move(c));
 }
 
+PublicKey KeyGenerator::create_public_key_with_u_prng(bool save_seed, utils::RandomGenerator& u_prng, MemoryPoolHandle pool) const {
+    Ciphertext c;
+    rlwe::symmetric(secret_key_, context_, context_->key_parms_id(), true, save_seed, c, pool, &u_prng);
+    return PublicKey(std::move(c));
+}
+
 void KeyGenerator::compute_secret_key_powers(HeContextPointer context, size_t max_power, utils::DynamicArray& secret_key_array) {
     // key_generator.cu:86-109
     ContextDataPointer kcd = context->key_context_data().value();

@@ -508,6 +508,7 @@ public:
     // device pointers of key_vector[index][j] (kswitch_keys.h:34-54), as a host array for the C-ABI
     std::vector<const uint64_t*> get_data_ptrs(size_t index) const;
     const KSwitchKeys& as_kswitch_keys() const { return *this; }
+    size_t key_count() const { size_t c = 0; for (const auto& v : keys_) c += !v.empty(); return c; }      // kswitch_keys.h:154
     size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const {
         size_t total = sizeof(ParmsID) + 2 * sizeof(size_t);
         for (const auto& v : keys_) { if (v.empty()) continue; total += 2 * sizeof(size_t); for (const PublicKey& k : v) total += k.serialized_size_upperbound(context, mode); }
@@ -566,6 +567,8 @@ public:
     bool on_device() const { return secret_key_.on_device(); }
     const SecretKey& secret_key() const { return secret_key_; }
     PublicKey create_public_key(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    // key_generator.h:65-67: the seed of the key's c1 drawn from the caller's generator (utils/rlwe.cu symmetric_with_c1_prng)
+    PublicKey create_public_key_with_u_prng(bool save_seed, utils::RandomGenerator& u_prng, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     KSwitchKeys create_keyswitching_key(const SecretKey& new_key, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     RelinKeys create_relin_keys(bool save_seed, size_t max_power = 2, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     GaloisKeys create_galois_keys_from_elements(const std::vector<size_t>& galois_elements, bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
