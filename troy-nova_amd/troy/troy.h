@@ -219,6 +219,8 @@ public:
     size_t poly_modulus_degree() const { return poly_modulus_degree_; }
     const std::vector<Modulus>& coeff_modulus() const { return coeff_modulus_; }
     const Modulus& plain_modulus() const { return plain_modulus_; }
+    const Modulus& plain_modulus_host() const noexcept { return plain_modulus_; }                 // encryption_parameters.h:118-124 (the host copies; this mirror keeps
+    const std::vector<Modulus>& coeff_modulus_host() const noexcept { return coeff_modulus_; }    //  parameters on the host, device constants live in the troyn_plan)
     bool use_special_prime_for_encryption() const { return use_special_prime_for_encryption_; }
     const ParmsID& parms_id() const { return parms_id_; }
     // encryption_parameters.cu:53-112 (raw little-endian fields, no compression header)
@@ -296,6 +298,11 @@ public:
     }
     std::optional<ContextDataPointer> key_context_data() const noexcept { return get_context_data(key_parms_id_); }
     std::optional<ContextDataPointer> first_context_data() const noexcept { return get_context_data(first_parms_id_); }
+    // he_context.h:60-82: the same lookups without the optional (nullptr when the level does not exist)
+    ContextDataPointer get_context_data_pointer(const ParmsID& id) const noexcept { auto c = get_context_data(id); return c.has_value() ? c.value() : nullptr; }
+    ContextDataPointer key_context_data_pointer() const noexcept { return get_context_data_pointer(key_parms_id_); }
+    ContextDataPointer first_context_data_pointer() const noexcept { return get_context_data_pointer(first_parms_id_); }
+    ContextDataPointer last_context_data_pointer() const noexcept { return get_context_data_pointer(last_parms_id_); }
     std::optional<ContextDataPointer> last_context_data() const noexcept { return get_context_data(last_parms_id_); }
     SecurityLevel security_level() const noexcept { return security_level_; }
     bool using_keyswitching() const noexcept { return using_keyswitching_; }
@@ -871,6 +878,11 @@ public:
     // lwe_ciphertext.cu:9-60: the RLWE ciphertext (c0 as constant coefficient, c1) -- coefficient form
     Ciphertext assemble_lwe(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     static std::vector<Ciphertext> assemble_lwe_batched_new(const std::vector<const LWECiphertext*>& lwes, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static void assemble_lwe_batched(const std::vector<const LWECiphertext*>& source, const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) {
+        std::vector<Ciphertext> r = assemble_lwe_batched_new(source, pool);
+        if (r.size() != destination.size()) throw std::invalid_argument("[LWECiphertext::assemble_lwe_batched] Input and destination have different sizes.");
+        for (size_t i = 0; i < r.size(); i++) *destination[i] = std::move(r[i]);
+    }
 private:
     size_t coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
     utils::DynamicArray c0_, c1_;
