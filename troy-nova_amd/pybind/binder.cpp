@@ -79,10 +79,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("__repr__", [](const Modulus& s) { return "Modulus(" + std::to_string(s.value()) + ")"; });
     py::class_<CoeffModulus>(m, "CoeffModulus")
         .def_static("max_bit_count", &CoeffModulus::max_bit_count, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128)
-        .def_static("create", &CoeffModulus::create, py::arg("poly_modulus_degree"), py::arg("bit_sizes"))
-        .def_static("bfv_default", [](size_t n, SecurityLevel sec) { return CoeffModulus::bfv_default(n, sec); }, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128);
+        .def_static("create", &CoeffModulus::create_vector, py::arg("poly_modulus_degree"), py::arg("bit_sizes"))
+        .def_static("bfv_default", [](size_t n, SecurityLevel sec) { return CoeffModulus::bfv_default_vector(n, sec); }, py::arg("poly_modulus_degree"), py::arg("sec_level") = SecurityLevel::Classical128);
     py::class_<PlainModulus>(m, "PlainModulus").def_static("batching", &PlainModulus::batching, py::arg("poly_modulus_degree"), py::arg("bit_size"))
-        .def_static("batching_multiple", [](size_t n, const std::vector<size_t>& bits) { return PlainModulus::batching_multiple(n, bits); }, py::arg("poly_modulus_degree"), py::arg("bit_sizes"));
+        .def_static("batching_multiple", [](size_t n, const std::vector<size_t>& bits) { return PlainModulus::batching_multiple(n, bits).to_vector(); }, py::arg("poly_modulus_degree"), py::arg("bit_sizes"));
 
     py::class_<ParmsID>(m, "ParmsID")
         .def("is_zero", &ParmsID::is_zero).def_static("zero", []() { return parms_id_zero; })
@@ -94,11 +94,12 @@ PYBIND11_MODULE(pytroy_raw, m) {
     py::class_<EncryptionParameters>(m, "EncryptionParameters")
         .def(py::init<SchemeType>(), py::arg("scheme"))
         .def("set_poly_modulus_degree", &EncryptionParameters::set_poly_modulus_degree)
-        .def("set_coeff_modulus", &EncryptionParameters::set_coeff_modulus)
+        .def("set_coeff_modulus", [](EncryptionParameters& s, const std::vector<Modulus>& q) { s.set_coeff_modulus(q); })
+        .def("set_coeff_modulus", [](EncryptionParameters& s, const std::vector<uint64_t>& q) { s.set_coeff_modulus(q); })
         .def("set_plain_modulus", py::overload_cast<const Modulus&>(&EncryptionParameters::set_plain_modulus))
         .def("set_plain_modulus", py::overload_cast<uint64_t>(&EncryptionParameters::set_plain_modulus))
         .def("scheme", &EncryptionParameters::scheme).def("poly_modulus_degree", &EncryptionParameters::poly_modulus_degree)
-        .def("coeff_modulus", &EncryptionParameters::coeff_modulus).def("plain_modulus", &EncryptionParameters::plain_modulus)
+        .def("coeff_modulus", [](const EncryptionParameters& s) { return s.coeff_modulus().to_vector(); }).def("plain_modulus", &EncryptionParameters::plain_modulus)
         .def("parms_id", &EncryptionParameters::parms_id)
         .def("pool", [](const EncryptionParameters&) { return MemoryPool::GlobalPool(); }).def("device_index", [](const EncryptionParameters&) { return size_t(0); })
         .def("save", [](const EncryptionParameters& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })

@@ -5,6 +5,8 @@
 // Device work goes through the C-ABI (include/troyn.h); nothing here computes ring arithmetic on the host.
 #include <hip/hip_runtime.h>
 
+#include <sstream>
+
 #include "troy.h"
 
 namespace troy {
@@ -73,6 +75,21 @@ utils::DynamicArray Plaintext::expanded_rns(size_t L, size_t n, MemoryPoolHandle
                                     hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
     }
     return full;
+}
+
+std::string Plaintext::to_string() const {
+    if (is_ntt_form_ || parms_id_ != parms_id_zero) throw std::invalid_argument("cannot convert NTT or RNS plaintext to string");
+    const std::vector<uint64_t> c = data_.to_vector();
+    std::ostringstream out;
+    bool empty = true;
+    for (size_t k = std::min(coeff_count_, c.size()); k-- > 0;) {
+        if (c[k] == 0) continue;
+        if (!empty) out << " + ";
+        out << std::hex << std::uppercase << c[k] << std::dec;
+        if (k) out << "x^" << k;
+        empty = false;
+    }
+    return empty ? std::string("0") : out.str();
 }
 
 bool Ciphertext::is_transparent() const {

@@ -315,7 +315,7 @@ size_t CoeffModulus::max_bit_count(size_t n, SecurityLevel sec) {
     return it->second[static_cast<size_t>(sec) - 1];
 }
 
-std::vector<Modulus> CoeffModulus::bfv_default(size_t poly_modulus_degree, SecurityLevel sec_level) {
+std::vector<Modulus> CoeffModulus::bfv_default_vector(size_t poly_modulus_degree, SecurityLevel sec_level) {
     // coeff_modulus.cu:6-63.  The chains are SEAL's published defaults (data, not logic): rows = (security level, degree).
     struct Row { SecurityLevel sec; size_t n; std::vector<uint64_t> q; };
     static const std::vector<Row> table = {
@@ -353,7 +353,7 @@ std::vector<Modulus> CoeffModulus::bfv_default(size_t poly_modulus_degree, Secur
     throw std::invalid_argument("[CoeffModulus::bfv_default_vector] Invalid poly_modulus_degree or sec_level.");
 }
 
-std::vector<Modulus> CoeffModulus::create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
+std::vector<Modulus> CoeffModulus::create_vector(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
     // coeff_modulus.cu:65-108 -- prime search lives in libtroyn's host helpers
     std::vector<uint64_t> out(bit_sizes.size());
     int rc = troyn_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), bit_sizes.size(), out.data());

@@ -20,6 +20,7 @@
 //   * multiply / relinearize / rescale also exist as *_batched (the reference lists them as
 //     "not implemented yet", test/bench/he_operations.cpp:119-135).
 #pragma once
+#include <algorithm>
 #include <complex>
 #include <cstdint>
 #include <cstring>
@@ -34,6 +35,7 @@
 #include <vector>
 
 #include "../../include/troyn.h"
+#include "timer.h"
 
 namespace troy {
 
@@ -41,6 +43,65 @@ enum class SchemeType : uint8_t { Nil = 0, BFV = 1, CKKS = 2, BGV = 3 };
 // utils/compression.h:15-18.  Only Nil is available (the reference's zstd submodule is not vendored either).
 enum class CompressionMode : uint8_t { Nil = 0, Zstd = 1 };
 enum class SecurityLevel : uint8_t { Nil = 0, Classical128 = 1, Classical192 = 2, Classical256 = 3 };
+namespace utils { namespace compression {
+inline bool available(CompressionMode mode) { return mode == CompressionMode::Nil; }         // utils/compression.h:46-52 (zstd is not part of this image)
+}}  // namespace utils::compression
+
+// utils/box.h: the non-owning (pointer, length) views and the owning array the reference's public API hands out for HOST-side
+// parameter data (moduli lists, ...).  Device payloads of this mirror are DynamicArray / raw device pointers; these types cover what
+// user programs touch: size(), operator[], iteration, to_vector(), Array::copy_from_slice.
+namespace utils {
+class MemoryPool;
+template <typename T>
+class ConstSlice {
+public:
+    ConstSlice(const T* ptr, size_t len, bool on_device = false, std::nullptr_t = nullptr) : ptr_(ptr), len_(len), device_(on_device) {}
+    ConstSlice(const std::vector<T>& v) : ptr_(v.data()), len_(v.size()), device_(false) {}      // NOLINT: implicit by design
+    size_t size() const noexcept { return len_; }
+    bool empty() const noexcept { return len_ == 0; }
+    bool on_device() const noexcept { return device_; }
+    const T* raw_pointer() const noexcept { return ptr_; }
+    const T& operator[](size_t i) const { return ptr_[i]; }
+    const T* begin() const noexcept { return ptr_; }
+    const T* end() const noexcept { return ptr_ + len_; }
+    ConstSlice const_slice(size_t begin, size_t end) const { return ConstSlice(ptr_ + begin, end - begin, device_); }
+    std::vector<T> to_vector() const { return std::vector<T>(ptr_, ptr_ + len_); }
+    operator std::vector<T>() const { return to_vector(); }                                       // NOLINT
+private:
+    const T* ptr_;
+    size_t len_;
+    bool device_;
+};
+
+template <typename T>
+class Array {
+public:
+    Array() = default;
+    Array(std::vector<T> values) : data_(std::move(values)) {}                                    // NOLINT: implicit by design
+    operator std::vector<T>() const { return data_; }                                            // NOLINT
+    typename std::vector<T>::const_iterator begin() const noexcept { return data_.begin(); }
+    typename std::vector<T>::const_iterator end() const noexcept { return data_.end(); }
+    Array(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) : data_(count) {
+        (void)pool;
+        if (on_device) throw std::invalid_argument("[Array::Array] device arrays of this mirror are utils::DynamicArray (uint64_t payloads); Array<T> holds host-side data.");
+    }
+    size_t size() const noexcept { return data_.size(); }
+    bool on_device() const noexcept { return false; }
+    T& operator[](size_t i) { return data_[i]; }
+    const T& operator[](size_t i) const { return data_[i]; }
+    void copy_from_slice(ConstSlice<T> source) {
+        if (source.size() != data_.size()) throw std::invalid_argument("[Array::copy_from_slice] Slice size does not match the array size.");
+        std::copy(source.begin(), source.end(), data_.begin());
+    }
+    static Array create_and_copy_from_slice(ConstSlice<T> source, bool on_device = false, std::shared_ptr<MemoryPool> pool = nullptr) { Array a(source.size(), on_device, pool); a.copy_from_slice(source); return a; }
+    ConstSlice<T> const_reference() const { return ConstSlice<T>(data_.data(), data_.size(), false); }
+    std::vector<T> to_vector() const { return data_; }
+    T* raw_pointer() { return data_.data(); }
+    const T* raw_pointer() const { return data_.data(); }
+private:
+    std::vector<T> data_;
+};
+}  // namespace utils
 
 // ----------------------------------------------------------------------------------------------
 // utils: device runtime shim + memory pool (src/kernel_provider.h, src/utils/memory_pool.h)
@@ -175,15 +236,20 @@ private:
 class CoeffModulus {
 public:
     static size_t max_bit_count(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
-    static std::vector<Modulus> create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes);
+    static std::vector<Modulus> create_vector(size_t poly_modulus_degree, std::vector<size_t> bit_sizes);
+    // coeff_modulus.h: the reference returns utils::Array<Modulus> (callers use .size(), [i], .to_vector(), or pass it to set_coeff_modulus)
+    static utils::Array<Modulus> create(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) { return utils::Array<Modulus>(create_vector(poly_modulus_degree, std::move(bit_sizes))); }
     // coeff_modulus.cu:6-63: SEAL's default BFV chains per degree and security level
-    static std::vector<Modulus> bfv_default(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
+    static std::vector<Modulus> bfv_default_vector(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128);
+    static utils::Array<Modulus> bfv_default(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::Classical128) {
+        return utils::Array<Modulus>(bfv_default_vector(poly_modulus_degree, sec_level));
+    }
 };
 
 class PlainModulus {
 public:
     static Modulus batching(size_t poly_modulus_degree, size_t bit_size);
-    static std::vector<Modulus> batching_multiple(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
+    static utils::Array<Modulus> batching_multiple(size_t poly_modulus_degree, std::vector<size_t> bit_sizes) {
         return CoeffModulus::create(poly_modulus_degree, std::move(bit_sizes));
     }
 };
@@ -202,6 +268,8 @@ struct ParmsID {
     uint64_t v[4] = {0, 0, 0, 0};
     bool operator==(const ParmsID& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
     bool operator!=(const ParmsID& o) const { return !(*this == o); }
+    uint64_t operator[](size_t i) const { return v[i]; }                  // ParmsID is std::array<uint64_t, 4>-like in the reference
+    uint64_t& operator[](size_t i) { return v[i]; }
     bool is_zero() const { return v[0] == 0 && v[1] == 0 && v[2] == 0 && v[3] == 0; }
 };
 extern const ParmsID parms_id_zero;
@@ -212,15 +280,18 @@ public:
     explicit EncryptionParameters(SchemeType scheme = SchemeType::Nil) : scheme_(scheme) { compute_parms_id(); }
     void set_poly_modulus_degree(size_t n) { poly_modulus_degree_ = n; compute_parms_id(); }
     void set_coeff_modulus(const std::vector<Modulus>& q) { coeff_modulus_ = q; compute_parms_id(); }
+    void set_coeff_modulus(utils::ConstSlice<Modulus> q) { coeff_modulus_ = q.to_vector(); compute_parms_id(); }
+    void set_coeff_modulus(const utils::Array<Modulus>& q) { coeff_modulus_ = q.to_vector(); compute_parms_id(); }
+    void set_coeff_modulus(const std::vector<uint64_t>& q) { coeff_modulus_.clear(); for (uint64_t v : q) coeff_modulus_.push_back(Modulus(v)); compute_parms_id(); }
     void set_plain_modulus(const Modulus& t) { plain_modulus_ = t; compute_parms_id(); }
     void set_plain_modulus(uint64_t t) { set_plain_modulus(Modulus(t)); }
     void set_use_special_prime_for_encryption(bool f) { use_special_prime_for_encryption_ = f; }
     SchemeType scheme() const { return scheme_; }
     size_t poly_modulus_degree() const { return poly_modulus_degree_; }
-    const std::vector<Modulus>& coeff_modulus() const { return coeff_modulus_; }
+    utils::ConstSlice<Modulus> coeff_modulus() const { return utils::ConstSlice<Modulus>(coeff_modulus_); }
     const Modulus& plain_modulus() const { return plain_modulus_; }
     const Modulus& plain_modulus_host() const noexcept { return plain_modulus_; }                 // encryption_parameters.h:118-124 (the host copies; this mirror keeps
-    const std::vector<Modulus>& coeff_modulus_host() const noexcept { return coeff_modulus_; }    //  parameters on the host, device constants live in the troyn_plan)
+    utils::ConstSlice<Modulus> coeff_modulus_host() const noexcept { return utils::ConstSlice<Modulus>(coeff_modulus_); }    //  parameters on the host, device constants live in the troyn_plan)
     bool use_special_prime_for_encryption() const { return use_special_prime_for_encryption_; }
     const ParmsID& parms_id() const { return parms_id_; }
     // encryption_parameters.cu:53-112 (raw little-endian fields, no compression header)
@@ -437,6 +508,7 @@ public:
     Plaintext to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p = *this; p.to_device_inplace(pool); return p; }
     Plaintext to_host() const { Plaintext p = *this; p.to_host_inplace(); return p; }
     MemoryPoolHandle pool() const { return data_.pool(); }
+    std::string to_string() const;                        // plaintext.h:225-232: "7FFx^3 + 1x^1 + 3" (hexadecimal coefficients, highest degree first)
     // a full-size ([L][N], zero-padded) device copy of an RNS plaintext that keeps only coeff_count coefficients per limb
     utils::DynamicArray expanded_rns(size_t coeff_modulus_size, size_t poly_modulus_degree, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
 private:
@@ -763,6 +835,7 @@ public:
     constexpr size_t row_count() const noexcept { return 2; }
     size_t column_count() const noexcept { return slots_ / 2; }
     bool simd_encoding_supported() const { return !matrix_reps_index_map_.empty(); }
+    void to_device_inplace(MemoryPoolHandle = MemoryPool::GlobalPool()) {}      // the index map stays on the host; encode / decode stage through the device themselves
     // batch_encoder.cu:558-662: a mod-t plaintext to / from its RNS form at a level.  scale_up = round(q/t * m) (what encryption adds to c0),
     // centralize = the centred lift (what multiply_plain uses); scale_down / decentralize are their inverses (the final steps of BFV /
     // BGV decryption).  The RNS plaintexts keep only the source's coeff_count coefficients per limb ("partial").
@@ -1005,6 +1078,10 @@ public:
     void negacyclic_shift_inplace_batched(const Ciphers& e, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { negacyclic_shift_batched(batch_utils::pcollect_const_pointer(e), shift, e, pool); }
     std::vector<Ciphertext> negacyclic_shift_new_batched(const ConstCiphers& e, size_t shift, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<Ciphertext> d(e.size()); negacyclic_shift_batched(e, shift, batch_utils::collect_pointer(d), pool); return d; }
     void divide_by_poly_modulus_degree_inplace_batched(const Ciphers& encrypted, uint64_t mul = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    Ciphertext pack_lwe_ciphertexts_new(const std::vector<LWECiphertext>& lwes, const GaloisKeys& automorphism_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
+                                        bool apply_field_trace = true) const {         // evaluator.h:970-973, kept by the reference for older callers
+        return pack_lwe_ciphertexts_new(batch_utils::collect_const_pointer(lwes), automorphism_keys, pool, apply_field_trace);
+    }
     void pack_lwe_ciphertexts(const std::vector<const LWECiphertext*>& lwes, const GaloisKeys& automorphism_keys, Ciphertext& output, MemoryPoolHandle pool = MemoryPool::GlobalPool(),
                               bool apply_field_trace = true) const { output = pack_lwe_ciphertexts_new(lwes, automorphism_keys, pool, apply_field_trace); }
     void pack_lwe_ciphertexts_batched(const std::vector<std::vector<const LWECiphertext*>>& lwe_groups, const GaloisKeys& automorphism_keys, const Ciphers& output,
