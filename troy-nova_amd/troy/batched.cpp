@@ -327,6 +327,35 @@ void Evaluator::multiply_plain_batched(const std::vector<const Ciphertext*>& enc
         for (size_t i = 0; i < tmp.size(); i++) *destination[i] = std::move(tmp[i]);
         return;
     }
+    // evaluator_multiply_plain.cu:70-194 (multiply_plain_normal_batched): coefficient-form ciphertexts times plaintexts modulo t (BFV) --
+    // the showcase of examples/15_batched_operation.cu.  One gather, one centralize launch and one NTT launch for the plaintexts, one
+    // NTT launch for the ciphertexts, one product launch, one inverse NTT launch.
+    bool normal = encrypted.size() >= BATCH_OP_THRESHOLD && distinct && uniform(encrypted) && !encrypted[0]->is_ntt_form() &&
+                  context_->key_context_data().value()->parms().scheme() == SchemeType::BFV;
+    for (size_t i = 0; i < plain.size() && normal; i++) normal = plain[i]->parms_id() == parms_id_zero && !plain[i]->is_ntt_form() && plain[i]->on_device();
+    if (normal) {
+        Ciphertext proto;
+        multiply_plain(*encrypted[0], *plain[0], proto, pool);           // every check of the per-object form; fixes shape and metadata
+        const size_t count = encrypted.size(), n = proto.poly_modulus_degree(), pcnt = proto.polynomial_count();
+        const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
+        const troyn_plan* plan = context_->plan();
+        const uint64_t t = context_->first_context_data().value()->parms().plain_modulus().value();
+        utils::DynamicArray staged(0, true, pool), plains(count * n, true, pool), lifted(count * L * n, true, pool);
+        const uint64_t* in = contiguous(encrypted, staged, pool);
+        plains.set_zero();
+        for (size_t i = 0; i < count; i++) {
+            if (plain[i]->coeff_count() > n) throw std::invalid_argument("[scaling_variant::centralize] plain_coeff_count exceeds the polynomial degree.");
+            hip_ok(hipMemcpyAsync(plains.raw_pointer() + i * n, plain[i]->poly(), plain[i]->coeff_count() * 8, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
+        }
+        auto block = result_block(proto, count, pool);
+        troyn_check_public(troyn_plain_centralize(plan, L, t, plains.raw_pointer(), n, n, lifted.raw_pointer(), count, stream()));
+        troyn_check_public(troyn_ntt(plan, 0, lifted.raw_pointer(), lifted.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
+        troyn_check_public(troyn_ntt(plan, 0, in, block->raw_pointer(), count, pcnt, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
+        troyn_check_public(troyn_dyadic_broadcast_product(plan, 0, L, block->raw_pointer(), pcnt, lifted.raw_pointer(), static_cast<size_t>(L) * n, block->raw_pointer(), count, stream()));
+        troyn_check_public(troyn_ntt(plan, 1, block->raw_pointer(), block->raw_pointer(), count, pcnt, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
+        assign_views(proto, block, destination);
+        return;
+    }
     for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; multiply_plain(*encrypted[i], *plain[i], out, pool); *destination[i] = std::move(out); }
 }
 
