@@ -7,7 +7,8 @@
 #   * the examples include "examples.h", which includes "../src/troy.h": the sources are fed to the compiler on stdin so that the
 #     include resolves to a generated header (this mirror's headers + the helper functions of the reference's examples.h) in the
 #     scratch build directory; the generated header is not kept.
-#   * 30_issue_multithread.cu includes the reference's internal utils/box.h directly and is replaced by a stub.
+#   * 30_issue_multithread.cu is a CUDA programming demonstration (its own __global__ kernels and <<<>>> launches on device arrays of
+#     the reference's internal utils/box.h), not a user of the library API; it is replaced by a stub.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 REF=${REF:-/root/reference}
@@ -30,7 +31,7 @@ for f in "$REF"/examples/*.cu; do
   g++ $CXXFLAGS -x c++ -c -o "$BUILD/$b.o" - < "$f"
   OBJS="$OBJS $BUILD/$b.o"
 done
-printf '#include <iostream>\nvoid example_issue_multithread() { std::cout << "skipped: includes the reference tree'"'"'s internal utils/box.h" << std::endl; }\n' > "$BUILD/stub.cpp"
+printf '#include <iostream>\nvoid example_issue_multithread() { std::cout << "skipped: a CUDA kernel-launch demonstration, not a user of the library API" << std::endl; }\n' > "$BUILD/stub.cpp"
 g++ $CXXFLAGS -c -o "$BUILD/stub.o" "$BUILD/stub.cpp"
 mkdir -p "$ROOT/oracle/_ref"
 g++ -o "$ROOT/oracle/_ref/ref_examples" $OBJS "$BUILD/stub.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
