@@ -20,7 +20,17 @@ out = {}
 for f, classes in sorted(CLASSES.items()):
     src = open(os.path.join(REF, f + ".cu")).read()
     names = sorted(set(re.findall(r'\.def(?:_static)?\(\s*"([A-Za-z0-9_]+)"', src)))
-    out[f] = {"classes": classes, "names": names}       # a file that registers several classes: every name must exist on one of them
+    # keyword-argument lists, one per overload that names its arguments (py::arg("...") and the header's argument macros)
+    macros = {"MEMORY_POOL_ARGUMENT": "pool", "COMPRESSION_MODE_ARGUMENT": "mode", "OPTIONAL_PARMS_ID_ARGUMENT": "parms_id"}
+    signatures = {}
+    for mm in re.finditer(r'\.def(?:_static)?\(\s*"([A-Za-z0-9_]+)"(.*?)(?=\n\s*\.def|\n\s*;)', src, re.S):
+        name, body = mm.group(1), mm.group(2)
+        tail = body[body.rfind("}") + 1:] if "}" in body else body
+        args = [t.group(1) or macros[t.group(2)]
+                for t in re.finditer(r'py::arg\("([a-z_0-9]+)"\)|(MEMORY_POOL_ARGUMENT|COMPRESSION_MODE_ARGUMENT|OPTIONAL_PARMS_ID_ARGUMENT)', tail)]
+        if args and args not in signatures.setdefault(name, []):
+            signatures[name].append(args)
+    out[f] = {"classes": classes, "names": names, "signatures": signatures}   # several classes per file: a name must exist on one of them
 out["binder"]["classes"] = ["<module>"]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pytroy_surface.json"), "w"), indent=1, sort_keys=True)
 print(sum(len(v["names"]) for v in out.values()), "names")

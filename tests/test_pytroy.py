@@ -65,6 +65,23 @@ def test_surface_is_complete(pytroy):
         missing += ["%s.%s" % (group, n) for n in entry["names"] if n not in have]
     assert not missing, missing
     assert sum(len(e["names"]) for e in surface.values()) > 400
+    # keyword names and their order: every argument list the reference declares is a prefix of one of the overloads here
+    import re
+    wrong, checked = [], 0
+    for group, entry in surface.items():
+        for name, overloads in entry.get("signatures", {}).items():
+            mine = []
+            for cls in entry["classes"]:
+                fn = getattr(raw, name, None) if cls == "<module>" else getattr(getattr(raw, cls), name, None)
+                for sig in re.findall(r"%s\((.*?)\) ->" % name, (getattr(fn, "__doc__", "") or "")):
+                    args = [a.split(":")[0].strip() for a in re.split(r",\s*(?![^\[]*\])", sig) if a.strip()]
+                    mine.append([a for a in args if a != "self"])
+            for want in overloads:
+                checked += 1
+                if not any(have[:len(want)] == want for have in mine):
+                    wrong.append((group, name, want, mine[:3]))
+    assert not wrong, wrong
+    assert checked > 200
 
 
 @pytest.mark.gpu
@@ -293,7 +310,7 @@ def test_wider_surface_in_python(pytroy, dev):
     # save_terms / load_terms: only the listed coefficients of c0 travel
     terms = [0, 5, 17, 99]
     blob = ca.save_terms(ctx, terms)
-    assert len(blob) <= ca.serialized_terms_size_upperbound(ctx, len(terms)) and len(blob) < len(ca.save(ctx))
+    assert len(blob) <= ca.serialized_terms_size_upperbound(ctx, terms) and len(blob) < len(ca.save(ctx))
     back = encoder.decode_polynomial_new(decryptor.decrypt_new(pytroy.Ciphertext.load_terms_new(blob, ctx, terms)))
     assert [back[i] for i in terms] == [msg[i] for i in terms]
     # the plaintext automorphism against the one under encryption

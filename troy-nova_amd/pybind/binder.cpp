@@ -23,6 +23,7 @@ using namespace troy;
 using PoolArg = std::optional<MemoryPoolHandle>;
 static MemoryPoolHandle P(const PoolArg& p) { return p.has_value() ? p.value() : MemoryPool::GlobalPool(); }
 #define POOL py::arg("pool") = std::nullopt
+#define MODE py::arg("mode") = CompressionMode::Nil
 
 // unary / binary / keyed evaluator operations come in (x, x_inplace, x_new) triples with identical shapes
 #define EV_UNARY(cls, name)                                                                                                  \
@@ -61,6 +62,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     m.def("destroy_memory_pool", []() { MemoryPool::Destroy(); });
 
     py::enum_<SchemeType>(m, "SchemeType").value("Nil", SchemeType::Nil).value("BFV", SchemeType::BFV).value("CKKS", SchemeType::CKKS).value("BGV", SchemeType::BGV);
+    py::enum_<CompressionMode>(m, "CompressionMode").value("Nil", CompressionMode::Nil).value("Zstd", CompressionMode::Zstd);
     py::enum_<SecurityLevel>(m, "SecurityLevel").value("Nil", SecurityLevel::Nil).value("Classical128", SecurityLevel::Classical128)
         .value("Classical192", SecurityLevel::Classical192).value("Classical256", SecurityLevel::Classical256);
 
@@ -74,7 +76,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     py::class_<Modulus>(m, "Modulus")
         .def(py::init<uint64_t>(), py::arg("value") = 0)
         .def("value", &Modulus::value).def("bit_count", &Modulus::bit_count).def("is_prime", &Modulus::is_prime)
-        .def("is_zero", &Modulus::is_zero).def("reduce", &Modulus::reduce).def("reduce_mul", &Modulus::reduce_mul_uint64)
+        .def("is_zero", &Modulus::is_zero).def("reduce", &Modulus::reduce, py::arg("input_uint64")).def("reduce_mul", &Modulus::reduce_mul_uint64, py::arg("a"), py::arg("b"))
         .def("__str__", [](const Modulus& s) { return std::to_string(s.value()); })
         .def("__repr__", [](const Modulus& s) { return "Modulus(" + std::to_string(s.value()) + ")"; });
     py::class_<CoeffModulus>(m, "CoeffModulus")
@@ -102,10 +104,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("coeff_modulus", [](const EncryptionParameters& s) { return s.coeff_modulus().to_vector(); }).def("plain_modulus", &EncryptionParameters::plain_modulus)
         .def("parms_id", &EncryptionParameters::parms_id)
         .def("pool", [](const EncryptionParameters&) { return MemoryPool::GlobalPool(); }).def("device_index", [](const EncryptionParameters&) { return size_t(0); })
-        .def("save", [](const EncryptionParameters& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
-        .def("load", [](EncryptionParameters& s, const py::bytes& b) { std::istringstream is{std::string(b)}; s.load(is); }, py::arg("data"))
-        .def_static("load_new", [](const py::bytes& b) { std::istringstream is{std::string(b)}; EncryptionParameters e(SchemeType::Nil); e.load(is); return e; }, py::arg("data"))
-        .def("serialized_size_upperbound", [](const EncryptionParameters& s) { std::ostringstream os; return s.save(os); });
+        .def("save", [](const EncryptionParameters& s, CompressionMode mode) { if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::compress] Zstd is not available in this build."); return to_bytes([&](std::ostream& os) { s.save(os); }); }, MODE)
+        .def("load", [](EncryptionParameters& s, const py::bytes& b) { std::istringstream is{std::string(b)}; s.load(is); }, py::arg("str"))
+        .def_static("load_new", [](const py::bytes& b) { std::istringstream is{std::string(b)}; EncryptionParameters e(SchemeType::Nil); e.load(is); return e; }, py::arg("str"))
+        .def("serialized_size_upperbound", [](const EncryptionParameters& s, CompressionMode) { std::ostringstream os; return s.save(os); }, MODE);
 
     using CDP = std::shared_ptr<ContextData>;
     auto unconst = [](const std::optional<ContextDataPointer>& c) -> std::optional<CDP> {
@@ -147,10 +149,10 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("set_parms_id", [](Plaintext& s, const ParmsID& id) { s.parms_id() = id; }).def("set_coeff_count", [](Plaintext& s, size_t c) { s.coeff_count() = c; })
         .def("set_is_ntt_form", [](Plaintext& s, bool f) { s.is_ntt_form() = f; }).def("resize", &Plaintext::resize)
         .def("coeff_modulus_size", [](const Plaintext& s) { return s.coeff_modulus_size(); }).def("poly_modulus_degree", [](const Plaintext& s) { return s.poly_modulus_degree(); })
-        .def("serialized_size_upperbound", [](const Plaintext& s) { return s.serialized_size_upperbound(); })
-        .def("save", [](const Plaintext& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
-        .def("load", [](Plaintext& s, const std::string& b, PoolArg p) { std::istringstream is(b); s.load(is, P(p)); }, py::arg("bytes"), POOL)
-        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return Plaintext::load_new(is, P(p)); }, py::arg("bytes"), POOL);
+        .def("serialized_size_upperbound", [](const Plaintext& s, CompressionMode mode) { return s.serialized_size_upperbound(mode); }, MODE)
+        .def("save", [](const Plaintext& s, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, mode); }); }, MODE)
+        .def("load", [](Plaintext& s, const std::string& b, PoolArg p) { std::istringstream is(b); s.load(is, P(p)); }, py::arg("str"), POOL)
+        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return Plaintext::load_new(is, P(p)); }, py::arg("str"), POOL);
 
     py::class_<Ciphertext>(m, "Ciphertext")
         .def(py::init<>())
@@ -174,19 +176,19 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("correction_factor", [](const Ciphertext& s) { return s.correction_factor(); }).def("set_correction_factor", [](Ciphertext& s, uint64_t f) { s.correction_factor() = f; })
         .def("seed", [](const Ciphertext& s) { return s.seed(); }).def("set_seed", [](Ciphertext& s, uint64_t v) { s.seed() = v; })
         .def("is_transparent", &Ciphertext::is_transparent)
-        .def("serialized_size_upperbound", [](const Ciphertext& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
-        .def("save_terms", [](const Ciphertext& s, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
-            return to_bytes([&](std::ostream& os) { s.save_terms(os, c, terms, P(p)); }); }, py::arg("context"), py::arg("terms"), POOL)
+        .def("serialized_size_upperbound", [](const Ciphertext& s, HeContextPointer c, CompressionMode mode) { return s.serialized_size_upperbound(c, mode); }, py::arg("context"), MODE)
+        .def("save_terms", [](const Ciphertext& s, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p, CompressionMode mode) {
+            return to_bytes([&](std::ostream& os) { s.save_terms(os, c, terms, P(p), mode); }); }, py::arg("context"), py::arg("terms"), POOL, MODE)
         .def("load_terms", [](Ciphertext& s, const py::bytes& b, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
-            std::istringstream is{std::string(b)}; s.load_terms(is, c, terms, P(p)); }, py::arg("data"), py::arg("context"), py::arg("terms"), POOL)
+            std::istringstream is{std::string(b)}; s.load_terms(is, c, terms, P(p)); }, py::arg("str"), py::arg("context"), py::arg("terms"), POOL)
         .def_static("load_terms_new", [](const py::bytes& b, HeContextPointer c, const std::vector<size_t>& terms, PoolArg p) {
-            std::istringstream is{std::string(b)}; return Ciphertext::load_terms_new(is, c, terms, P(p)); }, py::arg("data"), py::arg("context"), py::arg("terms"), POOL)
-        .def("serialized_terms_size_upperbound", [](const Ciphertext& s, HeContextPointer c, size_t terms_count) { return s.serialized_terms_size_upperbound(c, terms_count); },
-             py::arg("context"), py::arg("terms_count"))
-        .def("save", [](const Ciphertext& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
-        .def("load", [](Ciphertext& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL)
+            std::istringstream is{std::string(b)}; return Ciphertext::load_terms_new(is, c, terms, P(p)); }, py::arg("str"), py::arg("context"), py::arg("terms"), POOL)
+        .def("serialized_terms_size_upperbound", [](const Ciphertext& s, HeContextPointer c, const std::vector<size_t>& terms, CompressionMode mode) {
+            return s.serialized_terms_size_upperbound(c, terms.size(), mode); }, py::arg("context"), py::arg("terms"), MODE)
+        .def("save", [](const Ciphertext& s, HeContextPointer c, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, c, mode); }); }, py::arg("context"), MODE)
+        .def("load", [](Ciphertext& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("str"), py::arg("context"), POOL)
         .def_static("load_new", [](const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); return Ciphertext::load_new(is, c, P(p)); },
-                    py::arg("bytes"), py::arg("context"), POOL);
+                    py::arg("str"), py::arg("context"), POOL);
 
     py::class_<SecretKey>(m, "SecretKey").def(py::init<>()).def(py::init([](const Plaintext& p) { return SecretKey(Plaintext(p)); })).def("on_device", &SecretKey::on_device)
         .def("to_device_inplace", [](SecretKey& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &SecretKey::to_host_inplace)
@@ -194,11 +196,11 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("parms_id", [](const SecretKey& s) { return s.parms_id(); }).def("set_parms_id", [](SecretKey& s, const ParmsID& id) { s.parms_id() = id; })
         .def("pool", [](const SecretKey& s) { return s.as_plaintext().pool(); }).def("device_index", [](const SecretKey& s) { return s.as_plaintext().pool() ? s.as_plaintext().pool()->get_device() : size_t(0); })
         .def("as_plaintext", [](const SecretKey& s) { return s.as_plaintext(); }).def("get_plaintext", [](const SecretKey& s, PoolArg p) { return s.as_plaintext().clone(P(p)); }, POOL)
-        .def("load", [](SecretKey& s, const py::bytes& b, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, P(p)); }, py::arg("data"), POOL)
-        .def("serialized_size_upperbound", [](const SecretKey& s) { return s.serialized_size_upperbound(); })
+        .def("load", [](SecretKey& s, const py::bytes& b, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, P(p)); }, py::arg("str"), POOL)
+        .def("serialized_size_upperbound", [](const SecretKey& s, CompressionMode mode) { return s.serialized_size_upperbound(mode); }, MODE)
         .def("clone", [](const SecretKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("data", [](const SecretKey& s) { return s.data().to_vector(); })
-        .def("save", [](const SecretKey& s) { return to_bytes([&](std::ostream& os) { s.save(os); }); })
-        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return SecretKey::load_new(is, P(p)); }, py::arg("bytes"), POOL);
+        .def("save", [](const SecretKey& s, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, mode); }); }, MODE)
+        .def_static("load_new", [](const std::string& b, PoolArg p) { std::istringstream is(b); return SecretKey::load_new(is, P(p)); }, py::arg("str"), POOL);
     py::class_<PublicKey>(m, "PublicKey").def(py::init<>()).def("on_device", &PublicKey::on_device)
         .def("to_device_inplace", [](PublicKey& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &PublicKey::to_host_inplace)
         .def("to_device", [](const PublicKey& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &PublicKey::to_host)
@@ -206,24 +208,24 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("pool", [](const PublicKey& s) { return s.as_ciphertext().pool(); }).def("device_index", [](const PublicKey& s) { return s.as_ciphertext().pool() ? s.as_ciphertext().pool()->get_device() : size_t(0); })
         .def("get_ciphertext", [](const PublicKey& s, PoolArg p) { return s.as_ciphertext().clone(P(p)); }, POOL)
         .def("contains_seed", &PublicKey::contains_seed).def("expand_seed", &PublicKey::expand_seed)
-        .def("save", [](const PublicKey& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
-        .def("load", [](PublicKey& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("data"), py::arg("context"), POOL)
+        .def("save", [](const PublicKey& s, HeContextPointer c, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, c, mode); }); }, py::arg("context"), MODE)
+        .def("load", [](PublicKey& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("str"), py::arg("context"), POOL)
         .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; return PublicKey::load_new(is, c, P(p)); },
-                    py::arg("data"), py::arg("context"), POOL)
-        .def("serialized_size_upperbound", [](const PublicKey& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+                    py::arg("str"), py::arg("context"), POOL)
+        .def("serialized_size_upperbound", [](const PublicKey& s, HeContextPointer c, CompressionMode mode) { return s.serialized_size_upperbound(c, mode); }, py::arg("context"), MODE)
         .def("clone", [](const PublicKey& s, PoolArg p) { return s.clone(P(p)); }, POOL).def("as_ciphertext", [](const PublicKey& s) { return s.as_ciphertext(); });
     py::class_<KSwitchKeys>(m, "KSwitchKeys").def(py::init<>()).def("on_device", &KSwitchKeys::on_device).def("parms_id", [](const KSwitchKeys& s) { return s.parms_id(); })
         .def("set_parms_id", [](KSwitchKeys& s, const ParmsID& id) { s.parms_id() = id; })
         .def("pool", &KSwitchKeys::pool).def("device_index", [](const KSwitchKeys& s) { return s.pool() ? s.pool()->get_device() : size_t(0); })
-        .def("serialized_size_upperbound", [](const KSwitchKeys& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+        .def("serialized_size_upperbound", [](const KSwitchKeys& s, HeContextPointer c, CompressionMode mode) { return s.serialized_size_upperbound(c, mode); }, py::arg("context"), MODE)
         .def("clone", [](const KSwitchKeys& s, PoolArg p) { return s.clone(P(p)); }, POOL)
         .def("to_device_inplace", [](KSwitchKeys& s, PoolArg p) { s.to_device_inplace(P(p)); }, POOL).def("to_host_inplace", &KSwitchKeys::to_host_inplace)
         .def("to_device", [](const KSwitchKeys& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &KSwitchKeys::to_host)
         .def("as_kswitch_keys", [](const KSwitchKeys& s) { return s.as_kswitch_keys(); }).def("get_kswitch_keys", [](const KSwitchKeys& s, PoolArg p) { return s.as_kswitch_keys().clone(P(p)); }, POOL)
         .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; KSwitchKeys k; k.load(is, c, P(p)); return k; },
-                    py::arg("data"), py::arg("context"), POOL)
-        .def("save", [](const KSwitchKeys& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
-        .def("load", [](KSwitchKeys& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("bytes"), py::arg("context"), POOL);
+                    py::arg("str"), py::arg("context"), POOL)
+        .def("save", [](const KSwitchKeys& s, HeContextPointer c, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, c, mode); }); }, py::arg("context"), MODE)
+        .def("load", [](KSwitchKeys& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("str"), py::arg("context"), POOL);
     py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key);
     py::class_<GaloisKeys, KSwitchKeys>(m, "GaloisKeys").def(py::init<>()).def("has_key", &GaloisKeys::has_key);
 
@@ -236,13 +238,18 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("create_relin_keys", [](const KeyGenerator& s, bool save_seed, size_t max_power, PoolArg p) { return s.create_relin_keys(save_seed, max_power, P(p)); },
              py::arg("save_seed"), py::arg("max_power") = 2, POOL)
         .def("create_keyswitching_key", [](const KeyGenerator& s, const SecretKey& nk, bool save_seed, PoolArg p) { return s.create_keyswitching_key(nk, save_seed, P(p)); },
-             py::arg("new_key"), py::arg("save_seed"), POOL)
+             py::arg("secret_key"), py::arg("save_seed"), POOL)
         .def("create_galois_keys", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_galois_keys(save_seed, P(p)); }, py::arg("save_seed"), POOL)
         .def("create_automorphism_keys", [](const KeyGenerator& s, bool save_seed, PoolArg p) { return s.create_automorphism_keys(save_seed, P(p)); }, py::arg("save_seed"), POOL)
         .def("create_galois_keys_from_steps", [](const KeyGenerator& s, const std::vector<int>& st, bool save_seed, PoolArg p) { return s.create_galois_keys_from_steps(st, save_seed, P(p)); },
-             py::arg("steps"), py::arg("save_seed"), POOL)
+             py::arg("galois_steps"), py::arg("save_seed"), POOL)
         .def("create_galois_keys_from_elements", [](const KeyGenerator& s, const std::vector<size_t>& el, bool save_seed, PoolArg p) { return s.create_galois_keys_from_elements(el, save_seed, P(p)); },
-             py::arg("galois_elements"), py::arg("save_seed"), POOL);
+             py::arg("galois_elts"), py::arg("save_seed"), POOL);
+
+    py::class_<utils::RandomGenerator>(m, "RandomGenerator")
+        .def(py::init([]() { return new utils::RandomGenerator(); })).def(py::init([](uint64_t seed) { return new utils::RandomGenerator(seed); }), py::arg("seed"))
+        .def("reset_seed", [](utils::RandomGenerator& s, uint64_t seed) { s.reset_seed(seed); }, py::arg("seed"))
+        .def("sample_uint64", &utils::RandomGenerator::sample_uint64);
 
     py::class_<Encryptor>(m, "Encryptor")
         .def(py::init<HeContextPointer>()).def("context", &Encryptor::context)
@@ -256,6 +263,23 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("encrypt_symmetric_new", [](const Encryptor& s, const Plaintext& pl, bool seed, PoolArg p) { return s.encrypt_symmetric_new(pl, seed, P(p)); },
              py::arg("plain"), py::arg("save_seed"), POOL)
         .def("on_device", [](const Encryptor& s) { return s.context()->on_device(); })
+        // the overloads with a caller-supplied generator (pybind/src/encryptor.cu: py::arg("rng") before the pool)
+        .def("encrypt_asymmetric", [](const Encryptor& s, const Plaintext& pl, Ciphertext& d, utils::RandomGenerator& rng, PoolArg p) { s.encrypt_asymmetric(pl, d, &rng, P(p)); },
+             py::arg("plain"), py::arg("destination"), py::arg("rng"), POOL)
+        .def("encrypt_asymmetric_new", [](const Encryptor& s, const Plaintext& pl, utils::RandomGenerator& rng, PoolArg p) { return s.encrypt_asymmetric_new(pl, &rng, P(p)); },
+             py::arg("plain"), py::arg("rng"), POOL)
+        .def("encrypt_symmetric", [](const Encryptor& s, const Plaintext& pl, bool seed, Ciphertext& d, utils::RandomGenerator& rng, PoolArg p) { s.encrypt_symmetric(pl, seed, d, &rng, P(p)); },
+             py::arg("plain"), py::arg("save_seed"), py::arg("destination"), py::arg("rng"), POOL)
+        .def("encrypt_symmetric_new", [](const Encryptor& s, const Plaintext& pl, bool seed, utils::RandomGenerator& rng, PoolArg p) { return s.encrypt_symmetric_new(pl, seed, &rng, P(p)); },
+             py::arg("plain"), py::arg("save_seed"), py::arg("rng"), POOL)
+        .def("encrypt_zero_asymmetric", [](const Encryptor& s, Ciphertext& d, std::optional<ParmsID> id, utils::RandomGenerator& rng, PoolArg p) { s.encrypt_zero_asymmetric(d, id, &rng, P(p)); },
+             py::arg("destination"), py::arg("parms_id"), py::arg("rng"), POOL)
+        .def("encrypt_zero_asymmetric_new", [](const Encryptor& s, std::optional<ParmsID> id, utils::RandomGenerator& rng, PoolArg p) { return s.encrypt_zero_asymmetric_new(id, &rng, P(p)); },
+             py::arg("parms_id"), py::arg("rng"), POOL)
+        .def("encrypt_zero_symmetric", [](const Encryptor& s, bool seed, Ciphertext& d, std::optional<ParmsID> id, utils::RandomGenerator& rng, PoolArg p) { s.encrypt_zero_symmetric(seed, d, id, &rng, P(p)); },
+             py::arg("save_seed"), py::arg("destination"), py::arg("parms_id"), py::arg("rng"), POOL)
+        .def("encrypt_zero_symmetric_new", [](const Encryptor& s, bool seed, std::optional<ParmsID> id, utils::RandomGenerator& rng, PoolArg p) { return s.encrypt_zero_symmetric_new(seed, id, &rng, P(p)); },
+             py::arg("save_seed"), py::arg("parms_id"), py::arg("rng"), POOL)
         .def("public_key", [](const Encryptor& s) { return s.public_key(); }).def("secret_key", [](const Encryptor& s) { return s.secret_key(); })
         .def("encrypt_zero_asymmetric", [](const Encryptor& s, Ciphertext& d, std::optional<ParmsID> id, PoolArg p) { d = s.encrypt_zero_asymmetric_new(id, P(p)); },
              py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
@@ -282,23 +306,23 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("on_device", &BatchEncoder::on_device).def("to_device_inplace", [](BatchEncoder&, PoolArg) {}, POOL)
         .def("encode_simd", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
         .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("source"), POOL)
         .def("encode_polynomial_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_polynomial_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("source"), POOL)
         .def("encode_polynomial", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode_polynomial(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
         .def("row_count", &BatchEncoder::row_count).def("column_count", &BatchEncoder::column_count).def("simd_encoding_supported", &BatchEncoder::simd_encoding_supported)
         .def("scale_up", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, std::optional<ParmsID> id, PoolArg p) { s.scale_up(a, d, id, P(p)); },
-             py::arg("plain"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
-        .def("scale_up_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.scale_up_inplace(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
-        .def("scale_up_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.scale_up_new(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
+             py::arg("source"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_up_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.scale_up_inplace(a, id, P(p)); }, py::arg("source"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_up_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.scale_up_new(a, id, P(p)); }, py::arg("source"), py::arg("parms_id") = std::nullopt, POOL)
         .def("centralize", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, std::optional<ParmsID> id, PoolArg p) { s.centralize(a, d, id, P(p)); },
-             py::arg("plain"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
-        .def("centralize_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.centralize_inplace(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
-        .def("centralize_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.centralize_new(a, id, P(p)); }, py::arg("plain"), py::arg("parms_id") = std::nullopt, POOL)
-        .def("scale_down", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, PoolArg p) { s.scale_down(a, d, P(p)); }, py::arg("plain"), py::arg("destination"), POOL)
-        .def("scale_down_inplace", [](const BatchEncoder& s, Plaintext& a, PoolArg p) { s.scale_down_inplace(a, P(p)); }, py::arg("plain"), POOL)
-        .def("scale_down_new", [](const BatchEncoder& s, const Plaintext& a, PoolArg p) { return s.scale_down_new(a, P(p)); }, py::arg("plain"), POOL)
-        .def("decentralize_new", [](const BatchEncoder& s, const Plaintext& a, uint64_t cf, PoolArg p) { return s.decentralize_new(a, cf, P(p)); }, py::arg("plain"), py::arg("correction_factor") = 1, POOL);
+             py::arg("source"), py::arg("destination"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("centralize_inplace", [](const BatchEncoder& s, Plaintext& a, std::optional<ParmsID> id, PoolArg p) { s.centralize_inplace(a, id, P(p)); }, py::arg("source"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("centralize_new", [](const BatchEncoder& s, const Plaintext& a, std::optional<ParmsID> id, PoolArg p) { return s.centralize_new(a, id, P(p)); }, py::arg("source"), py::arg("parms_id") = std::nullopt, POOL)
+        .def("scale_down", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, PoolArg p) { s.scale_down(a, d, P(p)); }, py::arg("source"), py::arg("destination"), POOL)
+        .def("scale_down_inplace", [](const BatchEncoder& s, Plaintext& a, PoolArg p) { s.scale_down_inplace(a, P(p)); }, py::arg("source"), POOL)
+        .def("scale_down_new", [](const BatchEncoder& s, const Plaintext& a, PoolArg p) { return s.scale_down_new(a, P(p)); }, py::arg("source"), POOL)
+        .def("decentralize_new", [](const BatchEncoder& s, const Plaintext& a, uint64_t cf, PoolArg p) { return s.decentralize_new(a, cf, P(p)); }, py::arg("source"), py::arg("correction_factor") = 1, POOL);
 
     py::class_<CKKSEncoder>(m, "CKKSEncoder")
         .def(py::init<HeContextPointer>()).def("context", &CKKSEncoder::context).def("slot_count", &CKKSEncoder::slot_count)
@@ -310,8 +334,8 @@ PYBIND11_MODULE(pytroy_raw, m) {
             return s.encode_float64_polynomial_new(v, id, scale, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), POOL)
         .def("encode_float64_single_new", [](const CKKSEncoder& s, double v, std::optional<ParmsID> id, double scale, PoolArg p) {
             return s.encode_float64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
-        .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("plain"), POOL)
-        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("plain"), POOL)
+        .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("source"), POOL)
+        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("source"), POOL)
         .def("poly_modulus_degree", &CKKSEncoder::polynomial_modulus_degree)
         .def("encode_complex64_simd", [](const CKKSEncoder& s, const std::vector<std::complex<double>>& v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
             s.encode_complex64_simd(v, id, scale, d, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
@@ -355,10 +379,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     register_ring2k(uint32_t{}, "PolynomialEncoderRing2k32");
     register_ring2k(uint64_t{}, "PolynomialEncoderRing2k64");
 
-    py::class_<utils::RandomGenerator>(m, "RandomGenerator")
-        .def(py::init([]() { return new utils::RandomGenerator(); })).def(py::init([](uint64_t seed) { return new utils::RandomGenerator(seed); }), py::arg("seed"))
-        .def("reset_seed", [](utils::RandomGenerator& s, uint64_t seed) { s.reset_seed(seed); }, py::arg("seed"))
-        .def("sample_uint64", &utils::RandomGenerator::sample_uint64);
+
 
     py::class_<LWECiphertext>(m, "LWECiphertext")
         .def(py::init<>())
@@ -383,7 +404,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
     EV_UNARY(ev, square);
     EV_UNARY_INPLACE_POOL(ev, square);
     EV_KEYED(ev, relinearize, RelinKeys, "relin_keys");
-    EV_KEYED(ev, apply_keyswitching, KSwitchKeys, "kswitch_keys");
+    EV_KEYED(ev, apply_keyswitching, KSwitchKeys, "keyswitch_keys");
     EV_UNARY(ev, mod_switch_to_next);
     EV_UNARY_INPLACE_POOL(ev, mod_switch_to_next);
     EV_UNARY(ev, rescale_to_next);
@@ -482,9 +503,9 @@ PYBIND11_MODULE(pytroy_raw, m) {
     ev.def("apply_galois_plain_new", [](const Evaluator& s, const Plaintext& a, size_t g, PoolArg p) { return s.apply_galois_plain_new(a, g, P(p)); }, py::arg("plain"), py::arg("galois_element"), POOL);
     // LWE extraction and RLWE packing
     ev.def("extract_lwe_new", [](const Evaluator& s, const Ciphertext& a, size_t term, PoolArg p) { return s.extract_lwe_new(a, term, P(p)); }, py::arg("encrypted"), py::arg("term"), POOL);
-    ev.def("assemble_lwe_new", [](const Evaluator& s, const LWECiphertext& l, PoolArg p) { return s.assemble_lwe_new(l, P(p)); }, py::arg("lwe_encrypted"), POOL);
+    ev.def("assemble_lwe_new", [](const Evaluator& s, const LWECiphertext& l, PoolArg p) { return s.assemble_lwe_new(l, P(p)); }, py::arg("lwe_ciphertext"), POOL);
     ev.def("field_trace_inplace", [](const Evaluator& s, Ciphertext& a, const GaloisKeys& k, size_t logn, PoolArg p) { s.field_trace_inplace(a, k, logn, P(p)); },
-           py::arg("encrypted"), py::arg("automorphism_keys"), py::arg("logn"), POOL);
+           py::arg("encrypted"), py::arg("galois_keys"), py::arg("logn"), POOL);
     ev.def("divide_by_poly_modulus_degree_inplace", [](const Evaluator& s, Ciphertext& a, uint64_t mul) { s.divide_by_poly_modulus_degree_inplace(a, mul); },
            py::arg("encrypted"), py::arg("mul") = 1);
     ev.def("negacyclic_shift", [](const Evaluator& s, const Ciphertext& a, size_t shift, Ciphertext& d, PoolArg p) { s.negacyclic_shift(a, shift, d, P(p)); },
@@ -492,20 +513,20 @@ PYBIND11_MODULE(pytroy_raw, m) {
     ev.def("negacyclic_shift_inplace", [](const Evaluator& s, Ciphertext& a, size_t shift, PoolArg p) { s.negacyclic_shift_inplace(a, shift, P(p)); }, py::arg("encrypted"), py::arg("shift"), POOL);
     ev.def("negacyclic_shift_new", [](const Evaluator& s, const Ciphertext& a, size_t shift, PoolArg p) { return s.negacyclic_shift_new(a, shift, P(p)); }, py::arg("encrypted"), py::arg("shift"), POOL);
     ev.def("pack_lwe_ciphertexts_new", [](const Evaluator& s, const std::vector<LWECiphertext*>& l, const GaloisKeys& k, PoolArg p, bool trace) {
-        return s.pack_lwe_ciphertexts_new(const_ptrs(l), k, P(p), trace); }, py::arg("lwe_encrypted"), py::arg("automorphism_keys"), POOL, py::arg("apply_field_trace") = true);
+        return s.pack_lwe_ciphertexts_new(const_ptrs(l), k, P(p), trace); }, py::arg("lwe_ciphertexts"), py::arg("automorphism_keys"), POOL, py::arg("apply_field_trace") = true);
     ev.def("pack_lwe_ciphertexts_new_batched", [](const Evaluator& s, const std::vector<std::vector<LWECiphertext*>>& groups, const GaloisKeys& k, PoolArg p, bool trace) {
         std::vector<std::vector<const LWECiphertext*>> g;
         for (const auto& grp : groups) g.push_back(const_ptrs(grp));
         return s.pack_lwe_ciphertexts_new_batched(g, k, P(p), trace); }, py::arg("lwe_groups"), py::arg("automorphism_keys"), POOL, py::arg("apply_field_trace") = true);
     ev.def("pack_rlwe_ciphertexts_new", [](const Evaluator& s, const std::vector<Ciphertext*>& c, const GaloisKeys& k, size_t shift, size_t in_iv, size_t out_iv, PoolArg p, bool trace) {
         return s.pack_rlwe_ciphertexts_new(const_ptrs(c), k, shift, in_iv, out_iv, P(p), trace); },
-        py::arg("ciphers"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
+        py::arg("rlwe_ciphertexts"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
     ev.def("pack_rlwe_ciphertexts_new_batched", [](const Evaluator& s, const std::vector<std::vector<Ciphertext*>>& groups, const GaloisKeys& k, size_t shift, size_t in_iv, size_t out_iv,
                                                    PoolArg p, bool trace) {
         std::vector<std::vector<const Ciphertext*>> g;
         for (const auto& grp : groups) g.push_back(const_ptrs(grp));
         return s.pack_rlwe_ciphertexts_new_batched(g, k, shift, in_iv, out_iv, P(p), trace); },
-        py::arg("cipher_groups"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
+        py::arg("rlwe_groups"), py::arg("automorphism_keys"), py::arg("shift"), py::arg("input_interval"), py::arg("output_interval"), POOL, py::arg("apply_field_trace") = true);
 
     // ---- linear-algebra applications (pybind/src/matmul_helper.cu, conv2d_helper.cu): numpy arrays in, numpy arrays out ----
     using linear::Cipher2d; using linear::Conv2dHelper; using linear::MatmulHelper; using linear::MatmulObjective; using linear::Plain2d;
@@ -520,16 +541,16 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("clone", [](const Plain2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
         .def("encrypt_symmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_symmetric(e, P(p)); }, py::arg("encryptor"), POOL)
         .def("encrypt_asymmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_asymmetric(e, P(p)); }, py::arg("encryptor"), POOL)
-        .def("get", [](const Plain2d& s, size_t i, size_t j) { return s[i].at(j); });
+        .def("get", [](const Plain2d& s, size_t i, size_t j) { return s[i].at(j); }, py::arg("i"), py::arg("j"));
     py::class_<Cipher2d>(m, "Cipher2d")
         .def(py::init<>()).def("size", &Cipher2d::size).def("rows", &Cipher2d::rows).def("columns", &Cipher2d::columns)
         .def("clone", [](const Cipher2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
         .def("expand_seed", &Cipher2d::expand_seed)
-        .def("save", [](const Cipher2d& s, HeContextPointer c) { return to_bytes([&](std::ostream& os) { s.save(os, c); }); }, py::arg("context"))
-        .def("load", [](Cipher2d& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("data"), py::arg("context"), POOL)
+        .def("save", [](const Cipher2d& s, HeContextPointer c, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, c, mode); }); }, py::arg("context"), MODE)
+        .def("load", [](Cipher2d& s, const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; s.load(is, c, P(p)); }, py::arg("str"), py::arg("context"), POOL)
         .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; return Cipher2d::load_new(is, c, P(p)); },
-                    py::arg("data"), py::arg("context"), POOL)
-        .def("serialized_size_upperbound", [](const Cipher2d& s, HeContextPointer c) { return s.serialized_size_upperbound(c); }, py::arg("context"))
+                    py::arg("str"), py::arg("context"), POOL)
+        .def("serialized_size_upperbound", [](const Cipher2d& s, HeContextPointer c, CompressionMode mode) { return s.serialized_size_upperbound(c, mode); }, py::arg("context"), MODE)
         .def("mod_switch_to_next_inplace", [](Cipher2d& s, const Evaluator& e, PoolArg p) { s.mod_switch_to_next_inplace(e, P(p)); }, py::arg("evaluator"), POOL)
         .def("mod_switch_to_next", [](const Cipher2d& s, const Evaluator& e, PoolArg p) { return s.mod_switch_to_next(e, P(p)); }, py::arg("evaluator"), POOL)
         .def("relinearize_inplace", [](Cipher2d& s, const Evaluator& e, const RelinKeys& k, PoolArg p) { s.relinearize_inplace(e, k, P(p)); }, py::arg("evaluator"), py::arg("relin_keys"), POOL)
@@ -543,7 +564,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("sub_plain", [](const Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { return s.sub_plain(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
         .def("sub_plain_inplace", [](Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { s.sub_plain_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
         .def("decrypt", [](const Cipher2d& s, const Decryptor& d, PoolArg p) { return s.decrypt(d, P(p)); }, py::arg("decryptor"), POOL)
-        .def("get", [](const Cipher2d& s, size_t i, size_t j) { return s[i].at(j); });
+        .def("get", [](const Cipher2d& s, size_t i, size_t j) { return s[i].at(j); }, py::arg("i"), py::arg("j"));
     py::enum_<MatmulObjective>(m, "MatmulObjective").value("EncryptLeft", MatmulObjective::EncryptLeft).value("EncryptRight", MatmulObjective::EncryptRight)
         .value("Crossed", MatmulObjective::Crossed);
 
@@ -559,8 +580,9 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("output_block", [](const MatmulHelper& s) { return s.output_block; })
         .def("matmul", &MatmulHelper::matmul).def("matmul_reverse", &MatmulHelper::matmul_reverse).def("matmul_cipher", &MatmulHelper::matmul_cipher)
         .def("pack_outputs", &MatmulHelper::pack_outputs)
-        .def("serialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const Cipher2d& x) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os); }); })
-        .def("deserialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); });
+        .def("serialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const Cipher2d& x, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os, mode); }); },
+             py::arg("evaluator"), py::arg("x"), MODE)
+        .def("deserialize_outputs", [](const MatmulHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); }, py::arg("evaluator"), py::arg("str"));
     auto mm_enc_w = [=](const MatmulHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
         need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encode_weights"); return s.encode_weights_uint64s(enc, vec_u64(w).data()); };
     auto mm_enc_x = [=](const MatmulHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& x) {
@@ -601,8 +623,9 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("input_channel_block", [](const Conv2dHelper& s) { return s.input_channel_block; }).def("output_channel_block", [](const Conv2dHelper& s) { return s.output_channel_block; })
         .def("image_height_block", [](const Conv2dHelper& s) { return s.image_height_block; }).def("image_width_block", [](const Conv2dHelper& s) { return s.image_width_block; })
         .def("conv2d", &Conv2dHelper::conv2d).def("conv2d_reverse", &Conv2dHelper::conv2d_reverse).def("conv2d_cipher", &Conv2dHelper::conv2d_cipher)
-        .def("serialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const Cipher2d& x) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os); }); })
-        .def("deserialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); });
+        .def("serialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const Cipher2d& x, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.serialize_outputs(e, x, os, mode); }); },
+             py::arg("evaluator"), py::arg("x"), MODE)
+        .def("deserialize_outputs", [](const Conv2dHelper& s, const Evaluator& e, const py::bytes& b) { std::istringstream is{std::string(b)}; return s.deserialize_outputs(e, is); }, py::arg("evaluator"), py::arg("str"));
     auto cv_out = [](const Conv2dHelper& s) { return s.batch_size * s.output_channels * (s.image_height - s.kernel_height + 1) * (s.image_width - s.kernel_width + 1); };
     auto cv_enc_w = [=](const Conv2dHelper& s, const BatchEncoder& enc, const py::array_t<uint64_t, py::array::c_style | py::array::forcecast>& w) {
         need(w.size(), s.output_channels * s.input_channels * s.kernel_height * s.kernel_width, "Conv2dHelper::encode_weights"); return s.encode_weights_uint64s(enc, vec_u64(w).data()); };
