@@ -19,7 +19,11 @@ CLASSES = {
 out = {}
 for f, classes in sorted(CLASSES.items()):
     src = open(os.path.join(REF, f + ".cu")).read()
-    names = sorted(set(re.findall(r'\.def(?:_static)?\(\s*"([A-Za-z0-9_]+)"', src)))
+    names = set(re.findall(r'\.def(?:_static)?\(\s*"([A-Za-z0-9_]+)"', src))
+    # names assembled at registration time: .def((std::string("encode_weights_ring2k") + bitwidth_name).c_str(), ...) for "32" and "64"
+    for stem in re.findall(r'std::string\("([A-Za-z0-9_]+)"\)\s*\+\s*bitwidth_name', src):
+        names |= {stem + "32", stem + "64"}
+    names = sorted(names)
     # keyword-argument lists, one per overload that names its arguments (py::arg("...") and the header's argument macros)
     macros = {"MEMORY_POOL_ARGUMENT": "pool", "COMPRESSION_MODE_ARGUMENT": "mode", "OPTIONAL_PARMS_ID_ARGUMENT": "parms_id"}
     signatures = {}

@@ -381,3 +381,50 @@ def test_wider_surface_in_python(pytroy, dev):
             wantc += np.einsum("bchw,oc->bohw", xi[:, :, a:a + H - kh + 1, b:b + W - kw + 1], wk[:, :, a, b])
     assert np.abs(gotc - wantc).max() < 1e-3
     pytroy.destroy_memory_pool()
+
+
+@pytest.mark.gpu
+def test_ring2k_helpers_in_python(pytroy, dev):
+    """MatmulHelper / Conv2dHelper over Z_{2^k} from Python (pybind/tests/test_matmul.py, test_conv2d.py use these names): y = x * w + s
+    modulo 2^64 and a convolution modulo 2^32"""
+    import numpy as np
+    n = 8192
+    p = pytroy.EncryptionParameters(pytroy.SchemeType.BFV)
+    p.set_poly_modulus_degree(n)
+    p.set_coeff_modulus(pytroy.CoeffModulus.create(n, [60, 60, 60, 60, 60]))
+    p.set_plain_modulus(1 << 20)
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Nil, 0x99)
+    ctx.to_device_inplace()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_secret_key(keygen.secret_key())
+    decryptor = pytroy.Decryptor(ctx, keygen.secret_key())
+    evaluator = pytroy.Evaluator(ctx)
+    rs = np.random.RandomState(17)
+    ring64 = pytroy.PolynomialEncoderRing2k64(ctx, 64)
+    m, r, o = 7, 20, 9
+    x, w, s = (rs.randint(0, 2 ** 63, size, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1) for size in (m * r, r * o, m * o))
+    helper = pytroy.MatmulHelper(m, r, o, n, pytroy.MatmulObjective.EncryptLeft, False)
+    w_enc = helper.encode_weights_ring2k64(ring64, w, None)
+    x_enc = pytroy.Cipher2d.load_new(helper.encrypt_inputs_ring2k64(encryptor, ring64, x, None).save(ctx), ctx)
+    y = helper.matmul(evaluator, x_enc, w_enc)
+    y.add_plain_inplace(evaluator, helper.encode_outputs_ring2k64(ring64, s, None))
+    got = helper.decrypt_outputs_ring2k64(ring64, decryptor, y)
+    want = (x.reshape(m, r).astype(object) @ w.reshape(r, o).astype(object) + s.reshape(m, o).astype(object)) % (1 << 64)
+    assert [int(v) for v in got] == [int(v) for v in want.reshape(-1)]
+    ring32 = pytroy.PolynomialEncoderRing2k32(ctx, 32)
+    bs, ic, oc, H, W, kh, kw = 1, 2, 3, 9, 8, 3, 2
+    xi = rs.randint(0, 2 ** 32, (bs, ic, H, W), dtype=np.int64).astype(np.uint32)
+    wk = rs.randint(0, 2 ** 32, (oc, ic, kh, kw), dtype=np.int64).astype(np.uint32)
+    conv = pytroy.Conv2dHelper(bs, ic, oc, H, W, kh, kw, n)
+    xin = conv.encrypt_inputs_ring2k32(encryptor, ring32, xi.reshape(-1), None)
+    with pytest.raises(ValueError):                                          # seed-compressed as sent: c1 has to be expanded (load does it) before use
+        conv.conv2d(evaluator, xin, conv.encode_weights_ring2k32(ring32, wk.reshape(-1), None))
+    xin.expand_seed(ctx)
+    gotc = conv.decrypt_outputs_ring2k32(ring32, decryptor, conv.conv2d(evaluator, xin, conv.encode_weights_ring2k32(ring32, wk.reshape(-1), None)))
+    wantc = np.zeros((bs, oc, H - kh + 1, W - kw + 1), dtype=object)
+    for a in range(kh):
+        for b in range(kw):
+            wantc += np.einsum("bchw,oc->bohw", xi[:, :, a:a + H - kh + 1, b:b + W - kw + 1].astype(object), wk[:, :, a, b].astype(object))
+    assert [int(v) for v in gotc] == [int(v) for v in (wantc % (1 << 32)).reshape(-1)]
+    pytroy.destroy_memory_pool()

@@ -658,4 +658,36 @@ PYBIND11_MODULE(pytroy_raw, m) {
       .def("encode_outputs_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const ArrF& y, std::optional<ParmsID> id, double scale) {
             need(y.size(), cv_out(s), "Conv2dHelper::encode_outputs"); return s.encode_outputs_doubles(enc, vec_f64(y).data(), id, scale); })
       .def("decrypt_outputs_doubles", [=](const Conv2dHelper& s, const CKKSEncoder& enc, const Decryptor& d, const Cipher2d& y) { return arr_f64(s.decrypt_outputs_doubles(enc, d, y)); });
+    // ring-2^k forms of the helpers, registered per element width as <name>_ring2k32 / _ring2k64 (pybind/src/matmul_helper.cu:7-80, conv2d_helper.cu:9-85)
+    auto register_helper_ring2k = [&](auto tag, const std::string& bits) {
+        using T = decltype(tag);
+        using Encoder = linear::PolynomialEncoderRing2k<T>;
+        using Arr = py::array_t<T, py::array::c_style | py::array::forcecast>;
+        auto vec = [](const Arr& a) { return std::vector<T>(a.data(), a.data() + a.size()); };
+        auto out = [](const std::vector<T>& v) { return py::array_t<T>(v.size(), v.data()); };
+        mh.def(("encode_weights_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encoder& enc, const Arr& w, std::optional<ParmsID> id) {
+                need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encode_weights"); return s.encode_weights_ring2k<T>(enc, vec(w).data(), id); })
+          .def(("encode_inputs_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encoder& enc, const Arr& x, std::optional<ParmsID> id) {
+                need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encode_inputs"); return s.encode_inputs_ring2k<T>(enc, vec(x).data(), id); })
+          .def(("encode_outputs_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encoder& enc, const Arr& y, std::optional<ParmsID> id) {
+                need(y.size(), s.batch_size * s.output_dims, "MatmulHelper::encode_outputs"); return s.encode_outputs_ring2k<T>(enc, vec(y).data(), id); })
+          .def(("encrypt_weights_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encryptor& e, const Encoder& enc, const Arr& w, std::optional<ParmsID> id) {
+                need(w.size(), s.input_dims * s.output_dims, "MatmulHelper::encrypt_weights"); return s.encrypt_weights_ring2k<T>(e, enc, vec(w).data(), id); })
+          .def(("encrypt_inputs_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encryptor& e, const Encoder& enc, const Arr& x, std::optional<ParmsID> id) {
+                need(x.size(), s.batch_size * s.input_dims, "MatmulHelper::encrypt_inputs"); return s.encrypt_inputs_ring2k<T>(e, enc, vec(x).data(), id); })
+          .def(("decrypt_outputs_ring2k" + bits).c_str(), [=](const MatmulHelper& s, const Encoder& enc, const Decryptor& d, const Cipher2d& y) { return out(s.decrypt_outputs_ring2k<T>(enc, d, y)); });
+        ch.def(("encode_weights_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encoder& enc, const Arr& w, std::optional<ParmsID> id) {
+                need(w.size(), cv_w(s), "Conv2dHelper::encode_weights"); return s.encode_weights_ring2k<T>(enc, vec(w).data(), id); })
+          .def(("encode_inputs_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encoder& enc, const Arr& x, std::optional<ParmsID> id) {
+                need(x.size(), cv_x(s), "Conv2dHelper::encode_inputs"); return s.encode_inputs_ring2k<T>(enc, vec(x).data(), id); })
+          .def(("encode_outputs_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encoder& enc, const Arr& y, std::optional<ParmsID> id) {
+                need(y.size(), cv_out(s), "Conv2dHelper::encode_outputs"); return s.encode_outputs_ring2k<T>(enc, vec(y).data(), id); })
+          .def(("encrypt_weights_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encryptor& e, const Encoder& enc, const Arr& w, std::optional<ParmsID> id) {
+                need(w.size(), cv_w(s), "Conv2dHelper::encrypt_weights"); return s.encrypt_weights_ring2k<T>(e, enc, vec(w).data(), id); })
+          .def(("encrypt_inputs_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encryptor& e, const Encoder& enc, const Arr& x, std::optional<ParmsID> id) {
+                need(x.size(), cv_x(s), "Conv2dHelper::encrypt_inputs"); return s.encrypt_inputs_ring2k<T>(e, enc, vec(x).data(), id); })
+          .def(("decrypt_outputs_ring2k" + bits).c_str(), [=](const Conv2dHelper& s, const Encoder& enc, const Decryptor& d, const Cipher2d& y) { return out(s.decrypt_outputs_ring2k<T>(enc, d, y)); });
+    };
+    register_helper_ring2k(uint32_t{}, "32");
+    register_helper_ring2k(uint64_t{}, "64");
 }
