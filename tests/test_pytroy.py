@@ -319,7 +319,9 @@ def test_wider_surface_in_python(pytroy, dev):
     gk = keygen.create_galois_keys(False)
     gk2 = pytroy.KSwitchKeys.load_new(gk.save(ctx), ctx)
     assert gk2.parms_id() == gk.parms_id() and len(gk.save(ctx)) <= gk.serialized_size_upperbound(ctx)
-    rotated = encoder.decode_simd_new(decryptor.decrypt_new(evaluator.rotate_rows_new(encryptor.encrypt_symmetric_new(ps, False), 1, gk)))
+    gk3 = pytroy.GaloisKeys.load_new(gk.save(ctx), ctx)                      # a GaloisKeys again (the reference registers the class on its own)
+    assert isinstance(gk3, pytroy.GaloisKeys) and isinstance(gk.clone(), pytroy.GaloisKeys)
+    rotated = encoder.decode_simd_new(decryptor.decrypt_new(evaluator.rotate_rows_new(encryptor.encrypt_symmetric_new(ps, False), 1, gk3)))
     g = 3                                                                     # rotate_rows by one step = the generator itself
     assert encoder.decode_simd_new(evaluator.apply_galois_plain_new(ps, g)) == rotated and rotated != slots
     sk_plain = keygen.secret_key().get_plaintext()

@@ -226,8 +226,20 @@ PYBIND11_MODULE(pytroy_raw, m) {
                     py::arg("str"), py::arg("context"), POOL)
         .def("save", [](const KSwitchKeys& s, HeContextPointer c, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, c, mode); }); }, py::arg("context"), MODE)
         .def("load", [](KSwitchKeys& s, const std::string& b, HeContextPointer c, PoolArg p) { std::istringstream is(b); s.load(is, c, P(p)); }, py::arg("str"), py::arg("context"), POOL);
-    py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key);
-    py::class_<GaloisKeys, KSwitchKeys>(m, "GaloisKeys").def(py::init<>()).def("has_key", &GaloisKeys::has_key);
+    py::class_<RelinKeys, KSwitchKeys>(m, "RelinKeys").def(py::init<>()).def("has_key", &RelinKeys::has_key)
+        // the reference registers RelinKeys as a class of its own: load_new / clone / to_device / to_host return RelinKeys, not KSwitchKeys
+        .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; KSwitchKeys k; k.load(is, c, P(p)); return RelinKeys(std::move(k)); },
+                    py::arg("str"), py::arg("context"), POOL)
+        .def("clone", [](const RelinKeys& s, PoolArg p) { (void)p; return RelinKeys(s); }, POOL)
+        .def("to_device", [](const RelinKeys& s, PoolArg p) { RelinKeys k(s); k.to_device_inplace(P(p)); return k; }, POOL)
+        .def("to_host", [](const RelinKeys& s) { RelinKeys k(s); k.to_host_inplace(); return k; });
+    py::class_<GaloisKeys, KSwitchKeys>(m, "GaloisKeys").def(py::init<>()).def("has_key", &GaloisKeys::has_key)
+        // the reference registers GaloisKeys as a class of its own: load_new / clone / to_device / to_host return GaloisKeys, not KSwitchKeys
+        .def_static("load_new", [](const py::bytes& b, HeContextPointer c, PoolArg p) { std::istringstream is{std::string(b)}; KSwitchKeys k; k.load(is, c, P(p)); return GaloisKeys(std::move(k)); },
+                    py::arg("str"), py::arg("context"), POOL)
+        .def("clone", [](const GaloisKeys& s, PoolArg p) { (void)p; return GaloisKeys(s); }, POOL)
+        .def("to_device", [](const GaloisKeys& s, PoolArg p) { GaloisKeys k(s); k.to_device_inplace(P(p)); return k; }, POOL)
+        .def("to_host", [](const GaloisKeys& s) { GaloisKeys k(s); k.to_host_inplace(); return k; });
 
     py::class_<KeyGenerator>(m, "KeyGenerator")
         .def(py::init([](HeContextPointer c, PoolArg p) { return new KeyGenerator(c, P(p)); }), py::arg("context"), POOL)
