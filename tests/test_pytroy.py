@@ -106,7 +106,7 @@ def test_quickstart_flow_in_python(pytroy, dev):
             h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return "%016x" % h
     assert digest(c.data()) == G["ciphertext_digest"]                 # the reference's own output for this seed
-    dec = lambda ct: encoder.decode_simd_new(decryptor.decrypt_new(ct))
+    dec = lambda ct: encoder.decode_simd_new(decryptor.decrypt_new(ct)).tolist()
     assert dec(c)[:5] == [1, 2, 3, 4, 0]
     assert dec(evaluator.add_new(c, c))[:4] == [2, 4, 6, 8]
     prod = evaluator.multiply_new(c, c)
@@ -157,10 +157,10 @@ def test_ckks_flow_in_python(pytroy, dev):
     c2 = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z2, None, scale))
     m = ev.relinearize_new(ev.multiply_new(c1, c2), kg.create_relin_keys(False))
     ev.rescale_to_next_inplace(m)
-    got = enc.decode_complex64_simd_new(dec.decrypt_new(m))
+    got = enc.decode_complex64_simd_new(dec.decrypt_new(m)).tolist()
     assert max(abs(g - a * b) for g, a, b in zip(got, z1, z2)) < 1e-2
     gk = kg.create_galois_keys_from_steps([2], False)
-    rot = enc.decode_complex64_simd_new(dec.decrypt_new(ev.rotate_vector_new(c1, 2, gk)))
+    rot = enc.decode_complex64_simd_new(dec.decrypt_new(ev.rotate_vector_new(c1, 2, gk))).tolist()
     assert max(abs(rot[i] - z1[(i + 2) % len(z1)]) for i in range(len(z1))) < 2e-2   # scale 2^30: key-switch noise ~2^-10
     pytroy.MemoryPool.destroy_global_pool()
 
@@ -183,7 +183,7 @@ def test_lwe_packing_flow_in_python(pytroy, dev):
     evaluator = pytroy.Evaluator(ctx)
     auto = keygen.create_automorphism_keys(False)
     msg = [(7 * i + 3) % t for i in range(n)]
-    dec = lambda ct: encoder.decode_polynomial_new(decryptor.decrypt_new(ct))
+    dec = lambda ct: encoder.decode_polynomial_new(decryptor.decrypt_new(ct)).tolist()
     c = encryptor.encrypt_symmetric_new(encoder.encode_polynomial_new(msg), False)
     assert dec(c) == msg
     # X^5 * m: coefficients move up by 5, the wrapped ones change sign
@@ -298,20 +298,20 @@ def test_wider_surface_in_python(pytroy, dev):
     # scale_up / scale_down / centralize, partial RNS plaintexts as operands
     up = encoder.scale_up_new(plain)
     assert up.coeff_count() == 100 and len(up.obtain_data()) == 200 and not up.parms_id().is_zero() and up.parms_id() == ctx.first_parms_id()
-    assert encoder.decode_polynomial_new(encoder.scale_down_new(up)) == msg
+    assert encoder.decode_polynomial_new(encoder.scale_down_new(up)).tolist() == msg
     c = encryptor.encrypt_symmetric_new(up, False)
-    assert encoder.decode_polynomial_new(decryptor.decrypt_new(c))[:100] == msg
+    assert encoder.decode_polynomial_new(decryptor.decrypt_new(c)).tolist()[:100] == msg
     ca = encryptor.encrypt_asymmetric_new(plain)
     assert not ca.is_transparent() and pytroy.Ciphertext().is_transparent() and ca.correction_factor() == 1 and ca.seed() == 0
     assert ca.data_address() != 0 and ca.device_index() == 0 and ca.to_host().on_device() is False
     cen = encoder.centralize_new(plain)
-    assert encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, cen))) == \
-        encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, plain)))
+    assert encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, cen))).tolist() == \
+        encoder.decode_polynomial_new(decryptor.decrypt_new(evaluator.multiply_plain_new(ca, plain))).tolist()
     # save_terms / load_terms: only the listed coefficients of c0 travel
     terms = [0, 5, 17, 99]
     blob = ca.save_terms(ctx, terms)
     assert len(blob) <= ca.serialized_terms_size_upperbound(ctx, terms) and len(blob) < len(ca.save(ctx))
-    back = encoder.decode_polynomial_new(decryptor.decrypt_new(pytroy.Ciphertext.load_terms_new(blob, ctx, terms)))
+    back = encoder.decode_polynomial_new(decryptor.decrypt_new(pytroy.Ciphertext.load_terms_new(blob, ctx, terms))).tolist()
     assert [back[i] for i in terms] == [msg[i] for i in terms]
     # the plaintext automorphism against the one under encryption
     slots = [int(v) for v in rs.randint(0, t, n)]
@@ -321,9 +321,9 @@ def test_wider_surface_in_python(pytroy, dev):
     assert gk2.parms_id() == gk.parms_id() and len(gk.save(ctx)) <= gk.serialized_size_upperbound(ctx)
     gk3 = pytroy.GaloisKeys.load_new(gk.save(ctx), ctx)                      # a GaloisKeys again (the reference registers the class on its own)
     assert isinstance(gk3, pytroy.GaloisKeys) and isinstance(gk.clone(), pytroy.GaloisKeys)
-    rotated = encoder.decode_simd_new(decryptor.decrypt_new(evaluator.rotate_rows_new(encryptor.encrypt_symmetric_new(ps, False), 1, gk3)))
+    rotated = encoder.decode_simd_new(decryptor.decrypt_new(evaluator.rotate_rows_new(encryptor.encrypt_symmetric_new(ps, False), 1, gk3))).tolist()
     g = 3                                                                     # rotate_rows by one step = the generator itself
-    assert encoder.decode_simd_new(evaluator.apply_galois_plain_new(ps, g)) == rotated and rotated != slots
+    assert encoder.decode_simd_new(evaluator.apply_galois_plain_new(ps, g)).tolist() == rotated and rotated != slots
     sk_plain = keygen.secret_key().get_plaintext()
     assert sk_plain.is_ntt_form() and pytroy.SecretKey(sk_plain).parms_id() == ctx.key_parms_id()
     gen = pytroy.RandomGenerator(7)
@@ -363,9 +363,9 @@ def test_wider_surface_in_python(pytroy, dev):
     ctx3.to_device_inplace()
     ck = pytroy.CKKSEncoder(ctx3)
     assert ck.poly_modulus_degree() == n
-    assert ck.decode_float64_polynomial_new(ck.encode_integer64_polynomial_new([3, -4, 5], None))[:4] == [3.0, -4.0, 5.0, 0.0]
-    assert all(abs(v - (2 - 1j)) < 1e-6 for v in ck.decode_complex64_simd_new(ck.encode_complex64_single_new(2 - 1j, None, 2.0 ** 30)))
-    assert all(abs(v + 9) < 1e-9 for v in ck.decode_complex64_simd_new(ck.encode_integer64_single_new(-9, None)))
+    assert ck.decode_float64_polynomial_new(ck.encode_integer64_polynomial_new([3, -4, 5], None)).tolist()[:4] == [3.0, -4.0, 5.0, 0.0]
+    assert all(abs(v - (2 - 1j)) < 1e-6 for v in ck.decode_complex64_simd_new(ck.encode_complex64_single_new(2 - 1j, None, 2.0 ** 30)).tolist())
+    assert all(abs(v + 9) < 1e-9 for v in ck.decode_complex64_simd_new(ck.encode_integer64_single_new(-9, None)).tolist())
     kg3 = pytroy.KeyGenerator(ctx3)
     enc3 = pytroy.Encryptor(ctx3)
     enc3.set_secret_key(kg3.secret_key())

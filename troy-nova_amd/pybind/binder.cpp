@@ -90,7 +90,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("is_zero", &ParmsID::is_zero).def_static("zero", []() { return parms_id_zero; })
         .def("__eq__", [](const ParmsID& a, const ParmsID& b) { return a == b; })
         .def("__hash__", [](const ParmsID& a) { return ParmsIDHash{}(a); })
-        .def("to_vector", [](const ParmsID& a) { return std::vector<uint64_t>(a.v, a.v + 4); });
+        .def("to_vector", [](const ParmsID& a) { return py::array_t<uint64_t>(4, a.v); });
     m.attr("parms_id_zero") = parms_id_zero;
 
     py::class_<EncryptionParameters>(m, "EncryptionParameters")
@@ -318,9 +318,9 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("on_device", &BatchEncoder::on_device).def("to_device_inplace", [](BatchEncoder&, PoolArg) {}, POOL)
         .def("encode_simd", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
         .def("encode_simd_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_new(pl, P(p)); }, py::arg("source"), POOL)
+        .def("decode_simd_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { const std::vector<uint64_t> v = s.decode_new(pl, P(p)); return py::array_t<uint64_t>(v.size(), v.data()); }, py::arg("source"), POOL)
         .def("encode_polynomial_new", [](const BatchEncoder& s, const std::vector<uint64_t>& v, PoolArg p) { return s.encode_polynomial_new(v, P(p)); }, py::arg("values"), POOL)
-        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_polynomial_new(pl, P(p)); }, py::arg("source"), POOL)
+        .def("decode_polynomial_new", [](const BatchEncoder& s, const Plaintext& pl, PoolArg p) { const std::vector<uint64_t> v = s.decode_polynomial_new(pl, P(p)); return py::array_t<uint64_t>(v.size(), v.data()); }, py::arg("source"), POOL)
         .def("encode_polynomial", [](const BatchEncoder& s, const std::vector<uint64_t>& v, Plaintext& d, PoolArg p) { s.encode_polynomial(v, d, P(p)); }, py::arg("values"), py::arg("destination"), POOL)
         .def("row_count", &BatchEncoder::row_count).def("column_count", &BatchEncoder::column_count).def("simd_encoding_supported", &BatchEncoder::simd_encoding_supported)
         .def("scale_up", [](const BatchEncoder& s, const Plaintext& a, Plaintext& d, std::optional<ParmsID> id, PoolArg p) { s.scale_up(a, d, id, P(p)); },
@@ -346,8 +346,8 @@ PYBIND11_MODULE(pytroy_raw, m) {
             return s.encode_float64_polynomial_new(v, id, scale, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), POOL)
         .def("encode_float64_single_new", [](const CKKSEncoder& s, double v, std::optional<ParmsID> id, double scale, PoolArg p) {
             return s.encode_float64_single_new(v, id, scale, P(p)); }, py::arg("value"), py::arg("parms_id"), py::arg("scale"), POOL)
-        .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_complex64_simd_new(pl, P(p)); }, py::arg("source"), POOL)
-        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { return s.decode_float64_polynomial_new(pl, P(p)); }, py::arg("source"), POOL)
+        .def("decode_complex64_simd_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { const std::vector<std::complex<double>> v = s.decode_complex64_simd_new(pl, P(p)); return py::array_t<std::complex<double>>(v.size(), v.data()); }, py::arg("source"), POOL)
+        .def("decode_float64_polynomial_new", [](const CKKSEncoder& s, const Plaintext& pl, PoolArg p) { const std::vector<double> v = s.decode_float64_polynomial_new(pl, P(p)); return py::array_t<double>(v.size(), v.data()); }, py::arg("source"), POOL)
         .def("poly_modulus_degree", &CKKSEncoder::polynomial_modulus_degree)
         .def("encode_complex64_simd", [](const CKKSEncoder& s, const std::vector<std::complex<double>>& v, std::optional<ParmsID> id, double scale, Plaintext& d, PoolArg p) {
             s.encode_complex64_simd(v, id, scale, d, P(p)); }, py::arg("values"), py::arg("parms_id"), py::arg("scale"), py::arg("destination"), POOL)
