@@ -553,7 +553,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("clone", [](const Plain2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
         .def("encrypt_symmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_symmetric(e, P(p)); }, py::arg("encryptor"), POOL)
         .def("encrypt_asymmetric", [](const Plain2d& s, const Encryptor& e, PoolArg p) { return s.encrypt_asymmetric(e, P(p)); }, py::arg("encryptor"), POOL)
-        .def("get", [](const Plain2d& s, size_t i, size_t j) { return s[i].at(j); }, py::arg("i"), py::arg("j"));
+        .def("get", [](Plain2d& s, size_t i, size_t j) -> Plaintext& { return s[i].at(j); }, py::arg("i"), py::arg("j"), py::return_value_policy::reference_internal);
     py::class_<Cipher2d>(m, "Cipher2d")
         .def(py::init<>()).def("size", &Cipher2d::size).def("rows", &Cipher2d::rows).def("columns", &Cipher2d::columns)
         .def("clone", [](const Cipher2d& s, PoolArg p) { return s.clone(P(p)); }, POOL)
@@ -576,7 +576,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("sub_plain", [](const Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { return s.sub_plain(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
         .def("sub_plain_inplace", [](Cipher2d& s, const Evaluator& e, const Plain2d& o, PoolArg p) { s.sub_plain_inplace(e, o, P(p)); }, py::arg("evaluator"), py::arg("plain"), POOL)
         .def("decrypt", [](const Cipher2d& s, const Decryptor& d, PoolArg p) { return s.decrypt(d, P(p)); }, py::arg("decryptor"), POOL)
-        .def("get", [](const Cipher2d& s, size_t i, size_t j) { return s[i].at(j); }, py::arg("i"), py::arg("j"));
+        .def("get", [](Cipher2d& s, size_t i, size_t j) -> Ciphertext& { return s[i].at(j); }, py::arg("i"), py::arg("j"), py::return_value_policy::reference_internal);
     py::enum_<MatmulObjective>(m, "MatmulObjective").value("EncryptLeft", MatmulObjective::EncryptLeft).value("EncryptRight", MatmulObjective::EncryptRight)
         .value("Crossed", MatmulObjective::Crossed);
 
