@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "troy.h"
+#include "wrapper.h"
 
 namespace troy {
 
@@ -337,3 +338,7 @@ void Evaluator::transform_plain_from_ntt_batched(const std::vector<const Plainte
 }
 
 }  // namespace troy
+
+extern "C" void troy_wrapper::create_memory_pool_handle(size_t device_index, troy::MemoryPoolHandle* out) {
+    if (out) *out = troy::MemoryPool::create(device_index);
+}
