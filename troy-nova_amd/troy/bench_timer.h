@@ -1,4 +1,4 @@
-// timer.h -- troy::bench timers with the interface of the reference's src/utils/timer.h (TimerOnce, TimerSingle, Timer): wall-clock
+// bench_timer.h -- troy::bench timers with the interface of the reference's src/utils/timer.h (TimerOnce, TimerSingle, Timer): wall-clock
 // accumulation around host calls.  Device work of this mirror is synchronised before each public call returns, so tick()/tock()
 // around a call measures the call.
 #pragma once

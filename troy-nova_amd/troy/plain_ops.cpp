@@ -8,7 +8,6 @@
 #include <sstream>
 
 #include "troy.h"
-#include "wrapper.h"
 
 namespace troy {
 

@@ -35,7 +35,7 @@
 #include <vector>
 
 #include "../../include/troyn.h"
-#include "timer.h"
+#include "bench_timer.h"
 
 namespace troy {
 
@@ -1234,3 +1234,9 @@ private:
 };
 
 }  // namespace troy
+
+// The reference tree's one extern "C" entry (rustbind/wrapper.h:11-12): bindgen cannot return a std::shared_ptr, so the handle of a new
+// pool on `device_index` is written through `out`.
+namespace troy_wrapper {
+extern "C" void create_memory_pool_handle(size_t device_index, troy::MemoryPoolHandle* out);
+}
