@@ -103,6 +103,20 @@ static void run_bfv_like(SchemeType scheme) {
         check(threw, "even Galois elements are rejected");
     }
     check(Ciphertext().is_transparent() && !cs.is_transparent(), "is_transparent");
+    {
+        // the small host-side types user programs touch (utils/box.h, plaintext.h to_string, timer.h, compression.h)
+        check(encoder.encode_polynomial_new({4, 3, 0, 0x7ff}).to_string() == "7FFx^3 + 3x^1 + 4" && encoder.encode_polynomial_new({0, 0}).to_string() == "0", "Plaintext::to_string");
+        const ParmsID first = context->first_parms_id();
+        check(first[0] == first.v[0] && first[3] == first.v[3], "ParmsID::operator[]");
+        utils::ConstSlice<Modulus> q = parms.coeff_modulus();
+        utils::Array<Modulus> host(q.size(), false);
+        host.copy_from_slice(q);
+        check(q.size() == 3 && host[2].value() == q[2].value() && q.to_vector().size() == 3 && CoeffModulus::create(n, {40, 40}).to_vector().size() == 2, "ConstSlice / Array");
+        check(utils::compression::available(CompressionMode::Nil) && !utils::compression::available(CompressionMode::Zstd), "compression::available");
+        bench::TimerSingle timer;
+        timer.tick(); timer.tock();
+        check(timer.count() == 1 && context->first_context_data_pointer() != nullptr && context->get_context_data_pointer(parms_id_zero) == nullptr, "TimerSingle, *_pointer getters");
+    }
     const Modulus q0 = parms.coeff_modulus()[0];
     check(q0.reduce_mul_uint64(q0.value() - 1, q0.value() - 1) == 1, "Modulus::reduce_mul_uint64");
 }
