@@ -295,6 +295,11 @@ def test_wider_surface_in_python(pytroy, dev):
     rs = np.random.RandomState(3)
     msg = [int(v) for v in rs.randint(0, t, 100)]
     plain = encoder.encode_polynomial_new(msg)
+    # numpy arrays are accepted wherever the reference takes py::array_t, and decode returns numpy arrays
+    from_np = encoder.decode_polynomial_new(encoder.encode_polynomial_new(np.array(msg, dtype=np.uint64)))
+    assert isinstance(from_np, np.ndarray) and from_np.dtype == np.uint64 and from_np.tolist() == msg
+    simd = np.arange(n, dtype=np.uint64) % np.uint64(t)
+    assert np.array_equal(encoder.decode_simd_new(encoder.encode_simd_new(simd)), simd)
     # scale_up / scale_down / centralize, partial RNS plaintexts as operands
     up = encoder.scale_up_new(plain)
     assert up.coeff_count() == 100 and len(up.obtain_data()) == 200 and not up.parms_id().is_zero() and up.parms_id() == ctx.first_parms_id()
@@ -363,6 +368,9 @@ def test_wider_surface_in_python(pytroy, dev):
     ctx3.to_device_inplace()
     ck = pytroy.CKKSEncoder(ctx3)
     assert ck.poly_modulus_degree() == n
+    zs = (rs.uniform(-1, 1, n // 2) + 1j * rs.uniform(-1, 1, n // 2)).astype(np.complex128)
+    back = ck.decode_complex64_simd_new(ck.encode_complex64_simd_new(zs, None, 2.0 ** 40))
+    assert isinstance(back, np.ndarray) and back.dtype == np.complex128 and np.abs(back - zs).max() < 1e-6
     assert ck.decode_float64_polynomial_new(ck.encode_integer64_polynomial_new([3, -4, 5], None)).tolist()[:4] == [3.0, -4.0, 5.0, 0.0]
     assert all(abs(v - (2 - 1j)) < 1e-6 for v in ck.decode_complex64_simd_new(ck.encode_complex64_single_new(2 - 1j, None, 2.0 ** 30)).tolist())
     assert all(abs(v + 9) < 1e-9 for v in ck.decode_complex64_simd_new(ck.encode_integer64_single_new(-9, None)).tolist())
