@@ -438,3 +438,44 @@ def test_ring2k_helpers_in_python(pytroy, dev):
             wantc += np.einsum("bchw,oc->bohw", xi[:, :, a:a + H - kh + 1, b:b + W - kw + 1].astype(object), wk[:, :, a, b].astype(object))
     assert [int(v) for v in gotc] == [int(v) for v in (wantc % (1 << 32)).reshape(-1)]
     pytroy.destroy_memory_pool()
+
+
+@pytest.mark.gpu
+def test_memory_pools_in_python(pytroy, dev):
+    """pybind/tests/test_basics.py's pool checks (device side): objects report the pool they were allocated from -- the global pool by
+    default, a caller's pool when one is passed"""
+    n = 8192
+    p = _params(pytroy, pytroy.SchemeType.BFV, n, [60, 40, 40, 60])
+    global_pool = pytroy.MemoryPool.global_pool()
+    assert global_pool is not None
+    ctx = pytroy.HeContext(p)
+    encoder = pytroy.BatchEncoder(ctx)
+    ctx.to_device_inplace()
+    encoder.to_device_inplace()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    pk = keygen.create_public_key(False)
+    encryptor.set_public_key(pk)
+    assert ctx.pool() == global_pool and pk.pool() == global_pool
+    encoded = encoder.encode_simd_new([1, 2, 3, 4])
+    assert encoded.pool() == global_pool
+    assert encryptor.encrypt_asymmetric_new(encoded).pool() == global_pool
+    # custom pools
+    context_pool, text_pool = pytroy.MemoryPool(), pytroy.MemoryPool()
+    assert context_pool != global_pool and text_pool != context_pool and text_pool != global_pool
+    ctx2 = pytroy.HeContext(p)
+    enc2 = pytroy.BatchEncoder(ctx2)
+    ctx2.to_device_inplace(context_pool)
+    enc2.to_device_inplace(context_pool)
+    kg2 = pytroy.KeyGenerator(ctx2)
+    e2 = pytroy.Encryptor(ctx2)
+    pk2 = kg2.create_public_key(False, context_pool)
+    e2.set_public_key(pk2)
+    assert ctx2.pool() == context_pool and pk2.pool() == context_pool
+    encoded2 = enc2.encode_simd_new([1, 2, 3, 4], text_pool)
+    assert encoded2.pool() == text_pool
+    encrypted2 = e2.encrypt_asymmetric_new(encoded2, text_pool)
+    assert encrypted2.pool() == text_pool
+    dec = pytroy.Decryptor(ctx2, kg2.secret_key())
+    assert enc2.decode_simd_new(dec.decrypt_new(encrypted2)).tolist()[:5] == [1, 2, 3, 4, 0]
+    pytroy.destroy_memory_pool()
