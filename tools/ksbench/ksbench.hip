@@ -1,0 +1,230 @@
+// ksbench.hip -- standalone A/B harness for the key-switch / NTT kernels at the headline shape
+// (CKKS N = 16384, K = 6 limbs of 50 bits, L = 5).  Development tool: it instantiates only the kernels
+// under study (seconds to build instead of the minutes libtroyn.so takes) and checks every variant
+// bit-for-bit against the shipped kernel of the same name before timing it.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o ksbench ksbench.hip
+//   ./ksbench [batch] [reps] [variant ...]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../troy-nova_amd/csrc/host_math.hpp"
+#include "../../troy-nova_amd/csrc/ntt_kernels.hpp"
+#include "../../troy-nova_amd/csrc/ksmac_kernels.hpp"
+
+using namespace troyn;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr unsigned LOGN = 14, N = 1u << LOGN, K = 6, L = 5;
+
+__global__ void center_kernel(const u64* in, double* out, size_t count, unsigned n, const u64* moduli, unsigned nmod) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const u64 q = moduli[(i / n) % nmod], d = in[i];
+        out[i] = (double)d; (void)q;
+    }
+}
+
+__global__ void fill_kernel(u64* out, size_t count, unsigned n, const u64* moduli, unsigned nmod, unsigned mod_of_row_div, u64 seed) {
+    // row r of n words gets modulus moduli[(r / mod_of_row_div) % nmod]  (mod_of_row_div = 1: [..][nmod][n] layouts)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        u64 z = seed + i * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const size_t row = i / n;
+        out[i] = z % moduli[(row / mod_of_row_div) % nmod];
+    }
+}
+
+static DevModulus plan_modulus(const host::NttTable& t, unsigned log_n) {
+    DevModulus m;
+    std::memset(&m, 0, sizeof(m));
+    const u64 q = t.q;
+    m.q = q;
+    host::BarrettRatio r = host::barrett_ratio(q);
+    m.ratio_lo = r.lo; m.ratio_hi = r.hi;
+    m.inv_n_op = t.inv_degree.operand; m.inv_n_quo = t.inv_degree.quotient;
+    m.pd = (double)q; m.inv_pd = 1.0 / (double)q;
+    m.inv_n_d = (double)t.inv_degree.operand; m.inv_n_pd = (double)t.inv_degree.operand * (1.0 / (double)q);
+    const size_t n = (size_t)1 << log_n;
+    const u64 nw = host::mulmod(t.inv[n - 1].operand, t.inv_degree.operand, q);
+    m.inv_n_w_d = (double)nw; m.inv_n_w_pd = (double)nw * (1.0 / (double)q);
+    return m;
+}
+
+struct Bench {
+    size_t B;
+    DevModulus* d_mods;
+    double* d_fwd;
+    u64* d_moduli;
+    u64 *digits, *target, *out_ref, *out;
+    u64* keys[L];
+    KeyPtrs kp;
+    NttArgs args;
+};
+
+static float time_launch(const std::function<void()>& f, int reps) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    f();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) f();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipGetLastError());
+    return ms * 1e3f / reps;
+}
+
+int main(int argc, char** argv) {
+    const size_t B = argc > 1 ? (size_t)atoi(argv[1]) : 512;
+    const int reps = argc > 2 ? atoi(argv[2]) : 10;
+    std::vector<std::string> want;
+    for (int i = 3; i < argc; i++) want.push_back(argv[i]);
+    auto wanted = [&](const char* name) {
+        if (want.empty()) return true;
+        for (auto& w : want) if (w == name) return true;
+        return false;
+    };
+
+    std::vector<u64> q = host::get_primes(2ull * N, 50, K);
+    std::vector<DevModulus> mods(K);
+    std::vector<double> fwd((size_t)K * N), fwdp((size_t)K * N), r1((size_t)K * (N >> 10) * 32), r2((size_t)K * N);
+    for (unsigned i = 0; i < K; i++) {
+        host::NttTable t = host::make_ntt_table(LOGN, q[i], 0);
+        mods[i] = plan_modulus(t, LOGN);
+        const double inv_p = 1.0 / (double)q[i];
+        for (size_t x = 0; x < N; x++) { fwd[(size_t)i * N + x] = (double)t.fwd[x].operand; fwdp[(size_t)i * N + x] = (double)t.fwd[x].operand * inv_p; }
+        for (unsigned th = 0; th < (N >> 10); th++)
+            for (unsigned s = 1; s < 32; s++) {
+                unsigned lvl = 31 - __builtin_clz(s), g = s - (1u << lvl);
+                r1[((size_t)i * (N >> 10) + th) * 32 + s] = (double)t.fwd[(((N >> 10) + th) << lvl) + g].operand;
+            }
+        for (unsigned T = 0; T < (N >> 5); T++)
+            for (unsigned s = 1; s < 32; s++) {
+                unsigned lvl = 31 - __builtin_clz(s), g = s - (1u << lvl);
+                r2[(size_t)i * N + ksm_perm(T * 32 + s)] = (double)t.fwd[(((N >> 5) + T) << lvl) + g].operand;
+            }
+    }
+    Bench b;
+    b.B = B;
+    CHECK(hipMalloc(&b.d_mods, K * sizeof(DevModulus)));
+    CHECK(hipMalloc(&b.d_fwd, fwd.size() * sizeof(double)));
+    CHECK(hipMalloc(&b.d_moduli, K * sizeof(u64)));
+    CHECK(hipMemcpy(b.d_mods, mods.data(), K * sizeof(DevModulus), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(b.d_fwd, fwd.data(), fwd.size() * sizeof(double), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(b.d_moduli, q.data(), K * sizeof(u64), hipMemcpyHostToDevice));
+    const size_t dig_words = B * L * N, out_words = B * 2 * (L + 1) * N, key_words = 2ull * K * N;
+    CHECK(hipMalloc(&b.digits, dig_words * 8));
+    CHECK(hipMalloc(&b.target, dig_words * 8));
+    CHECK(hipMalloc(&b.out_ref, out_words * 8));
+    CHECK(hipMalloc(&b.out, out_words * 8));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, b.digits, dig_words, N, b.d_moduli, L, 1u, 0x1111ull);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, b.target, dig_words, N, b.d_moduli, L, 1u, 0x2222ull);
+    std::memset(&b.kp, 0, sizeof(b.kp));
+    for (unsigned j = 0; j < L; j++) {
+        CHECK(hipMalloc(&b.keys[j], key_words * 8));
+        hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, b.keys[j], key_words, N, b.d_moduli, K, 1u, 0x3333ull + j);
+        b.kp.p[j] = b.keys[j];
+    }
+    double *d_fwdp, *d_r1, *d_r2, *d_keys;
+    CHECK(hipMalloc(&d_fwdp, fwdp.size() * 8)); CHECK(hipMemcpy(d_fwdp, fwdp.data(), fwdp.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_r1, r1.size() * 8)); CHECK(hipMemcpy(d_r1, r1.data(), r1.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_r2, r2.size() * 8)); CHECK(hipMemcpy(d_r2, r2.data(), r2.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_keys, (size_t)L * key_words * 8));
+    CHECK(hipDeviceSynchronize());
+
+    NttArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = b.digits; a.out = b.out_ref;
+    a.mods = b.d_mods; a.tw = b.d_fwd;
+    a.in_bstride = (long long)L * N; a.in_pstride = 0; a.in_cstride = N;
+    a.out_bstride = 2ll * (L + 1) * N; a.out_pstride = (long long)(L + 1) * N; a.out_cstride = N;
+    a.pcount = 1; a.ncomp = L + 1;
+    a.table_start = 0; a.table_count = K; a.mode = 1; a.decomp = L;
+    a.reduce_input = 1; a.stream_loads = 0; a.skip_diag = 1;
+    a.ext0 = b.target; a.ext0_bstride = (long long)L * N; a.ext0_cstride = N;
+    a.batch = (unsigned)B; a.key_pstride = (long long)K * N;
+    a.xcd_groups = (B % 8 == 0) ? L + 1 : 0;
+    const unsigned blocks = (unsigned)(B * (L + 1));
+
+    // reference: the shipped kernel shape of round 1 (1024 threads x 16 coefficients)
+    float t_ref = time_launch([&] { hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 4>), dim3(blocks), dim3(1024), 0, 0, a, b.kp); }, reps);
+    printf("%-28s %9.1f us  (reference)\n", "ks_mac<14,4> 1024thr", t_ref);
+    std::vector<u64> ref(out_words), got(out_words);
+    CHECK(hipMemcpy(ref.data(), b.out_ref, out_words * 8, hipMemcpyDeviceToHost));
+
+    auto run_variant = [&](const char* name, const std::function<void(const NttArgs&)>& launch) {
+        if (!wanted(name)) return;
+        NttArgs v = a;
+        v.out = b.out;
+        CHECK(hipMemset(b.out, 0xff, out_words * 8));
+        float t = time_launch([&] { launch(v); }, reps);
+        CHECK(hipMemcpy(got.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t i = 0; i < out_words; i++) if (got[i] != ref[i]) { if (!bad) first = i; bad++; }
+        printf("%-28s %9.1f us  %s", name, t, bad ? "MISMATCH" : "bit-exact");
+        if (bad) printf(" (%zu words, first at %zu: got %llu want %llu)", bad, first, got[first], ref[first]);
+        printf("\n");
+    };
+
+    run_variant("ks_mac<14,5> 512thr", [&](const NttArgs& v) {
+        hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 5>), dim3(blocks), dim3(512), 0, 0, v, b.kp); });
+    KsMacArgs ka;
+    std::memset(&ka, 0, sizeof(ka));
+    ka.digits = b.digits; ka.dig_bstride = (long long)L * N; ka.dig_cstride = N;
+    ka.diag = b.target; ka.diag_bstride = (long long)L * N; ka.diag_cstride = N;
+    ka.out_bstride = 2ll * (L + 1) * N; ka.out_pstride = (long long)(L + 1) * N; ka.out_cstride = N;
+    ka.mods = b.d_mods; ka.tw = b.d_fwd; ka.tw_r1 = d_r1; ka.tw_r2 = d_r2;
+    ka.keys = d_keys; ka.key_jstride = 2ll * K * N; ka.key_pstride = (long long)K * N;
+    ka.L = L; ka.table_start = 0; ka.table_count = K; ka.batch = (unsigned)B; ka.grouped = (B % 8 == 0) ? 1 : 0;
+    float t_prep = time_launch([&] { hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(1024), dim3(256), 0, 0, b.kp, L, 2 * K, N, d_keys); }, reps);
+    printf("%-28s %9.1f us\n", "prepare_keys", t_prep);
+    run_variant("ksmac2", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out;
+        hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    double* d_digf;
+    CHECK(hipMalloc(&d_digf, dig_words * 8));
+    hipLaunchKernelGGL(center_kernel, dim3(4096), dim3(256), 0, 0, b.digits, d_digf, dig_words, N, b.d_moduli, L);
+    run_variant("ksmac2 f64 digits", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out; kv.digits = (const u64*)d_digf;
+        hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    run_variant("ksmac2 1wg/cu", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out;
+        hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 30000, 0, kv); });
+    run_variant("ksmac2 prio", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out;
+        hipLaunchKernelGGL((ksmac2_kernel<14, false, 64>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    run_variant("ksmac2 row-major", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out; kv.grouped = 2;
+        hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    run_variant("ksmac2 ungrouped", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out; kv.grouped = 0;
+        hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    // ablations (timing only; results are wrong by design)
+    auto run_abl = [&](const char* name, auto kern) {
+        if (!wanted("abl")) return;
+        KsMacArgs kv = ka; kv.out = b.out;
+        float t = time_launch([&] { hipLaunchKernelGGL(kern, dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); }, reps);
+        printf("%-28s %9.1f us\n", name, t);
+    };
+    run_abl("abl: no digit loads", ksmac2_kernel<14, false, 1>);
+    run_abl("abl: no key loads", ksmac2_kernel<14, false, 2>);
+    run_abl("abl: no LDS", ksmac2_kernel<14, false, 4>);
+    run_abl("abl: no butterflies", ksmac2_kernel<14, false, 8>);
+    run_abl("abl: no mac", ksmac2_kernel<14, false, 16>);
+    run_abl("abl: no twiddle loads", ksmac2_kernel<14, false, 32>);
+    run_abl("abl: no loads at all", ksmac2_kernel<14, false, 1 | 2 | 32>);
+    run_abl("abl: alu only", ksmac2_kernel<14, false, 1 | 2 | 4 | 32>);
+    run_abl("abl: mem only", ksmac2_kernel<14, false, 8 | 16>);
+    return 0;
+}

@@ -1,0 +1,389 @@
+// ksmac_kernels.hpp -- fused key-switch inner product for whole-limb rings, second generation.
+//
+// Replaces kernel_set_accumulate + ntt + kernel_accumulate_products (reference fgk/switch_key.cu:6-54, :83-154,
+// driven from evaluator_keyswitching_core.cu:904-919): for every item and every output row k <= L
+//     out[k][c] = sum_j  NTT_{q_key(k)}( digit_j mod q_key(k) ) (.) key_j[c][k]          c = 0, 1
+// with the transformed digits living only in registers / LDS.
+//
+// Why a second kernel (profiles/r01_bench_v7_summary.txt): the first one (ks_mac_kernel in
+// ntt_kernels.hpp) runs ONE 1024-thread workgroup per CU at N = 16384.  Its 2 x 16 accumulators + 16 coefficients
+// per thread do not fit the 128-VGPR cap of that shape (28 registers spilled, ~0.85 GB of scratch traffic per
+// 512-item launch), its phases (load, butterflies, LDS exchange, key loads) serialise behind workgroup barriers,
+// the keys are converted u64 -> f64 again for every item and the last butterfly rounds fetch their twiddles with one
+// 128-byte line per lane.
+//
+// Design here (gfx950, wave64, FP64-exact arithmetic of dev_math_f64.hpp, moduli < 2^50):
+//   * A workgroup owns a TILE of 2^13 outputs of one (item, row): the whole limb at N = 8192, one HALF of the
+//     outputs at N = 16384 -- after the first Cooley-Tukey layer the two halves of a negacyclic NTT are independent
+//     transforms, so a half-tile workgroup applies layer 0 while loading (u +- w*v, the twiddle multiply is the
+//     only duplicated work, ~8 % more FP64 ops) and then runs a 13-layer transform in 68 KiB of LDS.  Two
+//     independent workgroups share a CU: one computes while the other waits on HBM / LDS / a barrier.
+//   * 256 threads x 32 coefficients: 3 register rounds (3|4 + 5 + 5 layers) = two LDS exchanges per digit; the
+//     accumulators (2 x 32 doubles) and the coefficients use 192 of the 256 VGPRs available at 2 waves per SIMD.
+//   * Round-2 twiddles come from a lane-interleaved copy of the table (every load instruction reads 1 KiB of
+//     consecutive bytes), round-1 twiddles from a 256-byte vector per wave-half, round-0 twiddles are scalar loads.
+//   * Evaluation keys are prepared once per call (ksmac_prepare_keys_kernel): converted to exact doubles and
+//     permuted to the accumulators' register layout, so the multiply-accumulate reads its digit operand straight
+//     from the registers the last butterfly layer left it in (no transpose through LDS per digit) with 16-byte
+//     coalesced key loads, and spends 7 FP64 operations per term instead of 9.
+//   * LDS index padding of 2 words per 32 keeps every access of the last round a conflict-free 16-byte access.
+// Results are canonical residues, bit-identical to the reference (exactness argument: dev_math_f64.hpp; the growth
+// bound of a 5-layer block that starts from |x| <= p/2 + 1 is 7.7 p < 2^53 for p < 2^50).
+#pragma once
+#include "ntt_kernels.hpp"
+
+namespace troyn {
+
+struct KsMacArgs {
+    const u64* digits; long long dig_bstride, dig_cstride;      // coefficient-form digits [item][j][N]: canonical u64, or
+                                                                 // (DIGF64) the same integers stored as doubles
+    const u64* diag;   long long diag_bstride, diag_cstride;     // NTT-form input limbs [item][j][N]; nullptr: no diagonal shortcut
+    u64* out;          long long out_bstride, out_pstride, out_cstride;   // [item][2][L+1][N]: (item, component, row)
+    const DevModulus* mods;
+    const double* tw;       // [K][N]  forward twiddles w, reference table order
+    const double* tw_r1;    // [K][N/1024][32]  round-1 vector per value of the index bits above bit 9
+    const double* tw_r2;    // [K][N]  round-2 vectors, lane-interleaved (ksmac_r2_slot)
+    const double* keys;     // prepared keys [L][2][KEYROWS][N] (ksmac_prepare_keys_kernel)
+    long long key_jstride, key_pstride;   // elements between keys j / between the two components
+    unsigned L;             // digits = data limbs; rows = L + 1
+    unsigned table_start, table_count;    // row k uses modulus table_start + (k == L ? table_count - 1 : k)
+    unsigned batch;
+    unsigned grouped;       // 1: the (L+1) * HALVES workgroups of an item are dealt to one XCD (batch % 8 == 0)
+};
+
+constexpr int KSM_TB = 13;                  // tile bits
+constexpr int KSM_THREADS = 1 << (KSM_TB - 5);
+__host__ __device__ constexpr unsigned ksm_phys(unsigned w) { return w + 2u * (w >> 5); }     // LDS word -> padded word
+constexpr unsigned KSM_LDS_WORDS = (1u << KSM_TB) + 2u * ((1u << KSM_TB) >> 5);
+
+// position of natural index i (within one limb) in the prepared-key / round-2 layouts: blocks of 2048 words =
+// 64 lanes x 32 registers are stored as [m = reg/2][lane][reg%2], so that lane-consecutive 16-byte loads are contiguous
+__host__ __device__ constexpr unsigned ksm_perm(unsigned i) {
+    return (i & ~2047u) | ((((i >> 1) & 15u) * 64u + ((i >> 5) & 63u)) * 2u) | (i & 1u);
+}
+
+// keys[j] -> [2][K][N] u64 (the reference's KSwitchKeys layout)  ==>  prepared [j][2][K][N] doubles, permuted
+__global__ __launch_bounds__(256) void ksmac_prepare_keys_kernel(KeyPtrs keys, unsigned L, unsigned rows_per_key, unsigned n, double* out) {
+    const size_t pairs_per_key = (size_t)rows_per_key * (n / 2);
+    const size_t total = (size_t)L * pairs_per_key;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const unsigned j = (unsigned)(p / pairs_per_key);
+        const size_t q = p % pairs_per_key;
+        const size_t row = q / (n / 2);
+        const unsigned i = (unsigned)(q % (n / 2)) * 2u;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(keys.p[j] + row * n + i);
+        double2 d = make_double2(f64_from_u64(v.x), f64_from_u64(v.y));
+        *reinterpret_cast<double2*>(out + ((size_t)j * rows_per_key + row) * n + ksm_perm(i)) = d;
+    }
+}
+
+// A pointer every lane agrees on, pinned to scalar registers: loads through (uniform base + 32-bit lane offset + immediate)
+// then use the scalar-base addressing form instead of a 64-bit address per lane (and per loop iteration).
+template <class P>
+__device__ __forceinline__ P* ksm_uniform(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+// load a V from (uniform global base) + (32-bit lane byte offset): global address space, scalar-base addressing form
+template <class V> struct ksm_native;
+template <> struct ksm_native<double2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct ksm_native<ulonglong2> { typedef u64 type __attribute__((ext_vector_type(2))); };
+template <class V>
+__device__ __forceinline__ V ksm_gload(const void* ubase, unsigned byte_off) {
+    typedef typename ksm_native<V>::type NV;
+    typedef const char __attribute__((address_space(1)))* gcp;
+    typedef const NV __attribute__((address_space(1)))* gvp;
+    const NV v = *(gvp)((gcp)(unsigned long long)ubase + byte_off);
+    V r; r.x = v.x; r.y = v.y;
+    return r;
+}
+
+// y * w mod p (lazy, signed) with the quotient estimated from the rounded product itself: q = rint(fl(y*w) * fl(1/p)) is
+// within 0.5 + 1.5 |y| 2^-52 of y*w/p -- the bound of f64_mulc (dev_math_f64.hpp) -- and needs no per-twiddle w/p.
+__device__ __forceinline__ double ksm_mulq(double y, double w, double inv_p, double p) {
+    const double h = y * w;
+    const double l = __builtin_fma(y, w, -h);
+    const double q = __builtin_rint(h * inv_p);
+    return __builtin_fma(-q, p, h) + l;
+}
+
+// butterflies of register bit RB for the twiddle groups [G0, G0 + NG): tw[i] belongs to group G0 + i
+template <int RB, int G0, int NG, bool NOBF = false>
+__device__ __forceinline__ void ksm_layer(double (&x)[32], const double* tw, double inv_p, double p) {
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = G0 + decltype(gc)::value;
+        const double w = tw[decltype(gc)::value];
+        static_for<0, (1 << RB)>([&](auto oc) {
+            constexpr int R0 = (g << (RB + 1)) | decltype(oc)::value, R1 = R0 | (1 << RB);
+            const double r = NOBF ? w : ksm_mulq(x[R1], w, inv_p, p);
+            const double u = x[R0];
+            x[R0] = u + r; x[R1] = u - r;
+        });
+    });
+}
+
+// A 5-layer register round whose 31 twiddles sit in a 32-slot vector (slot (1 << lvl) + g; slot 0 unused), fetched 8
+// slots at a time one step ahead of the butterflies that use them.  ld(q) returns slots 2q, 2q+1.
+// first/second: slots 0..7 and 8..15, already requested by the caller (before the LDS exchange that feeds the round).
+template <bool NOBF = false, class LD>
+__device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], double (&tb)[8], LD&& ld, double inv_p, double p) {
+    ksm_layer<4, 0, 1, NOBF>(x, ta + 1, inv_p, p);
+    ksm_layer<3, 0, 2, NOBF>(x, ta + 2, inv_p, p);
+    ksm_layer<2, 0, 4, NOBF>(x, ta + 4, inv_p, p);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 4>([&](auto qc) { const double2 v = ld(8 + decltype(qc)::value); ta[2 * decltype(qc)::value] = v.x; ta[2 * decltype(qc)::value + 1] = v.y; });
+    ksm_layer<1, 0, 8, NOBF>(x, tb, inv_p, p);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 4>([&](auto qc) { const double2 v = ld(12 + decltype(qc)::value); tb[2 * decltype(qc)::value] = v.x; tb[2 * decltype(qc)::value + 1] = v.y; });
+    ksm_layer<0, 0, 8, NOBF>(x, ta, inv_p, p);
+    __builtin_amdgcn_sched_barrier(0);
+    ksm_layer<0, 8, 8, NOBF>(x, tb, inv_p, p);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads all hit one cache line,
+// bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
+template <int LOGN, bool DIGF64, int ABL = 0>
+__global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
+    constexpr auto abl = [](int bit) constexpr { return ((ABL >> bit) & 1) != 0; };
+    static_assert(LOGN == 13 || LOGN == 14, "ksmac2 covers N = 8192 and N = 16384");
+    constexpr bool SPLIT = LOGN == 14;
+    constexpr unsigned N = 1u << LOGN;
+    constexpr int HALVES = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) u64 lds[KSM_LDS_WORDS];
+
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if constexpr (abl(6)) {
+        // two workgroups share a CU: the one in the upper LDS slot yields VALU issue to the other, so that the pair does not
+        // run its compute and memory phases in lock-step
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);     // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+    }
+    // ---- workgroup -> (item, row, half) ------------------------------------------------------------------
+    unsigned b, k, h;
+    {
+        const unsigned G = (a.L + 1) * HALVES;
+        unsigned g;
+        if (a.grouped == 2) {
+            // row-major: the whole chip works on one output row at a time, so that row's 2L key limbs (1.3 MB at cfg3) stay
+            // in every XCD's L2; the halves of an item sit 8 workgroups apart = on the same XCD, back to back
+            const unsigned per = 8u * HALVES, r = blockIdx.x % per, q = blockIdx.x / per;
+            h = r / 8u; b = (q % (a.batch / 8u)) * 8u + (r % 8u); k = q / (a.batch / 8u);
+        } else {
+        if (a.grouped) {
+            const unsigned per = 8u * G, r = blockIdx.x % per;
+            g = r / 8u; b = (blockIdx.x / per) * 8u + (r % 8u);
+        } else {
+            g = blockIdx.x % G; b = blockIdx.x / G;
+        }
+        k = g / HALVES; h = g % HALVES;
+        }
+    }
+    const unsigned mrow = (k == a.L) ? a.table_count - 1 : k;    // row of the key / modulus slot
+    const unsigned mi = a.table_start + mrow;
+    const DevModulus dm = a.mods[mi];
+    const F64Mod fm{dm.pd, dm.inv_pd};
+    const double p = fm.p, inv_p = fm.inv_p;
+
+    typedef const double __attribute__((address_space(4)))* cdp;
+    const cdp tws = (cdp)(unsigned long long)(a.tw + (size_t)mi * N);       // scalar (wave-uniform) twiddle fetches
+
+    // every global address below is (workgroup-uniform base) + (32-bit per-thread byte offset) + immediate, so the loads use
+    // the scalar-base addressing form and no 64-bit address lives in VGPRs
+    auto at = [](const void* ubase, unsigned byte_off) { return reinterpret_cast<const char*>(ubase) + byte_off; };
+    const double* r1u = a.tw_r1 + ((size_t)mi * (N >> 10) + h * (KSM_THREADS >> 5)) * 32;   // index bits above bit 9 = T >> 5
+    const double* r2u = a.tw_r2 + (size_t)mi * N + (size_t)h * (KSM_THREADS * 32);
+    unsigned r1off = (t >> 5) * 256u, slice_off = wave * 16384u + lane * 16u;                // bytes
+
+    double acc0[32], acc1[32];
+    static_for<0, 32>([&](auto rc) { acc0[decltype(rc)::value] = 0.0; acc1[decltype(rc)::value] = 0.0; });
+
+    // LDS addresses (padded words).  Round 0 holds registers r = b0 | b9<<1 | R3<<2 of tile index
+    // b0 | t<<1 | b9<<9 | R3<<10; round 1 holds bits [5,10); round 2 holds bits [0,5).
+    const unsigned p0 = ksm_phys(t << 1);                                             // + ksm_phys(b9<<9 | R3<<10): multiples of 32 words
+    const unsigned p1 = ksm_phys((t & 31u) | ((t >> 5) << 10));                       // + 34 * R
+    const unsigned p2 = ksm_phys(t << 5);                                             // + R  (R < 32: no pad crossed)
+    const unsigned pt = ksm_phys(wave * 2048u + lane * 2u);                            // transposed pairs: + ksm_phys(128 m)
+
+    const double* kbase = a.keys + (size_t)mrow * N + (size_t)h * (KSM_THREADS * 32);
+    const u64* dig_item = a.digits + (long long)b * a.dig_bstride;
+
+    // one <digit, key> term per register:  acc += v * key  (mod p, lazy: |term| <= 0.69 p)
+    auto mac2 = [&](double& a0, double& a1, double v, double y0, double y1) {
+        const double h0 = v * y0, h1 = v * y1;
+        const double l0 = __builtin_fma(v, y0, -h0), l1 = __builtin_fma(v, y1, -h1);
+        const double q0 = __builtin_rint(h0 * inv_p), q1 = __builtin_rint(h1 * inv_p);
+        a0 += __builtin_fma(-q0, p, h0) + l0;
+        a1 += __builtin_fma(-q1, p, h1) + l1;
+    };
+    // multiply-accumulate the 32 registers v[] with key j, two registers per 16-byte key load; the key loads run AHEAD
+    // pairs ahead of the arithmetic (8 VGPRs per pair in flight).  v is re-centred here (|v| <= p/2 + 1).
+    auto mac_all = [&](double (&v)[32], unsigned j) {
+        const double* k0 = ksm_uniform(kbase + (long long)j * a.key_jstride);
+        const double* k1 = ksm_uniform(k0 + a.key_pstride);
+        constexpr int AHEAD = 3;
+        const unsigned koff = abl(1) ? (slice_off & 16u) : slice_off;
+        double2 y0[16], y1[16];
+        static_for<0, AHEAD>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            y0[m] = ksm_gload<double2>(k0 + (abl(1) ? 0 : m * 128), koff);
+            y1[m] = ksm_gload<double2>(k1 + (abl(1) ? 0 : m * 128), koff);
+        });
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m + AHEAD < 16) {
+                y0[m + AHEAD] = ksm_gload<double2>(k0 + (abl(1) ? 0 : (m + AHEAD) * 128), koff);
+                y1[m + AHEAD] = ksm_gload<double2>(k1 + (abl(1) ? 0 : (m + AHEAD) * 128), koff);
+            }
+            if constexpr (abl(4)) { acc0[2 * m] += v[2 * m] + y0[m].x + y1[m].x; acc1[2 * m + 1] += v[2 * m + 1] + y0[m].y + y1[m].y; return; }
+            const double v0 = f64_corr(v[2 * m], fm), v1 = f64_corr(v[2 * m + 1], fm);
+            mac2(acc0[2 * m], acc1[2 * m], v0, y0[m].x, y1[m].x);
+            mac2(acc0[2 * m + 1], acc1[2 * m + 1], v1, y0[m].y, y1[m].y);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // a digit word as it enters the transform
+    auto dig_in = [&](u64 raw) -> double {
+        if constexpr (DIGF64) return f64_bits_to_double(raw);
+        else return f64_from_u64(raw);
+    };
+
+    for (unsigned it = 0; it < a.L; ++it) {
+        double x[32];
+        // nothing below depends on the digit except the input and the key: without these the compiler hoists every
+        // twiddle load (and its w/p product) out of the digit loop and spills them
+        asm volatile("" : "+v"(r1off), "+v"(slice_off));
+        if (a.diag && it == k) {
+            // the digit of row k under its own modulus is the NTT-form input limb (evaluator_keyswitching_core.cu:851-852):
+            // coalesced load, transpose through the wave's own LDS slice into the accumulators' layout
+            const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const ulonglong2 v = ksm_gload<ulonglong2>(dg + m * 128, slice_off);
+                *reinterpret_cast<ulonglong2*>(&lds[pt + ksm_phys(m * 128u)]) = v;
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[p2 + 2 * m]);
+                x[2 * m] = f64_from_u64(v.x);
+                x[2 * m + 1] = f64_from_u64(v.y);
+            });
+        } else {
+        // ---- load (+ layer 0 for a half tile), two steps of 8 register pairs ---------------------------------
+        const u64* gin_u = ksm_uniform(dig_item + (long long)it * a.dig_cstride);
+        const unsigned gin_off = abl(0) ? ((t << 4) & 16u) : (t << 4);
+        if constexpr (SPLIT) {
+            const double w1 = tws[1];
+            const double sgn = h ? -1.0 : 1.0;       // upper half of the outputs: u - w*v
+            static_for<0, 2>([&](auto hc) {
+                constexpr int hb = decltype(hc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                ulonglong2 ru[8], rv[8];
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = hb * 8 + decltype(ic)::value;     // i = b9 | R3<<1
+                    ru[decltype(ic)::value] = ksm_gload<ulonglong2>(gin_u + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
+                    rv[decltype(ic)::value] = ksm_gload<ulonglong2>(gin_u + 8192 + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
+                });
+                __builtin_amdgcn_sched_barrier(0);     // all 16 loads of the step are in flight before the first is consumed
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int j = decltype(ic)::value, i = hb * 8 + j;
+                    const double u0 = dig_in(ru[j].x), u1 = dig_in(ru[j].y), v0 = dig_in(rv[j].x), v1 = dig_in(rv[j].y);
+                    // 0 <= u, v < 2^50: one re-centring after the layer instead of one per input
+                    x[2 * i] = f64_corr(__builtin_fma(sgn, ksm_mulq(v0, w1, inv_p, p), u0), fm);
+                    x[2 * i + 1] = f64_corr(__builtin_fma(sgn, ksm_mulq(v1, w1, inv_p, p), u1), fm);
+                });
+            });
+        } else {
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const ulonglong2 v = ksm_gload<ulonglong2>(gin_u + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
+                x[2 * i] = f64_corr(dig_in(v.x), fm);
+                x[2 * i + 1] = f64_corr(dig_in(v.y), fm);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- round 0: tile bits 12, 11, 10 = register bits 4, 3, 2; twiddles are workgroup-uniform ----------
+        static_for<0, 3>([&](auto lc) {
+            constexpr int li = decltype(lc)::value;
+            constexpr int bit = 12 - li, rb = 4 - li;
+            static_for<0, (1 << li)>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                const unsigned idx = (N >> (bit + 1)) + (SPLIT ? (h << (12 - bit)) : 0u) + g;
+                const double w = tws[idx];
+                static_for<0, (1 << rb)>([&](auto oc) {
+                    constexpr int R0 = (g << (rb + 1)) | decltype(oc)::value, R1 = R0 | (1 << rb);
+                    const double r = abl(3) ? w : ksm_mulq(x[R1], w, inv_p, p);
+                    const double u = x[R0];
+                    x[R0] = u + r; x[R1] = u - r;
+                });
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange 0 -> 1 -------------------------------------------------------------------------------
+        double ta[8], tb[8];
+        if constexpr (!abl(2)) __builtin_amdgcn_s_barrier();     // every wave has finished reading its slice of the previous digit
+        if constexpr (!abl(2)) static_for<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr unsigned off = ksm_phys(((i & 1) << 9) | ((i >> 1) << 10));
+            double2 v = make_double2(f64_corr(x[2 * i], fm), f64_corr(x[2 * i + 1], fm));
+            *reinterpret_cast<double2*>(&lds[p0 + off]) = v;
+        });
+        // the first 16 twiddle slots of round 1 travel while the exchange completes (x is dead here)
+        static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r1u + (abl(5) ? 0 : 2 * q), r1off); ta[2 * q] = v.x; ta[2 * q + 1] = v.y; });
+        static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r1u + (abl(5) ? 0 : 8 + 2 * q), r1off); tb[2 * q] = v.x; tb[2 * q + 1] = v.y; });
+        if constexpr (!abl(2)) __syncthreads();
+        if constexpr (!abl(2)) static_for<0, 32>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            x[R] = f64_bits_to_double(lds[p1 + 34 * R]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- round 1: tile bits 9..5 = register bits 4..0 ----------------------------------------------------
+        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r1u + (abl(5) ? 0 : 2 * q), r1off); }, inv_p, p);
+        // ---- exchange 1 -> 2 -------------------------------------------------------------------------------
+        if constexpr (!abl(2)) static_for<0, 32>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            lds[p1 + 34 * R] = f64_double_to_bits(f64_corr(x[R], fm));
+        });
+        static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * q), abl(5) ? (slice_off & 16u) : slice_off); ta[2 * q] = v.x; ta[2 * q + 1] = v.y; });
+        static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * (4 + q)), abl(5) ? (slice_off & 16u) : slice_off); tb[2 * q] = v.x; tb[2 * q + 1] = v.y; });
+        if constexpr (!abl(2)) __syncthreads();
+        if constexpr (!abl(2)) static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const double2 v = *reinterpret_cast<const double2*>(&lds[p2 + 2 * m]);
+            x[2 * m] = v.x; x[2 * m + 1] = v.y;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- round 2: tile bits 4..0 = register bits 4..0, lane-interleaved twiddle vectors --------------------
+        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * q), abl(5) ? (slice_off & 16u) : slice_off); }, inv_p, p);
+        }
+        // ---- multiply-accumulate with key `it` straight from the registers ---------------------------------------
+        mac_all(x, it);
+        if ((it & 7u) == 7u)
+            static_for<0, 32>([&](auto rc) { acc0[decltype(rc)::value] = f64_corr(acc0[decltype(rc)::value], fm); acc1[decltype(rc)::value] = f64_corr(acc1[decltype(rc)::value], fm); });
+    }
+
+    // ---- canonical results, transposed through the wave's own LDS slice, 16-byte coalesced stores --------------
+    u64* go = a.out + (long long)b * a.out_bstride + (long long)k * a.out_cstride + (size_t)h * (KSM_THREADS * 32);
+    static_for<0, 2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const ulonglong2 v = make_ulonglong2(f64_canon(c ? acc1[2 * m] : acc0[2 * m], fm), f64_canon(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm));
+            *reinterpret_cast<ulonglong2*>(&lds[p2 + 2 * m]) = v;
+        });
+        __builtin_amdgcn_wave_barrier();
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[pt + ksm_phys(m * 128u)]);
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + (long long)c * a.out_pstride + m * 128, slice_off))), v.x, v.y);
+        });
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
+}  // namespace troyn

@@ -18,6 +18,7 @@
 #include "ring2k_kernels.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
+#include "ksmac_kernels.hpp"
 #include "poly_kernels.hpp"
 
 using namespace troyn;
@@ -95,6 +96,9 @@ struct troyn_plan {
     double* d_inv_f64 = nullptr;          // [K][N]
     std::vector<char> small_modulus;      // [K] 1 iff q < 2^50 (FP64 fast path usable)
     ulonglong2* d_inv_last = nullptr;     // [(K+1)][K]: row L holds q_{L-1}^-1 mod q_i, i < L-1
+    // ksmac2_kernel (N = 8192 / 16384, moduli < 2^50): the forward twiddles in the order its register rounds read them
+    double* d_fwd_r1 = nullptr;           // [K][N/1024][32]
+    double* d_fwd_r2 = nullptr;           // [K][N], lane-interleaved (ksm_perm)
 };
 
 static DevModulus make_dev_modulus(u64 q, unsigned log_n, bool with_inv_n) {
@@ -166,6 +170,27 @@ static int plan_upload(troyn_plan* p) {
         for (size_t x = 0; x < n; x++) tmp[x] = (double)p->tables[i].inv[x].operand;
         HIP_TRY(hipMemcpy(p->d_inv_f64 + i * n, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (p->log_n == 13 || p->log_n == 14) {
+        // round vectors of ksmac2_kernel: slot s = (1 << lvl) + g of the thread (round 2) / of the index bits above
+        // bit 9 (round 1) holds the twiddle of butterfly group g of the round's layer lvl (ksmac_kernels.hpp)
+        const size_t r1n = (n >> 10) * 32;
+        std::vector<double> r1(K * r1n, 0.0), r2(K * n, 0.0);
+        for (size_t i = 0; i < K; i++) {
+            if (!p->small_modulus[i]) continue;
+            const auto& fw = p->tables[i].fwd;
+            for (unsigned s = 1; s < 32; s++) {
+                unsigned lvl = 0;
+                while ((2u << lvl) <= s) lvl++;
+                const unsigned g = s - (1u << lvl);
+                for (size_t th = 0; th < (n >> 10); th++) r1[i * r1n + th * 32 + s] = (double)fw[(((n >> 10) + th) << lvl) + g].operand;
+                for (size_t T = 0; T < (n >> 5); T++) r2[i * n + ksm_perm((unsigned)(T * 32 + s))] = (double)fw[(((n >> 5) + T) << lvl) + g].operand;
+            }
+        }
+        HIP_TRY(hipMalloc(&p->d_fwd_r1, r1.size() * sizeof(double)));
+        HIP_TRY(hipMalloc(&p->d_fwd_r2, r2.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(p->d_fwd_r1, r1.data(), r1.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_fwd_r2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return TROYN_OK;
 }
 
@@ -177,6 +202,8 @@ static void plan_free(troyn_plan* p) {
     if (p->d_inv_last) (void)hipFree(p->d_inv_last);
     if (p->d_fwd_f64) (void)hipFree(p->d_fwd_f64);
     if (p->d_inv_f64) (void)hipFree(p->d_inv_f64);
+    if (p->d_fwd_r1) (void)hipFree(p->d_fwd_r1);
+    if (p->d_fwd_r2) (void)hipFree(p->d_fwd_r2);
     delete p;
 }
 
@@ -472,7 +499,7 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // key switching
 // ---------------------------------------------------------------------------------------
 struct KsLayout {
-    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, total;  // element offsets
+    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, total;  // element offsets
 };
 
 static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
@@ -484,6 +511,7 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.poly_prod = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
+    w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n;     // prepared keys of ksmac2_kernel
     w.total = off;
     return w;
 }
@@ -542,7 +570,30 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
     //     (L+1)*L transformed digits never reach HBM.
     const bool mac_fused = !g_ks_unfused_mac && p->log_n >= 10 && p->log_n <= 14 && batch * (size_t)(L + 1) <= 0x7fffffffull;
-    if (mac_fused) {
+    static int ks_mac_gen = -1;     // TROYN_KS_MAC=v1 keeps the first-generation fused kernel (A/B testing)
+    if (ks_mac_gen < 0) { const char* e = getenv("TROYN_KS_MAC"); ks_mac_gen = (e && std::strcmp(e, "v1") == 0) ? 1 : 2; }
+    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 1) * 2 <= 0x7fffffffull) {
+        // ksmac2_kernel: tiles of 2^13 outputs, two workgroups per CU, keys prepared once per call (ksmac_kernels.hpp)
+        double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
+        {
+            const size_t pairs = (size_t)L * 2 * K * (n / 2);
+            const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
+            hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(blocks), dim3(256), 0, s, kp, L, 2 * K, n, kf);
+            LAUNCH_CHECK();
+        }
+        KsMacArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.digits = digits_src; a.dig_bstride = (long long)digits_bstride; a.dig_cstride = n;
+        a.diag = is_ntt_form ? target : nullptr; a.diag_bstride = (long long)target_bstride; a.diag_cstride = n;
+        a.out = ws + w.poly_prod; a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
+        a.mods = p->d_mods; a.tw = p->d_fwd_f64; a.tw_r1 = p->d_fwd_r1; a.tw_r2 = p->d_fwd_r2;
+        a.keys = kf; a.key_jstride = 2ll * K * n; a.key_pstride = (long long)K * n;
+        a.L = L; a.table_start = 0; a.table_count = K; a.batch = (unsigned)batch;
+        a.grouped = (batch % 8 == 0) ? 1u : 0u;
+        if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, a);
+        LAUNCH_CHECK();
+    } else if (mac_fused) {
         NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
         a.in_bstride = (long long)digits_bstride; a.in_pstride = 0; a.in_cstride = n;
         a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
