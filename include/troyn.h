@@ -51,6 +51,16 @@ typedef struct troyn_behz troyn_behz;
 const char* troyn_last_error(void);
 int troyn_version(void);
 
+/* Measurement hook (the reference times its kernels with bench::Timer around whole calls, test/bench/he_operations.cu:57-104;
+ * a fused call here contains several launches, so the library can bracket ONE named launch with hipEvents on the launch stream).
+ *   troyn_kernel_timer_enable(region, on)   start / stop recording an event pair around every launch of that region
+ *   troyn_kernel_timer_read(region, &ms, &n) wait for the recorded events, return their summed duration and count, and clear
+ * Region TROYN_TIMER_KS_INNER_PRODUCT = the fused key-switch inner product (kernel_set_accumulate + ntt +
+ * kernel_accumulate_products of fgk/switch_key.cu, one launch here). */
+enum { TROYN_TIMER_KS_INNER_PRODUCT = 0, TROYN_TIMER_REGIONS = 1 };
+int troyn_kernel_timer_enable(int region, int on);
+int troyn_kernel_timer_read(int region, double* total_ms, uint64_t* launches);
+
 /* Host-only helpers (no GPU touched) so that a host can build the same parameter sets as the
  * reference: CoeffModulus::create (coeff_modulus.cu:65-108: for every bit size the k largest primes
  * = 1 mod 2N, handed out smallest-first) and utils::get_primes (utils/number_theory.cu:22-39). */

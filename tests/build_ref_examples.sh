@@ -1,9 +1,10 @@
 #!/bin/bash
 # Builds the reference's OWN example programs (/root/reference/examples/*.cu, compiled where they lie -- nothing is copied into the
-# repo) against this repository's host-side mirror (troy-nova_amd/troy/*.h, libtroy_amd.so) into oracle/_ref/ref_examples.
+# repo) against this repository's host-side mirror (troy-nova_amd/troy/*.h, libtroy_amd.so) into tests/_ref_examples/ref_examples.
 # Purpose: the drop-in check of SURVEY 8b -- a program written for the reference compiles unchanged against the mirror and, on the
 # GPU box, runs on the HIP path (tests/test_gpu_ref_examples.py).  Test infrastructure only; needs /root/reference, so it runs in the
-# build container (the GPU box uses the prebuilt binary, like oracle/_ref's other artefacts).
+# build container (the GPU box uses the prebuilt binary).  This is NOT a build of the reference library (that would
+# live under oracle/_ref and needs the CUDA toolkit): only the reference's example CALLERS, linked against this implementation.
 #   * the examples include "examples.h", which includes "../src/troy.h": the sources are fed to the compiler on stdin so that the
 #     include resolves to a generated header (this mirror's headers + the helper functions of the reference's examples.h) in the
 #     scratch build directory; the generated header is not kept.
@@ -33,7 +34,7 @@ for f in "$REF"/examples/*.cu; do
 done
 printf '#include <iostream>\nvoid example_issue_multithread() { std::cout << "skipped: a CUDA kernel-launch demonstration, not a user of the library API" << std::endl; }\n' > "$BUILD/stub.cpp"
 g++ $CXXFLAGS -c -o "$BUILD/stub.o" "$BUILD/stub.cpp"
-mkdir -p "$ROOT/oracle/_ref"
-g++ -o "$ROOT/oracle/_ref/ref_examples" $OBJS "$BUILD/stub.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
+mkdir -p "$ROOT/tests/_ref_examples"
+g++ -o "$ROOT/tests/_ref_examples/ref_examples" $OBJS "$BUILD/stub.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
     -Wl,-rpath,'$ORIGIN/../../troy-nova_amd' -Wl,-rpath,/opt/rocm/lib
-echo "built oracle/_ref/ref_examples"
+echo "built tests/_ref_examples/ref_examples"

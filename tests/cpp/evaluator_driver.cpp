@@ -134,11 +134,14 @@ int main(int argc, char** argv) {
     if (bgv && (next.correction_factor() == 1 || relin.correction_factor() != 1)) { std::cerr << "FAIL: BGV correction factor bookkeeping\n"; failures++; }
     {
         Ciphertext last = a;
+        if (ckks) last.scale() = 1048576.0;   // 2^20: a scale that is still within bounds at the last level (is_scale_within_bounds, evaluator_utils.h:307-323)
         while (last.parms_id() != context->last_parms_id()) evaluator.mod_switch_to_next_inplace(last);
         if (!throws_invalid_argument([&] { evaluator.mod_switch_to_next_new(last); })) { std::cerr << "FAIL: end of chain accepted\n"; failures++; }
     }
     bool oor = false;
-    try { Ciphertext c4 = evaluator.multiply_new(prod, a); evaluator.relinearize_new(c4, rk); } catch (const std::out_of_range&) { oor = true; } catch (...) {}
+    Ciphertext prod_small = prod, a_small = a;
+    if (ckks) { prod_small.scale() = 2.0; a_small.scale() = 2.0; }   // keep the 4-polynomial product's scale within bounds (evaluator.cu:140-143)
+    try { Ciphertext c4 = evaluator.multiply_new(prod_small, a_small); evaluator.relinearize_new(c4, rk); } catch (const std::out_of_range&) { oor = true; } catch (...) {}
     if (!oor) { std::cerr << "FAIL: missing relin key power not reported as out_of_range\n"; failures++; }
 
     MemoryPool::Destroy();

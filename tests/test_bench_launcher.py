@@ -1,0 +1,50 @@
+"""bench.py's multi-GPU entry on CPU: the partition it would use, the self-launcher (`--gpus N` without torchrun
+starts N rank processes and relays rank 0's line) and its refusal of a world size that is not the one asked for."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_dry_shard_partitions_the_job():
+    r = _run(["--gpus", "2", "--dry-shard", "--workload", "cfg4"])
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["ranges"] == [[0, 512], [512, 1024]]
+    r = _run(["--gpus", "8", "--dry-shard", "--total", "1001"])
+    parts = json.loads(r.stdout.strip().splitlines()[-1])["ranges"]
+    assert parts[0][0] == 0 and parts[-1][1] == 1001 and all(parts[i][1] == parts[i + 1][0] for i in range(7))
+
+
+def test_self_launcher_starts_two_ranks():
+    r = _run(["--gpus", "2", "--dry-run", "--workload", "cfg4"])
+    assert r.returncode == 0, r.stderr
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["keys_broadcast_ok"] and j["items_covered"] == 1024 and j["rank0_range"] == [0, 512]
+    assert j["max_elapsed"] == 0.002 and j["scaling"] == "strong"
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "4", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_self_launcher_one_gpu():
+    """the launcher path on real hardware: a fresh rank process is started before anything touches the GPU"""
+    r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-extra"], env_extra={"TROYN_BENCH_SPAWN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["launches_timed"] == 3

@@ -1,0 +1,167 @@
+"""GPU parity on the corners of the exact-FP64 arithmetic policy (csrc/dev_math_f64.hpp, ksmac_kernels.hpp).
+
+The optimised kernels carry residues below 2^50 as integer-valued doubles and rely on magnitude bounds (a block of 5 butterfly layers
+that starts re-centred stays below 2^53).  Uniform random residues sit in the middle of those bounds; the vectors here sit on their
+edges: every coefficient q-1, alternating 0 / q-1, the largest lazy inputs the reference allows (4q-1 forward, 2q-1 inverse), impulses
+in every position class, (q-1)/2 and (q+1)/2 (the re-centring boundary) -- for the six largest 50-bit primes (BASELINE config 3's
+chain, the primes closest to the 2^50 limit of the policy) and for a chain that straddles 2^50 (the policy switches to the integer
+butterflies).  Expected values come from the oracle's integer arithmetic; everything is compared bit for bit through the C-ABI.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _is_prime(n):
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def _first_prime_above(bound, factor):
+    v = (bound // factor + 1) * factor + 1
+    while not _is_prime(v):
+        v += factor
+    return v
+
+
+def _patterns(q, n, lazy_mult):
+    """corner polynomials of one limb: name -> uint64[n] (values below lazy_mult * q)"""
+    top = lazy_mult * q - 1
+    idx = np.arange(n)
+    pats = {
+        "all_q-1": np.full(n, q - 1, dtype=np.uint64),
+        "alt_0_q-1": np.where(idx % 2 == 0, 0, q - 1).astype(np.uint64),
+        "alt_q-1_0": np.where(idx % 2 == 0, q - 1, 0).astype(np.uint64),
+        "blocks32": np.where((idx // 32) % 2 == 0, q - 1, 1).astype(np.uint64),
+        "lazy_top": np.full(n, top, dtype=np.uint64),
+        "half_lo": np.full(n, (q - 1) // 2, dtype=np.uint64),
+        "half_hi": np.full(n, (q + 1) // 2, dtype=np.uint64),
+        "ramp_top": ((q - 1 - idx) % q).astype(np.uint64),
+    }
+    for pos in (0, 1, 31, 32, n // 2 - 1, n // 2, n - 1):
+        v = np.zeros(n, dtype=np.uint64)
+        v[pos] = q - 1
+        pats["impulse_%d" % pos] = v
+    return pats
+
+
+def _chains(O, n):
+    """(name, moduli): the largest 50-bit primes = 1 mod 2n (FP64 policy) and a chain straddling 2^50 (integer policy)"""
+    below = O.coeff_modulus_create(n, [50] * 6)
+    above = _first_prime_above(1 << 50, 2 * n)
+    assert max(below) < (1 << 50) < above
+    return [("six_50bit", below), ("straddle_2^50", [max(below), above, min(below)])]
+
+
+@pytest.mark.parametrize("log_n", [13, 14, 15])
+def test_ntt_corner_vectors(O, pkg, dev, log_n):
+    n = 1 << log_n
+    for cname, q in _chains(O, n):
+        L = len(q)
+        tables = [O.NTTTables(log_n, qi) for qi in q]
+        plan = pkg.Plan(dev, log_n, q)
+        for inverse, lazy in ((False, 4), (True, 2)):
+            names = sorted(_patterns(q[0], n, lazy))
+            x = np.stack([np.stack([_patterns(q[j], n, lazy)[nm] for j in range(L)]) for nm in names])   # [pattern][limb][n]
+            d = pkg.to_device(x.reshape(len(names), 1, L, n), dev)
+            plan.ntt(d, 1, L, inverse=inverse)
+            got = pkg.to_host(d).reshape(len(names), L, n)
+            exp = x.copy().reshape(-1)
+            (O.ntt_inverse if inverse else O.ntt_forward)(exp, len(names), L, log_n, tables)
+            exp = exp.reshape(len(names), L, n)
+            for i, nm in enumerate(names):
+                assert np.array_equal(got[i], exp[i]), "%s N=%d %s pattern %s" % (cname, n, "INTT" if inverse else "NTT", nm)
+
+
+def _corner_ct(q, L, n, pcount, name):
+    return np.stack([np.stack([_patterns(q[j], n, 1)[name] for j in range(L)]) for _ in range(pcount)])
+
+
+@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [50] * 6, 5), (8192, [40] * 11, 10), (4096, [36] * 10, 9)])
+def test_switch_key_corner_vectors(O, pkg, dev, n, bits, L):
+    """the fused inner product: extreme targets against random keys AND against keys that are all q-1 (largest <digit, key> terms;
+    L = 9 / 10 also crosses the accumulators' re-centring after 8 digits)"""
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    K = len(q)
+    rkeys = ctx.random_keys(3, L)
+    ckeys = [np.stack([np.stack([np.full(n, q[k] - 1, dtype=np.uint64) for k in range(K)]) for _ in range(2)]) for _ in range(L)]
+    for keys in (rkeys, ckeys):
+        dkeys = [pkg.to_device(k, dev) for k in keys]
+        names = ["all_q-1", "alt_0_q-1", "half_hi", "impulse_0", "impulse_%d" % (n - 1), "ramp_top"]
+        tg = np.stack([_corner_ct(q, L, n, 1, nm)[0] for nm in names] + [ctx.random_ct(5, 1, L)[0], ctx.random_ct(6, 1, L)[0]])   # batch of 8
+        for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE):
+            d0 = np.stack([_corner_ct(q, L, n, 2, "all_q-1") for _ in range(tg.shape[0])])
+            dd = pkg.to_device(d0, dev)
+            plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=assign, is_ckks=True, is_ntt_form=True)
+            got = pkg.to_host(dd)
+            for i in range(tg.shape[0]):
+                exp = ctx.switch_key(L, True, tg[i], keys, assign=assign, dest=d0[i])
+                assert np.array_equal(got[i], exp), "item %d assign %d" % (i, assign)
+
+
+def test_switch_key_straddling_moduli(O, pkg, dev):
+    """a key chain with one modulus above 2^50: every fused kernel of the key switch takes the integer butterflies"""
+    n, L = 8192, 2
+    q = _chains(O, n)[1][1]
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, 13, q)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    tg = np.stack([_corner_ct(q, L, n, 1, nm)[0] for nm in ("all_q-1", "alt_q-1_0", "impulse_1", "half_lo")])
+    got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    for i in range(tg.shape[0]):
+        assert np.array_equal(got[i], ctx.switch_key(L, True, tg[i], keys, assign=pkg.ASSIGN_OVERWRITE)), i
+
+
+@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [50] * 4, 4), (32768, [50] * 4, 3)])
+def test_rescale_corner_vectors(O, pkg, dev, n, bits, L):
+    """fused CKKS rescale (INTT of the last limb, then the forward NTT with the rounding prologue and the divide epilogue)"""
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    names = ["all_q-1", "alt_0_q-1", "alt_q-1_0", "half_lo", "half_hi", "impulse_0", "impulse_%d" % (n // 2), "ramp_top"]
+    x = np.stack([_corner_ct(q, L, n, 2, nm) for nm in names])
+    got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(x, dev), 2))
+    for i, nm in enumerate(names):
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i])), nm
+
+
+def test_pipeline_corner_vectors(O, pkg, dev):
+    """multiply -> relinearize -> rescale at BASELINE config 3's parameters on extreme operands"""
+    n, L = 16384, 5
+    q = O.coeff_modulus_create(n, [50] * 6)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, 14, q)
+    keys = ctx.random_keys(11, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    names = ["all_q-1", "alt_0_q-1", "half_hi", "ramp_top"]
+    a = np.stack([_corner_ct(q, L, n, 2, nm) for nm in names])
+    b = np.stack([_corner_ct(q, L, n, 2, nm) for nm in reversed(names)])
+    prod = plan.dyadic_convolute(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2, L)
+    relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
+    got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, relin, 2))
+    for i in range(len(names)):
+        e = ctx.ckks_multiply(L, a[i], b[i])
+        e = ctx.relinearize(L, True, e, keys)
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), names[i]

@@ -1,6 +1,6 @@
 """The reference's OWN example programs, unchanged, on this repository's implementation ("a program written for the
-reference keeps compiling").  oracle/build_ref_examples.sh compiles /root/reference/examples/*.cu where they lie against the mirror's
-headers and links them with libtroy_amd.so into oracle/_ref/ref_examples (build container only; the binary travels to the GPU box,
+reference keeps compiling").  tests/build_ref_examples.sh compiles /root/reference/examples/*.cu where they lie against the mirror's
+headers and links them with libtroy_amd.so into tests/_ref_examples/ref_examples (build container only; the binary travels to the GPU box,
 the reference tree does not).  Each example is selected through the program's own menu on stdin; the checks are the examples' own
 "Correct." / "passed" / "Success!" self-checks."""
 import os
@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "oracle", "_ref", "ref_examples")
+BIN = os.path.join(ROOT, "tests", "_ref_examples", "ref_examples")
 
 # example number -> (marker that must appear, minimum number of occurrences)
 EXPECT = {
@@ -38,7 +38,7 @@ EXPECT = {
 @pytest.mark.parametrize("number", sorted(EXPECT))
 def test_reference_example_runs_on_the_mirror(dev, number):
     if not os.path.exists(BIN):
-        pytest.skip("oracle/_ref/ref_examples is not built (needs the reference tree: bash oracle/build_ref_examples.sh)")
+        pytest.skip("tests/_ref_examples/ref_examples is not built (needs the reference tree: bash tests/build_ref_examples.sh)")
     r = subprocess.run([BIN], input="%d\n0\n" % number, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     marker, count = EXPECT[number]

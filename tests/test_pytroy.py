@@ -166,6 +166,29 @@ def test_ckks_flow_in_python(pytroy, dev):
 
 
 @pytest.mark.gpu
+def test_ckks_scale_out_of_bounds_throws(pytroy, dev):
+    """is_scale_within_bounds (evaluator_utils.h:307-323): the reference refuses a CKKS product whose scale reaches the total
+    coefficient-modulus bit count (evaluator.cu:140-143) instead of returning a ciphertext that decrypts to garbage"""
+    p = _params(pytroy, pytroy.SchemeType.CKKS, 4096, [40, 40, 40])
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Nil, 7)
+    ctx.to_device_inplace()
+    enc = pytroy.CKKSEncoder(ctx)
+    kg = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_public_key(kg.create_public_key(False))
+    ev = pytroy.Evaluator(ctx)
+    z = [complex(0.5, 0.0)] * enc.slot_count()
+    ok = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z, None, float(1 << 30)))
+    ev.multiply_new(ok, ok)                                            # 2^60 < 2^80 data bits: accepted
+    big = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z, None, float(1 << 40)))
+    with pytest.raises(ValueError, match="Scale out of bounds"):
+        ev.multiply_new(big, big)                                      # 2^80 >= 80 bits of data modulus
+    with pytest.raises(ValueError, match="Scale out of bounds"):
+        ev.square_new(big)
+    pytroy.MemoryPool.destroy_global_pool()
+
+
+@pytest.mark.gpu
 def test_lwe_packing_flow_in_python(pytroy, dev):
     """pybind/tests-style use of the LWE / packing defs of pybind/src/evaluator.cu: extract_lwe_new, assemble_lwe_new,
     pack_lwe_ciphertexts_new(_batched), pack_rlwe_ciphertexts_new, negacyclic_shift_new, add_plain_new, field traces"""

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profiles the default bench.py run on the GPU box (rocprofv3 kernel trace + separate PMC passes) and writes the summaries that
+# profiles/ keeps:  tools/profile_bench.sh <tag>   ->  gpurun_out/<tag>_summary.txt, gpurun_out/<tag>_ksmac_counters.json
+# Run through gpurun from the repository root:  gpurun -- 'bash tools/profile_bench.sh r02_bench_v1'
+set -e
+TAG=${1:-r02_bench}
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o bench -- python3 $ARGS > "$OUT/${TAG}_bench.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d "$OUT/prof_$TAG/$C" -o bench -- python3 $ARGS > /dev/null 2>&1
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -d "$OUT/prof_$TAG/SQ" -o bench -- python3 $ARGS > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d "$OUT/prof_$TAG/GRBM" -o bench -- python3 $ARGS > /dev/null 2>&1
+cd "$ROOT"
+python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" --pmc "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" \
+        --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
+python3 tools/collect_counters.py ksmac2_kernel $((1024 * 6 * 2 * 256)) 1024 "$OUT/${TAG}_ksmac_counters.json" \
+        "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db"
+tail -3 "$OUT/${TAG}_bench.log"

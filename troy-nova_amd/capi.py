@@ -20,6 +20,8 @@ p64 = C.POINTER(C.c_uint64)
 SYMBOLS = {
     "troyn_last_error": (C.c_char_p, []),
     "troyn_version": (C.c_int, []),
+    "troyn_kernel_timer_enable": (C.c_int, [C.c_int, C.c_int]),
+    "troyn_kernel_timer_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), p64]),
     "troyn_coeff_modulus_create": (C.c_int, [sz, C.POINTER(sz), sz, p64]),
     "troyn_get_primes": (C.c_int, [u64, sz, sz, p64]),
     "troyn_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, u32, u32, p64, p64]),

@@ -58,6 +58,15 @@ TROYN_HD double f64_mulc(double y, double w, double wp, double p) {
     return t + l;
 }
 
+// y * w mod p (lazy, signed) with the quotient estimated from the rounded product itself: q = rint(fl(y*w) * fl(1/p)) is
+// within 0.5 + 1.5 |y| 2^-52 of y*w/p (the bound of f64_mulc) and needs no per-operand w/p.  w any integer in [0, p).
+TROYN_HD double f64_mulq(double y, double w, double inv_p, double p) {
+    const double h = y * w;
+    const double l = __builtin_fma(y, w, -h);
+    const double q = __builtin_rint(h * inv_p);
+    return __builtin_fma(-q, p, h) + l;
+}
+
 // canonical representative in [0, p) as u64
 TROYN_HD u64 f64_canon(double x, const F64Mod& m) {
     x = f64_corr(x, m);

@@ -100,15 +100,6 @@ __device__ __forceinline__ V ksm_gload(const void* ubase, unsigned byte_off) {
     return r;
 }
 
-// y * w mod p (lazy, signed) with the quotient estimated from the rounded product itself: q = rint(fl(y*w) * fl(1/p)) is
-// within 0.5 + 1.5 |y| 2^-52 of y*w/p -- the bound of f64_mulc (dev_math_f64.hpp) -- and needs no per-twiddle w/p.
-__device__ __forceinline__ double ksm_mulq(double y, double w, double inv_p, double p) {
-    const double h = y * w;
-    const double l = __builtin_fma(y, w, -h);
-    const double q = __builtin_rint(h * inv_p);
-    return __builtin_fma(-q, p, h) + l;
-}
-
 // butterflies of register bit RB for the twiddle groups [G0, G0 + NG): tw[i] belongs to group G0 + i
 template <int RB, int G0, int NG, bool NOBF = false>
 __device__ __forceinline__ void ksm_layer(double (&x)[32], const double* tw, double inv_p, double p) {
@@ -117,7 +108,7 @@ __device__ __forceinline__ void ksm_layer(double (&x)[32], const double* tw, dou
         const double w = tw[decltype(gc)::value];
         static_for<0, (1 << RB)>([&](auto oc) {
             constexpr int R0 = (g << (RB + 1)) | decltype(oc)::value, R1 = R0 | (1 << RB);
-            const double r = NOBF ? w : ksm_mulq(x[R1], w, inv_p, p);
+            const double r = NOBF ? w : f64_mulq(x[R1], w, inv_p, p);
             const double u = x[R0];
             x[R0] = u + r; x[R1] = u - r;
         });
@@ -294,8 +285,8 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
                     constexpr int j = decltype(ic)::value, i = hb * 8 + j;
                     const double u0 = dig_in(ru[j].x), u1 = dig_in(ru[j].y), v0 = dig_in(rv[j].x), v1 = dig_in(rv[j].y);
                     // 0 <= u, v < 2^50: one re-centring after the layer instead of one per input
-                    x[2 * i] = f64_corr(__builtin_fma(sgn, ksm_mulq(v0, w1, inv_p, p), u0), fm);
-                    x[2 * i + 1] = f64_corr(__builtin_fma(sgn, ksm_mulq(v1, w1, inv_p, p), u1), fm);
+                    x[2 * i] = f64_corr(__builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0), fm);
+                    x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
                 });
             });
         } else {
@@ -317,7 +308,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
                 const double w = tws[idx];
                 static_for<0, (1 << rb)>([&](auto oc) {
                     constexpr int R0 = (g << (rb + 1)) | decltype(oc)::value, R1 = R0 | (1 << rb);
-                    const double r = abl(3) ? w : ksm_mulq(x[R1], w, inv_p, p);
+                    const double r = abl(3) ? w : f64_mulq(x[R1], w, inv_p, p);
                     const double u = x[R0];
                     x[R0] = u + r; x[R1] = u - r;
                 });

@@ -49,6 +49,14 @@ struct NttArgs {
     unsigned batch;                // ks_mac_kernel: number of items (workgroup -> (row, item) mapping)
     unsigned xcd_groups;           // fused tail / rescale launches: batch * pcount groups whose ncomp limbs share one input row (0: off)
     long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
+    // ---- fused multiply -> relinearize -> rescale chain (IOM 3..5, NttFused below) ----
+    const u64* mul_a; const u64* mul_b;       // the two input ciphertexts [item][2][limbs][N] (NTT form)
+    long long mul_bstride, mul_pstride;       // element strides: item, polynomial (limb stride = N)
+    unsigned mul_limb0;                       // limb of a / b that component j = 0 of the launch works on
+    const u64* in2;                           // second coefficient-form input row (INTT of the dropped limb / of the special-prime row)
+    long long in2_bstride, in2_pstride;
+    unsigned aux2_mod;                        // modulus index of the dropped prime q_{L-1}
+    const ulonglong2* inv_table2;             // Shoup pairs of q_{L-1}^-1 mod q_j
 };
 
 // Fused prologues: what a coefficient looks like when it enters the transform.
@@ -71,6 +79,21 @@ enum NttStore {
     NTT_STORE_RESCALE = 2,
 };
 
+// Kernels of the fused CKKS multiply -> relinearize -> rescale chain (troyn_ckks_multiply_relinearize_rescale).  With c = a (x) b
+// the dyadic tensor product (c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1), P the key-switch inner product of c2, s = INTT of P's
+// special-prime row, r_j(s) the rounding fix of the key switch and f_j(l) the rounding fix of the rescale, linearity of the
+// transforms (all arithmetic is exact mod q_j) gives
+//     relin_j   = (P_j - NTT_j(r_j(s))) qk^-1 + c_j                         (evaluator_keyswitching_core.cu:570-658 + :143)
+//     l         = INTT(relin_{L-1}) = INTT(P_{L-1} qk^-1 + c_{L-1}) - r_{L-1}(s) qk^-1
+//     out_j     = (relin_j - NTT_j(f_j(l))) ql^-1                           (utils/rns_tool.cu:523-627)
+//               = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1
+// i.e. ONE forward transform per output limb instead of two, and c is never materialised:
+enum NttFused {
+    NTT_FUSED_MULPAIR = 3,       // inverse: input word = a1 (.) b1 (the product c2 formed while loading)
+    NTT_FUSED_LAST_LIMB = 4,     // inverse: input = P qk^-1 + c_k at limb L-1; stored word = result - r(s) qk^-1   (= l above)
+    NTT_FUSED_TAIL_RESCALE = 5,  // forward: input = r_j(s) qk^-1 + f_j(l); stored word = (P_j qk^-1 + c_kj - y) ql^-1
+};
+
 struct NttIo {
     unsigned load_mode, store_mode;
     // loader constants
@@ -83,6 +106,11 @@ struct NttIo {
     // the same constants as doubles, for the FP64 policy (all moduli < 2^50, exact integers)
     double aux_qd, aux_half_d, hm_d;     // other prime, floor(aux/2), (aux_half mod q)
     double inv_d, inv_pd;                // (dropped prime)^-1 mod q and fl(inv/q)
+    // fused chain: the dropped prime q_{L-1} next to the special prime
+    double aux2_qd, aux2_half_d, hm2_d, inv2_d;
+    const u64* in2;                      // second input row of this (item, polynomial)
+    const u64 *a0, *a1, *b0, *b1;        // this limb of the two input ciphertexts
+    unsigned poly;                       // output polynomial k: c_0 = a0 b0, c_1 = a0 b1 + a1 b0
 };
 
 __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi, u64* gout) {
@@ -112,6 +140,36 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
         io.add_inplace = (a.store_mode == NTT_STORE_KS_FINISH) && (assign == 0u || (k == 0u && assign == 2u));
     }
     return io;
+}
+
+// constants and operand rows of the fused chain for workgroup (item b, polynomial k, component j) under modulus mi
+__device__ __forceinline__ void ntt_io_fused(NttIo& io, const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi) {
+    const DevModulus md = a.mods[mi];
+    io.q = md.q; io.ratio_hi = md.ratio_hi;
+    io.poly = k;
+    io.in2 = nullptr; io.a0 = io.a1 = io.b0 = io.b1 = nullptr; io.ext0 = nullptr; io.ext1 = nullptr;
+    io.aux_qd = io.aux_half_d = io.hm_d = io.inv_d = io.inv_pd = 0.0;
+    io.aux2_qd = io.aux2_half_d = io.hm2_d = io.inv2_d = 0.0;
+    if (a.mul_a) {
+        const u64* pa = a.mul_a + (long long)b * a.mul_bstride;
+        const u64* pb = a.mul_b + (long long)b * a.mul_bstride;
+        io.a0 = pa; io.a1 = pa + a.mul_pstride; io.b0 = pb; io.b1 = pb + a.mul_pstride;    // + limb * N added by the caller (N is a template constant there)
+    }
+    if (a.in2) io.in2 = a.in2 + (long long)b * a.in2_bstride + (long long)k * a.in2_pstride;
+    if (a.ext0) io.ext0 = a.ext0 + (long long)b * a.ext0_bstride + (long long)k * a.ext0_pstride + (long long)j * a.ext0_cstride;
+    if (a.inv_table) {
+        // special prime qk: rounding fix r(s) = ((s + qk/2) mod qk) - (qk/2 mod q), and qk^-1 mod q
+        const DevModulus ax = a.mods[a.aux_mod];
+        const u64 half = ax.q >> 1;
+        io.aux_qd = ax.pd; io.aux_half_d = (double)half; io.hm_d = (double)barrett64(half, md.q, md.ratio_hi);
+        io.inv = a.inv_table[j]; io.inv_d = (double)io.inv.x;
+    }
+    if (a.inv_table2) {
+        const DevModulus ax = a.mods[a.aux2_mod];
+        const u64 half = ax.q >> 1;
+        io.aux2_qd = ax.pd; io.aux2_half_d = (double)half; io.hm2_d = (double)barrett64(half, md.q, md.ratio_hi);
+        io.inv2_d = (double)a.inv_table2[j].x;
+    }
 }
 
 // raw input word -> the word the transform should see (still subject to A::load_first)
@@ -316,6 +374,21 @@ struct ArithF64 {
             return f64_canon(d, m.m);
         }
     }
+    // ---- fused chain (NttFused): every value an exact integer; products by f64_mulq (|result| <= 0.69 p for a re-centred factor) ----
+    static __device__ __forceinline__ elem prod_in(u64 x, u64 y, const Mod& m) {
+        return f64_mulq(f64_corr(f64_from_u64(x), m.m), f64_from_u64(y), m.m.inv_p, m.m.p);
+    }
+    // c_k at one coefficient: c_0 = a0 b0, c_1 = a0 b1 + a1 b0
+    static __device__ __forceinline__ elem tensor_term(unsigned k, u64 a0, u64 a1, u64 b0, u64 b1, const Mod& m) {
+        return k == 0 ? prod_in(a0, b0, m) : prod_in(a0, b1, m) + prod_in(a1, b0, m);
+    }
+    // rounding fix of a coefficient x of a dropped prime `aux` (x < aux < 2^50): ((x + aux/2) mod aux) - (aux/2 mod p), re-centred
+    static __device__ __forceinline__ elem round_fix(u64 x, double aux_q, double aux_half, double hm, const Mod& m) {
+        double t = f64_from_u64(x) + aux_half;
+        t = (t >= aux_q) ? t - aux_q : t;
+        return f64_corr(t - hm, m.m);
+    }
+    static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= 0.5p+1
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
     static __device__ __forceinline__ elem from_lds(u64 raw) { return f64_bits_to_double(raw); }
@@ -360,6 +433,8 @@ __host__ __device__ constexpr unsigned ntt_wave_bits(int S, int EB, int TB) {
 // reach HBM.  Digit k of row k < L is the untouched NTT-form input limb (evaluator_keyswitching_core.cu:851-852).
 // IOM selects the fused element-wise prologue / epilogue at compile time: 0 plain, 1 key-switch tail
 // (NTT_LOAD_KS_ROUND on the first pass, NTT_STORE_KS_FINISH on the last), 2 rescale.
+__host__ __device__ constexpr bool ROUNDS_OK(int G, int EB) { return (G + EB - 1) / EB > 1; }
+
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM>
 __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t) {
     constexpr int C = TB - G;
@@ -426,9 +501,16 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     };
     constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
     constexpr int SM = (LAST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_STORE_KS_FINISH : IOM == 2 ? (int)NTT_STORE_RESCALE : (int)NTT_STORE_PLAIN) : (int)NTT_STORE_PLAIN;
+    constexpr bool FUSED = IOM >= 3;     // NttFused: whole-limb kernels of the multiply -> relinearize -> rescale chain
+    constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR, F_LAST = IOM == NTT_FUSED_LAST_LIMB, F_TAILRESC = IOM == NTT_FUSED_TAIL_RESCALE;
+    static_assert(!FUSED || (!KSMAC && FIRST && LAST && C == 0 && ROUNDS_OK(G, EB) && std::is_same<A, ArithF64>::value), "fused chain: whole-limb FP64 kernels");
+    static_assert(!FUSED || (INV == (F_MULPAIR || F_LAST)), "fused chain: transform direction");
     NttIo io;
-    if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
+    if constexpr (FUSED) { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; ntt_io_fused(io, a, b, k, j, mi); }
+    else if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
     else { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; }
+    // this workgroup's limb of the two input ciphertexts (fused chain)
+    const long long mul_off = FUSED ? (long long)(a.mul_limb0 + j) * N : 0ll;
 
     elem x[E];
     elem acc0[KSMAC ? E : 1], acc1[KSMAC ? E : 1];
@@ -499,15 +581,33 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
+                if constexpr (F_MULPAIR) {
+                    // c2 = a1 (.) b1 formed while loading (the tensor product is never written to HBM)
+                    const ulonglong2 va = nt_load2(io.a1 + mul_off + gbase + idx), vb = nt_load2(io.b1 + mul_off + gbase + idx);
+                    lds[pidx + lds_off(m * 128u)] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
+                    lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
+                } else if constexpr (F_LAST) {
+                    // P qk^-1 + c_k at the dropped limb
+                    const ulonglong2 vp = nt_load2(gin + gbase + idx);
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
+                    ulonglong2 a1 = a0, b1 = b0;
+                    if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
+                    const elem e0 = A::scale_by(f64_corr(f64_from_u64(vp.x), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md);
+                    const elem e1 = A::scale_by(f64_corr(f64_from_u64(vp.y), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md);
+                    lds[pidx + lds_off(m * 128u)] = A::to_lds(e0, md);
+                    lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(e1, md);
+                } else {
                 const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
                 lds[pidx + lds_off(m * 128u)] = ntt_io_load<LM>(io, v.x);
                 lds[pidx + lds_off(m * 128u) + 1] = ntt_io_load<LM>(io, v.y);
+                }
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 const u64 raw = lds[pown + R];
-                if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
+                if constexpr (F_MULPAIR || F_LAST) x[R] = A::from_lds(raw);     // re-centred when it was parked
+                else if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
         } else if constexpr (r == 0) {
@@ -519,6 +619,13 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
+                else if constexpr (F_TAILRESC) {
+                    // r_j(s) qk^-1 + f_j(l): the rounding fixes of the key switch and of the rescale enter ONE transform
+                    const u64 raw2 = io.in2[gindex(locbase | ((unsigned)R << S))];
+                    const elem rs = A::round_fix(raw, io.aux_qd, io.aux_half_d, io.hm_d, md);
+                    const elem fl = A::round_fix(raw2, io.aux2_qd, io.aux2_half_d, io.hm2_d, md);
+                    x[R] = f64_corr(A::scale_by(rs, io.inv_d, md) + fl, md.m);
+                }
                 else if constexpr (FIRST) x[R] = A::template load_io<LM>(io, raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });

@@ -82,6 +82,60 @@ extern "C" int troyn_coeff_modulus_create(size_t poly_modulus_degree, const size
 }
 
 // ---------------------------------------------------------------------------------------
+// in-library kernel timer (measurement hook, include/troyn.h): hipEvent pairs recorded on the launch stream
+// around one named launch, so that a caller can time that kernel inside its own timed region
+// ---------------------------------------------------------------------------------------
+namespace {
+struct KernelTimer {
+    bool enabled[TROYN_TIMER_REGIONS] = {};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[TROYN_TIMER_REGIONS];   // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_pairs;
+    std::mutex mu;
+};
+KernelTimer g_ktimer;
+
+struct TimerScope {
+    int region; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    TimerScope(int region_, hipStream_t s_) : region(region_), s(s_) {
+        if (!g_ktimer.enabled[region]) return;
+        std::lock_guard<std::mutex> g(g_ktimer.mu);
+        if (!g_ktimer.free_pairs.empty()) { e0 = g_ktimer.free_pairs.back().first; e1 = g_ktimer.free_pairs.back().second; g_ktimer.free_pairs.pop_back(); }
+        else if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+        (void)hipEventRecord(e0, s);
+    }
+    ~TimerScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> g(g_ktimer.mu);
+        g_ktimer.spans[region].push_back({e0, e1});
+    }
+};
+}  // namespace
+
+extern "C" int troyn_kernel_timer_enable(int region, int on) {
+    if (region < 0 || region >= TROYN_TIMER_REGIONS) return fail(TROYN_E_INVALID, "[troyn_kernel_timer_enable] unknown region");
+    g_ktimer.enabled[region] = on != 0;
+    return TROYN_OK;
+}
+
+extern "C" int troyn_kernel_timer_read(int region, double* total_ms, uint64_t* launches) {
+    if (region < 0 || region >= TROYN_TIMER_REGIONS || !total_ms || !launches) return fail(TROYN_E_INVALID, "[troyn_kernel_timer_read] bad argument");
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    { std::lock_guard<std::mutex> g(g_ktimer.mu); spans.swap(g_ktimer.spans[region]); }
+    double total = 0.0;
+    for (auto& sp : spans) {
+        HIP_TRY(hipEventSynchronize(sp.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sp.first, sp.second));
+        total += ms;
+    }
+    *total_ms = total; *launches = spans.size();
+    std::lock_guard<std::mutex> g(g_ktimer.mu);
+    for (auto& sp : spans) g_ktimer.free_pairs.push_back(sp);
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------
 struct troyn_plan {
@@ -286,25 +340,34 @@ static void launch_single(const NttArgs& a, size_t lp, bool inv, hipStream_t s) 
     else launch_pass<A, LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
 }
 
-// two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks
+// two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks.
+// The pass between them lives in `scratch` ([limb-polynomial][N], contiguous) when one is given, else in `out`: a fused
+// epilogue that READS the old destination (key-switch tail with AddInplace / OverwriteExceptFirst) must not find the first
+// pass's intermediate words there.
 template <class A, int LOGN, int TB, int EB>
-static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
+static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s, u64* scratch) {
     constexpr int G1 = LOGN - TB;
-    NttArgs second = a;   // the second pass works in place on `out`
-    second.in = a.out;
-    second.in_bstride = a.out_bstride; second.in_pstride = a.out_pstride; second.in_cstride = a.out_cstride;
+    NttArgs first = a, second = a;
+    if (scratch) {
+        first.out = scratch;
+        first.out_cstride = (long long)1 << LOGN;
+        first.out_pstride = (long long)a.ncomp << LOGN;
+        first.out_bstride = (long long)a.pcount * a.ncomp << LOGN;
+    }
+    second.in = first.out;
+    second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
     second.reduce_input = 0;
     if (!inv) {
-        launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, lp, s);
+        launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(first, lp, s);
         launch_pass<A, LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
     } else {
-        launch_pass<A, LOGN, G1, TB, TB, EB, true, true, false>(a, lp, s);
+        launch_pass<A, LOGN, G1, TB, TB, EB, true, true, false>(first, lp, s);
         launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
     }
 }
 
 template <class A>
-static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s) {
+static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
     // N = 4096 / 8192: 8 coefficients per thread (EB = 3) doubles the waves per tile, so a CU holds 32 waves instead
     // of 16; measured 5-14 % faster than EB = 4 despite the extra LDS exchange.  N = 16384 needs EB = 4 to fit one
     // workgroup (1024 threads x 16 coefficients).
@@ -314,9 +377,9 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
         case 12: launch_single<A, 12, 3>(a, lp, inverse, s); return true;
         case 13: launch_single<A, 13, 3>(a, lp, inverse, s); return true;
         case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
-        case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s); return true;
-        case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s); return true;
-        case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s); return true;
+        case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s, scratch); return true;
+        case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s, scratch); return true;
+        case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s, scratch); return true;
         default: return false;
     }
 }
@@ -347,7 +410,7 @@ static bool launch_ks_mac_t(unsigned log_n, const NttArgs& a, const KeyPtrs& kp,
     }
 }
 
-static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s) {
+static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s, u64* two_pass_scratch = nullptr) {
     a.mods = p->d_mods;
     // inputs shared by several limb-polynomials of the launch (stride 0) should stay cached
     a.stream_loads = ((a.pcount <= 1 || a.in_pstride != 0) && (a.ncomp <= 1 || a.in_cstride != 0)) ? 1u : 0u;
@@ -361,10 +424,10 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     bool done;
     if (f64) {
         a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
-        done = launch_ntt_optimised<ArithF64>(p->log_n, a, lp, inverse, s);
+        done = launch_ntt_optimised<ArithF64>(p->log_n, a, lp, inverse, s, two_pass_scratch);
     } else {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
-        done = launch_ntt_optimised<ArithU64>(p->log_n, a, lp, inverse, s);
+        done = launch_ntt_optimised<ArithU64>(p->log_n, a, lp, inverse, s, two_pass_scratch);
     }
     if (!done) {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
@@ -590,8 +653,11 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.keys = kf; a.key_jstride = 2ll * K * n; a.key_pstride = (long long)K * n;
         a.L = L; a.table_start = 0; a.table_count = K; a.batch = (unsigned)batch;
         a.grouped = (batch % 8 == 0) ? 1u : 0u;
-        if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, a);
+        {
+            TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
+            if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
+            else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, a);
+        }
         LAUNCH_CHECK();
     } else if (mac_fused) {
         NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
@@ -613,8 +679,11 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
-        if (f64) launch_ks_mac_t<ArithF64>(p->log_n, a, kp, batch * (L + 1), s);
-        else launch_ks_mac_t<ArithU64>(p->log_n, a, kp, batch * (L + 1), s);
+        {
+            TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
+            if (f64) launch_ks_mac_t<ArithF64>(p->log_n, a, kp, batch * (L + 1), s);
+            else launch_ks_mac_t<ArithU64>(p->log_n, a, kp, batch * (L + 1), s);
+        }
         LAUNCH_CHECK();
     } else {
     // (2) digit decomposition fused into the forward NTT (replaces kernel_set_accumulate, fgk/switch_key.cu:6-54,
@@ -666,7 +735,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.ext0 = ws + w.poly_prod; a.ext0_bstride = 2ll * (L + 1) * n; a.ext0_pstride = (long long)(L + 1) * n; a.ext0_cstride = n;
         a.ext1 = addend; a.ext1_bstride = (long long)addend_bstride; a.ext1_pstride = (long long)L * n; a.ext1_cstride = n;
         a.inv_table = p->d_inv_last + (size_t)K * K;
-        return launch_ntt(p, a, batch, false, s);
+        // N >= 32768 transforms in two passes: the pass in between goes to temp_last (unused on this path), never to dest
+        return launch_ntt(p, a, batch, false, s, ws + w.temp_last);
     }
     // (5) rounding fix of the special-prime component, per data limb (:570-598).  In NTT form the result goes to
     //     the unused tail of the prod_intt region so that step (6) can transform out of place.

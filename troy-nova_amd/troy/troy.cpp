@@ -666,6 +666,17 @@ static void check_no_seed(const char* prompt, const Ciphertext& c) {
 static void check_same_parms_id(const char* prompt, const Ciphertext& a, const Ciphertext& b) {
     if (a.parms_id() != b.parms_id()) throw std::invalid_argument(std::string(prompt) + " Arguments have different parms ID.");
 }
+// evaluator_utils.h:307-323
+static bool is_scale_within_bounds(double scale, const ContextDataPointer& cd) {
+    int bound = -1;
+    switch (cd->parms().scheme()) {
+        case SchemeType::BFV: case SchemeType::BGV: bound = static_cast<int>(cd->parms().plain_modulus_host().bit_count()); break;
+        case SchemeType::CKKS: bound = static_cast<int>(cd->total_coeff_modulus_bit_count()); break;
+        default: break;
+    }
+    return !(scale <= 0.0 || static_cast<int>(std::log2(scale)) >= bound);
+}
+
 static bool are_close_double(double a, double b) {
     double s = std::max(std::max(a, b), 1.0);
     return std::fabs(a - b) < s * 2.220446049250313e-16;   // basics.h:150-160
@@ -827,8 +838,10 @@ void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext&
             check_is_ntt_form(P, e1); check_is_ntt_form(P, e2);
             troyn_check(troyn_dyadic_convolute(context_->plan(), 0, L, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2,
                                                out.data().raw_pointer(), 1, current_stream()));
-            if (scheme == SchemeType::CKKS) out.scale() = e1.scale() * e2.scale();
-            else {
+            if (scheme == SchemeType::CKKS) {
+                out.scale() = e1.scale() * e2.scale();
+                if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument("[Evaluator::ckks_multiply] Scale out of bounds");   // evaluator.cu:140-143
+            } else {
                 const Modulus& t = cd->parms().plain_modulus();
                 out.correction_factor() = (uint64_t)(((unsigned __int128)e1.correction_factor() * e2.correction_factor()) % t.value());
             }
@@ -849,8 +862,10 @@ void Evaluator::square(const Ciphertext& encrypted, Ciphertext& destination, Mem
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     Ciphertext out = Ciphertext::like(encrypted, 3, false, pool);
     troyn_check(troyn_dyadic_square(context_->plan(), 0, L, encrypted.data().raw_pointer(), out.data().raw_pointer(), 1, current_stream()));
-    if (scheme == SchemeType::CKKS) out.scale() = encrypted.scale() * encrypted.scale();
-    else {
+    if (scheme == SchemeType::CKKS) {
+        out.scale() = encrypted.scale() * encrypted.scale();
+        if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument("[Evaluator::ckks_multiply_inplace] Scale out of bounds");   // evaluator.cu:308-311
+    } else {
         const Modulus& t = cd->parms().plain_modulus();
         out.correction_factor() = (uint64_t)(((unsigned __int128)encrypted.correction_factor() * encrypted.correction_factor()) % t.value());
     }
@@ -1011,6 +1026,7 @@ void Evaluator::mod_switch_drop_to_internal(const Ciphertext& encrypted, Ciphert
     if (cd->parms().scheme() == SchemeType::CKKS) check_is_ntt_form(P, encrypted);
     if (!cd->next_context_data().has_value()) throw std::invalid_argument("[Evaluator::mod_switch_drop_to_next_internal] Next context data is not set.");
     auto tcd = get_context_data("[Evaluator::mod_switch_drop_to_next_internal]", target);
+    if (!is_scale_within_bounds(encrypted.scale(), tcd)) throw std::invalid_argument("[Evaluator::mod_switch_drop_to_internal] Scale out of bounds.");   // evaluator_modswitch.cu:186-188
     check_on_device(P, context_, encrypted);
     const uint32_t L_in = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const uint32_t L_out = static_cast<uint32_t>(tcd->parms().coeff_modulus().size());
@@ -1174,7 +1190,10 @@ void Evaluator::multiply_plain(const Ciphertext& encrypted, const Plaintext& pla
     troyn_check(troyn_dyadic_broadcast_product(context_->plan(), 0, L, src, pc, pn->poly(), 0, out.data().raw_pointer(), 1, s));
     if (!encrypted.is_ntt_form())
         troyn_check(troyn_ntt(context_->plan(), 1, out.data().raw_pointer(), out.data().raw_pointer(), 1, pc, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
-    if (cd->parms().scheme() == SchemeType::CKKS) out.scale() = encrypted.scale() * plain.scale();
+    if (cd->parms().scheme() == SchemeType::CKKS) {
+        out.scale() = encrypted.scale() * plain.scale();
+        if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument(encrypted.is_ntt_form() ? "[Evaluator::multiply_plain_ntt] Scale out of bounds." : "[Evaluator::multiply_plain_normal] Scale out of bounds.");   // evaluator_multiply_plain.cu:63-67, :213-217
+    }
     hip_check(hipStreamSynchronize(s), "stream_sync");   // the temporary NTT plaintext returns to the pool
     destination = std::move(out);
 }
@@ -1218,7 +1237,10 @@ void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& 
     troyn_check(troyn_multiply_plain_accumulate(context_->plan(), 0, L, pc, cts.data(), pts.data(), dsts.data(), cts.size(), set_zero ? 1 : 0,
                                                 ws.raw_pointer(), wsb, current_stream()));
     if (cd->parms().scheme() == SchemeType::CKKS)
-        for (size_t i = 0; i < encrypted.size(); i++) destination[i]->scale() = encrypted[i]->scale() * plain[i]->scale();
+        for (size_t i = 0; i < encrypted.size(); i++) {
+            destination[i]->scale() = encrypted[i]->scale() * plain[i]->scale();
+            if (!is_scale_within_bounds(destination[i]->scale(), cd)) throw std::invalid_argument("[Evaluator::multiply_plain_ntt_batched] Scale out of bounds.");   // evaluator_multiply_plain.cu:250,:301
+        }
     hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
 }
 
