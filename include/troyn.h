@@ -155,6 +155,20 @@ int troyn_relinearize(const troyn_plan* plan, uint32_t L, int is_ckks, int is_nt
                       void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused CKKS chain: Evaluator::multiply (evaluator.cu:118-145) -> Evaluator::relinearize (evaluator_keyswitching.cu:119-144)
+ * -> Evaluator::rescale_to_next (evaluator_modswitch.cu, RNSTool::divide_and_round_q_last_ntt utils/rns_tool.cu:499-694) of
+ * `batch` ciphertext pairs in one call.  Results are bit-identical to troyn_dyadic_convolute + troyn_relinearize +
+ * troyn_divide_and_round_q_last_ntt; on whole-limb FP64 rings (N = 8192 / 16384, moduli < 2^50) the tensor product is formed
+ * inside the loaders of the transforms that consume it and the rounding steps of the key switch and of the rescale share one
+ * forward transform per output limb; other shapes run the three calls.
+ *   a, b  [batch][2][L][N] NTT form;  keys as troyn_switch_key;  out [batch][2][L-1][N] NTT form
+ * ------------------------------------------------------------------------------------- */
+size_t troyn_ckks_multiply_relinearize_rescale_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch);
+int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* plan, uint32_t L, const uint64_t* a, const uint64_t* b,
+                                            const uint64_t* const* keys, uint64_t* out, void* workspace, size_t workspace_bytes,
+                                            size_t batch, troyn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Modulus switching.
  * troyn_divide_and_round_q_last      RNSTool::divide_and_round_q_last (utils/rns_tool.cu:374-466),
  *                                    BFV mod_switch_to_next, coefficient form.

@@ -158,3 +158,29 @@ def test_error_behaviour(O, pkg, dev):
         pkg.Plan(dev, 10, [1 << 61])                                         # modulus too large
     with pytest.raises(pkg.capi.TroynInvalidArgument):
         pkg.Plan(dev, 10, [97])                                              # no 2N-th root of unity
+
+
+@pytest.mark.parametrize("n,bits,L,batch", [(16384, [50] * 6, 5, 8), (16384, [50] * 6, 3, 3), (8192, [40, 40, 40, 40], 3, 8), (8192, [50] * 3, 2, 5),
+                                            (4096, [36] * 4, 3, 2), (32768, [50] * 4, 3, 2), (8192, [55, 55, 56], 2, 2)])
+def test_ckks_multiply_relinearize_rescale_fused(O, pkg, dev, n, bits, L, batch):
+    """the one-call chain equals the three public calls AND the oracle's multiply -> relinearize -> mod_switch_scale_to_next
+    (fast path: N = 8192 / 16384 with moduli < 2^50, also below the top level; the other shapes compose the three calls)"""
+    import torch
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, bits)
+    keys = ctx.random_keys(21, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    a = np.stack([ctx.random_ct(100 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(200 + i, 2, L) for i in range(batch)])
+    da, db = pkg.to_device(a, dev), pkg.to_device(b, dev)
+    got = plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys)
+    prod = plan.dyadic_convolute(da, 2, db, 2, L)
+    relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
+    three = plan.divide_and_round_q_last_ntt(L, relin, 2)
+    assert torch.equal(got, three), "fused entry differs from the three-call composition"
+    got = pkg.to_host(got)
+    for i in sorted({0, batch // 2, batch - 1}):
+        e = ctx.ckks_multiply(L, a[i], b[i])
+        e = ctx.relinearize(L, True, e, keys)
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), i
+    # the operands are left untouched
+    assert np.array_equal(pkg.to_host(da), a) and np.array_equal(pkg.to_host(db), b)

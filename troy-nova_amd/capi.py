@@ -42,6 +42,8 @@ SYMBOLS = {
     "troyn_switch_key": (C.c_int, [vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), C.c_int, vp, vp, sz, sz, vp]),
     "troyn_relinearize_workspace_bytes": (sz, [vp, u32, sz]),
     "troyn_relinearize": (C.c_int, [vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), vp, vp, sz, sz, vp]),
+    "troyn_ckks_multiply_relinearize_rescale_workspace_bytes": (sz, [vp, u32, sz]),
+    "troyn_ckks_multiply_relinearize_rescale": (C.c_int, [vp, u32, vp, vp, C.POINTER(vp), vp, vp, sz, sz, vp]),
     "troyn_divide_and_round_q_last": (C.c_int, [vp, u32, vp, sz, vp, sz, vp]),
     "troyn_divide_and_round_q_last_ntt_workspace_bytes": (sz, [vp, u32, sz, sz]),
     "troyn_divide_and_round_q_last_ntt": (C.c_int, [vp, u32, vp, sz, vp, vp, sz, sz, vp]),

@@ -38,6 +38,8 @@ struct KsMacArgs {
     const u64* digits; long long dig_bstride, dig_cstride;      // coefficient-form digits [item][j][N]: canonical u64, or
                                                                  // (DIGF64) the same integers stored as doubles
     const u64* diag;   long long diag_bstride, diag_cstride;     // NTT-form input limbs [item][j][N]; nullptr: no diagonal shortcut
+    const u64* diag_b;                                           // non-null: the NTT-form input is the product diag (.) diag_b (same strides),
+                                                                 // formed while loading (fused multiply -> relinearize chain)
     u64* out;          long long out_bstride, out_pstride, out_cstride;   // [item][2][L+1][N]: (item, component, row)
     const DevModulus* mods;
     const double* tw;       // [K][N]  forward twiddles w, reference table order
@@ -264,6 +266,22 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
                 x[2 * m] = f64_from_u64(v.x);
                 x[2 * m + 1] = f64_from_u64(v.y);
             });
+            if (a.diag_b) {
+                const u64* dgb = ksm_uniform(a.diag_b + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
+                __builtin_amdgcn_wave_barrier();
+                static_for<0, 16>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const ulonglong2 v = ksm_gload<ulonglong2>(dgb + m * 128, slice_off);
+                    *reinterpret_cast<ulonglong2*>(&lds[pt + ksm_phys(m * 128u)]) = v;
+                });
+                __builtin_amdgcn_wave_barrier();
+                static_for<0, 16>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[p2 + 2 * m]);
+                    x[2 * m] = f64_mulq(f64_corr(x[2 * m], fm), f64_from_u64(v.x), inv_p, p);
+                    x[2 * m + 1] = f64_mulq(f64_corr(x[2 * m + 1], fm), f64_from_u64(v.y), inv_p, p);
+                });
+            }
         } else {
         // ---- load (+ layer 0 for a half tile), two steps of 8 register pairs ---------------------------------
         const u64* gin_u = ksm_uniform(dig_item + (long long)it * a.dig_cstride);

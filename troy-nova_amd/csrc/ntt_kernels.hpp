@@ -57,6 +57,7 @@ struct NttArgs {
     long long in2_bstride, in2_pstride;
     unsigned aux2_mod;                        // modulus index of the dropped prime q_{L-1}
     const ulonglong2* inv_table2;             // Shoup pairs of q_{L-1}^-1 mod q_j
+    unsigned fused_mode;                      // 0, or the NttFused variant to launch
 };
 
 // Fused prologues: what a coefficient looks like when it enters the transform.
@@ -712,7 +713,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                lds[pown + R] = A::template store_prep<SM>(x[R], md);
+                if constexpr (F_TAILRESC) lds[pown + R] = A::to_lds(x[R], md);       // stays a re-centred double through the transpose
+                else lds[pown + R] = A::template store_prep<SM>(x[R], md);
             });
             const unsigned gbase = gindex(wbase);
             // epilogue operands: request every word first (16 bytes per lane, all in flight together), then compute
@@ -739,6 +741,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = lds[pidx + lds_off(m * 128u)], v1 = lds[pidx + lds_off(m * 128u) + 1];
+                if constexpr (F_TAILRESC) {
+                    // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue
+                    const ulonglong2 pr = nt_load2(io.ext0 + gbase + idx);
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
+                    ulonglong2 a1 = a0, b1 = b0;
+                    if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
+                    const elem t0 = A::scale_by(f64_corr(f64_from_u64(pr.x), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
+                    const elem t1 = A::scale_by(f64_corr(f64_from_u64(pr.y), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
+                    v0 = f64_canon(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md.m);
+                    v1 = f64_canon(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md.m);
+                }
                 if constexpr (SM != NTT_STORE_PLAIN) {
                     constexpr int mk = (SM == NTT_STORE_KS_FINISH) ? m : 0;
                     v0 = A::template store_io<SM>(io, v0, e0[m].x, e1[mk].x, ed[mk].x, md);
@@ -751,7 +764,14 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int R = decltype(Rc)::value;
                 u64 v;
                 const unsigned gi = gindex(locbase | ((unsigned)R << S));
-                if constexpr (LAST) {
+                if constexpr (F_LAST) {
+                    // l = INTT(P qk^-1 + c) - r(s) qk^-1: the INTT of relinearize's last limb without ever forming that limb
+                    elem ys;
+                    if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) ys = x[R];                           // already scaled by N^-1
+                    else ys = f64_mulc(x[R], md.ninv, md.ninv_p, md.m.p);
+                    const elem rs = A::round_fix(io.in2[gi], io.aux_qd, io.aux_half_d, io.hm_d, md);
+                    v = f64_canon(ys - A::scale_by(rs, io.inv_d, md), md.m);
+                } else if constexpr (LAST) {
                     if constexpr (INV && A::FOLD_NINV && ((R >> (EB - 1)) & 1)) v = A::final_fwd(x[R], md);   // already scaled
                     else if constexpr (INV) v = A::final_inv(x[R], md);
                     else if constexpr (SM == NTT_STORE_PLAIN) v = A::final_fwd(x[R], md);

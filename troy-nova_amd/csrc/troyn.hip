@@ -320,6 +320,15 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
     // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
     const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
+    if constexpr (std::is_same<A, ArithF64>::value && (LOGN == 13 || LOGN == 14) && FIRST && LAST) {
+        // whole-limb kernels of the fused multiply -> relinearize -> rescale chain (NttFused)
+        if constexpr (INV) {
+            if (a.fused_mode == NTT_FUSED_MULPAIR) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>), grid, block, 0, s, a); return; }
+            if (a.fused_mode == NTT_FUSED_LAST_LIMB) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>), grid, block, 0, s, a); return; }
+        } else {
+            if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>), grid, block, 0, s, a); return; }
+        }
+    }
     if constexpr (!INV) {
         if (lm == NTT_LOAD_KS_ROUND || sm == NTT_STORE_KS_FINISH) {
             hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
@@ -417,7 +426,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     const size_t lp = batch * a.pcount * a.ncomp;
     if (lp == 0) return TROYN_OK;
     // limbs that share one input row (component stride 0) are co-located on an XCD by the fused forward kernels
-    a.xcd_groups = (a.load_mode != NTT_LOAD_PLAIN && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
+    a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     const bool f64 = use_f64(p, a.table_start, a.table_count);
@@ -863,6 +872,134 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
     hipLaunchKernelGGL(rescale_step2_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s, ch, p->d_mods, L, p->n,
                        (const u64*)in, temp, p->d_inv_last + (size_t)L * p->K, (u64*)out);
     LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused CKKS multiply -> relinearize -> rescale_to_next
+// ---------------------------------------------------------------------------------------
+struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, fast_total, prod3, relin2, sub, total; };
+
+static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
+    // the chain's kernels exist for whole-limb FP64 rings (N = 8192 / 16384, every modulus < 2^50)
+    return p->d_fwd_r2 && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);
+}
+
+static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
+    const size_t n = p->n;
+    MrrLayout w;
+    size_t off = 0;
+    w.digits = off;    off += batch * L * n;
+    w.poly_prod = off; off += batch * 2 * (size_t)(L + 1) * n;
+    w.spec_intt = off; off += batch * 2 * n;
+    w.last_intt = off; off += batch * 2 * n;
+    w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n;
+    w.fast_total = off;
+    // composition of the three public calls (any other shape)
+    off = 0;
+    w.prod3 = off;  off += batch * 3 * (size_t)L * n;
+    w.relin2 = off; off += batch * 2 * (size_t)L * n;
+    w.sub = off;
+    const size_t sub_bytes = std::max(troyn_relinearize_workspace_bytes(p, L, batch), troyn_divide_and_round_q_last_ntt_workspace_bytes(p, L, 2, batch));
+    off += (sub_bytes + 7) / 8;
+    w.total = std::max(off, w.fast_total);
+    return w;
+}
+
+extern "C" size_t troyn_ckks_multiply_relinearize_rescale_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch) {
+    if (!plan || L < 2 || L > plan->K) return 0;
+    return mrr_layout(plan, L, batch).total * sizeof(u64);
+}
+
+extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint32_t L, const uint64_t* a_, const uint64_t* b_,
+                                                       const uint64_t* const* keys, uint64_t* out_, void* workspace, size_t workspace_bytes,
+                                                       size_t batch, troyn_stream_t stream) {
+    const char* P = "[troyn_ckks_multiply_relinearize_rescale]";
+    if (!p || !a_ || !b_ || !keys || !out_ || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    const unsigned K = p->K, n = p->n;
+    if (K < 2) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
+    if (L < 2 || L > K - 1) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
+    const MrrLayout w = mrr_layout(p, L, batch);
+    if (workspace_bytes < w.total * sizeof(u64)) return fail(TROYN_E_WORKSPACE, std::string(P) + " workspace too small");
+    if (batch == 0) return TROYN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const u64* a = (const u64*)a_; const u64* b = (const u64*)b_;
+    u64* out = (u64*)out_;
+    u64* ws = (u64*)workspace;
+    int rc;
+    static int unfused = -1;    // TROYN_MRR=calls composes the three public calls (A/B testing)
+    if (unfused < 0) { const char* e = getenv("TROYN_MRR"); unfused = (e && std::strcmp(e, "calls") == 0) ? 1 : 0; }
+    if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 2 > 0x7fffffffull) {
+        // Evaluator::multiply (evaluator.cu:118-145) -> relinearize (evaluator_keyswitching.cu:119-144) -> rescale_to_next
+        if ((rc = launch_convolute(p->d_mods, n, 0, L, a, 2, b, 2, ws + w.prod3, batch, s))) return rc;
+        const size_t sub_bytes = (w.total - w.sub) * sizeof(u64);
+        if ((rc = troyn_relinearize(p, L, 1, 1, (const uint64_t*)(ws + w.prod3), keys, (uint64_t*)(ws + w.relin2), ws + w.sub, sub_bytes, batch, stream))) return rc;
+        return troyn_divide_and_round_q_last_ntt(p, L, (const uint64_t*)(ws + w.relin2), 2, out_, ws + w.sub, sub_bytes, batch, stream);
+    }
+    KeyPtrs kp;
+    std::memset(&kp, 0, sizeof(kp));
+    for (unsigned j = 0; j < L; j++) {
+        if (!keys[j]) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null key pointer");
+        kp.p[j] = (const u64*)keys[j];
+    }
+    const long long ct_b = 2ll * L * n, ct_p = (long long)L * n;           // strides of a, b
+    const long long pp_b = 2ll * (L + 1) * n, pp_p = (long long)(L + 1) * n;   // strides of poly_prod
+    auto mul_operands = [&](NttArgs& x, unsigned limb0) { x.mul_a = a; x.mul_b = b; x.mul_bstride = ct_b; x.mul_pstride = ct_p; x.mul_limb0 = limb0; };
+    // (1) digits = INTT(c2), c2 = a1 (.) b1 formed in the loader (kernel_dyadic_convolute's third output + transform_from_ntt, :817-821)
+    {
+        NttArgs x = contiguous_args(p, a, ws + w.digits, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        mul_operands(x, 0);
+        x.fused_mode = NTT_FUSED_MULPAIR;
+        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
+    }
+    // (2) key-switch inner product; the digit of row k under its own modulus is a1 (.) b1 again
+    {
+        double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
+        const size_t pairs = (size_t)L * 2 * K * (n / 2);
+        hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3((unsigned)std::min<size_t>((pairs + 255) / 256, 4096)), dim3(256), 0, s, kp, L, 2 * K, n, kf);
+        LAUNCH_CHECK();
+        KsMacArgs m;
+        std::memset(&m, 0, sizeof(m));
+        m.digits = ws + w.digits; m.dig_bstride = (long long)L * n; m.dig_cstride = n;
+        m.diag = a + ct_p; m.diag_b = b + ct_p; m.diag_bstride = ct_b; m.diag_cstride = n;
+        m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
+        m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
+        m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
+        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = (batch % 8 == 0) ? 1u : 0u;
+        TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
+        if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, m);
+        else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, m);
+    }
+    LAUNCH_CHECK();
+    // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
+    {
+        NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.spec_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        x.in_pstride = pp_p; x.in_bstride = pp_b;
+        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
+    }
+    // (4) l = INTT(relin_{L-1}) = INTT(P_{L-1} qk^-1 + c_{L-1}) - r(s) qk^-1   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
+    {
+        NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.last_intt, 2, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        x.in_pstride = pp_p; x.in_bstride = pp_b;
+        mul_operands(x, L - 1);
+        x.in2 = ws + w.spec_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
+        x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K + (L - 1);
+        x.fused_mode = NTT_FUSED_LAST_LIMB;
+        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
+    }
+    // (5) out_j = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1 for the L-1 remaining limbs: ski_util6/7 (:570-658), the
+    //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
+    {
+        NttArgs x = contiguous_args(p, ws + w.spec_intt, out, 2, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+        x.in_bstride = 2ll * n; x.in_pstride = n; x.in_cstride = 0;
+        x.in2 = ws + w.last_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
+        x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K;
+        x.aux2_mod = L - 1; x.inv_table2 = p->d_inv_last + (size_t)L * K;
+        x.ext0 = ws + w.poly_prod; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
+        mul_operands(x, 0);
+        x.fused_mode = NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
+        if ((rc = launch_ntt(p, x, batch, false, s))) return rc;
+    }
     return TROYN_OK;
 }
 

@@ -281,6 +281,17 @@ class Plan:
                                               _ptr(out), C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
         return out
 
+    def ckks_multiply_relinearize_rescale(self, L, a, b, keys, out=None):
+        """a, b [batch][2][L][N] (NTT form) -> rescale_to_next(relinearize(multiply(a, b))) [batch][2][L-1][N], one call"""
+        batch = a.numel() // (2 * L * self.n)
+        if out is None:
+            out = torch.empty((batch, 2, L - 1, self.n), dtype=torch.int64, device=a.device)
+        nbytes = self.lib.troyn_ckks_multiply_relinearize_rescale_workspace_bytes(self.h, L, batch)
+        ws = self.workspace(nbytes)
+        capi.check(self.lib.troyn_ckks_multiply_relinearize_rescale(self.h, L, _ptr(a), _ptr(b), self._key_ptrs(keys, L), _ptr(out),
+                                                                    C.c_void_p(ws.data_ptr()), ws.numel(), batch, _stream()))
+        return out
+
     # -- modulus switching -------------------------------------------------------------------------
     def divide_and_round_q_last(self, L, x, pcount, out=None):
         batch = x.numel() // (pcount * L * self.n)
