@@ -139,6 +139,7 @@ def test_ckks_cpp_api(dev):
 @pytest.mark.parametrize("dims,pack_lwe,mod_switch,objective", [
     ((25, 30, 35), 0, 1, "left"), ((25, 30, 35), 1, 1, "left"),                       # the example's two runs
     ((4, 600, 7), 0, 0, "left"), ((128, 64, 96), 1, 0, "left"), ((3, 5, 70), 1, 1, "left"), ((128, 64, 96), 0, 1, "left"),
+    ((512, 512, 512), 1, 1, "left"),                                                   # BASELINE config 5 at its quoted size, packed outputs
     ((25, 30, 35), 0, 1, "right"), ((128, 64, 96), 1, 1, "right"),                     # plaintext inputs x encrypted weights
     ((25, 30, 35), 0, 1, "crossed"), ((6, 40, 9), 0, 0, "crossed")])                   # both encrypted (BGV)
 def test_matmul_cpp_api(dev, dims, pack_lwe, mod_switch, objective):
@@ -285,3 +286,21 @@ def test_plain_ops_cpp_api(dev):
     r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "FAIL" not in r.stdout, r.stdout + r.stderr
     assert r.stdout.count(" ok\n") >= 54, r.stdout
+
+
+@pytest.mark.parametrize("scheme,log_t,bits", [
+    ("bfv", 20, [40, 40, 40]), ("bfv", 35, [30, 30, 30, 30]), ("bfv", 20, [60, 40, 40, 60]), ("bfv", 35, [60, 30, 30, 60]),
+    ("bgv", 20, [40, 40, 40]), ("bgv", 35, [30, 30, 30, 30]), ("bgv", 20, [60, 40, 40, 60]),
+    ("ckks", 0, [60, 60, 60]), ("ckks", 0, [40, 40, 40]), ("ckks", 0, [60, 40, 40, 60])])
+def test_decrypt_and_compare_matrix(dev, scheme, log_t, bits):
+    """The reference's own device-test matrix (test/evaluator.cu:276-690, :1115-1233: N = 32, these coefficient moduli, seed 0x123,
+    CKKS at scale 2^20 with tolerance 1e-2) through the C++ mirror: encode -> encrypt -> multiply / square / relinearize /
+    key-switch to another key / mod-switch / rescale / rotate / conjugate -> decrypt -> decode equals the plain computation.
+    An oracle-independent pin: a wrong key switch, tensor product or rescale does not decrypt to the right message."""
+    drv = os.path.join(ROOT, "tests", "cpp", "semantics_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/semantics_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme, str(log_t)] + [str(b) for b in bits], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "FAIL" not in r.stdout, r.stdout + r.stderr
+    names = [ln.split()[0] for ln in r.stdout.splitlines() if " pass " in ln]
+    assert "multiply" in names and "relinearize" in names and "keyswitching" in names

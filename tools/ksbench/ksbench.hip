@@ -210,6 +210,26 @@ int main(int argc, char** argv) {
     run_variant("ksmac2 ungrouped", [&](const NttArgs& v) {
         KsMacArgs kv = ka; kv.out = v.out; kv.grouped = 0;
         hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    // ---- plain forward / inverse NTT of B*(L+1)*L/2 limb-polynomials: register-block size A/B (profiles/r02_ntt_ab.txt) ----
+    if (wanted("ntt")) {
+        const size_t lp = B * 15;                     // limb-polynomials per launch
+        u64 *nin, *nout;
+        CHECK(hipMalloc(&nin, lp * N * 8)); CHECK(hipMalloc(&nout, lp * N * 8));
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, nin, lp * N, N, b.d_moduli, L, 1u, 0x7777ull);
+        NttArgs na;
+        std::memset(&na, 0, sizeof(na));
+        na.in = nin; na.out = nout; na.mods = b.d_mods; na.tw = b.d_fwd;
+        na.in_cstride = na.out_cstride = N; na.in_pstride = na.out_pstride = (long long)L * N; na.in_bstride = na.out_bstride = (long long)L * N;
+        na.pcount = 1; na.ncomp = L; na.table_start = 0; na.table_count = L; na.mode = 0; na.stream_loads = 1;
+        std::vector<u64> r4(lp * N), r5(lp * N);
+        float t4 = time_launch([&] { hipLaunchKernelGGL((ntt_pass_kernel<ArithF64, 14, 0, 14, 14, 4, false, true, true, 0>), dim3((unsigned)lp), dim3(1024), 0, 0, na); }, reps);
+        CHECK(hipMemcpy(r4.data(), nout, lp * N * 8, hipMemcpyDeviceToHost));
+        float t5 = time_launch([&] { hipLaunchKernelGGL((ntt_pass_kernel<ArithF64, 14, 0, 14, 14, 5, false, true, true, 0>), dim3((unsigned)lp), dim3(512), 0, 0, na); }, reps);
+        CHECK(hipMemcpy(r5.data(), nout, lp * N * 8, hipMemcpyDeviceToHost));
+        const double gb = 16.0 * N * lp / 1e3;
+        printf("%-28s %9.1f us  %7.1f GB/s\n", "ntt fwd 16/thr x1024 (3 xchg)", t4, gb / t4);
+        printf("%-28s %9.1f us  %7.1f GB/s  %s\n", "ntt fwd 32/thr x512 (2 xchg)", t5, gb / t5, r4 == r5 ? "bit-exact" : "MISMATCH");
+    }
     // ablations (timing only; results are wrong by design)
     auto run_abl = [&](const char* name, auto kern) {
         if (!wanted("abl")) return;

@@ -200,12 +200,21 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_centralize_kernel(unsigned c
                                                                       const u64* plain, unsigned plain_coeff_count, long long plain_bstride, u64* dest) {
     const unsigned l = blk_row(chunks) % L;
     const size_t item = blk_row(chunks) / L;
-    const u64 inc = mods[l].q - t, threshold = (t + 1) >> 1;
+    // fast plain lift (t < q_l): m + (q_l - t).  Otherwise (scaling_variant.cu:344-349, multiply_plain_normal_no_fast_plain_lift then
+    // decompose_array): the multi-precision m + (Q - t) reduced mod q_l = (m mod q_l) + (q_l - (t mod q_l)) mod q_l, as Q = 0 mod q_l
+    const DevModulus md = mods[l];
+    const bool fast = t < md.q;
+    const u64 t_red = fast ? t : barrett64(t, md.q, md.ratio_hi);
+    const u64 inc = md.q - t_red, threshold = (t + 1) >> 1;
     const u64* pl = plain + item * plain_bstride;
     u64* de = dest + (item * L + l) * (size_t)n;
     for (unsigned i = blk_col(chunks); i < n; i += chunks * blockDim.x) {
         u64 v = 0;
-        if (i < plain_coeff_count) { const u64 m = pl[i]; v = (m >= threshold) ? m + inc : m; }
+        if (i < plain_coeff_count) {
+            const u64 m = pl[i];
+            if (fast) v = (m >= threshold) ? m + inc : m;
+            else { const u64 r = barrett64(m, md.q, md.ratio_hi); v = (m >= threshold) ? add_mod(r, inc == md.q ? 0 : inc, md.q) : r; }
+        }
         de[i] = v;
     }
 }

@@ -1548,8 +1548,6 @@ extern "C" int troyn_plain_centralize(const troyn_plan* p, uint32_t L, uint64_t 
     if (!p || !plain || !dest) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] null argument");
     if (L < 1 || L > p->K) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] Destination has incorrect size.");
     if (plain_coeff_count > p->n) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] destination_coeff_count should no less than plain_coeff_count.");
-    for (unsigned i = 0; i < L; i++)
-        if (p->moduli[i] <= t) return fail(TROYN_E_MODULUS, "[scaling_variant::centralize] plain modulus is not below every coefficient modulus (no fast plain lift).");
     if (batch == 0) return TROYN_OK;
     const unsigned ch = chunks_single(p->n);
     const size_t rows = batch * L;
