@@ -174,6 +174,38 @@ def main():
         res["cfg5_e2e"]["cpu_packed_flow_ms_estimate"]["total"] = round(sum(phases.values()) * 1e3, 1)
         res["cfg5_e2e"]["cpu_packed_flow_note"] = "oracle (plain C restatement of the reference's host branches), one host thread, per-object timings multiplied out"
 
+    if a.only in ("", "u64"):
+        # the integer-butterfly policy (ArithU64): any modulus >= 2^50, e.g. the reference's troybench default {60,40,40,60}
+        # (test/bench/he_operations.cu:19-33) at N = 8192 -- every launch whose table slice contains a 60-bit prime takes it
+        n, B = 8192, 1024
+        q = pkg.capi.coeff_modulus_create(n, [60, 40, 40, 60])
+        K, L = 4, 3
+        plan = pkg.Plan(dev, 13, q)
+        x = residues(pkg, (B, 2), q[:L], n, dev, gen)
+        xn = torch.empty_like(x)
+        t_f = timed(lambda: plan.ntt(x, 2, L, out=xn), a.reps)
+        t_i = timed(lambda: plan.ntt(xn, 2, L, inverse=True, out=x), a.reps)
+        nb = 16.0 * n * B * 2 * L
+        keys = [residues(pkg, (2,), q, n, dev, gen) for _ in range(L)]
+        ct3 = residues(pkg, (B, 3), q[:L], n, dev, gen)
+        out = torch.empty((B, 2, L, n), dtype=torch.int64, device=dev)
+        t_rn = timed(lambda: plan.relinearize(L, ct3, keys, out=out, is_ckks=True, is_ntt_form=True), a.reps)
+        t_rc = timed(lambda: plan.relinearize(L, ct3, keys, out=out, is_ckks=False, is_ntt_form=False), a.reps)
+        # same shape with 40-bit primes only (FP64 policy) for comparison
+        q2 = pkg.capi.coeff_modulus_create(n, [40, 40, 40, 40])
+        plan2 = pkg.Plan(dev, 13, q2)
+        y = residues(pkg, (B, 2), q2[:L], n, dev, gen)
+        yn = torch.empty_like(y)
+        t_f2 = timed(lambda: plan2.ntt(y, 2, L, out=yn), a.reps)
+        keys2 = [residues(pkg, (2,), q2, n, dev, gen) for _ in range(L)]
+        ct32 = residues(pkg, (B, 3), q2[:L], n, dev, gen)
+        t_rn2 = timed(lambda: plan2.relinearize(L, ct32, keys2, out=out, is_ckks=True, is_ntt_form=True), a.reps)
+        res["u64_path"] = {"what": "N=8192 {60,40,40,60} (L=3, K=4): integer butterflies (ArithU64) vs the same shape on {40,40,40,40} (exact-FP64 policy)", "batch": B,
+                           "ntt_forward_GBps": round(nb / t_f / 1e9, 1), "ntt_forward_hbm_frac": round(nb / t_f / 1e9 / 8000.0, 4),
+                           "ntt_inverse_GBps": round(nb / t_i / 1e9, 1), "ntt_inverse_hbm_frac": round(nb / t_i / 1e9 / 8000.0, 4),
+                           "relinearize_ntt_form_ops_per_s": round(B / t_rn, 1), "relinearize_coeff_form_ops_per_s": round(B / t_rc, 1),
+                           "fp64_policy_same_shape": {"ntt_forward_GBps": round(nb / t_f2 / 1e9, 1), "relinearize_ntt_form_ops_per_s": round(B / t_rn2, 1)}}
+
     print(json.dumps(res, indent=1))
 
 

@@ -14,7 +14,8 @@
 //
 // Design here (gfx950, wave64, FP64-exact arithmetic of dev_math_f64.hpp, moduli < 2^50):
 //   * A workgroup owns a TILE of 2^13 outputs of one (item, row): the whole limb at N = 8192, one HALF of the
-//     outputs at N = 16384 -- after the first Cooley-Tukey layer the two halves of a negacyclic NTT are independent
+//     outputs at N = 16384 (one QUARTER at N = 32768, two layers applied while loading) -- after the first Cooley-Tukey
+//     layer the two halves of a negacyclic NTT are independent
 //     transforms, so a half-tile workgroup applies layer 0 while loading (u +- w*v, the twiddle multiply is the
 //     only duplicated work, ~8 % more FP64 ops) and then runs a 13-layer transform in 68 KiB of LDS.  Two
 //     independent workgroups share a CU: one computes while the other waits on HBM / LDS / a barrier.
@@ -141,10 +142,11 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 template <int LOGN, bool DIGF64, int ABL = 0>
 __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
     constexpr auto abl = [](int bit) constexpr { return ((ABL >> bit) & 1) != 0; };
-    static_assert(LOGN == 13 || LOGN == 14, "ksmac2 covers N = 8192 and N = 16384");
-    constexpr bool SPLIT = LOGN == 14;
+    static_assert(LOGN >= 13 && LOGN <= 15, "ksmac2 covers N = 8192, 16384 and 32768");
+    constexpr bool SPLIT = LOGN == 14;        // half tiles: one Cooley-Tukey layer applied while loading
+    constexpr bool SPLIT4 = LOGN == 15;       // quarter tiles: two layers applied while loading
     constexpr unsigned N = 1u << LOGN;
-    constexpr int HALVES = SPLIT ? 2 : 1;
+    constexpr int HALVES = 1 << (LOGN - KSM_TB);
     __shared__ __attribute__((aligned(16))) u64 lds[KSM_LDS_WORDS];
 
     const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -307,6 +309,37 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
                     x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
                 });
             });
+        } else if constexpr (SPLIT4) {
+            // quarter tile h = 2 hA + hB of a 2^15-point transform: with (a, b, c, d) = x[i], x[i+N/4], x[i+N/2], x[i+3N/4],
+            //   layer 0:  u = a + sA w1 c,  v = b + sA w1 d          (sA = -1 for the upper half hA = 1)
+            //   layer 1:  x = u + sB wB v,  wB = tw[2 + hA]           (sB = -1 for the odd quarter hB = 1)
+            // the three twiddle products are the work the four quarter-tile workgroups duplicate
+            const double w1 = tws[1], wB = tws[2 + (h >> 1)];
+            const double sA = (h >> 1) ? -1.0 : 1.0, sB = (h & 1) ? -1.0 : 1.0;
+            static_for<0, 4>([&](auto hc) {
+                constexpr int hb = decltype(hc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                ulonglong2 ra[4], rb_[4], rc[4], rd[4];
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int j = decltype(ic)::value, i = hb * 4 + j;     // i = b9 | R3<<1
+                    constexpr unsigned off = ((i & 1) << 9) + ((i >> 1) << 10);
+                    ra[j] = ksm_gload<ulonglong2>(gin_u + off, gin_off);
+                    rb_[j] = ksm_gload<ulonglong2>(gin_u + 8192 + off, gin_off);
+                    rc[j] = ksm_gload<ulonglong2>(gin_u + 16384 + off, gin_off);
+                    rd[j] = ksm_gload<ulonglong2>(gin_u + 24576 + off, gin_off);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int j = decltype(ic)::value, i = hb * 4 + j;
+                    // raw inputs below 2^50: |u|, |v| <= 3.3 p, |x| <= 5 p before the re-centring
+                    const double u0 = __builtin_fma(sA, f64_mulq(dig_in(rc[j].x), w1, inv_p, p), dig_in(ra[j].x));
+                    const double u1 = __builtin_fma(sA, f64_mulq(dig_in(rc[j].y), w1, inv_p, p), dig_in(ra[j].y));
+                    const double v0 = __builtin_fma(sA, f64_mulq(dig_in(rd[j].x), w1, inv_p, p), dig_in(rb_[j].x));
+                    const double v1 = __builtin_fma(sA, f64_mulq(dig_in(rd[j].y), w1, inv_p, p), dig_in(rb_[j].y));
+                    x[2 * i] = f64_corr(__builtin_fma(sB, f64_mulq(v0, wB, inv_p, p), u0), fm);
+                    x[2 * i + 1] = f64_corr(__builtin_fma(sB, f64_mulq(v1, wB, inv_p, p), u1), fm);
+                });
+            });
         } else {
             static_for<0, 16>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             constexpr int bit = 12 - li, rb = 4 - li;
             static_for<0, (1 << li)>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                const unsigned idx = (N >> (bit + 1)) + (SPLIT ? (h << (12 - bit)) : 0u) + g;
+                const unsigned idx = (N >> (bit + 1)) + (h << (12 - bit)) + g;
                 const double w = tws[idx];
                 static_for<0, (1 << rb)>([&](auto oc) {
                     constexpr int R0 = (g << (rb + 1)) | decltype(oc)::value, R1 = R0 | (1 << rb);

@@ -224,7 +224,7 @@ static int plan_upload(troyn_plan* p) {
         for (size_t x = 0; x < n; x++) tmp[x] = (double)p->tables[i].inv[x].operand;
         HIP_TRY(hipMemcpy(p->d_inv_f64 + i * n, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (p->log_n == 13 || p->log_n == 14) {
+    if (p->log_n >= 13 && p->log_n <= 15) {
         // round vectors of ksmac2_kernel: slot s = (1 << lvl) + g of the thread (round 2) / of the index bits above
         // bit 9 (round 1) holds the twiddle of butterfly group g of the round's layer lvl (ksmac_kernels.hpp)
         const size_t r1n = (n >> 10) * 32;
@@ -641,10 +641,10 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     //     transforms that row's L digits one after the other and multiplies them into register accumulators with
     //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
     //     (L+1)*L transformed digits never reach HBM.
-    const bool mac_fused = !g_ks_unfused_mac && p->log_n >= 10 && p->log_n <= 14 && batch * (size_t)(L + 1) <= 0x7fffffffull;
+    const bool mac_fused = !g_ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull;
     static int ks_mac_gen = -1;     // TROYN_KS_MAC=v1 keeps the first-generation fused kernel (A/B testing)
     if (ks_mac_gen < 0) { const char* e = getenv("TROYN_KS_MAC"); ks_mac_gen = (e && std::strcmp(e, "v1") == 0) ? 1 : 2; }
-    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 1) * 2 <= 0x7fffffffull) {
+    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 1) * 4 <= 0x7fffffffull) {
         // ksmac2_kernel: tiles of 2^13 outputs, two workgroups per CU, keys prepared once per call (ksmac_kernels.hpp)
         double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
         {
@@ -664,11 +664,12 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.grouped = (batch % 8 == 0) ? 1u : 0u;
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
+            if (p->log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * (L + 1) * 4)), dim3(KSM_THREADS), 0, s, a);
+            else if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
             else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, a);
         }
         LAUNCH_CHECK();
-    } else if (mac_fused) {
+    } else if (mac_fused && p->log_n <= 14) {
         NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
         a.in_bstride = (long long)digits_bstride; a.in_pstride = 0; a.in_cstride = n;
         a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
@@ -882,7 +883,7 @@ struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, fas
 
 static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
     // the chain's kernels exist for whole-limb FP64 rings (N = 8192 / 16384, every modulus < 2^50)
-    return p->d_fwd_r2 && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);
+    return p->d_fwd_r2 && (p->log_n == 13 || p->log_n == 14) && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);
 }
 
 static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
