@@ -32,6 +32,12 @@ struct DevModulus {
 static_assert(sizeof(DevModulus) == 96, "DevModulus layout");
 
 __device__ __forceinline__ u64 mul_hi(u64 a, u64 b) { return __umul64hi(a, b); }
+// full 64 x 64 -> 128 product in one piece: the compiler builds it from four v_mad_u64_u32; asking for a*b and
+// __umul64hi(a, b) separately costs seven multiplier instructions instead
+__device__ __forceinline__ void mul128(u64 a, u64 b, u64& lo, u64& hi) {
+    const u128 p = (u128)a * b;
+    lo = (u64)p; hi = (u64)(p >> 64);
+}
 
 // multiply_uint64operand_mod_lazy: result in [0, 2q) for any 64-bit x
 __device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 wq, u64 q) { return w * x - mul_hi(x, wq) * q; }
@@ -51,10 +57,11 @@ __device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 ratio_hi) {
 // Modulus::reduce_uint128_limbs, same word-level sequence as modulus.h:44-78
 __device__ __forceinline__ u64 barrett128(u64 in0, u64 in1, u64 q, u64 r0, u64 r1) {
     u64 carry = mul_hi(in0, r0);
-    u64 t2lo = in0 * r1, t2hi = mul_hi(in0, r1);
+    u64 t2lo, t2hi;
+    mul128(in0, r1, t2lo, t2hi);
     u64 tmp1 = t2lo + carry;
     u64 tmp3 = t2hi + (tmp1 < t2lo ? 1ull : 0ull);
-    t2lo = in1 * r0; t2hi = mul_hi(in1, r0);
+    mul128(in1, r0, t2lo, t2hi);
     u64 tmp1b = tmp1 + t2lo;
     carry = t2hi + (tmp1b < tmp1 ? 1ull : 0ull);
     u64 quot = in1 * r1 + tmp3 + carry;
@@ -63,7 +70,9 @@ __device__ __forceinline__ u64 barrett128(u64 in0, u64 in1, u64 q, u64 r0, u64 r
 }
 
 __device__ __forceinline__ u64 mul_mod(u64 a, u64 b, const DevModulus& m) {
-    return barrett128(a * b, mul_hi(a, b), m.q, m.ratio_lo, m.ratio_hi);
+    u64 lo, hi;
+    mul128(a, b, lo, hi);
+    return barrett128(lo, hi, m.q, m.ratio_lo, m.ratio_hi);
 }
 
 __device__ __forceinline__ u64 add_mod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
@@ -72,9 +81,9 @@ __device__ __forceinline__ u64 neg_mod(u64 a, u64 q) { return a == 0 ? 0 : q - a
 
 // 128-bit accumulate helper for lazy dot products
 __device__ __forceinline__ void mac128(u64& lo, u64& hi, u64 a, u64 b) {
-    u64 pl = a * b, ph = mul_hi(a, b);
-    lo += pl;
-    hi += ph + (lo < pl ? 1ull : 0ull);
+    u128 acc = ((u128)hi << 64) | lo;
+    acc += (u128)a * b;
+    lo = (u64)acc; hi = (u64)(acc >> 64);
 }
 
 }  // namespace troyn

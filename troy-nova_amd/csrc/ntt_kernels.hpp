@@ -376,8 +376,9 @@ struct ArithF64 {
         }
     }
     // ---- fused chain (NttFused): every value an exact integer; products by f64_mulq (|result| <= 0.69 p for a re-centred factor) ----
+    // canonical x, y < p: no re-centring needed in front of the product, |result| <= 0.875 p
     static __device__ __forceinline__ elem prod_in(u64 x, u64 y, const Mod& m) {
-        return f64_mulq(f64_corr(f64_from_u64(x), m.m), f64_from_u64(y), m.m.inv_p, m.m.p);
+        return f64_mulq(f64_from_u64(x), f64_from_u64(y), m.m.inv_p, m.m.p);
     }
     // c_k at one coefficient: c_0 = a0 b0, c_1 = a0 b1 + a1 b0
     static __device__ __forceinline__ elem tensor_term(unsigned k, u64 a0, u64 a1, u64 b0, u64 b1, const Mod& m) {
@@ -389,7 +390,7 @@ struct ArithF64 {
         t = (t >= aux_q) ? t - aux_q : t;
         return f64_corr(t - hm, m.m);
     }
-    static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= 0.5p+1
+    static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= p
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
     static __device__ __forceinline__ elem from_lds(u64 raw) { return f64_bits_to_double(raw); }
@@ -593,8 +594,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
                     ulonglong2 a1 = a0, b1 = b0;
                     if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
-                    const elem e0 = A::scale_by(f64_corr(f64_from_u64(vp.x), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md);
-                    const elem e1 = A::scale_by(f64_corr(f64_from_u64(vp.y), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md);
+                    const elem e0 = A::scale_by(f64_from_u64(vp.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md);
+                    const elem e1 = A::scale_by(f64_from_u64(vp.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md);
                     lds[pidx + lds_off(m * 128u)] = A::to_lds(e0, md);
                     lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(e1, md);
                 } else {
@@ -747,8 +748,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
                     ulonglong2 a1 = a0, b1 = b0;
                     if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
-                    const elem t0 = A::scale_by(f64_corr(f64_from_u64(pr.x), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
-                    const elem t1 = A::scale_by(f64_corr(f64_from_u64(pr.y), md.m), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
+                    const elem t0 = A::scale_by(f64_from_u64(pr.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
+                    const elem t1 = A::scale_by(f64_from_u64(pr.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
                     v0 = f64_canon(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md.m);
                     v1 = f64_canon(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md.m);
                 }
