@@ -429,7 +429,28 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
-    const bool f64 = use_f64(p, a.table_start, a.table_count);
+    bool f64 = use_f64(p, a.table_start, a.table_count);
+    if (!f64 && !g_force_integer_ntt && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
+        a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && a.fused_mode == 0 && !two_pass_scratch) {
+        // A plain component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
+        // runs of one class, so that the limbs below 2^50 take the FP64 butterflies instead of following the 60-bit limbs into the
+        // integer ones.  Limbs are independent; results are unchanged.
+        bool mixed = false;
+        for (unsigned j = 1; j < a.ncomp && !mixed; j++) mixed = p->small_modulus[a.table_start + j] != p->small_modulus[a.table_start];
+        if (mixed) {
+            unsigned j0 = 0;
+            while (j0 < a.ncomp) {
+                unsigned j1 = j0 + 1;
+                while (j1 < a.ncomp && p->small_modulus[a.table_start + j1] == p->small_modulus[a.table_start + j0]) j1++;
+                NttArgs r = a;
+                r.in = a.in + (long long)j0 * a.in_cstride; r.out = a.out + (long long)j0 * a.out_cstride;
+                r.ncomp = j1 - j0; r.table_start = a.table_start + j0; r.table_count = j1 - j0;
+                if (int rc = launch_ntt(p, r, batch, inverse, s)) return rc;
+                j0 = j1;
+            }
+            return TROYN_OK;
+        }
+    }
     bool done;
     if (f64) {
         a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
