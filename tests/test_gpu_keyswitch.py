@@ -186,3 +186,36 @@ def test_ckks_multiply_relinearize_rescale_fused(O, pkg, dev, n, bits, L, batch)
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), i
     # the operands are left untouched
     assert np.array_equal(pkg.to_host(da), a) and np.array_equal(pkg.to_host(db), b)
+
+
+def test_fused_entry_errors_and_timer(O, pkg, dev):
+    """error behaviour of the one-call chain (the reference's messages for the step that would have failed) and the kernel-timer hook"""
+    import ctypes as C
+    import torch
+    n, L = 8192, 3
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, [40, 40, 40, 40])
+    keys = [pkg.to_device(k, dev) for k in ctx.random_keys(2, L)]
+    a = pkg.to_device(np.stack([ctx.random_ct(1, 2, L)]), dev)
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.ckks_multiply_relinearize_rescale(1, a[:, :, :1].contiguous(), a[:, :, :1].contiguous(), keys)     # nothing to rescale to
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.ckks_multiply_relinearize_rescale(L + 1, a, a, keys)                                                  # no special prime left
+    lib = plan.lib
+    ws = torch.empty(64, dtype=torch.uint8, device=dev)
+    out = torch.empty((1, 2, L - 1, n), dtype=torch.int64, device=dev)
+    kp = (C.c_void_p * L)(*[k.data_ptr() for k in keys])
+    rc = lib.troyn_ckks_multiply_relinearize_rescale(plan.h, L, C.c_void_p(a.data_ptr()), C.c_void_p(a.data_ptr()), kp, C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(ws.data_ptr()), ws.numel(), 1, None)
+    assert rc == -3 and b"workspace too small" in lib.troyn_last_error()
+    # kernel timer: one span per key-switch inner product while enabled, none when disabled
+    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 1))
+    for _ in range(3):
+        plan.ckks_multiply_relinearize_rescale(L, a, a, keys)
+    ms, cnt = C.c_double(0.0), C.c_uint64(0)
+    pkg.capi.check(lib.troyn_kernel_timer_read(0, C.byref(ms), C.byref(cnt)))
+    assert cnt.value == 3 and 0.0 < ms.value < 1000.0
+    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 0))
+    plan.ckks_multiply_relinearize_rescale(L, a, a, keys)
+    pkg.capi.check(lib.troyn_kernel_timer_read(0, C.byref(ms), C.byref(cnt)))
+    assert cnt.value == 0
+    assert lib.troyn_kernel_timer_enable(7, 1) == -1

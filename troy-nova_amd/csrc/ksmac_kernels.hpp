@@ -368,7 +368,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- exchange 0 -> 1 -------------------------------------------------------------------------------
         double ta[8], tb[8];
-        if constexpr (!abl(2)) __builtin_amdgcn_s_barrier();     // every wave has finished reading its slice of the previous digit
+        if constexpr (!abl(2)) __syncthreads();     // every wave has finished reading its slice of the previous digit
         if constexpr (!abl(2)) static_for<0, 16>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr unsigned off = ksm_phys(((i & 1) << 9) | ((i >> 1) << 10));

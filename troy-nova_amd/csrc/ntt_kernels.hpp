@@ -390,6 +390,7 @@ struct ArithF64 {
         t = (t >= aux_q) ? t - aux_q : t;
         return f64_corr(t - hm, m.m);
     }
+    static __device__ __forceinline__ u64 canon_small(elem x, const Mod& m) { return f64_to_u64(x < 0.0 ? x + m.m.p : x); }   // |x| < p
     static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= p
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
     static __device__ __forceinline__ u64 store_mid(elem x, const Mod&) { return f64_double_to_bits(x); }
@@ -626,7 +627,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     const u64 raw2 = io.in2[gindex(locbase | ((unsigned)R << S))];
                     const elem rs = A::round_fix(raw, io.aux_qd, io.aux_half_d, io.hm_d, md);
                     const elem fl = A::round_fix(raw2, io.aux2_qd, io.aux2_half_d, io.hm2_d, md);
-                    x[R] = f64_corr(A::scale_by(rs, io.inv_d, md) + fl, md.m);
+                    x[R] = A::scale_by(rs, io.inv_d, md) + fl;      // |x| <= 1.2 p: a 4-layer block from here stays below 7.7 p < 2^53
                 }
                 else if constexpr (FIRST) x[R] = A::template load_io<LM>(io, raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
@@ -750,8 +751,9 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
                     const elem t0 = A::scale_by(f64_from_u64(pr.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
                     const elem t1 = A::scale_by(f64_from_u64(pr.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
-                    v0 = f64_canon(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md.m);
-                    v1 = f64_canon(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md.m);
+                    // the product of a re-centred factor is within (-0.7 p, 0.7 p): one conditional add canonicalises it
+                    v0 = A::canon_small(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md);
+                    v1 = A::canon_small(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md);
                 }
                 if constexpr (SM != NTT_STORE_PLAIN) {
                     constexpr int mk = (SM == NTT_STORE_KS_FINISH) ? m : 0;
