@@ -591,6 +591,14 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // ---------------------------------------------------------------------------------------
 // key switching
 // ---------------------------------------------------------------------------------------
+// workgroup order of ksmac2_kernel: 1 = all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache),
+// 2 = row-major (one output row at a time on the whole chip: keys L2-resident, digits re-fetched per row); TROYN_KS_ORDER=item|row
+static unsigned ksmac_order(size_t batch) {
+    static int order = -1;
+    if (order < 0) { const char* e = getenv("TROYN_KS_ORDER"); order = (e && std::strcmp(e, "row") == 0) ? 2 : 1; }
+    return (batch % 8 == 0) ? (unsigned)order : 0u;
+}
+
 struct KsLayout {
     size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, total;  // element offsets
 };
@@ -682,7 +690,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.mods = p->d_mods; a.tw = p->d_fwd_f64; a.tw_r1 = p->d_fwd_r1; a.tw_r2 = p->d_fwd_r2;
         a.keys = kf; a.key_jstride = 2ll * K * n; a.key_pstride = (long long)K * n;
         a.L = L; a.table_start = 0; a.table_count = K; a.batch = (unsigned)batch;
-        a.grouped = (batch % 8 == 0) ? 1u : 0u;
+        a.grouped = ksmac_order(batch);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
             if (p->log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * (L + 1) * 4)), dim3(KSM_THREADS), 0, s, a);
@@ -987,7 +995,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
         m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
-        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = (batch % 8 == 0) ? 1u : 0u;
+        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
         if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, m);
         else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, m);
