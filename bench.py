@@ -288,6 +288,19 @@ def extra_configs(torch, pkg, device):
     """NTT + dyadic + INTT and relinearize throughput at N = 8192 (cfg2 shape) and N = 32768 (cfg4 shape); synthetic residues"""
     res = {}
     gen = torch.Generator(device=device).manual_seed(7)
+    # the headline operation (CKKS multiply + relinearize + rescale, six 50-bit primes) at north_star's other two ring sizes
+    for n, log_n, Bn in ((8192, 13, 2048), (32768, 15, 256)):
+        q = pkg.capi.coeff_modulus_create(n, [50] * 6)
+        L = 5
+        plan = pkg.Plan(device, log_n, q)
+        x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
+        keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
+        out = torch.empty((Bn, 2, L - 1, n), dtype=torch.int64, device=device)
+        t = timed(torch, lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out), 10)
+        res["ckks_mul_relin_rescale_N%d" % n] = {"what": "CKKS N=%d, 6x50-bit (K=6, L=5): multiply + relinearize + rescale_to_next (fused entry)" % n,
+                                                  "batch": Bn, "ops_per_s": round(Bn / t, 1)}
+        del x, y, keys, out, plan
+        torch.cuda.empty_cache()
     # N = 8192, 3 x 40-bit (L = 2 data limbs): BASELINE configs[1]
     n, Bn = 8192, 2048
     q = pkg.capi.coeff_modulus_create(n, [40, 40, 40])

@@ -504,10 +504,13 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     };
     constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
     constexpr int SM = (LAST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_STORE_KS_FINISH : IOM == 2 ? (int)NTT_STORE_RESCALE : (int)NTT_STORE_PLAIN) : (int)NTT_STORE_PLAIN;
-    constexpr bool FUSED = IOM >= 3;     // NttFused: whole-limb kernels of the multiply -> relinearize -> rescale chain
-    constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR, F_LAST = IOM == NTT_FUSED_LAST_LIMB, F_TAILRESC = IOM == NTT_FUSED_TAIL_RESCALE;
-    static_assert(!FUSED || (!KSMAC && FIRST && LAST && C == 0 && ROUNDS_OK(G, EB) && std::is_same<A, ArithF64>::value), "fused chain: whole-limb FP64 kernels");
-    static_assert(!FUSED || (INV == (F_MULPAIR || F_LAST)), "fused chain: transform direction");
+    constexpr bool FUSED = IOM >= 3;     // NttFused: kernels of the multiply -> relinearize -> rescale chain (loaders act in the first pass
+                                         // of a transform, epilogues in its last pass: one kernel for N <= 16384, two for N = 32768)
+    constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR && FIRST;
+    constexpr bool F_LAST_LD = IOM == NTT_FUSED_LAST_LIMB && FIRST, F_LAST_ST = IOM == NTT_FUSED_LAST_LIMB && LAST;
+    constexpr bool F_TR_LD = IOM == NTT_FUSED_TAIL_RESCALE && FIRST, F_TR_ST = IOM == NTT_FUSED_TAIL_RESCALE && LAST;
+    static_assert(!FUSED || (!KSMAC && std::is_same<A, ArithF64>::value), "fused chain: FP64 kernels");
+    static_assert(!FUSED || (INV == (IOM == NTT_FUSED_MULPAIR || IOM == NTT_FUSED_LAST_LIMB)), "fused chain: transform direction");
     NttIo io;
     if constexpr (FUSED) { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; ntt_io_fused(io, a, b, k, j, mi); }
     else if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
@@ -589,7 +592,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     const ulonglong2 va = nt_load2(io.a1 + mul_off + gbase + idx), vb = nt_load2(io.b1 + mul_off + gbase + idx);
                     lds[pidx + lds_off(m * 128u)] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
                     lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
-                } else if constexpr (F_LAST) {
+                } else if constexpr (F_LAST_LD) {
                     // P qk^-1 + c_k at the dropped limb
                     const ulonglong2 vp = nt_load2(gin + gbase + idx);
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
@@ -609,7 +612,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 const u64 raw = lds[pown + R];
-                if constexpr (F_MULPAIR || F_LAST) x[R] = A::from_lds(raw);     // re-centred when it was parked
+                if constexpr (F_MULPAIR || F_LAST_LD) x[R] = A::from_lds(raw);     // re-centred when it was parked
                 else if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
             });
@@ -622,7 +625,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
 #endif
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
-                else if constexpr (F_TAILRESC) {
+                else if constexpr (F_TR_LD) {
                     // r_j(s) qk^-1 + f_j(l): the rounding fixes of the key switch and of the rescale enter ONE transform
                     const u64 raw2 = io.in2[gindex(locbase | ((unsigned)R << S))];
                     const elem rs = A::round_fix(raw, io.aux_qd, io.aux_half_d, io.hm_d, md);
@@ -715,7 +718,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                if constexpr (F_TAILRESC) lds[pown + R] = A::to_lds(x[R], md);       // stays a re-centred double through the transpose
+                if constexpr (F_TR_ST) lds[pown + R] = A::to_lds(x[R], md);       // stays a re-centred double through the transpose
                 else lds[pown + R] = A::template store_prep<SM>(x[R], md);
             });
             const unsigned gbase = gindex(wbase);
@@ -743,7 +746,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = lds[pidx + lds_off(m * 128u)], v1 = lds[pidx + lds_off(m * 128u) + 1];
-                if constexpr (F_TAILRESC) {
+                if constexpr (F_TR_ST) {
                     // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue
                     const ulonglong2 pr = nt_load2(io.ext0 + gbase + idx);
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
@@ -767,7 +770,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr int R = decltype(Rc)::value;
                 u64 v;
                 const unsigned gi = gindex(locbase | ((unsigned)R << S));
-                if constexpr (F_LAST) {
+                if constexpr (F_LAST_ST) {
                     // l = INTT(P qk^-1 + c) - r(s) qk^-1: the INTT of relinearize's last limb without ever forming that limb
                     elem ys;
                     if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) ys = x[R];                           // already scaled by N^-1

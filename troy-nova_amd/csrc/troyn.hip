@@ -320,8 +320,8 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
     // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
     const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
-    if constexpr (std::is_same<A, ArithF64>::value && (LOGN == 13 || LOGN == 14) && FIRST && LAST) {
-        // whole-limb kernels of the fused multiply -> relinearize -> rescale chain (NttFused)
+    if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
+        // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768
         if constexpr (INV) {
             if (a.fused_mode == NTT_FUSED_MULPAIR) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>), grid, block, 0, s, a); return; }
             if (a.fused_mode == NTT_FUSED_LAST_LIMB) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>), grid, block, 0, s, a); return; }
@@ -912,7 +912,7 @@ struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, fas
 
 static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
     // the chain's kernels exist for whole-limb FP64 rings (N = 8192 / 16384, every modulus < 2^50)
-    return p->d_fwd_r2 && (p->log_n == 13 || p->log_n == 14) && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);
+    return p->d_fwd_r2 && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);     // d_fwd_r2: N = 8192 / 16384 / 32768
 }
 
 static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
@@ -959,7 +959,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     int rc;
     static int unfused = -1;    // TROYN_MRR=calls composes the three public calls (A/B testing)
     if (unfused < 0) { const char* e = getenv("TROYN_MRR"); unfused = (e && std::strcmp(e, "calls") == 0) ? 1 : 0; }
-    if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 2 > 0x7fffffffull) {
+    if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 4 > 0x7fffffffull) {
         // Evaluator::multiply (evaluator.cu:118-145) -> relinearize (evaluator_keyswitching.cu:119-144) -> rescale_to_next
         if ((rc = launch_convolute(p->d_mods, n, 0, L, a, 2, b, 2, ws + w.prod3, batch, s))) return rc;
         const size_t sub_bytes = (w.total - w.sub) * sizeof(u64);
@@ -997,7 +997,8 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
         m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, m);
+        if (p->log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * (L + 1) * 4)), dim3(KSM_THREADS), 0, s, m);
+        else if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, m);
         else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, m);
     }
     LAUNCH_CHECK();
