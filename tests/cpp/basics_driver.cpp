@@ -67,6 +67,26 @@ int main() {
         while (budget > 0 && steps < 12) { ev.square_inplace(s); ev.relinearize_inplace(s, rk); budget = decryptor.invariant_noise_budget(s); steps++; }
         std::printf("budget exhausted after %zu squarings (budget %zu)\n", steps, budget);
         ok = ok && budget == 0 && steps >= 2 && steps < 12;
+        // utils::Slice / ConstSlice views of a ciphertext (ciphertext.h:211-252, utils/box.h:262-308): c0 + c1 built by hand through
+        // the views equals Evaluator::add of two ciphertexts that share c0 and have complementary halves
+        {
+            Ciphertext u = cx, v = cx;
+            utils::Slice<uint64_t> u1 = u.poly(1);
+            const Ciphertext& cu = u;
+            utils::ConstSlice<uint64_t> c0 = cu.poly(0), comp = cu.poly_component(1, 1), both = cu.polys(0, 2);
+            const size_t degree = u.poly_modulus_degree(), limbs = u.coeff_modulus_size();
+            bool views = u1.size() == degree * limbs && u1.on_device() && c0.size() == u1.size() && comp.size() == degree && both.size() == 2 * u1.size() &&
+                         comp.raw_pointer() == u1.raw_pointer() + degree && both.raw_pointer() == c0.raw_pointer() && u1.slice(degree, 2 * degree).raw_pointer() == comp.raw_pointer();
+            v.poly(1).set_zero();                              // v = (c0, 0): decrypts to the phase of c0 alone, not to x
+            v.poly(1).copy_from_slice(cu.const_poly(1));       // ... and back: v == u again
+            views = views && encoder.decode_polynomial_new(decryptor.decrypt_new(v))[0] == x;
+            std::vector<uint64_t> host(degree);
+            utils::Slice<uint64_t>(host.data(), degree, false).copy_from_slice(comp);    // device -> host through the views
+            Ciphertext h = cx.to_host();
+            views = views && host[5] == h.poly_component(1, 1)[5] && !h.poly(0).on_device();
+            std::printf("slice views %d\n", (int)views);
+            ok = ok && views;
+        }
         std::printf(ok ? "OK\n" : "FAIL\n");
         MemoryPool::Destroy();
         return ok ? 0 : 1;

@@ -229,6 +229,22 @@ void DynamicArray::copy_from(const uint64_t* src, size_t count, bool src_on_devi
     if (kind != hipMemcpyDeviceToDevice) hip_check(hipStreamSynchronize(current_stream()), "copy");
 }
 
+// utils/box.h:282-308 for the uint64_t views the public accessors hand out
+template <> void Slice<uint64_t>::set_zero() const {
+    if (!len_) return;
+    if (device_) hip_check(hipMemsetAsync(ptr_, 0, len_ * sizeof(uint64_t), current_stream()), "memset");
+    else std::memset(ptr_, 0, len_ * sizeof(uint64_t));
+}
+template <> void Slice<uint64_t>::copy_from_slice(ConstSlice<uint64_t> source) const {
+    if (source.size() != len_) throw std::runtime_error("[Slice::copy_from_slice] Slice size does not match array size");
+    if (!len_) return;
+    const size_t bytes = len_ * sizeof(uint64_t);
+    if (!device_ && !source.on_device()) { std::memcpy(ptr_, source.raw_pointer(), bytes); return; }
+    const hipMemcpyKind kind = device_ ? (source.on_device() ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : hipMemcpyDeviceToHost;
+    hip_check(hipMemcpyAsync(ptr_, source.raw_pointer(), bytes, kind, current_stream()), "copy");
+    if (kind != hipMemcpyDeviceToDevice) hip_check(hipStreamSynchronize(current_stream()), "copy");
+}
+
 void DynamicArray::set_zero() {
     if (!size_) return;
     if (device_) hip_check(hipMemsetAsync(data_, 0, size_ * sizeof(uint64_t), current_stream()), "memset");

@@ -67,8 +67,31 @@ public:
     ConstSlice const_slice(size_t begin, size_t end) const { return ConstSlice(ptr_ + begin, end - begin, device_); }
     std::vector<T> to_vector() const { return std::vector<T>(ptr_, ptr_ + len_); }
     operator std::vector<T>() const { return to_vector(); }                                       // NOLINT
+    operator const T*() const noexcept { return ptr_; }                                           // NOLINT: the C-ABI takes raw device pointers
 private:
     const T* ptr_;
+    size_t len_;
+    bool device_;
+};
+
+// utils/box.h:262-308: the mutable view (Ciphertext::poly, Plaintext::poly, ...).  Converts to ConstSlice and to a raw pointer.
+template <typename T>
+class Slice {
+public:
+    Slice(T* ptr, size_t len, bool on_device = false, std::nullptr_t = nullptr) : ptr_(ptr), len_(len), device_(on_device) {}
+    size_t size() const noexcept { return len_; }
+    bool on_device() const noexcept { return device_; }
+    T* raw_pointer() const noexcept { return ptr_; }
+    T& operator[](size_t i) const { return ptr_[i]; }
+    ConstSlice<T> as_const() const { return ConstSlice<T>(ptr_, len_, device_); }
+    operator ConstSlice<T>() const { return as_const(); }                                         // NOLINT
+    operator T*() const noexcept { return ptr_; }                                                 // NOLINT
+    ConstSlice<T> const_slice(size_t begin, size_t end) const { return ConstSlice<T>(ptr_ + begin, end - begin, device_); }
+    Slice slice(size_t begin, size_t end) const { return Slice(ptr_ + begin, end - begin, device_); }
+    void set_zero() const;                                                                        // box.h:298-308 (host memset / device memset)
+    void copy_from_slice(ConstSlice<T> source) const;                                             // box.h:282-297 (any host / device combination)
+private:
+    T* ptr_;
     size_t len_;
     bool device_;
 };
@@ -446,8 +469,16 @@ public:
     Ciphertext to_host() const { Ciphertext c = *this; c.to_host_inplace(); return c; }
     const utils::DynamicArray& data() const noexcept { return data_; }
     utils::DynamicArray& data() noexcept { return data_; }
-    uint64_t* poly(size_t p) { return data_.raw_pointer() + p * coeff_modulus_size_ * poly_modulus_degree_; }
-    const uint64_t* poly(size_t p) const { return data_.raw_pointer() + p * coeff_modulus_size_ * poly_modulus_degree_; }
+    // ciphertext.h:211-252: views of polynomial p, of polynomials [lo, hi) and of one RNS component
+    utils::Slice<uint64_t> poly(size_t p) { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::Slice<uint64_t>(data_.raw_pointer() + p * d, d, on_device()); }
+    utils::ConstSlice<uint64_t> poly(size_t p) const { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::ConstSlice<uint64_t>(data_.raw_pointer() + p * d, d, on_device()); }
+    utils::ConstSlice<uint64_t> const_poly(size_t p) const { return poly(p); }
+    utils::Slice<uint64_t> polys(size_t lo, size_t hi) { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::Slice<uint64_t>(data_.raw_pointer() + lo * d, (hi - lo) * d, on_device()); }
+    utils::ConstSlice<uint64_t> polys(size_t lo, size_t hi) const { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::ConstSlice<uint64_t>(data_.raw_pointer() + lo * d, (hi - lo) * d, on_device()); }
+    utils::ConstSlice<uint64_t> const_polys(size_t lo, size_t hi) const { return polys(lo, hi); }
+    utils::Slice<uint64_t> poly_component(size_t p, size_t c) { return utils::Slice<uint64_t>(data_.raw_pointer() + (p * coeff_modulus_size_ + c) * poly_modulus_degree_, poly_modulus_degree_, on_device()); }
+    utils::ConstSlice<uint64_t> poly_component(size_t p, size_t c) const { return utils::ConstSlice<uint64_t>(data_.raw_pointer() + (p * coeff_modulus_size_ + c) * poly_modulus_degree_, poly_modulus_degree_, on_device()); }
+    utils::ConstSlice<uint64_t> const_poly_component(size_t p, size_t c) const { return poly_component(p, c); }
     // resize(context, parms_id, polynomial_count) -- src/ciphertext.cu:26-60
     void resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep = true);
     // ciphertext.cu:79-210, ciphertext.h:257-270: [CompressionMode][raw fields]; a seeded ciphertext stores c0 + seed only
@@ -491,8 +522,11 @@ public:
     size_t& coeff_modulus_size() noexcept { return coeff_modulus_size_; }
     size_t poly_modulus_degree() const noexcept { return poly_modulus_degree_; }
     size_t& poly_modulus_degree() noexcept { return poly_modulus_degree_; }
-    uint64_t* poly() { return data_.raw_pointer(); }
-    const uint64_t* poly() const { return data_.raw_pointer(); }
+    // plaintext.h:127-170
+    utils::Slice<uint64_t> poly() { return utils::Slice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }
+    utils::ConstSlice<uint64_t> poly() const { return utils::ConstSlice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }
+    utils::ConstSlice<uint64_t> const_poly() const { return poly(); }
+    utils::ConstSlice<uint64_t> const_reference() const { return poly(); }
     void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
     void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
     // plaintext.cu resize_rns_partial: an RNS polynomial that keeps only its first coeff_count coefficients, data[l * coeff_count + i]
