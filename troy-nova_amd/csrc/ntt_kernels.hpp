@@ -89,6 +89,8 @@ enum NttStore {
 //     out_j     = (relin_j - NTT_j(f_j(l))) ql^-1                           (utils/rns_tool.cu:523-627)
 //               = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1
 // i.e. ONE forward transform per output limb instead of two, and c is never materialised:
+constexpr unsigned NTT_FLAG_STORE_ROUND_HALF = 8u;   // NttArgs::flags: a plain FP64 inverse transform stores T = (x + q/2) mod q as doubles
+
 enum NttFused {
     NTT_FUSED_MULPAIR = 3,       // inverse: input word = a1 (.) b1 (the product c2 formed while loading)
     NTT_FUSED_LAST_LIMB = 4,     // inverse: input = P qk^-1 + c_k at limb L-1; stored word = result - r(s) qk^-1   (= l above)
@@ -390,6 +392,13 @@ struct ArithF64 {
         t = (t >= aux_q) ? t - aux_q : t;
         return f64_corr(t - hm, m.m);
     }
+    // T = (x + floor(p/2)) mod p of a canonical x as an exact double: the modulus-independent half of a rounding fix
+    // (ski_util6 / divide_and_round_q_last step 1), stored by the producer so that every consumer limb only subtracts its constant
+    static __device__ __forceinline__ double round_half(double x_canon, const Mod& m) {
+        const double t = x_canon + 0.5 * (m.m.p - 1.0);
+        return t >= m.m.p ? t - m.m.p : t;
+    }
+    static __device__ __forceinline__ elem round_fix_t(u64 t_bits, double hm, const Mod& m) { return f64_corr(f64_bits_to_double(t_bits) - hm, m.m); }
     static __device__ __forceinline__ u64 canon_small(elem x, const Mod& m) { return f64_to_u64(x < 0.0 ? x + m.m.p : x); }   // |x| < p
     static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= p
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
@@ -628,8 +637,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 else if constexpr (F_TR_LD) {
                     // r_j(s) qk^-1 + f_j(l): the rounding fixes of the key switch and of the rescale enter ONE transform
                     const u64 raw2 = io.in2[gindex(locbase | ((unsigned)R << S))];
-                    const elem rs = A::round_fix(raw, io.aux_qd, io.aux_half_d, io.hm_d, md);
-                    const elem fl = A::round_fix(raw2, io.aux2_qd, io.aux2_half_d, io.hm2_d, md);
+                    const elem rs = A::round_fix_t(raw, io.hm_d, md);       // both rows arrive as T = (x + aux/2) mod aux (doubles)
+                    const elem fl = A::round_fix_t(raw2, io.hm2_d, md);
                     x[R] = A::scale_by(rs, io.inv_d, md) + fl;      // |x| <= 1.2 p: a 4-layer block from here stays below 7.7 p < 2^53
                 }
                 else if constexpr (FIRST) x[R] = A::template load_io<LM>(io, raw, a.reduce_input != 0, md);
@@ -775,8 +784,11 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     elem ys;
                     if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) ys = x[R];                           // already scaled by N^-1
                     else ys = f64_mulc(x[R], md.ninv, md.ninv_p, md.m.p);
-                    const elem rs = A::round_fix(io.in2[gi], io.aux_qd, io.aux_half_d, io.hm_d, md);
-                    v = f64_canon(ys - A::scale_by(rs, io.inv_d, md), md.m);
+                    const elem rs = A::round_fix_t(io.in2[gi], io.hm_d, md);
+                    // stored as T_l = (l + ql/2) mod ql (double): what the rescale's rounding fix of every remaining limb starts from
+                    double lc = f64_corr(ys - A::scale_by(rs, io.inv_d, md), md.m);
+                    lc = lc < 0.0 ? lc + md.m.p : lc;
+                    v = f64_double_to_bits(A::round_half(lc, md));
                 } else if constexpr (LAST) {
                     if constexpr (INV && A::FOLD_NINV && ((R >> (EB - 1)) & 1)) v = A::final_fwd(x[R], md);   // already scaled
                     else if constexpr (INV) v = A::final_inv(x[R], md);
@@ -784,6 +796,9 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     else v = A::template store_io<SM>(io, A::template store_prep<SM>(x[R], md), io.ext0[gi],
                                                       (SM == NTT_STORE_KS_FINISH && io.ext1) ? io.ext1[gi] : 0,
                                                       (SM == NTT_STORE_KS_FINISH && io.add_inplace) ? io.dest[gi] : 0, md);
+                    if constexpr (INV && IOM == 0 && std::is_same<A, ArithF64>::value) {
+                        if (a.flags & NTT_FLAG_STORE_ROUND_HALF) v = f64_double_to_bits(ArithF64::round_half(f64_from_u64(v), md));
+                    }
                 } else v = A::store_mid(x[R], md);
                 nt_store(gout + gi, v);
             });

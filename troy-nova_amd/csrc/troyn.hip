@@ -1006,6 +1006,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     {
         NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.spec_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         x.in_pstride = pp_p; x.in_bstride = pp_b;
+        x.flags = NTT_FLAG_STORE_ROUND_HALF;     // stored as (s + qk/2) mod qk, the limb-independent part of the key switch's rounding fix
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
     // (4) l = INTT(relin_{L-1}) = INTT(P_{L-1} qk^-1 + c_{L-1}) - r(s) qk^-1   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
