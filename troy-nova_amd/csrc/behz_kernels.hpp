@@ -21,6 +21,9 @@ struct BehzDev {
     const DevModulus* bsk_mods;             // [Bsk]  (B primes then m_sk)
     DevModulus m_tilde;                     // 2^32 (non-prime Modulus, rns_tool.cu:83)
     const ulonglong2* q_inv_punc;           // [L]   (q/q_i)^-1 mod q_i            (Shoup)
+    const ulonglong2* q_mt_inv_punc;        // [L]   m_tilde * (q/q_i)^-1 mod q_i  (Shoup): lift, scalar factor folded in
+    const ulonglong2* q_t_inv_punc;         // [L]   t * (q/q_i)^-1 mod q_i        (Shoup): floor, scalar factor folded in
+    const ulonglong2* t_inv_prod_q_mod_bsk; // [Bsk] t * q^-1 mod p_b              (Shoup)
     const u64* q_to_bsk;                    // [Bsk][L] (q/q_i) mod p_b
     const u64* q_to_mt;                     // [L]   (q/q_i) mod m_tilde
     ulonglong2 neg_inv_prod_q_mod_mt;       // -q^-1 mod m_tilde                    (Shoup wrt m_tilde)
@@ -68,16 +71,16 @@ __global__ __launch_bounds__(256) void behz_lift_kernel(unsigned chunks, BehzDev
     u64* op = out + item * (size_t)Bsk * n;
     const u64 mt = c.m_tilde.q;
     const cmodp q_mods = as_cmod(c.q_mods), bsk_mods = as_cmod(c.bsk_mods);
-    const cu64x2p q_inv_punc = as_c128(c.q_inv_punc), prod_q_mod_bsk = as_c128(c.prod_q_mod_bsk), inv_mt_mod_bsk = as_c128(c.inv_mt_mod_bsk);
+    const cu64x2p q_mt_inv_punc = as_c128(c.q_mt_inv_punc), prod_q_mod_bsk = as_c128(c.prod_q_mod_bsk), inv_mt_mod_bsk = as_c128(c.inv_mt_mod_bsk);
     const cu64p q_to_mt = as_c64(c.q_to_mt), q_to_bsk = as_c64(c.q_to_bsk);
     for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
         u64 y[MAXL];
 #pragma unroll
         for (int i = 0; i < MAXL; ++i) {
             if (i < (int)L) {
-                const DevModulus md = ld_mod(q_mods, i);
-                const u64 v = mul_mod(ip[(size_t)i * n + x], mt, md);      // multiply_scalar_p by m_tilde
-                y[i] = conv_scale(v, ld_pair(q_inv_punc, i), md);
+                // multiply_scalar_p by m_tilde, then the first step of fast_convert_array: one Shoup multiply by m_tilde * inv_punc
+                const ulonglong2 f = ld_pair(q_mt_inv_punc, i);
+                y[i] = shoup_mul(ip[(size_t)i * n + x], f.x, f.y, q_mods[i].q);
             } else y[i] = 0;
         }
         // q -> {m_tilde}
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
     const u64* bp = in_bsk + item * (size_t)Bsk * n;
     u64* op = out + item * (size_t)L * n;
     const cmodp q_mods = as_cmod(c.q_mods), bsk_mods = as_cmod(c.bsk_mods);
-    const cu64x2p q_inv_punc = as_c128(c.q_inv_punc), inv_prod_q_mod_bsk = as_c128(c.inv_prod_q_mod_bsk), B_inv_punc = as_c128(c.B_inv_punc),
+    const cu64x2p q_t_inv_punc = as_c128(c.q_t_inv_punc), inv_prod_q_mod_bsk = as_c128(c.inv_prod_q_mod_bsk), t_inv_prod_q_mod_bsk = as_c128(c.t_inv_prod_q_mod_bsk), B_inv_punc = as_c128(c.B_inv_punc),
                   prod_B_mod_q = as_c128(c.prod_B_mod_q), neg_prod_B_mod_q = as_c128(c.neg_prod_B_mod_q);
     const cu64p q_to_bsk = as_c64(c.q_to_bsk), B_to_q = as_c64(c.B_to_q), B_to_msk = as_c64(c.B_to_msk);
     for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
@@ -120,9 +123,8 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
             if (i < (int)L) {
-                const DevModulus md = ld_mod(q_mods, i);
-                const u64 v = mul_mod(qp[(size_t)i * n + x], c.t, md);       // step (6): times t
-                y[i] = conv_scale(v, ld_pair(q_inv_punc, i), md);
+                const ulonglong2 f = ld_pair(q_t_inv_punc, i);               // step (6) times t, folded into the conversion's scaling
+                y[i] = shoup_mul(qp[(size_t)i * n + x], f.x, f.y, q_mods[i].q);
             } else y[i] = 0;
         }
         // step (7) fast_floor into Bsk
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
 #pragma unroll
                 for (int i = 0; i < MAXB; ++i) if (i < (int)L) mac128(lo, hi, y[i], row[i]);
                 const u64 f = barrett128(lo, hi, mb.q, mb.ratio_lo, mb.ratio_hi);
-                const u64 tb = mul_mod(bp[(size_t)b * n + x], c.t, mb);
-                const ulonglong2 iq = ld_pair(inv_prod_q_mod_bsk, b);
-                r[b] = shoup_mul(tb + mb.q - f, iq.x, iq.y, mb.q);
+                // (x t - f) q^-1 = x (t q^-1) - f q^-1 mod p_b
+                const ulonglong2 iq = ld_pair(inv_prod_q_mod_bsk, b), tq = ld_pair(t_inv_prod_q_mod_bsk, b);
+                r[b] = sub_mod(shoup_mul(bp[(size_t)b * n + x], tq.x, tq.y, mb.q), shoup_mul(f, iq.x, iq.y, mb.q), mb.q);
             } else r[b] = 0;
         }
         // step (8) fast_b_conv_sk: B -> q and B -> {m_sk}
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void behz_floor_kernel(unsigned chunks, BehzDe
             for (int b = 0; b < MAXB; ++b) if (b < (int)Bn) mac128(lo, hi, y[b], row[b]);
             const u64 g = barrett128(lo, hi, md.q, md.ratio_lo, md.ratio_hi);
             const ulonglong2 f = neg ? ld_pair(prod_B_mod_q, i) : ld_pair(neg_prod_B_mod_q, i);
-            op[(size_t)i * n + x] = add_mod(shoup_mul(alpha_use, f.x, f.y, md.q), barrett64(g, md.q, md.ratio_hi), md.q);
+            op[(size_t)i * n + x] = add_mod(shoup_mul(alpha_use, f.x, f.y, md.q), g, md.q);      // g is canonical (Barrett-128 output)
         }
     }
 }

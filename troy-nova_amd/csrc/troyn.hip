@@ -1262,6 +1262,21 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
         if (L > 1 && !need_inv(host::product_mod(q, i, q[i]), q[i], inv)) return fail(TROYN_E_MODULUS, "[RNSBase::initialize] RNSBase product is not invertible.");
         push_shoup(inv, q[i]);
     }
+    // the scalar factor that precedes a base conversion folded into its first step: (x * c mod q_i) * inv_punc_i mod q_i
+    // = x * (c * inv_punc_i mod q_i) mod q_i -- one Shoup multiply instead of a Barrett-128 product followed by one (c = m_tilde for
+    // the lift, evaluator.cu:52-56 + rns_tool.cu:1083-1094; c = t for the floor, evaluator.cu:95-100)
+    size_t off_q_mt_inv_punc = blob.size();
+    for (size_t i = 0; i < L; i++) {
+        u64 inv = 1;
+        if (L > 1) need_inv(host::product_mod(q, i, q[i]), q[i], inv);
+        push_shoup(host::mulmod(mt % q[i], inv, q[i]), q[i]);
+    }
+    size_t off_q_t_inv_punc = blob.size();
+    for (size_t i = 0; i < L; i++) {
+        u64 inv = 1;
+        if (L > 1) need_inv(host::product_mod(q, i, q[i]), q[i], inv);
+        push_shoup(host::mulmod(t % q[i], inv, q[i]), q[i]);
+    }
     size_t off_q_to_bsk = blob.size();
     for (size_t bi = 0; bi < Bsk; bi++) for (size_t i = 0; i < L; i++) blob.push_back(host::product_mod(q, i, bsk[bi]));
     size_t off_q_to_mt = blob.size();
@@ -1280,6 +1295,13 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
         u64 inv;
         if (!need_inv(host::product_mod(q, SIZE_MAX, bsk[bi]), bsk[bi], inv)) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert base_q product.");
         push_shoup(inv, bsk[bi]);
+    }
+    // (x * t - f) * q^-1 = x * (t q^-1) - f * q^-1 mod p_b: the floor's multiplication by t folded into the division by q
+    size_t off_t_inv_prod_q_mod_bsk = blob.size();
+    for (size_t bi = 0; bi < Bsk; bi++) {
+        u64 inv = 0;
+        need_inv(host::product_mod(q, SIZE_MAX, bsk[bi]), bsk[bi], inv);
+        push_shoup(host::mulmod(t % bsk[bi], inv, bsk[bi]), bsk[bi]);
     }
     size_t off_B_inv_punc = blob.size();
     for (size_t bi = 0; bi < Bn; bi++) {
@@ -1340,6 +1362,9 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     d.m_tilde = make_dev_modulus(mt, plan->log_n, false);
     auto P2 = [&](size_t off) { return reinterpret_cast<const ulonglong2*>(b->d_consts + off); };
     d.q_inv_punc = P2(off_q_inv_punc);
+    d.q_mt_inv_punc = P2(off_q_mt_inv_punc);
+    d.q_t_inv_punc = P2(off_q_t_inv_punc);
+    d.t_inv_prod_q_mod_bsk = P2(off_t_inv_prod_q_mod_bsk);
     d.q_to_bsk = b->d_consts + off_q_to_bsk;
     d.q_to_mt = b->d_consts + off_q_to_mt;
     {
