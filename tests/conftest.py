@@ -32,3 +32,14 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return "cuda:0"
+
+
+@pytest.fixture(params=["v2", "v1"])
+def behz_gen(request, monkeypatch):
+    """both generations of the BEHZ conversion kernels (csrc/behz2_kernels.hpp, csrc/behz_kernels.hpp): the library reads
+    TROYN_BEHZ on every call"""
+    if request.param == "v1":
+        monkeypatch.setenv("TROYN_BEHZ", "v1")
+    else:
+        monkeypatch.delenv("TROYN_BEHZ", raising=False)
+    return request.param

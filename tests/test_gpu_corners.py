@@ -165,3 +165,18 @@ def test_pipeline_corner_vectors(O, pkg, dev):
         e = ctx.ckks_multiply(L, a[i], b[i])
         e = ctx.relinearize(L, True, e, keys)
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), names[i]
+
+
+@pytest.mark.parametrize("n,bits,L,t", [(4096, [50] * 6, 5, 65537), (2048, [59] * 6, 5, 40961), (1024, [36] * 11, 10, 12289)])
+def test_bfv_multiply_corner_vectors(O, pkg, dev, n, bits, L, t, behz_gen):
+    """BEHZ conversions on extreme residues: the carry-free partial sums of behz2_kernels.hpp are largest when every residue is q-1"""
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    behz = pkg.Behz(plan, L, t)
+    names = ["all_q-1", "alt_0_q-1", "half_hi", "ramp_top", "impulse_0"]
+    a = np.stack([_corner_ct(q, L, n, 2, nm) for nm in names])
+    b = np.stack([_corner_ct(q, L, n, 2, nm) for nm in reversed(names)])
+    got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
+    for i in range(len(names)):
+        assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i])), names[i]

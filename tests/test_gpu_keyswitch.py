@@ -128,8 +128,12 @@ def test_mod_switch_drop(O, pkg, dev):
     (8192, [60, 40, 40, 60], 3, 1 << 21, 2, 2),   # matmul app parameters (non-prime t)
     (16384, [50] * 6, 5, 1032193, 2, 2),
     (32768, [50] * 11, 10, 1032193, 2, 2),        # BASELINE config 4
+    (2048, [59] * 7, 6, 40961, 2, 2),             # wide moduli, more than one group of four carry-free terms
+    (1024, [36] * 17, 16, 12289, 2, 2),           # largest base the per-size kernels are instantiated for
+    (1024, [30] * 18, 17, 12289, 2, 2),           # beyond it: first-generation kernels
+    (4096, [49, 50, 51, 40], 3, 65537, 3, 2),     # one modulus above 2^50: integer class
 ])
-def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb):
+def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb, behz_gen):
     ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
     behz = pkg.Behz(plan, L, t)
     rt = O.lib().orc_context_rns_tool(ctx.h, L)
@@ -142,6 +146,30 @@ def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb):
     got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), pa, pkg.to_device(b, dev), pb))
     for i in range(batch):
         assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i]))
+
+
+@pytest.mark.parametrize("tensor", ["fused", "split"])
+@pytest.mark.parametrize("bits,L", [([50] * 4, 3), ([55] * 3, 2), ([55, 50, 50, 50], 3), ([40] * 2, 1)])
+def test_bfv_multiply_two_pass_sizes(O, pkg, dev, monkeypatch, bits, L, tensor):
+    """N = 32768: the tensor product is formed between the passes of the transforms (tensor_core_kernel: last forward pass, dyadic
+    product, first inverse pass in one launch) when both bases are of one arithmetic class; TROYN_BFV_TENSOR=split keeps the separate
+    launches.  Chains: FP64 class, integer class, mixed (never fused), single modulus."""
+    if tensor == "split":
+        monkeypatch.setenv("TROYN_BFV_TENSOR", "split")
+    else:
+        monkeypatch.delenv("TROYN_BFV_TENSOR", raising=False)
+    n, t = 32768, 786433
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
+    behz = pkg.Behz(plan, L, t)
+    batch = 3
+    a = np.stack([ctx.random_ct(131 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(147 + i, 2, L) for i in range(batch)])
+    got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i])), i
+    # squaring reads the same operand twice
+    got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(a, dev), 2))
+    assert np.array_equal(got[0], ctx.bfv_multiply(L, a[0], a[0]))
 
 
 def test_error_behaviour(O, pkg, dev):

@@ -316,6 +316,15 @@ struct ArithU64 {
         return shoup_lazy(final_fwd(v, m), m.ninv_op, m.ninv_quo, m.q);   // the reference's lazy N^-1 multiply
     }
     static __device__ __forceinline__ void inv_fold(elem&, elem&, const Mod&) {}   // FOLD_NINV is false: never used
+    // register hand-over between a forward and an inverse transform (tensor_core_kernel): canonical residues
+    static __device__ __forceinline__ elem keep(elem x, const Mod& m) { return final_fwd(x, m); }
+    static __device__ __forceinline__ elem prod(elem x, elem y, const Mod& m) {
+        u64 lo, hi;
+        mul128(x, y, lo, hi);
+        return barrett128(lo, hi, m.q, m.ratio_lo, m.ratio_hi);
+    }
+    static __device__ __forceinline__ elem sum(elem x, elem y, const Mod& m) { return add_mod(x, y, m.q); }
+    static __device__ __forceinline__ elem inv_in(elem x, const Mod&) { return x; }
 };
 
 struct ArithF64 {
@@ -419,6 +428,12 @@ struct ArithF64 {
     }
     static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) { return f64_canon(v, m.m); }
     static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) { return f64_canon(f64_mulc(v, m.ninv, m.ninv_p, m.m.p), m.m); }
+    // register hand-over between a forward and an inverse transform (tensor_core_kernel): re-centred doubles; a product of two
+    // re-centred factors is an exact integer of magnitude <= 0.69 p, a sum of two is re-centred again before the inverse butterflies
+    static __device__ __forceinline__ elem keep(elem x, const Mod& m) { return f64_corr(x, m.m); }
+    static __device__ __forceinline__ elem prod(elem x, elem y, const Mod& m) { return f64_mulq(x, y, m.m.inv_p, m.m.p); }
+    static __device__ __forceinline__ elem sum(elem x, elem y, const Mod&) { return x + y; }
+    static __device__ __forceinline__ elem inv_in(elem x, const Mod& m) { return f64_corr(x, m.m); }
 };
 
 // Which local index bits identify the wave (thread bits >= 6) when the register window starts at bit S.
@@ -447,9 +462,12 @@ __host__ __device__ constexpr unsigned ntt_wave_bits(int S, int EB, int TB) {
 // (NTT_LOAD_KS_ROUND on the first pass, NTT_STORE_KS_FINISH on the last), 2 rescale.
 __host__ __device__ constexpr bool ROUNDS_OK(int G, int EB) { return (G + EB - 1) / EB > 1; }
 
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM>
-__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t) {
+// REGIO (tensor_core_kernel): 1 = a forward last pass leaves its E consecutive outputs per thread in xio (A::keep form) instead of
+// storing them, 2 = an inverse first pass takes its E consecutive inputs per thread from xio (A::inv_in form) instead of loading them.
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0>
+__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t, typename A::elem* xio = nullptr) {
     constexpr int C = TB - G;
+    static_assert(REGIO == 0 || (!KSMAC && IOM == 0 && C == 0 && (G + EB - 1) / EB > 1 && (REGIO == 1 ? (!INV && LAST) : (INV && FIRST))), "register hand-over: last forward / first inverse pass on whole tiles");
     constexpr int E = 1 << EB;
     constexpr unsigned N = 1u << LOGN;
     constexpr int TILE_BITS = LOGN - TB;               // tiles per limb-polynomial = 2^TILE_BITS
@@ -585,7 +603,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         constexpr bool PRIVATE_OUT = (r < ROUNDS - 1) && ntt_wave_bits(S, EB, TB) == ntt_wave_bits(S_NEXT, EB, TB);
         (void)PRIVATE_IN;
 
-        if constexpr (r == 0 && INV && S == 0 && C == 0 && ROUNDS > 1) {
+        if constexpr (REGIO == 2 && r == 0) {
+            static_assert(r != 0 || REGIO != 2 || S == 0, "register hand-over: E consecutive coefficients per thread");
+            static_for<0, E>([&](auto Rc) { x[decltype(Rc)::value] = xio[decltype(Rc)::value]; });
+        } else if constexpr (r == 0 && INV && S == 0 && C == 0 && ROUNDS > 1) {
             // Mirror image of the forward store transpose: a thread starts with E consecutive coefficients.  Loading
             // them directly makes every load instruction touch 64 different 128-byte lines; instead the wave loads
             // its 64*E consecutive words with 16 bytes per lane, parks them in its own LDS slice (the words it will
@@ -688,7 +709,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             });
         });
 
-        if constexpr (KSMAC && r == ROUNDS - 1) {
+        if constexpr (REGIO == 1 && r == ROUNDS - 1) {
+            static_assert(r != ROUNDS - 1 || REGIO != 1 || S == 0, "register hand-over: E consecutive coefficients per thread");
+            static_for<0, E>([&](auto Rc) { xio[decltype(Rc)::value] = A::keep(x[decltype(Rc)::value], md); });
+        } else if constexpr (KSMAC && r == ROUNDS - 1) {
             // transpose inside the wave's own LDS slice (see the store path below), then multiply-accumulate with
             // 16-byte coalesced key loads
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
@@ -839,6 +863,50 @@ template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST
 __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
     __shared__ u64 lds[(G + EB - 1) / EB > 1 ? ntt_lds_words(TB) : 1];
     ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false, IOM>(a, nullptr, lds, blockIdx.x, threadIdx.x);
+}
+
+// Tensor product of two 2-component ciphertexts between the transforms (BEHZ steps (3)-(5), evaluator.cu:56-93): one workgroup takes
+// the same 2^TB-word tile of one limb of a0, a1, b0, b1, runs the last forward pass of each, forms d0 = a0 b0, d1 = a0 b1 + a1 b0,
+// d2 = a1 b1 in registers -- a thread ends a forward pass and starts an inverse pass with the same E consecutive coefficients -- and
+// runs the first inverse pass of d0, d1, d2.  The NTT-form operands and the NTT-form product never reach HBM.
+//   TB == LOGN (N <= 8192, whole-limb tiles): the passes are the whole transforms; 4 reads + 3 writes of a limb replace the forward
+//     transforms (4+4), the dyadic kernel (4+3) and the inverse transforms (3+3).
+//   TB <  LOGN (N >= 32768, two-pass transforms): the operands arrive after their strided first pass and the product leaves before
+//     its strided last pass; the same 4+3 replace the second forward pass, the dyadic kernel and the first inverse pass.
+//   fa, fb: forward arguments over [item][2][ncomp][N], id: inverse arguments over [item][3][ncomp][N]
+template <class A, int LOGN, int TB, int EB>
+__global__ __launch_bounds__(1 << (TB - EB), (TB - EB) <= 8 ? 2 : 1) void tensor_core_kernel(NttArgs fa, NttArgs fb, NttArgs id) {
+    constexpr int G1 = LOGN - TB, E = 1 << EB;
+    constexpr bool WHOLE = G1 == 0;
+    __shared__ u64 lds[ntt_lds_words(TB)];
+    using elem = typename A::elem;
+    const unsigned t = threadIdx.x;
+    const unsigned tile = blockIdx.x & ((1u << G1) - 1), lj = blockIdx.x >> G1;
+    const unsigned j = lj % fa.ncomp, b = lj / fa.ncomp;
+    auto bid = [&](unsigned pcount, unsigned k) { return (((b * pcount + k) * fa.ncomp + j) << G1) | tile; };
+    const typename A::Mod md = A::make(fa.mods[ntt_table_index(fa, 0, j)]);
+    // order chosen for register pressure: at most three held polynomials (3 * 2E registers) next to a transform in flight
+    elem a0[E], b0[E], a1[E], w[E];
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fa, nullptr, lds, bid(2, 0), t, a0);
+    __syncthreads();   // the next transform's first exchange overwrites words other waves read in this one's last round
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fb, nullptr, lds, bid(2, 0), t, b0);
+    __syncthreads();
+    static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; w[R] = A::inv_in(A::prod(a0[R], b0[R], md), md); });
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 0), t, w);          // d0 = a0 b0
+    __syncthreads();
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fa, nullptr, lds, bid(2, 1), t, a1);
+    __syncthreads();
+    static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; b0[R] = A::prod(a1[R], b0[R], md); });       // a1 b0
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fb, nullptr, lds, bid(2, 1), t, w);          // b1
+    __syncthreads();
+    static_for<0, E>([&](auto Rc) {
+        constexpr int R = decltype(Rc)::value;
+        a0[R] = A::inv_in(A::sum(b0[R], A::prod(a0[R], w[R], md), md), md);   // d1 = a1 b0 + a0 b1
+        a1[R] = A::inv_in(A::prod(a1[R], w[R], md), md);                       // d2 = a1 b1
+    });
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 1), t, a0);
+    __syncthreads();
+    ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 2), t, a1);
 }
 
 // Fused key-switch inner product: grid = (L+1) rows x batch items, one whole-limb workgroup each.

@@ -13,6 +13,7 @@
 
 #include "../../include/troyn.h"
 #include "behz_kernels.hpp"
+#include "behz2_kernels.hpp"
 #include "crypto_kernels.hpp"
 #include "bgv_kernels.hpp"
 #include "ring2k_kernels.hpp"
@@ -463,6 +464,45 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
         hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)lp), dim3(256), 0, s, a, p->log_n, inverse ? 1 : 0);
     }
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+// ---- tensor product of two 2-component ciphertexts fused with the transforms around it (tensor_core_kernel) ----
+// two-pass sizes (N = 32768, 65536): stage 0 = first forward pass alone, stage 1 = last forward pass + tensor product + first inverse
+// pass, stage 2 = last inverse pass.  Whole-limb sizes (N = 1024 .. 8192): stage 1 is everything.
+template <class A, int LOGN, int TB, int EB>
+static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
+    constexpr int G1 = LOGN - TB;
+    if constexpr (G1 > 0) {
+        if (stage == 0) { launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, batch * a.pcount * a.ncomp, s); return; }
+        if (stage == 2) { launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(a, batch * a.pcount * a.ncomp, s); return; }
+    }
+    if (stage == 1) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB>), dim3((unsigned)((batch * a.ncomp) << G1)), dim3(1u << (TB - EB)), 0, s, a, b, d);
+}
+// 0: limbs [0, ncomp) of plan p cannot take the fused tensor path; 1: whole-limb tiles; 2: two-pass transforms.  One arithmetic class.
+static int tensor_path_kind(const troyn_plan* p, unsigned ncomp) {
+    const char* e = getenv("TROYN_BFV_TENSOR");   // "split": separate transform and dyadic launches (A/B runs, tests of that path)
+    if (e && std::strcmp(e, "split") == 0) return 0;
+    for (unsigned j = 1; j < ncomp; j++) if (p->small_modulus[j] != p->small_modulus[0]) return 0;
+    if (p->log_n >= 10 && p->log_n <= 13) return 1;
+    if (p->log_n == 15 || p->log_n == 16) return 2;
+    return 0;
+}
+static int tensor_stage(const troyn_plan* p, int stage, NttArgs a, NttArgs b, NttArgs d, size_t batch, hipStream_t s) {
+    const bool f64 = use_f64(p, 0, a.ncomp);
+    auto prep = [&](NttArgs& x, bool inverse) {
+        x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
+        x.tw = f64 ? (inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64) : (inverse ? (const void*)p->d_inv : (const void*)p->d_fwd);
+    };
+    prep(a, stage == 2); prep(b, false); prep(d, true);
+    if ((batch * a.pcount * a.ncomp) << (p->log_n > 12 ? p->log_n - 12 : 0) > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
+#define TENSOR_CASE(LOGN, TB, EB) case LOGN: if (f64) tensor_stage_t<ArithF64, LOGN, TB, EB>(stage, a, b, d, batch, s); else tensor_stage_t<ArithU64, LOGN, TB, EB>(stage, a, b, d, batch, s); break;
+    switch (p->log_n) {
+        TENSOR_CASE(10, 10, 4) TENSOR_CASE(11, 11, 4) TENSOR_CASE(12, 12, 3) TENSOR_CASE(13, 13, 3) TENSOR_CASE(15, 12, 4) TENSOR_CASE(16, 12, 4)
+        default: return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused tensor kernel for this size");
+    }
+#undef TENSOR_CASE
     LAUNCH_CHECK();
     return TROYN_OK;
 }
@@ -1204,6 +1244,8 @@ struct troyn_behz {
     std::vector<u64> bsk_values;
     u64* d_consts = nullptr;
     BehzDev dev;
+    Behz2Dev dev2;                      // second-generation conversion kernels (behz2_kernels.hpp)
+    bool have2 = false, smallq = false; // have2: |B| == L <= 16 and every q_i < 2^60; smallq: every q_i < 2^50
     // encrypt / decrypt side constants of the same RNSTool / ContextData (context_data.cu:226-247, rns_tool.cu:168-211)
     u64 gamma = 0, q_mod_t = 0;
     DevModulus t_mod, gamma_mod;
@@ -1319,6 +1361,15 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     size_t off_neg_prod_B_mod_q = blob.size();
     for (size_t i = 0; i < L; i++) { u64 v = host::product_mod(B, SIZE_MAX, q[i]); push_shoup(q[i] - v, q[i]); }
 
+    // second-generation conversion tables (split matrices with the scalar factors folded in)
+    Behz2Offsets o2;
+    bool have2 = Bn == L && L <= BEHZ2_MAX_L, smallq = true;
+    for (u64 v : q) { if (v >> 60) have2 = false; if (v >= F64_MODULUS_LIMIT) smallq = false; }
+    if (have2) {
+        if (blob.size() & 1) blob.push_back(0);
+        have2 = behz2_build_tables(q, B, m_sk, t, smallq, blob, o2);
+    }
+
     // ---- encrypt / decrypt side ----
     const u64 gamma = primes[1];
     b->gamma = gamma;
@@ -1384,6 +1435,20 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     d.B_to_msk = b->d_consts + off_B_to_msk;
     d.prod_B_mod_q = P2(off_prod_B_mod_q);
     d.neg_prod_B_mod_q = P2(off_neg_prod_B_mod_q);
+    b->have2 = have2; b->smallq = smallq;
+    std::memset(&b->dev2, 0, sizeof(b->dev2));
+    if (have2) {
+        Behz2Dev& e = b->dev2;
+        e.L = L; e.n = n; e.rs = o2.rs;
+        e.q_mods = plan->d_mods; e.q_mt_inv_punc = d.q_mt_inv_punc; e.q_t_inv_punc = d.q_t_inv_punc;
+        e.lift_mt = reinterpret_cast<const u32*>(b->d_consts + o2.lift_mt);
+        e.lift_rows = reinterpret_cast<const u32*>(b->d_consts + o2.lift_rows);
+        e.lift_rc = b->d_consts + o2.lift_rc;
+        e.fa_rows = reinterpret_cast<const u32*>(b->d_consts + o2.fa_rows);
+        e.fa_rc = b->d_consts + o2.fa_rc;
+        e.fb_cols = reinterpret_cast<const u32*>(b->d_consts + o2.fb_cols);
+        e.fb_rc = b->d_consts + o2.fb_rc;
+    }
     b->d_delta = P2(off_delta);
     b->d_prod_t_gamma_mod_q = P2(off_ptg);
     b->d_q_to_t = b->d_consts + off_q_to_t;
@@ -1423,6 +1488,23 @@ static void dispatch_bound(unsigned v, F4 f4, F8 f8, F16 f16, F64 f64) {
     if (v <= 4) f4(); else if (v <= 8) f8(); else if (v <= 16) f16(); else f64();
 }
 
+// second-generation kernels: one instantiation per base size (register arrays are indexed statically) and modulus class
+template <int L>
+static void launch_behz2_lift(const troyn_behz* b, dim3 grid, hipStream_t s, unsigned ch, const u64* src, u64* dst) {
+    if (b->smallq) hipLaunchKernelGGL((behz2_lift_kernel<L, true>), grid, dim3(256), 0, s, ch, b->dev2, src, dst);
+    else hipLaunchKernelGGL((behz2_lift_kernel<L, false>), grid, dim3(256), 0, s, ch, b->dev2, src, dst);
+}
+template <int L>
+static void launch_behz2_floor(const troyn_behz* b, dim3 grid, hipStream_t s, unsigned ch, const u64* in_q, const u64* in_bsk, u64* out) {
+    if (b->smallq) hipLaunchKernelGGL((behz2_floor_kernel<L, true>), grid, dim3(256), 0, s, ch, b->dev2, in_q, in_bsk, out);
+    else hipLaunchKernelGGL((behz2_floor_kernel<L, false>), grid, dim3(256), 0, s, ch, b->dev2, in_q, in_bsk, out);
+}
+#define BEHZ2_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+static bool behz2_enabled(const troyn_behz* b) {
+    const char* e = getenv("TROYN_BEHZ");   // "v1": first-generation kernels (A/B runs and the tests of that path)
+    return b->have2 && !(e && std::strcmp(e, "v1") == 0);
+}
+
 extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_t pa, const uint64_t* b_, size_t pb,
                                   uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
     if (!b || !a_ || !b_ || !out || !workspace) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] null argument");
@@ -1438,25 +1520,52 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     u64* ws = (u64*)workspace;
     int rc;
     const unsigned ch1 = chunks_single(n);
+    const bool gen2 = behz2_enabled(b);
+    // 2 x 2 components at a two-pass size: the forward transforms stop after their first pass, tensor_core_kernel finishes them, forms the
+    // product and starts the inverse transforms
+    const int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
+    const bool tensor = tkind != 0, whole = tkind == 1;
     auto lift = [&](const u64* src, size_t pcount, u64* dst_q, u64* dst_bsk) -> int {
         // steps (1)-(3) of evaluator.cu:50-60 for one operand
         NttArgs a = contiguous_args(pq, src, dst_q, pcount, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
-        int r = launch_ntt(pq, a, batch, false, s);
+        int r = whole ? TROYN_OK : tensor ? tensor_stage(pq, 0, a, a, a, batch, s) : launch_ntt(pq, a, batch, false, s);   // whole: the tensor kernel reads src
         if (r) return r;
         const size_t items = batch * pcount;
         if ((r = check_rows(items, ch1))) return r;
         dim3 grid((unsigned)(items * ch1)), block(256);
-        dispatch_bound(L,
+        if (gen2) {
+            switch (L) {
+#define X(N) case N: launch_behz2_lift<N>(b, grid, s, ch1, src, dst_bsk); break;
+                BEHZ2_CASES(X)
+#undef X
+            }
+        } else dispatch_bound(L,
             [&] { hipLaunchKernelGGL((behz_lift_kernel<4>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
             [&] { hipLaunchKernelGGL((behz_lift_kernel<8>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
             [&] { hipLaunchKernelGGL((behz_lift_kernel<16>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
             [&] { hipLaunchKernelGGL((behz_lift_kernel<64>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); });
         LAUNCH_CHECK();
         NttArgs ab = contiguous_args(px, dst_bsk, dst_bsk, pcount, S, 0, S, TROYN_IDX_COMPONENTWISE, 0);
-        return launch_ntt(px, ab, batch, false, s);
+        return whole ? TROYN_OK : tensor ? tensor_stage(px, 0, ab, ab, ab, batch, s) : launch_ntt(px, ab, batch, false, s);
     };
     if ((rc = lift((const u64*)a_, pa, ws + w.a_q, ws + w.a_bsk))) return rc;
     if ((rc = lift((const u64*)b_, pb, ws + w.b_q, ws + w.b_bsk))) return rc;
+    if (tensor) {
+        // steps (4)-(5)
+        for (int base = 0; base < 2; base++) {
+            const troyn_plan* p = base ? px : pq;
+            const unsigned nc = base ? S : L;
+            // whole-limb tiles: base q is read straight from the operands (coefficient form), nothing of it is staged
+            const u64* xa = (whole && !base) ? (const u64*)a_ : ws + (base ? w.a_bsk : w.a_q);
+            const u64* xb = (whole && !base) ? (const u64*)b_ : ws + (base ? w.b_bsk : w.b_q);
+            u64* xd = ws + (base ? w.d_bsk : w.d_q);
+            NttArgs fa = contiguous_args(p, xa, nullptr, 2, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
+            NttArgs fb = contiguous_args(p, xb, nullptr, 2, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
+            NttArgs id = contiguous_args(p, xd, xd, 3, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
+            if ((rc = tensor_stage(p, 1, fa, fb, id, batch, s))) return rc;
+            if (!whole && (rc = tensor_stage(p, 2, id, id, id, batch, s))) return rc;
+        }
+    } else {
     // step (4)
     if ((rc = launch_convolute(pq->d_mods, n, 0, L, ws + w.a_q, pa, ws + w.b_q, pb, ws + w.d_q, batch, s))) return rc;
     if ((rc = launch_convolute(px->d_mods, n, 0, S, ws + w.a_bsk, pa, ws + w.b_bsk, pb, ws + w.d_bsk, batch, s))) return rc;
@@ -1467,12 +1576,19 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         NttArgs ab = contiguous_args(px, ws + w.d_bsk, ws + w.d_bsk, po, S, 0, S, TROYN_IDX_COMPONENTWISE, 0);
         if ((rc = launch_ntt(px, ab, batch, true, s))) return rc;
     }
+    }
     // steps (6)-(8)
     {
         const size_t items = batch * po;
         if ((rc = check_rows(items, ch1))) return rc;
         dim3 grid((unsigned)(items * ch1)), block(256);
-        dispatch_bound(S,
+        if (gen2) {
+            switch (L) {
+#define X(N) case N: launch_behz2_floor<N>(b, grid, s, ch1, ws + w.d_q, ws + w.d_bsk, (u64*)out); break;
+                BEHZ2_CASES(X)
+#undef X
+            }
+        } else dispatch_bound(S,
             [&] { hipLaunchKernelGGL((behz_floor_kernel<4>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
             [&] { hipLaunchKernelGGL((behz_floor_kernel<8>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
             [&] { hipLaunchKernelGGL((behz_floor_kernel<16>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
