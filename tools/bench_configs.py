@@ -89,6 +89,18 @@ def main():
                        "multiply_ops_per_s": round(B / tm, 1), "relinearize_ops_per_s": round(B / tr, 1),
                        "multiply_relinearize_ops_per_s": round(B / (tm + tr), 1)}
 
+    if a.only in ("", "bfv_mul"):
+        # BEHZ multiply of independent ciphertext pairs at the whole-limb sizes (cfg2's parameters, the matmul app's chain, a 50-bit chain)
+        for name, n, bits, L, B in (("N8192_3x40", 8192, [40] * 3, 2, 1024), ("N8192_60_40_40_60", 8192, [60, 40, 40, 60], 3, 512),
+                                    ("N4096_3x36", 4096, [36] * 3, 2, 2048), ("N8192_5x50", 8192, [50] * 5, 4, 512)):
+            q = pkg.capi.coeff_modulus_create(n, bits)
+            plan = pkg.Plan(dev, n.bit_length() - 1, q)
+            behz = pkg.Behz(plan, L, 1032193)
+            x, y = residues(pkg, (B, 2), q[:L], n, dev, gen), residues(pkg, (B, 2), q[:L], n, dev, gen)
+            prod = torch.empty((B, 3, L, n), dtype=torch.int64, device=dev)
+            tm = timed(lambda: behz.multiply(x, 2, y, 2, out=prod), a.reps)
+            res["bfv_mul_" + name] = {"batch": B, "multiply_ops_per_s": round(B / tm, 1)}
+
     if a.only in ("", "cfg5"):
         # 512x512x512 matmul packed into N=8192 slots: the kernel is ret[b][j] = sum_i a[b][i] (.) w[i][j]
         import ctypes as C

@@ -874,8 +874,8 @@ __global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
 //   TB <  LOGN (N >= 32768, two-pass transforms): the operands arrive after their strided first pass and the product leaves before
 //     its strided last pass; the same 4+3 replace the second forward pass, the dyadic kernel and the first inverse pass.
 //   fa, fb: forward arguments over [item][2][ncomp][N], id: inverse arguments over [item][3][ncomp][N]
-template <class A, int LOGN, int TB, int EB>
-__global__ __launch_bounds__(1 << (TB - EB), (TB - EB) <= 8 ? 2 : 1) void tensor_core_kernel(NttArgs fa, NttArgs fb, NttArgs id) {
+template <class A, int LOGN, int TB, int EB, int MINB = 1>
+__global__ __launch_bounds__(1 << (TB - EB), MINB) void tensor_core_kernel(NttArgs fa, NttArgs fb, NttArgs id) {
     constexpr int G1 = LOGN - TB, E = 1 << EB;
     constexpr bool WHOLE = G1 == 0;
     __shared__ u64 lds[ntt_lds_words(TB)];

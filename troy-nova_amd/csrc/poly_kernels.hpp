@@ -192,19 +192,34 @@ __global__ __launch_bounds__(POLY_BLOCK) void ks_util6_kernel(unsigned chunks, c
 __global__ __launch_bounds__(POLY_BLOCK) void ks_util7_kernel(unsigned chunks, const DevModulus* mods, unsigned L, unsigned prod_rows, unsigned n,
                                                               const u64* prod, const u64* temp_last, const ulonglong2* inv_qk,
                                                               int is_ckks, int assign_method, u64* dest,
-                                                              const u64* addend, size_t addend_bstride) {
+                                                              const u64* addend, size_t addend_bstride,
+                                                              const u64* last_intt = nullptr, size_t last_stride = 0, unsigned K = 0) {
     const unsigned j = blk_row(chunks) % L;
     const size_t kb = blk_row(chunks) / L;   // item*2 + k
     const unsigned k = kb & 1;
     const DevModulus md = mods[j];
     const ulonglong2 f = inv_qk[j];
+    // coefficient form: ski_util6's rounding fix is formed here from the special-prime row (last_intt) instead of being read back
+    // from temp_last -- the same word sequence as ks_util6_kernel
+    const DevModulus qk = mods[last_intt ? K - 1 : j];
+    const u64 qk_half = qk.q >> 1;
+    const u64 fix = md.q - barrett64(qk_half, md.q, md.ratio_hi);
+    const bool need_reduce = qk.q > md.q;
+    const u64* ls = last_intt ? last_intt + kb * last_stride : nullptr;
     const u64 lift = is_ckks ? (md.q << 2) : (md.q << 1);
     const bool add_inplace = (assign_method == 0) || (k == 0 && assign_method == 2);
     const u64* pp = prod + (kb * prod_rows + j) * (size_t)n;
     const u64* tl = temp_last + (kb * L + j) * (size_t)n;
     u64* dp = dest + (kb * L + j) * (size_t)n;
     for (unsigned x = blk_col(chunks) * 2; x < n; x += chunks * blockDim.x * 2) {
-        const u64x2 p = ld2(pp + x), t = ld2(tl + x);
+        const u64x2 p = ld2(pp + x);
+        u64x2 t;
+        if (ls) {
+            const u64x2 v = ld2(ls + x);
+            u64 t0 = barrett64(v.a + qk_half, qk.q, qk.ratio_hi), t1 = barrett64(v.b + qk_half, qk.q, qk.ratio_hi);
+            if (need_reduce) { t0 = barrett64(t0, md.q, md.ratio_hi); t1 = barrett64(t1, md.q, md.ratio_hi); }
+            t.a = t0 + fix; t.b = t1 + fix;
+        } else t = ld2(tl + x);
         u64 d0 = shoup_mul(p.a + lift - t.a, f.x, f.y, md.q);
         u64 d1 = shoup_mul(p.b + lift - t.b, f.x, f.y, md.q);
         if (add_inplace) {

@@ -478,19 +478,40 @@ static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const 
         if (stage == 0) { launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, batch * a.pcount * a.ncomp, s); return; }
         if (stage == 2) { launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(a, batch * a.pcount * a.ncomp, s); return; }
     }
-    if (stage == 1) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB>), dim3((unsigned)((batch * a.ncomp) << G1)), dim3(1u << (TB - EB)), 0, s, a, b, d);
+    if (stage != 1) return;
+    const dim3 grid((unsigned)((batch * a.ncomp) << G1)), block(1u << (TB - EB));
+    if constexpr (G1 > 0) {
+        // 256-thread workgroups holding three polynomials in registers: three per CU (168 registers, a few spilled words; measured 2-3 % faster
+        // than two per CU without spills, TROYN_TENSOR_WGS=2)
+        static int wgs = -1;
+        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 3; }
+        if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);
+        else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 2>), grid, block, 0, s, a, b, d);
+    } else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 1>), grid, block, 0, s, a, b, d);
 }
 // 0: limbs [0, ncomp) of plan p cannot take the fused tensor path; 1: whole-limb tiles; 2: two-pass transforms.  One arithmetic class.
 static int tensor_path_kind(const troyn_plan* p, unsigned ncomp) {
     const char* e = getenv("TROYN_BFV_TENSOR");   // "split": separate transform and dyadic launches (A/B runs, tests of that path)
     if (e && std::strcmp(e, "split") == 0) return 0;
+    if (p->log_n >= 10 && p->log_n <= 13) return 1;   // limbs of both classes: one launch per run of one class (tensor_stage)
     for (unsigned j = 1; j < ncomp; j++) if (p->small_modulus[j] != p->small_modulus[0]) return 0;
-    if (p->log_n >= 10 && p->log_n <= 13) return 1;
     if (p->log_n == 15 || p->log_n == 16) return 2;
     return 0;
 }
 static int tensor_stage(const troyn_plan* p, int stage, NttArgs a, NttArgs b, NttArgs d, size_t batch, hipStream_t s) {
-    const bool f64 = use_f64(p, 0, a.ncomp);
+    // limbs of both arithmetic classes ({60,40,40,60}): one launch per run of limbs of one class (limbs are independent)
+    for (unsigned j0 = 0, j1; j0 < a.ncomp; j0 = j1) {
+        for (j1 = j0 + 1; j1 < a.ncomp && p->small_modulus[a.table_start + j1] == p->small_modulus[a.table_start + j0]; j1++) {}
+        if (j0 == 0 && j1 == a.ncomp) break;   // one class: fall through to the single launch
+        auto sub = [&](NttArgs x) {
+            x.in += (long long)j0 * x.in_cstride; if (x.out) x.out += (long long)j0 * x.out_cstride;
+            x.ncomp = j1 - j0; x.table_start += j0; x.table_count = j1 - j0;
+            return x;
+        };
+        if (int rc = tensor_stage(p, stage, sub(a), sub(b), sub(d), batch, s)) return rc;
+        if (j1 == a.ncomp) return TROYN_OK;
+    }
+    const bool f64 = use_f64(p, a.table_start, a.ncomp);
     auto prep = [&](NttArgs& x, bool inverse) {
         x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
         x.tw = f64 ? (inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64) : (inverse ? (const void*)p->d_inv : (const void*)p->d_fwd);
@@ -828,14 +849,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         hipLaunchKernelGGL(bgv_delta_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, L, n, bgv->t, bgv->inv_special_mod_t, p->moduli[K - 1], last_src, last_stride, util6_out);
         LAUNCH_CHECK();
-    } else {
+    } else if (is_ntt_form) {
         const unsigned ch = chunks_pairs(n);
         const size_t rows = batch * 2 * L;
         if ((rc = check_rows(rows, ch))) return rc;
         hipLaunchKernelGGL(ks_util6_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, K, L, n, last_src, last_stride, util6_out);
         LAUNCH_CHECK();
-    }
+    }   // coefficient form: ks_util7_kernel forms the fix itself from the special-prime row
     // (6) back to NTT form when needed (:1033-1036)
     if (is_ntt_form) {
         NttArgs a = contiguous_args(p, util6_out, ws + w.temp_last, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
@@ -851,9 +872,11 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     } else {
         const unsigned ch = chunks_pairs(n);
         const size_t rows = batch * 2 * L;
+        if ((rc = check_rows(rows, ch))) return rc;
         hipLaunchKernelGGL(ks_util7_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, L, L + 1, n, prod_for_util7, ws + w.temp_last,
-                           p->d_inv_last + (size_t)K * K, is_ckks, assign_method, dest, addend, addend_bstride);
+                           p->d_inv_last + (size_t)K * K, is_ckks, assign_method, dest, addend, addend_bstride,
+                           is_ntt_form ? (const u64*)nullptr : last_src, last_stride, K);
         LAUNCH_CHECK();
     }
     return TROYN_OK;
