@@ -69,7 +69,10 @@ def _chains(O, n):
     below = O.coeff_modulus_create(n, [50] * 6)
     above = _first_prime_above(1 << 50, 2 * n)
     assert max(below) < (1 << 50) < above
-    return [("six_50bit", below), ("straddle_2^50", [max(below), above, min(below)])]
+    # the largest 61-bit primes (the BEHZ auxiliary base): the integer butterflies keep values below 8q, i.e. just under 2^64 here
+    top = O.get_primes(2 * n, 61, 3)
+    assert all((1 << 60) < v < (1 << 61) for v in top)
+    return [("six_50bit", below), ("straddle_2^50", [max(below), above, min(below)]), ("three_61bit", top)]
 
 
 @pytest.mark.parametrize("log_n", [13, 14, 15])

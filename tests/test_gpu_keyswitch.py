@@ -82,6 +82,34 @@ def test_relinearize(O, pkg, dev, scheme, ntt_form, n, bits, L):
         assert np.array_equal(got[i], ctx.relinearize(L, ntt_form, ct3[i], keys))
 
 
+@pytest.mark.parametrize("tail", ["fused", "split"])
+@pytest.mark.parametrize("n,bits,L", [(4096, [36, 36, 37], 2), (2048, [54, 54, 55], 2), (32768, [50] * 4, 3), (8192, [60, 40, 40, 60], 3)])
+def test_coefficient_form_tail(O, pkg, dev, monkeypatch, n, bits, L, tail):
+    """BFV (coefficient form): the inverse transforms of the data rows finish the key switch in their epilogue (rounding fix from the
+    special-prime row, divide by the special prime, assign / accumulate, relinearize's trailing add); TROYN_KS_TAIL=split keeps the
+    separate ski_util7 launch.  FP64 class, integer class, two-pass size, mixed chain; every assign method and relinearize."""
+    if tail == "split":
+        monkeypatch.setenv("TROYN_KS_TAIL", "split")
+    else:
+        monkeypatch.delenv("TROYN_KS_TAIL", raising=False)
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, 1032193)
+    keys = ctx.random_keys(13, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    batch = 3
+    tg = np.stack([ctx.random_ct(15 + i, 1, L)[0] for i in range(batch)])
+    for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE, pkg.ASSIGN_OVERWRITE_EXCEPT_FIRST):
+        d0 = np.stack([ctx.random_ct(140 + i, 2, L) for i in range(batch)])
+        dd = pkg.to_device(d0, dev)
+        plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=assign, is_ckks=False, is_ntt_form=False)
+        got = pkg.to_host(dd)
+        for i in range(batch):
+            assert np.array_equal(got[i], ctx.switch_key(L, False, tg[i], keys, assign=assign, dest=d0[i])), (assign, i)
+    ct3 = np.stack([ctx.random_ct(170 + i, 3, L) for i in range(batch)])
+    got = pkg.to_host(plan.relinearize(L, pkg.to_device(ct3, dev), dkeys, is_ckks=False, is_ntt_form=False))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.relinearize(L, False, ct3[i], keys)), i
+
+
 @pytest.mark.parametrize("n,bits,L", [(32, [40, 40, 40], 3), (32, [30, 40, 50, 60], 4), (32, [60, 50, 40, 30], 4),
                                       (8192, [40, 40, 40], 2), (16384, [50] * 6, 5), (32768, [50] * 3, 3)])
 def test_ckks_rescale(O, pkg, dev, n, bits, L):

@@ -269,11 +269,26 @@ struct ArithU64 {
 
     static constexpr bool MID_FIX = false;
     static constexpr bool FOLD_NINV = false;
-    struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo, ratio_lo; };
-    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo, d.ratio_lo}; }
-    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {
+    // Round 2: the butterflies estimate the Shoup quotient from the three high 32 x 32 partial products only (shoup_lazy3: never
+    // above floor(x wq / 2^64), at most 2 below), which saves the low product, its carry chain and the register moves around them --
+    // the product lands in [0, 4q) instead of [0, 2q), so the lazy ranges are twice the reference's: [0, 8q) forward, [0, 4q) inverse
+    // (q < 2^61, 8q < 2^64).  Stored results are canonical, hence unchanged.
+    struct Mod { u64 q, two_q, ratio_hi, ninv_op, ninv_quo, ratio_lo, four_q, neg_four_q, neg_q; };
+    static __device__ __forceinline__ Mod make(const DevModulus& d) { return Mod{d.q, d.q << 1, d.ratio_hi, d.inv_n_op, d.inv_n_quo, d.ratio_lo, d.q << 2, 0ull - (d.q << 2), 0ull - d.q}; }
+    static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) {     // [0, 8q) -> [0, q)
+        v = v >= m.four_q ? v - m.four_q : v;
         v = v >= m.two_q ? v - m.two_q : v;
         return v >= m.q ? v - m.q : v;
+    }
+    // neg_q = 2^64 - q: w x - qh q = w x + qh neg_q (mod 2^64) -- a 64-bit add is one v_lshl_add_u64, a subtract is a carry chain
+    static __device__ __forceinline__ u64 shoup_lazy3(u64 x, u64 w, u64 wq, u64 neg_q) {   // any 64-bit x -> [0, 4q)
+        const unsigned x0 = (unsigned)x, x1 = (unsigned)(x >> 32), w0 = (unsigned)wq, w1 = (unsigned)(wq >> 32);
+        const u64 qh = (u64)x1 * w1 + __umulhi(x1, w0) + __umulhi(x0, w1);
+        return w * x + qh * neg_q;
+    }
+    static __device__ __forceinline__ u64 csub4(u64 v, const Mod& m) {   // [0, 8q) -> [0, 4q)
+        const u64 t = v + m.neg_four_q;
+        return (long long)t < 0 ? v : t;
     }
     // <digit, key> accumulation of the fused key switch (ks_mac_kernel): canonical in, canonical accumulator
     static __device__ __forceinline__ elem mac_zero() { return 0; }
@@ -300,17 +315,15 @@ struct ArithU64 {
     static __device__ __forceinline__ u64 to_lds(elem x, const Mod&) { return x; }
     static __device__ __forceinline__ elem mid_fix(elem x, const Mod&) { return x; }
     static __device__ __forceinline__ void fwd(elem& a, elem& b, const tw_t w, const Mod& m) {
-        u64 u = a;
-        u = u >= m.two_q ? u - m.two_q : u;
-        const u64 v = shoup_lazy(b, w.x, w.y, m.q);
+        const u64 u = csub4(a, m);
+        const u64 v = shoup_lazy3(b, w.x, w.y, m.neg_q);
         a = u + v;
-        b = u + m.two_q - v;
+        b = u + m.four_q - v;
     }
     static __device__ __forceinline__ void inv(elem& a, elem& b, const tw_t w, const Mod& m) {
         const u64 u = a, v = b;
-        const u64 s = u + v;
-        a = s >= m.two_q ? s - m.two_q : s;
-        b = shoup_lazy(u + m.two_q - v, w.x, w.y, m.q);
+        a = csub4(u + v, m);
+        b = shoup_lazy3(u + m.four_q - v, w.x, w.y, m.neg_q);
     }
     static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) {
         return shoup_lazy(final_fwd(v, m), m.ninv_op, m.ninv_quo, m.q);   // the reference's lazy N^-1 multiply
@@ -536,11 +549,16 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR && FIRST;
     constexpr bool F_LAST_LD = IOM == NTT_FUSED_LAST_LIMB && FIRST, F_LAST_ST = IOM == NTT_FUSED_LAST_LIMB && LAST;
     constexpr bool F_TR_LD = IOM == NTT_FUSED_TAIL_RESCALE && FIRST, F_TR_ST = IOM == NTT_FUSED_TAIL_RESCALE && LAST;
+    // coefficient-form key-switch tail (BFV): the inverse transform of a data row ends with ski_util6_merged + ski_util7_merged
+    // (evaluator_keyswitching_core.cu:570-658) -- the rounding fix is formed from the INTT of the special-prime row (in2) at the same
+    // coefficient, then (this + lift - fix) qk^-1 [+ dest] [+ addend] is stored
+    constexpr bool F_KC_ST = INV && LAST && IOM == 1 && !KSMAC;
     static_assert(!FUSED || (!KSMAC && std::is_same<A, ArithF64>::value), "fused chain: FP64 kernels");
     static_assert(!FUSED || (INV == (IOM == NTT_FUSED_MULPAIR || IOM == NTT_FUSED_LAST_LIMB)), "fused chain: transform direction");
     NttIo io;
     if constexpr (FUSED) { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; ntt_io_fused(io, a, b, k, j, mi); }
     else if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
+    else if constexpr (F_KC_ST) { io = ntt_io_make(a, b, k, j, mi, gout); io.in2 = a.in2 + (long long)b * a.in2_bstride + (long long)k * a.in2_pstride; }
     else { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; }
     // this workgroup's limb of the two input ciphertexts (fused chain)
     const long long mul_off = FUSED ? (long long)(a.mul_limb0 + j) * N : 0ll;
@@ -813,6 +831,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     double lc = f64_corr(ys - A::scale_by(rs, io.inv_d, md), md.m);
                     lc = lc < 0.0 ? lc + md.m.p : lc;
                     v = f64_double_to_bits(A::round_half(lc, md));
+                } else if constexpr (F_KC_ST) {
+                    u64 pw;
+                    if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) pw = A::final_fwd(x[R], md);          // already scaled by N^-1
+                    else pw = A::final_inv(x[R], md);
+                    const elem fixv = A::template load_io<NTT_LOAD_KS_ROUND>(io, io.in2[gi], false, md);
+                    v = A::template store_io<NTT_STORE_KS_FINISH>(io, A::store_mid(fixv, md), pw, io.ext1 ? io.ext1[gi] : 0, io.add_inplace ? io.dest[gi] : 0, md);
                 } else if constexpr (LAST) {
                     if constexpr (INV && A::FOLD_NINV && ((R >> (EB - 1)) & 1)) v = A::final_fwd(x[R], md);   // already scaled
                     else if constexpr (INV) v = A::final_inv(x[R], md);

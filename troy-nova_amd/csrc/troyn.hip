@@ -330,6 +330,12 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
             if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>), grid, block, 0, s, a); return; }
         }
     }
+    if constexpr (INV && LAST) {
+        if (sm == NTT_STORE_KS_FINISH) {   // coefficient-form key-switch tail: the finish runs in the inverse transform's epilogue
+            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
+            return;
+        }
+    }
     if constexpr (!INV) {
         if (lm == NTT_LOAD_KS_ROUND || sm == NTT_STORE_KS_FINISH) {
             hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
@@ -690,6 +696,11 @@ extern "C" size_t troyn_relinearize_workspace_bytes(const troyn_plan* plan, uint
 struct BgvTail { DevModulus t; u64 inv_special_mod_t; };
 
 // target: [batch] items of L limbs, `target_bstride` elements apart.
+static bool coeff_tail_fused() {
+    const char* e = getenv("TROYN_KS_TAIL");   // "split": inverse transforms and ski_util7 in separate launches (A/B runs, tests of that path)
+    return !(e && std::strcmp(e, "split") == 0);
+}
+
 static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_ntt_form,
                            const u64* target, size_t target_bstride, const uint64_t* const* keys, int assign_method,
                            u64* dest, const u64* addend, size_t addend_bstride,
@@ -818,6 +829,25 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
         last_src = ws + w.prod_intt; last_stride = n;
         prod_for_util7 = ws + w.poly_prod;
+    } else if (!bgv && p->log_n >= 10 && p->log_n <= 17 && coeff_tail_fused()) {
+        // coefficient form: INTT of the two special-prime rows, then the INTT of the 2L data rows finishes the key switch in its epilogue
+        // ((5) + (7), ski_util6_merged / ski_util7_merged) and writes the destination -- the INTT'd rows never reach HBM
+        NttArgs a = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.prod_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_pstride = (long long)(L + 1) * n;
+        a.in_bstride = 2ll * (L + 1) * n;
+        if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
+        NttArgs f = contiguous_args(p, ws + w.poly_prod, dest, 2, L, 0, K, TROYN_IDX_COMPONENTWISE, 0);
+        f.in_pstride = (long long)(L + 1) * n;
+        f.in_bstride = 2ll * (L + 1) * n;
+        f.load_mode = NTT_LOAD_KS_ROUND; f.aux_mod = K - 1;      // constants of the rounding fix (no forward prologue runs)
+        f.store_mode = NTT_STORE_KS_FINISH;
+        f.flags = (is_ckks ? 1u : 0u) | ((unsigned)assign_method << 1);
+        f.in2 = ws + w.prod_intt; f.in2_bstride = 2ll * n; f.in2_pstride = n;
+        f.ext0 = dest; f.ext0_bstride = 2ll * L * n; f.ext0_pstride = (long long)L * n; f.ext0_cstride = n;   // unused by this epilogue
+        f.ext1 = addend; f.ext1_bstride = (long long)addend_bstride; f.ext1_pstride = (long long)L * n; f.ext1_cstride = n;
+        f.inv_table = p->d_inv_last + (size_t)K * K;
+        // two-pass sizes: the pass in between goes to the free part of prod_intt, never to dest (AddInplace reads the old destination)
+        return launch_ntt(p, f, batch, true, s, ws + w.prod_intt + batch * 2 * (size_t)n);
     } else {
         NttArgs a = contiguous_args(p, ws + w.poly_prod, ws + w.prod_intt, 2, L + 1, 0, K, TROYN_IDX_KS_SKIP_FINALS, L);
         if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
