@@ -66,7 +66,7 @@ __host__ __device__ constexpr unsigned ksm_perm(unsigned i) {
 }
 
 // keys[j] -> [2][K][N] u64 (the reference's KSwitchKeys layout)  ==>  prepared [j][2][K][N] doubles, permuted
-__global__ __launch_bounds__(256) void ksmac_prepare_keys_kernel(KeyPtrs keys, unsigned L, unsigned rows_per_key, unsigned n, double* out) {
+static __global__ __launch_bounds__(256) void ksmac_prepare_keys_kernel(KeyPtrs keys, unsigned L, unsigned rows_per_key, unsigned n, double* out) {
     const size_t pairs_per_key = (size_t)rows_per_key * (n / 2);
     const size_t total = (size_t)L * pairs_per_key;
     for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {

@@ -353,7 +353,7 @@ struct ArithF64 {
     static __device__ __forceinline__ void inv_fold(elem& a, elem& b, const Mod& m) {
         const double u = a, v = b;
         a = u + v;
-        b = f64_mulc(u - v, m.nw, m.nw_p, m.m.p);
+        b = f64_mulq(u - v, m.nw, m.m.inv_p, m.m.p);
     }
     // <digit, key> accumulation: |v| <= 0.5p+1, key in [0,p).  The quotient is estimated from the product itself
     // (q = rint(fl(v*y) * fl(1/p)), off by < 0.2 from v*y/p), so each term is an exact integer of magnitude <= 0.69p;
@@ -428,8 +428,10 @@ struct ArithF64 {
     static __device__ __forceinline__ elem from_lds(u64 raw) { return f64_bits_to_double(raw); }
     static __device__ __forceinline__ u64 to_lds(elem x, const Mod& m) { return f64_double_to_bits(f64_corr(x, m.m)); }
     static __device__ __forceinline__ elem mid_fix(elem x, const Mod& m) { return f64_corr(x, m.m); }
+    // f64_mulq: the quotient comes from the rounded product itself, so no w/p has to be formed per twiddle (w.y is never read and
+    // the compiler drops its multiply)
     static __device__ __forceinline__ void fwd(elem& a, elem& b, const tw_t w, const Mod& m) {
-        const double r = f64_mulc(b, w.x, w.y, m.m.p);
+        const double r = f64_mulq(b, w.x, m.m.inv_p, m.m.p);
         const double u = a;
         a = u + r;
         b = u - r;
@@ -437,7 +439,7 @@ struct ArithF64 {
     static __device__ __forceinline__ void inv(elem& a, elem& b, const tw_t w, const Mod& m) {
         const double u = a, v = b;
         a = u + v;
-        b = f64_mulc(u - v, w.x, w.y, m.m.p);
+        b = f64_mulq(u - v, w.x, m.m.inv_p, m.m.p);
     }
     static __device__ __forceinline__ u64 final_fwd(elem v, const Mod& m) { return f64_canon(v, m.m); }
     static __device__ __forceinline__ u64 final_inv(elem v, const Mod& m) { return f64_canon(f64_mulc(v, m.ninv, m.ninv_p, m.m.p), m.m); }
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(1 << (LOGN - EB)) void ks_mac_kernel(NttArgs a, Key
 // Generic fallback for any 2 <= N: one workgroup per limb-polynomial, radix-2 layer by layer.
 // N <= 4096 runs out of LDS; larger N (not covered by an optimised instantiation) works in
 // place in global memory.  Used for small test rings (the reference's tests use N = 32).
-__global__ __launch_bounds__(256) void ntt_generic_kernel(NttArgs a, unsigned log_n, int inverse) {
+static __global__ __launch_bounds__(256) void ntt_generic_kernel(NttArgs a, unsigned log_n, int inverse) {
     __shared__ u64 lds[4096];
     const unsigned n = 1u << log_n;
     unsigned bid = blockIdx.x;

@@ -1,0 +1,145 @@
+// ntt_launch.inl -- launch code of the NTT-family kernels (ntt_kernels.hpp), templated on the arithmetic policy.  Included by
+// troyn_ntt_f64.hip and troyn_ntt_u64.hip, which instantiate it for one policy each so that the two sets of kernels compile in
+// parallel; troyn.hip calls the non-template entry points declared in launch.hpp.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <hip/hip_runtime.h>
+#include "ntt_kernels.hpp"
+#include "launch.hpp"
+
+namespace troyn {
+
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
+static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
+    const unsigned tiles = 1u << (LOGN - TB);
+    dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
+    static int extra_lds = -1;   // TROYN_NTT_EXTRA_LDS=<bytes>: occupancy experiments only
+    if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
+    // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
+    const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
+    if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
+        // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768
+        if constexpr (INV) {
+            if (a.fused_mode == NTT_FUSED_MULPAIR) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>), grid, block, 0, s, a); return; }
+            if (a.fused_mode == NTT_FUSED_LAST_LIMB) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>), grid, block, 0, s, a); return; }
+        } else {
+            if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>), grid, block, 0, s, a); return; }
+        }
+    }
+    if constexpr (INV && LAST) {
+        if (sm == NTT_STORE_KS_FINISH) {   // coefficient-form key-switch tail: the finish runs in the inverse transform's epilogue
+            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
+            return;
+        }
+    }
+    if constexpr (!INV) {
+        if (lm == NTT_LOAD_KS_ROUND || sm == NTT_STORE_KS_FINISH) {
+            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
+            return;
+        }
+        if (lm == NTT_LOAD_RESCALE || sm == NTT_STORE_RESCALE) {
+            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 2>), grid, block, (size_t)extra_lds, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 0>), grid, block, (size_t)extra_lds, s, a);
+}
+
+// single pass: whole limb in one tile
+template <class A, int LOGN, int EB>
+static void launch_single(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
+    if (inv) launch_pass<A, LOGN, 0, LOGN, LOGN, EB, true, true, true>(a, lp, s);
+    else launch_pass<A, LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
+}
+
+// two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks.
+// The pass between them lives in `scratch` ([limb-polynomial][N], contiguous) when one is given, else in `out`: a fused
+// epilogue that READS the old destination (key-switch tail with AddInplace / OverwriteExceptFirst) must not find the first
+// pass's intermediate words there.
+template <class A, int LOGN, int TB, int EB>
+static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s, u64* scratch) {
+    constexpr int G1 = LOGN - TB;
+    NttArgs first = a, second = a;
+    if (scratch) {
+        first.out = scratch;
+        first.out_cstride = (long long)1 << LOGN;
+        first.out_pstride = (long long)a.ncomp << LOGN;
+        first.out_bstride = (long long)a.pcount * a.ncomp << LOGN;
+    }
+    second.in = first.out;
+    second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
+    second.reduce_input = 0;
+    if (!inv) {
+        launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(first, lp, s);
+        launch_pass<A, LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
+    } else {
+        launch_pass<A, LOGN, G1, TB, TB, EB, true, true, false>(first, lp, s);
+        launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
+    }
+}
+
+template <class A>
+static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
+    // N = 4096 / 8192: 8 coefficients per thread (EB = 3) doubles the waves per tile, so a CU holds 32 waves instead
+    // of 16; measured 5-14 % faster than EB = 4 despite the extra LDS exchange.  N = 16384 needs EB = 4 to fit one
+    // workgroup (1024 threads x 16 coefficients).
+    switch (log_n) {
+        case 10: launch_single<A, 10, 4>(a, lp, inverse, s); return true;
+        case 11: launch_single<A, 11, 4>(a, lp, inverse, s); return true;
+        case 12: launch_single<A, 12, 3>(a, lp, inverse, s); return true;
+        case 13: launch_single<A, 13, 3>(a, lp, inverse, s); return true;
+        case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
+        case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s, scratch); return true;
+        case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s, scratch); return true;
+        case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s, scratch); return true;
+        default: return false;
+    }
+}
+
+template <class A>
+static bool launch_ks_mac_t(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
+    switch (log_n) {
+        case 10: hipLaunchKernelGGL((ks_mac_kernel<A, 10, 4>), dim3((unsigned)blocks), dim3(1u << 6), 0, s, a, kp); return true;
+        case 11: hipLaunchKernelGGL((ks_mac_kernel<A, 11, 4>), dim3((unsigned)blocks), dim3(1u << 7), 0, s, a, kp); return true;
+        case 12: hipLaunchKernelGGL((ks_mac_kernel<A, 12, 4>), dim3((unsigned)blocks), dim3(1u << 8), 0, s, a, kp); return true;
+        case 13: hipLaunchKernelGGL((ks_mac_kernel<A, 13, 4>), dim3((unsigned)blocks), dim3(1u << 9), 0, s, a, kp); return true;
+        case 14: hipLaunchKernelGGL((ks_mac_kernel<A, 14, 4>), dim3((unsigned)blocks), dim3(1u << 10), 0, s, a, kp); return true;
+        default: return false;
+    }
+}
+
+template <class A, int LOGN, int TB, int EB>
+static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
+    constexpr int G1 = LOGN - TB;
+    if constexpr (G1 > 0) {
+        if (stage == 0) { launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, batch * a.pcount * a.ncomp, s); return; }
+        if (stage == 2) { launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(a, batch * a.pcount * a.ncomp, s); return; }
+    }
+    if (stage != 1) return;
+    const dim3 grid((unsigned)((batch * a.ncomp) << G1)), block(1u << (TB - EB));
+    if constexpr (G1 > 0) {
+        // 256-thread workgroups holding three polynomials in registers: three per CU (168 registers, a few spilled words; measured 2-3 % faster
+        // than two per CU without spills, TROYN_TENSOR_WGS=2)
+        static int wgs = -1;
+        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 3; }
+        if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);
+        else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 2>), grid, block, 0, s, a, b, d);
+    } else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 1>), grid, block, 0, s, a, b, d);
+}
+
+template <class A>
+static bool launch_tensor_class(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
+    switch (log_n) {
+        case 10: tensor_stage_t<A, 10, 10, 4>(stage, a, b, d, batch, s); return true;
+        case 11: tensor_stage_t<A, 11, 11, 4>(stage, a, b, d, batch, s); return true;
+        case 12: tensor_stage_t<A, 12, 12, 3>(stage, a, b, d, batch, s); return true;
+        case 13: tensor_stage_t<A, 13, 13, 3>(stage, a, b, d, batch, s); return true;
+        case 15: tensor_stage_t<A, 15, 12, 4>(stage, a, b, d, batch, s); return true;
+        case 16: tensor_stage_t<A, 16, 12, 4>(stage, a, b, d, batch, s); return true;
+        default: return false;
+    }
+}
+
+}  // namespace troyn

@@ -14,6 +14,7 @@
 #include "../../include/troyn.h"
 #include "behz_kernels.hpp"
 #include "behz2_kernels.hpp"
+#include "launch.hpp"
 #include "crypto_kernels.hpp"
 #include "bgv_kernels.hpp"
 #include "ring2k_kernels.hpp"
@@ -313,93 +314,6 @@ extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, i
 // ---------------------------------------------------------------------------------------
 // NTT launch
 // ---------------------------------------------------------------------------------------
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
-static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
-    const unsigned tiles = 1u << (LOGN - TB);
-    dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
-    static int extra_lds = -1;   // TROYN_NTT_EXTRA_LDS=<bytes>: occupancy experiments only
-    if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
-    // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
-    const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
-    if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
-        // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768
-        if constexpr (INV) {
-            if (a.fused_mode == NTT_FUSED_MULPAIR) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>), grid, block, 0, s, a); return; }
-            if (a.fused_mode == NTT_FUSED_LAST_LIMB) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>), grid, block, 0, s, a); return; }
-        } else {
-            if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>), grid, block, 0, s, a); return; }
-        }
-    }
-    if constexpr (INV && LAST) {
-        if (sm == NTT_STORE_KS_FINISH) {   // coefficient-form key-switch tail: the finish runs in the inverse transform's epilogue
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
-            return;
-        }
-    }
-    if constexpr (!INV) {
-        if (lm == NTT_LOAD_KS_ROUND || sm == NTT_STORE_KS_FINISH) {
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
-            return;
-        }
-        if (lm == NTT_LOAD_RESCALE || sm == NTT_STORE_RESCALE) {
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 2>), grid, block, (size_t)extra_lds, s, a);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 0>), grid, block, (size_t)extra_lds, s, a);
-}
-
-// single pass: whole limb in one tile
-template <class A, int LOGN, int EB>
-static void launch_single(const NttArgs& a, size_t lp, bool inv, hipStream_t s) {
-    if (inv) launch_pass<A, LOGN, 0, LOGN, LOGN, EB, true, true, true>(a, lp, s);
-    else launch_pass<A, LOGN, 0, LOGN, LOGN, EB, false, true, true>(a, lp, s);
-}
-
-// two passes: G1 strided layers (columns of 2^(TB-G1) consecutive words), then contiguous 2^TB chunks.
-// The pass between them lives in `scratch` ([limb-polynomial][N], contiguous) when one is given, else in `out`: a fused
-// epilogue that READS the old destination (key-switch tail with AddInplace / OverwriteExceptFirst) must not find the first
-// pass's intermediate words there.
-template <class A, int LOGN, int TB, int EB>
-static void launch_two_pass(const NttArgs& a, size_t lp, bool inv, hipStream_t s, u64* scratch) {
-    constexpr int G1 = LOGN - TB;
-    NttArgs first = a, second = a;
-    if (scratch) {
-        first.out = scratch;
-        first.out_cstride = (long long)1 << LOGN;
-        first.out_pstride = (long long)a.ncomp << LOGN;
-        first.out_bstride = (long long)a.pcount * a.ncomp << LOGN;
-    }
-    second.in = first.out;
-    second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
-    second.reduce_input = 0;
-    if (!inv) {
-        launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(first, lp, s);
-        launch_pass<A, LOGN, G1, TB, TB, EB, false, false, true>(second, lp, s);
-    } else {
-        launch_pass<A, LOGN, G1, TB, TB, EB, true, true, false>(first, lp, s);
-        launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(second, lp, s);
-    }
-}
-
-template <class A>
-static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
-    // N = 4096 / 8192: 8 coefficients per thread (EB = 3) doubles the waves per tile, so a CU holds 32 waves instead
-    // of 16; measured 5-14 % faster than EB = 4 despite the extra LDS exchange.  N = 16384 needs EB = 4 to fit one
-    // workgroup (1024 threads x 16 coefficients).
-    switch (log_n) {
-        case 10: launch_single<A, 10, 4>(a, lp, inverse, s); return true;
-        case 11: launch_single<A, 11, 4>(a, lp, inverse, s); return true;
-        case 12: launch_single<A, 12, 3>(a, lp, inverse, s); return true;
-        case 13: launch_single<A, 13, 3>(a, lp, inverse, s); return true;
-        case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
-        case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s, scratch); return true;
-        case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s, scratch); return true;
-        case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s, scratch); return true;
-        default: return false;
-    }
-}
-
 static int g_force_integer_ntt = -1;   // TROYN_NTT_ARITH=u64 forces the integer butterflies (A/B testing)
 static int g_ks_unfused_mac = -1;      // TROYN_KS_MAC=split keeps decomposition NTT and inner product in two launches (A/B testing)
 
@@ -412,18 +326,6 @@ static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_co
     bool f64 = !g_force_integer_ntt && p->log_n >= 10;
     for (unsigned i = 0; f64 && i < table_count; i++) f64 = p->small_modulus[table_start + i] != 0;
     return f64;
-}
-
-template <class A>
-static bool launch_ks_mac_t(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
-    switch (log_n) {
-        case 10: hipLaunchKernelGGL((ks_mac_kernel<A, 10, 4>), dim3((unsigned)blocks), dim3(1u << 6), 0, s, a, kp); return true;
-        case 11: hipLaunchKernelGGL((ks_mac_kernel<A, 11, 4>), dim3((unsigned)blocks), dim3(1u << 7), 0, s, a, kp); return true;
-        case 12: hipLaunchKernelGGL((ks_mac_kernel<A, 12, 4>), dim3((unsigned)blocks), dim3(1u << 8), 0, s, a, kp); return true;
-        case 13: hipLaunchKernelGGL((ks_mac_kernel<A, 13, 4>), dim3((unsigned)blocks), dim3(1u << 9), 0, s, a, kp); return true;
-        case 14: hipLaunchKernelGGL((ks_mac_kernel<A, 14, 4>), dim3((unsigned)blocks), dim3(1u << 10), 0, s, a, kp); return true;
-        default: return false;
-    }
 }
 
 static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse, hipStream_t s, u64* two_pass_scratch = nullptr) {
@@ -461,14 +363,14 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     bool done;
     if (f64) {
         a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
-        done = launch_ntt_optimised<ArithF64>(p->log_n, a, lp, inverse, s, two_pass_scratch);
+        done = launch_ntt_f64(p->log_n, a, lp, inverse, s, two_pass_scratch);
     } else {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
-        done = launch_ntt_optimised<ArithU64>(p->log_n, a, lp, inverse, s, two_pass_scratch);
+        done = launch_ntt_u64(p->log_n, a, lp, inverse, s, two_pass_scratch);
     }
     if (!done) {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
-        hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)lp), dim3(256), 0, s, a, p->log_n, inverse ? 1 : 0);
+        launch_ntt_generic(a, p->log_n, inverse, lp, s);
     }
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -477,24 +379,6 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
 // ---- tensor product of two 2-component ciphertexts fused with the transforms around it (tensor_core_kernel) ----
 // two-pass sizes (N = 32768, 65536): stage 0 = first forward pass alone, stage 1 = last forward pass + tensor product + first inverse
 // pass, stage 2 = last inverse pass.  Whole-limb sizes (N = 1024 .. 8192): stage 1 is everything.
-template <class A, int LOGN, int TB, int EB>
-static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
-    constexpr int G1 = LOGN - TB;
-    if constexpr (G1 > 0) {
-        if (stage == 0) { launch_pass<A, LOGN, 0, G1, TB, EB, false, true, false>(a, batch * a.pcount * a.ncomp, s); return; }
-        if (stage == 2) { launch_pass<A, LOGN, 0, G1, TB, EB, true, false, true>(a, batch * a.pcount * a.ncomp, s); return; }
-    }
-    if (stage != 1) return;
-    const dim3 grid((unsigned)((batch * a.ncomp) << G1)), block(1u << (TB - EB));
-    if constexpr (G1 > 0) {
-        // 256-thread workgroups holding three polynomials in registers: three per CU (168 registers, a few spilled words; measured 2-3 % faster
-        // than two per CU without spills, TROYN_TENSOR_WGS=2)
-        static int wgs = -1;
-        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 3; }
-        if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);
-        else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 2>), grid, block, 0, s, a, b, d);
-    } else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 1>), grid, block, 0, s, a, b, d);
-}
 // 0: limbs [0, ncomp) of plan p cannot take the fused tensor path; 1: whole-limb tiles; 2: two-pass transforms.  One arithmetic class.
 static int tensor_path_kind(const troyn_plan* p, unsigned ncomp) {
     const char* e = getenv("TROYN_BFV_TENSOR");   // "split": separate transform and dyadic launches (A/B runs, tests of that path)
@@ -524,12 +408,8 @@ static int tensor_stage(const troyn_plan* p, int stage, NttArgs a, NttArgs b, Nt
     };
     prep(a, stage == 2); prep(b, false); prep(d, true);
     if ((batch * a.pcount * a.ncomp) << (p->log_n > 12 ? p->log_n - 12 : 0) > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
-#define TENSOR_CASE(LOGN, TB, EB) case LOGN: if (f64) tensor_stage_t<ArithF64, LOGN, TB, EB>(stage, a, b, d, batch, s); else tensor_stage_t<ArithU64, LOGN, TB, EB>(stage, a, b, d, batch, s); break;
-    switch (p->log_n) {
-        TENSOR_CASE(10, 10, 4) TENSOR_CASE(11, 11, 4) TENSOR_CASE(12, 12, 3) TENSOR_CASE(13, 13, 3) TENSOR_CASE(15, 12, 4) TENSOR_CASE(16, 12, 4)
-        default: return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused tensor kernel for this size");
-    }
-#undef TENSOR_CASE
+if (!(f64 ? launch_tensor_f64(p->log_n, stage, a, b, d, batch, s) : launch_tensor_u64(p->log_n, stage, a, b, d, batch, s)))
+        return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused tensor kernel for this size");
     LAUNCH_CHECK();
     return TROYN_OK;
 }
@@ -751,7 +631,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         {
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
             const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
-            hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(blocks), dim3(256), 0, s, kp, L, 2 * K, n, kf);
+            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, blocks, s);
             LAUNCH_CHECK();
         }
         KsMacArgs a;
@@ -765,9 +645,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.grouped = ksmac_order(batch);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            if (p->log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * (L + 1) * 4)), dim3(KSM_THREADS), 0, s, a);
-            else if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, a);
-            else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, a);
+            launch_ksmac2(p->log_n, batch, L + 1, a, s);
         }
         LAUNCH_CHECK();
     } else if (mac_fused && p->log_n <= 14) {
@@ -792,8 +670,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            if (f64) launch_ks_mac_t<ArithF64>(p->log_n, a, kp, batch * (L + 1), s);
-            else launch_ks_mac_t<ArithU64>(p->log_n, a, kp, batch * (L + 1), s);
+            if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * (L + 1), s);
+            else launch_ks_mac_u64(p->log_n, a, kp, batch * (L + 1), s);
         }
         LAUNCH_CHECK();
     } else {
@@ -1079,7 +957,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     {
         double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
         const size_t pairs = (size_t)L * 2 * K * (n / 2);
-        hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3((unsigned)std::min<size_t>((pairs + 255) / 256, 4096)), dim3(256), 0, s, kp, L, 2 * K, n, kf);
+        launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s);
         LAUNCH_CHECK();
         KsMacArgs m;
         std::memset(&m, 0, sizeof(m));
@@ -1090,9 +968,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
         m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        if (p->log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * (L + 1) * 4)), dim3(KSM_THREADS), 0, s, m);
-        else if (p->log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * (L + 1) * 2)), dim3(KSM_THREADS), 0, s, m);
-        else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * (L + 1))), dim3(KSM_THREADS), 0, s, m);
+        launch_ksmac2(p->log_n, batch, L + 1, m, s);
     }
     LAUNCH_CHECK();
     // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
@@ -1541,18 +1417,6 @@ static void dispatch_bound(unsigned v, F4 f4, F8 f8, F16 f16, F64 f64) {
     if (v <= 4) f4(); else if (v <= 8) f8(); else if (v <= 16) f16(); else f64();
 }
 
-// second-generation kernels: one instantiation per base size (register arrays are indexed statically) and modulus class
-template <int L>
-static void launch_behz2_lift(const troyn_behz* b, dim3 grid, hipStream_t s, unsigned ch, const u64* src, u64* dst) {
-    if (b->smallq) hipLaunchKernelGGL((behz2_lift_kernel<L, true>), grid, dim3(256), 0, s, ch, b->dev2, src, dst);
-    else hipLaunchKernelGGL((behz2_lift_kernel<L, false>), grid, dim3(256), 0, s, ch, b->dev2, src, dst);
-}
-template <int L>
-static void launch_behz2_floor(const troyn_behz* b, dim3 grid, hipStream_t s, unsigned ch, const u64* in_q, const u64* in_bsk, u64* out) {
-    if (b->smallq) hipLaunchKernelGGL((behz2_floor_kernel<L, true>), grid, dim3(256), 0, s, ch, b->dev2, in_q, in_bsk, out);
-    else hipLaunchKernelGGL((behz2_floor_kernel<L, false>), grid, dim3(256), 0, s, ch, b->dev2, in_q, in_bsk, out);
-}
-#define BEHZ2_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 static bool behz2_enabled(const troyn_behz* b) {
     const char* e = getenv("TROYN_BEHZ");   // "v1": first-generation kernels (A/B runs and the tests of that path)
     return b->have2 && !(e && std::strcmp(e, "v1") == 0);
@@ -1587,11 +1451,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         if ((r = check_rows(items, ch1))) return r;
         dim3 grid((unsigned)(items * ch1)), block(256);
         if (gen2) {
-            switch (L) {
-#define X(N) case N: launch_behz2_lift<N>(b, grid, s, ch1, src, dst_bsk); break;
-                BEHZ2_CASES(X)
-#undef X
-            }
+            launch_behz2_lift(L, b->smallq, grid.x, s, ch1, b->dev2, src, dst_bsk);
         } else dispatch_bound(L,
             [&] { hipLaunchKernelGGL((behz_lift_kernel<4>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
             [&] { hipLaunchKernelGGL((behz_lift_kernel<8>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
@@ -1636,11 +1496,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         if ((rc = check_rows(items, ch1))) return rc;
         dim3 grid((unsigned)(items * ch1)), block(256);
         if (gen2) {
-            switch (L) {
-#define X(N) case N: launch_behz2_floor<N>(b, grid, s, ch1, ws + w.d_q, ws + w.d_bsk, (u64*)out); break;
-                BEHZ2_CASES(X)
-#undef X
-            }
+            launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out);
         } else dispatch_bound(S,
             [&] { hipLaunchKernelGGL((behz_floor_kernel<4>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
             [&] { hipLaunchKernelGGL((behz_floor_kernel<8>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
