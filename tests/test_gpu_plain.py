@@ -35,7 +35,8 @@ def test_centralize_and_multiply_plain(O, pkg, dev, n, bits, t):
         assert np.array_equal(pkg.to_host(shared)[i], ctx.multiply_plain_ntt(L, dct_h[i], ptn_h[0]))
 
 
-@pytest.mark.parametrize("n,bits,B,I,J", [(4096, [36, 36, 37], 2, 5, 3), (8192, [60, 40, 40, 60], 1, 40, 2), (32, [40, 40, 40], 3, 2, 2)])
+@pytest.mark.parametrize("n,bits,B,I,J", [(4096, [36, 36, 37], 2, 5, 3), (8192, [60, 40, 40, 60], 1, 40, 2), (32, [40, 40, 40], 3, 2, 2),
+                                        (2048, [60, 60, 61 - 1], 1, 71, 2)])   # 71 terms of 60-bit residues: two lazy-sum folds + a 3-term remainder
 def test_multiply_plain_accumulate_matmul_pattern(O, pkg, dev, n, bits, B, I, J):
     """ret[b][j] = sum_i a[b][i] (.) w[i][j]  (MatmulHelper::matmul, app/matmul.cu:352-370) in ONE launch"""
     q = [int(v) for v in O.coeff_modulus_create(n, bits)]

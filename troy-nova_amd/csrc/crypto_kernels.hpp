@@ -276,6 +276,81 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac_kernel(unsigned chunks, 
     }
 }
 
+// Round 2: the same accumulation with both polynomials of a destination in one thread and the term loop unrolled by four.  The
+// launch is bound by streaming the plaintexts (every weight is used once per destination): one thread now reads a weight word
+// once for the PC polynomials (the first kernel read it once per polynomial, from different workgroups), bypasses the caches for
+// it (the ciphertext words are re-read by every destination of the group and should stay cached), and has the loads of four
+// terms in flight before their multiply-accumulates start.
+template <int PC>
+__global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
+                                                                const u64* tab, unsigned count, unsigned groups, int set_zero) {
+    const unsigned row = blk_row(chunks);
+    const unsigned l = row % nmod;
+    const unsigned g = row / nmod;
+    const DevModulus md = mods[mod_start + l];
+    const u64* const* cts = reinterpret_cast<const u64* const*>(tab);
+    const u64* const* pts = reinterpret_cast<const u64* const*>(tab + count);
+    u64* dst = reinterpret_cast<u64* const*>(tab + 2 * (size_t)count)[g];
+    const u64* starts = tab + 2 * (size_t)count + groups;
+    const unsigned k0 = (unsigned)starts[g], k1 = (unsigned)starts[g + 1];
+    const size_t pstride = (size_t)nmod * n, loff = (size_t)l * n;
+    auto ldw = [](const u64* p) {
+        typedef u64 v2 __attribute__((ext_vector_type(2)));
+        const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+        return u64x2{v.x, v.y};
+    };
+    for (unsigned i = blk_col(chunks) * 2; i < n; i += chunks * blockDim.x * 2) {
+        u64 lo[PC][2], hi[PC][2], r[PC][2];
+#pragma unroll
+        for (int p = 0; p < PC; ++p) { lo[p][0] = lo[p][1] = hi[p][0] = hi[p][1] = 0; r[p][0] = r[p][1] = 0; }
+        auto fold = [&]() {      // 32 products of 61-bit residues stay below 2^128
+#pragma unroll
+            for (int p = 0; p < PC; ++p) {
+                r[p][0] = add_mod(r[p][0], barrett128(lo[p][0], hi[p][0], md.q, md.ratio_lo, md.ratio_hi), md.q);
+                r[p][1] = add_mod(r[p][1], barrett128(lo[p][1], hi[p][1], md.q, md.ratio_lo, md.ratio_hi), md.q);
+                lo[p][0] = lo[p][1] = hi[p][0] = hi[p][1] = 0;
+            }
+        };
+        unsigned k = k0, pending = 0;
+        // the operand pointers of the next four terms are fetched (scalar loads) while this iteration's words are in flight
+        const u64 *pw[4], *pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const unsigned kk = k + u < k1 ? k + u : k1 - 1; pw[u] = pts[kk]; pc[u] = cts[kk]; }
+        for (; k + 4 <= k1; k += 4) {
+            u64x2 w[4], c[4][PC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = ldw(pw[u] + loff + i);
+#pragma unroll
+                for (int p = 0; p < PC; ++p) c[u][p] = ld2(pc[u] + p * pstride + loff + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const unsigned kk = k + 4 + u < k1 ? k + 4 + u : k1 - 1; pw[u] = pts[kk]; pc[u] = cts[kk]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int p = 0; p < PC; ++p) { mac128(lo[p][0], hi[p][0], c[u][p].a, w[u].a); mac128(lo[p][1], hi[p][1], c[u][p].b, w[u].b); }
+            pending += 4;
+            if (pending == 32) { fold(); pending = 0; }
+        }
+        for (; k < k1; ++k) {
+            const u64x2 w = ldw(pts[k] + loff + i);
+#pragma unroll
+            for (int p = 0; p < PC; ++p) {
+                const u64x2 c = ld2(cts[k] + p * pstride + loff + i);
+                mac128(lo[p][0], hi[p][0], c.a, w.a); mac128(lo[p][1], hi[p][1], c.b, w.b);
+            }
+        }
+        fold();   // at most 28 + 3 pending products
+#pragma unroll
+        for (int p = 0; p < PC; ++p) {
+            u64 r0 = r[p][0], r1 = r[p][1];
+            if (!set_zero) { const u64x2 d = ld2(dst + p * pstride + loff + i); r0 = add_mod(r0, d.a, md.q); r1 = add_mod(r1, d.b, md.q); }
+            st2(dst + p * pstride + loff + i, r0, r1);
+        }
+    }
+}
+
 // ---- Galois automorphisms ---------------------------------------------------------------
 // GaloisTool::apply_ps (utils/galois.cu:168-185): coefficient form, X -> X^g: out[i*g mod N] = +/- in[i]
 // GaloisTool::apply_ntt_ps (:24-41 table + gather): NTT form, out[i] = in[table(i)],

@@ -1961,6 +1961,16 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
     HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // `tab` is a host temporary
     const unsigned ch = chunks_pairs(p->n);
+    static int mac_gen = -1;   // TROYN_PLAIN_MAC=v1: first-generation kernel (one polynomial per thread) for A/B runs
+    if (mac_gen < 0) { const char* e = getenv("TROYN_PLAIN_MAC"); mac_gen = (e && std::strcmp(e, "v1") == 0) ? 1 : 2; }
+    if (pcount == 2 && mac_gen == 2) {
+        const size_t rows2 = groups * nmod;
+        if (int rc = check_rows(rows2, ch)) return rc;
+        hipLaunchKernelGGL((plain_mac2_kernel<2>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
+                           ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
+        LAUNCH_CHECK();
+        return TROYN_OK;
+    }
     const size_t rows = groups * pcount * nmod;
     if (int rc = check_rows(rows, ch)) return rc;
     hipLaunchKernelGGL(plain_mac_kernel, dim3((unsigned)(rows * ch)), dim3(POLY_BLOCK), 0, s,
