@@ -120,11 +120,14 @@ static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const 
     if (stage != 1) return;
     const dim3 grid((unsigned)((batch * a.ncomp) << G1)), block(1u << (TB - EB));
     if constexpr (G1 > 0) {
-        // 256-thread workgroups holding three polynomials in registers: three per CU (168 registers, a few spilled words; measured 2-3 % faster
-        // than two per CU without spills, TROYN_TENSOR_WGS=2)
+        // three polynomials are held in registers next to the transform in flight.  Default: 512-thread workgroups x 8 coefficients
+        // (100-111 registers, no spills, two workgroups = 16 waves per CU).  TROYN_TENSOR_WGS=3 / 2: 256 threads x 16 coefficients with
+        // three (168 registers, 11-28 spilled) / two (no spills) workgroups per CU -- measured 1.8 % / 3 % slower at N = 32768 L = 10.
         static int wgs = -1;
-        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 3; }
-        if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);
+        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 8; }
+        if (wgs == 8) {   // 512-thread workgroups x 8 coefficients: 100-111 registers, no spills, two workgroups (16 waves) per CU
+            hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, 3, 2>), grid, dim3(1u << (TB - 3)), 0, s, a, b, d);
+        } else if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);
         else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 2>), grid, block, 0, s, a, b, d);
     } else hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 1>), grid, block, 0, s, a, b, d);
 }
