@@ -174,6 +174,10 @@ def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb, behz_gen):
     got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), pa, pkg.to_device(b, dev), pb))
     for i in range(batch):
         assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i]))
+    da = pkg.to_device(a, dev)                       # one buffer passed twice: the squaring shortcut
+    got = pkg.to_host(behz.multiply(da, pa, da, pa))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], a[i])), i
 
 
 @pytest.mark.parametrize("tensor", ["fused", "split"])
@@ -195,9 +199,14 @@ def test_bfv_multiply_two_pass_sizes(O, pkg, dev, monkeypatch, bits, L, tensor):
     got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
     for i in range(batch):
         assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i])), i
-    # squaring reads the same operand twice
+    # squaring: the same operand twice (two buffers), and one buffer passed twice (Evaluator::square: one lift, two forward transforms)
     got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(a, dev), 2))
     assert np.array_equal(got[0], ctx.bfv_multiply(L, a[0], a[0]))
+    da = pkg.to_device(a, dev)
+    got = pkg.to_host(behz.multiply(da, 2, da, 2))
+    for i in range(batch):
+        assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], a[i])), i
+    assert np.array_equal(pkg.to_host(da), a)
 
 
 def test_error_behaviour(O, pkg, dev):

@@ -913,6 +913,27 @@ __global__ __launch_bounds__(1 << (TB - EB), MINB) void tensor_core_kernel(NttAr
     const typename A::Mod md = A::make(fa.mods[ntt_table_index(fa, 0, j)]);
     // order chosen for register pressure: at most three held polynomials (3 * 2E registers) next to a transform in flight
     elem a0[E], b0[E], a1[E], w[E];
+    if (fa.in == fb.in && fa.in_bstride == fb.in_bstride) {
+        // squaring (Evaluator::square on BFV multiplies a ciphertext with itself, evaluator.cu:147-160): two forward transforms
+        // instead of four; d0 = a0^2, d1 = 2 a0 a1, d2 = a1^2
+        ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fa, nullptr, lds, bid(2, 0), t, a0);
+        __syncthreads();
+        static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; w[R] = A::inv_in(A::prod(a0[R], a0[R], md), md); });
+        ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 0), t, w);
+        __syncthreads();
+        ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fa, nullptr, lds, bid(2, 1), t, a1);
+        __syncthreads();
+        static_for<0, E>([&](auto Rc) {
+            constexpr int R = decltype(Rc)::value;
+            const elem c = A::prod(a0[R], a1[R], md);
+            a0[R] = A::inv_in(A::sum(c, c, md), md);
+            a1[R] = A::inv_in(A::prod(a1[R], a1[R], md), md);
+        });
+        ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 1), t, a0);
+        __syncthreads();
+        ntt_pass_body<A, LOGN, G1, TB, TB, EB, true, true, WHOLE, false, 0, 2>(id, nullptr, lds, bid(3, 2), t, a1);
+        return;
+    }
     ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fa, nullptr, lds, bid(2, 0), t, a0);
     __syncthreads();   // the next transform's first exchange overwrites words other waves read in this one's last round
     ntt_pass_body<A, LOGN, G1, TB, TB, EB, false, WHOLE, true, false, 0, 1>(fb, nullptr, lds, bid(2, 0), t, b0);

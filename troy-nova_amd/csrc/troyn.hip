@@ -1426,7 +1426,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
                                   uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
     if (!b || !a_ || !b_ || !out || !workspace) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] null argument");
     if (pa < 1 || pb < 1 || pa > 16 || pb > 16) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] invalid ciphertext size");
-    const BehzLayout w = behz_layout(b, pa, pb, batch);
+    BehzLayout w = behz_layout(b, pa, pb, batch);
     if (workspace_bytes < w.total * sizeof(u64)) return fail(TROYN_E_WORKSPACE, "[troyn_bfv_multiply] workspace too small");
     if (batch == 0) return TROYN_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1461,8 +1461,11 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         NttArgs ab = contiguous_args(px, dst_bsk, dst_bsk, pcount, S, 0, S, TROYN_IDX_COMPONENTWISE, 0);
         return whole ? TROYN_OK : tensor ? tensor_stage(px, 0, ab, ab, ab, batch, s) : launch_ntt(px, ab, batch, false, s);
     };
+    // squaring (a ciphertext multiplied with itself): one lift, and the staged copies of b are those of a
+    const bool square = a_ == b_ && pa == pb;
+    if (square) { w.b_q = w.a_q; w.b_bsk = w.a_bsk; }
     if ((rc = lift((const u64*)a_, pa, ws + w.a_q, ws + w.a_bsk))) return rc;
-    if ((rc = lift((const u64*)b_, pb, ws + w.b_q, ws + w.b_bsk))) return rc;
+    if (!square && (rc = lift((const u64*)b_, pb, ws + w.b_q, ws + w.b_bsk))) return rc;
     if (tensor) {
         // steps (4)-(5)
         for (int base = 0; base < 2; base++) {
