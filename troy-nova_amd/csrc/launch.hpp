@@ -8,16 +8,35 @@
 
 namespace troyn {
 
-// optimised transforms of one arithmetic class (false: no kernel for this size -> ntt_generic)
-bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, hipStream_t s, u64* scratch);
-bool launch_ntt_u64(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, hipStream_t s, u64* scratch);
+// optimised transforms of one arithmetic class (false: no kernel for this size -> ntt_generic); each class is instantiated in two
+// translation units, N <= 8192 and N >= 16384
+#define TROYN_DECL_NTT_UNIT(SUFFIX)                                                                                                   \
+    bool launch_ntt_##SUFFIX(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, hipStream_t s, u64* scratch);          \
+    bool launch_ks_mac_##SUFFIX(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s);                    \
+    bool launch_tensor_##SUFFIX(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s);
+TROYN_DECL_NTT_UNIT(f64_small) TROYN_DECL_NTT_UNIT(f64_large) TROYN_DECL_NTT_UNIT(u64_small) TROYN_DECL_NTT_UNIT(u64_large)
+#undef TROYN_DECL_NTT_UNIT
 void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t limb_polys, hipStream_t s);
+inline bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
+    return log_n <= 13 ? launch_ntt_f64_small(log_n, a, lp, inverse, s, scratch) : launch_ntt_f64_large(log_n, a, lp, inverse, s, scratch);
+}
+inline bool launch_ntt_u64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
+    return log_n <= 13 ? launch_ntt_u64_small(log_n, a, lp, inverse, s, scratch) : launch_ntt_u64_large(log_n, a, lp, inverse, s, scratch);
+}
 // first-generation fused key-switch inner product (ks_mac_kernel)
-bool launch_ks_mac_f64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s);
-bool launch_ks_mac_u64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s);
+inline bool launch_ks_mac_f64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
+    return log_n <= 13 ? launch_ks_mac_f64_small(log_n, a, kp, blocks, s) : launch_ks_mac_f64_large(log_n, a, kp, blocks, s);
+}
+inline bool launch_ks_mac_u64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
+    return log_n <= 13 ? launch_ks_mac_u64_small(log_n, a, kp, blocks, s) : launch_ks_mac_u64_large(log_n, a, kp, blocks, s);
+}
 // tensor product fused with the transforms (tensor_core_kernel); stage 0 / 2: the strided passes of the two-pass sizes
-bool launch_tensor_f64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s);
-bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s);
+inline bool launch_tensor_f64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
+    return log_n <= 13 ? launch_tensor_f64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_f64_large(log_n, stage, a, b, d, batch, s);
+}
+inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
+    return log_n <= 13 ? launch_tensor_u64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_u64_large(log_n, stage, a, b, d, batch, s);
+}
 // second-generation key-switch inner product (ksmac2_kernel, log_n = 13 / 14 / 15) and its key preparation
 void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s);
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s);

@@ -9,6 +9,13 @@
 #include "ntt_kernels.hpp"
 #include "launch.hpp"
 
+// TROYN_NTT_PART: 1 = the sizes N <= 8192 only, 2 = N >= 16384 only (one translation unit each, so that they compile in parallel)
+#ifndef TROYN_NTT_PART
+#define TROYN_NTT_PART 0
+#endif
+#define TROYN_NTT_SMALL (TROYN_NTT_PART != 2)
+#define TROYN_NTT_LARGE (TROYN_NTT_PART != 1)
+
 namespace troyn {
 
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
@@ -86,14 +93,30 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
     // of 16; measured 5-14 % faster than EB = 4 despite the extra LDS exchange.  N = 16384 needs EB = 4 to fit one
     // workgroup (1024 threads x 16 coefficients).
     switch (log_n) {
+#if TROYN_NTT_SMALL
         case 10: launch_single<A, 10, 4>(a, lp, inverse, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 11: launch_single<A, 11, 4>(a, lp, inverse, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 12: launch_single<A, 12, 3>(a, lp, inverse, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 13: launch_single<A, 13, 3>(a, lp, inverse, s); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s, scratch); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 16: launch_two_pass<A, 16, 12, 4>(a, lp, inverse, s, scratch); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 17: launch_two_pass<A, 17, 12, 4>(a, lp, inverse, s, scratch); return true;
+#endif
         default: return false;
     }
 }
@@ -101,11 +124,21 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
 template <class A>
 static bool launch_ks_mac_t(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
     switch (log_n) {
+#if TROYN_NTT_SMALL
         case 10: hipLaunchKernelGGL((ks_mac_kernel<A, 10, 4>), dim3((unsigned)blocks), dim3(1u << 6), 0, s, a, kp); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 11: hipLaunchKernelGGL((ks_mac_kernel<A, 11, 4>), dim3((unsigned)blocks), dim3(1u << 7), 0, s, a, kp); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 12: hipLaunchKernelGGL((ks_mac_kernel<A, 12, 4>), dim3((unsigned)blocks), dim3(1u << 8), 0, s, a, kp); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 13: hipLaunchKernelGGL((ks_mac_kernel<A, 13, 4>), dim3((unsigned)blocks), dim3(1u << 9), 0, s, a, kp); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 14: hipLaunchKernelGGL((ks_mac_kernel<A, 14, 4>), dim3((unsigned)blocks), dim3(1u << 10), 0, s, a, kp); return true;
+#endif
         default: return false;
     }
 }
@@ -135,12 +168,24 @@ static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const 
 template <class A>
 static bool launch_tensor_class(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
     switch (log_n) {
+#if TROYN_NTT_SMALL
         case 10: tensor_stage_t<A, 10, 10, 4>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 11: tensor_stage_t<A, 11, 11, 4>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 12: tensor_stage_t<A, 12, 12, 3>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_SMALL
         case 13: tensor_stage_t<A, 13, 13, 3>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 15: tensor_stage_t<A, 15, 12, 4>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 16: tensor_stage_t<A, 16, 12, 4>(stage, a, b, d, batch, s); return true;
+#endif
         default: return false;
     }
 }
