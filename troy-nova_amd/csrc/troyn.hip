@@ -157,6 +157,16 @@ struct troyn_plan {
     double* d_fwd_r2 = nullptr;           // [K][N], lane-interleaved (ksm_perm)
 };
 
+// One host thread may drive several devices (the reference calls utils::set_device before every launch, fgk/ntt_grouped.cu:286):
+// every entry point that takes a handle makes that handle's device current first.
+static inline void select_device_index(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) (void)hipSetDevice(device);
+}
+static inline void select_device(const troyn_plan* p) { if (p) select_device_index(p->device); }
+template <typename H> static inline void select_device(const H* h) { if (h && h->plan) select_device_index(h->plan->device); }
+
+
 static DevModulus make_dev_modulus(u64 q, unsigned log_n, bool with_inv_n) {
     DevModulus m;
     std::memset(&m, 0, sizeof(m));
@@ -299,12 +309,14 @@ extern "C" uint32_t troyn_plan_log_n(const troyn_plan* plan) { return plan ? pla
 extern "C" uint32_t troyn_plan_n_moduli(const troyn_plan* plan) { return plan ? plan->K : 0; }
 
 extern "C" int troyn_plan_get_root(const troyn_plan* plan, uint32_t mi, uint64_t* root) {
+    select_device(plan);
     if (!plan || !root || mi >= plan->K) return fail(TROYN_E_INVALID, "[troyn_plan_get_root] bad argument");
     *root = plan->tables[mi].root;
     return TROYN_OK;
 }
 
 extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, int inverse, uint64_t* out) {
+    select_device(plan);
     if (!plan || !out || mi >= plan->K) return fail(TROYN_E_INVALID, "[troyn_plan_get_root_powers] bad argument");
     const auto& v = inverse ? plan->tables[mi].inv : plan->tables[mi].fwd;
     for (size_t i = 0; i < v.size(); i++) { out[2 * i] = v[i].operand; out[2 * i + 1] = v[i].quotient; }
@@ -431,6 +443,7 @@ extern "C" int troyn_ntt(const troyn_plan* plan, int inverse, const uint64_t* in
                          size_t batch, size_t pcount, size_t ncomp,
                          uint32_t table_start, uint32_t table_count, int indexer_mode, uint32_t decomp_size,
                          troyn_stream_t stream) {
+    select_device(plan);
     if (!plan || !in || !out) return fail(TROYN_E_INVALID, "[troyn_ntt] null argument");
     if (table_count == 0 || table_start + table_count > plan->K)
         return fail(TROYN_E_INVALID, "[troyn_ntt] table slice out of range");
@@ -471,18 +484,23 @@ static int launch_elementwise(const troyn_plan* p, uint32_t mod_start, uint32_t 
 }
 
 extern "C" int troyn_add(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
     return launch_elementwise<EW_ADD>(p, ms, nm, a, b, 0, out, count, s);
 }
 extern "C" int troyn_sub(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
     return launch_elementwise<EW_SUB>(p, ms, nm, a, b, 0, out, count, s);
 }
 extern "C" int troyn_negate(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
     return launch_elementwise<EW_NEG>(p, ms, nm, a, nullptr, 0, out, count, s);
 }
 extern "C" int troyn_multiply_scalar(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
     return launch_elementwise<EW_MULS>(p, ms, nm, a, nullptr, scalar, out, count, s);
 }
 extern "C" int troyn_dyadic_product(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
     return launch_elementwise<EW_MUL>(p, ms, nm, a, b, 0, out, count, s);
 }
 
@@ -515,6 +533,7 @@ static int launch_convolute(const DevModulus* mods, unsigned n, uint32_t mod_sta
 extern "C" int troyn_dyadic_convolute(const troyn_plan* p, uint32_t mod_start, uint32_t nmod,
                                       const uint64_t* a, size_t pa, const uint64_t* b, size_t pb, uint64_t* out,
                                       size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !a || !b || !out) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] modulus slice out of range");
     if (pa < 1 || pb < 1 || pa > 16 || pb > 16) return fail(TROYN_E_INVALID, "[fgk::dyadic_convolute] Result size mismatch");
@@ -523,6 +542,7 @@ extern "C" int troyn_dyadic_convolute(const troyn_plan* p, uint32_t mod_start, u
 
 extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint32_t nmod,
                                    const uint64_t* a, uint64_t* out, size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !a || !out) return fail(TROYN_E_INVALID, "[fgk::dyadic_square] null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[fgk::dyadic_square] modulus slice out of range");
     const size_t rows = batch * nmod;
@@ -794,6 +814,7 @@ extern "C" int troyn_switch_key(const troyn_plan* plan, uint32_t L, int is_ckks,
                                 const uint64_t* target, const uint64_t* const* keys, int assign_method,
                                 uint64_t* destination, void* workspace, size_t workspace_bytes,
                                 size_t batch, troyn_stream_t stream) {
+    select_device(plan);
     if (!plan) return fail(TROYN_E_INVALID, "[troyn_switch_key] null plan");
     return switch_key_impl(plan, L, is_ckks, is_ntt_form, (const u64*)target, (size_t)L * plan->n, keys, assign_method,
                            (u64*)destination, nullptr, 0, workspace, workspace_bytes, batch, (hipStream_t)stream);
@@ -802,6 +823,7 @@ extern "C" int troyn_switch_key(const troyn_plan* plan, uint32_t L, int is_ckks,
 extern "C" int troyn_relinearize(const troyn_plan* plan, uint32_t L, int is_ckks, int is_ntt_form,
                                  const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2,
                                  void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    select_device(plan);
     if (!plan || !ct3) return fail(TROYN_E_INVALID, "[Evaluator::relinearize_inplace_internal] null argument");
     const size_t pc = (size_t)L * plan->n;
     // relinearize_internal (evaluator_keyswitching.cu:119-144): switch_key(target = c2, Overwrite) then += (c0, c1)
@@ -814,6 +836,7 @@ extern "C" int troyn_relinearize(const troyn_plan* plan, uint32_t L, int is_ckks
 // ---------------------------------------------------------------------------------------
 extern "C" int troyn_divide_and_round_q_last(const troyn_plan* p, uint32_t L, const uint64_t* in, size_t pcount,
                                              uint64_t* out, size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !in || !out) return fail(TROYN_E_INVALID, "[RNSTool::divide_and_round_q_last] null argument");
     if (L < 2 || L > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
     const size_t items = batch * pcount, rows = items * (L - 1);
@@ -834,6 +857,7 @@ extern "C" size_t troyn_divide_and_round_q_last_ntt_workspace_bytes(const troyn_
 extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L, const uint64_t* in, size_t pcount,
                                                  uint64_t* out, void* workspace, size_t workspace_bytes,
                                                  size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !in || !out || !workspace) return fail(TROYN_E_INVALID, "[RNSTool::divide_and_round_q_last_ntt] null argument");
     if (L < 2 || L > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
     if (workspace_bytes < troyn_divide_and_round_q_last_ntt_workspace_bytes(p, L, pcount, batch))
@@ -915,6 +939,7 @@ extern "C" size_t troyn_ckks_multiply_relinearize_rescale_workspace_bytes(const 
 extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint32_t L, const uint64_t* a_, const uint64_t* b_,
                                                        const uint64_t* const* keys, uint64_t* out_, void* workspace, size_t workspace_bytes,
                                                        size_t batch, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[troyn_ckks_multiply_relinearize_rescale]";
     if (!p || !a_ || !b_ || !keys || !out_ || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     const unsigned K = p->K, n = p->n;
@@ -1006,6 +1031,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
 
 extern "C" int troyn_mod_switch_drop(const troyn_plan* p, uint32_t L_in, uint32_t L_out, const uint64_t* in, size_t pcount,
                                      uint64_t* out, size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !in || !out) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_drop_to_internal] null argument");
     if (L_out < 1 || L_out > L_in || L_in > p->K) return fail(TROYN_E_INVALID, "[Evaluator::mod_switch_drop_to_next_internal] Next context data is not set.");
     const size_t items = batch * pcount, rows = items * L_out;
@@ -1073,6 +1099,7 @@ extern "C" size_t troyn_bgv_mod_switch_workspace_bytes(const troyn_bgv* b, size_
 
 extern "C" int troyn_bgv_mod_t_and_divide_q_last_ntt(const troyn_bgv* b, const uint64_t* in, size_t pcount, uint64_t* out, void* workspace, size_t workspace_bytes,
                                                      size_t batch, troyn_stream_t stream) {
+    select_device(b);
     const char* P = "[RNSTool::mod_t_and_divide_q_last_ntt]";
     if (!b || !in || !out || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     const troyn_plan* p = b->plan;
@@ -1109,6 +1136,7 @@ extern "C" int troyn_bgv_mod_t_and_divide_q_last_ntt(const troyn_bgv* b, const u
 }
 
 extern "C" int troyn_bgv_decrypt_mod_t(const troyn_bgv* b, const uint64_t* phase, uint64_t correction_factor, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    select_device(b);
     const char* P = "[scaling_variant::decentralize]";
     if (!b || !phase || !dest) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (batch == 0) return TROYN_OK;
@@ -1126,6 +1154,7 @@ extern "C" int troyn_bgv_decrypt_mod_t(const troyn_bgv* b, const uint64_t* phase
 }
 
 extern "C" int troyn_bgv_multiply_scalar_mod_t(const troyn_bgv* b, const uint64_t* in, uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t stream) {
+    select_device(b);
     if (!b || !in || !out) return fail(TROYN_E_INVALID, "[utils::multiply_scalar] null argument");
     if (count == 0) return TROYN_OK;
     hipLaunchKernelGGL(scalar_mod_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->t_mod, (u64)(scalar % b->t), (const u64*)in, (u64*)out, count);
@@ -1144,6 +1173,7 @@ static int bgv_tail_from(const troyn_bgv* key_level, BgvTail& tail) {
 
 extern "C" int troyn_bgv_switch_key(const troyn_bgv* key_level, uint32_t L, const uint64_t* target, const uint64_t* const* keys, int assign_method,
                                     uint64_t* destination, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    select_device(key_level);
     BgvTail tail;
     if (int rc = bgv_tail_from(key_level, tail)) return rc;
     const troyn_plan* plan = key_level->plan;
@@ -1153,6 +1183,7 @@ extern "C" int troyn_bgv_switch_key(const troyn_bgv* key_level, uint32_t L, cons
 
 extern "C" int troyn_bgv_relinearize(const troyn_bgv* key_level, uint32_t L, const uint64_t* ct3, const uint64_t* const* keys, uint64_t* out2, void* workspace,
                                      size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    select_device(key_level);
     BgvTail tail;
     if (int rc = bgv_tail_from(key_level, tail)) return rc;
     if (!ct3) return fail(TROYN_E_INVALID, "[Evaluator::relinearize_inplace_internal] null argument");
@@ -1388,6 +1419,7 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
 
 extern "C" uint32_t troyn_behz_base_Bsk_size(const troyn_behz* b) { return b ? b->Bsk : 0; }
 extern "C" int troyn_behz_get_base_Bsk(const troyn_behz* b, uint64_t* out) {
+    select_device(b);
     if (!b || !out) return fail(TROYN_E_INVALID, "[troyn_behz_get_base_Bsk] null argument");
     for (size_t i = 0; i < b->bsk_values.size(); i++) out[i] = b->bsk_values[i];
     return TROYN_OK;
@@ -1424,6 +1456,7 @@ static bool behz2_enabled(const troyn_behz* b) {
 
 extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_t pa, const uint64_t* b_, size_t pb,
                                   uint64_t* out, void* workspace, size_t workspace_bytes, size_t batch, troyn_stream_t stream) {
+    select_device(b);
     if (!b || !a_ || !b_ || !out || !workspace) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] null argument");
     if (pa < 1 || pb < 1 || pa > 16 || pb > 16) return fail(TROYN_E_INVALID, "[Evaluator::bfv_multiply_inplace] invalid ciphertext size");
     BehzLayout w = behz_layout(b, pa, pb, batch);
@@ -1537,22 +1570,26 @@ static int launch_sampler(K kernel, const char* who, const troyn_plan* p, uint32
 
 extern "C" int troyn_sample_ternary(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
                                     uint64_t* blocks_used, troyn_stream_t stream) {
+    select_device(p);
     return launch_sampler(sample_ternary_kernel, "[RandomGenerator::sample_poly_ternary]", p, nmod, seed, counter, out,
                           p ? ((size_t)p->n + 15) / 16 : 0, blocks_used, stream);
 }
 extern "C" int troyn_sample_centered_binomial(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
                                               uint64_t* blocks_used, troyn_stream_t stream) {
+    select_device(p);
     return launch_sampler(sample_cbd_kernel, "[RandomGenerator::sample_poly_centered_binomial]", p, nmod, seed, counter, out,
                           p ? ((size_t)p->n + 1) / 2 : 0, blocks_used, stream);
 }
 extern "C" int troyn_sample_uniform(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
                                     uint64_t* blocks_used, troyn_stream_t stream) {
+    select_device(p);
     return launch_sampler(sample_uniform_kernel, "[RandomGenerator::sample_poly_uniform]", p, nmod, seed, counter, out,
                           p ? ((size_t)p->n * nmod + 1) / 2 : 0, blocks_used, stream);
 }
 
 extern "C" int troyn_sample_centered_binomial_strided(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t counter_stride,
                                                       uint64_t* out, size_t count, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[RandomGenerator::sample_poly_centered_binomial]";
     if (!p || !seed || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
@@ -1567,6 +1604,7 @@ extern "C" int troyn_sample_centered_binomial_strided(const troyn_plan* p, uint3
 }
 
 extern "C" int troyn_sample_uniform_multi(const troyn_plan* p, uint32_t nmod, const uint64_t* seeds, uint64_t* out, size_t count, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[RandomGenerator::sample_poly_uniform]";
     if (!p || !seeds || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
@@ -1587,6 +1625,7 @@ extern "C" int troyn_sample_uniform_multi(const troyn_plan* p, uint32_t nmod, co
 extern "C" int troyn_bfv_scale_up(const troyn_behz* b, const uint64_t* plain, size_t plain_coeff_count, size_t plain_bstride,
                                   const uint64_t* from, size_t from_bstride, uint64_t* dest, size_t dest_bstride,
                                   int subtract, size_t batch, troyn_stream_t stream) {
+    select_device(b);
     if (!b || !plain || !dest) return fail(TROYN_E_INVALID, "[scaling_variant::scale_up] null argument");
     const unsigned n = b->plan->n;
     if (plain_coeff_count > n) return fail(TROYN_E_INVALID, "[scaling_variant::scale_up] destination_coeff_count should no less than plain_coeff_count.");
@@ -1607,6 +1646,7 @@ extern "C" int troyn_bfv_scale_up(const troyn_behz* b, const uint64_t* plain, si
 }
 
 extern "C" int troyn_bfv_decrypt_scale_and_round(const troyn_behz* b, const uint64_t* phase, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    select_device(b);
     if (!b || !phase || !dest) return fail(TROYN_E_INVALID, "[RNSTool::decrypt_scale_and_round] null argument");
     if (!b->decrypt_ready) return fail(TROYN_E_MODULUS, "[RNSTool::RNSTool] Unable to invert gamma mod t.");
     if (batch == 0) return TROYN_OK;
@@ -1630,6 +1670,7 @@ extern "C" uint64_t troyn_behz_gamma(const troyn_behz* b) { return b ? b->gamma 
 // ---------------------------------------------------------------------------------------
 extern "C" int troyn_plain_centralize(const troyn_plan* p, uint32_t L, uint64_t t, const uint64_t* plain, size_t plain_coeff_count,
                                       size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !plain || !dest) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] null argument");
     if (L < 1 || L > p->K) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] Destination has incorrect size.");
     if (plain_coeff_count > p->n) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] destination_coeff_count should no less than plain_coeff_count.");
@@ -1645,6 +1686,7 @@ extern "C" int troyn_plain_centralize(const troyn_plan* p, uint32_t L, uint64_t 
 
 extern "C" int troyn_dyadic_broadcast_product(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
                                               const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !ct || !pt || !out) return fail(TROYN_E_INVALID, "[dyadic_product_ps] null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[dyadic_product_ps] modulus slice out of range");
     if (batch == 0 || pcount == 0) return TROYN_OK;
@@ -1659,6 +1701,7 @@ extern "C" int troyn_dyadic_broadcast_product(const troyn_plan* p, uint32_t mod_
 
 extern "C" int troyn_apply_galois(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, int is_ntt_form, uint64_t galois_element,
                                   const uint64_t* in, uint64_t* out, size_t count, troyn_stream_t stream) {
+    select_device(p);
     if (!p || !in || !out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] null argument");
     if (in == out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] the permutation cannot run in place");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[GaloisTool::apply] modulus slice out of range");
@@ -1676,6 +1719,7 @@ extern "C" int troyn_apply_galois(const troyn_plan* p, uint32_t mod_start, uint3
 
 extern "C" int troyn_apply_galois_plain(const troyn_plan* p, uint64_t modulus, uint64_t galois_element, const uint64_t* in, uint64_t* out, size_t count,
                                         troyn_stream_t stream) {
+    select_device(p);
     if (!p || !in || !out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] null argument");
     if (in == out) return fail(TROYN_E_INVALID, "[GaloisTool::apply] the permutation cannot run in place");
     if (modulus < 2) return fail(TROYN_E_INVALID, "[GaloisTool::apply] modulus is invalid");
@@ -1691,6 +1735,7 @@ extern "C" int troyn_apply_galois_plain(const troyn_plan* p, uint64_t modulus, u
 
 extern "C" int troyn_negacyclic_shift(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, size_t shift,
                                       size_t count, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[negacyclic_shift_ps]";
     if (!p || !in || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (in == out) return fail(TROYN_E_INVALID, std::string(P) + " the shift cannot run in place");
@@ -1708,6 +1753,7 @@ extern "C" int troyn_negacyclic_shift(const troyn_plan* p, uint32_t mod_start, u
 
 extern "C" int troyn_multiply_inv_degree(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* in, uint64_t* out, uint64_t scalar,
                                          size_t count, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[ntt_multiply_inv_degree]";
     if (!p || !in || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
@@ -1725,6 +1771,7 @@ extern "C" size_t troyn_pack_prepare_workspace_bytes(size_t slots) { return (slo
 
 extern "C" int troyn_pack_prepare(const troyn_plan* p, uint32_t L, size_t pcount, const uint64_t* const* src, size_t slots, uint64_t mul, size_t shift,
                                   uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[Evaluator::pack_rlwe_ciphertexts_new]";
     if (!p || !src || !out || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
@@ -1745,6 +1792,7 @@ extern "C" int troyn_pack_prepare(const troyn_plan* p, uint32_t L, size_t pcount
 
 extern "C" int troyn_pack_layer(const troyn_plan* p, uint32_t L, uint64_t galois_element, size_t shift, const uint64_t* in, uint64_t* out,
                                 uint64_t* target, size_t pairs, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[Evaluator::pack_rlwe_ciphertexts_new]";
     if (!p || !in || !out || !target) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
@@ -1769,6 +1817,7 @@ extern "C" size_t troyn_extract_lwe_workspace_bytes(size_t count) { return (coun
 
 extern "C" int troyn_extract_lwe(const troyn_plan* p, uint32_t L, const uint64_t* const* ct, const size_t* terms, uint64_t* c0, uint64_t* c1, size_t count,
                                  void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[Evaluator::extract_lwe_new]";
     if (!p || !ct || !terms || !c0 || !c1 || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
@@ -1901,10 +1950,13 @@ static int ring2k_encode(const troyn_ring2k* h, bool scale, const void* src, siz
     return TROYN_OK;
 }
 
-extern "C" int troyn_ring2k_scale_up(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) { return ring2k_encode(h, true, src, count, out, stream); }
-extern "C" int troyn_ring2k_centralize(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) { return ring2k_encode(h, false, src, count, out, stream); }
+extern "C" int troyn_ring2k_scale_up(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) {
+    select_device(h); return ring2k_encode(h, true, src, count, out, stream); }
+extern "C" int troyn_ring2k_centralize(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream) {
+    select_device(h); return ring2k_encode(h, false, src, count, out, stream); }
 
 extern "C" int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in, void* dst, troyn_stream_t stream) {
+    select_device(h);
     if (!h || !in || !dst) return fail(TROYN_E_INVALID, "[PolynomialEncoderRNSHelper::scale_down] null argument");
     hipLaunchKernelGGL(ring2k_scale_down_kernel, dim3((h->dev.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev, (const u64*)in, dst);
     LAUNCH_CHECK();
@@ -1935,6 +1987,7 @@ extern "C" size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count) 
 extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, size_t pcount,
                                                const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,
                                                int set_zero, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    select_device(p);
     const char* P = "[Evaluator::multiply_plain_ntt_batched]";
     if (!p || !ct || !pt || !dst || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
