@@ -160,6 +160,8 @@ def test_mod_switch_drop(O, pkg, dev):
     (1024, [36] * 17, 16, 12289, 2, 2),           # largest base the per-size kernels are instantiated for
     (1024, [30] * 18, 17, 12289, 2, 2),           # beyond it: first-generation kernels
     (4096, [49, 50, 51, 40], 3, 65537, 3, 2),     # one modulus above 2^50: integer class
+    (2048, [40, 40, 40], 2, 12289, 2, 2),         # whole-limb tensor kernel at N = 2048 (16 coefficients per thread), FP64 class
+    (65536, [50, 50, 50], 2, 786433, 2, 2),       # N = 65536: two-pass transforms with 16 strided points
 ])
 def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb, behz_gen):
     ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
