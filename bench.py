@@ -319,9 +319,30 @@ def extra_configs(torch, pkg, device):
     t = timed(torch, pipe, 10)
     alg = 168.0 * n * L * Bn                                # 4 NTT (16 B/coeff) + dyadic (56) + 3 INTT (16), per limb coefficient
     tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=False, is_ntt_form=False), 10)
-    res["N8192_L2"] = {"what": "BFV N=8192, 3x40-bit (L=2): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3); relinearize (coefficient form)", "batch": Bn,
+    behz = pkg.Behz(plan, L, 1032193)
+    tm = timed(torch, lambda: behz.multiply(x, 2, y, 2, out=prod), 10)
+    res["N8192_L2"] = {"what": "BFV N=8192, 3x40-bit (L=2): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (coefficient form); BEHZ multiply", "batch": Bn,
                        "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
-                       "relinearize_ops_per_s": round(Bn / tr, 1)}
+                       "relinearize_ops_per_s": round(Bn / tr, 1), "multiply_ops_per_s": round(Bn / tm, 1)}
+    del x, y, xn, yn, prod, keys, out2, plan, behz
+    torch.cuda.empty_cache()
+    # N = 16384, 6 x 50-bit (L = 5): the headline's ring size, the same two pipelines as separate calls
+    n, Bn = 16384, 512
+    q = pkg.capi.coeff_modulus_create(n, [50] * 6)
+    L = 5
+    plan = pkg.Plan(device, 14, q)
+    x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
+    xn, yn = torch.empty_like(x), torch.empty_like(y)
+    prod = torch.empty((Bn, 3, L, n), dtype=torch.int64, device=device)
+    keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
+    out2 = torch.empty((Bn, 2, L, n), dtype=torch.int64, device=device)
+    t = timed(torch, lambda: (plan.ntt(x, 2, L, out=xn), plan.ntt(y, 2, L, out=yn), plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod),
+                              plan.ntt(prod, 3, L, inverse=True)), 10)
+    alg = 168.0 * n * L * Bn
+    tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=True, is_ntt_form=True), 10)
+    res["N16384_L5"] = {"what": "N=16384, 6x50-bit (L=5): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (NTT form)", "batch": Bn,
+                        "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "relinearize_ops_per_s": round(Bn / tr, 1)}
     del x, y, xn, yn, prod, keys, out2, plan
     torch.cuda.empty_cache()
     # N = 32768, 11 x 50-bit (L = 10): BASELINE configs[3]
