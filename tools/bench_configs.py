@@ -93,7 +93,8 @@ def main():
     if a.only in ("", "bfv_mul"):
         # BEHZ multiply of independent ciphertext pairs at the whole-limb sizes (cfg2's parameters, the matmul app's chain, a 50-bit chain)
         for name, n, bits, L, B in (("N8192_3x40", 8192, [40] * 3, 2, 1024), ("N8192_60_40_40_60", 8192, [60, 40, 40, 60], 3, 512),
-                                    ("N4096_3x36", 4096, [36] * 3, 2, 2048), ("N8192_5x50", 8192, [50] * 5, 4, 512)):
+                                    ("N4096_3x36", 4096, [36] * 3, 2, 2048), ("N8192_5x50", 8192, [50] * 5, 4, 512),
+                                    ("N16384_6x50", 16384, [50] * 6, 5, 256)):
             q = pkg.capi.coeff_modulus_create(n, bits)
             plan = pkg.Plan(dev, n.bit_length() - 1, q)
             behz = pkg.Behz(plan, L, 1032193)

@@ -181,6 +181,9 @@ static bool launch_tensor_class(unsigned log_n, int stage, const NttArgs& a, con
         case 13: tensor_stage_t<A, 13, 13, 3>(stage, a, b, d, batch, s); return true;
 #endif
 #if TROYN_NTT_LARGE
+        case 14: tensor_stage_t<A, 14, 14, 4>(stage, a, b, d, batch, s); return true;
+#endif
+#if TROYN_NTT_LARGE
         case 15: tensor_stage_t<A, 15, 12, 4>(stage, a, b, d, batch, s); return true;
 #endif
 #if TROYN_NTT_LARGE
