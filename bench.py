@@ -209,6 +209,15 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         roofline["ntt_probe"] = {"kernel": "ntt_pass_kernel<ArithF64,14,fwd>, %d limb-polynomials" % (RB * (L + 1) * L), "launch_ms": round(t_ntt * 1e3, 4),
                                  "achieved": round(nb / t_ntt / 1e9, 1), "frac": round(nb / t_ntt / 1e9 / HBM_PEAK_GBS, 4)}
         del digits
+        # what the memory system delivers on this box (not part of the timed region): a 1 GiB device-to-device copy and a read-only pass
+        probe = torch.empty(1 << 27, dtype=torch.int64, device=device)
+        sink = torch.empty_like(probe)
+        t_copy = timed(torch, lambda: sink.copy_(probe), 5)
+        t_read = timed(torch, lambda: probe.sum(), 5)
+        roofline["memory_system"] = {"what": "measured on this box: 1 GiB copy (read + write) and read-only reduction; `frac` above stays against the 8 TB/s peak",
+                                     "copy_GBps": round(2.0 * probe.numel() * 8 / t_copy / 1e9, 1), "read_GBps": round(probe.numel() * 8 / t_read / 1e9, 1)}
+        del probe, sink
+        torch.cuda.empty_cache()
 
     result = {
         "metric": "homomorphic mul+relinearize ops/sec (CKKS mul+relin+rescale), N=16384",
