@@ -248,6 +248,18 @@ __device__ __forceinline__ void nt_store2(u64* p, u64 a, u64 b) {
 }
 #endif
 
+// store / load of one word at (wave-uniform base) + (32-bit lane byte offset): the scalar-base addressing form, so that E strided
+// words of a thread cost one offset register instead of E 64-bit addresses
+typedef char __attribute__((address_space(1)))* nt_gcp;
+__device__ __forceinline__ void nt_store_at(u64* ubase, unsigned byte_off, u64 v) {
+    typedef u64 __attribute__((address_space(1)))* gp;
+    __builtin_nontemporal_store(v, (gp)((nt_gcp)(unsigned long long)ubase + byte_off));
+}
+__device__ __forceinline__ u64 ld_at(const u64* ubase, unsigned byte_off) {
+    typedef const u64 __attribute__((address_space(1)))* gp;
+    return *(gp)((nt_gcp)(unsigned long long)ubase + byte_off);
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E_, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -479,9 +491,13 @@ __host__ __device__ constexpr bool ROUNDS_OK(int G, int EB) { return (G + EB - 1
 
 // REGIO (tensor_core_kernel): 1 = a forward last pass leaves its E consecutive outputs per thread in xio (A::keep form) instead of
 // storing them, 2 = an inverse first pass takes its E consecutive inputs per thread from xio (A::inv_in form) instead of loading them.
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0>
+// HALF: the LDS tile holds 32-bit words (half the bytes): every exchange moves the low halves, then the high halves of its E words
+// (three barriers instead of one).  A whole-limb N = 16384 tile then takes 66 KB instead of 132 KB and TWO 1024-thread workgroups
+// share a CU, so one can load / store while the other computes -- what N = 8192 gets for free.
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0, bool HALF = false>
 __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t, typename A::elem* xio = nullptr) {
     constexpr int C = TB - G;
+    static_assert(!HALF || (!KSMAC && REGIO == 0), "half-word LDS tiles: plain and fused transform kernels only");
     static_assert(REGIO == 0 || (!KSMAC && IOM == 0 && C == 0 && (G + EB - 1) / EB > 1 && (REGIO == 1 ? (!INV && LAST) : (INV && FIRST))), "register hand-over: last forward / first inverse pass on whole tiles");
     constexpr int E = 1 << EB;
     constexpr unsigned N = 1u << LOGN;
@@ -544,6 +560,9 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     auto gindex = [&](unsigned loc) -> unsigned {
         return (top << (LOGN - LO)) | ((loc >> C) << (LOGN - LO - G)) | (lb << C) | (loc & ((1u << C) - 1));
     };
+    // gindex(x | y) = gindex(x) + gpart(y) for disjoint bit sets: the part of the index that a register number R contributes
+    // is a compile-time constant
+    auto gpart = [](unsigned loc) constexpr -> unsigned { return ((loc >> C) << (LOGN - LO - G)) | (loc & ((1u << C) - 1)); };
     constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
     constexpr int SM = (LAST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_STORE_KS_FINISH : IOM == 2 ? (int)NTT_STORE_RESCALE : (int)NTT_STORE_PLAIN) : (int)NTT_STORE_PLAIN;
     constexpr bool FUSED = IOM >= 3;     // NttFused: kernels of the multiply -> relinearize -> rescale chain (loaders act in the first pass
@@ -601,6 +620,33 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             return;
         }
     }
+    // Exchange of E words through the tile: word i of this thread goes to wa(i), its new word i comes from ra(i); `sync` is the
+    // barrier that separates the writes from the reads (workgroup, or wave when the exchange stays inside the wave's own slice).
+    // No barrier is needed in front: a thread writes exactly the words it read itself in its previous exchange.
+    unsigned* const lds32 = reinterpret_cast<unsigned*>(lds);
+    // `after_write` runs between the (first) write phase and its barrier: loads that should be in flight during the exchange
+    auto xchg = [&](auto wa, auto ra, u64 (&w)[E], auto sync, auto after_write) {
+        if constexpr (!HALF) {
+            static_for<0, E>([&](auto ic) { lds[wa(ic)] = w[decltype(ic)::value]; });
+            after_write();
+            sync();
+            static_for<0, E>([&](auto ic) { w[decltype(ic)::value] = lds[ra(ic)]; });
+        } else {
+            // the incoming low halves take the place of the outgoing ones (dead once written): no extra registers
+            static_for<0, E>([&](auto ic) { lds32[wa(ic)] = (unsigned)w[decltype(ic)::value]; });
+            after_write();
+            sync();
+            static_for<0, E>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = (w[i] & 0xffffffff00000000ull) | lds32[ra(ic)]; });
+            sync();
+            static_for<0, E>([&](auto ic) { lds32[wa(ic)] = (unsigned)(w[decltype(ic)::value] >> 32); });
+            sync();
+            static_for<0, E>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = ((u64)lds32[ra(ic)] << 32) | (unsigned)w[i]; });
+        }
+    };
+    auto nothing = [] {};
+    auto wave_sync = [] { __builtin_amdgcn_wave_barrier(); };
+    auto wg_sync = [] { __syncthreads(); };
+    (void)wg_sync;
     static_for<0, ROUNDS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         // transform bits handled this round, and the register window [S, S+EB)
@@ -634,14 +680,15 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
             const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
             const unsigned gbase = gindex(wbase);
+            u64 wv[E];
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
                 if constexpr (F_MULPAIR) {
                     // c2 = a1 (.) b1 formed while loading (the tensor product is never written to HBM)
                     const ulonglong2 va = nt_load2(io.a1 + mul_off + gbase + idx), vb = nt_load2(io.b1 + mul_off + gbase + idx);
-                    lds[pidx + lds_off(m * 128u)] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
-                    lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
+                    wv[2 * m] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
+                    wv[2 * m + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
                 } else if constexpr (F_LAST_LD) {
                     // P qk^-1 + c_k at the dropped limb
                     const ulonglong2 vp = nt_load2(gin + gbase + idx);
@@ -650,18 +697,19 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
                     const elem e0 = A::scale_by(f64_from_u64(vp.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md);
                     const elem e1 = A::scale_by(f64_from_u64(vp.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md);
-                    lds[pidx + lds_off(m * 128u)] = A::to_lds(e0, md);
-                    lds[pidx + lds_off(m * 128u) + 1] = A::to_lds(e1, md);
+                    wv[2 * m] = A::to_lds(e0, md);
+                    wv[2 * m + 1] = A::to_lds(e1, md);
                 } else {
-                const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
-                lds[pidx + lds_off(m * 128u)] = ntt_io_load<LM>(io, v.x);
-                lds[pidx + lds_off(m * 128u) + 1] = ntt_io_load<LM>(io, v.y);
+                    const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
+                    wv[2 * m] = ntt_io_load<LM>(io, v.x);
+                    wv[2 * m + 1] = ntt_io_load<LM>(io, v.y);
                 }
             });
-            __builtin_amdgcn_wave_barrier();
+            xchg([&](auto ic) { constexpr int i = decltype(ic)::value; return pidx + lds_off((i / 2) * 128u) + (i & 1); },
+                 [&](auto ic) { return pown + (unsigned)decltype(ic)::value; }, wv, wave_sync, nothing);
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                const u64 raw = lds[pown + R];
+                const u64 raw = wv[R];
                 if constexpr (F_MULPAIR || F_LAST_LD) x[R] = A::from_lds(raw);     // re-centred when it was parked
                 else if constexpr (FIRST) x[R] = A::load_first(raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
@@ -686,12 +734,15 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 else x[R] = A::load_mid(raw, md);
             });
         } else {
-#ifndef TROYN_ABLATE_NO_LDS
-            static_for<0, E>([&](auto Rc) {
-                constexpr int R = decltype(Rc)::value;
-                x[R] = A::from_lds(lds[pbase + lds_off((unsigned)R << S)]);
-            });
-#endif
+            // exchange with the previous round: the words leave from that round's register window (S_PREV) and arrive in this one's
+            const unsigned pprev = lds_phys((t & ((1u << S_PREV) - 1)) | ((t >> S_PREV) << (S_PREV + EB)));
+            u64 wv[E];
+            static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; wv[R] = A::to_lds(x[R], md); });
+            auto wa = [&](auto ic) { return pprev + lds_off((unsigned)decltype(ic)::value << S_PREV); };
+            auto ra = [&](auto ic) { return pbase + lds_off((unsigned)decltype(ic)::value << S); };
+            // RAW: readers are the writer's own wave (LDS executes a wave's accesses in order) or other waves
+            if constexpr (PRIVATE_IN) xchg(wa, ra, wv, wave_sync, nothing); else xchg(wa, ra, wv, wg_sync, nothing);
+            static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; x[R] = A::from_lds(wv[R]); });
         }
 
         constexpr int NLAYERS = BHI - BLO + 1;
@@ -702,7 +753,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             constexpr int rb = bit - S;            // register bit
             constexpr int kk = TB - 1 - bit;       // layer inside the tile
             constexpr int l = LO + kk;             // global (forward-numbered) layer of this bit
-            if constexpr (KSMAC) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
+            if constexpr (KSMAC || HALF) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
             static_for<0, (E >> (rb + 1))>([&](auto hc) {
                 constexpr int hi = decltype(hc)::value;
                 const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
@@ -769,36 +820,40 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // consecutive bytes instead of touching 64 different 128-byte lines.
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
             const unsigned pown = lds_phys(wbase + lane * E), pidx = lds_phys(wbase + lane * 2u);   // own E words / 16-byte pairs
+            u64 wv[E];
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-                if constexpr (F_TR_ST) lds[pown + R] = A::to_lds(x[R], md);       // stays a re-centred double through the transpose
-                else lds[pown + R] = A::template store_prep<SM>(x[R], md);
+                if constexpr (F_TR_ST) wv[R] = A::to_lds(x[R], md);       // stays a re-centred double through the transpose
+                else wv[R] = A::template store_prep<SM>(x[R], md);
             });
             const unsigned gbase = gindex(wbase);
             // epilogue operands: request every word first (16 bytes per lane, all in flight together), then compute
             ulonglong2 e0[SM != NTT_STORE_PLAIN ? E / 2 : 1], e1[SM == NTT_STORE_KS_FINISH ? E / 2 : 1], ed[SM == NTT_STORE_KS_FINISH ? E / 2 : 1];
-            if constexpr (SM != NTT_STORE_PLAIN) {
-                static_for<0, E / 2>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    e0[m] = *reinterpret_cast<const ulonglong2*>(io.ext0 + gbase + m * 128u + lane * 2u);
-                });
-                if constexpr (SM == NTT_STORE_KS_FINISH) {
-                    static_for<0, E / 2>([&](auto mc) { e1[decltype(mc)::value] = make_ulonglong2(0, 0); ed[decltype(mc)::value] = make_ulonglong2(0, 0); });
-                    if (io.ext1) static_for<0, E / 2>([&](auto mc) {
+            auto request_operands = [&] {
+                if constexpr (SM != NTT_STORE_PLAIN) {
+                    static_for<0, E / 2>([&](auto mc) {
                         constexpr int m = decltype(mc)::value;
-                        e1[m] = *reinterpret_cast<const ulonglong2*>(io.ext1 + gbase + m * 128u + lane * 2u);
+                        e0[m] = *reinterpret_cast<const ulonglong2*>(io.ext0 + gbase + m * 128u + lane * 2u);
                     });
-                    if (io.add_inplace) static_for<0, E / 2>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value;
-                        ed[m] = *reinterpret_cast<const ulonglong2*>(io.dest + gbase + m * 128u + lane * 2u);
-                    });
+                    if constexpr (SM == NTT_STORE_KS_FINISH) {
+                        static_for<0, E / 2>([&](auto mc) { e1[decltype(mc)::value] = make_ulonglong2(0, 0); ed[decltype(mc)::value] = make_ulonglong2(0, 0); });
+                        if (io.ext1) static_for<0, E / 2>([&](auto mc) {
+                            constexpr int m = decltype(mc)::value;
+                            e1[m] = *reinterpret_cast<const ulonglong2*>(io.ext1 + gbase + m * 128u + lane * 2u);
+                        });
+                        if (io.add_inplace) static_for<0, E / 2>([&](auto mc) {
+                            constexpr int m = decltype(mc)::value;
+                            ed[m] = *reinterpret_cast<const ulonglong2*>(io.dest + gbase + m * 128u + lane * 2u);
+                        });
+                    }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
+            };
+            xchg([&](auto ic) { return pown + (unsigned)decltype(ic)::value; },
+                 [&](auto ic) { constexpr int i = decltype(ic)::value; return pidx + lds_off((i / 2) * 128u) + (i & 1); }, wv, wave_sync, request_operands);
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 const unsigned idx = m * 128u + lane * 2u;
-                u64 v0 = lds[pidx + lds_off(m * 128u)], v1 = lds[pidx + lds_off(m * 128u) + 1];
+                u64 v0 = wv[2 * m], v1 = wv[2 * m + 1];
                 if constexpr (F_TR_ST) {
                     // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue
                     const ulonglong2 pr = nt_load2(io.ext0 + gbase + idx);
@@ -819,10 +874,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 nt_store2(gout + gbase + idx, v0, v1);
             });
         } else if constexpr (r == ROUNDS - 1) {
+            const unsigned gi0 = gindex(locbase), gb0 = gi0 * 8u;
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 u64 v;
-                const unsigned gi = gindex(locbase | ((unsigned)R << S));
+                constexpr unsigned GR = gpart((unsigned)R << S);     // this register's share of the index
+                const unsigned gi = gi0 + GR;
                 if constexpr (F_LAST_ST) {
                     // l = INTT(P qk^-1 + c) - r(s) qk^-1: the INTT of relinearize's last limb without ever forming that limb
                     elem ys;
@@ -850,21 +907,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                         if (a.flags & NTT_FLAG_STORE_ROUND_HALF) v = f64_double_to_bits(ArithF64::round_half(f64_from_u64(v), md));
                     }
                 } else v = A::store_mid(x[R], md);
-                nt_store(gout + gi, v);
+                nt_store_at(gout + GR, gb0, v);
             });
-        } else {
-#ifndef TROYN_ABLATE_NO_LDS
-            // WAR: a thread overwrites exactly the words it read itself at the start of this round (same window S),
-            // so no barrier is needed before the writes.
-            static_for<0, E>([&](auto Rc) {
-                constexpr int R = decltype(Rc)::value;
-                lds[pbase + lds_off((unsigned)R << S)] = A::to_lds(x[R], md);
-            });
-            // RAW: readers are the writer's own wave (LDS executes a wave's accesses in order) or other waves
-            if constexpr (PRIVATE_OUT) __builtin_amdgcn_wave_barrier();
-            else __syncthreads();
-#endif
-        }
+        }   // other rounds: the words stay in registers; the next round starts with the exchange
+        (void)PRIVATE_OUT;
     });
     };   // one_digit
     if constexpr (KSMAC) {
@@ -885,10 +931,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     }
 }
 
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
-__global__ __launch_bounds__(1 << (TB - EB)) void ntt_pass_kernel(NttArgs a) {
-    __shared__ u64 lds[(G + EB - 1) / EB > 1 ? ntt_lds_words(TB) : 1];
-    ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false, IOM>(a, nullptr, lds, blockIdx.x, threadIdx.x);
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM, bool HALF = false>
+__global__ __launch_bounds__(1 << (TB - EB), HALF ? (2 << (TB - EB - 8)) : 1) void ntt_pass_kernel(NttArgs a) {
+    __shared__ u64 lds[(G + EB - 1) / EB > 1 ? (HALF ? (ntt_lds_words(TB) + 1) / 2 : ntt_lds_words(TB)) : 1];
+    ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false, IOM, 0, HALF>(a, nullptr, lds, blockIdx.x, threadIdx.x);
 }
 
 // Tensor product of two 2-component ciphertexts between the transforms (BEHZ steps (3)-(5), evaluator.cu:56-93): one workgroup takes

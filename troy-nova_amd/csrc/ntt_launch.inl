@@ -18,6 +18,20 @@
 
 namespace troyn {
 
+// IOM: compile-time variant of the kernel (0 plain, 1 key-switch tail, 2 rescale, 3..5 fused chain).  Whole-limb N = 16384 tiles of the
+// FP64 policy can run with half-word LDS tiles (two workgroups per CU, ntt_pass_body HALF); they pay off where the kernel fits 64
+// registers: the plain forward transform (+18 %, 3.8 -> 4.5 TB/s) and the fused tail + rescale (+2 % on the headline).  The inverse
+// variants need 76-82 registers and lose to their spills.  TROYN_NTT_HALF=<mask> (bit (INV ? 8 : 0) + IOM) selects variants for A/B runs.
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
+static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
+    if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
+        static int half = -1;   // bit (INV ? 8 : 0) + IOM selects the variant
+        if (half < 0) { const char* e = getenv("TROYN_NTT_HALF"); half = e ? (int)strtol(e, nullptr, 0) : 0x0021; }
+        if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
+    }
+    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
+}
+
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST>
 static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     const unsigned tiles = 1u << (LOGN - TB);
@@ -29,29 +43,29 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
         // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768
         if constexpr (INV) {
-            if (a.fused_mode == NTT_FUSED_MULPAIR) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>), grid, block, 0, s, a); return; }
-            if (a.fused_mode == NTT_FUSED_LAST_LIMB) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>), grid, block, 0, s, a); return; }
+            if (a.fused_mode == NTT_FUSED_MULPAIR) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>(a, grid, block, 0, s); return; }
+            if (a.fused_mode == NTT_FUSED_LAST_LIMB) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>(a, grid, block, 0, s); return; }
         } else {
-            if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>), grid, block, 0, s, a); return; }
+            if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>(a, grid, block, 0, s); return; }
         }
     }
     if constexpr (INV && LAST) {
         if (sm == NTT_STORE_KS_FINISH) {   // coefficient-form key-switch tail: the finish runs in the inverse transform's epilogue
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
+            launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>(a, grid, block, (size_t)extra_lds, s);
             return;
         }
     }
     if constexpr (!INV) {
         if (lm == NTT_LOAD_KS_ROUND || sm == NTT_STORE_KS_FINISH) {
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>), grid, block, (size_t)extra_lds, s, a);
+            launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>(a, grid, block, (size_t)extra_lds, s);
             return;
         }
         if (lm == NTT_LOAD_RESCALE || sm == NTT_STORE_RESCALE) {
-            hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 2>), grid, block, (size_t)extra_lds, s, a);
+            launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 2>(a, grid, block, (size_t)extra_lds, s);
             return;
         }
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 0>), grid, block, (size_t)extra_lds, s, a);
+    launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 0>(a, grid, block, (size_t)extra_lds, s);
 }
 
 // single pass: whole limb in one tile
