@@ -255,6 +255,23 @@ __device__ __forceinline__ void nt_store_at(u64* ubase, unsigned byte_off, u64 v
     typedef u64 __attribute__((address_space(1)))* gp;
     __builtin_nontemporal_store(v, (gp)((nt_gcp)(unsigned long long)ubase + byte_off));
 }
+__device__ __forceinline__ ulonglong2 ld2_at(const u64* ubase, unsigned byte_off, bool nontemporal = false) {
+    typedef u64 v2 __attribute__((ext_vector_type(2)));
+    typedef const v2 __attribute__((address_space(1)))* gp;
+    const gp p = (gp)((nt_gcp)(unsigned long long)ubase + byte_off);
+    const v2 v = nontemporal ? __builtin_nontemporal_load(p) : *p;
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store2_at(u64* ubase, unsigned byte_off, u64 a, u64 b) {
+    typedef u64 v2 __attribute__((ext_vector_type(2)));
+    typedef v2 __attribute__((address_space(1)))* gp;
+    v2 v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, (gp)((nt_gcp)(unsigned long long)ubase + byte_off));
+}
+__device__ __forceinline__ u64 nt_ld_at(const u64* ubase, unsigned byte_off) {
+    typedef const u64 __attribute__((address_space(1)))* gp;
+    return __builtin_nontemporal_load((gp)((nt_gcp)(unsigned long long)ubase + byte_off));
+}
 __device__ __forceinline__ u64 ld_at(const u64* ubase, unsigned byte_off) {
     typedef const u64 __attribute__((address_space(1)))* gp;
     return *(gp)((nt_gcp)(unsigned long long)ubase + byte_off);
@@ -715,17 +732,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 else x[R] = A::load_mid(raw, md);
             });
         } else if constexpr (r == 0) {
+            const unsigned lb0 = gindex(locbase) * 8u;     // one 32-bit lane offset; the register number only moves the (uniform) base
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
-#ifdef TROYN_ABLATE_NO_GLOAD
-                const u64 raw = (u64)(t * 16 + R + blockIdx.x);
-#else
-                const u64 raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
-#endif
+                constexpr unsigned GR = gpart((unsigned)R << S);
+                u64 raw;
+                if constexpr (KSMAC) raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
+                else raw = a.stream_loads ? nt_ld_at(gin + GR, lb0) : ld_at(gin + GR, lb0);
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
                 else if constexpr (F_TR_LD) {
                     // r_j(s) qk^-1 + f_j(l): the rounding fixes of the key switch and of the rescale enter ONE transform
-                    const u64 raw2 = io.in2[gindex(locbase | ((unsigned)R << S))];
+                    const u64 raw2 = ld_at(io.in2 + GR, lb0);
                     const elem rs = A::round_fix_t(raw, io.hm_d, md);       // both rows arrive as T = (x + aux/2) mod aux (doubles)
                     const elem fl = A::round_fix_t(raw2, io.hm2_d, md);
                     x[R] = A::scale_by(rs, io.inv_d, md) + fl;      // |x| <= 1.2 p: a 4-layer block from here stays below 7.7 p < 2^53
@@ -855,11 +872,13 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = wv[2 * m], v1 = wv[2 * m + 1];
                 if constexpr (F_TR_ST) {
-                    // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue
-                    const ulonglong2 pr = nt_load2(io.ext0 + gbase + idx);
-                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
+                    // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue.  The five operand
+                    // rows share one 32-bit lane offset on wave-uniform bases
+                    const unsigned boff = (gbase + idx) * 8u;
+                    const ulonglong2 pr = ld2_at(io.ext0, boff, true);
+                    const ulonglong2 a0 = ld2_at(io.a0 + mul_off, boff), b0 = ld2_at(io.b0 + mul_off, boff);
                     ulonglong2 a1 = a0, b1 = b0;
-                    if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
+                    if (io.poly) { a1 = ld2_at(io.a1 + mul_off, boff); b1 = ld2_at(io.b1 + mul_off, boff); }
                     const elem t0 = A::scale_by(f64_from_u64(pr.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
                     const elem t1 = A::scale_by(f64_from_u64(pr.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
                     // the product of a re-centred factor is within (-0.7 p, 0.7 p): one conditional add canonicalises it
