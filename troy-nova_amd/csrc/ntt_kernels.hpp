@@ -770,7 +770,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             constexpr int rb = bit - S;            // register bit
             constexpr int kk = TB - 1 - bit;       // layer inside the tile
             constexpr int l = LO + kk;             // global (forward-numbered) layer of this bit
-            if constexpr (KSMAC || HALF) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
+            if constexpr (KSMAC || (HALF && !INV)) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
             static_for<0, (E >> (rb + 1))>([&](auto hc) {
                 constexpr int hi = decltype(hc)::value;
                 const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
