@@ -847,7 +847,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // epilogue operands: request every word first (16 bytes per lane, all in flight together), then compute
             ulonglong2 e0[SM != NTT_STORE_PLAIN ? E / 2 : 1], e1[SM == NTT_STORE_KS_FINISH ? E / 2 : 1], ed[SM == NTT_STORE_KS_FINISH ? E / 2 : 1];
             auto request_operands = [&] {
-                if constexpr (SM != NTT_STORE_PLAIN) {
+                if constexpr (SM != NTT_STORE_PLAIN && !HALF) {     // half-word tiles: 64 registers per thread, operands are loaded pair by pair below
                     static_for<0, E / 2>([&](auto mc) {
                         constexpr int m = decltype(mc)::value;
                         e0[m] = *reinterpret_cast<const ulonglong2*>(io.ext0 + gbase + m * 128u + lane * 2u);
@@ -885,7 +885,18 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     v0 = A::canon_small(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md);
                     v1 = A::canon_small(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md);
                 }
-                if constexpr (SM != NTT_STORE_PLAIN) {
+                if constexpr (SM != NTT_STORE_PLAIN && HALF) {
+                    const unsigned boff = (gbase + idx) * 8u;
+                    const ulonglong2 z = make_ulonglong2(0, 0);
+                    const ulonglong2 o0 = ld2_at(io.ext0, boff);
+                    ulonglong2 o1 = z, od = z;
+                    if constexpr (SM == NTT_STORE_KS_FINISH) {
+                        if (io.ext1) o1 = ld2_at(io.ext1, boff);
+                        if (io.add_inplace) od = ld2_at(io.dest, boff);
+                    }
+                    v0 = A::template store_io<SM>(io, v0, o0.x, o1.x, od.x, md);
+                    v1 = A::template store_io<SM>(io, v1, o0.y, o1.y, od.y, md);
+                } else if constexpr (SM != NTT_STORE_PLAIN) {
                     constexpr int mk = (SM == NTT_STORE_KS_FINISH) ? m : 0;
                     v0 = A::template store_io<SM>(io, v0, e0[m].x, e1[mk].x, ed[mk].x, md);
                     v1 = A::template store_io<SM>(io, v1, e0[m].y, e1[mk].y, ed[mk].y, md);
