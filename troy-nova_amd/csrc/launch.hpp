@@ -38,7 +38,8 @@ inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const
     return log_n <= 13 ? launch_tensor_u64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_u64_large(log_n, stage, a, b, d, batch, s);
 }
 // second-generation key-switch inner product (ksmac2_kernel, log_n = 13 / 14 / 15) and its key preparation
-void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s);
+// digits_f64: the digit rows hold doubles (fused chain: NTT_FLAG_STORE_F64) instead of u64 words
+void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64 = false);
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s);
 // second-generation BEHZ conversions (L = 1 .. 16)
 void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst);

@@ -89,6 +89,7 @@ enum NttStore {
 //     out_j     = (relin_j - NTT_j(f_j(l))) ql^-1                           (utils/rns_tool.cu:523-627)
 //               = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1
 // i.e. ONE forward transform per output limb instead of two, and c is never materialised:
+constexpr unsigned NTT_FLAG_STORE_F64 = 16u;         // NttArgs::flags: NTT_FUSED_MULPAIR stores its canonical outputs as doubles (the digits ksmac2 reads)
 constexpr unsigned NTT_FLAG_STORE_ROUND_HALF = 8u;   // NttArgs::flags: a plain FP64 inverse transform stores T = (x + q/2) mod q as doubles
 
 enum NttFused {
@@ -935,6 +936,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                                                       (SM == NTT_STORE_KS_FINISH && io.add_inplace) ? io.dest[gi] : 0, md);
                     if constexpr (INV && IOM == 0 && std::is_same<A, ArithF64>::value) {
                         if (a.flags & NTT_FLAG_STORE_ROUND_HALF) v = f64_double_to_bits(ArithF64::round_half(f64_from_u64(v), md));
+                    }
+                    if constexpr (INV && IOM == NTT_FUSED_MULPAIR) {
+                        // the digits of the key switch are consumed as doubles by ksmac2: convert once here instead of once per output row there
+                        if (a.flags & NTT_FLAG_STORE_F64) v = f64_double_to_bits(f64_from_u64(v));
                     }
                 } else v = A::store_mid(x[R], md);
                 nt_store_at(gout + GR, gb0, v);

@@ -979,6 +979,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         NttArgs x = contiguous_args(p, a, ws + w.digits, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
         mul_operands(x, 0);
         x.fused_mode = NTT_FUSED_MULPAIR;
+        x.flags = NTT_FLAG_STORE_F64;            // the digits go to ksmac2 as doubles (one conversion here instead of L + 1 there)
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
     // (2) key-switch inner product; the digit of row k under its own modulus is a1 (.) b1 again
@@ -996,7 +997,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
         m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        launch_ksmac2(p->log_n, batch, L + 1, m, s);
+        launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
     }
     LAUNCH_CHECK();
     // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)

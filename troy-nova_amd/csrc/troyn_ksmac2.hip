@@ -3,10 +3,15 @@
 
 namespace troyn {
 
-void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s) {
-    if (log_n == 15) hipLaunchKernelGGL((ksmac2_kernel<15, false>), dim3((unsigned)(batch * rows * 4)), dim3(KSM_THREADS), 0, s, a);
-    else if (log_n == 14) hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3((unsigned)(batch * rows * 2)), dim3(KSM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((ksmac2_kernel<13, false>), dim3((unsigned)(batch * rows)), dim3(KSM_THREADS), 0, s, a);
+void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64) {
+    const dim3 block(KSM_THREADS);
+#define KSMAC2_CASE(LOGN, TILES)                                                                                            \
+    if (digits_f64) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true>), dim3((unsigned)(batch * rows * TILES)), block, 0, s, a); \
+    else hipLaunchKernelGGL((ksmac2_kernel<LOGN, false>), dim3((unsigned)(batch * rows * TILES)), block, 0, s, a);
+    if (log_n == 15) { KSMAC2_CASE(15, 4) }
+    else if (log_n == 14) { KSMAC2_CASE(14, 2) }
+    else { KSMAC2_CASE(13, 1) }
+#undef KSMAC2_CASE
 }
 
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s) {
