@@ -393,7 +393,9 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
         });
         static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * q), abl(5) ? (slice_off & 16u) : slice_off); ta[2 * q] = v.x; ta[2 * q + 1] = v.y; });
         static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; const double2 v = ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * (4 + q)), abl(5) ? (slice_off & 16u) : slice_off); tb[2 * q] = v.x; tb[2 * q + 1] = v.y; });
-        if constexpr (!abl(2)) __syncthreads();
+        // this exchange stays inside groups of 32 consecutive threads (tile bits [10,13) = t >> 5 on both sides): a wave reads only
+        // what it wrote itself, LDS executes a wave's accesses in order -- no workgroup barrier
+        if constexpr (!abl(2)) __builtin_amdgcn_wave_barrier();
         if constexpr (!abl(2)) static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const double2 v = *reinterpret_cast<const double2*>(&lds[p2 + 2 * m]);
