@@ -704,7 +704,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned idx = m * 128u + lane * 2u;
                 if constexpr (F_MULPAIR) {
                     // c2 = a1 (.) b1 formed while loading (the tensor product is never written to HBM)
-                    const ulonglong2 va = nt_load2(io.a1 + mul_off + gbase + idx), vb = nt_load2(io.b1 + mul_off + gbase + idx);
+                    const ulonglong2 va = ld2_at(io.a1 + mul_off + gbase + m * 128u, lane * 16u, true), vb = ld2_at(io.b1 + mul_off + gbase + m * 128u, lane * 16u, true);
                     wv[2 * m] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
                     wv[2 * m + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
                 } else if constexpr (F_LAST_LD) {
@@ -718,7 +718,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     wv[2 * m] = A::to_lds(e0, md);
                     wv[2 * m + 1] = A::to_lds(e1, md);
                 } else {
-                    const ulonglong2 v = a.stream_loads ? nt_load2(gin + gbase + idx) : *reinterpret_cast<const ulonglong2*>(gin + gbase + idx);
+                    // (uniform row + pair offset) + one 32-bit lane offset: no 64-bit address per load
+                    const ulonglong2 v = ld2_at(gin + gbase + m * 128u, lane * 16u, a.stream_loads != 0);
                     wv[2 * m] = ntt_io_load<LM>(io, v.x);
                     wv[2 * m + 1] = ntt_io_load<LM>(io, v.y);
                 }
