@@ -106,8 +106,12 @@ int troyn_ntt(const troyn_plan* plan, int inverse, const uint64_t* in, uint64_t*
 /* ---------------------------------------------------------------------------------------
  * Element-wise RNS polynomial ops over count*nmod limb-polynomials ([count][nmod][N]); limb l
  * uses modulus mod_start + l.  Replace the device branches of utils::add_ps / sub_ps /
- * negate_ps / multiply_scalar_ps / dyadic_product_ps (utils/poly_small_mod.cu:243-304,
- * :306-365, :182-241, :653-714, :816-900).
+ * negate_ps / multiply_scalar_ps / dyadic_product_ps / modulo_ps / multiply_uint64operand_ps
+ * (utils/poly_small_mod.cu:243-304, :306-365, :182-241, :653-714, :816-900, :119-180, :752-814).
+ * troyn_modulo: Modulus::reduce (Barrett-64, modulus.h:22-42) of ANY 64-bit word.
+ * troyn_multiply_uint64operand: `operands` = nmod device-resident (operand, quotient) pairs, one
+ * MultiplyUint64Operand (utils/uint_small_mod.h:92-122) per limb of the slice; the input may be any
+ * 64-bit word, the result is canonical (multiply_uint64operand_mod, :130-139).
  * ------------------------------------------------------------------------------------- */
 int troyn_add(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
               uint64_t* out, size_t count, troyn_stream_t stream);
@@ -119,6 +123,10 @@ int troyn_multiply_scalar(const troyn_plan* plan, uint32_t mod_start, uint32_t n
                           uint64_t* out, size_t count, troyn_stream_t stream);
 int troyn_dyadic_product(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
                          uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_modulo(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a,
+                 uint64_t* out, size_t count, troyn_stream_t stream);
+int troyn_multiply_uint64operand(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* a,
+                                 const uint64_t* operands, uint64_t* out, size_t count, troyn_stream_t stream);
 
 /* fgk::dyadic_convolute::dyadic_convolute (fgk/dyadic_convolute.cu:43-90): a[pa][nmod][N] x
  * b[pb][nmod][N] -> out[pa+pb-1][nmod][N], per batch item.  CKKS/BGV multiply is exactly this

@@ -84,6 +84,7 @@ def lib():
     for nm in ("orc_negate_ps", "orc_modulo_ps"):
         sig(nm, None, p64, sz, sz, MP, sz, p64)
     sig("orc_multiply_scalar_ps", None, p64, u64, sz, sz, MP, sz, p64)
+    sig("orc_multiply_uint64operand_ps", None, p64, OP, sz, sz, MP, sz, p64)
     sig("orc_dyadic_convolute", None, p64, p64, sz, sz, MP, sz, sz, p64)
     sig("orc_dyadic_square", None, p64, MP, sz, sz, p64)
     sig("orc_rns_tool_create", vp, sz, p64, sz, u64)

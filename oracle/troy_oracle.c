@@ -464,6 +464,10 @@ void orc_multiply_scalar_ps(const uint64_t* a, uint64_t scalar, size_t pcount, s
     /* poly_small_mod.cu:653-662 host_multiply_scalar_ps */
     FOR_PS(out[idx] = orc_multiply_mod(a[idx], scalar, mod))
 }
+void orc_multiply_uint64operand_ps(const uint64_t* a, const orc_mulop* operand, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
+    /* poly_small_mod.cu:752-762 host_multiply_uint64operand_ps */
+    FOR_PS(out[idx] = orc_mulop_mod(a[idx], &operand[j], mod))
+}
 void orc_dyadic_product_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out) {
     /* poly_small_mod.cu:816-855 host_dyadic_product_ps */
     FOR_PS(out[idx] = orc_multiply_mod(a[idx], b[idx], mod))

@@ -105,6 +105,7 @@ void orc_add_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degr
 void orc_sub_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
 void orc_negate_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
 void orc_modulo_ps(const uint64_t* a, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
+void orc_multiply_uint64operand_ps(const uint64_t* a, const orc_mulop* operand, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
 void orc_multiply_scalar_ps(const uint64_t* a, uint64_t scalar, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
 void orc_dyadic_product_ps(const uint64_t* a, const uint64_t* b, size_t pcount, size_t degree, const orc_modulus* moduli, size_t nmod, uint64_t* out);
 /* fgk/dyadic_convolute.cu:43-80 (host branch) / :116-140 */

@@ -36,6 +36,8 @@ SYMBOLS = {
     "troyn_negate": (C.c_int, [vp, u32, u32, vp, vp, sz, vp]),
     "troyn_multiply_scalar": (C.c_int, [vp, u32, u32, vp, u64, vp, sz, vp]),
     "troyn_dyadic_product": (C.c_int, [vp, u32, u32, vp, vp, vp, sz, vp]),
+    "troyn_modulo": (C.c_int, [vp, u32, u32, vp, vp, sz, vp]),
+    "troyn_multiply_uint64operand": (C.c_int, [vp, u32, u32, vp, vp, vp, sz, vp]),
     "troyn_dyadic_convolute": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp, sz, vp]),
     "troyn_dyadic_square": (C.c_int, [vp, u32, u32, vp, vp, sz, vp]),
     "troyn_switch_key_workspace_bytes": (sz, [vp, u32, sz]),

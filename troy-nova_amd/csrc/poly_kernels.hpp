@@ -22,11 +22,13 @@ struct u64x2 { u64 a, b; };
 __device__ __forceinline__ u64x2 ld2(const u64* p) { ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p); return u64x2{v.x, v.y}; }
 __device__ __forceinline__ void st2(u64* p, u64 a, u64 b) { *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(a, b); }
 
-enum { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MULS = 3, EW_MUL = 4 };
+enum { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MULS = 3, EW_MUL = 4, EW_MOD = 5, EW_MULOP = 6 };
 
 // data [count][nmod][N]; grid.x covers N/2 pairs, grid.y = count*nmod limb-polynomials
 // (utils/poly_small_mod.cu kernel_add_ps / kernel_sub_ps / kernel_negate_ps /
-//  kernel_multiply_scalar_ps / kernel_dyadic_product_ps)
+//  kernel_multiply_scalar_ps / kernel_dyadic_product_ps / kernel_modulo_ps / kernel_multiply_uint64operand_ps)
+// EW_MOD: Modulus::reduce of ANY 64-bit word; EW_MULOP: b holds one (operand, quotient) pair per limb of the slice
+// (MultiplyUint64Operand, utils/uint_small_mod.h:92-139), the input may be any 64-bit word, the result is canonical.
 template <int OP>
 __global__ __launch_bounds__(POLY_BLOCK) void elementwise_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod,
                                                                  unsigned n, const u64* a, const u64* b, u64 scalar, u64* out) {
@@ -40,6 +42,11 @@ __global__ __launch_bounds__(POLY_BLOCK) void elementwise_kernel(unsigned chunks
         else if constexpr (OP == EW_SUB) { const u64x2 vb = ld2(b + base + i); r0 = sub_mod(va.a, vb.a, md.q); r1 = sub_mod(va.b, vb.b, md.q); }
         else if constexpr (OP == EW_NEG) { r0 = neg_mod(va.a, md.q); r1 = neg_mod(va.b, md.q); }
         else if constexpr (OP == EW_MULS) { r0 = mul_mod(va.a, scalar, md); r1 = mul_mod(va.b, scalar, md); }
+        else if constexpr (OP == EW_MOD) { r0 = barrett64(va.a, md.q, md.ratio_hi); r1 = barrett64(va.b, md.q, md.ratio_hi); }
+        else if constexpr (OP == EW_MULOP) {
+            const u64x2 w = ld2(b + 2 * (limb % nmod));     // wave-uniform (operand, quotient)
+            r0 = shoup_mul(va.a, w.a, w.b, md.q); r1 = shoup_mul(va.b, w.a, w.b, md.q);
+        }
         else { const u64x2 vb = ld2(b + base + i); r0 = mul_mod(va.a, vb.a, md); r1 = mul_mod(va.b, vb.b, md); }
         st2(out + base + i, r0, r1);
     }

@@ -474,7 +474,7 @@ static int check_rows(size_t rows, unsigned chunks) {
 template <int OP>
 static int launch_elementwise(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* a, const uint64_t* b,
                               uint64_t scalar, uint64_t* out, size_t count, troyn_stream_t stream) {
-    if (!p || !a || !out || (OP != EW_NEG && OP != EW_MULS && !b)) return fail(TROYN_E_INVALID, "[troyn elementwise] null argument");
+    if (!p || !a || !out || (OP != EW_NEG && OP != EW_MULS && OP != EW_MOD && !b)) return fail(TROYN_E_INVALID, "[troyn elementwise] null argument");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, "[troyn elementwise] modulus slice out of range");
     const size_t rows = count * nmod;
     if (rows == 0) return TROYN_OK;
@@ -505,6 +505,16 @@ extern "C" int troyn_multiply_scalar(const troyn_plan* p, uint32_t ms, uint32_t 
 extern "C" int troyn_dyadic_product(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count, troyn_stream_t s) {
     select_device(p);
     return launch_elementwise<EW_MUL>(p, ms, nm, a, b, 0, out, count, s);
+}
+
+extern "C" int troyn_modulo(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
+    return launch_elementwise<EW_MOD>(p, ms, nm, a, nullptr, 0, out, count, s);
+}
+extern "C" int troyn_multiply_uint64operand(const troyn_plan* p, uint32_t ms, uint32_t nm, const uint64_t* a, const uint64_t* operands,
+                                            uint64_t* out, size_t count, troyn_stream_t s) {
+    select_device(p);
+    return launch_elementwise<EW_MULOP>(p, ms, nm, a, operands, 0, out, count, s);
 }
 
 static int launch_convolute(const DevModulus* mods, unsigned n, uint32_t mod_start, uint32_t nmod,

@@ -118,6 +118,14 @@ class Plan:
     def negate(self, a, nmod, mod_start=0, out=None):
         return self._ew(self.lib.troyn_negate, a, None, nmod, mod_start, out)
 
+    def modulo(self, a, nmod, mod_start=0, out=None):
+        """utils::modulo_ps (utils/poly_small_mod.cu:119-180): Barrett-64 reduction of arbitrary 64-bit words"""
+        return self._ew(self.lib.troyn_modulo, a, None, nmod, mod_start, out)
+
+    def multiply_uint64operand(self, a, operands, nmod, mod_start=0, out=None):
+        """utils::multiply_uint64operand_ps (utils/poly_small_mod.cu:752-814); operands: int64 CUDA tensor [nmod][2] = (operand, quotient)"""
+        return self._ew(self.lib.troyn_multiply_uint64operand, a, operands, nmod, mod_start, out)
+
     def dyadic_product(self, a, b, nmod, mod_start=0, out=None):
         return self._ew(self.lib.troyn_dyadic_product, a, b, nmod, mod_start, out)
 
