@@ -5,9 +5,13 @@ Default workload (BASELINE.json configs[2], the configuration the metric is quot
   CKKS, N = 16384, CoeffModulus::create(16384, {50}x6)  ->  K = 6 key limbs, L = 5 data limbs.
   One "op"   = multiply (dyadic 2x2 -> 3) + relinearize (key-switch core) + rescale_to_next
                on one pair of ciphertexts.
-  One "step" = that pipeline over a batch of B independent ciphertext pairs per GPU, inputs and
-               evaluation keys already resident in HBM.
-  value = whole-job ops/s = n_gpus * B * steps / time (max over ranks);  "scaling": "weak".
+  One "step" = --inner (default 12) passes of that pipeline over a batch of B = 1024 independent ciphertext pairs per GPU,
+               inputs and evaluation keys already resident in HBM (12 x 1024 ops per step: 20 driver steps time about a second).
+  value = whole-job ops/s = n_gpus * B * inner * steps / time (max over ranks);  "scaling": "weak".
+  The same line carries the three-call figure (Evaluator::multiply + relinearize + rescale_to_next as three library calls, the
+  reference's own operator boundary) next to the fused entry's, the roofline of the dominant kernel, the CPU baseline, and
+  `other_configs`: BASELINE configs[3] (cfg4) and configs[4] (cfg5) each with value + roofline + cpu_baseline + parity, north_star's
+  other ring sizes, and the C++ mirror (troy::Evaluator) timed by tests/cpp/he_bench_driver.
 
 --workload cfg4 (BASELINE.json configs[3]): 1024 independent BFV N = 32768, L = 10 (K = 11) ciphertext
   multiplications (BEHZ multiply + relinearize), block-partitioned over the ranks with shard.shard_range
@@ -15,10 +19,12 @@ Default workload (BASELINE.json configs[2], the configuration the metric is quot
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  Under torchrun the ranks
 come from the environment; `python bench.py --gpus N` without WORLD_SIZE starts the N rank processes itself,
-BEFORE this process touches the GPU, and relays rank 0's JSON line.  Evaluation keys are broadcast once from
-rank 0 before the timed region; the data path has no collective.
+BEFORE this process touches the GPU, relays rank 0's JSON line, and ends every rank as soon as one of them fails.
+Evaluation keys are broadcast once from rank 0 before the timed region; the data path has no collective.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import socket
@@ -30,58 +36,100 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-FP64_VALU_PEAK = 39.3e12       # FP64 vector lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (78.6 TFLOP/s, FMA = 2)
+# FP64 vector rate: not a row of the guide; derived from its chip table (256 CUs x 4 SIMDs, 2.4 GHz) and the 16 FP64 lanes a SIMD
+# retires per clock (a wave64 FP64 instruction occupies its SIMD for 4 cycles, tools/ubench/alu_rates.hip): 39.3 T lane-ops/s = 78.6 TFLOP/s
+FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9
 CHECK_ITEMS = lambda B: sorted({0, 1, 7 % B, B // 2, B - 1})   # the fused kernels permute items over workgroups / XCDs
+TIMER_KS, TIMER_TENSOR, TIMER_PLAIN_MAC, TIMER_FLOOR = 0, 1, 2, 3   # include/troyn.h TROYN_TIMER_*
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--inner", type=int, default=0, help="passes over the batch per step (cfg3: 12; cfg4: 1 = the whole job once)")
     ap.add_argument("--workload", choices=["cfg3", "cfg4"], default="cfg3")
     ap.add_argument("--batch", type=int, default=0, help="ciphertext pairs per GPU per launch (cfg3: 1024; cfg4: chunk of 64)")
     ap.add_argument("--total", type=int, default=1024, help="cfg4: size of the fixed job that is sharded over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the N=8192 / N=32768 side measurements (rank 0, 1 GPU)")
+    ap.add_argument("--no-extra", action="store_true", help="skip other_configs (rank 0, 1 GPU)")
     ap.add_argument("--unfused", action="store_true", help="cfg3: three library calls per op instead of the fused entry point")
     ap.add_argument("--dry-shard", action="store_true", help="print the partition of the job over --gpus ranks and exit (no GPU)")
     ap.add_argument("--dry-run", action="store_true", help="run the launcher / rendezvous / key broadcast / timing reduction with the gloo backend on "
                                                               "CPU tensors and no evaluation (exercises the N > 1 plumbing where there is no GPU)")
-    return ap.parse_args()
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="--dry-run only: this rank exits non-zero before the rendezvous (launcher watchdog test)")
+    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------------
 # self-launcher: `python bench.py --gpus N` outside torchrun
 # ------------------------------------------------------------------------------------------------------
-def _free_port():
+def _reserve_port():
+    """a free rendezvous port; the socket stays open (SO_REUSEADDR) until the children have been started, which narrows the window in
+    which another process could take the port"""
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return s, s.getsockname()[1]
 
 
-def launch_ranks(n):
-    """start n fresh rank processes (this process has not initialised HIP) and relay rank 0's output"""
-    port = _free_port()
-    procs = []
+def launch_ranks(n, poll_s=0.2):
+    """start n FRESH rank processes (this process has not initialised HIP; nothing is ever re-exec'ed), relay rank 0's output and
+    watch every child: the first non-zero exit terminates the others, so a dead rank cannot leave rank 0 waiting in a collective"""
+    holder, port = _reserve_port()
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        err = open(os.path.join("/tmp", "bench_rank%d_%d.err" % (r, os.getpid())), "w+")
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0 or "")
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err, text=True))
+    holder.close()
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    reader.join(timeout=10)
+    text = out0[0] if out0 else ""
+    sys.stdout.write(text or "")
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+    for r, err in enumerate(errs):
+        err.seek(0)
+        tail = err.read()[-2000:]
+        err.close()
+        try:
+            os.unlink(err.name)
+        except OSError:
+            pass
+        if tail.strip() and (failed or r == 0):
+            sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, tail))
+    if failed:
+        sys.stderr.write("bench.py: rank(s) failed: %s; the remaining ranks were terminated\n" % failed)
         return 1
     try:
-        line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")][-1]
+        line = [ln for ln in (text or "").splitlines() if ln.startswith("{")][-1]
         if json.loads(line).get("n_gpus") != n:
             sys.stderr.write("bench.py: asked for %d GPUs, the job reports %s\n" % (n, json.loads(line).get("n_gpus")))
             return 3
@@ -92,7 +140,6 @@ def launch_ranks(n):
 
 
 def shard_plan(total, world):
-    sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     import importlib
     entry.load_package()
@@ -119,9 +166,57 @@ def timed(torch, fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def profile_record(name):
-    path = os.path.join(ROOT, "profiles", name)
-    return json.load(open(path)) if os.path.exists(path) else None
+def kernel_sources_sha(names):
+    """stamp of the kernel sources a counter record belongs to (tools/collect_counters.py writes the same value)"""
+    h = hashlib.sha256()
+    for nm in names:
+        with open(os.path.join(ROOT, "troy-nova_amd", "csrc", nm), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+KSMAC_SOURCES = ("ksmac_kernels.hpp", "dev_math_f64.hpp")
+
+
+def counters_record(kernel_tag, batch):
+    """newest profiles/r*_<kernel_tag>_counters.json whose kernel sources are the ones being timed (a record of an older kernel is stale: dropped)"""
+    sha = kernel_sources_sha(KSMAC_SOURCES)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.json" % kernel_tag)), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel_src_sha") == sha and rec.get("batch") == batch:
+            rec["_file"] = os.path.relpath(path, ROOT)
+            return rec
+    return None
+
+
+class KernelTimer:
+    """the library's measurement hook (include/troyn.h troyn_kernel_timer_*): hipEvent pairs on the launch stream around one named launch"""
+
+    def __init__(self, pkg, lib, region):
+        self.pkg, self.lib, self.region = pkg, lib, region
+
+    def __enter__(self):
+        self.pkg.capi.check(self.lib.troyn_kernel_timer_enable(self.region, 1))
+        return self
+
+    def __exit__(self, *exc):
+        self.pkg.capi.check(self.lib.troyn_kernel_timer_enable(self.region, 0))
+
+    def read(self):
+        import ctypes as C
+        ms, n = C.c_double(0.0), C.c_uint64(0)
+        self.pkg.capi.check(self.lib.troyn_kernel_timer_read(self.region, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+
+def ksmac_alg_bytes(B, n, L, ntt_form):
+    """algorithmic bytes of one key-switch inner-product launch (SURVEY.md 8d minimum traffic): per item the L
+    coefficient-form digits (+ the L NTT-form input limbs when the operand is in NTT form) read once, the two output polynomials of L+1
+    rows written once; the key set (16*N*L*(L+1) bytes) is shared by the whole batch and counted once per launch"""
+    return B * ((2 if ntt_form else 1) * 8.0 * n * L + 16.0 * n * (L + 1)) + 16.0 * n * L * (L + 1)
 
 
 def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
@@ -129,6 +224,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     q = pkg.capi.coeff_modulus_create(n, [50] * 6)
     K, L = 6, 5
     B = args.batch or 1024
+    inner = args.inner or 12
     plan = pkg.Plan(device, log_n, q)
     gen = torch.Generator(device=device).manual_seed(0x123 + rank)
     a = uniform_residues(torch, (B, 2), q[:L], n, device, gen)
@@ -144,61 +240,69 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     out = torch.empty((B, 2, L - 1, n), dtype=torch.int64, device=device)
     fused = hasattr(plan, "ckks_multiply_relinearize_rescale") and not args.unfused
 
-    def step3():
+    def pass3():
         plan.dyadic_convolute(a, 2, b, 2, L, out=prod)                       # Evaluator::multiply (CKKS)
         plan.relinearize(L, prod, keys, out=relin, is_ckks=True, is_ntt_form=True)  # Evaluator::relinearize
         plan.divide_and_round_q_last_ntt(L, relin, 2, out=out)               # Evaluator::rescale_to_next
 
-    def step1():
+    def pass1():
         plan.ckks_multiply_relinearize_rescale(L, a, b, keys, out=out)       # the same three calls behind one entry point
 
-    step = step1 if fused else step3
+    one_pass = pass1 if fused else pass3
+
+    def step():
+        for _ in range(inner):
+            one_pass()
+
     for _ in range(args.warmup):
         step()
     lib = plan.lib
-    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 1))
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    shard.barrier()
-    elapsed = time.perf_counter() - t0
-    import ctypes as C
-    ks_ms, ks_n = C.c_double(0.0), C.c_uint64(0)
-    pkg.capi.check(lib.troyn_kernel_timer_read(0, C.byref(ks_ms), C.byref(ks_n)))
-    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 0))
+    with KernelTimer(pkg, lib, TIMER_KS) as kt:
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        elapsed = time.perf_counter() - t0
+        ks_ms, ks_n = kt.read()
     elapsed = shard.max_over_ranks(elapsed, device=device)
-    value = world * B * args.steps / elapsed
+    value = world * B * inner * args.steps / elapsed
 
     # ---- roofline of the kernel with the largest share of the timed step: the fused key-switch inner product ----
-    # algorithmic bytes per launch (SURVEY.md 8d minimum traffic): per item the L coefficient-form digits and the
-    # L NTT-form input limbs are read once (2 * 8*N*L), the two output polynomials of L+1 rows written once (16*N*(L+1)); the key set
-    # (16*N*L*(L+1) bytes) is shared by the whole batch and counted once per launch.
-    ks_launch_ms = ks_ms.value / max(1, ks_n.value)
-    alg_bytes = B * (2 * 8.0 * n * L + 16.0 * n * (L + 1)) + 16.0 * n * L * (L + 1)
-    achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_n.value else 0.0
-    prof = profile_record("r02_ksmac_counters.json")      # written by tools/collect_traffic.py from the rocprofv3 PMC passes
-    traffic = None
-    valu = None
-    if prof and prof.get("batch") == B:
+    ks_launch_ms = ks_ms / max(1, ks_n)
+    alg_bytes = ksmac_alg_bytes(B, n, L, True)
+    achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_n else 0.0
+    prof = counters_record("ksmac", B)            # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
+    traffic, valu = None, None
+    if prof:
         traffic = prof.get("traffic_bytes_per_launch")
         if prof.get("valu_lane_ops_per_launch"):
             rate = prof["valu_lane_ops_per_launch"] / (ks_launch_ms * 1e-3)
-            valu = {"what": "the kernel is FP64-VALU-bound, not HBM-bound: exact 50-bit modular arithmetic on the FP64 vector ALU "
-                            "(no MFMA); lane-operations per launch from SQ_INSTS_VALU x 64 (profiles/r02_ksmac_counters.json)",
-                    "lane_ops_per_launch": prof["valu_lane_ops_per_launch"], "achieved_lane_ops_per_s": round(rate, 0),
+            valu = {"what": "exact 50-bit modular arithmetic on the FP64 vector ALU (no MFMA); lane-operations per launch = SQ_INSTS_VALU x 64 of the "
+                            "PMC pass in `record`; peak = 256 CUs x 4 SIMDs x 16 FP64 lanes x 2.4 GHz (derived from the guide's chip table, it has no FP64 row)",
+                    "record": prof["_file"], "lane_ops_per_launch": prof["valu_lane_ops_per_launch"], "achieved_lane_ops_per_s": round(rate, 0),
                     "peak_lane_ops_per_s": FP64_VALU_PEAK, "frac": round(rate / FP64_VALU_PEAK, 4),
-                    "simd_valu_busy_profiled": prof.get("simd_valu_busy")}
-    roofline = {"bound": "hbm", "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation), "
-                                          "largest share of the timed step (%.0f %%)" % (100.0 * ks_ms.value / (elapsed * 1e3)),
+                    "simd_valu_busy_profiled": prof.get("simd_valu_busy"), "effective_clock_GHz_profiled": prof.get("effective_clock_GHz")}
+    roofline = {"bound": "valu_fp64" if valu else "hbm",
+                "bound_note": "what binds the kernel is FP64 vector issue (see valu_fp64); achieved / peak / frac are the contract's HBM figures: algorithmic bytes per "
+                              "launch / the launch duration measured in this run, against the 8 TB/s peak",
+                "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation), "
+                          "largest share of the timed step (%.0f %%)" % (100.0 * ks_ms / (elapsed * 1e3)),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "launch_ms": round(ks_launch_ms, 4), "launches_timed": int(ks_n.value),
+                "traffic": traffic, "traffic_record": prof["_file"] if prof else None,
+                "launch_ms": round(ks_launch_ms, 4), "launches_timed": ks_n,
                 "algorithmic_bytes_per_launch": alg_bytes, "valu_fp64": valu,
-                # whole pipeline against the chip's HBM peak, both key accountings of the verdict (keys per op / keys once per batch)
+                # whole pipeline against the chip's HBM peak, both key accountings of SURVEY 8d (keys per op / keys once per batch)
                 "pipeline": {"bytes_per_op_keys_per_op": 18.0e6, "frac_keys_per_op": round(value / world * 18.0e6 / (HBM_PEAK_GBS * 1e9), 4),
                              "bytes_per_op_keys_amortised": 10.2e6, "frac_keys_amortised": round(value / world * 10.2e6 / (HBM_PEAK_GBS * 1e9), 4)}}
+
+    # the reference's operator boundary: the same ops as three library calls (Evaluator::multiply / relinearize / rescale_to_next), same buffers
+    three_call = None
+    if fused:
+        t3 = timed(torch, pass3, max(3, min(20, args.steps)))
+        three_call = round(world * B / shard.max_over_ranks(t3, device=device), 1)
 
     # secondary: the plain forward NTT of the key-switch digit shape (round-1's probe), not part of the timed region
     if rank == 0 and world == 1:
@@ -225,8 +329,14 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64 (q < 2^50: exact FP64-carried butterflies, canonical u64 residues at every call boundary)", "data": "synthetic",
         "config": {"workload": "CKKS N=16384, 6x50-bit coeff modulus (K=6, L=5): multiply + relinearize + rescale_to_next, "
-                               "batch of %d independent ciphertext pairs per GPU" % B,
-                   "batch_per_gpu": B, "entry": "troyn_ckks_multiply_relinearize_rescale" if fused else "troyn_dyadic_convolute + troyn_relinearize + troyn_divide_and_round_q_last_ntt",
+                               "batch of %d independent ciphertext pairs per GPU, %d passes over the batch per step" % (B, inner),
+                   "batch_per_gpu": B, "passes_per_step": inner, "ops_per_step": world * B * inner,
+                   "entry": "troyn_ckks_multiply_relinearize_rescale" if fused else "troyn_dyadic_convolute + troyn_relinearize + troyn_divide_and_round_q_last_ntt",
+                   "three_call_ops_per_s": three_call,
+                   "three_call_note": "the same ops through the reference's operator boundary -- troyn_dyadic_convolute + troyn_relinearize + "
+                                      "troyn_divide_and_round_q_last_ntt = Evaluator::multiply / relinearize / rescale_to_next -- on the same buffers, measured right "
+                                      "after the timed region; the fused entry is an addition to that boundary (troy::Evaluator::multiply_relinearize_rescale, "
+                                      "other_configs.cpp_api) with bit-identical results",
                    "parallelism": "batch-sharded x%d, keys broadcast once (RCCL)" % world},
         "roofline": roofline,
     }
@@ -243,6 +353,8 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
             e = c.relinearize(L, True, e, hk)
             return c.mod_switch_scale_to_next(L, e)
 
+        if fused:
+            one_pass()      # `out` holds the three-call results after the side measurement; both are checked
         items = CHECK_ITEMS(B)
         ops, t_cpu0 = 0, time.perf_counter()
         for i in items:
@@ -285,16 +397,23 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                                                 "sample": "%d ops by %d threads on independent copies in %.1f s" % (sum(counts), nthreads, t_mt)}}
         result["parity"] = "bit-exact vs CPU oracle (items %s of %d)" % (items, B)
 
-    # ---- north_star's other sizes, same run (rank 0, 1 GPU): N = 8192 and N = 32768 -------------------------------
+    # ---- the other BASELINE configurations and north_star's other sizes, same run (rank 0, 1 GPU) -------------------------------
     if rank == 0 and world == 1 and not args.no_extra:
-        del a, b, prod, relin, out
+        del a, b, prod, relin, out, plan
         torch.cuda.empty_cache()
-        result["other_configs"] = extra_configs(torch, pkg, device)
+        other = extra_configs(torch, pkg, device)
+        sub = parse_args(["--workload", "cfg4", "--total", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        other["cfg4"] = run_cfg4(sub, torch, pkg, shard, entry, 0, 1, device)
+        other["cfg4"]["note"] = "BASELINE configs[3] on one GPU with a 256-op job per step (`bench.py --workload cfg4` runs the 1024-op job and shards it over --gpus ranks)"
+        torch.cuda.empty_cache()
+        other["cfg5"] = run_cfg5(args, torch, pkg, entry, device)
+        other["cpp_api"] = run_cpp_api()
+        result["other_configs"] = other
     return result
 
 
 def extra_configs(torch, pkg, device):
-    """NTT + dyadic + INTT and relinearize throughput at N = 8192 (cfg2 shape) and N = 32768 (cfg4 shape); synthetic residues"""
+    """NTT + dyadic + INTT and relinearize throughput at N = 8192 (cfg2 shape), 16384 and 32768 (cfg4 shape); synthetic residues"""
     res = {}
     gen = torch.Generator(device=device).manual_seed(7)
     # the headline operation (CKKS multiply + relinearize + rescale, six 50-bit primes) at north_star's other two ring sizes
@@ -310,70 +429,58 @@ def extra_configs(torch, pkg, device):
                                                   "batch": Bn, "ops_per_s": round(Bn / t, 1)}
         del x, y, keys, out, plan
         torch.cuda.empty_cache()
-    # N = 8192, 3 x 40-bit (L = 2 data limbs): BASELINE configs[1]
-    n, Bn = 8192, 2048
-    q = pkg.capi.coeff_modulus_create(n, [40, 40, 40])
-    L = 2
-    plan = pkg.Plan(device, 13, q)
-    x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
-    xn, yn = torch.empty_like(x), torch.empty_like(y)
-    prod = torch.empty((Bn, 3, L, n), dtype=torch.int64, device=device)
-    keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
-    out2 = torch.empty((Bn, 2, L, n), dtype=torch.int64, device=device)
 
-    def pipe():
-        plan.ntt(x, 2, L, out=xn); plan.ntt(y, 2, L, out=yn)
-        plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod)
-        plan.ntt(prod, 3, L, inverse=True)
-    t = timed(torch, pipe, 10)
-    alg = 168.0 * n * L * Bn                                # 4 NTT (16 B/coeff) + dyadic (56) + 3 INTT (16), per limb coefficient
-    tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=False, is_ntt_form=False), 10)
-    behz = pkg.Behz(plan, L, 1032193)
-    tm = timed(torch, lambda: behz.multiply(x, 2, y, 2, out=prod), 10)
-    res["N8192_L2"] = {"what": "BFV N=8192, 3x40-bit (L=2): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (coefficient form); BEHZ multiply", "batch": Bn,
-                       "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
-                       "relinearize_ops_per_s": round(Bn / tr, 1), "multiply_ops_per_s": round(Bn / tm, 1)}
-    del x, y, xn, yn, prod, keys, out2, plan, behz
-    torch.cuda.empty_cache()
-    # N = 16384, 6 x 50-bit (L = 5): the headline's ring size, the same two pipelines as separate calls
-    n, Bn = 16384, 512
-    q = pkg.capi.coeff_modulus_create(n, [50] * 6)
-    L = 5
-    plan = pkg.Plan(device, 14, q)
-    x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
-    xn, yn = torch.empty_like(x), torch.empty_like(y)
-    prod = torch.empty((Bn, 3, L, n), dtype=torch.int64, device=device)
-    keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
-    out2 = torch.empty((Bn, 2, L, n), dtype=torch.int64, device=device)
-    t = timed(torch, lambda: (plan.ntt(x, 2, L, out=xn), plan.ntt(y, 2, L, out=yn), plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod),
-                              plan.ntt(prod, 3, L, inverse=True)), 10)
-    alg = 168.0 * n * L * Bn
-    tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=True, is_ntt_form=True), 10)
-    res["N16384_L5"] = {"what": "N=16384, 6x50-bit (L=5): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (NTT form)", "batch": Bn,
-                        "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
-                        "relinearize_ops_per_s": round(Bn / tr, 1)}
-    del x, y, xn, yn, prod, keys, out2, plan
-    torch.cuda.empty_cache()
-    # N = 32768, 11 x 50-bit (L = 10): BASELINE configs[3]
-    n, Bn = 32768, 64
-    q = pkg.capi.coeff_modulus_create(n, [50] * 11)
-    L = 10
-    plan = pkg.Plan(device, 15, q)
-    behz = pkg.Behz(plan, L, 1032193)
-    x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
-    xn, yn = torch.empty_like(x), torch.empty_like(y)
-    prod = torch.empty((Bn, 3, L, n), dtype=torch.int64, device=device)
-    keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
-    out2 = torch.empty((Bn, 2, L, n), dtype=torch.int64, device=device)
-    t = timed(torch, lambda: (plan.ntt(x, 2, L, out=xn), plan.ntt(y, 2, L, out=yn), plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod),
-                              plan.ntt(prod, 3, L, inverse=True)), 5)
-    alg = (7 * 32.0 + 56.0) * n * L * Bn                    # two-pass transforms move every coefficient twice (32 B)
-    tm = timed(torch, lambda: behz.multiply(x, 2, y, 2, out=prod), 5)
-    tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=False, is_ntt_form=False), 5)
-    res["N32768_L10"] = {"what": "BFV N=32768, 11x50-bit (L=10): NTT+dyadic+INTT; BEHZ multiply; relinearize; multiply+relinearize", "batch": Bn,
-                         "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
-                         "multiply_ops_per_s": round(Bn / tm, 1), "relinearize_ops_per_s": round(Bn / tr, 1),
-                         "multiply_relinearize_ops_per_s": round(Bn / (tm + tr), 1)}
+    def transform_pipeline(n, log_n, bits, L, Bn, key, what, ntt_form, two_pass=False, behz_t=0):
+        q = pkg.capi.coeff_modulus_create(n, bits)
+        K = len(q)
+        plan = pkg.Plan(device, log_n, q)
+        x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
+        xn, yn = torch.empty_like(x), torch.empty_like(y)
+        prod = torch.empty((Bn, 3, L, n), dtype=torch.int64, device=device)
+        keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
+        out2 = torch.empty((Bn, 2, L, n), dtype=torch.int64, device=device)
+
+        def pipe():
+            plan.ntt(x, 2, L, out=xn); plan.ntt(y, 2, L, out=yn)
+            plan.dyadic_convolute(xn, 2, yn, 2, L, out=prod)
+            plan.ntt(prod, 3, L, inverse=True)
+        reps = 10 if n < 32768 else 5
+        t = timed(torch, pipe, reps)
+        # 4 NTT (16 B/coeff) + dyadic (56) + 3 INTT (16) per limb coefficient; two-pass transforms move every coefficient twice
+        alg = ((7 * 32.0 + 56.0) if two_pass else 168.0) * n * L * Bn
+        with KernelTimer(pkg, plan.lib, TIMER_KS) as kt:
+            tr = timed(torch, lambda: plan.relinearize(L, prod, keys, out=out2, is_ckks=ntt_form, is_ntt_form=ntt_form), reps)
+            ks_ms, ks_n = kt.read()
+        # relinearize against SURVEY 8d's bytes for one key switch: keys 16 L K N (per op / once per batch) + target 8 L N + destination 16 L N
+        # (+ the c0, c1 read and the c2 INTT input of relinearize are left out: minimum traffic)
+        ks_keys, ks_rest = 16.0 * L * K * n, 24.0 * L * n
+        r = {"what": what, "batch": Bn, "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+             "relinearize_ops_per_s": round(Bn / tr, 1),
+             "relinearize_hbm_frac_keys_per_op": round((ks_keys + ks_rest) * Bn / tr / 1e9 / HBM_PEAK_GBS, 4),
+             "relinearize_hbm_frac_keys_once_per_batch": round((ks_keys + ks_rest * Bn) / tr / 1e9 / HBM_PEAK_GBS, 4)}
+        if ks_n:
+            r["relinearize_inner_product_launch_ms"] = round(ks_ms / ks_n, 4)
+            r["relinearize_inner_product_hbm_frac"] = round(ksmac_alg_bytes(Bn, n, L, ntt_form) / (ks_ms / ks_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if behz_t:
+            behz = pkg.Behz(plan, L, behz_t)
+            tm = timed(torch, lambda: behz.multiply(x, 2, y, 2, out=prod), reps)
+            r["multiply_ops_per_s"] = round(Bn / tm, 1)
+            r["multiply_relinearize_ops_per_s"] = round(Bn / (tm + tr), 1)
+            del behz
+        res[key] = r
+        del x, y, xn, yn, prod, keys, out2, plan
+        torch.cuda.empty_cache()
+
+    transform_pipeline(8192, 13, [40, 40, 40], 2, 2048, "N8192_L2",
+                       "BFV N=8192, 3x40-bit (L=2, BASELINE configs[1]): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (coefficient form); BEHZ multiply",
+                       False, behz_t=1032193)
+    transform_pipeline(16384, 14, [50] * 6, 5, 512, "N16384_L5",
+                       "N=16384, 6x50-bit (L=5): NTT(a), NTT(b) + dyadic 2x2->3 + INTT(3) as separate calls; relinearize (NTT form)", True)
+    transform_pipeline(32768, 15, [50] * 11, 10, 64, "N32768_L10",
+                       "BFV N=32768, 11x50-bit (L=10): NTT+dyadic+INTT; BEHZ multiply; relinearize; multiply+relinearize", False, two_pass=True, behz_t=1032193)
+    # the reference's default chain (test/bench/he_operations.cu:19-33): 60-bit primes take the integer policy
+    transform_pipeline(8192, 13, [60, 40, 40, 60], 3, 1024, "N8192_60_40_40_60",
+                       "N=8192 {60,40,40,60} (L=3, K=4; the reference bench tool's default log_q): transforms split by modulus class, relinearize (NTT form)", True)
     return res
 
 
@@ -387,6 +494,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     mine = hi - lo
     plan = pkg.Plan(device, log_n, q)
     behz = pkg.Behz(plan, L, t_plain)
+    S = len(behz.base_Bsk)
     gen = torch.Generator(device=device).manual_seed(0x123)      # the same job on every world size: item i has the same payload
     kgen = torch.Generator(device=device).manual_seed(0xC0FFEE)
     keys = [uniform_residues(torch, (2,), q, n, device, kgen) for _ in range(L)]
@@ -396,6 +504,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     y = uniform_residues(torch, (nb, 2), q[:L], n, device, gen)
     prod = torch.empty((nb, 3, L, n), dtype=torch.int64, device=device)
     out = torch.empty((nb, 2, L, n), dtype=torch.int64, device=device)
+    launches = [0]
 
     def step():
         done = 0
@@ -404,19 +513,62 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
             behz.multiply(x[:c], 2, y[:c], 2, out=prod[:c])                                         # Evaluator::multiply (BFV, BEHZ)
             plan.relinearize(L, prod[:c], keys, out=out[:c], is_ckks=False, is_ntt_form=False)      # Evaluator::relinearize
             done += c
+            launches[0] += 1
 
     for _ in range(args.warmup):
         step()
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    shard.barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=device)
+    lib = plan.lib
+    launches[0] = 0
+    with KernelTimer(pkg, lib, TIMER_KS) as kt_ks, KernelTimer(pkg, lib, TIMER_TENSOR) as kt_t, KernelTimer(pkg, lib, TIMER_FLOOR) as kt_f:
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        elapsed = time.perf_counter() - t0
+        ks_ms, ks_n = kt_ks.read()
+        tn_ms, tn_n = kt_t.read()
+        fl_ms, fl_n = kt_f.read()
+    elapsed = shard.max_over_ranks(elapsed, device=device)
     value = args.total * args.steps / elapsed
-    return {
+
+    # ---- roofline: the launch with the largest share of the step.  Full chunks only (the job is a multiple of the chunk in every quoted run).
+    share = lambda ms: 100.0 * ms / (elapsed * 1e3)
+    ks_launch_ms = ks_ms / max(1, ks_n)
+    ks_alg = ksmac_alg_bytes(nb, n, L, False)
+    # tensor_core_kernel: per limb 4 operand rows read + 3 result rows written (8*N bytes each), L limbs of base q + S limbs of base Bsk per item;
+    # the region brackets both bases' launches of a chunk, so per multiply call
+    tn_call_ms = tn_ms / max(1, launches[0])
+    tn_alg = nb * 7.0 * 8 * n * (L + S)
+    fl_call_ms = fl_ms / max(1, fl_n)
+    fl_alg = nb * 3 * 8.0 * n * (2 * L + S)     # behz2_floor: per result polynomial L + S limbs read, L written
+    kernels = {
+        "ksmac2_kernel<15> (key-switch inner product, quarter tiles)": {"launch_ms": round(ks_launch_ms, 4), "share_of_step_pct": round(share(ks_ms), 1),
+                                                                       "algorithmic_bytes_per_launch": ks_alg, "hbm_frac": round(ks_alg / (ks_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks_n else None},
+        "tensor_core_kernel (last forward pass + tensor product + first inverse pass, base q FP64 + base Bsk integer)": {
+            "ms_per_multiply_call": round(tn_call_ms, 4), "share_of_step_pct": round(share(tn_ms), 1), "algorithmic_bytes_per_call": tn_alg,
+            "hbm_frac": round(tn_alg / (tn_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tn_n else None},
+        "behz2_floor_kernel<10>": {"launch_ms": round(fl_call_ms, 4), "share_of_step_pct": round(share(fl_ms), 1), "algorithmic_bytes_per_launch": fl_alg,
+                                   "hbm_frac": round(fl_alg / (fl_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fl_n else None},
+    }
+    dominant_is_ks = ks_ms >= tn_ms
+    dom_alg, dom_ms = (ks_alg, ks_launch_ms) if dominant_is_ks else (tn_alg, tn_call_ms)
+    achieved = dom_alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+    # SURVEY 8d bytes per op: multiply 18.4 MB (operands 2 x 5 MB read + product 7.5 MB written, rounded as the survey does) + relinearize 70.8 MB with
+    # the keys per op, 13.1 MB with the keys once per launch
+    per_gpu = value / world
+    roofline = {"bound": "valu_fp64" if dominant_is_ks else "valu_int",
+                "bound_note": "issue-bound arithmetic (FP64 butterflies in ksmac2, integer butterflies of the 61-bit BEHZ base in tensor_core_kernel<ArithU64>); achieved / peak / "
+                              "frac are the contract's HBM figures for the dominant launch, timed in this run by the library's kernel timer",
+                "kernel": "ksmac2_kernel<15>" if dominant_is_ks else "tensor_core_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
+                "algorithmic_bytes_per_launch": dom_alg, "kernels": kernels,
+                "pipeline": {"bytes_per_op_keys_per_op": 89.2e6, "frac_keys_per_op": round(per_gpu * 89.2e6 / (HBM_PEAK_GBS * 1e9), 4),
+                             "bytes_per_op_keys_once_per_launch": 18.4e6 + 13.1e6 + 57.7e6 / nb,
+                             "frac_keys_once_per_launch": round(per_gpu * (18.4e6 + 13.1e6 + 57.7e6 / nb) / (HBM_PEAK_GBS * 1e9), 4)}}
+    result = {
         "metric": "homomorphic mul+relinearize ops/sec (BFV BEHZ multiply + relinearize), N=32768", "value": round(value, 1), "unit": "ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -424,20 +576,185 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         "config": {"workload": "BFV N=32768, 11x50-bit coeff modulus (K=11, L=10), t=1032193: %d independent multiply + relinearize ops per step, "
                                "block-partitioned over %d rank(s) (rank 0: items [%d, %d)), %d per launch" % (args.total, world, lo, hi, nb),
                    "total_ops_per_step": args.total, "parallelism": "batch-sharded x%d (shard.shard_range), keys broadcast once (RCCL)" % world},
-        "roofline": None,
+        "roofline": roofline,
     }
+    if rank == 0 and not args.no_cpu_baseline:
+        import numpy as np
+        O = entry.load_oracle()
+        ctx = O.Context("bfv", n, q, t_plain)
+        hk = [pkg.to_host(k) for k in keys]
+
+        def one_op(ha, hb):
+            return ctx.relinearize(L, False, ctx.bfv_multiply(L, ha, hb), hk)
+
+        items = sorted({0, 1, nb - 1})
+        ops, t0 = 0, time.perf_counter()
+        for i in items:
+            exp = one_op(pkg.to_host(x[i]), pkg.to_host(y[i]))
+            ops += 1
+            if not np.array_equal(pkg.to_host(out[i]), exp):
+                raise AssertionError("bench cfg4: GPU result of item %d differs from the CPU oracle" % i)
+        ha, hb = pkg.to_host(x[0]), pkg.to_host(y[0])
+        while time.perf_counter() - t0 < args.cpu_seconds and world == 1:
+            one_op(ha, hb)
+            ops += 1
+        t_cpu = time.perf_counter() - t0
+        result["parity"] = "bit-exact vs CPU oracle (items %s of the last chunk of %d)" % (items, nb)
+        result["cpu_baseline"] = {"value": round(ops / t_cpu, 3), "unit": "ops/s", "cores": 1, "kind": "port",
+                                  "sample": "%d sequential BEHZ multiply + relinearize ops (items %s of the same workload, then item 0 repeated; %.1f s, "
+                                            "oracle/troy_oracle.c, gcc -O3, 1 thread of %d host cores)" % (ops, items, t_cpu, os.cpu_count())}
+    del x, y, prod, out, keys, behz, plan
+    return result
+
+
+def run_cfg5(args, torch, pkg, entry, device):
+    """BASELINE configs[4]: BFV 512x512x512 matmul (examples/10_bfv_matmul.cu at that size), N=8192 {60,40,40,60}, t = 2^21, packed outputs.
+    value = end-to-end latency encrypt -> matmul -> mod-switch -> pack -> add bias -> decrypt through MatmulHelper (tests/cpp/matmul_driver, a
+    child process); roofline = the ct x pt multiply-accumulate launch of the same block shape, timed here by the library's kernel timer;
+    cpu_baseline = the oracle's restatement of the reference's host branches for the same flow, per-object timings on a bounded sample multiplied out."""
+    import ctypes as C
+    res = {"metric": "BFV 512x512x512 packed matmul end-to-end latency (encrypt -> decrypt), N=8192", "unit": "ms", "higher_is_better": False, "data": "synthetic",
+           "dtype": "u64 ({60,40,40,60}: 60-bit limb on integer butterflies, 40-bit limbs on exact-FP64 butterflies)"}
+    drv = os.path.join(ROOT, "tests", "cpp", "matmul_driver")
+    if os.path.exists(drv):
+        r = subprocess.run([drv, "512", "512", "512", "5", "1", "1"], capture_output=True, text=True, timeout=900)
+        lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+        if r.returncode == 0 and "ms" in lines:
+            ms = dict(zip(lines["ms"][0::2], [float(v) for v in lines["ms"][1::2]]))
+            rep = dict(zip(lines["ms_repeat"][0::2], [float(v) for v in lines["ms_repeat"][1::2]]))
+            first = ms["encrypt_inputs"] + ms["matmul_repeat"] + ms["mod_switch"] + ms["pack"] + ms["add_bias"] + ms["decrypt"]
+            steady = rep["encrypt_inputs"] + ms["matmul_repeat"] + ms["mod_switch"] + ms["pack"] + ms["add_bias"] + rep["decrypt"]
+            res.update({"value": round(steady, 3),
+                        "config": {"workload": "y = x*w + s, 512x512x512 over Z_{2^21}, MatmulHelper block %s, %s; encrypted inputs x plaintext weights, mod-switched and "
+                                               "LWE-packed outputs" % ("x".join(lines["block"][:3]), " ".join(lines["objects"])),
+                                   "phases_ms": ms, "steady_state_ms": rep, "first_call_latency_ms": round(first, 3),
+                                   "latency_definition": "encrypt_inputs + matmul + mod_switch + pack + add_bias + decrypt, client phases at their steady state "
+                                                         "(buffers already in the pool); the wire-format save / load phases are listed in phases_ms and not part of the value"},
+                        "parity": "all 262144 outputs equal the plain product mod 2^21; on-the-fly weight encoding gives word-identical ciphertexts" if "OK" in r.stdout else "FAILED"})
+        else:
+            res["error"] = (r.stdout + r.stderr)[-500:]
+    else:
+        res["error"] = "tests/cpp/matmul_driver is not built"
+
+    # ---- roofline of the dominant launch: the ct x pt multiply-accumulate over the same block shape (32 x 512 weight plaintexts, one input block row) ----
+    n, I, J, Bt, L = 8192, 32, 512, 1, 3
+    q = pkg.capi.coeff_modulus_create(n, [60, 40, 40, 60])
+    plan = pkg.Plan(device, 13, q)
+    gen = torch.Generator(device=device).manual_seed(11)
+    av = uniform_residues(torch, (Bt, I, 2), q[:L], n, device, gen)
+    w = torch.empty((I, J, L, n), dtype=torch.int64, device=device)
+    for l, m in enumerate(q[:L]):
+        w[:, :, l, :].random_(0, m, generator=gen)
+    out = torch.empty((Bt, J, 2, L, n), dtype=torch.int64, device=device)
+    cts, pts, dsts = [], [], []
+    for i in range(I):
+        for j in range(J):
+            for b in range(Bt):
+                cts.append(av[b, i].data_ptr()); pts.append(w[i, j].data_ptr()); dsts.append(out[b, j].data_ptr())
+    terms = len(cts)
+    arr = lambda v: (C.c_void_p * terms)(*v)
+    ca, pa, da = arr(cts), arr(pts), arr(dsts)
+    nbytes = plan.lib.troyn_multiply_plain_accumulate_workspace_bytes(terms)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def mac():
+        pkg.capi.check(plan.lib.troyn_multiply_plain_accumulate(plan.h, 0, L, 2, ca, pa, da, terms, 1, C.c_void_p(ws.data_ptr()), ws.numel(), stream))
+    with KernelTimer(pkg, plan.lib, TIMER_PLAIN_MAC) as kt:
+        t_call = timed(torch, mac, 10)
+        k_ms, k_n = kt.read()
+    launch_ms = k_ms / max(1, k_n)
+    # each operand once: every weight plaintext (L limbs), every input ciphertext (2 L limbs) read once, every output ciphertext written once
+    alg = terms * L * n * 8.0 + Bt * I * 2 * L * n * 8.0 + Bt * J * 2 * L * n * 8.0
+    achieved = alg / (launch_ms * 1e-3) / 1e9 if k_n else 0.0
+    res["roofline"] = {"bound": "hbm", "kernel": "plain_mac2_kernel<2> (multiply_plain_ntt_accumulate over %d terms: %d x %d weight plaintexts, %d input block row(s))" % (terms, I, J, Bt),
+                       "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                       "launch_ms": round(launch_ms, 4), "launches_timed": k_n, "call_ms_with_pointer_table_upload": round(t_call * 1e3, 4),
+                       "algorithmic_bytes_per_launch": alg}
+    # parity of that launch: two destinations against the oracle's multiply_plain_ntt + add
+    if not args.no_cpu_baseline:
+        import numpy as np
+        O = entry.load_oracle()
+        ctx = O.Context("bfv", n, q, 1 << 21)
+        mac()
+        torch.cuda.synchronize()
+        qa = np.array(q[:L], dtype=np.uint64)[None, :, None]
+        for j in (0, J - 1):
+            acc = np.zeros((2, L, n), dtype=np.uint64)
+            for i in range(I):
+                acc = (acc + ctx.multiply_plain_ntt(L, pkg.to_host(av[0, i]), pkg.to_host(w[i, j]))) % qa
+            if not np.array_equal(pkg.to_host(out[0, j]), acc):
+                raise AssertionError("bench cfg5: multiply-accumulate destination %d differs from the CPU oracle" % j)
+        res["roofline"]["parity"] = "destinations 0 and %d of the timed launch bit-exact vs the CPU oracle" % (J - 1)
+        # ---- CPU baseline of the packed flow: the oracle, one host thread, per-object timings multiplied out ----
+        ct, pt = ctx.random_ct(1, 2, 3), ctx.random_ct(2, 1, 3)[0]
+        acc = np.zeros_like(ct)
+        sample, t0 = 1500, time.perf_counter()
+        for _ in range(sample):
+            term = ctx.multiply_plain_ntt(3, ct, pt)
+            acc = (acc + term) % qa
+        per_term = (time.perf_counter() - t0) / sample
+        rng = O.Rng(3)
+        sk = ctx.secret_key(rng)
+        pk = ctx.public_key(rng, sk)
+        msg = O.fill_uniform(9, 1 << 21, 8192)
+
+        def cpu_timed(fn, reps):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                o = fn()
+            return (time.perf_counter() - t0) / reps, o
+        t_enc, c = cpu_timed(lambda: ctx.encrypt_asymmetric_bfv(rng, pk, msg), 3)
+        t_ntt, _ = cpu_timed(lambda: ctx.from_ntt(ctx.to_ntt(c, 2, 3), 2, 3), 3)            # one forward + one inverse transform of a ciphertext
+        t_dec, _ = cpu_timed(lambda: ctx.decrypt_bfv(sk, c), 3)
+        t_ms, low = cpu_timed(lambda: ctx.mod_switch_scale_to_next(3, c), 3)
+        gkeys = {(8192 // 16) * (1 << (k + 1)) + 1: ctx.random_keys(50 + k, 2) for k in range(4)}
+        t_pack, _ = cpu_timed(lambda: ctx.pack_rlwe_ciphertexts(2, [low] * 16, gkeys, 2 * 8192 - 15, 16, 1), 1)
+        phases = {"encrypt_32_inputs": t_enc * 32, "ntt_32_inputs_intt_512_outputs": t_ntt / 2 * (32 + 512), "matmul_core_16384_terms": per_term * terms,
+                  "mod_switch_512_outputs": t_ms * 512, "pack_32_groups_of_16": t_pack * 32, "decrypt_32_outputs": t_dec * 32}
+        res["cpu_baseline"] = {"value": round(sum(phases.values()) * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "oracle (oracle/troy_oracle.c, gcc -O3, one host thread of %d cores): %d of the %d multiply_plain_ntt + add terms, 3 encryptions / "
+                                         "transform pairs / decryptions / modulus switches and one packing tree of 16, each multiplied out to the flow's object counts "
+                                         "(src/app/matmul.cu:326-374 matmul + examples/10_bfv_matmul.cu)" % (os.cpu_count(), sample, terms),
+                               "phases_ms": {k: round(v * 1e3, 1) for k, v in phases.items()}}
+    del av, w, out, ws, plan
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_cpp_api():
+    """BASELINE config 3 through the C++ mirror of the reference's API (troy::Evaluator), timed by the troybench-shaped driver in a child process"""
+    drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
+    if not os.path.exists(drv):
+        return {"error": "tests/cpp/he_bench_driver is not built"}
+    r = subprocess.run([drv, "bench", "10"], capture_output=True, text=True, timeout=900)
+    kv = {ln.split()[0]: ln.split()[1] for ln in r.stdout.splitlines() if len(ln.split()) == 2}
+    if r.returncode != 0 or "OK" not in r.stdout:
+        return {"error": (r.stdout + r.stderr)[-500:]}
+    out = {"what": "CKKS N=16384 6x50-bit through troy::Evaluator (tests/cpp/he_bench_driver.cpp, shaped like the reference's test/bench/he_operations.cu): "
+                   "three_calls = multiply + relinearize + rescale_to_next (single objects: *_new with a stream synchronisation after every call as the tool does; "
+                   "batches: *_batched), fused = Evaluator::multiply_relinearize_rescale{_new,_batched}; threads = host threads with their own operands",
+           "fused_identical_to_three_calls": all(kv.get(k) == "1" for k in ("fused_single_identical", "fused_inplace_identical", "fused_batched_identical", "fused_mixed_levels_identical"))}
+    for k, v in kv.items():
+        if k.startswith(("single_", "batched_")):
+            out[k] = float(v)
+    return out
 
 
 def dry_run(args, rank, world):
     import torch
     import importlib
     import __graft_entry__ as entry
+    if rank == args.dry_fail_rank:
+        sys.stderr.write("bench.py --dry-run: rank %d fails on purpose\n" % rank)
+        return 7
     entry.load_package()
     shard = importlib.import_module("troy_nova_amd.shard")
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     keys = [torch.full((2, 3, 8), 100 + j if rank == 0 else -1, dtype=torch.int64) for j in range(2)]
     shard.broadcast_tensors(keys, src=0)
     ok = all(int(k[0, 0, 0]) == 100 + j for j, k in enumerate(keys))
@@ -466,7 +783,7 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         return 2
-    if args.workload == "cfg4" and args.steps == 200:
+    if args.workload == "cfg4" and args.steps == 20:
         args.steps = 5                          # one step = the whole 1024-op job
     if args.dry_run:
         return dry_run(args, rank, world)
@@ -478,9 +795,10 @@ def main():
     torch.cuda.set_device(local_rank)             # before the process group: RCCL binds its communicator to the current device
     device = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     pkg = entry.load_package()
     import importlib
     shard = importlib.import_module("troy_nova_amd.shard")

@@ -56,8 +56,12 @@ int troyn_version(void);
  *   troyn_kernel_timer_enable(region, on)   start / stop recording an event pair around every launch of that region
  *   troyn_kernel_timer_read(region, &ms, &n) wait for the recorded events, return their summed duration and count, and clear
  * Region TROYN_TIMER_KS_INNER_PRODUCT = the fused key-switch inner product (kernel_set_accumulate + ntt +
- * kernel_accumulate_products of fgk/switch_key.cu, one launch here). */
-enum { TROYN_TIMER_KS_INNER_PRODUCT = 0, TROYN_TIMER_REGIONS = 1 };
+ * kernel_accumulate_products of fgk/switch_key.cu, one launch here);
+ * TROYN_TIMER_BFV_TENSOR = the transform + tensor-product launches of bfv_multiply (ntt_inplace_ps x2 + kernel_dyadic_convolute +
+ * intt_inplace_ps, evaluator.cu:56-93; one launch per base and arithmetic class here);
+ * TROYN_TIMER_PLAIN_MAC = the ct x pt multiply-accumulate launch (multiply_plain_ntt_accumulate, evaluator_multiply_plain.cu:356-385);
+ * TROYN_TIMER_BEHZ_FLOOR = fast_floor_fast_b_conv_sk (fgk/rns_tool.cu:147-343). */
+enum { TROYN_TIMER_KS_INNER_PRODUCT = 0, TROYN_TIMER_BFV_TENSOR = 1, TROYN_TIMER_PLAIN_MAC = 2, TROYN_TIMER_BEHZ_FLOOR = 3, TROYN_TIMER_REGIONS = 4 };
 int troyn_kernel_timer_enable(int region, int on);
 int troyn_kernel_timer_read(int region, double* total_ms, uint64_t* launches);
 

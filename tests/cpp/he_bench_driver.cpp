@@ -1,0 +1,191 @@
+// troybench-shaped C++ driver (the reference's bench tool: test/bench/he_operations.cu:57-135, :695-735 "MultiplyRelinearize" and
+// :811-840 "RescaleToNext"): BASELINE config 3 -- CKKS N = 16384, 6 x 50-bit -- timed THROUGH troy::Evaluator, the reference's seam:
+//   * single objects: multiply_new + relinearize_new + rescale_to_next_new per op, stream synchronised after every call as the tool does
+//     (he_operations.cu:711-720), and the fused Evaluator::multiply_relinearize_rescale_new;
+//   * batches of 64 / 256 / 1024 ciphertext pairs: multiply_batched + relinearize_batched + rescale_to_next_batched, and
+//     multiply_relinearize_rescale_batched;  1 and 4 host threads (the tool's -c option), every thread with its own operands.
+// Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
+// decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
+//   he_bench_driver [check|bench] [repeat]
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <thread>
+
+#include "../../troy-nova_amd/troy/troy.h"
+
+using namespace troy;
+using cd = std::complex<double>;
+using clk = std::chrono::steady_clock;
+
+static double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct World {
+    HeContextPointer context;
+    std::unique_ptr<CKKSEncoder> encoder;
+    std::unique_ptr<KeyGenerator> keygen;
+    std::unique_ptr<Encryptor> encryptor;
+    std::unique_ptr<Decryptor> decryptor;
+    std::unique_ptr<Evaluator> evaluator;
+    RelinKeys rk;
+    double scale = std::pow(2.0, 40);
+};
+
+static bool same_ct(const Ciphertext& a, const Ciphertext& b) {
+    if (a.parms_id() != b.parms_id() || a.scale() != b.scale() || a.is_ntt_form() != b.is_ntt_form() || a.polynomial_count() != b.polynomial_count() ||
+        a.coeff_modulus_size() != b.coeff_modulus_size()) return false;
+    Ciphertext ha = a.to_host(), hb = b.to_host();
+    return ha.data().size() == hb.data().size() && std::memcmp(ha.data().raw_pointer(), hb.data().raw_pointer(), ha.data().size() * 8) == 0;
+}
+
+int main(int argc, char** argv) {
+    const bool bench = argc > 1 && std::strcmp(argv[1], "bench") == 0;
+    const size_t repeat = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 20;
+    try {
+        const size_t n = 16384;
+        World w;
+        EncryptionParameters params(SchemeType::CKKS);
+        params.set_poly_modulus_degree(n);
+        params.set_coeff_modulus(CoeffModulus::create(n, {50, 50, 50, 50, 50, 50}));
+        w.context = HeContext::create(params, true, SecurityLevel::Classical128, 0x123);
+        w.context->to_device_inplace();
+        w.encoder.reset(new CKKSEncoder(w.context));
+        w.keygen.reset(new KeyGenerator(w.context));
+        w.encryptor.reset(new Encryptor(w.context));
+        w.encryptor->set_public_key(w.keygen->create_public_key(false));
+        w.decryptor.reset(new Decryptor(w.context, w.keygen->secret_key()));
+        w.evaluator.reset(new Evaluator(w.context));
+        w.rk = w.keygen->create_relin_keys(false);
+        const Evaluator& ev = *w.evaluator;
+
+        const size_t slots = w.encoder->slot_count();
+        std::mt19937_64 gen(11);
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        auto fresh = [&](std::vector<cd>& z) {
+            z.resize(slots);
+            for (auto& v : z) v = cd(U(gen), U(gen));
+            return w.encryptor->encrypt_asymmetric_new(w.encoder->encode_complex64_simd_new(z, std::nullopt, w.scale));
+        };
+        std::vector<cd> z1, z2;
+        Ciphertext c1 = fresh(z1), c2 = fresh(z2);
+
+        // ---- parity of the fused method with the three calls + semantics --------------------------------------------------------------
+        Ciphertext m3 = ev.multiply_new(c1, c2);
+        ev.relinearize_inplace(m3, w.rk);
+        ev.rescale_to_next_inplace(m3);
+        Ciphertext m1 = ev.multiply_relinearize_rescale_new(c1, c2, w.rk);
+        std::printf("fused_single_identical %d\n", same_ct(m1, m3) ? 1 : 0);
+        {
+            std::vector<cd> got = w.encoder->decode_complex64_simd_new(w.decryptor->decrypt_new(m1));
+            double e = 0;
+            for (size_t i = 0; i < slots; i++) e = std::max(e, std::abs(got[i] - z1[i] * z2[i]));
+            std::printf("fused_single_error %.3e\n", e);
+        }
+        Ciphertext ip = c1;
+        ev.multiply_relinearize_rescale_inplace(ip, c2, w.rk);
+        std::printf("fused_inplace_identical %d\n", same_ct(ip, m3) ? 1 : 0);
+        {
+            // a batch of distinct pairs (16: above BATCH_OP_THRESHOLD, a multiple of 8 = the XCD-grouped order of the inner product)
+            const size_t B = 16;
+            std::vector<Ciphertext> a(B), b(B), d3(B), d1(B), t1(B), t2(B);
+            std::vector<cd> z;
+            for (size_t i = 0; i < B; i++) { a[i] = fresh(z); b[i] = fresh(z); }
+            std::vector<const Ciphertext*> pa, pb, pt1, pt2; std::vector<Ciphertext*> pd3, pd1, q1, q2;
+            for (size_t i = 0; i < B; i++) { pa.push_back(&a[i]); pb.push_back(&b[i]); pd3.push_back(&d3[i]); pd1.push_back(&d1[i]); q1.push_back(&t1[i]); q2.push_back(&t2[i]); pt1.push_back(&t1[i]); pt2.push_back(&t2[i]); }
+            ev.multiply_batched(pa, pb, q1);
+            ev.relinearize_batched(pt1, w.rk, q2);
+            ev.rescale_to_next_batched(pt2, pd3);
+            ev.multiply_relinearize_rescale_batched(pa, pb, w.rk, pd1);
+            int ok = 1;
+            for (size_t i = 0; i < B; i++) {
+                ok &= same_ct(d1[i], d3[i]) ? 1 : 0;
+                Ciphertext s = ev.multiply_relinearize_rescale_new(a[i], b[i], w.rk);
+                ok &= same_ct(d1[i], s) ? 1 : 0;
+            }
+            std::printf("fused_batched_identical %d\n", ok);
+            // a non-uniform batch (one operand at a lower level) takes the per-object path and still equals the three calls
+            Ciphertext lo_a = ev.mod_switch_to_next_new(a[0]), lo_b = ev.mod_switch_to_next_new(b[0]);
+            pa[3] = &lo_a; pb[3] = &lo_b;
+            ev.multiply_relinearize_rescale_batched(pa, pb, w.rk, pd1);
+            Ciphertext r = ev.multiply_new(lo_a, lo_b); ev.relinearize_inplace(r, w.rk); ev.rescale_to_next_inplace(r);
+            std::printf("fused_mixed_levels_identical %d\n", (same_ct(d1[3], r) && same_ct(d1[2], d3[2])) ? 1 : 0);
+        }
+        // the reference's error behaviour survives the fusion
+        {
+            int caught = 0;
+            try { Ciphertext c1c = ev.transform_from_ntt_new(c1); ev.multiply_relinearize_rescale_new(c1c, c2, w.rk); } catch (const std::invalid_argument&) { caught++; }
+            Ciphertext bottom = c1;
+            while (bottom.parms_id() != w.context->last_parms_id()) ev.mod_switch_to_next_inplace(bottom);
+            try { ev.multiply_relinearize_rescale_new(bottom, bottom, w.rk); } catch (const std::invalid_argument&) { caught++; }
+            std::printf("fused_errors %d\n", caught);
+        }
+        if (!bench) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
+
+        // ---- single objects (the tool's loop: every call followed by a stream synchronisation) -----------------------------------------
+        for (int fused = 0; fused < 2; fused++) {
+            const size_t reps = 200;
+            for (size_t i = 0; i < 10; i++) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, w.rk); }
+            troyn_sync_current_stream();
+            auto t0 = clk::now();
+            for (size_t i = 0; i < reps; i++) {
+                if (fused) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, w.rk); troyn_sync_current_stream(); }
+                else {
+                    Ciphertext t = ev.multiply_new(c1, c2); troyn_sync_current_stream();
+                    Ciphertext r = ev.relinearize_new(t, w.rk); troyn_sync_current_stream();
+                    Ciphertext s = ev.rescale_to_next_new(r); troyn_sync_current_stream();
+                }
+            }
+            const double dt = secs(t0, clk::now());
+            std::printf("single_%s_us_per_op %.2f\n", fused ? "fused" : "three_calls", dt / reps * 1e6);
+        }
+
+        // ---- batched forms ----------------------------------------------------------------------------------------------------------------
+        const size_t maxB = 1024, threads_max = 4;
+        // operands: one contiguous block per thread (what *_batched returns, so `contiguous()` uses them in place), made by transform round trips
+        std::vector<std::vector<Ciphertext>> A(threads_max), Bv(threads_max);
+        for (size_t t = 0; t < threads_max; t++) {
+            std::vector<Ciphertext> sa(maxB, c1), sb(maxB, c2);
+            std::vector<const Ciphertext*> pa, pb; std::vector<Ciphertext*> qa, qb;
+            A[t].resize(maxB); Bv[t].resize(maxB);
+            for (size_t i = 0; i < maxB; i++) { pa.push_back(&sa[i]); pb.push_back(&sb[i]); qa.push_back(&A[t][i]); qb.push_back(&Bv[t][i]); }
+            ev.negate_batched(pa, qa);       // adjacent windows of one buffer
+            ev.negate_batched(pb, qb);
+        }
+        for (size_t threads : {(size_t)1, (size_t)4}) {
+            for (size_t B : {(size_t)64, (size_t)256, (size_t)1024}) {
+                for (int fused = 0; fused < 2; fused++) {
+                    std::vector<double> elapsed(threads, 0.0);
+                    auto body = [&](size_t t) {
+                        std::vector<const Ciphertext*> pa, pb; std::vector<Ciphertext> d(B), t1(B), t2(B); std::vector<Ciphertext*> pd, q1, q2; std::vector<const Ciphertext*> pt1, pt2;
+                        for (size_t i = 0; i < B; i++) { pa.push_back(&A[t][i]); pb.push_back(&Bv[t][i]); pd.push_back(&d[i]); q1.push_back(&t1[i]); q2.push_back(&t2[i]); pt1.push_back(&t1[i]); pt2.push_back(&t2[i]); }
+                        auto once = [&] {
+                            if (fused) ev.multiply_relinearize_rescale_batched(pa, pb, w.rk, pd);
+                            else { ev.multiply_batched(pa, pb, q1); ev.relinearize_batched(pt1, w.rk, q2); ev.rescale_to_next_batched(pt2, pd); }
+                        };
+                        once(); once();
+                        troyn_sync_current_stream();
+                        auto t0 = clk::now();
+                        for (size_t r = 0; r < repeat; r++) once();
+                        troyn_sync_current_stream();
+                        elapsed[t] = secs(t0, clk::now());
+                    };
+                    std::vector<std::thread> th;
+                    for (size_t t = 0; t < threads; t++) th.emplace_back(body, t);
+                    for (auto& x : th) x.join();
+                    double mx = 0; for (double e : elapsed) mx = std::max(mx, e);
+                    std::printf("batched_%s_threads%zu_batch%zu_ops_per_s %.1f\n", fused ? "fused" : "three_calls", threads, B, (double)(threads * B * repeat) / mx);
+                }
+            }
+        }
+        std::printf("OK\n");
+        A.clear(); Bv.clear();
+        MemoryPool::Destroy();
+        return 0;
+    } catch (const std::exception& e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 1;
+    }
+}

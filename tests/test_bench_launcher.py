@@ -33,6 +33,17 @@ def test_self_launcher_starts_two_ranks():
     assert j["max_elapsed"] == 0.002 and j["scaling"] == "strong"
 
 
+def test_launcher_watchdog_ends_the_job_when_a_rank_dies():
+    """rank 1 exits before the rendezvous: the launcher terminates rank 0 (which waits in init_process_group) and reports the failure
+    within seconds instead of the store / collective timeout"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--dry-run", "--dry-fail-rank", "1"])
+    assert r.returncode == 1 and "rank(s) failed" in r.stderr and "(1, 7)" in r.stderr, r.stderr
+    assert "rank 1 fails on purpose" in r.stderr          # per-rank stderr attribution
+    assert time.time() - t0 < 60
+
+
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "4", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

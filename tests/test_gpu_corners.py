@@ -150,24 +150,36 @@ def test_rescale_corner_vectors(O, pkg, dev, n, bits, L):
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i])), nm
 
 
-def test_pipeline_corner_vectors(O, pkg, dev):
-    """multiply -> relinearize -> rescale at BASELINE config 3's parameters on extreme operands"""
-    n, L = 16384, 5
-    q = O.coeff_modulus_create(n, [50] * 6)
+@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [50] * 5, 4), (32768, [50] * 4, 3)])
+@pytest.mark.parametrize("key_kind", ["random", "all_q-1"])
+def test_pipeline_corner_vectors(O, pkg, dev, n, bits, L, key_kind):
+    """multiply -> relinearize -> rescale on extreme operands, through the three calls AND through the fused entry (the path bench.py
+    times): the fused tail sums scale_by + two tensor products - y to ~3.1 p before its re-centring, the MULPAIR / LAST_LIMB loaders and
+    the double-format digits have their own range assumptions -- all exercised at the edges here, with random keys and keys that are all q-1"""
+    q = O.coeff_modulus_create(n, bits)
+    K = len(q)
     ctx = O.Context("ckks", n, q)
-    plan = pkg.Plan(dev, 14, q)
-    keys = ctx.random_keys(11, L)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    if key_kind == "random":
+        keys = ctx.random_keys(11, L)
+    else:
+        keys = [np.stack([np.stack([np.full(n, q[k] - 1, dtype=np.uint64) for k in range(K)]) for c in range(2)]) for j in range(L)]
     dkeys = [pkg.to_device(k, dev) for k in keys]
-    names = ["all_q-1", "alt_0_q-1", "half_hi", "ramp_top"]
+    names = ["all_q-1", "alt_0_q-1", "half_hi", "ramp_top", "alt_q-1_0", "half_lo", "impulse_0", "blocks32"]     # 8 items: the XCD-grouped order
     a = np.stack([_corner_ct(q, L, n, 2, nm) for nm in names])
     b = np.stack([_corner_ct(q, L, n, 2, nm) for nm in reversed(names)])
-    prod = plan.dyadic_convolute(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2, L)
+    b[0] = a[0]                                                    # all q-1 times all q-1
+    da, db = pkg.to_device(a, dev), pkg.to_device(b, dev)
+    prod = plan.dyadic_convolute(da, 2, db, 2, L)
     relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
     got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, relin, 2))
+    fused = pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys))
     for i in range(len(names)):
         e = ctx.ckks_multiply(L, a[i], b[i])
         e = ctx.relinearize(L, True, e, keys)
-        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), names[i]
+        e = ctx.mod_switch_scale_to_next(L, e)
+        assert np.array_equal(got[i], e), ("three calls", names[i])
+        assert np.array_equal(fused[i], e), ("fused entry", names[i])
 
 
 @pytest.mark.parametrize("n,bits,L,t", [(4096, [50] * 6, 5, 65537), (2048, [59] * 6, 5, 40961), (1024, [36] * 11, 10, 12289)])

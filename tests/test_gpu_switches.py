@@ -1,0 +1,80 @@
+"""Every A/B switch of the library has both sides executed by the suite.  The switches are environment variables read on every call
+(csrc/troyn.hip env_is / env_int, csrc/ntt_launch.inl), so one process can run both sides; results must stay bit-identical to the oracle.
+
+  TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
+  TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: item-major, XCD-grouped)
+  TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
+  TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0021)
+  TROYN_NTT_ARITH=u64       integer butterflies for every modulus
+(TROYN_BEHZ, TROYN_KS_TAIL, TROYN_BFV_TENSOR, TROYN_TENSOR_WGS, TROYN_PLAIN_MAC are covered by parametrised tests next to their kernels.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(O, pkg, dev, n, bits, L, batch=8):
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    return q, ctx, plan, keys, dkeys
+
+
+@pytest.mark.parametrize("env", [{}, {"TROYN_KS_MAC": "v1"}, {"TROYN_KS_MAC": "split"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_ARITH": "u64"},
+                                 {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}],
+                         ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none"])
+@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [40, 40, 40, 40], 3)])
+def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L):
+    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, bits, L)
+    batch = 8
+    tg = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(batch)])
+    for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE):
+        d0 = np.stack([ctx.random_ct(40 + i, 2, L) for i in range(batch)])
+        dd = pkg.to_device(d0, dev)
+        plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=assign, is_ckks=True, is_ntt_form=True)
+        got = pkg.to_host(dd)
+        for i in (0, 3, 7):
+            assert np.array_equal(got[i], ctx.switch_key(L, True, tg[i], keys, assign=assign, dest=d0[i])), (env, assign, i)
+
+
+@pytest.mark.parametrize("env", [{}, {"TROYN_MRR": "calls"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}],
+                         ids=["default", "mrr_calls", "ks_order_row", "ntt_half_all", "ntt_half_none"])
+def test_fused_chain_under_every_switch(O, pkg, dev, monkeypatch, env):
+    for k in ("TROYN_MRR", "TROYN_KS_ORDER", "TROYN_NTT_HALF"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, L = 16384, 5
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [50] * 6, L)
+    batch = 8
+    a = np.stack([ctx.random_ct(11 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(29 + i, 2, L) for i in range(batch)])
+    got = pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, pkg.to_device(a, dev), pkg.to_device(b, dev), dkeys))
+    for i in (0, 5, 7):
+        e = ctx.relinearize(L, True, ctx.ckks_multiply(L, a[i], b[i]), keys)
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), (env, i)
+
+
+@pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021"])
+def test_ntt_half_word_variants(O, pkg, dev, monkeypatch, half):
+    """whole-limb N = 16384 transforms, forward and inverse, plain and rescale-fused, with every half-word LDS variant on / off"""
+    monkeypatch.setenv("TROYN_NTT_HALF", half)
+    n, L = 16384, 4
+    q = O.coeff_modulus_create(n, [50] * 4)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, 14, q)
+    x = np.stack([ctx.random_ct(3 + i, 2, L) for i in range(3)])
+    fw = pkg.to_host(plan.ntt(pkg.to_device(x, dev), 2, L))
+    for i in range(3):
+        assert np.array_equal(fw[i], ctx.to_ntt(x[i], 2, L))
+    back = pkg.to_host(plan.ntt(pkg.to_device(fw, dev), 2, L, inverse=True))
+    assert np.array_equal(back, x)
+    got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(fw, dev), 2))
+    for i in range(3):
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, fw[i]))

@@ -9,9 +9,22 @@ Every db is one `rocprofv3 --pmc ...` pass (separate passes, --kernel-trace only
   * SIMD VALU busy = SQ_ACTIVE_INST_VALU / (4 * SQ_BUSY_CYCLES-equivalent): reported as SQ_ACTIVE_INST_VALU (quad-cycles summed over
     waves) divided by (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 = cycles of the launch) * 1024 SIMDs / 4.
 """
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha(names=("ksmac_kernels.hpp", "dev_math_f64.hpp")):
+    """stamp of the kernel sources this record was measured on; bench.py drops a record whose stamp is not the current sources'"""
+    h = hashlib.sha256()
+    for nm in names:
+        with open(os.path.join(ROOT, "troy-nova_amd", "csrc", nm), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def lookup(dbs, counter, kernel, grid):
@@ -30,7 +43,7 @@ def lookup(dbs, counter, kernel, grid):
 def main():
     kernel, grid, batch, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     dbs = sys.argv[5:]
-    res = {"kernel": kernel, "grid_x": grid, "batch": batch}
+    res = {"kernel": kernel, "grid_x": grid, "batch": batch, "kernel_src_sha": kernel_sources_sha()}
     get = lambda c: lookup(dbs, c, kernel, grid)
     f, w = get("FETCH_SIZE"), get("WRITE_SIZE")
     if f and w:

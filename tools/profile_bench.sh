@@ -3,12 +3,12 @@
 # profiles/ keeps:  tools/profile_bench.sh <tag>   ->  gpurun_out/<tag>_summary.txt, gpurun_out/<tag>_ksmac_counters.json
 # Run through gpurun from the repository root:  gpurun -- 'bash tools/profile_bench.sh r02_bench_v1'
 set -e
-TAG=${1:-r02_bench}
+TAG=${1:-r03_bench}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
+ARGS="$ROOT/bench.py --steps 10 --warmup 1 --inner 4 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o bench -- python3 $ARGS > "$OUT/${TAG}_bench.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d "$OUT/prof_$TAG/$C" -o bench -- python3 $ARGS > /dev/null 2>&1

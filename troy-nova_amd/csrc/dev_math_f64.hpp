@@ -19,11 +19,17 @@
 #pragma once
 #include "dev_math.hpp"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TROYN_HD __host__ __device__ __forceinline__
 #else
 #define TROYN_HD inline
 #endif
+
+// Exactness rests on SEPARATE roundings of fl(y*w) and fma(y, w, -h): a compiler that contracts `a * b + c` into an FMA on its own
+// would change h and break the error-free product.  The build passes -ffp-contract=off (csrc/Makefile); the pragmas below make the
+// property travel with this header for any translation unit that includes it without that flag (tools/, one-line hipcc builds).
+// Every FMA this file wants is written as __builtin_fma.
+#pragma clang fp contract(off)
 
 namespace troyn {
 

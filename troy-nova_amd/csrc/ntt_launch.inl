@@ -25,8 +25,8 @@ namespace troyn {
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
-        static int half = -1;   // bit (INV ? 8 : 0) + IOM selects the variant
-        if (half < 0) { const char* e = getenv("TROYN_NTT_HALF"); half = e ? (int)strtol(e, nullptr, 0) : 0x0021; }
+        const char* e = getenv("TROYN_NTT_HALF");   // bit (INV ? 8 : 0) + IOM selects the variant; read per launch so that the suite runs every variant
+        const int half = e ? (int)strtol(e, nullptr, 0) : 0x0021;
         if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
@@ -36,8 +36,8 @@ template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST
 static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     const unsigned tiles = 1u << (LOGN - TB);
     dim3 grid((unsigned)(limb_polys * tiles)), block(1u << (TB - EB));
-    static int extra_lds = -1;   // TROYN_NTT_EXTRA_LDS=<bytes>: occupancy experiments only
-    if (extra_lds < 0) { const char* e = getenv("TROYN_NTT_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
+    const char* lds_env = getenv("TROYN_NTT_EXTRA_LDS");   // <bytes>: occupancy experiments only
+    const int extra_lds = lds_env ? atoi(lds_env) : 0;
     // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
     const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
     if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
@@ -170,8 +170,8 @@ static void tensor_stage_t(int stage, const NttArgs& a, const NttArgs& b, const 
         // three polynomials are held in registers next to the transform in flight.  Default: 512-thread workgroups x 8 coefficients
         // (100-111 registers, no spills, two workgroups = 16 waves per CU).  TROYN_TENSOR_WGS=3 / 2: 256 threads x 16 coefficients with
         // three (168 registers, 11-28 spilled) / two (no spills) workgroups per CU -- measured 1.8 % / 3 % slower at N = 32768 L = 10.
-        static int wgs = -1;
-        if (wgs < 0) { const char* e = getenv("TROYN_TENSOR_WGS"); wgs = e ? atoi(e) : 8; }
+        const char* wgs_env = getenv("TROYN_TENSOR_WGS");
+        const int wgs = wgs_env ? atoi(wgs_env) : 8;
         if (wgs == 8) {   // 512-thread workgroups x 8 coefficients: 100-111 registers, no spills, two workgroups (16 waves) per CU
             hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, 3, 2>), grid, dim3(1u << (TB - 3)), 0, s, a, b, d);
         } else if (wgs == 3) hipLaunchKernelGGL((tensor_core_kernel<A, LOGN, TB, EB, 3>), grid, block, 0, s, a, b, d);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,52 +89,77 @@ extern "C" int troyn_coeff_modulus_create(size_t poly_modulus_degree, const size
 // around one named launch, so that a caller can time that kernel inside its own timed region
 // ---------------------------------------------------------------------------------------
 namespace {
+// events belong to the device that was current when they were created: the pool and the recorded spans are kept per device, so one
+// host thread that alternates between devices (select_device) never records a pair on a foreign stream
+struct TimerSpan { hipEvent_t e0, e1; int device; };
 struct KernelTimer {
-    bool enabled[TROYN_TIMER_REGIONS] = {};
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[TROYN_TIMER_REGIONS];   // recorded, not yet read
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_pairs;
+    std::atomic<bool> enabled[TROYN_TIMER_REGIONS];
+    std::vector<TimerSpan> spans[TROYN_TIMER_REGIONS];   // recorded, not yet read
+    std::vector<TimerSpan> free_pairs;                   // reusable pairs of any device
     std::mutex mu;
+    KernelTimer() { for (auto& e : enabled) e.store(false); }
 };
 KernelTimer g_ktimer;
 
 struct TimerScope {
-    int region; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    int region; hipStream_t s; TimerSpan sp{nullptr, nullptr, -1};
     TimerScope(int region_, hipStream_t s_) : region(region_), s(s_) {
-        if (!g_ktimer.enabled[region]) return;
+        if (!g_ktimer.enabled[region].load(std::memory_order_relaxed)) return;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        {
+            std::lock_guard<std::mutex> g(g_ktimer.mu);
+            for (size_t i = 0; i < g_ktimer.free_pairs.size(); i++)
+                if (g_ktimer.free_pairs[i].device == dev) { sp = g_ktimer.free_pairs[i]; g_ktimer.free_pairs.erase(g_ktimer.free_pairs.begin() + i); break; }
+        }
+        if (!sp.e0) {
+            sp.device = dev;
+            if (hipEventCreate(&sp.e0) != hipSuccess) { sp.e0 = nullptr; return; }
+            if (hipEventCreate(&sp.e1) != hipSuccess) { (void)hipEventDestroy(sp.e0); sp.e0 = sp.e1 = nullptr; return; }
+        }
+        if (hipEventRecord(sp.e0, s) != hipSuccess) { release(); }
+    }
+    void release() {
         std::lock_guard<std::mutex> g(g_ktimer.mu);
-        if (!g_ktimer.free_pairs.empty()) { e0 = g_ktimer.free_pairs.back().first; e1 = g_ktimer.free_pairs.back().second; g_ktimer.free_pairs.pop_back(); }
-        else if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
-        (void)hipEventRecord(e0, s);
+        g_ktimer.free_pairs.push_back(sp);
+        sp.e0 = sp.e1 = nullptr;
     }
     ~TimerScope() {
-        if (!e0) return;
-        (void)hipEventRecord(e1, s);
+        if (!sp.e0) return;
+        if (hipEventRecord(sp.e1, s) != hipSuccess) { release(); return; }
         std::lock_guard<std::mutex> g(g_ktimer.mu);
-        g_ktimer.spans[region].push_back({e0, e1});
+        g_ktimer.spans[region].push_back(sp);
     }
 };
 }  // namespace
 
 extern "C" int troyn_kernel_timer_enable(int region, int on) {
     if (region < 0 || region >= TROYN_TIMER_REGIONS) return fail(TROYN_E_INVALID, "[troyn_kernel_timer_enable] unknown region");
-    g_ktimer.enabled[region] = on != 0;
+    g_ktimer.enabled[region].store(on != 0);
     return TROYN_OK;
 }
 
 extern "C" int troyn_kernel_timer_read(int region, double* total_ms, uint64_t* launches) {
     if (region < 0 || region >= TROYN_TIMER_REGIONS || !total_ms || !launches) return fail(TROYN_E_INVALID, "[troyn_kernel_timer_read] bad argument");
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    std::vector<TimerSpan> spans;
     { std::lock_guard<std::mutex> g(g_ktimer.mu); spans.swap(g_ktimer.spans[region]); }
     double total = 0.0;
+    hipError_t err = hipSuccess;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     for (auto& sp : spans) {
-        HIP_TRY(hipEventSynchronize(sp.second));
+        if (err != hipSuccess) break;
+        if (sp.device != cur) { if ((err = hipSetDevice(sp.device)) != hipSuccess) break; }
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, sp.first, sp.second));
-        total += ms;
+        if ((err = hipEventSynchronize(sp.e1)) == hipSuccess && (err = hipEventElapsedTime(&ms, sp.e0, sp.e1)) == hipSuccess) total += ms;
+        if (sp.device != cur) (void)hipSetDevice(cur);
     }
+    {   // the pairs go back to the pool whatever happened: nothing leaks, no sample is half-read
+        std::lock_guard<std::mutex> g(g_ktimer.mu);
+        for (auto& sp : spans) g_ktimer.free_pairs.push_back(sp);
+    }
+    if (err != hipSuccess) return fail((int)err, std::string("[troyn_kernel_timer_read] ") + hipGetErrorString(err));
     *total_ms = total; *launches = spans.size();
-    std::lock_guard<std::mutex> g(g_ktimer.mu);
-    for (auto& sp : spans) g_ktimer.free_pairs.push_back(sp);
     return TROYN_OK;
 }
 
@@ -326,16 +352,17 @@ extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, i
 // ---------------------------------------------------------------------------------------
 // NTT launch
 // ---------------------------------------------------------------------------------------
-static int g_force_integer_ntt = -1;   // TROYN_NTT_ARITH=u64 forces the integer butterflies (A/B testing)
-static int g_ks_unfused_mac = -1;      // TROYN_KS_MAC=split keeps decomposition NTT and inner product in two launches (A/B testing)
+// A/B switches are environment variables read on EVERY call (a getenv is a few hundred nanoseconds against launches of tens of
+// microseconds), so that a test can run both sides of a switch in one process (tests/test_gpu_switches.py).
+static inline bool env_is(const char* name, const char* value) { const char* e = getenv(name); return e && std::strcmp(e, value) == 0; }
+static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? (int)strtol(e, nullptr, 0) : dflt; }
+// TROYN_NTT_ARITH=u64 forces the integer butterflies; TROYN_KS_MAC=split keeps decomposition NTT and inner product in two launches,
+// TROYN_KS_MAC=v1 keeps the first-generation fused kernel
+static inline bool force_integer_ntt() { return env_is("TROYN_NTT_ARITH", "u64"); }
 
 static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_count) {
-    if (g_force_integer_ntt < 0) {
-        const char* e = getenv("TROYN_NTT_ARITH");
-        g_force_integer_ntt = (e && std::strcmp(e, "u64") == 0) ? 1 : 0;
-    }
     // FP64 butterflies when every modulus this launch can touch is below 2^50
-    bool f64 = !g_force_integer_ntt && p->log_n >= 10;
+    bool f64 = !force_integer_ntt() && p->log_n >= 10;
     for (unsigned i = 0; f64 && i < table_count; i++) f64 = p->small_modulus[table_start + i] != 0;
     return f64;
 }
@@ -351,7 +378,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
-    if (!f64 && !g_force_integer_ntt && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
+    if (!f64 && !force_integer_ntt() && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
         a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && a.fused_mode == 0 && !two_pass_scratch) {
         // A plain component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
         // runs of one class, so that the limbs below 2^50 take the FP64 butterflies instead of following the 60-bit limbs into the
@@ -574,9 +601,7 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // workgroup order of ksmac2_kernel: 1 = all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache),
 // 2 = row-major (one output row at a time on the whole chip: keys L2-resident, digits re-fetched per row); TROYN_KS_ORDER=item|row
 static unsigned ksmac_order(size_t batch) {
-    static int order = -1;
-    if (order < 0) { const char* e = getenv("TROYN_KS_ORDER"); order = (e && std::strcmp(e, "row") == 0) ? 2 : 1; }
-    return (batch % 8 == 0) ? (unsigned)order : 0u;
+    return (batch % 8 == 0) ? (env_is("TROYN_KS_ORDER", "row") ? 2u : 1u) : 0u;
 }
 
 struct KsLayout {
@@ -647,17 +672,13 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         digits_src = ws + w.target_intt;
         digits_bstride = (size_t)L * n;
     }
-    if (g_ks_unfused_mac < 0) {
-        const char* e = getenv("TROYN_KS_MAC");
-        g_ks_unfused_mac = (e && std::strcmp(e, "split") == 0) ? 1 : 0;
-    }
+    const bool ks_unfused_mac = env_is("TROYN_KS_MAC", "split");
     // (2)+(3) in ONE launch for whole-limb rings (N <= 16384): every workgroup owns one output row of one item,
     //     transforms that row's L digits one after the other and multiplies them into register accumulators with
     //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
     //     (L+1)*L transformed digits never reach HBM.
-    const bool mac_fused = !g_ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull;
-    static int ks_mac_gen = -1;     // TROYN_KS_MAC=v1 keeps the first-generation fused kernel (A/B testing)
-    if (ks_mac_gen < 0) { const char* e = getenv("TROYN_KS_MAC"); ks_mac_gen = (e && std::strcmp(e, "v1") == 0) ? 1 : 2; }
+    const bool mac_fused = !ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull;
+    const int ks_mac_gen = env_is("TROYN_KS_MAC", "v1") ? 1 : 2;
     if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 1) * 4 <= 0x7fffffffull) {
         // ksmac2_kernel: tiles of 2^13 outputs, two workgroups per CU, keys prepared once per call (ksmac_kernels.hpp)
         double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
@@ -693,8 +714,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         {
             // rows of an item co-scheduled per XCD: all L+1 by default (the item's digits are then fetched once per XCD instead of
             // once per row; measured 1265 vs 1310 us per 512-item launch at cfg3), TROYN_KS_ROWS=1 restores plain row-major order
-            static int ks_rows = -1;
-            if (ks_rows < 0) { const char* e = getenv("TROYN_KS_ROWS"); ks_rows = e ? std::atoi(e) : 0; }
+            const int ks_rows = env_int("TROYN_KS_ROWS", 0);
             const unsigned R = ks_rows > 0 ? (unsigned)ks_rows : L + 1;
             a.xcd_groups = (R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
         }
@@ -966,8 +986,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     u64* out = (u64*)out_;
     u64* ws = (u64*)workspace;
     int rc;
-    static int unfused = -1;    // TROYN_MRR=calls composes the three public calls (A/B testing)
-    if (unfused < 0) { const char* e = getenv("TROYN_MRR"); unfused = (e && std::strcmp(e, "calls") == 0) ? 1 : 0; }
+    const bool unfused = env_is("TROYN_MRR", "calls");    // composes the three public calls (A/B testing)
     if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 4 > 0x7fffffffull) {
         // Evaluator::multiply (evaluator.cu:118-145) -> relinearize (evaluator_keyswitching.cu:119-144) -> rescale_to_next
         if ((rc = launch_convolute(p->d_mods, n, 0, L, a, 2, b, 2, ws + w.prod3, batch, s))) return rc;
@@ -1525,7 +1544,10 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
             NttArgs fa = contiguous_args(p, xa, nullptr, 2, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
             NttArgs fb = contiguous_args(p, xb, nullptr, 2, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
             NttArgs id = contiguous_args(p, xd, xd, 3, nc, 0, nc, TROYN_IDX_COMPONENTWISE, 0);
-            if ((rc = tensor_stage(p, 1, fa, fb, id, batch, s))) return rc;
+            {
+                TimerScope ts(TROYN_TIMER_BFV_TENSOR, s);
+                if ((rc = tensor_stage(p, 1, fa, fb, id, batch, s))) return rc;
+            }
             if (!whole && (rc = tensor_stage(p, 2, id, id, id, batch, s))) return rc;
         }
     } else {
@@ -1545,6 +1567,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         const size_t items = batch * po;
         if ((rc = check_rows(items, ch1))) return rc;
         dim3 grid((unsigned)(items * ch1)), block(256);
+        TimerScope ts(TROYN_TIMER_BEHZ_FLOOR, s);
         if (gen2) {
             launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out);
         } else dispatch_bound(S,
@@ -2031,11 +2054,11 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
     HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // `tab` is a host temporary
     const unsigned ch = chunks_pairs(p->n);
-    static int mac_gen = -1;   // TROYN_PLAIN_MAC=v1: first-generation kernel (one polynomial per thread) for A/B runs
-    if (mac_gen < 0) { const char* e = getenv("TROYN_PLAIN_MAC"); mac_gen = (e && std::strcmp(e, "v1") == 0) ? 1 : 2; }
+    const int mac_gen = env_is("TROYN_PLAIN_MAC", "v1") ? 1 : 2;   // first-generation kernel (one polynomial per thread) for A/B runs
     if (pcount == 2 && mac_gen == 2) {
         const size_t rows2 = groups * nmod;
         if (int rc = check_rows(rows2, ch)) return rc;
+        TimerScope ts(TROYN_TIMER_PLAIN_MAC, s);
         hipLaunchKernelGGL((plain_mac2_kernel<2>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
         LAUNCH_CHECK();

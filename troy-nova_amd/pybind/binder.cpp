@@ -448,6 +448,17 @@ PYBIND11_MODULE(pytroy_raw, m) {
         s.relinearize_batched(const_ptrs(a), k, d, P(p)); }, py::arg("encrypted"), py::arg("relin_keys"), py::arg("destination"), POOL);
     ev.def("rescale_to_next_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Ciphertext*>& d, PoolArg p) {
         s.rescale_to_next_batched(const_ptrs(a), d, P(p)); }, py::arg("encrypted"), py::arg("destination"), POOL);
+    // additions to the reference's surface: multiply -> relinearize -> rescale_to_next behind one call (troy.h)
+    ev.def("multiply_relinearize_rescale", [](const Evaluator& s, const Ciphertext& a, const Ciphertext& b, const RelinKeys& k, Ciphertext& d, PoolArg p) {
+        s.multiply_relinearize_rescale(a, b, k, d, P(p)); }, py::arg("encrypted1"), py::arg("encrypted2"), py::arg("relin_keys"), py::arg("destination"), POOL);
+    ev.def("multiply_relinearize_rescale_inplace", [](const Evaluator& s, Ciphertext& a, const Ciphertext& b, const RelinKeys& k, PoolArg p) {
+        s.multiply_relinearize_rescale_inplace(a, b, k, P(p)); }, py::arg("encrypted1"), py::arg("encrypted2"), py::arg("relin_keys"), POOL);
+    ev.def("multiply_relinearize_rescale_new", [](const Evaluator& s, const Ciphertext& a, const Ciphertext& b, const RelinKeys& k, PoolArg p) {
+        return s.multiply_relinearize_rescale_new(a, b, k, P(p)); }, py::arg("encrypted1"), py::arg("encrypted2"), py::arg("relin_keys"), POOL);
+    ev.def("multiply_relinearize_rescale_batched", [](const Evaluator& s, const std::vector<Ciphertext*>& a, const std::vector<Ciphertext*>& b, const RelinKeys& k,
+                                                      const std::vector<Ciphertext*>& d, PoolArg p) {
+        s.multiply_relinearize_rescale_batched(const_ptrs(a), const_ptrs(b), k, d, P(p)); },
+           py::arg("encrypted1"), py::arg("encrypted2"), py::arg("relin_keys"), py::arg("destination"), POOL);
     // Galois
     ev.def("apply_galois", [](const Evaluator& s, const Ciphertext& a, size_t g, const GaloisKeys& k, Ciphertext& d, PoolArg p) { s.apply_galois(a, g, k, d, P(p)); },
            py::arg("encrypted"), py::arg("galois_element"), py::arg("galois_keys"), py::arg("destination"), POOL);

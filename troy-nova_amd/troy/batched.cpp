@@ -145,6 +145,35 @@ void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const
     assign_views(proto, block, d);
 }
 
+// -- multiply -> relinearize -> rescale_to_next, one call for the whole batch (addition) ------------------------------------------------
+void Evaluator::multiply_relinearize_rescale_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const RelinKeys& relin_keys,
+                                                     const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool) const {
+    if (e1.size() != e2.size() || e1.size() != destination.size())
+        throw std::invalid_argument("[Evaluator::multiply_relinearize_rescale_batched] Input and destination have different sizes.");
+    uint32_t L = 0; ParmsID next; double scale = 1.0; std::vector<const uint64_t*> keys;
+    const bool batched = e1.size() >= BATCH_OP_THRESHOLD && uniform(e1) && uniform(e2) &&
+                         multiply_relinearize_rescale_prepare(*e1[0], *e2[0], relin_keys, L, next, scale, keys);   // item 0 stands for every item of a uniform batch
+    if (!batched) {
+        for (size_t i = 0; i < e1.size(); i++) { Ciphertext out; multiply_relinearize_rescale(*e1[i], *e2[i], relin_keys, out, pool); *destination[i] = std::move(out); }
+        return;
+    }
+    const size_t count = e1.size();
+    const size_t n = e1[0]->poly_modulus_degree();
+    const uint64_t cf = e1[0]->correction_factor();
+    utils::DynamicArray s1(0, true, pool), s2(0, true, pool);
+    const uint64_t* a = contiguous(e1, s1, pool);
+    const uint64_t* b = contiguous(e2, s2, pool);
+    const size_t words = (size_t)2 * (L - 1) * n;
+    auto block = std::make_shared<utils::DynamicArray>(count * words, true, pool);
+    const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(context_->plan(), L, count);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    troyn_check_public(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, a, b, keys.data(), block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
+    troyn_sync_current_stream();
+    for (size_t i = 0; i < count; i++)
+        *destination[i] = Ciphertext::from_members(2, L - 1, n, next, scale, true, cf, 0,
+                                                   utils::DynamicArray::device_view(block->raw_pointer() + i * words, words, block));
+}
+
 // -- relinearize -------------------------------------------------------------------------------------------------------
 void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encrypted, const RelinKeys& relin_keys, const std::vector<Ciphertext*>& d, MemoryPoolHandle pool) const {
     same_size("[Evaluator::relinearize_batched]", encrypted.size(), d.size());

@@ -1096,6 +1096,62 @@ void Evaluator::rescale_to_next(const Ciphertext& encrypted, Ciphertext& destina
 }
 
 
+// -- multiply -> relinearize -> rescale_to_next as one call (addition; evaluator.cu:118-145, evaluator_keyswitching.cu:119-144, ---------
+// -- evaluator_modswitch.cu:14-74, :445-461) -------------------------------------------------------------------------------------
+bool Evaluator::multiply_relinearize_rescale_prepare(const Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, uint32_t& L, ParmsID& next_parms_id,
+                                                     double& scale, std::vector<const uint64_t*>& key_ptrs) const {
+    // Evaluator::multiply's checks
+    check_no_seed("[Evaluator::multiply]", e1); check_no_seed("[Evaluator::multiply]", e2);
+    check_same_parms_id("[Evaluator::multiply]", e1, e2);
+    check_on_device("[Evaluator::multiply]", context_, e1); check_on_device("[Evaluator::multiply]", context_, e2);
+    SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    if (scheme != SchemeType::CKKS || e1.polynomial_count() != 2 || e2.polynomial_count() != 2) return false;
+    auto cd = get_context_data("[Evaluator::multiply]", e1.parms_id());
+    check_is_ntt_form("[Evaluator::ckks_multiply_inplace]", e1); check_is_ntt_form("[Evaluator::ckks_multiply_inplace]", e2);
+    L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    scale = e1.scale() * e2.scale();
+    if (!is_scale_within_bounds(scale, cd)) throw std::invalid_argument("[Evaluator::ckks_multiply] Scale out of bounds");
+    // relinearize_internal's checks (3 -> 2 components)
+    const char* P = "[Evaluator::relinearize_inplace_internal]";
+    if (relin_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Relin keys has incorrect parms id.");
+    const size_t idx = RelinKeys::get_index(2);
+    if (idx >= relin_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
+    if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
+    if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
+    for (const auto& k : relin_keys.data()[idx]) {
+        check_no_seed("[Evaluator::switch_key_inplace_internal]", k.as_ciphertext());
+        if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
+    }
+    // rescale_to_next's checks
+    if (context_->last_parms_id() == e1.parms_id()) throw std::invalid_argument("[Evaluator::rescale_to_next] End of modulus switching chain reached.");
+    if (!cd->next_context_data().has_value()) throw std::invalid_argument("[Evaluator::mod_switch_scale_to_next_internal] Next context data is not set.");
+    next_parms_id = cd->next_context_data().value()->parms_id();
+    scale = scale / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
+    key_ptrs = relin_keys.get_data_ptrs(idx);
+    return true;
+}
+
+void Evaluator::multiply_relinearize_rescale(const Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    uint32_t L = 0; ParmsID next; double scale = 1.0; std::vector<const uint64_t*> keys;
+    if (!multiply_relinearize_rescale_prepare(e1, e2, relin_keys, L, next, scale, keys)) {
+        Ciphertext m, r;
+        multiply(e1, e2, m, pool);
+        relinearize(m, relin_keys, r, pool);
+        rescale_to_next(r, destination, pool);
+        return;
+    }
+    Ciphertext out = Ciphertext::like(e1, 2, L - 1, false, pool);
+    out.parms_id() = next;
+    out.scale() = scale;
+    out.is_ntt_form() = true;
+    const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(context_->plan(), L, 1);
+    utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+    troyn_check(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, e1.data().raw_pointer(), e2.data().raw_pointer(), keys.data(), out.data().raw_pointer(),
+                                                        ws.raw_pointer(), bytes, 1, current_stream()));
+    destination = std::move(out);
+}
+
+
 // -- NTT (evaluator_transform_ntt.cu:469-652) ----------------------------------------------------------------
 void Evaluator::transform_to_ntt_inplace(Ciphertext& encrypted) const {
     check_no_seed("[Evaluator::transform_to_ntt_inplace]", encrypted);

@@ -1038,6 +1038,22 @@ public:
     void multiply_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d,
                           MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // addition (see header comment)
 
+    // ADDITION to the reference's interface: destination = rescale_to_next(relinearize(multiply(e1, e2), relin_keys)) as ONE library call
+    // (troyn_ckks_multiply_relinearize_rescale: 5 launches instead of 8, the 3-component product never reaches HBM).  The result -- payload,
+    // parms_id, scale, form -- is bit-identical to composing evaluator.h's three methods (evaluator.cu:118-145, evaluator_keyswitching.cu:119-144,
+    // evaluator_modswitch.cu:445-461) and every argument check of those three is applied with the reference's messages.  Operands that are
+    // not 2-component CKKS ciphertexts are evaluated by composing the three methods.
+    void multiply_relinearize_rescale(const Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, Ciphertext& destination,
+                                      MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    void multiply_relinearize_rescale_inplace(Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; multiply_relinearize_rescale(e1, e2, relin_keys, d, pool); e1 = std::move(d);
+    }
+    Ciphertext multiply_relinearize_rescale_new(const Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Ciphertext d; multiply_relinearize_rescale(e1, e2, relin_keys, d, pool); return d;
+    }
+    void multiply_relinearize_rescale_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const RelinKeys& relin_keys,
+                                              const std::vector<Ciphertext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+
     // ciphertext x plaintext -- evaluator.h (multiply_plain*, transform_plain_to_ntt*); evaluator_multiply_plain.cu,
     // evaluator_transform_ntt.cu:35-70
     void transform_plain_to_ntt(const Plaintext& plain, const ParmsID& parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
@@ -1264,6 +1280,9 @@ private:
     void relinearize_internal(const Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, Ciphertext& destination, MemoryPoolHandle pool) const;
     void mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const;
     void mod_switch_drop_to_internal(const Ciphertext& encrypted, Ciphertext& destination, const ParmsID& target, MemoryPoolHandle pool) const;
+    // argument checks + result metadata of multiply -> relinearize -> rescale_to_next; false: the operands do not take the fused entry
+    bool multiply_relinearize_rescale_prepare(const Ciphertext& e1, const Ciphertext& e2, const RelinKeys& relin_keys, uint32_t& L, ParmsID& next_parms_id, double& scale,
+                                              std::vector<const uint64_t*>& key_ptrs) const;
     HeContextPointer context_;
 };
 
