@@ -7,6 +7,7 @@
 // Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
 // decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
 //   he_bench_driver [check|bench] [repeat]
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <complex>
@@ -157,7 +158,10 @@ int main(int argc, char** argv) {
         for (size_t threads : {(size_t)1, (size_t)4}) {
             for (size_t B : {(size_t)64, (size_t)256, (size_t)1024}) {
                 for (int fused = 0; fused < 2; fused++) {
-                    std::vector<double> elapsed(threads, 0.0);
+                    // every thread warms up, then all start their timed loops together; the wall clock runs from that common start to the last finish
+                    const size_t reps = std::max<size_t>(repeat, 40 * 1024 / B / threads);
+                    std::atomic<size_t> ready{0};
+                    std::atomic<bool> go{false};
                     auto body = [&](size_t t) {
                         std::vector<const Ciphertext*> pa, pb; std::vector<Ciphertext> d(B), t1(B), t2(B); std::vector<Ciphertext*> pd, q1, q2; std::vector<const Ciphertext*> pt1, pt2;
                         for (size_t i = 0; i < B; i++) { pa.push_back(&A[t][i]); pb.push_back(&Bv[t][i]); pd.push_back(&d[i]); q1.push_back(&t1[i]); q2.push_back(&t2[i]); pt1.push_back(&t1[i]); pt2.push_back(&t2[i]); }
@@ -167,16 +171,20 @@ int main(int argc, char** argv) {
                         };
                         once(); once();
                         troyn_sync_current_stream();
-                        auto t0 = clk::now();
-                        for (size_t r = 0; r < repeat; r++) once();
+                        ready.fetch_add(1);
+                        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+                        for (size_t r = 0; r < reps; r++) once();
                         troyn_sync_current_stream();
-                        elapsed[t] = secs(t0, clk::now());
                     };
                     std::vector<std::thread> th;
                     for (size_t t = 0; t < threads; t++) th.emplace_back(body, t);
+                    while (ready.load() < threads) std::this_thread::yield();
+                    auto t0 = clk::now();
+                    go.store(true, std::memory_order_release);
                     for (auto& x : th) x.join();
-                    double mx = 0; for (double e : elapsed) mx = std::max(mx, e);
-                    std::printf("batched_%s_threads%zu_batch%zu_ops_per_s %.1f\n", fused ? "fused" : "three_calls", threads, B, (double)(threads * B * repeat) / mx);
+                    const double mx = secs(t0, clk::now());
+                    const size_t repeat_used = reps;
+                    std::printf("batched_%s_threads%zu_batch%zu_ops_per_s %.1f\n", fused ? "fused" : "three_calls", threads, B, (double)(threads * B * repeat_used) / mx);
                 }
             }
         }

@@ -55,7 +55,7 @@ import pytest
 @pytest.mark.gpu
 def test_self_launcher_one_gpu():
     """the launcher path on real hardware: a fresh rank process is started before anything touches the GPU"""
-    r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-extra"], env_extra={"TROYN_BENCH_SPAWN": "1"})
+    r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--inner", "1", "--batch", "64", "--no-cpu-baseline", "--no-extra"], env_extra={"TROYN_BENCH_SPAWN": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["launches_timed"] == 3

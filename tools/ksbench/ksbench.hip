@@ -3,7 +3,7 @@
 // under study (seconds to build instead of the minutes libtroyn.so takes) and checks every variant
 // bit-for-bit against the shipped kernel of the same name before timing it.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o ksbench ksbench.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DKSBENCH_LEAN] -o ksbench ksbench.hip     (LEAN: shipped kernels only, 15 s)
 //   ./ksbench [batch] [reps] [variant ...]
 #include <hip/hip_runtime.h>
 
@@ -17,6 +17,10 @@
 #include "../../troy-nova_amd/csrc/host_math.hpp"
 #include "../../troy-nova_amd/csrc/ntt_kernels.hpp"
 #include "../../troy-nova_amd/csrc/ksmac_kernels.hpp"
+#if __has_include("ksmac_base.hpp")
+#include "ksmac_base.hpp"      // frozen copy of the committed kernel (tools/ksbench/freeze_base.sh): same-run A/B
+#define KSBENCH_HAVE_BASE 1
+#endif
 
 using namespace troyn;
 
@@ -177,8 +181,10 @@ int main(int argc, char** argv) {
         printf("\n");
     };
 
+#ifndef KSBENCH_LEAN
     run_variant("ks_mac<14,5> 512thr", [&](const NttArgs& v) {
         hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 5>), dim3(blocks), dim3(512), 0, 0, v, b.kp); });
+#endif
     KsMacArgs ka;
     std::memset(&ka, 0, sizeof(ka));
     ka.digits = b.digits; ka.dig_bstride = (long long)L * N; ka.dig_cstride = N;
@@ -195,9 +201,51 @@ int main(int argc, char** argv) {
     double* d_digf;
     CHECK(hipMalloc(&d_digf, dig_words * 8));
     hipLaunchKernelGGL(center_kernel, dim3(4096), dim3(256), 0, 0, b.digits, d_digf, dig_words, N, b.d_moduli, L);
+#ifdef KSBENCH_HAVE_BASE
+    {   // the fused chain's form: the NTT-form digit of row k is the product diag (.) diag_b formed while loading; base vs working copy
+        u64* t2; CHECK(hipMalloc(&t2, dig_words * 8));
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, t2, dig_words, N, b.d_moduli, L, 1u, 0x4444ull);
+        std::vector<u64> r0(out_words), r1(out_words);
+        for (int rep = 0; rep < 2; rep++) {
+            KsMacArgs kv = ka; kv.digits = (const u64*)d_digf; kv.diag_b = t2;
+            kv.out = b.out_ref;
+            float tb = time_launch([&] { hipLaunchKernelGGL((ksmac2_base_kernel<14, true>), dim3(blocks * 2), dim3(KSB_THREADS), 0, 0, kv); }, reps);
+            kv.out = b.out;
+            float tn = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); }, reps);
+            CHECK(hipMemcpy(r0.data(), b.out_ref, out_words * 8, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(r1.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
+            printf("%-28s %9.1f us   working copy %9.1f us  %s\n", "BASE fused form (diag_b)", tb, tn, r0 == r1 ? "identical" : "MISMATCH");
+        }
+        // restore the reference output of the plain form for the variants below
+        hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 4>), dim3(blocks), dim3(1024), 0, 0, a, b.kp);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipFree(t2));
+    }
+    for (int rep = 0; rep < 2; rep++) {
+    run_variant("BASE ksmac2 f64 digits", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out; kv.digits = (const u64*)d_digf;
+        hipLaunchKernelGGL((ksmac2_base_kernel<14, true>), dim3(blocks * 2), dim3(KSB_THREADS), 0, 0, kv); });
     run_variant("ksmac2 f64 digits", [&](const NttArgs& v) {
         KsMacArgs kv = ka; kv.out = v.out; kv.digits = (const u64*)d_digf;
         hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    }
+#endif
+    run_variant("ksmac2 f64 digits", [&](const NttArgs& v) {
+        KsMacArgs kv = ka; kv.out = v.out; kv.digits = (const u64*)d_digf;
+        hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+#ifdef KSM_PHASE_PROFILE
+    {   // shader cycles of wave 0 of every workgroup per phase (s_memtime), one launch
+        unsigned long long* d_prof; CHECK(hipMalloc(&d_prof, 9 * 8)); CHECK(hipMemset(d_prof, 0, 9 * 8));
+        KsMacArgs kv = ka; kv.out = b.out; kv.digits = (const u64*)d_digf; kv.prof = d_prof;
+        hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv);
+        unsigned long long hp[9]; CHECK(hipMemcpy(hp, d_prof, 72, hipMemcpyDeviceToHost));
+        const char* names[9] = {"load+layer0", "round0", "exchange0 (2 barriers)", "round1", "exchange1", "round2", "mac", "diag digit", "epilogue"};
+        double tot = 0; for (int i = 0; i < 9; i++) tot += (double)hp[i];
+        for (int i = 0; i < 9; i++) printf("phase %-24s %10.0f cycles per workgroup  %5.1f %%\n", names[i], (double)hp[i] / (blocks * 2), 100.0 * hp[i] / tot);
+        printf("phase total %.0f cycles per workgroup\n", tot / (blocks * 2));
+    }
+#endif
+#ifndef KSBENCH_LEAN
     run_variant("ksmac2 1wg/cu", [&](const NttArgs& v) {
         KsMacArgs kv = ka; kv.out = v.out;
         hipLaunchKernelGGL((ksmac2_kernel<14, false>), dim3(blocks * 2), dim3(KSM_THREADS), 30000, 0, kv); });
@@ -246,5 +294,6 @@ int main(int argc, char** argv) {
     run_abl("abl: no loads at all", ksmac2_kernel<14, false, 1 | 2 | 32>);
     run_abl("abl: alu only", ksmac2_kernel<14, false, 1 | 2 | 4 | 32>);
     run_abl("abl: mem only", ksmac2_kernel<14, false, 8 | 16>);
+#endif
     return 0;
 }

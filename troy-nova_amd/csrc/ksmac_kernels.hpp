@@ -52,6 +52,7 @@ struct KsMacArgs {
     unsigned table_start, table_count;    // row k uses modulus table_start + (k == L ? table_count - 1 : k)
     unsigned batch;
     unsigned grouped;       // 1: the (L+1) * HALVES workgroups of an item are dealt to one XCD (batch % 8 == 0)
+    unsigned long long* prof;   // development only (tools/ksbench -DKSM_PHASE_PROFILE): per-phase shader cycles of wave 0 of every workgroup, summed
 };
 
 constexpr int KSM_TB = 13;                  // tile bits
@@ -121,8 +122,8 @@ __device__ __forceinline__ void ksm_layer(double (&x)[32], const double* tw, dou
 // A 5-layer register round whose 31 twiddles sit in a 32-slot vector (slot (1 << lvl) + g; slot 0 unused), fetched 8
 // slots at a time one step ahead of the butterflies that use them.  ld(q) returns slots 2q, 2q+1.
 // first/second: slots 0..7 and 8..15, already requested by the caller (before the LDS exchange that feeds the round).
-template <bool NOBF = false, class LD>
-__device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], double (&tb)[8], LD&& ld, double inv_p, double p) {
+template <bool NOBF = false, class LD, class HK>
+__device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], double (&tb)[8], LD&& ld, HK&& after_last_load, double inv_p, double p) {
     ksm_layer<4, 0, 1, NOBF>(x, ta + 1, inv_p, p);
     ksm_layer<3, 0, 2, NOBF>(x, ta + 2, inv_p, p);
     ksm_layer<2, 0, 4, NOBF>(x, ta + 4, inv_p, p);
@@ -131,16 +132,32 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
     ksm_layer<1, 0, 8, NOBF>(x, tb, inv_p, p);
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 4>([&](auto qc) { const double2 v = ld(12 + decltype(qc)::value); tb[2 * decltype(qc)::value] = v.x; tb[2 * decltype(qc)::value + 1] = v.y; });
+    after_last_load();      // every load of the round is on its way: whatever is issued here queues behind them
     ksm_layer<0, 0, 8, NOBF>(x, ta, inv_p, p);
     __builtin_amdgcn_sched_barrier(0);
     ksm_layer<0, 8, 8, NOBF>(x, tb, inv_p, p);
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef KSM_PHASE_PROFILE
+#define KSM_MARK(ph) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[ph] += now_ - prof_t; prof_t = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KSM_MARK(ph) do { } while (0)
+#endif
+
 // ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads all hit one cache line,
 // bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
 template <int LOGN, bool DIGF64, int ABL = 0>
-__global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
+#ifndef KSM_WAVES_PER_SIMD
+#define KSM_WAVES_PER_SIMD 2
+#endif
+#ifndef KSM_KEY_AHEAD
+#define KSM_KEY_AHEAD 3
+#endif
+#ifndef KSM_LOAD_WINDOW
+#define KSM_LOAD_WINDOW 12
+#endif
+__global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel(KsMacArgs a) {
     constexpr auto abl = [](int bit) constexpr { return ((ABL >> bit) & 1) != 0; };
     static_assert(LOGN >= 13 && LOGN <= 15, "ksmac2 covers N = 8192, 16384 and 32768");
     constexpr bool SPLIT = LOGN == 14;        // half tiles: one Cooley-Tukey layer applied while loading
@@ -197,10 +214,10 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
 
     // LDS addresses (padded words).  Round 0 holds registers r = b0 | b9<<1 | R3<<2 of tile index
     // b0 | t<<1 | b9<<9 | R3<<10; round 1 holds bits [5,10); round 2 holds bits [0,5).
-    const unsigned p0 = ksm_phys(t << 1);                                             // + ksm_phys(b9<<9 | R3<<10): multiples of 32 words
-    const unsigned p1 = ksm_phys((t & 31u) | ((t >> 5) << 10));                       // + 34 * R
-    const unsigned p2 = ksm_phys(t << 5);                                             // + R  (R < 32: no pad crossed)
-    const unsigned pt = ksm_phys(wave * 2048u + lane * 2u);                            // transposed pairs: + ksm_phys(128 m)
+    unsigned p0 = ksm_phys(t << 1);                                             // + ksm_phys(b9<<9 | R3<<10): multiples of 32 words
+    unsigned p1 = ksm_phys((t & 31u) | ((t >> 5) << 10));                       // + 34 * R
+    unsigned p2 = ksm_phys(t << 5);                                             // + R  (R < 32: no pad crossed)
+    unsigned pt = ksm_phys(wave * 2048u + lane * 2u);                            // transposed pairs: + ksm_phys(128 m)
 
     const double* kbase = a.keys + (size_t)mrow * N + (size_t)h * (KSM_THREADS * 32);
     const u64* dig_item = a.digits + (long long)b * a.dig_bstride;
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
     auto mac_all = [&](double (&v)[32], unsigned j) {
         const double* k0 = ksm_uniform(kbase + (long long)j * a.key_jstride);
         const double* k1 = ksm_uniform(k0 + a.key_pstride);
-        constexpr int AHEAD = 3;
+        constexpr int AHEAD = KSM_KEY_AHEAD;
         const unsigned koff = abl(1) ? (slice_off & 16u) : slice_off;
         double2 y0[16], y1[16];
         static_for<0, AHEAD>([&](auto mc) {
@@ -247,43 +264,59 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
         else return f64_from_u64(raw);
     };
 
+#ifdef KSM_PHASE_PROFILE
+    unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     for (unsigned it = 0; it < a.L; ++it) {
         double x[32];
         // nothing below depends on the digit except the input and the key: without these the compiler hoists every
         // twiddle load (and its w/p product) out of the digit loop and spills them
         asm volatile("" : "+v"(r1off), "+v"(slice_off));
+        // the same for the LDS bases: the ds_read2 / ds_write offsets reach 2 KB, so the compiler derives ~6 more base registers from
+        // p1; hoisted out of the digit loop they are spilled, and every reload after the exchange barrier comes with s_waitcnt vmcnt(0),
+        // i.e. it waits for the round's twiddle loads that were issued to travel under the exchange (round 3: -5.6 % on the launch).
+        // Re-derived per digit they cost one v_add each.
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(pt));
         if (a.diag && it == k) {
             // the digit of row k under its own modulus is the NTT-form input limb (evaluator_keyswitching_core.cu:851-852):
             // coalesced load, transpose through the wave's own LDS slice into the accumulators' layout
             const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
-            static_for<0, 16>([&](auto mc) {
+            const u64* dgb = a.diag_b ? ksm_uniform(a.diag_b + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32)) : nullptr;
+            // two batches of 8 (+ 8) loads that are all in flight before the first is used; the product of the fused chain is formed in the
+            // coalesced layout, so there is ONE transposition (round 3: the second operand used to be loaded, transposed and multiplied
+            // one 16-byte load at a time, each behind its own s_waitcnt vmcnt(0))
+            auto diag_half = [&](auto hc, auto with_b) {
+                constexpr int hb = decltype(hc)::value;
+                constexpr bool WB = decltype(with_b)::value;
+                ulonglong2 va[8], vb[WB ? 8 : 1];
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 8>([&](auto ic) { va[decltype(ic)::value] = ksm_gload<ulonglong2>(dg + (hb * 8 + decltype(ic)::value) * 128, slice_off); });
+                if constexpr (WB) static_for<0, 8>([&](auto ic) { vb[decltype(ic)::value] = ksm_gload<ulonglong2>(dgb + (hb * 8 + decltype(ic)::value) * 128, slice_off); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int j = decltype(ic)::value, m = hb * 8 + j;
+                    double2 pr = make_double2(f64_from_u64(va[j].x), f64_from_u64(va[j].y));
+                    if constexpr (WB) {
+                        pr.x = f64_mulq(f64_corr(pr.x, fm), f64_from_u64(vb[j].x), inv_p, p);
+                        pr.y = f64_mulq(f64_corr(pr.y, fm), f64_from_u64(vb[j].y), inv_p, p);
+                    }
+                    *reinterpret_cast<double2*>(&lds[pt + ksm_phys(m * 128u)]) = pr;
+                });
+            };
+            if (dgb) { diag_half(std::integral_constant<int, 0>{}, std::true_type{}); diag_half(std::integral_constant<int, 1>{}, std::true_type{}); }
+            else static_for<0, 16>([&](auto mc) {       // plain form: the limb streams through the slice as it arrives
                 constexpr int m = decltype(mc)::value;
                 const ulonglong2 v = ksm_gload<ulonglong2>(dg + m * 128, slice_off);
-                *reinterpret_cast<ulonglong2*>(&lds[pt + ksm_phys(m * 128u)]) = v;
+                *reinterpret_cast<double2*>(&lds[pt + ksm_phys(m * 128u)]) = make_double2(f64_from_u64(v.x), f64_from_u64(v.y));
             });
             __builtin_amdgcn_wave_barrier();
             static_for<0, 16>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[p2 + 2 * m]);
-                x[2 * m] = f64_from_u64(v.x);
-                x[2 * m + 1] = f64_from_u64(v.y);
+                const double2 v = *reinterpret_cast<const double2*>(&lds[p2 + 2 * m]);
+                x[2 * m] = v.x; x[2 * m + 1] = v.y;
             });
-            if (a.diag_b) {
-                const u64* dgb = ksm_uniform(a.diag_b + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
-                __builtin_amdgcn_wave_barrier();
-                static_for<0, 16>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    const ulonglong2 v = ksm_gload<ulonglong2>(dgb + m * 128, slice_off);
-                    *reinterpret_cast<ulonglong2*>(&lds[pt + ksm_phys(m * 128u)]) = v;
-                });
-                __builtin_amdgcn_wave_barrier();
-                static_for<0, 16>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&lds[p2 + 2 * m]);
-                    x[2 * m] = f64_mulq(f64_corr(x[2 * m], fm), f64_from_u64(v.x), inv_p, p);
-                    x[2 * m + 1] = f64_mulq(f64_corr(x[2 * m + 1], fm), f64_from_u64(v.y), inv_p, p);
-                });
-            }
+            KSM_MARK(7);
         } else {
         // ---- load (+ layer 0 for a half tile), two steps of 8 register pairs ---------------------------------
         const u64* gin_u = ksm_uniform(dig_item + (long long)it * a.dig_cstride);
@@ -291,23 +324,27 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
         if constexpr (SPLIT) {
             const double w1 = tws[1];
             const double sgn = h ? -1.0 : 1.0;       // upper half of the outputs: u - w*v
-            static_for<0, 2>([&](auto hc) {
-                constexpr int hb = decltype(hc)::value;
+            // a rolling window of loads: KSM_LOAD_WINDOW register pairs (two 16-byte loads each) are requested up front, and every pair
+            // that is consumed makes room for the request of another one -- ONE exposed memory latency per digit instead of one per
+            // batch (the first version requested 8 pairs, consumed them, requested the other 8)
+            constexpr int W0 = KSM_LOAD_WINDOW;
+            ulonglong2 ru[16], rv[16];
+            auto request = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;     // i = b9 | R3<<1
+                ru[i] = ksm_gload<ulonglong2>(gin_u + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
+                rv[i] = ksm_gload<ulonglong2>(gin_u + 8192 + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, W0>([&](auto ic) { request(ic); });
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                ulonglong2 ru[8], rv[8];
-                static_for<0, 8>([&](auto ic) {
-                    constexpr int i = hb * 8 + decltype(ic)::value;     // i = b9 | R3<<1
-                    ru[decltype(ic)::value] = ksm_gload<ulonglong2>(gin_u + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
-                    rv[decltype(ic)::value] = ksm_gload<ulonglong2>(gin_u + 8192 + (((i & 1) << 9) + ((i >> 1) << 10)) * (abl(0) ? 0 : 1), gin_off);
-                });
-                __builtin_amdgcn_sched_barrier(0);     // all 16 loads of the step are in flight before the first is consumed
-                static_for<0, 8>([&](auto ic) {
-                    constexpr int j = decltype(ic)::value, i = hb * 8 + j;
-                    const double u0 = dig_in(ru[j].x), u1 = dig_in(ru[j].y), v0 = dig_in(rv[j].x), v1 = dig_in(rv[j].y);
-                    // 0 <= u, v < 2^50: one re-centring after the layer instead of one per input
-                    x[2 * i] = f64_corr(__builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0), fm);
-                    x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
-                });
+                const double u0 = dig_in(ru[i].x), u1 = dig_in(ru[i].y), v0 = dig_in(rv[i].x), v1 = dig_in(rv[i].y);
+                // 0 <= u, v < 2^50: one re-centring after the layer instead of one per input
+                x[2 * i] = f64_corr(__builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0), fm);
+                x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i + W0 < 16) request(std::integral_constant<int, i + W0>{});
             });
         } else if constexpr (SPLIT4) {
             // quarter tile h = 2 hA + hB of a 2^15-point transform: with (a, b, c, d) = x[i], x[i+N/4], x[i+N/2], x[i+3N/4],
@@ -316,29 +353,31 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             // the three twiddle products are the work the four quarter-tile workgroups duplicate
             const double w1 = tws[1], wB = tws[2 + (h >> 1)];
             const double sA = (h >> 1) ? -1.0 : 1.0, sB = (h & 1) ? -1.0 : 1.0;
-            static_for<0, 4>([&](auto hc) {
-                constexpr int hb = decltype(hc)::value;
+            // rolling window of loads as above: W4 register pairs (four 16-byte loads each) in flight
+            constexpr int W4 = KSM_LOAD_WINDOW / 3;
+            ulonglong2 ra[16], rb_[16], rc[16], rd[16];
+            auto request = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;     // i = b9 | R3<<1
+                constexpr unsigned off = ((i & 1) << 9) + ((i >> 1) << 10);
+                ra[i] = ksm_gload<ulonglong2>(gin_u + off, gin_off);
+                rb_[i] = ksm_gload<ulonglong2>(gin_u + 8192 + off, gin_off);
+                rc[i] = ksm_gload<ulonglong2>(gin_u + 16384 + off, gin_off);
+                rd[i] = ksm_gload<ulonglong2>(gin_u + 24576 + off, gin_off);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, W4>([&](auto ic) { request(ic); });
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                ulonglong2 ra[4], rb_[4], rc[4], rd[4];
-                static_for<0, 4>([&](auto ic) {
-                    constexpr int j = decltype(ic)::value, i = hb * 4 + j;     // i = b9 | R3<<1
-                    constexpr unsigned off = ((i & 1) << 9) + ((i >> 1) << 10);
-                    ra[j] = ksm_gload<ulonglong2>(gin_u + off, gin_off);
-                    rb_[j] = ksm_gload<ulonglong2>(gin_u + 8192 + off, gin_off);
-                    rc[j] = ksm_gload<ulonglong2>(gin_u + 16384 + off, gin_off);
-                    rd[j] = ksm_gload<ulonglong2>(gin_u + 24576 + off, gin_off);
-                });
+                // raw inputs below 2^50: |u|, |v| <= 3.3 p, |x| <= 5 p before the re-centring
+                const double u0 = __builtin_fma(sA, f64_mulq(dig_in(rc[i].x), w1, inv_p, p), dig_in(ra[i].x));
+                const double u1 = __builtin_fma(sA, f64_mulq(dig_in(rc[i].y), w1, inv_p, p), dig_in(ra[i].y));
+                const double v0 = __builtin_fma(sA, f64_mulq(dig_in(rd[i].x), w1, inv_p, p), dig_in(rb_[i].x));
+                const double v1 = __builtin_fma(sA, f64_mulq(dig_in(rd[i].y), w1, inv_p, p), dig_in(rb_[i].y));
+                x[2 * i] = f64_corr(__builtin_fma(sB, f64_mulq(v0, wB, inv_p, p), u0), fm);
+                x[2 * i + 1] = f64_corr(__builtin_fma(sB, f64_mulq(v1, wB, inv_p, p), u1), fm);
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<0, 4>([&](auto ic) {
-                    constexpr int j = decltype(ic)::value, i = hb * 4 + j;
-                    // raw inputs below 2^50: |u|, |v| <= 3.3 p, |x| <= 5 p before the re-centring
-                    const double u0 = __builtin_fma(sA, f64_mulq(dig_in(rc[j].x), w1, inv_p, p), dig_in(ra[j].x));
-                    const double u1 = __builtin_fma(sA, f64_mulq(dig_in(rc[j].y), w1, inv_p, p), dig_in(ra[j].y));
-                    const double v0 = __builtin_fma(sA, f64_mulq(dig_in(rd[j].x), w1, inv_p, p), dig_in(rb_[j].x));
-                    const double v1 = __builtin_fma(sA, f64_mulq(dig_in(rd[j].y), w1, inv_p, p), dig_in(rb_[j].y));
-                    x[2 * i] = f64_corr(__builtin_fma(sB, f64_mulq(v0, wB, inv_p, p), u0), fm);
-                    x[2 * i + 1] = f64_corr(__builtin_fma(sB, f64_mulq(v1, wB, inv_p, p), u1), fm);
-                });
+                if constexpr (i + W4 < 16) request(std::integral_constant<int, i + W4>{});
             });
         } else {
             static_for<0, 16>([&](auto ic) {
@@ -349,6 +388,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             });
         }
         __builtin_amdgcn_sched_barrier(0);
+        KSM_MARK(0);
         // ---- round 0: tile bits 12, 11, 10 = register bits 4, 3, 2; twiddles are workgroup-uniform ----------
         static_for<0, 3>([&](auto lc) {
             constexpr int li = decltype(lc)::value;
@@ -366,6 +406,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             });
         });
         __builtin_amdgcn_sched_barrier(0);
+        KSM_MARK(1);
         // ---- exchange 0 -> 1 -------------------------------------------------------------------------------
         double ta[8], tb[8];
         if constexpr (!abl(2)) __syncthreads();     // every wave has finished reading its slice of the previous digit
@@ -384,8 +425,10 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             x[R] = f64_bits_to_double(lds[p1 + 34 * R]);
         });
         __builtin_amdgcn_sched_barrier(0);
+        KSM_MARK(2);
         // ---- round 1: tile bits 9..5 = register bits 4..0 ----------------------------------------------------
-        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r1u + (abl(5) ? 0 : 2 * q), r1off); }, inv_p, p);
+        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r1u + (abl(5) ? 0 : 2 * q), r1off); }, [] {}, inv_p, p);
+        KSM_MARK(3);
         // ---- exchange 1 -> 2 -------------------------------------------------------------------------------
         if constexpr (!abl(2)) static_for<0, 32>([&](auto rc) {
             constexpr int R = decltype(rc)::value;
@@ -402,15 +445,21 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
             x[2 * m] = v.x; x[2 * m + 1] = v.y;
         });
         __builtin_amdgcn_sched_barrier(0);
+        KSM_MARK(4);
         // ---- round 2: tile bits 4..0 = register bits 4..0, lane-interleaved twiddle vectors --------------------
-        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * q), abl(5) ? (slice_off & 16u) : slice_off); }, inv_p, p);
+        ksm_round5<abl(3)>(x, ta, tb, [&](int q) { return ksm_gload<double2>(r2u + (abl(5) ? 0 : 128 * q), abl(5) ? (slice_off & 16u) : slice_off); }, [] {}, inv_p, p);
+        KSM_MARK(5);
         }
         // ---- multiply-accumulate with key `it` straight from the registers ---------------------------------------
         mac_all(x, it);
+        KSM_MARK(6);
         if ((it & 7u) == 7u)
             static_for<0, 32>([&](auto rc) { acc0[decltype(rc)::value] = f64_corr(acc0[decltype(rc)::value], fm); acc1[decltype(rc)::value] = f64_corr(acc1[decltype(rc)::value], fm); });
     }
 
+#ifdef KSM_PHASE_PROFILE
+    const unsigned long long prof_t0 = prof_t;
+#endif
     // ---- canonical results, transposed through the wave's own LDS slice, 16-byte coalesced stores --------------
     u64* go = a.out + (long long)b * a.out_bstride + (long long)k * a.out_cstride + (size_t)h * (KSM_THREADS * 32);
     static_for<0, 2>([&](auto cc) {
@@ -428,6 +477,12 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmac2_kernel(KsMacArgs a) {
         });
         __builtin_amdgcn_wave_barrier();
     });
+#ifdef KSM_PHASE_PROFILE
+    if (a.prof && t == 0) {
+        prof_acc[8] = __builtin_readcyclecounter() - prof_t0;
+        for (int i = 0; i < 9; i++) atomicAdd(a.prof + i, prof_acc[i]);
+    }
+#endif
 }
 
 }  // namespace troyn
