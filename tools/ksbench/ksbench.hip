@@ -24,6 +24,12 @@
 
 using namespace troyn;
 
+// plain forward whole-limb transform with the last wave-private exchange as a DPP register <-> lane transpose (A/B only)
+__global__ __launch_bounds__(1024, 1) void ntt_fwd14_shfl_kernel(NttArgs a) {
+    __shared__ u64 lds[ntt_lds_words(14)];
+    ntt_pass_body<ArithF64, 14, 0, 14, 14, 4, false, true, true, false, 0, 0, false, true>(a, nullptr, lds, blockIdx.x, threadIdx.x);
+}
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 constexpr unsigned LOGN = 14, N = 1u << LOGN, K = 6, L = 5;
@@ -275,6 +281,12 @@ int main(int argc, char** argv) {
         float t5 = time_launch([&] { hipLaunchKernelGGL((ntt_pass_kernel<ArithF64, 14, 0, 14, 14, 5, false, true, true, 0>), dim3((unsigned)lp), dim3(512), 0, 0, na); }, reps);
         CHECK(hipMemcpy(r5.data(), nout, lp * N * 8, hipMemcpyDeviceToHost));
         const double gb = 16.0 * N * lp / 1e3;
+        std::vector<u64> rs(lp * N);
+        float ts = time_launch([&] { hipLaunchKernelGGL(ntt_fwd14_shfl_kernel, dim3((unsigned)lp), dim3(1024), 0, 0, na); }, reps);
+        CHECK(hipMemcpy(rs.data(), nout, lp * N * 8, hipMemcpyDeviceToHost));
+        float t4b = time_launch([&] { hipLaunchKernelGGL((ntt_pass_kernel<ArithF64, 14, 0, 14, 14, 4, false, true, true, 0>), dim3((unsigned)lp), dim3(1024), 0, 0, na); }, reps);
+        printf("%-28s %9.1f us  %7.1f GB/s  %s\n", "ntt fwd 16/thr, DPP quad transpose for the wave-private exchange", ts, gb / ts, r4 == rs ? "bit-exact" : "MISMATCH");
+        printf("%-28s %9.1f us  %7.1f GB/s  (LDS exchange, repeated)\n", "ntt fwd 16/thr x1024 (3 xchg)", t4b, gb / t4b);
         printf("%-28s %9.1f us  %7.1f GB/s\n", "ntt fwd 16/thr x1024 (3 xchg)", t4, gb / t4);
         printf("%-28s %9.1f us  %7.1f GB/s  %s\n", "ntt fwd 32/thr x512 (2 xchg)", t5, gb / t5, r4 == r5 ? "bit-exact" : "MISMATCH");
     }

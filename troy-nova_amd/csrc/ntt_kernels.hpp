@@ -512,7 +512,7 @@ __host__ __device__ constexpr bool ROUNDS_OK(int G, int EB) { return (G + EB - 1
 // HALF: the LDS tile holds 32-bit words (half the bytes): every exchange moves the low halves, then the high halves of its E words
 // (three barriers instead of one).  A whole-limb N = 16384 tile then takes 66 KB instead of 132 KB and TWO 1024-thread workgroups
 // share a CU, so one can load / store while the other computes -- what N = 8192 gets for free.
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0, bool HALF = false>
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0, bool HALF = false, bool SHFL = false>
 __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t, typename A::elem* xio = nullptr) {
     constexpr int C = TB - G;
     static_assert(!HALF || (!KSMAC && REGIO == 0), "half-word LDS tiles: plain and fused transform kernels only");
@@ -759,9 +759,40 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; wv[R] = A::to_lds(x[R], md); });
             auto wa = [&](auto ic) { return pprev + lds_off((unsigned)decltype(ic)::value << S_PREV); };
             auto ra = [&](auto ic) { return pbase + lds_off((unsigned)decltype(ic)::value << S); };
+            if constexpr (SHFL && PRIVATE_IN && !INV && S_PREV == 2 && S == 0 && EB == 4 && std::is_same<A, ArithF64>::value) {
+                // Measured alternative (tools/ksbench `ntt`, profiles/r03_ntt_ab.txt; not used by the library): the wave-private exchange in
+                // front of the last forward round as a register <-> lane transpose.  Index bits (0, 1) sit in lane bits (0, 1) and must
+                // become register bits, index bits (4, 5) sit in register bits (2, 3) and must become lane bits (0, 1): two DPP quad_perm
+                // swaps (lane bit 0 <-> register bit 2, lane bit 1 <-> register bit 3) per 64-bit word pair, no LDS.
+                double y[E];
+                static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; y[R] = A::from_lds(wv[R]); });
+                auto dpp64 = [](double v, auto ctrl) {
+                    constexpr int CT = decltype(ctrl)::value;
+                    const u64 bits = f64_double_to_bits(v);
+                    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)bits, CT, 0xF, 0xF, false);
+                    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(bits >> 32), CT, 0xF, 0xF, false);
+                    return f64_bits_to_double(((u64)(unsigned)hi << 32) | (unsigned)lo);
+                };
+                static_for<0, 2>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;                       // lane bit st <-> register bit 2 + st
+                    constexpr int CT = st == 0 ? 0xB1 : 0x4E;                     // quad_perm [1,0,3,2] / [2,3,0,1]
+                    const bool odd = ((t >> st) & 1u) != 0;
+                    static_for<0, E>([&](auto Rc) {
+                        constexpr int R = decltype(Rc)::value;
+                        if constexpr (((R >> (2 + st)) & 1) == 0) {
+                            constexpr int R1 = R | (1 << (2 + st));
+                            const double pa = dpp64(y[R], std::integral_constant<int, CT>{}), pb = dpp64(y[R1], std::integral_constant<int, CT>{});
+                            const double na = odd ? pb : y[R], nb = odd ? y[R1] : pa;
+                            y[R] = na; y[R1] = nb;
+                        }
+                    });
+                });
+                static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; x[(R & 3) << 2 | (R >> 2)] = y[R]; });
+            } else {
             // RAW: readers are the writer's own wave (LDS executes a wave's accesses in order) or other waves
             if constexpr (PRIVATE_IN) xchg(wa, ra, wv, wave_sync, nothing); else xchg(wa, ra, wv, wg_sync, nothing);
             static_for<0, E>([&](auto Rc) { constexpr int R = decltype(Rc)::value; x[R] = A::from_lds(wv[R]); });
+            }
         }
 
         constexpr int NLAYERS = BHI - BLO + 1;
