@@ -52,6 +52,7 @@ struct KsMacArgs {
     unsigned table_start, table_count;    // row k uses modulus table_start + (k == L ? table_count - 1 : k)
     unsigned batch;
     unsigned grouped;       // 1: the (L+1) * HALVES workgroups of an item are dealt to one XCD (batch % 8 == 0)
+    unsigned long long row_mask;   // 0: all L + 1 output rows; else the launch covers the rows whose bit is set (mixed chains: rows of moduli < 2^50)
     unsigned long long* prof;   // development only (tools/ksbench -DKSM_PHASE_PROFILE): per-phase shader cycles of wave 0 of every workgroup, summed
 };
 
@@ -147,7 +148,7 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 
 // ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads all hit one cache line,
 // bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
-template <int LOGN, bool DIGF64, int ABL = 0>
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
     // ---- workgroup -> (item, row, half) ------------------------------------------------------------------
     unsigned b, k, h;
     {
-        const unsigned G = (a.L + 1) * HALVES;
+        const unsigned nrows = a.row_mask ? (unsigned)__builtin_popcountll(a.row_mask) : a.L + 1;
+        const unsigned G = nrows * HALVES;
         unsigned g;
         if (a.grouped == 2) {
             // row-major: the whole chip works on one output row at a time, so that row's 2L key limbs (1.3 MB at cfg3) stay
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         }
         k = g / HALVES; h = g % HALVES;
         }
+        if (a.row_mask) k = nth_set_bit(a.row_mask, k);
     }
     const unsigned mrow = (k == a.L) ? a.table_count - 1 : k;    // row of the key / modulus slot
     const unsigned mi = a.table_start + mrow;
@@ -259,8 +262,10 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
     };
 
     // a digit word as it enters the transform
+    // (WIDE: a chain with limbs of 2^50 and more -- the digit of such a limb is reduced with integer arithmetic first, Modulus::reduce)
     auto dig_in = [&](u64 raw) -> double {
         if constexpr (DIGF64) return f64_bits_to_double(raw);
+        else if constexpr (WIDE) return f64_from_u64(barrett64(raw, dm.q, dm.ratio_hi));
         else return f64_from_u64(raw);
     };
 

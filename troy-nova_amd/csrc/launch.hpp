@@ -38,8 +38,9 @@ inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const
     return log_n <= 13 ? launch_tensor_u64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_u64_large(log_n, stage, a, b, d, batch, s);
 }
 // second-generation key-switch inner product (ksmac2_kernel, log_n = 13 / 14 / 15) and its key preparation
-// digits_f64: the digit rows hold doubles (fused chain: NTT_FLAG_STORE_F64) instead of u64 words
-void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64 = false);
+// digits_f64: the digit rows hold doubles (fused chain: NTT_FLAG_STORE_F64) instead of u64 words; wide_digits: some digit limb is 2^50 or
+// wider (mixed chains, a.row_mask selects the rows of moduli < 2^50): digits are reduced with integer arithmetic while loading
+void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64 = false, bool wide_digits = false);
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s);
 // second-generation BEHZ conversions (L = 1 .. 16)
 void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst);

@@ -49,6 +49,8 @@ struct NttArgs {
     unsigned batch;                // ks_mac_kernel: number of items (workgroup -> (row, item) mapping)
     unsigned xcd_groups;           // fused tail / rescale launches: batch * pcount groups whose ncomp limbs share one input row (0: off)
     long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
+    unsigned long long ks_row_mask; // ks_mac_kernel: 0 = all decomp + 1 output rows; else the launch covers the rows whose bit is set (mixed chains:
+                                   // the rows of moduli >= 2^50 take this kernel, the others ksmac2_kernel)
     // ---- fused multiply -> relinearize -> rescale chain (IOM 3..5, NttFused below) ----
     const u64* mul_a; const u64* mul_b;       // the two input ciphertexts [item][2][limbs][N] (NTT form)
     long long mul_bstride, mul_pstride;       // element strides: item, polynomial (limb stride = N)
@@ -285,6 +287,13 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, B>{});
         static_for<B + 1, E_>(f);
     }
+}
+
+// index of the (n+1)-th set bit of mask (row subsets of the key-switch inner product kernels)
+__host__ __device__ inline unsigned nth_set_bit(unsigned long long mask, unsigned n) {
+    for (unsigned i = 0; i < 64; i++)
+        if ((mask >> i) & 1ull) { if (n == 0) return i; --n; }
+    return 0;
 }
 
 // ---- arithmetic policies -------------------------------------------------------------------
@@ -543,6 +552,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         } else {
             b = bid % a.batch; k = bid / a.batch;
         }
+        if (a.ks_row_mask) k = nth_set_bit(a.ks_row_mask, k);
     } else {
         tile = bid & ((1u << TILE_BITS) - 1); bid >>= TILE_BITS;
         unsigned g;   // (batch, poly) group

@@ -703,6 +703,37 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         }
         LAUNCH_CHECK();
     } else if (mac_fused && p->log_n <= 14) {
+        // A chain with moduli on both sides of 2^50 (the reference's default {60,40,40,60}): the output rows of the moduli below 2^50 take
+        // ksmac2_kernel (exact FP64 butterflies; digits of wider limbs are reduced with integer arithmetic while loading), the others the
+        // integer kernel.  Rows are independent; results are unchanged.
+        unsigned long long small_rows = 0, wide_rows = 0;
+        bool wide_digits = false;
+        for (unsigned k = 0; k <= L; k++) {
+            const unsigned mrow = (k == L) ? K - 1 : k;
+            if (p->small_modulus[mrow]) small_rows |= 1ull << k; else wide_rows |= 1ull << k;
+            if (k < L && !p->small_modulus[k]) wide_digits = true;
+        }
+        const bool mixed = ks_mac_gen == 2 && p->d_fwd_r2 && !force_integer_ntt() && small_rows != 0 && wide_rows != 0 && L + 1 <= 64 &&
+                           batch * (size_t)(L + 1) * 4 <= 0x7fffffffull;
+        TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
+        if (mixed) {
+            double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
+            const size_t pairs = (size_t)L * 2 * K * (n / 2);
+            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s);
+            LAUNCH_CHECK();
+            KsMacArgs m;
+            std::memset(&m, 0, sizeof(m));
+            m.digits = digits_src; m.dig_bstride = (long long)digits_bstride; m.dig_cstride = n;
+            m.diag = is_ntt_form ? target : nullptr; m.diag_bstride = (long long)target_bstride; m.diag_cstride = n;
+            m.out = ws + w.poly_prod; m.out_bstride = 2ll * (L + 1) * n; m.out_pstride = (long long)(L + 1) * n; m.out_cstride = n;
+            m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
+            m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
+            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
+            m.grouped = ksmac_order(batch);
+            m.row_mask = small_rows;
+            launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, false, wide_digits);
+            LAUNCH_CHECK();
+        }
         NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
         a.in_bstride = (long long)digits_bstride; a.in_pstride = 0; a.in_cstride = n;
         a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
@@ -716,16 +747,15 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             // once per row; measured 1265 vs 1310 us per 512-item launch at cfg3), TROYN_KS_ROWS=1 restores plain row-major order
             const int ks_rows = env_int("TROYN_KS_ROWS", 0);
             const unsigned R = ks_rows > 0 ? (unsigned)ks_rows : L + 1;
-            a.xcd_groups = (R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
+            a.xcd_groups = (!mixed && R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
         }
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
-        {
-            TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * (L + 1), s);
-            else launch_ks_mac_u64(p->log_n, a, kp, batch * (L + 1), s);
-        }
+        if (mixed) a.ks_row_mask = wide_rows;
+        const size_t mac_rows = mixed ? (size_t)__builtin_popcountll(wide_rows) : (size_t)(L + 1);
+        if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * mac_rows, s);
+        else launch_ks_mac_u64(p->log_n, a, kp, batch * mac_rows, s);
         LAUNCH_CHECK();
     } else {
     // (2) digit decomposition fused into the forward NTT (replaces kernel_set_accumulate, fgk/switch_key.cu:6-54,

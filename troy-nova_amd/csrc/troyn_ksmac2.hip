@@ -3,10 +3,11 @@
 
 namespace troyn {
 
-void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64) {
+void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64, bool wide_digits) {
     const dim3 block(KSM_THREADS);
 #define KSMAC2_CASE(LOGN, TILES)                                                                                            \
     if (digits_f64) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true>), dim3((unsigned)(batch * rows * TILES)), block, 0, s, a); \
+    else if (wide_digits) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, true>), dim3((unsigned)(batch * rows * TILES)), block, 0, s, a); \
     else hipLaunchKernelGGL((ksmac2_kernel<LOGN, false>), dim3((unsigned)(batch * rows * TILES)), block, 0, s, a);
     if (log_n == 15) { KSMAC2_CASE(15, 4) }
     else if (log_n == 14) { KSMAC2_CASE(14, 2) }
