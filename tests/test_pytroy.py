@@ -155,10 +155,17 @@ def test_ckks_flow_in_python(pytroy, dev):
     scale = float(1 << 30)
     c1 = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z1, None, scale))
     c2 = encryptor.encrypt_asymmetric_new(enc.encode_complex64_simd_new(z2, None, scale))
-    m = ev.relinearize_new(ev.multiply_new(c1, c2), kg.create_relin_keys(False))
+    rk = kg.create_relin_keys(False)
+    m = ev.relinearize_new(ev.multiply_new(c1, c2), rk)
     ev.rescale_to_next_inplace(m)
     got = enc.decode_complex64_simd_new(dec.decrypt_new(m)).tolist()
     assert max(abs(g - a * b) for g, a, b in zip(got, z1, z2)) < 1e-2
+    # the fused method (an addition to the reference's surface) is word-identical to the three calls, single and batched
+    f = ev.multiply_relinearize_rescale_new(c1, c2, rk)
+    assert f.data() == m.data() and f.scale() == m.scale() and f.parms_id() == m.parms_id()
+    outs = [pytroy.Ciphertext() for _ in range(4)]
+    ev.multiply_relinearize_rescale_batched([c1, c2, c1, c2], [c2, c1, c2, c1], rk, outs)
+    assert all(o.data() == m.data() for o in outs)
     gk = kg.create_galois_keys_from_steps([2], False)
     rot = enc.decode_complex64_simd_new(dec.decrypt_new(ev.rotate_vector_new(c1, 2, gk))).tolist()
     assert max(abs(rot[i] - z1[(i + 2) % len(z1)]) for i in range(len(z1))) < 2e-2   # scale 2^30: key-switch noise ~2^-10
