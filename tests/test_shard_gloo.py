@@ -1,4 +1,9 @@
-"""N > 1 path on CPU: batch sharding + key broadcast + max-over-ranks with gloo, world_size 2."""
+"""N > 1 path on CPU: batch sharding + key broadcast + max-over-ranks with gloo, world_size 2.
+
+What this covers is the PLUMBING of the multi-GPU path (troy-nova_amd/shard.py as bench.py uses it): the block partition, the one-time
+key broadcast, the timing / count reductions and the barrier.  The "evaluation" of a rank's slice is a stand-in (`torch.arange`): the
+product has no CPU path by design (tests/test_capi_symbols.py::test_no_cpu_path), so the kernels cannot run here; on a GPU box every
+rank runs exactly the single-GPU path on its slice, which the `-m gpu` suite covers, and the data path has no collective to test."""
 import os
 import socket
 import sys

@@ -601,6 +601,7 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // workgroup order of ksmac2_kernel: 1 = all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache),
 // 2 = row-major (one output row at a time on the whole chip: keys L2-resident, digits re-fetched per row); TROYN_KS_ORDER=item|row
 static unsigned ksmac_order(size_t batch) {
+    if (env_is("TROYN_KS_ORDER", "plain")) return 0u;      // workgroups of an item dealt round-robin to the XCDs
     return (batch % 8 == 0) ? (env_is("TROYN_KS_ORDER", "row") ? 2u : 1u) : 0u;
 }
 
