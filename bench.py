@@ -271,10 +271,35 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     value = world * B * inner * args.steps / elapsed
 
     # ---- roofline of the kernel with the largest share of the timed step: the fused key-switch inner product ----
-    ks_launch_ms = ks_ms / max(1, ks_n)
-    alg_bytes = ksmac_alg_bytes(B, n, L, True)
-    achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_n else 0.0
-    prof = counters_record("ksmac", B)            # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
+    # In the timed region the fused entry runs the batch as two halves on two internal streams, so a launch's event-bracketed duration
+    # includes the time it shares the chip with the other half's kernels (`in_region`).  The kernel's own figure is therefore measured in
+    # the same run right after the region, same buffers, with the chain on ONE stream (TROYN_MRR_CHUNK=0: the library reads its switches
+    # per call): `achieved` = algorithmic bytes per launch / the average of those launch durations.
+    in_region_ms = ks_ms / max(1, ks_n)
+    in_region_items = max(1, round(B * inner * args.steps / max(1, ks_n)))
+    excl_ms, excl_n = in_region_ms, ks_n
+    if fused and in_region_items != B:
+        saved = os.environ.get("TROYN_MRR_CHUNK")
+        os.environ["TROYN_MRR_CHUNK"] = "0"
+        try:
+            one_pass()
+            torch.cuda.synchronize()
+            with KernelTimer(pkg, lib, TIMER_KS) as kt:
+                for _ in range(max(inner, 8)):
+                    one_pass()
+                torch.cuda.synchronize()
+                ms1, n1 = kt.read()
+            excl_ms, excl_n = ms1 / max(1, n1), n1
+        finally:
+            if saved is None:
+                del os.environ["TROYN_MRR_CHUNK"]
+            else:
+                os.environ["TROYN_MRR_CHUNK"] = saved
+    ks_launch_ms = excl_ms
+    items_per_launch = B if (fused and in_region_items != B) else in_region_items
+    alg_bytes = ksmac_alg_bytes(items_per_launch, n, L, True)
+    achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_launch_ms else 0.0
+    prof = counters_record("ksmac", items_per_launch)   # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
     traffic, valu = None, None
     if prof:
         traffic = prof.get("traffic_bytes_per_launch")
@@ -289,10 +314,15 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                 "bound_note": "what binds the kernel is FP64 vector issue (see valu_fp64); achieved / peak / frac are the contract's HBM figures: algorithmic bytes per "
                               "launch / the launch duration measured in this run, against the 8 TB/s peak",
                 "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation), "
-                          "largest share of the timed step (%.0f %%)" % (100.0 * ks_ms / (elapsed * 1e3)),
+                          "largest share of the timed step (%.0f %% of its wall clock at the un-overlapped launch duration)"
+                          % (100.0 * ks_launch_ms * (B / items_per_launch) * inner * args.steps / (elapsed * 1e3)),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_record": prof["_file"] if prof else None,
-                "launch_ms": round(ks_launch_ms, 4), "launches_timed": ks_n,
+                "launch_ms": round(ks_launch_ms, 4), "launches_timed": excl_n, "items_per_launch": items_per_launch,
+                "measured": "HIP events on the launch stream around every launch (library kernel timer), same run and buffers, chain on one stream"
+                            if items_per_launch != in_region_items else "HIP events on the launch stream around every launch of the timed region (library kernel timer)",
+                "in_region": {"launch_ms": round(in_region_ms, 4), "launches_timed": ks_n, "items_per_launch": in_region_items,
+                              "note": "two chunks in flight on two internal streams: a launch shares the chip with the other chunk's kernels, its duration is not the kernel's own"},
                 "algorithmic_bytes_per_launch": alg_bytes, "valu_fp64": valu,
                 # whole pipeline against the chip's HBM peak, both key accountings of SURVEY 8d (keys per op / keys once per batch)
                 "pipeline": {"bytes_per_op_keys_per_op": 18.0e6, "frac_keys_per_op": round(value / world * 18.0e6 / (HBM_PEAK_GBS * 1e9), 4),

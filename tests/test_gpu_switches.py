@@ -61,6 +61,32 @@ def test_fused_chain_under_every_switch(O, pkg, dev, monkeypatch, env):
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), (env, i)
 
 
+@pytest.mark.parametrize("env,batch", [({"TROYN_MRR_CHUNK": "16"}, 40), ({"TROYN_MRR_CHUNK": "8", "TROYN_MRR_STREAMS": "3"}, 24), ({}, 264), ({"TROYN_MRR_CHUNK": "0"}, 264)],
+                         ids=["chunks_16_16_8", "three_streams", "default_split_in_two", "one_chunk"])
+def test_fused_chain_chunked_on_internal_streams(O, pkg, dev, monkeypatch, env, batch):
+    """the fused entry cuts large batches into chunks that alternate on internal streams (csrc/troyn.hip); every item must still be the
+    oracle's result, whatever the chunking, including a ragged last chunk"""
+    for k in ("TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, L = 8192, 3
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [50] * 4, L)
+    base_a = np.stack([ctx.random_ct(11 + i, 2, L) for i in range(8)])
+    base_b = np.stack([ctx.random_ct(29 + i, 2, L) for i in range(8)])
+    a = np.concatenate([base_a] * (batch // 8))
+    b = np.concatenate([np.roll(base_b, i, axis=0) for i in range(batch // 8)])      # item i of block r: a[i] x b[(i - r) mod 8]
+    got = pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, pkg.to_device(a, dev), pkg.to_device(b, dev), dkeys))
+    cache = {}
+    for item in sorted({0, 7, 8, 15, 16, 23, batch // 2, batch // 2 - 1, batch - 9, batch - 1}):
+        i, r = item % 8, item // 8
+        key = (i, (i - r) % 8)
+        if key not in cache:
+            e = ctx.relinearize(L, True, ctx.ckks_multiply(L, base_a[key[0]], base_b[key[1]]), keys)
+            cache[key] = ctx.mod_switch_scale_to_next(L, e)
+        assert np.array_equal(got[item], cache[key]), (env, item)
+
+
 @pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021"])
 def test_ntt_half_word_variants(O, pkg, dev, monkeypatch, half):
     """whole-limb N = 16384 transforms, forward and inverse, plain and rescale-fused, with every half-word LDS variant on / off"""
