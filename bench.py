@@ -157,8 +157,13 @@ def uniform_residues(torch, shape_prefix, moduli, n, device, gen):
 
 
 def timed(torch, fn, reps):
-    fn()
-    torch.cuda.synchronize()
+    # the clocks need 20-25 ms of load to come up after any idle gap (tools/ramp_probe.py): warm up for at least 50 ms
+    t0 = time.perf_counter()
+    while True:
+        fn()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 > 0.05:
+            break
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
@@ -432,7 +437,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         del a, b, prod, relin, out, plan
         torch.cuda.empty_cache()
         other = extra_configs(torch, pkg, device)
-        sub = parse_args(["--workload", "cfg4", "--total", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        sub = parse_args(["--workload", "cfg4", "--total", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "4"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         other["cfg4"] = run_cfg4(sub, torch, pkg, shard, entry, 0, 1, device)
         other["cfg4"]["note"] = "BASELINE configs[3] on one GPU with a 256-op job per step (`bench.py --workload cfg4` runs the 1024-op job and shards it over --gpus ranks)"
         torch.cuda.empty_cache()

@@ -104,3 +104,34 @@ def test_ntt_half_word_variants(O, pkg, dev, monkeypatch, half):
     got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(fw, dev), 2))
     for i in range(3):
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, fw[i]))
+
+
+@pytest.mark.parametrize("n,bits,L,batch,ckks", [(16384, [50] * 6, 5, 128, True), (16384, [50] * 5, 4, 256, True), (8192, [40] * 4, 3, 256, True),
+                                                  (8192, [60, 40, 40, 60], 3, 256, True), (8192, [50, 50, 60, 40, 50], 4, 256, True),
+                                                  (32768, [50] * 4, 3, 64, False), (32768, [50] * 5, 4, 128, True)],
+                         ids=["n16384_6rows", "n16384_5rows_odd", "n8192_4rows", "n8192_mixed_chain", "n8192_mixed_odd", "n32768_bfv", "n32768_5rows_odd"])
+def test_key_switch_workgroup_orders(O, pkg, dev, monkeypatch, n, bits, L, batch, ckks):
+    """ksmac2_kernel's workgroup orders (csrc/ksmac_kernels.hpp): the default for batches that fill whole bands is `band` (two rows x the
+    items that fill an XCD); item / row / plain must give the same words, and selected items are checked against the oracle.  Odd row
+    counts (a band with one row) and mixed chains (FP64 rows picked by a mask) included."""
+    monkeypatch.delenv("TROYN_KS_ORDER", raising=False)
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q) if ckks else O.Context("bfv", n, q, 65537)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    keys = ctx.random_keys(2024, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    base = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(8)])
+    tg = np.concatenate([np.roll(base, r, axis=0) for r in range(batch // 8)])       # item 8r + i = base[(i - r) mod 8]
+    dtg = pkg.to_device(tg, dev)
+    res = {}
+    for order in ("band", "item", "row", "plain"):
+        monkeypatch.setenv("TROYN_KS_ORDER", order)
+        dd = pkg.to_device(np.zeros((batch, 2, L, n), dtype=np.uint64), dev)
+        plan.switch_key(L, dtg, dkeys, dest=dd, assign=pkg.ASSIGN_OVERWRITE, is_ckks=ckks, is_ntt_form=ckks)
+        res[order] = pkg.to_host(dd)
+    for order in ("item", "row", "plain"):
+        assert np.array_equal(res["band"], res[order]), order
+    d0 = np.zeros((2, L, n), dtype=np.uint64)
+    for item in (0, 9, batch // 2 + 3, batch - 1):
+        want = ctx.switch_key(L, ckks, tg[item], keys, assign=pkg.ASSIGN_OVERWRITE, dest=d0)
+        assert np.array_equal(res["band"][item], want), item

@@ -201,6 +201,7 @@ int main(int argc, char** argv) {
     ka.mods = b.d_mods; ka.tw = b.d_fwd; ka.tw_r1 = d_r1; ka.tw_r2 = d_r2;
     ka.keys = d_keys; ka.key_jstride = 2ll * K * N; ka.key_pstride = (long long)K * N;
     ka.L = L; ka.table_start = 0; ka.table_count = K; ka.batch = (unsigned)B; ka.grouped = (B % 8 == 0) ? 1 : 0;
+    if (getenv("KSB_ORDER")) ka.grouped = (unsigned)atoi(getenv("KSB_ORDER"));      // 3: bands of two rows (B must be a multiple of 128)
     float t_prep = time_launch([&] { hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(1024), dim3(256), 0, 0, b.kp, L, 2 * K, N, d_keys); }, reps);
     printf("%-28s %9.1f us\n", "prepare_keys", t_prep);
     run_variant("ksmac2", [&](const NttArgs& v) {

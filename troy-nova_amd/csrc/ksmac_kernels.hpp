@@ -180,7 +180,19 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         const unsigned nrows = a.row_mask ? (unsigned)__builtin_popcountll(a.row_mask) : a.L + 1;
         const unsigned G = nrows * HALVES;
         unsigned g;
-        if (a.grouped == 2) {
+        if (a.grouped == 3) {
+            // bands of two rows x 64 / (2 HALVES) items per XCD: the 64 workgroup slots of an XCD hold one band, whose keys (2 rows x 2L
+            // limbs, 2.6 MB at cfg3) stay in that XCD's L2 while the items stream through; an item's digits are fetched once per band
+            // (order 1 fetches each digit once but every key line per workgroup: 7.8 MB of keys cycle through 4 MB of L2).
+            // Odd row count: the workgroups of the missing row exit.  Measured -4..-6 % on the launch (profiles/r03_ksmac_ab.txt).
+            constexpr unsigned ITEMS = 64u / (2u * HALVES);
+            const unsigned bands = (nrows + 1u) / 2u, per = bands * 64u;
+            const unsigned xcd = blockIdx.x & 7u, sq = blockIdx.x >> 3, r = sq % per, r2 = r & 63u;
+            k = 2u * (r >> 6) + (r2 % (2u * HALVES)) / HALVES;
+            h = r2 % HALVES;
+            b = ((sq / per) * 8u + xcd) * ITEMS + r2 / (2u * HALVES);
+            if (k >= nrows) return;
+        } else if (a.grouped == 2) {
             // row-major: the whole chip works on one output row at a time, so that row's 2L key limbs (1.3 MB at cfg3) stay
             // in every XCD's L2; the halves of an item sit 8 workgroups apart = on the same XCD, back to back
             const unsigned per = 8u * HALVES, r = blockIdx.x % per, q = blockIdx.x / per;

@@ -598,11 +598,22 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // ---------------------------------------------------------------------------------------
 // key switching
 // ---------------------------------------------------------------------------------------
-// workgroup order of ksmac2_kernel: 1 = all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache),
-// 2 = row-major (one output row at a time on the whole chip: keys L2-resident, digits re-fetched per row); TROYN_KS_ORDER=item|row
-static unsigned ksmac_order(size_t batch) {
-    if (env_is("TROYN_KS_ORDER", "plain")) return 0u;      // workgroups of an item dealt round-robin to the XCDs
-    return (batch % 8 == 0) ? (env_is("TROYN_KS_ORDER", "row") ? 2u : 1u) : 0u;
+// workgroup order of ksmac2_kernel (TROYN_KS_ORDER=plain|item|row|band):
+//   0 plain: workgroups of an item dealt round-robin to the XCDs
+//   1 item:  all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache)
+//   2 row:   one output row at a time on the whole chip (keys L2-resident, digits re-fetched per row)
+//   3 band:  per XCD, two rows x as many items as fill its 64 workgroup slots (keys of the band L2-resident, digits fetched once per band);
+//            needs the batch to be a multiple of 8 x 64 / (2 tiles per row) items.  Default for N >= 16384 where it applies.
+static unsigned ksmac_order(size_t batch, unsigned log_n) {
+    if (env_is("TROYN_KS_ORDER", "plain")) return 0u;
+    if (batch % 8 != 0) return 0u;
+    if (env_is("TROYN_KS_ORDER", "row")) return 2u;
+    if (env_is("TROYN_KS_ORDER", "item")) return 1u;
+    const size_t tiles = log_n >= 13 ? (size_t)1 << (log_n - 13) : 1, band_items = 8 * (64 / (2 * tiles));
+    if (batch % band_items != 0) return 1u;
+    // measured (bench.py other_configs, band vs item): N = 32768 relinearize +8 %, N = 16384 +2 % (the launch itself -4 %), N = 8192 -2..-7 %
+    // (a row's keys are 0.4 MB there: every row already fits in L2 under the item order)
+    return (log_n >= 14 || env_is("TROYN_KS_ORDER", "band")) ? 3u : 1u;
 }
 
 struct KsLayout {
@@ -697,7 +708,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.mods = p->d_mods; a.tw = p->d_fwd_f64; a.tw_r1 = p->d_fwd_r1; a.tw_r2 = p->d_fwd_r2;
         a.keys = kf; a.key_jstride = 2ll * K * n; a.key_pstride = (long long)K * n;
         a.L = L; a.table_start = 0; a.table_count = K; a.batch = (unsigned)batch;
-        a.grouped = ksmac_order(batch);
+        a.grouped = ksmac_order(batch, p->log_n);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
             launch_ksmac2(p->log_n, batch, L + 1, a, s);
@@ -730,7 +741,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
             m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
             m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
-            m.grouped = ksmac_order(batch);
+            m.grouped = ksmac_order(batch, p->log_n);
             m.row_mask = small_rows;
             launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, false, wide_digits);
             LAUNCH_CHECK();
@@ -1037,7 +1048,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
         m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
-        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch);
+        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
         launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
     }
