@@ -195,3 +195,40 @@ def test_bfv_multiply_corner_vectors(O, pkg, dev, n, bits, L, t, behz_gen):
     got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
     for i in range(len(names)):
         assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], b[i])), names[i]
+
+
+@pytest.mark.parametrize("n,bits", [(8192, [40, 40, 60]), (16384, [40, 40, 40, 60]), (8192, [60, 40, 40, 60]), (8192, [50, 40, 60, 40, 60]), (32768, [40, 40, 60]), (32768, [60, 40, 60])],
+                         ids=["n8192_40_40_60", "n16384_40_40_40_60", "n8192_60_40_40_60", "n8192_50_40_60_40_60", "n32768_40_40_60", "n32768_60_40_60"])
+def test_wide_dropped_prime_over_narrow_limbs(O, pkg, dev, monkeypatch, n, bits):
+    """the prime a fused tail divides by (special prime of the key switch, last limb of the rescale) has 60 bits while data limbs are
+    narrow: the narrow limbs take the FP64 butterflies and their loader must reduce the 60-bit word with integer arithmetic first
+    (ArithF64::load_io); chains of both classes split their tail / rescale launches by class.  Key switch in NTT and coefficient form,
+    three assign methods, and rescale at every level; each with the launches of mixed chains split by class (TROYN_NTT_SPLIT=1), with the
+    default (only plain transforms split) and with no split at all (=0: every limb follows the widest into the integer butterflies)."""
+    q = O.coeff_modulus_create(n, bits)
+    K = len(q)
+    log_n = n.bit_length() - 1
+    for split in ("1", "", "0"):
+        monkeypatch.setenv("TROYN_NTT_SPLIT", split)
+        for scheme, ntt_form in (("ckks", True), ("bfv", False)):
+            ctx = O.Context(scheme, n, q) if scheme == "ckks" else O.Context(scheme, n, q, 65537)
+            plan = pkg.Plan(dev, log_n, q)
+            L = K - 1
+            keys = ctx.random_keys(7, L)
+            dkeys = [pkg.to_device(k, dev) for k in keys]
+            names = ["all_q-1", "alt_q-1_0", "half_hi", "impulse_1"]
+            tg = np.stack([_corner_ct(q, L, n, 1, nm)[0] for nm in names] + [ctx.random_ct(5 + i, 1, L)[0] for i in range(4)])
+            for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE, pkg.ASSIGN_OVERWRITE_EXCEPT_FIRST):
+                d0 = np.stack([ctx.random_ct(50 + i, 2, L) for i in range(tg.shape[0])])
+                dd = pkg.to_device(d0, dev)
+                plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=assign, is_ckks=ntt_form, is_ntt_form=ntt_form)
+                got = pkg.to_host(dd)
+                for i in range(tg.shape[0]):
+                    assert np.array_equal(got[i], ctx.switch_key(L, ntt_form, tg[i], keys, assign=assign, dest=d0[i])), (split, scheme, assign, i)
+        ctx = O.Context("ckks", n, q)
+        plan = pkg.Plan(dev, log_n, q)
+        for L in range(2, K + 1):
+            x = np.stack([_corner_ct(q, L, n, 2, nm) for nm in ("all_q-1", "half_lo", "half_hi", "ramp_top")] + [ctx.random_ct(9 + i, 2, L) for i in range(4)])
+            got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(x, dev), 2))
+            for i in range(x.shape[0]):
+                assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i])), (split, "rescale", L, i)

@@ -1,21 +1,19 @@
 #!/bin/bash
-# Profiles BASELINE config 4 (BFV N=32768 L=10, batch 64: BEHZ multiply, relinearize) on the GPU box: rocprofv3 kernel trace plus
-# separate FETCH_SIZE / WRITE_SIZE passes of tools/bench_configs.py --only cfg4.
-#   gpurun -- 'bash tools/profile_cfg4.sh r02_cfg4'   ->  gpurun_out/<tag>_summary.txt, gpurun_out/<tag>.json
+# Kernel trace of the cfg4 workload (BFV N = 32768 L = 10 multiply + relinearize, 256 ops in chunks of 64) -> gpurun_out/<tag>_summary.txt
 set -e
-TAG=${1:-r02_cfg4}
+TAG=${1:-r03_cfg4}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/tools/bench_configs.py --only cfg4 --reps 4"
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o cfg4 -- python3 $ARGS > "$OUT/${TAG}.json" 2> "$OUT/${TAG}.log"
-if [ "$2" != "--no-pmc" ]; then
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace -d "$OUT/prof_$TAG/$C" -o cfg4 -- python3 $ARGS > /dev/null 2>&1
-  done
-  PMC="--pmc $OUT/prof_$TAG/FETCH_SIZE/cfg4_results.db --pmc $OUT/prof_$TAG/WRITE_SIZE/cfg4_results.db"
-fi
+ARGS="$ROOT/bench.py --workload cfg4 --total 256 --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o bench -- python3 $ARGS > "$OUT/${TAG}_bench.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace -d "$OUT/prof_$TAG/$C" -o bench -- python3 $ARGS > /dev/null 2>&1
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -d "$OUT/prof_$TAG/SQ" -o bench -- python3 $ARGS > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d "$OUT/prof_$TAG/GRBM" -o bench -- python3 $ARGS > /dev/null 2>&1
 cd "$ROOT"
-python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/cfg4_results.db" $PMC > "$OUT/${TAG}_summary.txt"
-cat "$OUT/${TAG}.json"
+python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" --pmc "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" \
+        --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
+tail -2 "$OUT/${TAG}_bench.log"

@@ -106,6 +106,7 @@ struct NttIo {
     u64 aux_q, aux_ratio_hi, aux_half;   // the other prime, its Barrett word, floor(aux/2)
     u64 q, ratio_hi, fix;                // this limb's prime; fix = q - (aux_half mod q)  (KS)  or  (aux_half mod q) (rescale)
     bool aux_bigger;
+    bool aux_wide;                       // aux >= 2^50: the FP64 policy reduces the word with integer arithmetic first
     // storer
     const u64* ext0; const u64* ext1; u64* dest;
     ulonglong2 inv; u64 lift; bool add_inplace;
@@ -124,7 +125,7 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
     io.load_mode = a.load_mode; io.store_mode = a.store_mode;
     const DevModulus md = a.mods[mi];
     io.q = md.q; io.ratio_hi = md.ratio_hi;
-    io.aux_q = 0; io.aux_ratio_hi = 0; io.aux_half = 0; io.fix = 0; io.aux_bigger = false;
+    io.aux_q = 0; io.aux_ratio_hi = 0; io.aux_half = 0; io.fix = 0; io.aux_bigger = false; io.aux_wide = false;
     io.aux_qd = 0.0; io.aux_half_d = 0.0; io.hm_d = 0.0;
     if (a.load_mode != NTT_LOAD_PLAIN) {
         const DevModulus ax = a.mods[a.aux_mod];
@@ -132,6 +133,7 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
         const u64 half_mod = barrett64(io.aux_half, md.q, md.ratio_hi);
         io.fix = (a.load_mode == NTT_LOAD_KS_ROUND) ? md.q - half_mod : half_mod;
         io.aux_bigger = ax.q > md.q;
+        io.aux_wide = (ax.q >> 50) != 0;
         io.aux_qd = ax.pd; io.aux_half_d = (double)io.aux_half; io.hm_d = (double)half_mod;
     }
     io.ext0 = nullptr; io.ext1 = nullptr; io.dest = gout; io.inv = make_ulonglong2(0, 0); io.lift = 0; io.add_inplace = false;
@@ -415,6 +417,14 @@ struct ArithF64 {
     template <int LM> static __device__ __forceinline__ elem load_io(const NttIo& io, u64 raw, bool, const Mod& m) {
         if constexpr (LM == NTT_LOAD_PLAIN) return f64_corr(f64_from_u64(raw), m.m);
         else {
+            if (io.aux_wide) {
+                // the dropped prime has 50 bits or more ({40,40,60}: a wide special / last prime over narrow data limbs): the word does not
+                // fit a double, so T and its residue mod p are formed with the integer policy's arithmetic (ntt_io_load) and only the
+                // canonical residue becomes a double
+                u64 t = barrett64(raw + io.aux_half, io.aux_q, io.aux_ratio_hi);
+                t = barrett64(t, io.q, io.ratio_hi);
+                return f64_corr(f64_from_u64(t) - io.hm_d, m.m);
+            }
             double t = f64_from_u64(raw) + io.aux_half_d;          // x < aux: t < 1.5 aux < 2^51, exact
             t = (t >= io.aux_qd) ? t - io.aux_qd : t;
             return f64_corr(t - io.hm_d, m.m);

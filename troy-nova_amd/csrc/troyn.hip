@@ -379,10 +379,14 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
     if (!f64 && !force_integer_ntt() && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
-        a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && a.fused_mode == 0 && !two_pass_scratch) {
-        // A plain component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
+        a.fused_mode == 0 && !env_is("TROYN_NTT_SPLIT", "0") &&
+        ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || env_is("TROYN_NTT_SPLIT", "1"))) {
+        // A component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
         // runs of one class, so that the limbs below 2^50 take the FP64 butterflies instead of following the 60-bit limbs into the
-        // integer ones.  Limbs are independent; results are unchanged.
+        // integer ones.  Limbs are independent; results are unchanged.  The launches with a fused prologue / epilogue (key-switch tail,
+        // rescale) can split the same way (TROYN_NTT_SPLIT=1: their per-component operands move with the run, and the FP64 loader
+        // reduces the word of a wide dropped prime with integer arithmetic first, ArithF64::load_io), but they run at the same ~3 TB/s
+        // under either policy, so the extra launch only costs: relinearize {60,40,40,60} 731 k split vs 749 k unsplit -- not the default.
         bool mixed = false;
         for (unsigned j = 1; j < a.ncomp && !mixed; j++) mixed = p->small_modulus[a.table_start + j] != p->small_modulus[a.table_start];
         if (mixed) {
@@ -393,7 +397,10 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
                 NttArgs r = a;
                 r.in = a.in + (long long)j0 * a.in_cstride; r.out = a.out + (long long)j0 * a.out_cstride;
                 r.ncomp = j1 - j0; r.table_start = a.table_start + j0; r.table_count = j1 - j0;
-                if (int rc = launch_ntt(p, r, batch, inverse, s)) return rc;
+                if (a.ext0) r.ext0 = a.ext0 + (long long)j0 * a.ext0_cstride;
+                if (a.ext1) r.ext1 = a.ext1 + (long long)j0 * a.ext1_cstride;
+                if (a.inv_table) r.inv_table = a.inv_table + j0;
+                if (int rc = launch_ntt(p, r, batch, inverse, s, two_pass_scratch)) return rc;
                 j0 = j1;
             }
             return TROYN_OK;
