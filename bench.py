@@ -276,10 +276,11 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     value = world * B * inner * args.steps / elapsed
 
     # ---- roofline of the kernel with the largest share of the timed step: the fused key-switch inner product ----
-    # In the timed region the fused entry runs the batch as two halves on two internal streams, so a launch's event-bracketed duration
-    # includes the time it shares the chip with the other half's kernels (`in_region`).  The kernel's own figure is therefore measured in
-    # the same run right after the region, same buffers, with the chain on ONE stream (TROYN_MRR_CHUNK=0: the library reads its switches
-    # per call): `achieved` = algorithmic bytes per launch / the average of those launch durations.
+    # The fused entry runs the whole batch as one launch sequence on the caller's stream (the default), so the launches timed inside the
+    # region are the kernel's own.  If TROYN_MRR_CHUNK is set the batch runs as chunks on internal streams and a launch's event-bracketed
+    # duration includes the time it shares the chip with another chunk's kernels (`in_region`); the kernel's own figure is then measured in
+    # the same run right after the region, same buffers, with the chain on ONE stream (the library reads its switches per call).
+    # `achieved` = algorithmic bytes per launch / the average of the kernel's own launch durations.
     in_region_ms = ks_ms / max(1, ks_n)
     in_region_items = max(1, round(B * inner * args.steps / max(1, ks_n)))
     excl_ms, excl_n = in_region_ms, ks_n
@@ -326,8 +327,9 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                 "launch_ms": round(ks_launch_ms, 4), "launches_timed": excl_n, "items_per_launch": items_per_launch,
                 "measured": "HIP events on the launch stream around every launch (library kernel timer), same run and buffers, chain on one stream"
                             if items_per_launch != in_region_items else "HIP events on the launch stream around every launch of the timed region (library kernel timer)",
-                "in_region": {"launch_ms": round(in_region_ms, 4), "launches_timed": ks_n, "items_per_launch": in_region_items,
-                              "note": "two chunks in flight on two internal streams: a launch shares the chip with the other chunk's kernels, its duration is not the kernel's own"},
+                "in_region": None if items_per_launch == in_region_items else
+                             {"launch_ms": round(in_region_ms, 4), "launches_timed": ks_n, "items_per_launch": in_region_items,
+                              "note": "TROYN_MRR_CHUNK set: chunks in flight on internal streams, a launch shares the chip with another chunk's kernels, its duration is not the kernel's own"},
                 "algorithmic_bytes_per_launch": alg_bytes, "valu_fp64": valu,
                 # whole pipeline against the chip's HBM peak, both key accountings of SURVEY 8d (keys per op / keys once per batch)
                 "pipeline": {"bytes_per_op_keys_per_op": 18.0e6, "frac_keys_per_op": round(value / world * 18.0e6 / (HBM_PEAK_GBS * 1e9), 4),

@@ -61,11 +61,12 @@ def test_fused_chain_under_every_switch(O, pkg, dev, monkeypatch, env):
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), (env, i)
 
 
-@pytest.mark.parametrize("env,batch", [({"TROYN_MRR_CHUNK": "16"}, 40), ({"TROYN_MRR_CHUNK": "8", "TROYN_MRR_STREAMS": "3"}, 24), ({}, 264), ({"TROYN_MRR_CHUNK": "0"}, 264)],
-                         ids=["chunks_16_16_8", "three_streams", "default_split_in_two", "one_chunk"])
+@pytest.mark.parametrize("env,batch", [({"TROYN_MRR_CHUNK": "16"}, 40), ({"TROYN_MRR_CHUNK": "8", "TROYN_MRR_STREAMS": "3"}, 24), ({"TROYN_MRR_CHUNK": "136"}, 264), ({}, 264)],
+                         ids=["chunks_16_16_8", "three_streams", "two_halves_ragged", "default_one_chunk"])
 def test_fused_chain_chunked_on_internal_streams(O, pkg, dev, monkeypatch, env, batch):
-    """the fused entry cuts large batches into chunks that alternate on internal streams (csrc/troyn.hip); every item must still be the
-    oracle's result, whatever the chunking, including a ragged last chunk"""
+    """the fused entry can cut a batch into chunks that alternate on internal streams (TROYN_MRR_CHUNK / TROYN_MRR_STREAMS, csrc/troyn.hip;
+    the default is one chunk on the caller's stream); every item must be the oracle's result, whatever the chunking, including a ragged
+    last chunk"""
     for k in ("TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():

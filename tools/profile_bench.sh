@@ -9,8 +9,7 @@ OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 10 --warmup 1 --inner 4 --no-cpu-baseline --no-extra"
-# the fused chain on ONE stream for the kernel trace and the counter passes: with the default two internal streams a launch shares the chip
-# with the other chunk's kernels and neither its duration nor its counters are the kernel's own (bench.py measures the same way)
+# the fused chain on ONE stream (the library's default) for the kernel trace and the counter passes
 export TROYN_MRR_CHUNK=0
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o bench -- python3 $ARGS > "$OUT/${TAG}_bench.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -23,8 +22,8 @@ python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$O
         --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
 python3 tools/collect_counters.py ksmac2_kernel $((1024 * 6 * 2 * 256)) 1024 "$OUT/${TAG}_ksmac_counters.json" \
         "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db"
-# the default (two-stream) command, kernel trace only, for the record
-unset TROYN_MRR_CHUNK
+# the chunked option (two halves on two internal streams), kernel trace only, for the record
+export TROYN_MRR_CHUNK=512
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace2" -o bench -- python3 $ARGS > "$OUT/${TAG}_bench_two_streams.log" 2>&1
 cd "$ROOT"

@@ -375,6 +375,8 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     if (lp == 0) return TROYN_OK;
     // limbs that share one input row (component stride 0) are co-located on an XCD by the fused forward kernels
     a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
+    a.xcd_item_major = ((a.fused_mode == NTT_FUSED_TAIL_RESCALE || a.fused_mode == NTT_FUSED_LAST_LIMB) && a.pcount > 1 && !env_is("TROYN_TAIL_ORDER", "poly")) ? 1u : 0u;
+    if (a.fused_mode == NTT_FUSED_LAST_LIMB && a.xcd_item_major) a.xcd_groups = (unsigned)(batch * a.pcount);
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
@@ -1136,20 +1138,18 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s);
         LAUNCH_CHECK();
     }
-    // Two-stream execution of the 5-launch chain (round 3): the batch is cut into an even number of chunks of at most 512 items that run
-    // alternately on two internal streams, forked from and joined to the caller's stream by events.  The chain of one chunk is strictly
-    // sequential, but its kernels bound differently -- the inner product by FP64 issue with HBM at 0.2, the transforms by memory -- so two
-    // chunks in flight fill each other's idle resource and the tails of each other's launches (measured on the headline: +3.2 % with two
-    // halves, +2.9 % with chunks of 256, -0.5 % with chunks of 64, three or four streams lose).  Chunks are independent (the batch is), so
-    // results are unchanged.  TROYN_MRR_CHUNK=<items> overrides the chunk size (0: one chunk), TROYN_MRR_STREAMS=<1..4> the stream count.
-    const int chunk_env = env_int("TROYN_MRR_CHUNK", -1);
+    // Chunked execution of the 5-launch chain on internal streams (round 3, an option: TROYN_MRR_CHUNK=<items, multiple of 8>,
+    // TROYN_MRR_STREAMS=<1..4>, default 2): the batch is cut into chunks that alternate on internal streams, forked from and joined to
+    // the caller's stream by events; chunks are independent (the batch is), results are unchanged.  The kernels of one chunk bound
+    // differently (the inner product by FP64 issue, the transforms by memory), so two chunks in flight fill each other's idle resource:
+    // +3 % when it was introduced.  Since then the inner product and the tail place the workgroups that share rows on one XCD (band
+    // order; polynomials of a limb back to back) and a second chunk's kernels evict exactly those rows from the L2: one chunk on the
+    // caller's stream is faster at every batch size measured (1024 items: 263.6 - 265.2 k vs 260.4 - 260.8 k ops/s with two halves,
+    // 263.2 - 264.1 k with three thirds; 2048: 264.1 - 264.6 k vs 260.1 - 262.7 k; 512: 262.3 - 262.9 k vs 257.4 - 258.1 k) and is the default.
+    const int chunk_env = env_int("TROYN_MRR_CHUNK", 0);
     const int ns = std::min(std::max(env_int("TROYN_MRR_STREAMS", 2), 1), MRR_MAX_STREAMS);
     size_t chunk = batch;
-    if (chunk_env > 0) { if (batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env; }
-    else if (chunk_env < 0 && batch >= 256) {
-        const size_t nchunks = 2 * ((batch + 1023) / 1024);
-        chunk = (((batch + nchunks - 1) / nchunks) + 7) & ~(size_t)7;
-    }
+    if (chunk_env > 0 && batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env;
     if (chunk == batch) return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s);
     MrrStreams* ms = mrr_streams(p->device);
     if (!ms) return fail(TROYN_E_INVALID, std::string(P) + " cannot create the internal streams");
