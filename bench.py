@@ -217,11 +217,14 @@ class KernelTimer:
         return ms.value, int(n.value)
 
 
-def ksmac_alg_bytes(B, n, L, ntt_form):
+def ksmac_alg_bytes(B, n, L, ntt_form, fused_chain=False):
     """algorithmic bytes of one key-switch inner-product launch (SURVEY.md 8d minimum traffic): per item the L
     coefficient-form digits (+ the L NTT-form input limbs when the operand is in NTT form) read once, the two output polynomials of L+1
-    rows written once; the key set (16*N*L*(L+1) bytes) is shared by the whole batch and counted once per launch"""
-    return B * ((2 if ntt_form else 1) * 8.0 * n * L + 16.0 * n * (L + 1)) + 16.0 * n * L * (L + 1)
+    rows written once; the key set (16*N*L*(L+1) bytes) is shared by the whole batch and counted once per launch.
+    fused_chain: the kernel of troyn_ckks_multiply_relinearize_rescale reads the L limbs of all four input polynomials a0, a1, b0, b1 once
+    (the diagonal digit a1 (.) b1 and the tensor terms it adds to the data rows) instead of one NTT-form limb per digit"""
+    operands = 4 if fused_chain else (1 if ntt_form else 0)
+    return B * ((1 + operands) * 8.0 * n * L + 16.0 * n * (L + 1)) + 16.0 * n * L * (L + 1)
 
 
 def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
@@ -303,7 +306,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                 os.environ["TROYN_MRR_CHUNK"] = saved
     ks_launch_ms = excl_ms
     items_per_launch = B if (fused and in_region_items != B) else in_region_items
-    alg_bytes = ksmac_alg_bytes(items_per_launch, n, L, True)
+    alg_bytes = ksmac_alg_bytes(items_per_launch, n, L, True, fused_chain=fused)
     achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_launch_ms else 0.0
     prof = counters_record("ksmac", items_per_launch)   # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
     traffic, valu = None, None
@@ -319,7 +322,8 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     roofline = {"bound": "valu_fp64" if valu else "hbm",
                 "bound_note": "what binds the kernel is FP64 vector issue (see valu_fp64); achieved / peak / frac are the contract's HBM figures: algorithmic bytes per "
                               "launch / the launch duration measured in this run, against the 8 TB/s peak",
-                "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation), "
+                "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation; in the fused chain its epilogue also "
+                          "divides by the special prime and adds the tensor terms c0, c1), "
                           "largest share of the timed step (%.0f %% of its wall clock at the un-overlapped launch duration)"
                           % (100.0 * ks_launch_ms * (B / items_per_launch) * inner * args.steps / (elapsed * 1e3)),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

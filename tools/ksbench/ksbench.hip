@@ -202,7 +202,7 @@ int main(int argc, char** argv) {
     ka.keys = d_keys; ka.key_jstride = 2ll * K * N; ka.key_pstride = (long long)K * N;
     ka.L = L; ka.table_start = 0; ka.table_count = K; ka.batch = (unsigned)B; ka.grouped = (B % 8 == 0) ? 1 : 0;
     if (getenv("KSB_ORDER")) ka.grouped = (unsigned)atoi(getenv("KSB_ORDER"));      // 3: bands of two rows (B must be a multiple of 128)
-    float t_prep = time_launch([&] { hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(1024), dim3(256), 0, 0, b.kp, L, 2 * K, N, d_keys); }, reps);
+    float t_prep = time_launch([&] { hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(1024), dim3(256), 0, 0, b.kp, L, 2 * K, N, d_keys, (const ulonglong2*)nullptr, (const DevModulus*)nullptr, 0u, (double*)nullptr); }, reps);
     printf("%-28s %9.1f us\n", "prepare_keys", t_prep);
     run_variant("ksmac2", [&](const NttArgs& v) {
         KsMacArgs kv = ka; kv.out = v.out;
@@ -224,6 +224,29 @@ int main(int argc, char** argv) {
             CHECK(hipMemcpy(r0.data(), b.out_ref, out_words * 8, hipMemcpyDeviceToHost));
             CHECK(hipMemcpy(r1.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
             printf("%-28s %9.1f us   working copy %9.1f us  %s\n", "BASE fused form (diag_b)", tb, tn, r0 == r1 ? "identical" : "MISMATCH");
+            if (rep == 1) {
+                // tensor terms folded into the epilogue (KsMacArgs::ten_a; the keys' qk^-1 factor does not change the timing): full, operand loads from one line, no products
+                u64* big; CHECK(hipMalloc(&big, 4 * dig_words * 8));      // [a0 | a1 | b0 | b1], each [item][L][N]
+                for (int q = 0; q < 4; q++) hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, big + q * dig_words, dig_words, N, b.d_moduli, L, 1u, 0x5555ull + q);
+                KsMacArgs kt = kv; kt.diag = big + dig_words; kt.diag_b = big + 3 * dig_words;
+                kt.ten_a = big; kt.ten_b = big + 2 * dig_words; kt.ten_bstride = ka.diag_bstride; kt.ten_pstride = (long long)dig_words;
+                kt.diag_keys = d_keys;     // any [L][2][N] doubles will do for the timing
+                { KsMacArgs k0 = kt; k0.ten_a = nullptr; k0.ten_b = nullptr;
+                  float t_none = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, k0); }, reps);
+                  printf("same operands, no tensor terms %9.1f us\n", t_none); }
+                float t_full = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_l = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 128>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_p = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 256>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_lp = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 384>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_9 = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 512>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                printf("tensor folded, a1 / b1 from one line %9.1f us\n", t_9);
+                for (unsigned ord : {1u, 3u}) { KsMacArgs ko = kt; ko.grouped = ord; KsMacArgs kn = ko; kn.ten_a = nullptr; kn.ten_b = nullptr;
+                  float t_o = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, ko); }, reps);
+                  float t_n = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kn); }, reps);
+                  printf("order %u: tensor folded %9.1f us   without %9.1f us\n", ord, t_o, t_n); }
+                printf("tensor folded: full %9.1f us   loads from one line %9.1f us   no products %9.1f us   neither %9.1f us\n", t_full, t_l, t_p, t_lp);
+                CHECK(hipFree(big));
+            }
         }
         // restore the reference output of the plain form for the variants below
         hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 4>), dim3(blocks), dim3(1024), 0, 0, a, b.kp);

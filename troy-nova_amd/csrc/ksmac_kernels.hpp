@@ -42,6 +42,15 @@ struct KsMacArgs {
     const u64* diag_b;                                           // non-null: the NTT-form input is the product diag (.) diag_b (same strides),
                                                                  // formed while loading (fused multiply -> relinearize chain)
     u64* out;          long long out_bstride, out_pstride, out_cstride;   // [item][2][L+1][N]: (item, component, row)
+    // fused multiply -> relinearize -> rescale chain: the two input ciphertexts a, b [item][2][limbs][N] (NTT form).  Non-null: the
+    // keys of the data rows were prepared times qk^-1 (ksmac_prepare_keys_kernel), and a data row k < L leaves the kernel as
+    //   Q_0 = P_0 qk^-1 + a0 (.) b0,   Q_1 = P_1 qk^-1 + a0 (.) b1 + a1 (.) b0      (limb k of a and b)
+    // i.e. with relinearize's division by the special prime and its trailing add (evaluator_keyswitching_core.cu:641-656,
+    // evaluator_keyswitching.cu:143) already applied to the inner product P; the special row stays P.  The memory-bound kernels
+    // behind this one then read one row where they read P and four rows of a and b.
+    const u64* ten_a; const u64* ten_b; long long ten_bstride, ten_pstride;
+    const double* diag_keys;   // with ten_a: [k][2][N] the two components of key k under modulus k (times qk^-1), NATURAL order: the diagonal
+                               // digit a1 (.) b1 of a data row is multiplied-accumulated in the epilogue's coalesced layout
     const DevModulus* mods;
     const double* tw;       // [K][N]  forward twiddles w, reference table order
     const double* tw_r1;    // [K][N/1024][32]  round-1 vector per value of the index bits above bit 9
@@ -67,18 +76,30 @@ __host__ __device__ constexpr unsigned ksm_perm(unsigned i) {
     return (i & ~2047u) | ((((i >> 1) & 15u) * 64u + ((i >> 5) & 63u)) * 2u) | (i & 1u);
 }
 
-// keys[j] -> [2][K][N] u64 (the reference's KSwitchKeys layout)  ==>  prepared [j][2][K][N] doubles, permuted
-static __global__ __launch_bounds__(256) void ksmac_prepare_keys_kernel(KeyPtrs keys, unsigned L, unsigned rows_per_key, unsigned n, double* out) {
+// keys[j] -> [2][K][N] u64 (the reference's KSwitchKeys layout)  ==>  prepared [j][2][K][N] doubles, permuted.
+// scale != nullptr (fused chain): the rows of the data moduli r < scale_rows (row index within a component) are multiplied by
+// scale[r] = qk^-1 mod q_r (Shoup pair) first -- exact integer arithmetic, so the inner product comes out as P qk^-1 mod q_r.
+static __global__ __launch_bounds__(256) void ksmac_prepare_keys_kernel(KeyPtrs keys, unsigned L, unsigned rows_per_key, unsigned n, double* out,
+                                                                        const ulonglong2* scale, const DevModulus* mods, unsigned scale_rows, double* diag_out) {
     const size_t pairs_per_key = (size_t)rows_per_key * (n / 2);
     const size_t total = (size_t)L * pairs_per_key;
+    const unsigned K = rows_per_key / 2;
     for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
         const unsigned j = (unsigned)(p / pairs_per_key);
         const size_t q = p % pairs_per_key;
         const size_t row = q / (n / 2);
         const unsigned i = (unsigned)(q % (n / 2)) * 2u;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(keys.p[j] + row * n + i);
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(keys.p[j] + row * n + i);
+        const unsigned r = (unsigned)(row % K);
+        if (scale && r < scale_rows) {
+            const ulonglong2 f = scale[r];
+            const u64 qr = mods[r].q;
+            v.x = shoup_mul(v.x, f.x, f.y, qr); v.y = shoup_mul(v.y, f.x, f.y, qr);
+        }
         double2 d = make_double2(f64_from_u64(v.x), f64_from_u64(v.y));
         *reinterpret_cast<double2*>(out + ((size_t)j * rows_per_key + row) * n + ksm_perm(i)) = d;
+        // the block (key j, modulus j) again in natural order for the epilogue of the fused chain's data rows (KsMacArgs::diag_keys)
+        if (diag_out && r == j) *reinterpret_cast<double2*>(diag_out + ((size_t)j * 2 + row / K) * n + i) = d;
     }
 }
 
@@ -146,7 +167,7 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 #define KSM_MARK(ph) do { } while (0)
 #endif
 
-// ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads all hit one cache line,
+// ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads / bit7 tensor operand loads all hit one cache line, bit8 no tensor products,
 // bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
 template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false>
 #ifndef KSM_WAVES_PER_SIMD
@@ -157,6 +178,9 @@ template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false>
 #endif
 #ifndef KSM_LOAD_WINDOW
 #define KSM_LOAD_WINDOW 12
+#endif
+#ifndef KSM_TEN_WINDOW
+#define KSM_TEN_WINDOW 2      // register pairs (six 16-byte loads each) in flight in the epilogue of the fused chain's data rows
 #endif
 __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel(KsMacArgs a) {
     constexpr auto abl = [](int bit) constexpr { return ((ABL >> bit) & 1) != 0; };
@@ -285,7 +309,12 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
     unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
-    for (unsigned it = 0; it < a.L; ++it) {
+    // fused chain, data row: the diagonal digit (a1 (.) b1 of limb k, NTT form) is left to the epilogue, which loads a1 and b1 anyway
+    // (the sum is exact, its order is free)
+    const bool ten_row = a.ten_a && k < a.L;
+    const unsigned steps = ten_row ? a.L - 1 : a.L;
+    for (unsigned step = 0; step < steps; ++step) {
+        const unsigned it = !ten_row ? step : (step < k ? step : step + 1);     // digit of this step
         double x[32];
         // nothing below depends on the digit except the input and the key: without these the compiler hoists every
         // twiddle load (and its w/p product) out of the digit loop and spills them
@@ -470,7 +499,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         // ---- multiply-accumulate with key `it` straight from the registers ---------------------------------------
         mac_all(x, it);
         KSM_MARK(6);
-        if ((it & 7u) == 7u)
+        if ((step & 7u) == 7u)
             static_for<0, 32>([&](auto rc) { acc0[decltype(rc)::value] = f64_corr(acc0[decltype(rc)::value], fm); acc1[decltype(rc)::value] = f64_corr(acc1[decltype(rc)::value], fm); });
     }
 
@@ -479,6 +508,77 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
 #endif
     // ---- canonical results, transposed through the wave's own LDS slice, 16-byte coalesced stores --------------
     u64* go = a.out + (long long)b * a.out_bstride + (long long)k * a.out_cstride + (size_t)h * (KSM_THREADS * 32);
+    if (ten_row) {
+        // fused chain, data row: Q_c = P_c qk^-1 (the keys carry the factor) + tensor term c.  Both accumulators cross the wave's slice
+        // (in place: 16 register pairs out, 16 pairs of the coalesced layout back) as re-centred doubles; then ONE sweep over the 16
+        // pairs loads a0, b0, a1, b1 and the two key components of the diagonal digit (natural order) with 16-byte loads in a rolling
+        // window of W pairs, adds the diagonal digit's term d (.) key with d = a1 (.) b1, adds the tensor terms and stores both
+        // components.  The operand rows are cold (HBM) and the workgroup has nothing else to do while they arrive, so every row is read
+        // once: with the diagonal digit in the loop (a1, b1 read there and again here) the launch was 0.18 ms slower, with one pass
+        // per component (a0, b0 twice as well) 0.3 ms.
+        const size_t toff = (size_t)b * a.ten_bstride + (size_t)k * N + (size_t)h * (KSM_THREADS * 32);
+        const u64* ta0 = ksm_uniform(a.ten_a + toff);
+        const u64* tb0 = ksm_uniform(a.ten_b + toff);
+        const u64* ta1 = ksm_uniform(a.ten_a + toff + a.ten_pstride);
+        const u64* tb1 = ksm_uniform(a.ten_b + toff + a.ten_pstride);
+        const double* dk0 = ksm_uniform(a.diag_keys + (size_t)k * 2 * N + (size_t)h * (KSM_THREADS * 32));
+        const double* dk1 = ksm_uniform(dk0 + N);
+        constexpr int W = KSM_TEN_WINDOW;
+        ulonglong2 xa0[16], xb0[16], xa1[16], xb1[16];
+        double2 y0[16], y1[16];
+        auto request = [&](auto ic) {
+            constexpr int m = decltype(ic)::value;
+            xa1[m] = ksm_gload<ulonglong2>(ta1 + ((abl(7) || abl(9)) ? 0 : m * 128), (abl(7) || abl(9)) ? (slice_off & 16u) : slice_off);
+            xb1[m] = ksm_gload<ulonglong2>(tb1 + ((abl(7) || abl(9)) ? 0 : m * 128), (abl(7) || abl(9)) ? (slice_off & 16u) : slice_off);
+            y0[m] = ksm_gload<double2>(dk0 + (abl(7) ? 0 : m * 128), abl(7) ? (slice_off & 16u) : slice_off);
+            y1[m] = ksm_gload<double2>(dk1 + (abl(7) ? 0 : m * 128), abl(7) ? (slice_off & 16u) : slice_off);
+            xa0[m] = ksm_gload<ulonglong2>(ta0 + (abl(7) ? 0 : m * 128), abl(7) ? (slice_off & 16u) : slice_off);
+            xb0[m] = ksm_gload<ulonglong2>(tb0 + (abl(7) ? 0 : m * 128), abl(7) ? (slice_off & 16u) : slice_off);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, W>([&](auto ic) { request(ic); });
+        __builtin_amdgcn_sched_barrier(0);
+        auto cross = [&](double (&acc)[32]) {
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                *reinterpret_cast<double2*>(&lds[p2 + 2 * m]) = make_double2(f64_corr(acc[2 * m], fm), f64_corr(acc[2 * m + 1], fm));
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const double2 v = *reinterpret_cast<const double2*>(&lds[pt + ksm_phys(m * 128u)]);
+                acc[2 * m] = v.x; acc[2 * m + 1] = v.y;
+            });
+            __builtin_amdgcn_wave_barrier();
+        };
+        cross(acc0);
+        cross(acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            const double a0x = f64_from_u64(xa0[m].x), a0y = f64_from_u64(xa0[m].y), b0x = f64_from_u64(xb0[m].x), b0y = f64_from_u64(xb0[m].y);
+            const double a1x = f64_from_u64(xa1[m].x), a1y = f64_from_u64(xa1[m].y), b1x = f64_from_u64(xb1[m].x), b1y = f64_from_u64(xb1[m].y);
+            double q0x = acc0[2 * m], q0y = acc0[2 * m + 1], q1x = acc1[2 * m], q1y = acc1[2 * m + 1];      // |.| <= p/2 + 1
+            if constexpr (abl(8)) {
+                q0x += a0x + b0x + y0[m].x; q0y += a0y + b0y + y0[m].y; q1x += b1x + a1x + y1[m].x; q1y += b1y + a1y + y1[m].y;
+            } else {
+            // diagonal digit: d = a1 (.) b1 re-centred (what the loop's loader produced), times the key of digit k under modulus k
+            const double dx = f64_corr(f64_mulq(f64_corr(a1x, fm), b1x, inv_p, p), fm), dy = f64_corr(f64_mulq(f64_corr(a1y, fm), b1y, inv_p, p), fm);
+            mac2(q0x, q1x, dx, y0[m].x, y1[m].x);
+            mac2(q0y, q1y, dy, y0[m].y, y1[m].y);
+            // tensor terms; canonical factors below p: each product is within (-0.875 p, 0.875 p) (ArithF64::prod_in)
+            q0x += f64_mulq(a0x, b0x, inv_p, p);
+            q0y += f64_mulq(a0y, b0y, inv_p, p);
+            q1x += f64_mulq(a0x, b1x, inv_p, p) + f64_mulq(a1x, b0x, inv_p, p);
+            q1y += f64_mulq(a0y, b1y, inv_p, p) + f64_mulq(a1y, b0y, inv_p, p);
+            }
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + m * 128, slice_off))), f64_canon(q0x, fm), f64_canon(q0y, fm));
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + a.out_pstride + m * 128, slice_off))), f64_canon(q1x, fm), f64_canon(q1y, fm));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m + W < 16) request(std::integral_constant<int, m + W>{});
+        });
+    } else
     static_for<0, 2>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         static_for<0, 16>([&](auto mc) {

@@ -741,15 +741,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     wv[2 * m] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
                     wv[2 * m + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
                 } else if constexpr (F_LAST_LD) {
-                    // P qk^-1 + c_k at the dropped limb
+                    // Q = P qk^-1 + c_k at the dropped limb, as ksmac2 left it (KsMacArgs::ten_a)
                     const ulonglong2 vp = nt_load2(gin + gbase + idx);
-                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(io.a0 + mul_off + gbase + idx), b0 = *reinterpret_cast<const ulonglong2*>(io.b0 + mul_off + gbase + idx);
-                    ulonglong2 a1 = a0, b1 = b0;
-                    if (io.poly) { a1 = *reinterpret_cast<const ulonglong2*>(io.a1 + mul_off + gbase + idx); b1 = *reinterpret_cast<const ulonglong2*>(io.b1 + mul_off + gbase + idx); }
-                    const elem e0 = A::scale_by(f64_from_u64(vp.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md);
-                    const elem e1 = A::scale_by(f64_from_u64(vp.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md);
-                    wv[2 * m] = A::to_lds(e0, md);
-                    wv[2 * m + 1] = A::to_lds(e1, md);
+                    wv[2 * m] = A::to_lds(f64_from_u64(vp.x), md);
+                    wv[2 * m + 1] = A::to_lds(f64_from_u64(vp.y), md);
                 } else {
                     // (uniform row + pair offset) + one 32-bit lane offset: no 64-bit address per load
                     const ulonglong2 v = ld2_at(gin + gbase + m * 128u, lane * 16u, a.stream_loads != 0);
@@ -938,15 +933,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned idx = m * 128u + lane * 2u;
                 u64 v0 = wv[2 * m], v1 = wv[2 * m + 1];
                 if constexpr (F_TR_ST) {
-                    // (P_j qk^-1 + c_kj - y) ql^-1: relinearize's divide-and-add and the rescale's divide in one epilogue.  The five operand
-                    // rows share one 32-bit lane offset on wave-uniform bases
+                    // (Q_kj - y) ql^-1 with Q_kj = P_j qk^-1 + c_kj as ksmac2 left it: relinearize's divide-and-add happened there, the
+                    // rescale's divide happens here
                     const unsigned boff = (gbase + idx) * 8u;
                     const ulonglong2 pr = ld2_at(io.ext0, boff, true);
-                    const ulonglong2 a0 = ld2_at(io.a0 + mul_off, boff), b0 = ld2_at(io.b0 + mul_off, boff);
-                    ulonglong2 a1 = a0, b1 = b0;
-                    if (io.poly) { a1 = ld2_at(io.a1 + mul_off, boff); b1 = ld2_at(io.b1 + mul_off, boff); }
-                    const elem t0 = A::scale_by(f64_from_u64(pr.x), io.inv_d, md) + A::tensor_term(io.poly, a0.x, a1.x, b0.x, b1.x, md) - A::from_lds(v0);
-                    const elem t1 = A::scale_by(f64_from_u64(pr.y), io.inv_d, md) + A::tensor_term(io.poly, a0.y, a1.y, b0.y, b1.y, md) - A::from_lds(v1);
+                    const elem t0 = f64_from_u64(pr.x) - A::from_lds(v0);
+                    const elem t1 = f64_from_u64(pr.y) - A::from_lds(v1);
                     // the product of a re-centred factor is within (-0.7 p, 0.7 p): one conditional add canonicalises it
                     v0 = A::canon_small(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md);
                     v1 = A::canon_small(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md);

@@ -1002,7 +1002,7 @@ static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
     w.poly_prod = off; off += batch * 2 * (size_t)(L + 1) * n;
     w.spec_intt = off; off += batch * 2 * n;
     w.last_intt = off; off += batch * 2 * n;
-    w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n;
+    w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys + the diagonal blocks in natural order
     w.fast_total = off;
     // composition of the three public calls (any other shape)
     off = 0;
@@ -1054,6 +1054,8 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         std::memset(&m, 0, sizeof(m));
         m.digits = ws + w.digits; m.dig_bstride = (long long)L * n; m.dig_cstride = n;
         m.diag = a + ct_p; m.diag_b = b + ct_p; m.diag_bstride = ct_b; m.diag_cstride = n;
+        m.ten_a = a; m.ten_b = b; m.ten_bstride = ct_b; m.ten_pstride = ct_p;      // data rows leave as Q = P qk^-1 + c (keys prepared times qk^-1)
+        m.diag_keys = kf + (size_t)L * 2 * K * n;
         m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
         m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
@@ -1135,7 +1137,9 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
     {
         const size_t pairs = (size_t)L * 2 * K * (n / 2);
-        launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s);
+        // the rows of the data moduli carry the factor qk^-1: the inner product leaves ksmac2 as P qk^-1 (+ the tensor term, KsMacArgs::ten_a)
+        launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s,
+                                  p->d_inv_last + (size_t)K * K, p->d_mods, L, kf + (size_t)L * 2 * K * n);
         LAUNCH_CHECK();
     }
     // Chunked execution of the 5-launch chain on internal streams (round 3, an option: TROYN_MRR_CHUNK=<items, multiple of 8>,

@@ -17,8 +17,9 @@ void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs&
 #undef KSMAC2_CASE
 }
 
-void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s) {
-    hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(blocks), dim3(256), 0, s, kp, L, polys, n, out);
+void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s,
+                               const ulonglong2* scale, const DevModulus* mods, unsigned scale_rows, double* diag_out) {
+    hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(blocks), dim3(256), 0, s, kp, L, polys, n, out, scale, mods, scale_rows, diag_out);
 }
 
 }  // namespace troyn
