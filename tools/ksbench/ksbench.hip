@@ -234,14 +234,14 @@ int main(int argc, char** argv) {
                 { KsMacArgs k0 = kt; k0.ten_a = nullptr; k0.ten_b = nullptr;
                   float t_none = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, k0); }, reps);
                   printf("same operands, no tensor terms %9.1f us\n", t_none); }
-                float t_full = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
-                float t_l = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 128>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
-                float t_p = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 256>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
-                float t_lp = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 384>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
-                float t_9 = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 512>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_full = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 0, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_l = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 128, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_p = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 256, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_lp = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 384, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
+                float t_9 = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 512, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kt); }, reps);
                 printf("tensor folded, a1 / b1 from one line %9.1f us\n", t_9);
                 for (unsigned ord : {1u, 3u}) { KsMacArgs ko = kt; ko.grouped = ord; KsMacArgs kn = ko; kn.ten_a = nullptr; kn.ten_b = nullptr;
-                  float t_o = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, ko); }, reps);
+                  float t_o = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 0, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, ko); }, reps);
                   float t_n = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kn); }, reps);
                   printf("order %u: tensor folded %9.1f us   without %9.1f us\n", ord, t_o, t_n); }
                 printf("tensor folded: full %9.1f us   loads from one line %9.1f us   no products %9.1f us   neither %9.1f us\n", t_full, t_l, t_p, t_lp);

@@ -29,3 +29,5 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace2" -o bench -- python3 
 cd "$ROOT"
 python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace2/bench_results.db" > "$OUT/${TAG}_two_streams_summary.txt"
 tail -3 "$OUT/${TAG}_bench.log"
+# the databases are scratch (tens of MB each; gpurun copies back at most 64 MiB): the summaries above are what profiles/ keeps
+rm -rf "$OUT/prof_$TAG"

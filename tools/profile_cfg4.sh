@@ -17,3 +17,5 @@ cd "$ROOT"
 python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" --pmc "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" \
         --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
 tail -2 "$OUT/${TAG}_bench.log"
+# the databases are scratch (tens of MB each; gpurun copies back at most 64 MiB): the summaries above are what profiles/ keeps
+rm -rf "$OUT/prof_$TAG"

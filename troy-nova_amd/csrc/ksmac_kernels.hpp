@@ -169,7 +169,9 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 
 // ABL: development-only ablation mask (tools/ksbench), 0 in the library.  bit0 digit loads / bit1 key loads / bit5 twiddle loads / bit7 tensor operand loads all hit one cache line, bit8 no tensor products,
 // bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
-template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false>
+// TEN: the instantiation of the fused chain (KsMacArgs::ten_a): data rows leave as Q = P qk^-1 + c; kept out of the other instantiations,
+// whose digit loop otherwise pays for the epilogue's registers (scratch 32 -> 48 bytes, relinearize -4 %)
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
 #endif
     // fused chain, data row: the diagonal digit (a1 (.) b1 of limb k, NTT form) is left to the epilogue, which loads a1 and b1 anyway
     // (the sum is exact, its order is free)
-    const bool ten_row = a.ten_a && k < a.L;
+    const bool ten_row = TEN && k < a.L;
     const unsigned steps = ten_row ? a.L - 1 : a.L;
     for (unsigned step = 0; step < steps; ++step) {
         const unsigned it = !ten_row ? step : (step < k ? step : step + 1);     // digit of this step
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         // i.e. it waits for the round's twiddle loads that were issued to travel under the exchange (round 3: -5.6 % on the launch).
         // Re-derived per digit they cost one v_add each.
         asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(pt));
-        if (a.diag && it == k) {
+        if (!TEN && a.diag && it == k) {      // (TEN: the diagonal digit of a data row is handled in the epilogue, the special row has none)
             // the digit of row k under its own modulus is the NTT-form input limb (evaluator_keyswitching_core.cu:851-852):
             // coalesced load, transpose through the wave's own LDS slice into the accumulators' layout
             const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
 #endif
     // ---- canonical results, transposed through the wave's own LDS slice, 16-byte coalesced stores --------------
     u64* go = a.out + (long long)b * a.out_bstride + (long long)k * a.out_cstride + (size_t)h * (KSM_THREADS * 32);
-    if (ten_row) {
+    if constexpr (TEN) { if (ten_row) {
         // fused chain, data row: Q_c = P_c qk^-1 (the keys carry the factor) + tensor term c.  Both accumulators cross the wave's slice
         // (in place: 16 register pairs out, 16 pairs of the coalesced layout back) as re-centred doubles; then ONE sweep over the 16
         // pairs loads a0, b0, a1, b1 and the two key components of the diagonal digit (natural order) with 16-byte loads in a rolling
@@ -578,7 +580,8 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (m + W < 16) request(std::integral_constant<int, m + W>{});
         });
-    } else
+    } }
+    if (!ten_row)
     static_for<0, 2>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         static_for<0, 16>([&](auto mc) {

@@ -48,7 +48,6 @@ struct NttArgs {
     const ulonglong2* inv_table;   // store: Shoup pair of (dropped prime)^-1 mod q_j, indexed by component j
     unsigned batch;                // ks_mac_kernel: number of items (workgroup -> (row, item) mapping)
     unsigned xcd_groups;           // fused tail / rescale launches: batch * pcount groups whose ncomp limbs share one input row (0: off)
-    unsigned xcd_item_major;       // NTT_FUSED_TAIL_RESCALE: all pcount * ncomp workgroups of an item on one XCD, the polynomials of a limb back to back
     long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
     unsigned long long ks_row_mask; // ks_mac_kernel: 0 = all decomp + 1 output rows; else the launch covers the rows whose bit is set (mixed chains:
                                    // the rows of moduli >= 2^50 take this kernel, the others ksmac2_kernel)
@@ -91,14 +90,16 @@ enum NttStore {
 //     l         = INTT(relin_{L-1}) = INTT(P_{L-1} qk^-1 + c_{L-1}) - r_{L-1}(s) qk^-1
 //     out_j     = (relin_j - NTT_j(f_j(l))) ql^-1                           (utils/rns_tool.cu:523-627)
 //               = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1
-// i.e. ONE forward transform per output limb instead of two, and c is never materialised:
+// i.e. ONE forward transform per output limb instead of two, and c is never materialised.  Since round 3 the inner product kernel hands
+// over Q_j = P_j qk^-1 + c_j for the data rows (its keys are prepared times qk^-1 and its epilogue adds the tensor terms, KsMacArgs::ten_a):
+// the kernels below read one row where they used to read P_j and four rows of a and b.
 constexpr unsigned NTT_FLAG_STORE_F64 = 16u;         // NttArgs::flags: NTT_FUSED_MULPAIR stores its canonical outputs as doubles (the digits ksmac2 reads)
 constexpr unsigned NTT_FLAG_STORE_ROUND_HALF = 8u;   // NttArgs::flags: a plain FP64 inverse transform stores T = (x + q/2) mod q as doubles
 
 enum NttFused {
     NTT_FUSED_MULPAIR = 3,       // inverse: input word = a1 (.) b1 (the product c2 formed while loading)
-    NTT_FUSED_LAST_LIMB = 4,     // inverse: input = P qk^-1 + c_k at limb L-1; stored word = result - r(s) qk^-1   (= l above)
-    NTT_FUSED_TAIL_RESCALE = 5,  // forward: input = r_j(s) qk^-1 + f_j(l); stored word = (P_j qk^-1 + c_kj - y) ql^-1
+    NTT_FUSED_LAST_LIMB = 4,     // inverse: input = Q = P qk^-1 + c_k at limb L-1 (from ksmac2); stored word = result - r(s) qk^-1   (= l above)
+    NTT_FUSED_TAIL_RESCALE = 5,  // forward: input = r_j(s) qk^-1 + f_j(l); stored word = (Q_kj - y) ql^-1
 };
 
 struct NttIo {
@@ -571,21 +572,9 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             // The ncomp limbs of a group read the SAME input row (fused key-switch tail / rescale).  Workgroups are
             // dealt round-robin to the 8 XCDs, so place a group's limbs 8 apart: they land on one XCD, back to back,
             // and the shared row is fetched from HBM once instead of ncomp times.
-            if ((IOM == NTT_FUSED_TAIL_RESCALE || IOM == NTT_FUSED_LAST_LIMB) && a.xcd_item_major) {
-                // the fused chain's tail: polynomial 0 of limb j reads a0, b0 and polynomial 1 reads a0, b1, a1, b0 in its epilogue, all
-                // limbs of polynomial k read the rows s_k, l_k in their loaders.  The pcount * ncomp workgroups of an ITEM go to one XCD
-                // (ids 8 apart), the two polynomials of a limb back to back, so that a0 / b0 are fetched once per limb as well.
-                // (NTT_FUSED_LAST_LIMB: ncomp = 1, the two polynomials of the item share a0, b0 of limb L-1 the same way.)
-                const unsigned wpi = a.ncomp * a.pcount, per = 8u * wpi, items = a.xcd_groups / a.pcount, full = (items / 8u) * per;
-                unsigned bi, idx;
-                if (bid < full) { const unsigned r = bid % per; idx = r / 8u; bi = (bid / per) * 8u + (r % 8u); }
-                else { const unsigned r = bid - full; idx = r % wpi; bi = (items / 8u) * 8u + r / wpi; }
-                j = idx / a.pcount; g = bi * a.pcount + idx % a.pcount;
-            } else {
             const unsigned per = 8u * a.ncomp, full = (a.xcd_groups / 8u) * per;
             if (bid < full) { const unsigned r = bid % per; j = r / 8u; g = (bid / per) * 8u + (r % 8u); }
             else { const unsigned r = bid - full; j = r % a.ncomp; g = (a.xcd_groups / 8u) * 8u + r / a.ncomp; }
-            }
         } else {
             j = bid % a.ncomp; g = bid / a.ncomp;
         }

@@ -375,8 +375,6 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     if (lp == 0) return TROYN_OK;
     // limbs that share one input row (component stride 0) are co-located on an XCD by the fused forward kernels
     a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
-    a.xcd_item_major = ((a.fused_mode == NTT_FUSED_TAIL_RESCALE || a.fused_mode == NTT_FUSED_LAST_LIMB) && a.pcount > 1 && !env_is("TROYN_TAIL_ORDER", "poly")) ? 1u : 0u;
-    if (a.fused_mode == NTT_FUSED_LAST_LIMB && a.xcd_item_major) a.xcd_groups = (unsigned)(batch * a.pcount);
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
@@ -1071,17 +1069,16 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         x.flags = NTT_FLAG_STORE_ROUND_HALF;     // stored as (s + qk/2) mod qk, the limb-independent part of the key switch's rounding fix
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
-    // (4) l = INTT(relin_{L-1}) = INTT(P_{L-1} qk^-1 + c_{L-1}) - r(s) qk^-1   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
+    // (4) l = INTT(relin_{L-1}) = INTT(Q_{L-1}) - r(s) qk^-1 with Q = P qk^-1 + c as ksmac2 left it   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
     {
         NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.last_intt, 2, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         x.in_pstride = pp_p; x.in_bstride = pp_b;
-        mul_operands(x, L - 1);
         x.in2 = ws + w.spec_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
         x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K + (L - 1);
         x.fused_mode = NTT_FUSED_LAST_LIMB;
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
-    // (5) out_j = (P_j qk^-1 + c_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1 for the L-1 remaining limbs: ski_util6/7 (:570-658), the
+    // (5) out_j = (Q_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1, Q_j = P_j qk^-1 + c_j, for the L-1 remaining limbs: ski_util6/7 (:570-658), the
     //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
     {
         NttArgs x = contiguous_args(p, ws + w.spec_intt, out, 2, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
@@ -1090,7 +1087,6 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K;
         x.aux2_mod = L - 1; x.inv_table2 = p->d_inv_last + (size_t)L * K;
         x.ext0 = ws + w.poly_prod; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
-        mul_operands(x, 0);
         x.fused_mode = NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
         if ((rc = launch_ntt(p, x, batch, false, s))) return rc;
     }
