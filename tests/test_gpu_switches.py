@@ -4,7 +4,7 @@
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: item-major, XCD-grouped)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
-  TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0021)
+  TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0027)
   TROYN_NTT_ARITH=u64       integer butterflies for every modulus
 (TROYN_BEHZ, TROYN_KS_TAIL, TROYN_BFV_TENSOR, TROYN_TENSOR_WGS, TROYN_PLAIN_MAC are covered by parametrised tests next to their kernels.)"""
 import numpy as np
@@ -88,7 +88,7 @@ def test_fused_chain_chunked_on_internal_streams(O, pkg, dev, monkeypatch, env, 
         assert np.array_equal(got[item], cache[key]), (env, item)
 
 
-@pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021"])
+@pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021", "0x0027"])
 def test_ntt_half_word_variants(O, pkg, dev, monkeypatch, half):
     """whole-limb N = 16384 transforms, forward and inverse, plain and rescale-fused, with every half-word LDS variant on / off"""
     monkeypatch.setenv("TROYN_NTT_HALF", half)
@@ -136,3 +136,24 @@ def test_key_switch_workgroup_orders(O, pkg, dev, monkeypatch, n, bits, L, batch
     for item in (0, 9, batch // 2 + 3, batch - 1):
         want = ctx.switch_key(L, ckks, tg[item], keys, assign=pkg.ASSIGN_OVERWRITE, dest=d0)
         assert np.array_equal(res["band"][item], want), item
+
+
+@pytest.mark.parametrize("n,batch", [(16384, 1), (16384, 13), (16384, 129), (16384, 136), (16384, 256), (8192, 5), (8192, 264), (32768, 3), (32768, 64)])
+def test_fused_chain_batch_shapes(O, pkg, dev, monkeypatch, n, batch):
+    """the fused entry on batches that select every workgroup order of its inner product (a multiple of the band size: band; a multiple
+    of 8: item; anything else: plain) and leave ragged last groups in the transform kernels' XCD placement; every item is the oracle's"""
+    for k in ("TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_KS_ORDER"):
+        monkeypatch.delenv(k, raising=False)
+    L = 3
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [50] * 4, L)
+    base_a = np.stack([ctx.random_ct(11 + i, 2, L) for i in range(4)])
+    base_b = np.stack([ctx.random_ct(29 + i, 2, L) for i in range(4)])
+    ia = np.arange(batch) % 4
+    ib = (np.arange(batch) // 4 + np.arange(batch)) % 4
+    got = pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, pkg.to_device(base_a[ia], dev), pkg.to_device(base_b[ib], dev), dkeys))
+    cache = {}
+    for item in range(batch):
+        key = (int(ia[item]), int(ib[item]))
+        if key not in cache:
+            cache[key] = ctx.mod_switch_scale_to_next(L, ctx.relinearize(L, True, ctx.ckks_multiply(L, base_a[key[0]], base_b[key[1]]), keys))
+        assert np.array_equal(got[item], cache[key]), item
