@@ -150,12 +150,14 @@ def test_rescale_corner_vectors(O, pkg, dev, n, bits, L):
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i])), nm
 
 
-@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [50] * 5, 4), (32768, [50] * 4, 3)])
+@pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [50] * 5, 4), (32768, [50] * 4, 3), (8192, [50] * 12, 11), (16384, [50] * 11, 9), (8192, [50] * 3, 2)])
 @pytest.mark.parametrize("key_kind", ["random", "all_q-1"])
 def test_pipeline_corner_vectors(O, pkg, dev, n, bits, L, key_kind):
     """multiply -> relinearize -> rescale on extreme operands, through the three calls AND through the fused entry (the path bench.py
     times): the fused tail sums scale_by + two tensor products - y to ~3.1 p before its re-centring, the MULPAIR / LAST_LIMB loaders and
-    the double-format digits have their own range assumptions -- all exercised at the edges here, with random keys and keys that are all q-1"""
+    the double-format digits have their own range assumptions -- all exercised at the edges here, with random keys and keys that are all q-1.
+    L = 9 / 11 cross the accumulators' re-centring after 8 digits with the diagonal digit and the tensor terms added in ksmac2's epilogue
+    (round 3), L = 2 is the shortest chain the fused entry takes."""
     q = O.coeff_modulus_create(n, bits)
     K = len(q)
     ctx = O.Context("ckks", n, q)
