@@ -4,7 +4,7 @@
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: item-major, XCD-grouped)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
-  TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0027)
+  TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0127)
   TROYN_NTT_ARITH=u64       integer butterflies for every modulus
 (TROYN_BEHZ, TROYN_KS_TAIL, TROYN_BFV_TENSOR, TROYN_TENSOR_WGS, TROYN_PLAIN_MAC are covered by parametrised tests next to their kernels.)"""
 import numpy as np
@@ -88,7 +88,7 @@ def test_fused_chain_chunked_on_internal_streams(O, pkg, dev, monkeypatch, env, 
         assert np.array_equal(got[item], cache[key]), (env, item)
 
 
-@pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021", "0x0027"])
+@pytest.mark.parametrize("half", ["0x3f3f", "0", "0x0021", "0x0027", "0x0127"])
 def test_ntt_half_word_variants(O, pkg, dev, monkeypatch, half):
     """whole-limb N = 16384 transforms, forward and inverse, plain and rescale-fused, with every half-word LDS variant on / off"""
     monkeypatch.setenv("TROYN_NTT_HALF", half)

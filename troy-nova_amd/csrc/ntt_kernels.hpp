@@ -813,6 +813,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         }
 
         constexpr int NLAYERS = BHI - BLO + 1;
+        unsigned tw_dep = 0;      // see below
         static_for<0, NLAYERS>([&](auto lc) {
             // forward: highest bit first; inverse: lowest bit first
             constexpr int li = decltype(lc)::value;
@@ -821,6 +822,13 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             constexpr int kk = TB - 1 - bit;       // layer inside the tile
             constexpr int l = LO + kk;             // global (forward-numbered) layer of this bit
             if constexpr (KSMAC || (HALF && !INV)) __builtin_amdgcn_sched_barrier(0);   // layer by layer: bounds the live twiddles
+            if constexpr (HALF && INV && r == 0 && std::is_same<A, ArithF64>::value && (decltype(lc)::value == 1 || decltype(lc)::value == 2)) {
+                // first inverse round, per-lane twiddles: the 8 twiddles of layer 0 and the 7 of layers 1..3 do not fit next to the 16
+                // coefficients in 64 registers.  An opaque zero derived from a layer-0 result is added to the later layers' table index, so
+                // their loads cannot be hoisted above layer 0 (a scheduling barrier here costs more registers than it saves).
+                const unsigned lo = (unsigned)f64_double_to_bits(x[0]);
+                asm volatile("v_and_b32 %0, 0, %1" : "=v"(tw_dep) : "v"(lo));
+            }
             static_for<0, (E >> (rb + 1))>([&](auto hc) {
                 constexpr int hi = decltype(hc)::value;
                 const unsigned loc0 = twbase | ((unsigned)(hi << (rb + 1)) << S);
@@ -828,7 +836,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
 #ifdef TROYN_ABLATE_NO_TWIDDLE
                 const tw_t w = tw_load(1u + (grp & 1u));
 #else
-                const tw_t w = tw_load(INV ? N - (2u << l) + 1 + grp : (1u << l) + grp);
+                const tw_t w = tw_load((INV ? N - (2u << l) + 1 + grp : (1u << l) + grp) + tw_dep);
 #endif
                 static_for<0, (1 << rb)>([&](auto oc) {
                     constexpr int R0 = (hi << (rb + 1)) | decltype(oc)::value;

@@ -22,13 +22,15 @@ namespace troyn {
 // FP64 policy can run with half-word LDS tiles (two workgroups per CU, ntt_pass_body HALF); they pay off where the kernel fits 64
 // registers: the plain forward transform (+18 %, 3.8 -> 4.5 TB/s), the fused tail + rescale (+2 % on the headline) and, measured in round 3
 // through the three-call path, the key-switch tail and the rescale (relinearize N = 16384 +2 %, multiply + relinearize + rescale as three calls
-// +4 %: default mask 0x0027).  The inverse variants need 76-82 registers and lose to their spills (bounding the live twiddles layer by layer
-// leaves 124-240 bytes of scratch).  TROYN_NTT_HALF=<mask> (bit (INV ? 8 : 0) + IOM) selects variants for A/B runs.
+// +4 %).  The inverse variants need 76-82 registers; the plain one fits since the per-lane twiddles of its first round are loaded in three
+// steps (ntt_pass_body: an opaque zero derived from the previous layer's result enters the table index, so the loads cannot be hoisted;
+// scratch 68 -> 12 bytes, NTT + dyadic + INTT +2 %) and is on by default (mask 0x0127); the fused chain's MULPAIR / LAST_LIMB variants still
+// spill 64 / 108 bytes in their loaders and stay on full-word tiles.  TROYN_NTT_HALF=<mask> (bit (INV ? 8 : 0) + IOM) selects variants for A/B runs.
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
         const char* e = getenv("TROYN_NTT_HALF");   // bit (INV ? 8 : 0) + IOM selects the variant; read per launch so that the suite runs every variant
-        const int half = e ? (int)strtol(e, nullptr, 0) : 0x0027;
+        const int half = e ? (int)strtol(e, nullptr, 0) : 0x0127;
         if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
