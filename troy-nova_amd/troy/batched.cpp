@@ -168,7 +168,8 @@ void Evaluator::multiply_relinearize_rescale_batched(const std::vector<const Cip
     const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(context_->plan(), L, count);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
     troyn_check_public(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, a, b, keys.data(), block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
-    troyn_sync_current_stream();
+    // no synchronisation: the call is asynchronous on the thread's stream like the reference's evaluator methods; `ws` returns to the pool, which
+    // hands a block back to the thread that released it in stream order and to any other thread only after a device synchronisation (MemoryPool)
     for (size_t i = 0; i < count; i++)
         *destination[i] = Ciphertext::from_members(2, L - 1, n, next, scale, true, cf, 0,
                                                    utils::DynamicArray::device_view(block->raw_pointer() + i * words, words, block));
