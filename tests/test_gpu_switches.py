@@ -2,7 +2,8 @@
 (csrc/troyn.hip env_is / env_int, csrc/ntt_launch.inl), so one process can run both sides; results must stay bit-identical to the oracle.
 
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
-  TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: item-major, XCD-grouped)
+  TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
+  TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
   TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0127)
   TROYN_NTT_ARITH=u64       integer butterflies for every modulus
@@ -23,11 +24,11 @@ def _case(O, pkg, dev, n, bits, L, batch=8):
 
 
 @pytest.mark.parametrize("env", [{}, {"TROYN_KS_MAC": "v1"}, {"TROYN_KS_MAC": "split"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_ARITH": "u64"},
-                                 {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}],
-                         ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none"])
+                                 {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}, {"TROYN_KS_DIAG": "loop"}],
+                         ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none", "ks_diag_in_loop"])
 @pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [40, 40, 40, 40], 3)])
 def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L):
-    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF"):
+    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

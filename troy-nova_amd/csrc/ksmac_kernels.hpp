@@ -49,7 +49,7 @@ struct KsMacArgs {
     // evaluator_keyswitching.cu:143) already applied to the inner product P; the special row stays P.  The memory-bound kernels
     // behind this one then read one row where they read P and four rows of a and b.
     const u64* ten_a; const u64* ten_b; long long ten_bstride, ten_pstride;
-    const double* diag_keys;   // with ten_a: [k][2][N] the two components of key k under modulus k (times qk^-1), NATURAL order: the diagonal
+    const double* diag_keys;   // with ten_a (TEN) or diag (DG): [k][2][N] the two components of key k under modulus k (times qk^-1), NATURAL order: the diagonal
                                // digit a1 (.) b1 of a data row is multiplied-accumulated in the epilogue's coalesced layout
     const DevModulus* mods;
     const double* tw;       // [K][N]  forward twiddles w, reference table order
@@ -171,7 +171,9 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 // bit2 no LDS exchange, bit3 no butterflies, bit4 no multiply-accumulate (results are wrong by design)
 // TEN: the instantiation of the fused chain (KsMacArgs::ten_a): data rows leave as Q = P qk^-1 + c; kept out of the other instantiations,
 // whose digit loop otherwise pays for the epilogue's registers (scratch 32 -> 48 bytes, relinearize -4 %)
-template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false>
+// DG: the same epilogue without the tensor terms, for the separate key switch on an NTT-form target (KsMacArgs::diag + diag_keys): the
+// diagonal digit is multiplied-accumulated in the coalesced layout, the loop drops its diagonal path (scratch 36 -> 12 bytes)
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
 #endif
     // fused chain, data row: the diagonal digit (a1 (.) b1 of limb k, NTT form) is left to the epilogue, which loads a1 and b1 anyway
     // (the sum is exact, its order is free)
-    const bool ten_row = TEN && k < a.L;
+    static_assert(!(TEN && DG), "one epilogue");
+    const bool ten_row = (TEN || DG) && k < a.L;      // data row of an instantiation whose epilogue takes the diagonal digit
     const unsigned steps = ten_row ? a.L - 1 : a.L;
     for (unsigned step = 0; step < steps; ++step) {
         const unsigned it = !ten_row ? step : (step < k ? step : step + 1);     // digit of this step
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         // i.e. it waits for the round's twiddle loads that were issued to travel under the exchange (round 3: -5.6 % on the launch).
         // Re-derived per digit they cost one v_add each.
         asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(pt));
-        if (!TEN && a.diag && it == k) {      // (TEN: the diagonal digit of a data row is handled in the epilogue, the special row has none)
+        if (!TEN && !DG && a.diag && it == k) {      // (TEN: the diagonal digit of a data row is handled in the epilogue, the special row has none)
             // the digit of row k under its own modulus is the NTT-form input limb (evaluator_keyswitching_core.cu:851-852):
             // coalesced load, transpose through the wave's own LDS slice into the accumulators' layout
             const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
@@ -575,6 +578,53 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
             q1x += f64_mulq(a0x, b1x, inv_p, p) + f64_mulq(a1x, b0x, inv_p, p);
             q1y += f64_mulq(a0y, b1y, inv_p, p) + f64_mulq(a1y, b0y, inv_p, p);
             }
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + m * 128, slice_off))), f64_canon(q0x, fm), f64_canon(q0y, fm));
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + a.out_pstride + m * 128, slice_off))), f64_canon(q1x, fm), f64_canon(q1y, fm));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m + W < 16) request(std::integral_constant<int, m + W>{});
+        });
+    } }
+    if constexpr (DG) { if (ten_row) {
+        // separate key switch, NTT-form target, data row: both accumulators cross the slice in place, then one sweep adds the diagonal
+        // digit's term (the target's limb k itself, coalesced 16-byte loads, times the natural-order copy of key k under modulus k)
+        const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
+        const double* dk0 = ksm_uniform(a.diag_keys + (size_t)k * 2 * N + (size_t)h * (KSM_THREADS * 32));
+        const double* dk1 = ksm_uniform(dk0 + N);
+        constexpr int W = 4;
+        ulonglong2 xd[16];
+        double2 y0[16], y1[16];
+        auto request = [&](auto ic) {
+            constexpr int m = decltype(ic)::value;
+            xd[m] = ksm_gload<ulonglong2>(dg + m * 128, slice_off);
+            y0[m] = ksm_gload<double2>(dk0 + m * 128, slice_off);
+            y1[m] = ksm_gload<double2>(dk1 + m * 128, slice_off);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, W>([&](auto ic) { request(ic); });
+        __builtin_amdgcn_sched_barrier(0);
+        auto cross = [&](double (&acc)[32]) {
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                *reinterpret_cast<double2*>(&lds[p2 + 2 * m]) = make_double2(f64_corr(acc[2 * m], fm), f64_corr(acc[2 * m + 1], fm));
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const double2 v = *reinterpret_cast<const double2*>(&lds[pt + ksm_phys(m * 128u)]);
+                acc[2 * m] = v.x; acc[2 * m + 1] = v.y;
+            });
+            __builtin_amdgcn_wave_barrier();
+        };
+        cross(acc0);
+        cross(acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            double q0x = acc0[2 * m], q0y = acc0[2 * m + 1], q1x = acc1[2 * m], q1y = acc1[2 * m + 1];      // |.| <= p/2 + 1
+            const double dx = f64_corr(f64_from_u64(xd[m].x), fm), dy = f64_corr(f64_from_u64(xd[m].y), fm);
+            mac2(q0x, q1x, dx, y0[m].x, y1[m].x);
+            mac2(q0y, q1y, dy, y0[m].y, y1[m].y);
             nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + m * 128, slice_off))), f64_canon(q0x, fm), f64_canon(q0y, fm));
             nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + a.out_pstride + m * 128, slice_off))), f64_canon(q1x, fm), f64_canon(q1y, fm));
             __builtin_amdgcn_sched_barrier(0);

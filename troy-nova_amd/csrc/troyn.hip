@@ -636,7 +636,7 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.poly_prod = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
-    w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n;     // prepared keys of ksmac2_kernel
+    w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
     w.total = off;
     return w;
 }
@@ -704,11 +704,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         {
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
             const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
-            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, blocks, s);
+            // NTT-form target: the block (key j, modulus j) a second time in natural order -- the diagonal digit is applied in ksmac2's epilogue (DG)
+            const bool dg = is_ntt_form && !env_is("TROYN_KS_DIAG", "loop");
+            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, blocks, s, nullptr, nullptr, 0, dg ? kf + (size_t)L * 2 * K * n : nullptr);
             LAUNCH_CHECK();
         }
         KsMacArgs a;
         std::memset(&a, 0, sizeof(a));
+        if (is_ntt_form && !env_is("TROYN_KS_DIAG", "loop")) a.diag_keys = kf + (size_t)L * 2 * K * n;
         a.digits = digits_src; a.dig_bstride = (long long)digits_bstride; a.dig_cstride = n;
         a.diag = is_ntt_form ? target : nullptr; a.diag_bstride = (long long)target_bstride; a.diag_cstride = n;
         a.out = ws + w.poly_prod; a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
