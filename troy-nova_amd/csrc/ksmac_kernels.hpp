@@ -173,7 +173,8 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 // whose digit loop otherwise pays for the epilogue's registers (scratch 32 -> 48 bytes, relinearize -4 %)
 // DG: the same epilogue without the tensor terms, for the separate key switch on an NTT-form target (KsMacArgs::diag + diag_keys): the
 // diagonal digit is multiplied-accumulated in the coalesced layout, the loop drops its diagonal path (scratch 36 -> 12 bytes)
-template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false>
+// NODIAG: coefficient-form target (BFV): there is no diagonal digit, and the instantiation does not carry the loop's diagonal path
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false, bool NODIAG = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         // i.e. it waits for the round's twiddle loads that were issued to travel under the exchange (round 3: -5.6 % on the launch).
         // Re-derived per digit they cost one v_add each.
         asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(pt));
-        if (!TEN && !DG && a.diag && it == k) {      // (TEN: the diagonal digit of a data row is handled in the epilogue, the special row has none)
+        if (!TEN && !DG && !NODIAG && a.diag && it == k) {      // (TEN: the diagonal digit of a data row is handled in the epilogue, the special row has none)
             // the digit of row k under its own modulus is the NTT-form input limb (evaluator_keyswitching_core.cu:851-852):
             // coalesced load, transpose through the wave's own LDS slice into the accumulators' layout
             const u64* dg = ksm_uniform(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + (size_t)h * (KSM_THREADS * 32));
