@@ -20,7 +20,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d "$OUT
 cd "$ROOT"
 python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" --pmc "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" \
         --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
-python3 tools/collect_counters.py ksmac2_kernel $((1024 * 6 * 2 * 256)) 1024 "$OUT/${TAG}_ksmac_counters.json" \
+python3 tools/collect_counters.py "ksmac2_kernel<14, true, 0, false, true" $((1024 * 6 * 2 * 256)) 1024 "$OUT/${TAG}_ksmac_counters.json" \
         "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db"
 # the chunked option (two halves on two internal streams), kernel trace only, for the record
 export TROYN_MRR_CHUNK=512
