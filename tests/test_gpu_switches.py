@@ -158,3 +158,20 @@ def test_fused_chain_batch_shapes(O, pkg, dev, monkeypatch, n, batch):
         if key not in cache:
             cache[key] = ctx.mod_switch_scale_to_next(L, ctx.relinearize(L, True, ctx.ckks_multiply(L, base_a[key[0]], base_b[key[1]]), keys))
         assert np.array_equal(got[item], cache[key]), item
+
+
+@pytest.mark.parametrize("n,bits,L", [(8192, [50, 50], 1), (16384, [50, 50, 50], 1), (32768, [50, 50, 50], 1), (8192, [40, 40, 40], 2)])
+@pytest.mark.parametrize("scheme", ["ckks", "bfv"])
+def test_relinearize_shortest_chains(O, pkg, dev, n, bits, L, scheme):
+    """L = 1: the digit loop of ksmac2's DG instantiation (NTT form: the only digit is the diagonal one, applied in the epilogue) runs zero
+    times for a data row; coefficient form takes the NODIAG instantiation.  Both against the oracle."""
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q) if scheme == "ckks" else O.Context("bfv", n, q, 65537)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    ntt = scheme == "ckks"
+    ct3 = np.stack([ctx.random_ct(70 + i, 3, L) for i in range(8)])
+    got = pkg.to_host(plan.relinearize(L, pkg.to_device(ct3, dev), dkeys, is_ckks=ntt, is_ntt_form=ntt))
+    for i in range(8):
+        assert np.array_equal(got[i], ctx.relinearize(L, ntt, ct3[i], keys)), i
