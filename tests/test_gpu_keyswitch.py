@@ -42,7 +42,7 @@ def test_switch_key_batches_of_eight(O, pkg, dev, n, bits, L, batch):
     ("ckks", True, 8192, [50] * 4, 3),             # N = 8192 instance of the half-tile inner product (whole-limb tiles)
     ("ckks", True, 8192, [40, 40], 1),             # a single digit: only the diagonal shortcut and one transformed row
     ("ckks", True, 16384, [45, 45, 45], 1),        # lower level (L < K-1) of the half-tile kernel
-    ("bfv", True, 2048, [54], 1) if False else ("bfv", False, 2048, [27, 27], 1),
+    ("bfv", False, 2048, [27, 27], 1),
 ])
 def test_switch_key(O, pkg, dev, scheme, ntt_form, n, bits, L):
     t = 1032193 if scheme == "bfv" else 0

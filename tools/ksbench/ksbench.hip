@@ -17,6 +17,8 @@
 #include "../../troy-nova_amd/csrc/host_math.hpp"
 #include "../../troy-nova_amd/csrc/ntt_kernels.hpp"
 #include "../../troy-nova_amd/csrc/ksmac_kernels.hpp"
+#include "ksmac3_experiment.hpp"
+#include "ksmac4_experiment.hpp"
 #if __has_include("ksmac_base.hpp")
 #include "ksmac_base.hpp"      // frozen copy of the committed kernel (tools/ksbench/freeze_base.sh): same-run A/B
 #define KSBENCH_HAVE_BASE 1
@@ -245,6 +247,36 @@ int main(int argc, char** argv) {
                   float t_n = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kn); }, reps);
                   printf("order %u: tensor folded %9.1f us   without %9.1f us\n", ord, t_o, t_n); }
                 printf("tensor folded: full %9.1f us   loads from one line %9.1f us   no products %9.1f us   neither %9.1f us\n", t_full, t_l, t_p, t_lp);
+                {   // third generation (wave-specialised, persistent): word-for-word against ksmac2's TEN instantiation, both orders
+                    int ncu = 256; { hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount / 8 * 8; }
+                    if (getenv("KSB_GRID")) ncu = atoi(getenv("KSB_GRID"));
+                    for (unsigned ord : {3u, 1u}) {
+                        KsMacArgs ko = kt; ko.grouped = ord;
+                        const unsigned grid_rows = ord == 3 ? (L + 2) / 2 * 2 : L + 1;
+                        const unsigned total_vb = (unsigned)(B * grid_rows * 2);
+                        ko.out = b.out_ref;
+                        CHECK(hipMemset(b.out_ref, 0xee, out_words * 8));
+                        float t2 = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 0, false, true>), dim3(total_vb), dim3(KSM_THREADS), 0, 0, ko); }, reps);
+                        ko.out = b.out;
+                        CHECK(hipMemset(b.out, 0xff, out_words * 8));
+                        float t3 = time_launch([&] { hipLaunchKernelGGL((ksmac3_kernel<14, true, false, 1>), dim3(ncu), dim3(KSM3_THREADS), 0, 0, ko, total_vb); }, reps);
+                        CHECK(hipMemcpy(r0.data(), b.out_ref, out_words * 8, hipMemcpyDeviceToHost));
+                        CHECK(hipMemcpy(r1.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
+                        size_t bad = 0, first = 0;
+                        for (size_t i = 0; i < out_words; i++) if (r0[i] != r1[i]) { if (!bad) first = i; bad++; }
+                        printf("order %u: ksmac2 TEN %9.1f us   ksmac3 (grid %d) %9.1f us   %s", ord, t2, ncu, t3, bad ? "MISMATCH" : "identical");
+                        if (bad) printf(" (%zu words, first at %zu: got %llu want %llu)", bad, first, (unsigned long long)r1[first], (unsigned long long)r0[first]);
+                        printf("\n");
+                        CHECK(hipMemset(b.out, 0xff, out_words * 8));
+                        float t4 = time_launch([&] { hipLaunchKernelGGL((ksmac4_kernel<14, true, false, 1>), dim3(ncu), dim3(KSM3_THREADS), 0, 0, ko, total_vb); }, reps);
+                        CHECK(hipMemcpy(r1.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
+                        bad = 0; first = 0;
+                        for (size_t i = 0; i < out_words; i++) if (r0[i] != r1[i]) { if (!bad) first = i; bad++; }
+                        printf("order %u: ksmac4 (two-stage pipeline, key prefetch %d) %9.1f us   %s", ord, KSM4_KEY_AHEAD, t4, bad ? "MISMATCH" : "identical");
+                        if (bad) printf(" (%zu words, first at %zu: got %llu want %llu)", bad, first, (unsigned long long)r1[first], (unsigned long long)r0[first]);
+                        printf("\n");
+                    }
+                }
                 CHECK(hipFree(big));
             }
         }

@@ -698,20 +698,22 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     //     (L+1)*L transformed digits never reach HBM.
     const bool mac_fused = !ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull;
     const int ks_mac_gen = env_is("TROYN_KS_MAC", "v1") ? 1 : 2;
-    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 1) * 4 <= 0x7fffffffull) {
+    // (the band order pads an odd row count with one row of workgroups that exit: the grid guard counts L + 2 rows)
+    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 2) * 4 <= 0x7fffffffull) {
         // ksmac2_kernel: tiles of 2^13 outputs, two workgroups per CU, keys prepared once per call (ksmac_kernels.hpp)
         double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
+        // NTT-form target: the block (key j, modulus j) a second time in natural order -- the diagonal digit is applied in the kernel's
+        // epilogue (DG).  The switch is read ONCE per call: the preparation and the instantiation choice must agree.
+        const bool dg = is_ntt_form && !env_is("TROYN_KS_DIAG", "loop");
         {
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
             const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
-            // NTT-form target: the block (key j, modulus j) a second time in natural order -- the diagonal digit is applied in ksmac2's epilogue (DG)
-            const bool dg = is_ntt_form && !env_is("TROYN_KS_DIAG", "loop");
             launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, blocks, s, nullptr, nullptr, 0, dg ? kf + (size_t)L * 2 * K * n : nullptr);
             LAUNCH_CHECK();
         }
         KsMacArgs a;
         std::memset(&a, 0, sizeof(a));
-        if (is_ntt_form && !env_is("TROYN_KS_DIAG", "loop")) a.diag_keys = kf + (size_t)L * 2 * K * n;
+        if (dg) a.diag_keys = kf + (size_t)L * 2 * K * n;
         a.digits = digits_src; a.dig_bstride = (long long)digits_bstride; a.dig_cstride = n;
         a.diag = is_ntt_form ? target : nullptr; a.diag_bstride = (long long)target_bstride; a.diag_cstride = n;
         a.out = ws + w.poly_prod; a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
@@ -736,7 +738,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             if (k < L && !p->small_modulus[k]) wide_digits = true;
         }
         const bool mixed = ks_mac_gen == 2 && p->d_fwd_r2 && !force_integer_ntt() && small_rows != 0 && wide_rows != 0 && L + 1 <= 64 &&
-                           batch * (size_t)(L + 1) * 4 <= 0x7fffffffull;
+                           batch * (size_t)(L + 2) * 4 <= 0x7fffffffull;
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
         if (mixed) {
             double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
