@@ -156,6 +156,15 @@ def uniform_residues(torch, shape_prefix, moduli, n, device, gen):
     return out
 
 
+def timed_broadcast(torch, shard, keys):
+    """the one exchange of the batched path (evaluation keys, rank 0 -> all), outside the timed region; seconds on this rank"""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    shard.broadcast_tensors(keys, src=0)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def timed(torch, fn, reps):
     # the clocks need 20-25 ms of load to come up after any idle gap (tools/ramp_probe.py): warm up for at least 50 ms
     t0 = time.perf_counter()
@@ -180,7 +189,9 @@ def kernel_sources_sha(names):
     return h.hexdigest()[:16]
 
 
-KSMAC_SOURCES = ("ksmac_kernels.hpp", "dev_math_f64.hpp")
+# everything the timed instantiation depends on: the kernel, its arithmetic, the helpers it takes from the transform header, the unit that
+# picks the instantiation, and troyn.hip (workgroup order, argument block).  tools/collect_counters.py hashes the same list.
+KSMAC_SOURCES = ("ksmac_kernels.hpp", "dev_math_f64.hpp", "dev_math.hpp", "ntt_kernels.hpp", "troyn_ksmac2.hip", "launch.hpp", "troyn.hip")
 
 
 def counters_record(kernel_tag, batch):
@@ -241,7 +252,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     # generated on rank 0 and broadcast once over RCCL (the only exchange of the batched path)
     kgen = torch.Generator(device=device).manual_seed(0xC0FFEE)
     keys = [uniform_residues(torch, (2,), q, n, device, kgen) for _ in range(L)]
-    shard.broadcast_tensors(keys, src=0)
+    key_broadcast_s = timed_broadcast(torch, shard, keys)
 
     prod = torch.empty((B, 3, L, n), dtype=torch.int64, device=device)
     relin = torch.empty((B, 2, L, n), dtype=torch.int64, device=device)
@@ -272,9 +283,11 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0          # this rank's own work (the contract's clock runs to the closing barrier)
         shard.barrier()
         elapsed = time.perf_counter() - t0
         ks_ms, ks_n = kt.read()
+    ranks = shard.rank_report(local_elapsed, args.steps, torch.cuda.get_device_name(device), key_broadcast_s, device=device)
     elapsed = shard.max_over_ranks(elapsed, device=device)
     value = world * B * inner * args.steps / elapsed
 
@@ -378,7 +391,9 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                                       "troyn_divide_and_round_q_last_ntt = Evaluator::multiply / relinearize / rescale_to_next -- on the same buffers, measured right "
                                       "after the timed region; the fused entry is an addition to that boundary (troy::Evaluator::multiply_relinearize_rescale, "
                                       "other_configs.cpp_api) with bit-identical results",
-                   "parallelism": "batch-sharded x%d, keys broadcast once (RCCL)" % world},
+                   "parallelism": "batch-sharded x%d, keys broadcast once (RCCL)" % world,
+                   # what the backend saw, per rank (a first multi-GPU run that goes wrong must be readable from this line alone)
+                   **ranks},
         "roofline": roofline,
     }
 
@@ -539,19 +554,21 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     gen = torch.Generator(device=device).manual_seed(0x123)      # the same job on every world size: item i has the same payload
     kgen = torch.Generator(device=device).manual_seed(0xC0FFEE)
     keys = [uniform_residues(torch, (2,), q, n, device, kgen) for _ in range(L)]
-    shard.broadcast_tensors(keys, src=0)
+    key_broadcast_s = timed_broadcast(torch, shard, keys)
     nb = min(chunk, max(mine, 1))
-    x = uniform_residues(torch, (nb, 2), q[:L], n, device, gen)
-    y = uniform_residues(torch, (nb, 2), q[:L], n, device, gen)
+    # the job's real operands: `mine` DISTINCT ciphertext pairs resident in HBM (1024 items = 2 x 5 GiB; the intermediates and results of a
+    # chunk are reused, a caller would consume them before the next launch)
+    x = torch.cat([uniform_residues(torch, (min(64, mine - i), 2), q[:L], n, device, gen) for i in range(0, max(mine, 1), 64)]) if mine else uniform_residues(torch, (1, 2), q[:L], n, device, gen)
+    y = torch.cat([uniform_residues(torch, (min(64, mine - i), 2), q[:L], n, device, gen) for i in range(0, max(mine, 1), 64)]) if mine else uniform_residues(torch, (1, 2), q[:L], n, device, gen)
     prod = torch.empty((nb, 3, L, n), dtype=torch.int64, device=device)
     out = torch.empty((nb, 2, L, n), dtype=torch.int64, device=device)
     launches = [0]
 
     def step():
         done = 0
-        while done < mine:      # the rank's slice, `chunk` ciphertext pairs per launch (synthetic operands reused per chunk)
+        while done < mine:      # the rank's slice, `chunk` ciphertext pairs per launch, every pair its own operands
             c = min(nb, mine - done)
-            behz.multiply(x[:c], 2, y[:c], 2, out=prod[:c])                                         # Evaluator::multiply (BFV, BEHZ)
+            behz.multiply(x[done:done + c], 2, y[done:done + c], 2, out=prod[:c])                   # Evaluator::multiply (BFV, BEHZ)
             plan.relinearize(L, prod[:c], keys, out=out[:c], is_ckks=False, is_ntt_form=False)      # Evaluator::relinearize
             done += c
             launches[0] += 1
@@ -567,11 +584,14 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0          # this rank's own work (the contract's clock runs to the closing barrier)
         shard.barrier()
         elapsed = time.perf_counter() - t0
         ks_ms, ks_n = kt_ks.read()
         tn_ms, tn_n = kt_t.read()
         fl_ms, fl_n = kt_f.read()
+    ranks = shard.rank_report(local_elapsed, args.steps, torch.cuda.get_device_name(device), key_broadcast_s, device=device)
+    ranks["items_per_rank"] = [int(v) for v in shard.gather_over_ranks(mine, device=device)]
     elapsed = shard.max_over_ranks(elapsed, device=device)
     value = args.total * args.steps / elapsed
 
@@ -616,7 +636,8 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         "dtype": "u64 (q < 2^50: exact FP64-carried butterflies; 61-bit BEHZ base: integer butterflies)", "data": "synthetic",
         "config": {"workload": "BFV N=32768, 11x50-bit coeff modulus (K=11, L=10), t=1032193: %d independent multiply + relinearize ops per step, "
                                "block-partitioned over %d rank(s) (rank 0: items [%d, %d)), %d per launch" % (args.total, world, lo, hi, nb),
-                   "total_ops_per_step": args.total, "parallelism": "batch-sharded x%d (shard.shard_range), keys broadcast once (RCCL)" % world},
+                   "total_ops_per_step": args.total, "operands": "%d distinct ciphertext pairs per rank resident in HBM" % mine,
+                   "parallelism": "batch-sharded x%d (shard.shard_range), keys broadcast once (RCCL)" % world, **ranks},
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline:
@@ -628,19 +649,20 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         def one_op(ha, hb):
             return ctx.relinearize(L, False, ctx.bfv_multiply(L, ha, hb), hk)
 
-        items = sorted({0, 1, nb - 1})
+        base = ((mine - 1) // nb) * nb                    # `out` holds the rank's LAST chunk: items base .. mine - 1
+        items = sorted({0, 1, mine - base - 1})
         ops, t0 = 0, time.perf_counter()
         for i in items:
-            exp = one_op(pkg.to_host(x[i]), pkg.to_host(y[i]))
+            exp = one_op(pkg.to_host(x[base + i]), pkg.to_host(y[base + i]))
             ops += 1
             if not np.array_equal(pkg.to_host(out[i]), exp):
-                raise AssertionError("bench cfg4: GPU result of item %d differs from the CPU oracle" % i)
+                raise AssertionError("bench cfg4: GPU result of item %d differs from the CPU oracle" % (base + i))
         ha, hb = pkg.to_host(x[0]), pkg.to_host(y[0])
         while time.perf_counter() - t0 < args.cpu_seconds and world == 1:
             one_op(ha, hb)
             ops += 1
         t_cpu = time.perf_counter() - t0
-        result["parity"] = "bit-exact vs CPU oracle (items %s of the last chunk of %d)" % (items, nb)
+        result["parity"] = "bit-exact vs CPU oracle (items %s of the job: %s of its last chunk of %d)" % ([base + i for i in items], items, mine - base)
         result["cpu_baseline"] = {"value": round(ops / t_cpu, 3), "unit": "ops/s", "cores": 1, "kind": "port",
                                   "sample": "%d sequential BEHZ multiply + relinearize ops (items %s of the same workload, then item 0 repeated; %.1f s, "
                                             "oracle/troy_oracle.c, gcc -O3, 1 thread of %d host cores)" % (ops, items, t_cpu, os.cpu_count())}
@@ -801,11 +823,12 @@ def dry_run(args, rank, world):
     ok = all(int(k[0, 0, 0]) == 100 + j for j, k in enumerate(keys))
     lo, hi = shard.shard_range(args.total, rank, world)
     shard.barrier()
+    ranks = shard.rank_report(0.001 * (rank + 1), 1, "cpu:%d" % rank, 0.0005 * (rank + 1))
     elapsed = shard.max_over_ranks(0.001 * (rank + 1))
     covered = shard.sum_over_ranks(hi - lo)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "keys_broadcast_ok": ok, "max_elapsed": elapsed, "items_covered": covered,
-                          "rank0_range": [lo, hi], "scaling": "strong" if args.workload == "cfg4" else "weak"}))
+                          "rank0_range": [lo, hi], "scaling": "strong" if args.workload == "cfg4" else "weak", "config": ranks}))
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0 if ok else 5
@@ -817,6 +840,13 @@ def main():
         print(json.dumps({"total": args.total, "world": args.gpus, "ranges": shard_plan(args.total, args.gpus)}))
         return 0
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("TROYN_BENCH_SPAWN")):
+        if not args.dry_run:
+            import torch      # device_count() does not initialise HIP on this image: the parent still never touches the GPU
+            visible = torch.cuda.device_count()
+            if args.gpus > visible:
+                sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+                                 "nothing was started\n" % (args.gpus, visible))
+                return 2
         return launch_ranks(args.gpus)         # nothing above touched the GPU (TROYN_BENCH_SPAWN: take this path at N = 1 too)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

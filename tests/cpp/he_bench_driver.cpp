@@ -6,7 +6,7 @@
 //     multiply_relinearize_rescale_batched;  1 and 4 host threads (the tool's -c option), every thread with its own operands.
 // Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
 // decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
-//   he_bench_driver [check|bench] [repeat]
+//   he_bench_driver [check|bench|threads] [repeat]
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -43,7 +43,8 @@ static bool same_ct(const Ciphertext& a, const Ciphertext& b) {
 }
 
 int main(int argc, char** argv) {
-    const bool bench = argc > 1 && std::strcmp(argv[1], "bench") == 0;
+    const bool threads_only = argc > 1 && std::strcmp(argv[1], "threads") == 0;      // only the N-thread single-object sweep
+    const bool bench = threads_only || (argc > 1 && std::strcmp(argv[1], "bench") == 0);
     const size_t repeat = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 20;
     try {
         const size_t n = 16384;
@@ -126,7 +127,7 @@ int main(int argc, char** argv) {
         if (!bench) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
 
         // ---- single objects (the tool's loop: every call followed by a stream synchronisation) -----------------------------------------
-        for (int fused = 0; fused < 2; fused++) {
+        for (int fused = 0; fused < 2 && !threads_only; fused++) {
             const size_t reps = 200;
             for (size_t i = 0; i < 10; i++) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, w.rk); }
             troyn_sync_current_stream();
@@ -143,6 +144,43 @@ int main(int argc, char** argv) {
             std::printf("single_%s_us_per_op %.2f\n", fused ? "fused" : "three_calls", dt / reps * 1e6);
         }
 
+        // ---- single objects from N host threads: the reference tool's -c N mode (he_operations.cu:85, :364-380: N threads, each on its own
+        // stream, sharing context and keys; the reference has NO batched multiply / relinearize / rescale, :119-135, so this is what an
+        // unmodified caller gets).  Every thread owns its operands; the three calls of an op are queued without a synchronisation in between
+        // and the stream is synchronised once per op (the result is consumed by the caller).
+        for (size_t threads : {(size_t)1, (size_t)4, (size_t)16, (size_t)64}) {
+            for (int fused = 0; fused < 2; fused++) {
+                const size_t reps = std::max<size_t>(50, 1600 / threads);
+                std::atomic<size_t> ready{0};
+                std::atomic<bool> go{false};
+                auto body = [&](size_t) {
+                    Ciphertext a = c1.clone(), b = c2.clone();
+                    auto once = [&] {
+                        if (fused) { Ciphertext t = ev.multiply_relinearize_rescale_new(a, b, w.rk); troyn_sync_current_stream(); }
+                        else {
+                            Ciphertext t = ev.multiply_new(a, b);
+                            Ciphertext r = ev.relinearize_new(t, w.rk);
+                            Ciphertext s = ev.rescale_to_next_new(r);
+                            troyn_sync_current_stream();
+                        }
+                    };
+                    for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05;) once();
+                    ready.fetch_add(1);
+                    while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+                    for (size_t r = 0; r < reps; r++) once();
+                };
+                std::vector<std::thread> th;
+                for (size_t t = 0; t < threads; t++) th.emplace_back(body, t);
+                while (ready.load() < threads) std::this_thread::yield();
+                auto t0 = clk::now();
+                go.store(true, std::memory_order_release);
+                for (auto& x : th) x.join();
+                const double mx = secs(t0, clk::now());
+                std::printf("single_threads%zu_%s_ops_per_s %.1f\n", threads, fused ? "fused" : "three_calls", (double)(threads * reps) / mx);
+            }
+        }
+
+        if (threads_only) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
         // ---- batched forms ----------------------------------------------------------------------------------------------------------------
         const size_t maxB = 1024, threads_max = 4;
         // operands: one contiguous block per thread (what *_batched returns, so `contiguous()` uses them in place), made by transform round trips

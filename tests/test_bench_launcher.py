@@ -31,6 +31,20 @@ def test_self_launcher_starts_two_ranks():
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["keys_broadcast_ok"] and j["items_covered"] == 1024 and j["rank0_range"] == [0, 512]
     assert j["max_elapsed"] == 0.002 and j["scaling"] == "strong"
+    # what makes a first multi-GPU run diagnosable: the world size the BACKEND reports, every rank's own step time, the slowest rank,
+    # the key broadcast time and what each rank ran on
+    c = j["config"]
+    assert c["ranks"] == 2 and c["ms_per_step_per_rank"] == [1.0, 2.0] and c["ms_per_step_min"] == 1.0 and c["ms_per_step_max"] == 2.0
+    assert c["slowest_rank"] == 1 and c["devices"] == ["cpu:0", "cpu:1"]
+    assert c["key_broadcast_s"] == 0.001 and c["key_broadcast_s_per_rank"] == [0.0005, 0.001]
+
+
+def test_more_ranks_than_devices_is_refused_before_spawning():
+    """no GPU in this container: any real (non --dry-run) multi-rank job asks for more devices than are visible"""
+    import torch
+    want = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(max(want, 2))])
+    assert r.returncode == 2 and "visible" in r.stderr and "nothing was started" in r.stderr, r.stderr
 
 
 def test_launcher_watchdog_ends_the_job_when_a_rank_dies():

@@ -18,7 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def kernel_sources_sha(names=("ksmac_kernels.hpp", "dev_math_f64.hpp")):
+KSMAC_SOURCES = ("ksmac_kernels.hpp", "dev_math_f64.hpp", "dev_math.hpp", "ntt_kernels.hpp", "troyn_ksmac2.hip", "launch.hpp", "troyn.hip")      # = bench.py KSMAC_SOURCES
+
+
+def kernel_sources_sha(names=KSMAC_SOURCES):
     """stamp of the kernel sources this record was measured on; bench.py drops a record whose stamp is not the current sources'"""
     h = hashlib.sha256()
     for nm in names:

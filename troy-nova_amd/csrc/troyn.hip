@@ -1026,12 +1026,21 @@ static MrrStreams* mrr_streams(int device) {
     for (auto& m : pool) if (m.device == device) return &m;
     MrrStreams m;
     m.device = device;
-    for (int q = 0; q < MRR_MAX_STREAMS; q++) {
-        if (hipStreamCreateWithFlags(&m.s[q], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&m.join[q], hipEventDisableTiming) != hipSuccess) return nullptr;
+    bool ok = true;
+    for (int q = 0; q < MRR_MAX_STREAMS && ok; q++) {
+        ok = hipStreamCreateWithFlags(&m.s[q], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&m.join[q], hipEventDisableTiming) == hipSuccess;
     }
-    if (hipEventCreateWithFlags(&m.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    pool.push_back(m);
+    ok = ok && hipEventCreateWithFlags(&m.fork, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {      // give back whatever was created before the failure
+        for (int q = 0; q < MRR_MAX_STREAMS; q++) {
+            if (m.join[q]) (void)hipEventDestroy(m.join[q]);
+            if (m.s[q]) (void)hipStreamDestroy(m.s[q]);
+        }
+        if (m.fork) (void)hipEventDestroy(m.fork);
+        return nullptr;
+    }
+    pool.push_back(m);      // kept for the life of the host thread (a handful of streams per thread and device; the runtime reclaims them at exit)
     return &pool.back();
 }
 
@@ -1164,15 +1173,21 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     HIP_TRY(hipEventRecord(ms->fork, s));
     for (int q = 0; q < ns; q++) HIP_TRY(hipStreamWaitEvent(ms->s[q], ms->fork, 0));
     size_t done = 0, idx = 0;
+    rc = TROYN_OK;
     while (done < batch) {
         const size_t c = std::min(chunk, batch - done);
         const int q = (int)(idx % (size_t)ns);
         if ((rc = mrr_chain(p, L, a + done * 2 * (size_t)L * n, b + done * 2 * (size_t)L * n, kf, out + done * 2 * (size_t)(L - 1) * n,
-                            ws + (size_t)q * slot_words, wc, c, ms->s[q]))) return rc;
+                            ws + (size_t)q * slot_words, wc, c, ms->s[q]))) break;
         done += c; idx++;
     }
-    for (int q = 0; q < ns; q++) { HIP_TRY(hipEventRecord(ms->join[q], ms->s[q])); HIP_TRY(hipStreamWaitEvent(s, ms->join[q], 0)); }
-    return TROYN_OK;
+    // join ALSO on an error: the chunks already queued keep writing the caller's workspace / output, so the caller's stream must not
+    // run ahead of them (the caller is free to release both as soon as this returns)
+    bool joined = true;
+    for (int q = 0; q < ns; q++)
+        joined = hipEventRecord(ms->join[q], ms->s[q]) == hipSuccess && hipStreamWaitEvent(s, ms->join[q], 0) == hipSuccess && joined;
+    if (!joined) { for (int q = 0; q < ns; q++) (void)hipStreamSynchronize(ms->s[q]); }
+    return rc;
 }
 
 extern "C" int troyn_mod_switch_drop(const troyn_plan* p, uint32_t L_in, uint32_t L_out, const uint64_t* in, size_t pcount,

@@ -46,6 +46,41 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, device="cpu"):
+    """every rank's value, in rank order (the first multi-GPU run must be diagnosable: which rank was slow, by how much)"""
+    if not is_distributed():
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def gather_objects(obj):
+    """small python objects (device names) from every rank, in rank order"""
+    if not is_distributed():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def backend_world_size():
+    """the world size the BACKEND reports (not the one the launcher asked for)"""
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank_report(elapsed_s, steps, device_name, key_broadcast_s, device="cpu"):
+    """the per-rank part of a bench line: spread of the step time over the ranks, who was slowest, what every rank ran on"""
+    per = gather_over_ranks(elapsed_s / max(1, steps) * 1e3, device=device)
+    names = gather_objects(device_name)
+    bc = gather_over_ranks(key_broadcast_s, device=device)
+    slow = max(range(len(per)), key=lambda r: per[r])
+    return {"ranks": backend_world_size(), "ms_per_step_per_rank": [round(v, 4) for v in per], "ms_per_step_min": round(min(per), 4),
+            "ms_per_step_max": round(max(per), 4), "slowest_rank": slow, "devices": names,
+            "key_broadcast_s": round(max(bc), 4), "key_broadcast_s_per_rank": [round(v, 4) for v in bc]}
+
+
 def barrier():
     if is_distributed():
         dist.barrier()

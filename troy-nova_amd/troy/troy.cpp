@@ -4,6 +4,7 @@
 #include "troy.h"
 
 #include <atomic>
+#include <unordered_set>
 
 #include <hip/hip_runtime_api.h>
 
@@ -51,10 +52,34 @@ MemoryPool::MemoryPool(size_t device) : device_(device) {
     if (device >= device_count()) throw std::runtime_error("[MemoryPool::MemoryPool] No such device.");
 }
 
+// A block in a free list carries the tag of the host thread that released it: kernels queued on THAT thread's stream may still be using
+// it.  Tag 0 = nobody's work is pending on it (it was in the free list at a device-wide synchronisation).  A thread that ends leaves its
+// tag in g_dead_tags (its destructor must not call into HIP: the runtime's own thread-local state may be gone by then); blocks of dead
+// threads are handed out after ONE device-wide synchronisation, which clears every tag.
+static std::mutex g_dead_mutex;
+static std::unordered_set<uint64_t> g_dead_tags;
+struct ThreadExit {
+    uint64_t tag = 0;
+    ~ThreadExit() {
+        if (!tag) return;
+        std::lock_guard<std::mutex> lock(g_dead_mutex);
+        g_dead_tags.insert(tag);
+    }
+};
 static uint64_t this_thread_tag() {
     static std::atomic<uint64_t> next{1};
-    thread_local uint64_t tag = next.fetch_add(1);
-    return tag;
+    thread_local ThreadExit te;
+    if (!te.tag) te.tag = next.fetch_add(1);
+    return te.tag;
+}
+static bool tag_is_dead(uint64_t tag) {
+    std::lock_guard<std::mutex> lock(g_dead_mutex);
+    return g_dead_tags.count(tag) != 0;
+}
+
+void MemoryPool::disown(uint64_t tag) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (auto& kv : free_) for (auto& blk : kv.second) if (blk.owner == tag || tag == ~uint64_t(0)) blk.owner = 0;
 }
 
 MemoryPool::~MemoryPool() {
@@ -73,44 +98,49 @@ void MemoryPool::Destroy() {
     g_global_pool.reset();
 }
 
+// Best fit with at most 2x slack (memory_pool_safe.in:119-148).  Order of preference: a block THIS thread released (safe by stream
+// order) or one nobody has work pending on (tag 0); a block of a host thread that has ended, behind one device-wide synchronisation
+// (which clears every tag, so this happens once per generation of threads); a fresh hipMalloc; and only when the device is out of
+// memory a block another LIVE thread released, again behind a device-wide synchronisation.  Round 3 took any foreign block before
+// trying hipMalloc: with N host threads working on single objects (the reference's -c N mode) blocks migrated between threads all the
+// time and every migration was a hipDeviceSynchronize -- 16 threads ran at the speed of 3 (tests/cpp/he_bench_driver threads).
 void* MemoryPool::allocate(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
     const uint64_t me = this_thread_tag();
-    void* found = nullptr;
-    bool foreign = false;
-    {
+    // which: 0 = mine or nobody's, 1 = a dead thread's (returns the block WITHOUT taking it: the caller synchronises first), 2 = anybody's
+    auto take = [&](int which) -> void* {
         std::lock_guard<std::mutex> lock(mutex_);
-        // best fit with at most 2x slack (memory_pool_safe.in:119-148); among the fitting blocks prefer one this thread released
-        auto first = free_.lower_bound(bytes);
-        auto pick = free_.end();
-        size_t pick_index = 0;
-        for (auto it = first; it != free_.end() && it->first <= bytes * 2 && !found; ++it) {
-            for (size_t i = it->second.size(); i-- > 0;)
-                if (it->second[i].owner == me) { pick = it; pick_index = i; found = it->second[i].ptr; break; }
+        for (auto it = free_.lower_bound(bytes); it != free_.end() && it->first <= bytes * 2; ++it) {
+            for (size_t i = it->second.size(); i-- > 0;) {
+                const uint64_t o = it->second[i].owner;
+                if (which == 0 && o != me && o != 0) continue;
+                if (which == 1) { if (o != me && o != 0 && tag_is_dead(o)) return it->second[i].ptr; continue; }
+                void* found = it->second[i].ptr;
+                const size_t sz = it->first;
+                it->second.erase(it->second.begin() + static_cast<std::ptrdiff_t>(i));
+                if (it->second.empty()) free_.erase(it);
+                live_[found] = sz;
+                return found;
+            }
         }
-        if (!found && first != free_.end() && first->first <= bytes * 2) {
-            pick = first; pick_index = first->second.size() - 1; found = first->second[pick_index].ptr; foreign = true;
-        }
-        if (found) {
-            const size_t sz = pick->first;
-            pick->second.erase(pick->second.begin() + static_cast<std::ptrdiff_t>(pick_index));
-            if (pick->second.empty()) free_.erase(pick);
-            live_[found] = sz;
-        }
-    }
-    if (found) {
-        if (foreign) {   // kernels of the releasing thread's stream may still be using the block
-            hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
-            hip_check(hipDeviceSynchronize(), "device_synchronize");
-        }
-        return found;
-    }
+        return nullptr;
+    };
+    if (void* p = take(0)) return p;
     hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
+    if (take(1)) {
+        // everything queued so far completes: every cached block is then safe for anyone
+        hip_check(hipDeviceSynchronize(), "device_synchronize");
+        disown(~uint64_t(0));
+        if (void* q = take(0)) return q;
+    }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {   // give cached blocks back and retry once
-        release_unused();
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        hip_check(hipDeviceSynchronize(), "device_synchronize");
+        disown(~uint64_t(0));
+        if (void* q = take(2)) return q;
+        release_unused();      // nothing of a fitting size: give the cache back and retry once
         hip_check(hipMalloc(&p, bytes), "malloc");
     }
     std::lock_guard<std::mutex> lock(mutex_);

@@ -139,8 +139,13 @@ using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 // Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
 // uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on its own
 // stream (hipStreamPerThread), and a block may be released while kernels that use it are still queued: a thread that
-// takes back one of ITS OWN blocks is safe by stream order; a block last released by another thread is handed out only
-// after a device-wide synchronisation (memory_pool_safe.in:133-143 does the same with cudaDeviceSynchronize).
+// takes back one of ITS OWN blocks is safe by stream order; blocks of host threads that have ended are handed out after one
+// device-wide synchronisation (which makes every cached block anybody's); otherwise the pool allocates fresh memory, and
+// only when the device is out of memory does it hand out a block last released by another LIVE thread, again after a
+// device-wide synchronisation (memory_pool_safe.in:133-143 does that with cudaDeviceSynchronize on every foreign reuse).
+// ASSUMPTION the asynchronous methods rest on: one stream per host thread, always the same one -- true here because every launch of this
+// library's C++ layer uses hipStreamPerThread; a caller that drives the C-ABI (include/troyn.h) with streams of its own must order the
+// release of a workspace after the work that uses it (stream-ordered free or an event), exactly as with any asynchronous HIP API.
 class MemoryPool {
 public:
     explicit MemoryPool(size_t device = 0);
@@ -152,6 +157,7 @@ public:
     void* allocate(size_t bytes);
     void release(void* ptr);
     void release_unused();
+    void disown(uint64_t thread_tag);   // internal: the blocks that thread released have no work pending any more (~0: every block)
 private:
     size_t device_;
     std::mutex mutex_;
