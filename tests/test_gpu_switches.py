@@ -4,6 +4,8 @@
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
   TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
+  TROYN_KS_SPLIT=0 | 1      digit-parallel form of the inner product (one workgroup per digit + a reducer) off / forced on (default: on when the
+                            launch would occupy at most half of the chip -- the batches of 8 used below take it, so "0" is the other side here)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
   TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0127)
   TROYN_NTT_ARITH=u64       integer butterflies for every modulus
@@ -24,11 +26,13 @@ def _case(O, pkg, dev, n, bits, L, batch=8):
 
 
 @pytest.mark.parametrize("env", [{}, {"TROYN_KS_MAC": "v1"}, {"TROYN_KS_MAC": "split"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_ARITH": "u64"},
-                                 {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}, {"TROYN_KS_DIAG": "loop"}],
-                         ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none", "ks_diag_in_loop"])
+                                 {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}, {"TROYN_KS_DIAG": "loop"}, {"TROYN_KS_SPLIT": "0"}, {"TROYN_KS_SPLIT": "1"},
+                                 {"TROYN_KS_SPLIT": "0", "TROYN_KS_DIAG": "loop"}],
+                         ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none", "ks_diag_in_loop",
+                              "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_diag_in_loop"])
 @pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [40, 40, 40, 40], 3)])
 def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L):
-    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG"):
+    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG", "TROYN_KS_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -44,10 +48,11 @@ def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L
             assert np.array_equal(got[i], ctx.switch_key(L, True, tg[i], keys, assign=assign, dest=d0[i])), (env, assign, i)
 
 
-@pytest.mark.parametrize("env", [{}, {"TROYN_MRR": "calls"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}],
-                         ids=["default", "mrr_calls", "ks_order_row", "ntt_half_all", "ntt_half_none"])
+@pytest.mark.parametrize("env", [{}, {"TROYN_MRR": "calls"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"},
+                                 {"TROYN_KS_SPLIT": "0"}, {"TROYN_KS_SPLIT": "1"}, {"TROYN_KS_SPLIT": "0", "TROYN_KS_ORDER": "row"}],
+                         ids=["default", "mrr_calls", "ks_order_row", "ntt_half_all", "ntt_half_none", "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_order_row"])
 def test_fused_chain_under_every_switch(O, pkg, dev, monkeypatch, env):
-    for k in ("TROYN_MRR", "TROYN_KS_ORDER", "TROYN_NTT_HALF"):
+    for k in ("TROYN_MRR", "TROYN_KS_ORDER", "TROYN_NTT_HALF", "TROYN_KS_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -175,3 +180,25 @@ def test_relinearize_shortest_chains(O, pkg, dev, n, bits, L, scheme):
     got = pkg.to_host(plan.relinearize(L, pkg.to_device(ct3, dev), dkeys, is_ckks=ntt, is_ntt_form=ntt))
     for i in range(8):
         assert np.array_equal(got[i], ctx.relinearize(L, ntt, ct3[i], keys)), i
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("scheme,ntt_form,n,bits,L,batch", [("bfv", False, 32768, [50] * 4, 3, 2), ("ckks", True, 32768, [50] * 4, 3, 1), ("bfv", False, 8192, [40, 40, 40], 2, 3),
+                                                            ("ckks", True, 16384, [50] * 6, 5, 1), ("ckks", True, 16384, [45, 45, 45], 2, 5), ("ckks", True, 8192, [50] * 4, 2, 64)])
+def test_digit_parallel_inner_product(O, pkg, dev, monkeypatch, split, scheme, ntt_form, n, bits, L, batch):
+    """the digit-parallel form of the key-switch inner product (small batches: ksmac2 SPLITJ + ksmac_split_reduce_kernel) against the oracle,
+    next to the serial form on the same operands: the three ring sizes, coefficient-form and NTT-form targets (no / diagonal-digit reducer
+    epilogue), a lower level, a single item and the largest batch the slots are provisioned for"""
+    monkeypatch.setenv("TROYN_KS_SPLIT", split)
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context(scheme, n, q, 1032193 if scheme == "bfv" else 0)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    tg = np.stack([ctx.random_ct(5 + (i % 7), 1, L)[0] for i in range(batch)])
+    d0 = np.stack([ctx.random_ct(40 + (i % 5), 2, L) for i in range(batch)])
+    dd = pkg.to_device(d0, dev)
+    plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=pkg.ASSIGN_ADD_INPLACE, is_ckks=scheme == "ckks", is_ntt_form=ntt_form)
+    got = pkg.to_host(dd)
+    for i in sorted({0, batch // 2, batch - 1}):
+        assert np.array_equal(got[i], ctx.switch_key(L, ntt_form, tg[i], keys, assign=pkg.ASSIGN_ADD_INPLACE, dest=d0[i])), (split, i)

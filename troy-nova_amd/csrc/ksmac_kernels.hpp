@@ -63,6 +63,12 @@ struct KsMacArgs {
     unsigned grouped;       // 1: the (L+1) * HALVES workgroups of an item are dealt to one XCD (batch % 8 == 0)
     unsigned long long row_mask;   // 0: all L + 1 output rows; else the launch covers the rows whose bit is set (mixed chains: rows of moduli < 2^50)
     unsigned long long* prof;   // development only (tools/ksbench -DKSM_PHASE_PROFILE): per-phase shader cycles of wave 0 of every workgroup, summed
+    // digit-parallel form for small batches (SPLITJ instantiations): the grid is L times larger, workgroup (tile, js) transforms and
+    // multiplies ONE digit js and leaves its two accumulators as re-centred doubles in part[js] (strides of `out` inside a slot);
+    // ksmac_split_reduce_kernel adds the L slots (and the diagonal digit / tensor terms of the NTT-form / fused callers) and stores
+    // canonical words.  split_skip_diag: slot js == k of a data row k is not produced (the reducer forms that term itself).
+    double* part; long long part_jstride;
+    unsigned split_skip_diag;
 };
 
 constexpr int KSM_TB = 13;                  // tile bits
@@ -174,7 +180,9 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 // DG: the same epilogue without the tensor terms, for the separate key switch on an NTT-form target (KsMacArgs::diag + diag_keys): the
 // diagonal digit is multiplied-accumulated in the coalesced layout, the loop drops its diagonal path (scratch 36 -> 12 bytes)
 // NODIAG: coefficient-form target (BFV): there is no diagonal digit, and the instantiation does not carry the loop's diagonal path
-template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false, bool NODIAG = false>
+// SPLITJ: one digit per workgroup (KsMacArgs::part), for launches that would otherwise leave most of the chip idle while 12 workgroups
+// walk their L digits one after the other (a single ciphertext: 85 us of a 150 us multiply + relinearize + rescale)
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false, bool NODIAG = false, bool SPLITJ = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -204,6 +212,9 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         if (lds_base) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
     }
     // ---- workgroup -> (item, row, half) ------------------------------------------------------------------
+    static_assert(!SPLITJ || (NODIAG && !TEN && !DG), "the digit-parallel form has no diagonal path of its own");
+    const unsigned split_js = SPLITJ ? blockIdx.x % a.L : 0u;                  // the one digit of this workgroup
+    const unsigned bx = SPLITJ ? blockIdx.x / a.L : blockIdx.x;
     unsigned b, k, h;
     {
         const unsigned nrows = a.row_mask ? (unsigned)__builtin_popcountll(a.row_mask) : a.L + 1;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
             // Odd row count: the workgroups of the missing row exit.  Measured -4..-6 % on the launch (profiles/r03_ksmac_ab.txt).
             constexpr unsigned ITEMS = 64u / (2u * HALVES);
             const unsigned bands = (nrows + 1u) / 2u, per = bands * 64u;
-            const unsigned xcd = blockIdx.x & 7u, sq = blockIdx.x >> 3, r = sq % per, r2 = r & 63u;
+            const unsigned xcd = bx & 7u, sq = bx >> 3, r = sq % per, r2 = r & 63u;
             k = 2u * (r >> 6) + (r2 % (2u * HALVES)) / HALVES;
             h = r2 % HALVES;
             b = ((sq / per) * 8u + xcd) * ITEMS + r2 / (2u * HALVES);
@@ -224,14 +235,14 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         } else if (a.grouped == 2) {
             // row-major: the whole chip works on one output row at a time, so that row's 2L key limbs (1.3 MB at cfg3) stay
             // in every XCD's L2; the halves of an item sit 8 workgroups apart = on the same XCD, back to back
-            const unsigned per = 8u * HALVES, r = blockIdx.x % per, q = blockIdx.x / per;
+            const unsigned per = 8u * HALVES, r = bx % per, q = bx / per;
             h = r / 8u; b = (q % (a.batch / 8u)) * 8u + (r % 8u); k = q / (a.batch / 8u);
         } else {
         if (a.grouped) {
-            const unsigned per = 8u * G, r = blockIdx.x % per;
-            g = r / 8u; b = (blockIdx.x / per) * 8u + (r % 8u);
+            const unsigned per = 8u * G, r = bx % per;
+            g = r / 8u; b = (bx / per) * 8u + (r % 8u);
         } else {
-            g = blockIdx.x % G; b = blockIdx.x / G;
+            g = bx % G; b = bx / G;
         }
         k = g / HALVES; h = g % HALVES;
         }
@@ -318,9 +329,10 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
     // (the sum is exact, its order is free)
     static_assert(!(TEN && DG), "one epilogue");
     const bool ten_row = (TEN || DG) && k < a.L;      // data row of an instantiation whose epilogue takes the diagonal digit
-    const unsigned steps = ten_row ? a.L - 1 : a.L;
+    if constexpr (SPLITJ) { if (a.split_skip_diag && k < a.L && split_js == k) return; }      // the reducer forms the diagonal digit's term
+    const unsigned steps = SPLITJ ? 1u : (ten_row ? a.L - 1 : a.L);
     for (unsigned step = 0; step < steps; ++step) {
-        const unsigned it = !ten_row ? step : (step < k ? step : step + 1);     // digit of this step
+        const unsigned it = SPLITJ ? split_js : (!ten_row ? step : (step < k ? step : step + 1));     // digit of this step
         double x[32];
         // nothing below depends on the digit except the input and the key: without these the compiler hoists every
         // twiddle load (and its w/p product) out of the digit loop and spills them
@@ -632,12 +644,15 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
             if constexpr (m + W < 16) request(std::integral_constant<int, m + W>{});
         });
     } }
+    if constexpr (SPLITJ) go = reinterpret_cast<u64*>(a.part) + (long long)split_js * a.part_jstride + (go - a.out);      // slot js, same place inside it
     if (!ten_row)
     static_for<0, 2>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            const ulonglong2 v = make_ulonglong2(f64_canon(c ? acc1[2 * m] : acc0[2 * m], fm), f64_canon(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm));
+            ulonglong2 v;
+            if constexpr (SPLITJ) v = make_ulonglong2(f64_double_to_bits(f64_corr(c ? acc1[2 * m] : acc0[2 * m], fm)), f64_double_to_bits(f64_corr(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm)));
+            else v = make_ulonglong2(f64_canon(c ? acc1[2 * m] : acc0[2 * m], fm), f64_canon(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm));
             *reinterpret_cast<ulonglong2*>(&lds[p2 + 2 * m]) = v;
         });
         __builtin_amdgcn_wave_barrier();
@@ -654,6 +669,64 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         for (int i = 0; i < 9; i++) atomicAdd(a.prof + i, prof_acc[i]);
     }
 #endif
+}
+
+// Second stage of the digit-parallel form: out[c][k] = canon( sum_js part[js][c][k]  +  the terms ksmac2's TEN / DG epilogues add ).
+// EPI 0: nothing more (coefficient-form target).  EPI 1 (fused chain, data rows): the diagonal digit (a1 (.) b1) key_kk and the tensor terms
+// a0 b0 / a0 b1 + a1 b0 (KsMacArgs::ten_a, ten_b, diag_keys; keys prepared times qk^-1).  EPI 2 (NTT-form target): the diagonal digit
+// (limb k of the target) times key_kk.  One thread per pair of coefficients; exact integer arithmetic, hence the same canonical words.
+template <int EPI>
+__global__ __launch_bounds__(256) void ksmac_split_reduce_kernel(KsMacArgs a, unsigned n) {
+    const unsigned chunks = n / 512u;
+    const unsigned ch = blockIdx.x % chunks, row = blockIdx.x / chunks;
+    const unsigned nrows = a.L + 1, k = row % nrows, b = row / nrows;
+    const unsigned i = ch * 512u + threadIdx.x * 2u;
+    const unsigned mrow = (k == a.L) ? a.table_count - 1 : k;
+    const DevModulus dm = a.mods[a.table_start + mrow];
+    const F64Mod fm{dm.pd, dm.inv_pd};
+    const double p = fm.p, inv_p = fm.inv_p;
+    const bool data_row = EPI != 0 && k < a.L;
+    const long long base = (long long)b * a.out_bstride + (long long)k * a.out_cstride + i;
+    double s0x = 0.0, s0y = 0.0, s1x = 0.0, s1y = 0.0;
+    for (unsigned js = 0; js < a.L; ++js) {
+        if (data_row && js == k) continue;
+        const double* ps = a.part + (long long)js * a.part_jstride + base;
+        const double2 v0 = *reinterpret_cast<const double2*>(ps), v1 = *reinterpret_cast<const double2*>(ps + a.out_pstride);
+        s0x += v0.x; s0y += v0.y; s1x += v1.x; s1y += v1.y;          // |slot| <= p/2 + 1: the sum of L <= 15 slots stays below 2^53
+    }
+    s0x = f64_corr(s0x, fm); s0y = f64_corr(s0y, fm); s1x = f64_corr(s1x, fm); s1y = f64_corr(s1y, fm);
+    auto mac2 = [&](double& a0, double& a1, double v, double y0, double y1) {
+        const double h0 = v * y0, h1 = v * y1;
+        const double l0 = __builtin_fma(v, y0, -h0), l1 = __builtin_fma(v, y1, -h1);
+        const double q0 = __builtin_rint(h0 * inv_p), q1 = __builtin_rint(h1 * inv_p);
+        a0 += __builtin_fma(-q0, p, h0) + l0;
+        a1 += __builtin_fma(-q1, p, h1) + l1;
+    };
+    if (data_row) {
+        const double* dk = a.diag_keys + (size_t)k * 2 * n + i;
+        const double2 y0 = *reinterpret_cast<const double2*>(dk), y1 = *reinterpret_cast<const double2*>(dk + n);
+        if constexpr (EPI == 1) {
+            const size_t toff = (size_t)b * a.ten_bstride + (size_t)k * n + i;
+            const ulonglong2 xa0 = *reinterpret_cast<const ulonglong2*>(a.ten_a + toff), xb0 = *reinterpret_cast<const ulonglong2*>(a.ten_b + toff);
+            const ulonglong2 xa1 = *reinterpret_cast<const ulonglong2*>(a.ten_a + toff + a.ten_pstride), xb1 = *reinterpret_cast<const ulonglong2*>(a.ten_b + toff + a.ten_pstride);
+            const double a0x = f64_from_u64(xa0.x), a0y = f64_from_u64(xa0.y), b0x = f64_from_u64(xb0.x), b0y = f64_from_u64(xb0.y);
+            const double a1x = f64_from_u64(xa1.x), a1y = f64_from_u64(xa1.y), b1x = f64_from_u64(xb1.x), b1y = f64_from_u64(xb1.y);
+            const double dx = f64_corr(f64_mulq(f64_corr(a1x, fm), b1x, inv_p, p), fm), dy = f64_corr(f64_mulq(f64_corr(a1y, fm), b1y, inv_p, p), fm);
+            mac2(s0x, s1x, dx, y0.x, y1.x);
+            mac2(s0y, s1y, dy, y0.y, y1.y);
+            s0x += f64_mulq(a0x, b0x, inv_p, p);
+            s0y += f64_mulq(a0y, b0y, inv_p, p);
+            s1x += f64_mulq(a0x, b1x, inv_p, p) + f64_mulq(a1x, b0x, inv_p, p);
+            s1y += f64_mulq(a0y, b1y, inv_p, p) + f64_mulq(a1y, b0y, inv_p, p);
+        } else if constexpr (EPI == 2) {
+            const ulonglong2 xd = *reinterpret_cast<const ulonglong2*>(a.diag + (long long)b * a.diag_bstride + (long long)k * a.diag_cstride + i);
+            mac2(s0x, s1x, f64_corr(f64_from_u64(xd.x), fm), y0.x, y1.x);
+            mac2(s0y, s1y, f64_corr(f64_from_u64(xd.y), fm), y0.y, y1.y);
+        }
+    }
+    u64* go = a.out + base;
+    *reinterpret_cast<ulonglong2*>(go) = make_ulonglong2(f64_canon(s0x, fm), f64_canon(s0y, fm));
+    *reinterpret_cast<ulonglong2*>(go + a.out_pstride) = make_ulonglong2(f64_canon(s1x, fm), f64_canon(s1y, fm));
 }
 
 }  // namespace troyn

@@ -41,6 +41,7 @@ inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const
 // digits_f64: the digit rows hold doubles (fused chain: NTT_FLAG_STORE_F64) instead of u64 words; wide_digits: some digit limb is 2^50 or
 // wider (mixed chains, a.row_mask selects the rows of moduli < 2^50): digits are reduced with integer arithmetic while loading
 void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs& a, hipStream_t s, bool digits_f64 = false, bool wide_digits = false);
+void launch_ksmac2_split(unsigned log_n, size_t batch, const KsMacArgs& a, hipStream_t s, bool digits_f64, int epi);
 // scale (optional): Shoup pairs of the factor the rows r < scale_rows of every key component are multiplied by (fused chain: qk^-1 mod q_r)
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s,
                                const ulonglong2* scale = nullptr, const DevModulus* mods = nullptr, unsigned scale_rows = 0,

@@ -623,8 +623,20 @@ static unsigned ksmac_order(size_t batch, unsigned log_n) {
     return (log_n >= 14 || env_is("TROYN_KS_ORDER", "band")) ? 3u : 1u;
 }
 
+// The digit-parallel form of the inner product (ksmac2 SPLITJ + ksmac_split_reduce_kernel) pays when the plain form would leave most of the
+// chip idle: batch * rows * tiles workgroups walking L digits one after the other (a single N = 16384 ciphertext: 12 workgroups, 85 us).
+// TROYN_KS_SPLIT=0 / 1 forces it off / on (A/B runs, tests); it needs L >= 2 and its slots in the workspace.
+static bool ksmac_split_wanted(size_t batch, unsigned L, unsigned log_n) {
+    const int e = env_int("TROYN_KS_SPLIT", -1);
+    if (e == 0 || L < 2 || log_n < 13 || log_n > 15) return false;
+    const size_t wgs = batch * (L + 1) << (log_n - 13);
+    if (batch > 64) return false;                      // the slots are provisioned for small batches only (ks_split_words)
+    return e == 1 || wgs <= 128;
+}
+static size_t ks_split_words(size_t batch, unsigned L, size_t n) { return batch <= 64 ? batch * L * 2 * (size_t)(L + 1) * n : 0; }
+
 struct KsLayout {
-    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, total;  // element offsets
+    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, total;  // element offsets
 };
 
 static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
@@ -637,6 +649,7 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
     w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
+    w.split = off;       off += ks_split_words(batch, L, n);                        // slots of the digit-parallel inner product (small batches)
     w.total = off;
     return w;
 }
@@ -723,7 +736,12 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.grouped = ksmac_order(batch, p->log_n);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            launch_ksmac2(p->log_n, batch, L + 1, a, s);
+            if (ksmac_split_wanted(batch, L, p->log_n) && (dg || !is_ntt_form)) {
+                a.grouped = 0;
+                a.part = reinterpret_cast<double*>(ws + w.split); a.part_jstride = (long long)batch * a.out_bstride;
+                a.split_skip_diag = dg ? 1u : 0u;
+                launch_ksmac2_split(p->log_n, batch, a, s, false, dg ? 2 : 0);
+            } else launch_ksmac2(p->log_n, batch, L + 1, a, s);
         }
         LAUNCH_CHECK();
     } else if (mac_fused && p->log_n <= 14) {
@@ -990,7 +1008,7 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
 // ---------------------------------------------------------------------------------------
 // fused CKKS multiply -> relinearize -> rescale_to_next
 // ---------------------------------------------------------------------------------------
-struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, fast_total, prod3, relin2, sub, total; };
+struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, split, fast_total, prod3, relin2, sub, total; };
 
 static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
     // the chain's kernels exist for whole-limb FP64 rings (N = 8192 / 16384, every modulus < 2^50)
@@ -1006,6 +1024,7 @@ static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
     w.spec_intt = off; off += batch * 2 * n;
     w.last_intt = off; off += batch * 2 * n;
     w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys + the diagonal blocks in natural order
+    w.split = off;     off += ks_split_words(batch, L, n);                        // slots of the digit-parallel inner product (small batches)
     w.fast_total = off;
     // composition of the three public calls (any other shape)
     off = 0;
@@ -1046,7 +1065,7 @@ static MrrStreams* mrr_streams(int device) {
 
 // launches (1)-(5) of the fused chain for `batch` items whose intermediates live in `ws` (layout w); kf: the prepared keys
 static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b, const double* kf, u64* out, u64* ws, const MrrLayout& w,
-                     size_t batch, hipStream_t s) {
+                     size_t batch, hipStream_t s, bool allow_split = true) {      // allow_split: the workspace has the slots of the digit-parallel form
     const unsigned K = p->K, n = p->n;
     int rc;
     const long long ct_b = 2ll * L * n, ct_p = (long long)L * n;           // strides of a, b
@@ -1073,7 +1092,12 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
         m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
+        if (allow_split && ksmac_split_wanted(batch, L, p->log_n)) {
+            m.grouped = 0;
+            m.part = reinterpret_cast<double*>(ws + w.split); m.part_jstride = (long long)batch * pp_b;
+            m.split_skip_diag = 1;
+            launch_ksmac2_split(p->log_n, batch, m, s, true, 1);
+        } else launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
     }
     LAUNCH_CHECK();
     // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
@@ -1178,7 +1202,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         const size_t c = std::min(chunk, batch - done);
         const int q = (int)(idx % (size_t)ns);
         if ((rc = mrr_chain(p, L, a + done * 2 * (size_t)L * n, b + done * 2 * (size_t)L * n, kf, out + done * 2 * (size_t)(L - 1) * n,
-                            ws + (size_t)q * slot_words, wc, c, ms->s[q]))) break;
+                            ws + (size_t)q * slot_words, wc, c, ms->s[q], false))) break;
         done += c; idx++;
     }
     // join ALSO on an error: the chunks already queued keep writing the caller's workspace / output, so the caller's stream must not

@@ -20,6 +20,25 @@ void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs&
 #undef KSMAC2_CASE
 }
 
+// digit-parallel form (small batches): one workgroup per (item, row, tile, digit) leaves its accumulators in a.part, then the reducer adds the
+// slots and the epilogue terms (epi: 0 none, 1 fused chain, 2 NTT-form target)
+void launch_ksmac2_split(unsigned log_n, size_t batch, const KsMacArgs& a, hipStream_t s, bool digits_f64, int epi) {
+    const dim3 block(KSM_THREADS);
+    const size_t rows = a.L + 1;
+#define KSMAC2_SPLIT_CASE(LOGN, TILES)                                                                                            \
+    if (digits_f64) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true, 0, false, false, false, true, true>), dim3((unsigned)(batch * rows * TILES * a.L)), block, 0, s, a); \
+    else hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, false, true, true>), dim3((unsigned)(batch * rows * TILES * a.L)), block, 0, s, a);
+    if (log_n == 15) { KSMAC2_SPLIT_CASE(15, 4) }
+    else if (log_n == 14) { KSMAC2_SPLIT_CASE(14, 2) }
+    else { KSMAC2_SPLIT_CASE(13, 1) }
+#undef KSMAC2_SPLIT_CASE
+    const unsigned n = 1u << log_n;
+    const dim3 grid((unsigned)(batch * rows * (n / 512u)));
+    if (epi == 1) hipLaunchKernelGGL(ksmac_split_reduce_kernel<1>, grid, dim3(256), 0, s, a, n);
+    else if (epi == 2) hipLaunchKernelGGL(ksmac_split_reduce_kernel<2>, grid, dim3(256), 0, s, a, n);
+    else hipLaunchKernelGGL(ksmac_split_reduce_kernel<0>, grid, dim3(256), 0, s, a, n);
+}
+
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s,
                                const ulonglong2* scale, const DevModulus* mods, unsigned scale_rows, double* diag_out) {
     hipLaunchKernelGGL(ksmac_prepare_keys_kernel, dim3(blocks), dim3(256), 0, s, kp, L, polys, n, out, scale, mods, scale_rows, diag_out);
