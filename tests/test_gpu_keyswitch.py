@@ -182,6 +182,42 @@ def test_bfv_multiply(O, pkg, dev, n, bits, L, t, pa, pb, behz_gen):
         assert np.array_equal(got[i], ctx.bfv_multiply(L, a[i], a[i])), i
 
 
+@pytest.mark.parametrize("n,bits,L,t", [(8192, [40, 40, 40], 2, 1032193), (16384, [50] * 6, 5, 1032193), (32768, [50] * 11, 10, 1032193), (4096, [36] * 5, 4, 65537)])
+def test_bfv_multiply_auxiliary_base(O, pkg, dev, monkeypatch, n, bits, L, t):
+    """TROYN_BEHZ_BASE=small with every q_i below 2^50: the multiply works in an auxiliary base of MORE primes BELOW 2^50 (all transforms on the
+    FP64 butterflies) whose capacity is at least the reference's 61-bit base; results must not depend on it.  Checked: the working base is larger than the reference's
+    and disjoint from the key chain, the known-answer hook still reports the reference's base, the products under both bases equal the oracle's
+    (which keeps the reference's base), and a handle created with the small-prime base also serves the first-generation kernels."""
+    monkeypatch.delenv("TROYN_BEHZ", raising=False)
+    monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
+    ref = pkg.Behz(plan, L, t)
+    monkeypatch.setenv("TROYN_BEHZ_BASE", "small")
+    fast = pkg.Behz(plan, L, t)
+    monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
+    assert ref.working_base_size == len(ref.base_Bsk) and fast.base_Bsk == ref.base_Bsk
+    assert fast.working_base_size > ref.working_base_size
+    # capacity: more than 61 bits per reference prime
+    assert 49.9 * (fast.working_base_size - 1) > 61 * (len(ref.base_Bsk) - 1) and 49.9 * fast.working_base_size > 61 * len(ref.base_Bsk)
+    batch = 3
+    a = np.stack([ctx.random_ct(231 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(247 + i, 2, L) for i in range(batch)])
+    # corner operands next to the random ones: all q - 1 and alternating 0 / q - 1
+    qa = np.array(q[:L], dtype=np.uint64)[None, :, None]
+    a[1] = np.broadcast_to(qa - 1, a[1].shape)
+    b[2][..., ::2] = 0
+    b[2][..., 1::2] = np.broadcast_to(qa - 1, b[2][..., 1::2].shape)
+    want = [ctx.bfv_multiply(L, a[i], b[i]) for i in range(batch)]
+    for h in (fast, ref):
+        got = pkg.to_host(h.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
+        for i in range(batch):
+            assert np.array_equal(got[i], want[i]), (h is fast, i)
+    monkeypatch.setenv("TROYN_BEHZ", "v1")          # first-generation kernels on the handle that holds the small-prime base
+    got = pkg.to_host(fast.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
+    for i in range(batch):
+        assert np.array_equal(got[i], want[i]), ("v1 kernels", i)
+
+
 @pytest.mark.parametrize("tensor", ["fused", "split"])
 @pytest.mark.parametrize("bits,L", [([50] * 4, 3), ([55] * 3, 2), ([55, 50, 50, 50], 3), ([40] * 2, 1)])
 def test_bfv_multiply_two_pass_sizes(O, pkg, dev, monkeypatch, bits, L, tensor):

@@ -53,6 +53,7 @@ SYMBOLS = {
     "troyn_behz_create": (C.c_int, [C.POINTER(vp), vp, u32, u64]),
     "troyn_behz_destroy": (C.c_int, [vp]),
     "troyn_behz_base_Bsk_size": (u32, [vp]),
+    "troyn_behz_working_base_size": (u32, [vp]),
     "troyn_behz_get_base_Bsk": (C.c_int, [vp, p64]),
     "troyn_plain_centralize": (C.c_int, [vp, u32, u64, vp, sz, sz, vp, sz, vp]),
     "troyn_dyadic_broadcast_product": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp, sz, vp]),

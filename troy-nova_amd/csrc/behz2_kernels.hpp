@@ -39,6 +39,8 @@ enum { B2_P = 0, B2_RLO = 1, B2_RHI = 2, B2_MU = 3, B2_C0 = 4, B2_C1 = 5 };
 
 struct Behz2Dev {
     unsigned L, n, rs;                 // rs: u32 stride of one split row = 2 * Lp (Lp = L rounded up to even)
+    unsigned NB;                       // primes of the auxiliary base B (rows 0 .. NB-1; row NB = m_sk).  NB == L for the reference's base of
+                                       // 61-bit primes; larger for the base of primes below 2^50 (troyn_behz_create), "L+1" below then reads "NB+1"
     const DevModulus* q_mods;          // [L]
     const ulonglong2* q_mt_inv_punc;   // [L] m_tilde (q/q_i)^-1 mod q_i (Shoup): lift input scaling
     const ulonglong2* q_t_inv_punc;    // [L] t (q/q_i)^-1 mod q_i (Shoup): floor input scaling
@@ -54,13 +56,13 @@ struct Behz2Dev {
 // ---- host: table construction -----------------------------------------------------------------------------------------------------
 struct Behz2Offsets { size_t lift_mt, lift_rows, lift_rc, fa_rows, fa_rc, fb_cols, fb_rc; unsigned rs; };
 
-// q: base q (all below 2^60), B: auxiliary base with |B| == |q|, m_sk, t.  smallq: every q_i < 2^50 (split point 25, else 30).
+// q: base q (all below 2^60), B: auxiliary base (|B| == |q| for wide q), m_sk, t.  smallq: every q_i < 2^50 (split point 25, else 30).
 // Appends to blob (u64 words); returns false when some inverse does not exist.
 inline bool behz2_build_tables(const std::vector<u64>& q, const std::vector<u64>& B, u64 m_sk, u64 t, bool smallq,
                                std::vector<u64>& blob, Behz2Offsets& o) {
     using namespace host;
-    const size_t L = q.size();
-    if (B.size() != L || L == 0 || L > BEHZ2_MAX_L) return false;
+    const size_t L = q.size(), NB = B.size();
+    if (NB == 0 || NB > 32 || (!smallq && NB != L) || L == 0 || L > BEHZ2_MAX_L) return false;
     const size_t Lp = (L + 1) & ~(size_t)1;
     const unsigned shq = smallq ? 25 : 30;
     const u64 mt = (u64)1 << 32;
@@ -94,51 +96,51 @@ inline bool behz2_build_tables(const std::vector<u64>& q, const std::vector<u64>
         for (size_t i = 0; i < L; i++) w[i] = (u32)((product_mod(q, i, mt) * neg_inv_q_mt) & 0xffffffffull);
         for (size_t k = 0; k < Lp; k += 2) blob.push_back((u64)w[k] | ((u64)w[k + 1] << 32));
     }
-    std::vector<u64> inv_mt(L + 1), inv_q(L + 1);
-    for (size_t b = 0; b <= L; b++) {
+    std::vector<u64> inv_mt(NB + 1), inv_q(NB + 1);
+    for (size_t b = 0; b <= NB; b++) {
         if (!inv_or_fail(mt, bsk[b], inv_mt[b])) return false;
         if (!inv_or_fail(product_mod(q, SIZE_MAX, bsk[b]), bsk[b], inv_q[b])) return false;
     }
     o.lift_rows = blob.size();
-    for (size_t b = 0; b <= L; b++) {
+    for (size_t b = 0; b <= NB; b++) {
         std::vector<u64> row(L);
         for (size_t i = 0; i < L; i++) row[i] = mulmod(product_mod(q, i, bsk[b]), inv_mt[b], bsk[b]);
         push_row(row, 32);
     }
     o.lift_rc = blob.size();
-    for (size_t b = 0; b <= L; b++) {
+    for (size_t b = 0; b <= NB; b++) {
         const u64 p = bsk[b];
         const u64 c = mulmod(product_mod(q, SIZE_MAX, p), inv_mt[b], p);
         push_rc(p, c, mulmod((p - mt % p) % p, c, p));
     }
     // ---- floor, first conversion (q -> Bsk) with the division by q and, for the B rows, the scaling of the second conversion ----
-    std::vector<u64> B_inv_punc(L, 1);
-    for (size_t b = 0; b < L; b++)
-        if (L > 1 && !inv_or_fail(product_mod(B, b, B[b]), B[b], B_inv_punc[b])) return false;
+    std::vector<u64> B_inv_punc(NB, 1);
+    for (size_t b = 0; b < NB; b++)
+        if (NB > 1 && !inv_or_fail(product_mod(B, b, B[b]), B[b], B_inv_punc[b])) return false;
     u64 inv_B_msk;
     if (!inv_or_fail(product_mod(B, SIZE_MAX, m_sk), m_sk, inv_B_msk)) return false;
     o.fa_rows = blob.size();
-    for (size_t b = 0; b <= L; b++) {
+    for (size_t b = 0; b <= NB; b++) {
         const u64 p = bsk[b];
         std::vector<u64> row(L);
         for (size_t i = 0; i < L; i++) {
             u64 v = mulmod(product_mod(q, i, p), inv_q[b], p);
-            if (b < L) v = mulmod(v, B_inv_punc[b], p);
+            if (b < NB) v = mulmod(v, B_inv_punc[b], p);
             row[i] = (p - v) % p;
         }
         push_row(row, 32);
     }
     o.fa_rc = blob.size();
-    for (size_t b = 0; b <= L; b++) {
+    for (size_t b = 0; b <= NB; b++) {
         const u64 p = bsk[b];
         u64 tq = mulmod(t % p, inv_q[b], p);
-        if (b < L) tq = mulmod(tq, B_inv_punc[b], p);
-        const u64 mk = b < L ? mulmod(product_mod(B, b, m_sk), inv_B_msk, m_sk) : (m_sk - inv_B_msk) % m_sk;
+        if (b < NB) tq = mulmod(tq, B_inv_punc[b], p);
+        const u64 mk = b < NB ? mulmod(product_mod(B, b, m_sk), inv_B_msk, m_sk) : (m_sk - inv_B_msk) % m_sk;
         push_rc(p, tq, mk);
     }
     // ---- floor, second conversion (B -> q), one column block per B prime ----
     o.fb_cols = blob.size();
-    for (size_t b = 0; b < L; b++) {
+    for (size_t b = 0; b < NB; b++) {
         std::vector<u64> col(L);
         for (size_t j = 0; j < L; j++) col[j] = product_mod(B, b, q[j]);
         push_row(col, shq);
@@ -163,9 +165,10 @@ __device__ __forceinline__ u64 behz2_reduce61(u128 v, u64 p, u64 mu) {
 
 __device__ __forceinline__ u64 behz2_reduce(u128 v, u64 p, u64 rlo, u64 rhi) { return barrett128((u64)v, (u64)(v >> 64), p, rlo, rhi); }
 
-template <bool SMALLQ>
+// reduction modulo an auxiliary prime: FAST61 = the one-multiply form for primes in [2^60, 2^61) (the reference's base under small q)
+template <bool FAST61>
 __device__ __forceinline__ u64 behz2_reduce_aux(u128 v, cu64p rc) {
-    if (SMALLQ) return behz2_reduce61(v, rc[B2_P], rc[B2_MU]);
+    if (FAST61) return behz2_reduce61(v, rc[B2_P], rc[B2_MU]);
     return behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]);
 }
 
@@ -208,14 +211,16 @@ __device__ __forceinline__ void behz2_load_q(const u64* ip, unsigned n, unsigned
     }
 }
 
-// BEHZ steps (1)-(2): in [items][L][N] (coefficient form, base q) -> out [items][L+1][N]
-template <int L, bool SMALLQ>
+// BEHZ steps (1)-(2): in [items][L][N] (coefficient form, base q) -> out [items][NB+1][N]
+// AUX50: the auxiliary primes are below 2^50 (NB > L of them) instead of the reference's 61-bit primes
+template <int L, bool SMALLQ, bool AUX50 = false>
 __global__ __launch_bounds__(256) void behz2_lift_kernel(unsigned chunks, Behz2Dev c, const u64* in, u64* out) {
     constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
-    const unsigned n = c.n;
+    static_assert(!AUX50 || SMALLQ, "the 50-bit auxiliary base is chosen for small q only");
+    const unsigned n = c.n, NB = c.NB;
     const size_t item = blockIdx.x / chunks;
     const u64* ip = in + item * (size_t)L * n;
-    u64* op = out + item * (size_t)(L + 1) * n;
+    u64* op = out + item * (size_t)(NB + 1) * n;
     const cmodp q_mods = as_cmod(c.q_mods);
     const cu64x2p scale = as_c128(c.q_mt_inv_punc);
     const cu32p mtrow = as_c32(c.lift_mt), rows = as_c32(c.lift_rows);
@@ -230,24 +235,25 @@ __global__ __launch_bounds__(256) void behz2_lift_kernel(unsigned chunks, Behz2D
         for (int i = 0; i < L; ++i) r_mt += (ylo[i] | (yhi[i] << SHQ)) * mtrow[i];
         const bool neg = r_mt >= 0x80000000u;
 #pragma unroll 1
-        for (unsigned b = 0; b <= (unsigned)L; ++b) {
+        for (unsigned b = 0; b <= NB; ++b) {
             const cu32p row = rows + (size_t)b * c.rs;
             const cu64p rc = rcs + (size_t)b * BEHZ2_RC;
             u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
             v += (u128)rc[B2_C0] * r_mt + (neg ? rc[B2_C1] : 0ull);
-            op[(size_t)b * n + x] = behz2_reduce_aux<SMALLQ>(v, rc);
+            op[(size_t)b * n + x] = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
         }
     }
 }
 
-// BEHZ steps (6)-(8): in_q [items][L][N], in_bsk [items][L+1][N] (coefficient form) -> out [items][L][N]
-template <int L, bool SMALLQ>
+// BEHZ steps (6)-(8): in_q [items][L][N], in_bsk [items][NB+1][N] (coefficient form) -> out [items][L][N]
+template <int L, bool SMALLQ, bool AUX50 = false>
 __global__ __launch_bounds__(256) void behz2_floor_kernel(unsigned chunks, Behz2Dev c, const u64* in_q, const u64* in_bsk, u64* out) {
     constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
-    const unsigned n = c.n;
+    static_assert(!AUX50 || SMALLQ, "the 50-bit auxiliary base is chosen for small q only");
+    const unsigned n = c.n, NB = c.NB;
     const size_t item = blockIdx.x / chunks;
     const u64* qp = in_q + item * (size_t)L * n;
-    const u64* bp = in_bsk + item * (size_t)(L + 1) * n;
+    const u64* bp = in_bsk + item * (size_t)(NB + 1) * n;
     u64* op = out + item * (size_t)L * n;
     const cmodp q_mods = as_cmod(c.q_mods);
     const cu64x2p scale = as_c128(c.q_t_inv_punc);
@@ -263,14 +269,14 @@ __global__ __launch_bounds__(256) void behz2_floor_kernel(unsigned chunks, Behz2
         for (int j = 0; j < L; ++j) { behz2_zero(acc[j]); wide[j] = 0; }
         u64 sk_lo = 0, sk_hi = 0;   // sum_b y'_b * ((B/p_b) B^-1 mod m_sk)
 #pragma unroll 1
-        for (unsigned b = 0; b < (unsigned)L; ++b) {
+        for (unsigned b = 0; b < NB; ++b) {
             const cu32p row = fa_rows + (size_t)b * c.rs;
             const cu64p rc = fa_rc + (size_t)b * BEHZ2_RC;
             // ((x_b t - conv_b) q^-1) (B/p_b)^-1 mod p_b in one dot product
             u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
             const u64 xb = bp[(size_t)b * n + x], tq = rc[B2_C0];
             v += (u128)xb * tq;
-            const u64 yb = behz2_reduce_aux<SMALLQ>(v, rc);
+            const u64 yb = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
             mac128(sk_lo, sk_hi, yb, rc[B2_C1]);
             const u32 zlo = (u32)yb, zhi = (u32)(yb >> 32);
             const cu32p col = fb_cols + (size_t)b * c.rs;
@@ -284,12 +290,12 @@ __global__ __launch_bounds__(256) void behz2_floor_kernel(unsigned chunks, Behz2
         // m_sk row: r_sk = (x_sk t - conv_sk) q^-1 mod m_sk, then alpha_sk = (sum_b y'_b (B/p_b) - r_sk) B^-1 mod m_sk
         u64 alpha_use; bool neg;
         {
-            const cu32p row = fa_rows + (size_t)L * c.rs;
-            const cu64p rc = fa_rc + (size_t)L * BEHZ2_RC;
+            const cu32p row = fa_rows + (size_t)NB * c.rs;
+            const cu64p rc = fa_rc + (size_t)NB * BEHZ2_RC;
             u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
-            v += (u128)bp[(size_t)L * n + x] * rc[B2_C0];
+            v += (u128)bp[(size_t)NB * n + x] * rc[B2_C0];
             const u64 msk = rc[B2_P];
-            const u64 r_sk = behz2_reduce_aux<SMALLQ>(v, rc);
+            const u64 r_sk = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
             mac128(sk_lo, sk_hi, r_sk, rc[B2_C1]);
             const u64 alpha_sk = barrett128(sk_lo, sk_hi, msk, rc[B2_RLO], rc[B2_RHI]);
             neg = alpha_sk > (msk >> 1);

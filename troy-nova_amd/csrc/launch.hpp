@@ -47,7 +47,8 @@ void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, un
                                const ulonglong2* scale = nullptr, const DevModulus* mods = nullptr, unsigned scale_rows = 0,
                                double* diag_out = nullptr);   // diag_out: [j][2][N], block (key j, modulus j) in natural order
 // second-generation BEHZ conversions (L = 1 .. 16)
-void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst);
-void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out);
+// aux50: the auxiliary base holds primes below 2^50 (Behz2Dev::NB > L of them) instead of the reference's 61-bit primes
+void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst, bool aux50 = false);
+void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out, bool aux50 = false);
 
 }  // namespace troyn

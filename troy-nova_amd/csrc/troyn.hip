@@ -1391,6 +1391,7 @@ struct troyn_behz {
     BehzDev dev;
     Behz2Dev dev2;                      // second-generation conversion kernels (behz2_kernels.hpp)
     bool have2 = false, smallq = false; // have2: |B| == L <= 16 and every q_i < 2^60; smallq: every q_i < 2^50
+    bool aux50 = false;                 // the multiply works in an auxiliary base of primes below 2^50 (troyn_behz_create); bsk_values stays the reference's
     // encrypt / decrypt side constants of the same RNSTool / ContextData (context_data.cu:226-247, rns_tool.cu:168-211)
     u64 gamma = 0, q_mod_t = 0;
     DevModulus t_mod, gamma_mod;
@@ -1423,18 +1424,55 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     size_t total_bits = host::product_bit_count(q);
     size_t Bn = L;
     if (32 + host::bit_count(t) + total_bits >= 61 * (size_t)L + 61) Bn++;
-    const size_t Bsk = Bn + 1;
+    const size_t Bsk_ref = Bn + 1;
     std::vector<u64> primes;
     try {
-        primes = host::get_primes(2 * (u64)n, 61, Bsk + 1);
+        primes = host::get_primes(2 * (u64)n, 61, Bsk_ref + 1);
     } catch (const std::exception& e) {
         return fail(TROYN_E_MODULUS, e.what());
     }
-    const u64 m_sk = primes[0];   // primes[1] = gamma (decrypt side only)
+    u64 m_sk = primes[0];   // primes[1] = gamma (decrypt side only)
     std::vector<u64> B(primes.begin() + 2, primes.begin() + 2 + Bn);
     std::vector<u64> bsk = B; bsk.push_back(m_sk);
     const u64 mt = (u64)1 << 32;
-    b->Bn = (unsigned)Bn; b->Bsk = (unsigned)Bsk; b->bsk_values = bsk;
+    b->bsk_values = bsk;          // the reference's base (troyn_behz_get_base_Bsk: known-answer hook), whatever base the multiply works in
+    // ---- working base.  BEHZ's result does not depend on the auxiliary primes: the conversion q -> Bsk yields the integer x + alpha q
+    // (alpha < L, a function of the residues mod q only), the small Montgomery reduction works modulo m_tilde = 2^32, the floor is an exact
+    // integer division in base Bsk and the Shenoy-Kumaresan conversion back to q is exact as long as the value fits B -- all statements about
+    // integers, true for ANY base whose product is at least the reference's (utils/rns_tool.cu:52-80 sizes B as |q| or |q| + 1 primes of 61 bits).
+    // When every q_i is below 2^50 the 61-bit base is the only reason half of the multiply's transforms, its tensor product and its two
+    // conversions run on the integer butterflies (27.5 issue slots against 8 FP64 instructions): take instead NB primes BELOW 2^50 with
+    //     prod(B') >= 2^(61 Bn)   and   prod(B') m_sk' >= 2^(61 (Bn + 1)),
+    // i.e. at least the capacity of any base the reference could have picked, so that every transform of the multiply takes the exact-FP64
+    // policy.  The oracle keeps the reference's base; equality of the final residues on every BEHZ test is the proof.
+    // MEASURED (round 4, BASELINE config 4, profiles/r04_cfg4_ab.txt): bit-identical results, and no gain -- the tensor kernels drop from 1.33 to
+    // 1.01 ms per 64 products, but 13 + 1 primes instead of 10 + 1 make both conversions 29 % longer (0.66 -> 0.83 ms for the floor alone) and
+    // add three limbs to every strided pass: 14.0 k against 14.2 k mul+relin ops/s.  It is therefore an OPTION (TROYN_BEHZ_BASE=small, read
+    // here), not the default.
+    bool aux50 = env_is("TROYN_BEHZ_BASE", "small");
+    for (u64 v : q) if (v >= F64_MODULUS_LIMIT) aux50 = false;
+    if (env_is("TROYN_BEHZ", "v1") || L > BEHZ2_MAX_L || plan->log_n < 10) aux50 = false;
+    if (aux50) {
+        try {
+            std::vector<u64> cand = host::get_primes(2 * (u64)n, 50, plan->K + 2 * Bsk_ref + 8);
+            std::vector<u64> fresh;
+            for (u64 c : cand) if (std::find(plan->moduli.begin(), plan->moduli.end(), c) == plan->moduli.end()) fresh.push_back(c);
+            std::vector<u64> B2;
+            size_t next = 1;                                  // fresh[0] becomes m_sk'
+            while (next < fresh.size()) {
+                B2.push_back(fresh[next++]);
+                std::vector<u64> with_sk = B2; with_sk.push_back(fresh[0]);
+                if (host::product_bit_count(B2) > 61 * Bn && host::product_bit_count(with_sk) > 61 * (Bn + 1)) break;
+            }
+            std::vector<u64> with_sk = B2; with_sk.push_back(fresh[0]);
+            if (!fresh.empty() && host::product_bit_count(B2) > 61 * Bn && host::product_bit_count(with_sk) > 61 * (Bn + 1) && B2.size() <= 32) {
+                B = B2; m_sk = fresh[0]; Bn = B.size();
+                bsk = B; bsk.push_back(m_sk);
+            } else aux50 = false;
+        } catch (const std::exception&) { aux50 = false; }
+    }
+    const size_t Bsk = Bn + 1;          // working base from here on
+    b->Bn = (unsigned)Bn; b->Bsk = (unsigned)Bsk; b->aux50 = aux50;
 
     int rc = troyn_plan_create(&b->aux, plan->device, plan->log_n, (uint32_t)Bsk, reinterpret_cast<const uint64_t*>(bsk.data()), nullptr);
     if (rc != TROYN_OK) return rc;
@@ -1508,7 +1546,7 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
 
     // second-generation conversion tables (split matrices with the scalar factors folded in)
     Behz2Offsets o2;
-    bool have2 = Bn == L && L <= BEHZ2_MAX_L, smallq = true;
+    bool have2 = (Bn == L || aux50) && L <= BEHZ2_MAX_L, smallq = true;
     for (u64 v : q) { if (v >> 60) have2 = false; if (v >= F64_MODULUS_LIMIT) smallq = false; }
     if (have2) {
         if (blob.size() & 1) blob.push_back(0);
@@ -1584,7 +1622,7 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     std::memset(&b->dev2, 0, sizeof(b->dev2));
     if (have2) {
         Behz2Dev& e = b->dev2;
-        e.L = L; e.n = n; e.rs = o2.rs;
+        e.L = L; e.n = n; e.rs = o2.rs; e.NB = (unsigned)Bn;
         e.q_mods = plan->d_mods; e.q_mt_inv_punc = d.q_mt_inv_punc; e.q_t_inv_punc = d.q_t_inv_punc;
         e.lift_mt = reinterpret_cast<const u32*>(b->d_consts + o2.lift_mt);
         e.lift_rows = reinterpret_cast<const u32*>(b->d_consts + o2.lift_rows);
@@ -1602,7 +1640,8 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     return TROYN_OK;
 }
 
-extern "C" uint32_t troyn_behz_base_Bsk_size(const troyn_behz* b) { return b ? b->Bsk : 0; }
+extern "C" uint32_t troyn_behz_base_Bsk_size(const troyn_behz* b) { return b ? (uint32_t)b->bsk_values.size() : 0; }
+extern "C" uint32_t troyn_behz_working_base_size(const troyn_behz* b) { return b ? b->Bsk : 0; }
 extern "C" int troyn_behz_get_base_Bsk(const troyn_behz* b, uint64_t* out) {
     select_device(b);
     if (!b || !out) return fail(TROYN_E_INVALID, "[troyn_behz_get_base_Bsk] null argument");
@@ -1669,7 +1708,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         if ((r = check_rows(items, ch1))) return r;
         dim3 grid((unsigned)(items * ch1)), block(256);
         if (gen2) {
-            launch_behz2_lift(L, b->smallq, grid.x, s, ch1, b->dev2, src, dst_bsk);
+            launch_behz2_lift(L, b->smallq, grid.x, s, ch1, b->dev2, src, dst_bsk, b->aux50);
         } else dispatch_bound(L,
             [&] { hipLaunchKernelGGL((behz_lift_kernel<4>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
             [&] { hipLaunchKernelGGL((behz_lift_kernel<8>), grid, block, 0, s, ch1, b->dev, src, dst_bsk); },
@@ -1721,7 +1760,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         dim3 grid((unsigned)(items * ch1)), block(256);
         TimerScope ts(TROYN_TIMER_BEHZ_FLOOR, s);
         if (gen2) {
-            launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out);
+            launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, b->aux50);
         } else dispatch_bound(S,
             [&] { hipLaunchKernelGGL((behz_floor_kernel<4>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },
             [&] { hipLaunchKernelGGL((behz_floor_kernel<8>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },

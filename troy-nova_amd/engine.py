@@ -521,6 +521,11 @@ class Behz:
         return [int(x) for x in out]
 
     @property
+    def working_base_size(self):
+        """primes of the auxiliary base the multiply works in (more, smaller primes than base_Bsk when every q_i is below 2^50)"""
+        return int(self.plan.lib.troyn_behz_working_base_size(self.h))
+
+    @property
     def gamma(self):
         return int(self.plan.lib.troyn_behz_gamma(self.h))
 
