@@ -533,16 +533,9 @@ __host__ __device__ constexpr bool ROUNDS_OK(int G, int EB) { return (G + EB - 1
 // HALF: the LDS tile holds 32-bit words (half the bytes): every exchange moves the low halves, then the high halves of its E words
 // (three barriers instead of one).  A whole-limb N = 16384 tile then takes 66 KB instead of 132 KB and TWO 1024-thread workgroups
 // share a CU, so one can load / store while the other computes -- what N = 8192 gets for free.
-// PRE / pf (persistent whole-limb inverse kernels, ntt_inv_pf_kernel): `pre` holds the 16-byte input pairs of THIS tile, requested while the
-// previous tile was still computing, and pf() requests the next tile's -- it is called at the start of round 2, behind the last per-lane twiddle
-// load of the transform (rounds 0 and 1), so that nothing of this tile queues behind those loads (a wave's loads return in order).
-struct NttNoPrefetch { __device__ __forceinline__ void operator()() const {} };
-template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0, bool HALF = false, bool SHFL = false, class PF = NttNoPrefetch>
-__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t, typename A::elem* xio = nullptr,
-                                              const ulonglong2* pre = nullptr, PF pf = PF{}) {
+template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, bool KSMAC, int IOM, int REGIO = 0, bool HALF = false, bool SHFL = false>
+__device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* keys, u64* lds, unsigned bid, unsigned t, typename A::elem* xio = nullptr) {
     constexpr int C = TB - G;
-    constexpr bool HASPF = !std::is_same<PF, NttNoPrefetch>::value;
-    static_assert(!HASPF || (INV && FIRST && LAST && !KSMAC && !HALF && REGIO == 0 && TB == LOGN), "prefetch: whole-limb inverse transforms");
     static_assert(!HALF || (!KSMAC && REGIO == 0), "half-word LDS tiles: plain and fused transform kernels only");
     static_assert(REGIO == 0 || (!KSMAC && IOM == 0 && C == 0 && (G + EB - 1) / EB > 1 && (REGIO == 1 ? (!INV && LAST) : (INV && FIRST))), "register hand-over: last forward / first inverse pass on whole tiles");
     constexpr int E = 1 << EB;
@@ -696,7 +689,6 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     (void)wg_sync;
     static_for<0, ROUNDS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        if constexpr (HASPF && r == (ROUNDS > 2 ? 2 : ROUNDS - 1)) { __builtin_amdgcn_sched_barrier(0); pf(); __builtin_amdgcn_sched_barrier(0); }
         // transform bits handled this round, and the register window [S, S+EB)
         constexpr int BHI = INV ? ((C + (r + 1) * EB - 1 < TB - 1) ? C + (r + 1) * EB - 1 : TB - 1) : TB - 1 - r * EB;
         constexpr int BLO = INV ? C + r * EB : ((TB - (r + 1) * EB > C) ? TB - (r + 1) * EB : C);
@@ -734,21 +726,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned idx = m * 128u + lane * 2u;
                 if constexpr (F_MULPAIR) {
                     // c2 = a1 (.) b1 formed while loading (the tensor product is never written to HBM)
-                    ulonglong2 va, vb;
-                    if constexpr (HASPF) { va = pre[m]; vb = pre[E / 2 + m]; }
-                    else { va = ld2_at(io.a1 + mul_off + gbase + m * 128u, lane * 16u, true); vb = ld2_at(io.b1 + mul_off + gbase + m * 128u, lane * 16u, true); }
+                    const ulonglong2 va = ld2_at(io.a1 + mul_off + gbase + m * 128u, lane * 16u, true), vb = ld2_at(io.b1 + mul_off + gbase + m * 128u, lane * 16u, true);
                     wv[2 * m] = A::to_lds(A::prod_in(va.x, vb.x, md), md);
                     wv[2 * m + 1] = A::to_lds(A::prod_in(va.y, vb.y, md), md);
                 } else if constexpr (F_LAST_LD) {
                     // Q = P qk^-1 + c_k at the dropped limb, as ksmac2 left it (KsMacArgs::ten_a)
-                    ulonglong2 vp;
-                    if constexpr (HASPF) vp = pre[m]; else vp = nt_load2(gin + gbase + idx);
+                    const ulonglong2 vp = nt_load2(gin + gbase + idx);
                     wv[2 * m] = A::to_lds(f64_from_u64(vp.x), md);
                     wv[2 * m + 1] = A::to_lds(f64_from_u64(vp.y), md);
                 } else {
                     // (uniform row + pair offset) + one 32-bit lane offset: no 64-bit address per load
-                    ulonglong2 v;
-                    if constexpr (HASPF) v = pre[m]; else v = ld2_at(gin + gbase + m * 128u, lane * 16u, a.stream_loads != 0);
+                    const ulonglong2 v = ld2_at(gin + gbase + m * 128u, lane * 16u, a.stream_loads != 0);
                     wv[2 * m] = ntt_io_load<LM>(io, v.x);
                     wv[2 * m + 1] = ntt_io_load<LM>(io, v.y);
                 }
@@ -1036,43 +1024,6 @@ template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST
 __global__ __launch_bounds__(1 << (TB - EB), HALF ? (2 << (TB - EB - 8)) : 1) void ntt_pass_kernel(NttArgs a) {
     __shared__ u64 lds[(G + EB - 1) / EB > 1 ? (HALF ? (ntt_lds_words(TB) + 1) / 2 : ntt_lds_words(TB)) : 1];
     ntt_pass_body<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, false, IOM, 0, HALF>(a, nullptr, lds, blockIdx.x, threadIdx.x);
-}
-
-// Persistent form of the whole-limb INVERSE transforms that keep a full-word tile (132 KB of LDS at N = 16384: ONE 1024-thread workgroup per
-// CU, so its load, transform and store phases run back to back and the CU's memory pipe idles while it computes).  One workgroup per CU walks
-// the tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests tile i + 1's input pairs (16 bytes per lane, E/2 or E registers pairs) from
-// inside tile i's transform, behind its last per-lane twiddle load: the HBM latency and transfer of the next tile travel under rounds 2, 3
-// and the stores of this one.  IOM: 0 plain, NTT_FUSED_MULPAIR (two operand rows), NTT_FUSED_LAST_LIMB.  Needs a.xcd_groups == 0.
-template <class A, int LOGN, int EB, int IOM>
-__global__ __launch_bounds__(1 << (LOGN - EB), 1) void ntt_inv_pf_kernel(NttArgs a, unsigned total) {
-    constexpr int E = 1 << EB;
-    constexpr unsigned N = 1u << LOGN;
-    constexpr int NP = (IOM == NTT_FUSED_MULPAIR) ? E : E / 2;
-    __shared__ u64 lds[ntt_lds_words(LOGN)];
-    const unsigned t = threadIdx.x, lane = t & 63u, wbase = (t >> 6) * (64u * E);
-    ulonglong2 cur[NP], nxt[NP];
-    auto fetch = [&](unsigned bid, ulonglong2 (&dst)[NP]) {
-        const unsigned j = bid % a.ncomp, g = bid / a.ncomp, k = g % a.pcount, b = g / a.pcount;
-        if constexpr (IOM == NTT_FUSED_MULPAIR) {
-            const size_t off = (size_t)((long long)b * a.mul_bstride + a.mul_pstride) + (size_t)(a.mul_limb0 + j) * N + wbase + lane * 2u;
-            const u64* pa = a.mul_a + off;
-            const u64* pb = a.mul_b + off;
-            static_for<0, E / 2>([&](auto mc) { constexpr int m = decltype(mc)::value; dst[m] = nt_load2(pa + m * 128u); dst[E / 2 + m] = nt_load2(pb + m * 128u); });
-        } else {
-            const u64* gin = a.in + (long long)b * a.in_bstride + (long long)k * a.in_pstride + (long long)j * a.in_cstride + wbase + lane * 2u;
-            if (a.stream_loads || IOM != 0) static_for<0, E / 2>([&](auto mc) { constexpr int m = decltype(mc)::value; dst[m] = nt_load2(gin + m * 128u); });
-            else static_for<0, E / 2>([&](auto mc) { constexpr int m = decltype(mc)::value; dst[m] = *reinterpret_cast<const ulonglong2*>(gin + m * 128u); });
-        }
-    };
-    unsigned bid = blockIdx.x;
-    if (bid < total) fetch(bid, cur);
-    for (; bid < total; bid += gridDim.x) {
-        const unsigned nb = bid + gridDim.x;
-        auto pf = [&] { if (nb < total) fetch(nb, nxt); };
-        ntt_pass_body<A, LOGN, 0, LOGN, LOGN, EB, true, true, true, false, IOM, 0, false, false, decltype(pf)>(a, nullptr, lds, bid, t, nullptr, cur, pf);
-        __syncthreads();      // the next tile's first exchange overwrites words other waves read in this tile's last rounds
-        static_for<0, NP>([&](auto ic) { cur[decltype(ic)::value] = nxt[decltype(ic)::value]; });
-    }
 }
 
 // Tensor product of two 2-component ciphertexts between the transforms (BEHZ steps (3)-(5), evaluator.cu:56-93): one workgroup takes

@@ -26,35 +26,12 @@ namespace troyn {
 // steps (ntt_pass_body: an opaque zero derived from the previous layer's result enters the table index, so the loads cannot be hoisted;
 // scratch 68 -> 12 bytes, NTT + dyadic + INTT +2 %) and is on by default (mask 0x0127); the fused chain's MULPAIR / LAST_LIMB variants still
 // spill 64 / 108 bytes in their loaders and stay on full-word tiles.  TROYN_NTT_HALF=<mask> (bit (INV ? 8 : 0) + IOM) selects variants for A/B runs.
-// workgroups of a persistent launch: one per CU of the current device
-static unsigned ntt_pf_grid() {
-    static thread_local int cached_dev = -1;
-    static thread_local unsigned cached = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev != cached_dev) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached = (unsigned)cus; cached_dev = dev;
-    }
-    return cached;
-}
-
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
         const char* e = getenv("TROYN_NTT_HALF");   // bit (INV ? 8 : 0) + IOM selects the variant; read per launch so that the suite runs every variant
         const int half = e ? (int)strtol(e, nullptr, 0) : 0x0127;
         if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
-    }
-    if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0 && INV && FIRST && LAST && (IOM == 0 || IOM == NTT_FUSED_MULPAIR || IOM == NTT_FUSED_LAST_LIMB)) {
-        // full-word inverse tiles (one workgroup per CU): persistent workgroups that request the next tile's rows from inside the current
-        // transform (ntt_inv_pf_kernel).  TROYN_NTT_PF=0 keeps one workgroup per tile (A/B runs, tests of that path).
-        const char* pe = getenv("TROYN_NTT_PF");
-        if (!(pe && pe[0] == '0') && a.xcd_groups == 0 && extra_lds == 0 && grid.x > ntt_pf_grid()) {
-            hipLaunchKernelGGL((ntt_inv_pf_kernel<A, LOGN, EB, IOM>), dim3(ntt_pf_grid()), block, 0, s, a, grid.x);
-            return;
-        }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
 }
