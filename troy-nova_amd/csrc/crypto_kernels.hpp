@@ -281,7 +281,10 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac_kernel(unsigned chunks, 
 // once for the PC polynomials (the first kernel read it once per polynomial, from different workgroups), bypasses the caches for
 // it (the ciphertext words are re-read by every destination of the group and should stay cached), and has the loads of four
 // terms in flight before their multiply-accumulates start.
-template <int PC>
+// PACKED (layout experiment, tools/plain_mac_ab.py; TROYN_PLAIN_MAC=packed): the weights of a destination are ONE block [limb][chunk of 512 words][term][512]
+// whose base is the plaintext pointer of the group's first term, so a workgroup's 4 KiB touches of T different plaintexts become one contiguous
+// stream of T x 4 KiB.  Not the reference's object layout (a Plain2d is a vector of stand-alone plaintexts): measured, profiles/r04_plain_mac_ab.txt.
+template <int PC, bool PACKED = false>
 __global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
                                                                 const u64* tab, unsigned count, unsigned groups, int set_zero) {
     const unsigned row = blk_row(chunks);
@@ -312,10 +315,14 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks,
             }
         };
         unsigned k = k0, pending = 0;
+        // packed weights: word (k, l, i) of the group at base + ((l * n/512 + i/512) * T + (k - k0)) * 512 + i % 512; expressed as a per-term pointer
+        // so that the loads below stay `pw + loff + i`
+        const u64* const wpk = PACKED ? pts[k0] + ((size_t)(l * (n >> 9) + (i >> 9)) * (k1 - k0)) * 512u + (i & 511u) - (loff + i) : nullptr;
+        auto wptr = [&](unsigned kk) -> const u64* { return PACKED ? wpk + (size_t)(kk - k0) * 512u : pts[kk]; };
         // the operand pointers of the next four terms are fetched (scalar loads) while this iteration's words are in flight
         const u64 *pw[4], *pc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const unsigned kk = k + u < k1 ? k + u : k1 - 1; pw[u] = pts[kk]; pc[u] = cts[kk]; }
+        for (int u = 0; u < 4; ++u) { const unsigned kk = k + u < k1 ? k + u : k1 - 1; pw[u] = wptr(kk); pc[u] = cts[kk]; }
         for (; k + 4 <= k1; k += 4) {
             u64x2 w[4], c[4][PC];
 #pragma unroll
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks,
                 for (int p = 0; p < PC; ++p) c[u][p] = ld2(pc[u] + p * pstride + loff + i);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const unsigned kk = k + 4 + u < k1 ? k + 4 + u : k1 - 1; pw[u] = pts[kk]; pc[u] = cts[kk]; }
+            for (int u = 0; u < 4; ++u) { const unsigned kk = k + 4 + u < k1 ? k + 4 + u : k1 - 1; pw[u] = wptr(kk); pc[u] = cts[kk]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks,
             if (pending == 32) { fold(); pending = 0; }
         }
         for (; k < k1; ++k) {
-            const u64x2 w = ldw(pts[k] + loff + i);
+            const u64x2 w = ldw(wptr(k) + loff + i);
 #pragma unroll
             for (int p = 0; p < PC; ++p) {
                 const u64x2 c = ld2(cts[k] + p * pstride + loff + i);

@@ -2250,6 +2250,10 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
         const size_t rows2 = groups * nmod;
         if (int rc = check_rows(rows2, ch)) return rc;
         TimerScope ts(TROYN_TIMER_PLAIN_MAC, s);
+        if (env_is("TROYN_PLAIN_MAC", "packed"))      // layout experiment (tools/plain_mac_ab.py): pt[first term of a destination] = base of its packed block
+            hipLaunchKernelGGL((plain_mac2_kernel<2, true>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
+                               ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
+        else
         hipLaunchKernelGGL((plain_mac2_kernel<2>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
         LAUNCH_CHECK();
