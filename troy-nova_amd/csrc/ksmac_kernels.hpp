@@ -317,7 +317,15 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
     // (WIDE: a chain with limbs of 2^50 and more -- the digit of such a limb is reduced with integer arithmetic first, Modulus::reduce)
     auto dig_in = [&](u64 raw) -> double {
         if constexpr (DIGF64) return f64_bits_to_double(raw);
-        else if constexpr (WIDE) return f64_from_u64(barrett64(raw, dm.q, dm.ratio_hi));
+        else if constexpr (WIDE) {
+            // raw < 2^61 = hi 2^30 + lo.  hi 2^30 is exact in a double (31 significant bits), so (hi 2^30 mod p) comes out of one quotient estimate and
+            // one exact fma; the result is raw mod p up to sign, |.| <= p/2 + 2^30 -- every consumer below re-centres.  Round 3 reduced the word with
+            // Modulus::reduce (64-bit integer multiplies): 376 / 396 bytes of scratch per lane at N = 16384 / 32768, the temporaries of 64 reductions
+            // in flight next to the load window.
+            const double h = (double)(unsigned)(raw >> 30) * 1073741824.0;
+            const double lo = (double)((unsigned)raw & 0x3fffffffu);
+            return __builtin_fma(-__builtin_rint(h * inv_p), p, h) + lo;
+        }
         else return f64_from_u64(raw);
     };
 
