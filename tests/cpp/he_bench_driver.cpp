@@ -6,7 +6,7 @@
 //     multiply_relinearize_rescale_batched;  1 and 4 host threads (the tool's -c option), every thread with its own operands.
 // Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
 // decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
-//   he_bench_driver [check|bench|threads] [repeat]
+//   he_bench_driver [check|bench|threads|single] [repeat]
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -44,7 +44,8 @@ static bool same_ct(const Ciphertext& a, const Ciphertext& b) {
 
 int main(int argc, char** argv) {
     const bool threads_only = argc > 1 && std::strcmp(argv[1], "threads") == 0;      // only the N-thread single-object sweep
-    const bool bench = threads_only || (argc > 1 && std::strcmp(argv[1], "bench") == 0);
+    const bool single_only = argc > 1 && std::strcmp(argv[1], "single") == 0;        // only the one-thread single-object loops (profiling)
+    const bool bench = threads_only || single_only || (argc > 1 && std::strcmp(argv[1], "bench") == 0);
     const size_t repeat = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 20;
     try {
         const size_t n = 16384;
@@ -144,6 +145,7 @@ int main(int argc, char** argv) {
             std::printf("single_%s_us_per_op %.2f\n", fused ? "fused" : "three_calls", dt / reps * 1e6);
         }
 
+        if (single_only) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
         // ---- single objects from N host threads: the reference tool's -c N mode (he_operations.cu:85, :364-380: N threads, each on its own
         // stream, sharing context and keys; the reference has NO batched multiply / relinearize / rescale, :119-135, so this is what an
         // unmodified caller gets).  Every thread owns its operands; the three calls of an op are queued without a synchronisation in between

@@ -26,11 +26,28 @@ namespace troyn {
 // steps (ntt_pass_body: an opaque zero derived from the previous layer's result enters the table index, so the loads cannot be hoisted;
 // scratch 68 -> 12 bytes, NTT + dyadic + INTT +2 %) and is on by default (mask 0x0127); the fused chain's MULPAIR / LAST_LIMB variants still
 // spill 64 / 108 bytes in their loaders and stay on full-word tiles.  TROYN_NTT_HALF=<mask> (bit (INV ? 8 : 0) + IOM) selects variants for A/B runs.
+// CUs of the current device (cached per host thread)
+static unsigned ntt_cu_count() {
+    static thread_local int cached_dev = -1;
+    static thread_local unsigned cached = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached = (unsigned)cus; cached_dev = dev;
+    }
+    return cached;
+}
+
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
         const char* e = getenv("TROYN_NTT_HALF");   // bit (INV ? 8 : 0) + IOM selects the variant; read per launch so that the suite runs every variant
-        const int half = e ? (int)strtol(e, nullptr, 0) : 0x0127;
+        // half-word tiles buy a second workgroup per CU at the price of three barriers per exchange: with no more workgroups than CUs there is
+        // nobody to share the CU with and the full-word tile is the faster one (a single ciphertext: three calls 174 -> 154 us per op); an
+        // explicit TROYN_NTT_HALF is obeyed at every size
+        const int half = e ? (int)strtol(e, nullptr, 0) : (grid.x > ntt_cu_count() ? 0x0127 : 0);
         if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
