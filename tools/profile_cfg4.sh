@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel trace of the cfg4 workload (BFV N = 32768 L = 10 multiply + relinearize, 256 ops in chunks of 64) -> gpurun_out/<tag>_summary.txt
 set -e
-TAG=${1:-r03_cfg4}
+TAG=${1:-r04_cfg4}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
