@@ -630,10 +630,13 @@ static bool ksmac_split_wanted(size_t batch, unsigned L, unsigned log_n) {
     const int e = env_int("TROYN_KS_SPLIT", -1);
     if (e == 0 || L < 2 || log_n < 13 || log_n > 15) return false;
     const size_t wgs = batch * (L + 1) << (log_n - 13);
-    if (batch > 64) return false;                      // the slots are provisioned for small batches only (ks_split_words)
+    if (batch > 64) return false;                      // small batches only (the slots cost L times the inner product's output)
     return e == 1 || wgs <= 128;
 }
-static size_t ks_split_words(size_t batch, unsigned L, size_t n) { return batch <= 64 ? batch * L * 2 * (size_t)(L + 1) * n : 0; }
+// slots of the digit-parallel form: provisioned exactly when a call of this shape would take it (both read the same switch)
+static size_t ks_split_words(size_t batch, unsigned L, unsigned log_n) {
+    return ksmac_split_wanted(batch, L, log_n) ? batch * L * 2 * (size_t)(L + 1) * ((size_t)1 << log_n) : 0;
+}
 
 struct KsLayout {
     size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, total;  // element offsets
@@ -649,7 +652,7 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
     w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
-    w.split = off;       off += ks_split_words(batch, L, n);                        // slots of the digit-parallel inner product (small batches)
+    w.split = off;       off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     w.total = off;
     return w;
 }
@@ -1024,7 +1027,7 @@ static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
     w.spec_intt = off; off += batch * 2 * n;
     w.last_intt = off; off += batch * 2 * n;
     w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys + the diagonal blocks in natural order
-    w.split = off;     off += ks_split_words(batch, L, n);                        // slots of the digit-parallel inner product (small batches)
+    w.split = off;     off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     w.fast_total = off;
     // composition of the three public calls (any other shape)
     off = 0;
