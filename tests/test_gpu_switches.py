@@ -4,6 +4,7 @@
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
   TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
+  TROYN_KS_MAC_SHOUP=0      integer inner product with Barrett-128 terms (default: the keys' Shoup quotients are prepared once per call, lazy Shoup terms)
   TROYN_KS_SPLIT=0 | 1      digit-parallel form of the inner product (one workgroup per digit + a reducer) off / forced on (default: on when the
                             launch would occupy at most half of the chip -- the batches of 8 used below take it, so "0" is the other side here)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
@@ -27,12 +28,12 @@ def _case(O, pkg, dev, n, bits, L, batch=8):
 
 @pytest.mark.parametrize("env", [{}, {"TROYN_KS_MAC": "v1"}, {"TROYN_KS_MAC": "split"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_ARITH": "u64"},
                                  {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}, {"TROYN_KS_DIAG": "loop"}, {"TROYN_KS_SPLIT": "0"}, {"TROYN_KS_SPLIT": "1"},
-                                 {"TROYN_KS_SPLIT": "0", "TROYN_KS_DIAG": "loop"}],
+                                 {"TROYN_KS_SPLIT": "0", "TROYN_KS_DIAG": "loop"}, {"TROYN_NTT_ARITH": "u64", "TROYN_KS_MAC_SHOUP": "0"}],
                          ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none", "ks_diag_in_loop",
-                              "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_diag_in_loop"])
+                              "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_diag_in_loop", "integer_inner_product_barrett_terms"])
 @pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [40, 40, 40, 40], 3)])
 def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L):
-    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG", "TROYN_KS_SPLIT"):
+    for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG", "TROYN_KS_SPLIT", "TROYN_KS_MAC_SHOUP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -51,6 +51,8 @@ struct NttArgs {
     long long key_pstride;         // ks_mac_kernel: elements between the two polynomials of a key (K*N)
     unsigned long long ks_row_mask; // ks_mac_kernel: 0 = all decomp + 1 output rows; else the launch covers the rows whose bit is set (mixed chains:
                                    // the rows of moduli >= 2^50 take this kernel, the others ksmac2_kernel)
+    const u64* key_quo;            // ks_mac_kernel, integer policy: Shoup quotients floor(key 2^64 / q) of the keys, [j][2][K][N] (ks_key_quotients_kernel);
+    long long key_quo_jstride;     // non-null: <digit, key> terms are lazy Shoup products instead of Barrett-128 reductions (elements between keys j)
     // ---- fused multiply -> relinearize -> rescale chain (IOM 3..5, NttFused below) ----
     const u64* mul_a; const u64* mul_b;       // the two input ciphertexts [item][2][limbs][N] (NTT form)
     long long mul_bstride, mul_pstride;       // element strides: item, polynomial (limb stride = N)
@@ -341,7 +343,13 @@ struct ArithU64 {
         acc = add_mod(acc, barrett128(v * key, mul_hi(v, key), m.q, m.ratio_lo, m.ratio_hi), m.q);
     }
     static __device__ __forceinline__ void mac_fix(elem&, const Mod&) {}
-    static __device__ __forceinline__ u64 mac_final(elem acc, const Mod&) { return acc; }
+    static __device__ __forceinline__ u64 mac_final(elem acc, const Mod& m) { return final_fwd(acc, m); }     // canonical stays canonical; the Shoup form leaves [0, 4q)
+    // the same term with the key's Shoup quotient kq = floor(key 2^64 / q) (exact): a lazy product in [0, 4q) on a lazy sum in [0, 4q)
+    // (8q < 2^64) -- 3 + 2 multiplier instructions instead of the 4 + ~12 of a 128-bit product and its Barrett reduction
+    static constexpr bool HAS_MAC_SHOUP = true;
+    static __device__ __forceinline__ void mac_shoup(elem& acc, elem v, u64 key, u64 kq, const Mod& m) {
+        acc = csub4(acc + shoup_lazy3(v, key, kq, m.neg_q), m);
+    }
     static __device__ __forceinline__ tw_t tw_from_mem(const tw_mem v, const Mod&) { return make_ulonglong2(v.x, v.y); }
     static __device__ __forceinline__ elem load_first(u64 raw, bool reduce, const Mod& m) { return reduce ? barrett64(raw, m.q, m.ratio_hi) : raw; }
     // fused prologue / epilogue (NttLoad / NttStore): integer forms of the reference kernels
@@ -384,6 +392,7 @@ struct ArithU64 {
 };
 
 struct ArithF64 {
+    static constexpr bool HAS_MAC_SHOUP = false;
     using elem = double;
     using tw_t = double2;
     using tw_mem = double;        // only w is stored (8 bytes per twiddle); w/p is rebuilt as w * fl(1/p)
@@ -627,6 +636,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     elem x[E];
     elem acc0[KSMAC ? E : 1], acc1[KSMAC ? E : 1];
     const u64* __restrict__ key0 = nullptr;   // this iteration's key, component 0, limb mi
+    const u64* __restrict__ kq0 = nullptr;    // its Shoup quotients (NttArgs::key_quo), or null
     if constexpr (KSMAC) {
         static_for<0, E>([&](auto Rc) { acc0[decltype(Rc)::value] = A::mac_zero(); acc1[decltype(Rc)::value] = A::mac_zero(); });
     }
@@ -642,6 +652,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
         twc = (ctw_ptr)(((unsigned long long)tw_hi << 32) | tw_lo);
         gin = gin0 + (long long)it * a.in_cstride;
         key0 = keys->p[it] + (size_t)(mi - a.table_start) * N;
+        kq0 = a.key_quo ? a.key_quo + (long long)it * a.key_quo_jstride + (size_t)(mi - a.table_start) * N : nullptr;
         if (a.skip_diag && it == k) {
             // own digit: already in NTT form under this modulus; read it in the accumulators' (transposed) layout
             const unsigned lane = t & 63u, wbase = (t >> 6) * (64u * E);
@@ -653,6 +664,13 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(key0 + idx);
                 const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(key0 + a.key_pstride + idx);
                 const elem v0 = A::mac_in(v.x, md), v1 = A::mac_in(v.y, md);
+                if constexpr (A::HAS_MAC_SHOUP) { if (kq0) {
+                    const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(kq0 + idx), q1 = *reinterpret_cast<const ulonglong2*>(kq0 + a.key_pstride + idx);
+                    A::mac_shoup(acc0[2 * m], v0, k0.x, q0.x, md); A::mac_shoup(acc0[2 * m + 1], v1, k0.y, q0.y, md);
+                    A::mac_shoup(acc1[2 * m], v0, k1.x, q1.x, md); A::mac_shoup(acc1[2 * m + 1], v1, k1.y, q1.y, md);
+                    __builtin_amdgcn_sched_barrier(0);
+                    return;
+                } }
                 A::mac(acc0[2 * m], v0, k0.x, md); A::mac(acc0[2 * m + 1], v1, k0.y, md);
                 A::mac(acc1[2 * m], v0, k1.x, md); A::mac(acc1[2 * m + 1], v1, k1.y, md);
                 __builtin_amdgcn_sched_barrier(0);   // keep the key loads of later pairs from piling up in registers
@@ -868,6 +886,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             const u64* kp0 = key0 + wbase + lane * 2u;
             const u64* kp1 = kp0 + a.key_pstride;
             ulonglong2 kc0 = *reinterpret_cast<const ulonglong2*>(kp0), kc1 = *reinterpret_cast<const ulonglong2*>(kp1);
+            // Shoup quotients of the same words (integer policy, NttArgs::key_quo): pipelined like the keys
+            const bool shoup = A::HAS_MAC_SHOUP && kq0 != nullptr;
+            const u64* qp0 = shoup ? kq0 + wbase + lane * 2u : kp0;
+            const u64* qp1 = qp0 + a.key_pstride;
+            ulonglong2 qc0 = make_ulonglong2(0, 0), qc1 = make_ulonglong2(0, 0);
+            if constexpr (A::HAS_MAC_SHOUP) { if (shoup) { qc0 = *reinterpret_cast<const ulonglong2*>(qp0); qc1 = *reinterpret_cast<const ulonglong2*>(qp1); } }
             static_for<0, E>([&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 lds[pown + R] = A::mac_to_lds(x[R], md);
@@ -875,15 +899,27 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
             __builtin_amdgcn_wave_barrier();
             static_for<0, E / 2>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                ulonglong2 kn0 = kc0, kn1 = kc1;
+                ulonglong2 kn0 = kc0, kn1 = kc1, qn0 = qc0, qn1 = qc1;
                 if constexpr (m + 1 < E / 2) {
                     kn0 = *reinterpret_cast<const ulonglong2*>(kp0 + (m + 1) * 128u);
                     kn1 = *reinterpret_cast<const ulonglong2*>(kp1 + (m + 1) * 128u);
+                    if constexpr (A::HAS_MAC_SHOUP) { if (shoup) {
+                        qn0 = *reinterpret_cast<const ulonglong2*>(qp0 + (m + 1) * 128u);
+                        qn1 = *reinterpret_cast<const ulonglong2*>(qp1 + (m + 1) * 128u);
+                    } }
                 }
                 const elem v0 = A::from_lds(lds[pidx + lds_off(m * 128u)]), v1 = A::from_lds(lds[pidx + lds_off(m * 128u) + 1]);
-                A::mac(acc0[2 * m], v0, kc0.x, md); A::mac(acc0[2 * m + 1], v1, kc0.y, md);
-                A::mac(acc1[2 * m], v0, kc1.x, md); A::mac(acc1[2 * m + 1], v1, kc1.y, md);
-                kc0 = kn0; kc1 = kn1;
+                bool done = false;
+                if constexpr (A::HAS_MAC_SHOUP) { if (shoup) {
+                    A::mac_shoup(acc0[2 * m], v0, kc0.x, qc0.x, md); A::mac_shoup(acc0[2 * m + 1], v1, kc0.y, qc0.y, md);
+                    A::mac_shoup(acc1[2 * m], v0, kc1.x, qc1.x, md); A::mac_shoup(acc1[2 * m + 1], v1, kc1.y, qc1.y, md);
+                    done = true;
+                } }
+                if (!done) {
+                    A::mac(acc0[2 * m], v0, kc0.x, md); A::mac(acc0[2 * m + 1], v1, kc0.y, md);
+                    A::mac(acc1[2 * m], v0, kc1.x, md); A::mac(acc1[2 * m + 1], v1, kc1.y, md);
+                }
+                kc0 = kn0; kc1 = kn1; qc0 = qn0; qc1 = qn1;
                 __builtin_amdgcn_sched_barrier(0);   // keep the key loads of later pairs from piling up in registers
             });
             // the next digit's first exchange overwrites every wave's slice

@@ -605,6 +605,23 @@ extern "C" int troyn_dyadic_square(const troyn_plan* p, uint32_t mod_start, uint
 // ---------------------------------------------------------------------------------------
 // key switching
 // ---------------------------------------------------------------------------------------
+// Shoup quotients of the evaluation keys for the integer inner product (ks_mac_kernel<ArithU64>, NttArgs::key_quo):
+// out[j][row][i] = floor(keys[j][row][i] * 2^64 / q_row), EXACT (estimate from the Barrett ratio, corrected with the 128-bit remainder), so
+// that a <digit, key> term is a lazy Shoup product in [0, 4q) instead of a 128-bit product and its Barrett reduction.  Once per call.
+static __global__ __launch_bounds__(256) void ks_key_quotients_kernel(KeyPtrs keys, unsigned L, unsigned K, unsigned n, const DevModulus* mods, u64* out) {
+    const size_t per_key = (size_t)2 * K * n, total = (size_t)L * per_key;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const unsigned j = (unsigned)(p / per_key);
+        const size_t w = p % per_key;
+        const DevModulus md = mods[(w / n) % K];
+        const u64 k = keys.p[j][w];
+        u64 e = k * md.ratio_hi + mul_hi(k, md.ratio_lo);            // floor(k floor(2^128/q) / 2^64): the quotient or up to two below it (k < q)
+        u128 rem = ((u128)k << 64) - (u128)e * md.q;
+        while (rem >= md.q) { ++e; rem -= md.q; }
+        out[p] = e;
+    }
+}
+
 // workgroup order of ksmac2_kernel (TROYN_KS_ORDER=plain|item|row|band):
 //   0 plain: workgroups of an item dealt round-robin to the XCDs
 //   1 item:  all workgroups of an item on one XCD (digits L2-resident, keys from the Infinity Cache)
@@ -639,7 +656,7 @@ static size_t ks_split_words(size_t batch, unsigned L, unsigned log_n) {
 }
 
 struct KsLayout {
-    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, total;  // element offsets
+    size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, keys_quo, total;  // element offsets
 };
 
 static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
@@ -653,6 +670,8 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
     w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
     w.split = off;       off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
+    // Shoup quotients of the keys for the integer inner product: chains with a modulus of 2^50 or more on the whole-limb sizes
+    w.keys_quo = off;    off += (p->log_n >= 10 && p->log_n <= 14 && !use_f64(p, 0, p->K)) ? (size_t)L * 2 * p->K * n : 0;
     w.total = off;
     return w;
 }
@@ -797,6 +816,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
+        if (!f64 && !env_is("TROYN_KS_MAC_SHOUP", "0")) {
+            // integer policy: the keys' Shoup quotients, once per call (TROYN_KS_MAC_SHOUP=0: Barrett-128 terms as in rounds 1-3; A/B, tests)
+            u64* kq = ws + w.keys_quo;
+            const size_t words = (size_t)L * 2 * K * n;
+            hipLaunchKernelGGL(ks_key_quotients_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 4096)), dim3(256), 0, s, kp, L, K, n, p->d_mods, kq);
+            LAUNCH_CHECK();
+            a.key_quo = kq; a.key_quo_jstride = 2ll * K * n;
+        }
         if (mixed) a.ks_row_mask = wide_rows;
         const size_t mac_rows = mixed ? (size_t)__builtin_popcountll(wide_rows) : (size_t)(L + 1);
         if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * mac_rows, s);
