@@ -708,7 +708,8 @@ def run_cfg5(args, torch, pkg, entry, device):
                           ms["pack"] + ms["add_bias"] + ms["outputs_wire"] + rep["decrypt"])
             res.update({"value": round(steady, 3), "end_to_end_ms": round(end_to_end, 3),
                         "end_to_end_definition": "value + encode_weights + encode_bias (done once per model by a server) + inputs_wire + outputs_wire (save / load of the "
-                                                 "ciphertexts that cross the client / server boundary); all at steady state",
+                                                 "ciphertexts that cross the client / server boundary); encrypt / decrypt at their steady state, the encodings and the wire phases as the driver "
+                                                 "measured them once (first use of the pool: they include its hipMalloc calls)",
                         "config": {"workload": "y = x*w + s, 512x512x512 over Z_{2^21}, MatmulHelper block %s, %s; encrypted inputs x plaintext weights, mod-switched and "
                                                "LWE-packed outputs" % ("x".join(lines["block"][:3]), " ".join(lines["objects"])),
                                    "phases_ms": ms, "steady_state_ms": rep, "first_call_latency_ms": round(first, 3),
