@@ -129,8 +129,10 @@ int main(int argc, char** argv) {
 
         // ---- single objects (the tool's loop: every call followed by a stream synchronisation) -----------------------------------------
         for (int fused = 0; fused < 2 && !threads_only; fused++) {
-            const size_t reps = 200;
-            for (size_t i = 0; i < 10; i++) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, w.rk); }
+            const size_t reps = 400;
+            // the clocks need 20-25 ms of load to come up after an idle gap (tools/ramp_probe.py): 50 ms of the loop's own work first.  Rounds 3
+            // and earlier warmed up with 10 calls (~1.5 ms) and timed 200 ops, i.e. mostly the ramp.
+            for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05;) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, w.rk); troyn_sync_current_stream(); }
             troyn_sync_current_stream();
             auto t0 = clk::now();
             for (size_t i = 0; i < reps; i++) {

@@ -4,6 +4,7 @@
   TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
   TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
+  TROYN_NTT_SMALL_TWO_PASS=0  N = 16384 launches of a few limbs keep the whole-limb tile (default: the two-pass form of the larger rings, 4 workgroups per limb)
   TROYN_KS_MAC_SHOUP=0      integer inner product with Barrett-128 terms (default: the keys' Shoup quotients are prepared once per call, lazy Shoup terms)
   TROYN_KS_SPLIT=0 | 1      digit-parallel form of the inner product (one workgroup per digit + a reducer) off / forced on (default: on when the
                             launch would occupy at most half of the chip -- the batches of 8 used below take it, so "0" is the other side here)
@@ -203,3 +204,33 @@ def test_digit_parallel_inner_product(O, pkg, dev, monkeypatch, split, scheme, n
     got = pkg.to_host(dd)
     for i in sorted({0, batch // 2, batch - 1}):
         assert np.array_equal(got[i], ctx.switch_key(L, ntt_form, tg[i], keys, assign=pkg.ASSIGN_ADD_INPLACE, dest=d0[i])), (split, i)
+
+
+@pytest.mark.parametrize("two_pass", ["1", "0"])
+@pytest.mark.parametrize("bits", [[50] * 6, [60, 50, 50, 50, 50, 60]])
+def test_small_launches_at_n16384(O, pkg, dev, monkeypatch, two_pass, bits):
+    """a single N = 16384 ciphertext: its transforms are launches of 2 - 10 limb-polynomials, which take the two-pass kernels (4 workgroups per limb and pass)
+    instead of one whole-limb workgroup per limb; TROYN_NTT_SMALL_TWO_PASS=0 is the other side.  Plain transforms (both directions, FP64 and mixed
+    arithmetic classes), the separate key switch and the fused chain against the oracle."""
+    monkeypatch.setenv("TROYN_NTT_SMALL_TWO_PASS", two_pass)
+    n, L = 16384, 5
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("ckks", n, q)
+    plan = pkg.Plan(dev, 14, q)
+    keys = ctx.random_keys(3, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    a = ctx.random_ct(11, 2, L)
+    b = ctx.random_ct(29, 2, L)
+    da, db = pkg.to_device(a[None], dev), pkg.to_device(b[None], dev)
+    # forward / inverse round trip and the oracle's transform
+    f = plan.ntt(da, 2, L)
+    assert np.array_equal(pkg.to_host(f)[0], ctx.to_ntt(a, 2, L))
+    assert np.array_equal(pkg.to_host(plan.ntt(f, 2, L, inverse=True))[0], a)
+    # separate calls and the fused chain
+    e = ctx.relinearize(L, True, ctx.ckks_multiply(L, a, b), keys)
+    prod = plan.dyadic_convolute(da, 2, db, 2, L)
+    relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
+    assert np.array_equal(pkg.to_host(relin)[0], e)
+    want = ctx.mod_switch_scale_to_next(L, e)
+    assert np.array_equal(pkg.to_host(plan.divide_and_round_q_last_ntt(L, relin, 2))[0], want)
+    assert np.array_equal(pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys))[0], want)

@@ -69,6 +69,14 @@ struct KsMacArgs {
     // canonical words.  split_skip_diag: slot js == k of a data row k is not produced (the reducer forms that term itself).
     double* part; long long part_jstride;
     unsigned split_skip_diag;
+    // The digit-parallel form reads the caller's keys AS THEY ARE (u64 [2][K][N] per digit, KSwitchKeys layout): with a handful of items a key word is
+    // used once or twice, so converting all of them first (ksmac_prepare_keys_kernel: 7 us + a launch for 16 MB of traffic at cfg3) costs more than
+    // converting the words a workgroup actually touches.  raw_pstride = K N.  The digit is crossed to the coalesced layout before the
+    // multiply-accumulate (one exchange through the wave's slice, the one the epilogue no longer needs).  split_scale (fused chain): Shoup pairs of
+    // qk^-1 mod q_r for the data rows -- applied by the reducer to the slot sum instead of to every key word.
+    KeyPtrs raw;
+    long long raw_pstride;
+    const ulonglong2* split_scale;
 };
 
 constexpr int KSM_TB = 13;                  // tile bits
@@ -528,6 +536,36 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         KSM_MARK(5);
         }
         // ---- multiply-accumulate with key `it` straight from the registers ---------------------------------------
+        if constexpr (SPLITJ) {
+            // digit-parallel form: cross the digit to the coalesced layout (register pair m <-> words m*128 + lane*2 of the wave's 2048), then
+            // the caller's own key words, 16 bytes per lane, converted on the fly; the accumulators stay in that layout for the store
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                *reinterpret_cast<double2*>(&lds[p2 + 2 * m]) = make_double2(f64_corr(x[2 * m], fm), f64_corr(x[2 * m + 1], fm));
+            });
+            const u64* k0 = ksm_uniform(a.raw.p[it] + (size_t)mrow * N + (size_t)h * (KSM_THREADS * 32));
+            const u64* k1 = ksm_uniform(k0 + a.raw_pstride);
+            constexpr int AHEAD = 4;
+            ulonglong2 y0[16], y1[16];
+            static_for<0, AHEAD>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                y0[m] = ksm_gload<ulonglong2>(k0 + m * 128, slice_off);
+                y1[m] = ksm_gload<ulonglong2>(k1 + m * 128, slice_off);
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m + AHEAD < 16) {
+                    y0[m + AHEAD] = ksm_gload<ulonglong2>(k0 + (m + AHEAD) * 128, slice_off);
+                    y1[m + AHEAD] = ksm_gload<ulonglong2>(k1 + (m + AHEAD) * 128, slice_off);
+                }
+                const double2 v = *reinterpret_cast<const double2*>(&lds[pt + ksm_phys(m * 128u)]);      // re-centred when it was written
+                mac2(acc0[2 * m], acc1[2 * m], v.x, f64_from_u64(y0[m].x), f64_from_u64(y1[m].x));
+                mac2(acc0[2 * m + 1], acc1[2 * m + 1], v.y, f64_from_u64(y0[m].y), f64_from_u64(y1[m].y));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        } else
         mac_all(x, it);
         KSM_MARK(6);
         if ((step & 7u) == 7u)
@@ -657,15 +695,22 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
             if constexpr (m + W < 16) request(std::integral_constant<int, m + W>{});
         });
     } }
-    if constexpr (SPLITJ) go = reinterpret_cast<u64*>(a.part) + (long long)split_js * a.part_jstride + (go - a.out);      // slot js, same place inside it
+    if constexpr (SPLITJ) {
+        // slot js, same place inside it; the accumulators are in the coalesced layout already
+        go = reinterpret_cast<u64*>(a.part) + (long long)split_js * a.part_jstride + (go - a.out);
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + m * 128, slice_off))), f64_double_to_bits(f64_corr(acc0[2 * m], fm)), f64_double_to_bits(f64_corr(acc0[2 * m + 1], fm)));
+            nt_store2(reinterpret_cast<u64*>(const_cast<char*>(at(go + a.out_pstride + m * 128, slice_off))), f64_double_to_bits(f64_corr(acc1[2 * m], fm)), f64_double_to_bits(f64_corr(acc1[2 * m + 1], fm)));
+        });
+        return;
+    }
     if (!ten_row)
     static_for<0, 2>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            ulonglong2 v;
-            if constexpr (SPLITJ) v = make_ulonglong2(f64_double_to_bits(f64_corr(c ? acc1[2 * m] : acc0[2 * m], fm)), f64_double_to_bits(f64_corr(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm)));
-            else v = make_ulonglong2(f64_canon(c ? acc1[2 * m] : acc0[2 * m], fm), f64_canon(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm));
+            const ulonglong2 v = make_ulonglong2(f64_canon(c ? acc1[2 * m] : acc0[2 * m], fm), f64_canon(c ? acc1[2 * m + 1] : acc0[2 * m + 1], fm));
             *reinterpret_cast<ulonglong2*>(&lds[p2 + 2 * m]) = v;
         });
         __builtin_amdgcn_wave_barrier();
@@ -716,8 +761,10 @@ __global__ __launch_bounds__(256) void ksmac_split_reduce_kernel(KsMacArgs a, un
         a1 += __builtin_fma(-q1, p, h1) + l1;
     };
     if (data_row) {
-        const double* dk = a.diag_keys + (size_t)k * 2 * n + i;
-        const double2 y0 = *reinterpret_cast<const double2*>(dk), y1 = *reinterpret_cast<const double2*>(dk + n);
+        // the diagonal digit's key block (key k, modulus k) straight from the caller's keys
+        const u64* dk = a.raw.p[k] + (size_t)k * n + i;
+        const ulonglong2 r0 = *reinterpret_cast<const ulonglong2*>(dk), r1 = *reinterpret_cast<const ulonglong2*>(dk + a.raw_pstride);
+        const double2 y0 = make_double2(f64_from_u64(r0.x), f64_from_u64(r0.y)), y1 = make_double2(f64_from_u64(r1.x), f64_from_u64(r1.y));
         if constexpr (EPI == 1) {
             const size_t toff = (size_t)b * a.ten_bstride + (size_t)k * n + i;
             const ulonglong2 xa0 = *reinterpret_cast<const ulonglong2*>(a.ten_a + toff), xb0 = *reinterpret_cast<const ulonglong2*>(a.ten_b + toff);
@@ -727,6 +774,10 @@ __global__ __launch_bounds__(256) void ksmac_split_reduce_kernel(KsMacArgs a, un
             const double dx = f64_corr(f64_mulq(f64_corr(a1x, fm), b1x, inv_p, p), fm), dy = f64_corr(f64_mulq(f64_corr(a1y, fm), b1y, inv_p, p), fm);
             mac2(s0x, s1x, dx, y0.x, y1.x);
             mac2(s0y, s1y, dy, y0.y, y1.y);
+            // relinearize's division by the special prime on the whole inner product (the batched form carries qk^-1 in its prepared keys)
+            const double sc = f64_from_u64(a.split_scale[k].x);
+            s0x = f64_mulq(f64_corr(s0x, fm), sc, inv_p, p); s0y = f64_mulq(f64_corr(s0y, fm), sc, inv_p, p);
+            s1x = f64_mulq(f64_corr(s1x, fm), sc, inv_p, p); s1y = f64_mulq(f64_corr(s1y, fm), sc, inv_p, p);
             s0x += f64_mulq(a0x, b0x, inv_p, p);
             s0y += f64_mulq(a0y, b0y, inv_p, p);
             s1x += f64_mulq(a0x, b1x, inv_p, p) + f64_mulq(a1x, b0x, inv_p, p);

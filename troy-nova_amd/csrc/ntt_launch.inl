@@ -40,6 +40,8 @@ static unsigned ntt_cu_count() {
     return cached;
 }
 
+static bool ntt_small_two_pass_off() { const char* e = getenv("TROYN_NTT_SMALL_TWO_PASS"); return e && e[0] == '0'; }
+
 template <class A, int LOGN, int LO, int G, int TB, int EB, bool INV, bool FIRST, bool LAST, int IOM>
 static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra_lds, hipStream_t s) {
     if constexpr (std::is_same<A, ArithF64>::value && LOGN == 14 && TB == 14 && LO == 0) {
@@ -141,7 +143,13 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
         case 13: launch_single<A, 13, 3>(a, lp, inverse, s); return true;
 #endif
 #if TROYN_NTT_LARGE
-        case 14: launch_single<A, 14, 4>(a, lp, inverse, s); return true;
+        case 14:
+            // A whole-limb tile puts a 16384-point transform on ONE CU: 15-23 us however few limbs the launch has.  Launches that leave most
+            // of the chip idle (a single ciphertext: 2-10 limb-polynomials) take the two-pass form of the larger rings instead -- 4 workgroups
+            // per limb and pass, ~3x shorter; TROYN_NTT_SMALL_TWO_PASS=0 keeps the single pass (A/B runs, tests).  Results are the same words.
+            if (lp * 8 <= ntt_cu_count() && !ntt_small_two_pass_off()) launch_two_pass<A, 14, 12, 4>(a, lp, inverse, s, scratch);
+            else launch_single<A, 14, 4>(a, lp, inverse, s);
+            return true;
 #endif
 #if TROYN_NTT_LARGE
         case 15: launch_two_pass<A, 15, 12, 4>(a, lp, inverse, s, scratch); return true;

@@ -740,7 +740,9 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         // NTT-form target: the block (key j, modulus j) a second time in natural order -- the diagonal digit is applied in the kernel's
         // epilogue (DG).  The switch is read ONCE per call: the preparation and the instantiation choice must agree.
         const bool dg = is_ntt_form && !env_is("TROYN_KS_DIAG", "loop");
-        {
+        // the digit-parallel form (small launches) reads the caller's keys as they are: no preparation pass
+        const bool split = ksmac_split_wanted(batch, L, p->log_n) && (dg || !is_ntt_form);
+        if (!split) {
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
             const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
             launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, blocks, s, nullptr, nullptr, 0, dg ? kf + (size_t)L * 2 * K * n : nullptr);
@@ -758,10 +760,11 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.grouped = ksmac_order(batch, p->log_n);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-            if (ksmac_split_wanted(batch, L, p->log_n) && (dg || !is_ntt_form)) {
+            if (split) {
                 a.grouped = 0;
                 a.part = reinterpret_cast<double*>(ws + w.split); a.part_jstride = (long long)batch * a.out_bstride;
                 a.split_skip_diag = dg ? 1u : 0u;
+                a.raw = kp; a.raw_pstride = (long long)K * n;
                 launch_ksmac2_split(p->log_n, batch, a, s, false, dg ? 2 : 0);
             } else launch_ksmac2(p->log_n, batch, L + 1, a, s);
         }
@@ -1094,8 +1097,9 @@ static MrrStreams* mrr_streams(int device) {
 }
 
 // launches (1)-(5) of the fused chain for `batch` items whose intermediates live in `ws` (layout w); kf: the prepared keys
+// raw != nullptr: digit-parallel inner product on the caller's own keys (small launches; the workspace has its slots and kf was not prepared)
 static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b, const double* kf, u64* out, u64* ws, const MrrLayout& w,
-                     size_t batch, hipStream_t s, bool allow_split = true) {      // allow_split: the workspace has the slots of the digit-parallel form
+                     size_t batch, hipStream_t s, const KeyPtrs* raw = nullptr) {
     const unsigned K = p->K, n = p->n;
     int rc;
     const long long ct_b = 2ll * L * n, ct_p = (long long)L * n;           // strides of a, b
@@ -1122,10 +1126,11 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
         m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        if (allow_split && ksmac_split_wanted(batch, L, p->log_n)) {
+        if (raw) {
             m.grouped = 0;
             m.part = reinterpret_cast<double*>(ws + w.split); m.part_jstride = (long long)batch * pp_b;
             m.split_skip_diag = 1;
+            m.raw = *raw; m.raw_pstride = (long long)K * n; m.split_scale = p->d_inv_last + (size_t)K * K;
             launch_ksmac2_split(p->log_n, batch, m, s, true, 1);
         } else launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
     }
@@ -1197,9 +1202,14 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         if (!keys[j]) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null key pointer");
         kp.p[j] = (const u64*)keys[j];
     }
-    // keys prepared once per call (converted to exact doubles in the accumulators' layout), shared by every chunk
+    const int chunk_env = env_int("TROYN_MRR_CHUNK", 0);
+    size_t chunk = batch;
+    if (chunk_env > 0 && batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env;
+    // small launches: the digit-parallel inner product reads the caller's keys as they are
+    const bool split = chunk == batch && ksmac_split_wanted(batch, L, p->log_n);
+    // otherwise: keys prepared once per call (converted to exact doubles in the accumulators' layout), shared by every chunk
     double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
-    {
+    if (!split) {
         const size_t pairs = (size_t)L * 2 * K * (n / 2);
         // the rows of the data moduli carry the factor qk^-1: the inner product leaves ksmac2 as P qk^-1 (+ the tensor term, KsMacArgs::ten_a)
         launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s,
@@ -1214,16 +1224,16 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     // order; polynomials of a limb back to back) and a second chunk's kernels evict exactly those rows from the L2: one chunk on the
     // caller's stream is faster at every batch size measured (1024 items: 263.6 - 265.2 k vs 260.4 - 260.8 k ops/s with two halves,
     // 263.2 - 264.1 k with three thirds; 2048: 264.1 - 264.6 k vs 260.1 - 262.7 k; 512: 262.3 - 262.9 k vs 257.4 - 258.1 k) and is the default.
-    const int chunk_env = env_int("TROYN_MRR_CHUNK", 0);
     const int ns = std::min(std::max(env_int("TROYN_MRR_STREAMS", 2), 1), MRR_MAX_STREAMS);
-    size_t chunk = batch;
-    if (chunk_env > 0 && batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env;
-    if (chunk == batch) return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s);
+    if (chunk == batch) return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s, split ? &kp : nullptr);
     MrrStreams* ms = mrr_streams(p->device);
     if (!ms) return fail(TROYN_E_INVALID, std::string(P) + " cannot create the internal streams");
     const MrrLayout wc = mrr_layout(p, L, chunk);        // two chunk-sized workspaces side by side in the caller's workspace
     const size_t slot_words = wc.keys_f64;               // a chunk's intermediates end where its (unused) key area would start
-    if ((size_t)ns * slot_words > w.keys_f64) return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s);
+    if ((size_t)ns * slot_words > w.keys_f64) {
+        if (split) return fail(TROYN_E_INVALID, std::string(P) + " internal: chunk layout");      // unreachable: split implies one chunk
+        return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s);
+    }
     HIP_TRY(hipEventRecord(ms->fork, s));
     for (int q = 0; q < ns; q++) HIP_TRY(hipStreamWaitEvent(ms->s[q], ms->fork, 0));
     size_t done = 0, idx = 0;
@@ -1232,7 +1242,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         const size_t c = std::min(chunk, batch - done);
         const int q = (int)(idx % (size_t)ns);
         if ((rc = mrr_chain(p, L, a + done * 2 * (size_t)L * n, b + done * 2 * (size_t)L * n, kf, out + done * 2 * (size_t)(L - 1) * n,
-                            ws + (size_t)q * slot_words, wc, c, ms->s[q], false))) break;
+                            ws + (size_t)q * slot_words, wc, c, ms->s[q]))) break;
         done += c; idx++;
     }
     // join ALSO on an error: the chunks already queued keep writing the caller's workspace / output, so the caller's stream must not
