@@ -19,6 +19,7 @@
 #include "../../troy-nova_amd/csrc/ksmac_kernels.hpp"
 #include "ksmac3_experiment.hpp"
 #include "ksmac4_experiment.hpp"
+#include "ksmac5_experiment.hpp"
 #if __has_include("ksmac_base.hpp")
 #include "ksmac_base.hpp"      // frozen copy of the committed kernel (tools/ksbench/freeze_base.sh): same-run A/B
 #define KSBENCH_HAVE_BASE 1
@@ -297,6 +298,54 @@ int main(int argc, char** argv) {
     run_variant("ksmac2 f64 digits", [&](const NttArgs& v) {
         KsMacArgs kv = ka; kv.out = v.out; kv.digits = (const u64*)d_digf;
         hipLaunchKernelGGL((ksmac2_kernel<14, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, kv); });
+    {   // 16 coefficients per thread, four waves per SIMD (ksmac5_experiment.hpp) against ksmac2's NODIAG instantiation: every digit transformed, no epilogue
+        double* d_keys5; CHECK(hipMalloc(&d_keys5, (size_t)L * key_words * 8));
+        // its round-2 / round-3 twiddle tables (layouts in the kernel's comments)
+        std::vector<double> t2((size_t)K * 2 * 8 * 128, 0.0), t3((size_t)K * 2 * 8 * 1024, 0.0);
+        for (unsigned i = 0; i < K; i++) {
+            auto tw = [&](int beta, unsigned hh, unsigned hi) { return fwd[(size_t)i * N + (N >> (beta + 1)) + (hh << (12 - beta)) + hi]; };
+            for (unsigned hh = 0; hh < 2; hh++) for (unsigned w = 0; w < 8; w++) {
+                for (unsigned j = 0; j < 16; j++) {
+                    const unsigned hi6 = (w << 4) | j;
+                    double* v = &t2[(((size_t)(i * 2 + hh) * 8 + w) * 16 + j) * 8];
+                    v[1] = tw(5, hh, hi6);
+                    for (unsigned g = 0; g < 2; g++) v[2 + g] = tw(4, hh, (hi6 << 1) | g);
+                    for (unsigned g = 0; g < 4; g++) v[4 + g] = tw(3, hh, (hi6 << 2) | g);
+                }
+                for (unsigned ln = 0; ln < 64; ln++) {
+                    const unsigned hi4 = (w << 6) | ln;
+                    double* blk = &t3[((size_t)(i * 2 + hh) * 8 + w) * 1024];
+                    auto put = [&](unsigned slot, double val) { blk[((slot >> 1) * 64 + ln) * 2 + (slot & 1)] = val; };
+                    for (unsigned g = 0; g < 2; g++) put(g, tw(2, hh, (hi4 << 1) | g));
+                    for (unsigned g = 0; g < 4; g++) put(2 + g, tw(1, hh, (hi4 << 2) | g));
+                    for (unsigned g = 0; g < 8; g++) put(6 + g, tw(0, hh, (hi4 << 3) | g));
+                }
+            }
+        }
+        double *d_t2, *d_t3;
+        CHECK(hipMalloc(&d_t2, t2.size() * 8)); CHECK(hipMemcpy(d_t2, t2.data(), t2.size() * 8, hipMemcpyHostToDevice));
+        CHECK(hipMalloc(&d_t3, t3.size() * 8)); CHECK(hipMemcpy(d_t3, t3.data(), t3.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ksm5_prepare_keys_kernel, dim3(1024), dim3(256), 0, 0, b.kp, L, 2 * K, N, d_keys5);
+        std::vector<u64> r0(out_words), r1(out_words);
+        for (int rep = 0; rep < 2; rep++) {
+            KsMacArgs k2 = ka; k2.digits = (const u64*)d_digf; k2.diag = nullptr; k2.out = b.out_ref; k2.grouped = 1;
+            float t2 = time_launch([&] { hipLaunchKernelGGL((ksmac2_kernel<14, true, 0, false, false, false, true>), dim3(blocks * 2), dim3(KSM_THREADS), 0, 0, k2); }, reps);
+            KsMacArgs k5 = k2; k5.keys = d_keys5; k5.out = b.out; k5.tw_r1 = d_t2; k5.tw_r2 = d_t3;
+            CHECK(hipMemset(b.out, 0xff, out_words * 8));
+            float t5 = time_launch([&] { hipLaunchKernelGGL((ksmac5_kernel<14>), dim3(blocks * 2), dim3(KSM5_THREADS), 0, 0, k5); }, reps);
+            CHECK(hipMemcpy(r0.data(), b.out_ref, out_words * 8, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(r1.data(), b.out, out_words * 8, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < out_words; i++) if (r0[i] != r1[i]) { if (!bad) first = i; bad++; }
+            printf("item order: ksmac2 NODIAG %9.1f us   ksmac5 (16 coefficients x 512 threads, 4 waves / SIMD) %9.1f us   %s", t2, t5, bad ? "MISMATCH" : "identical");
+            if (bad) printf(" (%zu words, first at %zu: got %llu want %llu)", bad, first, (unsigned long long)r1[first], (unsigned long long)r0[first]);
+            printf("\n");
+        }
+        // restore the reference output of the plain form
+        hipLaunchKernelGGL((ks_mac_kernel<ArithF64, 14, 4>), dim3(blocks), dim3(1024), 0, 0, a, b.kp);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipFree(d_keys5));
+    }
 #ifdef KSM_PHASE_PROFILE
     {   // shader cycles of wave 0 of every workgroup per phase (s_memtime), one launch
         unsigned long long* d_prof; CHECK(hipMalloc(&d_prof, 9 * 8)); CHECK(hipMemset(d_prof, 0, 9 * 8));
