@@ -56,8 +56,11 @@ MemoryPool::MemoryPool(size_t device) : device_(device) {
 // it.  Tag 0 = nobody's work is pending on it (it was in the free list at a device-wide synchronisation).  A thread that ends leaves its
 // tag in g_dead_tags (its destructor must not call into HIP: the runtime's own thread-local state may be gone by then); blocks of dead
 // threads are handed out after ONE device-wide synchronisation, which clears every tag.
-static std::mutex g_dead_mutex;
-static std::unordered_set<uint64_t> g_dead_tags;
+// (leaked on purpose: a host thread may end after the statics of this library have been destroyed)
+static std::mutex& g_dead_mutex_ref() { static std::mutex* m = new std::mutex; return *m; }
+static std::unordered_set<uint64_t>& g_dead_tags_ref() { static auto* s = new std::unordered_set<uint64_t>; return *s; }
+#define g_dead_mutex g_dead_mutex_ref()
+#define g_dead_tags g_dead_tags_ref()
 struct ThreadExit {
     uint64_t tag = 0;
     ~ThreadExit() {
