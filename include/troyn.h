@@ -151,6 +151,9 @@ int troyn_dyadic_square(const troyn_plan* plan, uint32_t mod_start, uint32_t nmo
  *                (KSwitchKeys::get_data_ptrs, kswitch_keys.h:34-54); shared by the batch
  *   destination  [batch][2][L][N], written or accumulated per `assign_method`
  *                (SwitchKeyDestinationAssignMethod, evaluator.h)
+ *   workspace    query it with the batch the call will use: small launches (a single ciphertext) take the digit-parallel
+ *                inner product (one workgroup per digit on the caller's own keys, no key preparation pass), whose slots are
+ *                part of the workspace; the result words do not depend on which form runs
  * ------------------------------------------------------------------------------------- */
 enum { TROYN_ASSIGN_ADD_INPLACE = 0, TROYN_ASSIGN_OVERWRITE = 1, TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST = 2 };
 size_t troyn_switch_key_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch);
