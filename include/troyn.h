@@ -331,6 +331,9 @@ int troyn_extract_lwe(const troyn_plan* plan, uint32_t L, const uint64_t* const*
  * the kernels): `count` scattered device buffers of `words` words (16-byte aligned) -> one contiguous block, one launch. */
 size_t troyn_gather_workspace_bytes(size_t count);
 int troyn_gather(const uint64_t* const* src, size_t count, size_t words, uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream);
+/* The inverse (results of one batched call back to `count` separate buffers; workspace as for troyn_gather).  Up to 64 buffers the
+ * pointers of either call travel in the kernel arguments: no upload, no host wait. */
+int troyn_scatter(const uint64_t* in, uint64_t* const* dst, size_t count, size_t words, void* workspace, size_t workspace_bytes, troyn_stream_t stream);
 size_t troyn_multiply_plain_accumulate_workspace_bytes(size_t count);
 int troyn_multiply_plain_accumulate(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, size_t pcount,
                                     const uint64_t* const* ct, const uint64_t* const* pt, uint64_t* const* dst, size_t count,

@@ -125,6 +125,58 @@ int main(int argc, char** argv) {
             try { ev.multiply_relinearize_rescale_new(bottom, bottom, w.rk); } catch (const std::invalid_argument&) { caught++; }
             std::printf("fused_errors %d\n", caught);
         }
+        {
+            // ---- call combining (troy.h): T threads of single-object calls on DISTINCT operands; every result equals the uncombined call's -------
+            const size_t T = 8, rounds = 4;
+            std::vector<Ciphertext> a(T), b(T), want3(T), want1(T);
+            std::vector<cd> z;
+            for (size_t t = 0; t < T; t++) {
+                a[t] = fresh(z); b[t] = fresh(z);
+                // two shapes in flight: three of the eight threads work one level down (their calls form batches of their own)
+                if (t % 3 == 2) { ev.mod_switch_to_next_inplace(a[t]); ev.mod_switch_to_next_inplace(b[t]); }
+                want3[t] = ev.multiply_new(a[t], b[t]); ev.relinearize_inplace(want3[t], w.rk); ev.rescale_to_next_inplace(want3[t]);
+                want1[t] = ev.multiply_relinearize_rescale_new(a[t], b[t], w.rk);
+            }
+            troyn_sync_current_stream();
+            combining::reset_stats();
+            combining::set_enabled(true);
+            const unsigned window_before = combining::window_us();
+            combining::set_window_us(2000);   // generous: this is a correctness run (threads start raggedly)
+            std::atomic<int> ok{1}, caught{0};
+            auto body = [&](size_t t) {
+                for (size_t r = 0; r < rounds; r++) {
+                    Ciphertext m = ev.multiply_new(a[t], b[t]);
+                    Ciphertext l = ev.relinearize_new(m, w.rk);
+                    Ciphertext s = ev.rescale_to_next_new(l);
+                    Ciphertext f = ev.multiply_relinearize_rescale_new(a[t], b[t], w.rk);
+                    troyn_sync_current_stream();
+                    if (!same_ct(s, want3[t]) || !same_ct(f, want1[t])) ok.store(0);
+                    // an argument error stays with the thread that made it (checks run before the rendezvous)
+                    if (t == 3 && r == 1) {
+                        try { Ciphertext cf = ev.transform_from_ntt_new(a[t]); ev.multiply_new(cf, b[t]); } catch (const std::invalid_argument&) { caught.fetch_add(1); }
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < T; t++) th.emplace_back(body, t);
+            for (auto& x : th) x.join();
+            combining::set_enabled(false);
+            combining::set_window_us(window_before);
+            const combining::Stats st = combining::stats();
+            std::printf("combined_identical %d\n", ok.load());
+            std::printf("combined_errors %d\n", caught.load());
+            std::printf("combined_calls %llu\n", (unsigned long long)st.calls);
+            std::printf("combined_batches %llu\n", (unsigned long long)st.batches);
+            std::printf("combined_largest_batch %llu\n", (unsigned long long)st.largest_batch);
+            // one thread alone is never combined (and stays asynchronous)
+            combining::reset_stats();
+            combining::set_enabled(true);
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            Ciphertext alone = ev.multiply_relinearize_rescale_new(a[0], b[0], w.rk);
+            combining::set_enabled(false);
+            std::printf("combined_alone_calls %llu\n", (unsigned long long)combining::stats().calls);
+            std::printf("combined_alone_identical %d\n", same_ct(alone, want1[0]) ? 1 : 0);
+        }
         if (!bench) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
 
         // ---- single objects (the tool's loop: every call followed by a stream synchronisation) -----------------------------------------
@@ -152,20 +204,32 @@ int main(int argc, char** argv) {
         // stream, sharing context and keys; the reference has NO batched multiply / relinearize / rescale, :119-135, so this is what an
         // unmodified caller gets).  Every thread owns its operands; the three calls of an op are queued without a synchronisation in between
         // and the stream is synchronised once per op (the result is consumed by the caller).
+        for (int combine = 0; combine < 2; combine++)
         for (size_t threads : {(size_t)1, (size_t)4, (size_t)16, (size_t)64}) {
+            if (combine && threads == 1) continue;
+            combining::set_enabled(combine != 0);
+            combining::reset_stats();
             for (int fused = 0; fused < 2; fused++) {
-                const size_t reps = std::max<size_t>(50, 1600 / threads);
+                const size_t reps = std::max<size_t>(50, (combine ? 6400 : 1600) / threads);
                 std::atomic<size_t> ready{0};
                 std::atomic<bool> go{false};
+                std::atomic<uint64_t> phase_ns[4] = {};   // where a caller's time goes: the three calls and the wait (three-call loop)
                 auto body = [&](size_t) {
                     Ciphertext a = c1.clone(), b = c2.clone();
                     auto once = [&] {
                         if (fused) { Ciphertext t = ev.multiply_relinearize_rescale_new(a, b, w.rk); troyn_sync_current_stream(); }
                         else {
+                            auto p0 = clk::now();
                             Ciphertext t = ev.multiply_new(a, b);
+                            auto p1 = clk::now();
                             Ciphertext r = ev.relinearize_new(t, w.rk);
+                            auto p2 = clk::now();
                             Ciphertext s = ev.rescale_to_next_new(r);
+                            auto p3 = clk::now();
                             troyn_sync_current_stream();
+                            auto p4 = clk::now();
+                            phase_ns[0] += (uint64_t)(secs(p0, p1) * 1e9); phase_ns[1] += (uint64_t)(secs(p1, p2) * 1e9);
+                            phase_ns[2] += (uint64_t)(secs(p2, p3) * 1e9); phase_ns[3] += (uint64_t)(secs(p3, p4) * 1e9);
                         }
                     };
                     for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05;) once();
@@ -180,8 +244,30 @@ int main(int argc, char** argv) {
                 go.store(true, std::memory_order_release);
                 for (auto& x : th) x.join();
                 const double mx = secs(t0, clk::now());
-                std::printf("single_threads%zu_%s_ops_per_s %.1f\n", threads, fused ? "fused" : "three_calls", (double)(threads * reps) / mx);
+                std::printf("single_threads%zu_%s%s_ops_per_s %.1f\n", threads, fused ? "fused" : "three_calls", combine ? "_combined" : "", (double)(threads * reps) / mx);
+                if (!fused) {
+                    const double calls = (double)threads * (double)reps + 1e-9;   // the warm-up loop's calls are in the sums too: shares, not absolutes
+                    const double tot = (double)(phase_ns[0] + phase_ns[1] + phase_ns[2] + phase_ns[3]) + 1e-9;
+                    (void)calls;
+                    std::printf("single_threads%zu_three_calls%s_time_shares multiply %.2f relinearize %.2f rescale %.2f wait %.2f\n", threads, combine ? "_combined" : "",
+                                (double)phase_ns[0] / tot, (double)phase_ns[1] / tot, (double)phase_ns[2] / tot, (double)phase_ns[3] / tot);
+                }
             }
+            if (combine) {
+                const combining::Stats st = combining::stats();
+                std::printf("single_threads%zu_combined_mean_batch %.2f\n", threads, st.batches ? (double)st.calls / (double)st.batches : 0.0);
+                std::printf("single_threads%zu_combined_gather_us_per_batch %.1f\n", threads, st.batches ? (double)st.gather_ns / 1e3 / (double)(st.batches + st.uncombined) : 0.0);
+                std::printf("single_threads%zu_combined_execute_us_per_batch %.1f\n", threads, st.batches ? (double)st.execute_ns / 1e3 / (double)st.batches : 0.0);
+                std::printf("single_threads%zu_combined_uncombined_calls %llu\n", threads, (unsigned long long)st.uncombined);
+                std::printf("single_threads%zu_combined_caller_us_between_calls %.1f (no wait in between), %.1f (with a stream wait); release lag %.1f us\n", threads,
+                            st.between_calls ? (double)st.between_ns / 1e3 / (double)st.between_calls : 0.0,
+                            st.between_wait_calls ? (double)st.between_wait_ns / 1e3 / (double)st.between_wait_calls : 0.0,
+                            st.release_lag_calls ? (double)st.release_lag_ns / 1e3 / (double)st.release_lag_calls : 0.0);
+                std::printf("single_threads%zu_combined_arrival_spread_us %.1f\n", threads, (double)st.spread_ns / 1e3 / (double)std::max<uint64_t>(1, st.batches + st.uncombined));
+                std::printf("single_threads%zu_combined_window_expired %llu of %llu leaders, mean target %.1f\n", threads, (unsigned long long)st.window_expired,
+                            (unsigned long long)(st.batches + st.uncombined), (double)st.target_sum / (double)std::max<uint64_t>(1, st.batches + st.uncombined));
+            }
+            combining::set_enabled(false);
         }
 
         if (threads_only) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }

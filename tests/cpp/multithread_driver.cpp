@@ -1,6 +1,8 @@
 // C++ driver for tests/test_gpu_cpp_api.py::test_multithread_cpp_api (the reference's test/test_multithread.cu scenario): several
 // host threads share one HeContext, one set of keys and the global memory pool, each on its own per-thread stream, and run
 // encrypt -> multiply -> relinearize -> mod-switch -> decrypt loops concurrently; every result must decrypt correctly.
+// With TROY_COMBINE=1 in the environment the same program runs with call combining (troy.h): one shared stream, the multiply /
+// relinearize calls of concurrent threads batched, everything else (encrypt, add, mod-switch, decrypt) queued between the batches.
 // usage: multithread_driver <threads> <iterations>
 #include <atomic>
 #include <cstdio>
@@ -59,6 +61,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < threads; i++) pool.emplace_back(work, i);
         for (auto& th : pool) th.join();
         std::printf("threads %zu iterations %zu completed %zu wrong %zu\n", threads, iterations, done.load(), bad.load());
+        std::printf("combining %d combined_calls %llu\n", combining::enabled() ? 1 : 0, (unsigned long long)combining::stats().calls);
         const bool ok = bad.load() == 0 && done.load() == threads * iterations;
         std::printf(ok ? "OK\n" : "FAIL\n");
         MemoryPool::Destroy();

@@ -150,6 +150,11 @@ def test_fused_multiply_relinearize_rescale_cpp_api(dev):
         assert kv[k][0] == "1", k
     assert float(kv["fused_single_error"][0]) < 1e-3
     assert kv["fused_errors"][0] == "2"
+    # call combining: 8 threads x 4 rounds of the three calls and of the fused call on distinct operands at two levels, word-identical to the
+    # uncombined calls; an argument error stays with its thread; a thread that is alone is not combined
+    assert kv["combined_identical"][0] == "1" and kv["combined_errors"][0] == "1"
+    assert int(kv["combined_calls"][0]) > 0 and int(kv["combined_largest_batch"][0]) >= 2
+    assert kv["combined_alone_calls"][0] == "0" and kv["combined_alone_identical"][0] == "1"
 
 
 @pytest.mark.parametrize("dims,pack_lwe,mod_switch,objective", [
@@ -229,6 +234,20 @@ def test_multithread_cpp_api(dev):
         pytest.fail("tests/cpp/multithread_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv, "4", "8"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "completed 32 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_multithread_call_combining_cpp_api(dev):
+    """The same program (BFV: encrypt -> multiply -> relinearize -> add -> mod-switch -> decrypt on 8 host threads) with TROY_COMBINE=1:
+    one shared stream, the multiply / relinearize calls of concurrent threads run as batches (troy.h "Call combining"), the other calls
+    are queued between them; every result still decrypts correctly and calls were in fact combined."""
+    drv = os.path.join(ROOT, "tests", "cpp", "multithread_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/multithread_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, TROY_COMBINE="1", TROY_COMBINE_WINDOW_US="2000")
+    r = subprocess.run([drv, "8", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "completed 64 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert kv["combining"][0] == "1" and int(kv["combining"][2]) > 0, r.stdout
 
 
 def test_basics_cpp_api(dev):

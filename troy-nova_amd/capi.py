@@ -87,6 +87,7 @@ SYMBOLS = {
     "troyn_ring2k_scale_down": (C.c_int, [vp, vp, vp, vp]),
     "troyn_gather_workspace_bytes": (sz, [sz]),
     "troyn_gather": (C.c_int, [vp, sz, sz, vp, vp, sz, vp]),
+    "troyn_scatter": (C.c_int, [vp, vp, sz, sz, vp, sz, vp]),
     "troyn_negacyclic_shift": (C.c_int, [vp, u32, u32, vp, vp, sz, sz, vp]),
     "troyn_multiply_inv_degree": (C.c_int, [vp, u32, u32, vp, vp, u64, sz, vp]),
     "troyn_pack_prepare_workspace_bytes": (sz, [sz]),

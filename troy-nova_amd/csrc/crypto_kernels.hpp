@@ -480,4 +480,35 @@ __global__ __launch_bounds__(256) void gather_kernel(const u64* const* src, size
     if ((words & 1) && blockIdx.x == 0 && threadIdx.x == 0) op[words - 1] = sp[words - 1];
 }
 
+// the same for up to 64 buffers with the pointers in the kernel arguments: no table upload, nothing to wait for on the host (the call
+// combining layer of the C++ mirror stages the operands of <= 64 concurrent single-object calls with it)
+struct GatherPtrs { const u64* p[64]; };
+__global__ __launch_bounds__(256) void gather_small_kernel(GatherPtrs src, size_t words, u64* out) {
+    const u64* sp = src.p[blockIdx.y];
+    u64* op = out + (size_t)blockIdx.y * words;
+    const size_t pairs = words / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2*>(op)[i] = reinterpret_cast<const ulonglong2*>(sp)[i];
+    if ((words & 1) && blockIdx.x == 0 && threadIdx.x == 0) op[words - 1] = sp[words - 1];
+}
+
+// the inverse: windows of one contiguous block back to `count` separate buffers (results of a combined batch go to the callers' own arrays)
+struct ScatterPtrs { u64* p[64]; };
+__global__ __launch_bounds__(256) void scatter_small_kernel(const u64* in, ScatterPtrs dst, size_t words) {
+    u64* op = dst.p[blockIdx.y];
+    const u64* sp = in + (size_t)blockIdx.y * words;
+    const size_t pairs = words / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2*>(op)[i] = reinterpret_cast<const ulonglong2*>(sp)[i];
+    if ((words & 1) && blockIdx.x == 0 && threadIdx.x == 0) op[words - 1] = sp[words - 1];
+}
+__global__ __launch_bounds__(256) void scatter_kernel(const u64* in, u64* const* dst, size_t words) {
+    u64* op = dst[blockIdx.y];
+    const u64* sp = in + (size_t)blockIdx.y * words;
+    const size_t pairs = words / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<ulonglong2*>(op)[i] = reinterpret_cast<const ulonglong2*>(sp)[i];
+    if ((words & 1) && blockIdx.x == 0 && threadIdx.x == 0) op[words - 1] = sp[words - 1];
+}
+
 }  // namespace troyn

@@ -2242,10 +2242,41 @@ extern "C" int troyn_gather(const uint64_t* const* src, size_t count, size_t wor
         if (!src[i] || ((uintptr_t)src[i] & 15)) return fail(TROYN_E_INVALID, "[troyn_gather] null or misaligned pointer in the batch");
     if ((uintptr_t)out & 15) return fail(TROYN_E_INVALID, "[troyn_gather] misaligned destination");
     hipStream_t s = (hipStream_t)stream;
+    const unsigned bx = (unsigned)std::min<size_t>((words / 2 + 255) / 256 + 1, 64);
+    if (count <= 64) {   // pointers by value: no upload, no host wait
+        GatherPtrs g;
+        for (size_t i = 0; i < 64; i++) g.p[i] = reinterpret_cast<const u64*>(src[i < count ? i : 0]);
+        hipLaunchKernelGGL(gather_small_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, g, words, (u64*)out);
+        LAUNCH_CHECK();
+        return TROYN_OK;
+    }
     HIP_TRY(hipMemcpyAsync(workspace, src, count * sizeof(u64), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));   // `src` belongs to the caller
-    const unsigned bx = (unsigned)std::min<size_t>((words / 2 + 255) / 256 + 1, 64);
     hipLaunchKernelGGL(gather_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64* const*)workspace, words, (u64*)out);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
+extern "C" int troyn_scatter(const uint64_t* in, uint64_t* const* dst, size_t count, size_t words, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {
+    if (!in || !dst || !workspace) return fail(TROYN_E_INVALID, "[troyn_scatter] null argument");
+    if (count == 0 || words == 0) return TROYN_OK;
+    if (count > 65535) return fail(TROYN_E_INVALID, "[troyn_scatter] batch too large for one launch");
+    if (workspace_bytes < troyn_gather_workspace_bytes(count)) return fail(TROYN_E_WORKSPACE, "[troyn_scatter] workspace too small");
+    for (size_t i = 0; i < count; i++)
+        if (!dst[i] || ((uintptr_t)dst[i] & 15)) return fail(TROYN_E_INVALID, "[troyn_scatter] null or misaligned pointer in the batch");
+    if ((uintptr_t)in & 15) return fail(TROYN_E_INVALID, "[troyn_scatter] misaligned source");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned bx = (unsigned)std::min<size_t>((words / 2 + 255) / 256 + 1, 64);
+    if (count <= 64) {
+        ScatterPtrs g;
+        for (size_t i = 0; i < 64; i++) g.p[i] = reinterpret_cast<u64*>(dst[i < count ? i : 0]);
+        hipLaunchKernelGGL(scatter_small_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64*)in, g, words);
+        LAUNCH_CHECK();
+        return TROYN_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(workspace, dst, count * sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // `dst` belongs to the caller
+    hipLaunchKernelGGL(scatter_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64*)in, (u64* const*)workspace, words);
     LAUNCH_CHECK();
     return TROYN_OK;
 }

@@ -31,11 +31,59 @@ static void troyn_check(int rc) {
     throw std::runtime_error(troyn_last_error());
 }
 
-static inline hipStream_t current_stream() { return hipStreamPerThread; }
+// The stream this thread's calls launch on: hipStreamPerThread -- or, while call combining is on (troy.h), ONE stream shared by every
+// host thread: the batches of combined calls and whatever else the threads queue are then ordered by that stream alone, so a combined
+// call needs no cross-stream dependency and nobody waits for the GPU inside it.
+namespace detail {
+static std::atomic<int> g_combining{-1};   // -1: not decided yet (environment TROY_COMBINE), 0 off, 1 on
+static std::once_flag g_shared_once;
+static hipStream_t g_shared_stream = nullptr;
+static int g_shared_device = -1;
+bool combining_on() {
+    int v = g_combining.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("TROY_COMBINE");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_combining.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+// created on the device that is current at the first call after the switch; null only if that failed
+hipStream_t shared_stream() {
+    std::call_once(g_shared_once, [] {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        hipStream_t s = nullptr;
+        if (hipStreamCreate(&s) != hipSuccess) { (void)hipGetLastError(); return; }   // a blocking stream: hipStreamSynchronize(0), the reference tool's idiom, still covers it
+        g_shared_stream = s;
+        g_shared_device = dev;
+    });
+    return g_shared_stream;   // no per-call device query (a runtime call per launch site from every thread): combining is a one-device mode
+}
+void combining_switch(bool on) {
+    if (combining_on() == on) return;
+    // a quiescent point by contract (no other thread inside the library); everything queued so far completes, every cached block is anybody's
+    (void)hipDeviceSynchronize();
+    g_combining.store(on ? 1 : 0, std::memory_order_release);
+    if (MemoryPoolHandle g = MemoryPool::GlobalPool()) g->disown(~uint64_t(0));
+}
+}  // namespace detail
+
+static inline hipStream_t current_stream() {
+    if (detail::combining_on()) if (hipStream_t s = detail::shared_stream()) return s;
+    return hipStreamPerThread;
+}
 
 void troyn_check_public(int rc) { troyn_check(rc); }
 troyn_stream_t troyn_current_stream() { return (troyn_stream_t)current_stream(); }
-void troyn_sync_current_stream() { hip_check(hipStreamSynchronize(current_stream()), "stream_sync"); }
+// every wait for the calling thread's stream goes through here: waits for the shared stream of call combining are grouped (combine.cpp)
+static hipError_t stream_wait() {
+    hipStream_t s = current_stream();
+    if (s != hipStreamPerThread) return static_cast<hipError_t>(detail::combining_stream_wait(s));
+    return hipStreamSynchronize(s);
+}
+void troyn_sync_current_stream() { hip_check(stream_wait(), "stream_sync"); }
+namespace utils { void stream_sync() { troyn_sync_current_stream(); } }   // utils/memory_pool.h:37
 
 namespace utils {
 
@@ -70,6 +118,8 @@ struct ThreadExit {
     }
 };
 static uint64_t this_thread_tag() {
+    // one shared stream (call combining): release and reuse are ordered by that stream whichever host thread does them
+    if (detail::combining_on() && detail::shared_stream()) return uint64_t(1) << 63;
     static std::atomic<uint64_t> next{1};
     thread_local ThreadExit te;
     if (!te.tag) te.tag = next.fetch_add(1);
@@ -238,7 +288,7 @@ std::vector<uint64_t> DynamicArray::to_vector() const {
     if (device_) {
         hip_check(hipSetDevice(static_cast<int>(device_index())), "copy_device_to_host");
         hip_check(hipMemcpyAsync(v.data(), data_, size_ * sizeof(uint64_t), hipMemcpyDeviceToHost, current_stream()), "copy_device_to_host");
-        hip_check(hipStreamSynchronize(current_stream()), "copy_device_to_host");
+        hip_check(stream_wait(), "copy_device_to_host");
     } else {
         std::memcpy(v.data(), data_, size_ * sizeof(uint64_t));
     }
@@ -259,7 +309,7 @@ void DynamicArray::copy_from(const uint64_t* src, size_t count, bool src_on_devi
     hipMemcpyKind kind = device_ ? (src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : hipMemcpyDeviceToHost;
     hip_check(hipMemcpyAsync(data_, src, bytes, kind, current_stream()), "copy");
     // host buffers may be freed or reused by the caller right away: finish the transfer (reference: D2H is synchronous)
-    if (kind != hipMemcpyDeviceToDevice) hip_check(hipStreamSynchronize(current_stream()), "copy");
+    if (kind != hipMemcpyDeviceToDevice) hip_check(stream_wait(), "copy");
 }
 
 // utils/box.h:282-308 for the uint64_t views the public accessors hand out
@@ -275,7 +325,7 @@ template <> void Slice<uint64_t>::copy_from_slice(ConstSlice<uint64_t> source) c
     if (!device_ && !source.on_device()) { std::memcpy(ptr_, source.raw_pointer(), bytes); return; }
     const hipMemcpyKind kind = device_ ? (source.on_device() ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) : hipMemcpyDeviceToHost;
     hip_check(hipMemcpyAsync(ptr_, source.raw_pointer(), bytes, kind, current_stream()), "copy");
-    if (kind != hipMemcpyDeviceToDevice) hip_check(hipStreamSynchronize(current_stream()), "copy");
+    if (kind != hipMemcpyDeviceToDevice) hip_check(stream_wait(), "copy");
 }
 
 void DynamicArray::set_zero() {
@@ -834,7 +884,7 @@ void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext
         a.correction_factor() = f0;
         b.correction_factor() = f0;
         translate(a, b, destination, subtract, pool);
-        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+        hip_check(stream_wait(), "stream_sync");
         return;
     }
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
@@ -872,6 +922,29 @@ void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext&
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const size_t p1 = e1.polynomial_count(), p2 = e2.polynomial_count();
     Ciphertext out = Ciphertext::like(e1, p1 + p2 - 1, false, pool);
+    // call combining (troy.h): every check is done and the result's metadata set here, the batch only needs shapes and pointers
+    if (detail::combining_wanted()) {
+        detail::CombineRequest rq;
+        rq.L = L; rq.p1 = static_cast<uint32_t>(p1); rq.p2 = static_cast<uint32_t>(p2);
+        rq.in1 = e1.data().raw_pointer(); rq.words1 = e1.data().size(); rq.in2 = e2.data().raw_pointer(); rq.words2 = e2.data().size();
+        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+        bool ok = true;
+        if (scheme == SchemeType::BFV) {
+            check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e1); check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e2);
+            rq.kind = detail::CombineKind::BfvMultiply; rq.handle = context_->behz(L);
+        } else if (scheme == SchemeType::CKKS || scheme == SchemeType::BGV) {
+            const char* P = scheme == SchemeType::CKKS ? "[Evaluator::ckks_multiply_inplace]" : "[Evaluator::bgv_multiply]";
+            check_is_ntt_form(P, e1); check_is_ntt_form(P, e2);
+            rq.kind = detail::CombineKind::DyadicMultiply; rq.handle = context_->plan(); rq.ntt_form = true;
+            if (scheme == SchemeType::CKKS) {
+                out.scale() = e1.scale() * e2.scale();
+                if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument("[Evaluator::ckks_multiply] Scale out of bounds");
+            } else {
+                out.correction_factor() = (uint64_t)(((unsigned __int128)e1.correction_factor() * e2.correction_factor()) % cd->parms().plain_modulus().value());
+            }
+        } else ok = false;
+        if (ok && detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
+    }
     switch (scheme) {
         case SchemeType::BFV: {
             check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e1); check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e2);
@@ -999,8 +1072,16 @@ void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKey
         if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
         if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
         for (const auto& k : relin_keys.data()[idx]) if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
-        Ciphertext out = Ciphertext::like(encrypted, 2, false, pool);
         std::vector<const uint64_t*> ptrs = relin_keys.get_data_ptrs(idx);
+        Ciphertext out = Ciphertext::like(encrypted, 2, false, pool);
+        if (scheme != SchemeType::BGV && detail::combining_wanted()) {
+            detail::CombineRequest rq;
+            rq.kind = detail::CombineKind::Relinearize; rq.handle = context_->plan(); rq.L = L; rq.p1 = 3;
+            rq.ckks = scheme == SchemeType::CKKS; rq.ntt_form = encrypted.is_ntt_form(); rq.keys = &ptrs;
+            rq.in1 = encrypted.data().raw_pointer(); rq.words1 = encrypted.data().size();
+            rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+            if (detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
+        }
         size_t bytes = troyn_relinearize_workspace_bytes(context_->plan(), L, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         if (scheme == SchemeType::BGV) {
@@ -1046,6 +1127,18 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
     const size_t pc = encrypted.polynomial_count();
     Ciphertext out = Ciphertext::like(encrypted, pc, L - 1, false, pool);
     out.parms_id() = next->parms_id();
+    if (scheme == SchemeType::CKKS && detail::combining_wanted()) {
+        detail::CombineRequest rq;
+        rq.kind = detail::CombineKind::Rescale; rq.handle = context_->plan(); rq.L = L; rq.p1 = static_cast<uint32_t>(pc); rq.ckks = true; rq.ntt_form = true;
+        rq.in1 = encrypted.data().raw_pointer(); rq.words1 = encrypted.data().size();
+        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+        if (detail::combine_submit(rq, pool)) {
+            out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
+            out.is_ntt_form() = encrypted.is_ntt_form();
+            destination = std::move(out);
+            return;
+        }
+    }
     if (scheme == SchemeType::BFV) {
         troyn_check(troyn_divide_and_round_q_last(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), 1, current_stream()));
     } else if (scheme == SchemeType::BGV) {
@@ -1054,7 +1147,7 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
         const size_t bytes = troyn_bgv_mod_switch_workspace_bytes(bg, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check(troyn_bgv_mod_t_and_divide_q_last_ntt(bg, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
-        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+        hip_check(stream_wait(), "stream_sync");
         const uint64_t t = next->parms().plain_modulus().value();
         out.correction_factor() = static_cast<uint64_t>((static_cast<unsigned __int128>(encrypted.correction_factor()) * troyn_bgv_inv_q_last_mod_t(bg)) % t);
     } else {
@@ -1177,6 +1270,14 @@ void Evaluator::multiply_relinearize_rescale(const Ciphertext& e1, const Ciphert
     out.parms_id() = next;
     out.scale() = scale;
     out.is_ntt_form() = true;
+    if (detail::combining_wanted()) {
+        detail::CombineRequest rq;
+        rq.kind = detail::CombineKind::MultiplyRelinearizeRescale; rq.handle = context_->plan(); rq.L = L; rq.p1 = 2; rq.p2 = 2; rq.ckks = true; rq.ntt_form = true;
+        rq.keys = &keys;
+        rq.in1 = e1.data().raw_pointer(); rq.words1 = e1.data().size(); rq.in2 = e2.data().raw_pointer(); rq.words2 = e2.data().size();
+        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+        if (detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
+    }
     const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(context_->plan(), L, 1);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
     troyn_check(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, e1.data().raw_pointer(), e2.data().raw_pointer(), keys.data(), out.data().raw_pointer(),
@@ -1346,7 +1447,7 @@ void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& 
             destination[i]->scale() = encrypted[i]->scale() * plain[i]->scale();
             if (!is_scale_within_bounds(destination[i]->scale(), cd)) throw std::invalid_argument("[Evaluator::multiply_plain_ntt_batched] Scale out of bounds.");   // evaluator_multiply_plain.cu:250,:301
         }
-    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    hip_check(stream_wait(), "stream_sync");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1449,7 +1550,7 @@ void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element,
     hip_check(hipMemcpyAsync(target.raw_pointer(), out.poly(1), static_cast<size_t>(L) * n * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
     switch_key_internal(encrypted, target.raw_pointer(), galois_keys, GaloisKeys::get_index(galois_element),
                         SwitchKeyDestinationAssignMethod::OverwriteExceptFirst, out, pool);
-    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    hip_check(stream_wait(), "stream_sync");
     destination = std::move(out);
 }
 
@@ -1719,7 +1820,7 @@ void Ciphertext::load_terms(std::istream& stream, HeContextPointer context, cons
     if (is_ntt_form_) {
         if (!context->on_device()) throw std::invalid_argument("[Ciphertext::load_terms] an NTT-form ciphertext is transformed on the GPU: the context must be on the device.");
         troyn_check(troyn_ntt(context->plan(), 0, data_.raw_pointer(), data_.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
-        hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+        hip_check(stream_wait(), "stream_sync");
     }
     if (seeded) expand_seed(context);
 }
@@ -1732,7 +1833,7 @@ void Ciphertext::expand_seed(HeContextPointer context) {
     if (!context->on_device() || !on_device()) throw std::invalid_argument("[Ciphertext::expand_seed] the seed is expanded on the GPU: context and ciphertext must be on the device.");
     utils::RandomGenerator c1_prng(seed_);
     c1_prng.sample_poly_uniform(context->plan(), coeff_modulus_size_, poly(1));
-    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    hip_check(stream_wait(), "stream_sync");
     seed_ = 0;
 }
 
@@ -2317,7 +2418,7 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
             out.parms_id() = parms_id_zero;
             out.resize(n);
             troyn_check(troyn_bfv_decrypt_scale_and_round(context_->behz(L), phase.raw_pointer(), out.poly(), 1, current_stream()));
-            hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+            hip_check(stream_wait(), "stream_sync");
             out.is_ntt_form() = false;
             out.coeff_modulus_size() = L;
             out.poly_modulus_degree() = n;
@@ -2347,7 +2448,7 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
             out.parms_id() = parms_id_zero;
             out.resize(n);
             troyn_check(troyn_bgv_decrypt_mod_t(context_->bgv(L), phase.raw_pointer(), encrypted.correction_factor(), out.poly(), 1, current_stream()));
-            hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+            hip_check(stream_wait(), "stream_sync");
             out.is_ntt_form() = false;
             out.coeff_modulus_size() = L;
             out.poly_modulus_degree() = n;
@@ -2561,7 +2662,7 @@ void BatchEncoder::encode(const std::vector<uint64_t>& values, Plaintext& destin
     out.resize(slots_);
     out.data().copy_from(buf.data(), slots_, false);
     troyn_check(troyn_ntt(context_->plain_plan(), 1, out.poly(), out.poly(), 1, 1, 1, 0, 1, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
-    hip_check(hipStreamSynchronize(current_stream()), "stream_sync");
+    hip_check(stream_wait(), "stream_sync");
     out.is_ntt_form() = false;
     out.poly_modulus_degree() = slots_;
     out.coeff_modulus_size() = context_->first_context_data().value()->parms().coeff_modulus().size();

@@ -21,6 +21,7 @@
 //     "not implemented yet", test/bench/he_operations.cpp:119-135).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <complex>
 #include <cstdint>
 #include <cstring>
@@ -232,10 +233,11 @@ private:
 namespace utils { void blake2b(void* out, size_t outlen, const void* in, size_t inlen); }   // RFC 7693, unkeyed
 
 // helpers for code layered on the mirror (matmul.cpp): C-ABI status -> the reference's exception types, the calling
-// thread's stream (hipStreamPerThread), and a wait on it
+// thread's stream (hipStreamPerThread; the shared stream while call combining is on), and a wait on it
 void troyn_check_public(int rc);
 troyn_stream_t troyn_current_stream();
 void troyn_sync_current_stream();
+namespace utils { void stream_sync(); }   // utils/memory_pool.h:37: wait for the calling thread's stream
 
 using MemoryPool = utils::MemoryPool;
 using MemoryPoolHandle = utils::MemoryPoolHandle;
@@ -1003,6 +1005,72 @@ private:
     double scale_ = 1.0;
     uint64_t correction_factor_ = 1;
 };
+
+// ----------------------------------------------------------------------------------------------
+// Call combining (ADDITION; off unless switched on).  The reference's concurrency model is N host threads, each issuing single-object
+// Evaluator calls on its own stream (test/bench/he_operations.cu:85, :364-380 `-c N`; test/test_multithread.cu:18-37) -- it has no
+// batched multiply / relinearize / rescale.  On this GPU small kernels of different streams overlap at most ~4-fold
+// (tools/ubench/stream_overlap.hip), so N such threads get <= 4 / (GPU time of one op), while ONE launch sequence over 16 objects costs
+// barely more than over one (tools/small_batch_sweep.py).  With combining on
+//   * every host thread's calls go to ONE shared stream instead of hipStreamPerThread (one order for everything the threads queue: no
+//     cross-stream dependencies, the pool may hand a block released by one thread to another at once);
+//   * a thread that enters multiply / relinearize / rescale_to_next / multiply_relinearize_rescale while other threads are doing the same
+//     hands its (already checked) call to a rendezvous: the first thread to arrive leads, waits at most `window` for the other active
+//     threads, queues the calls of ITS shape as one library call (operands staged by one gather launch, results delivered to the
+//     callers' own arrays by one scatter launch) and every caller returns -- as with the uncombined call, the work is queued, not
+//     finished: wait with utils::stream_sync() / troyn_sync_current_stream() (or hipDeviceSynchronize), NOT with
+//     hipStreamSynchronize(hipStreamPerThread), which no longer is the stream the work is on.
+// Results are the library's batched results, i.e. bit-identical to the uncombined calls.  A thread that is alone (no other thread inside
+// these methods within the last few ms) is never combined.  Switch it at a quiescent point (no other thread inside the library): the
+// switch waits for the device.  Environment: TROY_COMBINE=1 switches it on from the first call, TROY_COMBINE_WINDOW_US=<n> sets the
+// window (default 100).  A one-device mode: the shared stream lives on the device that was current at the first call after the switch.
+// ----------------------------------------------------------------------------------------------
+namespace combining {
+void set_enabled(bool on);
+bool enabled();
+void set_window_us(unsigned microseconds);
+unsigned window_us();
+struct Stats {
+    uint64_t calls = 0, batches = 0, largest_batch = 0;   // calls that went through a batch, batches run, size of the largest
+    uint64_t uncombined = 0;                              // calls that led alone and ran the ordinary way
+    uint64_t gather_ns = 0, execute_ns = 0;               // leaders: time spent waiting for the others / running and waiting for the batch
+    uint64_t between_ns = 0, between_calls = 0;           // callers: time from leaving one combined call to entering the next (host work of the caller)
+    uint64_t between_wait_ns = 0, between_wait_calls = 0; // the same when the caller waited for the stream in between
+    uint64_t release_lag_ns = 0, release_lag_calls = 0;   // from the leader's release to the waiting caller leaving the call
+    uint64_t spread_ns = 0;                               // first to last arrival of a batch
+    uint64_t window_expired = 0, target_sum = 0;          // leaders that stopped waiting because the window passed; sum of the thread counts they waited for
+};
+Stats stats();
+void reset_stats();
+}  // namespace combining
+
+namespace detail {
+// one checked single-object call handed to the rendezvous (combine.cpp); the submitting thread has done every argument check and knows
+// the result's metadata, the leader only needs shapes and pointers
+enum class CombineKind : uint8_t { DyadicMultiply, BfvMultiply, Relinearize, Rescale, MultiplyRelinearizeRescale };
+struct CombineRequest {
+    CombineKind kind;
+    const void* handle = nullptr;                 // troyn_plan* (troyn_behz* for BfvMultiply): same context + level
+    uint32_t L = 0, p1 = 0, p2 = 0;               // limbs, polynomial counts of the operands
+    bool ckks = false, ntt_form = false;
+    const std::vector<const uint64_t*>* keys = nullptr;   // key-switching forms: the L key pointers (identity: the first pointer)
+    const uint64_t* in1 = nullptr; size_t words1 = 0;
+    const uint64_t* in2 = nullptr; size_t words2 = 0;
+    uint64_t* out = nullptr; size_t out_words = 0;   // the caller's own destination array (allocated by the calling thread from ITS share of the pool)
+    // set by the leader
+    std::exception_ptr error;
+    CombineRequest* wake[2] = {nullptr, nullptr};   // the waiters this one wakes on its way out (the release fans out as a tree: a wake costs
+                                                    // microseconds per sleeper, the leader alone would release 64 callers one after the other)
+    std::atomic<int> state{0};
+    int64_t released_ns = 0;
+};
+// true: the call ran as part of a batch (or failed there: throws); false: not combined, the caller runs it itself
+bool combine_submit(CombineRequest& request, MemoryPoolHandle pool);
+bool combining_wanted();   // switched on AND another thread is active in the combinable methods
+bool combining_on();
+void combining_switch(bool on);
+int combining_stream_wait(void* stream);   // hipStreamSynchronize(shared stream), one waiter at a time (returns the hipError_t)
+}  // namespace detail
 
 // ----------------------------------------------------------------------------------------------
 // Evaluator  (src/evaluator.h)
