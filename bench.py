@@ -821,8 +821,11 @@ def run_cpp_api():
         return {"error": (r.stdout + r.stderr)[-500:]}
     out = {"what": "CKKS N=16384 6x50-bit through troy::Evaluator (tests/cpp/he_bench_driver.cpp, shaped like the reference's test/bench/he_operations.cu): "
                    "three_calls = multiply + relinearize + rescale_to_next (single objects: *_new with a stream synchronisation after every call as the tool does; "
-                   "batches: *_batched), fused = Evaluator::multiply_relinearize_rescale{_new,_batched}; threads = host threads with their own operands",
-           "fused_identical_to_three_calls": all(kv.get(k) == "1" for k in ("fused_single_identical", "fused_inplace_identical", "fused_batched_identical", "fused_mixed_levels_identical"))}
+                   "batches: *_batched), fused = Evaluator::multiply_relinearize_rescale{_new,_batched}; threads = host threads with their own operands; "
+                   "single_threadsN_* = the tool's -c N mode (N threads x single objects, one stream wait per op); *_combined = the same loops with call combining on "
+                   "(troy::combining, troy.h: one shared stream, the calls of concurrent threads run as one batched launch sequence; results bit-identical, see combined_identical)",
+           "fused_identical_to_three_calls": all(kv.get(k) == "1" for k in ("fused_single_identical", "fused_inplace_identical", "fused_batched_identical", "fused_mixed_levels_identical")),
+           "combined_identical": kv.get("combined_identical") == "1" and kv.get("combined_alone_identical") == "1"}
     for k, v in kv.items():
         if k.startswith(("single_", "batched_")):
             out[k] = float(v)

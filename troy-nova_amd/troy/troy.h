@@ -147,6 +147,7 @@ using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 // ASSUMPTION the asynchronous methods rest on: one stream per host thread, always the same one -- true here because every launch of this
 // library's C++ layer uses hipStreamPerThread; a caller that drives the C-ABI (include/troyn.h) with streams of its own must order the
 // release of a workspace after the work that uses it (stream-ordered free or an event), exactly as with any asynchronous HIP API.
+// While call combining is on (below) there is ONE stream for all host threads, and all of them count as the same owner.
 class MemoryPool {
 public:
     explicit MemoryPool(size_t device = 0);
