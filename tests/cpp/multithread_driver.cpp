@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
         KeyGenerator keygen(context);
         const PublicKey pk = keygen.create_public_key(false);
         const RelinKeys rk = keygen.create_relin_keys(false);
+        const GaloisKeys gk = keygen.create_galois_keys(false);
         Decryptor decryptor(context, keygen.secret_key());
         std::atomic<size_t> bad{0}, done{0};
         auto work = [&](size_t id) {
@@ -49,6 +50,13 @@ int main(int argc, char** argv) {
                     for (size_t i = 0; i < n; i++) {
                         const uint64_t want = (uint64_t)((((unsigned __int128)a[i] * b[i]) + a[i]) % t);
                         if (got[i] != want) { bad++; break; }
+                    }
+                    // a rotation (key switch by a Galois key): the rows of the 2 x n/2 slot matrix move left by 3
+                    const std::vector<uint64_t> rot = encoder.decode_new(decryptor.decrypt_new(ev.rotate_rows_new(ca, 3, gk)));
+                    const size_t half = n / 2;
+                    for (size_t i = 0; i < n; i++) {
+                        const size_t row = i / half, col = i % half;
+                        if (rot[i] != a[row * half + (col + 3) % half]) { bad++; break; }
                     }
                     done++;
                 }

@@ -152,6 +152,21 @@ void execute(std::vector<detail::CombineRequest*>& batch, MemoryPoolHandle pool)
                 lib_ok(troyn_divide_and_round_q_last_ntt(plan, h.L, a, h.p1, out, ws.raw_pointer(), bytes, count, (troyn_stream_t)s));
                 break;
             }
+            case CombineKind::ApplyGalois: {
+                // Evaluator::apply_galois (evaluator_keyswitching.cu:147-179) over the batch: permute (c0, c1) of every item, take the permuted c1s
+                // as key-switch targets, overwrite them with the switched result (c0 += ks0, c1 = ks1)
+                const troyn_plan* plan = static_cast<const troyn_plan*>(h.handle);
+                const size_t pc = h.words1 / 2;
+                lib_ok(troyn_apply_galois(plan, 0, h.L, h.ntt_form ? 1 : 0, h.p2, a, out, count * 2, (troyn_stream_t)s));
+                s2 = utils::DynamicArray(count * pc, true, pool);
+                if (hipMemcpy2DAsync(s2.raw_pointer(), pc * 8, out + pc, 2 * pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    throw std::runtime_error("[kernel_provider::copy_device_to_device] failed");
+                const size_t bytes = troyn_switch_key_workspace_bytes(plan, h.L, count);
+                ws = utils::DynamicArray((bytes + 7) / 8, true, pool);
+                lib_ok(troyn_switch_key(plan, h.L, h.ckks, h.ntt_form, s2.raw_pointer(), h.keys->data(), TROYN_ASSIGN_OVERWRITE_EXCEPT_FIRST, out, ws.raw_pointer(), bytes, count,
+                                        (troyn_stream_t)s));
+                break;
+            }
             case CombineKind::MultiplyRelinearizeRescale: {
                 const troyn_plan* plan = static_cast<const troyn_plan*>(h.handle);
                 const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(plan, h.L, count);

@@ -996,8 +996,8 @@ void Evaluator::square(const Ciphertext& encrypted, Ciphertext& destination, Mem
 
 
 // -- key switching (evaluator_keyswitching_core.cu:757-1052, evaluator_keyswitching.cu:11-144) ---------------
-void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
-                                    SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const {
+// the argument checks of switch_key_internal (evaluator_keyswitching_core.cu:757-830), also run by a call that is handed to the combining rendezvous
+void Evaluator::switch_key_checks(const Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index, const Ciphertext& destination) const {
     const char* P = "[Evaluator::switch_key_inplace_internal]";
     check_no_seed(P, encrypted);
     if (!context_->using_keyswitching()) throw std::invalid_argument(std::string(P) + " Keyswitching is not supported.");
@@ -1016,6 +1016,15 @@ void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t*
         if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
     }
     check_on_device(P, context_, encrypted); check_on_device(P, context_, destination);
+}
+
+void Evaluator::switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
+                                    SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::switch_key_inplace_internal]";
+    switch_key_checks(encrypted, kswitch_keys, kswitch_keys_index, destination);
+    auto cd = get_context_data(P, encrypted.parms_id());
+    SchemeType scheme = cd->parms().scheme();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const size_t n = cd->parms().poly_modulus_degree();
     if (destination.polynomial_count() > 2 && assign_method != SwitchKeyDestinationAssignMethod::AddInplace)
         hip_check(hipMemsetAsync(destination.poly(2), 0, (destination.polynomial_count() - 2) * L * n * 8, current_stream()), "memset");
@@ -1543,6 +1552,18 @@ void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element,
     if (!galois_keys.has_key(galois_element)) throw std::invalid_argument(std::string(P) + " Galois key not present.");
     if (encrypted.polynomial_count() > 2) throw std::invalid_argument(std::string(P) + " Ciphertext size must be 2.");
     Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    if (cd->parms().scheme() != SchemeType::BGV && encrypted.polynomial_count() == 2 && detail::combining_wanted()) {
+        // call combining (troy.h): the rotations of concurrent threads by the same element run as one permutation + one key switch
+        const size_t idx = GaloisKeys::get_index(galois_element);
+        switch_key_checks(encrypted, galois_keys, idx, out);
+        const std::vector<const uint64_t*> ptrs = galois_keys.get_data_ptrs(idx);
+        detail::CombineRequest rq;
+        rq.kind = detail::CombineKind::ApplyGalois; rq.handle = context_->plan(); rq.L = L; rq.p1 = 2; rq.p2 = static_cast<uint32_t>(galois_element);
+        rq.ckks = cd->parms().scheme() == SchemeType::CKKS; rq.ntt_form = encrypted.is_ntt_form(); rq.keys = &ptrs;
+        rq.in1 = encrypted.data().raw_pointer(); rq.words1 = encrypted.data().size();
+        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+        if (detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
+    }
     troyn_check(troyn_apply_galois(context_->plan(), 0, L, encrypted.is_ntt_form() ? 1 : 0, galois_element,
                                    encrypted.data().raw_pointer(), out.data().raw_pointer(), 2, current_stream()));
     // the permuted c1 is the key-switch target; the result overwrites it (c0 += ks0, c1 = ks1)

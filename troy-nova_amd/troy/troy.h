@@ -1015,7 +1015,8 @@ private:
 // barely more than over one (tools/small_batch_sweep.py).  With combining on
 //   * every host thread's calls go to ONE shared stream instead of hipStreamPerThread (one order for everything the threads queue: no
 //     cross-stream dependencies, the pool may hand a block released by one thread to another at once);
-//   * a thread that enters multiply / relinearize / rescale_to_next / multiply_relinearize_rescale while other threads are doing the same
+//   * a thread that enters multiply / relinearize / rescale_to_next / multiply_relinearize_rescale / apply_galois (hence every rotation and
+//     complex_conjugate) while other threads are doing the same
 //     hands its (already checked) call to a rendezvous: the first thread to arrive leads, waits at most `window` for the other active
 //     threads, queues the calls of ITS shape as one library call (operands staged by one gather launch, results delivered to the
 //     callers' own arrays by one scatter launch) and every caller returns -- as with the uncombined call, the work is queued, not
@@ -1048,11 +1049,11 @@ void reset_stats();
 namespace detail {
 // one checked single-object call handed to the rendezvous (combine.cpp); the submitting thread has done every argument check and knows
 // the result's metadata, the leader only needs shapes and pointers
-enum class CombineKind : uint8_t { DyadicMultiply, BfvMultiply, Relinearize, Rescale, MultiplyRelinearizeRescale };
+enum class CombineKind : uint8_t { DyadicMultiply, BfvMultiply, Relinearize, Rescale, MultiplyRelinearizeRescale, ApplyGalois };
 struct CombineRequest {
     CombineKind kind;
     const void* handle = nullptr;                 // troyn_plan* (troyn_behz* for BfvMultiply): same context + level
-    uint32_t L = 0, p1 = 0, p2 = 0;               // limbs, polynomial counts of the operands
+    uint32_t L = 0, p1 = 0, p2 = 0;               // limbs, polynomial counts of the operands (ApplyGalois: p2 = the Galois element)
     bool ckks = false, ntt_form = false;
     const std::vector<const uint64_t*>* keys = nullptr;   // key-switching forms: the L key pointers (identity: the first pointer)
     const uint64_t* in1 = nullptr; size_t words1 = 0;
@@ -1348,6 +1349,7 @@ private:
                                  bool subtract, MemoryPoolHandle pool) const;
     void translate_batched(const std::vector<const Ciphertext*>& e1, const std::vector<const Ciphertext*>& e2, const std::vector<Ciphertext*>& d, bool subtract,
                            MemoryPoolHandle pool) const;
+    void switch_key_checks(const Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index, const Ciphertext& destination) const;
     void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
                              SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
