@@ -198,7 +198,7 @@ namespace detail {
 // spins; the GPU boxes give a process a CPU quota).  One waiter at a time calls hipStreamSynchronize; a thread is satisfied by a wait
 // that STARTED after it asked (that wait covers everything the thread had queued), the others sleep on a futex meanwhile.
 namespace {
-struct Waiter { std::atomic<int> word{0}; Waiter* wake[2] = {nullptr, nullptr}; };   // word: 0 waiting, 1 covered by a finished wait, 2 lead the next one
+struct Waiter { std::atomic<int> word{0}; Waiter* wake[4] = {}; };   // word: 0 waiting, 1 covered by a finished wait, 2 lead the next one
 struct WaitGroup {
     std::mutex m;
     bool running = false;
@@ -233,11 +233,11 @@ int combining_stream_wait(void* stream) {
     if (!w.pending.empty()) { next = &w.pending.front()->word; w.pending.erase(w.pending.begin()); }
     else w.running = false;
     lk.unlock();
-    for (size_t k = 0; k < covered.size(); k++) {
-        covered[k]->wake[0] = 2 * k + 2 < covered.size() ? covered[2 * k + 2] : nullptr;
-        covered[k]->wake[1] = 2 * k + 3 < covered.size() ? covered[2 * k + 3] : nullptr;
-    }
-    std::atomic<int>* root[2] = {covered.size() > 0 ? &covered[0]->word : nullptr, covered.size() > 1 ? &covered[1]->word : nullptr};
+    constexpr size_t F = 4;
+    for (size_t k = 0; k < covered.size(); k++)
+        for (size_t i = 0; i < F; i++) covered[k]->wake[i] = F * (k + 1) + i < covered.size() ? covered[F * (k + 1) + i] : nullptr;
+    std::atomic<int>* root[F];
+    for (size_t i = 0; i < F; i++) root[i] = i < covered.size() ? &covered[i]->word : nullptr;
     for (Waiter* x : covered) x->word.store(1, std::memory_order_release);   // from here on `x` may be gone
     for (std::atomic<int>* r : root) if (r) futex_wake(r);
     if (next) { next->store(2, std::memory_order_release); futex_wake(next); }
@@ -364,15 +364,16 @@ bool combine_submit(CombineRequest& request, MemoryPoolHandle pool) {
         std::lock_guard<std::mutex> g(c.m);
         c.st.execute_ns += (uint64_t)(now_ns() - e0);
     }
-    // release the callers as a tree: this thread wakes two, each of them two more on its way out
+    // release the callers as a tree: this thread wakes FANOUT of them, each of those FANOUT more on its way out
     std::vector<CombineRequest*> f;
     for (CombineRequest* r : batch) if (r != &request) f.push_back(r);
+    constexpr size_t F = CombineRequest::FANOUT;
     for (size_t k = 0; k < f.size(); k++) {
         f[k]->error = err;
-        f[k]->wake[0] = 2 * k + 2 < f.size() ? f[2 * k + 2] : nullptr;
-        f[k]->wake[1] = 2 * k + 3 < f.size() ? f[2 * k + 3] : nullptr;
+        for (size_t i = 0; i < F; i++) f[k]->wake[i] = F * (k + 1) + i < f.size() ? f[F * (k + 1) + i] : nullptr;
     }
-    std::atomic<int>* root[2] = {f.size() > 0 ? &f[0]->state : nullptr, f.size() > 1 ? &f[1]->state : nullptr};
+    std::atomic<int>* root[F];
+    for (size_t i = 0; i < F; i++) root[i] = i < f.size() ? &f[i]->state : nullptr;
     const int64_t rel = now_ns();
     for (CombineRequest* r : f) r->released_ns = rel;
     for (CombineRequest* r : f) r->state.store(DONE, std::memory_order_release);   // from here on `r` may be gone

@@ -1061,7 +1061,8 @@ struct CombineRequest {
     uint64_t* out = nullptr; size_t out_words = 0;   // the caller's own destination array (allocated by the calling thread from ITS share of the pool)
     // set by the leader
     std::exception_ptr error;
-    CombineRequest* wake[2] = {nullptr, nullptr};   // the waiters this one wakes on its way out (the release fans out as a tree: a wake costs
+    static constexpr size_t FANOUT = 4;
+    CombineRequest* wake[FANOUT] = {};              // the waiters this one wakes on its way out (the release fans out as a tree: a wake costs
                                                     // microseconds per sleeper, the leader alone would release 64 callers one after the other)
     std::atomic<int> state{0};
     int64_t released_ns = 0;
