@@ -42,6 +42,45 @@ static int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail((int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Small host tables (pointer lists, offsets) for kernels that index them travel through a per-thread ring of pinned slots: the copy is
+// then truly asynchronous and the caller's array may go away at once.  (Rounds 1-3 copied from the caller's pageable array and waited for
+// the STREAM before returning -- i.e. for every kernel queued before: MatmulHelper's 32 multiply-accumulate calls ran one at a time.)
+// A slot is reused after the copy that last read it has completed (its event); tables above the slot size take the old path.
+namespace {
+struct PinnedSlot { void* host = nullptr; hipEvent_t done = nullptr; };
+struct PinnedRing {
+    static constexpr size_t SLOTS = 8, BYTES = 256u << 10;
+    PinnedSlot slot[SLOTS];
+    size_t next = 0;
+};   // never destroyed: a host thread may end after the runtime has shut down
+}  // namespace
+static int upload_host_table(hipStream_t s, void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return TROYN_OK;
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    constexpr int MAX_DEVICES = 16;
+    static thread_local PinnedRing* rings[MAX_DEVICES] = {};
+    if (bytes > PinnedRing::BYTES || device < 0 || device >= MAX_DEVICES) {
+        HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));   // `host` belongs to the caller
+        return TROYN_OK;
+    }
+    if (!rings[device]) rings[device] = new PinnedRing;
+    PinnedRing& ring = *rings[device];
+    PinnedSlot& sl = ring.slot[ring.next];
+    ring.next = (ring.next + 1) % PinnedRing::SLOTS;
+    if (!sl.host) {
+        HIP_TRY(hipHostMalloc(&sl.host, PinnedRing::BYTES, hipHostMallocPortable));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipEventSynchronize(sl.done));
+    }
+    std::memcpy(sl.host, host, bytes);
+    HIP_TRY(hipMemcpyAsync(dev, sl.host, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(sl.done, s));
+    return TROYN_OK;
+}
+
 #define LAUNCH_CHECK()                                                                     \
     do {                                                                                   \
         hipError_t e_ = hipGetLastError();                                                 \
@@ -2047,8 +2086,7 @@ extern "C" int troyn_pack_prepare(const troyn_plan* p, uint32_t L, size_t pcount
     if (slots == 0 || pcount == 0) return TROYN_OK;
     if (workspace_bytes < troyn_pack_prepare_workspace_bytes(slots)) return fail(TROYN_E_WORKSPACE, "[troyn_pack_prepare] workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(workspace, src, slots * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // `src` belongs to the caller
+    if (int rc = upload_host_table(s, workspace, src, slots * sizeof(u64))) return rc;
     const size_t rows = slots * pcount * L;
     const unsigned ch = chunks_single(p->n);
     if (int rc = check_rows(rows, ch)) return rc;
@@ -2102,8 +2140,7 @@ extern "C" int troyn_extract_lwe(const troyn_plan* p, uint32_t L, const uint64_t
         t32[i] = (unsigned)terms[i];
     }
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (int rc = upload_host_table(s, workspace, tab.data(), tab.size() * sizeof(u64))) return rc;
     // c1 of the LWE = c1 of the RLWE shifted by 2N - term (term 0: unshifted), evaluator_lwes.cu:72-79
     const unsigned ch = chunks_single(p->n);
     for (size_t i = 0; i < count; i++) {
@@ -2250,8 +2287,7 @@ extern "C" int troyn_gather(const uint64_t* const* src, size_t count, size_t wor
         LAUNCH_CHECK();
         return TROYN_OK;
     }
-    HIP_TRY(hipMemcpyAsync(workspace, src, count * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // `src` belongs to the caller
+    if (int rc = upload_host_table(s, workspace, src, count * sizeof(u64))) return rc;
     hipLaunchKernelGGL(gather_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64* const*)workspace, words, (u64*)out);
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -2274,8 +2310,7 @@ extern "C" int troyn_scatter(const uint64_t* in, uint64_t* const* dst, size_t co
         LAUNCH_CHECK();
         return TROYN_OK;
     }
-    HIP_TRY(hipMemcpyAsync(workspace, dst, count * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // `dst` belongs to the caller
+    if (int rc = upload_host_table(s, workspace, dst, count * sizeof(u64))) return rc;
     hipLaunchKernelGGL(scatter_kernel, dim3(bx, (unsigned)count), dim3(256), 0, s, (const u64*)in, (u64* const*)workspace, words);
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -2313,8 +2348,7 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
     tab.insert(tab.end(), gdst.begin(), gdst.end());
     tab.insert(tab.end(), gstart.begin(), gstart.end());
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // `tab` is a host temporary
+    if (int rc = upload_host_table(s, workspace, tab.data(), tab.size() * sizeof(u64))) return rc;
     const unsigned ch = chunks_pairs(p->n);
     const int mac_gen = env_is("TROYN_PLAIN_MAC", "v1") ? 1 : 2;   // first-generation kernel (one polynomial per thread) for A/B runs
     if (pcount == 2 && mac_gen == 2) {

@@ -138,7 +138,6 @@ void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const
         const size_t bytes = troyn_bfv_multiply_workspace_bytes(bz, p1, p2, count);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check_public(troyn_bfv_multiply(bz, a, p1, b, p2, block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
-        troyn_sync_current_stream();
     } else {
         troyn_check_public(troyn_dyadic_convolute(context_->plan(), 0, L, a, p1, b, p2, block->raw_pointer(), count, stream()));
     }

@@ -135,8 +135,7 @@ void Evaluator::translate_plain_inplace(Ciphertext& encrypted, const Plaintext& 
                     // a partial RNS plaintext (BatchEncoder::scale_up of a short polynomial): zero-padded to the full shape first
                     const utils::DynamicArray full = plain.expanded_rns(L, n, pool);
                     troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), full.raw_pointer(), encrypted.poly(0), 1, stream()));
-                    troyn_sync_current_stream();
-                    break;
+                    break;   // `full` returns to the pool; the pool hands it back to this thread in stream order (MemoryPool, troy.h)
                 }
                 troyn_check_public((subtract ? troyn_sub : troyn_add)(context_->plan(), 0, L, encrypted.poly(0), plain.poly(), encrypted.poly(0), 1, stream()));
             }
@@ -172,7 +171,8 @@ void Evaluator::translate_plain_inplace(Ciphertext& encrypted, const Plaintext& 
         default:
             throw std::logic_error(std::string(P) + " Scheme not implemented.");
     }
-    troyn_sync_current_stream();
+    // asynchronous on the thread's stream like the reference's method; the temporaries above return to the pool, which hands a block back to
+    // the thread that released it in stream order (round 4: this was a stream wait per call -- 32 of them in MatmulHelper's bias add)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,7 +449,7 @@ void Evaluator::pack_rlwe_ciphertexts_batched(const std::vector<std::vector<cons
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check_public(troyn_switch_key(plan, L, scheme == SchemeType::CKKS, 0, target.raw_pointer(), keys.data(), TROYN_ASSIGN_ADD_INPLACE, next->raw_pointer(),
                                             ws.raw_pointer(), bytes, pairs, s));
-        troyn_sync_current_stream();   // `target`, `ws` and the previous buffer return to the pool
+        // `target`, `ws` and the previous buffer return to the pool here: stream order protects them (same thread, same stream), no wait per layer
         current = std::move(next);
         count = pairs;
     }

@@ -1456,7 +1456,7 @@ void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& 
             destination[i]->scale() = encrypted[i]->scale() * plain[i]->scale();
             if (!is_scale_within_bounds(destination[i]->scale(), cd)) throw std::invalid_argument("[Evaluator::multiply_plain_ntt_batched] Scale out of bounds.");   // evaluator_multiply_plain.cu:250,:301
         }
-    hip_check(stream_wait(), "stream_sync");
+    // asynchronous like the reference's method: the pointer table went through the library's pinned ring, `ws` returns to the pool in stream order
 }
 
 // ------------------------------------------------------------------------------------------------
