@@ -884,7 +884,7 @@ void Evaluator::translate(const Ciphertext& e1, const Ciphertext& e2, Ciphertext
         a.correction_factor() = f0;
         b.correction_factor() = f0;
         translate(a, b, destination, subtract, pool);
-        hip_check(stream_wait(), "stream_sync");
+        // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
         return;
     }
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
@@ -1156,7 +1156,7 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
         const size_t bytes = troyn_bgv_mod_switch_workspace_bytes(bg, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check(troyn_bgv_mod_t_and_divide_q_last_ntt(bg, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
-        hip_check(stream_wait(), "stream_sync");
+        // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
         const uint64_t t = next->parms().plain_modulus().value();
         out.correction_factor() = static_cast<uint64_t>((static_cast<unsigned __int128>(encrypted.correction_factor()) * troyn_bgv_inv_q_last_mod_t(bg)) % t);
     } else {
@@ -1571,7 +1571,7 @@ void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element,
     hip_check(hipMemcpyAsync(target.raw_pointer(), out.poly(1), static_cast<size_t>(L) * n * 8, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
     switch_key_internal(encrypted, target.raw_pointer(), galois_keys, GaloisKeys::get_index(galois_element),
                         SwitchKeyDestinationAssignMethod::OverwriteExceptFirst, out, pool);
-    hip_check(stream_wait(), "stream_sync");
+    // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
     destination = std::move(out);
 }
 
@@ -1841,7 +1841,7 @@ void Ciphertext::load_terms(std::istream& stream, HeContextPointer context, cons
     if (is_ntt_form_) {
         if (!context->on_device()) throw std::invalid_argument("[Ciphertext::load_terms] an NTT-form ciphertext is transformed on the GPU: the context must be on the device.");
         troyn_check(troyn_ntt(context->plan(), 0, data_.raw_pointer(), data_.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
-        hip_check(stream_wait(), "stream_sync");
+        // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
     }
     if (seeded) expand_seed(context);
 }
@@ -2439,7 +2439,7 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
             out.parms_id() = parms_id_zero;
             out.resize(n);
             troyn_check(troyn_bfv_decrypt_scale_and_round(context_->behz(L), phase.raw_pointer(), out.poly(), 1, current_stream()));
-            hip_check(stream_wait(), "stream_sync");
+            // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
             out.is_ntt_form() = false;
             out.coeff_modulus_size() = L;
             out.poly_modulus_degree() = n;
@@ -2469,7 +2469,7 @@ void Decryptor::decrypt(const Ciphertext& encrypted, Plaintext& destination, Mem
             out.parms_id() = parms_id_zero;
             out.resize(n);
             troyn_check(troyn_bgv_decrypt_mod_t(context_->bgv(L), phase.raw_pointer(), encrypted.correction_factor(), out.poly(), 1, current_stream()));
-            hip_check(stream_wait(), "stream_sync");
+            // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
             out.is_ntt_form() = false;
             out.coeff_modulus_size() = L;
             out.poly_modulus_degree() = n;
@@ -2683,7 +2683,7 @@ void BatchEncoder::encode(const std::vector<uint64_t>& values, Plaintext& destin
     out.resize(slots_);
     out.data().copy_from(buf.data(), slots_, false);
     troyn_check(troyn_ntt(context_->plain_plan(), 1, out.poly(), out.poly(), 1, 1, 1, 0, 1, TROYN_IDX_COMPONENTWISE, 0, current_stream()));
-    hip_check(stream_wait(), "stream_sync");
+    // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
     out.is_ntt_form() = false;
     out.poly_modulus_degree() = slots_;
     out.coeff_modulus_size() = context_->first_context_data().value()->parms().coeff_modulus().size();
