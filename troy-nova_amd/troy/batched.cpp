@@ -44,8 +44,7 @@ const uint64_t* contiguous(const std::vector<const Ciphertext*>& v, utils::Dynam
     for (size_t i = 0; i < count; i++) src[i] = v[i]->data().raw_pointer();
     const size_t bytes = troyn_gather_workspace_bytes(count);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
-    troyn_check_public(troyn_gather(src.data(), count, words, staged.raw_pointer(), ws.raw_pointer(), bytes, stream()));
-    troyn_sync_current_stream();   // `ws` returns to the pool
+    troyn_check_public(troyn_gather(src.data(), count, words, staged.raw_pointer(), ws.raw_pointer(), bytes, stream()));   // (`src` is consumed by the call)
     return staged.raw_pointer();
 }
 
@@ -55,7 +54,6 @@ std::shared_ptr<utils::DynamicArray> result_block(const Ciphertext& proto, size_
 }
 
 void assign_views(const Ciphertext& proto, const std::shared_ptr<utils::DynamicArray>& block, const std::vector<Ciphertext*>& destination) {
-    troyn_sync_current_stream();
     const size_t words = proto.data().size();
     for (size_t i = 0; i < destination.size(); i++)
         *destination[i] = Ciphertext::from_members(proto.polynomial_count(), proto.coeff_modulus_size(), proto.poly_modulus_degree(), proto.parms_id(), proto.scale(),

@@ -9,6 +9,9 @@
 
 #include "troy.h"
 
+// Every method here is asynchronous on the calling thread's stream, like the reference's: temporaries return to the pool, which hands a
+// block back to the thread that released it in stream order (rounds 1-3 waited for the stream at the end of each method).
+
 namespace troy {
 
 namespace {
@@ -119,7 +122,6 @@ Plaintext BatchEncoder::scale_up_new(const Plaintext& plain, std::optional<Parms
     d.data() = utils::DynamicArray(0, true, pool);
     d.resize_rns_partial(*context_, pid, cc);
     compact_rows(full.raw_pointer(), d.poly(), L, n, cc);
-    troyn_sync_current_stream();
     d.is_ntt_form() = false;
     return d;
 }
@@ -141,7 +143,6 @@ Plaintext BatchEncoder::centralize_new(const Plaintext& plain, std::optional<Par
     d.data() = utils::DynamicArray(0, true, pool);
     d.resize_rns_partial(*context_, pid, cc);
     compact_rows(full.raw_pointer(), d.poly(), L, n, cc);
-    troyn_sync_current_stream();
     d.is_ntt_form() = false;
     return d;
 }
@@ -160,7 +161,6 @@ Plaintext BatchEncoder::scale_down_new(const Plaintext& plain, MemoryPoolHandle 
     troyn_check_public(troyn_bfv_decrypt_scale_and_round(context_->behz(L), full.raw_pointer(), out.raw_pointer(), 1, troyn_current_stream()));
     Plaintext d = mod_t_like(plain, L, n, pool);
     hip_ok(hipMemcpyAsync(d.poly(), out.raw_pointer(), plain.coeff_count() * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
-    troyn_sync_current_stream();
     return d;
 }
 
@@ -179,7 +179,6 @@ Plaintext BatchEncoder::decentralize_new(const Plaintext& plain, uint64_t correc
     troyn_check_public(troyn_bgv_decrypt_mod_t(context_->bgv(L), full.raw_pointer(), correction_factor, out.raw_pointer(), 1, troyn_current_stream()));
     Plaintext d = mod_t_like(plain, L, n, pool);
     hip_ok(hipMemcpyAsync(d.poly(), out.raw_pointer(), plain.coeff_count() * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
-    troyn_sync_current_stream();
     return d;
 }
 
@@ -207,7 +206,6 @@ void Evaluator::apply_galois_plain(const Plaintext& plain, size_t galois_element
             hip_ok(hipMemcpyAsync(padded.raw_pointer(), plain.poly(), plain.coeff_count() * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
             out.resize(n);
             troyn_check_public(troyn_apply_galois_plain(context_->plan(), t, galois_element, padded.raw_pointer(), out.poly(), 1, troyn_current_stream()));
-            troyn_sync_current_stream();                  // `padded` returns to the pool
         }
     } else {
         // RNS plaintext of a level (CKKS, or BFV / BGV after scale_up / centralize): limb-wise, either form
@@ -217,7 +215,6 @@ void Evaluator::apply_galois_plain(const Plaintext& plain, size_t galois_element
         troyn_check_public(troyn_apply_galois(context_->plan(), 0, static_cast<uint32_t>(L), plain.is_ntt_form() ? 1 : 0, galois_element, plain.poly(), out.poly(), 1,
                                               troyn_current_stream()));
     }
-    troyn_sync_current_stream();
     destination = std::move(out);
 }
 
@@ -249,7 +246,6 @@ void CKKSEncoder::encode_integer64_polynomial(const std::vector<int64_t>& values
     out.data().copy_from(host.data(), host.size(), false);
     troyn_check_public(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0,
                                  troyn_current_stream()));
-    troyn_sync_current_stream();
     out.scale() = 1.0;
     out.is_ntt_form() = true;
     destination = std::move(out);
@@ -275,7 +271,6 @@ void Evaluator::bfv_centralize(const Plaintext& plain, const ParmsID& parms_id, 
     out.resize_rns(*context_, parms_id);
     troyn_check_public(troyn_plain_centralize(context_->plan(), static_cast<uint32_t>(L), cd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n, out.poly(), 1,
                                               troyn_current_stream()));
-    troyn_sync_current_stream();
     out.is_ntt_form() = false;
     out.scale() = plain.scale();
     destination = std::move(out);
@@ -295,7 +290,6 @@ void Evaluator::bfv_scale_up(const Plaintext& plain, const ParmsID& parms_id, Pl
     out.resize_rns(*context_, parms_id);
     hip_ok(hipMemsetAsync(out.poly(), 0, L * n * sizeof(uint64_t), stream()), "memset");
     troyn_check_public(troyn_bfv_scale_up(context_->behz(L), plain.poly(), plain.coeff_count(), n, out.poly(), L * n, out.poly(), L * n, 0, 1, troyn_current_stream()));
-    troyn_sync_current_stream();
     out.is_ntt_form() = false;
     out.scale() = plain.scale();
     destination = std::move(out);
@@ -326,7 +320,6 @@ void Evaluator::transform_plain_from_ntt(const Plaintext& plain, Plaintext& dest
     Plaintext out = plain;
     out.data() = utils::DynamicArray(plain.data().size(), true, pool);
     troyn_check_public(troyn_ntt(context_->plan(), 1, plain.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, troyn_current_stream()));
-    troyn_sync_current_stream();
     out.is_ntt_form() = false;
     destination = std::move(out);
 }
