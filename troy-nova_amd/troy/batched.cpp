@@ -124,7 +124,7 @@ void Evaluator::multiply_batched(const std::vector<const Ciphertext*>& e1, const
         return;
     }
     Ciphertext proto;
-    multiply(*e1[0], *e2[0], proto, pool);
+    multiply_prepare(*e1[0], *e2[0], proto, pool);   // checks + shape of item 0 (a uniform batch), no device work
     const size_t count = e1.size(), p1 = e1[0]->polynomial_count(), p2 = e2[0]->polynomial_count();
     const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
     utils::DynamicArray s1(0, true, pool), s2(0, true, pool);
@@ -184,13 +184,13 @@ void Evaluator::relinearize_batched(const std::vector<const Ciphertext*>& encryp
         return;
     }
     Ciphertext proto;
-    relinearize_internal(*encrypted[0], relin_keys, 2, proto, pool);
+    std::vector<const uint64_t*> keys;
+    relinearize_prepare(*encrypted[0], relin_keys, proto, keys, pool);   // checks + shape of item 0, no device work
     const size_t count = encrypted.size();
     const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
     utils::DynamicArray staged(0, true, pool);
     const uint64_t* in = contiguous(encrypted, staged, pool);
     auto block = result_block(proto, count, pool);
-    const std::vector<const uint64_t*> keys = relin_keys.get_data_ptrs(RelinKeys::get_index(2));
     const size_t bytes = troyn_relinearize_workspace_bytes(context_->plan(), L, count);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
     const bool ckks = context_->key_context_data().value()->parms().scheme() == SchemeType::CKKS;
@@ -226,8 +226,12 @@ void Evaluator::rescale_to_next_batched(const std::vector<const Ciphertext*>& en
         for (size_t i = 0; i < encrypted.size(); i++) { Ciphertext out; rescale_to_next(*encrypted[i], out, pool); *destination[i] = std::move(out); }
         return;
     }
+    // rescale_to_next's own checks (evaluator_modswitch.cu:445-461), then checks + shape of item 0 without device work
+    if (encrypted[0]->contains_seed()) throw std::invalid_argument("[Evaluator::rescale_to_next] Argument contains seed.");
+    if (context_->last_parms_id() == encrypted[0]->parms_id()) throw std::invalid_argument("[Evaluator::rescale_to_next] End of modulus switching chain reached.");
+    if (context_->first_context_data().value()->parms().scheme() != SchemeType::CKKS) throw std::invalid_argument("[Evaluator::rescale_to_next] Cannot rescale BFV/BGV ciphertext.");
     Ciphertext proto;
-    rescale_to_next(*encrypted[0], proto, pool);
+    mod_switch_scale_prepare(*encrypted[0], proto, pool);
     const size_t count = encrypted.size(), pc = proto.polynomial_count();
     const uint32_t L = static_cast<uint32_t>(encrypted[0]->coeff_modulus_size());
     utils::DynamicArray staged(0, true, pool);

@@ -913,53 +913,24 @@ void Evaluator::translate_inplace(Ciphertext& e1, const Ciphertext& e2, bool sub
 
 
 // -- multiply / square (evaluator.cu:29-343) ------------------------------------------------------------
-void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, MemoryPoolHandle pool) const {
+// every argument check of multiply and the result object (allocated, metadata set) WITHOUT the product itself: shared by the method, by the
+// *_batched form (item 0 stands for a uniform batch) and by the call-combining rendezvous
+SchemeType Evaluator::multiply_prepare(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& out, MemoryPoolHandle pool) const {
     check_no_seed("[Evaluator::multiply]", e1); check_no_seed("[Evaluator::multiply]", e2);
     check_same_parms_id("[Evaluator::multiply]", e1, e2);
     check_on_device("[Evaluator::multiply]", context_, e1); check_on_device("[Evaluator::multiply]", context_, e2);
-    SchemeType scheme = context_->key_context_data().value()->parms().scheme();
+    const SchemeType scheme = context_->key_context_data().value()->parms().scheme();
     auto cd = get_context_data("[Evaluator::multiply]", e1.parms_id());
-    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     const size_t p1 = e1.polynomial_count(), p2 = e2.polynomial_count();
-    Ciphertext out = Ciphertext::like(e1, p1 + p2 - 1, false, pool);
-    // call combining (troy.h): every check is done and the result's metadata set here, the batch only needs shapes and pointers
-    if (detail::combining_wanted()) {
-        detail::CombineRequest rq;
-        rq.L = L; rq.p1 = static_cast<uint32_t>(p1); rq.p2 = static_cast<uint32_t>(p2);
-        rq.in1 = e1.data().raw_pointer(); rq.words1 = e1.data().size(); rq.in2 = e2.data().raw_pointer(); rq.words2 = e2.data().size();
-        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
-        bool ok = true;
-        if (scheme == SchemeType::BFV) {
-            check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e1); check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e2);
-            rq.kind = detail::CombineKind::BfvMultiply; rq.handle = context_->behz(L);
-        } else if (scheme == SchemeType::CKKS || scheme == SchemeType::BGV) {
-            const char* P = scheme == SchemeType::CKKS ? "[Evaluator::ckks_multiply_inplace]" : "[Evaluator::bgv_multiply]";
-            check_is_ntt_form(P, e1); check_is_ntt_form(P, e2);
-            rq.kind = detail::CombineKind::DyadicMultiply; rq.handle = context_->plan(); rq.ntt_form = true;
-            if (scheme == SchemeType::CKKS) {
-                out.scale() = e1.scale() * e2.scale();
-                if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument("[Evaluator::ckks_multiply] Scale out of bounds");
-            } else {
-                out.correction_factor() = (uint64_t)(((unsigned __int128)e1.correction_factor() * e2.correction_factor()) % cd->parms().plain_modulus().value());
-            }
-        } else ok = false;
-        if (ok && detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
-    }
     switch (scheme) {
-        case SchemeType::BFV: {
+        case SchemeType::BFV:
             check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e1); check_is_not_ntt_form("[Evaluator::bfv_multiply_inplace]", e2);
-            const troyn_behz* bz = context_->behz(L);
-            size_t bytes = troyn_bfv_multiply_workspace_bytes(bz, p1, p2, 1);
-            utils::DynamicArray ws((bytes + 7) / 8, true, pool);
-            troyn_check(troyn_bfv_multiply(bz, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(),
-                                           ws.raw_pointer(), bytes, 1, current_stream()));
+            out = Ciphertext::like(e1, p1 + p2 - 1, false, pool);
             break;
-        }
         case SchemeType::CKKS: case SchemeType::BGV: {
             const char* P = scheme == SchemeType::CKKS ? "[Evaluator::ckks_multiply_inplace]" : "[Evaluator::bgv_multiply]";
             check_is_ntt_form(P, e1); check_is_ntt_form(P, e2);
-            troyn_check(troyn_dyadic_convolute(context_->plan(), 0, L, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2,
-                                               out.data().raw_pointer(), 1, current_stream()));
+            out = Ciphertext::like(e1, p1 + p2 - 1, false, pool);
             if (scheme == SchemeType::CKKS) {
                 out.scale() = e1.scale() * e2.scale();
                 if (!is_scale_within_bounds(out.scale(), cd)) throw std::invalid_argument("[Evaluator::ckks_multiply] Scale out of bounds");   // evaluator.cu:140-143
@@ -970,6 +941,32 @@ void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext&
             break;
         }
         default: throw std::logic_error("[Evaluator::multiply] Scheme not implemented.");
+    }
+    return scheme;
+}
+
+void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& destination, MemoryPoolHandle pool) const {
+    Ciphertext out;
+    const SchemeType scheme = multiply_prepare(e1, e2, out, pool);
+    const uint32_t L = static_cast<uint32_t>(out.coeff_modulus_size());
+    const size_t p1 = e1.polynomial_count(), p2 = e2.polynomial_count();
+    // call combining (troy.h): the batch only needs shapes and pointers
+    if (detail::combining_wanted()) {
+        detail::CombineRequest rq;
+        rq.L = L; rq.p1 = static_cast<uint32_t>(p1); rq.p2 = static_cast<uint32_t>(p2);
+        rq.in1 = e1.data().raw_pointer(); rq.words1 = e1.data().size(); rq.in2 = e2.data().raw_pointer(); rq.words2 = e2.data().size();
+        rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
+        if (scheme == SchemeType::BFV) { rq.kind = detail::CombineKind::BfvMultiply; rq.handle = context_->behz(L); }
+        else { rq.kind = detail::CombineKind::DyadicMultiply; rq.handle = context_->plan(); rq.ntt_form = true; }
+        if (detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
+    }
+    if (scheme == SchemeType::BFV) {
+        const troyn_behz* bz = context_->behz(L);
+        size_t bytes = troyn_bfv_multiply_workspace_bytes(bz, p1, p2, 1);
+        utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        troyn_check(troyn_bfv_multiply(bz, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+    } else {
+        troyn_check(troyn_dyadic_convolute(context_->plan(), 0, L, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(), 1, current_stream()));
     }
     destination = std::move(out);
 }
@@ -1060,6 +1057,27 @@ void Evaluator::apply_keyswitching_inplace(Ciphertext& encrypted, const KSwitchK
     encrypted = std::move(d);
 }
 
+// 3 -> 2 components: every argument check of relinearize (evaluator_keyswitching.cu:119-144 and the key-switch checks behind it), the key
+// pointers and the result object WITHOUT the key switch: shared by the method, the *_batched form and the call-combining rendezvous
+void Evaluator::relinearize_prepare(const Ciphertext& encrypted, const RelinKeys& relin_keys, Ciphertext& out, std::vector<const uint64_t*>& key_ptrs, MemoryPoolHandle pool) const {
+    const char* P = "[Evaluator::relinearize_inplace_internal]";
+    check_no_seed(P, encrypted);
+    if (relin_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Relin keys has incorrect parms id.");
+    auto cd = get_context_data(P, encrypted.parms_id());
+    if (encrypted.polynomial_count() != 3) throw std::invalid_argument(std::string(P) + " Destination size must be at least 2 and less/equal to the size of the encrypted polynomial.");
+    check_on_device(P, context_, encrypted);
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    const size_t idx = RelinKeys::get_index(2);
+    if (idx >= relin_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
+    const SchemeType scheme = cd->parms().scheme();
+    if (scheme == SchemeType::BGV && !encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BGV ciphertexts are in NTT form.");
+    if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
+    if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
+    for (const auto& k : relin_keys.data()[idx]) if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
+    key_ptrs = relin_keys.get_data_ptrs(idx);
+    out = Ciphertext::like(encrypted, 2, false, pool);
+}
+
 void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, Ciphertext& destination, MemoryPoolHandle pool) const {
     // evaluator_keyswitching.cu:119-144
     const char* P = "[Evaluator::relinearize_inplace_internal]";
@@ -1074,15 +1092,10 @@ void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKey
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     if (encrypted_size == 3 && destination_size == 2) {
         // one call: switch_key(c2, Overwrite) + (c0, c1), the trailing add fused into the key-switch epilogue
-        size_t idx = RelinKeys::get_index(2);
-        if (idx >= relin_keys.data().size()) throw std::out_of_range(std::string(P) + " Key switch keys index out of range.");
-        SchemeType scheme = cd->parms().scheme();
-        if (scheme == SchemeType::BGV && !encrypted.is_ntt_form()) throw std::invalid_argument(std::string(P) + " BGV ciphertexts are in NTT form.");
-        if (!context_->using_keyswitching()) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Keyswitching is not supported.");
-        if (relin_keys.data()[idx].size() < L) throw std::invalid_argument(std::string(P) + " Key switching key has too few components for this level.");
-        for (const auto& k : relin_keys.data()[idx]) if (!k.on_device()) throw std::invalid_argument(std::string(P) + " Incompatible encryption parameters.");
-        std::vector<const uint64_t*> ptrs = relin_keys.get_data_ptrs(idx);
-        Ciphertext out = Ciphertext::like(encrypted, 2, false, pool);
+        Ciphertext out;
+        std::vector<const uint64_t*> ptrs;
+        relinearize_prepare(encrypted, relin_keys, out, ptrs, pool);
+        const SchemeType scheme = cd->parms().scheme();
         if (scheme != SchemeType::BGV && detail::combining_wanted()) {
             detail::CombineRequest rq;
             rq.kind = detail::CombineKind::Relinearize; rq.handle = context_->plan(); rq.L = L; rq.p1 = 3;
@@ -1121,32 +1134,37 @@ void Evaluator::relinearize_inplace_internal(Ciphertext& encrypted, const RelinK
 
 
 // -- modulus switching (evaluator_modswitch.cu) --------------------------------------------------------------
-void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
-    // evaluator_modswitch.cu:14-74
+// the argument checks of mod_switch_scale_to_next_internal (evaluator_modswitch.cu:14-74) and the result object one level down (allocated,
+// parms_id / form / CKKS scale set) WITHOUT the division: shared by the method, the *_batched forms and the call-combining rendezvous
+SchemeType Evaluator::mod_switch_scale_prepare(const Ciphertext& encrypted, Ciphertext& out, MemoryPoolHandle pool) const {
     const char* P = "[Evaluator::mod_switch_scale_to_next_internal]";
     auto cd = get_context_data(P, encrypted.parms_id());
-    SchemeType scheme = cd->parms().scheme();
+    const SchemeType scheme = cd->parms().scheme();
     if (scheme == SchemeType::BFV) check_is_not_ntt_form(P, encrypted);
     else if (scheme == SchemeType::CKKS || scheme == SchemeType::BGV) check_is_ntt_form(P, encrypted);
     else throw std::logic_error(std::string(P) + " Scheme not implemented.");
     if (!cd->next_context_data().has_value()) throw std::invalid_argument(std::string(P) + " Next context data is not set.");
     check_on_device(P, context_, encrypted);
-    ContextDataPointer next = cd->next_context_data().value();
     const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
+    out = Ciphertext::like(encrypted, encrypted.polynomial_count(), L - 1, false, pool);
+    out.parms_id() = cd->next_context_data().value()->parms_id();
+    out.is_ntt_form() = encrypted.is_ntt_form();
+    if (scheme == SchemeType::CKKS) out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
+    return scheme;
+}
+
+void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, Ciphertext& destination, MemoryPoolHandle pool) const {
+    // evaluator_modswitch.cu:14-74
+    Ciphertext out;
+    const SchemeType scheme = mod_switch_scale_prepare(encrypted, out, pool);
+    const uint32_t L = static_cast<uint32_t>(encrypted.coeff_modulus_size());
     const size_t pc = encrypted.polynomial_count();
-    Ciphertext out = Ciphertext::like(encrypted, pc, L - 1, false, pool);
-    out.parms_id() = next->parms_id();
     if (scheme == SchemeType::CKKS && detail::combining_wanted()) {
         detail::CombineRequest rq;
         rq.kind = detail::CombineKind::Rescale; rq.handle = context_->plan(); rq.L = L; rq.p1 = static_cast<uint32_t>(pc); rq.ckks = true; rq.ntt_form = true;
         rq.in1 = encrypted.data().raw_pointer(); rq.words1 = encrypted.data().size();
         rq.out = out.data().raw_pointer(); rq.out_words = out.data().size();
-        if (detail::combine_submit(rq, pool)) {
-            out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
-            out.is_ntt_form() = encrypted.is_ntt_form();
-            destination = std::move(out);
-            return;
-        }
+        if (detail::combine_submit(rq, pool)) { destination = std::move(out); return; }
     }
     if (scheme == SchemeType::BFV) {
         troyn_check(troyn_divide_and_round_q_last(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), 1, current_stream()));
@@ -1156,17 +1174,14 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
         const size_t bytes = troyn_bgv_mod_switch_workspace_bytes(bg, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check(troyn_bgv_mod_t_and_divide_q_last_ntt(bg, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
-        // (no stream wait: the temporaries return to the pool in stream order, the call is asynchronous like the reference's)
-        const uint64_t t = next->parms().plain_modulus().value();
+        const uint64_t t = context_->get_context_data(out.parms_id()).value()->parms().plain_modulus().value();
         out.correction_factor() = static_cast<uint64_t>((static_cast<unsigned __int128>(encrypted.correction_factor()) * troyn_bgv_inv_q_last_mod_t(bg)) % t);
     } else {
         size_t bytes = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), L, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check(troyn_divide_and_round_q_last_ntt(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(),
                                                       ws.raw_pointer(), bytes, 1, current_stream()));
-        out.scale() = encrypted.scale() / static_cast<double>(cd->parms().coeff_modulus()[L - 1].value());
     }
-    out.is_ntt_form() = encrypted.is_ntt_form();
     destination = std::move(out);
 }
 
