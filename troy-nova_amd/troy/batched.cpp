@@ -289,7 +289,8 @@ void Evaluator::apply_galois_batched(const std::vector<const Ciphertext*>& encry
         return;
     }
     Ciphertext proto;
-    apply_galois(*encrypted[0], galois_element, galois_keys, proto, pool);
+    std::vector<const uint64_t*> keys;
+    apply_galois_prepare(*encrypted[0], galois_element, galois_keys, proto, keys, pool);   // checks + shape of item 0, no device work
     const size_t count = encrypted.size(), n = proto.poly_modulus_degree();
     const uint32_t L = static_cast<uint32_t>(proto.coeff_modulus_size());
     const size_t pc = static_cast<size_t>(L) * n;
@@ -301,7 +302,6 @@ void Evaluator::apply_galois_batched(const std::vector<const Ciphertext*>& encry
     troyn_check_public(troyn_apply_galois(plan, 0, L, proto.is_ntt_form() ? 1 : 0, galois_element, in, block->raw_pointer(), count * 2, stream()));
     utils::DynamicArray target(count * pc, true, pool);
     hip_ok(hipMemcpy2DAsync(target.raw_pointer(), pc * 8, block->raw_pointer() + pc, 2 * pc * 8, pc * 8, count, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
-    const std::vector<const uint64_t*> keys = galois_keys.get_data_ptrs(GaloisKeys::get_index(galois_element));
     const size_t bytes = troyn_switch_key_workspace_bytes(plan, L, count);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
     const bool ckks = context_->key_context_data().value()->parms().scheme() == SchemeType::CKKS;

@@ -1554,24 +1554,34 @@ GaloisKeys KeyGenerator::create_galois_keys(bool save_seed, MemoryPoolHandle poo
     return create_galois_keys_from_elements(utils::galois_elements_all(n), save_seed, pool);
 }
 
-void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
-    // evaluator_keyswitching.cu:147-179
+// every argument check of apply_galois (evaluator_keyswitching.cu:147-179 and the key-switch checks behind it), the key pointers and the result
+// object WITHOUT the device work: shared by the method, apply_galois_batched and the call-combining rendezvous
+void Evaluator::apply_galois_prepare(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& out,
+                                     std::vector<const uint64_t*>& key_ptrs, MemoryPoolHandle pool) const {
     const char* P = "[Evaluator::apply_galois_inplace]";
     check_no_seed(P, encrypted);
     check_on_device(P, context_, encrypted);
     if (galois_keys.parms_id() != context_->key_parms_id()) throw std::invalid_argument(std::string(P) + " Galois keys has incorrect parms id.");
     auto cd = get_context_data(P, encrypted.parms_id());
     const size_t n = cd->parms().poly_modulus_degree();
-    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     if ((galois_element & 1) == 0 || galois_element > 2 * n) throw std::invalid_argument(std::string(P) + " Galois element is not valid.");
     if (!galois_keys.has_key(galois_element)) throw std::invalid_argument(std::string(P) + " Galois key not present.");
     if (encrypted.polynomial_count() > 2) throw std::invalid_argument(std::string(P) + " Ciphertext size must be 2.");
-    Ciphertext out = Ciphertext::like(encrypted, false, pool);
+    out = Ciphertext::like(encrypted, false, pool);
+    const size_t idx = GaloisKeys::get_index(galois_element);
+    switch_key_checks(encrypted, galois_keys, idx, out);
+    key_ptrs = galois_keys.get_data_ptrs(idx);
+}
+
+void Evaluator::apply_galois(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& destination, MemoryPoolHandle pool) const {
+    Ciphertext out;
+    std::vector<const uint64_t*> ptrs;
+    apply_galois_prepare(encrypted, galois_element, galois_keys, out, ptrs, pool);
+    auto cd = get_context_data("[Evaluator::apply_galois_inplace]", encrypted.parms_id());
+    const size_t n = cd->parms().poly_modulus_degree();
+    const uint32_t L = static_cast<uint32_t>(cd->parms().coeff_modulus().size());
     if (cd->parms().scheme() != SchemeType::BGV && encrypted.polynomial_count() == 2 && detail::combining_wanted()) {
         // call combining (troy.h): the rotations of concurrent threads by the same element run as one permutation + one key switch
-        const size_t idx = GaloisKeys::get_index(galois_element);
-        switch_key_checks(encrypted, galois_keys, idx, out);
-        const std::vector<const uint64_t*> ptrs = galois_keys.get_data_ptrs(idx);
         detail::CombineRequest rq;
         rq.kind = detail::CombineKind::ApplyGalois; rq.handle = context_->plan(); rq.L = L; rq.p1 = 2; rq.p2 = static_cast<uint32_t>(galois_element);
         rq.ckks = cd->parms().scheme() == SchemeType::CKKS; rq.ntt_form = encrypted.is_ntt_form(); rq.keys = &ptrs;

@@ -1355,6 +1355,8 @@ private:
     SchemeType multiply_prepare(const Ciphertext& e1, const Ciphertext& e2, Ciphertext& out, MemoryPoolHandle pool) const;
     void relinearize_prepare(const Ciphertext& encrypted, const RelinKeys& relin_keys, Ciphertext& out, std::vector<const uint64_t*>& key_ptrs, MemoryPoolHandle pool) const;
     SchemeType mod_switch_scale_prepare(const Ciphertext& encrypted, Ciphertext& out, MemoryPoolHandle pool) const;
+    void apply_galois_prepare(const Ciphertext& encrypted, size_t galois_element, const GaloisKeys& galois_keys, Ciphertext& out, std::vector<const uint64_t*>& key_ptrs,
+                              MemoryPoolHandle pool) const;
     void switch_key_internal(const Ciphertext& encrypted, const uint64_t* target, const KSwitchKeys& kswitch_keys, size_t kswitch_keys_index,
                              SwitchKeyDestinationAssignMethod assign_method, Ciphertext& destination, MemoryPoolHandle pool) const;
     void relinearize_inplace_internal(Ciphertext& encrypted, const RelinKeys& relin_keys, size_t destination_size, MemoryPoolHandle pool) const;
