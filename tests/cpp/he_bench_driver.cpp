@@ -301,8 +301,10 @@ int main(int argc, char** argv) {
                         for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05;) { once(); troyn_sync_current_stream(); }
                         ready.fetch_add(1);
                         while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
-                        for (size_t r = 0; r < reps; r++) once();
-                        troyn_sync_current_stream();
+                        // a stream wait behind every op, as the reference's tool does (he_operations.cu:711-720).  The methods themselves no longer
+                        // wait (round 4); without this wait 4 threads x batch 1024 queue ten ops deep each and the three-call chain drops from 198 k
+                        // to 134 k ops/s (kernels of four saturating launch sequences interleave on the GPU), every other shape gains 0-4 %
+                        for (size_t r = 0; r < reps; r++) { once(); troyn_sync_current_stream(); }
                     };
                     std::vector<std::thread> th;
                     for (size_t t = 0; t < threads; t++) th.emplace_back(body, t);
