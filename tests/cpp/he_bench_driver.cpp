@@ -259,10 +259,9 @@ int main(int argc, char** argv) {
                 std::printf("single_threads%zu_combined_gather_us_per_batch %.1f\n", threads, st.batches ? (double)st.gather_ns / 1e3 / (double)(st.batches + st.uncombined) : 0.0);
                 std::printf("single_threads%zu_combined_execute_us_per_batch %.1f\n", threads, st.batches ? (double)st.execute_ns / 1e3 / (double)st.batches : 0.0);
                 std::printf("single_threads%zu_combined_uncombined_calls %llu\n", threads, (unsigned long long)st.uncombined);
-                std::printf("single_threads%zu_combined_caller_us_between_calls %.1f (no wait in between), %.1f (with a stream wait); release lag %.1f us\n", threads,
+                std::printf("single_threads%zu_combined_caller_us_between_calls %.1f (no wait in between), %.1f (with a stream wait)\n", threads,
                             st.between_calls ? (double)st.between_ns / 1e3 / (double)st.between_calls : 0.0,
-                            st.between_wait_calls ? (double)st.between_wait_ns / 1e3 / (double)st.between_wait_calls : 0.0,
-                            st.release_lag_calls ? (double)st.release_lag_ns / 1e3 / (double)st.release_lag_calls : 0.0);
+                            st.between_wait_calls ? (double)st.between_wait_ns / 1e3 / (double)st.between_wait_calls : 0.0);
                 std::printf("single_threads%zu_combined_arrival_spread_us %.1f\n", threads, (double)st.spread_ns / 1e3 / (double)std::max<uint64_t>(1, st.batches + st.uncombined));
                 std::printf("single_threads%zu_combined_window_expired %llu of %llu leaders, mean target %.1f\n", threads, (unsigned long long)st.window_expired,
                             (unsigned long long)(st.batches + st.uncombined), (double)st.target_sum / (double)std::max<uint64_t>(1, st.batches + st.uncombined));

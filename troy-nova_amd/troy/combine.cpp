@@ -287,11 +287,6 @@ bool combine_submit(CombineRequest& request, MemoryPoolHandle pool) {
         }
         if (s == DONE) {
             for (CombineRequest* k : request.wake) if (k) futex_wake(&k->state);   // by address only: `k` may have left already
-            {
-                const int64_t lag = now_ns() - request.released_ns;
-                std::lock_guard<std::mutex> g(c.m);
-                c.st.release_lag_ns += (uint64_t)lag; c.st.release_lag_calls += 1;
-            }
             if (request.error) std::rethrow_exception(request.error);
             return true;
         }
@@ -374,8 +369,6 @@ bool combine_submit(CombineRequest& request, MemoryPoolHandle pool) {
     }
     std::atomic<int>* root[F];
     for (size_t i = 0; i < F; i++) root[i] = i < f.size() ? &f[i]->state : nullptr;
-    const int64_t rel = now_ns();
-    for (CombineRequest* r : f) r->released_ns = rel;
     for (CombineRequest* r : f) r->state.store(DONE, std::memory_order_release);   // from here on `r` may be gone
     for (std::atomic<int>* w : root) if (w) futex_wake(w);
     if (err) std::rethrow_exception(err);

@@ -1038,7 +1038,6 @@ struct Stats {
     uint64_t gather_ns = 0, execute_ns = 0;               // leaders: time spent waiting for the others / running and waiting for the batch
     uint64_t between_ns = 0, between_calls = 0;           // callers: time from leaving one combined call to entering the next (host work of the caller)
     uint64_t between_wait_ns = 0, between_wait_calls = 0; // the same when the caller waited for the stream in between
-    uint64_t release_lag_ns = 0, release_lag_calls = 0;   // from the leader's release to the waiting caller leaving the call
     uint64_t spread_ns = 0;                               // first to last arrival of a batch
     uint64_t window_expired = 0, target_sum = 0;          // leaders that stopped waiting because the window passed; sum of the thread counts they waited for
 };
@@ -1065,7 +1064,6 @@ struct CombineRequest {
     CombineRequest* wake[FANOUT] = {};              // the waiters this one wakes on its way out (the release fans out as a tree: a wake costs
                                                     // microseconds per sleeper, the leader alone would release 64 callers one after the other)
     std::atomic<int> state{0};
-    int64_t released_ns = 0;
 };
 // true: the call ran as part of a batch (or failed there: throws); false: not combined, the caller runs it itself
 bool combine_submit(CombineRequest& request, MemoryPoolHandle pool);
