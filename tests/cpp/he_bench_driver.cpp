@@ -308,10 +308,14 @@ int main(int argc, char** argv) {
                     std::vector<std::thread> th;
                     for (size_t t = 0; t < threads; t++) th.emplace_back(body, t);
                     while (ready.load() < threads) std::this_thread::yield();
+                    const uint64_t mallocs0 = MemoryPool::device_allocations();
                     auto t0 = clk::now();
                     go.store(true, std::memory_order_release);
                     for (auto& x : th) x.join();
                     const double mx = secs(t0, clk::now());
+                    if (MemoryPool::device_allocations() != mallocs0)
+                        std::printf("note batched_%s_threads%zu_batch%zu: %llu device allocations inside the timed loop\n", fused ? "fused" : "three_calls", threads, B,
+                                    (unsigned long long)(MemoryPool::device_allocations() - mallocs0));
                     const size_t repeat_used = reps;
                     std::printf("batched_%s_threads%zu_batch%zu_ops_per_s %.1f\n", fused ? "fused" : "three_calls", threads, B, (double)(threads * B * repeat_used) / mx);
                 }

@@ -157,6 +157,9 @@ void MemoryPool::Destroy() {
 // memory a block another LIVE thread released, again behind a device-wide synchronisation.  Round 3 took any foreign block before
 // trying hipMalloc: with N host threads working on single objects (the reference's -c N mode) blocks migrated between threads all the
 // time and every migration was a hipDeviceSynchronize -- 16 threads ran at the speed of 3 (tests/cpp/he_bench_driver threads).
+static std::atomic<uint64_t> g_pool_mallocs{0};
+uint64_t MemoryPool::device_allocations() { return g_pool_mallocs.load(std::memory_order_relaxed); }
+
 void* MemoryPool::allocate(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
@@ -188,6 +191,7 @@ void* MemoryPool::allocate(size_t bytes) {
         if (void* q = take(0)) return q;
     }
     void* p = nullptr;
+    g_pool_mallocs.fetch_add(1, std::memory_order_relaxed);
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         hip_check(hipDeviceSynchronize(), "device_synchronize");

@@ -159,6 +159,7 @@ public:
     void* allocate(size_t bytes);
     void release(void* ptr);
     void release_unused();
+    static uint64_t device_allocations();   // hipMalloc calls of all pools so far (a steady-state loop should not add any)
     void disown(uint64_t thread_tag);   // internal: the blocks that thread released have no work pending any more (~0: every block)
 private:
     size_t device_;
