@@ -463,7 +463,12 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         other["cfg4"]["note"] = "BASELINE configs[3] on one GPU with a 256-op job per step (`bench.py --workload cfg4` runs the 1024-op job and shards it over --gpus ranks)"
         torch.cuda.empty_cache()
         other["cfg5"] = run_cfg5(args, torch, pkg, entry, device)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info()
         other["cpp_api"] = run_cpp_api()
+        other["cpp_api"]["device_memory_free_before_GB"] = round(free_b / 2**30, 1)
         result["other_configs"] = other
     return result
 

@@ -267,6 +267,7 @@ int main(int argc, char** argv) {
                             (unsigned long long)(st.batches + st.uncombined), (double)st.target_sum / (double)std::max<uint64_t>(1, st.batches + st.uncombined));
             }
             combining::set_enabled(false);
+            MemoryPool::GlobalPool()->release_unused();
         }
 
         if (threads_only) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
@@ -318,6 +319,9 @@ int main(int argc, char** argv) {
                                     (unsigned long long)(MemoryPool::device_allocations() - mallocs0));
                     const size_t repeat_used = reps;
                     std::printf("batched_%s_threads%zu_batch%zu_ops_per_s %.1f\n", fused ? "fused" : "three_calls", threads, B, (double)(threads * B * repeat_used) / mx);
+                    // the blocks this configuration's threads cached (tens of GB at batch 1024) are of no use to the next one: give them back, or the
+                    // device fills up over the sweep and a later timed loop pays for the pool's out-of-memory path (seen as 134 k instead of 200 k)
+                    MemoryPool::GlobalPool()->release_unused();
                 }
             }
         }
