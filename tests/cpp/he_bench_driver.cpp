@@ -297,8 +297,10 @@ int main(int argc, char** argv) {
                             if (fused) ev.multiply_relinearize_rescale_batched(pa, pb, w.rk, pd);
                             else { ev.multiply_batched(pa, pb, q1); ev.relinearize_batched(pt1, w.rk, q2); ev.rescale_to_next_batched(pt2, pd); }
                         };
-                        // the clocks need 20-25 ms of load to come up after an idle gap: 50 ms of warm-up
-                        for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05;) { once(); troyn_sync_current_stream(); }
+                        // the clocks need 20-25 ms of load to come up after an idle gap: 50 ms of warm-up -- and at least 8 ops: the pool settles after a
+                        // few (an op's result block is released while the next op already holds its own, and a request may take a block up to twice its
+                        // size), and a hipMalloc of gigabytes inside the timed loop costs milliseconds (tens, when the memory was last used by another process)
+                        { size_t it = 0; for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05 || it < 8; it++) { once(); troyn_sync_current_stream(); } }
                         ready.fetch_add(1);
                         while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
                         // a stream wait behind every op, as the reference's tool does (he_operations.cu:711-720).  The methods themselves no longer
