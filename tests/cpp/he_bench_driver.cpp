@@ -6,7 +6,7 @@
 //     multiply_relinearize_rescale_batched;  1 and 4 host threads (the tool's -c option), every thread with its own operands.
 // Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
 // decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
-//   he_bench_driver [check|bench|threads|single] [repeat]
+//   he_bench_driver [check|bench|threads|single|stress] [repeat]
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -176,6 +176,58 @@ int main(int argc, char** argv) {
             combining::set_enabled(false);
             std::printf("combined_alone_calls %llu\n", (unsigned long long)combining::stats().calls);
             std::printf("combined_alone_identical %d\n", same_ct(alone, want1[0]) ? 1 : 0);
+        }
+        if (argc > 1 && std::strcmp(argv[1], "stress") == 0) {
+            // ---- call combining under ragged arrival: 24 threads, random op kinds (three calls / fused / only the multiply), two levels, random pauses,
+            // occasional stream waits, threads that start late and leave early; every result is compared with the uncombined one -------------------------
+            const size_t T = 24, ops = repeat > 20 ? repeat : 120;
+            std::vector<Ciphertext> a(2 * T), b(2 * T), want3(2 * T), want1(2 * T), wantm(2 * T);
+            std::vector<cd> z;
+            for (size_t t = 0; t < 2 * T; t++) {
+                a[t] = fresh(z); b[t] = fresh(z);
+                if (t >= T) { ev.mod_switch_to_next_inplace(a[t]); ev.mod_switch_to_next_inplace(b[t]); }   // the second half one level down
+                wantm[t] = ev.multiply_new(a[t], b[t]);
+                want3[t] = ev.relinearize_new(wantm[t], w.rk); ev.rescale_to_next_inplace(want3[t]);
+                want1[t] = ev.multiply_relinearize_rescale_new(a[t], b[t], w.rk);
+            }
+            troyn_sync_current_stream();
+            combining::reset_stats();
+            combining::set_enabled(true);
+            std::atomic<size_t> bad{0}, done{0};
+            auto body = [&](size_t t) {
+                try {
+                    std::mt19937_64 g(77 + t);
+                    if (t % 5 == 4) std::this_thread::sleep_for(std::chrono::milliseconds(3));     // late starters
+                    const size_t mine = t % 7 == 6 ? ops / 3 : ops;                               // early leavers
+                    for (size_t i = 0; i < mine; i++) {
+                        const size_t k = (g() & 1) ? t : t + T;                                    // level
+                        const unsigned kind = (unsigned)(g() % 3);
+                        if (kind == 0) {
+                            Ciphertext s = ev.rescale_to_next_new(ev.relinearize_new(ev.multiply_new(a[k], b[k]), w.rk));
+                            if (!same_ct(s, want3[k])) bad++;
+                        } else if (kind == 1) {
+                            Ciphertext f = ev.multiply_relinearize_rescale_new(a[k], b[k], w.rk);
+                            if (!same_ct(f, want1[k])) bad++;
+                        } else {
+                            Ciphertext m = ev.multiply_new(a[k], b[k]);
+                            if (g() % 4 == 0) troyn_sync_current_stream();
+                            if (!same_ct(m, wantm[k])) bad++;
+                        }
+                        if (g() % 3 == 0) std::this_thread::sleep_for(std::chrono::microseconds(g() % 200));
+                        done++;
+                    }
+                } catch (const std::exception& e) { std::printf("stress thread %zu EXCEPTION %s\n", t, e.what()); bad++; }
+            };
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < T; t++) th.emplace_back(body, t);
+            for (auto& x : th) x.join();
+            combining::set_enabled(false);
+            const combining::Stats st = combining::stats();
+            std::printf("stress_ops %zu\nstress_wrong %zu\nstress_combined_calls %llu\nstress_batches %llu\nstress_largest_batch %llu\n", done.load(), bad.load(),
+                        (unsigned long long)st.calls, (unsigned long long)st.batches, (unsigned long long)st.largest_batch);
+            std::printf(bad.load() == 0 ? "OK\n" : "FAIL\n");
+            MemoryPool::Destroy();
+            return bad.load() == 0 ? 0 : 1;
         }
         if (!bench) { std::printf("OK\n"); MemoryPool::Destroy(); return 0; }
 

@@ -236,6 +236,18 @@ def test_multithread_cpp_api(dev):
     assert r.returncode == 0 and "completed 32 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_call_combining_stress_cpp_api(dev):
+    """Call combining under ragged arrival: 24 host threads x 300 ops of random kind (three calls / fused / multiply alone) on two levels with
+    random pauses, stream waits, late starters and early leavers; every result word-identical to the uncombined call, nothing hangs."""
+    drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/he_bench_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "stress", "300"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert kv["stress_wrong"][0] == "0" and int(kv["stress_ops"][0]) >= 24 * 100 and int(kv["stress_combined_calls"][0]) > 0, r.stdout
+
+
 def test_multithread_call_combining_cpp_api(dev):
     """The same program (BFV: encrypt -> multiply -> relinearize -> add -> mod-switch -> decrypt on 8 host threads) with TROY_COMBINE=1:
     one shared stream, the multiply / relinearize calls of concurrent threads run as batches (troy.h "Call combining"), the other calls
