@@ -35,10 +35,18 @@ def test_centralize_and_multiply_plain(O, pkg, dev, n, bits, t):
         assert np.array_equal(pkg.to_host(shared)[i], ctx.multiply_plain_ntt(L, dct_h[i], ptn_h[0]))
 
 
+@pytest.mark.parametrize("mode", [None, "single", "dual"], ids=["default", "one_destination", "two_destinations"])
 @pytest.mark.parametrize("n,bits,B,I,J", [(4096, [36, 36, 37], 2, 5, 3), (8192, [60, 40, 40, 60], 1, 40, 2), (32, [40, 40, 40], 3, 2, 2),
-                                        (2048, [60, 60, 61 - 1], 1, 71, 2)])   # 71 terms of 60-bit residues: two lazy-sum folds + a 3-term remainder
-def test_multiply_plain_accumulate_matmul_pattern(O, pkg, dev, n, bits, B, I, J):
-    """ret[b][j] = sum_i a[b][i] (.) w[i][j]  (MatmulHelper::matmul, app/matmul.cu:352-370) in ONE launch"""
+                                        (2048, [60, 60, 61 - 1], 1, 71, 2),    # 71 terms of 60-bit residues: two lazy-sum folds + a 3-term remainder
+                                        (4096, [36, 36, 37], 2, 5, 4), (2048, [60, 60, 61 - 1], 1, 67, 8)])   # J % 4 == 0: four destinations per workgroup by default
+def test_multiply_plain_accumulate_matmul_pattern(O, pkg, dev, monkeypatch, mode, n, bits, B, I, J):
+    """ret[b][j] = sum_i a[b][i] (.) w[i][j]  (MatmulHelper::matmul, app/matmul.cu:352-370) in ONE launch; destinations that share their
+    ciphertext operands are computed 4 / 2 / 1 per workgroup (TROYN_PLAIN_MAC, read per call)"""
+    monkeypatch.delenv("TROYN_PLAIN_MAC", raising=False)
+    if mode:
+        if J % 2 and mode == "dual":
+            pytest.skip("an odd number of columns never pairs")
+        monkeypatch.setenv("TROYN_PLAIN_MAC", mode)
     q = [int(v) for v in O.coeff_modulus_create(n, bits)]
     ctx = O.Context("bfv", n, q, 1 << 16)
     plan = pkg.Plan(dev, n.bit_length() - 1, q)

@@ -48,7 +48,14 @@ def run(pt, dst, env):
 
 
 import bench
-for name, pt, dst, env in (("reference layout", pts, d1, None), ("packed layout", ppk, d2, "packed"), ("reference layout", pts, d1, None), ("packed layout", ppk, d2, "packed")):
+out3 = torch.empty_like(out)
+d3 = [out3[j].data_ptr() for j in range(J) for i in range(I)]
+out4 = torch.empty_like(out)
+d4 = [out4[j].data_ptr() for j in range(J) for i in range(I)]
+for name, pt, dst, env in (("one destination / workgroup", pts, d3, "single"), ("two destinations / workgroup", pts, d4, "dual"), ("four destinations / workgroup", pts, d1, None),
+                           ("packed layout", ppk, d2, "packed"),
+                           ("one destination / workgroup", pts, d3, "single"), ("two destinations / workgroup", pts, d4, "dual"), ("four destinations / workgroup", pts, d1, None),
+                           ("packed layout", ppk, d2, "packed")):
     for _ in range(30):
         run(pt, dst, env)
     torch.cuda.synchronize()
@@ -58,5 +65,5 @@ for name, pt, dst, env in (("reference layout", pts, d1, None), ("packed layout"
         torch.cuda.synchronize()
         ms, cnt = kt.read()
     alg = terms * L * n * 8.0 + I * 2 * L * n * 8.0 + J * 2 * L * n * 8.0
-    print("%-18s launch %.4f ms  %.1f GB/s  (%.3f of 8 TB/s)" % (name, ms / cnt, alg / (ms / cnt * 1e-3) / 1e9, alg / (ms / cnt * 1e-3) / 8e12))
-print("identical results:", bool(torch.equal(out, out2)))
+    print("%-30s launch %.4f ms  %.1f GB/s  (%.3f of 8 TB/s)" % (name, ms / cnt, alg / (ms / cnt * 1e-3) / 1e9, alg / (ms / cnt * 1e-3) / 8e12))
+print("identical results:", bool(torch.equal(out, out2)) and bool(torch.equal(out, out3)) and bool(torch.equal(out, out4)))

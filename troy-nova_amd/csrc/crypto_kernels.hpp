@@ -358,6 +358,89 @@ __global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_kernel(unsigned chunks,
     }
 }
 
+// ND destinations per workgroup (round 4): ND consecutive destinations share their ciphertext operands term by term (a matmul row: every output
+// column multiplies the same input ciphertexts by its own weights; the host checks it), so a ciphertext word is loaded once for both.  The launch
+// streams every weight once from HBM whatever the tiling; what the grouping divides by ND is the ciphertext traffic from L2 to the CUs (two thirds of
+// the vector-memory bytes of the one-destination kernel).
+template <int PC, int ND>
+__global__ __launch_bounds__(POLY_BLOCK) void plain_mac2_multi_kernel(unsigned chunks, const DevModulus* mods, unsigned mod_start, unsigned nmod, unsigned n,
+                                                                      const u64* tab, unsigned count, unsigned groups, int set_zero) {
+    const unsigned row = blk_row(chunks);
+    const unsigned l = row % nmod;
+    const unsigned gp = row / nmod;                       // group of ND destinations
+    const DevModulus md = mods[mod_start + l];
+    const u64* const* cts = reinterpret_cast<const u64* const*>(tab);
+    const u64* const* pts = reinterpret_cast<const u64* const*>(tab + count);
+    u64* const* dsts = reinterpret_cast<u64* const*>(tab + 2 * (size_t)count) + (size_t)ND * gp;
+    const u64* starts = tab + 2 * (size_t)count + groups + (size_t)ND * gp;
+    const unsigned k0 = (unsigned)starts[0], terms = (unsigned)starts[1] - k0;   // every destination of the group has `terms` terms, laid out back to back
+    const size_t pstride = (size_t)nmod * n, loff = (size_t)l * n;
+    auto ldw = [](const u64* p) {
+        typedef u64 v2 __attribute__((ext_vector_type(2)));
+        const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+        return u64x2{v.x, v.y};
+    };
+    for (unsigned i = blk_col(chunks) * 2; i < n; i += chunks * blockDim.x * 2) {
+        u64 lo[ND][PC][2], hi[ND][PC][2], r[ND][PC][2];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int p = 0; p < PC; ++p) { lo[d][p][0] = lo[d][p][1] = hi[d][p][0] = hi[d][p][1] = 0; r[d][p][0] = r[d][p][1] = 0; }
+        auto fold = [&]() {      // 32 products of 61-bit residues stay below 2^128
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int p = 0; p < PC; ++p) {
+                    r[d][p][0] = add_mod(r[d][p][0], barrett128(lo[d][p][0], hi[d][p][0], md.q, md.ratio_lo, md.ratio_hi), md.q);
+                    r[d][p][1] = add_mod(r[d][p][1], barrett128(lo[d][p][1], hi[d][p][1], md.q, md.ratio_lo, md.ratio_hi), md.q);
+                    lo[d][p][0] = lo[d][p][1] = hi[d][p][0] = hi[d][p][1] = 0;
+                }
+        };
+        constexpr int U = ND == 2 ? 4 : 2;    // terms in flight per step
+        unsigned j = 0, pending = 0;
+        for (; j + U <= terms; j += U) {
+            u64x2 w[U][ND], c[U][PC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const u64* pc = cts[k0 + j + u];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) w[u][d] = ldw(pts[k0 + (unsigned)d * terms + j + u] + loff + i);
+#pragma unroll
+                for (int p = 0; p < PC; ++p) c[u][p] = ld2(pc + p * pstride + loff + i);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < PC; ++p)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) { mac128(lo[d][p][0], hi[d][p][0], c[u][p].a, w[u][d].a); mac128(lo[d][p][1], hi[d][p][1], c[u][p].b, w[u][d].b); }
+            pending += U;
+            if (pending == 32) { fold(); pending = 0; }
+        }
+        for (; j < terms; ++j) {
+            u64x2 w[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) w[d] = ldw(pts[k0 + (unsigned)d * terms + j] + loff + i);
+#pragma unroll
+            for (int p = 0; p < PC; ++p) {
+                const u64x2 c = ld2(cts[k0 + j] + p * pstride + loff + i);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { mac128(lo[d][p][0], hi[d][p][0], c.a, w[d].a); mac128(lo[d][p][1], hi[d][p][1], c.b, w[d].b); }
+            }
+        }
+        fold();
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int p = 0; p < PC; ++p) {
+                u64 a0 = r[d][p][0], a1 = r[d][p][1];
+                u64* dp = dsts[d] + p * pstride + loff + i;
+                if (!set_zero) { const u64x2 dv = ld2(dp); a0 = add_mod(a0, dv.a, md.q); a1 = add_mod(a1, dv.b, md.q); }
+                st2(dp, a0, a1);
+            }
+    }
+}
+
 // ---- Galois automorphisms ---------------------------------------------------------------
 // GaloisTool::apply_ps (utils/galois.cu:168-185): coefficient form, X -> X^g: out[i*g mod N] = +/- in[i]
 // GaloisTool::apply_ntt_ps (:24-41 table + gather): NTT form, out[i] = in[table(i)],

@@ -2355,6 +2355,36 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
         const size_t rows2 = groups * nmod;
         if (int rc = check_rows(rows2, ch)) return rc;
         TimerScope ts(TROYN_TIMER_PLAIN_MAC, s);
+        // ND consecutive destinations with the same ciphertext operands term by term (the columns of a matmul row) share one workgroup: every
+        // ciphertext word is loaded once for all of them (TROYN_PLAIN_MAC=single / dual / quad forces the grouping; A/B, tests)
+        auto shared_operands = [&](size_t nd) {
+            if (groups < nd || groups % nd != 0) return false;
+            for (size_t g = 0; g < groups; g += nd) {
+                const size_t a0 = (size_t)gstart[g], len = (size_t)gstart[g + 1] - a0;
+                for (size_t d = 1; d < nd; d++) {
+                    const size_t b0 = (size_t)gstart[g + d];
+                    if ((size_t)gstart[g + d + 1] - b0 != len || b0 != a0 + d * len) return false;
+                    for (size_t j = 0; j < len; j++) if (tab[a0 + j] != tab[b0 + j]) return false;
+                }
+            }
+            return true;
+        };
+        size_t nd = 1;
+        if (!env_is("TROYN_PLAIN_MAC", "single") && !env_is("TROYN_PLAIN_MAC", "packed")) {
+            if (!env_is("TROYN_PLAIN_MAC", "dual") && shared_operands(4)) nd = 4;
+            else if (!env_is("TROYN_PLAIN_MAC", "quad") && shared_operands(2)) nd = 2;
+        }
+        if (nd > 1) {
+            const size_t rowsd = (groups / nd) * nmod;
+            if (nd == 4)
+                hipLaunchKernelGGL((plain_mac2_multi_kernel<2, 4>), dim3((unsigned)(rowsd * ch)), dim3(POLY_BLOCK), 0, s,
+                                   ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
+            else
+                hipLaunchKernelGGL((plain_mac2_multi_kernel<2, 2>), dim3((unsigned)(rowsd * ch)), dim3(POLY_BLOCK), 0, s,
+                                   ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
+            LAUNCH_CHECK();
+            return TROYN_OK;
+        }
         if (env_is("TROYN_PLAIN_MAC", "packed"))      // layout experiment (tools/plain_mac_ab.py): pt[first term of a destination] = base of its packed block
             hipLaunchKernelGGL((plain_mac2_kernel<2, true>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
                                ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
