@@ -12,8 +12,11 @@ import __graft_entry__ as entry
 
 pkg = entry.load_package()
 dev = torch.device("cuda", 0)
-n, log_n, L, B = 8192, 13, 3, 1024
-q = pkg.capi.coeff_modulus_create(n, [60, 40, 40, 60])
+# MIXED_SHAPE="n:bits,...:L:batch" selects another chain (default: the tool's default chain)
+_shape = os.environ.get("MIXED_SHAPE", "8192:60,40,40,60:3:1024").split(":")
+n, L, B = int(_shape[0]), int(_shape[2]), int(_shape[3])
+log_n = n.bit_length() - 1
+q = pkg.capi.coeff_modulus_create(n, [int(b) for b in _shape[1].split(",")])
 gen = torch.Generator(device=dev).manual_seed(1)
 
 
@@ -36,3 +39,14 @@ for _ in range(30):
     plan.relinearize(L, ct3, keys, out=out, is_ckks=True, is_ntt_form=True)
 torch.cuda.synchronize()
 print("relinearize ops/s", B * 30 / (time.perf_counter() - t0))
+if os.environ.get("MIXED_CHAIN", "") == "1":       # the fused entry (multiply + relinearize + rescale) on the same chain
+    x, y = residues((B, 2), q[:L]), residues((B, 2), q[:L])
+    o2 = torch.empty((B, 2, L - 1, n), dtype=torch.int64, device=dev)
+    for _ in range(20):
+        plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=o2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=o2)
+    torch.cuda.synchronize()
+    print("mul+relin+rescale ops/s", B * 20 / (time.perf_counter() - t0))

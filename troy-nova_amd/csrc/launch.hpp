@@ -46,6 +46,11 @@ void launch_ksmac2_split(unsigned log_n, size_t batch, const KsMacArgs& a, hipSt
 void launch_ksmac_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned polys, unsigned n, double* out, unsigned blocks, hipStream_t s,
                                const ulonglong2* scale = nullptr, const DevModulus* mods = nullptr, unsigned scale_rows = 0,
                                double* diag_out = nullptr);   // diag_out: [j][2][N], block (key j, modulus j) in natural order
+// integer inner product for the rows of moduli >= 2^50 (ksmaci_kernel, log_n = 13 / 14 / 15) and its key preparation; a.row_mask = those rows
+struct KsMacIArgs;
+void launch_ksmaci(unsigned log_n, size_t batch, const KsMacIArgs& a, hipStream_t s, int epi);
+void launch_ksmaci_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned K, unsigned n, unsigned long long row_mask, ulonglong2* out, unsigned blocks, hipStream_t s,
+                                const ulonglong2* scale, const DevModulus* mods, unsigned scale_rows, ulonglong2* diag_out);
 // second-generation BEHZ conversions (L = 1 .. 16)
 // aux50: the auxiliary base holds primes below 2^50 (Behz2Dev::NB > L of them) instead of the reference's 61-bit primes
 void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst, bool aux50 = false);

@@ -96,12 +96,20 @@ enum NttStore {
 // over Q_j = P_j qk^-1 + c_j for the data rows (its keys are prepared times qk^-1 and its epilogue adds the tensor terms, KsMacArgs::ten_a):
 // the kernels below read one row where they used to read P_j and four rows of a and b.
 constexpr unsigned NTT_FLAG_STORE_F64 = 16u;         // NttArgs::flags: NTT_FUSED_MULPAIR stores its canonical outputs as doubles (the digits ksmac2 reads)
-constexpr unsigned NTT_FLAG_STORE_ROUND_HALF = 8u;   // NttArgs::flags: a plain FP64 inverse transform stores T = (x + q/2) mod q as doubles
+constexpr unsigned NTT_FLAG_STORE_ROUND_HALF = 8u;   // NttArgs::flags: a plain inverse transform stores T = (x + q/2) mod q (FP64 policy: as doubles; integer policy: u64 words)
+// chains with moduli of 2^50 and more (round 5): a T row written by an integer kernel holds u64 words, one written by an FP64 kernel doubles
+constexpr unsigned NTT_FLAG_TS_U64 = 32u;            // NttArgs::flags: the rows T_s = (s + qk/2) mod qk (special prime) hold u64 words
+constexpr unsigned NTT_FLAG_TL_U64 = 64u;            // NttArgs::flags: the rows T_l = (l + ql/2) mod ql (dropped prime) hold u64 words
 
 enum NttFused {
     NTT_FUSED_MULPAIR = 3,       // inverse: input word = a1 (.) b1 (the product c2 formed while loading)
     NTT_FUSED_LAST_LIMB = 4,     // inverse: input = Q = P qk^-1 + c_k at limb L-1 (from ksmac2); stored word = result - r(s) qk^-1   (= l above)
     NTT_FUSED_TAIL_RESCALE = 5,  // forward: input = r_j(s) qk^-1 + f_j(l); stored word = (Q_kj - y) ql^-1
+    // FP64 policy only: the same two kernels for chains in which the special and / or the dropped prime is 2^50 or wider -- a T row may then hold
+    // u64 words (NTT_FLAG_TS_U64 / NTT_FLAG_TL_U64), reduced in FP64 while loading.  Separate instantiations: the all-FP64 chain's kernels are
+    // tuned to their register budgets and stay as they are.
+    NTT_FUSED_TAIL_RESCALE_W = 6,
+    NTT_FUSED_LAST_LIMB_W = 7,
 };
 
 struct NttIo {
@@ -122,6 +130,12 @@ struct NttIo {
     const u64* in2;                      // second input row of this (item, polynomial)
     const u64 *a0, *a1, *b0, *b1;        // this limb of the two input ciphertexts
     unsigned poly;                       // output polynomial k: c_0 = a0 b0, c_1 = a0 b1 + a1 b0
+    // fused chain, integer forms / mixed chains: the constants above as words, and what the T rows hold
+    u64 hm_u, hm2_u;                     // (qk/2 mod q), (ql/2 mod q)
+    u64 aux2_q;                          // the dropped prime ql
+    bool aux2_bigger;                    // ql > q
+    ulonglong2 inv2;                     // Shoup pair of ql^-1 mod q
+    bool ts_u64, tl_u64;                 // NTT_FLAG_TS_U64 / NTT_FLAG_TL_U64
 };
 
 __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi, u64* gout) {
@@ -162,6 +176,9 @@ __device__ __forceinline__ void ntt_io_fused(NttIo& io, const NttArgs& a, unsign
     io.in2 = nullptr; io.a0 = io.a1 = io.b0 = io.b1 = nullptr; io.ext0 = nullptr; io.ext1 = nullptr;
     io.aux_qd = io.aux_half_d = io.hm_d = io.inv_d = io.inv_pd = 0.0;
     io.aux2_qd = io.aux2_half_d = io.hm2_d = io.inv2_d = 0.0;
+    io.hm_u = io.hm2_u = 0; io.aux_q = io.aux2_q = 0; io.aux_bigger = io.aux2_bigger = false;
+    io.inv = io.inv2 = make_ulonglong2(0, 0);
+    io.ts_u64 = (a.flags & NTT_FLAG_TS_U64) != 0; io.tl_u64 = (a.flags & NTT_FLAG_TL_U64) != 0;
     if (a.mul_a) {
         const u64* pa = a.mul_a + (long long)b * a.mul_bstride;
         const u64* pb = a.mul_b + (long long)b * a.mul_bstride;
@@ -173,14 +190,16 @@ __device__ __forceinline__ void ntt_io_fused(NttIo& io, const NttArgs& a, unsign
         // special prime qk: rounding fix r(s) = ((s + qk/2) mod qk) - (qk/2 mod q), and qk^-1 mod q
         const DevModulus ax = a.mods[a.aux_mod];
         const u64 half = ax.q >> 1;
-        io.aux_qd = ax.pd; io.aux_half_d = (double)half; io.hm_d = (double)barrett64(half, md.q, md.ratio_hi);
+        io.hm_u = barrett64(half, md.q, md.ratio_hi); io.aux_q = ax.q; io.aux_bigger = ax.q > md.q;
+        io.aux_qd = ax.pd; io.aux_half_d = (double)half; io.hm_d = (double)io.hm_u;
         io.inv = a.inv_table[j]; io.inv_d = (double)io.inv.x;
     }
     if (a.inv_table2) {
         const DevModulus ax = a.mods[a.aux2_mod];
         const u64 half = ax.q >> 1;
-        io.aux2_qd = ax.pd; io.aux2_half_d = (double)half; io.hm2_d = (double)barrett64(half, md.q, md.ratio_hi);
-        io.inv2_d = (double)a.inv_table2[j].x;
+        io.hm2_u = barrett64(half, md.q, md.ratio_hi); io.aux2_q = ax.q; io.aux2_bigger = ax.q > md.q;
+        io.aux2_qd = ax.pd; io.aux2_half_d = (double)half; io.hm2_d = (double)io.hm2_u;
+        io.inv2 = a.inv_table2[j]; io.inv2_d = (double)io.inv2.x;
     }
 }
 
@@ -389,6 +408,31 @@ struct ArithU64 {
     }
     static __device__ __forceinline__ elem sum(elem x, elem y, const Mod& m) { return add_mod(x, y, m.q); }
     static __device__ __forceinline__ elem inv_in(elem x, const Mod&) { return x; }
+    // ---- fused multiply -> relinearize -> rescale chain (NttFused), integer forms: every value a canonical residue ----
+    static __device__ __forceinline__ elem prod_in(u64 x, u64 y, const Mod& m) { return prod(x, y, m); }
+    static __device__ __forceinline__ elem from_canon(u64 x) { return x; }
+    // a word of a T row (T = (x + aux/2) mod aux, stored by the producer as u64 or as an exact double) as a residue of this limb's modulus
+    static __device__ __forceinline__ u64 t_residue(u64 raw, bool is_u64, bool aux_bigger, const Mod& m) {
+        const u64 t = is_u64 ? raw : f64_to_u64(f64_bits_to_double(raw));
+        return aux_bigger ? barrett64(t, m.q, m.ratio_hi) : t;
+    }
+    // input of the fused tail + rescale transform: r_j(s) qk^-1 + f_j(l)
+    template <bool TW> static __device__ __forceinline__ elem tail_in(const NttIo& io, u64 raw_s, u64 raw_l, const Mod& m) {
+        const u64 rs = sub_mod(t_residue(raw_s, io.ts_u64, io.aux_bigger, m), io.hm_u, m.q);
+        const u64 fl = sub_mod(t_residue(raw_l, io.tl_u64, io.aux2_bigger, m), io.hm2_u, m.q);
+        return add_mod(shoup_mul(rs, io.inv.x, io.inv.y, m.q), fl, m.q);
+    }
+    // its stored word: (Q - y) ql^-1
+    static __device__ __forceinline__ u64 tail_out(const NttIo& io, u64 prod_word, elem y, const Mod& m) {
+        return shoup_mul(sub_mod(prod_word, final_fwd(y, m), m.q), io.inv2.x, io.inv2.y, m.q);
+    }
+    // stored word of the dropped limb's inverse transform: T_l = (l + ql/2) mod ql with l = INTT(Q) - r(s) qk^-1
+    template <bool TW> static __device__ __forceinline__ u64 last_out(const NttIo& io, elem xr, bool, u64 raw_s, const Mod& m) {
+        const u64 ys = final_inv(xr, m);
+        const u64 rs = sub_mod(t_residue(raw_s, io.ts_u64, io.aux_bigger, m), io.hm_u, m.q);
+        const u64 l = sub_mod(ys, shoup_mul(rs, io.inv.x, io.inv.y, m.q), m.q);
+        return add_mod(l, m.q >> 1, m.q);
+    }
 };
 
 struct ArithF64 {
@@ -481,6 +525,35 @@ struct ArithF64 {
         return t >= m.m.p ? t - m.m.p : t;
     }
     static __device__ __forceinline__ elem round_fix_t(u64 t_bits, double hm, const Mod& m) { return f64_corr(f64_bits_to_double(t_bits) - hm, m.m); }
+    // the same for a T row that may hold u64 words of a prime of 2^50 or more (NTT_FUSED_*_W): T < 2^61 = hi 2^30 + lo, hi 2^30 is exact in a
+    // double, so (hi 2^30 mod p) comes out of one quotient estimate and one exact fma; |.| <= p/2 + 2^30 before the constant is subtracted
+    static __device__ __forceinline__ elem round_fix_tw(u64 raw, bool is_u64, double hm, const Mod& m) {
+        double t;
+        if (is_u64) {
+            const double h = (double)(unsigned)(raw >> 30) * 1073741824.0;
+            const double lo = (double)((unsigned)raw & 0x3fffffffu);
+            t = __builtin_fma(-__builtin_rint(h * m.m.inv_p), m.m.p, h) + lo;
+        } else t = f64_bits_to_double(raw);
+        return f64_corr(t - hm, m.m);
+    }
+    static __device__ __forceinline__ elem from_canon(u64 x) { return f64_from_u64(x); }
+    template <bool TW> static __device__ __forceinline__ elem tail_in(const NttIo& io, u64 raw_s, u64 raw_l, const Mod& m) {
+        const elem rs = TW ? round_fix_tw(raw_s, io.ts_u64, io.hm_d, m) : round_fix_t(raw_s, io.hm_d, m);       // both rows arrive as T = (x + aux/2) mod aux
+        const elem fl = TW ? round_fix_tw(raw_l, io.tl_u64, io.hm2_d, m) : round_fix_t(raw_l, io.hm2_d, m);
+        return scale_by(rs, io.inv_d, m) + fl;      // |x| <= 1.2 p: a 4-layer block from here stays below 7.7 p < 2^53
+    }
+    static __device__ __forceinline__ u64 tail_out(const NttIo& io, u64 prod_word, elem y, const Mod& m) {
+        // the product of a re-centred factor is within (-0.7 p, 0.7 p): one conditional add canonicalises it
+        return canon_small(scale_by(f64_corr(f64_from_u64(prod_word) - y, m.m), io.inv2_d, m), m);
+    }
+    template <bool TW> static __device__ __forceinline__ u64 last_out(const NttIo& io, elem xr, bool scaled, u64 raw_s, const Mod& m) {
+        const elem ys = scaled ? xr : f64_mulc(xr, m.ninv, m.ninv_p, m.m.p);          // scaled: the folded final layer applied N^-1 already
+        const elem rs = TW ? round_fix_tw(raw_s, io.ts_u64, io.hm_d, m) : round_fix_t(raw_s, io.hm_d, m);
+        // stored as T_l = (l + ql/2) mod ql (double): what the rescale's rounding fix of every remaining limb starts from
+        double lc = f64_corr(ys - scale_by(rs, io.inv_d, m), m.m);
+        lc = lc < 0.0 ? lc + m.m.p : lc;
+        return f64_double_to_bits(round_half(lc, m));
+    }
     static __device__ __forceinline__ u64 canon_small(elem x, const Mod& m) { return f64_to_u64(x < 0.0 ? x + m.m.p : x); }   // |x| < p
     static __device__ __forceinline__ elem scale_by(elem x, double inv_d, const Mod& m) { return f64_mulq(x, inv_d, m.m.inv_p, m.m.p); }   // |x| <= p
     static __device__ __forceinline__ elem load_mid(u64 raw, const Mod& m) { return f64_corr(f64_bits_to_double(raw), m.m); }
@@ -617,14 +690,17 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     constexpr bool FUSED = IOM >= 3;     // NttFused: kernels of the multiply -> relinearize -> rescale chain (loaders act in the first pass
                                          // of a transform, epilogues in its last pass: one kernel for N <= 16384, two for N = 32768)
     constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR && FIRST;
-    constexpr bool F_LAST_LD = IOM == NTT_FUSED_LAST_LIMB && FIRST, F_LAST_ST = IOM == NTT_FUSED_LAST_LIMB && LAST;
-    constexpr bool F_TR_LD = IOM == NTT_FUSED_TAIL_RESCALE && FIRST, F_TR_ST = IOM == NTT_FUSED_TAIL_RESCALE && LAST;
+    constexpr bool F_LAST = IOM == NTT_FUSED_LAST_LIMB || IOM == NTT_FUSED_LAST_LIMB_W, F_TR = IOM == NTT_FUSED_TAIL_RESCALE || IOM == NTT_FUSED_TAIL_RESCALE_W;
+    constexpr bool TW = IOM == NTT_FUSED_LAST_LIMB_W || IOM == NTT_FUSED_TAIL_RESCALE_W;     // FP64 policy: the T rows may hold u64 words
+    constexpr bool F_LAST_LD = F_LAST && FIRST, F_LAST_ST = F_LAST && LAST;
+    constexpr bool F_TR_LD = F_TR && FIRST, F_TR_ST = F_TR && LAST;
     // coefficient-form key-switch tail (BFV): the inverse transform of a data row ends with ski_util6_merged + ski_util7_merged
     // (evaluator_keyswitching_core.cu:570-658) -- the rounding fix is formed from the INTT of the special-prime row (in2) at the same
     // coefficient, then (this + lift - fix) qk^-1 [+ dest] [+ addend] is stored
     constexpr bool F_KC_ST = INV && LAST && IOM == 1 && !KSMAC;
-    static_assert(!FUSED || (!KSMAC && std::is_same<A, ArithF64>::value), "fused chain: FP64 kernels");
-    static_assert(!FUSED || (INV == (IOM == NTT_FUSED_MULPAIR || IOM == NTT_FUSED_LAST_LIMB)), "fused chain: transform direction");
+    static_assert(!FUSED || !KSMAC, "fused chain: transform kernels");
+    static_assert(!TW || std::is_same<A, ArithF64>::value, "the _W variants exist for the FP64 policy (the integer forms read either kind of T row)");
+    static_assert(!FUSED || (INV == (IOM == NTT_FUSED_MULPAIR || F_LAST)), "fused chain: transform direction");
     NttIo io;
     if constexpr (FUSED) { io.load_mode = NTT_LOAD_PLAIN; io.store_mode = NTT_STORE_PLAIN; ntt_io_fused(io, a, b, k, j, mi); }
     else if constexpr (LM != NTT_LOAD_PLAIN || SM != NTT_STORE_PLAIN) io = ntt_io_make(a, b, k, j, mi, gout);
@@ -750,8 +826,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 } else if constexpr (F_LAST_LD) {
                     // Q = P qk^-1 + c_k at the dropped limb, as ksmac2 left it (KsMacArgs::ten_a)
                     const ulonglong2 vp = nt_load2(gin + gbase + idx);
-                    wv[2 * m] = A::to_lds(f64_from_u64(vp.x), md);
-                    wv[2 * m + 1] = A::to_lds(f64_from_u64(vp.y), md);
+                    wv[2 * m] = A::to_lds(A::from_canon(vp.x), md);
+                    wv[2 * m + 1] = A::to_lds(A::from_canon(vp.y), md);
                 } else {
                     // (uniform row + pair offset) + one 32-bit lane offset: no 64-bit address per load
                     const ulonglong2 v = ld2_at(gin + gbase + m * 128u, lane * 16u, a.stream_loads != 0);
@@ -780,9 +856,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 else if constexpr (F_TR_LD) {
                     // r_j(s) qk^-1 + f_j(l): the rounding fixes of the key switch and of the rescale enter ONE transform
                     const u64 raw2 = ld_at(io.in2 + GR, lb0);
-                    const elem rs = A::round_fix_t(raw, io.hm_d, md);       // both rows arrive as T = (x + aux/2) mod aux (doubles)
-                    const elem fl = A::round_fix_t(raw2, io.hm2_d, md);
-                    x[R] = A::scale_by(rs, io.inv_d, md) + fl;      // |x| <= 1.2 p: a 4-layer block from here stays below 7.7 p < 2^53
+                    x[R] = A::template tail_in<TW>(io, raw, raw2, md);
                 }
                 else if constexpr (FIRST) x[R] = A::template load_io<LM>(io, raw, a.reduce_input != 0, md);
                 else x[R] = A::load_mid(raw, md);
@@ -970,11 +1044,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     // rescale's divide happens here
                     const unsigned boff = (gbase + idx) * 8u;
                     const ulonglong2 pr = ld2_at(io.ext0, boff, true);
-                    const elem t0 = f64_from_u64(pr.x) - A::from_lds(v0);
-                    const elem t1 = f64_from_u64(pr.y) - A::from_lds(v1);
-                    // the product of a re-centred factor is within (-0.7 p, 0.7 p): one conditional add canonicalises it
-                    v0 = A::canon_small(A::scale_by(f64_corr(t0, md.m), io.inv2_d, md), md);
-                    v1 = A::canon_small(A::scale_by(f64_corr(t1, md.m), io.inv2_d, md), md);
+                    v0 = A::tail_out(io, pr.x, A::from_lds(v0), md);
+                    v1 = A::tail_out(io, pr.y, A::from_lds(v1), md);
                 }
                 if constexpr (SM != NTT_STORE_PLAIN && HALF) {
                     const unsigned boff = (gbase + idx) * 8u;
@@ -1003,14 +1074,8 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 const unsigned gi = gi0 + GR;
                 if constexpr (F_LAST_ST) {
                     // l = INTT(P qk^-1 + c) - r(s) qk^-1: the INTT of relinearize's last limb without ever forming that limb
-                    elem ys;
-                    if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) ys = x[R];                           // already scaled by N^-1
-                    else ys = f64_mulc(x[R], md.ninv, md.ninv_p, md.m.p);
-                    const elem rs = A::round_fix_t(io.in2[gi], io.hm_d, md);
-                    // stored as T_l = (l + ql/2) mod ql (double): what the rescale's rounding fix of every remaining limb starts from
-                    double lc = f64_corr(ys - A::scale_by(rs, io.inv_d, md), md.m);
-                    lc = lc < 0.0 ? lc + md.m.p : lc;
-                    v = f64_double_to_bits(A::round_half(lc, md));
+                    constexpr bool scaled = A::FOLD_NINV && ((R >> (EB - 1)) & 1);      // the folded final layer applied N^-1 already
+                    v = A::template last_out<TW>(io, x[R], scaled, io.in2[gi], md);
                 } else if constexpr (F_KC_ST) {
                     u64 pw;
                     if constexpr (A::FOLD_NINV && ((R >> (EB - 1)) & 1)) pw = A::final_fwd(x[R], md);          // already scaled by N^-1
@@ -1027,7 +1092,10 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                     if constexpr (INV && IOM == 0 && std::is_same<A, ArithF64>::value) {
                         if (a.flags & NTT_FLAG_STORE_ROUND_HALF) v = f64_double_to_bits(ArithF64::round_half(f64_from_u64(v), md));
                     }
-                    if constexpr (INV && IOM == NTT_FUSED_MULPAIR) {
+                    if constexpr (INV && IOM == 0 && std::is_same<A, ArithU64>::value) {
+                        if (a.flags & NTT_FLAG_STORE_ROUND_HALF) v = add_mod(v, md.q >> 1, md.q);      // the same T as a u64 word (NTT_FLAG_TS_U64)
+                    }
+                    if constexpr (INV && IOM == NTT_FUSED_MULPAIR && std::is_same<A, ArithF64>::value) {
                         // the digits of the key switch are consumed as doubles by ksmac2: convert once here instead of once per output row there
                         if (a.flags & NTT_FLAG_STORE_F64) v = f64_double_to_bits(f64_from_u64(v));
                     }

@@ -49,7 +49,7 @@ static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra
         // half-word tiles buy a second workgroup per CU at the price of three barriers per exchange: with no more workgroups than CUs there is
         // nobody to share the CU with and the full-word tile is the faster one (a single ciphertext: three calls 174 -> 154 us per op); an
         // explicit TROYN_NTT_HALF is obeyed at every size
-        const int half = e ? (int)strtol(e, nullptr, 0) : (grid.x > ntt_cu_count() ? 0x0127 : 0);
+        const int half = e ? (int)strtol(e, nullptr, 0) : (grid.x > ntt_cu_count() ? 0x0167 : 0);     // (bit 6: NTT_FUSED_TAIL_RESCALE_W follows bit 5)
         if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, s, a); return; }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, s, a);
@@ -63,13 +63,18 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, hipStream_t s) {
     const int extra_lds = lds_env ? atoi(lds_env) : 0;
     // the fused prologue / epilogue is a compile-time variant of the forward kernels (no runtime branches per word)
     const unsigned lm = FIRST ? a.load_mode : 0u, sm = LAST ? a.store_mode : 0u;
-    if constexpr (std::is_same<A, ArithF64>::value && LOGN >= 13 && LOGN <= 15) {
-        // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768
+    if constexpr (LOGN >= 13 && LOGN <= 15) {
+        // kernels of the fused multiply -> relinearize -> rescale chain (NttFused): whole-limb at N <= 16384, both passes at N = 32768; both
+        // policies since round 5 (chains with moduli of 2^50 and more run the chain per modulus class); the _W variants are FP64 kernels
         if constexpr (INV) {
             if (a.fused_mode == NTT_FUSED_MULPAIR) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_MULPAIR>(a, grid, block, 0, s); return; }
             if (a.fused_mode == NTT_FUSED_LAST_LIMB) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB>(a, grid, block, 0, s); return; }
+            if constexpr (std::is_same<A, ArithF64>::value)
+                if (a.fused_mode == NTT_FUSED_LAST_LIMB_W) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_LAST_LIMB_W>(a, grid, block, 0, s); return; }
         } else {
             if (a.fused_mode == NTT_FUSED_TAIL_RESCALE) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE>(a, grid, block, 0, s); return; }
+            if constexpr (std::is_same<A, ArithF64>::value)
+                if (a.fused_mode == NTT_FUSED_TAIL_RESCALE_W) { launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_FUSED_TAIL_RESCALE_W>(a, grid, block, 0, s); return; }
         }
     }
     if constexpr (INV && LAST) {

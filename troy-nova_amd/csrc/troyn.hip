@@ -22,6 +22,7 @@
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
 #include "ksmac_kernels.hpp"
+#include "ksmaci_kernels.hpp"
 #include "poly_kernels.hpp"
 
 using namespace troyn;
@@ -68,13 +69,18 @@ static int upload_host_table(hipStream_t s, void* dev, const void* host, size_t 
     if (!rings[device]) rings[device] = new PinnedRing;
     PinnedRing& ring = *rings[device];
     PinnedSlot& sl = ring.slot[ring.next];
-    ring.next = (ring.next + 1) % PinnedRing::SLOTS;
     if (!sl.host) {
-        HIP_TRY(hipHostMalloc(&sl.host, PinnedRing::BYTES, hipHostMallocPortable));
-        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        // a slot is published only when it is complete (buffer AND event): a failure leaves it empty for the next call to retry
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        void* host_buf = nullptr;
+        const hipError_t me = hipHostMalloc(&host_buf, PinnedRing::BYTES, hipHostMallocPortable);
+        if (me != hipSuccess) { (void)hipEventDestroy(ev); return fail((int)me, std::string("hipHostMalloc: ") + hipGetErrorString(me)); }
+        sl.done = ev; sl.host = host_buf;
     } else {
         HIP_TRY(hipEventSynchronize(sl.done));
     }
+    ring.next = (ring.next + 1) % PinnedRing::SLOTS;
     std::memcpy(sl.host, host, bytes);
     HIP_TRY(hipMemcpyAsync(dev, sl.host, bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(sl.done, s));
@@ -220,6 +226,9 @@ struct troyn_plan {
     // ksmac2_kernel (N = 8192 / 16384, moduli < 2^50): the forward twiddles in the order its register rounds read them
     double* d_fwd_r1 = nullptr;           // [K][N/1024][32]
     double* d_fwd_r2 = nullptr;           // [K][N], lane-interleaved (ksm_perm)
+    // ksmaci_kernel (same sizes, any modulus): the same two copies as (operand, quotient) pairs
+    ulonglong2* d_fwd_r1i = nullptr;      // [K][N/1024][32]
+    ulonglong2* d_fwd_r2i = nullptr;      // [K][N], lane-interleaved (ksm_perm)
 };
 
 // One host thread may drive several devices (the reference calls utils::set_device before every launch, fgk/ntt_grouped.cu:286):
@@ -321,6 +330,22 @@ static int plan_upload(troyn_plan* p) {
         HIP_TRY(hipMalloc(&p->d_fwd_r2, r2.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(p->d_fwd_r1, r1.data(), r1.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_fwd_r2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
+        // the integer copies (ksmaci_kernel), every modulus: a chain of narrow moduli can be forced onto the integer kernels (TROYN_NTT_ARITH=u64)
+        std::vector<ulonglong2> r1i(K * r1n, make_ulonglong2(0, 0)), r2i(K * n, make_ulonglong2(0, 0));
+        for (size_t i = 0; i < K; i++) {
+            const auto& fw = p->tables[i].fwd;
+            for (unsigned s = 1; s < 32; s++) {
+                unsigned lvl = 0;
+                while ((2u << lvl) <= s) lvl++;
+                const unsigned g = s - (1u << lvl);
+                for (size_t th = 0; th < (n >> 10); th++) { const auto& w = fw[(((n >> 10) + th) << lvl) + g]; r1i[i * r1n + th * 32 + s] = make_ulonglong2(w.operand, w.quotient); }
+                for (size_t T = 0; T < (n >> 5); T++) { const auto& w = fw[(((n >> 5) + T) << lvl) + g]; r2i[i * n + ksm_perm((unsigned)(T * 32 + s))] = make_ulonglong2(w.operand, w.quotient); }
+            }
+        }
+        HIP_TRY(hipMalloc(&p->d_fwd_r1i, r1i.size() * sizeof(ulonglong2)));
+        HIP_TRY(hipMalloc(&p->d_fwd_r2i, r2i.size() * sizeof(ulonglong2)));
+        HIP_TRY(hipMemcpy(p->d_fwd_r1i, r1i.data(), r1i.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_fwd_r2i, r2i.data(), r2i.size() * sizeof(ulonglong2), hipMemcpyHostToDevice));
     }
     return TROYN_OK;
 }
@@ -335,6 +360,8 @@ static void plan_free(troyn_plan* p) {
     if (p->d_inv_f64) (void)hipFree(p->d_inv_f64);
     if (p->d_fwd_r1) (void)hipFree(p->d_fwd_r1);
     if (p->d_fwd_r2) (void)hipFree(p->d_fwd_r2);
+    if (p->d_fwd_r1i) (void)hipFree(p->d_fwd_r1i);
+    if (p->d_fwd_r2i) (void)hipFree(p->d_fwd_r2i);
     delete p;
 }
 
@@ -413,7 +440,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     const size_t lp = batch * a.pcount * a.ncomp;
     if (lp == 0) return TROYN_OK;
     // limbs that share one input row (component stride 0) are co-located on an XCD by the fused forward kernels
-    a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
+    a.xcd_groups = ((a.load_mode != NTT_LOAD_PLAIN || a.fused_mode == NTT_FUSED_TAIL_RESCALE || a.fused_mode == NTT_FUSED_TAIL_RESCALE_W) && a.in_cstride == 0 && a.ncomp > 1) ? (unsigned)(batch * a.pcount) : 0u;
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
@@ -684,7 +711,8 @@ static unsigned ksmac_order(size_t batch, unsigned log_n) {
 // TROYN_KS_SPLIT=0 / 1 forces it off / on (A/B runs, tests); it needs L >= 2 and its slots in the workspace.
 static bool ksmac_split_wanted(size_t batch, unsigned L, unsigned log_n) {
     const int e = env_int("TROYN_KS_SPLIT", -1);
-    if (e == 0 || L < 2 || log_n < 13 || log_n > 15) return false;
+    // L <= 15: the reducer adds the L re-centred slots (|slot| <= p/2 + 1, p < 2^50) in plain doubles, exact below 2^53 (ksmac_split_reduce_kernel)
+    if (e == 0 || L < 2 || L > 15 || log_n < 13 || log_n > 15) return false;
     const size_t wgs = batch * (L + 1) << (log_n - 13);
     if (batch > 64) return false;                      // small batches only (the slots cost L times the inner product's output)
     return e == 1 || wgs <= 128;
@@ -710,7 +738,8 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
     w.split = off;       off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     // Shoup quotients of the keys for the integer inner product: chains with a modulus of 2^50 or more on the whole-limb sizes
-    w.keys_quo = off;    off += (p->log_n >= 10 && p->log_n <= 14 && !use_f64(p, 0, p->K)) ? (size_t)L * 2 * p->K * n : 0;
+    // (N >= 8192: (key, quotient) pairs of the wide rows in the accumulators' layout + the diagonal blocks in natural order, ksmaci_kernel)
+    w.keys_quo = off;    off += (p->log_n >= 10 && p->log_n <= 15 && !use_f64(p, 0, p->K)) ? (size_t)L * 2 * p->K * n * (p->log_n >= 13 ? 2 : 1) + (p->log_n >= 13 ? (size_t)p->K * 2 * n * 2 : 0) : 0;
     w.total = off;
     return w;
 }
@@ -808,19 +837,21 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             } else launch_ksmac2(p->log_n, batch, L + 1, a, s);
         }
         LAUNCH_CHECK();
-    } else if (mac_fused && p->log_n <= 14) {
-        // A chain with moduli on both sides of 2^50 (the reference's default {60,40,40,60}): the output rows of the moduli below 2^50 take
-        // ksmac2_kernel (exact FP64 butterflies; digits of wider limbs are reduced with integer arithmetic while loading), the others the
-        // integer kernel.  Rows are independent; results are unchanged.
+    } else if (mac_fused && (p->log_n <= 14 || (ks_mac_gen == 2 && p->d_fwd_r2i))) {
+        // A chain with moduli of 2^50 and more (the reference's default {60,40,40,60}; {60,50,...,60} CKKS chains): the output rows of the
+        // moduli below 2^50 take ksmac2_kernel (exact FP64 butterflies; digits of wider limbs are reduced while loading), the rows of the wide
+        // moduli the integer kernel of the same shape (ksmaci_kernel, N = 8192 / 16384 / 32768; round 5).  Rows are independent; results are
+        // unchanged.  TROYN_NTT_ARITH=u64 sends every row to the integer kernel; N < 8192 and TROYN_KS_MAC=v1 keep the first-generation kernel.
         unsigned long long small_rows = 0, wide_rows = 0;
         bool wide_digits = false;
+        const bool all_integer = force_integer_ntt();
         for (unsigned k = 0; k <= L; k++) {
             const unsigned mrow = (k == L) ? K - 1 : k;
-            if (p->small_modulus[mrow]) small_rows |= 1ull << k; else wide_rows |= 1ull << k;
+            if (p->small_modulus[mrow] && !all_integer) small_rows |= 1ull << k; else wide_rows |= 1ull << k;
             if (k < L && !p->small_modulus[k]) wide_digits = true;
         }
-        const bool mixed = ks_mac_gen == 2 && p->d_fwd_r2 && !force_integer_ntt() && small_rows != 0 && wide_rows != 0 && L + 1 <= 64 &&
-                           batch * (size_t)(L + 2) * 4 <= 0x7fffffffull;
+        const bool gen2 = ks_mac_gen == 2 && p->d_fwd_r2 && p->d_fwd_r2i && L + 1 <= 64 && batch * (size_t)(L + 2) * 4 <= 0x7fffffffull;
+        const bool mixed = gen2 && small_rows != 0;
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
         if (mixed) {
             double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
@@ -840,6 +871,29 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, false, wide_digits);
             LAUNCH_CHECK();
         }
+        if (gen2 && wide_rows != 0) {
+            // integer rows: (key, Shoup quotient) pairs of exactly these rows, in the accumulators' layout, once per call
+            const unsigned slots = (unsigned)__builtin_popcountll(wide_rows);
+            ulonglong2* ki = reinterpret_cast<ulonglong2*>(ws + w.keys_quo);
+            ulonglong2* kdiag = ki + (size_t)L * 2 * slots * n;
+            const size_t words = (size_t)L * 2 * slots * n;
+            launch_ksmaci_prepare_keys(kp, L, K, n, wide_rows, ki, (unsigned)std::min<size_t>((words + 255) / 256, 4096), s, nullptr, p->d_mods, 0,
+                                       is_ntt_form ? kdiag : nullptr);
+            LAUNCH_CHECK();
+            KsMacIArgs m;
+            std::memset(&m, 0, sizeof(m));
+            m.digits = digits_src; m.dig_bstride = (long long)digits_bstride; m.dig_cstride = n;
+            m.diag = is_ntt_form ? target : nullptr; m.diag_bstride = (long long)target_bstride; m.diag_cstride = n;
+            m.out = ws + w.poly_prod; m.out_bstride = 2ll * (L + 1) * n; m.out_pstride = (long long)(L + 1) * n; m.out_cstride = n;
+            m.mods = p->d_mods; m.tw = p->d_fwd; m.tw_r1 = p->d_fwd_r1i; m.tw_r2 = p->d_fwd_r2i;
+            m.keys = ki; m.key_jstride = 2ll * slots * n; m.key_pstride = (long long)slots * n;
+            m.diag_keys = kdiag;
+            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
+            m.grouped = (batch % 8 == 0 && !env_is("TROYN_KS_ORDER", "plain")) ? 1u : 0u;
+            m.row_mask = wide_rows;
+            launch_ksmaci(p->log_n, batch, m, s, is_ntt_form ? 1 : 0);
+            LAUNCH_CHECK();
+        } else {
         NttArgs a = contiguous_args(p, digits_src, ws + w.poly_prod, 1, L + 1, 0, K, TROYN_IDX_KS_SET_PRODUCTS, L);
         a.in_bstride = (long long)digits_bstride; a.in_pstride = 0; a.in_cstride = n;
         a.out_bstride = 2ll * (L + 1) * n; a.out_pstride = (long long)(L + 1) * n; a.out_cstride = n;
@@ -853,7 +907,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             // once per row; measured 1265 vs 1310 us per 512-item launch at cfg3), TROYN_KS_ROWS=1 restores plain row-major order
             const int ks_rows = env_int("TROYN_KS_ROWS", 0);
             const unsigned R = ks_rows > 0 ? (unsigned)ks_rows : L + 1;
-            a.xcd_groups = (!mixed && R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
+            a.xcd_groups = (R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
         }
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
@@ -866,11 +920,10 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             LAUNCH_CHECK();
             a.key_quo = kq; a.key_quo_jstride = 2ll * K * n;
         }
-        if (mixed) a.ks_row_mask = wide_rows;
-        const size_t mac_rows = mixed ? (size_t)__builtin_popcountll(wide_rows) : (size_t)(L + 1);
-        if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * mac_rows, s);
-        else launch_ks_mac_u64(p->log_n, a, kp, batch * mac_rows, s);
+        if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * (size_t)(L + 1), s);
+        else launch_ks_mac_u64(p->log_n, a, kp, batch * (size_t)(L + 1), s);
         LAUNCH_CHECK();
+        }
     } else {
     // (2) digit decomposition fused into the forward NTT (replaces kernel_set_accumulate, fgk/switch_key.cu:6-54,
     //     + ntt_inplace_ps with key_switching_set_products, :907-908): row i = digits reduced mod q_key(i)
@@ -1080,11 +1133,18 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
 // ---------------------------------------------------------------------------------------
 // fused CKKS multiply -> relinearize -> rescale_to_next
 // ---------------------------------------------------------------------------------------
-struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, split, fast_total, prod3, relin2, sub, total; };
+struct MrrLayout { size_t digits, poly_prod, spec_intt, last_intt, keys_f64, keys_int, split, fast_total, prod3, relin2, sub, total; };
+
+// the moduli the chain of level L touches (data limbs 0 .. L-1 and the special prime K-1) are all below 2^50 and the FP64 policy is not switched off
+static bool mrr_all_f64(const troyn_plan* p, uint32_t L) { return use_f64(p, 0, L) && use_f64(p, p->K - 1, 1); }
 
 static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
-    // the chain's kernels exist for whole-limb FP64 rings (N = 8192 / 16384, every modulus < 2^50)
-    return p->d_fwd_r2 && L >= 2 && L + 1 <= p->K && use_f64(p, 0, p->K);     // d_fwd_r2: N = 8192 / 16384 / 32768
+    // the chain's kernels exist for N = 8192 / 16384 / 32768 (d_fwd_r2); every modulus below 2^50: the FP64 kernels of rounds 2-4; chains with
+    // moduli of 2^50 and more (round 5): every launch runs per modulus class, integer kernels for the wide limbs (ksmaci_kernel, the integer
+    // forms of the fused transforms).  TROYN_MRR_MIXED=0 composes the three public calls for such chains as rounds 2-4 did (A/B runs, tests).
+    if (!(p->d_fwd_r2 && L >= 2 && L + 1 <= p->K)) return false;
+    if (mrr_all_f64(p, L)) return true;
+    return p->d_fwd_r2i != nullptr && L + 1 <= 64 && !env_is("TROYN_MRR_MIXED", "0");
 }
 
 static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
@@ -1096,6 +1156,8 @@ static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
     w.spec_intt = off; off += batch * 2 * n;
     w.last_intt = off; off += batch * 2 * n;
     w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys + the diagonal blocks in natural order
+    // integer rows of a chain with wide moduli: (key, quotient) pairs [L][2][rows][N] + the diagonal blocks [rows][2][N]
+    w.keys_int = off;  off += (L >= 1 && L + 1 <= p->K && !mrr_all_f64(p, L)) ? ((size_t)L * 2 * (L + 1) * n + (size_t)(L + 1) * 2 * n) * 2 : 0;
     w.split = off;     off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     w.fast_total = off;
     // composition of the three public calls (any other shape)
@@ -1137,43 +1199,85 @@ static MrrStreams* mrr_streams(int device) {
 
 // launches (1)-(5) of the fused chain for `batch` items whose intermediates live in `ws` (layout w); kf: the prepared keys
 // raw != nullptr: digit-parallel inner product on the caller's own keys (small launches; the workspace has its slots and kf was not prepared)
-static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b, const double* kf, u64* out, u64* ws, const MrrLayout& w,
+// Chains with moduli of 2^50 and more: every launch is issued once per run of limbs of one arithmetic class (limbs are independent), the rows
+// that cross classes are canonical u64 words (digits; T rows written by an integer kernel) and each consumer reduces what it reads.
+// ki: the integer rows' prepared keys (chains with wide moduli; nullptr otherwise)
+static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b, const double* kf, const ulonglong2* ki, u64* out, u64* ws, const MrrLayout& w,
                      size_t batch, hipStream_t s, const KeyPtrs* raw = nullptr) {
     const unsigned K = p->K, n = p->n;
     int rc;
     const long long ct_b = 2ll * L * n, ct_p = (long long)L * n;           // strides of a, b
     const long long pp_b = 2ll * (L + 1) * n, pp_p = (long long)(L + 1) * n;   // strides of poly_prod
     auto mul_operands = [&](NttArgs& x, unsigned limb0) { x.mul_a = a; x.mul_b = b; x.mul_bstride = ct_b; x.mul_pstride = ct_p; x.mul_limb0 = limb0; };
-    // (1) digits = INTT(c2), c2 = a1 (.) b1 formed in the loader (kernel_dyadic_convolute's third output + transform_from_ntt, :817-821)
-    {
-        NttArgs x = contiguous_args(p, a, ws + w.digits, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
-        mul_operands(x, 0);
-        x.fused_mode = NTT_FUSED_MULPAIR;
-        x.flags = NTT_FLAG_STORE_F64;            // the digits go to ksmac2 as doubles (one conversion here instead of L + 1 there)
-        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
+    const bool all_f64 = mrr_all_f64(p, L);
+    auto small = [&](unsigned mi) { return use_f64(p, mi, 1); };          // this modulus takes the FP64 kernels
+    // runs of data limbs [j0, j1) of one class within [0, count)
+    auto for_runs = [&](unsigned count, auto&& f) -> int {
+        for (unsigned j0 = 0, j1; j0 < count; j0 = j1) {
+            for (j1 = j0 + 1; j1 < count && small(j1) == small(j0); j1++) {}
+            if (int r = f(j0, j1)) return r;
+        }
+        return TROYN_OK;
+    };
+    const bool special_wide = !small(K - 1), last_wide = !small(L - 1);
+    bool wide_digits = false;
+    unsigned long long small_rows = 0, wide_rows = 0;
+    for (unsigned k = 0; k <= L; k++) {
+        const unsigned mrow = (k == L) ? K - 1 : k;
+        if (small(mrow)) small_rows |= 1ull << k; else wide_rows |= 1ull << k;
+        if (k < L && !small(k)) wide_digits = true;
     }
+    // (1) digits = INTT(c2), c2 = a1 (.) b1 formed in the loader (kernel_dyadic_convolute's third output + transform_from_ntt, :817-821)
+    if ((rc = for_runs(L, [&](unsigned j0, unsigned j1) {
+        NttArgs x = contiguous_args(p, a + (size_t)j0 * n, ws + w.digits + (size_t)j0 * n, 1, j1 - j0, j0, j1 - j0, TROYN_IDX_COMPONENTWISE, 0);
+        x.in_bstride = ct_b; x.in_pstride = ct_p;                          // (the loader reads mul_a / mul_b; `in` only anchors the shapes)
+        x.out_bstride = (long long)L * n; x.out_pstride = (long long)L * n;
+        mul_operands(x, j0);
+        x.fused_mode = NTT_FUSED_MULPAIR;
+        if (all_f64) x.flags = NTT_FLAG_STORE_F64;            // the digits go to ksmac2 as doubles (one conversion here instead of L + 1 there)
+        return launch_ntt(p, x, batch, true, s);
+    }))) return rc;
     // (2) key-switch inner product; the digit of row k under its own modulus is a1 (.) b1 again
     {
-        KsMacArgs m;
-        std::memset(&m, 0, sizeof(m));
-        m.digits = ws + w.digits; m.dig_bstride = (long long)L * n; m.dig_cstride = n;
-        m.diag = a + ct_p; m.diag_b = b + ct_p; m.diag_bstride = ct_b; m.diag_cstride = n;
-        m.ten_a = a; m.ten_b = b; m.ten_bstride = ct_b; m.ten_pstride = ct_p;      // data rows leave as Q = P qk^-1 + c (keys prepared times qk^-1)
-        m.diag_keys = kf + (size_t)L * 2 * K * n;
-        m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
-        m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
-        m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
-        m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
-        if (raw) {
-            m.grouped = 0;
-            m.part = reinterpret_cast<double*>(ws + w.split); m.part_jstride = (long long)batch * pp_b;
-            m.split_skip_diag = 1;
-            m.raw = *raw; m.raw_pstride = (long long)K * n; m.split_scale = p->d_inv_last + (size_t)K * K;
-            launch_ksmac2_split(p->log_n, batch, m, s, true, 1);
-        } else launch_ksmac2(p->log_n, batch, L + 1, m, s, true);
+        if (small_rows) {
+            KsMacArgs m;
+            std::memset(&m, 0, sizeof(m));
+            m.digits = ws + w.digits; m.dig_bstride = (long long)L * n; m.dig_cstride = n;
+            m.diag = a + ct_p; m.diag_b = b + ct_p; m.diag_bstride = ct_b; m.diag_cstride = n;
+            m.ten_a = a; m.ten_b = b; m.ten_bstride = ct_b; m.ten_pstride = ct_p;      // data rows leave as Q = P qk^-1 + c (keys prepared times qk^-1)
+            m.diag_keys = kf + (size_t)L * 2 * K * n;
+            m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
+            m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
+            m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
+            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
+            if (wide_rows) m.row_mask = small_rows;
+            if (raw) {
+                m.grouped = 0;
+                m.part = reinterpret_cast<double*>(ws + w.split); m.part_jstride = (long long)batch * pp_b;
+                m.split_skip_diag = 1;
+                m.raw = *raw; m.raw_pstride = (long long)K * n; m.split_scale = p->d_inv_last + (size_t)K * K;
+                launch_ksmac2_split(p->log_n, batch, m, s, true, 1);
+            } else launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, all_f64, wide_digits);
+            LAUNCH_CHECK();
+        }
+        if (wide_rows) {
+            const unsigned slots = (unsigned)__builtin_popcountll(wide_rows);
+            KsMacIArgs m;
+            std::memset(&m, 0, sizeof(m));
+            m.digits = ws + w.digits; m.dig_bstride = (long long)L * n; m.dig_cstride = n;
+            m.ten_a = a; m.ten_b = b; m.ten_bstride = ct_b; m.ten_pstride = ct_p;
+            m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
+            m.mods = p->d_mods; m.tw = p->d_fwd; m.tw_r1 = p->d_fwd_r1i; m.tw_r2 = p->d_fwd_r2i;
+            m.keys = ki; m.key_jstride = 2ll * slots * n; m.key_pstride = (long long)slots * n;
+            m.diag_keys = ki + (size_t)L * 2 * slots * n;
+            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
+            m.grouped = (batch % 8 == 0 && !env_is("TROYN_KS_ORDER", "plain")) ? 1u : 0u;
+            m.row_mask = wide_rows;
+            launch_ksmaci(p->log_n, batch, m, s, 2);
+            LAUNCH_CHECK();
+        }
     }
-    LAUNCH_CHECK();
     // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
     {
         NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.spec_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
@@ -1181,28 +1285,31 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         x.flags = NTT_FLAG_STORE_ROUND_HALF;     // stored as (s + qk/2) mod qk, the limb-independent part of the key switch's rounding fix
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
+    const unsigned t_flags = (special_wide ? NTT_FLAG_TS_U64 : 0u) | (last_wide ? NTT_FLAG_TL_U64 : 0u);
     // (4) l = INTT(relin_{L-1}) = INTT(Q_{L-1}) - r(s) qk^-1 with Q = P qk^-1 + c as ksmac2 left it   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
     {
         NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.last_intt, 2, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         x.in_pstride = pp_p; x.in_bstride = pp_b;
         x.in2 = ws + w.spec_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
         x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K + (L - 1);
-        x.fused_mode = NTT_FUSED_LAST_LIMB;
+        x.fused_mode = (!last_wide && special_wide) ? NTT_FUSED_LAST_LIMB_W : NTT_FUSED_LAST_LIMB;
+        x.flags = t_flags;
         if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
     }
     // (5) out_j = (Q_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1, Q_j = P_j qk^-1 + c_j, for the L-1 remaining limbs: ski_util6/7 (:570-658), the
     //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
-    {
-        NttArgs x = contiguous_args(p, ws + w.spec_intt, out, 2, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+    return for_runs(L - 1, [&](unsigned j0, unsigned j1) {
+        NttArgs x = contiguous_args(p, ws + w.spec_intt, out + (size_t)j0 * n, 2, j1 - j0, j0, j1 - j0, TROYN_IDX_COMPONENTWISE, 0);
         x.in_bstride = 2ll * n; x.in_pstride = n; x.in_cstride = 0;
+        x.out_bstride = 2ll * (L - 1) * n; x.out_pstride = (long long)(L - 1) * n;
         x.in2 = ws + w.last_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
-        x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K;
-        x.aux2_mod = L - 1; x.inv_table2 = p->d_inv_last + (size_t)L * K;
-        x.ext0 = ws + w.poly_prod; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
-        x.fused_mode = NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
-        if ((rc = launch_ntt(p, x, batch, false, s))) return rc;
-    }
-    return TROYN_OK;
+        x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K + j0;
+        x.aux2_mod = L - 1; x.inv_table2 = p->d_inv_last + (size_t)L * K + j0;
+        x.ext0 = ws + w.poly_prod + (size_t)j0 * n; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
+        x.fused_mode = (small(j0) && t_flags) ? NTT_FUSED_TAIL_RESCALE_W : NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
+        x.flags = t_flags;
+        return launch_ntt(p, x, batch, false, s);
+    });
 }
 
 extern "C" size_t troyn_ckks_multiply_relinearize_rescale_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch) {
@@ -1244,15 +1351,27 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     const int chunk_env = env_int("TROYN_MRR_CHUNK", 0);
     size_t chunk = batch;
     if (chunk_env > 0 && batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env;
-    // small launches: the digit-parallel inner product reads the caller's keys as they are
-    const bool split = chunk == batch && ksmac_split_wanted(batch, L, p->log_n);
+    const bool all_f64 = mrr_all_f64(p, L);
+    // small launches: the digit-parallel inner product reads the caller's keys as they are (chains of moduli below 2^50)
+    const bool split = chunk == batch && all_f64 && ksmac_split_wanted(batch, L, p->log_n);
     // otherwise: keys prepared once per call (converted to exact doubles in the accumulators' layout), shared by every chunk
     double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
-    if (!split) {
+    ulonglong2* ki = reinterpret_cast<ulonglong2*>(ws + w.keys_int);
+    unsigned long long wide_rows = 0, small_rows = 0;
+    for (unsigned k = 0; k <= L; k++) { if (use_f64(p, k == L ? K - 1 : k, 1)) small_rows |= 1ull << k; else wide_rows |= 1ull << k; }
+    if (!split && small_rows) {
         const size_t pairs = (size_t)L * 2 * K * (n / 2);
         // the rows of the data moduli carry the factor qk^-1: the inner product leaves ksmac2 as P qk^-1 (+ the tensor term, KsMacArgs::ten_a)
         launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s,
                                   p->d_inv_last + (size_t)K * K, p->d_mods, L, kf + (size_t)L * 2 * K * n);
+        LAUNCH_CHECK();
+    }
+    if (wide_rows) {
+        // the integer rows' (key qk^-1, Shoup quotient) pairs in the accumulators' layout + their diagonal blocks in natural order
+        const unsigned slots = (unsigned)__builtin_popcountll(wide_rows);
+        const size_t words = (size_t)L * 2 * slots * n;
+        launch_ksmaci_prepare_keys(kp, L, K, n, wide_rows, ki, (unsigned)std::min<size_t>((words + 255) / 256, 4096), s,
+                                   p->d_inv_last + (size_t)K * K, p->d_mods, L, ki + words);
         LAUNCH_CHECK();
     }
     // Chunked execution of the 5-launch chain on internal streams (round 3, an option: TROYN_MRR_CHUNK=<items, multiple of 8>,
@@ -1264,14 +1383,14 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     // caller's stream is faster at every batch size measured (1024 items: 263.6 - 265.2 k vs 260.4 - 260.8 k ops/s with two halves,
     // 263.2 - 264.1 k with three thirds; 2048: 264.1 - 264.6 k vs 260.1 - 262.7 k; 512: 262.3 - 262.9 k vs 257.4 - 258.1 k) and is the default.
     const int ns = std::min(std::max(env_int("TROYN_MRR_STREAMS", 2), 1), MRR_MAX_STREAMS);
-    if (chunk == batch) return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s, split ? &kp : nullptr);
+    if (chunk == batch) return mrr_chain(p, L, a, b, kf, ki, out, ws, w, batch, s, split ? &kp : nullptr);
     MrrStreams* ms = mrr_streams(p->device);
     if (!ms) return fail(TROYN_E_INVALID, std::string(P) + " cannot create the internal streams");
     const MrrLayout wc = mrr_layout(p, L, chunk);        // two chunk-sized workspaces side by side in the caller's workspace
     const size_t slot_words = wc.keys_f64;               // a chunk's intermediates end where its (unused) key area would start
     if ((size_t)ns * slot_words > w.keys_f64) {
         if (split) return fail(TROYN_E_INVALID, std::string(P) + " internal: chunk layout");      // unreachable: split implies one chunk
-        return mrr_chain(p, L, a, b, kf, out, ws, w, batch, s);
+        return mrr_chain(p, L, a, b, kf, ki, out, ws, w, batch, s);
     }
     HIP_TRY(hipEventRecord(ms->fork, s));
     for (int q = 0; q < ns; q++) HIP_TRY(hipStreamWaitEvent(ms->s[q], ms->fork, 0));
@@ -1280,7 +1399,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     while (done < batch) {
         const size_t c = std::min(chunk, batch - done);
         const int q = (int)(idx % (size_t)ns);
-        if ((rc = mrr_chain(p, L, a + done * 2 * (size_t)L * n, b + done * 2 * (size_t)L * n, kf, out + done * 2 * (size_t)(L - 1) * n,
+        if ((rc = mrr_chain(p, L, a + done * 2 * (size_t)L * n, b + done * 2 * (size_t)L * n, kf, ki, out + done * 2 * (size_t)(L - 1) * n,
                             ws + (size_t)q * slot_words, wc, c, ms->s[q]))) break;
         done += c; idx++;
     }

@@ -9,6 +9,7 @@ void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs&
     const size_t grid_rows = a.grouped == 3 ? (rows + 1) / 2 * 2 : rows;
 #define KSMAC2_CASE(LOGN, TILES)                                                                                            \
     if (digits_f64 && a.ten_a) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true, 0, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
+    else if (a.ten_a) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, true, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); /* fused chain of a mixed chain: u64 digits, wide ones reduced while loading */ \
     else if (!digits_f64 && !wide_digits && !a.diag) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (!digits_f64 && !wide_digits && a.diag && a.diag_keys) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (digits_f64) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \

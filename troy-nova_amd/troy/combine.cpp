@@ -198,7 +198,7 @@ namespace detail {
 // spins; the GPU boxes give a process a CPU quota).  One waiter at a time calls hipStreamSynchronize; a thread is satisfied by a wait
 // that STARTED after it asked (that wait covers everything the thread had queued), the others sleep on a futex meanwhile.
 namespace {
-struct Waiter { std::atomic<int> word{0}; Waiter* wake[4] = {}; };   // word: 0 waiting, 1 covered by a finished wait, 2 lead the next one
+struct Waiter { std::atomic<int> word{0}; Waiter* wake[4] = {}; int err = 0; };   // word: 0 waiting, 1 covered by a finished wait (err = that wait's hipError_t), 2 lead the next one
 struct WaitGroup {
     std::mutex m;
     bool running = false;
@@ -219,7 +219,7 @@ int combining_stream_wait(void* stream) {
         while ((s = me.word.load(std::memory_order_acquire)) == 0) futex_wait(&me.word, 0);
         if (s == 1) {
             for (Waiter* k : me.wake) if (k) futex_wake(&k->word);   // by address only
-            return 0;
+            return me.err;      // the result of the wait that covered this thread: a faulted stream is everybody's error
         }
         lk.lock();   // 2: lead the next wait (`running` stayed set)
     }
@@ -238,7 +238,7 @@ int combining_stream_wait(void* stream) {
         for (size_t i = 0; i < F; i++) covered[k]->wake[i] = F * (k + 1) + i < covered.size() ? covered[F * (k + 1) + i] : nullptr;
     std::atomic<int>* root[F];
     for (size_t i = 0; i < F; i++) root[i] = i < covered.size() ? &covered[i]->word : nullptr;
-    for (Waiter* x : covered) x->word.store(1, std::memory_order_release);   // from here on `x` may be gone
+    for (Waiter* x : covered) { x->err = (int)e; x->word.store(1, std::memory_order_release); }   // from here on `x` may be gone
     for (std::atomic<int>* r : root) if (r) futex_wake(r);
     if (next) { next->store(2, std::memory_order_release); futex_wake(next); }
     return (int)e;

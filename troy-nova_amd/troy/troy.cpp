@@ -65,12 +65,17 @@ void combining_switch(bool on) {
     // a quiescent point by contract (no other thread inside the library); everything queued so far completes, every cached block is anybody's
     (void)hipDeviceSynchronize();
     g_combining.store(on ? 1 : 0, std::memory_order_release);
-    if (MemoryPoolHandle g = MemoryPool::GlobalPool()) g->disown(~uint64_t(0));
+    utils::MemoryPool::disown_all_pools();    // user-created pools too: their blocks carry the shared tag / per-thread tags of the mode that ends
 }
 }  // namespace detail
 
+// call combining is a one-device mode: a thread whose current device is not the shared stream's keeps its own stream (and its own owner tag)
+static inline bool on_shared_device() {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess && dev == detail::g_shared_device;
+}
 static inline hipStream_t current_stream() {
-    if (detail::combining_on()) if (hipStream_t s = detail::shared_stream()) return s;
+    if (detail::combining_on()) if (hipStream_t s = detail::shared_stream()) if (on_shared_device()) return s;
     return hipStreamPerThread;
 }
 
@@ -96,8 +101,15 @@ size_t device_count() {
 static std::mutex g_global_pool_mutex;
 static MemoryPoolHandle g_global_pool;
 
+// every live pool (call combining disowns all of them when it is switched); leaked on purpose like the tables below
+static std::mutex& g_pools_mutex() { static std::mutex* m = new std::mutex; return *m; }
+static std::unordered_set<MemoryPool*>& g_pools() { static auto* s = new std::unordered_set<MemoryPool*>; return *s; }
+
 MemoryPool::MemoryPool(size_t device) : device_(device) {
     if (device >= device_count()) throw std::runtime_error("[MemoryPool::MemoryPool] No such device.");
+    if (const char* e = std::getenv("TROY_POOL_HIGH_WATER_MB")) high_water_ = static_cast<size_t>(std::strtoull(e, nullptr, 0)) << 20;
+    std::lock_guard<std::mutex> lock(g_pools_mutex());
+    g_pools().insert(this);
 }
 
 // A block in a free list carries the tag of the host thread that released it: kernels queued on THAT thread's stream may still be using
@@ -119,7 +131,7 @@ struct ThreadExit {
 };
 static uint64_t this_thread_tag() {
     // one shared stream (call combining): release and reuse are ordered by that stream whichever host thread does them
-    if (detail::combining_on() && detail::shared_stream()) return uint64_t(1) << 63;
+    if (detail::combining_on() && detail::shared_stream() && on_shared_device()) return uint64_t(1) << 63;
     static std::atomic<uint64_t> next{1};
     thread_local ThreadExit te;
     if (!te.tag) te.tag = next.fetch_add(1);
@@ -130,12 +142,20 @@ static bool tag_is_dead(uint64_t tag) {
     return g_dead_tags.count(tag) != 0;
 }
 
-void MemoryPool::disown(uint64_t tag) {
+void MemoryPool::disown(uint64_t tag, uint64_t upto) {
     std::lock_guard<std::mutex> lock(mutex_);
-    for (auto& kv : free_) for (auto& blk : kv.second) if (blk.owner == tag || tag == ~uint64_t(0)) blk.owner = 0;
+    for (auto& kv : free_) for (auto& blk : kv.second) if ((blk.owner == tag || tag == ~uint64_t(0)) && blk.seq <= upto) blk.owner = 0;
 }
+void MemoryPool::disown_all_pools() {
+    std::lock_guard<std::mutex> lock(g_pools_mutex());
+    for (MemoryPool* p : g_pools()) p->disown(~uint64_t(0));
+}
+uint64_t MemoryPool::release_mark() { std::lock_guard<std::mutex> lock(mutex_); return release_seq_; }
+void MemoryPool::set_high_water_bytes(size_t bytes) { std::lock_guard<std::mutex> lock(mutex_); high_water_ = bytes; }
+size_t MemoryPool::held_bytes() { std::lock_guard<std::mutex> lock(mutex_); return held_bytes_; }
 
 MemoryPool::~MemoryPool() {
+    { std::lock_guard<std::mutex> lock(g_pools_mutex()); g_pools().erase(this); }
     for (auto& kv : free_) for (auto& blk : kv.second) (void)hipFree(blk.ptr);
     for (auto& kv : live_) (void)hipFree(kv.first);
 }
@@ -164,7 +184,7 @@ void* MemoryPool::allocate(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
     const uint64_t me = this_thread_tag();
-    // which: 0 = mine or nobody's, 1 = a dead thread's (returns the block WITHOUT taking it: the caller synchronises first), 2 = anybody's
+    // which: 0 = mine or nobody's, 1 = a dead thread's (returns the block WITHOUT taking it: the caller synchronises first)
     auto take = [&](int which) -> void* {
         std::lock_guard<std::mutex> lock(mutex_);
         for (auto it = free_.lower_bound(bytes); it != free_.end() && it->first <= bytes * 2; ++it) {
@@ -184,24 +204,38 @@ void* MemoryPool::allocate(size_t bytes) {
     };
     if (void* p = take(0)) return p;
     hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
-    if (take(1)) {
-        // everything queued so far completes: every cached block is then safe for anyone
+    // A device-wide synchronisation covers what was queued BEFORE it: the blocks in the free lists when it STARTS are then anybody's.  A block
+    // another thread releases while it drains (or after) may still have that thread's kernels pending and must keep its tag, so the tags
+    // are cleared only up to the release number read before the wait (round 4 cleared every tag afterwards: a block released during the
+    // wait could be handed to a different stream with work still pending on it).
+    auto sync_and_disown = [&] {
+        const uint64_t mark = release_mark();
         hip_check(hipDeviceSynchronize(), "device_synchronize");
-        disown(~uint64_t(0));
+        disown(~uint64_t(0), mark);
+    };
+    if (take(1)) {
+        sync_and_disown();
         if (void* q = take(0)) return q;
     }
     void* p = nullptr;
+    bool capped;
+    { std::lock_guard<std::mutex> lock(mutex_); capped = high_water_ != 0 && held_bytes_ + bytes > high_water_; }
+    if (capped) {
+        // above the high-water mark: reuse what other threads have released (one device-wide wait) before growing any further
+        sync_and_disown();
+        if (void* q = take(0)) return q;
+    }
     g_pool_mallocs.fetch_add(1, std::memory_order_relaxed);
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
-        hip_check(hipDeviceSynchronize(), "device_synchronize");
-        disown(~uint64_t(0));
-        if (void* q = take(2)) return q;
+        sync_and_disown();
+        if (void* q = take(0)) return q;      // only blocks whose tag the wait cleared (or this thread's own)
         release_unused();      // nothing of a fitting size: give the cache back and retry once
         hip_check(hipMalloc(&p, bytes), "malloc");
     }
     std::lock_guard<std::mutex> lock(mutex_);
     live_[p] = bytes;
+    held_bytes_ += bytes;
     return p;
 }
 
@@ -211,7 +245,7 @@ void MemoryPool::release(void* ptr) {
     std::lock_guard<std::mutex> lock(mutex_);
     auto it = live_.find(ptr);
     if (it == live_.end()) return;
-    free_[it->second].push_back(FreeBlock{ptr, me});
+    free_[it->second].push_back(FreeBlock{ptr, me, ++release_seq_});
     live_.erase(it);
 }
 
@@ -220,6 +254,7 @@ void MemoryPool::release_unused() {
     {
         std::lock_guard<std::mutex> lock(mutex_);
         drop.swap(free_);
+        for (auto& kv : drop) held_bytes_ -= std::min(held_bytes_, kv.first * kv.second.size());
     }
     if (drop.empty()) return;
     (void)hipDeviceSynchronize();   // queued kernels may still read blocks released a moment ago

@@ -160,13 +160,23 @@ public:
     void release(void* ptr);
     void release_unused();
     static uint64_t device_allocations();   // hipMalloc calls of all pools so far (a steady-state loop should not add any)
-    void disown(uint64_t thread_tag);   // internal: the blocks that thread released have no work pending any more (~0: every block)
+    // internal: the blocks that thread released (~0: every block) at or before release number `upto` have no work pending any more
+    void disown(uint64_t thread_tag, uint64_t upto = ~uint64_t(0));
+    static void disown_all_pools();     // internal (call combining switched at a quiescent point): every cached block of every pool is anybody's
+    // Fresh device memory is preferred over a block another live thread released (no device-wide wait) only while the pool holds less than
+    // this many bytes (live + cached); above it the pool synchronises and reuses, as it does when the device is out of memory.
+    // 0 = no cap.  Default: environment TROY_POOL_HIGH_WATER_MB read when the pool is created, else no cap.
+    void set_high_water_bytes(size_t bytes);
+    size_t held_bytes();                // live + cached bytes of this pool
 private:
+    uint64_t release_mark();            // number of the latest release (under the lock)
     size_t device_;
     std::mutex mutex_;
-    struct FreeBlock { void* ptr; uint64_t owner; };   // owner = tag of the thread that released it
+    struct FreeBlock { void* ptr; uint64_t owner; uint64_t seq; };   // owner = tag of the thread that released it, seq = number of that release
     std::unordered_map<void*, size_t> live_;
     std::map<size_t, std::vector<FreeBlock>> free_;
+    uint64_t release_seq_ = 0;
+    size_t held_bytes_ = 0, high_water_ = 0;
 };
 
 // Owning array of uint64_t on the host (malloc) or on a device (pool) -- src/utils/dynamic_array.h
