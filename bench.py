@@ -295,14 +295,13 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     # The fused entry runs the whole batch as one launch sequence on the caller's stream (the default), so the launches timed inside the
     # region are the kernel's own.  If TROYN_MRR_CHUNK is set the batch runs as chunks on internal streams and a launch's event-bracketed
     # duration includes the time it shares the chip with another chunk's kernels (`in_region`); the kernel's own figure is then measured in
-    # the same run right after the region, same buffers, with the chain on ONE stream (the library reads its switches per call).
+    # the same run right after the region, same buffers, with the chain on ONE stream (Plan.set_option).
     # `achieved` = algorithmic bytes per launch / the average of the kernel's own launch durations.
     in_region_ms = ks_ms / max(1, ks_n)
     in_region_items = max(1, round(B * inner * args.steps / max(1, ks_n)))
     excl_ms, excl_n = in_region_ms, ks_n
     if fused and in_region_items != B:
-        saved = os.environ.get("TROYN_MRR_CHUNK")
-        os.environ["TROYN_MRR_CHUNK"] = "0"
+        plan.set_option("TROYN_MRR_CHUNK", "0")       # (the library reads its switches when the plan is created; per-plan changes go through set_option)
         try:
             one_pass()
             torch.cuda.synchronize()
@@ -313,10 +312,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                 ms1, n1 = kt.read()
             excl_ms, excl_n = ms1 / max(1, n1), n1
         finally:
-            if saved is None:
-                del os.environ["TROYN_MRR_CHUNK"]
-            else:
-                os.environ["TROYN_MRR_CHUNK"] = saved
+            plan.set_option("TROYN_MRR_CHUNK", os.environ.get("TROYN_MRR_CHUNK"))
     ks_launch_ms = excl_ms
     items_per_launch = B if (fused and in_region_items != B) else in_region_items
     alg_bytes = ksmac_alg_bytes(items_per_launch, n, L, True, fused_chain=fused)

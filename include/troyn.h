@@ -84,6 +84,10 @@ int troyn_get_primes(uint64_t factor, size_t bit_size, size_t count, uint64_t* o
 int troyn_plan_create(troyn_plan** plan, int device, uint32_t log_n, uint32_t n_moduli,
                       const uint64_t* moduli, const uint64_t* roots);
 int troyn_plan_destroy(troyn_plan* plan);
+/* A/B switches (DESIGN.md section 4 "A/B switches"): read from the environment variables of the same names ONCE, when the plan is created;
+ * this sets one of them on an existing plan ("TROYN_KS_ORDER", "row"; value NULL or "" = the default).  The library never reads the
+ * environment on a call path.  Not to be called while other threads use the plan.  Replaces nothing in the reference (development hook). */
+int troyn_plan_set_option(troyn_plan* plan, const char* name, const char* value);
 uint32_t troyn_plan_log_n(const troyn_plan* plan);
 uint32_t troyn_plan_n_moduli(const troyn_plan* plan);
 /* host copies of table contents, for known-answer checks: out[2*i] = operand, out[2*i+1] = quotient */

@@ -57,3 +57,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert "troy_oracle" not in text and "import oracle" not in text and "from oracle" not in text, os.path.join(base, f)
+
+
+def test_switches_are_read_once_at_plan_creation():
+    """the library's A/B switches come from the environment in exactly one place (options_from_environment, called by troyn_plan_create): no
+    getenv is reachable from any other troyn_* entry (tests/test_gpu_switches.py checks the behaviour on the GPU)"""
+    csrc = os.path.join(ROOT, "troy-nova_amd", "csrc")
+    hits = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".hpp", ".inl")):
+            continue
+        for no, line in enumerate(open(os.path.join(csrc, name)), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bgetenv\s*\(", code):
+                hits.append((name, no, code.strip()))
+    assert len(hits) == 1 and hits[0][0] == "troyn.hip" and "option_apply" in hits[0][2], hits
+    text = open(os.path.join(csrc, "troyn.hip")).read()
+    body = text[text.index("static TroynOptions options_from_environment()"):]
+    assert hits[0][2] in body[:body.index("\n}\n")]
+    assert text.count("options_from_environment()") == 2      # the definition and troyn_plan_create

@@ -192,9 +192,9 @@ def test_bfv_multiply_auxiliary_base(O, pkg, dev, monkeypatch, n, bits, L, t):
     monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
     ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
     ref = pkg.Behz(plan, L, t)
-    monkeypatch.setenv("TROYN_BEHZ_BASE", "small")
+    plan.set_option("TROYN_BEHZ_BASE", "small")     # (read by troyn_behz_create from the plan)
     fast = pkg.Behz(plan, L, t)
-    monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
+    plan.set_option("TROYN_BEHZ_BASE", None)
     assert ref.working_base_size == len(ref.base_Bsk) and fast.base_Bsk == ref.base_Bsk
     assert fast.working_base_size > ref.working_base_size
     # capacity: more than 61 bits per reference prime
@@ -212,7 +212,7 @@ def test_bfv_multiply_auxiliary_base(O, pkg, dev, monkeypatch, n, bits, L, t):
         got = pkg.to_host(h.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
         for i in range(batch):
             assert np.array_equal(got[i], want[i]), (h is fast, i)
-    monkeypatch.setenv("TROYN_BEHZ", "v1")          # first-generation kernels on the handle that holds the small-prime base
+    plan.set_option("TROYN_BEHZ", "v1")          # first-generation kernels on the handle that holds the small-prime base
     got = pkg.to_host(fast.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
     for i in range(batch):
         assert np.array_equal(got[i], want[i]), ("v1 kernels", i)

@@ -1,7 +1,9 @@
-"""Every A/B switch of the library has both sides executed by the suite.  The switches are environment variables read on every call
-(csrc/troyn.hip env_is / env_int, csrc/ntt_launch.inl), so one process can run both sides; results must stay bit-identical to the oracle.
+"""Every A/B switch of the library has both sides executed by the suite.  The switches are environment variables read ONCE, when a plan is
+created (csrc/troyn.hip TroynOptions), and settable per plan (Plan.set_option = troyn_plan_set_option); the tests below set the environment
+before they create their plan, so one process runs both sides; results must stay bit-identical to the oracle.
 
-  TROYN_KS_MAC=v1 | split   first-generation fused inner product / separate NTT + accumulate launches (default: ksmac2_kernel)
+  TROYN_KS_MAC=split        separate NTT + accumulate launches (default: ksmac2_kernel / ksmaci_kernel; "v1" is accepted and ignored since round 5:
+                            the first-generation kernel's N >= 8192 instantiations left the library)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
   TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
   TROYN_NTT_SMALL_TWO_PASS=0  N = 16384 launches of a few limbs keep the whole-limb tile (default: the two-pass form of the larger rings, 4 workgroups per limb)
@@ -134,7 +136,7 @@ def test_key_switch_workgroup_orders(O, pkg, dev, monkeypatch, n, bits, L, batch
     dtg = pkg.to_device(tg, dev)
     res = {}
     for order in ("band", "item", "row", "plain"):
-        monkeypatch.setenv("TROYN_KS_ORDER", order)
+        plan.set_option("TROYN_KS_ORDER", order)
         dd = pkg.to_device(np.zeros((batch, 2, L, n), dtype=np.uint64), dev)
         plan.switch_key(L, dtg, dkeys, dest=dd, assign=pkg.ASSIGN_OVERWRITE, is_ckks=ckks, is_ntt_form=ckks)
         res[order] = pkg.to_host(dd)
@@ -234,3 +236,42 @@ def test_small_launches_at_n16384(O, pkg, dev, monkeypatch, two_pass, bits):
     want = ctx.mod_switch_scale_to_next(L, e)
     assert np.array_equal(pkg.to_host(plan.divide_and_round_q_last_ntt(L, relin, 2))[0], want)
     assert np.array_equal(pkg.to_host(plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys))[0], want)
+
+
+def test_environment_is_read_only_at_plan_creation(O, pkg, dev, monkeypatch):
+    """no getenv on a call path: flipping the environment after troyn_plan_create changes nothing, troyn_plan_set_option does.  Observable: the
+    fused entry's chunked form needs a workspace layout the one-chunk call does not check -- a plan created under TROYN_MRR=calls keeps composing the
+    three calls; the kernel timer region of the inner product counts two launches per call for the composed form of a mixed chain and more than
+    that nowhere else.  Simpler observable used here: an unknown option is an error, a known one is accepted, and results are the oracle's under
+    options set either way."""
+    n, L = 8192, 3
+    monkeypatch.setenv("TROYN_KS_ORDER", "row")
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [40, 40, 40, 40], L)
+    monkeypatch.setenv("TROYN_KS_ORDER", "definitely-not-an-order")     # ignored: the plan exists already
+    monkeypatch.setenv("TROYN_NTT_ARITH", "u64")
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        plan.set_option("TROYN_NO_SUCH_SWITCH", "1")
+    tg = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(8)])
+    want = [ctx.switch_key(L, True, tg[i], keys, assign=pkg.ASSIGN_OVERWRITE) for i in (0, 7)]
+    t0 = _ks_launches(pkg, plan, lambda: plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    plan.set_option("TROYN_KS_MAC", "split")       # the unfused path has no inner-product launch inside the timer region
+    t1 = _ks_launches(pkg, plan, lambda: plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    plan.set_option("TROYN_KS_MAC", None)
+    t2 = _ks_launches(pkg, plan, lambda: plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    assert (t0, t1, t2) == (1, 0, 1), (t0, t1, t2)
+    got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[7], want[1])
+
+
+def _ks_launches(pkg, plan, fn):
+    """inner-product launches the library's kernel timer saw while fn ran (TROYN_TIMER_KS_INNER_PRODUCT)"""
+    import ctypes as C
+    import torch
+    lib = plan.lib
+    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 1))
+    fn()
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(), C.c_uint64()
+    pkg.capi.check(lib.troyn_kernel_timer_read(0, C.byref(ms), C.byref(cnt)))
+    pkg.capi.check(lib.troyn_kernel_timer_enable(0, 0))
+    return int(cnt.value)

@@ -100,7 +100,7 @@ MIXED_FUSED = [
 
 
 @pytest.mark.parametrize("n,bits,L,batch", MIXED_FUSED)
-def test_fused_chain_mixed_moduli(O, pkg, dev, monkeypatch, n, bits, L, batch):
+def test_fused_chain_mixed_moduli(O, pkg, dev, n, bits, L, batch):
     """multiply -> relinearize -> rescale as one call on chains with moduli of 2^50 and more (per-class launches: ksmaci_kernel and the integer
     forms of the fused transforms next to the FP64 kernels) == the three public calls == the composition of the calls inside the entry
     (TROYN_MRR_MIXED=0) == the oracle"""
@@ -116,9 +116,9 @@ def test_fused_chain_mixed_moduli(O, pkg, dev, monkeypatch, n, bits, L, batch):
     relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
     three = plan.divide_and_round_q_last_ntt(L, relin, 2)
     assert torch.equal(got, three), "fused entry differs from the three-call composition"
-    monkeypatch.setenv("TROYN_MRR_MIXED", "0")
+    plan.set_option("TROYN_MRR_MIXED", "0")
     composed = plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys)
-    monkeypatch.delenv("TROYN_MRR_MIXED")
+    plan.set_option("TROYN_MRR_MIXED", None)
     assert torch.equal(got, composed)
     got = pkg.to_host(got)
     for i in sorted({0, batch // 2, batch - 1}):

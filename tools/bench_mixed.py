@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Chains with moduli of 2^50 and more: relinearize and multiply + relinearize + rescale throughput, with the inner-product launch timed by
-the library's kernel timer.  A/B of the integer inner product: TROYN_KS_MAC=v1 (first-generation kernels) against the default.
+the library's kernel timer.  --ab: the fused entry against the three-call composition inside it (plan option TROYN_MRR_MIXED=0).
   python tools/bench_mixed.py [--ab]"""
 import argparse
 import json
@@ -15,12 +15,14 @@ import __graft_entry__ as entry
 import bench
 
 
-def run(pkg, dev, n, bits, L, B, reps=10):
+def run(pkg, dev, n, bits, L, B, reps=10, opts=()):
     log_n = n.bit_length() - 1
     gen = torch.Generator(device=dev).manual_seed(7)
     q = pkg.capi.coeff_modulus_create(n, bits)
     K = len(q)
     plan = pkg.Plan(dev, log_n, q)
+    for name, val in opts:
+        plan.set_option(name, val)
     prod = bench.uniform_residues(torch, (B, 3), q[:L], n, dev, gen)
     x, y = bench.uniform_residues(torch, (B, 2), q[:L], n, dev, gen), bench.uniform_residues(torch, (B, 2), q[:L], n, dev, gen)
     keys = [bench.uniform_residues(torch, (2,), q, n, dev, gen) for _ in range(L)]
@@ -48,20 +50,12 @@ def main():
     dev = torch.device("cuda", 0)
     shapes = [(8192, [60, 40, 40, 60], 3, 1024), (16384, [60, 50, 50, 50, 50, 60], 5, 512), (8192, [60, 60, 60, 60], 3, 1024), (32768, [60, 50, 50, 60], 3, 256)]
     for n, bits, L, B in shapes:
-        modes = [("default", None)] + ([("v1", "v1")] if a.ab else [])
-        for name, val in modes:
-            if val:
-                os.environ["TROYN_KS_MAC"] = val
-            else:
-                os.environ.pop("TROYN_KS_MAC", None)
-            try:
-                r = run(pkg, dev, n, bits, L, B)
-            except Exception as e:   # a shape one of the generations does not cover
-                r = {"chain": bits, "n": n, "error": str(e)}
-            r["ks_mac"] = name
+        modes = [("default", ())] + ([("three_calls_inside_the_entry", (("TROYN_MRR_MIXED", "0"),))] if a.ab else [])
+        for name, opts in modes:
+            r = run(pkg, dev, n, bits, L, B, opts=opts)
+            r["mode"] = name
             print(json.dumps(r), flush=True)
             torch.cuda.empty_cache()
-    os.environ.pop("TROYN_KS_MAC", None)
 
 
 if __name__ == "__main__":

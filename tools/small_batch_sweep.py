@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a batch of B single-object calls costs when it runs as ONE launch sequence (the call-combining layer of the C++ mirror hands the
 library exactly this): CKKS N = 16384, 6 x 50-bit, B = 1 .. 64, the three calls and the fused entry, digit-parallel inner product forced
-off / on / default (TROYN_KS_SPLIT, read per call).
+off / on / default (plan option TROYN_KS_SPLIT).
 usage: python tools/small_batch_sweep.py"""
 import json
 import os
@@ -45,14 +45,11 @@ def main():
         relin = torch.empty((B, 2, L, n), dtype=torch.int64, device=dev)
         row = {}
         for split in ("default", "0", "1"):
-            if split == "default":
-                os.environ.pop("TROYN_KS_SPLIT", None)
-            else:
-                os.environ["TROYN_KS_SPLIT"] = split
+            plan.set_option("TROYN_KS_SPLIT", None if split == "default" else split)
             t_f = timed(lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out), 100)
             t_r = timed(lambda: plan.relinearize(L, prod, keys, out=relin, is_ckks=True, is_ntt_form=True), 100)
             row["split_" + split] = {"fused_us": round(t_f * 1e6, 1), "relinearize_us": round(t_r * 1e6, 1)}
-        os.environ.pop("TROYN_KS_SPLIT", None)
+        plan.set_option("TROYN_KS_SPLIT", None)
         t_m = timed(lambda: plan.dyadic_convolute(x, 2, y, 2, L, out=prod), 100)
         t_s = timed(lambda: plan.divide_and_round_q_last_ntt(L, relin, 2, out=out), 100)
         row["multiply_us"] = round(t_m * 1e6, 1)

@@ -28,6 +28,7 @@ SYMBOLS = {
     "troyn_plan_destroy": (C.c_int, [vp]),
     "troyn_plan_log_n": (u32, [vp]),
     "troyn_plan_n_moduli": (u32, [vp]),
+    "troyn_plan_set_option": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
     "troyn_plan_get_root": (C.c_int, [vp, u32, p64]),
     "troyn_plan_get_root_powers": (C.c_int, [vp, u32, C.c_int, p64]),
     "troyn_ntt": (C.c_int, [vp, C.c_int, vp, vp, sz, sz, sz, u32, u32, C.c_int, u32, vp]),

@@ -8,34 +8,43 @@
 
 namespace troyn {
 
+// what a launch of the NTT family needs besides its arguments: the stream and the plan's A/B options that select kernel variants
+// (read once when the plan is created, troyn.hip TroynOptions -- no environment access on the launch path)
+struct LaunchCtx {
+    hipStream_t s;
+    int half_mask;             // TROYN_NTT_HALF: half-word LDS tile variants of the whole-limb N = 16384 FP64 transforms; -1 = default
+    bool small_two_pass_off;   // TROYN_NTT_SMALL_TWO_PASS=0
+    int tensor_wgs;            // TROYN_TENSOR_WGS (8 = default)
+};
+
 // optimised transforms of one arithmetic class (false: no kernel for this size -> ntt_generic); each class is instantiated in two
 // translation units, N <= 8192 and N >= 16384
 #define TROYN_DECL_NTT_UNIT(SUFFIX)                                                                                                   \
-    bool launch_ntt_##SUFFIX(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, hipStream_t s, u64* scratch);          \
-    bool launch_ks_mac_##SUFFIX(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s);                    \
-    bool launch_tensor_##SUFFIX(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s);
+    bool launch_ntt_##SUFFIX(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, const LaunchCtx& lc, u64* scratch);          \
+    bool launch_ks_mac_##SUFFIX(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, const LaunchCtx& lc);                    \
+    bool launch_tensor_##SUFFIX(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, const LaunchCtx& lc);
 TROYN_DECL_NTT_UNIT(f64_small) TROYN_DECL_NTT_UNIT(f64_large) TROYN_DECL_NTT_UNIT(u64_small) TROYN_DECL_NTT_UNIT(u64_large)
 #undef TROYN_DECL_NTT_UNIT
-void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t limb_polys, hipStream_t s);
-inline bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
-    return log_n <= 13 ? launch_ntt_f64_small(log_n, a, lp, inverse, s, scratch) : launch_ntt_f64_large(log_n, a, lp, inverse, s, scratch);
+void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t limb_polys, const LaunchCtx& lc);
+inline bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, const LaunchCtx& lc, u64* scratch) {
+    return log_n <= 13 ? launch_ntt_f64_small(log_n, a, lp, inverse, lc, scratch) : launch_ntt_f64_large(log_n, a, lp, inverse, lc, scratch);
 }
-inline bool launch_ntt_u64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, hipStream_t s, u64* scratch) {
-    return log_n <= 13 ? launch_ntt_u64_small(log_n, a, lp, inverse, s, scratch) : launch_ntt_u64_large(log_n, a, lp, inverse, s, scratch);
+inline bool launch_ntt_u64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, const LaunchCtx& lc, u64* scratch) {
+    return log_n <= 13 ? launch_ntt_u64_small(log_n, a, lp, inverse, lc, scratch) : launch_ntt_u64_large(log_n, a, lp, inverse, lc, scratch);
 }
 // first-generation fused key-switch inner product (ks_mac_kernel)
-inline bool launch_ks_mac_f64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
-    return log_n <= 13 ? launch_ks_mac_f64_small(log_n, a, kp, blocks, s) : launch_ks_mac_f64_large(log_n, a, kp, blocks, s);
+inline bool launch_ks_mac_f64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, const LaunchCtx& lc) {
+    return log_n <= 13 ? launch_ks_mac_f64_small(log_n, a, kp, blocks, lc) : launch_ks_mac_f64_large(log_n, a, kp, blocks, lc);
 }
-inline bool launch_ks_mac_u64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
-    return log_n <= 13 ? launch_ks_mac_u64_small(log_n, a, kp, blocks, s) : launch_ks_mac_u64_large(log_n, a, kp, blocks, s);
+inline bool launch_ks_mac_u64(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, const LaunchCtx& lc) {
+    return log_n <= 13 ? launch_ks_mac_u64_small(log_n, a, kp, blocks, lc) : launch_ks_mac_u64_large(log_n, a, kp, blocks, lc);
 }
 // tensor product fused with the transforms (tensor_core_kernel); stage 0 / 2: the strided passes of the two-pass sizes
-inline bool launch_tensor_f64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
-    return log_n <= 13 ? launch_tensor_f64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_f64_large(log_n, stage, a, b, d, batch, s);
+inline bool launch_tensor_f64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, const LaunchCtx& lc) {
+    return log_n <= 13 ? launch_tensor_f64_small(log_n, stage, a, b, d, batch, lc) : launch_tensor_f64_large(log_n, stage, a, b, d, batch, lc);
 }
-inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
-    return log_n <= 13 ? launch_tensor_u64_small(log_n, stage, a, b, d, batch, s) : launch_tensor_u64_large(log_n, stage, a, b, d, batch, s);
+inline bool launch_tensor_u64(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, const LaunchCtx& lc) {
+    return log_n <= 13 ? launch_tensor_u64_small(log_n, stage, a, b, d, batch, lc) : launch_tensor_u64_large(log_n, stage, a, b, d, batch, lc);
 }
 // second-generation key-switch inner product (ksmac2_kernel, log_n = 13 / 14 / 15) and its key preparation
 // digits_f64: the digit rows hold doubles (fused chain: NTT_FLAG_STORE_F64) instead of u64 words; wide_digits: some digit limb is 2^50 or

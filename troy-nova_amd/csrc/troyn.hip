@@ -211,8 +211,71 @@ extern "C" int troyn_kernel_timer_read(int region, double* total_ms, uint64_t* l
 // ---------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------
+// A/B switches.  Rounds 1-4 read them from the environment on EVERY library call (getenv is not safe against a concurrent setenv, and
+// host threads of the C++ mirror run the library concurrently); since round 5 they are read ONCE, when a plan is created, into the plan
+// (troyn_plan_create), and changed per plan with troyn_plan_set_option(plan, "TROYN_...", "value") -- no environment access on any call path.
+struct TroynOptions {
+    bool ntt_u64 = false;            // TROYN_NTT_ARITH=u64: integer butterflies (and the integer inner product) for every modulus
+    int ntt_split = -1;              // TROYN_NTT_SPLIT=0|1: launches over limbs of both classes as one integer launch / always split by class
+    bool tensor_split = false;       // TROYN_BFV_TENSOR=split: separate transform and dyadic launches in the BFV multiply
+    int ks_order = -1;               // TROYN_KS_ORDER=plain|item|row|band (0..3): workgroup order of the inner product kernels
+    int ks_split = -1;               // TROYN_KS_SPLIT=0|1: digit-parallel inner product off / forced on
+    bool ks_tail_split = false;      // TROYN_KS_TAIL=split: coefficient-form tail as separate launches
+    bool ks_mac_split = false;       // TROYN_KS_MAC=split: decomposition NTT and inner product in two launches (the path of N < 1024 / N > 32768)
+    bool ks_diag_loop = false;       // TROYN_KS_DIAG=loop: diagonal digit as an iteration of ksmac2's digit loop
+    int ks_rows = 0;                 // TROYN_KS_ROWS=<r>: rows co-scheduled per XCD by the whole-limb inner product of N < 8192
+    bool ks_mac_shoup_off = false;   // TROYN_KS_MAC_SHOUP=0: Barrett-128 terms in that kernel's integer form
+    bool mrr_mixed_off = false;      // TROYN_MRR_MIXED=0: chains with moduli >= 2^50 compose the three calls inside the fused entry
+    bool mrr_calls = false;          // TROYN_MRR=calls: the fused entry composes the three public calls
+    int mrr_chunk = 0, mrr_streams = 2;   // TROYN_MRR_CHUNK=<items>, TROYN_MRR_STREAMS=<1..4>
+    bool behz_v1 = false;            // TROYN_BEHZ=v1: first-generation conversion kernels (they stay the path of L > 16 and N < 1024)
+    bool behz_base_small = false;    // TROYN_BEHZ_BASE=small: auxiliary base of primes below 2^50 (read by troyn_behz_create)
+    int plain_mac = 0;               // TROYN_PLAIN_MAC=v1|single|dual|quad (1..4): grouping of the ct x pt multiply-accumulate
+    int ntt_half = -1;               // TROYN_NTT_HALF=<mask>
+    bool ntt_small_two_pass_off = false;   // TROYN_NTT_SMALL_TWO_PASS=0
+    int tensor_wgs = 8;              // TROYN_TENSOR_WGS=8|3|2
+};
+static const char* const TROYN_OPTION_NAMES[] = {"TROYN_NTT_ARITH", "TROYN_NTT_SPLIT", "TROYN_BFV_TENSOR", "TROYN_KS_ORDER", "TROYN_KS_SPLIT", "TROYN_KS_TAIL", "TROYN_KS_MAC",
+    "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE",
+    "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS"};
+// value == nullptr or "": the option's default.  false: unknown name.
+static bool option_apply(TroynOptions& o, const char* name, const char* value) {
+    const TroynOptions d;
+    const std::string n = name ? name : "", v = value ? value : "";
+    auto num = [&](int dflt) { return v.empty() ? dflt : (int)strtol(v.c_str(), nullptr, 0); };
+    if (n == "TROYN_NTT_ARITH") o.ntt_u64 = v == "u64";
+    else if (n == "TROYN_NTT_SPLIT") o.ntt_split = v == "0" ? 0 : v == "1" ? 1 : d.ntt_split;
+    else if (n == "TROYN_BFV_TENSOR") o.tensor_split = v == "split";
+    else if (n == "TROYN_KS_ORDER") o.ks_order = v == "plain" ? 0 : v == "item" ? 1 : v == "row" ? 2 : v == "band" ? 3 : d.ks_order;
+    else if (n == "TROYN_KS_SPLIT") o.ks_split = v.empty() ? d.ks_split : num(-1);
+    else if (n == "TROYN_KS_TAIL") o.ks_tail_split = v == "split";
+    else if (n == "TROYN_KS_MAC") o.ks_mac_split = v == "split";
+    else if (n == "TROYN_KS_DIAG") o.ks_diag_loop = v == "loop";
+    else if (n == "TROYN_KS_ROWS") o.ks_rows = num(d.ks_rows);
+    else if (n == "TROYN_KS_MAC_SHOUP") o.ks_mac_shoup_off = v == "0";
+    else if (n == "TROYN_MRR_MIXED") o.mrr_mixed_off = v == "0";
+    else if (n == "TROYN_MRR") o.mrr_calls = v == "calls";
+    else if (n == "TROYN_MRR_CHUNK") o.mrr_chunk = num(d.mrr_chunk);
+    else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
+    else if (n == "TROYN_BEHZ") o.behz_v1 = v == "v1";
+    else if (n == "TROYN_BEHZ_BASE") o.behz_base_small = v == "small";
+    else if (n == "TROYN_PLAIN_MAC") o.plain_mac = v == "v1" ? 1 : v == "single" ? 2 : v == "dual" ? 3 : v == "quad" ? 4 : 0;
+    else if (n == "TROYN_NTT_HALF") o.ntt_half = v.empty() ? d.ntt_half : num(-1);
+    else if (n == "TROYN_NTT_SMALL_TWO_PASS") o.ntt_small_two_pass_off = v == "0";
+    else if (n == "TROYN_TENSOR_WGS") o.tensor_wgs = num(d.tensor_wgs);
+    else return false;
+    return true;
+}
+static TroynOptions options_from_environment() {      // the ONLY place the library reads its switches from the environment (troyn_plan_create)
+    TroynOptions o;
+    for (const char* name : TROYN_OPTION_NAMES)
+        if (const char* e = getenv(name)) option_apply(o, name, e);
+    return o;
+}
+
 struct troyn_plan {
     int device = 0;
+    TroynOptions opt;
     unsigned log_n = 0, n = 0, K = 0;
     std::vector<u64> moduli;
     std::vector<host::NttTable> tables;   // host copies (KAT hooks, BEHZ construction)
@@ -373,6 +436,7 @@ extern "C" int troyn_plan_create(troyn_plan** plan, int device, uint32_t log_n, 
     if (n_moduli < 1 || n_moduli > 64) return fail(TROYN_E_INVALID, "[troyn_plan_create] Invalid coeff modulus count.");
     std::unique_ptr<troyn_plan, void (*)(troyn_plan*)> p(new troyn_plan, plan_free);
     p->device = device; p->log_n = log_n; p->n = 1u << log_n; p->K = n_moduli;
+    p->opt = options_from_environment();
     p->moduli.assign(moduli, moduli + n_moduli);
     for (uint32_t i = 0; i < n_moduli; i++) {
         u64 q = moduli[i];
@@ -397,6 +461,13 @@ extern "C" int troyn_plan_destroy(troyn_plan* plan) {
     return TROYN_OK;
 }
 
+extern "C" int troyn_plan_set_option(troyn_plan* plan, const char* name, const char* value) {
+    if (!plan || !name) return fail(TROYN_E_INVALID, "[troyn_plan_set_option] null argument");
+    // (a handle created from this plan -- troyn_behz, troyn_bgv, ... -- reads the plan's options at call time; TROYN_BEHZ_BASE is read by troyn_behz_create)
+    if (!option_apply(plan->opt, name, value)) return fail(TROYN_E_INVALID, std::string("[troyn_plan_set_option] unknown option ") + name);
+    return TROYN_OK;
+}
+
 extern "C" uint32_t troyn_plan_log_n(const troyn_plan* plan) { return plan ? plan->log_n : 0; }
 extern "C" uint32_t troyn_plan_n_moduli(const troyn_plan* plan) { return plan ? plan->K : 0; }
 
@@ -418,17 +489,13 @@ extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, i
 // ---------------------------------------------------------------------------------------
 // NTT launch
 // ---------------------------------------------------------------------------------------
-// A/B switches are environment variables read on EVERY call (a getenv is a few hundred nanoseconds against launches of tens of
-// microseconds), so that a test can run both sides of a switch in one process (tests/test_gpu_switches.py).
-static inline bool env_is(const char* name, const char* value) { const char* e = getenv(name); return e && std::strcmp(e, value) == 0; }
-static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? (int)strtol(e, nullptr, 0) : dflt; }
-// TROYN_NTT_ARITH=u64 forces the integer butterflies; TROYN_KS_MAC=split keeps decomposition NTT and inner product in two launches,
-// TROYN_KS_MAC=v1 keeps the first-generation fused kernel
-static inline bool force_integer_ntt() { return env_is("TROYN_NTT_ARITH", "u64"); }
+// (the A/B switches live in the plan: TroynOptions above)
+static inline bool force_integer_ntt(const troyn_plan* p) { return p->opt.ntt_u64; }
+static inline LaunchCtx launch_ctx(const troyn_plan* p, hipStream_t s) { return LaunchCtx{s, p->opt.ntt_half, p->opt.ntt_small_two_pass_off, p->opt.tensor_wgs}; }
 
 static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_count) {
     // FP64 butterflies when every modulus this launch can touch is below 2^50
-    bool f64 = !force_integer_ntt() && p->log_n >= 10;
+    bool f64 = !force_integer_ntt(p) && p->log_n >= 10;
     for (unsigned i = 0; f64 && i < table_count; i++) f64 = p->small_modulus[table_start + i] != 0;
     return f64;
 }
@@ -444,15 +511,18 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     if (lp * ((size_t)1 << (p->log_n > 12 ? p->log_n - 12 : 0)) > 0x7fffffffull)
         return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
     bool f64 = use_f64(p, a.table_start, a.table_count);
-    if (!f64 && !force_integer_ntt() && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
-        a.fused_mode == 0 && !env_is("TROYN_NTT_SPLIT", "0") &&
-        ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || env_is("TROYN_NTT_SPLIT", "1"))) {
+    if (!f64 && !force_integer_ntt(p) && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
+        a.fused_mode == 0 && p->opt.ntt_split != 0 &&
+        ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || p->log_n >= 14 || p->opt.ntt_split == 1)) {
         // A component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
         // runs of one class, so that the limbs below 2^50 take the FP64 butterflies instead of following the 60-bit limbs into the
         // integer ones.  Limbs are independent; results are unchanged.  The launches with a fused prologue / epilogue (key-switch tail,
         // rescale) can split the same way (TROYN_NTT_SPLIT=1: their per-component operands move with the run, and the FP64 loader
         // reduces the word of a wide dropped prime with integer arithmetic first, ArithF64::load_io), but they run at the same ~3 TB/s
-        // under either policy, so the extra launch only costs: relinearize {60,40,40,60} 731 k split vs 749 k unsplit -- not the default.
+        // under either policy at N = 8192, so the extra launch only costs there: relinearize {60,40,40,60} 731 k split vs 749 k unsplit -- not the
+        // default at N <= 8192.  N >= 16384 (round 5): the integer kernels are one 1024-thread workgroup per CU (whole-limb tiles) or two strided
+        // passes, the FP64 ones run on half-word tiles: {60,50,50,50,50,60} key-switch tail 835 us unsplit for 512 items, i.e. 163 ns per row
+        // against 83 ns -- split by default (TROYN_NTT_SPLIT=0: one integer launch).
         bool mixed = false;
         for (unsigned j = 1; j < a.ncomp && !mixed; j++) mixed = p->small_modulus[a.table_start + j] != p->small_modulus[a.table_start];
         if (mixed) {
@@ -475,14 +545,14 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     bool done;
     if (f64) {
         a.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
-        done = launch_ntt_f64(p->log_n, a, lp, inverse, s, two_pass_scratch);
+        done = launch_ntt_f64(p->log_n, a, lp, inverse, launch_ctx(p, s), two_pass_scratch);
     } else {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
-        done = launch_ntt_u64(p->log_n, a, lp, inverse, s, two_pass_scratch);
+        done = launch_ntt_u64(p->log_n, a, lp, inverse, launch_ctx(p, s), two_pass_scratch);
     }
     if (!done) {
         a.tw = inverse ? (const void*)p->d_inv : (const void*)p->d_fwd;
-        launch_ntt_generic(a, p->log_n, inverse, lp, s);
+        launch_ntt_generic(a, p->log_n, inverse, lp, launch_ctx(p, s));
     }
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -493,8 +563,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
 // pass, stage 2 = last inverse pass.  Whole-limb sizes (N = 1024 .. 8192): stage 1 is everything.
 // 0: limbs [0, ncomp) of plan p cannot take the fused tensor path; 1: whole-limb tiles; 2: two-pass transforms.  One arithmetic class.
 static int tensor_path_kind(const troyn_plan* p, unsigned ncomp) {
-    const char* e = getenv("TROYN_BFV_TENSOR");   // "split": separate transform and dyadic launches (A/B runs, tests of that path)
-    if (e && std::strcmp(e, "split") == 0) return 0;
+    if (p->opt.tensor_split) return 0;   // TROYN_BFV_TENSOR=split: separate transform and dyadic launches (A/B runs, tests of that path)
     // whole-limb tiles; limbs of both classes: one launch per run of one class (tensor_stage).  N = 16384 holds three polynomials of
     // 16 coefficients per thread under the 128-register cap of a 1024-thread workgroup only with 78-93 spilled registers, and is
     // still 8 % faster than the separate launches (83.8 k vs 77.2 k products/s at 6 x 50-bit)
@@ -523,7 +592,7 @@ static int tensor_stage(const troyn_plan* p, int stage, NttArgs a, NttArgs b, Nt
     };
     prep(a, stage == 2); prep(b, false); prep(d, true);
     if ((batch * a.pcount * a.ncomp) << (p->log_n > 12 ? p->log_n - 12 : 0) > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_ntt] batch too large for one launch");
-if (!(f64 ? launch_tensor_f64(p->log_n, stage, a, b, d, batch, s) : launch_tensor_u64(p->log_n, stage, a, b, d, batch, s)))
+    if (!(f64 ? launch_tensor_f64(p->log_n, stage, a, b, d, batch, launch_ctx(p, s)) : launch_tensor_u64(p->log_n, stage, a, b, d, batch, launch_ctx(p, s))))
         return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused tensor kernel for this size");
     LAUNCH_CHECK();
     return TROYN_OK;
@@ -694,23 +763,24 @@ static __global__ __launch_bounds__(256) void ks_key_quotients_kernel(KeyPtrs ke
 //   2 row:   one output row at a time on the whole chip (keys L2-resident, digits re-fetched per row)
 //   3 band:  per XCD, two rows x as many items as fill its 64 workgroup slots (keys of the band L2-resident, digits fetched once per band);
 //            needs the batch to be a multiple of 8 x 64 / (2 tiles per row) items.  Default for N >= 16384 where it applies.
-static unsigned ksmac_order(size_t batch, unsigned log_n) {
-    if (env_is("TROYN_KS_ORDER", "plain")) return 0u;
+static unsigned ksmac_order(const troyn_plan* p, size_t batch, unsigned log_n) {
+    const int want = p->opt.ks_order;
+    if (want == 0) return 0u;
     if (batch % 8 != 0) return 0u;
-    if (env_is("TROYN_KS_ORDER", "row")) return 2u;
-    if (env_is("TROYN_KS_ORDER", "item")) return 1u;
+    if (want == 2) return 2u;
+    if (want == 1) return 1u;
     const size_t tiles = log_n >= 13 ? (size_t)1 << (log_n - 13) : 1, band_items = 8 * (64 / (2 * tiles));
     if (batch % band_items != 0) return 1u;
     // measured (bench.py other_configs, band vs item): N = 32768 relinearize +8 %, N = 16384 +2 % (the launch itself -4 %), N = 8192 -2..-7 %
     // (a row's keys are 0.4 MB there: every row already fits in L2 under the item order)
-    return (log_n >= 14 || env_is("TROYN_KS_ORDER", "band")) ? 3u : 1u;
+    return (log_n >= 14 || want == 3) ? 3u : 1u;
 }
 
 // The digit-parallel form of the inner product (ksmac2 SPLITJ + ksmac_split_reduce_kernel) pays when the plain form would leave most of the
 // chip idle: batch * rows * tiles workgroups walking L digits one after the other (a single N = 16384 ciphertext: 12 workgroups, 85 us).
 // TROYN_KS_SPLIT=0 / 1 forces it off / on (A/B runs, tests); it needs L >= 2 and its slots in the workspace.
-static bool ksmac_split_wanted(size_t batch, unsigned L, unsigned log_n) {
-    const int e = env_int("TROYN_KS_SPLIT", -1);
+static bool ksmac_split_wanted(const troyn_plan* p, size_t batch, unsigned L, unsigned log_n) {
+    const int e = p->opt.ks_split;
     // L <= 15: the reducer adds the L re-centred slots (|slot| <= p/2 + 1, p < 2^50) in plain doubles, exact below 2^53 (ksmac_split_reduce_kernel)
     if (e == 0 || L < 2 || L > 15 || log_n < 13 || log_n > 15) return false;
     const size_t wgs = batch * (L + 1) << (log_n - 13);
@@ -718,8 +788,8 @@ static bool ksmac_split_wanted(size_t batch, unsigned L, unsigned log_n) {
     return e == 1 || wgs <= 128;
 }
 // slots of the digit-parallel form: provisioned exactly when a call of this shape would take it (both read the same switch)
-static size_t ks_split_words(size_t batch, unsigned L, unsigned log_n) {
-    return ksmac_split_wanted(batch, L, log_n) ? batch * L * 2 * (size_t)(L + 1) * ((size_t)1 << log_n) : 0;
+static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsigned log_n) {
+    return ksmac_split_wanted(p, batch, L, log_n) ? batch * L * 2 * (size_t)(L + 1) * ((size_t)1 << log_n) : 0;
 }
 
 struct KsLayout {
@@ -736,7 +806,7 @@ static KsLayout ks_layout(const troyn_plan* p, unsigned L, size_t batch) {
     w.prod_intt = off;   off += batch * 2 * (size_t)(L + 1) * n;
     w.temp_last = off;   off += batch * 2 * (size_t)L * n;
     w.keys_f64 = off;    off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys of ksmac2_kernel + the diagonal blocks in natural order
-    w.split = off;       off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
+    w.split = off;       off += ks_split_words(p, batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     // Shoup quotients of the keys for the integer inner product: chains with a modulus of 2^50 or more on the whole-limb sizes
     // (N >= 8192: (key, quotient) pairs of the wide rows in the accumulators' layout + the diagonal blocks in natural order, ksmaci_kernel)
     w.keys_quo = off;    off += (p->log_n >= 10 && p->log_n <= 15 && !use_f64(p, 0, p->K)) ? (size_t)L * 2 * p->K * n * (p->log_n >= 13 ? 2 : 1) + (p->log_n >= 13 ? (size_t)p->K * 2 * n * 2 : 0) : 0;
@@ -756,10 +826,7 @@ extern "C" size_t troyn_relinearize_workspace_bytes(const troyn_plan* plan, uint
 struct BgvTail { DevModulus t; u64 inv_special_mod_t; };
 
 // target: [batch] items of L limbs, `target_bstride` elements apart.
-static bool coeff_tail_fused() {
-    const char* e = getenv("TROYN_KS_TAIL");   // "split": inverse transforms and ski_util7 in separate launches (A/B runs, tests of that path)
-    return !(e && std::strcmp(e, "split") == 0);
-}
+static bool coeff_tail_fused(const troyn_plan* p) { return !p->opt.ks_tail_split; }   // TROYN_KS_TAIL=split: inverse transforms and ski_util7 in separate launches
 
 static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_ntt_form,
                            const u64* target, size_t target_bstride, const uint64_t* const* keys, int assign_method,
@@ -794,22 +861,25 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         digits_src = ws + w.target_intt;
         digits_bstride = (size_t)L * n;
     }
-    const bool ks_unfused_mac = env_is("TROYN_KS_MAC", "split");
+    const bool ks_unfused_mac = p->opt.ks_mac_split;
     // (2)+(3) in ONE launch for whole-limb rings (N <= 16384): every workgroup owns one output row of one item,
     //     transforms that row's L digits one after the other and multiplies them into register accumulators with
     //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
     //     (L+1)*L transformed digits never reach HBM.
-    const bool mac_fused = !ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull;
-    const int ks_mac_gen = env_is("TROYN_KS_MAC", "v1") ? 1 : 2;
+    // (N >= 8192: the half-tile kernels, whose grid is up to 4 (L + 2) workgroups per item; the first-generation whole-limb kernel stays the path
+    // of N = 1024 .. 4096 -- its N = 8192 / 16384 instantiations left the library in round 5)
+    const bool mac_fused = !ks_unfused_mac && p->log_n >= 10 && p->log_n <= 15 && batch * (size_t)(L + 1) <= 0x7fffffffull &&
+                           (p->log_n <= 12 || (p->d_fwd_r2 && p->d_fwd_r2i && L + 1 <= 64 && batch * (size_t)(L + 2) * 4 <= 0x7fffffffull));
+    const int ks_mac_gen = p->log_n >= 13 ? 2 : 1;
     // (the band order pads an odd row count with one row of workgroups that exit: the grid guard counts L + 2 rows)
-    if (mac_fused && ks_mac_gen == 2 && p->d_fwd_r2 && use_f64(p, 0, K) && batch * (size_t)(L + 2) * 4 <= 0x7fffffffull) {
+    if (mac_fused && ks_mac_gen == 2 && use_f64(p, 0, K)) {
         // ksmac2_kernel: tiles of 2^13 outputs, two workgroups per CU, keys prepared once per call (ksmac_kernels.hpp)
         double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
         // NTT-form target: the block (key j, modulus j) a second time in natural order -- the diagonal digit is applied in the kernel's
         // epilogue (DG).  The switch is read ONCE per call: the preparation and the instantiation choice must agree.
-        const bool dg = is_ntt_form && !env_is("TROYN_KS_DIAG", "loop");
+        const bool dg = is_ntt_form && !p->opt.ks_diag_loop;
         // the digit-parallel form (small launches) reads the caller's keys as they are: no preparation pass
-        const bool split = ksmac_split_wanted(batch, L, p->log_n) && (dg || !is_ntt_form);
+        const bool split = ksmac_split_wanted(p, batch, L, p->log_n) && (dg || !is_ntt_form);
         if (!split) {
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
             const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 4096);
@@ -825,7 +895,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.mods = p->d_mods; a.tw = p->d_fwd_f64; a.tw_r1 = p->d_fwd_r1; a.tw_r2 = p->d_fwd_r2;
         a.keys = kf; a.key_jstride = 2ll * K * n; a.key_pstride = (long long)K * n;
         a.L = L; a.table_start = 0; a.table_count = K; a.batch = (unsigned)batch;
-        a.grouped = ksmac_order(batch, p->log_n);
+        a.grouped = ksmac_order(p, batch, p->log_n);
         {
             TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
             if (split) {
@@ -837,20 +907,20 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             } else launch_ksmac2(p->log_n, batch, L + 1, a, s);
         }
         LAUNCH_CHECK();
-    } else if (mac_fused && (p->log_n <= 14 || (ks_mac_gen == 2 && p->d_fwd_r2i))) {
+    } else if (mac_fused) {
         // A chain with moduli of 2^50 and more (the reference's default {60,40,40,60}; {60,50,...,60} CKKS chains): the output rows of the
         // moduli below 2^50 take ksmac2_kernel (exact FP64 butterflies; digits of wider limbs are reduced while loading), the rows of the wide
         // moduli the integer kernel of the same shape (ksmaci_kernel, N = 8192 / 16384 / 32768; round 5).  Rows are independent; results are
         // unchanged.  TROYN_NTT_ARITH=u64 sends every row to the integer kernel; N < 8192 and TROYN_KS_MAC=v1 keep the first-generation kernel.
         unsigned long long small_rows = 0, wide_rows = 0;
         bool wide_digits = false;
-        const bool all_integer = force_integer_ntt();
+        const bool all_integer = force_integer_ntt(p);
         for (unsigned k = 0; k <= L; k++) {
             const unsigned mrow = (k == L) ? K - 1 : k;
             if (p->small_modulus[mrow] && !all_integer) small_rows |= 1ull << k; else wide_rows |= 1ull << k;
             if (k < L && !p->small_modulus[k]) wide_digits = true;
         }
-        const bool gen2 = ks_mac_gen == 2 && p->d_fwd_r2 && p->d_fwd_r2i && L + 1 <= 64 && batch * (size_t)(L + 2) * 4 <= 0x7fffffffull;
+        const bool gen2 = ks_mac_gen == 2;
         const bool mixed = gen2 && small_rows != 0;
         TimerScope ts(TROYN_TIMER_KS_INNER_PRODUCT, s);
         if (mixed) {
@@ -866,7 +936,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
             m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
             m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
-            m.grouped = ksmac_order(batch, p->log_n);
+            m.grouped = ksmac_order(p, batch, p->log_n);
             m.row_mask = small_rows;
             launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, false, wide_digits);
             LAUNCH_CHECK();
@@ -889,7 +959,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             m.keys = ki; m.key_jstride = 2ll * slots * n; m.key_pstride = (long long)slots * n;
             m.diag_keys = kdiag;
             m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
-            m.grouped = (batch % 8 == 0 && !env_is("TROYN_KS_ORDER", "plain")) ? 1u : 0u;
+            m.grouped = (batch % 8 == 0 && p->opt.ks_order != 0) ? 1u : 0u;
             m.row_mask = wide_rows;
             launch_ksmaci(p->log_n, batch, m, s, is_ntt_form ? 1 : 0);
             LAUNCH_CHECK();
@@ -905,14 +975,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         {
             // rows of an item co-scheduled per XCD: all L+1 by default (the item's digits are then fetched once per XCD instead of
             // once per row; measured 1265 vs 1310 us per 512-item launch at cfg3), TROYN_KS_ROWS=1 restores plain row-major order
-            const int ks_rows = env_int("TROYN_KS_ROWS", 0);
+            const int ks_rows = p->opt.ks_rows;
             const unsigned R = ks_rows > 0 ? (unsigned)ks_rows : L + 1;
             a.xcd_groups = (R > 1 && batch % 8 == 0 && (L + 1) % R == 0) ? R : 0u;
         }
         a.mods = p->d_mods;
         const bool f64 = use_f64(p, 0, K);
         a.tw = f64 ? (const void*)p->d_fwd_f64 : (const void*)p->d_fwd;
-        if (!f64 && !env_is("TROYN_KS_MAC_SHOUP", "0")) {
+        if (!f64 && !p->opt.ks_mac_shoup_off) {
             // integer policy: the keys' Shoup quotients, once per call (TROYN_KS_MAC_SHOUP=0: Barrett-128 terms as in rounds 1-3; A/B, tests)
             u64* kq = ws + w.keys_quo;
             const size_t words = (size_t)L * 2 * K * n;
@@ -920,8 +990,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             LAUNCH_CHECK();
             a.key_quo = kq; a.key_quo_jstride = 2ll * K * n;
         }
-        if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * (size_t)(L + 1), s);
-        else launch_ks_mac_u64(p->log_n, a, kp, batch * (size_t)(L + 1), s);
+        if (f64) launch_ks_mac_f64(p->log_n, a, kp, batch * (size_t)(L + 1), launch_ctx(p, s));
+        else launch_ks_mac_u64(p->log_n, a, kp, batch * (size_t)(L + 1), launch_ctx(p, s));
         LAUNCH_CHECK();
         }
     } else {
@@ -957,7 +1027,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         if ((rc = launch_ntt(p, a, batch, true, s))) return rc;
         last_src = ws + w.prod_intt; last_stride = n;
         prod_for_util7 = ws + w.poly_prod;
-    } else if (!bgv && p->log_n >= 10 && p->log_n <= 17 && coeff_tail_fused()) {
+    } else if (!bgv && p->log_n >= 10 && p->log_n <= 17 && coeff_tail_fused(p)) {
         // coefficient form: INTT of the two special-prime rows, then the INTT of the 2L data rows finishes the key switch in its epilogue
         // ((5) + (7), ski_util6_merged / ski_util7_merged) and writes the destination -- the INTT'd rows never reach HBM
         NttArgs a = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.prod_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
@@ -1144,7 +1214,7 @@ static bool mrr_fast_path(const troyn_plan* p, uint32_t L) {
     // forms of the fused transforms).  TROYN_MRR_MIXED=0 composes the three public calls for such chains as rounds 2-4 did (A/B runs, tests).
     if (!(p->d_fwd_r2 && L >= 2 && L + 1 <= p->K)) return false;
     if (mrr_all_f64(p, L)) return true;
-    return p->d_fwd_r2i != nullptr && L + 1 <= 64 && !env_is("TROYN_MRR_MIXED", "0");
+    return p->d_fwd_r2i != nullptr && L + 1 <= 64 && !p->opt.mrr_mixed_off;
 }
 
 static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
@@ -1158,7 +1228,7 @@ static MrrLayout mrr_layout(const troyn_plan* p, uint32_t L, size_t batch) {
     w.keys_f64 = off;  off += (size_t)L * 2 * p->K * n + (size_t)L * 2 * n;     // prepared keys + the diagonal blocks in natural order
     // integer rows of a chain with wide moduli: (key, quotient) pairs [L][2][rows][N] + the diagonal blocks [rows][2][N]
     w.keys_int = off;  off += (L >= 1 && L + 1 <= p->K && !mrr_all_f64(p, L)) ? ((size_t)L * 2 * (L + 1) * n + (size_t)(L + 1) * 2 * n) * 2 : 0;
-    w.split = off;     off += ks_split_words(batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
+    w.split = off;     off += ks_split_words(p, batch, L, p->log_n);                        // slots of the digit-parallel inner product (small batches)
     w.fast_total = off;
     // composition of the three public calls (any other shape)
     off = 0;
@@ -1250,7 +1320,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
             m.out = ws + w.poly_prod; m.out_bstride = pp_b; m.out_pstride = pp_p; m.out_cstride = n;
             m.mods = p->d_mods; m.tw = p->d_fwd_f64; m.tw_r1 = p->d_fwd_r1; m.tw_r2 = p->d_fwd_r2;
             m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
-            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(batch, p->log_n);
+            m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(p, batch, p->log_n);
             if (wide_rows) m.row_mask = small_rows;
             if (raw) {
                 m.grouped = 0;
@@ -1272,7 +1342,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
             m.keys = ki; m.key_jstride = 2ll * slots * n; m.key_pstride = (long long)slots * n;
             m.diag_keys = ki + (size_t)L * 2 * slots * n;
             m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch;
-            m.grouped = (batch % 8 == 0 && !env_is("TROYN_KS_ORDER", "plain")) ? 1u : 0u;
+            m.grouped = (batch % 8 == 0 && p->opt.ks_order != 0) ? 1u : 0u;
             m.row_mask = wide_rows;
             launch_ksmaci(p->log_n, batch, m, s, 2);
             LAUNCH_CHECK();
@@ -1334,7 +1404,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     u64* out = (u64*)out_;
     u64* ws = (u64*)workspace;
     int rc;
-    const bool unfused = env_is("TROYN_MRR", "calls");    // composes the three public calls (A/B testing)
+    const bool unfused = p->opt.mrr_calls;    // TROYN_MRR=calls: composes the three public calls (A/B testing)
     if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 4 > 0x7fffffffull) {
         // Evaluator::multiply (evaluator.cu:118-145) -> relinearize (evaluator_keyswitching.cu:119-144) -> rescale_to_next
         if ((rc = launch_convolute(p->d_mods, n, 0, L, a, 2, b, 2, ws + w.prod3, batch, s))) return rc;
@@ -1348,12 +1418,12 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
         if (!keys[j]) return fail(TROYN_E_INVALID, "[Evaluator::switch_key_inplace_internal] null key pointer");
         kp.p[j] = (const u64*)keys[j];
     }
-    const int chunk_env = env_int("TROYN_MRR_CHUNK", 0);
+    const int chunk_env = p->opt.mrr_chunk;
     size_t chunk = batch;
     if (chunk_env > 0 && batch >= 2 * (size_t)chunk_env && (chunk_env % 8) == 0) chunk = (size_t)chunk_env;
     const bool all_f64 = mrr_all_f64(p, L);
     // small launches: the digit-parallel inner product reads the caller's keys as they are (chains of moduli below 2^50)
-    const bool split = chunk == batch && all_f64 && ksmac_split_wanted(batch, L, p->log_n);
+    const bool split = chunk == batch && all_f64 && ksmac_split_wanted(p, batch, L, p->log_n);
     // otherwise: keys prepared once per call (converted to exact doubles in the accumulators' layout), shared by every chunk
     double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
     ulonglong2* ki = reinterpret_cast<ulonglong2*>(ws + w.keys_int);
@@ -1382,7 +1452,7 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     // order; polynomials of a limb back to back) and a second chunk's kernels evict exactly those rows from the L2: one chunk on the
     // caller's stream is faster at every batch size measured (1024 items: 263.6 - 265.2 k vs 260.4 - 260.8 k ops/s with two halves,
     // 263.2 - 264.1 k with three thirds; 2048: 264.1 - 264.6 k vs 260.1 - 262.7 k; 512: 262.3 - 262.9 k vs 257.4 - 258.1 k) and is the default.
-    const int ns = std::min(std::max(env_int("TROYN_MRR_STREAMS", 2), 1), MRR_MAX_STREAMS);
+    const int ns = std::min(std::max(p->opt.mrr_streams, 1), MRR_MAX_STREAMS);
     if (chunk == batch) return mrr_chain(p, L, a, b, kf, ki, out, ws, w, batch, s, split ? &kp : nullptr);
     MrrStreams* ms = mrr_streams(p->device);
     if (!ms) return fail(TROYN_E_INVALID, std::string(P) + " cannot create the internal streams");
@@ -1647,9 +1717,9 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     // 1.01 ms per 64 products, but 13 + 1 primes instead of 10 + 1 make both conversions 29 % longer (0.66 -> 0.83 ms for the floor alone) and
     // add three limbs to every strided pass: 14.0 k against 14.2 k mul+relin ops/s.  It is therefore an OPTION (TROYN_BEHZ_BASE=small, read
     // here), not the default.
-    bool aux50 = env_is("TROYN_BEHZ_BASE", "small");
+    bool aux50 = plan->opt.behz_base_small;
     for (u64 v : q) if (v >= F64_MODULUS_LIMIT) aux50 = false;
-    if (env_is("TROYN_BEHZ", "v1") || L > BEHZ2_MAX_L || plan->log_n < 10) aux50 = false;
+    if (plan->opt.behz_v1 || L > BEHZ2_MAX_L || plan->log_n < 10) aux50 = false;
     if (aux50) {
         try {
             std::vector<u64> cand = host::get_primes(2 * (u64)n, 50, plan->K + 2 * Bsk_ref + 8);
@@ -1674,6 +1744,7 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
 
     int rc = troyn_plan_create(&b->aux, plan->device, plan->log_n, (uint32_t)Bsk, reinterpret_cast<const uint64_t*>(bsk.data()), nullptr);
     if (rc != TROYN_OK) return rc;
+    b->aux->opt = plan->opt;            // the auxiliary base follows the options its plan has NOW (later troyn_plan_set_option calls reach only the plan)
 
     // constant block: all tables in one allocation
     std::vector<u64> blob;
@@ -1872,8 +1943,7 @@ static void dispatch_bound(unsigned v, F4 f4, F8 f8, F16 f16, F64 f64) {
 }
 
 static bool behz2_enabled(const troyn_behz* b) {
-    const char* e = getenv("TROYN_BEHZ");   // "v1": first-generation kernels (A/B runs and the tests of that path)
-    return b->have2 && !(e && std::strcmp(e, "v1") == 0);
+    return b->have2 && !b->plan->opt.behz_v1;   // TROYN_BEHZ=v1: first-generation kernels (A/B runs and the tests of that path)
 }
 
 extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_t pa, const uint64_t* b_, size_t pb,
@@ -2469,7 +2539,8 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
     hipStream_t s = (hipStream_t)stream;
     if (int rc = upload_host_table(s, workspace, tab.data(), tab.size() * sizeof(u64))) return rc;
     const unsigned ch = chunks_pairs(p->n);
-    const int mac_gen = env_is("TROYN_PLAIN_MAC", "v1") ? 1 : 2;   // first-generation kernel (one polynomial per thread) for A/B runs
+    const int pm = p->opt.plain_mac;          // TROYN_PLAIN_MAC: 1 v1 (the kernel of pcount != 2, one polynomial per thread), 2 single, 3 dual, 4 quad
+    const int mac_gen = pm == 1 ? 1 : 2;
     if (pcount == 2 && mac_gen == 2) {
         const size_t rows2 = groups * nmod;
         if (int rc = check_rows(rows2, ch)) return rc;
@@ -2489,9 +2560,9 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
             return true;
         };
         size_t nd = 1;
-        if (!env_is("TROYN_PLAIN_MAC", "single") && !env_is("TROYN_PLAIN_MAC", "packed")) {
-            if (!env_is("TROYN_PLAIN_MAC", "dual") && shared_operands(4)) nd = 4;
-            else if (!env_is("TROYN_PLAIN_MAC", "quad") && shared_operands(2)) nd = 2;
+        if (pm != 2) {
+            if (pm != 3 && shared_operands(4)) nd = 4;
+            else if (pm != 4 && shared_operands(2)) nd = 2;
         }
         if (nd > 1) {
             const size_t rowsd = (groups / nd) * nmod;
@@ -2504,10 +2575,8 @@ extern "C" int troyn_multiply_plain_accumulate(const troyn_plan* p, uint32_t mod
             LAUNCH_CHECK();
             return TROYN_OK;
         }
-        if (env_is("TROYN_PLAIN_MAC", "packed"))      // layout experiment (tools/plain_mac_ab.py): pt[first term of a destination] = base of its packed block
-            hipLaunchKernelGGL((plain_mac2_kernel<2, true>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
-                               ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
-        else
+        // (the packed weight layout of round 4 -- plain_mac2_kernel<2, true>, 0.506 -> 0.537 of HBM, profiles/r04_plain_mac_ab.txt -- was a
+        // development experiment with a second plaintext representation; its instantiation left the library in round 5)
         hipLaunchKernelGGL((plain_mac2_kernel<2>), dim3((unsigned)(rows2 * ch)), dim3(POLY_BLOCK), 0, s,
                            ch, p->d_mods, mod_start, nmod, p->n, (const u64*)workspace, (unsigned)count, (unsigned)groups, set_zero ? 1 : 0);
         LAUNCH_CHECK();

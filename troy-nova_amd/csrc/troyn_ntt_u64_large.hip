@@ -4,14 +4,14 @@
 
 namespace troyn {
 
-bool launch_ntt_u64_large(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, hipStream_t s, u64* scratch) {
-    return launch_ntt_optimised<ArithU64>(log_n, a, limb_polys, inverse, s, scratch);
+bool launch_ntt_u64_large(unsigned log_n, const NttArgs& a, size_t limb_polys, bool inverse, const LaunchCtx& lc, u64* scratch) {
+    return launch_ntt_optimised<ArithU64>(log_n, a, limb_polys, inverse, lc, scratch);
 }
-bool launch_ks_mac_u64_large(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, hipStream_t s) {
-    return launch_ks_mac_t<ArithU64>(log_n, a, kp, blocks, s);
+bool launch_ks_mac_u64_large(unsigned log_n, const NttArgs& a, const KeyPtrs& kp, size_t blocks, const LaunchCtx& lc) {
+    return launch_ks_mac_t<ArithU64>(log_n, a, kp, blocks, lc);
 }
-bool launch_tensor_u64_large(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, hipStream_t s) {
-    return launch_tensor_class<ArithU64>(log_n, stage, a, b, d, batch, s);
+bool launch_tensor_u64_large(unsigned log_n, int stage, const NttArgs& a, const NttArgs& b, const NttArgs& d, size_t batch, const LaunchCtx& lc) {
+    return launch_tensor_class<ArithU64>(log_n, stage, a, b, d, batch, lc);
 }
 
 }  // namespace troyn

@@ -69,6 +69,10 @@ class Plan:
         except Exception:
             pass
 
+    def set_option(self, name, value=None):
+        """an A/B switch of this plan (the library reads the TROYN_* environment variables once, in troyn_plan_create; never on a call)"""
+        capi.check(self.lib.troyn_plan_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
     # -- table inspection (known-answer hooks) --------------------------------------------
     def root(self, i):
         out = C.c_uint64()
