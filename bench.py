@@ -833,6 +833,20 @@ def run_cpp_api():
     for k, v in kv.items():
         if k.startswith(("single_", "batched_")):
             out[k] = float(v)
+    # the reference tool's -c N -mp -md mode: thread i in MemoryPool::create(i % device_count()), one context per device, the same secret key everywhere
+    # (on a one-GPU box: 8 pools on device 0); per-device and aggregate ops/s of single-object and batch-64 calls
+    r2 = subprocess.run([drv, "devices", "8", "10"], capture_output=True, text=True, timeout=900)
+    kv2 = {ln.split()[0]: ln.split()[1] for ln in r2.stdout.splitlines() if len(ln.split()) == 2}
+    if r2.returncode == 0 and "OK" in r2.stdout:
+        out["multi_device_mode"] = {"what": "he_bench_driver devices 8: 8 host threads, pool i on device i % devices, contexts = min(devices, 8) sharing one secret key; "
+                                            "ops/s summed over threads (their timed loops start together)",
+                                    "devices": int(kv2.get("devices", 0)), "pools": int(kv2.get("pools", 0)), "contexts": int(kv2.get("contexts", 0)),
+                                    "same_secret_key": kv2.get("devices_same_secret_key") == "1", "identical": kv2.get("devices_identical") == "1"}
+        for k, v in kv2.items():
+            if k.startswith("devices_") and k.endswith("_ops_per_s"):
+                out["multi_device_mode"][k[len("devices_"):]] = float(v)
+    else:
+        out["multi_device_mode"] = {"error": (r2.stdout + r2.stderr)[-300:]}
     return out
 
 

@@ -6,7 +6,7 @@
 //     multiply_relinearize_rescale_batched;  1 and 4 host threads (the tool's -c option), every thread with its own operands.
 // Every configuration first checks that the fused method is BIT-IDENTICAL to the three calls (payload, parms_id, scale) and that the result
 // decrypts to the slot-wise product.  Output: one `key value` line per measurement (tests/test_gpu_cpp_api.py, bench.py other_configs.cpp_api).
-//   he_bench_driver [check|bench|threads|single|stress] [repeat]
+//   he_bench_driver [check|bench|threads|single|stress] [repeat]   |   he_bench_driver devices [threads] [repeat]  (the tool's -c N -mp -md mode, below)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -42,7 +42,151 @@ static bool same_ct(const Ciphertext& a, const Ciphertext& b) {
     return ha.data().size() == hb.data().size() && std::memcmp(ha.data().raw_pointer(), hb.data().raw_pointer(), ha.data().size() * 8) == 0;
 }
 
+// ---- the reference tool's multi-device mode (`troybench -c N -mp -md`: test/bench/he_operations.cu:33-34, :87-88, :139-147; test/test_multithread.cu:18-37;
+// readme.md:179-202; scripts/compare_bench.sh:12-13): thread i works in its OWN pool on device i % device_count, one context per device (moved there with
+// to_device_inplace(pool)), every context's KeyGenerator built from the SAME secret key cloned to its device.  On a one-GPU box this degrades to N pools on
+// device 0 (the tool's -mp mode).  Checks: all contexts share the secret key; on every pool the fused call equals the three calls and decrypts to the product
+// (with a decryptor of ANOTHER device's context where there is one -- the keys are the same); then single-object and *_batched throughput per device and aggregate.
+//   he_bench_driver devices [threads = 8] [repeat = 20]
+static int run_devices(size_t threads, size_t repeat) {
+    const size_t n = 16384, D = std::max<size_t>(1, utils::device_count());
+    const size_t contexts = std::min(D, threads);
+    EncryptionParameters params(SchemeType::CKKS);
+    params.set_poly_modulus_degree(n);
+    params.set_coeff_modulus(CoeffModulus::create(n, {50, 50, 50, 50, 50, 50}));
+    const double scale = std::pow(2.0, 40);
+    struct Dev {
+        MemoryPoolHandle pool;
+        HeContextPointer context;
+        std::unique_ptr<CKKSEncoder> encoder;
+        std::unique_ptr<KeyGenerator> keygen;
+        std::unique_ptr<Encryptor> encryptor;
+        std::unique_ptr<Decryptor> decryptor;
+        std::unique_ptr<Evaluator> evaluator;
+        RelinKeys rk;
+    };
+    std::vector<MemoryPoolHandle> pools(threads);
+    for (size_t i = 0; i < threads; i++) pools[i] = MemoryPool::create(i % D);
+    // the secret key comes from a key generator on the default device (readme.md:186-190)
+    HeContextPointer he0 = HeContext::create(params, true, SecurityLevel::Classical128, 0x123);
+    he0->to_device_inplace();
+    KeyGenerator keygen0(he0);
+    const SecretKey secret_key = keygen0.secret_key().clone();
+    std::vector<Dev> dev(contexts);
+    for (size_t d = 0; d < contexts; d++) {
+        Dev& x = dev[d];
+        x.pool = pools[d];                       // pools[d] lives on device d (d < D)
+        x.context = HeContext::create(params, true, SecurityLevel::Classical128, 0x123 + d);
+        x.context->to_device_inplace(x.pool);
+        x.encoder.reset(new CKKSEncoder(x.context));
+        x.keygen.reset(new KeyGenerator(x.context, secret_key.to_host().to_device(x.pool), x.pool));      // through the host: no peer access between devices is assumed
+        x.encryptor.reset(new Encryptor(x.context));
+        x.encryptor->set_public_key(x.keygen->create_public_key(false, x.pool));
+        x.decryptor.reset(new Decryptor(x.context, x.keygen->secret_key()));
+        x.evaluator.reset(new Evaluator(x.context));
+        x.rk = x.keygen->create_relin_keys(false, 2, x.pool);
+    }
+    {   // all contexts share the secret key (test_multithread.cu:58-73)
+        const std::vector<uint64_t> s0 = dev[0].keygen->secret_key().to_host().data().to_vector();
+        int same = 1;
+        for (size_t d = 1; d < contexts; d++) same &= dev[d].keygen->secret_key().to_host().data().to_vector() == s0 ? 1 : 0;
+        std::printf("devices %zu\npools %zu\ncontexts %zu\ndevices_same_secret_key %d\n", D, threads, contexts, same);
+    }
+    std::atomic<int> ok{1};
+    std::atomic<size_t> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<double> single3(threads), single1(threads), batched3(threads), batched1(threads);
+    const size_t B = 64, reps_single = std::max<size_t>(50, 800 / threads), reps_batched = std::max<size_t>(repeat, 8);
+    for (int phase = 0; phase < 2; phase++) {     // 0: single objects, 1: batches of 64
+        ready.store(0); go.store(false);
+        auto body = [&](size_t i) {
+            try {
+                Dev& x = dev[i % contexts];
+                MemoryPoolHandle pool = pools[i];
+                const Evaluator& ev = *x.evaluator;
+                std::mt19937_64 gen(11 + i);
+                std::uniform_real_distribution<double> U(-1.0, 1.0);
+                const size_t slots = x.encoder->slot_count();
+                std::vector<cd> z1(slots), z2(slots);
+                for (auto& v : z1) v = cd(U(gen), U(gen));
+                for (auto& v : z2) v = cd(U(gen), U(gen));
+                Ciphertext c1 = x.encryptor->encrypt_asymmetric_new(x.encoder->encode_complex64_simd_new(z1, std::nullopt, scale, pool), pool);
+                Ciphertext c2 = x.encryptor->encrypt_asymmetric_new(x.encoder->encode_complex64_simd_new(z2, std::nullopt, scale, pool), pool);
+                if (phase == 0) {
+                    // parity on THIS pool: fused == three calls; the product decrypts (through the decryptor of the next device's context: same secret key)
+                    Ciphertext m3 = ev.multiply_new(c1, c2, pool);
+                    ev.relinearize_inplace(m3, x.rk, pool);
+                    ev.rescale_to_next_inplace(m3, pool);
+                    Ciphertext m1 = ev.multiply_relinearize_rescale_new(c1, c2, x.rk, pool);
+                    if (!same_ct(m1, m3)) ok.store(0);
+                    Dev& y = dev[(i + 1) % contexts];
+                    Ciphertext moved = &y == &x ? m1.clone(pool) : m1.to_host().to_device(y.pool);
+                    std::vector<cd> got = y.encoder->decode_complex64_simd_new(y.decryptor->decrypt_new(moved, y.pool), y.pool);
+                    double e = 0;
+                    for (size_t k = 0; k < slots; k++) e = std::max(e, std::abs(got[k] - z1[k] * z2[k]));
+                    if (!(e < 1e-4)) ok.store(0);
+                }
+                auto once_single = [&](int fused) {
+                    if (fused) { Ciphertext t = ev.multiply_relinearize_rescale_new(c1, c2, x.rk, pool); }
+                    else { Ciphertext t = ev.multiply_new(c1, c2, pool); Ciphertext r = ev.relinearize_new(t, x.rk, pool); Ciphertext s = ev.rescale_to_next_new(r, pool); }
+                    troyn_sync_current_stream();
+                };
+                std::vector<Ciphertext> A, Bv, d, t1, t2;
+                std::vector<const Ciphertext*> pa, pb, pt1, pt2; std::vector<Ciphertext*> pd, q1, q2;
+                if (phase == 1) {
+                    A.assign(B, c1); Bv.assign(B, c2); d.resize(B); t1.resize(B); t2.resize(B);
+                    for (size_t k = 0; k < B; k++) { pa.push_back(&A[k]); pb.push_back(&Bv[k]); pd.push_back(&d[k]); q1.push_back(&t1[k]); q2.push_back(&t2[k]); pt1.push_back(&t1[k]); pt2.push_back(&t2[k]); }
+                }
+                auto once_batched = [&](int fused) {
+                    if (fused) ev.multiply_relinearize_rescale_batched(pa, pb, x.rk, pd, pool);
+                    else { ev.multiply_batched(pa, pb, q1, pool); ev.relinearize_batched(pt1, x.rk, q2, pool); ev.rescale_to_next_batched(pt2, pd, pool); }
+                    troyn_sync_current_stream();
+                };
+                for (int fused = 0; fused < 2; fused++) {
+                    auto once = [&] { if (phase == 0) once_single(fused); else once_batched(fused); };
+                    { size_t it = 0; for (auto w0 = clk::now(); secs(w0, clk::now()) < 0.05 || it < 4; it++) once(); }
+                    ready.fetch_add(1);
+                    while (ready.load() < (size_t)(fused + 1) * threads) std::this_thread::yield();      // all threads start each timed loop together
+                    const size_t reps = phase == 0 ? reps_single : reps_batched;
+                    auto t0 = clk::now();
+                    for (size_t r = 0; r < reps; r++) once();
+                    const double dt = secs(t0, clk::now());
+                    const double rate = (double)(phase == 0 ? reps : reps * B) / dt;
+                    (phase == 0 ? (fused ? single1 : single3) : (fused ? batched1 : batched3))[i] = rate;
+                }
+                if (phase == 1) {   // the batched results are the single-object results
+                    Ciphertext s = ev.multiply_relinearize_rescale_new(c1, c2, x.rk, pool);
+                    if (!same_ct(d[0], s) || !same_ct(d[B - 1], s)) ok.store(0);
+                }
+            } catch (const std::exception& e) { std::printf("devices thread %zu EXCEPTION %s\n", i, e.what()); ok.store(0); ready.fetch_add(4); }
+        };
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < threads; i++) th.emplace_back(body, i);
+        for (auto& t : th) t.join();
+    }
+    // a thread's rate is measured over its own loop; the loops start together, so per-device and aggregate figures are sums
+    auto report = [&](const char* name, const std::vector<double>& v) {
+        double total = 0;
+        std::vector<double> per(D, 0.0);
+        for (size_t i = 0; i < threads; i++) { total += v[i]; per[i % D] += v[i]; }
+        std::printf("devices_%s_ops_per_s %.1f\n", name, total);
+        for (size_t d = 0; d < D; d++) std::printf("devices_%s_device%zu_ops_per_s %.1f\n", name, d, per[d]);
+    };
+    report("single_three_calls", single3); report("single_fused", single1);
+    report("batch64_three_calls", batched3); report("batch64_fused", batched1);
+    std::printf("devices_identical %d\n", ok.load());
+    std::printf(ok.load() ? "OK\n" : "FAIL\n");
+    dev.clear(); pools.clear();
+    MemoryPool::Destroy();
+    return ok.load() ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::strcmp(argv[1], "devices") == 0) {
+        try {
+            return run_devices(argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 8, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 20);
+        } catch (const std::exception& e) { std::printf("EXCEPTION %s\n", e.what()); return 1; }
+    }
     const bool threads_only = argc > 1 && std::strcmp(argv[1], "threads") == 0;      // only the N-thread single-object sweep
     const bool single_only = argc > 1 && std::strcmp(argv[1], "single") == 0;        // only the one-thread single-object loops (profiling)
     const bool bench = threads_only || single_only || (argc > 1 && std::strcmp(argv[1], "bench") == 0);

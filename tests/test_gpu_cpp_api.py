@@ -248,6 +248,25 @@ def test_call_combining_stress_cpp_api(dev):
     assert kv["stress_wrong"][0] == "0" and int(kv["stress_ops"][0]) >= 24 * 100 and int(kv["stress_combined_calls"][0]) > 0, r.stdout
 
 
+def test_multi_device_mode_cpp_api(dev):
+    """The reference tool's `-c N -mp -md` mode (test/bench/he_operations.cu:33-34, :139-147; test/test_multithread.cu:18-37; readme.md:179-202): thread i
+    works in MemoryPool::create(i % device_count()), one context per device moved there with to_device_inplace(pool), every KeyGenerator built from the
+    same secret key.  On a one-GPU box: 6 pools on device 0.  All contexts share the secret key; on every pool the fused call equals the three calls,
+    decrypts to the product through ANOTHER context's decryptor, and the *_batched results equal the single-object ones; per-device rates are reported."""
+    drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/he_bench_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "devices", "6", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert kv["pools"][0] == "6" and kv["devices_same_secret_key"][0] == "1" and kv["devices_identical"][0] == "1", r.stdout
+    assert int(kv["contexts"][0]) == min(int(kv["devices"][0]), 6)
+    for name in ("single_three_calls", "single_fused", "batch64_three_calls", "batch64_fused"):
+        total = float(kv["devices_%s_ops_per_s" % name][0])
+        per = sum(float(kv["devices_%s_device%d_ops_per_s" % (name, d)][0]) for d in range(int(kv["devices"][0])))
+        assert total > 0 and abs(total - per) <= 1e-6 * total + 1.0, (name, total, per)
+
+
 def test_multithread_call_combining_cpp_api(dev):
     """The same program (BFV: encrypt -> multiply -> relinearize -> add -> mod-switch -> decrypt on 8 host threads) with TROY_COMBINE=1:
     one shared stream, the multiply / relinearize calls of concurrent threads run as batches (troy.h "Call combining"), the other calls
