@@ -537,21 +537,25 @@ def extra_configs(torch, pkg, device):
                        "BFV N=32768, 11x50-bit (L=10): NTT+dyadic+INTT; BEHZ multiply; relinearize; multiply+relinearize", False, two_pass=True, behz_t=1032193)
     # the reference's default chain (test/bench/he_operations.cu:19-33): 60-bit primes take the integer policy
     transform_pipeline(8192, 13, [60, 40, 40, 60], 3, 1024, "N8192_60_40_40_60",
-                       "N=8192 {60,40,40,60} (L=3, K=4; the reference bench tool's default log_q): transforms split by modulus class, relinearize (NTT form)", True)
-    # the usual CKKS shape: wide first and special primes around 50-bit scaling primes (mixed arithmetic classes at N = 16384).  The fused chain composes
-    # the three calls for this chain (its kernels are the all-FP64 ones); reported next to relinearize for the record.
+                       "N=8192 {60,40,40,60} (L=3, K=4; the reference bench tool's default log_q): transforms split by modulus class, relinearize (NTT form): 40-bit rows on "
+                       "ksmac2, 60-bit rows on ksmaci_kernel", True)
+    # the usual CKKS shape: wide first and special primes around 50-bit scaling primes (mixed arithmetic classes at N = 16384).  Since round 5 the fused
+    # chain runs per modulus class for such chains (integer kernels for the wide limbs: ksmaci_kernel, integer forms of the fused transforms).
     transform_pipeline(16384, 14, [60, 50, 50, 50, 50, 60], 5, 512, "N16384_60_50_50_50_50_60",
                        "N=16384 {60,50,50,50,50,60} (L=5, K=6): transforms split by modulus class; relinearize (NTT form): rows of the 50-bit moduli on ksmac2 (wide digits "
-                       "reduced in FP64 while loading), rows of the 60-bit moduli on the integer inner product", True)
-    if True:
-        n, log_n, L, Bn = 16384, 14, 5, 256
-        q = pkg.capi.coeff_modulus_create(n, [60, 50, 50, 50, 50, 60])
+                       "reduced in FP64 while loading), rows of the 60-bit moduli on the integer half-tile inner product (ksmaci_kernel)", True)
+    for key, n, log_n, bits, L, Bn in (("N16384_60_50_50_50_50_60", 16384, 14, [60, 50, 50, 50, 50, 60], 5, 512), ("N8192_60_40_40_60", 8192, 13, [60, 40, 40, 60], 3, 1024)):
+        q = pkg.capi.coeff_modulus_create(n, bits)
         plan = pkg.Plan(device, log_n, q)
         x, y = uniform_residues(torch, (Bn, 2), q[:L], n, device, gen), uniform_residues(torch, (Bn, 2), q[:L], n, device, gen)
         keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
         out = torch.empty((Bn, 2, L - 1, n), dtype=torch.int64, device=device)
-        t = timed(torch, lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out), 5)
-        res["N16384_60_50_50_50_50_60"]["ckks_mul_relin_rescale_ops_per_s"] = round(Bn / t, 1)
+        t = timed(torch, lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out), 10)
+        res[key]["ckks_mul_relin_rescale_ops_per_s"] = round(Bn / t, 1)
+        res[key]["ckks_mul_relin_rescale_batch"] = Bn
+        plan.set_option("TROYN_MRR_MIXED", "0")         # rounds 2-4: the three calls composed inside the entry
+        t3 = timed(torch, lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out), 10)
+        res[key]["ckks_mul_relin_rescale_three_calls_ops_per_s"] = round(Bn / t3, 1)
         del x, y, keys, out, plan
         torch.cuda.empty_cache()
     return res

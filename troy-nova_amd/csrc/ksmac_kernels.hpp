@@ -77,6 +77,7 @@ struct KsMacArgs {
     KeyPtrs raw;
     long long raw_pstride;
     const ulonglong2* split_scale;
+    unsigned no_load_corr;   // half tiles, fused chain: the chain passed ksmac_no_load_corr_ok -> the NLC instantiation
 };
 
 constexpr int KSM_TB = 13;                  // tile bits
@@ -190,7 +191,9 @@ __device__ __forceinline__ void ksm_round5(double (&x)[32], double (&ta)[8], dou
 // NODIAG: coefficient-form target (BFV): there is no diagonal digit, and the instantiation does not carry the loop's diagonal path
 // SPLITJ: one digit per workgroup (KsMacArgs::part), for launches that would otherwise leave most of the chip idle while 12 workgroups
 // walk their L digits one after the other (a single ciphertext: 85 us of a 150 us multiply + relinearize + rescale)
-template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false, bool NODIAG = false, bool SPLITJ = false>
+// NLC (half tiles): no re-centring between layer 0 (applied while loading) and round 0 -- exact when every digit modulus is within ~1.2x of the
+// row's modulus (the host checks the growth bound of the four layers, ksmac_no_load_corr_ok): -3 of ~107 FP64 operations per coefficient and digit
+template <int LOGN, bool DIGF64, int ABL = 0, bool WIDE = false, bool TEN = false, bool DG = false, bool NODIAG = false, bool SPLITJ = false, bool NLC = false>
 #ifndef KSM_WAVES_PER_SIMD
 #define KSM_WAVES_PER_SIMD 2
 #endif
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
         });
         static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
+#ifndef KSM_MAC_NO_FENCE      // experiment (tools/ksmac_variants.sh): let the compiler place the key loads of the window itself
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if constexpr (m + AHEAD < 16) {
                 y0[m + AHEAD] = ksm_gload<double2>(k0 + (abl(1) ? 0 : (m + AHEAD) * 128), koff);
                 y1[m + AHEAD] = ksm_gload<double2>(k1 + (abl(1) ? 0 : (m + AHEAD) * 128), koff);
@@ -421,13 +426,13 @@ __global__ __launch_bounds__(KSM_THREADS, KSM_WAVES_PER_SIMD) void ksmac2_kernel
                 __builtin_amdgcn_sched_barrier(0);
                 const double u0 = dig_in(ru[i].x), u1 = dig_in(ru[i].y), v0 = dig_in(rv[i].x), v1 = dig_in(rv[i].y);
                 // 0 <= u, v < 2^50: one re-centring after the layer instead of one per input
-#ifdef KSM_NO_LOAD_CORR      // experiment (tools/ksbench): chains whose moduli are all within 1.2x of 2^50 need no re-centring before round 0 (|x| <= 1.9 p -> 7.1 p after three layers)
-                x[2 * i] = __builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0);
-                x[2 * i + 1] = __builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1);
-#else
-                x[2 * i] = f64_corr(__builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0), fm);
-                x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
-#endif
+                if constexpr (NLC) {       // |x| <= max q_j + 0.875 p; three more layers stay below 2^53 (checked on the host for this chain)
+                    x[2 * i] = __builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0);
+                    x[2 * i + 1] = __builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1);
+                } else {
+                    x[2 * i] = f64_corr(__builtin_fma(sgn, f64_mulq(v0, w1, inv_p, p), u0), fm);
+                    x[2 * i + 1] = f64_corr(__builtin_fma(sgn, f64_mulq(v1, w1, inv_p, p), u1), fm);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i + W0 < 16) request(std::integral_constant<int, i + W0>{});
             });

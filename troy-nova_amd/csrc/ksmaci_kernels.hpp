@@ -123,7 +123,7 @@ __device__ __forceinline__ void ksmi_round5(u64 (&x)[32], ulonglong2 (&ga)[4], u
 #define KSMI_LOAD_WINDOW 6       // register pairs of the half / quarter tile loaders in flight (two / four 16-byte loads each)
 #endif
 #ifndef KSMI_KEY_AHEAD
-#define KSMI_KEY_AHEAD 2
+#define KSMI_KEY_AHEAD 1       // (1 vs 2 vs 3 measured: profiles/r05_ksmaci_variants.txt; 2 spills 16 more bytes per lane)
 #endif
 
 // EPI: 0 = every digit in the loop (coefficient-form target), 1 = DG (NTT-form target), 2 = TEN (fused chain)

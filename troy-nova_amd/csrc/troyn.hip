@@ -1271,6 +1271,22 @@ static MrrStreams* mrr_streams(int device) {
 // raw != nullptr: digit-parallel inner product on the caller's own keys (small launches; the workspace has its slots and kf was not prepared)
 // Chains with moduli of 2^50 and more: every launch is issued once per run of limbs of one arithmetic class (limbs are independent), the rows
 // that cross classes are canonical u64 words (digits; T rows written by an integer kernel) and each consumer reduces what it reads.
+// ksmac2's NLC instantiation (half tiles, N = 16384, all-FP64 fused chain): the words of a digit enter layer 0 as they are (u, v < max q_j), leave it
+// as |x| <= max q_j + 0.875 p and run the three layers of round 0 without a re-centring in between.  Growth per layer: |x'| <= |x| + (0.5 + 1.5 |x| 2^-52) p
+// (dev_math_f64.hpp); the chain qualifies when every value stays below 2^53 with a 2 % margin for EVERY row modulus p of the launch.
+static bool ksmac_no_load_corr_ok(const troyn_plan* p, unsigned L) {
+    if (p->log_n != 14 || p->opt.ntt_u64) return false;
+    double qmax = 0.0;
+    for (unsigned j = 0; j < L; j++) qmax = std::max(qmax, (double)p->moduli[j]);
+    for (unsigned k = 0; k <= L; k++) {
+        const double pm = (double)p->moduli[k == L ? p->K - 1 : k];
+        double a = qmax + 0.875 * pm;
+        for (int layer = 0; layer < 3; layer++) a += (0.5 + 1.5 * a * 0x1p-52) * pm;
+        if (!(a < 0.98 * 0x1p53)) return false;
+    }
+    return true;
+}
+
 // ki: the integer rows' prepared keys (chains with wide moduli; nullptr otherwise)
 static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b, const double* kf, const ulonglong2* ki, u64* out, u64* ws, const MrrLayout& w,
                      size_t batch, hipStream_t s, const KeyPtrs* raw = nullptr) {
@@ -1322,6 +1338,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
             m.keys = kf; m.key_jstride = 2ll * K * n; m.key_pstride = (long long)K * n;
             m.L = L; m.table_start = 0; m.table_count = K; m.batch = (unsigned)batch; m.grouped = ksmac_order(p, batch, p->log_n);
             if (wide_rows) m.row_mask = small_rows;
+            m.no_load_corr = (all_f64 && ksmac_no_load_corr_ok(p, L)) ? 1u : 0u;
             if (raw) {
                 m.grouped = 0;
                 m.part = reinterpret_cast<double*>(ws + w.split); m.part_jstride = (long long)batch * pp_b;

@@ -7,8 +7,14 @@ void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs&
     const dim3 block(KSM_THREADS);
     // order 3 (bands of two rows): an odd row count is padded with workgroups that exit
     const size_t grid_rows = a.grouped == 3 ? (rows + 1) / 2 * 2 : rows;
+#ifdef KSM_NLC_OFF      // A/B builds (tools/ksmac_variants.sh)
+    const bool nlc = false;
+#else
+    const bool nlc = a.no_load_corr != 0;
+#endif
 #define KSMAC2_CASE(LOGN, TILES)                                                                                            \
-    if (digits_f64 && a.ten_a) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true, 0, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
+    if (digits_f64 && a.ten_a && LOGN == 14 && nlc) hipLaunchKernelGGL((ksmac2_kernel<14, true, 0, false, true, false, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
+    else if (digits_f64 && a.ten_a) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true, 0, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (a.ten_a) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, true, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); /* fused chain of a mixed chain: u64 digits, wide ones reduced while loading */ \
     else if (!digits_f64 && !wide_digits && !a.diag) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (!digits_f64 && !wide_digits && a.diag && a.diag_keys) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
