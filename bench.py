@@ -208,6 +208,31 @@ def counters_record(kernel_tag, batch):
     return None
 
 
+def all_sources_sha():
+    """stamp of every kernel source (tools/collect_valu.py writes the same value)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "troy-nova_amd", "csrc")
+    for nm in sorted(os.listdir(d)):
+        if nm.endswith((".hip", ".hpp", ".inl")):
+            with open(os.path.join(d, nm), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def valu_record(tag):
+    """newest profiles/r*_<tag>_valu.json (tools/collect_valu.py: per-kernel VALU issue accounting of a profiled run) measured on the current kernel sources"""
+    sha = all_sources_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_valu.json" % tag)), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("sources_sha") == sha:
+            rec["_file"] = os.path.relpath(path, ROOT)
+            return rec
+    return None
+
+
 class KernelTimer:
     """the library's measurement hook (include/troyn.h troyn_kernel_timer_*): hipEvent pairs on the launch stream around one named launch"""
 
@@ -347,6 +372,24 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
                 # whole pipeline against the chip's HBM peak, both key accountings of SURVEY 8d (keys per op / keys once per batch)
                 "pipeline": {"bytes_per_op_keys_per_op": 18.0e6, "frac_keys_per_op": round(value / world * 18.0e6 / (HBM_PEAK_GBS * 1e9), 4),
                              "bytes_per_op_keys_amortised": 10.2e6, "frac_keys_amortised": round(value / world * 10.2e6 / (HBM_PEAK_GBS * 1e9), 4)}}
+
+    # The floor of this chain, written down so that it is not asked again: every kernel of the pass is bound by vector-ALU issue
+    # (exact 50-bit modular arithmetic carried in FP64: ~107 FP64 instructions per coefficient and digit in the inner product, ~81-91 per coefficient in the
+    # transforms) -- chain_valu is the per-kernel accounting of a profiled pass; five rebuilds of the inner product (rounds 3-4) and the scheduling / window
+    # variants of round 5 (profiles/r05_ksmac_variants.txt) moved its launch by < 1.5 %.
+    cv = valu_record("bench_chain") if (rank == 0 and fused) else None
+    roofline["floor"] = {
+        "what": "chain-wide vector-ALU issue: lane-operations of one pass over 1024 ciphertext pairs (SQ_INSTS_VALU x 64, every kernel of the chain) against the nominal "
+                "39.3 T lane-operations/s (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; the chip sustains ~2.15-2.25 GHz under this load), next to the pass's measured time",
+        "record": cv["_file"] if cv else None,
+        "lane_ops_per_pass": cv["per_pass"]["valu_lane_ops"] if cv else None,
+        "nominal_ms_per_pass_at_full_issue": cv["per_pass"]["nominal_ms_at_full_issue"] if cv else None,
+        "measured_ms_per_pass": round(elapsed / args.steps / inner * 1e3, 4),
+        "issue_frac_profiled": cv["per_pass"]["issue_frac"] if cv else None,
+        "kernels": [{k: r[k] for k in ("kernel", "avg_us", "time_share", "valu_lane_ops", "simd_valu_busy", "nominal_us_at_full_issue") if k in r} for r in cv["kernels"][:8]] if cv else None,
+        "l2_ceiling": "a tile-step of the inner product moves 320 KB through the L1 (digits 64 KB, twiddles 128 KB, keys 128 KB): at 100 % FP64 issue that is 61 B/clk/CU against "
+                      "56 B/clk/CU of L2 bandwidth, so ~0.8 of the FP64 rate is the most this structure can reach (DESIGN.md section 4)",
+        "experiments": ["profiles/r03_ksmac_ab.txt", "profiles/r04_ksmac_ab.txt", "profiles/r05_ksmac_variants.txt"]}
 
     # the reference's operator boundary: the same ops as three library calls (Evaluator::multiply / relinearize / rescale_to_next), same buffers
     three_call = None
@@ -561,6 +604,30 @@ def extra_configs(torch, pkg, device):
     return res
 
 
+def cfg4_valu_block(nb, n, L, S):
+    """SURVEY 8d's secondary ceiling for cfg4: per kernel, SIMD vector-ALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (launch cycles x 1024 SIMDs)
+    and VALU instructions per coefficient, from the PMC passes of the cfg4 workload (tools/profile_cfg4.sh -> profiles/rNN_cfg4_valu.json).  Every VALU instruction of
+    gfx950 (v_mad_u64_u32, v_mul_lo/hi_u32, v_fma_f64, adds) holds its SIMD for 4 cycles per wave64, so a kernel at busy ~1 can only get faster with fewer instructions."""
+    rec = valu_record("cfg4")
+    if not rec:
+        return {"record": None, "note": "no profiles/r*_cfg4_valu.json for the current kernel sources (tools/profile_cfg4.sh)"}
+    per_coeff = {"tensor_core_kernel<troyn::ArithU64": nb * S * n * 7.0,      # 4 operand + 3 product polynomials per auxiliary limb
+                 "tensor_core_kernel<troyn::ArithF64": nb * L * n * 7.0,
+                 "behz2_floor_kernel": nb * 3 * n * 1.0,                       # per coefficient of a result polynomial (all limbs)
+                 "behz2_lift_kernel": nb * 2 * n * 1.0,
+                 "ksmac2_kernel": nb * (L + 1) * L * n * 1.0}                  # per coefficient and (row, digit)
+    out = []
+    for r in rec["kernels"][:10]:
+        e = {k: r[k] for k in ("kernel", "avg_us", "time_share", "simd_valu_busy", "valu_lane_ops", "nominal_us_at_full_issue") if k in r}
+        for key, denom in per_coeff.items():
+            if key in r["kernel"]:
+                e["valu_instructions_per_coefficient"] = round(r["valu_lane_ops"] / denom, 1)
+        out.append(e)
+    return {"record": rec["_file"], "what": "per kernel of one 64-pair chunk: SIMD VALU busy and instruction counts (integer: 4 v_mad_u64_u32 per base-conversion term with no "
+                                          "carries, 20 instructions per Harvey butterfly; FP64: 8 per butterfly)",
+            "per_chunk": rec.get("per_pass"), "kernels": out}
+
+
 def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     """BASELINE configs[3]: a fixed job of --total BFV N=32768 L=10 multiply+relinearize ops, block-partitioned over the ranks"""
     n, log_n, t_plain = 32768, 15, 1032193
@@ -647,6 +714,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
                 "kernel": "ksmac2_kernel<15>" if dominant_is_ks else "tensor_core_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
                 "algorithmic_bytes_per_launch": dom_alg, "kernels": kernels,
+                "valu_int": cfg4_valu_block(nb, n, L, S),
                 "pipeline": {"bytes_per_op_keys_per_op": 89.2e6, "frac_keys_per_op": round(per_gpu * 89.2e6 / (HBM_PEAK_GBS * 1e9), 4),
                              "bytes_per_op_keys_once_per_launch": 18.4e6 + 13.1e6 + 57.7e6 / nb,
                              "frac_keys_once_per_launch": round(per_gpu * (18.4e6 + 13.1e6 + 57.7e6 / nb) / (HBM_PEAK_GBS * 1e9), 4)}}

@@ -3,7 +3,7 @@
 # profiles/ keeps:  tools/profile_bench.sh <tag>   ->  gpurun_out/<tag>_summary.txt, gpurun_out/<tag>_ksmac_counters.json
 # Run through gpurun from the repository root:  gpurun -- 'bash tools/profile_bench.sh r02_bench_v1'
 set -e
-TAG=${1:-r04_bench}
+TAG=${1:-r05_bench}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
@@ -22,6 +22,10 @@ python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$O
         --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
 python3 tools/collect_counters.py "ksmac2_kernel<14, true, 0, false, true" $((1024 * 6 * 2 * 256)) 1024 "$OUT/${TAG}_ksmac_counters.json" \
         "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db"
+# vector-ALU issue accounting of every kernel of the pass (the chain-wide FP64 floor bench.py reports as roofline.floor)
+python3 tools/collect_valu.py "$OUT/${TAG}_chain_valu.json" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db" --units 1024 --unit-name "ciphertext pairs" \
+        --pass "ksmac2_kernel<14, true, 0, false, true=1" --pass "false, true, true, 5, true>=1" --pass "true, true, true, 3, false>=1" --pass "true, true, true, 4, false>=1" \
+        --pass "true, true, true, 0, true>@2097152=1" --pass "ksmac_prepare_keys_kernel=1"
 # the chunked option (two halves on two internal streams), kernel trace only, for the record
 export TROYN_MRR_CHUNK=512
 cd /tmp

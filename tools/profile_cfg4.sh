@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel trace of the cfg4 workload (BFV N = 32768 L = 10 multiply + relinearize, 256 ops in chunks of 64) -> gpurun_out/<tag>_summary.txt
 set -e
-TAG=${1:-r04_cfg4}
+TAG=${1:-r05_cfg4}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
@@ -16,6 +16,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d "$OUT
 cd "$ROOT"
 python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" --pmc "$OUT/prof_$TAG/FETCH_SIZE/bench_results.db" --pmc "$OUT/prof_$TAG/WRITE_SIZE/bench_results.db" \
         --pmc "$OUT/prof_$TAG/SQ/bench_results.db" --pmc "$OUT/prof_$TAG/GRBM/bench_results.db" > "$OUT/${TAG}_summary.txt"
+python3 tools/collect_valu.py "$OUT/${TAG}_valu.json" "$OUT/prof_$TAG/SQ/bench_results.db" "$OUT/prof_$TAG/GRBM/bench_results.db" --units 64 --unit-name "ciphertext pairs (one chunk)" --base-calls 28
 tail -2 "$OUT/${TAG}_bench.log"
 # the databases are scratch (tens of MB each; gpurun copies back at most 64 MiB): the summaries above are what profiles/ keeps
 rm -rf "$OUT/prof_$TAG"
