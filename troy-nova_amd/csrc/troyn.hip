@@ -926,10 +926,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         if (mixed) {
             double* kf = reinterpret_cast<double*>(ws + w.keys_f64);
             const size_t pairs = (size_t)L * 2 * K * (n / 2);
-            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s);
+            // NTT-form target: the diagonal digit in the epilogue (DG) as in the all-FP64 path -- needs the diagonal key blocks in natural order
+            const bool dg = is_ntt_form && !p->opt.ks_diag_loop;
+            launch_ksmac_prepare_keys(kp, L, 2 * K, n, kf, (unsigned)std::min<size_t>((pairs + 255) / 256, 4096), s, nullptr, nullptr, 0,
+                                      dg ? kf + (size_t)L * 2 * K * n : nullptr);
             LAUNCH_CHECK();
             KsMacArgs m;
             std::memset(&m, 0, sizeof(m));
+            if (dg) m.diag_keys = kf + (size_t)L * 2 * K * n;
             m.digits = digits_src; m.dig_bstride = (long long)digits_bstride; m.dig_cstride = n;
             m.diag = is_ntt_form ? target : nullptr; m.diag_bstride = (long long)target_bstride; m.diag_cstride = n;
             m.out = ws + w.poly_prod; m.out_bstride = 2ll * (L + 1) * n; m.out_pstride = (long long)(L + 1) * n; m.out_cstride = n;

@@ -19,6 +19,7 @@ void launch_ksmac2(unsigned log_n, size_t batch, unsigned rows, const KsMacArgs&
     else if (!digits_f64 && !wide_digits && !a.diag) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (!digits_f64 && !wide_digits && a.diag && a.diag_keys) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, false, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else if (digits_f64) hipLaunchKernelGGL((ksmac2_kernel<LOGN, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
+    else if (wide_digits && a.diag && a.diag_keys) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, true, false, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); /* mixed chain, NTT-form target: DG epilogue */ \
     else if (wide_digits) hipLaunchKernelGGL((ksmac2_kernel<LOGN, false, 0, true>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a); \
     else hipLaunchKernelGGL((ksmac2_kernel<LOGN, false>), dim3((unsigned)(batch * grid_rows * TILES)), block, 0, s, a);
     if (log_n == 15) { KSMAC2_CASE(15, 4) }
