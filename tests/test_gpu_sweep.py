@@ -30,6 +30,7 @@ SWITCHES = {
     "TROYN_NTT_SPLIT": ("0", "1"),
     "TROYN_NTT_HALF": ("0", "0x3f3f", "0x0040", "0x8000"),
     "TROYN_NTT_SMALL_TWO_PASS": ("0",),
+    "TROYN_NTT_OVERLAP": ("0",),
     "TROYN_MRR": ("calls",),
     "TROYN_MRR_MIXED": ("0",),
     "TROYN_MRR_CHUNK": ("8", "16"),

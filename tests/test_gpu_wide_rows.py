@@ -165,3 +165,51 @@ def test_fused_chain_mixed_corner_operands(O, pkg, dev):
         e = ctx.ckks_multiply(L, a[i], a[i])
         e = ctx.relinearize(L, True, e, keys)
         assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), i
+
+
+@pytest.mark.parametrize("n,bits,L,batch", [(8192, [60, 40, 40, 60], 3, 192), (8192, [40, 60, 40, 55, 50], 4, 128), (16384, [60, 50, 50, 60], 3, 96), (32768, [60, 50, 60], 2, 160)])
+def test_per_class_launches_in_flight_together(O, pkg, dev, n, bits, L, batch):
+    """Launches over limbs of both classes run one launch per run of one class; for launches of >= 512 limb-polynomials every other run goes to a side
+    stream (forked from / joined to the caller's stream by events) so that integer (issue-bound) and FP64 (memory-side) runs overlap.  Same words with the
+    overlap off (TROYN_NTT_OVERLAP=0) and in the oracle: key switch in both forms (three assign methods: AddInplace reads the old destination), rescale,
+    plain transforms and the fused chain; the two-pass size keeps one scratch part per run."""
+    import torch
+    q = O.coeff_modulus_create(n, bits)
+    plans = {"on": pkg.Plan(dev, n.bit_length() - 1, q), "off": pkg.Plan(dev, n.bit_length() - 1, q)}
+    plans["off"].set_option("TROYN_NTT_OVERLAP", "0")
+    for scheme, ntt_form in (("ckks", True), ("bfv", False)):
+        ctx = O.Context(scheme, n, q, 0 if scheme == "ckks" else 65537)
+        keys = ctx.random_keys(3, L)
+        dkeys = [pkg.to_device(k, dev) for k in keys]
+        base = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(4)])
+        tg = base[np.arange(batch) % 4]
+        d0b = np.stack([ctx.random_ct(40 + i, 2, L) for i in range(4)])
+        d0 = d0b[(np.arange(batch) + 1) % 4]
+        for assign in (pkg.ASSIGN_OVERWRITE, pkg.ASSIGN_ADD_INPLACE, pkg.ASSIGN_OVERWRITE_EXCEPT_FIRST):
+            res = {}
+            for name, plan in plans.items():
+                dd = pkg.to_device(d0, dev)
+                plan.switch_key(L, pkg.to_device(tg, dev), dkeys, dest=dd, assign=assign, is_ckks=ntt_form, is_ntt_form=ntt_form)
+                res[name] = dd
+            assert torch.equal(res["on"], res["off"]), (scheme, assign)
+            got = pkg.to_host(res["on"])
+            for i in (0, 5, batch - 1):
+                assert np.array_equal(got[i], ctx.switch_key(L, ntt_form, tg[i], keys, assign=assign, dest=d0[i])), (scheme, assign, i)
+    ctx = O.Context("ckks", n, q)
+    keys = ctx.random_keys(21, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    ba = np.stack([ctx.random_ct(100 + i, 2, L) for i in range(4)])
+    bb = np.stack([ctx.random_ct(200 + i, 2, L) for i in range(4)])
+    a, b = ba[np.arange(batch) % 4], bb[(np.arange(batch) // 4) % 4]
+    da, db = pkg.to_device(a, dev), pkg.to_device(b, dev)
+    fused = {name: plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys) for name, plan in plans.items()}
+    assert torch.equal(fused["on"], fused["off"])
+    resc = {name: plan.divide_and_round_q_last_ntt(L, da, 2) for name, plan in plans.items()}
+    assert torch.equal(resc["on"], resc["off"])
+    fwd = {name: plan.ntt(plan.ntt(da, 2, L, inverse=True), 2, L) for name, plan in plans.items()}
+    assert torch.equal(fwd["on"], da) and torch.equal(fwd["off"], da)
+    got, gr = pkg.to_host(fused["on"]), pkg.to_host(resc["on"])
+    for i in (0, 7, batch - 1):
+        e = ctx.relinearize(L, True, ctx.ckks_multiply(L, a[i], b[i]), keys)
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), i
+        assert np.array_equal(gr[i], ctx.mod_switch_scale_to_next(L, a[i])), i

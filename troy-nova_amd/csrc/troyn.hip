@@ -232,12 +232,13 @@ struct TroynOptions {
     bool behz_base_small = false;    // TROYN_BEHZ_BASE=small: auxiliary base of primes below 2^50 (read by troyn_behz_create)
     int plain_mac = 0;               // TROYN_PLAIN_MAC=v1|single|dual|quad (1..4): grouping of the ct x pt multiply-accumulate
     int ntt_half = -1;               // TROYN_NTT_HALF=<mask>
+    bool ntt_overlap_off = false;    // TROYN_NTT_OVERLAP=0: the per-class launches of a chain with wide moduli run one after the other on the caller's stream
     bool ntt_small_two_pass_off = false;   // TROYN_NTT_SMALL_TWO_PASS=0
     int tensor_wgs = 8;              // TROYN_TENSOR_WGS=8|3|2
 };
 static const char* const TROYN_OPTION_NAMES[] = {"TROYN_NTT_ARITH", "TROYN_NTT_SPLIT", "TROYN_BFV_TENSOR", "TROYN_KS_ORDER", "TROYN_KS_SPLIT", "TROYN_KS_TAIL", "TROYN_KS_MAC",
     "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE",
-    "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS"};
+    "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS", "TROYN_NTT_OVERLAP"};
 // value == nullptr or "": the option's default.  false: unknown name.
 static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     const TroynOptions d;
@@ -262,6 +263,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_PLAIN_MAC") o.plain_mac = v == "v1" ? 1 : v == "single" ? 2 : v == "dual" ? 3 : v == "quad" ? 4 : 0;
     else if (n == "TROYN_NTT_HALF") o.ntt_half = v.empty() ? d.ntt_half : num(-1);
     else if (n == "TROYN_NTT_SMALL_TWO_PASS") o.ntt_small_two_pass_off = v == "0";
+    else if (n == "TROYN_NTT_OVERLAP") o.ntt_overlap_off = v == "0";
     else if (n == "TROYN_TENSOR_WGS") o.tensor_wgs = num(d.tensor_wgs);
     else return false;
     return true;
@@ -493,6 +495,53 @@ extern "C" int troyn_plan_get_root_powers(const troyn_plan* plan, uint32_t mi, i
 static inline bool force_integer_ntt(const troyn_plan* p) { return p->opt.ntt_u64; }
 static inline LaunchCtx launch_ctx(const troyn_plan* p, hipStream_t s) { return LaunchCtx{s, p->opt.ntt_half, p->opt.ntt_small_two_pass_off, p->opt.tensor_wgs}; }
 
+// Launches over limbs of BOTH arithmetic classes are issued once per run of limbs of one class (limbs are independent).  The integer runs are bound
+// by vector-ALU issue, the FP64 runs of the memory-side kernels by memory latency / bandwidth, so two such runs in flight fill each other's idle
+// resource: every other run goes to a side stream (one per host thread and device, non-blocking), forked from the caller's stream by an event and
+// joined back to it before the call returns -- the caller still sees one stream order.  Only for launches large enough to fill the chip on their own
+// (a handful of workgroups gains nothing from a second queue and pays two event waits).  TROYN_NTT_OVERLAP=0: one run after the other.
+namespace {
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+SideStream* side_stream(int device) {
+    static thread_local std::vector<SideStream> pool;      // kept for the life of the host thread (the runtime reclaims them at exit)
+    for (auto& x : pool) if (x.device == device) return &x;
+    SideStream x;
+    x.device = device;
+    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (x.fork) (void)hipEventDestroy(x.fork);
+        (void)hipStreamDestroy(x.s);
+        return nullptr;
+    }
+    pool.push_back(x);
+    return &pool.back();
+}
+// runs 0, 2, 4, ... of a split launch go to the side stream, the others stay on the caller's; join() orders the caller's stream behind the side stream
+struct RunOverlap {
+    SideStream* ss = nullptr; hipStream_t main; bool forked = false; unsigned idx = 0;
+    RunOverlap(const troyn_plan* p, hipStream_t s, bool enable) : main(s) { if (enable && !p->opt.ntt_overlap_off) ss = side_stream(p->device); }
+    hipStream_t next() {
+        const bool side = ss && (idx++ & 1u) == 0u;
+        if (!side) return main;
+        if (!forked) {
+            if (hipEventRecord(ss->fork, main) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) { (void)hipGetLastError(); ss = nullptr; return main; }
+            forked = true;
+        }
+        return ss->s;
+    }
+    int join() {       // also on an error path: whatever was queued on the side stream keeps writing the caller's buffers
+        if (!forked) return TROYN_OK;
+        forked = false;
+        if (hipEventRecord(ss->join, ss->s) == hipSuccess && hipStreamWaitEvent(main, ss->join, 0) == hipSuccess) return TROYN_OK;
+        (void)hipStreamSynchronize(ss->s);
+        return TROYN_OK;
+    }
+    ~RunOverlap() { (void)join(); }
+};
+constexpr size_t OVERLAP_MIN_LIMB_POLYS = 512;      // per split launch (all runs together)
+}  // namespace
+
 static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_count) {
     // FP64 butterflies when every modulus this launch can touch is below 2^50
     bool f64 = !force_integer_ntt(p) && p->log_n >= 10;
@@ -513,7 +562,8 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     bool f64 = use_f64(p, a.table_start, a.table_count);
     if (!f64 && !force_integer_ntt(p) && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
         a.fused_mode == 0 && p->opt.ntt_split != 0 &&
-        ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || p->log_n >= 14 || p->opt.ntt_split == 1)) {
+        ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || p->log_n >= 14 || p->opt.ntt_split == 1 ||
+         (!p->opt.ntt_overlap_off && lp >= OVERLAP_MIN_LIMB_POLYS))) {
         // A component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
         // runs of one class, so that the limbs below 2^50 take the FP64 butterflies instead of following the 60-bit limbs into the
         // integer ones.  Limbs are independent; results are unchanged.  The launches with a fused prologue / epilogue (key-switch tail,
@@ -526,6 +576,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
         bool mixed = false;
         for (unsigned j = 1; j < a.ncomp && !mixed; j++) mixed = p->small_modulus[a.table_start + j] != p->small_modulus[a.table_start];
         if (mixed) {
+            RunOverlap ov(p, s, lp >= OVERLAP_MIN_LIMB_POLYS);
             unsigned j0 = 0;
             while (j0 < a.ncomp) {
                 unsigned j1 = j0 + 1;
@@ -536,10 +587,12 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
                 if (a.ext0) r.ext0 = a.ext0 + (long long)j0 * a.ext0_cstride;
                 if (a.ext1) r.ext1 = a.ext1 + (long long)j0 * a.ext1_cstride;
                 if (a.inv_table) r.inv_table = a.inv_table + j0;
-                if (int rc = launch_ntt(p, r, batch, inverse, s, two_pass_scratch)) return rc;
+                // (two-pass sizes: every run keeps its own part of the scratch -- the runs may be in flight together)
+                u64* run_scratch = two_pass_scratch ? two_pass_scratch + batch * (size_t)a.pcount * j0 * p->n : nullptr;
+                if (int rc = launch_ntt(p, r, batch, inverse, ov.next(), run_scratch)) return rc;
                 j0 = j1;
             }
-            return TROYN_OK;
+            return ov.join();
         }
     }
     bool done;
@@ -1302,12 +1355,14 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
     const bool all_f64 = mrr_all_f64(p, L);
     auto small = [&](unsigned mi) { return use_f64(p, mi, 1); };          // this modulus takes the FP64 kernels
     // runs of data limbs [j0, j1) of one class within [0, count)
-    auto for_runs = [&](unsigned count, auto&& f) -> int {
+    // (runs of different classes in flight together: RunOverlap above)
+    auto for_runs = [&](unsigned count, unsigned polys, auto&& f) -> int {
+        RunOverlap ov(p, s, !all_f64 && batch * (size_t)polys * count >= OVERLAP_MIN_LIMB_POLYS);
         for (unsigned j0 = 0, j1; j0 < count; j0 = j1) {
             for (j1 = j0 + 1; j1 < count && small(j1) == small(j0); j1++) {}
-            if (int r = f(j0, j1)) return r;
+            if (int r = f(j0, j1, (j0 == 0 && j1 == count) ? s : ov.next())) return r;
         }
-        return TROYN_OK;
+        return ov.join();
     };
     const bool special_wide = !small(K - 1), last_wide = !small(L - 1);
     bool wide_digits = false;
@@ -1318,14 +1373,14 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         if (k < L && !small(k)) wide_digits = true;
     }
     // (1) digits = INTT(c2), c2 = a1 (.) b1 formed in the loader (kernel_dyadic_convolute's third output + transform_from_ntt, :817-821)
-    if ((rc = for_runs(L, [&](unsigned j0, unsigned j1) {
+    if ((rc = for_runs(L, 1, [&](unsigned j0, unsigned j1, hipStream_t rs) {
         NttArgs x = contiguous_args(p, a + (size_t)j0 * n, ws + w.digits + (size_t)j0 * n, 1, j1 - j0, j0, j1 - j0, TROYN_IDX_COMPONENTWISE, 0);
         x.in_bstride = ct_b; x.in_pstride = ct_p;                          // (the loader reads mul_a / mul_b; `in` only anchors the shapes)
         x.out_bstride = (long long)L * n; x.out_pstride = (long long)L * n;
         mul_operands(x, j0);
         x.fused_mode = NTT_FUSED_MULPAIR;
         if (all_f64) x.flags = NTT_FLAG_STORE_F64;            // the digits go to ksmac2 as doubles (one conversion here instead of L + 1 there)
-        return launch_ntt(p, x, batch, true, s);
+        return launch_ntt(p, x, batch, true, rs);
     }))) return rc;
     // (2) key-switch inner product; the digit of row k under its own modulus is a1 (.) b1 again
     {
@@ -1389,7 +1444,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
     }
     // (5) out_j = (Q_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1, Q_j = P_j qk^-1 + c_j, for the L-1 remaining limbs: ski_util6/7 (:570-658), the
     //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
-    return for_runs(L - 1, [&](unsigned j0, unsigned j1) {
+    return for_runs(L - 1, 2, [&](unsigned j0, unsigned j1, hipStream_t rs) {
         NttArgs x = contiguous_args(p, ws + w.spec_intt, out + (size_t)j0 * n, 2, j1 - j0, j0, j1 - j0, TROYN_IDX_COMPONENTWISE, 0);
         x.in_bstride = 2ll * n; x.in_pstride = n; x.in_cstride = 0;
         x.out_bstride = 2ll * (L - 1) * n; x.out_pstride = (long long)(L - 1) * n;
@@ -1399,7 +1454,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         x.ext0 = ws + w.poly_prod + (size_t)j0 * n; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
         x.fused_mode = (small(j0) && t_flags) ? NTT_FUSED_TAIL_RESCALE_W : NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
         x.flags = t_flags;
-        return launch_ntt(p, x, batch, false, s);
+        return launch_ntt(p, x, batch, false, rs);
     });
 }
 
