@@ -386,7 +386,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         "nominal_ms_per_pass_at_full_issue": cv["per_pass"]["nominal_ms_at_full_issue"] if cv else None,
         "measured_ms_per_pass": round(elapsed / args.steps / inner * 1e3, 4),
         "issue_frac_profiled": cv["per_pass"]["issue_frac"] if cv else None,
-        "kernels": [{k: r[k] for k in ("kernel", "avg_us", "time_share", "valu_lane_ops", "simd_valu_busy", "nominal_us_at_full_issue") if k in r} for r in cv["kernels"][:8]] if cv else None,
+        "kernels": [{k: r[k] for k in ("kernel", "avg_us", "time_share", "valu_lane_ops", "simd_valu_busy", "nominal_us_at_full_issue") if k in r} for r in cv["kernels"] if r.get("launches_per_pass", 1) > 0][:8] if cv else None,
         "l2_ceiling": "a tile-step of the inner product moves 320 KB through the L1 (digits 64 KB, twiddles 128 KB, keys 128 KB): at 100 % FP64 issue that is 61 B/clk/CU against "
                       "56 B/clk/CU of L2 bandwidth, so ~0.8 of the FP64 rate is the most this structure can reach (DESIGN.md section 4)",
         "experiments": ["profiles/r03_ksmac_ab.txt", "profiles/r04_ksmac_ab.txt", "profiles/r05_ksmac_variants.txt"]}
