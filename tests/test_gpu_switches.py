@@ -275,3 +275,21 @@ def _ks_launches(pkg, plan, fn):
     pkg.capi.check(lib.troyn_kernel_timer_read(0, C.byref(ms), C.byref(cnt)))
     pkg.capi.check(lib.troyn_kernel_timer_enable(0, 0))
     return int(cnt.value)
+
+
+@pytest.mark.parametrize("split", ["", "1"])
+def test_many_digits_never_take_the_digit_parallel_form(O, pkg, dev, monkeypatch, split):
+    """ADVICE r04: the reducer of the digit-parallel inner product adds its L slots in plain doubles, exact only for L <= 15 (|slot| <= p/2 + 1, p < 2^50);
+    L = 17 digits of 50-bit primes on a single ciphertext -- a launch small enough to want the digit-parallel form, also when it is forced on -- must
+    take the serial form (accumulators re-centred every 8 digits) and equal the oracle"""
+    if split:
+        monkeypatch.setenv("TROYN_KS_SPLIT", split)
+    else:
+        monkeypatch.delenv("TROYN_KS_SPLIT", raising=False)
+    n, L = 8192, 17
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [50] * 18, L)
+    tg = np.stack([ctx.random_ct(5, 1, L)[0], np.stack([np.full(n, q[l] - 1, dtype=np.uint64) for l in range(L)])])
+    for ntt_form, c in ((True, ctx), (False, O.Context("bfv", n, q, 65537))):
+        got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=ntt_form, is_ntt_form=ntt_form))
+        for i in range(2):
+            assert np.array_equal(got[i], c.switch_key(L, ntt_form, tg[i], keys, assign=pkg.ASSIGN_OVERWRITE)), (ntt_form, i)
