@@ -239,11 +239,9 @@ def test_small_launches_at_n16384(O, pkg, dev, monkeypatch, two_pass, bits):
 
 
 def test_environment_is_read_only_at_plan_creation(O, pkg, dev, monkeypatch):
-    """no getenv on a call path: flipping the environment after troyn_plan_create changes nothing, troyn_plan_set_option does.  Observable: the
-    fused entry's chunked form needs a workspace layout the one-chunk call does not check -- a plan created under TROYN_MRR=calls keeps composing the
-    three calls; the kernel timer region of the inner product counts two launches per call for the composed form of a mixed chain and more than
-    that nowhere else.  Simpler observable used here: an unknown option is an error, a known one is accepted, and results are the oracle's under
-    options set either way."""
+    """No getenv on a call path: the environment is read inside troyn_plan_create only, so flipping it afterwards changes nothing, while
+    troyn_plan_set_option does.  Observable through the library's kernel timer: the fused inner product is ONE timed launch per key switch, the
+    unfused chain (TROYN_KS_MAC=split) has none.  An unknown option name is an error.  Results equal the oracle throughout."""
     n, L = 8192, 3
     monkeypatch.setenv("TROYN_KS_ORDER", "row")
     q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [40, 40, 40, 40], L)
