@@ -998,7 +998,9 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
             launch_ksmac2(p->log_n, batch, (unsigned)__builtin_popcountll(small_rows), m, s, false, wide_digits);
             LAUNCH_CHECK();
         }
-        if (gen2 && wide_rows != 0) {
+        if (gen2 && wide_rows == 0) {
+            // (every row this level touches is narrow although the chain holds a wide modulus elsewhere: ksmac2 above took all of them)
+        } else if (gen2) {
             // integer rows: (key, Shoup quotient) pairs of exactly these rows, in the accumulators' layout, once per call
             const unsigned slots = (unsigned)__builtin_popcountll(wide_rows);
             ulonglong2* ki = reinterpret_cast<ulonglong2*>(ws + w.keys_quo);
