@@ -90,33 +90,28 @@ __device__ __forceinline__ void ksmi_layer(u64 (&x)[32], const ulonglong2* tw, c
 }
 
 // A 5-layer register round whose 31 twiddle pairs sit in a 32-slot vector (slot (1 << lvl) + g; slot 0 unused), fetched four slots at a
-// time, one group ahead of the butterflies that use them.  ga: slots 0..3, gb: slots 4..7, already requested by the caller.
+// time, KSMI_TW_AHEAD groups ahead of the butterflies that use them (ring of KSMI_TW_AHEAD + 1 buffers of four pairs).  Groups 0 .. KSMI_TW_AHEAD - 1
+// (slots 0 .. 4 KSMI_TW_AHEAD - 1) were requested by the caller into tw[0 ..] before the LDS exchange that feeds the round.
+#ifndef KSMI_TW_AHEAD
+#define KSMI_TW_AHEAD 1
+#endif
+constexpr int KSMI_TW_BUFS = KSMI_TW_AHEAD + 1;
 template <class LD>
-__device__ __forceinline__ void ksmi_round5(u64 (&x)[32], ulonglong2 (&ga)[4], ulonglong2 (&gb)[4], LD&& ld, const ArithU64::Mod& md) {
-    auto fetch = [&](ulonglong2 (&g)[4], auto basec) { static_for<0, 4>([&](auto ic) { g[decltype(ic)::value] = ld(decltype(basec)::value + decltype(ic)::value); }); };
-    ksmi_layer<4, 0, 1>(x, ga + 1, md);
-    ksmi_layer<3, 0, 2>(x, ga + 2, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(ga, std::integral_constant<int, 8>{});
-    ksmi_layer<2, 0, 4>(x, gb, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(gb, std::integral_constant<int, 12>{});
-    ksmi_layer<1, 0, 4>(x, ga, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(ga, std::integral_constant<int, 16>{});
-    ksmi_layer<1, 4, 4>(x, gb, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(gb, std::integral_constant<int, 20>{});
-    ksmi_layer<0, 0, 4>(x, ga, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(ga, std::integral_constant<int, 24>{});
-    ksmi_layer<0, 4, 4>(x, gb, md);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(gb, std::integral_constant<int, 28>{});
-    ksmi_layer<0, 8, 4>(x, ga, md);
-    __builtin_amdgcn_sched_barrier(0);
-    ksmi_layer<0, 12, 4>(x, gb, md);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ void ksmi_round5(u64 (&x)[32], ulonglong2 (&tw)[KSMI_TW_BUFS][4], LD&& ld, const ArithU64::Mod& md) {
+    // group g (slots 4g .. 4g+3) serves: g0 -> layers rb 4 (slot 1) and rb 3 (slots 2, 3); g1 -> rb 2; g2, g3 -> rb 1; g4 .. g7 -> rb 0
+    static_for<0, 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + KSMI_TW_AHEAD < 8) {
+            constexpr int gn = g + KSMI_TW_AHEAD;
+            static_for<0, 4>([&](auto ic) { tw[gn % KSMI_TW_BUFS][decltype(ic)::value] = ld(4 * gn + decltype(ic)::value); });
+        }
+        ulonglong2 (&t)[4] = tw[g % KSMI_TW_BUFS];
+        if constexpr (g == 0) { ksmi_layer<4, 0, 1>(x, t + 1, md); ksmi_layer<3, 0, 2>(x, t + 2, md); }
+        else if constexpr (g == 1) ksmi_layer<2, 0, 4>(x, t, md);
+        else if constexpr (g <= 3) ksmi_layer<1, 4 * (g - 2), 4>(x, t, md);
+        else ksmi_layer<0, 4 * (g - 4), 4>(x, t, md);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 #ifndef KSMI_LOAD_WINDOW
@@ -286,7 +281,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmaci_kernel(KsMacIArgs a) {
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- exchange 0 -> 1 -------------------------------------------------------------------------------
-        ulonglong2 ga[4], gb[4];
+        ulonglong2 tw[KSMI_TW_BUFS][4];
         auto ld1 = [&](int s) { return ksm_gload<ulonglong2>(r1u + s, r1off); };
         auto ld2 = [&](int s) { return ksm_gload<ulonglong2>(r2u + ((s >> 1) * 128 + (s & 1)), r2off); };
         __syncthreads();     // every wave has finished reading its slice of the previous digit
@@ -295,10 +290,9 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmaci_kernel(KsMacIArgs a) {
             constexpr unsigned off = ksm_phys(((i & 1) << 9) | ((i >> 1) << 10));
             *reinterpret_cast<ulonglong2*>(&lds[p0 + off]) = make_ulonglong2(x[2 * i], x[2 * i + 1]);
         });
-        // the first two twiddle groups of round 1 travel while the exchange completes (x is dead here)
-        static_for<1, 4>([&](auto ic) { ga[decltype(ic)::value] = ld1(decltype(ic)::value); });
-        ga[0] = ga[1];
-        static_for<0, 4>([&](auto ic) { gb[decltype(ic)::value] = ld1(4 + decltype(ic)::value); });
+        // the first twiddle group(s) of round 1 travel while the exchange completes (x is dead here)
+        static_for<1, 4 * KSMI_TW_AHEAD>([&](auto ic) { constexpr int sl = decltype(ic)::value; tw[sl / 4][sl % 4] = ld1(sl); });
+        tw[0][0] = tw[0][1];
         __syncthreads();
         static_for<0, 32>([&](auto rc) {
             constexpr int R = decltype(rc)::value;
@@ -306,15 +300,14 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmaci_kernel(KsMacIArgs a) {
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- round 1: tile bits 9..5 = register bits 4..0 ----------------------------------------------------
-        ksmi_round5(x, ga, gb, ld1, md);
+        ksmi_round5(x, tw, ld1, md);
         // ---- exchange 1 -> 2: stays inside groups of 32 consecutive threads (tile bits [10,13) = t >> 5 on both sides) -------
         static_for<0, 32>([&](auto rc) {
             constexpr int R = decltype(rc)::value;
             lds[p1 + 34 * R] = x[R];
         });
-        static_for<1, 4>([&](auto ic) { ga[decltype(ic)::value] = ld2(decltype(ic)::value); });
-        ga[0] = ga[1];
-        static_for<0, 4>([&](auto ic) { gb[decltype(ic)::value] = ld2(4 + decltype(ic)::value); });
+        static_for<1, 4 * KSMI_TW_AHEAD>([&](auto ic) { constexpr int sl = decltype(ic)::value; tw[sl / 4][sl % 4] = ld2(sl); });
+        tw[0][0] = tw[0][1];
         __builtin_amdgcn_wave_barrier();
         static_for<0, 16>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -323,7 +316,7 @@ __global__ __launch_bounds__(KSM_THREADS, 2) void ksmaci_kernel(KsMacIArgs a) {
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- round 2: tile bits 4..0 = register bits 4..0, lane-interleaved twiddle pairs ----------------------
-        ksmi_round5(x, ga, gb, ld2, md);
+        ksmi_round5(x, tw, ld2, md);
         // ---- multiply-accumulate with key `it` straight from the registers: lazy Shoup products (any 64-bit digit word may enter) --------
         {
             const ulonglong2* k0 = ksm_uniform(kbase + (long long)it * a.key_jstride);
