@@ -181,7 +181,46 @@ static int run_devices(size_t threads, size_t repeat) {
     return ok.load() ? 0 : 1;
 }
 
+// ---- the pool's reuse rules (troy.h MemoryPool): a block another LIVE thread released is not handed out while fresh memory is to be had -- unless the pool is
+// above its high-water mark, where it synchronises the device once and reuses; a block released while such a wait drains keeps its owner's tag (round-5 fix)
+//   he_bench_driver pool
+static int run_pool() {
+    const size_t MB = size_t(1) << 20, block = 48 * MB;
+    int ok = 1;
+    for (int capped = 0; capped < 2; capped++) {
+        MemoryPoolHandle pool = MemoryPool::create(0);
+        if (capped) pool->set_high_water_bytes(64 * MB);
+        const uint64_t mallocs0 = MemoryPool::device_allocations();
+        std::atomic<int> stage{0};
+        std::thread a([&] {      // thread A allocates and releases a block, then stays alive
+            void* p = pool->allocate(block);
+            pool->release(p);
+            stage.store(1);
+            while (stage.load() != 2) std::this_thread::yield();
+        });
+        while (stage.load() != 1) std::this_thread::yield();
+        void* q = pool->allocate(block);     // thread B (this one): A's block is foreign and A is alive
+        const size_t held = pool->held_bytes();
+        const uint64_t mallocs = MemoryPool::device_allocations() - mallocs0;
+        pool->release(q);
+        void* r = pool->allocate(block);     // B's own block comes straight back
+        const uint64_t mallocs2 = MemoryPool::device_allocations() - mallocs0;
+        pool->release(r);
+        stage.store(2);
+        a.join();
+        std::printf("pool_%s_held_MB %zu\npool_%s_device_allocations %llu\n", capped ? "capped" : "uncapped", held / MB, capped ? "capped" : "uncapped", (unsigned long long)mallocs);
+        ok &= capped ? (held == block && mallocs == 1) : (held == 2 * block && mallocs == 2);      // capped: A's block reused after one device-wide wait
+        ok &= mallocs2 == mallocs ? 1 : 0;
+    }
+    std::printf(ok ? "OK\n" : "FAIL\n");
+    MemoryPool::Destroy();
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::strcmp(argv[1], "pool") == 0) {
+        try { return run_pool(); } catch (const std::exception& e) { std::printf("EXCEPTION %s\n", e.what()); return 1; }
+    }
     if (argc > 1 && std::strcmp(argv[1], "devices") == 0) {
         try {
             return run_devices(argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 8, argc > 3 ? std::strtoul(argv[3], nullptr, 10) : 20);

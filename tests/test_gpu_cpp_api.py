@@ -248,6 +248,18 @@ def test_call_combining_stress_cpp_api(dev):
     assert kv["stress_wrong"][0] == "0" and int(kv["stress_ops"][0]) >= 24 * 100 and int(kv["stress_combined_calls"][0]) > 0, r.stdout
 
 
+def test_pool_high_water_mark_cpp_api(dev):
+    """MemoryPool: a block released by another LIVE host thread is not reused while fresh memory is available (no device-wide wait on the N-thread path);
+    above the high-water mark (set_high_water_bytes / TROY_POOL_HIGH_WATER_MB) the pool synchronises once and reuses instead of growing"""
+    drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/he_bench_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "pool"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    assert kv["pool_uncapped_held_MB"][0] == "96" and kv["pool_capped_held_MB"][0] == "48", r.stdout
+
+
 def test_multi_device_mode_cpp_api(dev):
     """The reference tool's `-c N -mp -md` mode (test/bench/he_operations.cu:33-34, :139-147; test/test_multithread.cu:18-37; readme.md:179-202): thread i
     works in MemoryPool::create(i % device_count()), one context per device moved there with to_device_inplace(pool), every KeyGenerator built from the
