@@ -638,7 +638,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     mine = hi - lo
     plan = pkg.Plan(device, log_n, q)
     behz = pkg.Behz(plan, L, t_plain)
-    S = behz.working_base_size      # limbs of the auxiliary base the multiply works in (14 primes below 2^50 here; the reference's base has 11 of 61 bits)
+    S = behz.working_base_size      # limbs of the auxiliary base the multiply works in (11 + 1 primes below 2^50 here since round 5; the reference's base has 10 + 1 of 61 bits)
     gen = torch.Generator(device=device).manual_seed(0x123)      # the same job on every world size: item i has the same payload
     kgen = torch.Generator(device=device).manual_seed(0xC0FFEE)
     keys = [uniform_residues(torch, (2,), q, n, device, kgen) for _ in range(L)]

@@ -34,16 +34,15 @@ def dev():
     return "cuda:0"
 
 
-@pytest.fixture(params=["v2", "v2-smallbase", "v1"])
+@pytest.fixture(params=["v2", "v2-refbase", "v1"])
 def behz_gen(request, monkeypatch):
-    """both generations of the BEHZ conversion kernels (csrc/behz2_kernels.hpp, csrc/behz_kernels.hpp; the library reads TROYN_BEHZ on
-    every call) and, for the second generation, both auxiliary bases: the reference's 61-bit base (default) and the base of primes below 2^50
-    (TROYN_BEHZ_BASE=small, read by troyn_behz_create; takes effect when every q_i is below 2^50: the multiply's transforms then all run on the
-    FP64 butterflies)"""
+    """both generations of the BEHZ conversion kernels (csrc/behz2_kernels.hpp, csrc/behz_kernels.hpp; TROYN_BEHZ, read when the plan is created) and, for the
+    second generation, both auxiliary bases: primes below 2^50 (the default since round 5 when every q_i is below 2^50: the multiply's transforms then all run on
+    the FP64 butterflies) and the reference's 61-bit base (TROYN_BEHZ_BASE=ref, read by troyn_behz_create)"""
     monkeypatch.delenv("TROYN_BEHZ", raising=False)
     monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
     if request.param == "v1":
         monkeypatch.setenv("TROYN_BEHZ", "v1")
-    elif request.param == "v2-smallbase":
-        monkeypatch.setenv("TROYN_BEHZ_BASE", "small")
+    elif request.param == "v2-refbase":
+        monkeypatch.setenv("TROYN_BEHZ_BASE", "ref")
     return request.param

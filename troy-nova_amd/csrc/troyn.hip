@@ -229,7 +229,8 @@ struct TroynOptions {
     bool mrr_calls = false;          // TROYN_MRR=calls: the fused entry composes the three public calls
     int mrr_chunk = 0, mrr_streams = 2;   // TROYN_MRR_CHUNK=<items>, TROYN_MRR_STREAMS=<1..4>
     bool behz_v1 = false;            // TROYN_BEHZ=v1: first-generation conversion kernels (they stay the path of L > 16 and N < 1024)
-    bool behz_base_small = false;    // TROYN_BEHZ_BASE=small: auxiliary base of primes below 2^50 (read by troyn_behz_create)
+    bool behz_base_ref = false;      // TROYN_BEHZ_BASE=ref: the reference's auxiliary base of 61-bit primes also when every q_i is below 2^50 (read by
+                                     // troyn_behz_create; default since round 5: a base of primes below 2^50 there, "small" = that default)
     int plain_mac = 0;               // TROYN_PLAIN_MAC=v1|single|dual|quad (1..4): grouping of the ct x pt multiply-accumulate
     int ntt_half = -1;               // TROYN_NTT_HALF=<mask>
     bool ntt_overlap_off = false;    // TROYN_NTT_OVERLAP=0: the per-class launches of a chain with wide moduli run one after the other on the caller's stream
@@ -259,7 +260,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_MRR_CHUNK") o.mrr_chunk = num(d.mrr_chunk);
     else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
     else if (n == "TROYN_BEHZ") o.behz_v1 = v == "v1";
-    else if (n == "TROYN_BEHZ_BASE") o.behz_base_small = v == "small";
+    else if (n == "TROYN_BEHZ_BASE") o.behz_base_ref = v == "ref";
     else if (n == "TROYN_PLAIN_MAC") o.plain_mac = v == "v1" ? 1 : v == "single" ? 2 : v == "dual" ? 3 : v == "quad" ? 4 : 0;
     else if (n == "TROYN_NTT_HALF") o.ntt_half = v.empty() ? d.ntt_half : num(-1);
     else if (n == "TROYN_NTT_SMALL_TWO_PASS") o.ntt_small_two_pass_off = v == "0";
@@ -1793,9 +1794,11 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
     // policy.  The oracle keeps the reference's base; equality of the final residues on every BEHZ test is the proof.
     // MEASURED (round 4, BASELINE config 4, profiles/r04_cfg4_ab.txt): bit-identical results, and no gain -- the tensor kernels drop from 1.33 to
     // 1.01 ms per 64 products, but 13 + 1 primes instead of 10 + 1 make both conversions 29 % longer (0.66 -> 0.83 ms for the floor alone) and
-    // add three limbs to every strided pass: 14.0 k against 14.2 k mul+relin ops/s.  It is therefore an OPTION (TROYN_BEHZ_BASE=small, read
-    // here), not the default.
-    bool aux50 = plan->opt.behz_base_small;
+    // add three limbs to every strided pass: 14.0 k against 14.2 k mul+relin ops/s.  ROUND 5: 13 + 1 came from asking for the capacity of the
+    // reference's base itself; the reference's own size criterion (below) is met by 11 + 1 primes -- one row more than the 61-bit base instead of
+    // three: tensor launches 1.33 -> 0.95 ms per 64 products, 14.15 k -> 14.7 k ops/s same box.  It is the DEFAULT whenever it applies (every q_i
+    // below 2^50, second-generation conversions); TROYN_BEHZ_BASE=ref keeps the reference's base (read here).
+    bool aux50 = !plan->opt.behz_base_ref;
     for (u64 v : q) if (v >= F64_MODULUS_LIMIT) aux50 = false;
     if (plan->opt.behz_v1 || L > BEHZ2_MAX_L || plan->log_n < 10) aux50 = false;
     if (aux50) {
@@ -1805,13 +1808,20 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
             for (u64 c : cand) if (std::find(plan->moduli.begin(), plan->moduli.end(), c) == plan->moduli.end()) fresh.push_back(c);
             std::vector<u64> B2;
             size_t next = 1;                                  // fresh[0] becomes m_sk'
+            // Size of the base: the reference's own criterion (utils/rns_tool.cu:50-62: K n t q^2 < q prod(B) m_sk with 32 bits reserved for K n, i.e.
+            // bits(prod(B) m_sk) > 32 + bits(t) + bits(q); it states it for 61-bit primes as 61 (#B + 1)) evaluated on the ACTUAL product of the primes
+            // taken, with two more bits of margin.  (Round 4 asked for the capacity of the reference's base itself, 2^(61 (Bn + 1)): 13 + 1 primes at
+            // BASELINE config 4 where 11 + 1 satisfy the criterion -- every conversion and strided pass scales with the number of rows.)
+            const size_t need_bits = 32 + (size_t)host::product_bit_count(std::vector<u64>{t}) + (size_t)host::product_bit_count(q) + 2;
+            auto enough = [&](const std::vector<u64>& base) {
+                std::vector<u64> with_sk = base; with_sk.push_back(fresh[0]);
+                return (size_t)host::product_bit_count(with_sk) > need_bits;
+            };
             while (next < fresh.size()) {
                 B2.push_back(fresh[next++]);
-                std::vector<u64> with_sk = B2; with_sk.push_back(fresh[0]);
-                if (host::product_bit_count(B2) > 61 * Bn && host::product_bit_count(with_sk) > 61 * (Bn + 1)) break;
+                if (enough(B2)) break;
             }
-            std::vector<u64> with_sk = B2; with_sk.push_back(fresh[0]);
-            if (!fresh.empty() && host::product_bit_count(B2) > 61 * Bn && host::product_bit_count(with_sk) > 61 * (Bn + 1) && B2.size() <= 32) {
+            if (!fresh.empty() && !B2.empty() && enough(B2) && B2.size() <= 32) {
                 B = B2; m_sk = fresh[0]; Bn = B.size();
                 bsk = B; bsk.push_back(m_sk);
             } else aux50 = false;
