@@ -354,8 +354,9 @@ int troyn_behz_destroy(troyn_behz* behz);
 uint32_t troyn_behz_base_Bsk_size(const troyn_behz* behz);
 int troyn_behz_get_base_Bsk(const troyn_behz* behz, uint64_t* out); /* host copy, KAT hook: the base utils/rns_tool.cu:52-80 picks */
 /* Number of primes of the auxiliary base troyn_bfv_multiply actually works in.  Equal to troyn_behz_base_Bsk_size unless every q_i is below
- * 2^50: then the multiply uses MORE primes BELOW 2^50 (same capacity as the reference's 61-bit base, results are independent of the choice),
- * so that all of its transforms take the exact-FP64 butterflies.  Sizes of intermediates follow this count. */
+ * 2^50: then the multiply uses primes BELOW 2^50, sized by the reference's own criterion bits(prod(B) m_sk) > 32 + bits(t) + bits(q)
+ * (utils/rns_tool.cu:50-62; results are independent of the choice), so that all of its transforms take the exact-FP64 butterflies
+ * (plan option TROYN_BEHZ_BASE=ref at creation keeps the reference's base).  Sizes of intermediates follow this count. */
 uint32_t troyn_behz_working_base_size(const troyn_behz* behz);
 uint64_t troyn_behz_gamma(const troyn_behz* behz);
 /* scaling_variant::scale_up / multiply_add_plain / multiply_sub_plain (utils/scaling_variant.cu:17-90,
