@@ -248,6 +248,20 @@ def test_call_combining_stress_cpp_api(dev):
     assert kv["stress_wrong"][0] == "0" and int(kv["stress_ops"][0]) >= 24 * 100 and int(kv["stress_combined_calls"][0]) > 0, r.stdout
 
 
+def test_fused_method_on_wide_chain_cpp_api(dev):
+    """Evaluator::multiply_relinearize_rescale{_new,_inplace,_batched} on the usual CKKS chain {60,50,50,50,50,60} (N = 16384): word-identical to the three calls
+    (single objects, a batch of 16, mixed levels), decrypts to the slot-wise product, the reference's error behaviour, and the same under call combining"""
+    drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/he_bench_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "check60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
+    for key in ("fused_single_identical", "fused_inplace_identical", "fused_batched_identical", "fused_mixed_levels_identical", "combined_identical"):
+        assert kv[key][0] == "1", r.stdout
+    assert float(kv["fused_single_error"][0]) < 1e-4 and kv["fused_errors"][0] == "2", r.stdout
+
+
 def test_pool_high_water_mark_cpp_api(dev):
     """MemoryPool: a block released by another LIVE host thread is not reused while fresh memory is available (no device-wide wait on the N-thread path);
     above the high-water mark (set_high_water_bytes / TROY_POOL_HIGH_WATER_MB) the pool synchronises once and reuses instead of growing"""
