@@ -63,6 +63,8 @@ void launch_ksmaci_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned K, unsig
 // second-generation BEHZ conversions (L = 1 .. 16)
 // aux50: the auxiliary base holds primes below 2^50 (Behz2Dev::NB > L of them) instead of the reference's 61-bit primes
 void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst, bool aux50 = false);
+bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* src, u64* dst_q, u64* dst_bsk,
+                             const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods);
 void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out, bool aux50 = false);
 
 }  // namespace troyn

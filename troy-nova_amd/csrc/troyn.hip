@@ -231,6 +231,7 @@ struct TroynOptions {
     bool behz_v1 = false;            // TROYN_BEHZ=v1: first-generation conversion kernels (they stay the path of L > 16 and N < 1024)
     bool behz_base_ref = false;      // TROYN_BEHZ_BASE=ref: the reference's auxiliary base of 61-bit primes also when every q_i is below 2^50 (read by
                                      // troyn_behz_create; default since round 5: a base of primes below 2^50 there, "small" = that default)
+    bool behz_lift_split = false;    // TROYN_BEHZ_LIFT=split: N = 32768 lifts an operand in three launches (first pass, lift, first pass) instead of one
     int plain_mac = 0;               // TROYN_PLAIN_MAC=v1|single|dual|quad (1..4): grouping of the ct x pt multiply-accumulate
     int ntt_half = -1;               // TROYN_NTT_HALF=<mask>
     bool ntt_overlap_off = false;    // TROYN_NTT_OVERLAP=0: the per-class launches of a chain with wide moduli run one after the other on the caller's stream
@@ -238,7 +239,7 @@ struct TroynOptions {
     int tensor_wgs = 8;              // TROYN_TENSOR_WGS=8|3|2
 };
 static const char* const TROYN_OPTION_NAMES[] = {"TROYN_NTT_ARITH", "TROYN_NTT_SPLIT", "TROYN_BFV_TENSOR", "TROYN_KS_ORDER", "TROYN_KS_SPLIT", "TROYN_KS_TAIL", "TROYN_KS_MAC",
-    "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE",
+    "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE", "TROYN_BEHZ_LIFT",
     "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS", "TROYN_NTT_OVERLAP"};
 // value == nullptr or "": the option's default.  false: unknown name.
 static bool option_apply(TroynOptions& o, const char* name, const char* value) {
@@ -261,6 +262,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
     else if (n == "TROYN_BEHZ") o.behz_v1 = v == "v1";
     else if (n == "TROYN_BEHZ_BASE") o.behz_base_ref = v == "ref";
+    else if (n == "TROYN_BEHZ_LIFT") o.behz_lift_split = v == "split";
     else if (n == "TROYN_PLAIN_MAC") o.plain_mac = v == "v1" ? 1 : v == "single" ? 2 : v == "dual" ? 3 : v == "quad" ? 4 : 0;
     else if (n == "TROYN_NTT_HALF") o.ntt_half = v.empty() ? d.ntt_half : num(-1);
     else if (n == "TROYN_NTT_SMALL_TWO_PASS") o.ntt_small_two_pass_off = v == "0";
@@ -2055,8 +2057,18 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     // product and starts the inverse transforms
     const int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
     const bool tensor = tkind != 0, whole = tkind == 1;
+    // N = 32768 under the FP64 policy: first pass of base q, lift and first pass of the lifted rows as one launch (behz2_lift_pass1.hpp)
+    const bool lift_fused = tkind == 2 && gen2 && b->aux50 && b->smallq && pq->log_n == 15 && !pq->opt.behz_lift_split
+                            && use_f64(pq, 0, L) && use_f64(px, 0, S);
     auto lift = [&](const u64* src, size_t pcount, u64* dst_q, u64* dst_bsk) -> int {
         // steps (1)-(3) of evaluator.cu:50-60 for one operand
+        if (lift_fused) {
+            if (batch * pcount * 128u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
+            if (launch_behz2_lift_pass1(L, batch * pcount, s, b->dev2, src, dst_q, dst_bsk, (const double*)pq->d_fwd_f64, (const double*)px->d_fwd_f64, pq->d_mods, px->d_mods)) {
+                LAUNCH_CHECK();
+                return TROYN_OK;
+            }
+        }
         NttArgs a = contiguous_args(pq, src, dst_q, pcount, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
         int r = whole ? TROYN_OK : tensor ? tensor_stage(pq, 0, a, a, a, batch, s) : launch_ntt(pq, a, batch, false, s);   // whole: the tensor kernel reads src
         if (r) return r;

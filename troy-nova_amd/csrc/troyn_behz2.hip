@@ -1,5 +1,6 @@
 // kernel instantiations of the second-generation BEHZ conversions (behz2_kernels.hpp): one per base size and modulus class
 #include "launch.hpp"
+#include "behz2_lift_pass1.hpp"
 
 namespace troyn {
 
@@ -24,6 +25,22 @@ void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, u
         BEHZ2_CASES(X)
 #undef X
         default: break;
+    }
+}
+
+// lift + first forward pass of both bases in one launch (behz2_lift_pass1.hpp): N = 32768, FP64 policy
+bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* src, u64* dst_q, u64* dst_bsk,
+                             const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods) {
+    const unsigned rows = L + c.NB + 1;
+    if (rows > LIFT_PASS1_MAX_ROWS) return false;
+    LiftPass1Args a{src, dst_q, dst_bsk, tw_q, tw_aux, q_mods, aux_mods};
+    const dim3 grid((unsigned)(items * 128u)), block(256);
+    const size_t lds = (size_t)rows * 256u * sizeof(u64);
+    switch (L) {
+#define X(N) case N: hipLaunchKernelGGL((behz2_lift_pass1_kernel<N>), grid, block, lds, s, c, a); return true;
+        BEHZ2_CASES(X)
+#undef X
+        default: return false;
     }
 }
 
