@@ -248,6 +248,36 @@ def test_bfv_multiply_two_pass_sizes(O, pkg, dev, monkeypatch, bits, L, tensor):
     assert np.array_equal(pkg.to_host(da), a)
 
 
+@pytest.mark.parametrize("bits,L", [([45] * 2, 1), ([40, 45, 49], 2), ([50] * 8, 7), ([36] * 13, 12), ([30] * 16, 15)])
+def test_bfv_multiply_lift_with_first_pass(O, pkg, dev, bits, L):
+    """N = 32768, every modulus below 2^50: the operand's first forward pass over base q, the lift q -> Bsk (fgk/rns_tool.cu:7-100) and the
+    first pass over the lifted rows run as ONE launch (behz2_lift_pass1_kernel; rows of both bases meet in LDS); TROYN_BEHZ_LIFT=split keeps the
+    three launches.  Both must give the oracle's product; 2 x 2 components, an odd batch, corner operands, the squaring shortcut.  L = 15: more
+    rows than the kernel's LDS budget covers -- the entry falls back to the three launches by itself."""
+    n, t = 32768, 65537
+    ctx, plan, q = _setup(O, pkg, dev, "bfv", n, bits, t)
+    batch = 3
+    a = np.stack([ctx.random_ct(331 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(347 + i, 2, L) for i in range(batch)])
+    qa = np.array(q[:L], dtype=np.uint64)[None, :, None]
+    a[1] = np.broadcast_to(qa - 1, a[1].shape)
+    b[1][..., ::2] = 0
+    b[1][..., 1::2] = np.broadcast_to(qa - 1, b[1][..., 1::2].shape)
+    want = [ctx.bfv_multiply(L, a[i], b[i]) for i in (0, 1)]
+    outs = {}
+    for mode in (None, "split"):
+        plan.set_option("TROYN_BEHZ_LIFT", mode)
+        behz = pkg.Behz(plan, L, t)
+        got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), 2, pkg.to_device(b, dev), 2))
+        for i in (0, 1):
+            assert np.array_equal(got[i], want[i]), (mode, i)
+        da = pkg.to_device(a, dev)
+        sq = pkg.to_host(behz.multiply(da, 2, da, 2))
+        outs[mode] = (got, sq)
+    assert np.array_equal(outs[None][0], outs["split"][0]) and np.array_equal(outs[None][1], outs["split"][1])
+    assert np.array_equal(outs[None][1][2], ctx.bfv_multiply(L, a[2], a[2]))
+
+
 def test_error_behaviour(O, pkg, dev):
     # misuse -> invalid_argument-style errors, mirroring the reference's checks
     n = 1024

@@ -38,6 +38,7 @@ SWITCHES = {
     "TROYN_BFV_TENSOR": ("split",),
     "TROYN_TENSOR_WGS": ("2", "3"),
     "TROYN_BEHZ": ("v1",),
+    "TROYN_BEHZ_LIFT": ("split",),
     "TROYN_PLAIN_MAC": ("v1", "single", "dual", "quad"),
 }
 

@@ -33,6 +33,7 @@ template <typename T> __device__ __forceinline__ cu32p as_c32(const T* p) { retu
 
 constexpr unsigned BEHZ2_MAX_L = 16;
 constexpr unsigned BEHZ2_RC = 8;   // u64 words of per-row constants
+constexpr unsigned BEHZ2_FUSED_MAX_ROWS = 31;   // behz2_lift_pass1.hpp: rows of both bases in LDS, 2 KB each (64 KB of dynamic LDS without an attribute)
 
 // row constants (u64 index)
 enum { B2_P = 0, B2_RLO = 1, B2_RHI = 2, B2_MU = 3, B2_C0 = 4, B2_C1 = 5 };
@@ -199,15 +200,39 @@ __device__ __forceinline__ u128 behz2_dot(const u32 (&xlo)[L], const u32 (&xhi)[
     return v;
 }
 
-// scaled input residues of base q, split at SHQ
-template <int L, int SHQ>
-__device__ __forceinline__ void behz2_load_q(const u64* ip, unsigned n, unsigned x, cu64x2p scale, cmodp q_mods, u32 (&ylo)[L], u32 (&yhi)[L]) {
+// scaled input residues of base q from any source (load(i) = canonical residue i of this coefficient)
+template <int L, int SHQ, class LD>
+__device__ __forceinline__ void behz2_scale_q(LD&& load, cu64x2p scale, cmodp q_mods, u32 (&ylo)[L], u32 (&yhi)[L]) {
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const ulonglong2 f = ld_pair(scale, i);
-        const u64 y = shoup_mul(ip[(size_t)i * n + x], f.x, f.y, q_mods[i].q);
+        const u64 y = shoup_mul(load(i), f.x, f.y, q_mods[i].q);
         ylo[i] = (u32)y & ((1u << SHQ) - 1);
         yhi[i] = (u32)(y >> SHQ);
+    }
+}
+
+// BEHZ steps (1)-(2) at one coefficient: load(i) = residue of base q, store(b, word) = lifted residue of row b (0 .. NB)
+template <int L, bool SMALLQ, bool AUX50, class LD, class ST>
+__device__ __forceinline__ void behz2_lift_one(const Behz2Dev& c, LD&& load, ST&& store) {
+    constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
+    const cu32p mtrow = as_c32(c.lift_mt), rows = as_c32(c.lift_rows);
+    const cu64p rcs = as_c64(c.lift_rc);
+    const unsigned Lp = c.rs >> 1, NB = c.NB;
+    u32 ylo[L], yhi[L];
+    behz2_scale_q<L, SHQ>(load, as_c128(c.q_mt_inv_punc), as_cmod(c.q_mods), ylo, yhi);
+    // q -> {m_tilde = 2^32} and the multiplication by -q^-1: everything modulo 2^32
+    u32 r_mt = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r_mt += (ylo[i] | (yhi[i] << SHQ)) * mtrow[i];
+    const bool neg = r_mt >= 0x80000000u;
+#pragma unroll 1
+    for (unsigned b = 0; b <= NB; ++b) {
+        const cu32p row = rows + (size_t)b * c.rs;
+        const cu64p rc = rcs + (size_t)b * BEHZ2_RC;
+        u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
+        v += (u128)rc[B2_C0] * r_mt + (neg ? rc[B2_C1] : 0ull);
+        store(b, behz2_reduce_aux<SMALLQ && !AUX50>(v, rc));
     }
 }
 
@@ -215,100 +240,86 @@ __device__ __forceinline__ void behz2_load_q(const u64* ip, unsigned n, unsigned
 // AUX50: the auxiliary primes are below 2^50 (NB > L of them) instead of the reference's 61-bit primes
 template <int L, bool SMALLQ, bool AUX50 = false>
 __global__ __launch_bounds__(256) void behz2_lift_kernel(unsigned chunks, Behz2Dev c, const u64* in, u64* out) {
-    constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
     static_assert(!AUX50 || SMALLQ, "the 50-bit auxiliary base is chosen for small q only");
-    const unsigned n = c.n, NB = c.NB;
+    const unsigned n = c.n;
     const size_t item = blockIdx.x / chunks;
     const u64* ip = in + item * (size_t)L * n;
-    u64* op = out + item * (size_t)(NB + 1) * n;
-    const cmodp q_mods = as_cmod(c.q_mods);
-    const cu64x2p scale = as_c128(c.q_mt_inv_punc);
-    const cu32p mtrow = as_c32(c.lift_mt), rows = as_c32(c.lift_rows);
-    const cu64p rcs = as_c64(c.lift_rc);
-    const unsigned Lp = c.rs >> 1;
-    for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
-        u32 ylo[L], yhi[L];
-        behz2_load_q<L, SHQ>(ip, n, x, scale, q_mods, ylo, yhi);
-        // q -> {m_tilde = 2^32} and the multiplication by -q^-1: everything modulo 2^32
-        u32 r_mt = 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i) r_mt += (ylo[i] | (yhi[i] << SHQ)) * mtrow[i];
-        const bool neg = r_mt >= 0x80000000u;
+    u64* op = out + item * (size_t)(c.NB + 1) * n;
 #pragma unroll 1
-        for (unsigned b = 0; b <= NB; ++b) {
-            const cu32p row = rows + (size_t)b * c.rs;
-            const cu64p rc = rcs + (size_t)b * BEHZ2_RC;
-            u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
-            v += (u128)rc[B2_C0] * r_mt + (neg ? rc[B2_C1] : 0ull);
-            op[(size_t)b * n + x] = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
+    for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x)
+        behz2_lift_one<L, SMALLQ, AUX50>(c, [&](int i) { return ip[(size_t)i * n + x]; }, [&](unsigned b, u64 w) { op[(size_t)b * n + x] = w; });
+}
+
+// BEHZ steps (6)-(8) at one coefficient: load_q(i) / load_b(b) = residues of the product in base q / Bsk (b = NB: m_sk), store(j, word)
+template <int L, bool SMALLQ, bool AUX50, class LQ, class LB, class ST>
+__device__ __forceinline__ void behz2_floor_one(const Behz2Dev& c, LQ&& load_q, LB&& load_b, ST&& store) {
+    constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
+    const unsigned NB = c.NB;
+    const cu32p fa_rows = as_c32(c.fa_rows), fb_cols = as_c32(c.fb_cols);
+    const cu64p fa_rc = as_c64(c.fa_rc), fb_rc = as_c64(c.fb_rc);
+    const unsigned Lp = c.rs >> 1;
+    u32 ylo[L], yhi[L];
+    behz2_scale_q<L, SHQ>(load_q, as_c128(c.q_t_inv_punc), as_cmod(c.q_mods), ylo, yhi);
+    Behz2Acc acc[L];
+    u128 wide[L];           // only live when the partial sums must be folded every GROUP rows
+#pragma unroll
+    for (int j = 0; j < L; ++j) { behz2_zero(acc[j]); wide[j] = 0; }
+    u64 sk_lo = 0, sk_hi = 0;   // sum_b y'_b * ((B/p_b) B^-1 mod m_sk)
+#pragma unroll 1
+    for (unsigned b = 0; b < NB; ++b) {
+        const cu32p row = fa_rows + (size_t)b * c.rs;
+        const cu64p rc = fa_rc + (size_t)b * BEHZ2_RC;
+        // ((x_b t - conv_b) q^-1) (B/p_b)^-1 mod p_b in one dot product
+        u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
+        const u64 xb = load_b(b), tq = rc[B2_C0];
+        v += (u128)xb * tq;
+        const u64 yb = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
+        mac128(sk_lo, sk_hi, yb, rc[B2_C1]);
+        const u32 zlo = (u32)yb, zhi = (u32)(yb >> 32);
+        const cu32p col = fb_cols + (size_t)b * c.rs;
+#pragma unroll
+        for (int j = 0; j < L; ++j) behz2_mac(acc[j], zlo, zhi, col[j], col[Lp + j]);
+        if (GROUP < L && (b % GROUP) == GROUP - 1) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) { wide[j] += behz2_combine<32, SHQ>(acc[j]); behz2_zero(acc[j]); }
         }
+    }
+    // m_sk row: r_sk = (x_sk t - conv_sk) q^-1 mod m_sk, then alpha_sk = (sum_b y'_b (B/p_b) - r_sk) B^-1 mod m_sk
+    u64 alpha_use; bool neg;
+    {
+        const cu32p row = fa_rows + (size_t)NB * c.rs;
+        const cu64p rc = fa_rc + (size_t)NB * BEHZ2_RC;
+        u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
+        v += (u128)load_b(NB) * rc[B2_C0];
+        const u64 msk = rc[B2_P];
+        const u64 r_sk = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
+        mac128(sk_lo, sk_hi, r_sk, rc[B2_C1]);
+        const u64 alpha_sk = barrett128(sk_lo, sk_hi, msk, rc[B2_RLO], rc[B2_RHI]);
+        neg = alpha_sk > (msk >> 1);
+        alpha_use = neg ? msk - alpha_sk : alpha_sk;
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const cu64p rc = fb_rc + (size_t)j * BEHZ2_RC;
+        u128 v = wide[j] + behz2_combine<32, SHQ>(acc[j]);
+        v += (u128)alpha_use * (neg ? rc[B2_C0] : rc[B2_C1]);
+        store(j, behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]));
     }
 }
 
 // BEHZ steps (6)-(8): in_q [items][L][N], in_bsk [items][NB+1][N] (coefficient form) -> out [items][L][N]
 template <int L, bool SMALLQ, bool AUX50 = false>
 __global__ __launch_bounds__(256) void behz2_floor_kernel(unsigned chunks, Behz2Dev c, const u64* in_q, const u64* in_bsk, u64* out) {
-    constexpr int SHQ = SMALLQ ? 25 : 30, GROUP = SMALLQ ? 64 : 4;
     static_assert(!AUX50 || SMALLQ, "the 50-bit auxiliary base is chosen for small q only");
-    const unsigned n = c.n, NB = c.NB;
+    const unsigned n = c.n;
     const size_t item = blockIdx.x / chunks;
     const u64* qp = in_q + item * (size_t)L * n;
-    const u64* bp = in_bsk + item * (size_t)(NB + 1) * n;
+    const u64* bp = in_bsk + item * (size_t)(c.NB + 1) * n;
     u64* op = out + item * (size_t)L * n;
-    const cmodp q_mods = as_cmod(c.q_mods);
-    const cu64x2p scale = as_c128(c.q_t_inv_punc);
-    const cu32p fa_rows = as_c32(c.fa_rows), fb_cols = as_c32(c.fb_cols);
-    const cu64p fa_rc = as_c64(c.fa_rc), fb_rc = as_c64(c.fb_rc);
-    const unsigned Lp = c.rs >> 1;
-    for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x) {
-        u32 ylo[L], yhi[L];
-        behz2_load_q<L, SHQ>(qp, n, x, scale, q_mods, ylo, yhi);
-        Behz2Acc acc[L];
-        u128 wide[L];           // only live when the partial sums must be folded every GROUP rows
-#pragma unroll
-        for (int j = 0; j < L; ++j) { behz2_zero(acc[j]); wide[j] = 0; }
-        u64 sk_lo = 0, sk_hi = 0;   // sum_b y'_b * ((B/p_b) B^-1 mod m_sk)
 #pragma unroll 1
-        for (unsigned b = 0; b < NB; ++b) {
-            const cu32p row = fa_rows + (size_t)b * c.rs;
-            const cu64p rc = fa_rc + (size_t)b * BEHZ2_RC;
-            // ((x_b t - conv_b) q^-1) (B/p_b)^-1 mod p_b in one dot product
-            u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
-            const u64 xb = bp[(size_t)b * n + x], tq = rc[B2_C0];
-            v += (u128)xb * tq;
-            const u64 yb = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
-            mac128(sk_lo, sk_hi, yb, rc[B2_C1]);
-            const u32 zlo = (u32)yb, zhi = (u32)(yb >> 32);
-            const cu32p col = fb_cols + (size_t)b * c.rs;
-#pragma unroll
-            for (int j = 0; j < L; ++j) behz2_mac(acc[j], zlo, zhi, col[j], col[Lp + j]);
-            if (GROUP < L && (b % GROUP) == GROUP - 1) {
-#pragma unroll
-                for (int j = 0; j < L; ++j) { wide[j] += behz2_combine<32, SHQ>(acc[j]); behz2_zero(acc[j]); }
-            }
-        }
-        // m_sk row: r_sk = (x_sk t - conv_sk) q^-1 mod m_sk, then alpha_sk = (sum_b y'_b (B/p_b) - r_sk) B^-1 mod m_sk
-        u64 alpha_use; bool neg;
-        {
-            const cu32p row = fa_rows + (size_t)NB * c.rs;
-            const cu64p rc = fa_rc + (size_t)NB * BEHZ2_RC;
-            u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
-            v += (u128)bp[(size_t)NB * n + x] * rc[B2_C0];
-            const u64 msk = rc[B2_P];
-            const u64 r_sk = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
-            mac128(sk_lo, sk_hi, r_sk, rc[B2_C1]);
-            const u64 alpha_sk = barrett128(sk_lo, sk_hi, msk, rc[B2_RLO], rc[B2_RHI]);
-            neg = alpha_sk > (msk >> 1);
-            alpha_use = neg ? msk - alpha_sk : alpha_sk;
-        }
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const cu64p rc = fb_rc + (size_t)j * BEHZ2_RC;
-            u128 v = wide[j] + behz2_combine<32, SHQ>(acc[j]);
-            v += (u128)alpha_use * (neg ? rc[B2_C0] : rc[B2_C1]);
-            op[(size_t)j * n + x] = behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]);
-        }
-    }
+    for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x)
+        behz2_floor_one<L, SMALLQ, AUX50>(c, [&](int i) { return qp[(size_t)i * n + x]; }, [&](unsigned b) { return bp[(size_t)b * n + x]; },
+                                          [&](int j, u64 w) { op[(size_t)j * n + x] = w; });
 }
 
 }  // namespace troyn

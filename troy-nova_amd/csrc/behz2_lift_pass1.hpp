@@ -1,10 +1,11 @@
-// behz2_lift_pass1.hpp -- BEHZ steps (1)-(3) of one operand of a BFV multiply at N = 32768 as ONE launch (round 5).
+// behz2_lift_pass1.hpp -- N = 32768 BFV multiply: the BEHZ conversions fused with the strided transform pass next to them (round 5).
+// (1) BEHZ steps (1)-(3) of one operand as ONE launch; (2) below: the last inverse pass of the product + the floor as one launch.
 //
 // At the two-pass ring sizes the operand used to make three trips through HBM before tensor_core_kernel: the strided first forward pass
 // over its L rows of base q (read L, write L), behz2_lift_kernel (read L, write NB + 1) and the strided first pass over the lifted rows
 // (read NB + 1, write NB + 1).  The lift works on one coefficient of all rows, the strided pass on the 8 coefficients {base + k N/8} of one
 // row.  Here a 256-thread workgroup owns 32 consecutive bases x 8 strides:
-//   phase A: thread (k, j) lifts coefficient base_j + k N/8 exactly as behz2_lift_kernel does (20 registers of split residues) and parks the
+//   phase A: thread (k, j) lifts coefficient base_j + k N/8 exactly as behz2_lift_kernel does (behz2_lift_one, 2 L registers of split residues) and parks the
 //            re-centred doubles of its L input words and NB + 1 lifted words in LDS ([row][k][j], 2 KB per row);
 //   phase B: the (L + NB + 1) x 32 octets are dealt to the threads; each runs layers 0-2 on its 8 words and stores the first-pass words.
 // Giving a thread the 8 strided coefficients of all rows instead (no LDS) needs 16 L registers of split residues next to the partial sums:
@@ -32,48 +33,25 @@ struct LiftPass1Args {
     const DevModulus* aux_mods; // [NB+1]
 };
 
-constexpr unsigned LIFT_PASS1_MAX_ROWS = 31;      // 2 KB of LDS per row, 64 KB of dynamic LDS without an attribute
-
 template <int L>
 __global__ __launch_bounds__(256) void behz2_lift_pass1_kernel(Behz2Dev c, LiftPass1Args a) {
-    constexpr int SHQ = 25, GROUP = 64;
     constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, CHUNKS = SEG / 32;
     extern __shared__ u64 lift_lds[];              // [L + NB + 1][8][32] re-centred doubles
     const unsigned NB = c.NB, t = threadIdx.x;
     const size_t item = blockIdx.x / CHUNKS;
     const unsigned base0 = (blockIdx.x % CHUNKS) * 32u;
     {
-        // ---- phase A: one coefficient of all rows ----
+        // ---- phase A: one coefficient of all rows (behz2_lift_one: the same arithmetic as behz2_lift_kernel) ----
         const unsigned x = (t >> 5) * SEG + base0 + (t & 31u);
         const u64* ip = a.in + item * (size_t)L * N;
-        const cmodp q_mods = as_cmod(c.q_mods);
-        const cu64x2p scale = as_c128(c.q_mt_inv_punc);
-        const cu32p mtrow = as_c32(c.lift_mt), rows = as_c32(c.lift_rows);
-        const cu64p rcs = as_c64(c.lift_rc);
-        const unsigned Lp = c.rs >> 1;
-        u32 ylo[L], yhi[L];
-        u32 r_mt = 0;
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const u64 xv = __builtin_nontemporal_load(ip + (size_t)i * N + x);
-            const ulonglong2 f = ld_pair(scale, i);
-            const u64 y = shoup_mul(xv, f.x, f.y, q_mods[i].q);
-            ylo[i] = (u32)y & ((1u << SHQ) - 1);
-            yhi[i] = (u32)(y >> SHQ);
-            r_mt += (u32)y * mtrow[i];
-            lift_lds[i * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{q_mods[i].pd, q_mods[i].inv_pd}));
-        }
-        const bool neg = r_mt >= 0x80000000u;
-        const cmodp am = as_cmod(a.aux_mods);
-#pragma unroll 1
-        for (unsigned b = 0; b <= NB; ++b) {
-            const cu32p row = rows + (size_t)b * c.rs;
-            const cu64p rc = rcs + (size_t)b * BEHZ2_RC;
-            u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
-            v += (u128)rc[B2_C0] * r_mt + (neg ? rc[B2_C1] : 0ull);
-            const u64 w = behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]);
-            lift_lds[(L + b) * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(w), F64Mod{am[b].pd, am[b].inv_pd}));
-        }
+        const cmodp qm = as_cmod(a.q_mods), am = as_cmod(a.aux_mods);
+        behz2_lift_one<L, true, true>(c,
+            [&](int i) {
+                const u64 xv = __builtin_nontemporal_load(ip + (size_t)i * N + x);
+                lift_lds[i * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{qm[i].pd, qm[i].inv_pd}));
+                return xv;
+            },
+            [&](unsigned b, u64 w) { lift_lds[(L + b) * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(w), F64Mod{am[b].pd, am[b].inv_pd})); });
     }
     __syncthreads();
     // ---- phase B: layers 0-2 on the octets; a wave covers two rows, so the modulus constants and twiddles are per-lane loads ----
@@ -106,6 +84,72 @@ __global__ __launch_bounds__(256) void behz2_lift_pass1_kernel(Behz2Dev c, LiftP
 #pragma unroll
         for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(f64_double_to_bits(x[k]), out + k * SEG);
     }
+}
+
+// ---- BEHZ steps (5)-(8) tail: last inverse pass of both bases + kernel_fast_floor_fast_b_conv_sk as ONE launch ----
+// The product leaves tensor_core_kernel after the first inverse pass (12 layers inside 4096-word blocks).  The last pass (layers 2, 1, 0:
+// octets {base + k N/8}, ntt_pass_body<ArithF64, 15, 0, 3, 12, 4, true, false, true>) used to write the L + NB + 1 rows in coefficient form
+// and behz2_floor_kernel read them back.  Same workgroup shape as above, phases swapped:
+//   phase A: the (L + NB + 1) x 32 octets are dealt to the threads: load_mid, three Gentleman-Sande layers (the last one folded with N^-1),
+//            N^-1 on the sum outputs, canonical words into LDS ([row][k][j]);
+//   phase B: thread (k, j) runs behz2_floor_one on coefficient base_j + k N/8 with its residues read from LDS and stores the L output words.
+// The coefficient-form product never reaches HBM: per product polynomial L + NB + 1 rows read and L written instead of 3 (L + NB + 1) + L.
+struct FloorPass2Args {
+    const u64* in_q;            // [items][L][N] words after the first inverse pass, base q
+    const u64* in_bsk;          // [items][NB+1][N] the same for the auxiliary rows
+    u64* out;                   // [items][L][N] coefficient form, base q
+    const double* tw_q;         // inverse twiddles of the plan of base q  [L][N]
+    const double* tw_aux;       // inverse twiddles of the auxiliary plan   [NB+1][N]
+    const DevModulus* q_mods;   // [L]
+    const DevModulus* aux_mods; // [NB+1]
+};
+
+template <int L>
+__global__ __launch_bounds__(256) void behz2_floor_pass2_kernel(Behz2Dev c, FloorPass2Args a) {
+    constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, CHUNKS = SEG / 32;
+    extern __shared__ u64 lift_lds[];              // [L + NB + 1][8][32] canonical words
+    const unsigned NB = c.NB, t = threadIdx.x;
+    const size_t item = blockIdx.x / CHUNKS;
+    const unsigned base0 = (blockIdx.x % CHUNKS) * 32u;
+    const unsigned nrows = L + NB + 1;
+    const u64* iq = a.in_q + item * (size_t)L * N;
+    const u64* ib = a.in_bsk + item * (size_t)(NB + 1) * N;
+    for (unsigned w = t; w < nrows * 32u; w += 256u) {
+        const unsigned row = w >> 5, j = w & 31u;
+        const bool isq = row < (unsigned)L;
+        const unsigned r = isq ? row : row - L;
+        const DevModulus* md = (isq ? a.q_mods : a.aux_mods) + r;
+        const double* tw = (isq ? a.tw_q : a.tw_aux) + (size_t)r * N;
+        const u64* in = (isq ? iq : ib) + (size_t)r * N + base0 + j;
+        const F64Mod m{md->pd, md->inv_pd};
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = f64_corr(f64_bits_to_double(__builtin_nontemporal_load(in + k * SEG)), m);     // ArithF64::load_mid
+        auto bf = [&](int r0, int r1, double tw_w) {
+            const double u = x[r0], v = x[r1];
+            x[r0] = u + v;
+            x[r1] = f64_mulq(u - v, tw_w, m.inv_p, m.p);
+        };
+        // inverse table: layer l (forward numbering) starts at N - 2^(l+1) + 1
+        const double w4 = tw[N - 7], w5 = tw[N - 6], w6 = tw[N - 5], w7 = tw[N - 4];
+        bf(0, 1, w4); bf(2, 3, w5); bf(4, 5, w6); bf(6, 7, w7);
+        const double w2 = tw[N - 3], w3 = tw[N - 2];
+        bf(0, 2, w2); bf(1, 3, w2); bf(4, 6, w3); bf(5, 7, w3);
+        const double nw = md->inv_n_w_d;            // ArithF64::inv_fold: the difference outputs take w N^-1 in one product
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bf(k, k + 4, nw);
+        const double ninv = md->inv_n_d, ninv_p = md->inv_n_pd;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double y = k < 4 ? f64_mulc(x[k], ninv, ninv_p, m.p) : x[k];          // final_inv / final_fwd
+            lift_lds[row * 256 + k * 32 + j] = f64_canon(y, m);
+        }
+    }
+    __syncthreads();
+    const unsigned x = (t >> 5) * SEG + base0 + (t & 31u);
+    u64* op = a.out + item * (size_t)L * N;
+    behz2_floor_one<L, true, true>(c, [&](int i) { return lift_lds[i * 256 + t]; }, [&](unsigned b) { return lift_lds[(L + b) * 256 + t]; },
+                                   [&](int jj, u64 wv) { __builtin_nontemporal_store(wv, op + (size_t)jj * N + x); });
 }
 
 }  // namespace troyn

@@ -65,6 +65,8 @@ void launch_ksmaci_prepare_keys(const KeyPtrs& kp, unsigned L, unsigned K, unsig
 void launch_behz2_lift(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* src, u64* dst, bool aux50 = false);
 bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* src, u64* dst_q, u64* dst_bsk,
                              const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods);
+bool launch_behz2_floor_pass2(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out,
+                              const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods);
 void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, unsigned chunks, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out, bool aux50 = false);
 
 }  // namespace troyn

@@ -2057,9 +2057,10 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     // product and starts the inverse transforms
     const int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
     const bool tensor = tkind != 0, whole = tkind == 1;
-    // N = 32768 under the FP64 policy: first pass of base q, lift and first pass of the lifted rows as one launch (behz2_lift_pass1.hpp)
+    // N = 32768 under the FP64 policy: first pass of base q, lift and first pass of the lifted rows as one launch, and the last inverse pass of
+    // both bases inside the floor launch (behz2_lift_pass1.hpp)
     const bool lift_fused = tkind == 2 && gen2 && b->aux50 && b->smallq && pq->log_n == 15 && !pq->opt.behz_lift_split
-                            && use_f64(pq, 0, L) && use_f64(px, 0, S);
+                            && use_f64(pq, 0, L) && use_f64(px, 0, S) && L + S <= BEHZ2_FUSED_MAX_ROWS;
     auto lift = [&](const u64* src, size_t pcount, u64* dst_q, u64* dst_bsk) -> int {
         // steps (1)-(3) of evaluator.cu:50-60 for one operand
         if (lift_fused) {
@@ -2107,7 +2108,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
                 TimerScope ts(TROYN_TIMER_BFV_TENSOR, s);
                 if ((rc = tensor_stage(p, 1, fa, fb, id, batch, s))) return rc;
             }
-            if (!whole && (rc = tensor_stage(p, 2, id, id, id, batch, s))) return rc;
+            if (!whole && !lift_fused && (rc = tensor_stage(p, 2, id, id, id, batch, s))) return rc;      // lift_fused: the floor launch runs the last pass
         }
     } else {
     // step (4)
@@ -2127,7 +2128,10 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         if ((rc = check_rows(items, ch1))) return rc;
         dim3 grid((unsigned)(items * ch1)), block(256);
         TimerScope ts(TROYN_TIMER_BEHZ_FLOOR, s);
-        if (gen2) {
+        if (lift_fused) {
+            if (items * 128u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
+            launch_behz2_floor_pass2(L, items, s, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, (const double*)pq->d_inv_f64, (const double*)px->d_inv_f64, pq->d_mods, px->d_mods);
+        } else if (gen2) {
             launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, b->aux50);
         } else dispatch_bound(S,
             [&] { hipLaunchKernelGGL((behz_floor_kernel<4>), grid, block, 0, s, ch1, b->dev, ws + w.d_q, ws + w.d_bsk, (u64*)out); },

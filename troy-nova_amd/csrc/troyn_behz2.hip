@@ -32,12 +32,28 @@ void launch_behz2_floor(unsigned L, bool smallq, unsigned grid, hipStream_t s, u
 bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* src, u64* dst_q, u64* dst_bsk,
                              const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods) {
     const unsigned rows = L + c.NB + 1;
-    if (rows > LIFT_PASS1_MAX_ROWS) return false;
+    if (rows > BEHZ2_FUSED_MAX_ROWS) return false;
     LiftPass1Args a{src, dst_q, dst_bsk, tw_q, tw_aux, q_mods, aux_mods};
     const dim3 grid((unsigned)(items * 128u)), block(256);
     const size_t lds = (size_t)rows * 256u * sizeof(u64);
     switch (L) {
 #define X(N) case N: hipLaunchKernelGGL((behz2_lift_pass1_kernel<N>), grid, block, lds, s, c, a); return true;
+        BEHZ2_CASES(X)
+#undef X
+        default: return false;
+    }
+}
+
+// last inverse pass of both bases + floor in one launch (behz2_lift_pass1.hpp): N = 32768, FP64 policy
+bool launch_behz2_floor_pass2(unsigned L, size_t items, hipStream_t s, const Behz2Dev& c, const u64* in_q, const u64* in_bsk, u64* out,
+                              const double* tw_q, const double* tw_aux, const DevModulus* q_mods, const DevModulus* aux_mods) {
+    const unsigned rows = L + c.NB + 1;
+    if (rows > BEHZ2_FUSED_MAX_ROWS) return false;
+    FloorPass2Args a{in_q, in_bsk, out, tw_q, tw_aux, q_mods, aux_mods};
+    const dim3 grid((unsigned)(items * 128u)), block(256);
+    const size_t lds = (size_t)rows * 256u * sizeof(u64);
+    switch (L) {
+#define X(N) case N: hipLaunchKernelGGL((behz2_floor_pass2_kernel<N>), grid, block, lds, s, c, a); return true;
         BEHZ2_CASES(X)
 #undef X
         default: return false;
