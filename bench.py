@@ -613,8 +613,9 @@ def cfg4_valu_block(nb, n, L, S):
         return {"record": None, "note": "no profiles/r*_cfg4_valu.json for the current kernel sources (tools/profile_cfg4.sh)"}
     per_coeff = {"tensor_core_kernel<troyn::ArithU64": nb * S * n * 7.0,      # 4 operand + 3 product polynomials per auxiliary limb
                  "tensor_core_kernel<troyn::ArithF64": nb * L * n * 7.0,
-                 "behz2_floor_kernel": nb * 3 * n * 1.0,                       # per coefficient of a result polynomial (all limbs)
-                 "behz2_lift_kernel": nb * 2 * n * 1.0,
+                 "behz2_floor": nb * 3 * n * 1.0,                              # per coefficient of a result polynomial (all limbs; behz2_floor_pass2_kernel
+                                                                               # includes the last inverse pass of its L + S rows)
+                 "behz2_lift": nb * 2 * n * 1.0,                               # (behz2_lift_pass1_kernel: + the first forward pass of L + S rows)
                  "ksmac2_kernel": nb * (L + 1) * L * n * 1.0}                  # per coefficient and (row, digit)
     out = []
     for r in rec["kernels"][:10]:
@@ -692,14 +693,14 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     tn_call_ms = tn_ms / max(1, launches[0])
     tn_alg = nb * 7.0 * 8 * n * (L + S)
     fl_call_ms = fl_ms / max(1, fl_n)
-    fl_alg = nb * 3 * 8.0 * n * (2 * L + S)     # behz2_floor: per result polynomial L + S limbs read, L written
+    fl_alg = nb * 3 * 8.0 * n * (2 * L + S)     # last inverse pass + floor in one launch: per result polynomial L + S limbs read, L written
     kernels = {
         "ksmac2_kernel<15> (key-switch inner product, quarter tiles)": {"launch_ms": round(ks_launch_ms, 4), "share_of_step_pct": round(share(ks_ms), 1),
                                                                        "algorithmic_bytes_per_launch": ks_alg, "hbm_frac": round(ks_alg / (ks_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks_n else None},
-        "tensor_core_kernel (last forward pass + tensor product + first inverse pass, base q FP64 + base Bsk integer)": {
+        "tensor_core_kernel (last forward pass + tensor product + first inverse pass; both bases on FP64 butterflies since the auxiliary primes are below 2^50)": {
             "ms_per_multiply_call": round(tn_call_ms, 4), "share_of_step_pct": round(share(tn_ms), 1), "algorithmic_bytes_per_call": tn_alg,
             "hbm_frac": round(tn_alg / (tn_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tn_n else None},
-        "behz2_floor_kernel<10>": {"launch_ms": round(fl_call_ms, 4), "share_of_step_pct": round(share(fl_ms), 1), "algorithmic_bytes_per_launch": fl_alg,
+        "behz2_floor_pass2_kernel<10> (last inverse pass of both bases + floor)": {"launch_ms": round(fl_call_ms, 4), "share_of_step_pct": round(share(fl_ms), 1), "algorithmic_bytes_per_launch": fl_alg,
                                    "hbm_frac": round(fl_alg / (fl_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fl_n else None},
     }
     dominant_is_ks = ks_ms >= tn_ms
@@ -709,7 +710,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     # the keys per op, 13.1 MB with the keys once per launch
     per_gpu = value / world
     roofline = {"bound": "valu_fp64" if dominant_is_ks else "valu_int",
-                "bound_note": "issue-bound arithmetic (FP64 butterflies in ksmac2, integer butterflies of the 61-bit BEHZ base in tensor_core_kernel<ArithU64>); achieved / peak / "
+                "bound_note": "issue-bound arithmetic (FP64 butterflies in ksmac2 and tensor_core_kernel, integer multiply-accumulates in the base conversions); achieved / peak / "
                               "frac are the contract's HBM figures for the dominant launch, timed in this run by the library's kernel timer",
                 "kernel": "ksmac2_kernel<15>" if dominant_is_ks else "tensor_core_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
@@ -722,7 +723,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         "metric": "homomorphic mul+relinearize ops/sec (BFV BEHZ multiply + relinearize), N=32768", "value": round(value, 1), "unit": "ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u64 (q < 2^50: exact FP64-carried butterflies; 61-bit BEHZ base: integer butterflies)", "data": "synthetic",
+        "dtype": "u64 (every q_i and auxiliary prime < 2^50: exact FP64-carried butterflies; base conversions: integer multiply-accumulates)", "data": "synthetic",
         "config": {"workload": "BFV N=32768, 11x50-bit coeff modulus (K=11, L=10), t=1032193: %d independent multiply + relinearize ops per step, "
                                "block-partitioned over %d rank(s) (rank 0: items [%d, %d)), %d per launch" % (args.total, world, lo, hi, nb),
                    "total_ops_per_step": args.total, "operands": "%d distinct ciphertext pairs per rank resident in HBM" % mine,

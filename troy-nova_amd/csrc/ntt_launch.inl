@@ -15,6 +15,9 @@
 #endif
 #define TROYN_NTT_SMALL (TROYN_NTT_PART != 2)
 #define TROYN_NTT_LARGE (TROYN_NTT_PART != 1)
+#ifndef TROYN_SMALL_EB
+#define TROYN_SMALL_EB 3      // small launches at N = 16384 (two-pass form): 512 threads x 8 coefficients (single fused op 82 -> 78 us; 4: 82, 2: 81)
+#endif
 
 namespace troyn {
 
@@ -150,7 +153,7 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
             // A whole-limb tile puts a 16384-point transform on ONE CU: 15-23 us however few limbs the launch has.  Launches that leave most
             // of the chip idle (a single ciphertext: 2-10 limb-polynomials) take the two-pass form of the larger rings instead -- 4 workgroups
             // per limb and pass, ~3x shorter; TROYN_NTT_SMALL_TWO_PASS=0 keeps the single pass (A/B runs, tests).  Results are the same words.
-            if (lp * 8 <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 14, 12, 4>(a, lp, inverse, lc, scratch);
+            if (lp * 8 <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 14, 12, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
             else launch_single<A, 14, 4>(a, lp, inverse, lc);
             return true;
 #endif
