@@ -22,8 +22,10 @@
 #include "dev_math.hpp"
 #include "behz_kernels.hpp"
 
+#include <cstring>
 #include <vector>
 #include "host_math.hpp"
+#include "dev_math_f64.hpp"
 
 namespace troyn {
 
@@ -36,7 +38,7 @@ constexpr unsigned BEHZ2_RC = 8;   // u64 words of per-row constants
 constexpr unsigned BEHZ2_FUSED_MAX_ROWS = 31;   // behz2_lift_pass1.hpp: rows of both bases in LDS, 2 KB each (64 KB of dynamic LDS without an attribute)
 
 // row constants (u64 index)
-enum { B2_P = 0, B2_RLO = 1, B2_RHI = 2, B2_MU = 3, B2_C0 = 4, B2_C1 = 5 };
+enum { B2_P = 0, B2_RLO = 1, B2_RHI = 2, B2_MU = 3, B2_C0 = 4, B2_C1 = 5, B2_W32 = 6, B2_W64 = 7 };
 
 struct Behz2Dev {
     unsigned L, n, rs;                 // rs: u32 stride of one split row = 2 * Lp (Lp = L rounded up to even)
@@ -80,9 +82,17 @@ inline bool behz2_build_tables(const std::vector<u64>& q, const std::vector<u64>
     };
     auto push_rc = [&](u64 p, u64 c0, u64 c1) {
         BarrettRatio r = barrett_ratio(p);
-        const u64 mu = (p >> 60) == 1 ? (u64)((((u128)1) << 124) / p) : 0;   // one-multiply Barrett, 61-bit moduli only
+        const bool small = p < ((u64)1 << 50);
+        // slot 3: one-multiply Barrett constant (61-bit moduli) or, for p < 2^50, fl(1/p) of the FP64 reduction (behz2_reduce_f64)
+        u64 mu = (p >> 60) == 1 ? (u64)((((u128)1) << 124) / p) : 0, w32 = 0, w64 = 0;
+        auto dbits = [](double d) { u64 b; std::memcpy(&b, &d, 8); return b; };
+        if (small) {
+            mu = dbits(1.0 / (double)p);
+            w32 = dbits((double)((((u128)1) << 32) % p));
+            w64 = dbits((double)((((u128)1) << 64) % p));
+        }
         blob.push_back(p); blob.push_back(r.lo); blob.push_back(r.hi); blob.push_back(mu);
-        blob.push_back(c0); blob.push_back(c1); blob.push_back(0); blob.push_back(0);
+        blob.push_back(c0); blob.push_back(c1); blob.push_back(w32); blob.push_back(w64);
     };
     // ---- lift ----
     u64 neg_inv_q_mt;
@@ -166,6 +176,19 @@ __device__ __forceinline__ u64 behz2_reduce61(u128 v, u64 p, u64 mu) {
 
 __device__ __forceinline__ u64 behz2_reduce(u128 v, u64 p, u64 rlo, u64 rhi) { return barrett128((u64)v, (u64)(v >> 64), p, rlo, rhi); }
 
+// p < 2^50, v < 2^106: v = (x3 2^32 + x2) 2^64 + x1 2^32 + x0 in 32-bit words; the two upper parts are multiplied by (2^64 mod p) and (2^32 mod p) with
+// the exact FP64 modular product (f64_mulq: the quotient comes from the rounded product, error < 2^-10 here), every value an integer below 2^53.
+// ~24 instructions against ~50 of the Barrett-128 form; returns the re-centred residue (|r| <= p/2 + 1) as a double.
+__device__ __forceinline__ double behz2_reduce_f64(u128 v, cu64p rc) {
+    const double p = f64_from_u64(rc[B2_P]), inv_p = f64_bits_to_double(rc[B2_MU]);
+    const double w32 = f64_bits_to_double(rc[B2_W32]), w64 = f64_bits_to_double(rc[B2_W64]);
+    const u64 lo = (u64)v, hi = (u64)(v >> 64);
+    const double xh = __builtin_fma((double)(u32)(hi >> 32), 4294967296.0, (double)(u32)hi);
+    const double r = f64_mulq(xh, w64, inv_p, p) + f64_mulq((double)(u32)(lo >> 32), w32, inv_p, p) + (double)(u32)lo;
+    return f64_corr(r, F64Mod{p, inv_p});
+}
+__device__ __forceinline__ u64 behz2_canon_f64(double r, cu64p rc) { return f64_to_u64(r < 0.0 ? r + f64_from_u64(rc[B2_P]) : r); }
+
 // reduction modulo an auxiliary prime: FAST61 = the one-multiply form for primes in [2^60, 2^61) (the reference's base under small q)
 template <bool FAST61>
 __device__ __forceinline__ u64 behz2_reduce_aux(u128 v, cu64p rc) {
@@ -232,7 +255,8 @@ __device__ __forceinline__ void behz2_lift_one(const Behz2Dev& c, LD&& load, ST&
         const cu64p rc = rcs + (size_t)b * BEHZ2_RC;
         u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
         v += (u128)rc[B2_C0] * r_mt + (neg ? rc[B2_C1] : 0ull);
-        store(b, behz2_reduce_aux<SMALLQ && !AUX50>(v, rc));
+        if constexpr (AUX50) store(b, behz2_reduce_f64(v, rc));      // the re-centred residue as a double (the caller canonicalises or keeps it)
+        else store(b, behz2_reduce_aux<SMALLQ>(v, rc));
     }
 }
 
@@ -247,7 +271,9 @@ __global__ __launch_bounds__(256) void behz2_lift_kernel(unsigned chunks, Behz2D
     u64* op = out + item * (size_t)(c.NB + 1) * n;
 #pragma unroll 1
     for (unsigned x = (blockIdx.x % chunks) * blockDim.x + threadIdx.x; x < n; x += chunks * blockDim.x)
-        behz2_lift_one<L, SMALLQ, AUX50>(c, [&](int i) { return ip[(size_t)i * n + x]; }, [&](unsigned b, u64 w) { op[(size_t)b * n + x] = w; });
+        behz2_lift_one<L, SMALLQ, AUX50>(c, [&](int i) { return ip[(size_t)i * n + x]; }, [&](unsigned b, auto w) {
+                if constexpr (AUX50) op[(size_t)b * n + x] = behz2_canon_f64(w, as_c64(c.lift_rc) + (size_t)b * BEHZ2_RC); else op[(size_t)b * n + x] = w;
+            });
 }
 
 // BEHZ steps (6)-(8) at one coefficient: load_q(i) / load_b(b) = residues of the product in base q / Bsk (b = NB: m_sk), store(j, word)
@@ -273,7 +299,8 @@ __device__ __forceinline__ void behz2_floor_one(const Behz2Dev& c, LQ&& load_q, 
         u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
         const u64 xb = load_b(b), tq = rc[B2_C0];
         v += (u128)xb * tq;
-        const u64 yb = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
+        u64 yb;
+        if constexpr (AUX50) yb = behz2_canon_f64(behz2_reduce_f64(v, rc), rc); else yb = behz2_reduce_aux<SMALLQ>(v, rc);
         mac128(sk_lo, sk_hi, yb, rc[B2_C1]);
         const u32 zlo = (u32)yb, zhi = (u32)(yb >> 32);
         const cu32p col = fb_cols + (size_t)b * c.rs;
@@ -292,7 +319,8 @@ __device__ __forceinline__ void behz2_floor_one(const Behz2Dev& c, LQ&& load_q, 
         u128 v = behz2_dot<L, SHQ, 32, GROUP>(ylo, yhi, row, row + Lp);
         v += (u128)load_b(NB) * rc[B2_C0];
         const u64 msk = rc[B2_P];
-        const u64 r_sk = behz2_reduce_aux<SMALLQ && !AUX50>(v, rc);
+        u64 r_sk;
+        if constexpr (AUX50) r_sk = behz2_canon_f64(behz2_reduce_f64(v, rc), rc); else r_sk = behz2_reduce_aux<SMALLQ>(v, rc);
         mac128(sk_lo, sk_hi, r_sk, rc[B2_C1]);
         const u64 alpha_sk = barrett128(sk_lo, sk_hi, msk, rc[B2_RLO], rc[B2_RHI]);
         neg = alpha_sk > (msk >> 1);
@@ -303,7 +331,8 @@ __device__ __forceinline__ void behz2_floor_one(const Behz2Dev& c, LQ&& load_q, 
         const cu64p rc = fb_rc + (size_t)j * BEHZ2_RC;
         u128 v = wide[j] + behz2_combine<32, SHQ>(acc[j]);
         v += (u128)alpha_use * (neg ? rc[B2_C0] : rc[B2_C1]);
-        store(j, behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]));
+        if constexpr (AUX50) store(j, behz2_canon_f64(behz2_reduce_f64(v, rc), rc));      // AUX50 implies every q_j below 2^50
+        else store(j, behz2_reduce(v, rc[B2_P], rc[B2_RLO], rc[B2_RHI]));
     }
 }
 

@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256) void behz2_lift_pass1_kernel(Behz2Dev c, LiftP
         // ---- phase A: one coefficient of all rows (behz2_lift_one: the same arithmetic as behz2_lift_kernel) ----
         const unsigned x = (t >> 5) * SEG + base0 + (t & 31u);
         const u64* ip = a.in + item * (size_t)L * N;
-        const cmodp qm = as_cmod(a.q_mods), am = as_cmod(a.aux_mods);
+        const cmodp qm = as_cmod(a.q_mods);
         behz2_lift_one<L, true, true>(c,
             [&](int i) {
                 const u64 xv = __builtin_nontemporal_load(ip + (size_t)i * N + x);
                 lift_lds[i * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{qm[i].pd, qm[i].inv_pd}));
                 return xv;
             },
-            [&](unsigned b, u64 w) { lift_lds[(L + b) * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(w), F64Mod{am[b].pd, am[b].inv_pd})); });
+            [&](unsigned b, double w) { lift_lds[(L + b) * 256 + t] = f64_double_to_bits(w); });      // already re-centred (behz2_reduce_f64)
     }
     __syncthreads();
     // ---- phase B: layers 0-2 on the octets; a wave covers two rows, so the modulus constants and twiddles are per-lane loads ----
