@@ -770,7 +770,7 @@ def run_cfg5(args, torch, pkg, entry, device):
            "dtype": "u64 ({60,40,40,60}: 60-bit limb on integer butterflies, 40-bit limbs on exact-FP64 butterflies)"}
     drv = os.path.join(ROOT, "tests", "cpp", "matmul_driver")
     if os.path.exists(drv):
-        r = subprocess.run([drv, "512", "512", "512", "5", "1", "1"], capture_output=True, text=True, timeout=900)
+        r = subprocess.run([drv, "512", "512", "512", "20", "1", "1"], capture_output=True, text=True, timeout=900)
         lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
         if r.returncode == 0 and "ms" in lines:
             ms = dict(zip(lines["ms"][0::2], [float(v) for v in lines["ms"][1::2]]))

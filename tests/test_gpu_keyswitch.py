@@ -322,6 +322,34 @@ def test_ckks_multiply_relinearize_rescale_fused(O, pkg, dev, n, bits, L, batch)
     assert np.array_equal(pkg.to_host(da), a) and np.array_equal(pkg.to_host(db), b)
 
 
+@pytest.mark.parametrize("bits,L,batch", [([50] * 6, 5, 1), ([50] * 6, 5, 2), ([50] * 6, 2, 1), ([45, 49, 40, 50], 3, 3), ([50] * 6, 4, 1)])
+def test_fused_chain_single_objects(O, pkg, dev, bits, L, batch):
+    """N = 16384, a few ciphertexts: every launch of the chain's tail takes the two-pass form and its three strided passes (special rows, dropped limb
+    with the key switch's rounding fix, output limbs with both fixes) run as ONE launch on the shared quartets (mrr_quartet_kernel; T_s and T_l stay in
+    registers).  TROYN_MRR_SMALL=0 keeps the six launches.  Both equal the oracle's multiply -> relinearize -> rescale (evaluator_keyswitching_core.cu:570-658,
+    utils/rns_tool.cu:523-627), below the top level as well; corner operands (all q - 1)."""
+    import torch
+    n = 16384
+    ctx, plan, q = _setup(O, pkg, dev, "ckks", n, bits)
+    keys = ctx.random_keys(29, L)
+    dkeys = [pkg.to_device(k, dev) for k in keys]
+    a = np.stack([ctx.random_ct(500 + i, 2, L) for i in range(batch)])
+    b = np.stack([ctx.random_ct(600 + i, 2, L) for i in range(batch)])
+    qa = np.array(q[:L], dtype=np.uint64)[None, :, None]
+    b[batch - 1] = np.broadcast_to(qa - 1, b[batch - 1].shape)
+    da, db = pkg.to_device(a, dev), pkg.to_device(b, dev)
+    got = plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys)
+    plan.set_option("TROYN_MRR_SMALL", "0")
+    six = plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys)
+    plan.set_option("TROYN_MRR_SMALL", None)
+    assert torch.equal(got, six), "merged tail differs from the six-launch tail"
+    got = pkg.to_host(got)
+    for i in range(batch):
+        e = ctx.relinearize(L, True, ctx.ckks_multiply(L, a[i], b[i]), keys)
+        assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, e)), i
+    assert np.array_equal(pkg.to_host(da), a) and np.array_equal(pkg.to_host(db), b)
+
+
 def test_fused_entry_errors_and_timer(O, pkg, dev):
     """error behaviour of the one-call chain (the reference's messages for the step that would have failed) and the kernel-timer hook"""
     import ctypes as C

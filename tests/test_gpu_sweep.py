@@ -33,6 +33,7 @@ SWITCHES = {
     "TROYN_NTT_OVERLAP": ("0",),
     "TROYN_MRR": ("calls",),
     "TROYN_MRR_MIXED": ("0",),
+    "TROYN_MRR_SMALL": ("0",),
     "TROYN_MRR_CHUNK": ("8", "16"),
     "TROYN_MRR_STREAMS": ("1", "3"),
     "TROYN_BFV_TENSOR": ("split",),

@@ -226,6 +226,7 @@ struct TroynOptions {
     int ks_rows = 0;                 // TROYN_KS_ROWS=<r>: rows co-scheduled per XCD by the whole-limb inner product of N < 8192
     bool ks_mac_shoup_off = false;   // TROYN_KS_MAC_SHOUP=0: Barrett-128 terms in that kernel's integer form
     bool mrr_mixed_off = false;      // TROYN_MRR_MIXED=0: chains with moduli >= 2^50 compose the three calls inside the fused entry
+    bool mrr_small_off = false;      // TROYN_MRR_SMALL=0: single objects at N = 16384 keep the six-launch tail of the fused chain
     bool mrr_calls = false;          // TROYN_MRR=calls: the fused entry composes the three public calls
     int mrr_chunk = 0, mrr_streams = 2;   // TROYN_MRR_CHUNK=<items>, TROYN_MRR_STREAMS=<1..4>
     bool behz_v1 = false;            // TROYN_BEHZ=v1: first-generation conversion kernels (they stay the path of L > 16 and N < 1024)
@@ -239,7 +240,7 @@ struct TroynOptions {
     int tensor_wgs = 8;              // TROYN_TENSOR_WGS=8|3|2
 };
 static const char* const TROYN_OPTION_NAMES[] = {"TROYN_NTT_ARITH", "TROYN_NTT_SPLIT", "TROYN_BFV_TENSOR", "TROYN_KS_ORDER", "TROYN_KS_SPLIT", "TROYN_KS_TAIL", "TROYN_KS_MAC",
-    "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE", "TROYN_BEHZ_LIFT",
+    "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR_SMALL", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE", "TROYN_BEHZ_LIFT",
     "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS", "TROYN_NTT_OVERLAP"};
 // value == nullptr or "": the option's default.  false: unknown name.
 static bool option_apply(TroynOptions& o, const char* name, const char* value) {
@@ -257,6 +258,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_KS_ROWS") o.ks_rows = num(d.ks_rows);
     else if (n == "TROYN_KS_MAC_SHOUP") o.ks_mac_shoup_off = v == "0";
     else if (n == "TROYN_MRR_MIXED") o.mrr_mixed_off = v == "0";
+    else if (n == "TROYN_MRR_SMALL") o.mrr_small_off = v == "0";
     else if (n == "TROYN_MRR") o.mrr_calls = v == "calls";
     else if (n == "TROYN_MRR_CHUNK") o.mrr_chunk = num(d.mrr_chunk);
     else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
@@ -544,6 +546,20 @@ struct RunOverlap {
 };
 constexpr size_t OVERLAP_MIN_LIMB_POLYS = 512;      // per split launch (all runs together)
 }  // namespace
+
+// CUs of the current device (cached per host thread; the same figure ntt_launch.inl sizes its small launches by)
+static unsigned device_cu_count() {
+    static thread_local int cached_dev = -1;
+    static thread_local unsigned cached = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached = (unsigned)cus; cached_dev = dev;
+    }
+    return cached;
+}
 
 static bool use_f64(const troyn_plan* p, unsigned table_start, unsigned table_count) {
     // FP64 butterflies when every modulus this launch can touch is below 2^50
@@ -1429,27 +1445,18 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
             LAUNCH_CHECK();
         }
     }
-    // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
-    {
-        NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.spec_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
-        x.in_pstride = pp_p; x.in_bstride = pp_b;
-        x.flags = NTT_FLAG_STORE_ROUND_HALF;     // stored as (s + qk/2) mod qk, the limb-independent part of the key switch's rounding fix
-        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
-    }
     const unsigned t_flags = (special_wide ? NTT_FLAG_TS_U64 : 0u) | (last_wide ? NTT_FLAG_TL_U64 : 0u);
-    // (4) l = INTT(relin_{L-1}) = INTT(Q_{L-1}) - r(s) qk^-1 with Q = P qk^-1 + c as ksmac2 left it   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
-    {
+    // arguments of steps (4) and (5) below (also read by the single-object form of the tail)
+    auto last_args = [&]() {
         NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.last_intt, 2, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         x.in_pstride = pp_p; x.in_bstride = pp_b;
         x.in2 = ws + w.spec_intt; x.in2_bstride = 2ll * n; x.in2_pstride = n;
         x.aux_mod = K - 1; x.inv_table = p->d_inv_last + (size_t)K * K + (L - 1);
         x.fused_mode = (!last_wide && special_wide) ? NTT_FUSED_LAST_LIMB_W : NTT_FUSED_LAST_LIMB;
         x.flags = t_flags;
-        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
-    }
-    // (5) out_j = (Q_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1, Q_j = P_j qk^-1 + c_j, for the L-1 remaining limbs: ski_util6/7 (:570-658), the
-    //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
-    return for_runs(L - 1, 2, [&](unsigned j0, unsigned j1, hipStream_t rs) {
+        return x;
+    };
+    auto tail_args = [&](unsigned j0, unsigned j1) {
         NttArgs x = contiguous_args(p, ws + w.spec_intt, out + (size_t)j0 * n, 2, j1 - j0, j0, j1 - j0, TROYN_IDX_COMPONENTWISE, 0);
         x.in_bstride = 2ll * n; x.in_pstride = n; x.in_cstride = 0;
         x.out_bstride = 2ll * (L - 1) * n; x.out_pstride = (long long)(L - 1) * n;
@@ -1459,8 +1466,51 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         x.ext0 = ws + w.poly_prod + (size_t)j0 * n; x.ext0_bstride = pp_b; x.ext0_pstride = pp_p; x.ext0_cstride = n;
         x.fused_mode = (small(j0) && t_flags) ? NTT_FUSED_TAIL_RESCALE_W : NTT_FUSED_TAIL_RESCALE;     // (launch_ntt co-locates the limbs that share the two input rows on one XCD)
         x.flags = t_flags;
-        return launch_ntt(p, x, batch, false, rs);
-    });
+        return x;
+    };
+    // Single objects at N = 16384 (every launch of the tail in its two-pass form, FP64 policy): the three strided passes between the first
+    // inverse pass of {limb L-1, special rows} and the last forward pass of the output limbs run as ONE launch with T_s and T_l in registers
+    // (troyn_mrr_small.hip): 3 launches instead of 6.  TROYN_MRR_SMALL=0 keeps the six.
+    if (all_f64 && p->log_n == 14 && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && batch * 2 * (size_t)(L - 1) * 8 <= device_cu_count()) {
+        const LaunchCtx lc = launch_ctx(p, s);
+        auto prep = [&](NttArgs& x, bool inverse) {
+            x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
+            x.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
+        };
+        // first inverse pass of rows L-1 and L (special) of both polynomials, in place in poly_prod (nothing else reads those rows)
+        NttArgs pa = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.poly_prod + (size_t)(L - 1) * n, 2, 2, L - 1, K - (L - 1), TROYN_IDX_KS_SKIP_FINALS, 1);
+        pa.in_pstride = pa.out_pstride = pp_p; pa.in_bstride = pa.out_bstride = pp_b;
+        prep(pa, true);
+        launch_ntt_f64_pass14(0, pa, batch * 4, lc);
+        LAUNCH_CHECK();
+        NttArgs sp = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, nullptr, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        sp.in_pstride = pp_p; sp.in_bstride = pp_b;
+        prep(sp, true);
+        NttArgs la = last_args();
+        prep(la, true);
+        NttArgs ta = tail_args(0, L - 1);
+        prep(ta, false);
+        launch_mrr_quartet(p->log_n, batch, sp, la, ta, s);
+        LAUNCH_CHECK();
+        // last forward pass of the output limbs, in place in `out`, with step (5)'s epilogue
+        ta.in = ta.out; ta.in_bstride = ta.out_bstride; ta.in_pstride = ta.out_pstride; ta.in_cstride = ta.out_cstride;
+        ta.reduce_input = 0;
+        launch_ntt_f64_pass14(1, ta, batch * 2 * (L - 1), lc);
+        LAUNCH_CHECK();
+        return TROYN_OK;
+    }
+    // (3) s = INTT of the special-prime rows (:991-996, only the two rows the NTT-form tail needs)
+    {
+        NttArgs x = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.spec_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        x.in_pstride = pp_p; x.in_bstride = pp_b;
+        x.flags = NTT_FLAG_STORE_ROUND_HALF;     // stored as (s + qk/2) mod qk, the limb-independent part of the key switch's rounding fix
+        if ((rc = launch_ntt(p, x, batch, true, s))) return rc;
+    }
+    // (4) l = INTT(relin_{L-1}) = INTT(Q_{L-1}) - r(s) qk^-1 with Q = P qk^-1 + c as ksmac2 left it   (divide_and_round_q_last_ntt's INTT of the last limb, :675)
+    if ((rc = launch_ntt(p, last_args(), batch, true, s))) return rc;
+    // (5) out_j = (Q_j - NTT_j(r_j(s) qk^-1 + f_j(l))) ql^-1, Q_j = P_j qk^-1 + c_j, for the L-1 remaining limbs: ski_util6/7 (:570-658), the
+    //     trailing add of relinearize (:143) and both steps of divide_and_round_q_last_ntt (utils/rns_tool.cu:523-627) around ONE transform
+    return for_runs(L - 1, 2, [&](unsigned j0, unsigned j1, hipStream_t rs) { return launch_ntt(p, tail_args(j0, j1), batch, false, rs); });
 }
 
 extern "C" size_t troyn_ckks_multiply_relinearize_rescale_workspace_bytes(const troyn_plan* plan, uint32_t L, size_t batch) {

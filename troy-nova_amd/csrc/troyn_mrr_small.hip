@@ -1,0 +1,92 @@
+// troyn_mrr_small.hip -- single objects through the fused multiply -> relinearize -> rescale entry at N = 16384 (round 5).
+//
+// A launch of a few limb-polynomials takes the two-pass form of the transforms (ntt_launch.inl: 4 workgroups per limb and pass instead of one
+// CU per 16384-point transform).  In that form the tail of the chain was six launches: special rows INTT (pass A, pass B) -> LAST_LIMB (A, B)
+// -> TAIL_RESCALE (A, B).  The three strided passes in the middle -- the last two inverse layers of the special rows, the last two inverse
+// layers of the dropped limb with the key switch's rounding fix, the first two forward layers of the L - 1 output limbs with both rounding
+// fixes -- all work on the SAME quartets {i, i + N/4, i + N/2, i + 3N/4}: one thread can run them back to back with T_s and T_l in registers.
+// The chain's tail becomes three launches: pass A over the rows {L - 1, special} together (they only depend on the inner product), this
+// kernel, TAIL_RESCALE's pass B.  T_s and T_l never reach memory.
+// Arithmetic: ArithF64's own functions in the order ntt_pass_body applies them (load_mid, inv / inv_fold, final_inv / final_fwd + round_half,
+// last_out, tail_in, fwd, store_mid) with the constants of ntt_io_fused -- the words handed to TAIL_RESCALE's pass B are the ones its pass A wrote.
+// Reference: evaluator_keyswitching_core.cu:570-658 (ski_util6/7), utils/rns_tool.cu:523-627 (divide_and_round_q_last_ntt).
+#include "launch.hpp"
+
+namespace troyn {
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void mrr_quartet_kernel(NttArgs sp, NttArgs la, NttArgs ta) {
+    using A = ArithF64;
+    constexpr unsigned N = 1u << LOGN, Q = N / 4;
+    typedef const double __attribute__((address_space(4)))* ctw;
+    // one thread per (output limb j, item, polynomial, quartet): the two inverse tails are recomputed by the L - 1 threads that share a quartet
+    // (8 loads and ~70 FP64 operations, from L2) -- a launch of a single ciphertext is latency-bound, and one limb per thread is the shorter chain
+    const unsigned gid = (blockIdx.x % ta.xcd_groups) * 256u + threadIdx.x, j = blockIdx.x / ta.xcd_groups;      // xcd_groups: workgroups per limb
+    const unsigned i = gid % Q, g = gid / Q, k = g & 1u, b = g >> 1;
+    auto inverse_tail = [&](const NttArgs& x, unsigned mi, const A::Mod& md, double (&v)[4]) {
+        // pass B of an inverse transform in its two-pass form: layers 1 and 0 (Gentleman-Sande, the last one folded with N^-1)
+        const u64* in = x.in + (long long)b * x.in_bstride + (long long)k * x.in_pstride;
+        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(x.tw) + (size_t)mi * N);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) v[kk] = A::load_mid(in[i + kk * Q], md);
+        A::inv(v[0], v[1], A::tw_from_mem(tw[N - 3], md), md);
+        A::inv(v[2], v[3], A::tw_from_mem(tw[N - 2], md), md);
+        A::inv_fold(v[0], v[2], md);
+        A::inv_fold(v[1], v[3], md);
+    };
+    // T_s = (s + qk/2) mod qk at the four coefficients (the plain inverse transform's NTT_FLAG_STORE_ROUND_HALF epilogue)
+    u64 ts[4], tl[4];
+    {
+        const unsigned mi = sp.table_start;
+        const A::Mod md = A::make(sp.mods[mi]);
+        double v[4];
+        inverse_tail(sp, mi, md, v);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const u64 c = kk >= 2 ? A::final_fwd(v[kk], md) : A::final_inv(v[kk], md);      // the folded layer scaled its difference outputs already
+            ts[kk] = f64_double_to_bits(A::round_half(f64_from_u64(c), md));
+        }
+    }
+    // T_l = (l + ql/2) mod ql, l = INTT(Q_{L-1}) - r(s) qk^-1 (NTT_FUSED_LAST_LIMB's epilogue)
+    {
+        const unsigned mi = la.table_start;
+        const A::Mod md = A::make(la.mods[mi]);
+        NttIo io;
+        ntt_io_fused(io, la, b, k, 0, mi);
+        double v[4];
+        inverse_tail(la, mi, md, v);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tl[kk] = A::template last_out<false>(io, v[kk], kk >= 2, ts[kk], md);
+    }
+    // the L - 1 output limbs: r_j(s) qk^-1 + f_j(l) enters ONE forward transform; its first two layers here (pass A of NTT_FUSED_TAIL_RESCALE)
+    {
+        const unsigned mi = ta.table_start + j;
+        const A::Mod md = A::make(ta.mods[mi]);
+        NttIo io;
+        ntt_io_fused(io, ta, b, k, j, mi);
+        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(ta.tw) + (size_t)mi * N);
+        double y[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) y[kk] = A::template tail_in<false>(io, ts[kk], tl[kk], md);
+        const A::tw_t w1 = A::tw_from_mem(tw[1], md);
+        A::fwd(y[0], y[2], w1, md);
+        A::fwd(y[1], y[3], w1, md);
+        A::fwd(y[0], y[1], A::tw_from_mem(tw[2], md), md);
+        A::fwd(y[2], y[3], A::tw_from_mem(tw[3], md), md);
+        u64* out = ta.out + (long long)b * ta.out_bstride + (long long)k * ta.out_pstride + (long long)j * ta.out_cstride;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) __builtin_nontemporal_store(A::store_mid(y[kk], md), out + i + kk * Q);
+    }
+}
+
+// sp / la: the pass-A words of the special rows / of limb L - 1 (in, strides, table_start = their modulus, tw = inverse tables; la with the
+// constants of step (4)); ta: step (5)'s arguments (out = where pass B reads, tw = forward tables).  batch * 2 polynomials.
+void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s) {
+    if (log_n != 14) return;
+    const unsigned blocks = (unsigned)(batch * 2 * ((1u << 14) / 4) / 256);
+    NttArgs t = ta;
+    t.xcd_groups = blocks;        // (the field is free in this kernel: workgroups per output limb)
+    hipLaunchKernelGGL((mrr_quartet_kernel<14>), dim3(blocks * ta.ncomp), dim3(256), 0, s, sp, la, t);
+}
+
+}  // namespace troyn

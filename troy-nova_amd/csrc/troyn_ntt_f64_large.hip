@@ -14,4 +14,11 @@ bool launch_tensor_f64_large(unsigned log_n, int stage, const NttArgs& a, const 
     return launch_tensor_class<ArithF64>(log_n, stage, a, b, d, batch, lc);
 }
 
+// single passes of the two-pass form of a small N = 16384 launch (troyn_mrr_small.hip runs the strided passes between them itself):
+// which = 0: first inverse pass (12 layers inside 4096-word blocks), 1: last forward pass (12 layers + the fused epilogue a.fused_mode selects)
+void launch_ntt_f64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (which == 0) launch_pass<ArithF64, 14, 2, 12, 12, TROYN_SMALL_EB, true, true, false>(a, limb_polys, lc);
+    else launch_pass<ArithF64, 14, 2, 12, 12, TROYN_SMALL_EB, false, false, true>(a, limb_polys, lc);
+}
+
 }  // namespace troyn
