@@ -343,6 +343,24 @@ def test_fused_chain_single_objects(O, pkg, dev, bits, L, batch):
     six = plan.ckks_multiply_relinearize_rescale(L, da, db, dkeys)
     plan.set_option("TROYN_MRR_SMALL", None)
     assert torch.equal(got, six), "merged tail differs from the six-launch tail"
+    # the separate calls merge the strided passes of their tails the same way (mrr_quartet_load_kernel): relinearize / switch_key in NTT form
+    # (every assign method: AddInplace reads the old destination) and rescale, against the unmerged launches
+    prod = plan.dyadic_convolute(da, 2, db, 2, L)
+    outs = {}
+    for mode in (None, "0"):
+        plan.set_option("TROYN_MRR_SMALL", mode)
+        relin = plan.relinearize(L, prod, dkeys, is_ckks=True, is_ntt_form=True)
+        three = plan.divide_and_round_q_last_ntt(L, relin, 2)
+        sk = []
+        for assign in (0, 1, 2):
+            dd = da.clone()
+            plan.switch_key(L, db[:, 1].contiguous(), dkeys, dest=dd, assign=assign, is_ckks=True, is_ntt_form=True)
+            sk.append(dd)
+        outs[mode] = [relin, three] + sk
+    plan.set_option("TROYN_MRR_SMALL", None)
+    for x, y in zip(outs[None], outs["0"]):
+        assert torch.equal(x, y)
+    assert torch.equal(got, outs[None][1]), "fused entry differs from the three-call composition"
     got = pkg.to_host(got)
     for i in range(batch):
         e = ctx.relinearize(L, True, ctx.ckks_multiply(L, a[i], b[i]), keys)

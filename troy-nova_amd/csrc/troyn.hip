@@ -864,6 +864,38 @@ static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsi
     return ksmac_split_wanted(p, batch, L, log_n) ? batch * L * 2 * (size_t)(L + 1) * ((size_t)1 << log_n) : 0;
 }
 
+
+// Single objects at N = 16384 under the FP64 policy: "INTT of one row, then a forward transform of `fw.ncomp` limbs whose loader reads that row"
+// in three launches instead of four -- first inverse pass, mrr_quartet_load_kernel (last inverse layers + loader + first forward layers on the
+// shared quartets, troyn_mrr_small.hip), last forward pass with the epilogue of `fw`.  pa: the first inverse pass (in -> out); iv.in = pa.out.
+static bool small_tail_wanted(const troyn_plan* p, size_t limb_polys) {
+    return p->log_n == 14 && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * 8 <= device_cu_count();
+}
+static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
+    const LaunchCtx lc = launch_ctx(p, s);
+    auto prep = [&](NttArgs& x, bool inverse) {
+        x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
+        x.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
+    };
+    prep(pa, true);
+    launch_ntt_f64_pass14(0, pa, pa_limb_polys, lc);
+    LAUNCH_CHECK();
+    NttArgs iv = pa;
+    iv.in = pa.out; iv.in_bstride = pa.out_bstride; iv.in_pstride = pa.out_pstride; iv.in_cstride = pa.out_cstride;
+    prep(fw, false);
+    NttArgs first = fw;                 // the pass in between: [group][limb][N], contiguous (the layout launch_two_pass gives a scratch buffer)
+    const long long N = (long long)p->n;
+    first.out = between; first.out_cstride = N; first.out_pstride = (long long)fw.ncomp * N; first.out_bstride = (long long)fw.pcount * fw.ncomp * N;
+    launch_mrr_quartet_load(p->log_n, groups, iv, first, s);
+    LAUNCH_CHECK();
+    NttArgs second = fw;
+    second.in = first.out; second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
+    second.reduce_input = 0;
+    launch_ntt_f64_pass14(1, second, groups * fw.ncomp, lc);
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
 struct KsLayout {
     size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, keys_quo, total;  // element offsets
 };
@@ -1098,6 +1130,27 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
     const u64* last_src;
     size_t last_stride;
     const u64* prod_for_util7;
+    // (5)-(7) in ONE launch: the forward NTT reads the INTT'd special rows through the rounding-fix prologue (ski_util6_merged) and finishes
+    // with the divide-by-special-prime / assign epilogue (ski_util7_merged)
+    auto fused_tail_args = [&](const u64* src) {
+        NttArgs a = contiguous_args(p, src, dest, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+        a.in_bstride = 2ll * n; a.in_pstride = n; a.in_cstride = 0;
+        a.load_mode = NTT_LOAD_KS_ROUND; a.aux_mod = K - 1;
+        a.store_mode = NTT_STORE_KS_FINISH;
+        a.flags = (is_ckks ? 1u : 0u) | ((unsigned)assign_method << 1);
+        a.ext0 = ws + w.poly_prod; a.ext0_bstride = 2ll * (L + 1) * n; a.ext0_pstride = (long long)(L + 1) * n; a.ext0_cstride = n;
+        a.ext1 = addend; a.ext1_bstride = (long long)addend_bstride; a.ext1_pstride = (long long)L * n; a.ext1_cstride = n;
+        a.inv_table = p->d_inv_last + (size_t)K * K;
+        return a;
+    };
+    if (fused && use_f64(p, 0, L) && use_f64(p, K - 1, 1) && small_tail_wanted(p, batch * 2 * L)) {
+        // a few ciphertexts at N = 16384: first inverse pass of the special rows in place (nothing else reads them), then the strided passes of both
+        // transforms as one launch (small_tail)
+        NttArgs pa = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.poly_prod + (size_t)L * n, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+        pa.in_pstride = pa.out_pstride = (long long)(L + 1) * n;
+        pa.in_bstride = pa.out_bstride = 2ll * (L + 1) * n;
+        return small_tail(p, pa, batch * 2, fused_tail_args(ws + w.prod_intt), ws + w.temp_last, batch * 2, s);
+    }
     if (is_ntt_form) {
         NttArgs a = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.prod_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         a.in_pstride = (long long)(L + 1) * n;
@@ -1131,18 +1184,8 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         prod_for_util7 = ws + w.prod_intt;
     }
     if (fused) {
-        // (5)-(7) in ONE launch: the forward NTT reads the INTT'd special rows through the rounding-fix prologue
-        // (ski_util6_merged) and finishes with the divide-by-special-prime / assign epilogue (ski_util7_merged)
-        NttArgs a = contiguous_args(p, last_src, dest, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
-        a.in_bstride = 2ll * n; a.in_pstride = n; a.in_cstride = 0;
-        a.load_mode = NTT_LOAD_KS_ROUND; a.aux_mod = K - 1;
-        a.store_mode = NTT_STORE_KS_FINISH;
-        a.flags = (is_ckks ? 1u : 0u) | ((unsigned)assign_method << 1);
-        a.ext0 = ws + w.poly_prod; a.ext0_bstride = 2ll * (L + 1) * n; a.ext0_pstride = (long long)(L + 1) * n; a.ext0_cstride = n;
-        a.ext1 = addend; a.ext1_bstride = (long long)addend_bstride; a.ext1_pstride = (long long)L * n; a.ext1_cstride = n;
-        a.inv_table = p->d_inv_last + (size_t)K * K;
         // N >= 32768 transforms in two passes: the pass in between goes to temp_last (unused on this path), never to dest
-        return launch_ntt(p, a, batch, false, s, ws + w.temp_last);
+        return launch_ntt(p, fused_tail_args(last_src), batch, false, s, ws + w.temp_last);
     }
     // (5) rounding fix of the special-prime component, per data limb (:570-598).  In NTT form the result goes to
     //     the unused tail of the prod_intt region so that step (6) can transform out of place.
@@ -1248,21 +1291,19 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
     u64* temp = temp0 + items * (size_t)(L - 1) * n;  // its NTT (out of place: lets the NTT use half-limb workgroups)
     int rc;
     // INTT of the last limb only (the reference's device branch transforms all L limbs, utils/rns_tool.cu:675)
-    {
-        NttArgs a = contiguous_args(p, (const u64*)in + (size_t)(L - 1) * n, last_intt, 1, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
-        a.in_bstride = (long long)L * n;
-        if ((rc = launch_ntt(p, a, items, true, s))) return rc;
-    }
-    if (p->log_n >= 10) {
-        // step1 -> NTT -> step2 in one launch (prologue / epilogue of the forward transform)
-        NttArgs a = contiguous_args(p, last_intt, (u64*)out, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
-        a.in_bstride = (long long)n; a.in_pstride = 0; a.in_cstride = 0;
-        a.load_mode = NTT_LOAD_RESCALE; a.aux_mod = L - 1;
-        a.store_mode = NTT_STORE_RESCALE;
-        a.ext0 = (const u64*)in; a.ext0_bstride = (long long)L * n; a.ext0_pstride = 0; a.ext0_cstride = n;
-        a.inv_table = p->d_inv_last + (size_t)L * p->K;
-        return launch_ntt(p, a, items, false, s);
-    }
+    NttArgs li = contiguous_args(p, (const u64*)in + (size_t)(L - 1) * n, last_intt, 1, 1, L - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
+    li.in_bstride = (long long)L * n;
+    // step1 -> NTT -> step2 in one launch (prologue / epilogue of the forward transform)
+    NttArgs fw = contiguous_args(p, last_intt, (u64*)out, 1, L - 1, 0, L - 1, TROYN_IDX_COMPONENTWISE, 0);
+    fw.in_bstride = (long long)n; fw.in_pstride = 0; fw.in_cstride = 0;
+    fw.load_mode = NTT_LOAD_RESCALE; fw.aux_mod = L - 1;
+    fw.store_mode = NTT_STORE_RESCALE;
+    fw.ext0 = (const u64*)in; fw.ext0_bstride = (long long)L * n; fw.ext0_pstride = 0; fw.ext0_cstride = n;
+    fw.inv_table = p->d_inv_last + (size_t)L * p->K;
+    // a few ciphertexts at N = 16384: three launches instead of four (small_tail; the pass in between lives in `out`, as in the two-pass form)
+    if (use_f64(p, 0, L) && small_tail_wanted(p, items * (L - 1))) return small_tail(p, li, items, fw, (u64*)out, items, s);
+    if ((rc = launch_ntt(p, li, items, true, s))) return rc;
+    if (p->log_n >= 10) return launch_ntt(p, fw, items, false, s);
     const unsigned ch = chunks_pairs(p->n);
     const size_t rows = items * (L - 1);
     if ((rc = check_rows(rows, ch))) return rc;
