@@ -227,6 +227,7 @@ struct TroynOptions {
     bool ks_mac_shoup_off = false;   // TROYN_KS_MAC_SHOUP=0: Barrett-128 terms in that kernel's integer form
     bool mrr_mixed_off = false;      // TROYN_MRR_MIXED=0: chains with moduli >= 2^50 compose the three calls inside the fused entry
     bool mrr_small_off = false;      // TROYN_MRR_SMALL=0: single objects at N = 16384 keep the six-launch tail of the fused chain
+    bool mrr_small_serial = false;   // TROYN_MRR_SMALL=serial: one thread per quartet loops over the output limbs (no recomputation of the inverse tails)
     bool mrr_calls = false;          // TROYN_MRR=calls: the fused entry composes the three public calls
     int mrr_chunk = 0, mrr_streams = 2;   // TROYN_MRR_CHUNK=<items>, TROYN_MRR_STREAMS=<1..4>
     bool behz_v1 = false;            // TROYN_BEHZ=v1: first-generation conversion kernels (they stay the path of L > 16 and N < 1024)
@@ -258,7 +259,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_KS_ROWS") o.ks_rows = num(d.ks_rows);
     else if (n == "TROYN_KS_MAC_SHOUP") o.ks_mac_shoup_off = v == "0";
     else if (n == "TROYN_MRR_MIXED") o.mrr_mixed_off = v == "0";
-    else if (n == "TROYN_MRR_SMALL") o.mrr_small_off = v == "0";
+    else if (n == "TROYN_MRR_SMALL") { o.mrr_small_off = v == "0"; o.mrr_small_serial = v == "serial"; }
     else if (n == "TROYN_MRR") o.mrr_calls = v == "calls";
     else if (n == "TROYN_MRR_CHUNK") o.mrr_chunk = num(d.mrr_chunk);
     else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
@@ -1531,7 +1532,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         prep(la, true);
         NttArgs ta = tail_args(0, L - 1);
         prep(ta, false);
-        launch_mrr_quartet(p->log_n, batch, sp, la, ta, s);
+        launch_mrr_quartet(p->log_n, batch, sp, la, ta, s, !p->opt.mrr_small_serial);
         LAUNCH_CHECK();
         // last forward pass of the output limbs, in place in `out`, with step (5)'s epilogue
         ta.in = ta.out; ta.in_bstride = ta.out_bstride; ta.in_pstride = ta.out_pstride; ta.in_cstride = ta.out_cstride;

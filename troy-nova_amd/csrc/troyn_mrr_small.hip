@@ -14,19 +14,25 @@
 
 namespace troyn {
 
-template <int LOGN>
-__global__ __launch_bounds__(256) void mrr_quartet_kernel(NttArgs sp, NttArgs la, NttArgs ta) {
+// the special rows share `la`'s tables: only their address and modulus travel (two NttArgs + 32 bytes of kernel arguments)
+struct QuartetSpecial { const u64* in; long long in_bstride, in_pstride; unsigned mod; };
+
+template <int LOGN, bool JPAR>
+__global__ __launch_bounds__(256) void mrr_quartet_kernel(QuartetSpecial qs, NttArgs la, NttArgs ta) {
     using A = ArithF64;
     constexpr unsigned N = 1u << LOGN, Q = N / 4;
     typedef const double __attribute__((address_space(4)))* ctw;
     // one thread per (output limb j, item, polynomial, quartet): the two inverse tails are recomputed by the L - 1 threads that share a quartet
     // (8 loads and ~70 FP64 operations, from L2) -- a launch of a single ciphertext is latency-bound, and one limb per thread is the shorter chain
-    const unsigned gid = (blockIdx.x % ta.xcd_groups) * 256u + threadIdx.x, j = blockIdx.x / ta.xcd_groups;      // xcd_groups: workgroups per limb
+    // (JPAR = false: one thread per quartet loops over the output limbs -- a quarter of the workgroups and no recomputation: several host threads
+    // with a stream each keep the GPU busy, and then total work counts, not the length of one chain)
+    const unsigned gid = (JPAR ? blockIdx.x % ta.xcd_groups : blockIdx.x) * 256u + threadIdx.x;      // xcd_groups: workgroups per limb
+    const unsigned j0 = JPAR ? blockIdx.x / ta.xcd_groups : 0u, j1 = JPAR ? j0 + 1u : ta.ncomp;
     const unsigned i = gid % Q, g = gid / Q, k = g & 1u, b = g >> 1;
-    auto inverse_tail = [&](const NttArgs& x, unsigned mi, const A::Mod& md, double (&v)[4]) {
+    auto inverse_tail = [&](const u64* base, long long bstride, long long pstride, unsigned mi, const A::Mod& md, double (&v)[4]) {
         // pass B of an inverse transform in its two-pass form: layers 1 and 0 (Gentleman-Sande, the last one folded with N^-1)
-        const u64* in = x.in + (long long)b * x.in_bstride + (long long)k * x.in_pstride;
-        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(x.tw) + (size_t)mi * N);
+        const u64* in = base + (long long)b * bstride + (long long)k * pstride;
+        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(la.tw) + (size_t)mi * N);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) v[kk] = A::load_mid(in[i + kk * Q], md);
         A::inv(v[0], v[1], A::tw_from_mem(tw[N - 3], md), md);
@@ -37,10 +43,10 @@ __global__ __launch_bounds__(256) void mrr_quartet_kernel(NttArgs sp, NttArgs la
     // T_s = (s + qk/2) mod qk at the four coefficients (the plain inverse transform's NTT_FLAG_STORE_ROUND_HALF epilogue)
     u64 ts[4], tl[4];
     {
-        const unsigned mi = sp.table_start;
-        const A::Mod md = A::make(sp.mods[mi]);
+        const unsigned mi = qs.mod;
+        const A::Mod md = A::make(la.mods[mi]);
         double v[4];
-        inverse_tail(sp, mi, md, v);
+        inverse_tail(qs.in, qs.in_bstride, qs.in_pstride, mi, md, v);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const u64 c = kk >= 2 ? A::final_fwd(v[kk], md) : A::final_inv(v[kk], md);      // the folded layer scaled its difference outputs already
@@ -54,12 +60,12 @@ __global__ __launch_bounds__(256) void mrr_quartet_kernel(NttArgs sp, NttArgs la
         NttIo io;
         ntt_io_fused(io, la, b, k, 0, mi);
         double v[4];
-        inverse_tail(la, mi, md, v);
+        inverse_tail(la.in, la.in_bstride, la.in_pstride, mi, md, v);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) tl[kk] = A::template last_out<false>(io, v[kk], kk >= 2, ts[kk], md);
     }
     // the L - 1 output limbs: r_j(s) qk^-1 + f_j(l) enters ONE forward transform; its first two layers here (pass A of NTT_FUSED_TAIL_RESCALE)
-    {
+    for (unsigned j = j0; j < j1; ++j) {
         const unsigned mi = ta.table_start + j;
         const A::Mod md = A::make(ta.mods[mi]);
         NttIo io;
@@ -136,12 +142,14 @@ void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, c
 
 // sp / la: the pass-A words of the special rows / of limb L - 1 (in, strides, table_start = their modulus, tw = inverse tables; la with the
 // constants of step (4)); ta: step (5)'s arguments (out = where pass B reads, tw = forward tables).  batch * 2 polynomials.
-void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s) {
+void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s, bool limb_parallel) {
     if (log_n != 14) return;
     const unsigned blocks = (unsigned)(batch * 2 * ((1u << 14) / 4) / 256);
     NttArgs t = ta;
     t.xcd_groups = blocks;        // (the field is free in this kernel: workgroups per output limb)
-    hipLaunchKernelGGL((mrr_quartet_kernel<14>), dim3(blocks * ta.ncomp), dim3(256), 0, s, sp, la, t);
+    const QuartetSpecial qs{sp.in, sp.in_bstride, sp.in_pstride, sp.table_start};
+    if (limb_parallel) hipLaunchKernelGGL((mrr_quartet_kernel<14, true>), dim3(blocks * ta.ncomp), dim3(256), 0, s, qs, la, t);
+    else hipLaunchKernelGGL((mrr_quartet_kernel<14, false>), dim3(blocks), dim3(256), 0, s, qs, la, t);
 }
 
 }  // namespace troyn
