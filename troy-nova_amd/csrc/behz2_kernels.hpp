@@ -35,6 +35,9 @@ template <typename T> __device__ __forceinline__ cu32p as_c32(const T* p) { retu
 
 constexpr unsigned BEHZ2_MAX_L = 16;
 constexpr unsigned BEHZ2_RC = 8;   // u64 words of per-row constants
+#ifndef BEHZ2_FUSED_THREADS
+#define BEHZ2_FUSED_THREADS 256
+#endif
 constexpr unsigned BEHZ2_FUSED_MAX_ROWS = 31;   // behz2_lift_pass1.hpp: rows of both bases in LDS, 2 KB each (64 KB of dynamic LDS without an attribute)
 
 // row constants (u64 index)

@@ -33,33 +33,33 @@ struct LiftPass1Args {
     const DevModulus* aux_mods; // [NB+1]
 };
 
-template <int L>
-__global__ __launch_bounds__(256) void behz2_lift_pass1_kernel(Behz2Dev c, LiftPass1Args a) {
-    constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, CHUNKS = SEG / 32;
+template <int L, int T = BEHZ2_FUSED_THREADS>
+__global__ __launch_bounds__(T) void behz2_lift_pass1_kernel(Behz2Dev c, LiftPass1Args a) {
+    constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, BASES = T / 8, CHUNKS = SEG / BASES;
     extern __shared__ u64 lift_lds[];              // [L + NB + 1][8][32] re-centred doubles
     const unsigned NB = c.NB, t = threadIdx.x;
     const size_t item = blockIdx.x / CHUNKS;
-    const unsigned base0 = (blockIdx.x % CHUNKS) * 32u;
+    const unsigned base0 = (blockIdx.x % CHUNKS) * BASES;
     {
         // ---- phase A: one coefficient of all rows (behz2_lift_one: the same arithmetic as behz2_lift_kernel) ----
-        const unsigned x = (t >> 5) * SEG + base0 + (t & 31u);
+        const unsigned x = (t / BASES) * SEG + base0 + (t % BASES);
         const u64* ip = a.in + item * (size_t)L * N;
         const cmodp qm = as_cmod(a.q_mods);
         behz2_lift_one<L, true, true>(c,
             [&](int i) {
                 const u64 xv = __builtin_nontemporal_load(ip + (size_t)i * N + x);
-                lift_lds[i * 256 + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{qm[i].pd, qm[i].inv_pd}));
+                lift_lds[i * T + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{qm[i].pd, qm[i].inv_pd}));
                 return xv;
             },
-            [&](unsigned b, double w) { lift_lds[(L + b) * 256 + t] = f64_double_to_bits(w); });      // already re-centred (behz2_reduce_f64)
+            [&](unsigned b, double w) { lift_lds[(L + b) * T + t] = f64_double_to_bits(w); });      // already re-centred (behz2_reduce_f64)
     }
     __syncthreads();
     // ---- phase B: layers 0-2 on the octets; a wave covers two rows, so the modulus constants and twiddles are per-lane loads ----
     const unsigned nrows = L + NB + 1;
     u64* oq = a.out_q + item * (size_t)L * N;
     u64* ob = a.out_bsk + item * (size_t)(NB + 1) * N;
-    for (unsigned w = t; w < nrows * 32u; w += 256u) {
-        const unsigned row = w >> 5, j = w & 31u;
+    for (unsigned w = t; w < nrows * BASES; w += T) {
+        const unsigned row = w / BASES, j = w % BASES;
         const bool isq = row < (unsigned)L;
         const unsigned r = isq ? row : row - L;
         const DevModulus* md = (isq ? a.q_mods : a.aux_mods) + r;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void behz2_lift_pass1_kernel(Behz2Dev c, LiftP
         const double p = md->pd, inv_p = md->inv_pd;
         double x[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = f64_bits_to_double(lift_lds[row * 256 + k * 32 + j]);
+        for (int k = 0; k < 8; ++k) x[k] = f64_bits_to_double(lift_lds[row * T + k * BASES + j]);
         auto bf = [&](int r0, int r1, double tw_w) {
             const double rr = f64_mulq(x[r1], tw_w, inv_p, p);
             const double u = x[r0];
@@ -104,18 +104,18 @@ struct FloorPass2Args {
     const DevModulus* aux_mods; // [NB+1]
 };
 
-template <int L>
-__global__ __launch_bounds__(256) void behz2_floor_pass2_kernel(Behz2Dev c, FloorPass2Args a) {
-    constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, CHUNKS = SEG / 32;
+template <int L, int T = BEHZ2_FUSED_THREADS>
+__global__ __launch_bounds__(T) void behz2_floor_pass2_kernel(Behz2Dev c, FloorPass2Args a) {
+    constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, BASES = T / 8, CHUNKS = SEG / BASES;
     extern __shared__ u64 lift_lds[];              // [L + NB + 1][8][32] canonical words
     const unsigned NB = c.NB, t = threadIdx.x;
     const size_t item = blockIdx.x / CHUNKS;
-    const unsigned base0 = (blockIdx.x % CHUNKS) * 32u;
+    const unsigned base0 = (blockIdx.x % CHUNKS) * BASES;
     const unsigned nrows = L + NB + 1;
     const u64* iq = a.in_q + item * (size_t)L * N;
     const u64* ib = a.in_bsk + item * (size_t)(NB + 1) * N;
-    for (unsigned w = t; w < nrows * 32u; w += 256u) {
-        const unsigned row = w >> 5, j = w & 31u;
+    for (unsigned w = t; w < nrows * BASES; w += T) {
+        const unsigned row = w / BASES, j = w % BASES;
         const bool isq = row < (unsigned)L;
         const unsigned r = isq ? row : row - L;
         const DevModulus* md = (isq ? a.q_mods : a.aux_mods) + r;
@@ -142,13 +142,13 @@ __global__ __launch_bounds__(256) void behz2_floor_pass2_kernel(Behz2Dev c, Floo
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double y = k < 4 ? f64_mulc(x[k], ninv, ninv_p, m.p) : x[k];          // final_inv / final_fwd
-            lift_lds[row * 256 + k * 32 + j] = f64_canon(y, m);
+            lift_lds[row * T + k * BASES + j] = f64_canon(y, m);
         }
     }
     __syncthreads();
-    const unsigned x = (t >> 5) * SEG + base0 + (t & 31u);
+    const unsigned x = (t / BASES) * SEG + base0 + (t % BASES);
     u64* op = a.out + item * (size_t)L * N;
-    behz2_floor_one<L, true, true>(c, [&](int i) { return lift_lds[i * 256 + t]; }, [&](unsigned b) { return lift_lds[(L + b) * 256 + t]; },
+    behz2_floor_one<L, true, true>(c, [&](int i) { return lift_lds[i * T + t]; }, [&](unsigned b) { return lift_lds[(L + b) * T + t]; },
                                    [&](int jj, u64 wv) { __builtin_nontemporal_store(wv, op + (size_t)jj * N + x); });
 }
 

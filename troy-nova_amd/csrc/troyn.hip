@@ -2156,11 +2156,12 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     auto lift = [&](const u64* src, size_t pcount, u64* dst_q, u64* dst_bsk) -> int {
         // steps (1)-(3) of evaluator.cu:50-60 for one operand
         if (lift_fused) {
-            if (batch * pcount * 128u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
-            if (launch_behz2_lift_pass1(L, batch * pcount, s, b->dev2, src, dst_q, dst_bsk, (const double*)pq->d_fwd_f64, (const double*)px->d_fwd_f64, pq->d_mods, px->d_mods)) {
-                LAUNCH_CHECK();
-                return TROYN_OK;
-            }
+            if (batch * pcount * 512u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
+            // (lift_fused holds only for shapes both fused launches cover: the floor below skips the last inverse pass on the same condition)
+            if (!launch_behz2_lift_pass1(L, batch * pcount, s, b->dev2, src, dst_q, dst_bsk, (const double*)pq->d_fwd_f64, (const double*)px->d_fwd_f64, pq->d_mods, px->d_mods))
+                return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused lift kernel for this shape");
+            LAUNCH_CHECK();
+            return TROYN_OK;
         }
         NttArgs a = contiguous_args(pq, src, dst_q, pcount, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
         int r = whole ? TROYN_OK : tensor ? tensor_stage(pq, 0, a, a, a, batch, s) : launch_ntt(pq, a, batch, false, s);   // whole: the tensor kernel reads src
@@ -2221,8 +2222,9 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
         dim3 grid((unsigned)(items * ch1)), block(256);
         TimerScope ts(TROYN_TIMER_BEHZ_FLOOR, s);
         if (lift_fused) {
-            if (items * 128u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
-            launch_behz2_floor_pass2(L, items, s, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, (const double*)pq->d_inv_f64, (const double*)px->d_inv_f64, pq->d_mods, px->d_mods);
+            if (items * 512u > 0x7fffffffull) return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] batch too large for one launch");
+            if (!launch_behz2_floor_pass2(L, items, s, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, (const double*)pq->d_inv_f64, (const double*)px->d_inv_f64, pq->d_mods, px->d_mods))
+                return fail(TROYN_E_INVALID, "[troyn_bfv_multiply] no fused floor kernel for this shape");
         } else if (gen2) {
             launch_behz2_floor(L, b->smallq, grid.x, s, ch1, b->dev2, ws + w.d_q, ws + w.d_bsk, (u64*)out, b->aux50);
         } else dispatch_bound(S,

@@ -34,8 +34,8 @@ bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz
     const unsigned rows = L + c.NB + 1;
     if (rows > BEHZ2_FUSED_MAX_ROWS) return false;
     LiftPass1Args a{src, dst_q, dst_bsk, tw_q, tw_aux, q_mods, aux_mods};
-    const dim3 grid((unsigned)(items * 128u)), block(256);
-    const size_t lds = (size_t)rows * 256u * sizeof(u64);
+    const dim3 grid((unsigned)(items * (4096u / (BEHZ2_FUSED_THREADS / 8)))), block(BEHZ2_FUSED_THREADS);
+    const size_t lds = (size_t)rows * BEHZ2_FUSED_THREADS * sizeof(u64);
     switch (L) {
 #define X(N) case N: hipLaunchKernelGGL((behz2_lift_pass1_kernel<N>), grid, block, lds, s, c, a); return true;
         BEHZ2_CASES(X)
@@ -50,8 +50,8 @@ bool launch_behz2_floor_pass2(unsigned L, size_t items, hipStream_t s, const Beh
     const unsigned rows = L + c.NB + 1;
     if (rows > BEHZ2_FUSED_MAX_ROWS) return false;
     FloorPass2Args a{in_q, in_bsk, out, tw_q, tw_aux, q_mods, aux_mods};
-    const dim3 grid((unsigned)(items * 128u)), block(256);
-    const size_t lds = (size_t)rows * 256u * sizeof(u64);
+    const dim3 grid((unsigned)(items * (4096u / (BEHZ2_FUSED_THREADS / 8)))), block(BEHZ2_FUSED_THREADS);
+    const size_t lds = (size_t)rows * BEHZ2_FUSED_THREADS * sizeof(u64);
     switch (L) {
 #define X(N) case N: hipLaunchKernelGGL((behz2_floor_pass2_kernel<N>), grid, block, lds, s, c, a); return true;
         BEHZ2_CASES(X)
