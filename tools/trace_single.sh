@@ -1,7 +1,12 @@
 #!/bin/bash
-ROOT="$(pwd)"; OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
+# Kernel trace of single-object multiply + relinearize + rescale through troy::Evaluator (tests/cpp/he_bench_driver bench) -> gpurun_out/<tag>_single_trace.txt
+set -e
+TAG=${1:-single}
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-export LD_LIBRARY_PATH=$ROOT/troy-nova_amd:$ROOT/troy-nova_amd/troy:$LD_LIBRARY_PATH
-rocprofv3 --kernel-trace --stats -d "$OUT/single_tr" -o single -- $ROOT/tests/cpp/he_bench_driver single > "$OUT/single_run.txt" 2>&1
-python3 $ROOT/tools/rocpd_summary.py "$OUT/single_tr/single_results.db" | head -40 | cut -c1-170
-tail -3 "$OUT/single_run.txt"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_$TAG/trace" -o bench -- $ROOT/tests/cpp/he_bench_driver single > "$OUT/${TAG}_single.log" 2>&1
+cd "$ROOT"
+python3 tools/rocpd_summary.py "$OUT/prof_$TAG/trace/bench_results.db" > "$OUT/${TAG}_single_trace.txt"
+rm -rf "$OUT/prof_$TAG"
