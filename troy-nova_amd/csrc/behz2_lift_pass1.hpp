@@ -5,9 +5,11 @@
 // over its L rows of base q (read L, write L), behz2_lift_kernel (read L, write NB + 1) and the strided first pass over the lifted rows
 // (read NB + 1, write NB + 1).  The lift works on one coefficient of all rows, the strided pass on the 8 coefficients {base + k N/8} of one
 // row.  Here a 256-thread workgroup owns 32 consecutive bases x 8 strides:
-//   phase A: thread (k, j) lifts coefficient base_j + k N/8 exactly as behz2_lift_kernel does (behz2_lift_one, 2 L registers of split residues) and parks the
-//            re-centred doubles of its L input words and NB + 1 lifted words in LDS ([row][k][j], 2 KB per row);
-//   phase B: the (L + NB + 1) x 32 octets are dealt to the threads; each runs layers 0-2 on its 8 words and stores the first-pass words.
+//   thread (k, j) reads coefficient base_j + k N/8 of the L input rows and parks their re-centred doubles in LDS ([row][k][j], 2 KB per row);
+//   the L x 32 octets are dealt to the threads, each runs layers 0-2 on its 8 words and stores the first-pass words of base q;
+//   thread (k, j) lifts its coefficient exactly as behz2_lift_kernel does (behz2_lift_one, 2 L registers of split residues) into the same LDS rows;
+//   the (NB + 1) x 32 octets of the lifted rows follow.  One base in LDS at a time: max(L, NB + 1) rows, 26 KB at cfg4 (both bases together: 45 KB and
+//   half the workgroups per CU, -1 %).
 // Giving a thread the 8 strided coefficients of all rows instead (no LDS) needs 16 L registers of split residues next to the partial sums:
 // measured at the compiler, 255 registers and 1.4 KB of scratch per lane at L = 10.
 // HBM traffic per operand: L + (L + NB + 1) rows instead of 3 L + 3 (NB + 1); same words at the same addresses as the three launches
@@ -36,54 +38,55 @@ struct LiftPass1Args {
 template <int L, int T = BEHZ2_FUSED_THREADS>
 __global__ __launch_bounds__(T) void behz2_lift_pass1_kernel(Behz2Dev c, LiftPass1Args a) {
     constexpr unsigned LOGN = 15, N = 1u << LOGN, SEG = N / 8, BASES = T / 8, CHUNKS = SEG / BASES;
-    extern __shared__ u64 lift_lds[];              // [L + NB + 1][8][32] re-centred doubles
+    // LDS holds ONE base at a time ([rows][8][BASES] re-centred doubles): the rows of base q leave before the lifted rows arrive, so a workgroup
+    // needs max(L, NB + 1) rows instead of L + NB + 1 and twice as many workgroups share a CU (two more barriers)
+    extern __shared__ u64 lift_lds[];
     const unsigned NB = c.NB, t = threadIdx.x;
     const size_t item = blockIdx.x / CHUNKS;
     const unsigned base0 = (blockIdx.x % CHUNKS) * BASES;
-    {
-        // ---- phase A: one coefficient of all rows (behz2_lift_one: the same arithmetic as behz2_lift_kernel) ----
-        const unsigned x = (t / BASES) * SEG + base0 + (t % BASES);
-        const u64* ip = a.in + item * (size_t)L * N;
-        const cmodp qm = as_cmod(a.q_mods);
-        behz2_lift_one<L, true, true>(c,
-            [&](int i) {
-                const u64 xv = __builtin_nontemporal_load(ip + (size_t)i * N + x);
-                lift_lds[i * T + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv), F64Mod{qm[i].pd, qm[i].inv_pd}));
-                return xv;
-            },
-            [&](unsigned b, double w) { lift_lds[(L + b) * T + t] = f64_double_to_bits(w); });      // already re-centred (behz2_reduce_f64)
+    // layers 0-2 on the octets of `nrows` rows in LDS; a wave covers several rows, so the modulus constants and twiddles are per-lane loads
+    auto octets = [&](unsigned nrows, const DevModulus* mods, const double* twt, u64* outp) {
+        for (unsigned w = t; w < nrows * BASES; w += T) {
+            const unsigned row = w / BASES, j = w % BASES;
+            const DevModulus* md = mods + row;
+            const double* tw = twt + (size_t)row * N;
+            u64* out = outp + (size_t)row * N + base0 + j;
+            const double p = md->pd, inv_p = md->inv_pd;
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = f64_bits_to_double(lift_lds[row * T + k * BASES + j]);
+            auto bf = [&](int r0, int r1, double tw_w) {
+                const double rr = f64_mulq(x[r1], tw_w, inv_p, p);
+                const double u = x[r0];
+                x[r0] = u + rr; x[r1] = u - rr;
+            };
+            const double w1 = tw[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bf(k, k + 4, w1);
+            const double w2 = tw[2], w3 = tw[3];
+            bf(0, 2, w2); bf(1, 3, w2); bf(4, 6, w3); bf(5, 7, w3);
+            const double w4 = tw[4], w5 = tw[5], w6 = tw[6], w7 = tw[7];
+            bf(0, 1, w4); bf(2, 3, w5); bf(4, 5, w6); bf(6, 7, w7);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(f64_double_to_bits(x[k]), out + k * SEG);
+        }
+    };
+    // ---- one coefficient of all rows (behz2_lift_one: the same arithmetic as behz2_lift_kernel) ----
+    const unsigned x = (t / BASES) * SEG + base0 + (t % BASES);
+    const u64* ip = a.in + item * (size_t)L * N;
+    const cmodp qm = as_cmod(a.q_mods);
+    u64 xv[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        xv[i] = __builtin_nontemporal_load(ip + (size_t)i * N + x);
+        lift_lds[i * T + t] = f64_double_to_bits(f64_corr(f64_from_u64(xv[i]), F64Mod{qm[i].pd, qm[i].inv_pd}));
     }
     __syncthreads();
-    // ---- phase B: layers 0-2 on the octets; a wave covers two rows, so the modulus constants and twiddles are per-lane loads ----
-    const unsigned nrows = L + NB + 1;
-    u64* oq = a.out_q + item * (size_t)L * N;
-    u64* ob = a.out_bsk + item * (size_t)(NB + 1) * N;
-    for (unsigned w = t; w < nrows * BASES; w += T) {
-        const unsigned row = w / BASES, j = w % BASES;
-        const bool isq = row < (unsigned)L;
-        const unsigned r = isq ? row : row - L;
-        const DevModulus* md = (isq ? a.q_mods : a.aux_mods) + r;
-        const double* tw = (isq ? a.tw_q : a.tw_aux) + (size_t)r * N;
-        u64* out = (isq ? oq : ob) + (size_t)r * N + base0 + j;
-        const double p = md->pd, inv_p = md->inv_pd;
-        double x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = f64_bits_to_double(lift_lds[row * T + k * BASES + j]);
-        auto bf = [&](int r0, int r1, double tw_w) {
-            const double rr = f64_mulq(x[r1], tw_w, inv_p, p);
-            const double u = x[r0];
-            x[r0] = u + rr; x[r1] = u - rr;
-        };
-        const double w1 = tw[1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bf(k, k + 4, w1);
-        const double w2 = tw[2], w3 = tw[3];
-        bf(0, 2, w2); bf(1, 3, w2); bf(4, 6, w3); bf(5, 7, w3);
-        const double w4 = tw[4], w5 = tw[5], w6 = tw[6], w7 = tw[7];
-        bf(0, 1, w4); bf(2, 3, w5); bf(4, 5, w6); bf(6, 7, w7);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(f64_double_to_bits(x[k]), out + k * SEG);
-    }
+    octets(L, a.q_mods, a.tw_q, a.out_q + item * (size_t)L * N);
+    __syncthreads();
+    behz2_lift_one<L, true, true>(c, [&](int i) { return xv[i]; }, [&](unsigned b, double w) { lift_lds[b * T + t] = f64_double_to_bits(w); });      // already re-centred (behz2_reduce_f64)
+    __syncthreads();
+    octets(NB + 1, a.aux_mods, a.tw_aux, a.out_bsk + item * (size_t)(NB + 1) * N);
 }
 
 // ---- BEHZ steps (5)-(8) tail: last inverse pass of both bases + kernel_fast_floor_fast_b_conv_sk as ONE launch ----

@@ -35,7 +35,7 @@ bool launch_behz2_lift_pass1(unsigned L, size_t items, hipStream_t s, const Behz
     if (rows > BEHZ2_FUSED_MAX_ROWS) return false;
     LiftPass1Args a{src, dst_q, dst_bsk, tw_q, tw_aux, q_mods, aux_mods};
     const dim3 grid((unsigned)(items * (4096u / (BEHZ2_FUSED_THREADS / 8)))), block(BEHZ2_FUSED_THREADS);
-    const size_t lds = (size_t)rows * BEHZ2_FUSED_THREADS * sizeof(u64);
+    const size_t lds = (size_t)(L > c.NB + 1 ? L : c.NB + 1) * BEHZ2_FUSED_THREADS * sizeof(u64);      // one base at a time
     switch (L) {
 #define X(N) case N: hipLaunchKernelGGL((behz2_lift_pass1_kernel<N>), grid, block, lds, s, c, a); return true;
         BEHZ2_CASES(X)
