@@ -22,7 +22,7 @@ SWITCHES = {
     "TROYN_KS_ORDER": ("plain", "item", "row", "band"),
     "TROYN_KS_SPLIT": ("0", "1"),
     "TROYN_KS_DIAG": ("loop",),
-    "TROYN_KS_MAC": ("split",),
+    "TROYN_KS_MAC": ("split", "fused"),
     "TROYN_KS_TAIL": ("split",),
     "TROYN_KS_MAC_SHOUP": ("0",),
     "TROYN_KS_ROWS": ("1", "2"),

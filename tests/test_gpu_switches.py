@@ -31,9 +31,10 @@ def _case(O, pkg, dev, n, bits, L, batch=8):
 
 @pytest.mark.parametrize("env", [{}, {"TROYN_KS_MAC": "v1"}, {"TROYN_KS_MAC": "split"}, {"TROYN_KS_ORDER": "row"}, {"TROYN_NTT_ARITH": "u64"},
                                  {"TROYN_NTT_HALF": "0x3f3f"}, {"TROYN_NTT_HALF": "0"}, {"TROYN_KS_DIAG": "loop"}, {"TROYN_KS_SPLIT": "0"}, {"TROYN_KS_SPLIT": "1"},
-                                 {"TROYN_KS_SPLIT": "0", "TROYN_KS_DIAG": "loop"}, {"TROYN_NTT_ARITH": "u64", "TROYN_KS_MAC_SHOUP": "0"}],
+                                 {"TROYN_KS_SPLIT": "0", "TROYN_KS_DIAG": "loop"}, {"TROYN_NTT_ARITH": "u64", "TROYN_KS_MAC_SHOUP": "0", "TROYN_KS_MAC": "fused"},
+                                 {"TROYN_NTT_ARITH": "u64", "TROYN_KS_MAC": "fused"}],
                          ids=["default", "ks_mac_v1", "ks_mac_split", "ks_order_row", "ntt_arith_u64", "ntt_half_all", "ntt_half_none", "ks_diag_in_loop",
-                              "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_diag_in_loop", "integer_inner_product_barrett_terms"])
+                              "ks_digits_serial", "ks_digits_parallel", "ks_digits_serial_diag_in_loop", "integer_inner_product_barrett_terms", "integer_inner_product_one_launch"])
 @pytest.mark.parametrize("n,bits,L", [(16384, [50] * 6, 5), (8192, [40, 40, 40, 40], 3)])
 def test_switch_key_under_every_switch(O, pkg, dev, monkeypatch, env, n, bits, L):
     for k in ("TROYN_KS_MAC", "TROYN_KS_ORDER", "TROYN_NTT_ARITH", "TROYN_NTT_HALF", "TROYN_KS_DIAG", "TROYN_KS_SPLIT", "TROYN_KS_MAC_SHOUP"):

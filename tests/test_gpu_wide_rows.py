@@ -28,6 +28,19 @@ WIDE_CHAINS = [
 ]
 
 
+@pytest.fixture(autouse=True, params=["fused", "default"])
+def inner_product_form(request, monkeypatch):
+    """Every test of this module twice: a few ciphertexts of a chain with moduli >= 2^50 take the two-launch inner product by default (digit
+    transforms, then the multiply-accumulate: the one-launch kernels have no digit-parallel form and a launch that cannot fill the chip is one
+    long chain -- ks_small_mixed in troyn.hip); TROYN_KS_MAC=fused (read when the plan is created) keeps ksmac2<WIDE> + ksmaci_kernel at every
+    size, which is what these tests were written for.  Results are the same words either way."""
+    if request.param == "fused":
+        monkeypatch.setenv("TROYN_KS_MAC", "fused")
+    else:
+        monkeypatch.delenv("TROYN_KS_MAC", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("scheme,ntt_form", [("ckks", True), ("bfv", False)])
 @pytest.mark.parametrize("n,bits,L", WIDE_CHAINS)
 def test_switch_key_wide_rows(O, pkg, dev, scheme, ntt_form, n, bits, L):

@@ -222,6 +222,7 @@ struct TroynOptions {
     int ks_split = -1;               // TROYN_KS_SPLIT=0|1: digit-parallel inner product off / forced on
     bool ks_tail_split = false;      // TROYN_KS_TAIL=split: coefficient-form tail as separate launches
     bool ks_mac_split = false;       // TROYN_KS_MAC=split: decomposition NTT and inner product in two launches (the path of N < 1024 / N > 32768)
+    bool ks_mac_fused = false;       // TROYN_KS_MAC=fused: the one-launch inner product also for small launches of chains with moduli >= 2^50 (see ks_small_mixed)
     bool ks_diag_loop = false;       // TROYN_KS_DIAG=loop: diagonal digit as an iteration of ksmac2's digit loop
     int ks_rows = 0;                 // TROYN_KS_ROWS=<r>: rows co-scheduled per XCD by the whole-limb inner product of N < 8192
     bool ks_mac_shoup_off = false;   // TROYN_KS_MAC_SHOUP=0: Barrett-128 terms in that kernel's integer form
@@ -254,7 +255,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     else if (n == "TROYN_KS_ORDER") o.ks_order = v == "plain" ? 0 : v == "item" ? 1 : v == "row" ? 2 : v == "band" ? 3 : d.ks_order;
     else if (n == "TROYN_KS_SPLIT") o.ks_split = v.empty() ? d.ks_split : num(-1);
     else if (n == "TROYN_KS_TAIL") o.ks_tail_split = v == "split";
-    else if (n == "TROYN_KS_MAC") o.ks_mac_split = v == "split";
+    else if (n == "TROYN_KS_MAC") { o.ks_mac_split = v == "split"; o.ks_mac_fused = v == "fused"; }
     else if (n == "TROYN_KS_DIAG") o.ks_diag_loop = v == "loop";
     else if (n == "TROYN_KS_ROWS") o.ks_rows = num(d.ks_rows);
     else if (n == "TROYN_KS_MAC_SHOUP") o.ks_mac_shoup_off = v == "0";
@@ -897,6 +898,17 @@ static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, Ntt
     return TROYN_OK;
 }
 
+// A chain with moduli of 2^50 and more, a few ciphertexts: its one-launch inner products (ksmac2<WIDE> + ksmaci) loop over the L digits inside
+// 2 .. 4 workgroups per item and have no digit-parallel form, so a launch that cannot fill the chip is one long chain (one ciphertext at
+// N = 16384 {60,50,50,50,50,60}: 148 us of inner product).  The two-launch form -- (L + 1) L digit transforms, then the multiply-accumulate -- spreads
+// the same work over L times the workgroups: relinearize of one ciphertext 214 -> 84 us (N = 16384), 140 -> 78 us (N = 8192 {60,40,40,60}); equal at
+// 256 workgroups of the one-launch form (N = 16384: 32 items; N = 8192: ~100), which is where this rule hands over.  TROYN_KS_MAC=fused / split force either.
+static bool ks_small_mixed(const troyn_plan* p, unsigned L, size_t batch) {
+    if (p->opt.ks_mac_fused || p->log_n < 13 || p->log_n > 15) return false;
+    if (use_f64(p, 0, L) && use_f64(p, p->K - 1, 1)) return false;
+    return (batch * (size_t)(L + 1) << (p->log_n - 13)) <= 256;
+}
+
 struct KsLayout {
     size_t target_intt, temp_ntt, poly_prod, prod_intt, temp_last, keys_f64, split, keys_quo, total;  // element offsets
 };
@@ -966,7 +978,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         digits_src = ws + w.target_intt;
         digits_bstride = (size_t)L * n;
     }
-    const bool ks_unfused_mac = p->opt.ks_mac_split;
+    const bool ks_unfused_mac = p->opt.ks_mac_split || ks_small_mixed(p, L, batch);
     // (2)+(3) in ONE launch for whole-limb rings (N <= 16384): every workgroup owns one output row of one item,
     //     transforms that row's L digits one after the other and multiplies them into register accumulators with
     //     the key (kernel_set_accumulate + ntt + kernel_accumulate_products, fgk/switch_key.cu:6-154); the
@@ -1578,7 +1590,8 @@ extern "C" int troyn_ckks_multiply_relinearize_rescale(const troyn_plan* p, uint
     u64* ws = (u64*)workspace;
     int rc;
     const bool unfused = p->opt.mrr_calls;    // TROYN_MRR=calls: composes the three public calls (A/B testing)
-    if (!mrr_fast_path(p, L) || unfused || batch * (size_t)(L + 1) * 4 > 0x7fffffffull) {
+    // (a few ciphertexts of a chain with moduli >= 2^50: the three calls, whose key switch then takes the two-launch inner product -- ks_small_mixed)
+    if (!mrr_fast_path(p, L) || unfused || ks_small_mixed(p, L, batch) || batch * (size_t)(L + 1) * 4 > 0x7fffffffull) {
         // Evaluator::multiply (evaluator.cu:118-145) -> relinearize (evaluator_keyswitching.cu:119-144) -> rescale_to_next
         if ((rc = launch_convolute(p->d_mods, n, 0, L, a, 2, b, 2, ws + w.prod3, batch, s))) return rc;
         const size_t sub_bytes = (w.total - w.sub) * sizeof(u64);
