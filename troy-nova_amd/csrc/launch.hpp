@@ -26,9 +26,13 @@ struct LaunchCtx {
 TROYN_DECL_NTT_UNIT(f64_small) TROYN_DECL_NTT_UNIT(f64_large) TROYN_DECL_NTT_UNIT(u64_small) TROYN_DECL_NTT_UNIT(u64_large)
 #undef TROYN_DECL_NTT_UNIT
 void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t limb_polys, const LaunchCtx& lc);
-// single objects through the fused chain at N = 16384 (troyn_mrr_small.hip): one pass of a two-pass transform, and the strided passes of the
+// single objects through the fused chain at N = 8192 / 16384 (troyn_mrr_small.hip): one pass of a two-pass transform, and the strided passes of the
 // chain's tail (special rows, dropped limb, output limbs) as one launch
 void launch_ntt_f64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+void launch_ntt_f64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+inline void launch_ntt_f64_small_pass(unsigned log_n, int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (log_n == 13) launch_ntt_f64_pass13(which, a, limb_polys, lc); else launch_ntt_f64_pass14(which, a, limb_polys, lc);
+}
 void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s, bool limb_parallel);
 void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s);
 inline bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, const LaunchCtx& lc, u64* scratch) {

@@ -146,7 +146,11 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
         case 12: launch_single<A, 12, 3>(a, lp, inverse, lc); return true;
 #endif
 #if TROYN_NTT_SMALL
-        case 13: launch_single<A, 13, 3>(a, lp, inverse, lc); return true;
+        case 13:
+            // (the same for N = 8192: 4 workgroups of 2048 words per limb and pass)
+            if (lp * 8 <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 13, 11, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
+            else launch_single<A, 13, 3>(a, lp, inverse, lc);
+            return true;
 #endif
 #if TROYN_NTT_LARGE
         case 14:

@@ -871,7 +871,7 @@ static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsi
 // in three launches instead of four -- first inverse pass, mrr_quartet_load_kernel (last inverse layers + loader + first forward layers on the
 // shared quartets, troyn_mrr_small.hip), last forward pass with the epilogue of `fw`.  pa: the first inverse pass (in -> out); iv.in = pa.out.
 static bool small_tail_wanted(const troyn_plan* p, size_t limb_polys) {
-    return p->log_n == 14 && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * 8 <= device_cu_count();
+    return (p->log_n == 13 || p->log_n == 14) && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * 8 <= device_cu_count();
 }
 static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
     const LaunchCtx lc = launch_ctx(p, s);
@@ -880,7 +880,7 @@ static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, Ntt
         x.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
     };
     prep(pa, true);
-    launch_ntt_f64_pass14(0, pa, pa_limb_polys, lc);
+    launch_ntt_f64_small_pass(p->log_n, 0, pa, pa_limb_polys, lc);
     LAUNCH_CHECK();
     NttArgs iv = pa;
     iv.in = pa.out; iv.in_bstride = pa.out_bstride; iv.in_pstride = pa.out_pstride; iv.in_cstride = pa.out_cstride;
@@ -893,7 +893,7 @@ static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, Ntt
     NttArgs second = fw;
     second.in = first.out; second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
     second.reduce_input = 0;
-    launch_ntt_f64_pass14(1, second, groups * fw.ncomp, lc);
+    launch_ntt_f64_small_pass(p->log_n, 1, second, groups * fw.ncomp, lc);
     LAUNCH_CHECK();
     return TROYN_OK;
 }
@@ -1525,7 +1525,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
     // Single objects at N = 16384 (every launch of the tail in its two-pass form, FP64 policy): the three strided passes between the first
     // inverse pass of {limb L-1, special rows} and the last forward pass of the output limbs run as ONE launch with T_s and T_l in registers
     // (troyn_mrr_small.hip): 3 launches instead of 6.  TROYN_MRR_SMALL=0 keeps the six.
-    if (all_f64 && p->log_n == 14 && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && batch * 2 * (size_t)(L - 1) * 8 <= device_cu_count()) {
+    if (all_f64 && small_tail_wanted(p, batch * 2 * (size_t)(L - 1))) {
         const LaunchCtx lc = launch_ctx(p, s);
         auto prep = [&](NttArgs& x, bool inverse) {
             x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
@@ -1535,7 +1535,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         NttArgs pa = contiguous_args(p, ws + w.poly_prod + (size_t)(L - 1) * n, ws + w.poly_prod + (size_t)(L - 1) * n, 2, 2, L - 1, K - (L - 1), TROYN_IDX_KS_SKIP_FINALS, 1);
         pa.in_pstride = pa.out_pstride = pp_p; pa.in_bstride = pa.out_bstride = pp_b;
         prep(pa, true);
-        launch_ntt_f64_pass14(0, pa, batch * 4, lc);
+        launch_ntt_f64_small_pass(p->log_n, 0, pa, batch * 4, lc);
         LAUNCH_CHECK();
         NttArgs sp = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, nullptr, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         sp.in_pstride = pp_p; sp.in_bstride = pp_b;
@@ -1549,7 +1549,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         // last forward pass of the output limbs, in place in `out`, with step (5)'s epilogue
         ta.in = ta.out; ta.in_bstride = ta.out_bstride; ta.in_pstride = ta.out_pstride; ta.in_cstride = ta.out_cstride;
         ta.reduce_input = 0;
-        launch_ntt_f64_pass14(1, ta, batch * 2 * (L - 1), lc);
+        launch_ntt_f64_small_pass(p->log_n, 1, ta, batch * 2 * (L - 1), lc);
         LAUNCH_CHECK();
         return TROYN_OK;
     }

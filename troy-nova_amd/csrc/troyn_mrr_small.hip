@@ -1,4 +1,4 @@
-// troyn_mrr_small.hip -- single objects through the fused multiply -> relinearize -> rescale entry at N = 16384 (round 5).
+// troyn_mrr_small.hip -- single objects through the fused multiply -> relinearize -> rescale entry at N = 8192 / 16384 (round 5).
 //
 // A launch of a few limb-polynomials takes the two-pass form of the transforms (ntt_launch.inl: 4 workgroups per limb and pass instead of one
 // CU per 16384-point transform).  In that form the tail of the chain was six launches: special rows INTT (pass A, pass B) -> LAST_LIMB (A, B)
@@ -132,24 +132,37 @@ __global__ __launch_bounds__(256) void mrr_quartet_load_kernel(NttArgs iv, NttAr
 // iv: pass-A words of the row to invert (in, strides, table_start = its modulus, tw = inverse tables); fw: the forward launch's arguments with
 // out = where its pass B reads; groups = batch * fw.pcount
 void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s) {
-    if (log_n != 14) return;
-    const unsigned blocks = (unsigned)(groups * ((1u << 14) / 4) / 256);
+    if (log_n != 13 && log_n != 14) return;
+    const unsigned blocks = (unsigned)(groups * ((1u << log_n) / 4) / 256);
     NttArgs t = fw;
     t.xcd_groups = blocks;
-    if (fw.load_mode == NTT_LOAD_KS_ROUND) hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_KS_ROUND>), dim3(blocks * fw.ncomp), dim3(256), 0, s, iv, t);
-    else hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_RESCALE>), dim3(blocks * fw.ncomp), dim3(256), 0, s, iv, t);
+    const dim3 grid(blocks * fw.ncomp), block(256);
+    const bool ks = fw.load_mode == NTT_LOAD_KS_ROUND;
+    if (log_n == 14) {
+        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
+        else hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
+    } else {
+        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<13, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
+        else hipLaunchKernelGGL((mrr_quartet_load_kernel<13, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
+    }
 }
 
 // sp / la: the pass-A words of the special rows / of limb L - 1 (in, strides, table_start = their modulus, tw = inverse tables; la with the
 // constants of step (4)); ta: step (5)'s arguments (out = where pass B reads, tw = forward tables).  batch * 2 polynomials.
 void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s, bool limb_parallel) {
-    if (log_n != 14) return;
-    const unsigned blocks = (unsigned)(batch * 2 * ((1u << 14) / 4) / 256);
+    if (log_n != 13 && log_n != 14) return;
+    const unsigned blocks = (unsigned)(batch * 2 * ((1u << log_n) / 4) / 256);
     NttArgs t = ta;
     t.xcd_groups = blocks;        // (the field is free in this kernel: workgroups per output limb)
     const QuartetSpecial qs{sp.in, sp.in_bstride, sp.in_pstride, sp.table_start};
-    if (limb_parallel) hipLaunchKernelGGL((mrr_quartet_kernel<14, true>), dim3(blocks * ta.ncomp), dim3(256), 0, s, qs, la, t);
-    else hipLaunchKernelGGL((mrr_quartet_kernel<14, false>), dim3(blocks), dim3(256), 0, s, qs, la, t);
+    const dim3 grid(limb_parallel ? blocks * ta.ncomp : blocks), block(256);
+    if (log_n == 14) {
+        if (limb_parallel) hipLaunchKernelGGL((mrr_quartet_kernel<14, true>), grid, block, 0, s, qs, la, t);
+        else hipLaunchKernelGGL((mrr_quartet_kernel<14, false>), grid, block, 0, s, qs, la, t);
+    } else {
+        if (limb_parallel) hipLaunchKernelGGL((mrr_quartet_kernel<13, true>), grid, block, 0, s, qs, la, t);
+        else hipLaunchKernelGGL((mrr_quartet_kernel<13, false>), grid, block, 0, s, qs, la, t);
+    }
 }
 
 }  // namespace troyn

@@ -14,4 +14,10 @@ bool launch_tensor_f64_small(unsigned log_n, int stage, const NttArgs& a, const 
     return launch_tensor_class<ArithF64>(log_n, stage, a, b, d, batch, lc);
 }
 
+// single passes of the two-pass form of a small N = 8192 launch (see launch_ntt_f64_pass14)
+void launch_ntt_f64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (which == 0) launch_pass<ArithF64, 13, 2, 11, 11, TROYN_SMALL_EB, true, true, false>(a, limb_polys, lc);
+    else launch_pass<ArithF64, 13, 2, 11, 11, TROYN_SMALL_EB, false, false, true>(a, limb_polys, lc);
+}
+
 }  // namespace troyn
