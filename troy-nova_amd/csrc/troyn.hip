@@ -583,6 +583,9 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
     bool f64 = use_f64(p, a.table_start, a.table_count);
     if (!f64 && !force_integer_ntt(p) && p->log_n >= 10 && a.mode == TROYN_IDX_COMPONENTWISE && a.ncomp > 1 && a.ncomp <= a.table_count &&
         a.fused_mode == 0 && p->opt.ntt_split != 0 &&
+        // (a launch that cannot fill the chip is latency-bound: one integer launch beats two half-empty ones -- one ciphertext at N = 16384
+        // {60,50,50,50,50,60}: relinearize 102 -> 80 us, rescale 51 -> 40 us)
+        (p->opt.ntt_split == 1 || lp * 8 > device_cu_count()) &&
         ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || p->log_n >= 14 || p->opt.ntt_split == 1 ||
          (!p->opt.ntt_overlap_off && lp >= OVERLAP_MIN_LIMB_POLYS))) {
         // A component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
