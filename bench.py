@@ -508,8 +508,44 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         free_b, total_b = torch.cuda.mem_get_info()
         other["cpp_api"] = run_cpp_api()
         other["cpp_api"]["device_memory_free_before_GB"] = round(free_b / 2**30, 1)
+        other["single_object_latency_us"] = single_object_latency(torch, pkg, device)
         result["other_configs"] = other
     return result
+
+
+def single_object_latency(torch, pkg, device):
+    """ONE ciphertext through the C-ABI (ctypes layer, a stream wait after every call -- what an unmodified single-object caller sees): the fused entry and
+    the three calls, for the reference bench tool's default chain (test/bench/he_operations.cu:22-24), its all-40-bit sibling and the headline chain with and
+    without 60-bit primes.  A launch that cannot fill the chip is latency-bound: two-pass transforms, merged strided passes (troyn_mrr_small.hip), the
+    two-launch inner product for chains with moduli >= 2^50."""
+    res = {"what": "microseconds per call, batch 1, 300 calls after 30 warm-up calls, torch.cuda.synchronize() after each", "shapes": []}
+    for n, bits, L in ((8192, [60, 40, 40, 60], 3), (8192, [40, 40, 40, 40], 3), (16384, [50] * 6, 5), (16384, [60, 50, 50, 50, 50, 60], 5)):
+        gen = torch.Generator(device=device).manual_seed(7)
+        q = pkg.capi.coeff_modulus_create(n, bits)
+        plan = pkg.Plan(device, n.bit_length() - 1, q)
+        x, y = uniform_residues(torch, (1, 2), q[:L], n, device, gen), uniform_residues(torch, (1, 2), q[:L], n, device, gen)
+        keys = [uniform_residues(torch, (2,), q, n, device, gen) for _ in range(L)]
+        out = torch.empty((1, 2, L - 1, n), dtype=torch.int64, device=device)
+        prod = torch.empty((1, 3, L, n), dtype=torch.int64, device=device)
+        rel = torch.empty((1, 2, L, n), dtype=torch.int64, device=device)
+
+        def lat(f, reps=300):
+            for _ in range(30):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+                torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / reps * 1e6, 1)
+        res["shapes"].append({"n": n, "chain_bits": bits, "L": L,
+                              "fused_mul_relin_rescale": lat(lambda: plan.ckks_multiply_relinearize_rescale(L, x, y, keys, out=out)),
+                              "multiply": lat(lambda: plan.dyadic_convolute(x, 2, y, 2, L, out=prod)),
+                              "relinearize": lat(lambda: plan.relinearize(L, prod, keys, out=rel, is_ckks=True, is_ntt_form=True)),
+                              "rescale": lat(lambda: plan.divide_and_round_q_last_ntt(L, rel, 2, out=out))})
+        del plan, x, y, keys, out, prod, rel
+    torch.cuda.empty_cache()
+    return res
 
 
 def extra_configs(torch, pkg, device):

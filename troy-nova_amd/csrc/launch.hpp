@@ -30,11 +30,16 @@ void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t l
 // chain's tail (special rows, dropped limb, output limbs) as one launch
 void launch_ntt_f64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
 void launch_ntt_f64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+void launch_ntt_u64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+void launch_ntt_u64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
 inline void launch_ntt_f64_small_pass(unsigned log_n, int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
     if (log_n == 13) launch_ntt_f64_pass13(which, a, limb_polys, lc); else launch_ntt_f64_pass14(which, a, limb_polys, lc);
 }
+inline void launch_ntt_u64_small_pass(unsigned log_n, int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (log_n == 13) launch_ntt_u64_pass13(which, a, limb_polys, lc); else launch_ntt_u64_pass14(which, a, limb_polys, lc);
+}
 void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s, bool limb_parallel);
-void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s);
+void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s, bool f64);
 inline bool launch_ntt_f64(unsigned log_n, const NttArgs& a, size_t lp, bool inverse, const LaunchCtx& lc, u64* scratch) {
     return log_n <= 13 ? launch_ntt_f64_small(log_n, a, lp, inverse, lc, scratch) : launch_ntt_f64_large(log_n, a, lp, inverse, lc, scratch);
 }

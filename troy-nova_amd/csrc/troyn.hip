@@ -876,14 +876,17 @@ static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsi
 static bool small_tail_wanted(const troyn_plan* p, size_t limb_polys) {
     return (p->log_n == 13 || p->log_n == 14) && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * 8 <= device_cu_count();
 }
-static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
+static int small_tail(const troyn_plan* p, bool f64, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
     const LaunchCtx lc = launch_ctx(p, s);
     auto prep = [&](NttArgs& x, bool inverse) {
         x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
-        x.tw = inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64;
+        x.tw = f64 ? (inverse ? (const void*)p->d_inv_f64 : (const void*)p->d_fwd_f64) : (inverse ? (const void*)p->d_inv : (const void*)p->d_fwd);
+    };
+    auto pass = [&](int which, const NttArgs& x, size_t lp) {
+        if (f64) launch_ntt_f64_small_pass(p->log_n, which, x, lp, lc); else launch_ntt_u64_small_pass(p->log_n, which, x, lp, lc);
     };
     prep(pa, true);
-    launch_ntt_f64_small_pass(p->log_n, 0, pa, pa_limb_polys, lc);
+    pass(0, pa, pa_limb_polys);
     LAUNCH_CHECK();
     NttArgs iv = pa;
     iv.in = pa.out; iv.in_bstride = pa.out_bstride; iv.in_pstride = pa.out_pstride; iv.in_cstride = pa.out_cstride;
@@ -891,12 +894,12 @@ static int small_tail(const troyn_plan* p, NttArgs pa, size_t pa_limb_polys, Ntt
     NttArgs first = fw;                 // the pass in between: [group][limb][N], contiguous (the layout launch_two_pass gives a scratch buffer)
     const long long N = (long long)p->n;
     first.out = between; first.out_cstride = N; first.out_pstride = (long long)fw.ncomp * N; first.out_bstride = (long long)fw.pcount * fw.ncomp * N;
-    launch_mrr_quartet_load(p->log_n, groups, iv, first, s);
+    launch_mrr_quartet_load(p->log_n, groups, iv, first, s, f64);
     LAUNCH_CHECK();
     NttArgs second = fw;
     second.in = first.out; second.in_bstride = first.out_bstride; second.in_pstride = first.out_pstride; second.in_cstride = first.out_cstride;
     second.reduce_input = 0;
-    launch_ntt_f64_small_pass(p->log_n, 1, second, groups * fw.ncomp, lc);
+    pass(1, second, groups * fw.ncomp);
     LAUNCH_CHECK();
     return TROYN_OK;
 }
@@ -1159,13 +1162,14 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         a.inv_table = p->d_inv_last + (size_t)K * K;
         return a;
     };
-    if (fused && use_f64(p, 0, L) && use_f64(p, K - 1, 1) && small_tail_wanted(p, batch * 2 * L)) {
+    if (fused && small_tail_wanted(p, batch * 2 * L)) {
+        const bool tail_f64 = use_f64(p, 0, L) && use_f64(p, K - 1, 1);      // else both transforms on the integer kernels (small launches are not split by class)
         // a few ciphertexts at N = 16384: first inverse pass of the special rows in place (nothing else reads them), then the strided passes of both
         // transforms as one launch (small_tail)
         NttArgs pa = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.poly_prod + (size_t)L * n, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
         pa.in_pstride = pa.out_pstride = (long long)(L + 1) * n;
         pa.in_bstride = pa.out_bstride = 2ll * (L + 1) * n;
-        return small_tail(p, pa, batch * 2, fused_tail_args(ws + w.prod_intt), ws + w.temp_last, batch * 2, s);
+        return small_tail(p, tail_f64, pa, batch * 2, fused_tail_args(ws + w.prod_intt), ws + w.temp_last, batch * 2, s);
     }
     if (is_ntt_form) {
         NttArgs a = contiguous_args(p, ws + w.poly_prod + (size_t)L * n, ws + w.prod_intt, 2, 1, K - 1, 1, TROYN_IDX_COMPONENTWISE, 0);
@@ -1317,7 +1321,7 @@ extern "C" int troyn_divide_and_round_q_last_ntt(const troyn_plan* p, uint32_t L
     fw.ext0 = (const u64*)in; fw.ext0_bstride = (long long)L * n; fw.ext0_pstride = 0; fw.ext0_cstride = n;
     fw.inv_table = p->d_inv_last + (size_t)L * p->K;
     // a few ciphertexts at N = 16384: three launches instead of four (small_tail; the pass in between lives in `out`, as in the two-pass form)
-    if (use_f64(p, 0, L) && small_tail_wanted(p, items * (L - 1))) return small_tail(p, li, items, fw, (u64*)out, items, s);
+    if (small_tail_wanted(p, items * (L - 1))) return small_tail(p, use_f64(p, 0, L), li, items, fw, (u64*)out, items, s);
     if ((rc = launch_ntt(p, li, items, true, s))) return rc;
     if (p->log_n >= 10) return launch_ntt(p, fw, items, false, s);
     const unsigned ch = chunks_pairs(p->n);

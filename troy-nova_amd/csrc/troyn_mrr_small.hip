@@ -89,37 +89,45 @@ __global__ __launch_bounds__(256) void mrr_quartet_kernel(QuartetSpecial qs, Ntt
 // INTT of one row (special prime / dropped limb; passes A, B) -> forward transform of the data limbs whose loader forms the rounding fix from that
 // row (ski_util6_merged :570-598 / divide_and_round_q_last_ntt step 1, utils/rns_tool.cu:523-550; passes A, B).  Pass B of the inverse and pass A of
 // the forward transform share their quartets: one launch, the coefficient-form row never reaches memory.  LM = NTT_LOAD_KS_ROUND / NTT_LOAD_RESCALE.
-template <int LOGN, int LM>
+template <class A, int LOGN, int LM>
 __global__ __launch_bounds__(256) void mrr_quartet_load_kernel(NttArgs iv, NttArgs fw) {
-    using A = ArithF64;
     constexpr unsigned N = 1u << LOGN, Q = N / 4;
-    typedef const double __attribute__((address_space(4)))* ctw;
+    typedef const typename A::tw_mem __attribute__((address_space(4)))* ctw;
     const unsigned gid = (blockIdx.x % fw.xcd_groups) * 256u + threadIdx.x, j = blockIdx.x / fw.xcd_groups;      // xcd_groups: workgroups per limb
     const unsigned i = gid % Q, g = gid / Q, k = g % fw.pcount, b = g / fw.pcount;
     u64 c[4];
     {
         const unsigned mi = iv.table_start;
-        const A::Mod md = A::make(iv.mods[mi]);
+        const typename A::Mod md = A::make(iv.mods[mi]);
         const u64* in = iv.in + (long long)b * iv.in_bstride + (long long)k * iv.in_pstride;
-        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(iv.tw) + (size_t)mi * N);
-        double v[4];
+        const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const typename A::tw_mem*>(iv.tw) + (size_t)mi * N);
+        typename A::elem v[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) v[kk] = A::load_mid(in[i + kk * Q], md);
         A::inv(v[0], v[1], A::tw_from_mem(tw[N - 3], md), md);
         A::inv(v[2], v[3], A::tw_from_mem(tw[N - 2], md), md);
-        A::inv_fold(v[0], v[2], md);
-        A::inv_fold(v[1], v[3], md);
+        if constexpr (A::FOLD_NINV) {
+            A::inv_fold(v[0], v[2], md);
+            A::inv_fold(v[1], v[3], md);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) c[kk] = kk >= 2 ? A::final_fwd(v[kk], md) : A::final_inv(v[kk], md);
+            for (int kk = 0; kk < 4; ++kk) c[kk] = kk >= 2 ? A::final_fwd(v[kk], md) : A::final_inv(v[kk], md);
+        } else {
+            // integer policy: the last layer is an ordinary butterfly and every output takes the (lazy) N^-1 multiply, as ntt_pass_body stores it
+            const typename A::tw_t w0 = A::tw_from_mem(tw[N - 1], md);
+            A::inv(v[0], v[2], w0, md);
+            A::inv(v[1], v[3], w0, md);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c[kk] = A::final_inv(v[kk], md);
+        }
     }
     const unsigned mi = ntt_table_index(fw, k, j);
-    const A::Mod md = A::make(fw.mods[mi]);
+    const typename A::Mod md = A::make(fw.mods[mi]);
     const NttIo io = ntt_io_make(fw, b, k, j, mi, nullptr);
-    const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const double*>(fw.tw) + (size_t)mi * N);
-    double y[4];
+    const ctw tw = (ctw)(unsigned long long)(reinterpret_cast<const typename A::tw_mem*>(fw.tw) + (size_t)mi * N);
+    typename A::elem y[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) y[kk] = A::template load_io<LM>(io, c[kk], false, md);
-    const A::tw_t w1 = A::tw_from_mem(tw[1], md);
+    for (int kk = 0; kk < 4; ++kk) y[kk] = A::template load_io<LM>(io, c[kk], fw.reduce_input != 0, md);
+    const typename A::tw_t w1 = A::tw_from_mem(tw[1], md);
     A::fwd(y[0], y[2], w1, md);
     A::fwd(y[1], y[3], w1, md);
     A::fwd(y[0], y[1], A::tw_from_mem(tw[2], md), md);
@@ -130,21 +138,26 @@ __global__ __launch_bounds__(256) void mrr_quartet_load_kernel(NttArgs iv, NttAr
 }
 
 // iv: pass-A words of the row to invert (in, strides, table_start = its modulus, tw = inverse tables); fw: the forward launch's arguments with
-// out = where its pass B reads; groups = batch * fw.pcount
-void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s) {
+// out = where its pass B reads; groups = batch * fw.pcount; f64: the arithmetic policy of BOTH transforms (one class per small launch)
+template <class A>
+static void launch_quartet_load_t(unsigned log_n, const dim3 grid, const NttArgs& iv, const NttArgs& t, hipStream_t s) {
+    const dim3 block(256);
+    const bool ks = t.load_mode == NTT_LOAD_KS_ROUND;
+    if (log_n == 14) {
+        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<A, 14, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
+        else hipLaunchKernelGGL((mrr_quartet_load_kernel<A, 14, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
+    } else {
+        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<A, 13, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
+        else hipLaunchKernelGGL((mrr_quartet_load_kernel<A, 13, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
+    }
+}
+void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s, bool f64) {
     if (log_n != 13 && log_n != 14) return;
     const unsigned blocks = (unsigned)(groups * ((1u << log_n) / 4) / 256);
     NttArgs t = fw;
     t.xcd_groups = blocks;
-    const dim3 grid(blocks * fw.ncomp), block(256);
-    const bool ks = fw.load_mode == NTT_LOAD_KS_ROUND;
-    if (log_n == 14) {
-        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
-        else hipLaunchKernelGGL((mrr_quartet_load_kernel<14, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
-    } else {
-        if (ks) hipLaunchKernelGGL((mrr_quartet_load_kernel<13, NTT_LOAD_KS_ROUND>), grid, block, 0, s, iv, t);
-        else hipLaunchKernelGGL((mrr_quartet_load_kernel<13, NTT_LOAD_RESCALE>), grid, block, 0, s, iv, t);
-    }
+    if (f64) launch_quartet_load_t<ArithF64>(log_n, dim3(blocks * fw.ncomp), iv, t, s);
+    else launch_quartet_load_t<ArithU64>(log_n, dim3(blocks * fw.ncomp), iv, t, s);
 }
 
 // sp / la: the pass-A words of the special rows / of limb L - 1 (in, strides, table_start = their modulus, tw = inverse tables; la with the

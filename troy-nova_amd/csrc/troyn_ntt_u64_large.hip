@@ -14,4 +14,10 @@ bool launch_tensor_u64_large(unsigned log_n, int stage, const NttArgs& a, const 
     return launch_tensor_class<ArithU64>(log_n, stage, a, b, d, batch, lc);
 }
 
+// single passes of the two-pass form of a small N = 16384 launch under the integer policy (see launch_ntt_f64_pass14)
+void launch_ntt_u64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (which == 0) launch_pass<ArithU64, 14, 2, 12, 12, TROYN_SMALL_EB, true, true, false>(a, limb_polys, lc);
+    else launch_pass<ArithU64, 14, 2, 12, 12, TROYN_SMALL_EB, false, false, true>(a, limb_polys, lc);
+}
+
 }  // namespace troyn

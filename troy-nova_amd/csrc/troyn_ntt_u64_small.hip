@@ -18,4 +18,10 @@ void launch_ntt_generic(const NttArgs& a, unsigned log_n, bool inverse, size_t l
     hipLaunchKernelGGL(ntt_generic_kernel, dim3((unsigned)limb_polys), dim3(256), 0, lc.s, a, log_n, inverse ? 1 : 0);
 }
 
+// single passes of the two-pass form of a small N = 8192 launch under the integer policy (see launch_ntt_f64_pass14)
+void launch_ntt_u64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (which == 0) launch_pass<ArithU64, 13, 2, 11, 11, TROYN_SMALL_EB, true, true, false>(a, limb_polys, lc);
+    else launch_pass<ArithU64, 13, 2, 11, 11, TROYN_SMALL_EB, false, false, true>(a, limb_polys, lc);
+}
+
 }  // namespace troyn
