@@ -14,8 +14,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SEED = 20261003
-CASES = 1000
+SEED = int(os.environ.get("SWEEP_SEED", "20261003"))      # (another seed / more cases for a longer soak: SWEEP_SEED=7 SWEEP_CASES=5000)
+CASES = int(os.environ.get("SWEEP_CASES", "1000"))
 BATCHES = (1, 2, 3, 5, 8, 12, 24, 64)
 OPS = ("switch_key", "relinearize", "rescale", "mod_switch", "bfv_multiply", "fused_chain", "plain_mac")
 SWITCHES = {
