@@ -34,13 +34,17 @@ def dev():
     return "cuda:0"
 
 
-@pytest.fixture(params=["v2", "v2-refbase", "v1"])
+@pytest.fixture(params=["v2", "v2-refbase", "v1", "v2-small"])
 def behz_gen(request, monkeypatch):
     """both generations of the BEHZ conversion kernels (csrc/behz2_kernels.hpp, csrc/behz_kernels.hpp; TROYN_BEHZ, read when the plan is created) and, for the
     second generation, both auxiliary bases: primes below 2^50 (the default since round 5 when every q_i is below 2^50: the multiply's transforms then all run on
-    the FP64 butterflies) and the reference's 61-bit base (TROYN_BEHZ_BASE=ref, read by troyn_behz_create)"""
-    monkeypatch.delenv("TROYN_BEHZ", raising=False)
-    monkeypatch.delenv("TROYN_BEHZ_BASE", raising=False)
+    the FP64 butterflies) and the reference's 61-bit base (TROYN_BEHZ_BASE=ref, read by troyn_behz_create).  The tests multiply a few ciphertexts, and at
+    the whole-limb sizes such a launch takes separate transform / dyadic launches by default (troyn_bfv_multiply); the first three parameters force
+    tensor_core_kernel (TROYN_BFV_TENSOR=fused), "v2-small" is the library's default."""
+    for k in ("TROYN_BEHZ", "TROYN_BEHZ_BASE", "TROYN_BFV_TENSOR"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param != "v2-small":
+        monkeypatch.setenv("TROYN_BFV_TENSOR", "fused")
     if request.param == "v1":
         monkeypatch.setenv("TROYN_BEHZ", "v1")
     elif request.param == "v2-refbase":

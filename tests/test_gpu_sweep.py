@@ -36,7 +36,7 @@ SWITCHES = {
     "TROYN_MRR_SMALL": ("0",),
     "TROYN_MRR_CHUNK": ("8", "16"),
     "TROYN_MRR_STREAMS": ("1", "3"),
-    "TROYN_BFV_TENSOR": ("split",),
+    "TROYN_BFV_TENSOR": ("split", "fused"),
     "TROYN_TENSOR_WGS": ("2", "3"),
     "TROYN_BEHZ": ("v1",),
     "TROYN_BEHZ_LIFT": ("split",),

@@ -218,6 +218,7 @@ struct TroynOptions {
     bool ntt_u64 = false;            // TROYN_NTT_ARITH=u64: integer butterflies (and the integer inner product) for every modulus
     int ntt_split = -1;              // TROYN_NTT_SPLIT=0|1: launches over limbs of both classes as one integer launch / always split by class
     bool tensor_split = false;       // TROYN_BFV_TENSOR=split: separate transform and dyadic launches in the BFV multiply
+    bool tensor_fused = false;       // TROYN_BFV_TENSOR=fused: tensor_core_kernel also for launches of a few ciphertexts (whole-limb sizes, see troyn_bfv_multiply)
     int ks_order = -1;               // TROYN_KS_ORDER=plain|item|row|band (0..3): workgroup order of the inner product kernels
     int ks_split = -1;               // TROYN_KS_SPLIT=0|1: digit-parallel inner product off / forced on
     bool ks_tail_split = false;      // TROYN_KS_TAIL=split: coefficient-form tail as separate launches
@@ -251,7 +252,7 @@ static bool option_apply(TroynOptions& o, const char* name, const char* value) {
     auto num = [&](int dflt) { return v.empty() ? dflt : (int)strtol(v.c_str(), nullptr, 0); };
     if (n == "TROYN_NTT_ARITH") o.ntt_u64 = v == "u64";
     else if (n == "TROYN_NTT_SPLIT") o.ntt_split = v == "0" ? 0 : v == "1" ? 1 : d.ntt_split;
-    else if (n == "TROYN_BFV_TENSOR") o.tensor_split = v == "split";
+    else if (n == "TROYN_BFV_TENSOR") { o.tensor_split = v == "split"; o.tensor_fused = v == "fused"; }
     else if (n == "TROYN_KS_ORDER") o.ks_order = v == "plain" ? 0 : v == "item" ? 1 : v == "row" ? 2 : v == "band" ? 3 : d.ks_order;
     else if (n == "TROYN_KS_SPLIT") o.ks_split = v.empty() ? d.ks_split : num(-1);
     else if (n == "TROYN_KS_TAIL") o.ks_tail_split = v == "split";
@@ -2167,7 +2168,12 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     const bool gen2 = behz2_enabled(b);
     // 2 x 2 components at a two-pass size: the forward transforms stop after their first pass, tensor_core_kernel finishes them, forms the
     // product and starts the inverse transforms
-    const int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
+    int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
+    // Whole-limb sizes, a few ciphertexts: tensor_core_kernel puts seven transforms of a limb on ONE workgroup (L + S workgroups per item) -- a launch
+    // that cannot fill the chip is one long chain (one product at N = 16384 6 x 50-bit: 240 us).  The separate launches (two-pass transforms of many
+    // small workgroups, dyadic product) finish in 92 us; equal at ~256 workgroups of the fused form, where this rule hands over (N = 8192 {60,40,40,60}:
+    // 245 -> 78 us for one product, equal at 64).  TROYN_BFV_TENSOR=fused / split force either.
+    if (tkind == 1 && !pq->opt.tensor_fused && batch * (size_t)(L + S) <= 256) tkind = 0;
     const bool tensor = tkind != 0, whole = tkind == 1;
     // N = 32768 under the FP64 policy: first pass of base q, lift and first pass of the lifted rows as one launch, and the last inverse pass of
     // both bases inside the floor launch (behz2_lift_pass1.hpp)
