@@ -6,14 +6,20 @@ before they create their plan, so one process runs both sides; results must stay
                             the first-generation kernel's N >= 8192 instantiations left the library)
   TROYN_KS_ORDER=row        row-major workgroup order of ksmac2_kernel (default: band / item)
   TROYN_KS_DIAG=loop        the diagonal digit of an NTT-form key switch as an iteration of ksmac2's digit loop (default: in its epilogue)
-  TROYN_NTT_SMALL_TWO_PASS=0  N = 16384 launches of a few limbs keep the whole-limb tile (default: the two-pass form of the larger rings, 4 workgroups per limb)
+  TROYN_NTT_SMALL_TWO_PASS=0  N = 8192 / 16384 launches of a few limbs keep the whole-limb tile (default: the two-pass form of the larger rings, 4 workgroups per limb)
   TROYN_KS_MAC_SHOUP=0      integer inner product with Barrett-128 terms (default: the keys' Shoup quotients are prepared once per call, lazy Shoup terms)
   TROYN_KS_SPLIT=0 | 1      digit-parallel form of the inner product (one workgroup per digit + a reducer) off / forced on (default: on when the
                             launch would occupy at most half of the chip -- the batches of 8 used below take it, so "0" is the other side here)
   TROYN_MRR=calls           the fused multiply -> relinearize -> rescale entry composes the three public calls
   TROYN_NTT_HALF=<mask>     half-word LDS tiles per kernel variant of the whole-limb N = 16384 FP64 transforms (default 0x0127)
   TROYN_NTT_ARITH=u64       integer butterflies for every modulus
-(TROYN_BEHZ, TROYN_KS_TAIL, TROYN_BFV_TENSOR, TROYN_TENSOR_WGS, TROYN_PLAIN_MAC are covered by parametrised tests next to their kernels.)"""
+  TROYN_KS_MAC=fused        a few ciphertexts of a chain with moduli >= 2^50 keep the one-launch inner product (default: two launches below 256 workgroups;
+                            tests/test_gpu_wide_rows.py runs every test in both forms)
+  TROYN_MRR_SMALL=0 | serial  single objects at N = 8192 / 16384: unmerged tails / one thread per quartet (tests/test_gpu_keyswitch.py::test_fused_chain_single_objects)
+  TROYN_BEHZ_LIFT=split     N = 32768 BFV multiply: lift and floor apart from the strided transform passes (test_bfv_multiply_lift_with_first_pass)
+  TROYN_BFV_TENSOR=fused    tensor_core_kernel also for a few ciphertexts at the whole-limb sizes (the behz_gen fixture forces it for three of its four parameters)
+(TROYN_BEHZ, TROYN_KS_TAIL, TROYN_BFV_TENSOR, TROYN_TENSOR_WGS, TROYN_PLAIN_MAC are covered by parametrised tests next to their kernels; the sweep draws
+random sets of all of them.)"""
 import numpy as np
 import pytest
 
