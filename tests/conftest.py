@@ -50,3 +50,23 @@ def behz_gen(request, monkeypatch):
     elif request.param == "v2-refbase":
         monkeypatch.setenv("TROYN_BEHZ_BASE", "ref")
     return request.param
+
+# Key-switch tests on a few ciphertexts: below 128 (N <= 4096) / 256 (chains with moduli >= 2^50, N >= 8192) workgroups of the one-launch inner product the
+# library takes the two-launch form by itself (csrc/troyn.hip ks_small_mixed).  The modules below were written against the one-launch kernels, so each of
+# their tests runs twice: TROYN_KS_MAC=fused (read when the plan is created) and the library's default.
+KS_FORM_MODULES = {"test_gpu_keyswitch", "test_gpu_keyswitch_spec", "test_gpu_corners", "test_gpu_bgv"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in KS_FORM_MODULES and "ks_form" in metafunc.fixturenames:
+        metafunc.parametrize("ks_form", ["one-launch", "default"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def ks_form(request, monkeypatch):
+    form = getattr(request, "param", None)
+    if form == "one-launch":
+        monkeypatch.setenv("TROYN_KS_MAC", "fused")
+    elif form == "default":
+        monkeypatch.delenv("TROYN_KS_MAC", raising=False)
+    return form

@@ -910,8 +910,12 @@ static int small_tail(const troyn_plan* p, bool f64, NttArgs pa, size_t pa_limb_
 // N = 16384 {60,50,50,50,50,60}: 148 us of inner product).  The two-launch form -- (L + 1) L digit transforms, then the multiply-accumulate -- spreads
 // the same work over L times the workgroups: relinearize of one ciphertext 214 -> 84 us (N = 16384), 140 -> 78 us (N = 8192 {60,40,40,60}); equal at
 // 256 workgroups of the one-launch form (N = 16384: 32 items; N = 8192: ~100), which is where this rule hands over.  TROYN_KS_MAC=fused / split force either.
+// The first-generation kernel of N = 1024 .. 4096 (one workgroup per output row looping over the L digits, no digit-parallel form either) hands over
+// the same way below 128 workgroups: one ciphertext at N = 4096, relinearize 40 -> 31 us (4 x 36-bit), 59 -> 42 us ({50,55,50}).
 static bool ks_small_mixed(const troyn_plan* p, unsigned L, size_t batch) {
-    if (p->opt.ks_mac_fused || p->log_n < 13 || p->log_n > 15) return false;
+    if (p->opt.ks_mac_fused) return false;
+    if (p->log_n >= 10 && p->log_n <= 12) return batch * (size_t)(L + 1) <= 128;
+    if (p->log_n < 13 || p->log_n > 15) return false;
     if (use_f64(p, 0, L) && use_f64(p, p->K - 1, 1)) return false;
     return (batch * (size_t)(L + 1) << (p->log_n - 13)) <= 256;
 }
