@@ -2281,11 +2281,12 @@ extern "C" int troyn_prng_block(const uint64_t seed[2], uint64_t counter, uint64
 
 template <typename K>
 static int launch_sampler(K kernel, const char* who, const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter,
-                          uint64_t* out, size_t blocks, uint64_t* blocks_used, troyn_stream_t stream) {
+                          uint64_t* out, size_t blocks, uint64_t* blocks_used, troyn_stream_t stream, size_t threads = 0) {
     if (!p || !seed || !out) return fail(TROYN_E_INVALID, std::string(who) + " null argument");
     if (nmod == 0 || nmod > p->K) return fail(TROYN_E_INVALID, std::string(who) + " modulus count out of range");
     const AesRoundKeys k = aes128_expand(seed[0], seed[1]);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    if (!threads) threads = blocks;        // one thread per AES block unless the kernel says otherwise
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        k, (u64)counter, p->d_mods, (unsigned)nmod, p->n, (u64*)out);
     LAUNCH_CHECK();
     if (blocks_used) *blocks_used = blocks;
@@ -2296,7 +2297,7 @@ extern "C" int troyn_sample_ternary(const troyn_plan* p, uint32_t nmod, const ui
                                     uint64_t* blocks_used, troyn_stream_t stream) {
     select_device(p);
     return launch_sampler(sample_ternary_kernel, "[RandomGenerator::sample_poly_ternary]", p, nmod, seed, counter, out,
-                          p ? ((size_t)p->n + 15) / 16 : 0, blocks_used, stream);
+                          p ? ((size_t)p->n + 15) / 16 : 0, blocks_used, stream, p ? (size_t)p->n : 0);      // (a thread per coefficient)
 }
 extern "C" int troyn_sample_centered_binomial(const troyn_plan* p, uint32_t nmod, const uint64_t seed[2], uint64_t counter, uint64_t* out,
                                               uint64_t* blocks_used, troyn_stream_t stream) {
