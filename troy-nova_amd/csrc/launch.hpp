@@ -6,6 +6,11 @@
 #include "ksmac_kernels.hpp"
 #include "behz2_kernels.hpp"
 
+// a launch of at most CUs / TROYN_SMALL_LP_FACTOR limb-polynomials counts as small (two-pass transforms at N = 8192 / 16384, merged tails, no split by class)
+#ifndef TROYN_SMALL_LP_FACTOR
+#define TROYN_SMALL_LP_FACTOR 2      // measured 8 | 2 | 1: eight ciphertexts at N = 16384, fused chain 100 | 75 | 75 us; 128: 473 | 469 | 481
+#endif
+
 namespace troyn {
 
 // what a launch of the NTT family needs besides its arguments: the stream and the plan's A/B options that select kernel variants

@@ -148,7 +148,7 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
 #if TROYN_NTT_SMALL
         case 13:
             // (the same for N = 8192: 4 workgroups of 2048 words per limb and pass)
-            if (lp * 8 <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 13, 11, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
+            if (lp * TROYN_SMALL_LP_FACTOR <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 13, 11, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
             else launch_single<A, 13, 3>(a, lp, inverse, lc);
             return true;
 #endif
@@ -157,7 +157,7 @@ static bool launch_ntt_optimised(unsigned log_n, const NttArgs& a, size_t lp, bo
             // A whole-limb tile puts a 16384-point transform on ONE CU: 15-23 us however few limbs the launch has.  Launches that leave most
             // of the chip idle (a single ciphertext: 2-10 limb-polynomials) take the two-pass form of the larger rings instead -- 4 workgroups
             // per limb and pass, ~3x shorter; TROYN_NTT_SMALL_TWO_PASS=0 keeps the single pass (A/B runs, tests).  Results are the same words.
-            if (lp * 8 <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 14, 12, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
+            if (lp * TROYN_SMALL_LP_FACTOR <= ntt_cu_count() && !lc.small_two_pass_off) launch_two_pass<A, 14, 12, TROYN_SMALL_EB>(a, lp, inverse, lc, scratch);
             else launch_single<A, 14, 4>(a, lp, inverse, lc);
             return true;
 #endif

@@ -586,7 +586,7 @@ static int launch_ntt(const troyn_plan* p, NttArgs a, size_t batch, bool inverse
         a.fused_mode == 0 && p->opt.ntt_split != 0 &&
         // (a launch that cannot fill the chip is latency-bound: one integer launch beats two half-empty ones -- one ciphertext at N = 16384
         // {60,50,50,50,50,60}: relinearize 102 -> 80 us, rescale 51 -> 40 us)
-        (p->opt.ntt_split == 1 || lp * 8 > device_cu_count()) &&
+        (p->opt.ntt_split == 1 || lp * TROYN_SMALL_LP_FACTOR > device_cu_count()) &&
         ((a.load_mode == NTT_LOAD_PLAIN && a.store_mode == NTT_STORE_PLAIN && !two_pass_scratch) || p->log_n >= 14 || p->opt.ntt_split == 1 ||
          (!p->opt.ntt_overlap_off && lp >= OVERLAP_MIN_LIMB_POLYS))) {
         // A component-wise launch over limbs of both size classes ({60,40,40,60}: the reference's default chain): split it into
@@ -875,7 +875,7 @@ static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsi
 // in three launches instead of four -- first inverse pass, mrr_quartet_load_kernel (last inverse layers + loader + first forward layers on the
 // shared quartets, troyn_mrr_small.hip), last forward pass with the epilogue of `fw`.  pa: the first inverse pass (in -> out); iv.in = pa.out.
 static bool small_tail_wanted(const troyn_plan* p, size_t limb_polys) {
-    return (p->log_n == 13 || p->log_n == 14) && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * 8 <= device_cu_count();
+    return (p->log_n == 13 || p->log_n == 14) && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * TROYN_SMALL_LP_FACTOR <= device_cu_count();
 }
 static int small_tail(const troyn_plan* p, bool f64, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
     const LaunchCtx lc = launch_ctx(p, s);
