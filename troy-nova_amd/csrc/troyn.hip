@@ -2175,9 +2175,11 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     int tkind = (pa == 2 && pb == 2 && tensor_path_kind(pq, L) == tensor_path_kind(px, S)) ? tensor_path_kind(pq, L) : 0;
     // Whole-limb sizes, a few ciphertexts: tensor_core_kernel puts seven transforms of a limb on ONE workgroup (L + S workgroups per item) -- a launch
     // that cannot fill the chip is one long chain (one product at N = 16384 6 x 50-bit: 240 us).  The separate launches (two-pass transforms of many
-    // small workgroups, dyadic product) finish in 92 us; equal at ~256 workgroups of the fused form, where this rule hands over (N = 8192 {60,40,40,60}:
-    // 245 -> 78 us for one product, equal at 64).  TROYN_BFV_TENSOR=fused / split force either.
-    if (tkind == 1 && !pq->opt.tensor_fused && batch * (size_t)(L + S) <= 256) tkind = 0;
+    // small workgroups, dyadic product) finish in 92 us (N = 8192 {60,40,40,60}: 245 -> 78 us for one product).  TROYN_BFV_TENSOR=fused / split force either.
+    // (the hand-over point, measured: ~200 workgroups where tensor_core_kernel is at its best -- N <= 8192, FP64 policy -- and ~350 where it spills
+    // (N = 16384) or runs the integer butterflies)
+    const size_t tensor_small = (pq->log_n <= 13 && use_f64(pq, 0, L) && use_f64(px, 0, S)) ? 192 : 352;
+    if (tkind == 1 && !pq->opt.tensor_fused && batch * (size_t)(L + S) <= tensor_small) tkind = 0;
     const bool tensor = tkind != 0, whole = tkind == 1;
     // N = 32768 under the FP64 policy: first pass of base q, lift and first pass of the lifted rows as one launch, and the last inverse pass of
     // both bases inside the floor launch (behz2_lift_pass1.hpp)
