@@ -917,7 +917,7 @@ static bool ks_small_mixed(const troyn_plan* p, unsigned L, size_t batch) {
     if (p->log_n >= 10 && p->log_n <= 12) return batch * (size_t)(L + 1) <= 128;
     if (p->log_n < 13 || p->log_n > 15) return false;
     if (use_f64(p, 0, L) && use_f64(p, p->K - 1, 1)) return false;
-    return (batch * (size_t)(L + 1) << (p->log_n - 13)) <= 256;
+    return (batch * (size_t)(L + 1) << (p->log_n - 13)) <= (p->log_n == 13 ? 384u : 256u);      // (N = 8192: equal at ~400, 96 items of {60,40,40,60})
 }
 
 struct KsLayout {
