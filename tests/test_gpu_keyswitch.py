@@ -323,9 +323,10 @@ def test_ckks_multiply_relinearize_rescale_fused(O, pkg, dev, n, bits, L, batch)
 
 
 @pytest.mark.parametrize("n,bits,L,batch", [(16384, [50] * 6, 5, 1), (16384, [50] * 6, 5, 2), (16384, [50] * 6, 2, 1), (16384, [45, 49, 40, 50], 3, 3), (16384, [50] * 6, 4, 1),
-                                            (8192, [40] * 4, 3, 1), (8192, [50, 49, 40], 2, 2), (8192, [36] * 5, 4, 3)])
+                                            (8192, [40] * 4, 3, 1), (8192, [50, 49, 40], 2, 2), (8192, [36] * 5, 4, 3),
+                                            (32768, [50] * 6, 5, 1), (32768, [50, 45, 40], 2, 2)])
 def test_fused_chain_single_objects(O, pkg, dev, n, bits, L, batch):
-    """N = 8192 / 16384, a few ciphertexts: every launch of the chain's tail takes the two-pass form and its three strided passes (special rows, dropped limb
+    """N = 8192 / 16384 / 32768, a few ciphertexts: every launch of the chain's tail takes the two-pass form and its three strided passes (special rows, dropped limb
     with the key switch's rounding fix, output limbs with both fixes) run as ONE launch on the shared quartets (mrr_quartet_kernel; T_s and T_l stay in
     registers).  TROYN_MRR_SMALL=0 keeps the six launches.  Both equal the oracle's multiply -> relinearize -> rescale (evaluator_keyswitching_core.cu:570-658,
     utils/rns_tool.cu:523-627), below the top level as well; corner operands (all q - 1)."""

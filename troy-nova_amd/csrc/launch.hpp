@@ -37,11 +37,13 @@ void launch_ntt_f64_pass14(int which, const NttArgs& a, size_t limb_polys, const
 void launch_ntt_f64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
 void launch_ntt_u64_pass14(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
 void launch_ntt_u64_pass13(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+void launch_ntt_f64_pass15(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
+void launch_ntt_u64_pass15(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc);
 inline void launch_ntt_f64_small_pass(unsigned log_n, int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
-    if (log_n == 13) launch_ntt_f64_pass13(which, a, limb_polys, lc); else launch_ntt_f64_pass14(which, a, limb_polys, lc);
+    if (log_n == 13) launch_ntt_f64_pass13(which, a, limb_polys, lc); else if (log_n == 14) launch_ntt_f64_pass14(which, a, limb_polys, lc); else launch_ntt_f64_pass15(which, a, limb_polys, lc);
 }
 inline void launch_ntt_u64_small_pass(unsigned log_n, int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
-    if (log_n == 13) launch_ntt_u64_pass13(which, a, limb_polys, lc); else launch_ntt_u64_pass14(which, a, limb_polys, lc);
+    if (log_n == 13) launch_ntt_u64_pass13(which, a, limb_polys, lc); else if (log_n == 14) launch_ntt_u64_pass14(which, a, limb_polys, lc); else launch_ntt_u64_pass15(which, a, limb_polys, lc);
 }
 void launch_mrr_quartet(unsigned log_n, size_t batch, const NttArgs& sp, const NttArgs& la, const NttArgs& ta, hipStream_t s, bool limb_parallel);
 void launch_mrr_quartet_load(unsigned log_n, size_t groups, const NttArgs& iv, const NttArgs& fw, hipStream_t s, bool f64);

@@ -875,7 +875,8 @@ static size_t ks_split_words(const troyn_plan* p, size_t batch, unsigned L, unsi
 // in three launches instead of four -- first inverse pass, mrr_quartet_load_kernel (last inverse layers + loader + first forward layers on the
 // shared quartets, troyn_mrr_small.hip), last forward pass with the epilogue of `fw`.  pa: the first inverse pass (in -> out); iv.in = pa.out.
 static bool small_tail_wanted(const troyn_plan* p, size_t limb_polys) {
-    return (p->log_n == 13 || p->log_n == 14) && !p->opt.mrr_small_off && !p->opt.ntt_small_two_pass_off && limb_polys * TROYN_SMALL_LP_FACTOR <= device_cu_count();
+    // (N = 32768 transforms are two-pass at every size; the merged form is taken for the same small launches)
+    return p->log_n >= 13 && p->log_n <= 15 && !p->opt.mrr_small_off && (p->log_n == 15 || !p->opt.ntt_small_two_pass_off) && limb_polys * TROYN_SMALL_LP_FACTOR <= device_cu_count();
 }
 static int small_tail(const troyn_plan* p, bool f64, NttArgs pa, size_t pa_limb_polys, NttArgs fw, u64* between, size_t groups, hipStream_t s) {
     const LaunchCtx lc = launch_ctx(p, s);

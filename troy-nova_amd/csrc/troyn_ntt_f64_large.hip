@@ -21,4 +21,10 @@ void launch_ntt_f64_pass14(int which, const NttArgs& a, size_t limb_polys, const
     else launch_pass<ArithF64, 14, 2, 12, 12, TROYN_SMALL_EB, false, false, true>(a, limb_polys, lc);
 }
 
+// N = 32768: the two passes of launch_two_pass<A, 15, 12, 4> one at a time (troyn_mrr_small.hip runs the strided passes between them itself)
+void launch_ntt_f64_pass15(int which, const NttArgs& a, size_t limb_polys, const LaunchCtx& lc) {
+    if (which == 0) launch_pass<ArithF64, 15, 3, 12, 12, 4, true, true, false>(a, limb_polys, lc);
+    else launch_pass<ArithF64, 15, 3, 12, 12, 4, false, false, true>(a, limb_polys, lc);
+}
+
 }  // namespace troyn
