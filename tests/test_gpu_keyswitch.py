@@ -297,7 +297,8 @@ def test_error_behaviour(O, pkg, dev):
 
 
 @pytest.mark.parametrize("n,bits,L,batch", [(16384, [50] * 6, 5, 8), (16384, [50] * 6, 3, 3), (8192, [40, 40, 40, 40], 3, 8), (8192, [50] * 3, 2, 5),
-                                            (4096, [36] * 4, 3, 2), (32768, [50] * 4, 3, 2), (32768, [50] * 6, 5, 8), (8192, [55, 55, 56], 2, 2)])
+                                            (4096, [36] * 4, 3, 2), (32768, [50] * 4, 3, 2), (32768, [50] * 6, 5, 8), (8192, [55, 55, 56], 2, 2),
+                                            (32768, [50] * 4, 3, 40), (32768, [45] * 6, 5, 24)])      # (N = 32768 beyond the small launches: merged strided passes, one thread per octet)
 def test_ckks_multiply_relinearize_rescale_fused(O, pkg, dev, n, bits, L, batch):
     """the one-call chain equals the three public calls AND the oracle's multiply -> relinearize -> mod_switch_scale_to_next
     (fast path: N = 8192 / 16384 / 32768 with moduli < 2^50, also below the top level; the other shapes compose the three calls)"""

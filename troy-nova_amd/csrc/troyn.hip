@@ -1538,7 +1538,9 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
     // Single objects at N = 16384 (every launch of the tail in its two-pass form, FP64 policy): the three strided passes between the first
     // inverse pass of {limb L-1, special rows} and the last forward pass of the output limbs run as ONE launch with T_s and T_l in registers
     // (troyn_mrr_small.hip): 3 launches instead of 6.  TROYN_MRR_SMALL=0 keeps the six.
-    if (all_f64 && small_tail_wanted(p, batch * 2 * (size_t)(L - 1))) {
+    // N = 32768 (two-pass transforms at every size): the merged form at EVERY batch -- T_s and T_l never reach memory, three strided passes
+    // become one (one thread per octet loops over the output limbs when the launch is not small): fused chain 6 x 50-bit, 256 items 117.5 k -> 126 k ops/s
+    if (all_f64 && (small_tail_wanted(p, batch * 2 * (size_t)(L - 1)) || (p->log_n == 15 && !p->opt.mrr_small_off))) {
         const LaunchCtx lc = launch_ctx(p, s);
         auto prep = [&](NttArgs& x, bool inverse) {
             x.mods = p->d_mods; x.stream_loads = 1u; x.xcd_groups = 0u;
@@ -1557,7 +1559,7 @@ static int mrr_chain(const troyn_plan* p, uint32_t L, const u64* a, const u64* b
         prep(la, true);
         NttArgs ta = tail_args(0, L - 1);
         prep(ta, false);
-        launch_mrr_quartet(p->log_n, batch, sp, la, ta, s, !p->opt.mrr_small_serial);
+        launch_mrr_quartet(p->log_n, batch, sp, la, ta, s, !p->opt.mrr_small_serial && batch * 2 * (size_t)(L - 1) * TROYN_SMALL_LP_FACTOR <= device_cu_count());
         LAUNCH_CHECK();
         // last forward pass of the output limbs, in place in `out`, with step (5)'s epilogue
         ta.in = ta.out; ta.in_bstride = ta.out_bstride; ta.in_pstride = ta.out_pstride; ta.in_cstride = ta.out_cstride;
