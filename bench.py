@@ -139,6 +139,96 @@ def launch_ranks(n, poll_s=0.2):
     return 0
 
 
+# ------------------------------------------------------------------------------------------------------
+# Output: the driver parses ONE line -- the LAST line of stdout.  It is the headline and stays below HEADLINE_LIMIT bytes (numbers and short
+# names only; prose lives in DESIGN.md section 6).  Everything else the run measured is printed BEFORE it, one self-contained JSON line per block
+# ({"extra": "<name>", ...}), each below EXTRA_LIMIT bytes.  (Round 5 printed one 23 KB line; the driver could not parse it.)
+# ------------------------------------------------------------------------------------------------------
+HEADLINE_LIMIT = 6144
+EXTRA_LIMIT = 8192
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline", "parity")
+ROOFLINE_KEYS = ("bound", "limiter", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_record", "launch_ms", "launches_timed", "items_per_launch",
+                 "algorithmic_bytes_per_launch", "share_of_step")
+
+
+def _pack(tag, block, limit=EXTRA_LIMIT):
+    """one or more {"extra": tag, ...} dicts whose JSON stays below `limit`: top-level keys are packed greedily; a single value that is too large on its
+    own is descended into (dict) or dropped with a marker -- an extra line never endangers the headline"""
+    lines, cur = [], {"extra": tag}
+    for k, v in block.items():
+        piece = len(json.dumps({k: v})) + 2
+        if piece + len(json.dumps({"extra": tag})) >= limit:
+            if len(cur) > 1:
+                lines.append(cur)
+                cur = {"extra": tag}
+            if isinstance(v, dict):
+                lines.extend(_pack("%s.%s" % (tag, k), v, limit))
+            else:
+                lines.append({"extra": tag, k: "dropped: %d bytes" % piece})
+            continue
+        if len(json.dumps(cur)) + piece >= limit:
+            lines.append(cur)
+            cur = {"extra": tag, "continued": True}
+        cur[k] = v
+    if len(cur) > (2 if cur.get("continued") else 1):
+        lines.append(cur)
+    return lines
+
+
+def split_output(result):
+    """(extra lines, headline) of a run_* result.  The headline keeps HEADLINE_KEYS; of `roofline` the numeric fields, valu_fp64 as {frac, busy, record} and
+    floor as four numbers + the record's file name; every other block becomes an extra line."""
+    result = dict(result)
+    extras = []
+    other = result.pop("other_configs", None) or {}
+    roof = dict(result.get("roofline") or {})
+    head_roof = {k: roof.pop(k) for k in ROOFLINE_KEYS if k in roof}
+    vf = roof.get("valu_fp64")
+    if vf:
+        head_roof["valu_fp64"] = {"frac": vf.get("frac"), "lane_ops_per_launch": vf.get("lane_ops_per_launch"), "peak_lane_ops_per_s": vf.get("peak_lane_ops_per_s"),
+                                  "simd_valu_busy_profiled": vf.get("simd_valu_busy_profiled"), "record": vf.get("record")}
+    fl = roof.get("floor")
+    if fl:
+        head_roof["floor"] = {k: fl.get(k) for k in ("lane_ops_per_pass", "nominal_ms_per_pass_at_full_issue", "measured_ms_per_pass", "issue_frac_profiled", "record")}
+    if "pipeline" in roof:
+        head_roof["pipeline"] = roof.pop("pipeline")
+    if roof:
+        extras.extend(_pack("roofline_detail", roof))
+    head = {k: result.pop(k) for k in HEADLINE_KEYS if k in result}
+    head["roofline"] = head_roof
+    if result:                      # anything a run_* function added that is not a headline key
+        extras.extend(_pack("more", result))
+    small = {k: v for k, v in other.items() if k not in ("cfg4", "cfg5", "cpp_api", "single_object_latency_us")}
+    if small:
+        extras.extend(_pack("sizes", small))
+    for k in ("cfg4", "cfg5", "cpp_api", "single_object_latency_us"):
+        if k in other:
+            v = other[k]
+            if k == "cfg4":         # itself a bench result: same split, its headline becomes the block's first line
+                sub_extras, sub_head = split_output(v)
+                extras.extend(_pack("cfg4", sub_head))
+                for e in sub_extras:
+                    e["extra"] = "cfg4." + e["extra"]
+                    extras.append(e)
+            else:
+                extras.extend(_pack(k, v))
+    head["extras"] = sorted({e["extra"].split(".")[0] for e in extras})
+    return extras, head
+
+
+def emit(result, out=sys.stdout):
+    extras, head = split_output(result)
+    for e in extras:
+        out.write(json.dumps(e) + "\n")
+    line = json.dumps(head)
+    if len(line) >= HEADLINE_LIMIT:
+        raise RuntimeError("bench.py: the headline line is %d bytes (limit %d)" % (len(line), HEADLINE_LIMIT))
+    out.write(line + "\n")
+    out.flush()
+    return line
+
+
 def shard_plan(total, world):
     import __graft_entry__ as entry
     import importlib
@@ -348,26 +438,21 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         traffic = prof.get("traffic_bytes_per_launch")
         if prof.get("valu_lane_ops_per_launch"):
             rate = prof["valu_lane_ops_per_launch"] / (ks_launch_ms * 1e-3)
-            valu = {"what": "exact 50-bit modular arithmetic on the FP64 vector ALU (no MFMA); lane-operations per launch = SQ_INSTS_VALU x 64 of the "
-                            "PMC pass in `record`; peak = 256 CUs x 4 SIMDs x 16 FP64 lanes x 2.4 GHz (derived from the guide's chip table, it has no FP64 row)",
-                    "record": prof["_file"], "lane_ops_per_launch": prof["valu_lane_ops_per_launch"], "achieved_lane_ops_per_s": round(rate, 0),
+            valu = {"record": prof["_file"], "lane_ops_per_launch": prof["valu_lane_ops_per_launch"], "achieved_lane_ops_per_s": round(rate, 0),
                     "peak_lane_ops_per_s": FP64_VALU_PEAK, "frac": round(rate / FP64_VALU_PEAK, 4),
                     "simd_valu_busy_profiled": prof.get("simd_valu_busy"), "effective_clock_GHz_profiled": prof.get("effective_clock_GHz")}
-    roofline = {"bound": "valu_fp64" if valu else "hbm",
-                "bound_note": "what binds the kernel is FP64 vector issue (see valu_fp64); achieved / peak / frac are the contract's HBM figures: algorithmic bytes per "
-                              "launch / the launch duration measured in this run, against the 8 TB/s peak",
-                "kernel": "ksmac2_kernel<14> (fused key-switch inner product: digit NTTs + <digit, key> accumulation; in the fused chain its epilogue also "
-                          "divides by the special prime and adds the tensor terms c0, c1), "
-                          "largest share of the timed step (%.0f %% of its wall clock at the un-overlapped launch duration)"
-                          % (100.0 * ks_launch_ms * (B / items_per_launch) * inner * args.steps / (elapsed * 1e3)),
+    # `bound` / achieved / peak / frac are the contract's HBM figures (algorithmic bytes per launch / the launch duration measured in this run, against
+    # 8 TB/s); what limits the kernel is FP64 vector issue: `limiter` + valu_fp64 (DESIGN.md section 6 has the prose)
+    roofline = {"bound": "hbm", "limiter": "valu_fp64" if valu else None,
+                "kernel": "ksmac2_kernel<14,TEN> (fused key-switch inner product)" if fused else "ksmac2_kernel<14,DG> (key-switch inner product)",
+                "share_of_step": round(ks_launch_ms * (B / items_per_launch) * inner * args.steps / (elapsed * 1e3), 4),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_record": prof["_file"] if prof else None,
                 "launch_ms": round(ks_launch_ms, 4), "launches_timed": excl_n, "items_per_launch": items_per_launch,
-                "measured": "HIP events on the launch stream around every launch (library kernel timer), same run and buffers, chain on one stream"
-                            if items_per_launch != in_region_items else "HIP events on the launch stream around every launch of the timed region (library kernel timer)",
+                "measured": "library kernel timer: HIP events on the launch stream around every launch" + (" of the timed region" if items_per_launch == in_region_items else "; same run and buffers, chain on one stream"),
                 "in_region": None if items_per_launch == in_region_items else
                              {"launch_ms": round(in_region_ms, 4), "launches_timed": ks_n, "items_per_launch": in_region_items,
-                              "note": "TROYN_MRR_CHUNK set: chunks in flight on internal streams, a launch shares the chip with another chunk's kernels, its duration is not the kernel's own"},
+                              "note": "TROYN_MRR_CHUNK set: chunks in flight on internal streams, a launch shares the chip with another chunk's kernels"},
                 "algorithmic_bytes_per_launch": alg_bytes, "valu_fp64": valu,
                 # whole pipeline against the chip's HBM peak, both key accountings of SURVEY 8d (keys per op / keys once per batch)
                 "pipeline": {"bytes_per_op_keys_per_op": 18.0e6, "frac_keys_per_op": round(value / world * 18.0e6 / (HBM_PEAK_GBS * 1e9), 4),
@@ -379,16 +464,12 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     # variants of round 5 (profiles/r05_ksmac_variants.txt) moved its launch by < 1.5 %.
     cv = valu_record("bench_chain") if (rank == 0 and fused) else None
     roofline["floor"] = {
-        "what": "chain-wide vector-ALU issue: lane-operations of one pass over 1024 ciphertext pairs (SQ_INSTS_VALU x 64, every kernel of the chain) against the nominal "
-                "39.3 T lane-operations/s (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; the chip sustains ~2.15-2.25 GHz under this load), next to the pass's measured time",
         "record": cv["_file"] if cv else None,
         "lane_ops_per_pass": cv["per_pass"]["valu_lane_ops"] if cv else None,
         "nominal_ms_per_pass_at_full_issue": cv["per_pass"]["nominal_ms_at_full_issue"] if cv else None,
         "measured_ms_per_pass": round(elapsed / args.steps / inner * 1e3, 4),
         "issue_frac_profiled": cv["per_pass"]["issue_frac"] if cv else None,
         "kernels": [{k: r[k] for k in ("kernel", "avg_us", "time_share", "valu_lane_ops", "simd_valu_busy", "nominal_us_at_full_issue") if k in r} for r in cv["kernels"] if r.get("launches_per_pass", 1) > 0][:8] if cv else None,
-        "l2_ceiling": "a tile-step of the inner product moves 320 KB through the L1 (digits 64 KB, twiddles 128 KB, keys 128 KB): at 100 % FP64 issue that is 61 B/clk/CU against "
-                      "56 B/clk/CU of L2 bandwidth, so ~0.8 of the FP64 rate is the most this structure can reach (DESIGN.md section 4)",
         "experiments": ["profiles/r03_ksmac_ab.txt", "profiles/r04_ksmac_ab.txt", "profiles/r05_ksmac_variants.txt"]}
 
     # the reference's operator boundary: the same ops as three library calls (Evaluator::multiply / relinearize / rescale_to_next), same buffers
@@ -420,16 +501,11 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
         "metric": "homomorphic mul+relinearize ops/sec (CKKS mul+relin+rescale), N=16384",
         "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64 (q < 2^50: exact FP64-carried butterflies, canonical u64 residues at every call boundary)", "data": "synthetic",
-        "config": {"workload": "CKKS N=16384, 6x50-bit coeff modulus (K=6, L=5): multiply + relinearize + rescale_to_next, "
-                               "batch of %d independent ciphertext pairs per GPU, %d passes over the batch per step" % (B, inner),
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "CKKS N=16384, 6x50-bit coeff modulus (K=6, L=5): multiply + relinearize + rescale_to_next (BASELINE configs[2])",
                    "batch_per_gpu": B, "passes_per_step": inner, "ops_per_step": world * B * inner,
                    "entry": "troyn_ckks_multiply_relinearize_rescale" if fused else "troyn_dyadic_convolute + troyn_relinearize + troyn_divide_and_round_q_last_ntt",
                    "three_call_ops_per_s": three_call,
-                   "three_call_note": "the same ops through the reference's operator boundary -- troyn_dyadic_convolute + troyn_relinearize + "
-                                      "troyn_divide_and_round_q_last_ntt = Evaluator::multiply / relinearize / rescale_to_next -- on the same buffers, measured right "
-                                      "after the timed region; the fused entry is an addition to that boundary (troy::Evaluator::multiply_relinearize_rescale, "
-                                      "other_configs.cpp_api) with bit-identical results",
                    "parallelism": "batch-sharded x%d, keys broadcast once (RCCL)" % world,
                    # what the backend saw, per rank (a first multi-GPU run that goes wrong must be readable from this line alone)
                    **ranks},
@@ -745,9 +821,9 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     # SURVEY 8d bytes per op: multiply 18.4 MB (operands 2 x 5 MB read + product 7.5 MB written, rounded as the survey does) + relinearize 70.8 MB with
     # the keys per op, 13.1 MB with the keys once per launch
     per_gpu = value / world
-    roofline = {"bound": "valu_fp64" if dominant_is_ks else "valu_int",
-                "bound_note": "issue-bound arithmetic (FP64 butterflies in ksmac2 and tensor_core_kernel, integer multiply-accumulates in the base conversions); achieved / peak / "
-                              "frac are the contract's HBM figures for the dominant launch, timed in this run by the library's kernel timer",
+    # `bound` = the contract's HBM figures of the dominant launch, timed in this run by the library's kernel timer; `limiter` = what binds it (FP64 butterflies
+    # in ksmac2 / tensor_core_kernel, integer multiply-accumulates in the base conversions)
+    roofline = {"bound": "hbm", "limiter": "valu_fp64" if dominant_is_ks else "valu_int",
                 "kernel": "ksmac2_kernel<15>" if dominant_is_ks else "tensor_core_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
                 "algorithmic_bytes_per_launch": dom_alg, "kernels": kernels,
@@ -759,7 +835,7 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
         "metric": "homomorphic mul+relinearize ops/sec (BFV BEHZ multiply + relinearize), N=32768", "value": round(value, 1), "unit": "ops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u64 (every q_i and auxiliary prime < 2^50: exact FP64-carried butterflies; base conversions: integer multiply-accumulates)", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic",
         "config": {"workload": "BFV N=32768, 11x50-bit coeff modulus (K=11, L=10), t=1032193: %d independent multiply + relinearize ops per step, "
                                "block-partitioned over %d rank(s) (rank 0: items [%d, %d)), %d per launch" % (args.total, world, lo, hi, nb),
                    "total_ops_per_step": args.total, "operands": "%d distinct ciphertext pairs per rank resident in HBM" % mine,
@@ -1031,7 +1107,7 @@ def main():
     run = run_cfg3 if args.workload == "cfg3" else run_cfg4
     result = run(args, torch, pkg, shard, entry, rank, world, device)
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

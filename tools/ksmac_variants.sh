@@ -24,7 +24,7 @@ else
       if [ -n "$lib" ]; then export TROYN_LIB="$lib"; else unset TROYN_LIB; fi
       python bench.py --steps $STEPS --warmup 2 --no-extra --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); r=d['roofline']
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']   # the headline is the LAST line
 print('$name', 'ops/s', d['value'], 'ksmac_launch_ms', r.get('launch_ms'), 'frac', r['frac'])"
     done
   done
