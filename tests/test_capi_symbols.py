@@ -71,8 +71,9 @@ def test_switches_are_read_once_at_plan_creation():
             code = line.split("//")[0]
             if re.search(r"\bgetenv\s*\(", code):
                 hits.append((name, no, code.strip()))
-    assert len(hits) == 1 and hits[0][0] == "troyn.hip" and "option_apply" in hits[0][2], hits
+    assert len(hits) == 1 and hits[0][0] == "troyn.hip", hits
     text = open(os.path.join(csrc, "troyn.hip")).read()
-    body = text[text.index("static TroynOptions options_from_environment()"):]
-    assert hits[0][2] in body[:body.index("\n}\n")]
-    assert text.count("options_from_environment()") == 2      # the definition and troyn_plan_create
+    body = text[text.index("static int options_from_environment(TroynOptions& o)"):]
+    body = body[:body.index("\n}\n")]
+    assert hits[0][2] in body and "option_apply" in body
+    assert text.count("options_from_environment(") == 2      # the definition and troyn_plan_create

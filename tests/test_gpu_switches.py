@@ -297,3 +297,48 @@ def test_many_digits_never_take_the_digit_parallel_form(O, pkg, dev, monkeypatch
         got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=ntt_form, is_ntt_form=ntt_form))
         for i in range(2):
             assert np.array_equal(got[i], c.switch_key(L, ntt_form, tg[i], keys, assign=pkg.ASSIGN_OVERWRITE)), (ntt_form, i)
+
+
+def test_option_values_are_validated(O, pkg, dev, monkeypatch):
+    """a value an option does not have is an error (TROYN_TENSOR_WGS=foo used to parse as 0 and select the two-workgroup kernel; a misspelt word
+    silently meant "default").  None / "" stay the default; a bad value in the environment fails troyn_plan_create; a refused value changes nothing."""
+    for k in ("TROYN_KS_ORDER", "TROYN_TENSOR_WGS", "TROYN_KS_MAC"):
+        monkeypatch.delenv(k, raising=False)
+    n, L = 8192, 3
+    q, ctx, plan, keys, dkeys = _case(O, pkg, dev, n, [40, 40, 40, 40], L)
+    for name, bad in (("TROYN_TENSOR_WGS", "foo"), ("TROYN_TENSOR_WGS", "5"), ("TROYN_KS_ORDER", "definitely-not-an-order"), ("TROYN_KS_MAC", "v1"),
+                      ("TROYN_NTT_HALF", "0x1ffff"), ("TROYN_MRR_STREAMS", "9"), ("TROYN_NTT_ARITH", "u32"), ("TROYN_PLAIN_MAC", "triple"), ("TROYN_NTT_OVERLAP", "off")):
+        with pytest.raises(pkg.capi.TroynInvalidArgument):
+            plan.set_option(name, bad)
+    for name, good in (("TROYN_TENSOR_WGS", "3"), ("TROYN_TENSOR_WGS", None), ("TROYN_KS_ORDER", "row"), ("TROYN_KS_ORDER", ""), ("TROYN_NTT_HALF", "0x3f3f"),
+                       ("TROYN_NTT_HALF", None), ("TROYN_KS_MAC", "fused"), ("TROYN_KS_MAC", None)):
+        plan.set_option(name, good)
+    tg = np.stack([ctx.random_ct(5 + i, 1, L)[0] for i in range(2)])
+    got = pkg.to_host(plan.switch_key(L, pkg.to_device(tg, dev), dkeys, assign=pkg.ASSIGN_OVERWRITE, is_ckks=True, is_ntt_form=True))
+    assert np.array_equal(got[1], ctx.switch_key(L, True, tg[1], keys, assign=pkg.ASSIGN_OVERWRITE))
+    monkeypatch.setenv("TROYN_KS_ORDER", "definitely-not-an-order")
+    with pytest.raises(pkg.capi.TroynInvalidArgument):
+        pkg.Plan(dev, 13, q)
+
+
+def test_behz_follows_later_plan_options(O, pkg, dev, monkeypatch):
+    """troyn_behz_create snapshots the plan's options into the auxiliary plan; a later set_option on the plan must reach it (both bases of one
+    multiply on the same transform policies).  Observable: results stay the oracle's for switches set AFTER the handle was created, and the
+    integer policy forced afterwards gives the same words as a plan created with it."""
+    for k in ("TROYN_NTT_ARITH", "TROYN_BFV_TENSOR", "TROYN_NTT_HALF"):
+        monkeypatch.delenv(k, raising=False)
+    n, bits, L, t = 8192, [40, 40, 40], 2, 1032193
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, 13, q)
+    behz = pkg.Behz(plan, L, t)
+    a = np.stack([ctx.random_ct(31 + i, 2, L) for i in range(2)])
+    b = np.stack([ctx.random_ct(47 + i, 2, L) for i in range(2)])
+    want = [ctx.bfv_multiply(L, a[i], b[i]) for i in range(2)]
+    da, db = pkg.to_device(a, dev), pkg.to_device(b, dev)
+    for name, value in ((None, None), ("TROYN_NTT_ARITH", "u64"), ("TROYN_BFV_TENSOR", "fused"), ("TROYN_NTT_HALF", "0"), ("TROYN_NTT_ARITH", None)):
+        if name:
+            plan.set_option(name, value)
+        got = pkg.to_host(behz.multiply(da, 2, db, 2))
+        for i in range(2):
+            assert np.array_equal(got[i], want[i]), (name, value, i)

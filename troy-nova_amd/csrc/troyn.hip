@@ -245,47 +245,68 @@ struct TroynOptions {
 static const char* const TROYN_OPTION_NAMES[] = {"TROYN_NTT_ARITH", "TROYN_NTT_SPLIT", "TROYN_BFV_TENSOR", "TROYN_KS_ORDER", "TROYN_KS_SPLIT", "TROYN_KS_TAIL", "TROYN_KS_MAC",
     "TROYN_KS_DIAG", "TROYN_KS_ROWS", "TROYN_KS_MAC_SHOUP", "TROYN_MRR_MIXED", "TROYN_MRR_SMALL", "TROYN_MRR", "TROYN_MRR_CHUNK", "TROYN_MRR_STREAMS", "TROYN_BEHZ", "TROYN_BEHZ_BASE", "TROYN_BEHZ_LIFT",
     "TROYN_PLAIN_MAC", "TROYN_NTT_HALF", "TROYN_NTT_SMALL_TWO_PASS", "TROYN_TENSOR_WGS", "TROYN_NTT_OVERLAP"};
-// value == nullptr or "": the option's default.  false: unknown name.
-static bool option_apply(TroynOptions& o, const char* name, const char* value) {
+// value == nullptr or "": the option's default.  Returns 1 = applied, 0 = unknown name, -1 = a value this option does not have (nothing is changed:
+// a misspelt value must not silently select a variant -- TROYN_TENSOR_WGS=foo used to parse as 0 and pick the two-workgroup kernel).
+static int option_apply(TroynOptions& o, const char* name, const char* value) {
     const TroynOptions d;
     const std::string n = name ? name : "", v = value ? value : "";
-    auto num = [&](int dflt) { return v.empty() ? dflt : (int)strtol(v.c_str(), nullptr, 0); };
-    if (n == "TROYN_NTT_ARITH") o.ntt_u64 = v == "u64";
-    else if (n == "TROYN_NTT_SPLIT") o.ntt_split = v == "0" ? 0 : v == "1" ? 1 : d.ntt_split;
-    else if (n == "TROYN_BFV_TENSOR") { o.tensor_split = v == "split"; o.tensor_fused = v == "fused"; }
-    else if (n == "TROYN_KS_ORDER") o.ks_order = v == "plain" ? 0 : v == "item" ? 1 : v == "row" ? 2 : v == "band" ? 3 : d.ks_order;
-    else if (n == "TROYN_KS_SPLIT") o.ks_split = v.empty() ? d.ks_split : num(-1);
-    else if (n == "TROYN_KS_TAIL") o.ks_tail_split = v == "split";
-    else if (n == "TROYN_KS_MAC") { o.ks_mac_split = v == "split"; o.ks_mac_fused = v == "fused"; }
-    else if (n == "TROYN_KS_DIAG") o.ks_diag_loop = v == "loop";
-    else if (n == "TROYN_KS_ROWS") o.ks_rows = num(d.ks_rows);
-    else if (n == "TROYN_KS_MAC_SHOUP") o.ks_mac_shoup_off = v == "0";
-    else if (n == "TROYN_MRR_MIXED") o.mrr_mixed_off = v == "0";
-    else if (n == "TROYN_MRR_SMALL") { o.mrr_small_off = v == "0"; o.mrr_small_serial = v == "serial"; }
-    else if (n == "TROYN_MRR") o.mrr_calls = v == "calls";
-    else if (n == "TROYN_MRR_CHUNK") o.mrr_chunk = num(d.mrr_chunk);
-    else if (n == "TROYN_MRR_STREAMS") o.mrr_streams = num(d.mrr_streams);
-    else if (n == "TROYN_BEHZ") o.behz_v1 = v == "v1";
-    else if (n == "TROYN_BEHZ_BASE") o.behz_base_ref = v == "ref";
-    else if (n == "TROYN_BEHZ_LIFT") o.behz_lift_split = v == "split";
-    else if (n == "TROYN_PLAIN_MAC") o.plain_mac = v == "v1" ? 1 : v == "single" ? 2 : v == "dual" ? 3 : v == "quad" ? 4 : 0;
-    else if (n == "TROYN_NTT_HALF") o.ntt_half = v.empty() ? d.ntt_half : num(-1);
-    else if (n == "TROYN_NTT_SMALL_TWO_PASS") o.ntt_small_two_pass_off = v == "0";
-    else if (n == "TROYN_NTT_OVERLAP") o.ntt_overlap_off = v == "0";
-    else if (n == "TROYN_TENSOR_WGS") o.tensor_wgs = num(d.tensor_wgs);
-    else return false;
-    return true;
+    bool bad = false;
+    // one of the listed words (index), or the default for ""; anything else is invalid
+    auto word = [&](std::initializer_list<const char*> words, int dflt) {
+        if (v.empty()) return dflt;
+        int i = 0;
+        for (const char* w : words) { if (v == w) return i; i++; }
+        bad = true;
+        return dflt;
+    };
+    auto num = [&](long lo, long hi, int dflt) {
+        if (v.empty()) return dflt;
+        char* end = nullptr;
+        const long x = strtol(v.c_str(), &end, 0);
+        if (end == v.c_str() || *end || x < lo || x > hi) { bad = true; return dflt; }
+        return (int)x;
+    };
+    TroynOptions t = o;
+    if (n == "TROYN_NTT_ARITH") t.ntt_u64 = word({"auto", "u64"}, 0) == 1;
+    else if (n == "TROYN_NTT_SPLIT") t.ntt_split = num(0, 1, d.ntt_split);
+    else if (n == "TROYN_BFV_TENSOR") { const int w = word({"auto", "split", "fused"}, 0); t.tensor_split = w == 1; t.tensor_fused = w == 2; }
+    else if (n == "TROYN_KS_ORDER") t.ks_order = word({"plain", "item", "row", "band"}, d.ks_order);
+    else if (n == "TROYN_KS_SPLIT") t.ks_split = num(0, 1, d.ks_split);
+    else if (n == "TROYN_KS_TAIL") t.ks_tail_split = word({"fused", "split"}, 0) == 1;
+    else if (n == "TROYN_KS_MAC") { const int w = word({"auto", "split", "fused"}, 0); t.ks_mac_split = w == 1; t.ks_mac_fused = w == 2; }
+    else if (n == "TROYN_KS_DIAG") t.ks_diag_loop = word({"epilogue", "loop"}, 0) == 1;
+    else if (n == "TROYN_KS_ROWS") t.ks_rows = num(0, 64, d.ks_rows);
+    else if (n == "TROYN_KS_MAC_SHOUP") t.ks_mac_shoup_off = num(0, 1, 1) == 0;
+    else if (n == "TROYN_MRR_MIXED") t.mrr_mixed_off = num(0, 1, 1) == 0;
+    else if (n == "TROYN_MRR_SMALL") { const int w = word({"1", "0", "serial"}, 0); t.mrr_small_off = w == 1; t.mrr_small_serial = w == 2; }
+    else if (n == "TROYN_MRR") t.mrr_calls = word({"fused", "calls"}, 0) == 1;
+    else if (n == "TROYN_MRR_CHUNK") t.mrr_chunk = num(0, 1 << 20, d.mrr_chunk);
+    else if (n == "TROYN_MRR_STREAMS") t.mrr_streams = num(1, 4, d.mrr_streams);
+    else if (n == "TROYN_BEHZ") t.behz_v1 = word({"v2", "v1"}, 0) == 1;
+    else if (n == "TROYN_BEHZ_BASE") t.behz_base_ref = word({"small", "ref"}, 0) == 1;
+    else if (n == "TROYN_BEHZ_LIFT") t.behz_lift_split = word({"fused", "split"}, 0) == 1;
+    else if (n == "TROYN_PLAIN_MAC") t.plain_mac = word({"auto", "v1", "single", "dual", "quad"}, 0);
+    else if (n == "TROYN_NTT_HALF") t.ntt_half = num(0, 0xffff, d.ntt_half);
+    else if (n == "TROYN_NTT_SMALL_TWO_PASS") t.ntt_small_two_pass_off = num(0, 1, 1) == 0;
+    else if (n == "TROYN_NTT_OVERLAP") t.ntt_overlap_off = num(0, 1, 1) == 0;
+    else if (n == "TROYN_TENSOR_WGS") { t.tensor_wgs = num(2, 8, d.tensor_wgs); if (t.tensor_wgs != 8 && t.tensor_wgs != 3 && t.tensor_wgs != 2) bad = true; }
+    else return 0;
+    if (bad) return -1;
+    o = t;
+    return 1;
 }
-static TroynOptions options_from_environment() {      // the ONLY place the library reads its switches from the environment (troyn_plan_create)
-    TroynOptions o;
+// the ONLY place the library reads its switches from the environment (troyn_plan_create); a value an option does not have fails the creation
+static int options_from_environment(TroynOptions& o) {
     for (const char* name : TROYN_OPTION_NAMES)
-        if (const char* e = getenv(name)) option_apply(o, name, e);
-    return o;
+        if (const char* e = getenv(name))
+            if (option_apply(o, name, e) < 0) return fail(TROYN_E_INVALID, std::string("[troyn_plan_create] environment: ") + name + "=" + e + " is not a value of this option");
+    return TROYN_OK;
 }
 
 struct troyn_plan {
     int device = 0;
     TroynOptions opt;
+    std::atomic<uint64_t> opt_gen{0};     // bumped by troyn_plan_set_option: handles that own a second plan (troyn_behz: the auxiliary base) re-read `opt` when it moved
     unsigned log_n = 0, n = 0, K = 0;
     std::vector<u64> moduli;
     std::vector<host::NttTable> tables;   // host copies (KAT hooks, BEHZ construction)
@@ -446,7 +467,7 @@ extern "C" int troyn_plan_create(troyn_plan** plan, int device, uint32_t log_n, 
     if (n_moduli < 1 || n_moduli > 64) return fail(TROYN_E_INVALID, "[troyn_plan_create] Invalid coeff modulus count.");
     std::unique_ptr<troyn_plan, void (*)(troyn_plan*)> p(new troyn_plan, plan_free);
     p->device = device; p->log_n = log_n; p->n = 1u << log_n; p->K = n_moduli;
-    p->opt = options_from_environment();
+    { const int orc = options_from_environment(p->opt); if (orc != TROYN_OK) return orc; }
     p->moduli.assign(moduli, moduli + n_moduli);
     for (uint32_t i = 0; i < n_moduli; i++) {
         u64 q = moduli[i];
@@ -474,7 +495,10 @@ extern "C" int troyn_plan_destroy(troyn_plan* plan) {
 extern "C" int troyn_plan_set_option(troyn_plan* plan, const char* name, const char* value) {
     if (!plan || !name) return fail(TROYN_E_INVALID, "[troyn_plan_set_option] null argument");
     // (a handle created from this plan -- troyn_behz, troyn_bgv, ... -- reads the plan's options at call time; TROYN_BEHZ_BASE is read by troyn_behz_create)
-    if (!option_apply(plan->opt, name, value)) return fail(TROYN_E_INVALID, std::string("[troyn_plan_set_option] unknown option ") + name);
+    const int rc = option_apply(plan->opt, name, value);
+    if (rc == 0) return fail(TROYN_E_INVALID, std::string("[troyn_plan_set_option] unknown option ") + name);
+    if (rc < 0) return fail(TROYN_E_INVALID, std::string("[troyn_plan_set_option] ") + name + "=" + value + " is not a value of this option");
+    plan->opt_gen.fetch_add(1, std::memory_order_release);
     return TROYN_OK;
 }
 
@@ -509,21 +533,35 @@ static inline LaunchCtx launch_ctx(const troyn_plan* p, hipStream_t s) { return 
 // joined back to it before the call returns -- the caller still sees one stream order.  Only for launches large enough to fill the chip on their own
 // (a handful of workgroups gains nothing from a second queue and pays two event waits).  TROYN_NTT_OVERLAP=0: one run after the other.
 namespace {
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+// one side stream per host thread and device, created on first use and destroyed when the host thread ends (the reference tool's -c N mode spawns such
+// threads per run: round 5 leaked a stream and two events per thread).  Fixed slots: a pointer handed out stays valid while other devices are added.
+struct SideStreams {
+    static constexpr int MAX_DEVICES = 16;
+    SideStream slot[MAX_DEVICES];
+    ~SideStreams() {
+        for (SideStream& x : slot) {
+            if (!x.s) continue;
+            (void)hipEventDestroy(x.fork); (void)hipEventDestroy(x.join); (void)hipStreamDestroy(x.s);
+            (void)hipGetLastError();       // (a thread that ends while the runtime shuts down: nothing left to release)
+        }
+    }
+};
 SideStream* side_stream(int device) {
-    static thread_local std::vector<SideStream> pool;      // kept for the life of the host thread (the runtime reclaims them at exit)
-    for (auto& x : pool) if (x.device == device) return &x;
-    SideStream x;
-    x.device = device;
-    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+    static thread_local SideStreams pool;
+    if (device < 0 || device >= SideStreams::MAX_DEVICES) return nullptr;
+    SideStream& x = pool.slot[device];
+    if (x.s) return &x;
+    hipStream_t st = nullptr; hipEvent_t f = nullptr, j = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
-        if (x.fork) (void)hipEventDestroy(x.fork);
-        (void)hipStreamDestroy(x.s);
+        if (f) (void)hipEventDestroy(f);
+        (void)hipStreamDestroy(st);
         return nullptr;
     }
-    pool.push_back(x);
-    return &pool.back();
+    x.fork = f; x.join = j; x.s = st;      // published complete
+    return &x;
 }
 // runs 0, 2, 4, ... of a split launch go to the side stream, the others stay on the caller's; join() orders the caller's stream behind the side stream
 struct RunOverlap {
@@ -542,7 +580,9 @@ struct RunOverlap {
         if (!forked) return TROYN_OK;
         forked = false;
         if (hipEventRecord(ss->join, ss->s) == hipSuccess && hipStreamWaitEvent(main, ss->join, 0) == hipSuccess) return TROYN_OK;
-        (void)hipStreamSynchronize(ss->s);
+        (void)hipGetLastError();
+        const hipError_t e = hipStreamSynchronize(ss->s);      // fallback: the host waits for the side stream instead of the caller's stream
+        if (e != hipSuccess) return fail((int)e, std::string("[RunOverlap::join] ") + hipGetErrorString(e));
         return TROYN_OK;
     }
     ~RunOverlap() { (void)join(); }
@@ -1040,7 +1080,7 @@ static int switch_key_impl(const troyn_plan* p, unsigned L, int is_ckks, int is_
         // A chain with moduli of 2^50 and more (the reference's default {60,40,40,60}; {60,50,...,60} CKKS chains): the output rows of the
         // moduli below 2^50 take ksmac2_kernel (exact FP64 butterflies; digits of wider limbs are reduced while loading), the rows of the wide
         // moduli the integer kernel of the same shape (ksmaci_kernel, N = 8192 / 16384 / 32768; round 5).  Rows are independent; results are
-        // unchanged.  TROYN_NTT_ARITH=u64 sends every row to the integer kernel; N < 8192 and TROYN_KS_MAC=v1 keep the first-generation kernel.
+        // unchanged.  TROYN_NTT_ARITH=u64 sends every row to the integer kernel; N < 8192 keeps the first-generation kernel.
         unsigned long long small_rows = 0, wide_rows = 0;
         bool wide_digits = false;
         const bool all_integer = force_integer_ntt(p);
@@ -1870,7 +1910,20 @@ struct troyn_behz {
     const u64* d_q_to_gamma = nullptr;                 // [L]
     ulonglong2 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t;
     bool decrypt_ready = false;
+    // options of the auxiliary plan = the plan's (both bases of one multiply on the same transform policies); followed at call time (below)
+    mutable std::atomic<uint64_t> aux_gen{0};
+    mutable std::mutex aux_mutex;
 };
+// A troyn_plan_set_option on the plan after troyn_behz_create used to leave base q and base Bsk on different policies inside one multiply:
+// the auxiliary plan's options are brought up to date at the first call after the change (double-checked; set_option itself is a quiescent-point call).
+static inline void behz_follow_options(const troyn_behz* b) {
+    const uint64_t g = b->plan->opt_gen.load(std::memory_order_acquire);
+    if (b->aux_gen.load(std::memory_order_acquire) == g || !b->aux) return;
+    std::lock_guard<std::mutex> lock(b->aux_mutex);
+    if (b->aux_gen.load(std::memory_order_relaxed) == g) return;
+    b->aux->opt = b->plan->opt;
+    b->aux_gen.store(g, std::memory_order_release);
+}
 
 extern "C" int troyn_behz_destroy(troyn_behz* b) {
     if (!b) return TROYN_OK;
@@ -1954,7 +2007,8 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
 
     int rc = troyn_plan_create(&b->aux, plan->device, plan->log_n, (uint32_t)Bsk, reinterpret_cast<const uint64_t*>(bsk.data()), nullptr);
     if (rc != TROYN_OK) return rc;
-    b->aux->opt = plan->opt;            // the auxiliary base follows the options its plan has NOW (later troyn_plan_set_option calls reach only the plan)
+    b->aux->opt = plan->opt;            // the auxiliary base takes the options its plan has now and follows later changes (behz_follow_options)
+    b->aux_gen.store(plan->opt_gen.load(std::memory_order_acquire), std::memory_order_release);
 
     // constant block: all tables in one allocation
     std::vector<u64> blob;
@@ -2164,6 +2218,7 @@ extern "C" int troyn_bfv_multiply(const troyn_behz* b, const uint64_t* a_, size_
     BehzLayout w = behz_layout(b, pa, pb, batch);
     if (workspace_bytes < w.total * sizeof(u64)) return fail(TROYN_E_WORKSPACE, "[troyn_bfv_multiply] workspace too small");
     if (batch == 0) return TROYN_OK;
+    behz_follow_options(b);
     hipStream_t s = (hipStream_t)stream;
     const troyn_plan* pq = b->plan;
     const troyn_plan* px = b->aux;

@@ -167,7 +167,7 @@ void Evaluator::multiply_relinearize_rescale_batched(const std::vector<const Cip
     troyn_check_public(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, a, b, keys.data(), block->raw_pointer(), ws.raw_pointer(), bytes, count, stream()));
     // no synchronisation: the call is asynchronous on the thread's stream like the reference's evaluator methods; `ws` returns to the pool, which
     // hands a block back to the thread that released it in stream order and to any other thread only after a device synchronisation (MemoryPool).
-    // "In stream order" holds by construction: every launch of this mirror goes to hipStreamPerThread (troy.cpp current_stream(); with call
+    // "In stream order" holds by construction: every launch of this mirror goes to the calling thread's stream (troy.cpp current_stream(); with call
     // combining on, to the one shared stream, and the pool then treats every thread as the same owner); there is no
     // API through which a host thread could move its work to another stream between the release and the reuse.
     for (size_t i = 0; i < count; i++)

@@ -245,7 +245,7 @@ int combining_stream_wait(void* stream) {
 }
 
 bool combining_wanted() {
-    if (!combining_on() || (hipStream_t)troyn_current_stream() == hipStreamPerThread) return false;   // off, or this thread is on another device
+    if (!combining_on() || !on_combining_stream()) return false;   // off, or this thread is on another device (it keeps its own stream)
     Combiner& c = combiner();
     const int64_t t = now_ns();
     c.last_seen[my_slot(c)].store(t, std::memory_order_relaxed);

@@ -31,7 +31,7 @@ static void troyn_check(int rc) {
     throw std::runtime_error(troyn_last_error());
 }
 
-// The stream this thread's calls launch on: hipStreamPerThread -- or, while call combining is on (troy.h), ONE stream shared by every
+// The stream this thread's calls launch on: its slot of the per-device stream set (below) -- or, while call combining is on (troy.h), ONE stream shared by every
 // host thread: the batches of combined calls and whatever else the threads queue are then ordered by that stream alone, so a combined
 // call needs no cross-stream dependency and nobody waits for the GPU inside it.
 namespace detail {
@@ -74,17 +74,63 @@ static inline bool on_shared_device() {
     int dev = -1;
     return hipGetDevice(&dev) == hipSuccess && dev == detail::g_shared_device;
 }
+
+// Host threads are mapped onto a BOUNDED set of streams per device (default 4 = the hardware queues the runtime drives; TROY_STREAMS=<1..16>, read once;
+// TROY_STREAMS=per-thread keeps one stream per host thread, hipStreamPerThread, the mapping of rounds 1-5).  The reference tool's -c N mode
+// (test/bench/he_operations.cu:135-147: N host threads of single-object calls) lost 60-75 % of its throughput between 16 and 64 threads with one stream per
+// thread: 64 streams share the 4 hardware queues, and every switch of a queue between streams costs a barrier packet and a signal round trip.  With Q streams
+// the calls of the threads that share a stream simply queue behind one another.  The streams are BLOCKING streams (hipStreamCreate): a caller that still
+// writes hipStreamSynchronize(0) / hipDeviceSynchronize() -- the reference's idiom without --default-stream per-thread -- waits for them too;
+// utils::stream_sync() (utils/memory_pool.h:37) waits for exactly the calling thread's stream.
+namespace detail {
+constexpr int MAX_POOL_DEVICES = 16, MAX_POOL_STREAMS = 16;
+static int stream_pool_size() {      // 0 = one stream per host thread
+    static const int q = [] {
+        const char* e = std::getenv("TROY_STREAMS");
+        if (!e || !*e) return 4;
+        if (std::string(e) == "per-thread") return 0;
+        char* end = nullptr;
+        const long v = std::strtol(e, &end, 10);
+        if (end == e || *end || v < 1 || v > MAX_POOL_STREAMS) throw std::invalid_argument("[troy] TROY_STREAMS must be 1..16 or per-thread");
+        return (int)v;
+    }();
+    return q;
+}
+struct DeviceStreams { std::once_flag once; hipStream_t s[MAX_POOL_STREAMS] = {}; };
+static DeviceStreams& device_streams(int dev) { static DeviceStreams* all = new DeviceStreams[MAX_POOL_DEVICES]; return all[dev]; }   // never destroyed (threads may outlive statics)
+static std::atomic<unsigned> g_next_slot{0};
+static inline unsigned this_thread_slot() {        // fixed for the life of the host thread: its launches and its releases stay on one stream per device
+    thread_local unsigned slot = g_next_slot.fetch_add(1, std::memory_order_relaxed);
+    return slot;
+}
+// null: no pool on this device (creation failed or the device index is out of range) -> hipStreamPerThread
+static inline hipStream_t pooled_stream(int q, int* slot_out = nullptr) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_POOL_DEVICES) return nullptr;
+    DeviceStreams& d = device_streams(dev);
+    std::call_once(d.once, [&] {
+        for (int i = 0; i < q; i++) if (hipStreamCreate(&d.s[i]) != hipSuccess) { (void)hipGetLastError(); d.s[i] = nullptr; }
+    });
+    const int slot = (int)(this_thread_slot() % (unsigned)q);
+    if (slot_out) *slot_out = dev * MAX_POOL_STREAMS + slot;
+    return d.s[slot];
+}
+}  // namespace detail
+
 static inline hipStream_t current_stream() {
     if (detail::combining_on()) if (hipStream_t s = detail::shared_stream()) if (on_shared_device()) return s;
+    if (const int q = detail::stream_pool_size()) if (hipStream_t s = detail::pooled_stream(q)) return s;
     return hipStreamPerThread;
 }
+
+namespace detail { bool on_combining_stream() { return combining_on() && g_shared_stream && current_stream() == g_shared_stream; } }
 
 void troyn_check_public(int rc) { troyn_check(rc); }
 troyn_stream_t troyn_current_stream() { return (troyn_stream_t)current_stream(); }
 // every wait for the calling thread's stream goes through here: waits for the shared stream of call combining are grouped (combine.cpp)
 static hipError_t stream_wait() {
     hipStream_t s = current_stream();
-    if (s != hipStreamPerThread) return static_cast<hipError_t>(detail::combining_stream_wait(s));
+    if (detail::combining_on() && s == detail::g_shared_stream) return static_cast<hipError_t>(detail::combining_stream_wait(s));
     return hipStreamSynchronize(s);
 }
 void troyn_sync_current_stream() { hip_check(stream_wait(), "stream_sync"); }
@@ -132,6 +178,12 @@ struct ThreadExit {
 static uint64_t this_thread_tag() {
     // one shared stream (call combining): release and reuse are ordered by that stream whichever host thread does them
     if (detail::combining_on() && detail::shared_stream() && on_shared_device()) return uint64_t(1) << 63;
+    // a pooled stream: the tag is the STREAM's (bit 62 + device / slot), so a block released by one of the threads that share it is reusable by
+    // any of them at once -- release and reuse are ordered by that stream.  These tags never die.
+    if (const int q = detail::stream_pool_size()) {
+        int slot = 0;
+        if (detail::pooled_stream(q, &slot)) return (uint64_t(1) << 62) | (uint64_t)slot;
+    }
     static std::atomic<uint64_t> next{1};
     thread_local ThreadExit te;
     if (!te.tag) te.tag = next.fetch_add(1);

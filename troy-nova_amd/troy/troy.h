@@ -138,14 +138,16 @@ class MemoryPool;
 using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 
 // Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
-// uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on its own
-// stream (hipStreamPerThread), and a block may be released while kernels that use it are still queued: a thread that
-// takes back one of ITS OWN blocks is safe by stream order; blocks of host threads that have ended are handed out after one
+// uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on ONE stream per device for its
+// whole life -- one of a bounded set of streams per device that the threads share (default 4; TROY_STREAMS=<1..16>, or
+// TROY_STREAMS=per-thread for hipStreamPerThread as in rounds 1-5) -- and a block may be released while kernels that use it are
+// still queued: a block carries the tag of the STREAM it was released on, and a thread that takes a block of its own stream
+// is safe by stream order; blocks of host threads that have ended (per-thread mode) are handed out after one
 // device-wide synchronisation (which makes every cached block anybody's); otherwise the pool allocates fresh memory, and
 // only when the device is out of memory does it hand out a block last released by another LIVE thread, again after a
 // device-wide synchronisation (memory_pool_safe.in:133-143 does that with cudaDeviceSynchronize on every foreign reuse).
-// ASSUMPTION the asynchronous methods rest on: one stream per host thread, always the same one -- true here because every launch of this
-// library's C++ layer uses hipStreamPerThread; a caller that drives the C-ABI (include/troyn.h) with streams of its own must order the
+// ASSUMPTION the asynchronous methods rest on: a host thread always launches on the same stream -- true here because every launch of this
+// library's C++ layer goes to troyn_current_stream(); a caller that drives the C-ABI (include/troyn.h) with streams of its own must order the
 // release of a workspace after the work that uses it (stream-ordered free or an event), exactly as with any asynchronous HIP API.
 // While call combining is on (below) there is ONE stream for all host threads, and all of them count as the same owner.
 class MemoryPool {
@@ -245,7 +247,9 @@ private:
 namespace utils { void blake2b(void* out, size_t outlen, const void* in, size_t inlen); }   // RFC 7693, unkeyed
 
 // helpers for code layered on the mirror (matmul.cpp): C-ABI status -> the reference's exception types, the calling
-// thread's stream (hipStreamPerThread; the shared stream while call combining is on), and a wait on it
+// thread's stream (its slot of the per-device stream set, troy.cpp current_stream(); the shared stream while call combining is on), and a
+// wait on it.  Wait with these (or hipStreamSynchronize(0) / hipDeviceSynchronize() in a translation unit compiled WITHOUT
+// -fgpu-default-stream=per-thread: the streams are blocking streams), not with hipStreamSynchronize(hipStreamPerThread).
 void troyn_check_public(int rc);
 troyn_stream_t troyn_current_stream();
 void troyn_sync_current_stream();
@@ -1024,7 +1028,7 @@ private:
 // batched multiply / relinearize / rescale.  On this GPU small kernels of different streams overlap at most ~4-fold
 // (tools/ubench/stream_overlap.hip), so N such threads get <= 4 / (GPU time of one op), while ONE launch sequence over 16 objects costs
 // barely more than over one (tools/small_batch_sweep.py).  With combining on
-//   * every host thread's calls go to ONE shared stream instead of hipStreamPerThread (one order for everything the threads queue: no
+//   * every host thread's calls go to ONE shared stream instead of the thread's slot of the stream set (one order for everything the threads queue: no
 //     cross-stream dependencies, the pool may hand a block released by one thread to another at once);
 //   * a thread that enters multiply / relinearize / rescale_to_next / multiply_relinearize_rescale / apply_galois (hence every rotation and
 //     complex_conjugate) while other threads are doing the same
@@ -1082,6 +1086,7 @@ bool combining_wanted();   // switched on AND another thread is active in the co
 bool combining_on();
 void combining_switch(bool on);
 int combining_stream_wait(void* stream);   // hipStreamSynchronize(shared stream), one waiter at a time (returns the hipError_t)
+bool on_combining_stream();                // combining is on and this thread's calls go to the shared stream (its current device is the stream's)
 }  // namespace detail
 
 // ----------------------------------------------------------------------------------------------
