@@ -75,11 +75,13 @@ static inline bool on_shared_device() {
     return hipGetDevice(&dev) == hipSuccess && dev == detail::g_shared_device;
 }
 
-// Host threads are mapped onto a BOUNDED set of streams per device (default 4 = the hardware queues the runtime drives; TROY_STREAMS=<1..16>, read once;
+// Host threads are mapped onto a BOUNDED set of streams per device (default 8 = two per hardware queue the runtime drives; TROY_STREAMS=<1..16>, read once;
 // TROY_STREAMS=per-thread keeps one stream per host thread, hipStreamPerThread, the mapping of rounds 1-5).  The reference tool's -c N mode
 // (test/bench/he_operations.cu:135-147: N host threads of single-object calls) lost 60-75 % of its throughput between 16 and 64 threads with one stream per
 // thread: 64 streams share the 4 hardware queues, and every switch of a queue between streams costs a barrier packet and a signal round trip.  With Q streams
-// the calls of the threads that share a stream simply queue behind one another.  The streams are BLOCKING streams (hipStreamCreate): a caller that still
+// the calls of the threads that share a stream simply queue behind one another.  Measured (profiles/r06_streams_ab.txt, he_bench_driver, CKKS N = 16384 6 x 50-bit,
+// three calls / fused k ops/s): per-thread 34 / 31 at 16 threads and 14 / 24 at 64; Q = 4: 25 / 35 flat; Q = 8: 31 / 44 and 22 / 42; Q = 16: 35 / 50 and 21 / 27.
+// The streams are BLOCKING streams (hipStreamCreate): a caller that still
 // writes hipStreamSynchronize(0) / hipDeviceSynchronize() -- the reference's idiom without --default-stream per-thread -- waits for them too;
 // utils::stream_sync() (utils/memory_pool.h:37) waits for exactly the calling thread's stream.
 namespace detail {
@@ -87,7 +89,7 @@ constexpr int MAX_POOL_DEVICES = 16, MAX_POOL_STREAMS = 16;
 static int stream_pool_size() {      // 0 = one stream per host thread
     static const int q = [] {
         const char* e = std::getenv("TROY_STREAMS");
-        if (!e || !*e) return 4;
+        if (!e || !*e) return 8;
         if (std::string(e) == "per-thread") return 0;
         char* end = nullptr;
         const long v = std::strtol(e, &end, 10);

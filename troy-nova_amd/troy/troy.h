@@ -139,7 +139,7 @@ using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 
 // Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
 // uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on ONE stream per device for its
-// whole life -- one of a bounded set of streams per device that the threads share (default 4; TROY_STREAMS=<1..16>, or
+// whole life -- one of a bounded set of streams per device that the threads share (default 8; TROY_STREAMS=<1..16>, or
 // TROY_STREAMS=per-thread for hipStreamPerThread as in rounds 1-5) -- and a block may be released while kernels that use it are
 // still queued: a block carries the tag of the STREAM it was released on, and a thread that takes a block of its own stream
 // is safe by stream order; blocks of host threads that have ended (per-thread mode) are handed out after one
