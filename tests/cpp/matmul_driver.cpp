@@ -4,6 +4,7 @@
 // optional output packing, add the bias, serialize / load the outputs, decrypt, compare with the plain result mod t.
 // usage: matmul_driver <batch> <input_dims> <output_dims> [repeat] [pack_lwe 0|1] [mod_switch 0|1] [objective: left|right|crossed]
 // (right: plaintext inputs x encrypted weights; crossed: both encrypted, BGV -- the reference's BFV ciphertexts cannot be multiplied in NTT form)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -149,12 +150,51 @@ int main(int argc, char** argv) {
             dec_rep += (a2 - a1) * 1e3 / (repeat - 1);
             if (gr != got) { std::printf("repeat decrypt differs\nFAIL\n"); return 1; }
         }
+        // ---- the WHOLE flow of the example at its steady state: every phase of examples/10_bfv_matmul.cu:96-120 -- the encodings and
+        // the wire phases included -- timed on complete passes AFTER the first one: the pool holds the buffers (no hipMalloc inside a timed phase), the
+        // level's one-off constants exist.  Objects of a pass are released before the next one starts, as a server loop would.
         size_t weights_n = 0, inputs_n = 0, outputs_n = 0;
         for (auto& r : we.data()) weights_n += r.size();
         for (auto& r : wc.data()) weights_n += r.size();
         for (auto& r : xp.data()) inputs_n += r.size();
         for (auto& r : xe.data()) inputs_n += r.size();
         for (auto& r : ye.data()) outputs_n += r.size();
+        const int flow_passes = (objective == MatmulObjective::EncryptLeft && repeat > 1) ? 4 : 0;     // the first one warms the wire buffers (reported, not averaged)
+        static const char* flow_names[10] = {"encode_weights", "encode_bias", "encrypt_inputs", "inputs_wire", "matmul", "mod_switch", "pack", "add_bias", "outputs_wire", "decrypt"};
+        double flow_sum[10] = {}, flow_max[10] = {}, flow_total_min = 1e30, flow_total_max = 0, flow_warm = 0;
+        we = Plain2d(); se = Plain2d(); xe = Cipher2d(); ye = Cipher2d(); yl = Cipher2d();     // first-pass objects back to the pool
+        std::stringstream xs, ys;        // a server loop keeps its wire buffers: a fresh 8 MB stringstream is ~2000 first-touch page faults per pass
+        for (int fp = 0; fp < flow_passes; fp++) {
+            double ph[11];
+            xs.clear(); xs.seekp(0); xs.seekg(0); ys.clear(); ys.seekp(0); ys.seekg(0);
+            ph[0] = now();
+            Plain2d fwe = helper.encode_weights_uint64s(encoder, w.data());
+            ph[1] = now();
+            Plain2d fse = helper.encode_outputs_uint64s(encoder, sbias.data());
+            ph[2] = now();
+            Cipher2d fxe = helper.encrypt_inputs_uint64s(encryptor, encoder, x.data());
+            ph[3] = now();
+            fxe.save(xs, context);
+            fxe = Cipher2d::load_new(xs, context);
+            ph[4] = now();
+            Cipher2d fye = helper.matmul(evaluator, fxe, fwe);
+            ph[5] = now();
+            if (mod_switch) fye.mod_switch_to_next_inplace(evaluator);
+            ph[6] = now();
+            if (pack_lwe) fye = helper.pack_outputs(evaluator, automorphism_key, fye);
+            ph[7] = now();
+            fye.add_plain_inplace(evaluator, fse);
+            ph[8] = now();
+            helper.serialize_outputs(evaluator, fye, ys);
+            Cipher2d fyl = helper.deserialize_outputs(evaluator, ys);
+            ph[9] = now();
+            std::vector<uint64_t> fgot = helper.decrypt_outputs_uint64s(encoder, decryptor, fyl);
+            ph[10] = now();
+            if (fgot != want) { std::printf("steady-state pass %d differs from the plain product\nFAIL\n", fp); return 1; }
+            if (fp == 0) { flow_warm = (ph[10] - ph[0]) * 1e3; continue; }
+            for (int k = 0; k < 10; k++) { const double ms = (ph[k + 1] - ph[k]) * 1e3; flow_sum[k] += ms; flow_max[k] = std::max(flow_max[k], ms); }
+            flow_total_min = std::min(flow_total_min, (ph[10] - ph[0]) * 1e3); flow_total_max = std::max(flow_total_max, (ph[10] - ph[0]) * 1e3);
+        }
         std::printf("objects weights %zu inputs %zu outputs %zu\n", weights_n, inputs_n, outputs_n);
         std::printf("bytes inputs %zu outputs %zu\n", x_bytes, y_bytes);
         std::printf("ms encode_weights %.3f encode_bias %.3f encrypt_inputs %.3f inputs_wire %.3f matmul_first %.3f matmul_repeat %.3f mod_switch %.3f pack %.3f add_bias %.3f "
@@ -162,6 +202,13 @@ int main(int argc, char** argv) {
                     (t1 - t0) * 1e3, (t1b - t1) * 1e3, (t2 - t1b) * 1e3, (t2b - t2) * 1e3, (t3 - t2b) * 1e3, repeat > 1 ? (t4m - t3b) * 1e3 / (repeat - 1) : 0.0,
                     (t4a - t4) * 1e3, (t4b - t4a) * 1e3, (t4c - t4b) * 1e3, (t4d - t4w) * 1e3, (t5 - t4d) * 1e3);
         std::printf("ms_repeat encrypt_inputs %.3f decrypt %.3f mod_switch %.3f pack %.3f add_bias %.3f\n", enc_rep, dec_rep, ms_rep, pack_rep, bias_rep);
+        if (flow_passes) {
+            std::printf("ms_steady");
+            for (int k = 0; k < 10; k++) std::printf(" %s %.3f", flow_names[k], flow_sum[k] / (flow_passes - 1));
+            std::printf("\nms_steady_max");
+            for (int k = 0; k < 10; k++) std::printf(" %s %.3f", flow_names[k], flow_max[k]);
+            std::printf("\nms_steady_total passes %d min %.3f max %.3f warmup_pass %.3f\n", flow_passes - 1, flow_total_min, flow_total_max, flow_warm);
+        }
         size_t bad = 0;
         for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];
         std::printf("mismatches %zu of %zu\n", bad, got.size());

@@ -80,10 +80,13 @@ void Cipher2d::expand_seed(HeContextPointer context) {
 }
 
 size_t Cipher2d::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
+    // app/cipher2d.cu: rows, then per row its length and its ciphertexts; the ciphertexts of a row leave as one batch (Ciphertext::save_many)
     put_size(stream, rows());
     for (const auto& row : inner) {
         put_size(stream, row.size());
-        for (const Ciphertext& c : row) c.save(stream, context, mode);
+        std::vector<const Ciphertext*> ptrs;
+        for (const Ciphertext& c : row) ptrs.push_back(&c);
+        Ciphertext::save_many(stream, ptrs.data(), ptrs.size(), context, mode);
     }
     return serialized_size_upperbound(context, mode);
 }
@@ -93,8 +96,12 @@ void Cipher2d::load(std::istream& stream, HeContextPointer context, MemoryPoolHa
     const size_t rows = get_size(stream);
     for (size_t i = 0; i < rows; i++) {
         const size_t count = get_size(stream);
+        if (count > (size_t(1) << 24)) throw std::runtime_error("[Cipher2d::load] invalid row length");
         std::vector<Ciphertext>& row = new_row();
-        for (size_t j = 0; j < count; j++) { Ciphertext c; c.load(stream, context, pool); row.push_back(std::move(c)); }
+        row.resize(count);
+        std::vector<Ciphertext*> ptrs;
+        for (Ciphertext& c : row) ptrs.push_back(&c);
+        Ciphertext::load_many(stream, ptrs.data(), ptrs.size(), context, pool);
     }
 }
 
@@ -478,7 +485,13 @@ Plain2d MatmulHelper::encode_outputs_uint64s(const BatchEncoder& encoder, const 
     // app/matmul.cu:452-512: the same coefficient positions decrypt_outputs reads
     const size_t n = slot_count, ocols = ceil_div(output_dims, output_block), brows = ceil_div(batch_size, batch_block);
     const size_t count = pack_lwe ? ceil_div(brows * ocols, input_block) : brows * ocols;
-    std::vector<std::vector<uint64_t>> buffers(count, std::vector<uint64_t>(n, 0));
+    // all plaintexts in ONE host image, ONE copy; the plaintext objects are windows of the shared device buffer (as encode_blocks_for_plain hands out the
+    // weights) -- BatchEncoder::encode_polynomial_new per plaintext was an allocation, a pageable copy and a stream wait each (32 of them at 512^3)
+    HeContextPointer context = encoder.context();
+    if (!context->on_device()) throw std::invalid_argument("[MatmulHelper::encode_outputs] HeContext is not on device (call to_device_inplace).");
+    const auto& parms = context->first_context_data().value()->parms();
+    const uint64_t t = parms.plain_modulus().value();
+    std::vector<uint64_t> image(count * n, 0);
     size_t di = 0;
     for (size_t li = 0; li < batch_size; li += batch_block, di++) {
         const size_t ui = std::min(li + batch_block, batch_size);
@@ -486,20 +499,36 @@ Plain2d MatmulHelper::encode_outputs_uint64s(const BatchEncoder& encoder, const 
         for (size_t lj = 0; lj < output_dims; lj += output_block, dj++) {
             const size_t uj = std::min(lj + output_block, output_dims);
             const size_t cipher_id = di * ocols + dj;
-            std::vector<uint64_t>& buf = buffers[pack_lwe ? cipher_id / input_block : cipher_id];
+            uint64_t* buf = image.data() + (pack_lwe ? cipher_id / input_block : cipher_id) * n;
             const size_t offset = pack_lwe ? cipher_id % input_block : input_block - 1;
             for (size_t i = li; i < ui; i++)
-                for (size_t j = lj; j < uj; j++) buf[(i - li) * input_block * output_block + (j - lj) * input_block + offset] = outputs[i * output_dims + j];
+                for (size_t j = lj; j < uj; j++) {
+                    const uint64_t v = outputs[i * output_dims + j];
+                    if (v >= t) throw std::invalid_argument("[BatchEncoder::encode_polynomial] Value is larger than plain modulus");
+                    buf[(i - li) * input_block * output_block + (j - lj) * input_block + offset] = v;
+                }
         }
     }
+    auto shared = std::make_shared<utils::DynamicArray>(count * n, true, pool);
+    shared->copy_from(image.data(), image.size(), false);
+    auto window = [&](size_t idx) {
+        Plaintext p;                                         // = BatchEncoder::encode_polynomial_new of n values (batch_encoder.cu encode_polynomial)
+        p.data() = utils::DynamicArray::device_view(shared->raw_pointer() + idx * n, n, shared);
+        p.parms_id() = parms_id_zero;
+        p.coeff_count() = n;
+        p.is_ntt_form() = false;
+        p.poly_modulus_degree() = n;
+        p.coeff_modulus_size() = parms.coeff_modulus().size();
+        return p;
+    };
     Plain2d out;
     if (pack_lwe) {
         std::vector<Plaintext>& row = out.new_row();
-        for (const auto& buf : buffers) row.push_back(encoder.encode_polynomial_new(buf, pool));
+        for (size_t k = 0; k < count; k++) row.push_back(window(k));
     } else {
         for (size_t r = 0; r < brows; r++) {
             std::vector<Plaintext>& row = out.new_row();
-            for (size_t c = 0; c < ocols; c++) row.push_back(encoder.encode_polynomial_new(buffers[r * ocols + c], pool));
+            for (size_t c = 0; c < ocols; c++) row.push_back(window(r * ocols + c));
         }
     }
     return out;
@@ -569,7 +598,9 @@ void MatmulHelper::serialize_outputs(const Evaluator& evaluator, const Cipher2d&
     } else {
         const size_t count = ceil_div(ceil_div(batch_size, batch_block) * ceil_div(output_dims, output_block), input_block);
         if (x.data().empty() || count != x.data()[0].size()) throw std::invalid_argument("[MatmulHelper::serialize_outputs] Output ciphertext count incorrect");
-        for (const Ciphertext& c : x.data()[0]) c.save(stream, context, mode);
+        std::vector<const Ciphertext*> ptrs;
+        for (const Ciphertext& c : x.data()[0]) ptrs.push_back(&c);
+        Ciphertext::save_many(stream, ptrs.data(), ptrs.size(), context, mode);
     }
 }
 
@@ -587,7 +618,10 @@ Cipher2d MatmulHelper::deserialize_outputs(const Evaluator& evaluator, std::istr
     } else {
         const size_t count = ceil_div(ceil_div(batch_size, batch_block) * ceil_div(output_dims, output_block), input_block);
         std::vector<Ciphertext>& row = ret.new_row();
-        for (size_t i = 0; i < count; i++) { Ciphertext c; c.load(stream, context, pool); row.push_back(std::move(c)); }
+        row.resize(count);
+        std::vector<Ciphertext*> ptrs;
+        for (Ciphertext& c : row) ptrs.push_back(&c);
+        Ciphertext::load_many(stream, ptrs.data(), ptrs.size(), context, pool);
     }
     return ret;
 }

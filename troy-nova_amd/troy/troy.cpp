@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <istream>
 #include <ostream>
+#include <sstream>
 
 namespace troy {
 
@@ -1824,53 +1825,182 @@ size_t Ciphertext::serialized_size_upperbound(HeContextPointer context, Compress
     return bytes;
 }
 
-size_t Ciphertext::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
-    put_mode(stream, mode);
-    put(stream, parms_id_);
-    put(stream, polynomial_count_);
-    put(stream, coeff_modulus_size_);
-    put(stream, poly_modulus_degree_);
-    unsigned char flags = static_cast<unsigned char>(is_ntt_form_) | static_cast<unsigned char>(contains_seed() << 1) | static_cast<unsigned char>(on_device() << 2);
-    put(stream, flags);
-    const SchemeType scheme = context_scheme(context);
-    if (scheme == SchemeType::CKKS) put(stream, scale_);
-    if (scheme == SchemeType::BGV) put(stream, correction_factor_);
-    const std::vector<uint64_t> words = data_.to_vector();
-    if (contains_seed()) {
-        if (polynomial_count_ != 2) throw std::logic_error("[Ciphertext::save] Ciphertext contains seed but polynomial count is not 2.");
-        put(stream, seed_);
-        put_words(stream, words, poly_modulus_degree_ * coeff_modulus_size_);     // c0 only; c1 is regenerated from the seed
-    } else {
-        put_words(stream, words, words.size());
+// ---- pinned staging image of the wire path (one per host thread, grown on demand, reused) -------------------------------------------------------
+// save: headers are written into it, the payloads arrive by asynchronous device-to-host copies at their final offsets, ONE wait, ONE stream.write.
+// load: the payloads are read from the caller's stream straight into it and leave by asynchronous host-to-device copies; `busy` marks the last copy that
+// reads it, the next user of the image waits for that event (the loading call itself does not wait: it is asynchronous like the reference's).
+namespace {
+struct PinnedImage {
+    char* p = nullptr; size_t cap = 0; hipEvent_t busy = nullptr; bool pending = false;
+    ~PinnedImage() { if (p) { (void)hipHostFree(p); (void)hipGetLastError(); } if (busy) { (void)hipEventDestroy(busy); (void)hipGetLastError(); } }
+    void quiesce() { if (pending) { hip_check(hipEventSynchronize(busy), "event_sync"); pending = false; } }
+    char* reserve(size_t bytes) {
+        quiesce();
+        if (bytes > cap) {
+            if (p) { hip_check(hipHostFree(p), "host_free"); p = nullptr; cap = 0; }
+            const size_t want = std::max<size_t>(bytes + bytes / 4, size_t(1) << 20);
+            void* q = nullptr;
+            hip_check(hipHostMalloc(&q, want, hipHostMallocPortable), "host_malloc");
+            p = static_cast<char*>(q); cap = want;
+        }
+        if (!busy) hip_check(hipEventCreateWithFlags(&busy, hipEventDisableTiming), "event_create");
+        return p;
     }
-    return serialized_size_upperbound(context, mode);
+    void mark(hipStream_t s) { hip_check(hipEventRecord(busy, s), "event_record"); pending = true; }
+};
+PinnedImage& pinned_image() { static thread_local PinnedImage img; return img; }
+}  // namespace
+
+size_t Ciphertext::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
+    const Ciphertext* one = this;
+    return save_many(stream, &one, 1, context, mode);
+}
+
+size_t Ciphertext::save_many(std::ostream& stream, const Ciphertext* const* cts, size_t count, HeContextPointer context, CompressionMode mode) {
+    // ciphertext.cu:93-150 per object: mode, parms_id, the three sizes, flags, scale (CKKS) / correction factor (BGV), seed, words
+    const SchemeType scheme = context_scheme(context);
+    std::vector<std::string> headers(count);
+    std::vector<size_t> payload(count);
+    size_t total = 0, bound = 0;
+    for (size_t i = 0; i < count; i++) {
+        const Ciphertext& c = *cts[i];
+        std::ostringstream h;
+        put_mode(h, mode);
+        put(h, c.parms_id_);
+        put(h, c.polynomial_count_);
+        put(h, c.coeff_modulus_size_);
+        put(h, c.poly_modulus_degree_);
+        const unsigned char flags = static_cast<unsigned char>(c.is_ntt_form_) | static_cast<unsigned char>(c.contains_seed() << 1) | static_cast<unsigned char>(c.on_device() << 2);
+        put(h, flags);
+        if (scheme == SchemeType::CKKS) put(h, c.scale_);
+        if (scheme == SchemeType::BGV) put(h, c.correction_factor_);
+        if (c.contains_seed()) {
+            if (c.polynomial_count_ != 2) throw std::logic_error("[Ciphertext::save] Ciphertext contains seed but polynomial count is not 2.");
+            put(h, c.seed_);
+            payload[i] = c.poly_modulus_degree_ * c.coeff_modulus_size_;     // c0 only; c1 is regenerated from the seed
+        } else {
+            payload[i] = c.data_.size();
+        }
+        if (payload[i] > c.data_.size()) throw std::logic_error("[Ciphertext::save] Ciphertext data is smaller than its shape.");
+        headers[i] = h.str();
+        total += headers[i].size() + payload[i] * 8;
+        bound += c.serialized_size_upperbound(context, mode);
+    }
+    if (count == 0) return 0;
+    PinnedImage& img = pinned_image();
+    char* base = img.reserve(total);
+    size_t off = 0;
+    bool queued = false;
+    for (size_t i = 0; i < count; i++) {
+        const Ciphertext& c = *cts[i];
+        std::memcpy(base + off, headers[i].data(), headers[i].size());
+        off += headers[i].size();
+        if (payload[i]) {
+            if (c.on_device()) {
+                hip_check(hipSetDevice(static_cast<int>(c.data_.device_index())), "copy_device_to_host");
+                hip_check(hipMemcpyAsync(base + off, c.data_.raw_pointer(), payload[i] * 8, hipMemcpyDeviceToHost, current_stream()), "copy_device_to_host");
+                queued = true;
+            } else {
+                std::memcpy(base + off, c.data_.raw_pointer(), payload[i] * 8);
+            }
+        }
+        off += payload[i] * 8;
+    }
+    if (queued) hip_check(stream_wait(), "copy_device_to_host");
+    stream.write(base, static_cast<std::streamsize>(total));
+    return bound;
 }
 
 void Ciphertext::load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool) {
-    get_mode(stream);
-    get(stream, parms_id_);
-    get(stream, polynomial_count_);
-    get(stream, coeff_modulus_size_);
-    get(stream, poly_modulus_degree_);
-    unsigned char flags;
-    get(stream, flags);
-    is_ntt_form_ = flags & 1;
-    const bool seeded = flags & 2, device = flags & 4;
-    if (flags & 8) throw std::logic_error("[Ciphertext::load] Trying to call load with ciphertext with only terms saved.");
+    Ciphertext* one = this;
+    load_many(stream, &one, 1, context, pool);
+}
+
+void Ciphertext::load_many(std::istream& stream, Ciphertext* const* cts, size_t count, HeContextPointer context, MemoryPoolHandle pool) {
+    // ciphertext.cu:152-210 per object.  Device-bound payloads (flag bit 2, or seeded: the seed is expanded on the device) go through the pinned
+    // image; the seeded c1 polynomials of one shape are expanded by ONE troyn_sample_uniform_multi launch into a block the ciphertexts window.
+    if (count == 0) return;
     const SchemeType scheme = context_scheme(context);
-    scale_ = 1.0; correction_factor_ = 1;
-    if (scheme == SchemeType::CKKS) get(stream, scale_);
-    if (scheme == SchemeType::BGV) get(stream, correction_factor_);
-    const size_t poly = poly_modulus_degree_ * coeff_modulus_size_;
-    if (poly_modulus_degree_ > 131072 || coeff_modulus_size_ > 64 || polynomial_count_ > 64) throw std::runtime_error("[Ciphertext::load] invalid shape");
-    std::vector<uint64_t> words(poly * (seeded ? 2 : polynomial_count_), 0);
-    seed_ = 0;
-    if (seeded) get(stream, seed_);
-    stream.read(reinterpret_cast<char*>(words.data()), (seeded ? poly : words.size()) * 8);
-    if (!stream) throw std::runtime_error("[Ciphertext::load] unexpected end of stream");
-    data_ = utils::DynamicArray::from_vector(words);
-    if (device || seeded) data_.to_device_inplace(pool);     // seed expansion runs on the device
-    if (seeded) expand_seed(context);
+    struct Pending { Ciphertext* c; size_t words, img_off; bool seeded; };
+    std::vector<Pending> dev;
+    PinnedImage& img = pinned_image();
+    size_t used = 0;
+    char* base = img.reserve(size_t(1) << 20);
+    auto flush = [&]() {
+        // seeded ciphertexts of one shape become windows of ONE block [count][2][poly] (as Encryptor::encrypt_symmetric_packed hands them out): their c1
+        // polynomials are expanded by one troyn_sample_uniform_multi launch (the c1 generators of rlwe::symmetric, utils/rlwe.cu:262-266; ciphertext.cu:79-91)
+        // and dealt to the windows by one strided copy; everything else gets its own array
+        std::vector<Pending*> seeded;
+        for (Pending& d : dev) {
+            if (d.seeded) seeded.push_back(&d);
+            else d.c->data_ = utils::DynamicArray(d.words, true, pool);
+        }
+        while (!seeded.empty()) {
+            const Ciphertext& f = *seeded.front()->c;
+            std::vector<Pending*> group, rest;
+            for (Pending* d : seeded) (d->c->parms_id_ == f.parms_id_ && d->c->coeff_modulus_size_ == f.coeff_modulus_size_ && d->c->poly_modulus_degree_ == f.poly_modulus_degree_ ? group : rest).push_back(d);
+            auto cd = context->get_context_data(f.parms_id_);
+            if (!cd.has_value()) throw std::invalid_argument("[Ciphertext::expand_seed] ParmsID is not valid.");
+            if (!context->on_device()) throw std::invalid_argument("[Ciphertext::expand_seed] the seed is expanded on the GPU: context and ciphertext must be on the device.");
+            const size_t poly = f.poly_modulus_degree_ * f.coeff_modulus_size_, m = group.size();
+            std::vector<uint64_t> seeds(2 * m, 0);
+            for (size_t g = 0; g < m; g++) seeds[2 * g] = group[g]->c->seed_;
+            auto shared = std::make_shared<utils::DynamicArray>(m * 2 * poly, true, pool);
+            for (size_t g = 0; g < m; g++) group[g]->c->data_ = utils::DynamicArray::device_view(shared->raw_pointer() + g * 2 * poly, 2 * poly, shared);
+            if (m == 1) {
+                troyn_check(troyn_sample_uniform_multi(context->plan(), static_cast<uint32_t>(f.coeff_modulus_size_), seeds.data(), shared->raw_pointer() + poly, 1, current_stream()));
+            } else {
+                utils::DynamicArray block(m * poly, true, pool);
+                troyn_check(troyn_sample_uniform_multi(context->plan(), static_cast<uint32_t>(f.coeff_modulus_size_), seeds.data(), block.raw_pointer(), m, current_stream()));
+                hip_check(hipMemcpy2DAsync(shared->raw_pointer() + poly, 2 * poly * 8, block.raw_pointer(), poly * 8, poly * 8, m, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+                // (`block` returns to the pool in stream order)
+            }
+            for (Pending* d : group) d->c->seed_ = 0;
+            seeded.swap(rest);
+        }
+        for (const Pending& d : dev)
+            hip_check(hipMemcpyAsync(d.c->data_.raw_pointer(), base + d.img_off, d.words * 8, hipMemcpyHostToDevice, current_stream()), "copy_host_to_device");
+        if (!dev.empty()) img.mark(current_stream());      // the image may be overwritten once these copies have run
+        dev.clear();
+        used = 0;
+    };
+    for (size_t i = 0; i < count; i++) {
+        Ciphertext& c = *cts[i];
+        get_mode(stream);
+        get(stream, c.parms_id_);
+        get(stream, c.polynomial_count_);
+        get(stream, c.coeff_modulus_size_);
+        get(stream, c.poly_modulus_degree_);
+        unsigned char flags;
+        get(stream, flags);
+        c.is_ntt_form_ = flags & 1;
+        const bool seeded = flags & 2, device = flags & 4;
+        if (flags & 8) throw std::logic_error("[Ciphertext::load] Trying to call load with ciphertext with only terms saved.");
+        c.scale_ = 1.0; c.correction_factor_ = 1;
+        if (scheme == SchemeType::CKKS) get(stream, c.scale_);
+        if (scheme == SchemeType::BGV) get(stream, c.correction_factor_);
+        const size_t poly = c.poly_modulus_degree_ * c.coeff_modulus_size_;
+        if (c.poly_modulus_degree_ > 131072 || c.coeff_modulus_size_ > 64 || c.polynomial_count_ > 64) throw std::runtime_error("[Ciphertext::load] invalid shape");
+        if (seeded && c.polynomial_count_ != 2) throw std::runtime_error("[Ciphertext::load] a seeded ciphertext has two polynomials");
+        c.seed_ = 0;
+        if (seeded) get(stream, c.seed_);
+        const size_t words = seeded ? poly : poly * c.polynomial_count_;
+        if (device || seeded) {
+            if ((used + words * 8) > img.cap) {
+                if (!dev.empty()) { flush(); }
+                base = img.reserve(std::max<size_t>(words * 8, std::min<size_t>(size_t(64) << 20, (count - i) * words * 8)));
+            }
+            stream.read(base + used, static_cast<std::streamsize>(words * 8));
+            if (!stream) throw std::runtime_error("[Ciphertext::load] unexpected end of stream");
+            dev.push_back(Pending{&c, words, used, seeded});      // (its device array is made by flush())
+            used += words * 8;
+        } else {
+            c.data_ = utils::DynamicArray(words, false);
+            stream.read(reinterpret_cast<char*>(c.data_.raw_pointer()), static_cast<std::streamsize>(words * 8));
+            if (!stream) throw std::runtime_error("[Ciphertext::load] unexpected end of stream");
+        }
+    }
+    flush();
 }
 
 size_t Ciphertext::serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode) const {

@@ -509,6 +509,11 @@ public:
     size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
     static Ciphertext load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { Ciphertext c; c.load(stream, context, pool); return c; }
+    // ADDITION: `count` ciphertexts in the byte format of `count` save() / load() calls, moved as ONE batch -- the payloads cross the bus through a pinned
+    // staging image with one stream wait per batch (save) or none (load: the copies and ONE seed-expansion launch are queued on the caller's stream), instead of a
+    // pageable copy, a wait and a launch per ciphertext.  save() / load() are the count == 1 case; Cipher2d::save / load and MatmulHelper::(de)serialize_outputs use them.
+    static size_t save_many(std::ostream& stream, const Ciphertext* const* cts, size_t count, HeContextPointer context, CompressionMode mode = CompressionMode::Nil);
+    static void load_many(std::istream& stream, Ciphertext* const* cts, size_t count, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
     size_t serialized_size_upperbound(HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void expand_seed(HeContextPointer context);
     // ciphertext.cu:213-339: only the listed coefficients of c0 are written (flag bit 3); the other polynomials in full
