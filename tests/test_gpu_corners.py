@@ -234,3 +234,52 @@ def test_wide_dropped_prime_over_narrow_limbs(O, pkg, dev, monkeypatch, n, bits)
             got = pkg.to_host(plan.divide_and_round_q_last_ntt(L, pkg.to_device(x, dev), 2))
             for i in range(x.shape[0]):
                 assert np.array_equal(got[i], ctx.mod_switch_scale_to_next(L, x[i])), (split, "rescale", L, i)
+
+
+@pytest.mark.parametrize("n,bits,L,t,pa,pb", [
+    (8192, [40, 40, 40], 2, 1032193, 2, 2),                       # BASELINE config 2
+    (8192, [40, 40, 40], 2, (1 << 40) - 87, 3, 3),                # the widest t the chain carries (t < q_i), 3-component operands
+    (8192, [50, 50, 50, 50], 3, (1 << 49) - 69, 3, 2),
+    (32768, [50] * 11, 10, 1032193, 2, 2),                        # BASELINE config 4
+    (32768, [50] * 11, 10, (1 << 49) - 69, 2, 2),
+    (16384, [50] * 6, 5, (1 << 30) + 3, 3, 3),
+])
+def test_bfv_multiply_worst_case_magnitudes(O, pkg, dev, n, bits, L, t, pa, pb):
+    """ADVICE r05: the default auxiliary base of primes below 2^50 is sized by the reference's criterion (utils/rns_tool.cu:50-62) with two bits of slack;
+    random operands do not reach the magnitudes the criterion is about.  Operands at the extremes -- every coefficient q_i - 1 (the centred value -1 in every
+    limb is NOT the worst case, so also the residues of +-floor(q/2) and alternating signs), the widest plain modulus, 3-component ciphertexts (the tensor
+    sums up to three products per output) -- against the oracle, which keeps the reference's 61-bit base; both bases of the library must agree with it."""
+    q = O.coeff_modulus_create(n, bits)
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    qL = [int(v) for v in q[:L]]
+    Q = 1
+    for v in qL:
+        Q *= v
+    half = Q // 2
+
+    def const_poly(value):           # every coefficient = value (an integer in [0, Q)), as residues
+        return np.stack([np.full(n, value % m, dtype=np.uint64) for m in qL])
+
+    def alt_poly(v0, v1):
+        rows = []
+        for m in qL:
+            r = np.empty(n, dtype=np.uint64)
+            r[0::2] = v0 % m
+            r[1::2] = v1 % m
+            rows.append(r)
+        return np.stack(rows)
+
+    shapes = [const_poly(Q - 1), const_poly(half), const_poly(half + 1), alt_poly(half, half + 1), alt_poly(Q - 1, 1), alt_poly(half, Q - 1)]
+    a = np.stack([np.stack([shapes[(i + p) % len(shapes)] for p in range(pa)]) for i in range(len(shapes))])
+    b = np.stack([np.stack([shapes[(2 * i + p + 1) % len(shapes)] for p in range(pb)]) for i in range(len(shapes))])
+    want = [ctx.bfv_multiply(L, a[i], b[i]) for i in range(len(shapes))]
+    for base in (None, "ref"):
+        plan.set_option("TROYN_BEHZ_BASE", base)
+        behz = pkg.Behz(plan, L, t)
+        got = pkg.to_host(behz.multiply(pkg.to_device(a, dev), pa, pkg.to_device(b, dev), pb))
+        for i in range(len(shapes)):
+            assert np.array_equal(got[i], want[i]), (base, i)
+        sq = pkg.to_host(behz.multiply(pkg.to_device(a, dev), pa, pkg.to_device(a, dev), pa))
+        for i in (0, 1, 3):
+            assert np.array_equal(sq[i], ctx.bfv_multiply(L, a[i], a[i])), (base, "square", i)

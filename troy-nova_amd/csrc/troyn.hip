@@ -2002,6 +2002,10 @@ extern "C" int troyn_behz_create(troyn_behz** out, const troyn_plan* plan, uint3
             } else aux50 = false;
         } catch (const std::exception&) { aux50 = false; }
     }
+    // Shenoy-Kumaresan (rns_tool.cu:1000-1036): the correction term alpha_sk of the conversion B -> q is recovered modulo m_sk and satisfies
+    // |alpha_sk| <= |B| (+ the lambda of the fast floor); it is read off a centred residue, so m_sk must exceed twice that -- any prime of 50 or
+    // 61 bits does by ~45 bits, but the working base is chosen above, so state what it relies on
+    if (m_sk < 2 * ((u64)Bn + 2) + 1) return fail(TROYN_E_MODULUS, "[troyn_behz_create] m_sk is too small for the Shenoy-Kumaresan correction of this base");
     const size_t Bsk = Bn + 1;          // working base from here on
     b->Bn = (unsigned)Bn; b->Bsk = (unsigned)Bsk; b->aux50 = aux50;
 
