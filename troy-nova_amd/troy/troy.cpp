@@ -76,8 +76,9 @@ static inline bool on_shared_device() {
     return hipGetDevice(&dev) == hipSuccess && dev == detail::g_shared_device;
 }
 
-// Host threads are mapped onto a BOUNDED set of streams per device (default 8 = two per hardware queue the runtime drives; TROY_STREAMS=<1..16>, read once;
-// TROY_STREAMS=per-thread keeps one stream per host thread, hipStreamPerThread, the mapping of rounds 1-5).  The reference tool's -c N mode
+// Host threads are mapped onto a BOUNDED set of streams per device.  Default: 16 streams while at most 16 host threads use the library, 8 once there are
+// more (a thread re-reads the number only when its stream has just drained, see stream_wait()); TROY_STREAMS=<1..16> fixes the number, TROY_STREAMS=per-thread
+// keeps one stream per host thread (hipStreamPerThread, the mapping of rounds 1-5); read once.  The reference tool's -c N mode
 // (test/bench/he_operations.cu:135-147: N host threads of single-object calls) lost 60-75 % of its throughput between 16 and 64 threads with one stream per
 // thread: 64 streams share the 4 hardware queues, and every switch of a queue between streams costs a barrier packet and a signal round trip.  With Q streams
 // the calls of the threads that share a stream simply queue behind one another.  Measured (profiles/r06_streams_ab.txt, he_bench_driver, CKKS N = 16384 6 x 50-bit,
@@ -86,11 +87,11 @@ static inline bool on_shared_device() {
 // writes hipStreamSynchronize(0) / hipDeviceSynchronize() -- the reference's idiom without --default-stream per-thread -- waits for them too;
 // utils::stream_sync() (utils/memory_pool.h:37) waits for exactly the calling thread's stream.
 namespace detail {
-constexpr int MAX_POOL_DEVICES = 16, MAX_POOL_STREAMS = 16;
-static int stream_pool_size() {      // 0 = one stream per host thread
+constexpr int MAX_POOL_DEVICES = 16, MAX_POOL_STREAMS = 16, ADAPTIVE_MANY_THREADS = 17, ADAPTIVE_FEW = 16, ADAPTIVE_MANY = 8;
+static int stream_pool_size() {      // 0 = one stream per host thread, -1 = by the number of host threads (the default)
     static const int q = [] {
         const char* e = std::getenv("TROY_STREAMS");
-        if (!e || !*e) return 8;
+        if (!e || !*e) return -1;
         if (std::string(e) == "per-thread") return 0;
         char* end = nullptr;
         const long v = std::strtol(e, &end, 10);
@@ -102,9 +103,24 @@ static int stream_pool_size() {      // 0 = one stream per host thread
 struct DeviceStreams { std::once_flag once; hipStream_t s[MAX_POOL_STREAMS] = {}; };
 static DeviceStreams& device_streams(int dev) { static DeviceStreams* all = new DeviceStreams[MAX_POOL_DEVICES]; return all[dev]; }   // never destroyed (threads may outlive statics)
 static std::atomic<unsigned> g_next_slot{0};
-static inline unsigned this_thread_slot() {        // fixed for the life of the host thread: its launches and its releases stay on one stream per device
-    thread_local unsigned slot = g_next_slot.fetch_add(1, std::memory_order_relaxed);
-    return slot;
+static std::atomic<int> g_live_threads{0};          // host threads that have used the library and have not ended
+struct ThreadSlot {
+    unsigned slot; int q = 0;                        // q: the stream count this thread currently maps by (adaptive mode)
+    unsigned busy_devices = 0;                       // bit d: this thread may have work in flight on device d (it took that device's stream since its last wait there)
+    ThreadSlot() : slot(g_next_slot.fetch_add(1, std::memory_order_relaxed)) { g_live_threads.fetch_add(1, std::memory_order_relaxed); }
+    ~ThreadSlot() { g_live_threads.fetch_sub(1, std::memory_order_relaxed); }
+};
+static inline ThreadSlot& this_thread_slot() { thread_local ThreadSlot ts; return ts; }   // the slot is fixed for the life of the host thread
+static inline int adaptive_streams() { return g_live_threads.load(std::memory_order_relaxed) <= ADAPTIVE_MANY_THREADS ? ADAPTIVE_FEW : ADAPTIVE_MANY; }
+// A thread may move to another stream only while nothing of its own is in flight: right after a wait for its stream (stream_wait) -- everything it
+// queued has completed, so what it releases later is safely tagged with the new stream.
+static inline void stream_drained() {
+    if (stream_pool_size() >= 0) return;
+    ThreadSlot& ts = this_thread_slot();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_POOL_DEVICES) return;
+    ts.busy_devices &= ~(1u << dev);
+    if (ts.busy_devices == 0) ts.q = adaptive_streams();     // (a thread that drives several devices moves only when all of its streams have drained)
 }
 // null: no pool on this device (creation failed or the device index is out of range) -> hipStreamPerThread
 static inline hipStream_t pooled_stream(int q, int* slot_out = nullptr) {
@@ -112,9 +128,12 @@ static inline hipStream_t pooled_stream(int q, int* slot_out = nullptr) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_POOL_DEVICES) return nullptr;
     DeviceStreams& d = device_streams(dev);
     std::call_once(d.once, [&] {
-        for (int i = 0; i < q; i++) if (hipStreamCreate(&d.s[i]) != hipSuccess) { (void)hipGetLastError(); d.s[i] = nullptr; }
+        const int create = q < 0 ? ADAPTIVE_FEW : q;
+        for (int i = 0; i < create; i++) if (hipStreamCreate(&d.s[i]) != hipSuccess) { (void)hipGetLastError(); d.s[i] = nullptr; }
     });
-    const int slot = (int)(this_thread_slot() % (unsigned)q);
+    ThreadSlot& ts = this_thread_slot();
+    if (q < 0) { if (!ts.q) ts.q = adaptive_streams(); q = ts.q; ts.busy_devices |= 1u << dev; }
+    const int slot = (int)(ts.slot % (unsigned)q);
     if (slot_out) *slot_out = dev * MAX_POOL_STREAMS + slot;
     return d.s[slot];
 }
@@ -134,7 +153,9 @@ troyn_stream_t troyn_current_stream() { return (troyn_stream_t)current_stream();
 static hipError_t stream_wait() {
     hipStream_t s = current_stream();
     if (detail::combining_on() && s == detail::g_shared_stream) return static_cast<hipError_t>(detail::combining_stream_wait(s));
-    return hipStreamSynchronize(s);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) detail::stream_drained();
+    return e;
 }
 void troyn_sync_current_stream() { hip_check(stream_wait(), "stream_sync"); }
 namespace utils { void stream_sync() { troyn_sync_current_stream(); } }   // utils/memory_pool.h:37
@@ -154,8 +175,10 @@ static MemoryPoolHandle g_global_pool;
 static std::mutex& g_pools_mutex() { static std::mutex* m = new std::mutex; return *m; }
 static std::unordered_set<MemoryPool*>& g_pools() { static auto* s = new std::unordered_set<MemoryPool*>; return *s; }
 
-MemoryPool::MemoryPool(size_t device) : device_(device) {
+static std::atomic<uint64_t> g_pool_ids{1};
+MemoryPool::MemoryPool(size_t device) : device_(device), id_(g_pool_ids.fetch_add(1)) {
     if (device >= device_count()) throw std::runtime_error("[MemoryPool::MemoryPool] No such device.");
+    for (auto& sp : stream_shards_) sp.store(nullptr, std::memory_order_relaxed);
     if (const char* e = std::getenv("TROY_POOL_HIGH_WATER_MB")) high_water_ = static_cast<size_t>(std::strtoull(e, nullptr, 0)) << 20;
     std::lock_guard<std::mutex> lock(g_pools_mutex());
     g_pools().insert(this);
@@ -197,22 +220,103 @@ static bool tag_is_dead(uint64_t tag) {
     return g_dead_tags.count(tag) != 0;
 }
 
+static constexpr uint64_t STREAM_TAG_BIT = uint64_t(1) << 62;
+
+MemoryPool::Shard* MemoryPool::shard_of(uint64_t tag) {
+    if (tag == 0) return &nobody_;
+    if ((tag & STREAM_TAG_BIT) && (tag & ~STREAM_TAG_BIT) < STREAM_SHARDS) {
+        std::atomic<Shard*>& slot = stream_shards_[tag & ~STREAM_TAG_BIT];
+        Shard* s = slot.load(std::memory_order_acquire);
+        if (s) return s;
+        Shard* fresh = new Shard;
+        if (slot.compare_exchange_strong(s, fresh, std::memory_order_acq_rel)) return fresh;
+        delete fresh;
+        return s;
+    }
+    // per-thread tags (TROY_STREAMS=per-thread) and the combining tag: a table under its own lock, with this thread's last answer cached
+    struct Cached { uint64_t pool_id = 0, tag = 0; Shard* s = nullptr; };
+    thread_local Cached cached;
+    if (cached.pool_id == id_ && cached.tag == tag) return cached.s;
+    std::lock_guard<std::mutex> lock(table_mutex_);
+    std::unique_ptr<Shard>& sp = other_shards_[tag];
+    if (!sp) sp.reset(new Shard);
+    cached.pool_id = id_; cached.tag = tag; cached.s = sp.get();      // (a shard is removed only once its thread has ended: nobody caches that tag any more)
+    return sp.get();
+}
+
+void* MemoryPool::take_from(Shard& sh, size_t bytes) {
+    void* found = nullptr;
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lock(sh.m);
+        auto it = sh.free_.lower_bound(bytes);
+        if (it == sh.free_.end() || it->first > bytes * 2) return nullptr;
+        found = it->second.back().ptr;
+        sz = it->first;
+        it->second.pop_back();
+        if (it->second.empty()) sh.free_.erase(it);
+    }
+    LiveShard& ls = live_shard(found);
+    std::lock_guard<std::mutex> lock(ls.m);
+    ls.map[found] = sz;
+    return found;
+}
+
+bool MemoryPool::dead_owner_has(size_t bytes) {
+    { std::lock_guard<std::mutex> dl(g_dead_mutex); if (g_dead_tags.empty()) return false; }
+    std::lock_guard<std::mutex> lock(table_mutex_);
+    for (auto& kv : other_shards_) {
+        if (!tag_is_dead(kv.first)) continue;
+        std::lock_guard<std::mutex> sl(kv.second->m);
+        auto it = kv.second->free_.lower_bound(bytes);
+        if (it != kv.second->free_.end() && it->first <= bytes * 2) return true;
+    }
+    return false;
+}
+
+// the blocks released under `tag` (~0: under any tag) at or before release number `upto` move to shard 0: nobody has work pending on them any more
 void MemoryPool::disown(uint64_t tag, uint64_t upto) {
-    std::lock_guard<std::mutex> lock(mutex_);
-    for (auto& kv : free_) for (auto& blk : kv.second) if ((blk.owner == tag || tag == ~uint64_t(0)) && blk.seq <= upto) blk.owner = 0;
+    std::vector<std::pair<size_t, FreeBlock>> moved;
+    auto drain = [&](Shard& sh) {
+        std::lock_guard<std::mutex> lock(sh.m);
+        for (auto it = sh.free_.begin(); it != sh.free_.end();) {
+            auto& v = it->second;
+            for (size_t i = v.size(); i-- > 0;)
+                if (v[i].seq <= upto) { moved.emplace_back(it->first, v[i]); v.erase(v.begin() + static_cast<std::ptrdiff_t>(i)); }
+            it = v.empty() ? sh.free_.erase(it) : std::next(it);
+        }
+    };
+    if (tag == ~uint64_t(0)) {
+        for (auto& sp : stream_shards_) if (Shard* sh = sp.load(std::memory_order_acquire)) drain(*sh);
+        std::lock_guard<std::mutex> lock(table_mutex_);
+        for (auto it = other_shards_.begin(); it != other_shards_.end();) {
+            drain(*it->second);
+            bool empty;
+            { std::lock_guard<std::mutex> sl(it->second->m); empty = it->second->free_.empty(); }
+            // the shard of a host thread that has ended is dropped once it is empty (nothing refers to that tag any more)
+            it = (empty && tag_is_dead(it->first)) ? other_shards_.erase(it) : std::next(it);
+        }
+    } else if (tag != 0) {
+        drain(*shard_of(tag));
+    }
+    if (moved.empty()) return;
+    std::lock_guard<std::mutex> lock(nobody_.m);
+    for (auto& kv : moved) { kv.second.owner = 0; nobody_.free_[kv.first].push_back(kv.second); }
 }
 void MemoryPool::disown_all_pools() {
     std::lock_guard<std::mutex> lock(g_pools_mutex());
     for (MemoryPool* p : g_pools()) p->disown(~uint64_t(0));
 }
-uint64_t MemoryPool::release_mark() { std::lock_guard<std::mutex> lock(mutex_); return release_seq_; }
-void MemoryPool::set_high_water_bytes(size_t bytes) { std::lock_guard<std::mutex> lock(mutex_); high_water_ = bytes; }
-size_t MemoryPool::held_bytes() { std::lock_guard<std::mutex> lock(mutex_); return held_bytes_; }
+void MemoryPool::set_high_water_bytes(size_t bytes) { high_water_.store(bytes, std::memory_order_relaxed); }
+size_t MemoryPool::held_bytes() { return held_bytes_.load(std::memory_order_relaxed); }
 
 MemoryPool::~MemoryPool() {
     { std::lock_guard<std::mutex> lock(g_pools_mutex()); g_pools().erase(this); }
-    for (auto& kv : free_) for (auto& blk : kv.second) (void)hipFree(blk.ptr);
-    for (auto& kv : live_) (void)hipFree(kv.first);
+    auto free_all = [](Shard& sh) { for (auto& kv : sh.free_) for (auto& blk : kv.second) (void)hipFree(blk.ptr); };
+    free_all(nobody_);
+    for (auto& sp : stream_shards_) if (Shard* sh = sp.load()) { free_all(*sh); delete sh; }
+    for (auto& kv : other_shards_) free_all(*kv.second);
+    for (auto& ls : live_) for (auto& kv : ls.map) (void)hipFree(kv.first);
 }
 
 MemoryPoolHandle MemoryPool::GlobalPool() {
@@ -226,94 +330,94 @@ void MemoryPool::Destroy() {
     g_global_pool.reset();
 }
 
-// Best fit with at most 2x slack (memory_pool_safe.in:119-148).  Order of preference: a block THIS thread released (safe by stream
-// order) or one nobody has work pending on (tag 0); a block of a host thread that has ended, behind one device-wide synchronisation
-// (which clears every tag, so this happens once per generation of threads); a fresh hipMalloc; and only when the device is out of
-// memory a block another LIVE thread released, again behind a device-wide synchronisation.  Round 3 took any foreign block before
-// trying hipMalloc: with N host threads working on single objects (the reference's -c N mode) blocks migrated between threads all the
-// time and every migration was a hipDeviceSynchronize -- 16 threads ran at the speed of 3 (tests/cpp/he_bench_driver threads).
+// Best fit with at most 2x slack (memory_pool_safe.in:119-148).  Order of preference: a block released on THIS thread's stream (safe by stream
+// order) or one nobody has work pending on (shard 0) -- the fast path, one shard lock each; then, one thread at a time: a block of a host thread
+// that has ended, behind one device-wide synchronisation (which moves every block released before it to shard 0, so this happens once per
+// generation of threads); a fresh hipMalloc; and only when the device is out of memory (or the pool is above its high-water mark) a block another
+// LIVE stream released, again behind a device-wide synchronisation.  Round 3 took any foreign block before trying hipMalloc: with N host threads
+// working on single objects (the reference's -c N mode) blocks migrated between threads all the time and every migration was a
+// hipDeviceSynchronize -- 16 threads ran at the speed of 3 (tests/cpp/he_bench_driver threads).
 static std::atomic<uint64_t> g_pool_mallocs{0};
 uint64_t MemoryPool::device_allocations() { return g_pool_mallocs.load(std::memory_order_relaxed); }
 
 void* MemoryPool::allocate(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
-    const uint64_t me = this_thread_tag();
-    // which: 0 = mine or nobody's, 1 = a dead thread's (returns the block WITHOUT taking it: the caller synchronises first)
-    auto take = [&](int which) -> void* {
-        std::lock_guard<std::mutex> lock(mutex_);
-        for (auto it = free_.lower_bound(bytes); it != free_.end() && it->first <= bytes * 2; ++it) {
-            for (size_t i = it->second.size(); i-- > 0;) {
-                const uint64_t o = it->second[i].owner;
-                if (which == 0 && o != me && o != 0) continue;
-                if (which == 1) { if (o != me && o != 0 && tag_is_dead(o)) return it->second[i].ptr; continue; }
-                void* found = it->second[i].ptr;
-                const size_t sz = it->first;
-                it->second.erase(it->second.begin() + static_cast<std::ptrdiff_t>(i));
-                if (it->second.empty()) free_.erase(it);
-                live_[found] = sz;
-                return found;
-            }
-        }
-        return nullptr;
-    };
-    if (void* p = take(0)) return p;
+    Shard& mine = *shard_of(this_thread_tag());
+    if (void* p = take_from(mine, bytes)) return p;
+    if (void* p = take_from(nobody_, bytes)) return p;
+    std::lock_guard<std::mutex> slow(slow_mutex_);
+    if (void* p = take_from(nobody_, bytes)) return p;       // another thread's device-wide wait may have filled shard 0 meanwhile
     hip_check(hipSetDevice(static_cast<int>(device_)), "malloc");
     // A device-wide synchronisation covers what was queued BEFORE it: the blocks in the free lists when it STARTS are then anybody's.  A block
-    // another thread releases while it drains (or after) may still have that thread's kernels pending and must keep its tag, so the tags
-    // are cleared only up to the release number read before the wait (round 4 cleared every tag afterwards: a block released during the
-    // wait could be handed to a different stream with work still pending on it).
+    // another thread releases while it drains (or after) may still have that thread's kernels pending and must keep its owner, so blocks move to
+    // shard 0 only up to the release number read before the wait (round 4 cleared every tag afterwards: a block released during the wait could be
+    // handed to a different stream with work still pending on it).
     auto sync_and_disown = [&] {
-        const uint64_t mark = release_mark();
+        const uint64_t mark = release_seq_.load(std::memory_order_acquire);
         hip_check(hipDeviceSynchronize(), "device_synchronize");
         disown(~uint64_t(0), mark);
     };
-    if (take(1)) {
+    if (dead_owner_has(bytes)) {
         sync_and_disown();
-        if (void* q = take(0)) return q;
+        if (void* q = take_from(nobody_, bytes)) return q;
+    }
+    const size_t cap = high_water_.load(std::memory_order_relaxed);
+    if (cap != 0 && held_bytes_.load(std::memory_order_relaxed) + bytes > cap) {
+        // above the high-water mark: reuse what other streams have released (one device-wide wait) before growing any further
+        sync_and_disown();
+        if (void* q = take_from(nobody_, bytes)) return q;
     }
     void* p = nullptr;
-    bool capped;
-    { std::lock_guard<std::mutex> lock(mutex_); capped = high_water_ != 0 && held_bytes_ + bytes > high_water_; }
-    if (capped) {
-        // above the high-water mark: reuse what other threads have released (one device-wide wait) before growing any further
-        sync_and_disown();
-        if (void* q = take(0)) return q;
-    }
     g_pool_mallocs.fetch_add(1, std::memory_order_relaxed);
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         sync_and_disown();
-        if (void* q = take(0)) return q;      // only blocks whose tag the wait cleared (or this thread's own)
+        if (void* q = take_from(nobody_, bytes)) return q;      // only blocks the wait covered
         release_unused();      // nothing of a fitting size: give the cache back and retry once
         hip_check(hipMalloc(&p, bytes), "malloc");
     }
-    std::lock_guard<std::mutex> lock(mutex_);
-    live_[p] = bytes;
-    held_bytes_ += bytes;
+    {
+        LiveShard& ls = live_shard(p);
+        std::lock_guard<std::mutex> lock(ls.m);
+        ls.map[p] = bytes;
+    }
+    held_bytes_.fetch_add(bytes, std::memory_order_relaxed);
     return p;
 }
 
 void MemoryPool::release(void* ptr) {
     if (!ptr) return;
+    size_t sz;
+    {
+        LiveShard& ls = live_shard(ptr);
+        std::lock_guard<std::mutex> lock(ls.m);
+        auto it = ls.map.find(ptr);
+        if (it == ls.map.end()) return;
+        sz = it->second;
+        ls.map.erase(it);
+    }
     const uint64_t me = this_thread_tag();
-    std::lock_guard<std::mutex> lock(mutex_);
-    auto it = live_.find(ptr);
-    if (it == live_.end()) return;
-    free_[it->second].push_back(FreeBlock{ptr, me, ++release_seq_});
-    live_.erase(it);
+    Shard& sh = *shard_of(me);
+    std::lock_guard<std::mutex> lock(sh.m);
+    sh.free_[sz].push_back(FreeBlock{ptr, me, release_seq_.fetch_add(1, std::memory_order_acq_rel) + 1});
 }
 
 void MemoryPool::release_unused() {
-    std::map<size_t, std::vector<FreeBlock>> drop;
-    {
-        std::lock_guard<std::mutex> lock(mutex_);
-        drop.swap(free_);
-        for (auto& kv : drop) held_bytes_ -= std::min(held_bytes_, kv.first * kv.second.size());
-    }
+    std::vector<void*> drop;
+    size_t bytes = 0;
+    auto take_all = [&](Shard& sh) {
+        std::lock_guard<std::mutex> lock(sh.m);
+        for (auto& kv : sh.free_) { for (auto& blk : kv.second) drop.push_back(blk.ptr); bytes += kv.first * kv.second.size(); }
+        sh.free_.clear();
+    };
+    take_all(nobody_);
+    for (auto& sp : stream_shards_) if (Shard* sh = sp.load(std::memory_order_acquire)) take_all(*sh);
+    { std::lock_guard<std::mutex> lock(table_mutex_); for (auto& kv : other_shards_) take_all(*kv.second); }
     if (drop.empty()) return;
+    held_bytes_.fetch_sub(std::min(bytes, held_bytes_.load(std::memory_order_relaxed)), std::memory_order_relaxed);
     (void)hipDeviceSynchronize();   // queued kernels may still read blocks released a moment ago
-    for (auto& kv : drop) for (auto& blk : kv.second) (void)hipFree(blk.ptr);
+    for (void* q : drop) (void)hipFree(q);
 }
 
 DynamicArray::DynamicArray(size_t count, bool device, MemoryPoolHandle pool) : size_(count), device_(device) {

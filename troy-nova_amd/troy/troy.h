@@ -139,7 +139,7 @@ using MemoryPoolHandle = std::shared_ptr<MemoryPool>;
 
 // Pooled device allocator: freed blocks are kept in per-size free lists and reused (the reference
 // uses a best-fit multimap, memory_pool_safe.in:119-148).  Thread safe.  Every host thread works on ONE stream per device for its
-// whole life -- one of a bounded set of streams per device that the threads share (default 8; TROY_STREAMS=<1..16>, or
+// whole life -- one of a bounded set of streams per device that the threads share (default 16, 8 once more than 16 host threads use the library; TROY_STREAMS=<1..16>, or
 // TROY_STREAMS=per-thread for hipStreamPerThread as in rounds 1-5) -- and a block may be released while kernels that use it are
 // still queued: a block carries the tag of the STREAM it was released on, and a thread that takes a block of its own stream
 // is safe by stream order; blocks of host threads that have ended (per-thread mode) are handed out after one
@@ -171,14 +171,28 @@ public:
     void set_high_water_bytes(size_t bytes);
     size_t held_bytes();                // live + cached bytes of this pool
 private:
-    uint64_t release_mark();            // number of the latest release (under the lock)
+    // The cached blocks live in one shard per OWNER tag (the stream they were released on; shard 0: nobody has work pending on them), each with its own lock,
+    // and the live blocks in a table sharded by address: threads on different streams never meet on a lock in the steady state, and a thread looks only at
+    // blocks it may take (round 5: one mutex and one free list for everybody -- every allocation walked past the other streams' blocks).  Measured on one GPU:
+    // no change at 16 / 64 host threads (what binds there is the dispatch path, profiles/r06_streams_ab.txt).  The slow path (fresh memory, device-wide waits) is serialised.
+    struct FreeBlock { void* ptr; uint64_t owner; uint64_t seq; };   // owner = tag it was released under, seq = number of that release
+    struct Shard { std::mutex m; std::map<size_t, std::vector<FreeBlock>> free_; };
+    struct LiveShard { std::mutex m; std::unordered_map<void*, size_t> map; };
+    static constexpr size_t LIVE_SHARDS = 64, STREAM_SHARDS = 256;
+    Shard* shard_of(uint64_t tag);                       // created on first use; never removed while the pool lives (except shards of ended threads, under the table lock)
+    void* take_from(Shard& s, size_t bytes);             // best fit with at most 2x slack, or null
+    bool dead_owner_has(size_t bytes);                   // some ended thread's shard holds a fitting block
+    LiveShard& live_shard(const void* p) { return live_[(reinterpret_cast<uintptr_t>(p) >> 8) % LIVE_SHARDS]; }
     size_t device_;
-    std::mutex mutex_;
-    struct FreeBlock { void* ptr; uint64_t owner; uint64_t seq; };   // owner = tag of the thread that released it, seq = number of that release
-    std::unordered_map<void*, size_t> live_;
-    std::map<size_t, std::vector<FreeBlock>> free_;
-    uint64_t release_seq_ = 0;
-    size_t held_bytes_ = 0, high_water_ = 0;
+    uint64_t id_;                                        // unique per pool object (thread-local shard caches are keyed by it)
+    Shard nobody_;                                       // owner 0
+    std::atomic<Shard*> stream_shards_[STREAM_SHARDS];   // owner tags of the per-device stream set (troy.cpp this_thread_tag)
+    std::mutex table_mutex_;                             // the shard table of every other tag (per-thread tags, the combining tag)
+    std::unordered_map<uint64_t, std::unique_ptr<Shard>> other_shards_;
+    LiveShard live_[LIVE_SHARDS];
+    std::mutex slow_mutex_;                              // one thread at a time on the slow path
+    std::atomic<uint64_t> release_seq_{0};
+    std::atomic<size_t> held_bytes_{0}, high_water_{0};
 };
 
 // Owning array of uint64_t on the host (malloc) or on a device (pool) -- src/utils/dynamic_array.h
