@@ -284,7 +284,7 @@ def kernel_sources_sha(names):
 KSMAC_SOURCES = ("ksmac_kernels.hpp", "dev_math_f64.hpp", "dev_math.hpp", "ntt_kernels.hpp", "troyn_ksmac2.hip", "launch.hpp", "troyn.hip")
 
 
-def counters_record(kernel_tag, batch):
+def counters_record(kernel_tag, batch, kernel_contains=None):
     """newest profiles/r*_<kernel_tag>_counters.json whose kernel sources are the ones being timed (a record of an older kernel is stale: dropped)"""
     sha = kernel_sources_sha(KSMAC_SOURCES)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.json" % kernel_tag)), reverse=True):
@@ -292,7 +292,7 @@ def counters_record(kernel_tag, batch):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("kernel_src_sha") == sha and rec.get("batch") == batch:
+        if rec.get("kernel_src_sha") == sha and rec.get("batch") == batch and (kernel_contains is None or kernel_contains in rec.get("kernel", "")):
             rec["_file"] = os.path.relpath(path, ROOT)
             return rec
     return None
@@ -432,7 +432,7 @@ def run_cfg3(args, torch, pkg, shard, entry, rank, world, device):
     items_per_launch = B if (fused and in_region_items != B) else in_region_items
     alg_bytes = ksmac_alg_bytes(items_per_launch, n, L, True, fused_chain=fused)
     achieved = alg_bytes / (ks_launch_ms * 1e-3) / 1e9 if ks_launch_ms else 0.0
-    prof = counters_record("ksmac", items_per_launch)   # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
+    prof = counters_record("ksmac", items_per_launch, "ksmac2_kernel<14")   # tools/profile_bench.sh + tools/collect_counters.py, separate rocprofv3 --pmc passes
     traffic, valu = None, None
     if prof:
         traffic = prof.get("traffic_bytes_per_launch")
@@ -821,11 +821,24 @@ def run_cfg4(args, torch, pkg, shard, entry, rank, world, device):
     # SURVEY 8d bytes per op: multiply 18.4 MB (operands 2 x 5 MB read + product 7.5 MB written, rounded as the survey does) + relinearize 70.8 MB with
     # the keys per op, 13.1 MB with the keys once per launch
     per_gpu = value / world
+    # counter bytes of the dominant launch (tools/profile_cfg4.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the guide prescribes; sha-locked);
+    # tensor_core_kernel is two launches per multiply (base q and base Bsk): the region brackets both, so both records are added
+    rec4 = counters_record("cfg4_ksmac", nb) if dominant_is_ks else counters_record("cfg4_tensor_bsk", nb)
+    traffic4 = rec4.get("traffic_bytes_per_launch") if rec4 else None
+    if rec4 and not dominant_is_ks:
+        rq = counters_record("cfg4_tensor_q", nb)
+        traffic4 = (traffic4 + rq["traffic_bytes_per_launch"]) if (traffic4 and rq and rq.get("traffic_bytes_per_launch")) else None
+    for tag, key in (("cfg4_ksmac", "ksmac2_kernel<15>"), ("cfg4_tensor_bsk", "tensor_core_kernel"), ("cfg4_tensor_q", "tensor_core_kernel")):
+        r_ = counters_record(tag, nb)
+        for kname, kd in kernels.items():
+            if r_ and kname.startswith(key) and r_.get("traffic_bytes_per_launch"):
+                kd["traffic_" + tag.split("_", 1)[1]] = r_["traffic_bytes_per_launch"]
     # `bound` = the contract's HBM figures of the dominant launch, timed in this run by the library's kernel timer; `limiter` = what binds it (FP64 butterflies
     # in ksmac2 / tensor_core_kernel, integer multiply-accumulates in the base conversions)
     roofline = {"bound": "hbm", "limiter": "valu_fp64" if dominant_is_ks else "valu_int",
                 "kernel": "ksmac2_kernel<15>" if dominant_is_ks else "tensor_core_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic4, "traffic_record": rec4["_file"] if rec4 else None,
+                "launch_ms": round(dom_ms, 4), "launches_timed": ks_n if dominant_is_ks else tn_n,
                 "algorithmic_bytes_per_launch": dom_alg, "kernels": kernels,
                 "valu_int": cfg4_valu_block(nb, n, L, S),
                 "pipeline": {"bytes_per_op_keys_per_op": 89.2e6, "frac_keys_per_op": round(per_gpu * 89.2e6 / (HBM_PEAK_GBS * 1e9), 4),

@@ -2,9 +2,9 @@
 # After `gpurun -- 'bash tools/profile_cfg4.sh r05_cfg4; bash tools/profile_bench.sh r05_bench; bash tools/prof_mixed_all.sh r05 pmc'`:
 # copies the sha-locked records and summaries from gpurun_out/ (scratch) into profiles/ (tracked) and rebuilds profiles/<tag>_mixed_summary.txt.
 # bench.py only attaches records whose source hash matches the tree, so this must run BEFORE the bench line that should carry them.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.."
-for f in ${TAG}_cfg4_valu.json ${TAG}_cfg4_summary.txt ${TAG}_bench_ksmac_counters.json ${TAG}_bench_chain_valu.json ${TAG}_bench_summary.txt ${TAG}_bench_two_streams_summary.txt; do
+for f in ${TAG}_cfg4_valu.json ${TAG}_cfg4_summary.txt ${TAG}_cfg4_ksmac_counters.json ${TAG}_cfg4_tensor_bsk_counters.json ${TAG}_cfg4_tensor_q_counters.json ${TAG}_bench_ksmac_counters.json ${TAG}_bench_chain_valu.json ${TAG}_bench_summary.txt ${TAG}_bench_two_streams_summary.txt; do
   cp gpurun_out/$f profiles/$f
 done
 python3 - "$TAG" <<'PY'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace + SQ counters of relinearize (and the fused chain) on chains with moduli >= 2^50 -> gpurun_out/<tag>_mixed_{trace,pmc}_<shape>.txt
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"

@@ -3,7 +3,7 @@
 # profiles/ keeps:  tools/profile_bench.sh <tag>   ->  gpurun_out/<tag>_summary.txt, gpurun_out/<tag>_ksmac_counters.json
 # Run through gpurun from the repository root:  gpurun -- 'bash tools/profile_bench.sh r02_bench_v1'
 set -e
-TAG=${1:-r05_bench}
+TAG=${1:-r06_bench}
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
