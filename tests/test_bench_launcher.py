@@ -73,3 +73,23 @@ def test_self_launcher_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["launches_timed"] == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("cfg3", ["--batch", "16", "--inner", "1"]), ("cfg4", ["--total", "6", "--batch", "2"])])
+def test_two_ranks_on_hardware_oversubscribed(workload, extra):
+    """SURVEY 8e on a one-GPU box: TWO rank processes through the self-launcher, both on the visible device, collectives over gloo (RCCL refuses a duplicate
+    device).  Everything but the transport is the real N > 1 path: fresh rank processes, rendezvous, key broadcast from rank 0, the block partition, evaluation on
+    the GPU in both ranks at once, max-over-ranks, the per-rank block of the line -- and rank 0's results equal the oracle's.  (Timings mean nothing here.)"""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--no-extra", "--cpu-seconds", "0"] + extra,
+             env_extra={"TROYN_BENCH_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = j["config"]
+    assert j["n_gpus"] == 2 and c["ranks"] == 2 and len(c["ms_per_step_per_rank"]) == 2 and len(c["devices"]) == 2 and "oversubscribed" in c
+    assert j["value"] > 0 and j["scaling"] == ("weak" if workload == "cfg3" else "strong")
+    assert "bit-exact" in j.get("parity", ""), j.get("parity")
+    if workload == "cfg4":
+        assert c["items_per_rank"] == [3, 3] and c["total_ops_per_step"] == 6
+    else:
+        assert c["ops_per_step"] == 2 * 16

@@ -1,7 +1,7 @@
 """Seeded shape x switch sweep against the oracle: the dispatch matrix of the library (arithmetic class per limb, ring
 size, level, batch-dependent workgroup orders, ~20 per-plan switches) has outgrown hand-picked parametrisations -- bugs in this kind of code
 live at shape x switch boundaries (batch not a multiple of 8, L = K - 1 vs lower levels, the <= 128-workgroup threshold).  One fixed seed,
-~1000 cases: N in 2^10 .. 2^15, K in 2 .. 12, bit sizes 27 .. 60 (mixed classes included), L in 1 .. K - 1, batch in {1, 2, 3, 5, 8, 12, 24, 64},
+~1000 cases: N in 2^10 .. 2^15 (3 % of the cases: 2^16 / 2^17, K <= 3, batch <= 3), K in 2 .. 12, bit sizes 27 .. 60 (mixed classes included), L in 1 .. K - 1, batch in {1, 2, 3, 5, 8, 12, 24, 64},
 scheme x form x assign method, and one random set of switches per case.  Operations: switch_key, relinearize, rescale / mod-switch, BEHZ
 multiply, the fused multiply -> relinearize -> rescale entry, multiply_plain_accumulate.  A failure prints a one-line reproducer
 (`SWEEP_CASE=<index> python -m pytest tests/test_gpu_sweep.py -m gpu -k one_case`).
@@ -51,7 +51,9 @@ def make_case(index):
     log_n = rng.choice((10, 11, 12, 13, 13, 14, 14, 15))
     if op == "bfv_multiply":
         log_n = rng.choice((10, 11, 12, 13, 13, 14, 15))
-    kmax = {10: 12, 11: 12, 12: 10, 13: 8, 14: 6, 15: 4}[log_n]
+    elif op != "plain_mac" and rng.random() < 0.03:
+        log_n = rng.choice((16, 17))        # the sizes above 32768 (utils/constants.h:13 allows 131072): the unfused key-switch chain, multi-pass transforms
+    kmax = {10: 12, 11: 12, 12: 10, 13: 8, 14: 6, 15: 4, 16: 3, 17: 3}[log_n]
     K = rng.randint(2, kmax)
     style = rng.choice(("narrow", "wide", "mixed", "mixed", "ckks_like", "any"))
     if style == "narrow":
@@ -69,6 +71,8 @@ def make_case(index):
     batch = rng.choice(BATCHES)
     if log_n == 15 and batch == 64 and K > 3:
         batch = 24
+    if log_n >= 16:
+        batch = min(batch, 3)
     scheme = rng.choice(("ckks", "bfv"))
     if op in ("rescale", "fused_chain"):
         scheme = "ckks"

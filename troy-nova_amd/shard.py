@@ -26,13 +26,27 @@ def broadcast_tensors(tensors, src=0):
     if not is_distributed():
         return tensors
     for t in tensors:
-        dist.broadcast(t, src=src)
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            # gloo moves host memory: stage through a CPU copy (test modes only; the product path is nccl = RCCL, device to device over xGMI)
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            if dist.get_rank() != src:
+                t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
     return tensors
+
+
+def _coll_device(device):
+    """where the small reduction tensors live: the rank's GPU under nccl (= RCCL), the host under gloo (CPU tests; the oversubscribed hardware test of
+    bench.py, where several ranks share one GPU and RCCL would refuse the duplicate device)"""
+    return "cpu" if dist.get_backend() == "gloo" else device
 
 
 def max_over_ranks(value, device="cpu"):
     if not is_distributed():
         return float(value)
+    device = _coll_device(device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -41,6 +55,7 @@ def max_over_ranks(value, device="cpu"):
 def sum_over_ranks(value, device="cpu"):
     if not is_distributed():
         return float(value)
+    device = _coll_device(device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
@@ -50,6 +65,7 @@ def gather_over_ranks(value, device="cpu"):
     """every rank's value, in rank order (the first multi-GPU run must be diagnosable: which rank was slow, by how much)"""
     if not is_distributed():
         return [float(value)]
+    device = _coll_device(device)
     mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
