@@ -236,6 +236,22 @@ def test_multithread_cpp_api(dev):
     assert r.returncode == 0 and "completed 32 wrong 0" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("streams,threads", [(None, 40), ("3", 12), ("per-thread", 12), ("16", 24)])
+def test_multithread_stream_sets_cpp_api(dev, streams, threads):
+    """Round 6: host threads share a bounded set of streams per device (troy.cpp current_stream(): 16 while <= 17 threads use the library, 8 above;
+    TROY_STREAMS=<n> | per-thread).  40 threads cross the threshold (threads move to another stream only when theirs has drained), 12 threads on 3 streams share
+    each stream four ways (blocks released by one thread are reused by its stream mates at once), per-thread is the mapping of rounds 1-5: every result of the
+    reference's multi-thread scenario (encrypt -> multiply -> relinearize -> rotate -> mod-switch -> decrypt) must still decrypt correctly."""
+    drv = os.path.join(ROOT, "tests", "cpp", "multithread_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/multithread_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = {k: v for k, v in os.environ.items() if k not in ("TROY_STREAMS", "TROY_COMBINE")}
+    if streams:
+        env["TROY_STREAMS"] = streams
+    r = subprocess.run([drv, str(threads), "6"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "completed %d wrong 0" % (threads * 6) in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_call_combining_stress_cpp_api(dev):
     """Call combining under ragged arrival: 24 host threads x 300 ops of random kind (three calls / fused / multiply alone) on two levels with
     random pauses, stream waits, late starters and early leavers; every result word-identical to the uncombined call, nothing hangs."""
