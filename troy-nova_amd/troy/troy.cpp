@@ -139,6 +139,24 @@ static inline hipStream_t pooled_stream(int q, int* slot_out = nullptr) {
 }
 }  // namespace detail
 
+// The threads that share a stream enter the library one at a time: a host mutex per stream around the launches of one multiply / relinearize / rescale /
+// fused call.  Without it they meet on the runtime's own per-stream lock launch by launch; with it 64 host threads run 26-29 k three-call / 43 k fused
+// ops/s instead of 22-25 k / 35-41 k (same session, profiles/r06_streams_ab.txt); neutral at 4 and 16 threads.  TROY_STREAM_GATE=0 switches it off.
+namespace detail {
+static bool stream_gate_on() { static const bool on = [] { const char* e = std::getenv("TROY_STREAM_GATE"); return !(e && e[0] == '0'); }(); return on; }
+static std::mutex* stream_gates() { static std::mutex* g = new std::mutex[MAX_POOL_DEVICES * MAX_POOL_STREAMS]; return g; }
+struct LaunchGate {
+    std::mutex* m = nullptr;
+    LaunchGate() {
+        if (!stream_gate_on() || combining_on()) return;
+        const int q = stream_pool_size();
+        int slot = 0;
+        if (q != 0 && pooled_stream(q, &slot)) { m = &stream_gates()[slot]; m->lock(); }
+    }
+    ~LaunchGate() { if (m) m->unlock(); }
+};
+}  // namespace detail
+
 static inline hipStream_t current_stream() {
     if (detail::combining_on()) if (hipStream_t s = detail::shared_stream()) if (on_shared_device()) return s;
     if (const int q = detail::stream_pool_size()) if (hipStream_t s = detail::pooled_stream(q)) return s;
@@ -1164,6 +1182,7 @@ void Evaluator::multiply(const Ciphertext& e1, const Ciphertext& e2, Ciphertext&
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
         troyn_check(troyn_bfv_multiply(bz, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
     } else {
+        detail::LaunchGate gate;
         troyn_check(troyn_dyadic_convolute(context_->plan(), 0, L, e1.data().raw_pointer(), p1, e2.data().raw_pointer(), p2, out.data().raw_pointer(), 1, current_stream()));
     }
     destination = std::move(out);
@@ -1307,9 +1326,11 @@ void Evaluator::relinearize_internal(const Ciphertext& encrypted, const RelinKey
         if (scheme == SchemeType::BGV) {
             const size_t K = context_->key_context_data().value()->parms().coeff_modulus().size();
             troyn_check(troyn_bgv_relinearize(context_->bgv(K), L, encrypted.data().raw_pointer(), ptrs.data(), out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
-        } else
+        } else {
+        detail::LaunchGate gate;
         troyn_check(troyn_relinearize(context_->plan(), L, scheme == SchemeType::CKKS, encrypted.is_ntt_form(), encrypted.data().raw_pointer(), ptrs.data(),
                                       out.data().raw_pointer(), ws.raw_pointer(), bytes, 1, current_stream()));
+        }
         destination = std::move(out);
         return;
     }
@@ -1377,6 +1398,7 @@ void Evaluator::mod_switch_scale_to_next_internal(const Ciphertext& encrypted, C
     } else {
         size_t bytes = troyn_divide_and_round_q_last_ntt_workspace_bytes(context_->plan(), L, pc, 1);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        detail::LaunchGate gate;
         troyn_check(troyn_divide_and_round_q_last_ntt(context_->plan(), L, encrypted.data().raw_pointer(), pc, out.data().raw_pointer(),
                                                       ws.raw_pointer(), bytes, 1, current_stream()));
     }
@@ -1502,8 +1524,11 @@ void Evaluator::multiply_relinearize_rescale(const Ciphertext& e1, const Ciphert
     }
     const size_t bytes = troyn_ckks_multiply_relinearize_rescale_workspace_bytes(context_->plan(), L, 1);
     utils::DynamicArray ws((bytes + 7) / 8, true, pool);
-    troyn_check(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, e1.data().raw_pointer(), e2.data().raw_pointer(), keys.data(), out.data().raw_pointer(),
-                                                        ws.raw_pointer(), bytes, 1, current_stream()));
+    {
+        detail::LaunchGate gate;
+        troyn_check(troyn_ckks_multiply_relinearize_rescale(context_->plan(), L, e1.data().raw_pointer(), e2.data().raw_pointer(), keys.data(), out.data().raw_pointer(),
+                                                            ws.raw_pointer(), bytes, 1, current_stream()));
+    }
     destination = std::move(out);
 }
 
