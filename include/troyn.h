@@ -246,6 +246,12 @@ int troyn_sample_uniform_multi(const troyn_plan* plan, uint32_t nmod, const uint
  * ------------------------------------------------------------------------------------- */
 int troyn_plain_centralize(const troyn_plan* plan, uint32_t L, uint64_t plain_modulus, const uint64_t* plain, size_t plain_coeff_count,
                            size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream);
+/* Evaluator::transform_plain_to_ntt (evaluator_transform_ntt.cu:35-70) as ONE launch: scaling_variant::centralize (utils/scaling_variant.cu:326-357) in the
+ * loader of the forward transform -- dest[batch][L][N] = NTT_j(centralize_j(plain[b])), the words troyn_plain_centralize + troyn_ntt give; the centred
+ * coefficient-form polynomial is never written and the zeros beyond plain_coeff_count are never read.  (Falls back to the two launches where the fused loader
+ * does not apply: N < 1024, or t not below every modulus.) */
+int troyn_plain_centralize_ntt(const troyn_plan* plan, uint32_t L, uint64_t plain_modulus, const uint64_t* plain, size_t plain_coeff_count,
+                               size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream);
 int troyn_dyadic_broadcast_product(const troyn_plan* plan, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
                                    const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream);
 /* Galois automorphism X -> X^g of `count` polynomials of nmod limbs each:

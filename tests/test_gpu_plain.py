@@ -154,3 +154,45 @@ def test_rotation_decrypts(O, pkg, dev):
         else:
             want = [((i + step) % row) + 1 for i in range(4)]
             assert dec[:4] == want and dec[row:row + 4] == [w + row for w in want]
+
+
+@pytest.mark.parametrize("n,bits,t,count,stride,batch", [
+    (8192, [60, 40, 40, 60], 1 << 21, 16, 16, 300),        # BASELINE config 5's weight blocks: 16 coefficients per plaintext, mixed chain (split by class, >= 512 limb-polys)
+    (8192, [60, 40, 40, 60], 1 << 21, 8192, 8192, 3),      # full plaintexts, a few: one launch of the integer kernels over all limbs
+    (8192, [40, 40, 40], 1032193, 100, 128, 5),            # row stride above the coefficient count, FP64 class
+    (16384, [50] * 4, 65537, 16384, 16384, 2),             # small launch: two-pass form of the transform
+    (16384, [50] * 4, 65537, 1000, 1000, 200),             # whole-limb tiles, half-word LDS variant of the plain forward kernel
+    (16384, [60, 50, 50, 60], (1 << 30) + 3, 77, 80, 150),
+    (32768, [50] * 3, 786433, 5000, 5000, 4),              # two passes: the loader acts in the strided first pass
+    (65536, [55, 56], 12289, 65536, 65536, 2),
+    (4096, [36, 36, 37], 40961, 4096, 4096, 7),
+    (1024, [30, 30], 12289, 10, 10, 9),
+    (64, [40, 40], 97, 64, 64, 3),                         # N < 1024: falls back to the two launches
+    (8192, [40, 40, 40], (1 << 45) + 59, 500, 500, 3),     # t not below every modulus: the general lift, two launches
+])
+def test_plain_centralize_ntt_one_launch(O, pkg, dev, n, bits, t, count, stride, batch):
+    """troyn_plain_centralize_ntt = Evaluator::transform_plain_to_ntt (evaluator_transform_ntt.cu:35-70): scaling_variant::centralize in the loader of the forward
+    transform.  Same words as the two calls (which the tests above pin to the oracle) and as the oracle's centralize + NTT directly; values at and around
+    the threshold (t + 1) / 2, 0 and t - 1 included; the coefficients beyond `count` are never read (poisoned here)."""
+    import torch
+    q = O.coeff_modulus_create(n, bits)
+    L = len(bits) - 1
+    ctx = O.Context("bfv", n, q, t)
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    rng = np.random.default_rng(n + count + batch)
+    plain = rng.integers(0, t, size=(batch, stride), dtype=np.uint64)
+    edge = np.array([0, 1, t - 1, (t + 1) // 2, (t + 1) // 2 - 1, (t + 1) // 2 + 1, t // 2], dtype=np.uint64)
+    plain[0, :min(len(edge), count)] = edge[:min(len(edge), count)]
+    plain[:, count:] = np.uint64(0xDEADBEEFDEADBEEF)       # padding between rows: must not enter the transform
+    dp = pkg.to_device(plain, dev)
+    got = pkg.to_host(plan.plain_centralize_ntt(L, t, dp, coeff_count=count))
+    # the two launches on zero-padded full rows
+    full = np.zeros((batch, n), dtype=np.uint64)
+    full[:, :count] = plain[:, :count]
+    two = pkg.to_host(plan.ntt(plan.plain_centralize(L, t, pkg.to_device(full, dev)), 1, L))
+    assert np.array_equal(got, two.reshape(got.shape))
+    fast = all(t < int(v) for v in q[:L])
+    for i in sorted({0, batch // 2, batch - 1}):
+        if fast:
+            want = ctx.to_ntt(ctx.plain_centralize(L, full[i])[None], 1, L)[0]
+            assert np.array_equal(got[i], want), i

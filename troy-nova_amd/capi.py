@@ -57,6 +57,7 @@ SYMBOLS = {
     "troyn_behz_working_base_size": (u32, [vp]),
     "troyn_behz_get_base_Bsk": (C.c_int, [vp, p64]),
     "troyn_plain_centralize": (C.c_int, [vp, u32, u64, vp, sz, sz, vp, sz, vp]),
+    "troyn_plain_centralize_ntt": (C.c_int, [vp, u32, u64, vp, sz, sz, vp, sz, vp]),
     "troyn_dyadic_broadcast_product": (C.c_int, [vp, u32, u32, vp, sz, vp, sz, vp, sz, vp]),
     "troyn_multiply_plain_accumulate_workspace_bytes": (sz, [sz]),
     "troyn_multiply_plain_accumulate": (C.c_int, [vp, u32, u32, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.c_int, vp, sz, vp]),

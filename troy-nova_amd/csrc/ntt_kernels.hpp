@@ -62,6 +62,9 @@ struct NttArgs {
     unsigned aux2_mod;                        // modulus index of the dropped prime q_{L-1}
     const ulonglong2* inv_table2;             // Shoup pairs of q_{L-1}^-1 mod q_j
     unsigned fused_mode;                      // 0, or the NttFused variant to launch
+    // ---- NTT_LOAD_CENTRALIZE: the input row is a plaintext modulo t, shared by the ncomp limbs (in_cstride = 0) ----
+    u64 cz_t;                                 // plain modulus (t < every modulus of the launch: the fast plain lift)
+    unsigned cz_count;                        // coefficients the plaintext holds; the rest of the row is zero and is not read
 };
 
 // Fused prologues: what a coefficient looks like when it enters the transform.
@@ -73,7 +76,12 @@ enum NttLoad {
     // utils/rns_tool.cu:523-550 (divide_and_round_q_last_ntt step 1): input = INTT of the last limb;
     // value = ((x + ql/2) mod ql) mod q_i - (ql/2 mod q_i)
     NTT_LOAD_RESCALE = 2,
+    // utils/scaling_variant.cu:326-357 (scaling_variant::centralize, fast plain lift t < q_j) in front of Evaluator::transform_plain_to_ntt
+    // (evaluator_transform_ntt.cu:35-70): input = plaintext coefficient m in [0, t), zero beyond the plaintext's length;
+    // value = m + (q_j - t) when m >= (t + 1) / 2, else m
+    NTT_LOAD_CENTRALIZE = 3,
 };
+constexpr int NTT_IOM_CENTRALIZE = 8;      // kernel variant (template parameter IOM of ntt_pass_kernel) that loads through NTT_LOAD_CENTRALIZE
 // Fused epilogues: what happens to a canonical NTT output y before it is stored.
 enum NttStore {
     NTT_STORE_PLAIN = 0,
@@ -136,6 +144,9 @@ struct NttIo {
     bool aux2_bigger;                    // ql > q
     ulonglong2 inv2;                     // Shoup pair of ql^-1 mod q
     bool ts_u64, tl_u64;                 // NTT_FLAG_TS_U64 / NTT_FLAG_TL_U64
+    // NTT_LOAD_CENTRALIZE
+    u64 cz_thr, cz_inc;                  // (t + 1) / 2 and q - t
+    unsigned cz_count;
 };
 
 __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsigned k, unsigned j, unsigned mi, u64* gout) {
@@ -145,7 +156,10 @@ __device__ __forceinline__ NttIo ntt_io_make(const NttArgs& a, unsigned b, unsig
     io.q = md.q; io.ratio_hi = md.ratio_hi;
     io.aux_q = 0; io.aux_ratio_hi = 0; io.aux_half = 0; io.fix = 0; io.aux_bigger = false; io.aux_wide = false;
     io.aux_qd = 0.0; io.aux_half_d = 0.0; io.hm_d = 0.0;
-    if (a.load_mode != NTT_LOAD_PLAIN) {
+    io.cz_thr = 0; io.cz_inc = 0; io.cz_count = 0;
+    if (a.load_mode == NTT_LOAD_CENTRALIZE) {
+        io.cz_thr = (a.cz_t + 1) >> 1; io.cz_inc = md.q - a.cz_t; io.cz_count = a.cz_count;
+    } else if (a.load_mode != NTT_LOAD_PLAIN) {
         const DevModulus ax = a.mods[a.aux_mod];
         io.aux_q = ax.q; io.aux_ratio_hi = ax.ratio_hi; io.aux_half = ax.q >> 1;
         const u64 half_mod = barrett64(io.aux_half, md.q, md.ratio_hi);
@@ -216,6 +230,7 @@ __device__ __forceinline__ u64 ntt_io_load(const NttIo& io, u64 raw) {
         if (io.aux_bigger) t = barrett64(t, io.q, io.ratio_hi);   // q_i < q_last
         return sub_mod(t, io.fix, io.q);
     }
+    if constexpr (LM == NTT_LOAD_CENTRALIZE) return raw >= io.cz_thr ? raw + io.cz_inc : raw;      // canonical: m + q - t < q
     return raw;
 }
 
@@ -471,6 +486,7 @@ struct ArithF64 {
     // fused prologue: T = (x + aux/2) mod aux, value = T - (aux/2 mod p)  (KS_ROUND adds p - (..), the same residue)
     template <int LM> static __device__ __forceinline__ elem load_io(const NttIo& io, u64 raw, bool, const Mod& m) {
         if constexpr (LM == NTT_LOAD_PLAIN) return f64_corr(f64_from_u64(raw), m.m);
+        else if constexpr (LM == NTT_LOAD_CENTRALIZE) return f64_corr(f64_from_u64(ntt_io_load<LM>(io, raw)), m.m);
         else {
             if (io.aux_wide) {
                 // the dropped prime has 50 bits or more ({40,40,60}: a wide special / last prime over narrow data limbs): the word does not
@@ -685,9 +701,9 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
     // gindex(x | y) = gindex(x) + gpart(y) for disjoint bit sets: the part of the index that a register number R contributes
     // is a compile-time constant
     auto gpart = [](unsigned loc) constexpr -> unsigned { return ((loc >> C) << (LOGN - LO - G)) | (loc & ((1u << C) - 1)); };
-    constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
+    constexpr int LM = (FIRST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_LOAD_KS_ROUND : IOM == 2 ? (int)NTT_LOAD_RESCALE : IOM == NTT_IOM_CENTRALIZE ? (int)NTT_LOAD_CENTRALIZE : (int)NTT_LOAD_PLAIN) : (int)NTT_LOAD_PLAIN;
     constexpr int SM = (LAST && !KSMAC && !INV) ? (IOM == 1 ? (int)NTT_STORE_KS_FINISH : IOM == 2 ? (int)NTT_STORE_RESCALE : (int)NTT_STORE_PLAIN) : (int)NTT_STORE_PLAIN;
-    constexpr bool FUSED = IOM >= 3;     // NttFused: kernels of the multiply -> relinearize -> rescale chain (loaders act in the first pass
+    constexpr bool FUSED = IOM >= 3 && IOM <= 7;     // NttFused: kernels of the multiply -> relinearize -> rescale chain (loaders act in the first pass
                                          // of a transform, epilogues in its last pass: one kernel for N <= 16384, two for N = 32768)
     constexpr bool F_MULPAIR = IOM == NTT_FUSED_MULPAIR && FIRST;
     constexpr bool F_LAST = IOM == NTT_FUSED_LAST_LIMB || IOM == NTT_FUSED_LAST_LIMB_W, F_TR = IOM == NTT_FUSED_TAIL_RESCALE || IOM == NTT_FUSED_TAIL_RESCALE_W;
@@ -851,6 +867,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttArgs& a, const KeyPtrs* k
                 constexpr unsigned GR = gpart((unsigned)R << S);
                 u64 raw;
                 if constexpr (KSMAC) raw = a.stream_loads ? nt_load(gin + gindex(locbase | ((unsigned)R << S))) : gin[gindex(locbase | ((unsigned)R << S))];
+                else if constexpr (LM == NTT_LOAD_CENTRALIZE) raw = ((lb0 >> 3) + GR < io.cz_count) ? ld_at(gin + GR, lb0) : 0ull;      // a plaintext shorter than N: zeros are not read
                 else raw = a.stream_loads ? nt_ld_at(gin + GR, lb0) : ld_at(gin + GR, lb0);
                 if constexpr (KSMAC) x[R] = A::load_first(raw, true, md);
                 else if constexpr (F_TR_LD) {

@@ -52,7 +52,8 @@ static void launch_variant(const NttArgs& a, dim3 grid, dim3 block, size_t extra
         // nobody to share the CU with and the full-word tile is the faster one (a single ciphertext: three calls 174 -> 154 us per op); an
         // explicit TROYN_NTT_HALF is obeyed at every size
         const int half = lc.half_mask >= 0 ? lc.half_mask : (grid.x > ntt_cu_count() ? 0x0167 : 0);     // (bit 6: NTT_FUSED_TAIL_RESCALE_W follows bit 5)
-        if ((half >> ((INV ? 8 : 0) + IOM)) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, lc.s, a); return; }
+        constexpr int half_bit = IOM == NTT_IOM_CENTRALIZE ? 0 : (INV ? 8 : 0) + IOM;                     // (the centralising loader follows the plain forward kernel)
+        if ((half >> half_bit) & 1) { hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, true>), grid, block, extra_lds, lc.s, a); return; }
     }
     hipLaunchKernelGGL((ntt_pass_kernel<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, IOM, false>), grid, block, extra_lds, lc.s, a);
 }
@@ -81,6 +82,12 @@ static void launch_pass(const NttArgs& a, size_t limb_polys, const LaunchCtx& lc
     if constexpr (INV && LAST) {
         if (sm == NTT_STORE_KS_FINISH) {   // coefficient-form key-switch tail: the finish runs in the inverse transform's epilogue
             launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, 1>(a, grid, block, (size_t)extra_lds, lc);
+            return;
+        }
+    }
+    if constexpr (!INV && FIRST) {
+        if (lm == NTT_LOAD_CENTRALIZE) {     // plaintext -> NTT form in one launch (troyn_plain_centralize_ntt)
+            launch_variant<A, LOGN, LO, G, TB, EB, INV, FIRST, LAST, NTT_IOM_CENTRALIZE>(a, grid, block, (size_t)extra_lds, lc);
             return;
         }
     }

@@ -2473,6 +2473,27 @@ extern "C" int troyn_plain_centralize(const troyn_plan* p, uint32_t L, uint64_t 
     return TROYN_OK;
 }
 
+extern "C" int troyn_plain_centralize_ntt(const troyn_plan* p, uint32_t L, uint64_t t, const uint64_t* plain, size_t plain_coeff_count,
+                                          size_t plain_bstride, uint64_t* dest, size_t batch, troyn_stream_t stream) {
+    select_device(p);
+    if (!p || !plain || !dest) return fail(TROYN_E_INVALID, "[Evaluator::transform_plain_to_ntt] null argument");
+    if (L < 1 || L > p->K) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] Destination has incorrect size.");
+    if (plain_coeff_count > p->n) return fail(TROYN_E_INVALID, "[scaling_variant::centralize] destination_coeff_count should no less than plain_coeff_count.");
+    if (batch == 0) return TROYN_OK;
+    bool fast = p->log_n >= 10 && t >= 2;
+    for (uint32_t j = 0; fast && j < L; j++) fast = t < p->moduli[j];
+    if (!fast) {
+        // the general lift (t not below every q_j) and the rings the optimised transforms do not cover: the two launches
+        if (int rc = troyn_plain_centralize(p, L, t, plain, plain_coeff_count, plain_bstride, dest, batch, stream)) return rc;
+        return troyn_ntt(p, 0, dest, dest, batch, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream);
+    }
+    // one forward launch whose loader reads the plaintext row (shared by the L limbs: component stride 0, the limbs of an item co-located on an XCD)
+    NttArgs a = contiguous_args(p, (const u64*)plain, (u64*)dest, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0);
+    a.in_cstride = 0; a.in_pstride = 0; a.in_bstride = (long long)plain_bstride;
+    a.load_mode = NTT_LOAD_CENTRALIZE; a.cz_t = t; a.cz_count = (unsigned)plain_coeff_count;
+    return launch_ntt(p, a, batch, false, (hipStream_t)stream);
+}
+
 extern "C" int troyn_dyadic_broadcast_product(const troyn_plan* p, uint32_t mod_start, uint32_t nmod, const uint64_t* ct, size_t pcount,
                                               const uint64_t* pt, size_t pt_bstride, uint64_t* out, size_t batch, troyn_stream_t stream) {
     select_device(p);

@@ -162,6 +162,17 @@ class Plan:
         capi.check(self.lib.troyn_plain_centralize(self.h, L, int(t), _ptr(plain), self.n, self.n, _ptr(out), batch, _stream()))
         return out
 
+    def plain_centralize_ntt(self, L, t, plain, coeff_count=None, out=None):
+        """plain [batch][stride] mod t (coeff_count <= stride <= N words used per row) -> NTT form [batch][L][N] in one launch
+        (Evaluator::transform_plain_to_ntt = scaling_variant::centralize + forward NTT)"""
+        stride = plain.shape[-1]
+        batch = plain.numel() // stride
+        cc = stride if coeff_count is None else int(coeff_count)
+        if out is None:
+            out = torch.empty((batch, L, self.n), dtype=torch.int64, device=plain.device)
+        capi.check(self.lib.troyn_plain_centralize_ntt(self.h, L, int(t), _ptr(plain), cc, stride, _ptr(out), batch, _stream()))
+        return out
+
     def dyadic_broadcast_product(self, ct, pcount, pt, nmod, shared_plain=False, mod_start=0, out=None):
         """ct [batch][pcount][nmod][N] (.) pt [batch][nmod][N] (or one shared [nmod][N])"""
         batch = ct.numel() // (pcount * nmod * self.n)

@@ -382,8 +382,7 @@ void Evaluator::multiply_plain_batched(const std::vector<const Ciphertext*>& enc
             hip_ok(hipMemcpyAsync(plains.raw_pointer() + i * n, plain[i]->poly(), plain[i]->coeff_count() * 8, hipMemcpyDeviceToDevice, stream()), "copy_device_to_device");
         }
         auto block = result_block(proto, count, pool);
-        troyn_check_public(troyn_plain_centralize(plan, L, t, plains.raw_pointer(), n, n, lifted.raw_pointer(), count, stream()));
-        troyn_check_public(troyn_ntt(plan, 0, lifted.raw_pointer(), lifted.raw_pointer(), count, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
+        troyn_check_public(troyn_plain_centralize_ntt(plan, L, t, plains.raw_pointer(), n, n, lifted.raw_pointer(), count, stream()));
         troyn_check_public(troyn_ntt(plan, 0, in, block->raw_pointer(), count, pcnt, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));
         troyn_check_public(troyn_dyadic_broadcast_product(plan, 0, L, block->raw_pointer(), pcnt, lifted.raw_pointer(), static_cast<size_t>(L) * n, block->raw_pointer(), count, stream()));
         troyn_check_public(troyn_ntt(plan, 1, block->raw_pointer(), block->raw_pointer(), count, pcnt, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, stream()));

@@ -238,8 +238,8 @@ std::vector<uint64_t> MatmulHelper::pack_input_blocks(uint64_t t, const uint64_t
 }
 
 Plain2d detail::encode_blocks_for_plain(const BatchEncoder& encoder, const std::vector<uint64_t>& packed, size_t rows, size_t cols, size_t len, MemoryPoolHandle pool) {
-    // encode_for_plain + ensure_ntt_form(centralize = true) (app/matmul.cu:14-70,:200-203): all blocks go through ONE copy, ONE
-    // centralize launch and ONE NTT launch; the plaintext objects are windows of the shared result buffer
+    // encode_for_plain + ensure_ntt_form(centralize = true) (app/matmul.cu:14-70,:200-203): all blocks go through ONE copy and ONE launch
+    // (the forward transform centralizes while it loads; of a block only its `len` coefficients are read); the plaintext objects are windows of the shared result buffer
     HeContextPointer context = encoder.context();
     if (!context->on_device()) throw std::invalid_argument("[MatmulHelper::encode_weights] HeContext is not on device (call to_device_inplace).");
     ContextDataPointer cd = context->first_context_data().value();
@@ -249,9 +249,7 @@ Plain2d detail::encode_blocks_for_plain(const BatchEncoder& encoder, const std::
     utils::DynamicArray staged(packed.size(), true, pool);
     staged.copy_from(packed.data(), packed.size(), false);
     auto shared = std::make_shared<utils::DynamicArray>(count * L * n, true, pool);
-    troyn_check_public(troyn_plain_centralize(context->plan(), static_cast<uint32_t>(L), t, staged.raw_pointer(), len, len, shared->raw_pointer(), count, troyn_current_stream()));
-    troyn_check_public(troyn_ntt(context->plan(), 0, shared->raw_pointer(), shared->raw_pointer(), count, 1, L, 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0,
-                                 troyn_current_stream()));
+    troyn_check_public(troyn_plain_centralize_ntt(context->plan(), static_cast<uint32_t>(L), t, staged.raw_pointer(), len, len, shared->raw_pointer(), count, troyn_current_stream()));
     troyn_sync_current_stream();     // `staged` returns to the pool
     Plain2d out;
     size_t idx = 0;

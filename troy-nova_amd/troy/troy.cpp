@@ -1599,9 +1599,9 @@ void Evaluator::transform_plain_to_ntt(const Plaintext& plain, const ParmsID& pa
     out.scale() = plain.scale();
     hipStream_t s = current_stream();
     if (plain.parms_id() == parms_id_zero) {
-        troyn_check(troyn_plain_centralize(context_->plan(), L, cd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n,
-                                           out.poly(), 1, s));
-        troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+        // scaling_variant::centralize in the loader of the forward transform: one launch, the centred polynomial is never written
+        troyn_check(troyn_plain_centralize_ntt(context_->plan(), L, cd->parms().plain_modulus().value(), plain.poly(), plain.coeff_count(), n,
+                                               out.poly(), 1, s));
     } else {
         if (plain.parms_id() != parms_id) throw std::invalid_argument(std::string(P) + " Plaintext parameters do not match.");
         if (plain.coeff_count() != n) {
