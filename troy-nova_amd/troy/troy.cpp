@@ -2020,12 +2020,16 @@ size_t Ciphertext::save_many(std::ostream& stream, const Ciphertext* const* cts,
     char* base = img.reserve(total);
     size_t off = 0;
     bool queued = false;
+    size_t queued_device = 0;
     for (size_t i = 0; i < count; i++) {
         const Ciphertext& c = *cts[i];
         std::memcpy(base + off, headers[i].data(), headers[i].size());
         off += headers[i].size();
         if (payload[i]) {
             if (c.on_device()) {
+                // (a batch that spans devices: the copies queued on one device's stream are waited for before the thread moves to the next device)
+                if (queued && c.data_.device_index() != queued_device) { hip_check(stream_wait(), "copy_device_to_host"); queued = false; }
+                queued_device = c.data_.device_index();
                 hip_check(hipSetDevice(static_cast<int>(c.data_.device_index())), "copy_device_to_host");
                 hip_check(hipMemcpyAsync(base + off, c.data_.raw_pointer(), payload[i] * 8, hipMemcpyDeviceToHost, current_stream()), "copy_device_to_host");
                 queued = true;
