@@ -2053,6 +2053,7 @@ void Ciphertext::load_many(std::istream& stream, Ciphertext* const* cts, size_t 
     // ciphertext.cu:152-210 per object.  Device-bound payloads (flag bit 2, or seeded: the seed is expanded on the device) go through the pinned
     // image; the seeded c1 polynomials of one shape are expanded by ONE troyn_sample_uniform_multi launch into a block the ciphertexts window.
     if (count == 0) return;
+    if (pool) hip_check(hipSetDevice(static_cast<int>(pool->get_device())), "copy_host_to_device");      // the pool's device: where the arrays live and the copies are queued
     const SchemeType scheme = context_scheme(context);
     struct Pending { Ciphertext* c; size_t words, img_off; bool seeded; };
     std::vector<Pending> dev;
