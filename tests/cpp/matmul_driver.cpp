@@ -76,6 +76,31 @@ int main(int argc, char** argv) {
         Cipher2d& sent = objective == MatmulObjective::EncryptRight ? wc : xe;
         sent.save(x_serialized, context);
         const size_t x_bytes = x_serialized.str().size();
+        // the batched wire path (Ciphertext::save_many / load_many) writes and reads exactly the bytes / words of the per-object calls
+        size_t wire_bad = 0;
+        {
+            std::stringstream manual;
+            const size_t nrows = sent.data().size();
+            manual.write(reinterpret_cast<const char*>(&nrows), sizeof(nrows));
+            for (const auto& row : sent.data()) {
+                const size_t cnt = row.size();
+                manual.write(reinterpret_cast<const char*>(&cnt), sizeof(cnt));
+                for (const Ciphertext& c : row) c.save(manual, context);
+            }
+            wire_bad += manual.str() != x_serialized.str();
+            std::stringstream again(x_serialized.str());
+            size_t tmp; again.read(reinterpret_cast<char*>(&tmp), sizeof(tmp));
+            Cipher2d batched = Cipher2d::load_new(x_serialized, context);
+            x_serialized.clear(); x_serialized.seekg(0);
+            for (size_t r = 0; r < nrows; r++) {
+                again.read(reinterpret_cast<char*>(&tmp), sizeof(tmp));
+                for (size_t c = 0; c < batched[r].size(); c++) {
+                    Ciphertext one = Ciphertext::load_new(again, context);
+                    wire_bad += one.data().to_vector() != batched[r][c].data().to_vector() || one.contains_seed() || batched[r][c].contains_seed() ||
+                                one.parms_id() != batched[r][c].parms_id() || one.is_ntt_form() != batched[r][c].is_ntt_form();
+                }
+            }
+        }
         sent = Cipher2d::load_new(x_serialized, context);
         if (objective == MatmulObjective::Crossed) wc.expand_seed(context);
         double t2b = now();
@@ -213,7 +238,8 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < got.size(); i++) bad += got[i] != want[i];
         std::printf("mismatches %zu of %zu\n", bad, got.size());
         std::printf("fly_mismatches %zu\n", fly_bad);
-        bad += fly_bad;
+        std::printf("wire_mismatches %zu\n", wire_bad);
+        bad += fly_bad + wire_bad;
         std::printf(bad ? "FAIL\n" : "OK\n");
         MemoryPool::Destroy();
         return bad ? 1 : 0;
