@@ -312,7 +312,7 @@ int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in, void* dst
 
 /* RLWE / LWE packing (evaluator_lwes.cu):
  *   troyn_negacyclic_shift     utils::negacyclic_shift_ps (utils/poly_small_mod.cu:927-968): multiply `count` RNS polynomials by
- *                              X^shift, shift in [0, 2N); out of place
+ *                              X^shift, any shift (taken modulo 2N as the reference does); out of place
  *   troyn_multiply_inv_degree  utils::ntt_multiply_inv_degree (utils/ntt.cu:93-134): x * N^-1 * scalar mod q_l
  *                              (Evaluator::divide_by_poly_modulus_degree_inplace, evaluator_lwes.cu:142-151)
  *   troyn_pack_prepare         first step of Evaluator::pack_rlwe_ciphertexts_new(_batched) (evaluator_lwes.cu:361-381, :599-640):

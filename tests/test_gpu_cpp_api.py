@@ -226,6 +226,20 @@ def test_bgv_cpp_api(dev):
     assert len(checks) >= 13 and all(ln.endswith(" 0") for ln in checks), r.stdout
 
 
+@pytest.mark.parametrize("scheme,n", [("bfv", 32), ("bgv", 32), ("bfv", 4096), ("bgv", 4096)])
+def test_lwe_cpp_api(dev, scheme, n):
+    """the reference's test/lwe.cu through the mirror: extract / assemble, pack_lwe_ciphertexts(_batched), pack_rlwe_ciphertexts(_batched) with its
+    parameter sets (N = 32, {60,40,40,60}, 20-bit t; shifts given as 2N + offset) and a larger ring, BFV and -- new in round 6 -- BGV (the packing tree keeps BGV's
+    key switch on NTT-form operands as the reference does, evaluator_lwes.cu:655-657); every result decrypts to the expected polynomial"""
+    drv = os.path.join(ROOT, "tests", "cpp", "lwe_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/lwe_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme, str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    checks = [ln for ln in r.stdout.splitlines() if ln.split()[-1].isdigit() and not ln.startswith("scheme")]
+    assert len(checks) >= 4 + 6 + 3 + 6 and all(ln.endswith(" 0") for ln in checks), r.stdout
+
+
 def test_multithread_cpp_api(dev):
     """test/test_multithread.cu's scenario: host threads sharing one context, keys and the global pool, each on its own
     per-thread stream; the Evaluator methods are const and re-entrant, the context generator is the only shared mutable state"""

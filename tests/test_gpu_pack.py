@@ -22,8 +22,8 @@ def test_shift_inv_degree_extract(O, pkg, dev, n, bits):
     da = pkg.to_device(a, dev)
     for shift in (0, 1, n - 1, n, n + 5, 2 * n - 1):
         assert np.array_equal(pkg.to_host(plan.negacyclic_shift(da, L, shift)), ctx.negacyclic_shift(L, a, shift)), shift
-    with pytest.raises(Exception):
-        plan.negacyclic_shift(da, L, 2 * n)
+    # (shift = 2N is the identity: the reference reduces the shift implicitly, test_negacyclic_shift_takes_any_shift below)
+    assert np.array_equal(pkg.to_host(plan.negacyclic_shift(da, L, 2 * n)), a)
     for scalar in (1, 2, n // 4):
         assert np.array_equal(pkg.to_host(plan.multiply_inv_degree(da, L, scalar)), ctx.multiply_inv_degree(L, a, scalar))
     b = ctx.random_ct(4, 2, L)
@@ -83,3 +83,18 @@ def test_pack_rlwe_decrypts(O, pkg, dev):
     for j, m in enumerate(msgs):
         want[j::I] = m[I - 1::I]
     assert np.array_equal(dec, want)
+
+
+def test_negacyclic_shift_takes_any_shift(O, pkg, dev):
+    """the reference reduces the shift implicitly (index (shift + k) & (N - 1), sign from bit log2 N: utils/poly_small_mod.cu:927-944); its own test packs with
+    shift = 2N + (a non-positive offset) (test/lwe.cu:223): shift = 2N is the identity, 2N + s == s, 3N == N (negation)"""
+    n, L = 1024, 2
+    q = O.coeff_modulus_create(n, [40, 40, 41])
+    ctx = O.Context("bfv", n, q, 65537)
+    plan = pkg.Plan(dev, 10, q)
+    x = ctx.random_ct(3, 2, L)
+    dx = pkg.to_device(x[None], dev)
+    base = {s: pkg.to_host(plan.negacyclic_shift(dx.view(-1, L, n), L, s)) for s in (0, 5, n)}
+    for s, ref in ((2 * n, 0), (2 * n + 5, 5), (3 * n, n), (4 * n + 5, 5)):
+        assert np.array_equal(pkg.to_host(plan.negacyclic_shift(dx.view(-1, L, n), L, s)), base[ref]), s
+    assert np.array_equal(base[0].reshape(x.shape), x)

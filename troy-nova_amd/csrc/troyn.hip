@@ -2550,7 +2550,7 @@ extern "C" int troyn_negacyclic_shift(const troyn_plan* p, uint32_t mod_start, u
     if (!p || !in || !out) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (in == out) return fail(TROYN_E_INVALID, std::string(P) + " the shift cannot run in place");
     if (nmod == 0 || mod_start + nmod > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus slice out of range");
-    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    shift %= 2ull * p->n;      // the reference takes any shift: index (shift + k) & (N - 1), sign from bit log2 N of shift + k (utils/poly_small_mod.cu:927-944)
     const size_t rows = count * nmod;
     if (rows == 0) return TROYN_OK;
     const unsigned ch = chunks_single(p->n);
@@ -2585,7 +2585,7 @@ extern "C" int troyn_pack_prepare(const troyn_plan* p, uint32_t L, size_t pcount
     const char* P = "[Evaluator::pack_rlwe_ciphertexts_new]";
     if (!p || !src || !out || !workspace) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
-    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    shift %= 2ull * p->n;      // the reference takes any shift: index (shift + k) & (N - 1), sign from bit log2 N of shift + k (utils/poly_small_mod.cu:927-944)
     if (slots == 0 || pcount == 0) return TROYN_OK;
     if (workspace_bytes < troyn_pack_prepare_workspace_bytes(slots)) return fail(TROYN_E_WORKSPACE, "[troyn_pack_prepare] workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -2606,7 +2606,7 @@ extern "C" int troyn_pack_layer(const troyn_plan* p, uint32_t L, uint64_t galois
     if (!p || !in || !out || !target) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
     if (L == 0 || L > p->K) return fail(TROYN_E_INVALID, std::string(P) + " modulus count out of range");
     if ((galois_element & 1) == 0 || galois_element >= 2ull * p->n) return fail(TROYN_E_INVALID, "[Evaluator::apply_galois_inplace] Galois element is not valid.");
-    if (shift >= 2ull * p->n) return fail(TROYN_E_INVALID, std::string(P) + " shift must be below 2N");
+    shift %= 2ull * p->n;      // the reference takes any shift: index (shift + k) & (N - 1), sign from bit log2 N of shift + k (utils/poly_small_mod.cu:927-944)
     if (pairs == 0) return TROYN_OK;
     // g^-1 mod 2N (g odd): Newton iteration on the 2-adic inverse
     const u64 two_n = 2ull * p->n;

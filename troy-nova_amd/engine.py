@@ -218,7 +218,7 @@ class Plan:
 
     # -- RLWE / LWE packing (evaluator_lwes.cu) -----------------------------------------------------
     def negacyclic_shift(self, x, nmod, shift, mod_start=0):
-        """x [count][nmod][N] * X^shift (utils::negacyclic_shift_ps), shift in [0, 2N)"""
+        """x [count][nmod][N] * X^shift (utils::negacyclic_shift_ps), any shift (modulo 2N)"""
         out = torch.empty_like(x)
         capi.check(self.lib.troyn_negacyclic_shift(self.h, mod_start, nmod, _ptr(x), _ptr(out), int(shift), x.numel() // (nmod * self.n), _stream()))
         return out

@@ -376,8 +376,7 @@ void Evaluator::pack_rlwe_ciphertexts_batched(const std::vector<std::vector<cons
     ContextDataPointer cd = level(P, context_, parms_id);
     const EncryptionParameters& parms = cd->parms();
     const SchemeType scheme = parms.scheme();
-    if (scheme == SchemeType::BGV) throw std::logic_error(std::string(P) + " BGV is not part of this build.");
-    const bool output_ntt_form = scheme == SchemeType::CKKS;
+    const bool output_ntt_form = scheme == SchemeType::CKKS || scheme == SchemeType::BGV;      // evaluator_lwes.cu:522
     const size_t n = parms.poly_modulus_degree();
     const uint32_t L = static_cast<uint32_t>(parms.coeff_modulus().size());
     if (input_interval > n) throw std::invalid_argument(std::string(P) + " input_interval must be less than poly_modulus_degree.");
@@ -399,6 +398,8 @@ void Evaluator::pack_rlwe_ciphertexts_batched(const std::vector<std::vector<cons
             if (group[j]->is_ntt_form() != input_ntt_form) throw std::invalid_argument(std::string(P) + at + " has different ntt_form.");
             if (group[j]->polynomial_count() != 2) throw std::invalid_argument(std::string(P) + at + " has different polynomial count.");
             if (scheme == SchemeType::CKKS && group[j]->scale() != group[0]->scale()) throw std::invalid_argument(std::string(P) + at + " has different scale.");
+            if (scheme == SchemeType::BGV && group[j]->correction_factor() != group[0]->correction_factor())
+                throw std::invalid_argument(std::string(P) + at + " has different correction factor.");      // evaluator_lwes.cu:566-570
         }
     }
     for (size_t layer = 0; layer < layers; layer++) {
@@ -447,6 +448,18 @@ void Evaluator::pack_rlwe_ciphertexts_batched(const std::vector<std::vector<cons
         if (keys.size() < L) throw std::invalid_argument("[Evaluator::switch_key_inplace_internal] Key switching key has too few components for this level.");
         const size_t bytes = troyn_switch_key_workspace_bytes(plan, L, pairs);
         utils::DynamicArray ws((bytes + 7) / 8, true, pool);
+        if (scheme == SchemeType::BGV) {
+            // BGV key switching is defined on NTT-form operands (its tail removes the special prime AND keeps the result a multiple of t:
+            // ski_util5, evaluator_keyswitching_core.cu:998-1030), so the reference transforms the odd member around apply_galois
+            // (evaluator_lwes.cu:655-657).  Here: the permuted c1 to NTT form, the BGV key switch into a temporary, back to coefficient
+            // form, added to the pair's sum -- the same words (key switching is linear in its target; the additions are exact).
+            const size_t K = context_->key_context_data().value()->parms().coeff_modulus().size();
+            utils::DynamicArray switched(pairs * words, true, pool);
+            troyn_check_public(troyn_ntt(plan, 0, target.raw_pointer(), target.raw_pointer(), pairs, 1, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+            troyn_check_public(troyn_bgv_switch_key(context_->bgv(K), L, target.raw_pointer(), keys.data(), TROYN_ASSIGN_OVERWRITE, switched.raw_pointer(), ws.raw_pointer(), bytes, pairs, s));
+            troyn_check_public(troyn_ntt(plan, 1, switched.raw_pointer(), switched.raw_pointer(), pairs, 2, L, 0, L, TROYN_IDX_COMPONENTWISE, 0, s));
+            troyn_check_public(troyn_add(plan, 0, L, next->raw_pointer(), switched.raw_pointer(), next->raw_pointer(), pairs * 2, s));
+        } else
         troyn_check_public(troyn_switch_key(plan, L, scheme == SchemeType::CKKS, 0, target.raw_pointer(), keys.data(), TROYN_ASSIGN_ADD_INPLACE, next->raw_pointer(),
                                             ws.raw_pointer(), bytes, pairs, s));
         // `target`, `ws` and the previous buffer return to the pool here: stream order protects them (same thread, same stream), no wait per layer
