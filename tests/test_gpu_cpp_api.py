@@ -240,6 +240,19 @@ def test_lwe_cpp_api(dev, scheme, n):
     assert len(checks) >= 4 + 6 + 3 + 6 and all(ln.endswith(" 0") for ln in checks), r.stdout
 
 
+@pytest.mark.parametrize("scheme", ["bfv", "bgv", "ckks"])
+@pytest.mark.parametrize("n", [32, 8192])
+def test_special_prime_for_encryption_cpp_api(dev, scheme, n):
+    """the reference's test/special_prime_for_encryption.cu:16-70: EncryptionParameters::set_use_special_prime_for_encryption(true) makes the first level the key
+    level (he_context.cu:77) -- fresh ciphertexts carry all four primes of {60,40,40,60}; asymmetric and symmetric encryption decrypt to the message, and an
+    addition at that level works"""
+    drv = os.path.join(ROOT, "tests", "cpp", "special_prime_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/special_prime_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme, str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "first_is_key_level 1 first_limbs 4" in r.stdout and "mismatches 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_multithread_cpp_api(dev):
     """test/test_multithread.cu's scenario: host threads sharing one context, keys and the global pool, each on its own
     per-thread stream; the Evaluator methods are const and re-entrant, the context generator is the only shared mutable state"""
