@@ -212,6 +212,20 @@ static int run_pool() {
         ok &= capped ? (held == block && mallocs == 1) : (held == 2 * block && mallocs == 2);      // capped: A's block reused after one device-wide wait
         ok &= mallocs2 == mallocs ? 1 : 0;
     }
+    // test/multithread.cu:23-55 (MultithreadTest.DeviceAllocate): 64 threads allocate at the same time, 4 rounds; no two live arrays share an address
+    {
+        size_t clashes = 0;
+        for (int round = 0; round < 4; round++) {
+            std::vector<utils::DynamicArray> arrays(64);
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < 64; i++) th.emplace_back([&arrays, i] { arrays[i] = utils::DynamicArray(64, true); });
+            for (auto& x : th) x.join();
+            for (size_t i = 0; i < 64; i++)
+                for (size_t j = i + 1; j < 64; j++) clashes += arrays[i].raw_pointer() == arrays[j].raw_pointer() || !arrays[i].raw_pointer();
+        }
+        std::printf("pool_concurrent_allocate_clashes %zu\n", clashes);
+        ok &= clashes == 0;
+    }
     std::printf(ok ? "OK\n" : "FAIL\n");
     MemoryPool::Destroy();
     return ok ? 0 : 1;

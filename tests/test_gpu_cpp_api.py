@@ -253,6 +253,19 @@ def test_special_prime_for_encryption_cpp_api(dev, scheme, n):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "first_is_key_level 1 first_limbs 4" in r.stdout and "mismatches 0" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("scheme", ["bfv", "bgv", "ckks"])
+def test_every_call_uses_the_pool_it_is_given(dev, scheme):
+    """the idea of the reference's test/multithread.cu:1250-1340 (SharedContextMultiPools), sharpened: the context's pool AND the global pool are set to deny
+    (MemoryPool::deny, utils/memory_pool.h:100 -- added to the mirror in round 6 with the rest of the reference's pool surface), then four host threads with a pool
+    each run the encoder / Encryptor / Decryptor / Evaluator / LWE / KeyGenerator calls with that pool: every result reports that pool and is correct, and no
+    internal temporary falls back to another pool (it would throw) -- what makes the multi-device mode (pool i on device i) safe"""
+    drv = os.path.join(ROOT, "tests", "cpp", "pools_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/pools_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "failures 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_multithread_cpp_api(dev):
     """test/test_multithread.cu's scenario: host threads sharing one context, keys and the global pool, each on its own
     per-thread stream; the Evaluator methods are const and re-entrant, the context generator is the only shared mutable state"""
@@ -314,7 +327,7 @@ def test_pool_high_water_mark_cpp_api(dev):
     r = subprocess.run([drv, "pool"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
-    assert kv["pool_uncapped_held_MB"][0] == "96" and kv["pool_capped_held_MB"][0] == "48", r.stdout
+    assert kv["pool_uncapped_held_MB"][0] == "96" and kv["pool_capped_held_MB"][0] == "48" and kv["pool_concurrent_allocate_clashes"][0] == "0", r.stdout
 
 
 def test_multi_device_mode_cpp_api(dev):

@@ -358,7 +358,21 @@ void MemoryPool::Destroy() {
 static std::atomic<uint64_t> g_pool_mallocs{0};
 uint64_t MemoryPool::device_allocations() { return g_pool_mallocs.load(std::memory_order_relaxed); }
 
+void MemoryPool::set_device() { hip_check(hipSetDevice(static_cast<int>(device_)), "set_device"); }
+
+void MemoryPool::destroy() {
+    // memory_pool_safe.in:168-205: cached blocks and blocks still handed out are freed (the latter become dangling in their owners, as in the reference)
+    release_unused();
+    (void)hipDeviceSynchronize();
+    for (auto& ls : live_) {
+        std::lock_guard<std::mutex> lock(ls.m);
+        for (auto& kv : ls.map) { (void)hipFree(kv.first); held_bytes_.fetch_sub(std::min(kv.second, held_bytes_.load()), std::memory_order_relaxed); }
+        ls.map.clear();
+    }
+}
+
 void* MemoryPool::allocate(size_t bytes) {
+    if (denying_.load(std::memory_order_relaxed)) throw std::runtime_error("[MemoryPool(safe)::get] DEBUG: The pool is denying allocation.");
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
     Shard& mine = *shard_of(this_thread_tag());

@@ -22,6 +22,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <complex>
 #include <cstdint>
 #include <cstring>
@@ -158,6 +159,15 @@ public:
     static MemoryPoolHandle GlobalPool();
     static void Destroy();   // releases the global pool; call before exit (reference readme.md:129)
     size_t get_device() const { return device_; }
+    // the rest of the reference's public surface (utils/memory_pool.h:91-140)
+    static int implementation_type() { return 2; }                 // the thread-safe pool (memory_pool_safe.in:11)
+    void set_device();                                             // makes the pool's device current
+    void deny(bool set = true) { denying_.store(set, std::memory_order_relaxed); }      // debugging aid: every further allocation throws (memory_pool_safe.in:120-122)
+    void destroy();                                                // frees everything the pool holds, cached or handed out (memory_pool_safe.in:168-205)
+    void force_set_thread_id(std::thread::id) {}                   // (the reference re-tags its cached blocks; here blocks are tagged by stream, nothing to re-tag)
+    static void* Allocate(size_t bytes) { return GlobalPool()->allocate(bytes); }
+    static void Free(void* ptr) { GlobalPool()->release(ptr); }
+    static void ReleaseUnused() { GlobalPool()->release_unused(); }
     void* allocate(size_t bytes);
     void release(void* ptr);
     void release_unused();
@@ -193,6 +203,7 @@ private:
     std::mutex slow_mutex_;                              // one thread at a time on the slow path
     std::atomic<uint64_t> release_seq_{0};
     std::atomic<size_t> held_bytes_{0}, high_water_{0};
+    std::atomic<bool> denying_{false};
 };
 
 // Owning array of uint64_t on the host (malloc) or on a device (pool) -- src/utils/dynamic_array.h
