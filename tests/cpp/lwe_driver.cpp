@@ -42,6 +42,25 @@ int main(int argc, char** argv) {
         auto dec = [&](const Ciphertext& c) { return encoder.decode_polynomial_new(decryptor.decrypt_new(c)); };
         std::printf("scheme %s n %zu t %llu\n", bgv ? "bgv" : "bfv", n, (unsigned long long)t);
 
+        {   // the encoders' *_slice forms (batch_encoder.h:55-131): host and device views give the words of the vector forms
+            const std::vector<uint64_t> m = random_poly();
+            const Plaintext want = encoder.encode_new(m), want_poly = encoder.encode_polynomial_new(m);
+            utils::DynamicArray dm = utils::DynamicArray::from_vector(m);
+            dm.to_device_inplace(MemoryPool::GlobalPool());
+            const utils::ConstSlice<uint64_t> host_view(m.data(), m.size(), false), dev_view(dm.raw_pointer(), dm.size(), true);
+            check("encode_slice_host", encoder.encode_slice_new(host_view).data().to_vector(), want.data().to_vector());
+            check("encode_slice_device", encoder.encode_slice_new(dev_view).data().to_vector(), want.data().to_vector());
+            check("encode_polynomial_slice_device", encoder.encode_polynomial_slice_new(dev_view).data().to_vector(), want_poly.data().to_vector());
+            check("decode_slice_new", encoder.decode_slice_new(want).to_vector(), m);
+            utils::DynamicArray back(n, true, MemoryPool::GlobalPool());
+            encoder.decode_slice(want, utils::Slice<uint64_t>(back.raw_pointer(), back.size(), true));
+            check("decode_slice_device", back.to_vector(), m);
+            std::vector<uint64_t> hb(n);
+            encoder.decode_polynomial_slice(want_poly, utils::Slice<uint64_t>(hb.data(), hb.size(), false));
+            check("decode_polynomial_slice_host", hb, m);
+            std::vector<Plaintext> many = encoder.encode_slice_new_batched({host_view, dev_view});
+            check("encode_slice_new_batched", many[1].data().to_vector(), want.data().to_vector());
+        }
         {   // test_extract_lwe
             const std::vector<uint64_t> m = random_poly();
             Ciphertext c = enc(m);

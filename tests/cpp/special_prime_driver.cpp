@@ -40,6 +40,19 @@ int main(int argc, char** argv) {
             std::uniform_real_distribution<double> U(-10.0, 10.0);
             for (auto& v : m) v = {U(gen), U(gen)};
             Plaintext p = encoder.encode_complex64_simd_new(m, std::nullopt, scale);
+            {   // the *_slice forms (ckks_encoder.h:93-283) give the words of the vector forms
+                const Plaintext ps = encoder.encode_complex64_simd_slice_new(utils::ConstSlice<std::complex<double>>(m.data(), m.size(), false), std::nullopt, scale);
+                bad += ps.data().to_vector() != p.data().to_vector();
+                const std::vector<std::complex<double>> a = encoder.decode_complex64_simd_new(p), b = encoder.decode_complex64_simd_slice_new(p).to_vector();
+                bad += a != b;
+                std::vector<double> coeffs(2 * m.size());
+                for (size_t i = 0; i < coeffs.size(); i++) coeffs[i] = 0.25 * (double)(i % 17) - 1.0;
+                const Plaintext pf = encoder.encode_float64_polynomial_new(coeffs, std::nullopt, scale);
+                bad += encoder.encode_float64_polynomial_slice_new(utils::ConstSlice<double>(coeffs.data(), coeffs.size(), false), std::nullopt, scale).data().to_vector() != pf.data().to_vector();
+                std::vector<double> out(coeffs.size());
+                encoder.decode_float64_polynomial_slice(pf, utils::Slice<double>(out.data(), out.size(), false));
+                bad += out != encoder.decode_float64_polynomial_new(pf);
+            }
             for (int sym = 0; sym < 2; sym++) {
                 Ciphertext c = sym ? encryptor.encrypt_symmetric_new(p, false) : encryptor.encrypt_asymmetric_new(p);
                 if (c.coeff_modulus_size() != 4) bad++;

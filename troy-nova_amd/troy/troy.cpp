@@ -180,6 +180,17 @@ namespace utils { void stream_sync() { troyn_sync_current_stream(); } }   // uti
 
 namespace utils {
 
+void slice_bytes_to_host(const void* src, bool src_on_device, void* dst, size_t bytes) {
+    if (!src_on_device) { std::memcpy(dst, src, bytes); return; }
+    hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, current_stream()), "copy_device_to_host");
+    hip_check(stream_wait(), "copy_device_to_host");
+}
+void host_bytes_to_slice(void* dst, bool dst_on_device, const void* src, size_t bytes) {
+    if (!dst_on_device) { std::memcpy(dst, src, bytes); return; }
+    hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, current_stream()), "copy_host_to_device");
+    hip_check(stream_wait(), "copy_host_to_device");       // `src` is the caller's (often a temporary)
+}
+
 size_t device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;   // memory_pool.h:14-33: no usable device -> 0

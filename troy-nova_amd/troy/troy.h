@@ -120,12 +120,27 @@ public:
     }
     static Array create_and_copy_from_slice(ConstSlice<T> source, bool on_device = false, std::shared_ptr<MemoryPool> pool = nullptr) { Array a(source.size(), on_device, pool); a.copy_from_slice(source); return a; }
     ConstSlice<T> const_reference() const { return ConstSlice<T>(data_.data(), data_.size(), false); }
+    Slice<T> reference() { return Slice<T>(data_.data(), data_.size(), false); }
     std::vector<T> to_vector() const { return data_; }
     T* raw_pointer() { return data_.data(); }
     const T* raw_pointer() const { return data_.data(); }
 private:
     std::vector<T> data_;
 };
+// bytes between a slice (host or device) and host memory: what the encoders' *_slice forms stage through (troy.cpp)
+void slice_bytes_to_host(const void* src, bool src_on_device, void* dst, size_t bytes);
+void host_bytes_to_slice(void* dst, bool dst_on_device, const void* src, size_t bytes);
+template <typename T> std::vector<T> slice_to_vector(ConstSlice<T> s) {
+    std::vector<T> v(s.size());
+    if (s.size()) slice_bytes_to_host(s.raw_pointer(), s.on_device(), v.data(), s.size() * sizeof(T));
+    return v;
+}
+template <typename T> void vector_to_slice(const std::vector<T>& v, Slice<T> d, const char* prompt) {
+    if (d.size() < v.size()) throw std::invalid_argument(std::string(prompt) + " destination is too small.");
+    if (!v.empty()) host_bytes_to_slice(d.raw_pointer(), d.on_device(), v.data(), v.size() * sizeof(T));
+}
+template <typename T> using ConstSliceVec = std::vector<ConstSlice<T>>;
+template <typename T> using SliceVec = std::vector<Slice<T>>;
 }  // namespace utils
 
 // ----------------------------------------------------------------------------------------------
@@ -920,6 +935,40 @@ public:
     std::vector<uint64_t> decode_polynomial_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     void encode_polynomial(const std::vector<uint64_t>& values, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encode_polynomial_new(values, pool); }
     void decode_polynomial(const Plaintext& plain, std::vector<uint64_t>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = decode_polynomial_new(plain, pool); }
+    // the *_slice forms (batch_encoder.h:55-131): the values come from / go to a (pointer, length) view that may live on the host or on the device
+    void encode_slice(utils::ConstSlice<uint64_t> values, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encode(utils::slice_to_vector(values), destination, pool); }
+    Plaintext encode_slice_new(utils::ConstSlice<uint64_t> values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_slice(values, p, pool); return p; }
+    void encode_slice_batched(const utils::ConstSliceVec<uint64_t>& values, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (values.size() != destination.size()) throw std::invalid_argument("[BatchEncoder::encode_slice_batched] values and destination size mismatch.");
+        for (size_t i = 0; i < values.size(); i++) encode_slice(values[i], *destination[i], pool);
+    }
+    std::vector<Plaintext> encode_slice_new_batched(const utils::ConstSliceVec<uint64_t>& values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<Plaintext> d(values.size());
+        for (size_t i = 0; i < values.size(); i++) encode_slice(values[i], d[i], pool);
+        return d;
+    }
+    void encode_polynomial_slice(utils::ConstSlice<uint64_t> values, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { destination = encode_polynomial_new(utils::slice_to_vector(values), pool); }
+    Plaintext encode_polynomial_slice_new(utils::ConstSlice<uint64_t> values, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return encode_polynomial_new(utils::slice_to_vector(values), pool); }
+    void decode_slice(const Plaintext& plaintext, utils::Slice<uint64_t> destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (destination.size() != slots_) throw std::invalid_argument("[BatchEncoder::decode_slice] Destination has incorrect size.");
+        utils::vector_to_slice(decode_new(plaintext, pool), destination, "[BatchEncoder::decode_slice]");
+    }
+    utils::Array<uint64_t> decode_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::Array<uint64_t>(decode_new(plaintext, pool)); }
+    void decode_slice_batched(const std::vector<const Plaintext*>& plaintexts, const std::vector<utils::Slice<uint64_t>>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (plaintexts.size() != destination.size()) throw std::invalid_argument("[BatchEncoder::decode_slice_batched] plaintexts and destination size mismatch.");
+        for (size_t i = 0; i < plaintexts.size(); i++) decode_slice(*plaintexts[i], destination[i], pool);
+    }
+    std::vector<utils::Array<uint64_t>> decode_slice_new_batched(const std::vector<const Plaintext*>& plaintexts, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        std::vector<utils::Array<uint64_t>> d;
+        for (const Plaintext* p : plaintexts) d.push_back(decode_slice_new(*p, pool));
+        return d;
+    }
+    void decode_polynomial_slice(const Plaintext& plaintext, utils::Slice<uint64_t> destination) const {
+        const std::vector<uint64_t> v = decode_polynomial_new(plaintext);
+        if (destination.size() != v.size()) throw std::invalid_argument("[BatchEncoder::decode_polynomial_slice] Destination has incorrect size.");
+        utils::vector_to_slice(v, destination, "[BatchEncoder::decode_polynomial_slice]");
+    }
+    utils::Array<uint64_t> decode_polynomial_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::Array<uint64_t>(decode_polynomial_new(plaintext, pool)); }
     constexpr size_t row_count() const noexcept { return 2; }
     size_t column_count() const noexcept { return slots_ / 2; }
     bool simd_encoding_supported() const { return !matrix_reps_index_map_.empty(); }
@@ -998,6 +1047,34 @@ public:
     void decode_float64_polynomial(const Plaintext& plain, std::vector<double>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     std::vector<double> decode_float64_polynomial_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
         std::vector<double> v; decode_float64_polynomial(plain, v, pool); return v;
+    }
+    // the *_slice forms (ckks_encoder.h:93-283): values from / to host or device views
+    void encode_complex64_simd_slice(utils::ConstSlice<std::complex<double>> values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
+                                     MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encode_complex64_simd(utils::slice_to_vector(values), parms_id, scale, destination, pool); }
+    Plaintext encode_complex64_simd_slice_new(utils::ConstSlice<std::complex<double>> values, std::optional<ParmsID> parms_id, double scale,
+                                              MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_complex64_simd_slice(values, parms_id, scale, p, pool); return p; }
+    void encode_float64_polynomial_slice(utils::ConstSlice<double> values, std::optional<ParmsID> parms_id, double scale, Plaintext& destination,
+                                         MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encode_float64_polynomial(utils::slice_to_vector(values), parms_id, scale, destination, pool); }
+    Plaintext encode_float64_polynomial_slice_new(utils::ConstSlice<double> values, std::optional<ParmsID> parms_id, double scale,
+                                                  MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; encode_float64_polynomial_slice(values, parms_id, scale, p, pool); return p; }
+    void encode_integer64_polynomial_slice(utils::ConstSlice<int64_t> values, std::optional<ParmsID> parms_id, Plaintext& destination,
+                                           MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { encode_integer64_polynomial(utils::slice_to_vector(values), parms_id, destination, pool); }
+    Plaintext encode_integer64_polynomial_slice_new(utils::ConstSlice<int64_t> values, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        Plaintext p; encode_integer64_polynomial_slice(values, parms_id, p, pool); return p;
+    }
+    void decode_complex64_simd_slice(const Plaintext& plain, utils::Slice<std::complex<double>> destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (destination.size() != slots_) throw std::invalid_argument("[ckks_encoder::decode_complex64_simd_slice] destination size must be equal to slot_count.");
+        utils::vector_to_slice(decode_complex64_simd_new(plain, pool), destination, "[ckks_encoder::decode_complex64_simd_slice]");
+    }
+    utils::Array<std::complex<double>> decode_complex64_simd_slice_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        return utils::Array<std::complex<double>>(decode_complex64_simd_new(plain, pool));
+    }
+    void decode_float64_polynomial_slice(const Plaintext& plain, utils::Slice<double> destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (destination.size() != slots_ * 2) throw std::invalid_argument("[ckks_encoder::decode_float64_polynomial_slice] destination size must be equal to slot_count * 2.");
+        utils::vector_to_slice(decode_float64_polynomial_new(plain, pool), destination, "[ckks_encoder::decode_float64_polynomial_slice]");
+    }
+    utils::Array<double> decode_float64_polynomial_slice_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        return utils::Array<double>(decode_float64_polynomial_new(plain, pool));
     }
 private:
     void set_plaintext(const std::vector<double>& coeffs, const ParmsID& parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool) const;
