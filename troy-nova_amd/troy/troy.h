@@ -313,6 +313,9 @@ public:
     uint64_t reduce_mul_uint64(uint64_t operand1, uint64_t operand2) const {                 // modulus.h:86-92 (Barrett-128; the canonical residue)
         return static_cast<uint64_t>((static_cast<unsigned __int128>(operand1) * operand2) % value_);
     }
+    uint64_t reduce_uint128(unsigned __int128 value) const { return static_cast<uint64_t>(value % value_); }      // modulus.h:43-84: the canonical residue of a 128-bit value
+    uint64_t reduce_uint128_limbs(utils::ConstSlice<uint64_t> input) const { return reduce_uint128((static_cast<unsigned __int128>(input[1]) << 64) | input[0]); }
+    uint64_t uint64_count() const { return 1; }                                                                  // modulus.h:105-107
 private:
     uint64_t value_ = 0;
     uint64_t const_ratio_[3] = {0, 0, 0};
@@ -595,6 +598,17 @@ public:
     utils::Slice<uint64_t> poly() { return utils::Slice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }
     utils::ConstSlice<uint64_t> poly() const { return utils::ConstSlice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }
     utils::ConstSlice<uint64_t> const_poly() const { return poly(); }
+    // plaintext.h:123-170: the data array; limb `index` of an RNS plaintext (a mod-t plaintext has the one component 0); the whole polynomial
+    const utils::DynamicArray& const_data() const noexcept { return data_; }
+    utils::ConstSlice<uint64_t> component(size_t index) const {
+        if (parms_id_ == parms_id_zero) { if (index != 0) throw std::out_of_range("[Plaintext::component] Index out of range"); return poly(); }
+        return poly().const_slice(index * coeff_count_, (index + 1) * coeff_count_);
+    }
+    utils::Slice<uint64_t> component(size_t index) {
+        if (parms_id_ == parms_id_zero) { if (index != 0) throw std::out_of_range("[Plaintext::component] Index out of range"); return poly(); }
+        return poly().slice(index * coeff_count_, (index + 1) * coeff_count_);
+    }
+    utils::ConstSlice<uint64_t> const_component(size_t index) const { return component(index); }
     utils::ConstSlice<uint64_t> const_reference() const { return poly(); }
     void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
     void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
@@ -1107,6 +1121,8 @@ public:
     utils::DynamicArray& c1_dyn() { return c1_; }
     const uint64_t* c0() const { return c0_.raw_pointer(); }
     const uint64_t* c1() const { return c1_.raw_pointer(); }
+    utils::ConstSlice<uint64_t> const_c0() const { return utils::ConstSlice<uint64_t>(c0_.raw_pointer(), c0_.size(), c0_.on_device()); }      // lwe_ciphertext.h:96-100
+    utils::ConstSlice<uint64_t> const_c1() const { return utils::ConstSlice<uint64_t>(c1_.raw_pointer(), c1_.size(), c1_.on_device()); }
     const ParmsID& parms_id() const noexcept { return parms_id_; }
     ParmsID& parms_id() noexcept { return parms_id_; }
     double scale() const noexcept { return scale_; }
