@@ -465,3 +465,16 @@ def test_operand_forms_cpp_api(dev):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.endswith(" ok")]
     assert len(lines) >= 50 and "FAIL" not in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("scheme,n", [("bfv", 32), ("bgv", 32), ("ckks", 32), ("bfv", 8192), ("bgv", 4096), ("ckks", 8192)])
+def test_serialize_cpp_api(dev, scheme, n):
+    """the reference's test/serialize.cu through the mirror: EncryptionParameters, Plaintext, Ciphertext (plain, seeded, 3 polynomials, terms), SecretKey,
+    PublicKey, KSwitchKeys, RelinKeys, GaloisKeys -- save, bytes written == serialized_size_upperbound, T::load_new, and then the loaded object is used
+    (decrypt / apply_keyswitching / relinearize / rotate); its parameter sets (N = 32, {60,40,40,60}) and production-size rings"""
+    drv = os.path.join(ROOT, "tests", "cpp", "serialize_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/serialize_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, scheme, str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 28 and "FAIL" not in r.stdout, r.stdout

@@ -387,6 +387,11 @@ public:
     // encryption_parameters.cu:53-112 (raw little-endian fields, no compression header)
     size_t save(std::ostream& stream) const;
     void load(std::istream& stream);
+    static EncryptionParameters load_new(std::istream& stream) { EncryptionParameters p(SchemeType::Nil); p.load(stream); return p; }      // encryption_parameters.h:238-242
+    size_t serialized_size_upperbound() const {                                                                                          // encryption_parameters.cu:70-82
+        const bool has_t = scheme_ == SchemeType::BFV || scheme_ == SchemeType::BGV;
+        return sizeof(SchemeType) + 2 * sizeof(size_t) + coeff_modulus_.size() * sizeof(uint64_t) + (has_t ? sizeof(uint64_t) : 0) + sizeof(bool);
+    }
 private:
     void compute_parms_id();
     SchemeType scheme_;
@@ -567,6 +572,9 @@ public:
         Ciphertext c; c.load_terms(stream, context, terms, pool); return c;
     }
     size_t serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode mode = CompressionMode::Nil) const;
+    size_t serialized_terms_size_upperbound(HeContextPointer context, const std::vector<size_t>& terms, CompressionMode mode = CompressionMode::Nil) const {   // ciphertext.h:283-285
+        return serialized_terms_size_upperbound(context, terms.size(), mode);
+    }
 private:
     size_t polynomial_count_ = 0, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
     ParmsID parms_id_;
@@ -717,6 +725,7 @@ public:
     // kswitch_keys.cu:5-55
     size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
+    static KSwitchKeys load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { KSwitchKeys k; k.load(stream, context, pool); return k; }   // kswitch_keys.h:205-209
 private:
     ParmsID parms_id_;
     std::vector<std::vector<PublicKey>> keys_;
@@ -726,6 +735,7 @@ class RelinKeys : public KSwitchKeys {
 public:
     RelinKeys() = default;
     explicit RelinKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    static RelinKeys load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { RelinKeys k; k.load(stream, context, pool); return k; }       // kswitch_keys.h:300-304
     static size_t get_index(size_t key_power) {
         if (key_power < 2) throw std::invalid_argument("[RelinKeys::get_index] key_power must be at least 2.");
         return key_power - 2;
@@ -738,6 +748,7 @@ class GaloisKeys : public KSwitchKeys {
 public:
     GaloisKeys() = default;
     explicit GaloisKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    static GaloisKeys load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { GaloisKeys k; k.load(stream, context, pool); return k; }     // kswitch_keys.h:393-397
     static size_t get_index(size_t galois_element) {
         if ((galois_element & 1) == 0) throw std::invalid_argument("[GaloisTool::get_index_from_element] galois_element must be odd");
         return (galois_element - 1) >> 1;
