@@ -478,3 +478,16 @@ def test_serialize_cpp_api(dev, scheme, n):
     r = subprocess.run([drv, scheme, str(n)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 28 and "FAIL" not in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("args", [("bfv", "32"), ("bgv", "32"), ("ckks", "32"), ("bfv", "8192"), ("bgv", "4096"), ("ckks", "8192"), ("budget",)])
+def test_encryptor_cpp_api(dev, args):
+    """the reference's test/encryptor.cu and test/encryptor_batched.cu through the mirror: encrypt_zero at two levels, full / partial SIMD messages, BFV scale_up /
+    scale_down around the ciphertext, equal u_prng => equal c1, for one ciphertext and for batches of 16; test_invariant_noise_budget (BFV and BGV: 30..40 bits fresh,
+    <= 10 after one square, 0 after two)"""
+    drv = os.path.join(ROOT, "tests", "cpp", "encryptor_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/encryptor_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= (2 if args[0] == "budget" else 19) and "FAIL" not in r.stdout, r.stdout
