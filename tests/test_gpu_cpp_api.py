@@ -491,3 +491,14 @@ def test_encryptor_cpp_api(dev, args):
     r = subprocess.run([drv, *args], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= (2 if args[0] == "budget" else 19) and "FAIL" not in r.stdout, r.stdout
+
+
+def test_context_cpp_api(dev):
+    """the reference's test/he_context.cu through the mirror (the host part also runs in the CPU suite, tests/test_mirror_host.py) plus HeContextToDevice: the N = 4
+    chains of the three schemes move to the device"""
+    drv = os.path.join(ROOT, "tests", "cpp", "context_driver")
+    if not os.path.exists(drv):
+        pytest.fail("tests/cpp/context_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([drv, "device"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 32 and "FAIL" not in r.stdout, r.stdout

@@ -117,7 +117,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("parms", &ContextData::parms).def("parms_id", &ContextData::parms_id).def("chain_index", &ContextData::chain_index)
         .def("device_index", [](const ContextData&) { return size_t(0); })
         .def("next_context_data", [unconst](const ContextData& s) { return unconst(s.next_context_data()); })
-        .def("prev_context_data", [unconst](const ContextData& s) { return unconst(s.prev_context_data()); });
+        .def("prev_context_data", [unconst](const ContextData& s) { auto p = s.prev_context_data_pointer().lock(); return unconst(p ? std::optional<ContextDataPointer>(p) : std::nullopt); });
 
     py::class_<HeContext, HeContextPointer>(m, "HeContext")
         .def(py::init([](const EncryptionParameters& parms, bool expand, SecurityLevel sec, uint64_t seed) { return HeContext::create(parms, expand, sec, seed); }),

@@ -777,32 +777,92 @@ void EncryptionParameters::compute_parms_id() {
 // ------------------------------------------------------------------------------------------------
 // HeContext
 // ------------------------------------------------------------------------------------------------
-static bool validate_parms(const EncryptionParameters& p, SecurityLevel sec) {
-    // the subset of ContextData::validate (context_data.cu:71-345) that decides parameters_set()
-    const size_t n = p.poly_modulus_degree();
-    if (p.scheme() == SchemeType::Nil) return false;
-    if (n < 2 || n > 131072 || (n & (n - 1)) != 0) return false;
+// little-endian multi-word helpers of the level constants (utils/uint_small_mod, utils/basics of the reference; a handful of words, host side)
+static uint64_t words_mod_u64(const std::vector<uint64_t>& w, uint64_t m) {
+    unsigned __int128 r = 0;
+    for (size_t i = w.size(); i-- > 0;) r = ((r << 64) | w[i]) % m;
+    return static_cast<uint64_t>(r);
+}
+static uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { const uint64_t r = a % b; a = b; b = r; } return a; }
+
+void ContextData::validate(SecurityLevel sec_level) {
+    // context_data.cu:71-345, in its order: the FIRST failing check is the one reported, and the qualifiers keep what was established before it
+    using E = EncryptionParameterErrorType;
+    EncryptionParameterQualifiers& ql = qualifiers_;
+    const EncryptionParameters& p = parms_;
+    ql = EncryptionParameterQualifiers();
+    ql.parameter_error = E::Success;
+    if (p.scheme() == SchemeType::Nil) { ql.parameter_error = E::InvalidScheme; return; }
     const auto& q = p.coeff_modulus();
-    if (q.empty() || q.size() > 64) return false;
-    size_t total_bits = 0;
-    for (size_t i = 0; i < q.size(); i++) {
-        if (q[i].is_zero() || q[i].bit_count() > 60 || q[i].bit_count() < 2) return false;
-        if ((q[i].value() - 1) % (2 * n) != 0 || !q[i].is_prime()) return false;   // NTT tables must exist
-        for (size_t j = 0; j < i; j++) if (q[j].value() == q[i].value()) return false;
-        total_bits += q[i].bit_count();
+    const size_t k = q.size();
+    if (k > 64 || k < 1) { ql.parameter_error = E::InvalidCoeffModulusSize; return; }
+    for (const Modulus& m : q) if ((m.value() >> 60) > 0 || (m.value() >> 1) == 0) { ql.parameter_error = E::InvalidCoeffModulusBitCount; return; }
+    {
+        std::vector<uint64_t> prod{1};
+        for (const Modulus& m : q) {
+            uint64_t carry = 0;
+            for (uint64_t& w : prod) { const unsigned __int128 v = static_cast<unsigned __int128>(w) * m.value() + carry; w = static_cast<uint64_t>(v); carry = static_cast<uint64_t>(v >> 64); }
+            if (carry) prod.push_back(carry);
+        }
+        size_t bits = (prod.size() - 1) * 64;
+        for (uint64_t top = prod.back(); top; top >>= 1) bits++;
+        total_coeff_modulus_bit_count_ = bits;
+        prod.resize(k, 0);                         // the reference keeps coeff_modulus_size words
+        total_coeff_modulus_ = std::move(prod);
     }
-    if (sec != SecurityLevel::Nil) {
-        size_t maxb = CoeffModulus::max_bit_count(n, sec);
-        if (maxb == 0 || total_bits > maxb) return false;
+    const size_t n = p.poly_modulus_degree();
+    if (n < 2 || n > 131072) { ql.parameter_error = E::InvalidPolyModulusDegree; return; }
+    if ((n & (n - 1)) != 0) { ql.parameter_error = E::InvalidPolyModulusDegreeNonPowerOfTwo; return; }
+    if (k * n > (size_t(1) << 32)) { ql.parameter_error = E::InvalidParametersTooLarge; return; }
+    ql.using_fft = true;
+    ql.security_level = sec_level;
+    if (total_coeff_modulus_bit_count_ > CoeffModulus::max_bit_count(n, sec_level)) {
+        ql.security_level = SecurityLevel::Nil;
+        if (sec_level != SecurityLevel::Nil) { ql.parameter_error = E::InvalidParametersInsecure; return; }
     }
+    // RNSBase: the moduli must be pairwise coprime (utils/rns_base.cu: the punctured products need inverses)
+    for (size_t i = 0; i < k; i++) for (size_t j = 0; j < i; j++) if (gcd_u64(q[i].value(), q[j].value()) != 1) { ql.parameter_error = E::FailedCreatingRNSBase; return; }
+    // NTT tables: a primitive 2N-th root of unity modulo every q_i
+    ql.using_ntt = true;
+    for (const Modulus& m : q) if ((m.value() - 1) % (2 * n) != 0 || !m.is_prime()) { ql.using_ntt = false; ql.parameter_error = E::InvalidCoeffModulusNoNTT; return; }
     if (p.scheme() == SchemeType::BFV || p.scheme() == SchemeType::BGV) {
-        const Modulus& t = p.plain_modulus();
-        if (t.is_zero() || t.bit_count() > 60) return false;
-        for (const auto& qi : q) if (qi.value() <= t.value() && qi.value() == t.value()) return false;
-    } else if (!p.plain_modulus().is_zero()) {
-        return false;   // CKKS must not set a plain modulus
+        const uint64_t t = p.plain_modulus().value();
+        if ((t >> 60) > 0 || (t >> 1) == 0) { ql.parameter_error = E::InvalidPlainModulusBitCount; return; }
+        for (const Modulus& m : q) if (gcd_u64(m.value(), t) != 1) { ql.parameter_error = E::InvalidPlainModulusCoprimality; return; }
+        bool t_below_q = false;
+        for (size_t i = 1; i < k; i++) t_below_q = t_below_q || total_coeff_modulus_[i] != 0;
+        t_below_q = t_below_q || t < total_coeff_modulus_[0];
+        if (!t_below_q) { ql.parameter_error = E::InvalidPlainModulusTooLarge; return; }
+        ql.using_batching = p.plain_modulus().is_prime() && (t - 1) % (2 * n) == 0;
+        ql.using_fast_plain_lift = true;
+        for (const Modulus& m : q) if (m.value() <= t) { ql.using_fast_plain_lift = false; break; }
+        coeff_modulus_mod_plain_modulus_ = words_mod_u64(total_coeff_modulus_, t);
+        upper_half_increment_.resize(k);
+        for (size_t i = 0; i < k; i++) upper_half_increment_[i] = coeff_modulus_mod_plain_modulus_ % q[i].value();
+        plain_upper_half_threshold_ = (t + 1) >> 1;
+        plain_upper_half_increment_.assign(k, 0);
+        if (ql.using_fast_plain_lift) {
+            for (size_t i = 0; i < k; i++) plain_upper_half_increment_[i] = q[i].value() - t;
+        } else {                                   // Q - t as one multi-word integer
+            uint64_t borrow = t;
+            for (size_t i = 0; i < k; i++) { const uint64_t w = total_coeff_modulus_[i]; plain_upper_half_increment_[i] = w - borrow; borrow = w < borrow ? 1 : 0; }
+        }
+    } else {
+        if (!p.plain_modulus().is_zero()) { ql.parameter_error = E::InvalidPlainModulusNonZero; return; }
+        ql.using_batching = true;
+        ql.using_fast_plain_lift = false;
+        plain_upper_half_threshold_ = 1ull << 63;
+        plain_upper_half_increment_.resize(k);
+        for (size_t i = 0; i < k; i++) {                                   // (2^63 mod q_i) * (q_i - 2) mod q_i  (= -2^64 mod q_i, context_data.cu:286-293)
+            const uint64_t qi = q[i].value();
+            plain_upper_half_increment_[i] = static_cast<uint64_t>(static_cast<unsigned __int128>((1ull << 63) % qi) * (qi - 2) % qi);
+        }
+        upper_half_threshold_ = total_coeff_modulus_;                      // (Q + 1) >> 1
+        for (size_t i = 0; i < k; i++) if (++upper_half_threshold_[i] != 0) break;
+        for (size_t i = 0; i < k; i++) upper_half_threshold_[i] = (upper_half_threshold_[i] >> 1) | (i + 1 < k ? upper_half_threshold_[i + 1] << 63 : 0);
     }
-    return true;
+    ql.using_descending_modulus_chain = true;
+    for (size_t i = 1; i < k; i++) if (q[i - 1].value() <= q[i].value()) { ql.using_descending_modulus_chain = false; break; }
 }
 
 HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_chain, SecurityLevel sec_level, uint64_t random_seed) {
@@ -812,36 +872,13 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
     auto add = [&](const EncryptionParameters& p) {
         auto cd = std::make_shared<ContextData>();
         cd->parms_ = p;
-        // context_data.cu:137-218,:330-336
-        EncryptionParameterQualifiers& ql = cd->qualifiers_;
-        ql.security_level = sec_level;
-        const auto& q = p.coeff_modulus();
-        ql.using_descending_modulus_chain = true;
-        for (size_t i = 1; i < q.size(); i++) if (q[i - 1].value() <= q[i].value()) ql.using_descending_modulus_chain = false;
-        {
-            std::vector<uint64_t> prod{1};
-            for (const Modulus& m : q) {
-                uint64_t carry = 0;
-                for (uint64_t& w : prod) { const unsigned __int128 v = static_cast<unsigned __int128>(w) * m.value() + carry; w = static_cast<uint64_t>(v); carry = static_cast<uint64_t>(v >> 64); }
-                if (carry) prod.push_back(carry);
-            }
-            size_t bits = (prod.size() - 1) * 64;
-            for (uint64_t top = prod.back(); top; top >>= 1) bits++;
-            cd->total_coeff_modulus_bit_count_ = bits;
-        }
-        if (p.scheme() == SchemeType::BFV || p.scheme() == SchemeType::BGV) {
-            const uint64_t t = p.plain_modulus().value();
-            ql.using_batching = t > 1 && p.plain_modulus().is_prime() && (t - 1) % (2 * p.poly_modulus_degree()) == 0;
-            ql.using_fast_plain_lift = true;
-            for (const Modulus& m : q) if (m.value() <= t) ql.using_fast_plain_lift = false;
-        }
-        he->map_[p.parms_id()] = cd;
+        cd->validate(sec_level);
         return cd;
     };
-    auto key_cd = add(parms);
+    auto key_cd = add(parms);                                            // recorded even when the parameters are refused (he_context.cu:56-66)
+    he->map_[parms.parms_id()] = key_cd;
     he->key_parms_id_ = parms.parms_id();
-    he->parameters_set_ = validate_parms(parms, sec_level);
-    key_cd->qualifiers_.parameters_set = he->parameters_set_;
+    he->parameters_set_ = key_cd->qualifiers_.parameters_set();
     auto drop_last = [](const EncryptionParameters& p) {
         EncryptionParameters nx = p;
         std::vector<Modulus> q(p.coeff_modulus().begin(), p.coeff_modulus().end() - 1);
@@ -850,9 +887,10 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
     };
     std::shared_ptr<ContextData> first_cd = key_cd;
     if (he->parameters_set_ && parms.coeff_modulus().size() > 1 && !parms.use_special_prime_for_encryption()) {
-        EncryptionParameters nx = drop_last(parms);
-        if (validate_parms(nx, sec_level)) {
-            first_cd = add(nx);
+        auto cd = add(drop_last(parms));
+        if (cd->qualifiers_.parameters_set()) {
+            first_cd = cd;
+            he->map_[cd->parms_id()] = cd;
             key_cd->next_ = first_cd;
             first_cd->prev_ = key_cd;
         }
@@ -862,9 +900,9 @@ HeContextPointer HeContext::create(EncryptionParameters parms, bool expand_mod_c
     std::shared_ptr<ContextData> last_cd = first_cd;
     if (expand_mod_chain && he->parameters_set_) {
         while (last_cd->parms().coeff_modulus().size() > 1) {
-            EncryptionParameters nx = drop_last(last_cd->parms());
-            if (!validate_parms(nx, sec_level)) break;
-            auto cd = add(nx);
+            auto cd = add(drop_last(last_cd->parms()));
+            if (!cd->qualifiers_.parameters_set()) break;
+            he->map_[cd->parms_id()] = cd;
             last_cd->next_ = cd;
             cd->prev_ = last_cd;
             last_cd = cd;
@@ -2581,13 +2619,12 @@ void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form,
         rlwe::symmetric(secret_key(), context_, parms_id, is_ntt_form, save_seed, destination, pool, u_prng);
         return;
     }
-    auto prev = cd->prev_context_data();
-    if (!prev.has_value()) {
+    ContextDataPointer pcd = cd->prev_context_data_pointer().lock();
+    if (!pcd) {
         rlwe::asymmetric(public_key(), context_, parms_id, is_ntt_form, destination, pool, u_prng);
         return;
     }
     // encrypt one level up, then switch the extra prime away (encryptor.cu:44-75)
-    ContextDataPointer pcd = prev.value();
     Ciphertext temp;
     rlwe::asymmetric(public_key(), context_, pcd->parms_id(), is_ntt_form, temp, pool, u_prng);
     const uint32_t Lp = static_cast<uint32_t>(pcd->parms().coeff_modulus().size());

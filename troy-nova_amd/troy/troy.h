@@ -410,36 +410,57 @@ class ContextData;
 using ContextDataPointer = std::shared_ptr<const ContextData>;
 using HeContextPointer = std::shared_ptr<HeContext>;
 
+// encryption_parameters.h:256-275: why a parameter set was refused (HeContext::create never throws for that: it records the reason)
+enum class EncryptionParameterErrorType {
+    Nil = -1, Success = 0, CreatedFromDeviceParms, InvalidScheme, InvalidCoeffModulusSize, InvalidCoeffModulusBitCount, InvalidCoeffModulusNoNTT,
+    InvalidPolyModulusDegree, InvalidPolyModulusDegreeNonPowerOfTwo, InvalidParametersTooLarge, InvalidParametersInsecure, FailedCreatingRNSBase,
+    InvalidPlainModulusBitCount, InvalidPlainModulusCoprimality, InvalidPlainModulusTooLarge, InvalidPlainModulusNonZero, FailedCreatingRNSTool,
+    FailedCreatingGaloisTool,
+};
+
 // encryption_parameters.h:277-289
 struct EncryptionParameterQualifiers {
-    bool parameters_set = false;
-    bool using_fft = true, using_ntt = true;
-    bool using_batching = false;                 // t is an NTT prime for this degree (BFV / BGV)
+    EncryptionParameterErrorType parameter_error = EncryptionParameterErrorType::Nil;
+    bool using_fft = false, using_ntt = false;
+    bool using_batching = false;                 // t is an NTT prime for this degree (BFV / BGV); always for CKKS
     bool using_fast_plain_lift = false;          // every q_i > t
     bool using_descending_modulus_chain = false;
     SecurityLevel security_level = SecurityLevel::Nil;
+    bool parameters_set() const noexcept { return parameter_error == EncryptionParameterErrorType::Success; }
 };
 
 class ContextData {
 public:
     const EncryptionParameters& parms() const { return parms_; }
     const EncryptionParameterQualifiers& qualifiers() const { return qualifiers_; }
+    // context_data.h:81-111: the host-side constants of the level (the device copies live in the troyn_plan / troyn_behz / troyn_bgv handles)
+    utils::ConstSlice<uint64_t> total_coeff_modulus() const { return utils::ConstSlice<uint64_t>(total_coeff_modulus_); }      // little-endian words, coeff_modulus_size of them
     size_t total_coeff_modulus_bit_count() const { return total_coeff_modulus_bit_count_; }
+    uint64_t plain_upper_half_threshold() const noexcept { return plain_upper_half_threshold_; }                               // (t + 1) / 2; 2^63 for CKKS
+    utils::ConstSlice<uint64_t> plain_upper_half_increment() const { return utils::ConstSlice<uint64_t>(plain_upper_half_increment_); }
+    utils::ConstSlice<uint64_t> upper_half_threshold() const { return utils::ConstSlice<uint64_t>(upper_half_threshold_); }    // CKKS: (Q + 1) / 2
+    utils::ConstSlice<uint64_t> upper_half_increment() const { return utils::ConstSlice<uint64_t>(upper_half_increment_); }    // BFV / BGV: (Q mod t) mod q_i
+    uint64_t coeff_modulus_mod_plain_modulus() const noexcept { return coeff_modulus_mod_plain_modulus_; }                     // Q mod t
     const ParmsID& parms_id() const { return parms_.parms_id(); }
     size_t chain_index() const { return chain_index_; }
-    std::optional<ContextDataPointer> next_context_data() const { return next_ ? std::optional<ContextDataPointer>(next_) : std::nullopt; }
-    std::optional<ContextDataPointer> prev_context_data() const {
-        auto p = prev_.lock();
-        return p ? std::optional<ContextDataPointer>(p) : std::nullopt;
+    std::optional<ContextDataPointer> next_context_data() const noexcept { return next_ ? std::optional<ContextDataPointer>(next_) : std::nullopt; }
+    // context_data.h:113-135: the link towards the key level is weak, as in the reference (.value().lock())
+    std::optional<std::weak_ptr<const ContextData>> prev_context_data() const noexcept {
+        return prev_.expired() ? std::nullopt : std::optional<std::weak_ptr<const ContextData>>(prev_);
     }
-    bool is_ckks() const { return parms_.scheme() == SchemeType::CKKS; }
-    bool is_bfv() const { return parms_.scheme() == SchemeType::BFV; }
-    bool is_bgv() const { return parms_.scheme() == SchemeType::BGV; }
+    std::weak_ptr<const ContextData> prev_context_data_pointer() const noexcept { return prev_; }
+    ContextDataPointer next_context_data_pointer() const noexcept { return next_; }
+    bool is_ckks() const noexcept { return parms_.scheme() == SchemeType::CKKS; }
+    bool is_bfv() const noexcept { return parms_.scheme() == SchemeType::BFV; }
+    bool is_bgv() const noexcept { return parms_.scheme() == SchemeType::BGV; }
 private:
     friend class HeContext;
+    void validate(SecurityLevel sec_level);      // context_data.cu:71-345
     EncryptionParameters parms_;
     EncryptionParameterQualifiers qualifiers_;
+    std::vector<uint64_t> total_coeff_modulus_, plain_upper_half_increment_, upper_half_threshold_, upper_half_increment_;
     size_t total_coeff_modulus_bit_count_ = 0;
+    uint64_t plain_upper_half_threshold_ = 0, coeff_modulus_mod_plain_modulus_ = 0;
     size_t chain_index_ = 0;
     std::shared_ptr<const ContextData> next_;
     std::weak_ptr<const ContextData> prev_;
