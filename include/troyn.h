@@ -301,6 +301,8 @@ int troyn_bgv_relinearize(const troyn_bgv* key_level, uint32_t L, const uint64_t
  *   troyn_ring2k_scale_up     scale_up (:299-360): src elements [count] -> out u64[L][N] = round(Q/t * m), zero beyond `count`
  *   troyn_ring2k_centralize   centralize (:488-560): centred lift of m
  *   troyn_ring2k_scale_down   scale_down (:620-735): in u64[L][N] (phase, coefficient form) -> dst elements [N]
+ *   troyn_ring2k_decentralize decentralize (:752-911): in u64[L][N] (x mod Q, coefficient form) -> dst elements [N] = x mod 2^k, times correction^-1 mod 2^k
+ *                             (correction_lo / _hi: the odd correction factor as a 128-bit value; 1, 0 for none)
  * ------------------------------------------------------------------------------------- */
 typedef struct troyn_ring2k troyn_ring2k;
 int troyn_ring2k_create(troyn_ring2k** out, const troyn_plan* plan, uint32_t L, uint32_t t_bit_length, uint32_t element_bytes);
@@ -309,6 +311,7 @@ uint64_t troyn_ring2k_gamma(const troyn_ring2k* h);
 int troyn_ring2k_scale_up(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream);
 int troyn_ring2k_centralize(const troyn_ring2k* h, const void* src, size_t count, uint64_t* out, troyn_stream_t stream);
 int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in, void* dst, troyn_stream_t stream);
+int troyn_ring2k_decentralize(const troyn_ring2k* h, const uint64_t* in, void* dst, uint64_t correction_lo, uint64_t correction_hi, troyn_stream_t stream);
 
 /* RLWE / LWE packing (evaluator_lwes.cu):
  *   troyn_negacyclic_shift     utils::negacyclic_shift_ps (utils/poly_small_mod.cu:927-968): multiply `count` RNS polynomials by

@@ -724,3 +724,25 @@ class Ring2k:
             else:
                 out.append(((on_t - on_gamma) * self.inv_gamma_mod_t) & self.mask)
         return out
+
+    def decentralize(self, plain, correction_factor=1):
+        """PolynomialEncoderRNSHelper::decentralize (:752-911): x mod Q -> x mod 2^k by the fast base conversion with the quotient estimated in doubles
+        (step 1: y_l = x_l (Q/q_l)^-1 mod q_l, v_l = double(y_l) / double(q_l); step 2: v = round(sum v_l) summed in the order l = 0 .. L-1,
+        out = sum y_l ((Q/q_l) mod 2^k) - v (Q mod 2^k)), then times correction_factor^-1 mod 2^k (inverse_ring2k, :33-40: the factor must be odd)."""
+        import math
+        cf = int(correction_factor) & ((1 << self.bits) - 1)
+        if cf & 1 == 0:
+            raise ValueError("[bfv_ring2k::inverse_ring2k] x must be odd")
+        fix = pow(cf, -1, 1 << self.bits) & self.mask
+        out = []
+        for c in range(self.n):
+            y = [int(plain[l, c]) % ql * self.inv_punct[l] % ql for l, ql in enumerate(self.q)]
+            v = 0.0
+            for yl, ql in zip(y, self.q):
+                v += float(yl) / float(ql)
+            r = math.floor(v)
+            if v - r >= 0.5:                                   # std::round: halves away from zero (v >= 0)
+                r += 1
+            x = (sum(yl * (p & self.mask) for yl, p in zip(y, self.punct)) - r * self.Q_mod_t) & self.mask
+            out.append(x * fix & self.mask)
+        return out

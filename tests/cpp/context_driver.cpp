@@ -111,7 +111,7 @@ static void run_chain(SchemeType scheme) {
     bool ok = true;
     for (size_t i = 0; i < totals.size(); i++) {
         ok = ok && cd->chain_index() == totals.size() - 1 - i && cd->total_coeff_modulus()[0] == totals[i] && cd->total_coeff_modulus().size() == 4 - i;
-        if (i) ok = ok && cd->prev_context_data().has_value() && cd->prev_context_data().value().lock()->parms_id() == prev->parms_id();
+        if (i) { auto up = cd->prev_context_data().has_value() ? cd->prev_context_data().value().lock() : nullptr; ok = ok && up && up->parms_id() == prev->parms_id(); }
         else ok = ok && !cd->prev_context_data().has_value();
         prev = cd;
         if (i + 1 < totals.size()) { ok = ok && cd->next_context_data().has_value(); if (!ok) break; cd = cd->next_context_data().value(); }

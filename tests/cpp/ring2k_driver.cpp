@@ -2,6 +2,7 @@
 // PolynomialEncoderRing2k<T>: scale_up -> encrypt -> multiply by a centralized plaintext -> bfv_decrypt_without_scaling_down ->
 // scale_down gives the negacyclic product mod 2^k; for T = uint32_t, uint64_t and unsigned __int128 (N=16384, six 60-bit primes).
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <sstream>
 
@@ -89,6 +90,74 @@ static bool run_matmul(const HeContextPointer& he, const KeyGenerator& keygen, c
     return bad == 0;
 }
 
+// test/app/bfv_ring2k.cu:119-370 replayed: scale_up -> scale_down and centralize -> decentralize give the message back, for one source and for a batch of 16
+// sources of 0..15 elements; the plaintexts keep only the source's coefficients (coeff_count = source size, data = coeff_modulus_size * coeff_count);
+// first and second level; plus the slice forms on device-resident sources / destinations and decentralize's correction factor
+template <typename T>
+static bool run_forms(const std::vector<size_t>& q_bits, const std::vector<size_t>& t_bits, const char* name) {
+    bool all = true;
+    for (size_t k : t_bits) {
+        const size_t n = 32, B = 16;
+        EncryptionParameters parms(SchemeType::BFV);
+        parms.set_plain_modulus(PlainModulus::batching(n, 30));          // unused by the encoder
+        parms.set_poly_modulus_degree(n);
+        parms.set_coeff_modulus(CoeffModulus::create(n, q_bits));
+        HeContextPointer he = HeContext::create(parms, true, SecurityLevel::Nil, 0x123);
+        linear::PolynomialEncoderRing2k<T> encoder(he, k);
+        he->to_device_inplace();
+        encoder.to_device_inplace();
+        const T mask = encoder.t_mask();
+        std::mt19937_64 gen(sizeof(T) * 1000 + k);
+        auto sample = [&](size_t count) { std::vector<T> v(count); for (auto& x : v) { T r = static_cast<T>(gen()); if (sizeof(T) == 16) r = (r << 32 << 32) | static_cast<T>(gen()); x = static_cast<T>(r & mask); } return v; };
+        const ParmsID second = he->first_context_data_pointer()->next_context_data_pointer()->parms_id();
+        auto shape = [&](const Plaintext& p, size_t cc) { return p.coeff_count() == cc && p.poly_modulus_degree() == n && p.data().size() == p.coeff_modulus_size() * cc; };
+        size_t bad = 0;
+        for (const std::optional<ParmsID>& level : {std::optional<ParmsID>(std::nullopt), std::optional<ParmsID>(second)}) {
+            std::vector<T> m = sample(10);
+            Plaintext up = encoder.scale_up_new(m, level), ce = encoder.centralize_new(m, level);
+            bad += !shape(up, 10) || !shape(ce, 10) || encoder.scale_down_new(up) != m || encoder.decentralize_new(ce) != m;
+            if (level.has_value()) bad += !(up.parms_id() == second);
+            // a correction factor divides the decoded value (bfv_ring2k.cu:913-924)
+            const T cf = static_cast<T>(sample(1)[0] | 1);
+            std::vector<T> scaled(m.size());
+            for (size_t i = 0; i < m.size(); i++) scaled[i] = static_cast<T>((m[i] * cf) & mask);
+            bad += encoder.decentralize_new(encoder.centralize_new(scaled, level), cf) != m;
+            // batches of 0 .. 15 elements
+            std::vector<utils::Array<T>> message(B);
+            for (size_t i = 0; i < B; i++) { message[i] = utils::Array<T>::from_vector(sample(i)); message[i].to_device_inplace(); }
+            std::vector<Plaintext> ups(B), ces(B);
+            encoder.scale_up_slice_batched(batch_utils::rcollect_const_reference<utils::Array<T>, T>(message), level, batch_utils::collect_pointer(ups));
+            encoder.centralize_slice_batched(batch_utils::rcollect_const_reference<utils::Array<T>, T>(message), level, batch_utils::collect_pointer(ces));
+            for (size_t i = 0; i < B; i++)
+                bad += !shape(ups[i], i) || !shape(ces[i], i) || encoder.scale_down_new(ups[i]) != message[i].to_vector() || encoder.decentralize_new(ces[i]) != message[i].to_vector();
+            // the batch equals the single calls word for word
+            for (size_t i = 1; i < B; i++)
+                bad += ups[i].data().to_vector() != encoder.scale_up_new(message[i].to_vector(), level).data().to_vector() ||
+                       ces[i].data().to_vector() != encoder.centralize_slice_new(message[i].const_reference(), level).data().to_vector();
+            // device-resident source and destination: elements as raw bytes in device memory
+            std::vector<T> full = sample(n);
+            const size_t words = (n * sizeof(T) + 7) / 8;
+            std::vector<uint64_t> raw(words, 0);
+            std::memcpy(raw.data(), full.data(), n * sizeof(T));
+            utils::DynamicArray dev(words, true), back(words, true);
+            dev.copy_from(raw.data(), words, false);
+            const utils::ConstSlice<T> src(reinterpret_cast<const T*>(dev.raw_pointer()), n, true);
+            Plaintext fu = encoder.scale_up_slice_new(src, level), fc = encoder.centralize_slice_new(src, level);
+            bad += !shape(fu, n) || fu.data().to_vector() != encoder.scale_up_new(full, level).data().to_vector();
+            encoder.decentralize_slice(fc, utils::Slice<T>(reinterpret_cast<T*>(back.raw_pointer()), n, true));
+            std::vector<T> got(n);
+            const std::vector<uint64_t> rb = back.to_vector();
+            std::memcpy(got.data(), rb.data(), n * sizeof(T));
+            bad += got != full || encoder.scale_down_slice_new(fu).to_vector() != full;
+        }
+        bool threw = false;
+        try { encoder.decentralize_new(encoder.centralize_new(sample(4), std::nullopt), static_cast<T>(2)); } catch (const std::exception&) { threw = true; }
+        std::printf("forms %s k=%zu mismatches %zu even_correction_rejected %d\n", name, k, bad, threw ? 1 : 0);
+        all = all && bad == 0 && threw;
+    }
+    return all;
+}
+
 int main() {
     try {
         const size_t n = 16384;
@@ -113,6 +182,9 @@ int main() {
         ok = run_matmul<uint64_t>(he, keygen, encryptor, decryptor, evaluator, 50, true, "uint64") && ok;
         ok = run_matmul<uint32_t>(he, keygen, encryptor, decryptor, evaluator, 32, true, "uint32") && ok;
         ok = run_matmul<u128>(he, keygen, encryptor, decryptor, evaluator, 100, false, "uint128") && ok;
+        ok = run_forms<uint32_t>({40, 40, 40}, {32, 20, 17}, "uint32") && ok;
+        ok = run_forms<uint64_t>({40, 40, 40, 40}, {64, 50, 33}, "uint64") && ok;
+        ok = run_forms<u128>({60, 60, 60, 60, 60, 60}, {128, 100, 65}, "uint128") && ok;
         bool threw = false;
         try { linear::PolynomialEncoderRing2k<uint64_t> bad(he, 32); } catch (const std::invalid_argument&) { threw = true; }
         std::printf("narrow_k_rejected %d\n", threw ? 1 : 0);

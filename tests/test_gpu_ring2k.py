@@ -70,3 +70,30 @@ def test_ring2k_product_decrypts(O, pkg, dev):
         for j, y in enumerate(b):
             want[i + j] = (want[i + j] + x * y) & ((1 << k) - 1)
     assert got == want
+
+
+@pytest.mark.parametrize("n,bits,L,elem_bits,k", [(64, [60, 60, 60, 60], 2, 64, 64), (64, [60, 60, 60, 60], 3, 64, 40), (1024, [50, 50, 50], 2, 32, 32),
+                                                  (1024, [50, 50, 50], 1, 32, 17), (8192, [60, 60, 60, 60], 3, 128, 128), (4096, [60, 60, 60, 60], 3, 128, 65),
+                                                  (16384, [60, 60, 60, 60], 4, 64, 64), (32768, [60, 40, 40, 60], 3, 64, 33)])
+def test_ring2k_decentralize_matches_oracle(O, pkg, dev, n, bits, L, elem_bits, k):
+    """decentralize (bfv_ring2k.cu:752-911): the double-precision quotient estimate is summed in the reference's order, so the HIP kernel equals the oracle
+    bit for bit on arbitrary residues (where the estimate sits anywhere in [0, L)) as well as on centred lifts; the reference's round trip holds"""
+    q = [int(v) for v in O.coeff_modulus_create(n, bits)]
+    plan = pkg.Plan(dev, n.bit_length() - 1, q)
+    ref = O.Ring2k(n, q[:L], k, elem_bits)
+    gpu = pkg.Ring2k(plan, L, k, elem_bits)
+    rnd = random.Random(k * 77 + n)
+    m = [rnd.getrandbits(k) for _ in range(n)]
+    m[:6] = [0, 1, (1 << k) - 1, 1 << (k - 1), (1 << (k - 1)) + 1, (1 << (k - 1)) - 1]
+    ce = gpu.centralize(m)
+    assert gpu.decentralize(ce) == m
+    cf = rnd.getrandbits(k) | 1
+    assert gpu.decentralize(ce, cf) == [x * pow(cf, -1, 1 << k) & ((1 << k) - 1) for x in m]
+    rows = min(n, 2048)                                  # the oracle is a Python loop: compare a window of arbitrary residues
+    arbitrary = np.stack([O.fill_uniform(91 + l, q[l], n) for l in range(L)])
+    small = O.Ring2k(rows, q[:L], k, elem_bits)
+    small.gamma = ref.gamma
+    assert gpu.decentralize(pkg.to_device(arbitrary, dev))[:rows] == small.decentralize(arbitrary[:, :rows])
+    assert gpu.decentralize(pkg.to_device(arbitrary, dev), cf)[:rows] == small.decentralize(arbitrary[:, :rows], cf)
+    with pytest.raises(Exception):
+        gpu.decentralize(ce, 2)                          # inverse_ring2k: the correction factor must be odd

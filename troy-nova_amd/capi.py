@@ -87,6 +87,7 @@ SYMBOLS = {
     "troyn_ring2k_scale_up": (C.c_int, [vp, vp, sz, vp, vp]),
     "troyn_ring2k_centralize": (C.c_int, [vp, vp, sz, vp, vp]),
     "troyn_ring2k_scale_down": (C.c_int, [vp, vp, vp, vp]),
+    "troyn_ring2k_decentralize": (C.c_int, [vp, vp, vp, u64, u64, vp]),
     "troyn_gather_workspace_bytes": (sz, [sz]),
     "troyn_gather": (C.c_int, [vp, sz, sz, vp, vp, sz, vp]),
     "troyn_scatter": (C.c_int, [vp, vp, sz, sz, vp, sz, vp]),

@@ -3,6 +3,7 @@
 //   scale_up     m -> round(Q/t * m) mod q_l              (encode for encryption)
 //   centralize   m -> centred lift of m mod q_l            (encode for multiplication with a ciphertext)
 //   scale_down   phase mod Q -> m mod t                    (decode: the BEHZ rounding of SEAL's rns.cpp with t = 2^k and an auxiliary prime gamma)
+//   decentralize x mod Q -> x mod t                        (the inverse of centralize: an exact base conversion {q_l} -> {2^k} with a floating-point quotient estimate)
 // Elements are 4, 8 or 16 bytes wide; every computation runs on 128-bit words and masks with 2^k - 1 at the end, which equals the
 // reference's arithmetic in uint32 / uint64 / uint128 (reduction mod 2^k commutes with the wrap-around of the narrower types).
 #pragma once
@@ -120,6 +121,29 @@ __global__ __launch_bounds__(256) void ring2k_scale_down_kernel(Ring2kDev c, con
     const u128 ig = ring2k_make(c.inv_gamma_mod_t[0], c.inv_gamma_mod_t[1]);
     // 4. subtract the centred remainder mod gamma, divide by gamma mod t
     const u128 r = (on_gamma > (c.gamma.q >> 1)) ? ((on_t + c.gamma.q - on_gamma) * ig) & mask : ((on_t - on_gamma) * ig) & mask;
+    ring2k_store(dst, i, c.elem_bytes, r);
+}
+
+// PolynomialEncoderRNSHelper::decentralize (:752-911; steps 1 and 2 of the reference in one pass, one thread per coefficient): in [L][n] (coefficient form) -> elements.
+//   y_l = x_l * (Q/q_l)^-1 mod q_l;   v = round(sum_l y_l / q_l) (doubles, summed in the order l = 0 .. L-1 as the reference does);
+//   out = (sum_l y_l * ((Q/q_l) mod 2^k) - v * (Q mod 2^k)) * fix  mod 2^k,   fix = correction_factor^-1 mod 2^k (1 when there is none)
+__global__ __launch_bounds__(256) void ring2k_decentralize_kernel(Ring2kDev c, const u64* in, void* dst, u64 fix_lo, u64 fix_hi) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    const u128 mask = ring2k_make(c.mask[0], c.mask[1]);
+    u128 acc = 0;
+    double v = 0.0;
+    for (unsigned l = 0; l < c.L; l++) {
+        const DevModulus m = c.mods[l];
+        const ulonglong2 ip = c.inv_punctured[l];
+        const u64 x = in[(size_t)l * c.n + i];
+        const u64 y = (ip.x == 1) ? barrett64(x, m.q, m.ratio_hi) : shoup_mul(x, ip.x, ip.y, m.q);
+        v += (double)y / (double)m.q;
+        acc += (u128)y * ring2k_make(c.punctured_mod_t[2 * l], c.punctured_mod_t[2 * l + 1]);
+    }
+    const u128 rounded = (u128)(u64)round(v);                      // v < L <= 64
+    u128 r = (acc - rounded * ring2k_make(c.q_mod_t[0], c.q_mod_t[1])) & mask;
+    r = (r * ring2k_make(fix_lo, fix_hi)) & mask;
     ring2k_store(dst, i, c.elem_bytes, r);
 }
 

@@ -2771,6 +2771,23 @@ extern "C" int troyn_ring2k_scale_down(const troyn_ring2k* h, const uint64_t* in
     return TROYN_OK;
 }
 
+extern "C" int troyn_ring2k_decentralize(const troyn_ring2k* h, const uint64_t* in, void* dst, uint64_t correction_lo, uint64_t correction_hi, troyn_stream_t stream) {
+    select_device(h);
+    const char* P = "[PolynomialEncoderRNSHelper::decentralize]";
+    if (!h || !in || !dst) return fail(TROYN_E_INVALID, std::string(P) + " null argument");
+    typedef unsigned __int128 u128h;
+    u128h cf = ((u128h)correction_hi << 64) | correction_lo;
+    if (h->dev.elem_bytes == 4) cf &= 0xffffffffull; else if (h->dev.elem_bytes == 8) cf &= ~0ull;
+    if ((cf & 1) == 0) return fail(TROYN_E_INVALID, "[bfv_ring2k::inverse_ring2k] x must be odd");
+    u128h fix = cf;                                                  // Newton: the inverse modulo 2^128 (its low k bits are the inverse modulo 2^k)
+    for (int it = 0; it < 8; it++) fix *= 2 - cf * fix;
+    const u128h mask = h->dev.t_bits == 128 ? ~(u128h)0 : (((u128h)1 << h->dev.t_bits) - 1);
+    fix &= mask;
+    hipLaunchKernelGGL(ring2k_decentralize_kernel, dim3((h->dev.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dev, (const u64*)in, dst, (u64)fix, (u64)(fix >> 64));
+    LAUNCH_CHECK();
+    return TROYN_OK;
+}
+
 extern "C" size_t troyn_gather_workspace_bytes(size_t count) { return (count + 1) * sizeof(u64); }
 
 extern "C" int troyn_gather(const uint64_t* const* src, size_t count, size_t words, uint64_t* out, void* workspace, size_t workspace_bytes, troyn_stream_t stream) {

@@ -507,6 +507,15 @@ class Ring2k:
         raw = out.cpu().numpy().tobytes()
         return [int.from_bytes(raw[i * self.elem_bytes:(i + 1) * self.elem_bytes], "little") for i in range(self.plan.n)]
 
+    def decentralize(self, plain, correction_factor=1):
+        """plain [L][N] coefficient form (x mod Q) -> list of N Python ints x * correction_factor^-1 mod 2^k (bfv_ring2k.cu:872-925)"""
+        words = (self.plan.n * self.elem_bytes + 7) // 8
+        out = torch.empty(words, dtype=torch.int64, device=self.plan.device)
+        cf = int(correction_factor)
+        capi.check(self.plan.lib.troyn_ring2k_decentralize(self.h, _ptr(plain), _ptr(out), cf & ((1 << 64) - 1), (cf >> 64) & ((1 << 64) - 1), _stream()))
+        raw = out.cpu().numpy().tobytes()
+        return [int.from_bytes(raw[i * self.elem_bytes:(i + 1) * self.elem_bytes], "little") for i in range(self.plan.n)]
+
 
 class Behz:
     """troyn_behz: BEHZ constants (RNSTool, utils/rns_tool.cu:29-275) for level L and plain modulus t."""

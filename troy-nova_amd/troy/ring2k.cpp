@@ -35,45 +35,86 @@ const troyn_ring2k* PolynomialEncoderRing2k<T>::helper(const ParmsID& parms_id) 
 }
 
 template <typename T>
-void PolynomialEncoderRing2k<T>::encode(const std::vector<T>& source, std::optional<ParmsID> parms_id, bool scale, Plaintext& destination, MemoryPoolHandle pool) const {
+void PolynomialEncoderRing2k<T>::encode(const utils::ConstSlice<T>* source, size_t count, std::optional<ParmsID> parms_id, bool scale, Plaintext* const* destination, MemoryPoolHandle pool) const {
     const ParmsID pid = parms_id.value_or(context_->first_parms_id());
     const troyn_ring2k* h = helper(pid);
     const size_t n = slot_count();
-    if (source.size() > n) throw std::invalid_argument("[PolynomialEncoderRNSHelper:scale_up] source size is larger than poly_modulus_degree");
-    // the elements travel as raw bytes in a word buffer
-    const size_t words = (source.size() * sizeof(T) + 7) / 8 + 1;
-    std::vector<uint64_t> raw(words, 0);
-    std::memcpy(raw.data(), source.data(), source.size() * sizeof(T));
+    if (count == 0) return;
+    // the elements travel as raw bytes in ONE word buffer (each source at an 8-byte aligned offset); device-resident sources are copied device to device
+    std::vector<size_t> offset(count);
+    size_t words = 0;
+    for (size_t i = 0; i < count; i++) {
+        if (source[i].size() > n) throw std::invalid_argument(scale ? "[PolynomialEncoderRNSHelper:scale_up] source size is larger than poly_modulus_degree"
+                                                                    : "[PolynomialEncoderRNSHelper:centralize] source size is larger than poly_modulus_degree");
+        offset[i] = words;
+        words += (source[i].size() * sizeof(T) + 7) / 8 + 1;
+    }
     utils::DynamicArray staged(words, true, pool);
-    staged.copy_from(raw.data(), words, false);
-    Plaintext out;
-    out.data() = utils::DynamicArray(0, true, pool);
-    out.resize_rns(*context_, pid);
     hipStream_t s = static_cast<hipStream_t>(troyn_current_stream());
-    if (scale) troyn_check_public(troyn_ring2k_scale_up(h, staged.raw_pointer(), source.size(), out.poly(), s));
-    else troyn_check_public(troyn_ring2k_centralize(h, staged.raw_pointer(), source.size(), out.poly(), s));
+    std::vector<uint64_t> raw(words, 0);
+    bool any_host = false;
+    for (size_t i = 0; i < count; i++) if (!source[i].on_device() && source[i].size()) { std::memcpy(raw.data() + offset[i], source[i].raw_pointer(), source[i].size() * sizeof(T)); any_host = true; }
+    if (any_host) staged.copy_from(raw.data(), words, false);
+    for (size_t i = 0; i < count; i++)
+        if (source[i].on_device() && source[i].size())
+            if (hipMemcpyAsync(staged.raw_pointer() + offset[i], source[i].raw_pointer(), source[i].size() * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                throw std::runtime_error("[PolynomialEncoderRing2k] device copy of a source slice failed");
+    // the result keeps only the source's coefficients (bfv_ring2k.cu:330-347, :540-556: resize_rns_partial(.., source.size())), data[l * count + i];
+    // the kernels write full rows, so a shorter source goes through one scratch polynomial and a strided copy
+    const size_t L = context_->get_context_data(pid).value()->parms().coeff_modulus().size();
+    utils::DynamicArray scratch(0, true, pool);
+    for (size_t i = 0; i < count; i++) {
+        const size_t cc = source[i].size();
+        Plaintext out;
+        out.data() = utils::DynamicArray(0, true, pool);
+        out.resize_rns_partial(*context_, pid, cc);
+        if (cc > 0) {
+            uint64_t* target = out.poly();
+            if (cc < n) { if (scratch.size() == 0) scratch = utils::DynamicArray(L * n, true, pool); target = scratch.raw_pointer(); }
+            if (scale) troyn_check_public(troyn_ring2k_scale_up(h, staged.raw_pointer() + offset[i], cc, target, s));
+            else troyn_check_public(troyn_ring2k_centralize(h, staged.raw_pointer() + offset[i], cc, target, s));
+            if (cc < n && hipMemcpy2DAsync(out.poly(), cc * sizeof(uint64_t), target, n * sizeof(uint64_t), cc * sizeof(uint64_t), L, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                throw std::runtime_error("[PolynomialEncoderRing2k] strided copy of a partial plaintext failed");
+        }
+        out.is_ntt_form() = false;
+        *destination[i] = std::move(out);
+    }
     troyn_sync_current_stream();
-    out.is_ntt_form() = false;
-    destination = std::move(out);
 }
 
 template <typename T>
-std::vector<T> PolynomialEncoderRing2k<T>::scale_down_new(const Plaintext& input, MemoryPoolHandle pool) const {
-    const char* P = "[PolynomialEncoderRNSHelper::scale_down]";
+void PolynomialEncoderRing2k<T>::decode(const Plaintext& input, bool scale, T correction_factor, utils::Slice<T> destination, MemoryPoolHandle pool) const {
+    const char* P = "[PolynomialEncoderRNSHelper::scale_down]";       // the reference reports both decoders under this name
     if (input.parms_id() == parms_id_zero) throw std::invalid_argument(std::string(P) + " input is not valid");
     if (!input.on_device()) throw std::invalid_argument(std::string(P) + " self, input, destination are not in the same device");
     if (input.is_ntt_form()) throw std::invalid_argument(std::string(P) + " input is in NTT form");
     const troyn_ring2k* h = helper(input.parms_id());
-    const size_t n = slot_count();
-    if (input.coeff_count() != n) throw std::invalid_argument(std::string(P) + " input is not a full RNS polynomial");
+    const size_t n = slot_count(), cc = input.coeff_count(), L = input.coeff_modulus_size();
+    if (cc > n || input.data().size() != L * cc) throw std::invalid_argument(std::string(P) + " input does not have the shape of an RNS plaintext");
+    if (destination.size() != cc) throw std::invalid_argument(std::string(P) + " destination size must be the input's coeff_count");
+    if (cc == 0) return;
+    hipStream_t s = static_cast<hipStream_t>(troyn_current_stream());
+    // a partial plaintext (bfv_ring2k.cu:700-712: coeff_count = destination.size()) is widened to full rows for the kernel; only its coeff_count elements come back
+    utils::DynamicArray widened(0, true, pool);
+    const uint64_t* in = input.poly();
+    if (cc < n) { widened = input.expanded_rns(L, n, pool); in = widened.raw_pointer(); }
     const size_t words = (n * sizeof(T) + 7) / 8;
-    utils::DynamicArray out(words, true, pool);
-    troyn_check_public(troyn_ring2k_scale_down(h, input.poly(), out.raw_pointer(), troyn_current_stream()));
+    const bool direct = destination.on_device() && cc == n;
+    utils::DynamicArray out(direct ? 0 : words, true, pool);
+    void* dst = direct ? static_cast<void*>(destination.raw_pointer()) : static_cast<void*>(out.raw_pointer());
+    if (scale) {
+        troyn_check_public(troyn_ring2k_scale_down(h, in, dst, s));
+    } else {
+        const unsigned __int128 cf = static_cast<unsigned __int128>(correction_factor);
+        troyn_check_public(troyn_ring2k_decentralize(h, in, dst, static_cast<uint64_t>(cf), static_cast<uint64_t>(cf >> 64), s));
+    }
+    if (!direct && destination.on_device() && hipMemcpyAsync(destination.raw_pointer(), dst, cc * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        throw std::runtime_error("[PolynomialEncoderRing2k] device copy of the decoded elements failed");
     troyn_sync_current_stream();
-    const std::vector<uint64_t> raw = out.to_vector();
-    std::vector<T> result(n);
-    std::memcpy(result.data(), raw.data(), n * sizeof(T));
-    return result;
+    if (!destination.on_device()) {
+        const std::vector<uint64_t> raw = out.to_vector();
+        std::memcpy(destination.raw_pointer(), raw.data(), cc * sizeof(T));
+    }
 }
 
 template class PolynomialEncoderRing2k<uint32_t>;

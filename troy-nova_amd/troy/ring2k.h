@@ -1,12 +1,11 @@
-// ring2k.h -- troy::linear::PolynomialEncoderRing2k<T>, the Z_{2^k} polynomial encoder of the reference's ring-2^k application
-// (src/app/bfv_ring2k.{h,cu}; examples/13_ring2k.cu): elements of Z_{2^k}, k up to 128, carried by a BFV context whose own plain
-// modulus is not used.  T = uint32_t, uint64_t or unsigned __int128; bits(T)/2 < k <= bits(T).
-//   scale_up     for the operand that is encrypted:            round(Q/2^k * m) mod q_l
-//   centralize   for the operand that multiplies a ciphertext: the centred lift of m mod q_l
-//   scale_down   on Decryptor::bfv_decrypt_without_scaling_down's output: m mod 2^k
-// Plaintexts are full-size RNS polynomials of the chosen level (coefficients beyond the input are zero).  GPU only.
+// ring2k.h -- PolynomialEncoderRing2k<T> of the reference (src/app/bfv_ring2k.h:78-330): polynomials over Z_{2^k}, k up to 128, encoded for BFV
+// outside the context's own plain modulus.  T is uint32_t / uint64_t / unsigned __int128 and k > bits(T) / 2.  The arithmetic lives behind the
+// C-ABI (troyn_ring2k_*, csrc/ring2k_kernels.hpp); this class keeps the reference's method surface: vector, slice (host or device memory) and
+// batched forms of scale_up / centralize, scale_down and decentralize.
 #pragma once
+#include <cstring>
 #include <map>
+#include <mutex>
 
 #include "troy.h"
 
@@ -29,23 +28,55 @@ public:
     size_t slot_count() const { return context_->first_context_data().value()->parms().poly_modulus_degree(); }
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { (void)pool; }   // constants are built on the device on first use
 
-    void scale_up(const std::vector<T>& source, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        encode(source, parms_id, true, destination, pool);
+    // ---- encode: m -> round(Q / 2^k * m) (scale_up, for encryption) or the centred lift of m (centralize, for ciphertext x plaintext) ----
+    void scale_up_slice(utils::ConstSlice<T> source, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        const utils::ConstSlice<T>* one = &source; Plaintext* d = &destination; encode(one, 1, parms_id, true, &d, pool);
     }
-    Plaintext scale_up_new(const std::vector<T>& source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        Plaintext p; scale_up(source, parms_id, p, pool); return p;
+    void scale_up_slice_batched(const utils::ConstSliceVec<T>& source, std::optional<ParmsID> parms_id, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (source.size() != destination.size()) throw std::invalid_argument("[PolynomialEncoderRNSHelper::scale_up_batched] source and destination must have the same size");
+        encode(source.data(), source.size(), parms_id, true, destination.data(), pool);
+    }
+    void scale_up(const std::vector<T>& source, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        scale_up_slice(utils::ConstSlice<T>(source.data(), source.size(), false), parms_id, destination, pool);
+    }
+    Plaintext scale_up_slice_new(utils::ConstSlice<T> source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; scale_up_slice(source, parms_id, p, pool); return p; }
+    Plaintext scale_up_new(const std::vector<T>& source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; scale_up(source, parms_id, p, pool); return p; }
+
+    void centralize_slice(utils::ConstSlice<T> source, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        const utils::ConstSlice<T>* one = &source; Plaintext* d = &destination; encode(one, 1, parms_id, false, &d, pool);
+    }
+    void centralize_slice_batched(const utils::ConstSliceVec<T>& source, std::optional<ParmsID> parms_id, const std::vector<Plaintext*>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        if (source.size() != destination.size()) throw std::invalid_argument("[PolynomialEncoderRNSHelper::centralize_batched] source and destination must have the same size");
+        encode(source.data(), source.size(), parms_id, false, destination.data(), pool);
     }
     void centralize(const std::vector<T>& source, std::optional<ParmsID> parms_id, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        encode(source, parms_id, false, destination, pool);
+        centralize_slice(utils::ConstSlice<T>(source.data(), source.size(), false), parms_id, destination, pool);
     }
-    Plaintext centralize_new(const std::vector<T>& source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        Plaintext p; centralize(source, parms_id, p, pool); return p;
+    Plaintext centralize_slice_new(utils::ConstSlice<T> source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; centralize_slice(source, parms_id, p, pool); return p; }
+    Plaintext centralize_new(const std::vector<T>& source, std::optional<ParmsID> parms_id, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext p; centralize(source, parms_id, p, pool); return p; }
+
+    // ---- decode: scale_down takes the phase c(s) of a ciphertext in coefficient form (Decryptor::bfv_decrypt_without_scaling_down); decentralize takes
+    //      x mod Q (the inverse of centralize) and optionally divides by an odd correction factor ----
+    void scale_down_slice(const Plaintext& input, utils::Slice<T> destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { decode(input, true, 1, destination, pool); }
+    void scale_down(const Plaintext& input, std::vector<T>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        destination.resize(input.coeff_count());
+        scale_down_slice(input, utils::Slice<T>(destination.data(), destination.size(), false), pool);
     }
-    // input: the phase c(s) of a ciphertext in coefficient form (Decryptor::bfv_decrypt_without_scaling_down)
-    std::vector<T> scale_down_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+    utils::Array<T> scale_down_slice_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a(input.coeff_count(), false); scale_down_slice(input, a.reference(), pool); return a; }
+    std::vector<T> scale_down_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<T> v; scale_down(input, v, pool); return v; }
+
+    void decentralize_slice(const Plaintext& input, utils::Slice<T> destination, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { decode(input, false, correction_factor, destination, pool); }
+    void decentralize(const Plaintext& input, std::vector<T>& destination, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
+        destination.resize(input.coeff_count());
+        decentralize_slice(input, utils::Slice<T>(destination.data(), destination.size(), false), correction_factor, pool);
+    }
+    utils::Array<T> decentralize_slice_new(const Plaintext& input, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a(input.coeff_count(), false); decentralize_slice(input, a.reference(), correction_factor, pool); return a; }
+    std::vector<T> decentralize_new(const Plaintext& input, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<T> v; decentralize(input, v, correction_factor, pool); return v; }
 
 private:
-    void encode(const std::vector<T>& source, std::optional<ParmsID> parms_id, bool scale, Plaintext& destination, MemoryPoolHandle pool) const;
+    // `count` sources (host or device memory each) -> `count` plaintexts: one staging buffer, `count` launches on the thread's stream, one wait
+    void encode(const utils::ConstSlice<T>* source, size_t count, std::optional<ParmsID> parms_id, bool scale, Plaintext* const* destination, MemoryPoolHandle pool) const;
+    void decode(const Plaintext& input, bool scale, T correction_factor, utils::Slice<T> destination, MemoryPoolHandle pool) const;
     const troyn_ring2k* helper(const ParmsID& parms_id) const;   // PolynomialEncoderRNSHelper of that level
     HeContextPointer context_;
     size_t t_bit_length_;

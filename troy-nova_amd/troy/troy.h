@@ -119,8 +119,16 @@ public:
         std::copy(source.begin(), source.end(), data_.begin());
     }
     static Array create_and_copy_from_slice(ConstSlice<T> source, bool on_device = false, std::shared_ptr<MemoryPool> pool = nullptr) { Array a(source.size(), on_device, pool); a.copy_from_slice(source); return a; }
+    static Array create_uninitialized(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) { return Array(count, on_device, pool); }   // box.h:342-350
+    static Array from_vector(std::vector<T> values) { return Array(std::move(values)); }
+    // an Array<T> of this mirror stays in host memory (device payloads are DynamicArray): the slices it hands out say so, and the encoders stage them
+    void to_device_inplace(std::shared_ptr<MemoryPool> pool = nullptr) { (void)pool; }
+    void to_host_inplace() {}
+    Array clone(std::shared_ptr<MemoryPool> pool = nullptr) const { (void)pool; return *this; }
     ConstSlice<T> const_reference() const { return ConstSlice<T>(data_.data(), data_.size(), false); }
     Slice<T> reference() { return Slice<T>(data_.data(), data_.size(), false); }
+    ConstSlice<T> const_slice(size_t begin, size_t end) const { return ConstSlice<T>(data_.data() + begin, end - begin, false); }
+    Slice<T> slice(size_t begin, size_t end) { return Slice<T>(data_.data() + begin, end - begin, false); }
     std::vector<T> to_vector() const { return data_; }
     T* raw_pointer() { return data_.data(); }
     const T* raw_pointer() const { return data_.data(); }
@@ -349,6 +357,15 @@ namespace batch_utils {
 template <typename T> std::vector<T*> collect_pointer(std::vector<T>& v) { std::vector<T*> r; r.reserve(v.size()); for (T& x : v) r.push_back(&x); return r; }
 template <typename T> std::vector<const T*> collect_const_pointer(const std::vector<T>& v) { std::vector<const T*> r; r.reserve(v.size()); for (const T& x : v) r.push_back(&x); return r; }
 template <typename T> std::vector<const T*> pcollect_const_pointer(const std::vector<T*>& v) { return std::vector<const T*>(v.begin(), v.end()); }
+// the view-collecting helpers of utils/box_batch.h:256-398 (r*: from a vector of objects, p*: from a vector of pointers), written over one generic mapper
+namespace detail { template <typename R, typename V, typename F> std::vector<R> mapped(V&& v, F f) { std::vector<R> r; r.reserve(v.size()); for (auto&& x : v) r.push_back(f(x)); return r; } }
+template <typename T> utils::ConstSliceVec<T> rcollect_as_const(const utils::SliceVec<T>& v) { return detail::mapped<utils::ConstSlice<T>>(v, [](const utils::Slice<T>& x) { return x.as_const(); }); }
+template <typename T> std::vector<T> clone(const std::vector<T>& v) { return detail::mapped<T>(v, [](const T& x) { return x.clone(); }); }
+template <typename T> std::vector<T> pclone(const std::vector<T*>& v) { return detail::mapped<T>(v, [](T* x) { return x->clone(); }); }
+template <typename T, typename U = uint64_t> utils::ConstSliceVec<U> pcollect_const_reference(const std::vector<const T*>& v) { return detail::mapped<utils::ConstSlice<U>>(v, [](const T* x) { return x->const_reference(); }); }
+template <typename T, typename U = uint64_t> utils::ConstSliceVec<U> rcollect_const_reference(const std::vector<T>& v) { return detail::mapped<utils::ConstSlice<U>>(v, [](const T& x) { return x.const_reference(); }); }
+template <typename T, typename U = uint64_t> utils::SliceVec<U> pcollect_reference(const std::vector<T*>& v) { return detail::mapped<utils::Slice<U>>(v, [](T* x) { return x->reference(); }); }
+template <typename T, typename U = uint64_t> utils::SliceVec<U> rcollect_reference(std::vector<T>& v) { return detail::mapped<utils::Slice<U>>(v, [](T& x) { return x.reference(); }); }
 }  // namespace batch_utils
 
 // ----------------------------------------------------------------------------------------------
@@ -566,6 +583,9 @@ public:
     utils::Slice<uint64_t> poly(size_t p) { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::Slice<uint64_t>(data_.raw_pointer() + p * d, d, on_device()); }
     utils::ConstSlice<uint64_t> poly(size_t p) const { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::ConstSlice<uint64_t>(data_.raw_pointer() + p * d, d, on_device()); }
     utils::ConstSlice<uint64_t> const_poly(size_t p) const { return poly(p); }
+    utils::ConstSlice<uint64_t> const_reference() const { return utils::ConstSlice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }   // ciphertext.h:199-209: all polynomials
+    utils::ConstSlice<uint64_t> reference() const { return const_reference(); }
+    utils::Slice<uint64_t> reference() { return utils::Slice<uint64_t>(data_.raw_pointer(), data_.size(), on_device()); }
     utils::Slice<uint64_t> polys(size_t lo, size_t hi) { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::Slice<uint64_t>(data_.raw_pointer() + lo * d, (hi - lo) * d, on_device()); }
     utils::ConstSlice<uint64_t> polys(size_t lo, size_t hi) const { const size_t d = coeff_modulus_size_ * poly_modulus_degree_; return utils::ConstSlice<uint64_t>(data_.raw_pointer() + lo * d, (hi - lo) * d, on_device()); }
     utils::ConstSlice<uint64_t> const_polys(size_t lo, size_t hi) const { return polys(lo, hi); }
@@ -639,6 +659,8 @@ public:
     }
     utils::ConstSlice<uint64_t> const_component(size_t index) const { return component(index); }
     utils::ConstSlice<uint64_t> const_reference() const { return poly(); }
+    utils::ConstSlice<uint64_t> reference() const { return poly(); }                                    // plaintext.h:167-169
+    utils::Slice<uint64_t> reference() { return poly(); }
     void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
     void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
     // plaintext.cu resize_rns_partial: an RNS polynomial that keeps only its first coeff_count coefficients, data[l * coeff_count + i]
