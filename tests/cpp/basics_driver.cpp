@@ -2,6 +2,7 @@
 // SEAL's default parameters (CoeffModulus::bfv_default), context qualifiers, the invariant noise budget along a computation
 // (fresh > after a multiplication > ... > 0, at which point decryption stops being correct), modulus switching down the chain.
 #include <cstdio>
+#include <sstream>
 #include <random>
 
 #include "../../troy-nova_amd/troy/troy.h"
@@ -86,6 +87,41 @@ int main() {
             views = views && host[5] == h.poly_component(1, 1)[5] && !h.poly(0).on_device();
             std::printf("slice views %d\n", (int)views);
             ok = ok && views;
+        }
+        // batch_utils collectors, Ciphertext::resize / reconfigure_like with the reference's argument meaning, Modulus::const_ratio as a slice, operator<<
+        {
+            std::vector<Ciphertext> batch{cx, cx, cx};
+            const auto c1s = batch_utils::rcollect_const_poly(batch, 1);
+            const auto both = batch_utils::rcollect_polys(batch, 0, 2);
+            const auto ptrs = batch_utils::collect_const_pointer(batch);
+            const auto c0s = batch_utils::pcollect_const_poly(ptrs, 0);
+            const size_t d = cx.poly_modulus_degree() * cx.coeff_modulus_size();
+            bool surf = c1s.size() == 3 && c1s[2].size() == d && c1s[1].raw_pointer() == batch[1].poly(1).raw_pointer() && both[0].size() == 2 * d && c0s[2].raw_pointer() == batch[2].data().raw_pointer();
+            surf = surf && batch_utils::rcollect_as_const(both)[1].raw_pointer() == both[1].raw_pointer() && batch_utils::clone(batch).size() == 3 && batch_utils::rcollect_const_reference(batch)[0].size() == 2 * d;
+            Ciphertext grown = cx;
+            grown.resize(context, cx.parms_id(), 3);                                   // defaults: the old polynomials are kept, the new one is zero
+            surf = surf && grown.polynomial_count() == 3 && grown.polys(0, 2).to_vector() == cx.data().to_vector();
+            bool zero = true;
+            for (uint64_t w : grown.poly(2).to_vector()) zero = zero && w == 0;
+            surf = surf && zero && !grown.is_transparent();
+            Ciphertext raw = cx;
+            raw.resize(context, cx.parms_id(), 3, false, true);                        // the new polynomial is left as allocated; the old ones are still there
+            surf = surf && raw.polys(0, 2).to_vector() == cx.data().to_vector();
+            Ciphertext like;
+            like.data() = utils::DynamicArray(0, true);
+            like.scale() = 0.5;
+            like.reconfigure_like(context, cx, 2);
+            surf = surf && like.parms_id() == cx.parms_id() && like.polynomial_count() == 2 && like.is_ntt_form() == cx.is_ntt_form() && like.scale() == cx.scale() && like.is_transparent();
+            bool threw = false;
+            try { like.resize(context, cx.parms_id(), 1); } catch (const std::invalid_argument&) { threw = true; }
+            const Modulus q0 = context->first_context_data().value()->parms().coeff_modulus()[0];
+            const unsigned __int128 ratio = (static_cast<unsigned __int128>(q0.const_ratio()[1]) << 64) | q0.const_ratio()[0];
+            surf = surf && threw && q0.const_ratio().size() == 3 && ratio == (~static_cast<unsigned __int128>(0)) / q0.value();     // floor(2^128 / q) for an odd q
+            std::stringstream text;
+            text << q0;
+            surf = surf && text.str() == "Modulus(" + std::to_string(q0.value()) + ")";
+            std::printf("collectors, resize, reconfigure_like, const_ratio %d\n", (int)surf);
+            ok = ok && surf;
         }
         std::printf(ok ? "OK\n" : "FAIL\n");
         MemoryPool::Destroy();

@@ -55,6 +55,14 @@ int main(int argc, char** argv) {
                     }
 
         Conv2dHelper helper(bs, ic, oc, ih, iw, kh, kw, n, right ? MatmulObjective::EncryptRight : MatmulObjective::EncryptLeft);
+        {
+            std::stringstream text;
+            text << helper;
+            if (text.str().rfind("Conv2dHelper(batch_size=", 0) != 0 || text.str().find(right ? "objective=EncryptRight)" : "objective=EncryptLeft)") == std::string::npos || !helper.batched_mul) {
+                std::printf("operator<< gives %s\n", text.str().c_str());
+                return 1;
+            }
+        }
         std::printf("block b %zu ci %zu co %zu h %zu w %zu tiles %zu objective %s\n", helper.batch_block, helper.input_channel_block, helper.output_channel_block,
                     helper.image_height_block, helper.image_width_block, helper.get_total_batch_size(), right ? "right" : "left");
         const double t0 = now();

@@ -61,6 +61,12 @@ static bool run_matmul(const HeContextPointer& he, const KeyGenerator& keygen, c
     for (size_t i = 0; i < M; i++) for (size_t k = 0; k < R; k++) for (size_t j = 0; j < Nn; j++) want[i * Nn + j] = static_cast<T>((want[i * Nn + j] + x[i * R + k] * w[k * Nn + j]) & mask);
     for (size_t i = 0; i < M * Nn; i++) want[i] = static_cast<T>((want[i] + sb[i]) & mask);
     linear::MatmulHelper helper(M, R, Nn, n, linear::MatmulObjective::EncryptLeft, pack_lwe);
+    {
+        std::stringstream text;
+        text << helper;
+        const std::string want_text = "MatmulHelper(batch_size=9, input_dims=40, output_dims=17, slot_count=" + std::to_string(n) + ", objective=EncryptLeft, pack_lwe=" + (pack_lwe ? "1" : "0") + ")";
+        if (text.str() != want_text) { std::printf("operator<< gives %s\n", text.str().c_str()); return false; }
+    }
     linear::Plain2d we = helper.encode_weights_ring2k(encoder, w.data(), std::nullopt);
     linear::Cipher2d xe = helper.encrypt_inputs_ring2k(encryptor, encoder, x.data(), std::nullopt);
     std::stringstream wire;

@@ -52,6 +52,7 @@ public:
     template <typename T> Cipher2d encrypt_inputs_ring2k(const Encryptor& encryptor, const PolynomialEncoderRing2k<T>& encoder, const T* inputs, std::optional<ParmsID> parms_id) const;
     template <typename T> Plain2d encode_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const T* outputs, std::optional<ParmsID> parms_id) const;
     template <typename T> std::vector<T> decrypt_outputs_ring2k(const PolynomialEncoderRing2k<T>& encoder, const Decryptor& decryptor, const Cipher2d& outputs) const;
+    bool batched_mul = true;          // conv2d.h:49-52: always the case here
     void set_pool(MemoryPoolHandle p) { pool = std::move(p); }
     void serialize_outputs(const Evaluator& evaluator, const Cipher2d& x, std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
     Cipher2d deserialize_outputs(const Evaluator& evaluator, std::istream& stream) const;
@@ -224,6 +225,12 @@ std::vector<T> Conv2dHelper::decrypt_outputs_ring2k(const PolynomialEncoderRing2
     std::vector<T> out(batch_size * output_channels * oyh * oyw, 0);
     for_each_output([&](size_t tile, size_t group, size_t coefficient, size_t index) { out[index] = coeffs[tile * groups + group][coefficient]; });
     return out;
+}
+
+inline std::ostream& operator<<(std::ostream& os, const Conv2dHelper& h) {               // conv2d.cu:5-18
+    return os << "Conv2dHelper(batch_size=" << h.batch_size << ", input_channels=" << h.input_channels << ", output_channels=" << h.output_channels << ", image_height=" << h.image_height
+              << ", image_width=" << h.image_width << ", kernel_height=" << h.kernel_height << ", kernel_width=" << h.kernel_width << ", slot_count=" << h.slot_count
+              << ", objective=" << h.objective << ")";
 }
 
 }}  // namespace troy::linear

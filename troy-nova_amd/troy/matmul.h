@@ -11,6 +11,7 @@
 // with (bb, ib, ob) = (batch_block, input_block, output_block), bb*ib*ob <= N.
 #pragma once
 #include <functional>
+#include <ostream>
 
 #include "ring2k.h"
 #include "troy.h"
@@ -18,6 +19,10 @@
 namespace troy { namespace linear {
 
 enum class MatmulObjective : uint8_t { EncryptLeft = 0, EncryptRight = 1, Crossed = 2 };
+inline std::ostream& operator<<(std::ostream& os, const MatmulObjective& obj) {        // matmul.h:165-172
+    static const char* const names[] = {"EncryptLeft", "EncryptRight", "Crossed"};
+    return os << names[static_cast<size_t>(obj) < 3 ? static_cast<size_t>(obj) : 0];
+}
 
 class Cipher2d;
 
@@ -315,6 +320,11 @@ Cipher2d MatmulHelper::matmul_fly_ring2k(const PolynomialEncoderRing2k<T>& encod
         }
         return row;
     }, pool);
+}
+
+inline std::ostream& operator<<(std::ostream& os, const MatmulHelper& h) {               // matmul.cu:6-10
+    return os << "MatmulHelper(batch_size=" << h.batch_size << ", input_dims=" << h.input_dims << ", output_dims=" << h.output_dims << ", slot_count=" << h.slot_count
+              << ", objective=" << h.objective << ", pack_lwe=" << h.pack_lwe << ")";
 }
 
 }}  // namespace troy::linear

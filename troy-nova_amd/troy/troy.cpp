@@ -575,20 +575,19 @@ void DynamicArray::set_zero() {
     else std::memset(data_, 0, size_ * sizeof(uint64_t));
 }
 
-void DynamicArray::resize(size_t count, bool keep) {
-    if (count == size_) return;
-    DynamicArray n(count, device_, pool_);
-    if (keep && size_ && count) {
-        n.copy_from(data_, std::min(count, size_), device_);
-        if (count > size_) {
-            if (device_) hip_check(hipMemsetAsync(n.data_ + size_, 0, (count - size_) * sizeof(uint64_t), current_stream()), "memset");
-            else std::memset(n.data_ + size_, 0, (count - size_) * sizeof(uint64_t));
-        }
-    } else {
-        n.set_zero();
+static void resize_array(DynamicArray& a, size_t count, bool zero_rest, bool copy_data, size_t old_size, bool device, MemoryPoolHandle pool) {
+    if (count == old_size) return;
+    DynamicArray n(count, device, pool);
+    const size_t kept = (copy_data && old_size && count) ? std::min(count, old_size) : 0;
+    if (kept) n.copy_from(a.raw_pointer(), kept, device);
+    if (zero_rest && count > kept) {
+        if (device) hip_check(hipMemsetAsync(n.raw_pointer() + kept, 0, (count - kept) * sizeof(uint64_t), current_stream()), "memset");
+        else std::memset(n.raw_pointer() + kept, 0, (count - kept) * sizeof(uint64_t));
     }
-    *this = std::move(n);
+    a = std::move(n);
 }
+void DynamicArray::resize(size_t count, bool copy_data) { resize_array(*this, count, true, copy_data, size_, device_, pool_); }
+void DynamicArray::resize_uninitialized(size_t count, bool copy_data) { resize_array(*this, count, false, copy_data, size_, device_, pool_); }
 
 void DynamicArray::to_device_inplace(MemoryPoolHandle pool) {
     if (device_) return;
@@ -1009,15 +1008,25 @@ Ciphertext Ciphertext::clone(MemoryPoolHandle pool) const {
     return c;
 }
 
-void Ciphertext::resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep) {
+void Ciphertext::resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool fill_extra_with_zeros, bool copy_data) {
+    if (!context->parameters_set()) throw std::invalid_argument("[Ciphertext::resize] Context is not set correctly.");
     auto cd = context->get_context_data(parms_id);
-    if (!cd.has_value()) throw std::invalid_argument("[Ciphertext::resize] ParmsID is not valid for the current context.");
+    if (!cd.has_value()) throw std::invalid_argument("[Ciphertext::resize] ParmsID is not valid.");
+    if (polynomial_count < 2 || polynomial_count > 16) throw std::invalid_argument("[Ciphertext::resize_internal] Polynomial count is invalid.");    // HE_CIPHERTEXT_SIZE_MIN / _MAX
     const EncryptionParameters& p = cd.value()->parms();
     parms_id_ = parms_id;
     polynomial_count_ = polynomial_count;
     coeff_modulus_size_ = p.coeff_modulus().size();
     poly_modulus_degree_ = p.poly_modulus_degree();
-    data_.resize(polynomial_count_ * coeff_modulus_size_ * poly_modulus_degree_, keep);
+    const size_t words = polynomial_count_ * coeff_modulus_size_ * poly_modulus_degree_;
+    if (fill_extra_with_zeros) data_.resize(words, copy_data); else data_.resize_uninitialized(words, copy_data);
+}
+
+void Ciphertext::reconfigure_like(const HeContextPointer& context, const Ciphertext& other, size_t polynomial_count, bool fill_extra_with_zeros) {
+    resize(context, other.parms_id(), polynomial_count, fill_extra_with_zeros, true);
+    correction_factor_ = other.correction_factor();
+    scale_ = other.scale();
+    is_ntt_form_ = other.is_ntt_form();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2420,7 +2429,7 @@ void symmetric(const SecretKey& sk, HeContextPointer context, const ParmsID& par
     hipStream_t s = current_stream();
     destination = Ciphertext();
     destination.data() = utils::DynamicArray(0, true, pool);
-    destination.resize(context, parms_id, 2, false);
+    destination.resize(context, parms_id, 2, true, false);
     destination.is_ntt_form() = is_ntt_form;
     destination.scale() = 1.0;
     destination.correction_factor() = 1;
@@ -2465,7 +2474,7 @@ void asymmetric(const PublicKey& pk, HeContextPointer context, const ParmsID& pa
     const size_t encrypted_size = public_key.polynomial_count();
     destination = Ciphertext();
     destination.data() = utils::DynamicArray(0, true, pool);
-    destination.resize(context, parms_id, encrypted_size, false);
+    destination.resize(context, parms_id, encrypted_size, true, false);
     destination.is_ntt_form() = is_ntt_form;
     destination.scale() = 1.0;
     destination.correction_factor() = 1;
@@ -2632,7 +2641,7 @@ void Encryptor::encrypt_zero_internal(const ParmsID& parms_id, bool is_ntt_form,
     const size_t pc = temp.polynomial_count();
     Ciphertext out;
     out.data() = utils::DynamicArray(0, true, pool);
-    out.resize(context_, parms_id, pc, false);
+    out.resize(context_, parms_id, pc, true, false);
     hipStream_t s = current_stream();
     if (cd->parms().scheme() == SchemeType::BGV) {
         // encryptor.cu:65-84

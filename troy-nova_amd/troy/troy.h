@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstring>
 #include <iosfwd>
+#include <ostream>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -54,6 +55,9 @@ inline bool available(CompressionMode mode) { return mode == CompressionMode::Ni
 // user programs touch: size(), operator[], iteration, to_vector(), Array::copy_from_slice.
 namespace utils {
 class MemoryPool;
+// bytes between a slice (host or device) and host memory: what to_vector() and the encoders' *_slice forms go through (troy.cpp)
+void slice_bytes_to_host(const void* src, bool src_on_device, void* dst, size_t bytes);
+void host_bytes_to_slice(void* dst, bool dst_on_device, const void* src, size_t bytes);
 template <typename T>
 class ConstSlice {
 public:
@@ -67,7 +71,12 @@ public:
     const T* begin() const noexcept { return ptr_; }
     const T* end() const noexcept { return ptr_ + len_; }
     ConstSlice const_slice(size_t begin, size_t end) const { return ConstSlice(ptr_ + begin, end - begin, device_); }
-    std::vector<T> to_vector() const { return std::vector<T>(ptr_, ptr_ + len_); }
+    std::vector<T> to_vector() const {                                                            // box.h: a host copy, wherever the view points
+        if (!device_) return std::vector<T>(ptr_, ptr_ + len_);
+        std::vector<T> v(len_);
+        if (len_) slice_bytes_to_host(ptr_, true, v.data(), len_ * sizeof(T));
+        return v;
+    }
     operator std::vector<T>() const { return to_vector(); }                                       // NOLINT
     operator const T*() const noexcept { return ptr_; }                                           // NOLINT: the C-ABI takes raw device pointers
 private:
@@ -86,6 +95,7 @@ public:
     T* raw_pointer() const noexcept { return ptr_; }
     T& operator[](size_t i) const { return ptr_[i]; }
     ConstSlice<T> as_const() const { return ConstSlice<T>(ptr_, len_, device_); }
+    std::vector<T> to_vector() const { return as_const().to_vector(); }
     operator ConstSlice<T>() const { return as_const(); }                                         // NOLINT
     operator T*() const noexcept { return ptr_; }                                                 // NOLINT
     ConstSlice<T> const_slice(size_t begin, size_t end) const { return ConstSlice<T>(ptr_ + begin, end - begin, device_); }
@@ -135,9 +145,6 @@ public:
 private:
     std::vector<T> data_;
 };
-// bytes between a slice (host or device) and host memory: what the encoders' *_slice forms stage through (troy.cpp)
-void slice_bytes_to_host(const void* src, bool src_on_device, void* dst, size_t bytes);
-void host_bytes_to_slice(void* dst, bool dst_on_device, const void* src, size_t bytes);
 template <typename T> std::vector<T> slice_to_vector(ConstSlice<T> s) {
     std::vector<T> v(s.size());
     if (s.size()) slice_bytes_to_host(s.raw_pointer(), s.on_device(), v.data(), s.size() * sizeof(T));
@@ -257,7 +264,8 @@ public:
     uint64_t& operator[](size_t i) { return data_[i]; }             // host only
     const uint64_t& operator[](size_t i) const { return data_[i]; } // host only
     void set_zero();
-    void resize(size_t count, bool keep = true);
+    void resize(size_t count, bool copy_data = true);                 // dynamic_array.h:183-189: what is not copied is zero
+    void resize_uninitialized(size_t count, bool copy_data = true);   //   ... or left as allocated
     void to_device_inplace(MemoryPoolHandle pool);
     void to_host_inplace();
     void copy_from(const uint64_t* src, size_t count, bool src_on_device);
@@ -316,7 +324,7 @@ public:
     size_t bit_count() const { return bit_count_; }
     bool is_prime() const { return is_prime_; }
     bool is_zero() const { return value_ == 0; }
-    const uint64_t* const_ratio() const { return const_ratio_; }
+    utils::ConstSlice<uint64_t> const_ratio() const { return utils::ConstSlice<uint64_t>(const_ratio_, 3, false); }   // modulus.h:94-97: floor(2^128 / value) (two words) and the remainder
     uint64_t reduce(uint64_t input) const;
     uint64_t reduce_mul_uint64(uint64_t operand1, uint64_t operand2) const {                 // modulus.h:86-92 (Barrett-128; the canonical residue)
         return static_cast<uint64_t>((static_cast<unsigned __int128>(operand1) * operand2) % value_);
@@ -330,6 +338,8 @@ private:
     size_t bit_count_ = 0;
     bool is_prime_ = false;
 };
+
+inline std::ostream& operator<<(std::ostream& os, const Modulus& modulus) { return os << "Modulus(" << modulus.value() << ")"; }   // modulus.h:126-129
 
 class CoeffModulus {
 public:
@@ -593,7 +603,9 @@ public:
     utils::ConstSlice<uint64_t> poly_component(size_t p, size_t c) const { return utils::ConstSlice<uint64_t>(data_.raw_pointer() + (p * coeff_modulus_size_ + c) * poly_modulus_degree_, poly_modulus_degree_, on_device()); }
     utils::ConstSlice<uint64_t> const_poly_component(size_t p, size_t c) const { return poly_component(p, c); }
     // resize(context, parms_id, polynomial_count) -- src/ciphertext.cu:26-60
-    void resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool keep = true);
+    // ciphertext.h:196-197 (ciphertext.cu:25-71)
+    void resize(const HeContextPointer& context, const ParmsID& parms_id, size_t polynomial_count, bool fill_extra_with_zeros = true, bool copy_data = true);
+    void reconfigure_like(const HeContextPointer& context, const Ciphertext& other, size_t polynomial_count, bool fill_extra_with_zeros = true);
     // ciphertext.cu:79-210, ciphertext.h:257-270: [CompressionMode][raw fields]; a seeded ciphertext stores c0 + seed only
     size_t save(std::ostream& stream, HeContextPointer context, CompressionMode mode = CompressionMode::Nil) const;
     void load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool());
@@ -1560,6 +1572,22 @@ private:
                                               std::vector<const uint64_t*>& key_ptrs) const;
     HeContextPointer context_;
 };
+
+// batch_utils.h:28-135: views of one polynomial (or a range of polynomials) of every ciphertext / of every plaintext of a batch
+namespace batch_utils {
+inline utils::ConstSliceVec<uint64_t> pcollect_const_poly(const std::vector<const Ciphertext*>& v, size_t poly_id) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [poly_id](const Ciphertext* c) { return c->const_poly(poly_id); }); }
+inline utils::ConstSliceVec<uint64_t> rcollect_const_poly(const std::vector<Ciphertext>& v, size_t poly_id) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [poly_id](const Ciphertext& c) { return c.const_poly(poly_id); }); }
+inline utils::ConstSliceVec<uint64_t> pcollect_const_poly(const std::vector<const Plaintext*>& v) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [](const Plaintext* p) { return p->const_poly(); }); }
+inline utils::ConstSliceVec<uint64_t> rcollect_const_poly(std::vector<Plaintext>& v) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [](const Plaintext& p) { return p.const_poly(); }); }
+inline utils::SliceVec<uint64_t> pcollect_poly(const std::vector<Ciphertext*>& v, size_t poly_id) { return detail::mapped<utils::Slice<uint64_t>>(v, [poly_id](Ciphertext* c) { return c->poly(poly_id); }); }
+inline utils::SliceVec<uint64_t> rcollect_poly(std::vector<Ciphertext>& v, size_t poly_id) { return detail::mapped<utils::Slice<uint64_t>>(v, [poly_id](Ciphertext& c) { return c.poly(poly_id); }); }
+inline utils::SliceVec<uint64_t> pcollect_poly(const std::vector<Plaintext*>& v) { return detail::mapped<utils::Slice<uint64_t>>(v, [](Plaintext* p) { return p->poly(); }); }
+inline utils::SliceVec<uint64_t> rcollect_poly(std::vector<Plaintext>& v) { return detail::mapped<utils::Slice<uint64_t>>(v, [](Plaintext& p) { return p.poly(); }); }
+inline utils::ConstSliceVec<uint64_t> pcollect_const_polys(const std::vector<const Ciphertext*>& v, size_t lo, size_t hi) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [lo, hi](const Ciphertext* c) { return c->const_polys(lo, hi); }); }
+inline utils::ConstSliceVec<uint64_t> rcollect_const_polys(const std::vector<Ciphertext>& v, size_t lo, size_t hi) { return detail::mapped<utils::ConstSlice<uint64_t>>(v, [lo, hi](const Ciphertext& c) { return c.const_polys(lo, hi); }); }
+inline utils::SliceVec<uint64_t> pcollect_polys(const std::vector<Ciphertext*>& v, size_t lo, size_t hi) { return detail::mapped<utils::Slice<uint64_t>>(v, [lo, hi](Ciphertext* c) { return c->polys(lo, hi); }); }
+inline utils::SliceVec<uint64_t> rcollect_polys(std::vector<Ciphertext>& v, size_t lo, size_t hi) { return detail::mapped<utils::Slice<uint64_t>>(v, [lo, hi](Ciphertext& c) { return c.polys(lo, hi); }); }
+}  // namespace batch_utils
 
 }  // namespace troy
 
