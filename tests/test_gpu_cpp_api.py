@@ -324,7 +324,9 @@ def test_pool_high_water_mark_cpp_api(dev):
     drv = os.path.join(ROOT, "tests", "cpp", "he_bench_driver")
     if not os.path.exists(drv):
         pytest.fail("tests/cpp/he_bench_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    r = subprocess.run([drv, "pool"], capture_output=True, text=True, timeout=300)
+    # the policy under test is the DEFAULT mapping of host threads to streams: with call combining or a one-stream set every thread shares a stream and reuse is immediate
+    env = {k: v for k, v in os.environ.items() if k not in ("TROY_COMBINE", "TROY_STREAMS", "TROY_POOL_HIGH_WATER_MB")}
+    r = subprocess.run([drv, "pool"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     kv = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.strip()}
     assert kv["pool_uncapped_held_MB"][0] == "96" and kv["pool_capped_held_MB"][0] == "48" and kv["pool_concurrent_allocate_clashes"][0] == "0", r.stdout
