@@ -4,6 +4,8 @@
 // prev_context_data of every level.  `context_driver host` touches no device; `context_driver device` adds to_device_inplace for the three schemes.
 #include <cstdio>
 #include <cstring>
+#include <iostream>
+#include <sstream>
 
 #include "../../troy-nova_amd/troy/troy.h"
 
@@ -154,6 +156,35 @@ static void run_constants() {
     check(ok, "CKKS level constants: 2^63, (Q + 1) / 2, -2^64 mod q_i");
 }
 
+// troy::bench timers (src/utils/timer.h, timer.cpp): the merged view over host threads, the default divisor, reset, the byte formatter
+static void run_timers() {
+    std::vector<bench::Timer> per_thread(3);
+    for (size_t t = 0; t < per_thread.size(); t++) {
+        per_thread[t].tab(1);
+        const size_t a = per_thread[t].register_timer("encrypt"), b = per_thread[t].register_timer(t == 2 ? "only-here" : "multiply");
+        for (size_t rep = 0; rep <= t; rep++) { per_thread[t].tick(a); per_thread[t].tock(a); }
+        per_thread[t].tick(b); per_thread[t].tock(b);
+    }
+    std::stringstream captured;
+    std::streambuf* old = std::cout.rdbuf(captured.rdbuf());
+    bench::TimerThreaded::Print(per_thread);
+    bench::TimerThreaded::PrintDivided(per_thread, 10);
+    per_thread[2].print_divided();                       // the default divisor is the number of tick / tock pairs (3 for "encrypt")
+    bench::print_communication("ciphertexts", 1, 3 * 1024 * 1024, 3);
+    bench::print_communication(512); std::cout << std::endl;
+    std::cout.rdbuf(old);
+    const std::string text = captured.str();
+    size_t lines = 0;
+    for (char c : text) lines += c == '\n';
+    const bool merged = text.find("  encrypt") != std::string::npos && text.find("  multiply") != std::string::npos && text.find("  only-here") != std::string::npos &&
+                        text.find("/ thread, avg") != std::string::npos && text.find("/ op (total max") != std::string::npos && text.find(", 10 times)") != std::string::npos;
+    const bool divisor = text.find(", 3 times)") != std::string::npos && text.find("1.000 MB (total     3.000 MB, 3 times)") != std::string::npos && text.find("512 B") != std::string::npos;
+    check(merged && lines == 3 + 3 + 2 + 1 + 1, "TimerThreaded: one line per distinct name, max and mean over the threads that carry it");
+    check(divisor, "print_divided() divides by the tick count; print_communication formats bytes");
+    per_thread[2].reset();
+    check(per_thread[2].get()[0] == bench::Duration(0) && per_thread[2].names().size() == 2, "Timer::reset clears the accumulations and keeps the names");
+}
+
 int main(int argc, char** argv) {
     try {
         const bool device = argc > 1 && !std::strcmp(argv[1], "device");
@@ -162,6 +193,7 @@ int main(int argc, char** argv) {
         run_chain(SchemeType::BGV);
         run_chain(SchemeType::CKKS);
         run_constants();
+        run_timers();
         if (device) {                                  // he_context.cu:323-360
             for (SchemeType scheme : {SchemeType::BFV, SchemeType::BGV, SchemeType::CKKS}) {
                 EncryptionParameters parms(scheme);
