@@ -131,6 +131,7 @@ static bool run_forms(const std::vector<size_t>& q_bits, const std::vector<size_
             // batches of 0 .. 15 elements
             std::vector<utils::Array<T>> message(B);
             for (size_t i = 0; i < B; i++) { message[i] = utils::Array<T>::from_vector(sample(i)); message[i].to_device_inplace(); }
+            bad += !message[B - 1].on_device() || !message[B - 1].const_reference().on_device() || message[B - 1].to_host().to_vector() != message[B - 1].to_vector();   // really device-resident sources
             std::vector<Plaintext> ups(B), ces(B);
             encoder.scale_up_slice_batched(batch_utils::rcollect_const_reference<utils::Array<T>, T>(message), level, batch_utils::collect_pointer(ups));
             encoder.centralize_slice_batched(batch_utils::rcollect_const_reference<utils::Array<T>, T>(message), level, batch_utils::collect_pointer(ces));
@@ -155,6 +156,19 @@ static bool run_forms(const std::vector<size_t>& q_bits, const std::vector<size_
             const std::vector<uint64_t> rb = back.to_vector();
             std::memcpy(got.data(), rb.data(), n * sizeof(T));
             bad += got != full || encoder.scale_down_slice_new(fu).to_vector() != full;
+        }
+        {   // utils::Array<T> on the device (box.h:300-560): clone / to_host / copy_from_slice in every host-device combination, zero-initialised construction
+            const std::vector<T> v = sample(7);
+            utils::Array<T> d = utils::Array<T>::from_vector(std::vector<T>(v)).to_device(), z(7, true), h(7, false);
+            utils::Array<T> c = d.clone();
+            h.copy_from_slice(d.const_reference());
+            z.copy_from_slice(h.const_reference());
+            utils::Array<T> z2(7, true);
+            z2.copy_from_slice(d.const_slice(0, 7));
+            bad += !d.on_device() || c.to_vector() != v || h.to_vector() != v || z.to_vector() != v || z2.to_vector() != v || utils::Array<T>(5, true).to_vector() != std::vector<T>(5, 0) ||
+                   d.const_slice(2, 5).to_vector() != std::vector<T>(v.begin() + 2, v.begin() + 5);
+            d.to_host_inplace();
+            bad += d.on_device() || d[3] != v[3];
         }
         bool threw = false;
         try { encoder.decentralize_new(encoder.centralize_new(sample(4), std::nullopt), static_cast<T>(2)); } catch (const std::exception&) { threw = true; }

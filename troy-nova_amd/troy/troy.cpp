@@ -191,6 +191,16 @@ void host_bytes_to_slice(void* dst, bool dst_on_device, const void* src, size_t 
     hip_check(stream_wait(), "copy_host_to_device");       // `src` is the caller's (often a temporary)
 }
 
+std::shared_ptr<void> device_bytes_allocate(size_t bytes, std::shared_ptr<MemoryPool> pool, bool zero) {
+    // the block is a DynamicArray of whole words (pool memory, returned to the pool in stream order); the shared_ptr's control block owns it
+    auto block = std::make_shared<DynamicArray>((bytes + 7) / 8, true, pool ? pool : MemoryPool::GlobalPool());
+    if (zero) block->set_zero();
+    return std::shared_ptr<void>(block, static_cast<void*>(block->raw_pointer()));
+}
+void device_bytes_copy(void* dst, const void* src, size_t bytes) {
+    if (bytes) hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, current_stream()), "copy_device_to_device");
+}
+
 size_t device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;   // memory_pool.h:14-33: no usable device -> 0

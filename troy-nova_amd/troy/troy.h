@@ -108,42 +108,63 @@ private:
     bool device_;
 };
 
+// raw device memory for Array<T> (any element type; the uint64_t payloads of ciphertexts / plaintexts are DynamicArray): troy.cpp
+std::shared_ptr<void> device_bytes_allocate(size_t bytes, std::shared_ptr<MemoryPool> pool, bool zero);     // freed (returned to its pool) with the last owner
+void device_bytes_copy(void* dst, const void* src, size_t bytes);                                             // device to device, on the calling thread's stream
+
+// utils/box.h:300-560: the owning array.  Host-resident (a std::vector) or device-resident (pool memory); the views it hands out carry the location, and
+// to_vector() / copy_from_slice() move bytes across whatever the combination.  operator[] and iteration are for host-resident arrays, as in the reference.
 template <typename T>
 class Array {
 public:
     Array() = default;
-    Array(std::vector<T> values) : data_(std::move(values)) {}                                    // NOLINT: implicit by design
-    operator std::vector<T>() const { return data_; }                                            // NOLINT
-    typename std::vector<T>::const_iterator begin() const noexcept { return data_.begin(); }
-    typename std::vector<T>::const_iterator end() const noexcept { return data_.end(); }
-    Array(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) : data_(count) {
-        (void)pool;
-        if (on_device) throw std::invalid_argument("[Array::Array] device arrays of this mirror are utils::DynamicArray (uint64_t payloads); Array<T> holds host-side data.");
+    Array(std::vector<T> values) : host_(std::move(values)), count_(host_.size()) {}             // NOLINT: implicit by design
+    Array(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) : count_(count), device_(on_device) { allocate(pool, true); }
+    static Array create_uninitialized(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) {   // box.h:342-350
+        Array a; a.count_ = count; a.device_ = on_device; a.allocate(pool, false); return a;
     }
-    size_t size() const noexcept { return data_.size(); }
-    bool on_device() const noexcept { return false; }
-    T& operator[](size_t i) { return data_[i]; }
-    const T& operator[](size_t i) const { return data_[i]; }
-    void copy_from_slice(ConstSlice<T> source) {
-        if (source.size() != data_.size()) throw std::invalid_argument("[Array::copy_from_slice] Slice size does not match the array size.");
-        std::copy(source.begin(), source.end(), data_.begin());
-    }
-    static Array create_and_copy_from_slice(ConstSlice<T> source, bool on_device = false, std::shared_ptr<MemoryPool> pool = nullptr) { Array a(source.size(), on_device, pool); a.copy_from_slice(source); return a; }
-    static Array create_uninitialized(size_t count, bool on_device, std::shared_ptr<MemoryPool> pool = nullptr) { return Array(count, on_device, pool); }   // box.h:342-350
     static Array from_vector(std::vector<T> values) { return Array(std::move(values)); }
-    // an Array<T> of this mirror stays in host memory (device payloads are DynamicArray): the slices it hands out say so, and the encoders stage them
-    void to_device_inplace(std::shared_ptr<MemoryPool> pool = nullptr) { (void)pool; }
-    void to_host_inplace() {}
-    Array clone(std::shared_ptr<MemoryPool> pool = nullptr) const { (void)pool; return *this; }
-    ConstSlice<T> const_reference() const { return ConstSlice<T>(data_.data(), data_.size(), false); }
-    Slice<T> reference() { return Slice<T>(data_.data(), data_.size(), false); }
-    ConstSlice<T> const_slice(size_t begin, size_t end) const { return ConstSlice<T>(data_.data() + begin, end - begin, false); }
-    Slice<T> slice(size_t begin, size_t end) { return Slice<T>(data_.data() + begin, end - begin, false); }
-    std::vector<T> to_vector() const { return data_; }
-    T* raw_pointer() { return data_.data(); }
-    const T* raw_pointer() const { return data_.data(); }
+    static Array create_and_copy_from_slice(ConstSlice<T> source, bool on_device = false, std::shared_ptr<MemoryPool> pool = nullptr) {
+        Array a = create_uninitialized(source.size(), on_device, pool); a.copy_from_slice(source); return a;
+    }
+    operator std::vector<T>() const { return to_vector(); }                                      // NOLINT
+    typename std::vector<T>::const_iterator begin() const noexcept { return host_.begin(); }
+    typename std::vector<T>::const_iterator end() const noexcept { return host_.end(); }
+    size_t size() const noexcept { return count_; }
+    bool on_device() const noexcept { return device_; }
+    T& operator[](size_t i) { return host_[i]; }
+    const T& operator[](size_t i) const { return host_[i]; }
+    T* raw_pointer() { return device_ ? static_cast<T*>(dev_.get()) : host_.data(); }
+    const T* raw_pointer() const { return device_ ? static_cast<const T*>(dev_.get()) : host_.data(); }
+    ConstSlice<T> const_reference() const { return ConstSlice<T>(raw_pointer(), count_, device_); }
+    Slice<T> reference() { return Slice<T>(raw_pointer(), count_, device_); }
+    ConstSlice<T> const_slice(size_t begin, size_t end) const { return ConstSlice<T>(raw_pointer() + begin, end - begin, device_); }
+    Slice<T> slice(size_t begin, size_t end) { return Slice<T>(raw_pointer() + begin, end - begin, device_); }
+    std::vector<T> to_vector() const { return const_reference().to_vector(); }
+    void copy_from_slice(ConstSlice<T> source) {
+        if (source.size() != count_) throw std::invalid_argument("[Array::copy_from_slice] Slice size does not match the array size.");
+        if (!count_) return;
+        if (device_ && source.on_device()) device_bytes_copy(raw_pointer(), source.raw_pointer(), count_ * sizeof(T));
+        else if (device_) host_bytes_to_slice(raw_pointer(), true, source.raw_pointer(), count_ * sizeof(T));
+        else slice_bytes_to_host(source.raw_pointer(), source.on_device(), host_.data(), count_ * sizeof(T));
+    }
+    Array clone(std::shared_ptr<MemoryPool> pool = nullptr) const { Array a = create_uninitialized(count_, device_, pool ? pool : pool_); a.copy_from_slice(const_reference()); return a; }
+    Array to_host() const { Array a = create_uninitialized(count_, false); a.copy_from_slice(const_reference()); return a; }
+    Array to_device(std::shared_ptr<MemoryPool> pool = nullptr) const { Array a = create_uninitialized(count_, true, pool); a.copy_from_slice(const_reference()); return a; }
+    void to_host_inplace() { if (device_) *this = to_host(); }
+    void to_device_inplace(std::shared_ptr<MemoryPool> pool = nullptr) { if (!device_) *this = to_device(pool); }
+    void set_zero() { if (device_) { Array z(count_, true, pool_); *this = std::move(z); } else std::fill(host_.begin(), host_.end(), T()); }
 private:
-    std::vector<T> data_;
+    void allocate(std::shared_ptr<MemoryPool> pool, bool zero) {
+        if (!device_) { host_.assign(count_, T()); return; }
+        pool_ = std::move(pool);
+        dev_ = device_bytes_allocate(count_ * sizeof(T), pool_, zero);
+    }
+    std::vector<T> host_;
+    std::shared_ptr<void> dev_;
+    std::shared_ptr<MemoryPool> pool_;
+    size_t count_ = 0;
+    bool device_ = false;
 };
 template <typename T> std::vector<T> slice_to_vector(ConstSlice<T> s) {
     std::vector<T> v(s.size());
