@@ -155,7 +155,8 @@ static bool run_forms(const std::vector<size_t>& q_bits, const std::vector<size_
             std::vector<T> got(n);
             const std::vector<uint64_t> rb = back.to_vector();
             std::memcpy(got.data(), rb.data(), n * sizeof(T));
-            bad += got != full || encoder.scale_down_slice_new(fu).to_vector() != full;
+            const utils::Array<T> down = encoder.scale_down_slice_new(fu);
+            bad += got != full || !down.on_device() || down.to_vector() != full || encoder.decentralize_slice_new(fc).to_vector() != full;
         }
         {   // utils::Array<T> on the device (box.h:300-560): clone / to_host / copy_from_slice in every host-device combination, zero-initialised construction
             const std::vector<T> v = sample(7);

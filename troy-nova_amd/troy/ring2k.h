@@ -62,7 +62,7 @@ public:
         destination.resize(input.coeff_count());
         scale_down_slice(input, utils::Slice<T>(destination.data(), destination.size(), false), pool);
     }
-    utils::Array<T> scale_down_slice_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a(input.coeff_count(), false); scale_down_slice(input, a.reference(), pool); return a; }
+    utils::Array<T> scale_down_slice_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a = utils::Array<T>::create_uninitialized(input.coeff_count(), on_device(), pool); scale_down_slice(input, a.reference(), pool); return a; }
     std::vector<T> scale_down_new(const Plaintext& input, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<T> v; scale_down(input, v, pool); return v; }
 
     void decentralize_slice(const Plaintext& input, utils::Slice<T> destination, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { decode(input, false, correction_factor, destination, pool); }
@@ -70,7 +70,7 @@ public:
         destination.resize(input.coeff_count());
         decentralize_slice(input, utils::Slice<T>(destination.data(), destination.size(), false), correction_factor, pool);
     }
-    utils::Array<T> decentralize_slice_new(const Plaintext& input, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a(input.coeff_count(), false); decentralize_slice(input, a.reference(), correction_factor, pool); return a; }
+    utils::Array<T> decentralize_slice_new(const Plaintext& input, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { utils::Array<T> a = utils::Array<T>::create_uninitialized(input.coeff_count(), on_device(), pool); decentralize_slice(input, a.reference(), correction_factor, pool); return a; }
     std::vector<T> decentralize_new(const Plaintext& input, T correction_factor = 1, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { std::vector<T> v; decentralize(input, v, correction_factor, pool); return v; }
 
 private:

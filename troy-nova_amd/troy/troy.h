@@ -175,6 +175,8 @@ template <typename T> void vector_to_slice(const std::vector<T>& v, Slice<T> d, 
     if (d.size() < v.size()) throw std::invalid_argument(std::string(prompt) + " destination is too small.");
     if (!v.empty()) host_bytes_to_slice(d.raw_pointer(), d.on_device(), v.data(), v.size() * sizeof(T));
 }
+// the *_slice_new decoders return their array where the plaintext lives, as the reference's do (batch_encoder.h:103-135, ckks_encoder.h)
+template <typename T> Array<T> located(Array<T> a, bool on_device, std::shared_ptr<MemoryPool> pool) { if (on_device) a.to_device_inplace(std::move(pool)); return a; }
 template <typename T> using ConstSliceVec = std::vector<ConstSlice<T>>;
 template <typename T> using SliceVec = std::vector<Slice<T>>;
 }  // namespace utils
@@ -1054,7 +1056,7 @@ public:
         if (destination.size() != slots_) throw std::invalid_argument("[BatchEncoder::decode_slice] Destination has incorrect size.");
         utils::vector_to_slice(decode_new(plaintext, pool), destination, "[BatchEncoder::decode_slice]");
     }
-    utils::Array<uint64_t> decode_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::Array<uint64_t>(decode_new(plaintext, pool)); }
+    utils::Array<uint64_t> decode_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::located(utils::Array<uint64_t>(decode_new(plaintext, pool)), plaintext.on_device(), pool); }
     void decode_slice_batched(const std::vector<const Plaintext*>& plaintexts, const std::vector<utils::Slice<uint64_t>>& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
         if (plaintexts.size() != destination.size()) throw std::invalid_argument("[BatchEncoder::decode_slice_batched] plaintexts and destination size mismatch.");
         for (size_t i = 0; i < plaintexts.size(); i++) decode_slice(*plaintexts[i], destination[i], pool);
@@ -1069,7 +1071,7 @@ public:
         if (destination.size() != v.size()) throw std::invalid_argument("[BatchEncoder::decode_polynomial_slice] Destination has incorrect size.");
         utils::vector_to_slice(v, destination, "[BatchEncoder::decode_polynomial_slice]");
     }
-    utils::Array<uint64_t> decode_polynomial_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::Array<uint64_t>(decode_polynomial_new(plaintext, pool)); }
+    utils::Array<uint64_t> decode_polynomial_slice_new(const Plaintext& plaintext, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { return utils::located(utils::Array<uint64_t>(decode_polynomial_new(plaintext, pool)), plaintext.on_device(), pool); }
     constexpr size_t row_count() const noexcept { return 2; }
     size_t column_count() const noexcept { return slots_ / 2; }
     bool simd_encoding_supported() const { return !matrix_reps_index_map_.empty(); }
@@ -1168,14 +1170,14 @@ public:
         utils::vector_to_slice(decode_complex64_simd_new(plain, pool), destination, "[ckks_encoder::decode_complex64_simd_slice]");
     }
     utils::Array<std::complex<double>> decode_complex64_simd_slice_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        return utils::Array<std::complex<double>>(decode_complex64_simd_new(plain, pool));
+        return utils::located(utils::Array<std::complex<double>>(decode_complex64_simd_new(plain, pool)), plain.on_device(), pool);
     }
     void decode_float64_polynomial_slice(const Plaintext& plain, utils::Slice<double> destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
         if (destination.size() != slots_ * 2) throw std::invalid_argument("[ckks_encoder::decode_float64_polynomial_slice] destination size must be equal to slot_count * 2.");
         utils::vector_to_slice(decode_float64_polynomial_new(plain, pool), destination, "[ckks_encoder::decode_float64_polynomial_slice]");
     }
     utils::Array<double> decode_float64_polynomial_slice_new(const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const {
-        return utils::Array<double>(decode_float64_polynomial_new(plain, pool));
+        return utils::located(utils::Array<double>(decode_float64_polynomial_new(plain, pool)), plain.on_device(), pool);
     }
 private:
     void set_plaintext(const std::vector<double>& coeffs, const ParmsID& parms_id, double scale, Plaintext& destination, MemoryPoolHandle pool) const;
