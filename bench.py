@@ -673,6 +673,10 @@ def extra_configs(torch, pkg, device):
             plan.ntt(prod, 3, L, inverse=True)
         reps = 10 if n < 32768 else 5
         t = timed(torch, pipe, reps)
+        # BASELINE's second figure: the transform alone against HBM -- algorithmic bytes 16 N per limb-polynomial, out of place, forward and inverse
+        t_f = timed(torch, lambda: plan.ntt(x, 2, L, out=xn), reps)
+        t_i = timed(torch, lambda: plan.ntt(xn, 2, L, out=yn, inverse=True), reps)
+        ntt_bytes = 16.0 * n * L * 2 * Bn
         # 4 NTT (16 B/coeff) + dyadic (56) + 3 INTT (16) per limb coefficient; two-pass transforms move every coefficient twice
         alg = ((7 * 32.0 + 56.0) if two_pass else 168.0) * n * L * Bn
         with KernelTimer(pkg, plan.lib, TIMER_KS) as kt:
@@ -682,6 +686,8 @@ def extra_configs(torch, pkg, device):
         # (+ the c0, c1 read and the c2 INTT input of relinearize are left out: minimum traffic)
         ks_keys, ks_rest = 16.0 * L * K * n, 24.0 * L * n
         r = {"what": what, "batch": Bn, "ntt_dyadic_intt_ciphertexts_per_s": round(Bn / t, 1), "ntt_dyadic_intt_hbm_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+             "ntt_GBps": round(ntt_bytes / t_f / 1e9, 1), "ntt_hbm_frac": round(ntt_bytes / t_f / 1e9 / HBM_PEAK_GBS, 4),
+             "intt_GBps": round(ntt_bytes / t_i / 1e9, 1), "intt_hbm_frac": round(ntt_bytes / t_i / 1e9 / HBM_PEAK_GBS, 4),
              "relinearize_ops_per_s": round(Bn / tr, 1),
              "relinearize_hbm_frac_keys_per_op": round((ks_keys + ks_rest) * Bn / tr / 1e9 / HBM_PEAK_GBS, 4),
              "relinearize_hbm_frac_keys_once_per_batch": round((ks_keys + ks_rest * Bn) / tr / 1e9 / HBM_PEAK_GBS, 4)}
