@@ -4,6 +4,7 @@
 // CKKS with full and partial (coeff_count = N / 3) plaintexts: every result is decrypted and compared with the plain computation.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 
 #include "../../troy-nova_amd/troy/troy.h"
@@ -32,8 +33,8 @@ static std::vector<uint64_t> mul_poly(const std::vector<uint64_t>& a, const std:
     return r;
 }
 
-static void run_bfv_like(SchemeType scheme) {
-    const size_t n = 2048, cc = n / 3;
+static void run_bfv_like(SchemeType scheme, size_t n) {
+    const size_t cc = n / 3;
     const bool bgv = scheme == SchemeType::BGV;
     EncryptionParameters parms(scheme);
     parms.set_poly_modulus_degree(n);
@@ -175,8 +176,8 @@ static void run_bfv_like(SchemeType scheme) {
     }
 }
 
-static void run_ckks() {
-    const size_t n = 2048, cc = n / 3;
+static void run_ckks(size_t n) {
+    const size_t cc = n / 3;
     std::printf("-- CKKS\n");
     EncryptionParameters parms(SchemeType::CKKS);
     parms.set_poly_modulus_degree(n);
@@ -262,11 +263,13 @@ static void run_ckks() {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     try {
-        run_bfv_like(SchemeType::BFV);
-        run_bfv_like(SchemeType::BGV);
-        run_ckks();
+        const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 2048;      // 32: the reference's own test size (the small-ring kernels)
+        std::printf("N %zu\n", n);
+        run_bfv_like(SchemeType::BFV, n);
+        run_bfv_like(SchemeType::BGV, n);
+        run_ckks(n);
         std::printf(failures ? "FAIL\n" : "OK\n");
         MemoryPool::Destroy();
         return failures ? 1 : 0;

@@ -456,14 +456,15 @@ def test_decrypt_and_compare_matrix(dev, scheme, log_t, bits):
     assert "multiply" in names and "relinearize" in names and "keyswitching" in names
 
 
-def test_operand_forms_cpp_api(dev):
+@pytest.mark.parametrize("n", [32, 2048])
+def test_operand_forms_cpp_api(dev, n):
     """the reference's evaluator scenarios whose operands are in the non-default representation (test/evaluator.cu: test_add_subtract_ntt / _intt,
     test_add_plain_scaled(_ntt), test_multiply_plain_ntt, test_multiply_plain_centralized, test_transform_plain_ntt, test_mod_switch_plain_to_next)
     through the mirror, BFV / BGV / CKKS, full and partial (coeff_count = N / 3) plaintexts; every result is decrypted"""
     drv = os.path.join(ROOT, "tests", "cpp", "forms_driver")
     if not os.path.exists(drv):
         pytest.fail("tests/cpp/forms_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
-    r = subprocess.run([drv], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([drv, str(n)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.endswith(" ok")]
     assert len(lines) >= 50 and "FAIL" not in r.stdout, r.stdout

@@ -74,7 +74,7 @@ def test_ring2k_product_decrypts(O, pkg, dev):
 
 @pytest.mark.parametrize("n,bits,L,elem_bits,k", [(64, [60, 60, 60, 60], 2, 64, 64), (64, [60, 60, 60, 60], 3, 64, 40), (1024, [50, 50, 50], 2, 32, 32),
                                                   (1024, [50, 50, 50], 1, 32, 17), (8192, [60, 60, 60, 60], 3, 128, 128), (4096, [60, 60, 60, 60], 3, 128, 65),
-                                                  (16384, [60, 60, 60, 60], 4, 64, 64), (32768, [60, 40, 40, 60], 3, 64, 33)])
+                                                  (16384, [60, 60, 60, 60], 4, 64, 64), (32768, [60, 40, 40, 60], 3, 64, 33), (65536, [60, 60, 60], 2, 128, 90)])
 def test_ring2k_decentralize_matches_oracle(O, pkg, dev, n, bits, L, elem_bits, k):
     """decentralize (bfv_ring2k.cu:752-911): the double-precision quotient estimate is summed in the reference's order, so the HIP kernel equals the oracle
     bit for bit on arbitrary residues (where the estimate sits anywhere in [0, L)) as well as on centred lifts; the reference's round trip holds"""
