@@ -148,6 +148,8 @@ def lib():
     sig("orc_multiply_plain_ntt", None, vp, sz, p64, sz, p64, p64)
     sig("orc_keygen_relin_keys", None, vp, vp, p64, p64)
     sig("orc_rns_decrypt_scale_and_round", C.c_int, vp, p64, p64)
+    sig("orc_rns_tool_decrypt_mod_t", C.c_int, vp, p64, p64)
+    sig("orc_rns_tool_mod_t_and_divide_q_last_inplace", None, vp, p64)
     sig("orc_decrypt_bfv", C.c_int, vp, p64, p64, sz, sz, p64)
     sig("orc_batch_decode", C.c_int, vp, p64, p64)
     _lib = L
@@ -331,6 +333,26 @@ class RNSTool:
         out = np.zeros(out_len, dtype=np.uint64)
         getattr(lib(), name)(self.h, ptr(inp), ptr(out))
         return out
+
+    def decrypt_scale_and_round(self, phase):
+        """RNSTool::decrypt_scale_and_round on a bare tool: phase [q_size][N] -> [N] mod t"""
+        out = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_rns_decrypt_scale_and_round(self.h, ptr(arr(phase)), ptr(out)) != 0:
+            raise ValueError("decrypt_scale_and_round failed")
+        return out
+
+    def decrypt_mod_t(self, phase):
+        """RNSTool::decrypt_mod_t (BGV): phase [q_size][N] -> [N] mod t"""
+        out = np.zeros(self.n, dtype=np.uint64)
+        if lib().orc_rns_tool_decrypt_mod_t(self.h, ptr(arr(phase)), ptr(out)) != 0:
+            raise ValueError("decrypt_mod_t needs a plain modulus")
+        return out
+
+    def mod_t_and_divide_q_last_inplace(self, data):
+        """RNSTool::mod_t_and_divide_q_last_inplace (BGV mod switch, coefficient form): [q_size][N] -> the same array, rows 0 .. q_size-2 replaced"""
+        buf = arr(data).copy()
+        lib().orc_rns_tool_mod_t_and_divide_q_last_inplace(self.h, ptr(buf))
+        return buf
 
     def fast_b_conv_m_tilde(self, inp):
         return self._call("orc_rns_fast_b_conv_m_tilde", inp, (self.base_Bsk_size + 1) * self.n)

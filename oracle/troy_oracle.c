@@ -1702,11 +1702,37 @@ void orc_rns_mod_t_and_divide_q_last_ntt(const orc_context* c, size_t nl, const 
 
 uint64_t orc_bgv_inv_q_last_mod_t(const orc_context* c, size_t nl) { return c->rns_tools[nl]->inv_q_last_mod_t; }
 
+void orc_rns_tool_mod_t_and_divide_q_last_inplace(const orc_rns_tool* r, uint64_t* input) {
+    /* RNSTool::mod_t_and_divide_q_last_inplace, host branch (utils/rns_tool.cu:1432-1466, :1515-1538): input [q_size][N] coefficient form;
+     * rows 0 .. q_size-2 are replaced by (c_i - c_last - [-c_last q_last^-1]_t q_last) q_last^-1 mod q_i, the last row is left as it was */
+    const size_t n = r->coeff_count, nl = r->q_size;
+    const orc_modulus* pm = &r->t;
+    const uint64_t* c_last = input + (nl - 1) * n;
+    const uint64_t last_q = r->base_q.base[nl - 1].value;
+    uint64_t* neg = (uint64_t*)malloc(n * sizeof(uint64_t));
+    for (size_t x = 0; x < n; x++) {
+        uint64_t v = orc_negate_mod(orc_barrett_reduce64(c_last[x], pm), pm);
+        neg[x] = (r->inv_q_last_mod_t != 1) ? orc_multiply_mod(v, r->inv_q_last_mod_t, pm) : v;
+    }
+    for (size_t i = 0; i + 1 < nl; i++) {
+        const orc_modulus* qi = &r->base_q.base[i];
+        for (size_t x = 0; x < n; x++) {
+            const uint64_t delta = orc_multiply_mod(orc_barrett_reduce64(neg[x], qi), last_q, qi);
+            const uint64_t lazy = input[i * n + x] + (qi->value << 1) - orc_barrett_reduce64(c_last[x], qi) - delta;      /* in [0, 3 q_i) */
+            input[i * n + x] = orc_mulop_mod(lazy, &r->inv_q_last_mod_q[i], qi);
+        }
+    }
+    free(neg);
+}
+
 int orc_rns_decrypt_mod_t(const orc_context* c, size_t nl, const uint64_t* phase, uint64_t* dest) {
-    /* BaseConverter::exact_convey_array q -> {t} (utils/rns_base.cu:445-465, :510-529): phase [nl][N] coefficient form */
-    const orc_rns_tool* r = c->rns_tools[nl];
+    return orc_rns_tool_decrypt_mod_t(c->rns_tools[nl], phase, dest);
+}
+
+int orc_rns_tool_decrypt_mod_t(const orc_rns_tool* r, const uint64_t* phase, uint64_t* dest) {
+    /* BaseConverter::exact_convey_array q -> {t} (utils/rns_base.cu:445-465, :510-529): phase [q_size][N] coefficient form */
     if (!r->has_t) return -1;
-    const size_t n = c->n, ni = nl;
+    const size_t n = r->coeff_count, ni = r->q_size;
     const rns_base* ib = &r->q_to_t.ibase;
     const orc_modulus* pm = &r->q_to_t.obase.base[0];
     uint64_t qv[64];

@@ -229,6 +229,10 @@ void orc_rns_mod_t_and_divide_q_last_ntt(const orc_context* c, size_t nl, const 
 uint64_t orc_bgv_inv_q_last_mod_t(const orc_context* c, size_t nl);
 /* RNSTool::decrypt_mod_t = BaseConverter::exact_convey_array (utils/rns_base.cu:445-529): phase [nl][N] -> [N] mod t */
 int orc_rns_decrypt_mod_t(const orc_context* c, size_t nl, const uint64_t* phase, uint64_t* dest);
+/* the same two on a bare RNSTool (any coprime base, no NTT tables needed: the shape of the reference's own known-answer tests, test/utils/rns_tool.cu:470-640):
+ * RNSTool::decrypt_mod_t, phase [q_size][N] -> [N] mod t; RNSTool::mod_t_and_divide_q_last_inplace (utils/rns_tool.cu:1432-1466,:1515-1538), [q_size][N] in place */
+int orc_rns_tool_decrypt_mod_t(const orc_rns_tool* r, const uint64_t* phase, uint64_t* dest);
+void orc_rns_tool_mod_t_and_divide_q_last_inplace(const orc_rns_tool* r, uint64_t* input);
 /* Decryptor::bgv_decrypt (decryptor.cu:509-539) */
 int orc_decrypt_bgv(const orc_context* c, const uint64_t* sk, const uint64_t* ct, size_t pcount, size_t L, uint64_t correction_factor, uint64_t* plain);
 /* Encryptor::encrypt_asymmetric for BGV, plaintext mod t (encryptor.cu:300-333): out [2][K-1][N] NTT form */

@@ -156,6 +156,20 @@ static void run_constants() {
     check(ok, "CKKS level constants: 2^63, (Q + 1) / 2, -2^64 mod q_i");
 }
 
+// GaloisTool known answers of the reference (test/utils/galois.cu:20-44, N = 8): elements from steps, the generating set, key indices
+static void run_galois() {
+    const int steps[] = {0, 1, -3, 2, -2, 3, -1};
+    const size_t want[] = {15, 3, 3, 9, 9, 11, 11};
+    bool ok = true;
+    for (size_t i = 0; i < 7; i++) ok = ok && utils::galois_element_from_step(8, steps[i]) == want[i];
+    check(ok, "galois_element_from_step at N = 8: 15, 3, 3, 9, 9, 11, 11");
+    check(utils::galois_elements_all(8) == std::vector<size_t>({15, 3, 11, 9, 9}), "galois_elements_all at N = 8: {15, 3, 11, 9, 9}");
+    check(GaloisKeys::get_index(15) == 7 && GaloisKeys::get_index(3) == 1 && GaloisKeys::get_index(11) == 5 && GaloisKeys::get_index(9) == 4, "GaloisKeys::get_index: 15 -> 7, 3 -> 1, 11 -> 5, 9 -> 4");
+    bool threw = false;
+    try { GaloisKeys::get_index(4); } catch (const std::invalid_argument&) { threw = true; }
+    check(threw, "an even Galois element has no key index");
+}
+
 // troy::bench timers (src/utils/timer.h, timer.cpp): the merged view over host threads, the default divisor, reset, the byte formatter
 static void run_timers() {
     std::vector<bench::Timer> per_thread(3);
@@ -194,6 +208,7 @@ int main(int argc, char** argv) {
         run_chain(SchemeType::CKKS);
         run_constants();
         run_timers();
+        run_galois();
         if (device) {                                  // he_context.cu:323-360
             for (SchemeType scheme : {SchemeType::BFV, SchemeType::BGV, SchemeType::CKKS}) {
                 EncryptionParameters parms(scheme);

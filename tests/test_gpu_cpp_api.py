@@ -504,4 +504,4 @@ def test_context_cpp_api(dev):
         pytest.fail("tests/cpp/context_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv, "device"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
-    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 35 and "FAIL" not in r.stdout, r.stdout
+    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 39 and "FAIL" not in r.stdout, r.stdout

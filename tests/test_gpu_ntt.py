@@ -149,3 +149,16 @@ def test_ntt_linearity_full_size(O, pkg, dev):
     assert torch.equal(plan.add(fa, fb, 10), fs)
     back = plan.ntt(fa.clone(), 2, 10, inverse=True)
     assert torch.equal(back, da)
+
+
+def test_reference_kat_galois(pkg, dev):
+    """GaloisTool known answers of the reference (test/utils/galois.cu:50-76, committed as data in tests/golden/ref_kats.json): X -> X^3 on 0..7 modulo 17,
+    coefficient form and NTT form, through troyn_apply_galois"""
+    import json
+    import os
+    a = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kats.json")))["galois"]["apply"]
+    plan = pkg.Plan(dev, 3, [a["modulus"]])
+    x = pkg.to_device(np.array(a["input"], dtype=np.uint64).reshape(1, 1, 8), dev)
+    assert pkg.to_host(plan.apply_galois_poly(x, 1, a["element"], False)).reshape(-1).tolist() == a["coefficient_form"]
+    assert pkg.to_host(plan.apply_galois_poly(x, 1, a["element"], True)).reshape(-1).tolist() == a["ntt_form"]
+    assert pkg.to_host(plan.apply_galois_plain(x.view(1, 8), a["modulus"], a["element"])).reshape(-1).tolist() == a["coefficient_form"]

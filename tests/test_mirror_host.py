@@ -14,4 +14,4 @@ def test_context_validation_and_chain_host():
         pytest.fail("tests/cpp/context_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([drv, "host"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
-    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 32 and "FAIL" not in r.stdout, r.stdout
+    assert sum(ln.endswith(" ok") for ln in r.stdout.splitlines()) >= 36 and "FAIL" not in r.stdout, r.stdout

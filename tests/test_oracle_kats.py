@@ -181,3 +181,30 @@ def test_oracle_self_consistency(O):
             r = (int(x[0, 2, i]) + ql // 2) % ql
             exp = ((int(x[0, l, i]) - (r - ql // 2)) * pow(ql, -1, q[l])) % q[l]
             assert int(out_c[0, l, i]) == exp
+
+
+def test_rns_tool_bgv_and_decrypt_kats(O):
+    """the reference's known answers for the decryption / BGV half of RNSTool (test/utils/rns_tool.cu:436-634), on bare tools over the tiny coprime bases the
+    reference uses: BFV decrypt_scale_and_round, BGV mod_t_and_divide_q_last_inplace (coefficient form) and decrypt_mod_t"""
+    k = KATS["rns_tool"]
+    for c in k["decrypt_scale_and_round"]:
+        assert [int(v) for v in O.RNSTool(2, c["q"], c["t"]).decrypt_scale_and_round(c["input"])] == c["output"]
+    for c in k["mod_t_and_divide_q_last_inplace"]:
+        got = O.RNSTool(2, c["q"], c["t"]).mod_t_and_divide_q_last_inplace(c["input"])
+        assert [int(v) for v in got[:len(c["output"])]] == c["output"]
+        assert [int(v) for v in got[len(c["output"]):]] == c["input"][len(c["output"]):]      # the last row is left as it was
+    for c in k["decrypt_mod_t"]:
+        assert [int(v) for v in O.RNSTool(2, c["q"], c["t"]).decrypt_mod_t(c["input"])] == c["output"]
+
+
+def test_galois_kats(O):
+    """GaloisTool known answers (test/utils/galois.cu:20-76): elements from steps, and the automorphism of 0..7 by element 3 in both forms"""
+    g = KATS["galois"]
+    n = 1 << g["log_n"]
+    a = g["apply"]
+    ctx = O.Context("bfv", n, [a["modulus"]], 3)
+    for step, want in g["element_from_step"]:
+        assert ctx.galois_element_from_step(step) == want
+    x = np.array(a["input"], dtype=np.uint64).reshape(1, 1, n)
+    assert ctx.apply_galois(1, False, a["element"], x).reshape(-1).tolist() == a["coefficient_form"]
+    assert ctx.apply_galois(1, True, a["element"], x).reshape(-1).tolist() == a["ntt_form"]
