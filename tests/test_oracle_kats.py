@@ -208,3 +208,10 @@ def test_galois_kats(O):
     x = np.array(a["input"], dtype=np.uint64).reshape(1, 1, n)
     assert ctx.apply_galois(1, False, a["element"], x).reshape(-1).tolist() == a["coefficient_form"]
     assert ctx.apply_galois(1, True, a["element"], x).reshape(-1).tolist() == a["ntt_form"]
+
+
+def test_uint_small_mod_negate(O):
+    for blk in KATS["uint_small_mod"]["negate"]:
+        m = O.modulus(blk["modulus"])
+        for a, exp in blk["cases"]:
+            assert O.lib().orc_negate_mod(a, C.byref(m)) == exp, (blk["modulus"], a)
