@@ -117,6 +117,11 @@ int main() {
             const Modulus q0 = context->first_context_data().value()->parms().coeff_modulus()[0];
             const unsigned __int128 ratio = (static_cast<unsigned __int128>(q0.const_ratio()[1]) << 64) | q0.const_ratio()[0];
             surf = surf && threw && q0.const_ratio().size() == 3 && ratio == (~static_cast<unsigned __int128>(0)) / q0.value();     // floor(2^128 / q) for an odd q
+            // EncryptionParameters::plain_modulus(): the reference's pointer style (->, *) and the value style both compile and agree
+            const EncryptionParameters& kp = context->key_context_data().value()->parms();
+            const Modulus& by_ref = kp.plain_modulus();
+            surf = surf && kp.plain_modulus()->value() == kp.plain_modulus().value() && (*kp.plain_modulus()).bit_count() == by_ref.bit_count() && !kp.plain_modulus().is_null() &&
+                   by_ref.value() == kp.plain_modulus_host().value();
             std::stringstream text;
             text << q0;
             surf = surf && text.str() == "Modulus(" + std::to_string(q0.value()) + ")";

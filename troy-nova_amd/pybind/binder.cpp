@@ -101,7 +101,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("set_plain_modulus", py::overload_cast<const Modulus&>(&EncryptionParameters::set_plain_modulus))
         .def("set_plain_modulus", py::overload_cast<uint64_t>(&EncryptionParameters::set_plain_modulus))
         .def("scheme", &EncryptionParameters::scheme).def("poly_modulus_degree", &EncryptionParameters::poly_modulus_degree)
-        .def("coeff_modulus", [](const EncryptionParameters& s) { return s.coeff_modulus().to_vector(); }).def("plain_modulus", &EncryptionParameters::plain_modulus)
+        .def("coeff_modulus", [](const EncryptionParameters& s) { return s.coeff_modulus().to_vector(); }).def("plain_modulus", [](const EncryptionParameters& s) { return Modulus(s.plain_modulus().value()); })
         .def("parms_id", &EncryptionParameters::parms_id)
         .def("pool", [](const EncryptionParameters&) { return MemoryPool::GlobalPool(); }).def("device_index", [](const EncryptionParameters&) { return size_t(0); })
         .def("save", [](const EncryptionParameters& s, CompressionMode mode) { if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::compress] Zstd is not available in this build."); return to_bytes([&](std::ostream& os) { s.save(os); }); }, MODE)

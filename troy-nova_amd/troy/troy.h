@@ -362,6 +362,31 @@ private:
     bool is_prime_ = false;
 };
 
+// What EncryptionParameters::plain_modulus() hands out.  The reference returns utils::ConstPointer<Modulus> (encryption_parameters.h:114: callers write
+// parms.plain_modulus()->value() or *parms.plain_modulus()); earlier rounds of this mirror returned const Modulus& (callers wrote .value()).  This view does both:
+// -> and * as the reference's pointer, the Modulus queries forwarded, and an implicit conversion to const Modulus&.
+class ModulusPointer {
+public:
+    explicit ModulusPointer(const Modulus* m) : m_(m) {}
+    const Modulus* operator->() const { return m_; }
+    const Modulus& operator*() const { return *m_; }
+    operator const Modulus&() const { return *m_; }                                               // NOLINT
+    bool is_null() const noexcept { return m_ == nullptr; }
+    const Modulus* get() const noexcept { return m_; }
+    bool on_device() const noexcept { return false; }
+    uint64_t value() const { return m_->value(); }
+    size_t bit_count() const { return m_->bit_count(); }
+    bool is_prime() const { return m_->is_prime(); }
+    bool is_zero() const { return m_->is_zero(); }
+    utils::ConstSlice<uint64_t> const_ratio() const { return m_->const_ratio(); }
+    uint64_t reduce(uint64_t input) const { return m_->reduce(input); }
+    uint64_t reduce_mul_uint64(uint64_t a, uint64_t b) const { return m_->reduce_mul_uint64(a, b); }
+    uint64_t reduce_uint128(unsigned __int128 v) const { return m_->reduce_uint128(v); }
+private:
+    const Modulus* m_;
+};
+inline std::ostream& operator<<(std::ostream& os, const ModulusPointer& modulus) { return os << "Modulus(" << modulus.value() << ")"; }
+
 inline std::ostream& operator<<(std::ostream& os, const Modulus& modulus) { return os << "Modulus(" << modulus.value() << ")"; }   // modulus.h:126-129
 
 class CoeffModulus {
@@ -429,7 +454,7 @@ public:
     SchemeType scheme() const { return scheme_; }
     size_t poly_modulus_degree() const { return poly_modulus_degree_; }
     utils::ConstSlice<Modulus> coeff_modulus() const { return utils::ConstSlice<Modulus>(coeff_modulus_); }
-    const Modulus& plain_modulus() const { return plain_modulus_; }
+    ModulusPointer plain_modulus() const noexcept { return ModulusPointer(&plain_modulus_); }      // encryption_parameters.h:114-116
     const Modulus& plain_modulus_host() const noexcept { return plain_modulus_; }                 // encryption_parameters.h:118-124 (the host copies; this mirror keeps
     utils::ConstSlice<Modulus> coeff_modulus_host() const noexcept { return utils::ConstSlice<Modulus>(coeff_modulus_); }    //  parameters on the host, device constants live in the troyn_plan)
     bool use_special_prime_for_encryption() const { return use_special_prime_for_encryption_; }
