@@ -1,0 +1,47 @@
+"""The reference's OWN test suite (its test/*.cu and test/app/*.cu, 362 googletest cases) run against this repository's mirror on the GPU: the strongest form of
+the drop-in check of SURVEY 8b.  tests/build_ref_tests.sh compiles those sources WHERE THEY LIE in the build container against the mirror's headers (nothing of
+the reference enters the repository; the binary tests/_ref_tests/ref_tests is git-ignored and travels to the GPU box like the built libraries) with a 50-line
+stand-in for the googletest macros (tests/ref_tests_support/gtest/gtest.h).  Run here: every case whose name contains "Device" (the mirror has no host path).
+
+Not expected to pass, each for a stated reason that the test itself shows:
+  * seven cases that are HOST-path tests despite their names -- they build `GeneralHeContext(false, ...)` (device = false: evaluator.cu:561-571,
+    special_prime_for_encryption.cu:48-66) or are called Host*MultiDevices; the mirror refuses a context that is not on the device, loudly, which is what the
+    product must do (no CPU fallback);
+  * SerializeTest.DeviceCKKSCiphertext (serialize.cu:169: CKKS N = 32 at scale 2^16, tolerance 1e-2 on the SQUARE of values up to 10 + 10i): the expected error of
+    that square is 2 |m| x (fresh error 5e-4) ~ 1e-2, i.e. the assertion is a coin toss that the reference wins with the noise its seed 0x123 happens to draw.
+    Measured on the mirror over 200 seeds: the same flow exceeds 1e-2 for 71 seeds, mean largest error 0.0093 (fresh 0.0005) -- the arithmetic is right, the
+    tolerance is marginal; the same scenario at scale 2^20 (SerializeTest.DeviceCKKS* of the other groups, tests/cpp/serialize_driver.cpp) passes with error 5e-4.
+"""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_PATH_DESPITE_NAME = {"EvaluatorTest.DeviceBGVRelinearize", "SpecialPrimeForEncryptionTest.DeviceBFVEncrypt", "SpecialPrimeForEncryptionTest.DeviceBGVEncrypt",
+                          "SpecialPrimeForEncryptionTest.DeviceCKKSEncrypt", "MultithreadTest.HostBFVMultiDevices", "MultithreadTest.HostBGVMultiDevices",
+                          "MultithreadTest.HostCKKSMultiDevices"}
+MARGINAL_TOLERANCE = {"SerializeTest.DeviceCKKSCiphertext"}
+
+
+def test_reference_test_suite_on_the_mirror(dev):
+    exe = os.path.join(ROOT, "tests", "_ref_tests", "ref_tests")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_ref_tests/ref_tests is not built (bash tests/build_ref_tests.sh, needs the reference tree: build container only)")
+    r = subprocess.run([exe, "Device"], capture_output=True, text=True, timeout=1800)
+    lines = r.stdout.splitlines()
+    verdicts = {}
+    for i, ln in enumerate(lines):
+        if ln.startswith("[ ") and " ] " in ln:
+            verdicts[ln.split(" ] ", 1)[1]] = (ln[2:ln.index(" ]")].strip(), lines[max(0, i - 3):i])
+    assert len(verdicts) >= 180, r.stdout[-2000:] + r.stderr[-2000:]
+    failed = {k for k, (v, _) in verdicts.items() if v == "FAILED"}
+    unexpected = failed - HOST_PATH_DESPITE_NAME - MARGINAL_TOLERANCE
+    assert not unexpected, "\n".join("%s: %s" % (k, " | ".join(verdicts[k][1])) for k in sorted(unexpected))
+    # the host-path cases must fail for THAT reason (the loud refusal), not for any other
+    for k in HOST_PATH_DESPITE_NAME & failed:
+        assert any("HeContext is not on device" in c for c in verdicts[k][1]), (k, verdicts[k][1])
+    passed = sum(1 for v, _ in verdicts.values() if v == "OK")
+    assert passed >= 170, "only %d of the reference's Device cases passed" % passed

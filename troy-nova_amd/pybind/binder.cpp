@@ -147,7 +147,7 @@ PYBIND11_MODULE(pytroy_raw, m) {
         .def("pool", &Plaintext::pool).def("device_index", [](const Plaintext& s) { return s.pool() ? s.pool()->get_device() : size_t(0); })
         .def("to_device", [](const Plaintext& s, PoolArg p) { return s.to_device(P(p)); }, POOL).def("to_host", &Plaintext::to_host)
         .def("set_parms_id", [](Plaintext& s, const ParmsID& id) { s.parms_id() = id; }).def("set_coeff_count", [](Plaintext& s, size_t c) { s.coeff_count() = c; })
-        .def("set_is_ntt_form", [](Plaintext& s, bool f) { s.is_ntt_form() = f; }).def("resize", &Plaintext::resize)
+        .def("set_is_ntt_form", [](Plaintext& s, bool f) { s.is_ntt_form() = f; }).def("resize", &Plaintext::resize, py::arg("coeff_count"), py::arg("fill_extra_with_zeros") = true, py::arg("copy_data") = true)
         .def("coeff_modulus_size", [](const Plaintext& s) { return s.coeff_modulus_size(); }).def("poly_modulus_degree", [](const Plaintext& s) { return s.poly_modulus_degree(); })
         .def("serialized_size_upperbound", [](const Plaintext& s, CompressionMode mode) { return s.serialized_size_upperbound(mode); }, MODE)
         .def("save", [](const Plaintext& s, CompressionMode mode) { return to_bytes([&](std::ostream& os) { s.save(os, mode); }); }, MODE)

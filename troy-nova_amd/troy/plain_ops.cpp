@@ -53,16 +53,17 @@ Plaintext mod_t_like(const Plaintext& rns, size_t L, size_t n, MemoryPoolHandle 
 // ------------------------------------------------------------------------------------------------
 // partial RNS plaintexts
 // ------------------------------------------------------------------------------------------------
-void Plaintext::resize_rns_partial(const HeContext& context, const ParmsID& parms_id, size_t coeff_count) {
+void Plaintext::resize_rns_partial(const HeContext& context, const ParmsID& parms_id, size_t coeff_count, bool fill_extra_with_zeros, bool copy_data) {
     auto cd = context.get_context_data(parms_id);
-    if (!cd.has_value()) throw std::invalid_argument("[Plaintext::resize_rns_partial] ParmsID is not valid for the current context.");
+    if (!cd.has_value()) throw std::invalid_argument("[Plaintext::resize_rns] parms_id is not valid");
     const EncryptionParameters& p = cd.value()->parms();
-    if (coeff_count > p.poly_modulus_degree()) throw std::invalid_argument("[Plaintext::resize_rns_partial] coeff_count exceeds the polynomial degree.");
+    // (no upper bound: the reference lets a partial plaintext hold MORE than N coefficients per limb, test/app/bfv_ring2k.cu:93-110 decodes such a one)
     parms_id_ = parms_id;
     coeff_modulus_size_ = p.coeff_modulus().size();
     poly_modulus_degree_ = p.poly_modulus_degree();
     coeff_count_ = coeff_count;
-    data_.resize(coeff_modulus_size_ * coeff_count, false);
+    const size_t words = coeff_modulus_size_ * coeff_count;
+    if (fill_extra_with_zeros) data_.resize(words, copy_data); else data_.resize_uninitialized(words, copy_data);
 }
 
 utils::DynamicArray Plaintext::expanded_rns(size_t L, size_t n, MemoryPoolHandle pool) const {

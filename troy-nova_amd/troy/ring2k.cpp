@@ -15,9 +15,14 @@ PolynomialEncoderRing2k<T>::PolynomialEncoderRing2k(HeContextPointer context, si
 }
 
 template <typename T>
-PolynomialEncoderRing2k<T>::~PolynomialEncoderRing2k() {
+void PolynomialEncoderRing2k<T>::release_helpers() {
+    std::lock_guard<std::mutex> lock(mutex_);
     for (auto& kv : helpers_) troyn_ring2k_destroy(kv.second);
+    helpers_.clear();
 }
+
+template <typename T>
+PolynomialEncoderRing2k<T>::~PolynomialEncoderRing2k() { release_helpers(); }
 
 template <typename T>
 const troyn_ring2k* PolynomialEncoderRing2k<T>::helper(const ParmsID& parms_id) const {
@@ -90,31 +95,41 @@ void PolynomialEncoderRing2k<T>::decode(const Plaintext& input, bool scale, T co
     if (input.is_ntt_form()) throw std::invalid_argument(std::string(P) + " input is in NTT form");
     const troyn_ring2k* h = helper(input.parms_id());
     const size_t n = slot_count(), cc = input.coeff_count(), L = input.coeff_modulus_size();
-    if (cc > n || input.data().size() != L * cc) throw std::invalid_argument(std::string(P) + " input does not have the shape of an RNS plaintext");
+    if (input.data().size() != L * cc) throw std::invalid_argument(std::string(P) + " input does not have the shape of an RNS plaintext");
     if (destination.size() != cc) throw std::invalid_argument(std::string(P) + " destination size must be the input's coeff_count");
     if (cc == 0) return;
     hipStream_t s = static_cast<hipStream_t>(troyn_current_stream());
-    // a partial plaintext (bfv_ring2k.cu:700-712: coeff_count = destination.size()) is widened to full rows for the kernel; only its coeff_count elements come back
-    utils::DynamicArray widened(0, true, pool);
-    const uint64_t* in = input.poly();
-    if (cc < n) { widened = input.expanded_rns(L, n, pool); in = widened.raw_pointer(); }
-    const size_t words = (n * sizeof(T) + 7) / 8;
-    const bool direct = destination.on_device() && cc == n;
-    utils::DynamicArray out(direct ? 0 : words, true, pool);
-    void* dst = direct ? static_cast<void*>(destination.raw_pointer()) : static_cast<void*>(out.raw_pointer());
-    if (scale) {
-        troyn_check_public(troyn_ring2k_scale_down(h, in, dst, s));
-    } else {
-        const unsigned __int128 cf = static_cast<unsigned __int128>(correction_factor);
-        troyn_check_public(troyn_ring2k_decentralize(h, in, dst, static_cast<uint64_t>(cf), static_cast<uint64_t>(cf >> 64), s));
+    // Both decoders work coefficient by coefficient on data[l * coeff_count + i] (bfv_ring2k.cu:700-712, :872-911: coeff_count = destination.size(), which may be
+    // SHORTER than the ring degree -- a partial plaintext -- or LONGER: the reference's test decodes 54 coefficients of an N = 32 context in one call).  The kernels
+    // take full rows [L][N]: the input is walked in chunks of N coefficients, each widened (zero-padded) to full rows when it is not one already.
+    const unsigned __int128 cf = static_cast<unsigned __int128>(correction_factor);
+    const size_t chunk_words = (n * sizeof(T) + 7) / 8;
+    utils::DynamicArray rows(cc == n ? 0 : L * n, true, pool), out(destination.on_device() && cc == n ? 0 : chunk_words, true, pool);
+    std::vector<uint64_t> raw;
+    for (size_t base = 0; base < cc; base += n) {
+        const size_t len = std::min(n, cc - base);
+        const uint64_t* in = input.poly();
+        if (cc != n) {
+            if (len < n && hipMemsetAsync(rows.raw_pointer(), 0, L * n * sizeof(uint64_t), s) != hipSuccess) throw std::runtime_error("[PolynomialEncoderRing2k] memset failed");
+            if (hipMemcpy2DAsync(rows.raw_pointer(), n * sizeof(uint64_t), input.poly().raw_pointer() + base, cc * sizeof(uint64_t), len * sizeof(uint64_t), L, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                throw std::runtime_error("[PolynomialEncoderRing2k] strided copy of a plaintext chunk failed");
+            in = rows.raw_pointer();
+        }
+        const bool direct = destination.on_device() && cc == n;
+        void* dst = direct ? static_cast<void*>(destination.raw_pointer()) : static_cast<void*>(out.raw_pointer());
+        if (scale) troyn_check_public(troyn_ring2k_scale_down(h, in, dst, s));
+        else troyn_check_public(troyn_ring2k_decentralize(h, in, dst, static_cast<uint64_t>(cf), static_cast<uint64_t>(cf >> 64), s));
+        if (direct) continue;
+        if (destination.on_device()) {
+            if (hipMemcpyAsync(destination.raw_pointer() + base, dst, len * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                throw std::runtime_error("[PolynomialEncoderRing2k] device copy of the decoded elements failed");
+        } else {
+            troyn_sync_current_stream();
+            raw = out.to_vector();
+            std::memcpy(destination.raw_pointer() + base, raw.data(), len * sizeof(T));
+        }
     }
-    if (!direct && destination.on_device() && hipMemcpyAsync(destination.raw_pointer(), dst, cc * sizeof(T), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        throw std::runtime_error("[PolynomialEncoderRing2k] device copy of the decoded elements failed");
     troyn_sync_current_stream();
-    if (!destination.on_device()) {
-        const std::vector<uint64_t> raw = out.to_vector();
-        std::memcpy(destination.raw_pointer(), raw.data(), cc * sizeof(T));
-    }
 }
 
 template class PolynomialEncoderRing2k<uint32_t>;

@@ -20,6 +20,20 @@ public:
     ~PolynomialEncoderRing2k();
     PolynomialEncoderRing2k(const PolynomialEncoderRing2k&) = delete;
     PolynomialEncoderRing2k& operator=(const PolynomialEncoderRing2k&) = delete;
+    // movable, as the reference's (test_adv.h keeps the encoders in std::optional): the per-level helpers travel, the mutex is the new object's own
+    PolynomialEncoderRing2k(PolynomialEncoderRing2k&& other) noexcept : context_(std::move(other.context_)), t_bit_length_(other.t_bit_length_) {
+        std::lock_guard<std::mutex> lock(other.mutex_);
+        helpers_ = std::move(other.helpers_);
+        other.helpers_.clear();
+    }
+    PolynomialEncoderRing2k& operator=(PolynomialEncoderRing2k&& other) noexcept {
+        if (this != &other) {
+            release_helpers();
+            std::lock_guard<std::mutex> lock(other.mutex_);
+            context_ = std::move(other.context_); t_bit_length_ = other.t_bit_length_; helpers_ = std::move(other.helpers_); other.helpers_.clear();
+        }
+        return *this;
+    }
 
     HeContextPointer context() const noexcept { return context_; }
     size_t t_bit_length() const noexcept { return t_bit_length_; }
@@ -78,6 +92,7 @@ private:
     void encode(const utils::ConstSlice<T>* source, size_t count, std::optional<ParmsID> parms_id, bool scale, Plaintext* const* destination, MemoryPoolHandle pool) const;
     void decode(const Plaintext& input, bool scale, T correction_factor, utils::Slice<T> destination, MemoryPoolHandle pool) const;
     const troyn_ring2k* helper(const ParmsID& parms_id) const;   // PolynomialEncoderRNSHelper of that level
+    void release_helpers();
     HeContextPointer context_;
     size_t t_bit_length_;
     mutable std::mutex mutex_;

@@ -1735,6 +1735,43 @@ void Evaluator::multiply_plain(const Ciphertext& encrypted, const Plaintext& pla
 
 void Evaluator::multiply_plain_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
                                           const std::vector<Ciphertext*>& destination, bool set_zero, MemoryPoolHandle pool) const {
+    // evaluator_multiply_plain.cu:356-383: by the forms of the operands (the form of the first element speaks for its vector, as get_is_ntt_form_vec does)
+    if (encrypted.size() != plain.size() || encrypted.size() != destination.size()) throw std::invalid_argument("[Evaluator::multiply_plain_ntt_batched] Input vectors have different sizes.");
+    if (encrypted.empty()) return;
+    const bool encrypted_ntt = encrypted[0]->is_ntt_form(), plain_ntt = plain[0]->is_ntt_form();
+    if (encrypted_ntt && plain_ntt) { multiply_plain_ntt_accumulate(encrypted, plain, destination, set_zero, pool); return; }
+    if (!encrypted_ntt && !plain_ntt) {
+        // multiply_plain_normal_accumulate (:156-193): the products are formed by multiply_plain_batched and added one by one; equal destination pointers accumulate
+        const char* P = "[Evaluator::multiply_plain_normal_batched]";
+        for (const Ciphertext* c : encrypted) check_no_seed(P, *c);
+        if (set_zero) {
+            for (size_t i = 0; i < encrypted.size(); i++) *destination[i] = Ciphertext::like(*encrypted[i], true, pool);
+        } else {
+            for (size_t i = 0; i < encrypted.size(); i++)
+                if (destination[i]->parms_id() != encrypted[i]->parms_id() || destination[i]->is_ntt_form() != encrypted[i]->is_ntt_form())
+                    throw std::invalid_argument("[Evaluator::multiply_plain_normal_accumulate] Destination parameters do not match.");
+        }
+        std::vector<Ciphertext> temp(encrypted.size());
+        multiply_plain_batched(encrypted, plain, batch_utils::collect_pointer(temp), pool);
+        for (size_t i = 0; i < encrypted.size(); i++) { destination[i]->scale() = temp[i].scale(); add_inplace(*destination[i], temp[i], pool); }
+        return;
+    }
+    if (encrypted_ntt) {       // the plaintexts are brought to NTT form at the ciphertexts' level
+        std::vector<Plaintext> moved(plain.size());
+        transform_plain_to_ntt_batched(plain, encrypted[0]->parms_id(), batch_utils::collect_pointer(moved), pool);
+        multiply_plain_ntt_accumulate(encrypted, batch_utils::collect_const_pointer(moved), destination, set_zero, pool);
+        return;
+    }
+    std::vector<Ciphertext> moved(encrypted.size());       // coefficient-form ciphertexts, NTT-form plaintexts: through the NTT domain and back
+    transform_to_ntt_batched(encrypted, batch_utils::collect_pointer(moved), pool);
+    multiply_plain_ntt_accumulate(batch_utils::collect_const_pointer(moved), plain, destination, set_zero, pool);
+    std::vector<Ciphertext*> distinct;
+    for (Ciphertext* d : destination) if (std::find(distinct.begin(), distinct.end(), d) == distinct.end()) distinct.push_back(d);
+    transform_from_ntt_inplace_batched(distinct, pool);
+}
+
+void Evaluator::multiply_plain_ntt_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
+                                              const std::vector<Ciphertext*>& destination, bool set_zero, MemoryPoolHandle pool) const {
     // evaluator_multiply_plain.cu:258-307 (multiply_plain_ntt_accumulate): all operands in NTT form, same parms_id
     const char* P = "[Evaluator::multiply_plain_ntt_batched]";
     if (encrypted.size() != plain.size() || encrypted.size() != destination.size()) throw std::invalid_argument(std::string(P) + " Input vectors have different sizes.");
@@ -2398,7 +2435,7 @@ void RandomGenerator::sample_poly_uniform(const troyn_plan* plan, size_t nmod, u
 
 }  // namespace utils
 
-void Plaintext::resize_rns(const HeContext& context, const ParmsID& parms_id) {
+void Plaintext::resize_rns(const HeContext& context, const ParmsID& parms_id, bool fill_extra_with_zeros, bool copy_data) {
     // plaintext.cu resize_rns: a full RNS polynomial of the level's shape
     auto cd = context.get_context_data(parms_id);
     if (!cd.has_value()) throw std::invalid_argument("[Plaintext::resize_rns] ParmsID is not valid for the current context.");
@@ -2407,7 +2444,8 @@ void Plaintext::resize_rns(const HeContext& context, const ParmsID& parms_id) {
     coeff_modulus_size_ = p.coeff_modulus().size();
     poly_modulus_degree_ = p.poly_modulus_degree();
     coeff_count_ = poly_modulus_degree_;
-    data_.resize(coeff_modulus_size_ * poly_modulus_degree_, false);
+    const size_t words = coeff_modulus_size_ * poly_modulus_degree_;
+    if (fill_extra_with_zeros) data_.resize(words, copy_data); else data_.resize_uninitialized(words, copy_data);
 }
 
 static void require_device_context(const char* prompt, const HeContextPointer& ctx) {

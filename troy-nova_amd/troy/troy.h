@@ -179,6 +179,15 @@ template <typename T> void vector_to_slice(const std::vector<T>& v, Slice<T> d, 
 template <typename T> Array<T> located(Array<T> a, bool on_device, std::shared_ptr<MemoryPool> pool) { if (on_device) a.to_device_inplace(std::move(pool)); return a; }
 template <typename T> using ConstSliceVec = std::vector<ConstSlice<T>>;
 template <typename T> using SliceVec = std::vector<Slice<T>>;
+// utils/box.h:562-590: "[a, b, c]" for host views, "device[a, b, c]" for device views (copied to the host to be printed)
+template <typename T> std::ostream& operator<<(std::ostream& os, const ConstSlice<T>& view) {
+    const std::vector<T> v = view.to_vector();
+    os << (view.on_device() ? "device[" : "[");
+    for (size_t i = 0; i < v.size(); i++) { if (i) os << ", "; os << v[i]; }
+    return os << "]";
+}
+template <typename T> std::ostream& operator<<(std::ostream& os, const Slice<T>& view) { return os << view.as_const(); }
+template <typename T> std::ostream& operator<<(std::ostream& os, const Array<T>& array) { return os << array.const_reference(); }
 }  // namespace utils
 
 // ----------------------------------------------------------------------------------------------
@@ -477,6 +486,14 @@ private:
     ParmsID parms_id_;
 };
 
+// a one-line description (the reference's special_prime_for_encryption test streams its parameters to std::cerr on failure)
+inline std::ostream& operator<<(std::ostream& os, const EncryptionParameters& p) {
+    static const char* const schemes[] = {"Nil", "BFV", "CKKS", "BGV"};
+    os << "EncryptionParameters(scheme=" << schemes[static_cast<size_t>(p.scheme()) & 3] << ", poly_modulus_degree=" << p.poly_modulus_degree() << ", coeff_modulus=" << p.coeff_modulus();
+    if (p.scheme() == SchemeType::BFV || p.scheme() == SchemeType::BGV) os << ", plain_modulus=" << p.plain_modulus();
+    return os << ")";
+}
+
 // ----------------------------------------------------------------------------------------------
 // ContextData, HeContext  (src/context_data.h, he_context.h)
 // ----------------------------------------------------------------------------------------------
@@ -721,10 +738,15 @@ public:
     utils::ConstSlice<uint64_t> const_reference() const { return poly(); }
     utils::ConstSlice<uint64_t> reference() const { return poly(); }                                    // plaintext.h:167-169
     utils::Slice<uint64_t> reference() { return poly(); }
-    void resize(size_t coeff_count) { coeff_count_ = coeff_count; data_.resize(coeff_count, true); }   // plaintext.h resize
-    void resize_rns(const HeContext& context, const ParmsID& parms_id);                                 // plaintext.cu resize_rns
+    // plaintext.h:171-200: what is not copied over is zero (fill_extra_with_zeros) or left as allocated
+    void resize(size_t coeff_count, bool fill_extra_with_zeros = true, bool copy_data = true) {
+        if (!(parms_id_ == parms_id_zero)) throw std::invalid_argument("[Plaintext::resize] Cannot resize if the plaintext is not mod t. Call resize_rns instead.");
+        coeff_count_ = coeff_count;
+        if (fill_extra_with_zeros) data_.resize(coeff_count, copy_data); else data_.resize_uninitialized(coeff_count, copy_data);
+    }
+    void resize_rns(const HeContext& context, const ParmsID& parms_id, bool fill_extra_with_zeros = true, bool copy_data = true);
     // plaintext.cu resize_rns_partial: an RNS polynomial that keeps only its first coeff_count coefficients, data[l * coeff_count + i]
-    void resize_rns_partial(const HeContext& context, const ParmsID& parms_id, size_t coeff_count);
+    void resize_rns_partial(const HeContext& context, const ParmsID& parms_id, size_t coeff_count, bool fill_extra_with_zeros = true, bool copy_data = true);
     Plaintext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }
     // plaintext.cu:20-70, plaintext.h save/load: [CompressionMode][raw fields]; byte-compatible with the reference
     size_t save(std::ostream& stream, CompressionMode mode = CompressionMode::Nil) const;
@@ -838,6 +860,9 @@ class RelinKeys : public KSwitchKeys {
 public:
     RelinKeys() = default;
     explicit RelinKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    RelinKeys clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }                      // kswitch_keys.h:226-250
+    RelinKeys to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { RelinKeys k = *this; k.to_device_inplace(pool); return k; }
+    RelinKeys to_host() const { RelinKeys k = *this; k.to_host_inplace(); return k; }
     static RelinKeys load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { RelinKeys k; k.load(stream, context, pool); return k; }       // kswitch_keys.h:300-304
     static size_t get_index(size_t key_power) {
         if (key_power < 2) throw std::invalid_argument("[RelinKeys::get_index] key_power must be at least 2.");
@@ -851,6 +876,9 @@ class GaloisKeys : public KSwitchKeys {
 public:
     GaloisKeys() = default;
     explicit GaloisKeys(KSwitchKeys&& k) : KSwitchKeys(std::move(k)) {}
+    GaloisKeys clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { (void)pool; return *this; }                     // kswitch_keys.h:322-346
+    GaloisKeys to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { GaloisKeys k = *this; k.to_device_inplace(pool); return k; }
+    GaloisKeys to_host() const { GaloisKeys k = *this; k.to_host_inplace(); return k; }
     static GaloisKeys load_new(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { GaloisKeys k; k.load(stream, context, pool); return k; }     // kswitch_keys.h:393-397
     static size_t get_index(size_t galois_element) {
         if ((galois_element & 1) == 0) throw std::invalid_argument("[GaloisTool::get_index_from_element] galois_element must be odd");
@@ -875,6 +903,12 @@ public:
     KeyGenerator(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool());
     HeContextPointer context() const { return context_; }
     bool on_device() const { return secret_key_.on_device(); }
+    // key_generator.h:35-41.  Keys of this mirror are created where the context lives (on the device), so for a device context this moves nothing
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) {
+        std::lock_guard<std::mutex> lock(secret_key_array_mutex_);
+        if (secret_key_array_.size()) secret_key_array_.to_device_inplace(pool);
+        secret_key_.to_device_inplace(pool);
+    }
     const SecretKey& secret_key() const { return secret_key_; }
     PublicKey create_public_key(bool save_seed, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     // key_generator.h:65-67: the seed of the key's c1 drawn from the caller's generator (utils/rlwe.cu symmetric_with_c1_prng)
@@ -919,6 +953,10 @@ public:
     void set_secret_key(const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool()) { secret_key_ = secret_key.clone(pool); }
     const PublicKey& public_key() const;
     const SecretKey& secret_key() const;
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) {                      // encryptor.h:76-83
+        if (public_key_.has_value()) public_key_.value().to_device_inplace(pool);
+        if (secret_key_.has_value()) secret_key_.value().to_device_inplace(pool);
+    }
     // encryptor.h:140-230.  The reference's argument order: (..., u_prng = nullptr, pool = GlobalPool()).  u_prng, when given, supplies the
     // ternary u of an asymmetric encryption / the seed of c1 of a symmetric one (utils/rlwe.cu asymmetric_with_u_prng,
     // symmetric_with_c1_prng); the noise always comes from the context's generator.  The (..., pool) overloads keep three-argument
@@ -1011,6 +1049,7 @@ public:
     Decryptor(HeContextPointer context, const SecretKey& secret_key, MemoryPoolHandle pool = MemoryPool::GlobalPool());
     HeContextPointer context() const { return context_; }
     bool on_device() const { return secret_key_array_.on_device(); }
+    void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { std::lock_guard<std::mutex> lock(secret_key_array_mutex_); if (secret_key_array_.size()) secret_key_array_.to_device_inplace(pool); }   // decryptor.h:43
     void decrypt(const Ciphertext& encrypted, Plaintext& destination, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     Plaintext decrypt_new(const Ciphertext& encrypted, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Plaintext d; decrypt(encrypted, d, pool); return d; }
     // decryptor.cu:581-640 (BFV / BGV): bits of room left before decryption fails; the phase is formed on the device, the
@@ -1221,6 +1260,7 @@ public:
     LWECiphertext() = default;
     LWECiphertext clone(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
     bool on_device() const;
+    MemoryPoolHandle pool() const { return c1_.pool(); }                                        // lwe_ciphertext.h:21
     void to_device_inplace(MemoryPoolHandle pool = MemoryPool::GlobalPool()) { c0_.to_device_inplace(pool); c1_.to_device_inplace(pool); }
     void to_host_inplace() { c0_.to_host_inplace(); c1_.to_host_inplace(); }
     LWECiphertext to_device(MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { LWECiphertext r = clone(pool); r.to_device_inplace(pool); return r; }
@@ -1392,7 +1432,9 @@ public:
     Ciphertext multiply_plain_new(const Ciphertext& encrypted, const Plaintext& plain, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const { Ciphertext d; multiply_plain(encrypted, plain, d, pool); return d; }
     // destination[i] (+)= encrypted[i] * plain[i]; equal destination pointers accumulate (MatmulHelper::matmul's call)
     void multiply_plain_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
-                                   const std::vector<Ciphertext*>& destination, bool set_zero, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
+                                   const std::vector<Ciphertext*>& destination, bool set_zero = true, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // evaluator.h:491-497
+    void multiply_plain_ntt_accumulate(const std::vector<const Ciphertext*>& encrypted, const std::vector<const Plaintext*>& plain,
+                                       const std::vector<Ciphertext*>& destination, bool set_zero = true, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;   // evaluator_multiply_plain.cu:258-307
 
     // key switching -- evaluator.h:267-303 (evaluator_keyswitching.cu)
     void apply_keyswitching_inplace(Ciphertext& encrypted, const KSwitchKeys& kswitch_keys, MemoryPoolHandle pool = MemoryPool::GlobalPool()) const;
