@@ -8,7 +8,7 @@
 #   * the sources include "../src/<name>.h": they are compiled in a scratch directory where those resolve to one-line forwarders to the mirror's headers;
 #   * <gtest/gtest.h> (an un-vendored submodule of the reference) resolves to tests/ref_tests_support/gtest/gtest.h, a 50-line runner written for this repository;
 #   * "cuda_runtime.h" (test_adv.h:3) resolves to <hip/hip_runtime.h> plus the four names the tests spell out (cudaError_t, cudaSuccess, cudaGetDeviceCount,
-#     cudaDeviceSynchronize): the tests ask the runtime how many devices there are;
+#     cudaDeviceSynchronize, cudaStreamSynchronize): the tests ask the runtime how many devices there are;
 #   * not built: test/utils/*.cu and test/modulus.cu (unit tests of the reference's internal utilities and CUDA kernels, not users of the public API),
 #     test/serialize_zstd.cu (zstd is absent), test/bench/*.cu (tools; tests/cpp/he_bench_driver.cpp is their counterpart).
 set -e
@@ -25,6 +25,9 @@ echo "#include \"$T/troy.h\"" > "$W/src/utils/box.h"
 echo "#include \"$T/bench_timer.h\"" > "$W/src/utils/timer.h"
 for h in bfv_ring2k matmul conv2d cipher2d encoder_adapter; do printf '#include "%s/troy.h"\n#include "%s/ring2k.h"\n#include "%s/matmul.h"\n#include "%s/conv2d.h"\n' "$T" "$T" "$T" "$T" > "$W/src/app/$h.h"; done
 printf '#include <hip/hip_runtime.h>\n#define cudaError_t hipError_t\n#define cudaSuccess hipSuccess\n#define cudaGetDeviceCount hipGetDeviceCount\n#define cudaDeviceSynchronize hipDeviceSynchronize\n' > "$W/test/cuda_runtime.h"
+# the bench tool waits with cudaStreamSynchronize(0): under the reference's --default-stream per-thread build that is the CALLING THREAD's stream, i.e. the mirror's
+# utils::stream_sync() (a literal hipStreamSynchronize(0) would wait for every thread's stream)
+printf 'namespace troy { namespace utils { void stream_sync(); } }\n#define cudaStreamSynchronize(s) ((s) == 0 ? (troy::utils::stream_sync(), hipSuccess) : hipStreamSynchronize(s))\n' >> "$W/test/cuda_runtime.h"
 cp "$REF"/test/*.h "$REF"/test/*.cu "$W/test/"
 cp "$REF"/test/app/*.cu "$W/test/app/"
 CXXFLAGS="-O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/tests/ref_tests_support -I."
@@ -43,3 +46,13 @@ mkdir -p "$ROOT/tests/_ref_tests"
 g++ -o "$ROOT/tests/_ref_tests/ref_tests" $OBJS "$W/main.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
     -Wl,-rpath,'$ORIGIN/../../troy-nova_amd' -Wl,-rpath,/opt/rocm/lib
 echo "built tests/_ref_tests/ref_tests ($("$ROOT/tests/_ref_tests/ref_tests" --list | wc -l) cases)"
+# the reference's bench tool (test/bench/he_operations.cu = `troybench`, its own main) against the mirror: tests/_ref_tests/ref_troybench -D ... is the tool a
+# maintainer of the reference would run (tests/cpp/he_bench_driver.cpp is this repository's counterpart, which also times the batched and fused entries)
+mkdir -p "$W/test/bench"
+cp "$REF"/test/bench/he_operations.cu "$REF"/test/bench/argument_helper.h "$W/test/bench/"
+cp "$REF"/test/argparse.cpp "$W/test/"
+( cd "$W/test/bench" && g++ $CXXFLAGS -I.. -x c++ -c -o "$W/troybench.o" he_operations.cu )
+g++ $CXXFLAGS -c -o "$W/argparse.o" "$W/test/argparse.cpp"
+g++ -o "$ROOT/tests/_ref_tests/ref_troybench" "$W/troybench.o" "$W/argparse.o" "$W/test_adv.o" "$W/test_multithread.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
+    -Wl,-rpath,'$ORIGIN/../../troy-nova_amd' -Wl,-rpath,/opt/rocm/lib
+echo "built tests/_ref_tests/ref_troybench"

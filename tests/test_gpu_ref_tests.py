@@ -45,3 +45,18 @@ def test_reference_test_suite_on_the_mirror(dev):
         assert any("HeContext is not on device" in c for c in verdicts[k][1]), (k, verdicts[k][1])
     passed = sum(1 for v, _ in verdicts.values() if v == "OK")
     assert passed >= 170, "only %d of the reference's Device cases passed" % passed
+
+
+@pytest.mark.parametrize("args", [["-D", "-R", "5", "-W", "1"], ["-D", "--ckks", "-N", "16384", "-q", "50,50,50,50,50,50", "-s", "1099511627776", "-R", "8", "-W", "2"],
+                                  ["-D", "-c", "4", "-mp", "-R", "8", "-W", "2"], ["-D", "--bfv", "-B", "4", "-R", "5", "-W", "1"]])
+def test_reference_bench_tool_on_the_mirror(dev, args):
+    """the reference's own bench tool (test/bench/he_operations.cu = `troybench`, its own main and argument parser) linked against the mirror: device mode with its
+    default parameters (N = 8192, {60,40,40,60}, every scheme), the headline shape, the -c N -mp thread mode and -B (its batched operations).  The tool checks the
+    first result of everything it times and exits with 1 on a wrong one (he_operations.cu:254-259).  Timings of full runs: profiles/r06_ref_troybench_*.txt."""
+    exe = os.path.join(ROOT, "tests", "_ref_tests", "ref_troybench")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_ref_tests/ref_troybench is not built (bash tests/build_ref_tests.sh, build container only)")
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "failed" not in r.stderr.lower() and "exception" not in (r.stdout + r.stderr).lower(), r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Negate" in r.stdout, r.stdout[-2000:]
