@@ -56,3 +56,11 @@ g++ $CXXFLAGS -c -o "$W/argparse.o" "$W/test/argparse.cpp"
 g++ -o "$ROOT/tests/_ref_tests/ref_troybench" "$W/troybench.o" "$W/argparse.o" "$W/test_adv.o" "$W/test_multithread.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
     -Wl,-rpath,'$ORIGIN/../../troy-nova_amd' -Wl,-rpath,/opt/rocm/lib
 echo "built tests/_ref_tests/ref_troybench"
+# ... and its matmul / conv2d bench tools (test/bench/matmul.cu, conv2d.cu: BASELINE config 5 is `bench_matmul -D --bfv -m 512 -r 512 -n 512 ...`)
+cp "$REF"/test/bench/matmul.cu "$REF"/test/bench/conv2d.cu "$W/test/bench/"
+for t in matmul conv2d; do
+  ( cd "$W/test/bench" && g++ $CXXFLAGS -I.. -x c++ -c -o "$W/bench_$t.o" $t.cu )
+  g++ -o "$ROOT/tests/_ref_tests/ref_bench_$t" "$W/bench_$t.o" "$W/argparse.o" "$W/test_adv.o" "$W/test_multithread.o" -L"$PKG" -ltroy_amd -ltroyn -L/opt/rocm/lib -lamdhip64 -lpthread \
+      -Wl,-rpath,'$ORIGIN/../../troy-nova_amd' -Wl,-rpath,/opt/rocm/lib
+  echo "built tests/_ref_tests/ref_bench_$t"
+done

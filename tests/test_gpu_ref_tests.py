@@ -60,3 +60,19 @@ def test_reference_bench_tool_on_the_mirror(dev, args):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "failed" not in r.stderr.lower() and "exception" not in (r.stdout + r.stderr).lower(), r.stdout[-3000:] + r.stderr[-3000:]
     assert "Negate" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("tool,args", [("ref_bench_matmul", ["-D", "--bfv", "-R", "2"]), ("ref_bench_matmul", ["-D", "--bfv", "-m", "64", "-r", "256", "-n", "32", "-st", "21", "-R", "2"]),
+                                       ("ref_bench_matmul", ["-D", "--ckks", "-m", "16", "-r", "32", "-n", "16", "-R", "1"]),
+                                       ("ref_bench_matmul", ["-D", "--bfv", "-rt", "64", "-st", "0", "-q", "60,60,60,60", "-m", "16", "-r", "16", "-n", "16", "-R", "1"]),
+                                       ("ref_bench_matmul", ["-D", "--bfv", "-np", "-R", "1"]), ("ref_bench_conv2d", ["-D", "--bfv"])])
+def test_reference_matmul_and_conv2d_tools_on_the_mirror(dev, tool, args):
+    """the reference's matmul / conv2d bench tools (test/bench/matmul.cu, conv2d.cu: encode, encrypt, serialise, multiply, pack, serialise, decrypt -- the flow of BASELINE
+    config 5) linked against the mirror; they verify the decrypted product themselves and return 1 when it is wrong.  A full run at 512 x 512 x 512:
+    profiles/r06_ref_bench_matmul.txt."""
+    exe = os.path.join(ROOT, "tests", "_ref_tests", tool)
+    if not os.path.exists(exe):
+        pytest.skip("tests/_ref_tests/%s is not built (bash tests/build_ref_tests.sh, build container only)" % tool)
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Time cost" in r.stdout and "exception" not in (r.stdout + r.stderr).lower(), r.stdout[-3000:] + r.stderr[-3000:]
