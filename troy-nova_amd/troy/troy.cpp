@@ -3291,7 +3291,11 @@ void CKKSEncoder::set_plaintext(const std::vector<double>& coeffs, const ParmsID
     for (const Modulus& mdl : q) total_bits += mdl.bit_count();
     if (scale <= 0 || std::log2(scale) + 1.0 >= static_cast<double>(total_bits))
         throw std::invalid_argument("[CKKSEncoder::encode_internal_complex_array] scale out of bounds.");
-    std::vector<uint64_t> host(L * n, 0);
+    // the residues are written straight into the thread's pinned staging image and leave by one asynchronous copy (a pageable source would be staged by the
+    // runtime and waited for); the next user of the image waits for that copy, this call does not
+    PinnedImage& img = pinned_image();
+    uint64_t* host = reinterpret_cast<uint64_t*>(img.reserve(L * n * sizeof(uint64_t)));
+    if (coeffs.size() < n) for (size_t i = 0; i < L; i++) std::memset(host + i * n + coeffs.size(), 0, (n - coeffs.size()) * sizeof(uint64_t));
     const double two64 = 18446744073709551616.0;
     for (size_t j = 0; j < n && j < coeffs.size(); j++) {
         const double v = std::nearbyint(coeffs[j]);
@@ -3302,15 +3306,18 @@ void CKKSEncoder::set_plaintext(const std::vector<double>& coeffs, const ParmsID
         const uint64_t lo = static_cast<uint64_t>(a - static_cast<double>(hi) * two64);
         for (size_t i = 0; i < L; i++) {
             const uint64_t qi = q[i].value();
-            uint64_t r = static_cast<uint64_t>(((static_cast<unsigned __int128>(hi) << 64) | lo) % qi);
+            // below 2^64 (every practical scale): one Barrett reduction instead of a 128-bit division
+            const uint64_t r = hi ? static_cast<uint64_t>(((static_cast<unsigned __int128>(hi) << 64) | lo) % qi) : q[i].reduce(lo);
             host[i * n + j] = (neg && r) ? qi - r : r;
         }
     }
     Plaintext out;
     out.data() = utils::DynamicArray(0, true, pool);
-    out.resize_rns(*context_, parms_id);
-    out.data().copy_from(host.data(), host.size(), false);
-    troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
+    out.resize_rns(*context_, parms_id, false, false);        // every word is written by the copy below
+    hipStream_t s = current_stream();
+    hip_check(hipMemcpyAsync(out.poly().raw_pointer(), host, L * n * sizeof(uint64_t), hipMemcpyHostToDevice, s), "copy_host_to_device");
+    img.mark(s);
+    troyn_check(troyn_ntt(context_->plan(), 0, out.poly(), out.poly(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, s));
     out.scale() = scale;
     out.is_ntt_form() = true;
     destination = std::move(out);
@@ -3332,10 +3339,14 @@ void CKKSEncoder::encode_complex64_simd(const std::vector<std::complex<double>>&
         size_t offset = 0;
         for (size_t i = 0; i < mm; i++) {
             const std::complex<double> r = inv_root_powers_[root_index++];
+            // products written out: std::complex's operator* goes through __muldc3 (the C99 Annex G NaN recovery), several times the cost of these
+            // four multiplications, and returns the same bits whenever the result is finite
+            const double rr = r.real(), ri = r.imag();
             for (size_t j = offset; j < offset + gap; j++) {
                 const std::complex<double> u = a[j], v = a[j + gap];
-                a[j] = u + v;
-                a[j + gap] = (u - v) * r;
+                const double dr = u.real() - v.real(), di = u.imag() - v.imag();
+                a[j] = std::complex<double>(u.real() + v.real(), u.imag() + v.imag());
+                a[j + gap] = std::complex<double>(dr * rr - di * ri, dr * ri + di * rr);
             }
             offset += gap << 1;
         }
@@ -3366,8 +3377,12 @@ std::vector<double> CKKSEncoder::plaintext_coefficients(const Plaintext& plain, 
     const auto& q = cdo.value()->parms().coeff_modulus();
     const size_t n = cdo.value()->parms().poly_modulus_degree(), L = q.size();
     utils::DynamicArray tmp(L * n, true, pool);
-    troyn_check(troyn_ntt(context_->plan(), 1, plain.poly(), tmp.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, current_stream()));
-    std::vector<uint64_t> h = tmp.to_vector();
+    hipStream_t s = current_stream();
+    troyn_check(troyn_ntt(context_->plan(), 1, plain.poly(), tmp.raw_pointer(), 1, 1, static_cast<uint32_t>(L), 0, static_cast<uint32_t>(L), TROYN_IDX_COMPONENTWISE, 0, s));
+    PinnedImage& img = pinned_image();                        // a pageable destination would be staged by the runtime: read the residues from pinned memory
+    const uint64_t* h = reinterpret_cast<const uint64_t*>(img.reserve(L * n * sizeof(uint64_t)));
+    hip_check(hipMemcpyAsync(const_cast<uint64_t*>(h), tmp.raw_pointer(), L * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s), "copy_device_to_host");
+    hip_check(stream_wait(), "copy_device_to_host");
     auto mulmod = [](uint64_t a, uint64_t b, uint64_t m) { return static_cast<uint64_t>(static_cast<unsigned __int128>(a) * b % m); };
     auto invmod = [&](uint64_t a, uint64_t m) {   // m prime
         uint64_t r = 1, e = m - 2, b = a % m;
@@ -3375,17 +3390,28 @@ std::vector<double> CKKSEncoder::plaintext_coefficients(const Plaintext& plain, 
         return r;
     };
     // inv[i][j] = q_j^-1 mod q_i (j < i)
-    std::vector<std::vector<uint64_t>> inv(L);
-    for (size_t i = 0; i < L; i++) for (size_t j = 0; j < i; j++) inv[i].push_back(invmod(q[j].value() % q[i].value(), q[i].value()));
+    // ... with its Shoup quotient floor(inv 2^64 / q_i): a product by a constant is two multiplications and a conditional subtraction instead of a 128-bit division
+    std::vector<std::vector<uint64_t>> inv(L), inv_quo(L);
+    for (size_t i = 0; i < L; i++) for (size_t j = 0; j < i; j++) {
+        const uint64_t w = invmod(q[j].value() % q[i].value(), q[i].value());
+        inv[i].push_back(w);
+        inv_quo[i].push_back(static_cast<uint64_t>((static_cast<unsigned __int128>(w) << 64) / q[i].value()));
+    }
+    std::vector<bool> digit_fits(L * L, false);      // q_j <= q_i: a digit below q_j needs no reduction modulo q_i
+    for (size_t i = 0; i < L; i++) for (size_t j = 0; j < i; j++) digit_fits[i * L + j] = q[j].value() <= q[i].value();
     std::vector<double> out(n);
     std::vector<uint64_t> d(L);
     for (size_t x = 0; x < n; x++) {
         for (size_t i = 0; i < L; i++) {
             const uint64_t qi = q[i].value();
-            uint64_t v = h[i * n + x] % qi;
+            uint64_t v = h[i * n + x];                // the inverse transform leaves canonical residues
+            if (v >= qi) v = q[i].reduce(v);
             for (size_t j = 0; j < i; j++) {
-                const uint64_t dj = d[j] % qi;
-                v = mulmod(v >= dj ? v - dj : v + qi - dj, inv[i][j], qi);
+                const uint64_t dj = digit_fits[i * L + j] ? d[j] : q[i].reduce(d[j]);
+                const uint64_t t = v >= dj ? v - dj : v + qi - dj;
+                const uint64_t est = static_cast<uint64_t>((static_cast<unsigned __int128>(t) * inv_quo[i][j]) >> 64);
+                uint64_t r = t * inv[i][j] - est * qi;
+                v = r >= qi ? r - qi : r;
             }
             d[i] = v;
         }
@@ -3418,10 +3444,12 @@ void CKKSEncoder::decode_complex64_simd(const Plaintext& plain, std::vector<std:
         size_t offset = 0;
         for (size_t i = 0; i < mm; i++) {
             const std::complex<double> r = root_powers_[root_index++];
+            const double rr = r.real(), ri = r.imag();
             for (size_t j = offset; j < offset + gap; j++) {
-                const std::complex<double> u = a[j], v = a[j + gap] * r;
-                a[j] = u + v;
-                a[j + gap] = u - v;
+                const std::complex<double> u = a[j], w = a[j + gap];
+                const double vr = w.real() * rr - w.imag() * ri, vi = w.real() * ri + w.imag() * rr;      // w * r without __muldc3 (see encode)
+                a[j] = std::complex<double>(u.real() + vr, u.imag() + vi);
+                a[j + gap] = std::complex<double>(u.real() - vr, u.imag() - vi);
             }
             offset += gap << 1;
         }
