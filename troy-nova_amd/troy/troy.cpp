@@ -2079,7 +2079,7 @@ size_t Ciphertext::serialized_size_upperbound(HeContextPointer context, Compress
 // reads it, the next user of the image waits for that event (the loading call itself does not wait: it is asynchronous like the reference's).
 namespace {
 struct PinnedImage {
-    char* p = nullptr; size_t cap = 0; hipEvent_t busy = nullptr; bool pending = false;
+    char* p = nullptr; size_t cap = 0; hipEvent_t busy = nullptr; bool pending = false; int busy_device = -1;   // an event belongs to the device it was created on
     ~PinnedImage() { if (p) { (void)hipHostFree(p); (void)hipGetLastError(); } if (busy) { (void)hipEventDestroy(busy); (void)hipGetLastError(); } }
     void quiesce() { if (pending) { hip_check(hipEventSynchronize(busy), "event_sync"); pending = false; } }
     char* reserve(size_t bytes) {
@@ -2091,10 +2091,17 @@ struct PinnedImage {
             hip_check(hipHostMalloc(&q, want, hipHostMallocPortable), "host_malloc");
             p = static_cast<char*>(q); cap = want;
         }
-        if (!busy) hip_check(hipEventCreateWithFlags(&busy, hipEventDisableTiming), "event_create");
         return p;
     }
-    void mark(hipStream_t s) { hip_check(hipEventRecord(busy, s), "event_record"); pending = true; }
+    // the copies that read (or fill) the image were queued on `s`, a stream of the CURRENT device: the event is (re)created there if the thread moved to another device
+    void mark(hipStream_t s) {
+        int dev = 0;
+        hip_check(hipGetDevice(&dev), "get_device");
+        if (busy && dev != busy_device) { hip_check(hipEventDestroy(busy), "event_destroy"); busy = nullptr; }      // nothing pending: reserve() waited
+        if (!busy) { hip_check(hipEventCreateWithFlags(&busy, hipEventDisableTiming), "event_create"); busy_device = dev; }
+        hip_check(hipEventRecord(busy, s), "event_record");
+        pending = true;
+    }
 };
 PinnedImage& pinned_image() { static thread_local PinnedImage img; return img; }
 }  // namespace
