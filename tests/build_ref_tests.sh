@@ -10,7 +10,7 @@
 #   * "cuda_runtime.h" (test_adv.h:3) resolves to <hip/hip_runtime.h> plus the four names the tests spell out (cudaError_t, cudaSuccess, cudaGetDeviceCount,
 #     cudaDeviceSynchronize, cudaStreamSynchronize): the tests ask the runtime how many devices there are;
 #   * not built: test/utils/*.cu and test/modulus.cu (unit tests of the reference's internal utilities and CUDA kernels, not users of the public API),
-#     test/serialize_zstd.cu (zstd is absent), test/bench/*.cu (tools; tests/cpp/he_bench_driver.cpp is their counterpart).
+#     (test/serialize_zstd.cu IS built: the mirror loads the zstd runtime library, troy.cpp).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 REF=${REF:-/root/reference}
@@ -33,7 +33,7 @@ cp "$REF"/test/app/*.cu "$W/test/app/"
 CXXFLAGS="-O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$ROOT/tests/ref_tests_support -I."
 cd "$W/test"
 OBJS=""
-for f in test_adv test_multithread evaluator evaluator_batched encryptor encryptor_batched serialize lwe batch_encoder batch_encoder_batched ckks_encoder he_context \
+for f in test_adv test_multithread evaluator evaluator_batched encryptor encryptor_batched serialize serialize_zstd lwe batch_encoder batch_encoder_batched ckks_encoder he_context \
          special_prime_for_encryption multithread app/matmul app/conv2d app/matmul_ckks app/conv2d_ckks app/bfv_ring2k app/matmul_ring2k app/conv2d_ring2k; do
   o="$W/$(echo "$f" | tr / _).o"
   g++ $CXXFLAGS -x c++ -c -o "$o" "$f.cu" &

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <sstream>
 
 #include "../../troy-nova_amd/troy/troy.h"
 
@@ -112,7 +113,21 @@ static void run_bfv_like(SchemeType scheme) {
         utils::Array<Modulus> host(q.size(), false);
         host.copy_from_slice(q);
         check(q.size() == 3 && host[2].value() == q[2].value() && q.to_vector().size() == 3 && CoeffModulus::create(n, {40, 40}).to_vector().size() == 2, "ConstSlice / Array");
-        check(utils::compression::available(CompressionMode::Nil) && !utils::compression::available(CompressionMode::Zstd), "compression::available");
+        {   // Zstd is available exactly when the zstd runtime library can be loaded; either it round-trips or it is refused loudly
+            bool consistent = utils::compression::available(CompressionMode::Nil);
+            std::stringstream ss;
+            Plaintext probe = encoder.encode_polynomial_new({1, 2, 3});
+            if (utils::compression::available(CompressionMode::Zstd)) {
+                const size_t written = probe.save(ss, CompressionMode::Zstd);
+                consistent = consistent && written == ss.str().size() && written <= probe.serialized_size_upperbound(CompressionMode::Zstd) &&
+                             Plaintext::load_new(ss).data().to_vector() == probe.data().to_vector();
+            } else {
+                bool threw = false;
+                try { probe.save(ss, CompressionMode::Zstd); } catch (const std::invalid_argument&) { threw = true; }
+                consistent = consistent && threw;
+            }
+            check(consistent, "compression::available agrees with what save does");
+        }
         bench::TimerSingle timer;
         timer.tick(); timer.tock();
         check(timer.count() == 1 && context->first_context_data_pointer() != nullptr && context->get_context_data_pointer(parms_id_zero) == nullptr, "TimerSingle, *_pointer getters");

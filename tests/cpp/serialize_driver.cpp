@@ -20,22 +20,27 @@ static void check(bool ok, const char* what) {
 }
 
 static bool sizes_ok = true;
+static CompressionMode wire_mode = CompressionMode::Nil;      // the second pass of main() repeats everything with Zstd (test/serialize_zstd.cu)
+static bool size_ok(size_t written, size_t stream_bytes, size_t bound) {
+    // Nil: the bound IS the size (serialize.cu:17); Zstd: an upper bound (serialize_zstd.cu:17)
+    return written == stream_bytes && (wire_mode == CompressionMode::Nil ? bound == stream_bytes : bound >= stream_bytes);
+}
 template <typename T> static void reserialize(T& t) {                                     // serialize.cu:14-20
     std::stringstream ss;
-    const size_t written = t.save(ss);
-    sizes_ok = sizes_ok && t.serialized_size_upperbound() == ss.str().size() && written == ss.str().size();
+    const size_t written = t.save(ss, wire_mode);
+    sizes_ok = sizes_ok && size_ok(written, ss.str().size(), t.serialized_size_upperbound(wire_mode));
     t = T::load_new(ss);
 }
 template <typename T> static void reserialize(T& t, HeContextPointer context) {           // serialize.cu:22-28
     std::stringstream ss;
-    const size_t written = t.save(ss, context);
-    sizes_ok = sizes_ok && t.serialized_size_upperbound(context) == ss.str().size() && written == ss.str().size();
+    const size_t written = t.save(ss, context, wire_mode);
+    sizes_ok = sizes_ok && size_ok(written, ss.str().size(), t.serialized_size_upperbound(context, wire_mode));
     t = T::load_new(ss, context);
 }
 static void reserialize_terms(Ciphertext& t, HeContextPointer context, const std::vector<size_t>& terms) {   // serialize.cu:373-378
     std::stringstream ss;
-    t.save_terms(ss, context, terms);
-    sizes_ok = sizes_ok && t.serialized_terms_size_upperbound(context, terms) == ss.str().size();
+    t.save_terms(ss, context, terms, MemoryPool::GlobalPool(), wire_mode);
+    sizes_ok = sizes_ok && size_ok(ss.str().size(), ss.str().size(), t.serialized_terms_size_upperbound(context, terms, wire_mode));
     t = Ciphertext::load_terms_new(ss, context, terms);
 }
 
@@ -63,7 +68,12 @@ struct Fixture {
         {   // serialize.cu:31-58
             const ParmsID id = parms.parms_id();
             EncryptionParameters copy = parms;
-            reserialize(copy);
+            {   // raw fields, no compression header (encryption_parameters.cu:53-112)
+                std::stringstream ss;
+                const size_t written = copy.save(ss);
+                sizes_ok = sizes_ok && copy.serialized_size_upperbound() == ss.str().size() && written == ss.str().size();
+                copy = EncryptionParameters::load_new(ss);
+            }
             check(sizes_ok && copy.parms_id() == id && copy.poly_modulus_degree() == n && copy.coeff_modulus().size() == 4, "EncryptionParameters: save / load_new keeps parms_id");
         }
         context = HeContext::create(parms, true, SecurityLevel::Nil, 0x123);
@@ -274,6 +284,17 @@ int main(int argc, char** argv) {
         const SchemeType scheme = !std::strcmp(s, "ckks") ? SchemeType::CKKS : !std::strcmp(s, "bgv") ? SchemeType::BGV : SchemeType::BFV;
         std::printf("scheme %s N %zu\n", s, n);
         run(scheme, n);
+        if (utils::compression::available(CompressionMode::Zstd)) {      // test/serialize_zstd.cu: the same scenarios with every object compressed
+            std::printf("-- Zstd\n");
+            wire_mode = CompressionMode::Zstd;
+            run(scheme, n);
+            // ciphertexts of uniform residues do not compress (they are written raw, mode byte Nil); structured data does
+            Fixture f(scheme, n);
+            Plaintext zeros = f.encode_simd(Fixture::Vec(f.slots(), 0.0));
+            std::stringstream a, b;
+            zeros.save(a, CompressionMode::Nil); zeros.save(b, CompressionMode::Zstd);
+            check(b.str().size() < a.str().size() / 4 && Plaintext::load_new(b).data().to_vector() == zeros.data().to_vector(), "an all-zero plaintext shrinks under Zstd and comes back");
+        } else std::printf("(no zstd runtime library: the Zstd pass is skipped)\n");
         std::printf(failures ? "FAIL\n" : "OK\n");
         MemoryPool::Destroy();
         return failures ? 1 : 0;

@@ -1,4 +1,4 @@
-"""The reference's OWN test suite (its test/*.cu and test/app/*.cu, 362 googletest cases) run against this repository's mirror on the GPU: the strongest form of
+"""The reference's OWN test suite (its test/*.cu and test/app/*.cu, 392 googletest cases, the zstd serialization group included) run against this repository's mirror on the GPU: the strongest form of
 the drop-in check of SURVEY 8b.  tests/build_ref_tests.sh compiles those sources WHERE THEY LIE in the build container against the mirror's headers (nothing of
 the reference enters the repository; the binary tests/_ref_tests/ref_tests is git-ignored and travels to the GPU box like the built libraries) with a 50-line
 stand-in for the googletest macros (tests/ref_tests_support/gtest/gtest.h).  Run here: every case whose name contains "Device" (the mirror has no host path).

@@ -54,7 +54,7 @@ cp "$REF"/test/app/*.cu "$W/test/app/"
 cp "$REF"/test/bench/*.cu "$REF"/test/bench/*.h "$W/test/bench/"
 cd "$W/test"
 bad=0
-for f in test_adv evaluator evaluator_batched encryptor encryptor_batched serialize lwe batch_encoder batch_encoder_batched ckks_encoder he_context special_prime_for_encryption \
+for f in test_adv evaluator evaluator_batched encryptor encryptor_batched serialize serialize_zstd lwe batch_encoder batch_encoder_batched ckks_encoder he_context special_prime_for_encryption \
          multithread test_multithread app/matmul app/conv2d app/matmul_ckks app/conv2d_ckks app/bfv_ring2k app/matmul_ring2k app/conv2d_ring2k bench/he_operations bench/matmul bench/conv2d; do
   [ -f "$f.cu" ] || continue
   n=$(g++ -std=c++17 -fsyntax-only -w -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -x c++ "$f.cu" 2>&1 | grep -c " error" || true)

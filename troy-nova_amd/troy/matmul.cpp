@@ -82,13 +82,14 @@ void Cipher2d::expand_seed(HeContextPointer context) {
 size_t Cipher2d::save(std::ostream& stream, HeContextPointer context, CompressionMode mode) const {
     // app/cipher2d.cu: rows, then per row its length and its ciphertexts; the ciphertexts of a row leave as one batch (Ciphertext::save_many)
     put_size(stream, rows());
+    size_t bytes = sizeof(size_t);
     for (const auto& row : inner) {
         put_size(stream, row.size());
         std::vector<const Ciphertext*> ptrs;
         for (const Ciphertext& c : row) ptrs.push_back(&c);
-        Ciphertext::save_many(stream, ptrs.data(), ptrs.size(), context, mode);
+        bytes += sizeof(size_t) + Ciphertext::save_many(stream, ptrs.data(), ptrs.size(), context, mode);
     }
-    return serialized_size_upperbound(context, mode);
+    return bytes;      // what was written (with Zstd: less than serialized_size_upperbound)
 }
 
 void Cipher2d::load(std::istream& stream, HeContextPointer context, MemoryPoolHandle pool) {

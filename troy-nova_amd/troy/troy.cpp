@@ -15,6 +15,7 @@
 #include <istream>
 #include <ostream>
 #include <sstream>
+#include <dlfcn.h>
 
 namespace troy {
 
@@ -1984,14 +1985,111 @@ template <typename T> void get(std::istream& is, T& v) {
     if (!is) throw std::runtime_error("[serialize::load_object] unexpected end of stream");
 }
 void put_words(std::ostream& os, const std::vector<uint64_t>& v, size_t count) { os.write(reinterpret_cast<const char*>(v.data()), count * 8); }
-void put_mode(std::ostream& os, CompressionMode mode) {
-    if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::compress] Zstd is not available in this build.");
+// ---- zstd (utils/compression.h, compression_zstd.cpp, serialize.h:59-110) ---------------------------------------------------------------------------
+// The reference compiles zstd in from a submodule (TROY_ZSTD).  Neither the submodule nor <zstd.h> exists in this image, but the zstd RUNTIME library does
+// (libzstd.so.1): it is loaded on first use and the handful of entry points of its stable C ABI are declared here.  When it cannot be loaded, Zstd is refused at
+// run time as before and compression::available(Zstd) is false.  Framing as the reference's: [Zstd][compressed size][one zstd frame] when that is shorter than the
+// raw object, else [Nil][raw]; a reader accepts either.  (Frames are interchangeable, not byte-identical: the reference streams chunks through ZSTD_compressStream2,
+// this writes one frame per object; any zstd decoder reads both.)
+struct ZstdRuntime {
+    struct InBuffer { const void* src; size_t size; size_t pos; };
+    struct OutBuffer { void* dst; size_t size; size_t pos; };
+    size_t (*compress_bound)(size_t) = nullptr;
+    size_t (*compress)(void*, size_t, const void*, size_t, int) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    const char* (*error_name)(size_t) = nullptr;
+    void* (*create_dctx)() = nullptr;
+    size_t (*free_dctx)(void*) = nullptr;
+    size_t (*decompress_stream)(void*, OutBuffer*, InBuffer*) = nullptr;
+    size_t (*dstream_out_size)() = nullptr;
+    bool ok = false;
+    ZstdRuntime() {
+        void* h = nullptr;
+        for (const char* name : {"libzstd.so.1", "libzstd.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        auto sym = [&](const char* n) { return dlsym(h, n); };
+        compress_bound = reinterpret_cast<decltype(compress_bound)>(sym("ZSTD_compressBound"));
+        compress = reinterpret_cast<decltype(compress)>(sym("ZSTD_compress"));
+        is_error = reinterpret_cast<decltype(is_error)>(sym("ZSTD_isError"));
+        error_name = reinterpret_cast<decltype(error_name)>(sym("ZSTD_getErrorName"));
+        create_dctx = reinterpret_cast<decltype(create_dctx)>(sym("ZSTD_createDCtx"));
+        free_dctx = reinterpret_cast<decltype(free_dctx)>(sym("ZSTD_freeDCtx"));
+        decompress_stream = reinterpret_cast<decltype(decompress_stream)>(sym("ZSTD_decompressStream"));
+        dstream_out_size = reinterpret_cast<decltype(dstream_out_size)>(sym("ZSTD_DStreamOutSize"));
+        ok = compress_bound && compress && is_error && error_name && create_dctx && free_dctx && decompress_stream && dstream_out_size;
+    }
+};
+const ZstdRuntime& zstd_runtime() { static const ZstdRuntime* z = new ZstdRuntime(); return *z; }
+const ZstdRuntime& zstd_or_throw(const char* prompt) {
+    const ZstdRuntime& z = zstd_runtime();
+    if (!z.ok) throw std::invalid_argument(std::string(prompt) + " Zstd is not available: libzstd.so.1 could not be loaded.");
+    return z;
+}
+std::string zstd_compress(const char* raw, size_t size) {
+    const ZstdRuntime& z = zstd_or_throw("[serialize::compress]");
+    std::string out(z.compress_bound(size), '\0');
+    const size_t n = z.compress(&out[0], out.size(), raw, size, 3);      // ZSTD_CLEVEL_DEFAULT, as compression_zstd.cpp:38
+    if (z.is_error(n)) throw std::runtime_error(std::string("[utils::compression::zstd::compress] ") + z.error_name(n));
+    out.resize(n);
+    return out;
+}
+std::string zstd_decompress(const char* data, size_t size) {
+    // streaming: a frame written by the reference carries no content size
+    const ZstdRuntime& z = zstd_or_throw("[serialize::decompress]");
+    void* ctx = z.create_dctx();
+    if (!ctx) throw std::runtime_error("[utils::compression::zstd::decompress] ZSTD_createDCtx() failed");
+    std::string out, chunk(z.dstream_out_size(), '\0');
+    ZstdRuntime::InBuffer in{data, size, 0};
+    size_t state = 1;
+    while (in.pos < in.size || state != 0) {
+        ZstdRuntime::OutBuffer ob{&chunk[0], chunk.size(), 0};
+        state = z.decompress_stream(ctx, &ob, &in);
+        if (z.is_error(state)) { z.free_dctx(ctx); throw std::runtime_error(std::string("[utils::compression::zstd::decompress] ") + z.error_name(state)); }
+        out.append(chunk.data(), ob.pos);
+        if (in.pos == in.size && ob.pos < ob.size) {
+            if (state != 0) { z.free_dctx(ctx); throw std::runtime_error("[utils::compression::zstd::decompress] truncated frame"); }
+            break;
+        }
+    }
+    z.free_dctx(ctx);
+    return out;
+}
+// serialize.h:59-89: `save_nil` writes the object with CompressionMode::Nil (mode byte + raw fields); the Zstd form replaces that by [Zstd][size][frame] when shorter
+template <typename F> size_t save_framed(std::ostream& os, CompressionMode mode, F save_nil) {
+    if (mode == CompressionMode::Nil) return save_nil(os);
+    std::ostringstream plain;
+    save_nil(plain);
+    const std::string raw = plain.str();                          // raw[0] is the Nil mode byte
+    const std::string packed = zstd_compress(raw.data() + 1, raw.size() - 1);
+    if (packed.size() < raw.size() - 1) {
+        put(os, CompressionMode::Zstd);
+        put(os, packed.size());
+        os.write(packed.data(), static_cast<std::streamsize>(packed.size()));
+        return packed.size() + sizeof(CompressionMode) + sizeof(size_t);
+    }
+    os.write(raw.data(), static_cast<std::streamsize>(raw.size()));
+    return raw.size();
+}
+void put_mode(std::ostream& os, CompressionMode mode) {          // the Nil writers only
+    if (mode != CompressionMode::Nil) throw std::logic_error("[serialize::compress] internal: a Nil writer was asked for another mode");
     put(os, mode);
 }
-void get_mode(std::istream& is) {
+// serialize.h:91-108: reads the mode; for a compressed object the frame is unpacked into `unpacked` (which then holds the raw fields) and that stream is returned,
+// otherwise `is` itself
+std::istream& get_mode(std::istream& is, std::istringstream& unpacked) {
     CompressionMode mode;
     get(is, mode);
-    if (mode != CompressionMode::Nil) throw std::invalid_argument("[serialize::decompress] Zstd is not available in this build.");
+    if (mode == CompressionMode::Nil) return is;
+    if (mode != CompressionMode::Zstd) throw std::runtime_error("Invalid compression mode");
+    size_t size;
+    get(is, size);
+    if (size > (size_t(1) << 40)) throw std::runtime_error("[serialize::decompress] invalid compressed size");
+    std::string packed(size, '\0');
+    is.read(&packed[0], static_cast<std::streamsize>(size));
+    if (!is) throw std::runtime_error("[serialize::decompress] unexpected end of stream");
+    unpacked.str(zstd_decompress(packed.data(), packed.size()));
+    unpacked.clear();
+    return unpacked;
 }
 bool get_bool(std::istream& is) {
     unsigned char c;
@@ -2000,6 +2098,8 @@ bool get_bool(std::istream& is) {
     return c != 0;
 }
 }  // namespace
+
+namespace utils { namespace compression { bool available(CompressionMode mode) { return mode == CompressionMode::Nil || (mode == CompressionMode::Zstd && zstd_runtime().ok); } } }
 
 size_t EncryptionParameters::save(std::ostream& stream) const {
     put(stream, scheme_);
@@ -2025,11 +2125,19 @@ void EncryptionParameters::load(std::istream& stream) {
     compute_parms_id();
 }
 
-size_t Plaintext::serialized_size_upperbound(CompressionMode) const {
-    return sizeof(CompressionMode) + sizeof(ParmsID) + sizeof(double) + 2 * sizeof(size_t) + 2 * sizeof(bool) + data_.size() * 8 + 2 * sizeof(size_t);
+// serialize.h:46-52: for Zstd the bound of the compressed form, or the raw form when that is what gets written
+static size_t framed_size_upperbound(size_t nil_size, CompressionMode mode) {
+    if (mode == CompressionMode::Nil) return nil_size;
+    const size_t raw = nil_size - sizeof(CompressionMode);
+    return std::max(zstd_or_throw("[serialize::serialized_size_upperbound]").compress_bound(raw) + sizeof(CompressionMode) + sizeof(size_t), nil_size);
+}
+
+size_t Plaintext::serialized_size_upperbound(CompressionMode mode) const {
+    return framed_size_upperbound(sizeof(CompressionMode) + sizeof(ParmsID) + sizeof(double) + 2 * sizeof(size_t) + 2 * sizeof(bool) + data_.size() * 8 + 2 * sizeof(size_t), mode);
 }
 
 size_t Plaintext::save(std::ostream& stream, CompressionMode mode) const {
+    if (mode != CompressionMode::Nil) return save_framed(stream, mode, [&](std::ostream& os) { return save(os, CompressionMode::Nil); });
     put_mode(stream, mode);
     put(stream, parms_id_);
     put(stream, scale_);
@@ -2043,8 +2151,9 @@ size_t Plaintext::save(std::ostream& stream, CompressionMode mode) const {
     return serialized_size_upperbound(mode);
 }
 
-void Plaintext::load(std::istream& stream, MemoryPoolHandle pool) {
-    get_mode(stream);
+void Plaintext::load(std::istream& outer, MemoryPoolHandle pool) {
+    std::istringstream unpacked;
+    std::istream& stream = get_mode(outer, unpacked);
     get(stream, parms_id_);
     get(stream, scale_);
     get(stream, coeff_count_);
@@ -2063,14 +2172,14 @@ void Plaintext::load(std::istream& stream, MemoryPoolHandle pool) {
 
 static SchemeType context_scheme(const HeContextPointer& context) { return context->key_context_data().value()->parms().scheme(); }
 
-size_t Ciphertext::serialized_size_upperbound(HeContextPointer context, CompressionMode) const {
+size_t Ciphertext::serialized_size_upperbound(HeContextPointer context, CompressionMode mode) const {
     size_t bytes = sizeof(CompressionMode) + sizeof(ParmsID) + 3 * sizeof(size_t) + 1;
     const SchemeType scheme = context_scheme(context);
     if (scheme == SchemeType::CKKS) bytes += sizeof(double);
     if (scheme == SchemeType::BGV) bytes += sizeof(uint64_t);
     const size_t poly = poly_modulus_degree_ * coeff_modulus_size_;
     bytes += contains_seed() ? 8 + poly * 8 : poly * polynomial_count_ * 8;
-    return bytes;
+    return framed_size_upperbound(bytes, mode);
 }
 
 // ---- pinned staging image of the wire path (one per host thread, grown on demand, reused) -------------------------------------------------------
@@ -2112,6 +2221,14 @@ size_t Ciphertext::save(std::ostream& stream, HeContextPointer context, Compress
 }
 
 size_t Ciphertext::save_many(std::ostream& stream, const Ciphertext* const* cts, size_t count, HeContextPointer context, CompressionMode mode) {
+    if (mode != CompressionMode::Nil) {      // every object is its own frame, as when the reference saves them one by one (serialize.h:59-89)
+        size_t total = 0;
+        for (size_t i = 0; i < count; i++) {
+            const Ciphertext* one = cts[i];
+            total += save_framed(stream, mode, [&](std::ostream& os) { return save_many(os, &one, 1, context, CompressionMode::Nil); });
+        }
+        return total;
+    }
     // ciphertext.cu:93-150 per object: mode, parms_id, the three sizes, flags, scale (CKKS) / correction factor (BGV), seed, words
     const SchemeType scheme = context_scheme(context);
     std::vector<std::string> headers(count);
@@ -2175,7 +2292,7 @@ void Ciphertext::load(std::istream& stream, HeContextPointer context, MemoryPool
     load_many(stream, &one, 1, context, pool);
 }
 
-void Ciphertext::load_many(std::istream& stream, Ciphertext* const* cts, size_t count, HeContextPointer context, MemoryPoolHandle pool) {
+void Ciphertext::load_many(std::istream& outer, Ciphertext* const* cts, size_t count, HeContextPointer context, MemoryPoolHandle pool) {
     // ciphertext.cu:152-210 per object.  Device-bound payloads (flag bit 2, or seeded: the seed is expanded on the device) go through the pinned
     // image; the seeded c1 polynomials of one shape are expanded by ONE troyn_sample_uniform_multi launch into a block the ciphertexts window.
     if (count == 0) return;
@@ -2226,7 +2343,8 @@ void Ciphertext::load_many(std::istream& stream, Ciphertext* const* cts, size_t 
     };
     for (size_t i = 0; i < count; i++) {
         Ciphertext& c = *cts[i];
-        get_mode(stream);
+        std::istringstream unpacked;
+        std::istream& stream = get_mode(outer, unpacked);      // a compressed object is read from its unpacked copy, the others from the caller's stream
         get(stream, c.parms_id_);
         get(stream, c.polynomial_count_);
         get(stream, c.coeff_modulus_size_);
@@ -2263,7 +2381,7 @@ void Ciphertext::load_many(std::istream& stream, Ciphertext* const* cts, size_t 
     flush();
 }
 
-size_t Ciphertext::serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode) const {
+size_t Ciphertext::serialized_terms_size_upperbound(HeContextPointer context, size_t terms_count, CompressionMode mode) const {
     // ciphertext.cu:341-365
     size_t bytes = sizeof(CompressionMode) + sizeof(ParmsID) + 3 * sizeof(size_t) + 1;
     const SchemeType scheme = context_scheme(context);
@@ -2273,11 +2391,12 @@ size_t Ciphertext::serialized_terms_size_upperbound(HeContextPointer context, si
     if (contains_seed()) bytes += 8;
     bytes += terms_count * coeff_modulus_size_ * 8;
     bytes += contains_seed() ? 0 : poly * (polynomial_count_ - 1) * 8;
-    return bytes;
+    return framed_size_upperbound(bytes, mode);
 }
 
 size_t Ciphertext::save_terms(std::ostream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool, CompressionMode mode) const {
     // ciphertext.cu:213-280: as save(), flag bit 3 set, and of c0 only the coefficients `terms` (taken in coefficient form)
+    if (mode != CompressionMode::Nil) return save_framed(stream, mode, [&](std::ostream& os) { return save_terms(os, context, terms, pool, CompressionMode::Nil); });
     put_mode(stream, mode);
     put(stream, parms_id_);
     put(stream, polynomial_count_);
@@ -2315,9 +2434,10 @@ size_t Ciphertext::save_terms(std::ostream& stream, HeContextPointer context, co
     return serialized_terms_size_upperbound(context, terms.size(), mode);
 }
 
-void Ciphertext::load_terms(std::istream& stream, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool) {
+void Ciphertext::load_terms(std::istream& outer, HeContextPointer context, const std::vector<size_t>& terms, MemoryPoolHandle pool) {
     // ciphertext.cu:282-339: the coefficients of c0 that were not saved are zero
-    get_mode(stream);
+    std::istringstream unpacked;
+    std::istream& stream = get_mode(outer, unpacked);
     get(stream, parms_id_);
     get(stream, polynomial_count_);
     get(stream, coeff_modulus_size_);

@@ -43,11 +43,11 @@
 namespace troy {
 
 enum class SchemeType : uint8_t { Nil = 0, BFV = 1, CKKS = 2, BGV = 3 };
-// utils/compression.h:15-18.  Only Nil is available (the reference's zstd submodule is not vendored either).
+// utils/compression.h:15-18.  Zstd works when libzstd.so.1 is present at run time (the reference compiles zstd in from a submodule; see troy.cpp).
 enum class CompressionMode : uint8_t { Nil = 0, Zstd = 1 };
 enum class SecurityLevel : uint8_t { Nil = 0, Classical128 = 1, Classical192 = 2, Classical256 = 3 };
 namespace utils { namespace compression {
-inline bool available(CompressionMode mode) { return mode == CompressionMode::Nil; }         // utils/compression.h:46-52 (zstd is not part of this image)
+bool available(CompressionMode mode);       // utils/compression.h:46-52: Nil always; Zstd when the zstd runtime library (libzstd.so.1) can be loaded (troy.cpp)
 }}  // namespace utils::compression
 
 // utils/box.h: the non-owning (pointer, length) views and the owning array the reference's public API hands out for HOST-side
