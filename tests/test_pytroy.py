@@ -509,3 +509,41 @@ def test_memory_pools_in_python(pytroy, dev):
     dec = pytroy.Decryptor(ctx2, kg2.secret_key())
     assert enc2.decode_simd_new(dec.decrypt_new(encrypted2)).tolist()[:5] == [1, 2, 3, 4, 0]
     pytroy.destroy_memory_pool()
+
+
+@pytest.mark.gpu
+def test_zstd_wire_format_interoperates(pytroy, dev):
+    """CompressionMode.Zstd (round 6: through the zstd runtime library): objects round-trip, structured data shrinks, and -- the interoperability that matters -- a
+    frame written by ANOTHER zstd producer with the streaming API (no content size in the frame header: what the reference's compression_zstd.cpp emits) inside the
+    reference's framing [mode = 1][u64 compressed size][frame] loads as the same object.  The other producer here is pyarrow's CompressedOutputStream."""
+    import struct
+    pa = pytest.importorskip("pyarrow")
+    p = _params(pytroy, pytroy.SchemeType.BFV, 8192, [40, 40, 40])
+    ctx = pytroy.HeContext(p, True, pytroy.SecurityLevel.Classical128, 0x123)
+    ctx.to_device_inplace()
+    encoder = pytroy.BatchEncoder(ctx)
+    encoder.to_device_inplace()
+    keygen = pytroy.KeyGenerator(ctx)
+    encryptor = pytroy.Encryptor(ctx)
+    encryptor.set_secret_key(keygen.secret_key())
+    Z, N = pytroy.CompressionMode.Zstd, pytroy.CompressionMode.Nil
+    plain = encoder.encode_polynomial_new([5, 4, 3, 2, 1] + [0] * 100)
+    nil, z = plain.save(N), plain.save(Z)
+    assert z[0] == 1 and len(z) < len(nil) and len(z) <= plain.serialized_size_upperbound(Z)
+    assert pytroy.Plaintext.load_new(z).data() == plain.data()
+    ct = encryptor.encrypt_symmetric_new(plain, True)
+    cz = ct.save(ctx, Z)
+    assert len(cz) <= ct.serialized_size_upperbound(ctx, Z)            # uniform residues do not compress: written raw (mode byte 0) when the frame would be longer
+    back = pytroy.Ciphertext.load_new(cz, ctx)
+    assert not back.contains_seed() and encoder.decode_polynomial_new(pytroy.Decryptor(ctx, keygen.secret_key()).decrypt_new(back)).tolist()[:5] == [5, 4, 3, 2, 1]
+    # a frame from a streaming writer, in the reference's framing
+    raw = nil[1:]
+    sink = pa.BufferOutputStream()
+    w = pa.CompressedOutputStream(sink, "zstd")
+    w.write(raw)
+    w.close()
+    frame = sink.getvalue().to_pybytes()
+    foreign = bytes([1]) + struct.pack("<Q", len(frame)) + frame
+    assert pytroy.Plaintext.load_new(foreign).data() == plain.data() and frame != z[9:]      # another producer's bytes, the same object
+    # and a frame of ours opens with another zstd consumer
+    assert pa.decompress(z[9:], decompressed_size=len(raw), codec="zstd").to_pybytes() == raw
